@@ -1,0 +1,456 @@
+/*
+ * orbit_abi.h — C ABI of the MI355X-native culling / light-clustering engine.
+ *
+ * This header is the drop-in boundary.  The reference has no
+ * FFI: its cull passes are Rust functions that record Vulkan compute work
+ * (src/passes/draw_gen.rs, src/passes/cluster.rs).  Each entry point below
+ * replaces the *body* of one of those functions; the Rust-side `extern "C"`
+ * declarations a maintainer adds are listed in INTEGRATION.md and
+ * bindings/rust/orbit_hip.rs.
+ *
+ * Conventions
+ *  - plain C, no HIP / torch types: `void *stream` is a hipStream_t,
+ *    every `*_buffer` pointer is a DEVICE pointer unless the comment says HOST.
+ *  - all structs are byte-identical to the reference's std430 / repr(C)
+ *    layouts (shaders/include/types.glsl); sizes and offsets are asserted.
+ *  - every call only ENQUEUES work on `stream` (no hidden device sync, no
+ *    allocation); ordering between calls is stream order, exactly like the
+ *    render graph's barrier-separated batches (src/graphics/graph.rs:874-1050).
+ *  - return value: 0 = ORBIT_OK, < 0 = ORBIT_E_*; text via orbit_last_error().
+ *    Conditions only detectable on the device (capacity overflow, a bounded
+ *    spin that gave up) are latched in the context and read with
+ *    orbit_ctx_status().
+ */
+#ifndef ORBIT_ABI_H
+#define ORBIT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#define ORBIT_STATIC_ASSERT(c, m) static_assert(c, m)
+#else
+#define ORBIT_STATIC_ASSERT(c, m) _Static_assert(c, m)
+#endif
+
+#define ORBIT_ABI_VERSION 1u
+
+/* u32::MAX = "resource absent" (src/passes/draw_gen.rs:142-144,
+ * shaders/meshlet_cull.comp:127). */
+#define ORBIT_NONE 0xFFFFFFFFu
+#define ORBIT_MAX_CULL_PLANES 12 /* src/passes/draw_gen.rs:206 */
+#define ORBIT_MAX_MESH_LODS 8    /* shaders/include/types.glsl:4 */
+/* The only dispatch size for which the reference's visibility-word addressing
+ * is self-consistent (src/graphics/device.rs:369-372). */
+#define ORBIT_MESHLET_DISPATCH_SIZE 32u
+#define ORBIT_MAX_LIGHTS_PER_CLUSTER 256u /* light_culling.comp:135 */
+
+enum {
+    ORBIT_OK = 0,
+    ORBIT_E_INVALID = -1,  /* bad argument (NULL buffer, projection_type > 1, S != 32 ...) */
+    ORBIT_E_PLANES = -2,   /* more than 12 cull planes: assert! at draw_gen.rs:247,334,390 */
+    ORBIT_E_CAPACITY = -3, /* an append would overflow a caller buffer (latched on device) */
+    ORBIT_E_HIP = -4,      /* a HIP runtime call failed */
+    ORBIT_E_NO_DEVICE = -5,/* no gfx950 device / kernels not loadable: there is NO CPU fallback */
+    ORBIT_E_TIMEOUT = -6,  /* a bounded in-kernel wait gave up (latched on device) */
+    ORBIT_E_MISSING = -7   /* a resource the CullInfo declares present was passed as NULL
+                              (.unwrap() at draw_gen.rs:123-133) */
+};
+
+/* ------------------------------------------------------------------------ */
+/* Scene / asset input layouts                                               */
+/* ------------------------------------------------------------------------ */
+
+/* types.glsl:112-116, src/scene.rs:127-133 */
+typedef struct OrbitEntityDraw {
+    uint32_t entity_index;
+    uint32_t mesh_index;
+    uint32_t visibility_offset;
+} OrbitEntityDraw;
+ORBIT_STATIC_ASSERT(sizeof(OrbitEntityDraw) == 12, "EntityDraw is 12 B");
+/* EntityDrawBuffer (types.glsl:118-121): u32 count @0, draws[] @4, stride 12. */
+#define ORBIT_ENTITY_DRAW_HEADER 4u
+
+/* types.glsl:75-78, src/scene.rs:120-125; matrices column-major */
+typedef struct OrbitEntityData {
+    float model_matrix[16];
+    float normal_matrix[16];
+} OrbitEntityData;
+ORBIT_STATIC_ASSERT(sizeof(OrbitEntityData) == 128, "EntityData is 128 B");
+
+typedef struct OrbitMeshLod {
+    uint32_t meshlet_offset;
+    uint32_t meshlet_count;
+} OrbitMeshLod;
+
+/* types.glsl:133-141, src/assets/mod.rs:18-28 */
+typedef struct OrbitMeshInfo {
+    float bounding_sphere[4];
+    float aabb_min[4];
+    float aabb_max[4];
+    uint32_t vertex_offset;
+    uint32_t meshlet_data_offset;
+    uint32_t lod_count;
+    uint32_t _padding;
+    OrbitMeshLod mesh_lods[ORBIT_MAX_MESH_LODS];
+} OrbitMeshInfo;
+ORBIT_STATIC_ASSERT(sizeof(OrbitMeshInfo) == 128, "MeshInfo is 128 B");
+ORBIT_STATIC_ASSERT(offsetof(OrbitMeshInfo, lod_count) == 56, "lod_count @56");
+ORBIT_STATIC_ASSERT(offsetof(OrbitMeshInfo, mesh_lods) == 64, "mesh_lods @64");
+
+/* types.glsl:143-152, src/assets/mod.rs:111-122 */
+typedef struct OrbitMeshlet {
+    float bounding_sphere[4];
+    int8_t cone_axis[3];
+    int8_t cone_cutoff;
+    uint32_t vertex_offset;
+    uint32_t data_offset;
+    uint16_t material_index;
+    uint8_t vertex_count;
+    uint8_t triangle_count;
+} OrbitMeshlet;
+ORBIT_STATIC_ASSERT(sizeof(OrbitMeshlet) == 32, "Meshlet is 32 B");
+ORBIT_STATIC_ASSERT(offsetof(OrbitMeshlet, vertex_offset) == 20, "vertex_offset @20");
+ORBIT_STATIC_ASSERT(offsetof(OrbitMeshlet, material_index) == 28, "material_index @28");
+
+/* types.glsl:92-110, src/assets/mod.rs:171-191 */
+typedef struct OrbitMaterialData {
+    float base_color[4];
+    float emissive_factor[3];
+    float metallic_factor;
+    float roughness_factor;
+    float occlusion_factor;
+    float alpha_cutoff;
+    uint32_t base_texture_index;
+    uint32_t normal_texture_index;
+    uint32_t metallic_roughness_texture_index;
+    uint32_t occlusion_texture_index;
+    uint32_t emissive_texture_index;
+    uint32_t alpha_mode; /* 0 opaque, 1 masked, 2 transparent: assets/mod.rs:124-130 */
+    uint32_t _padding[3];
+} OrbitMaterialData;
+ORBIT_STATIC_ASSERT(sizeof(OrbitMaterialData) == 80, "MaterialData is 80 B");
+ORBIT_STATIC_ASSERT(offsetof(OrbitMaterialData, alpha_mode) == 64, "alpha_mode @64");
+
+/* AlphaModeFlags, draw_gen.rs:630-641 */
+#define ORBIT_ALPHA_OPAQUE 1u
+#define ORBIT_ALPHA_MASKED 2u
+#define ORBIT_ALPHA_TRANSPARENT 4u
+#define ORBIT_ALPHA_ALL 7u
+
+/* types.glsl:16-27, src/scene.rs:278-291 */
+typedef struct OrbitLightData {
+    uint32_t light_type; /* 0 sky, 1 directional, 2 point: types.glsl:298-300 */
+    uint32_t shadow_data_index;
+    uint32_t irradiance_map_index;
+    uint32_t prefiltered_map_index;
+    float color[3];
+    float intensity;
+    float position[3];
+    float inner_radius;
+    float direction[3];
+    float outer_radius;
+} OrbitLightData;
+ORBIT_STATIC_ASSERT(sizeof(OrbitLightData) == 64, "LightData is 64 B");
+ORBIT_STATIC_ASSERT(offsetof(OrbitLightData, position) == 32, "position @32");
+ORBIT_STATIC_ASSERT(offsetof(OrbitLightData, outer_radius) == 60, "outer_radius @60");
+#define ORBIT_LIGHT_TYPE_POINT 2u
+
+/* ------------------------------------------------------------------------ */
+/* Cull-pass output layouts                                                  */
+/* ------------------------------------------------------------------------ */
+
+/* types.glsl:166-171 */
+typedef struct OrbitMeshletDispatch {
+    uint32_t entity_index;
+    uint32_t meshlet_offset;
+    uint32_t meshlet_count;
+    uint32_t visibility_offset;
+} OrbitMeshletDispatch;
+ORBIT_STATIC_ASSERT(sizeof(OrbitMeshletDispatch) == 16, "MeshletDispatch is 16 B");
+/* MeshletDispatchBuffer (types.glsl:173-178): u32 workgroup_count_{x,y,z} @0,
+ * dispatches[] @12, stride 16.  x = record count, y = z = 1. */
+#define ORBIT_DISPATCH_HEADER 12u
+
+/* types.glsl:180-189, src/assets/mod.rs:98-109.  The first 20 B are a
+ * VkDrawIndexedIndirectCommand consumed with stride 28 (context.rs:1101-1108). */
+typedef struct OrbitMeshletDrawCommand {
+    uint32_t cmd_index_count;
+    uint32_t cmd_instance_count;
+    uint32_t cmd_first_index;
+    int32_t cmd_vertex_offset;
+    uint32_t cmd_first_instance;
+    uint32_t meshlet_vertex_offset;
+    uint32_t meshlet_index;
+} OrbitMeshletDrawCommand;
+ORBIT_STATIC_ASSERT(sizeof(OrbitMeshletDrawCommand) == 28, "MeshletDrawCommand is 28 B");
+/* MeshletDrawCommandBuffer (types.glsl:191-194): u32 count @0, draws[] @4. */
+#define ORBIT_DRAW_HEADER 4u
+
+/* GpuCullInfo, draw_gen.rs:208-237 == CullInfo, types.glsl:202-228 */
+typedef struct OrbitGpuCullInfo {
+    float view_matrix[16];         /* @0   */
+    float reprojection_matrix[16]; /* @64  always zero, unused */
+    float cull_planes[ORBIT_MAX_CULL_PLANES][4]; /* @128 view-space, normalised */
+    uint32_t cull_plane_count;     /* @320 */
+    uint32_t alpha_mode_flag;      /* @324 */
+    uint32_t noskip_alphamode;     /* @328 */
+    uint32_t occlusion_pass;       /* @332 0 none / 1 read / 2 write: draw_gen.rs:96-102 */
+    uint32_t visibility_buffer;         /* @336 bindless index or ORBIT_NONE */
+    uint32_t meshlet_visibility_buffer; /* @340 */
+    uint32_t depth_pyramid;             /* @344 */
+    uint32_t secondary_depth_pyramid;   /* @348 unused */
+    uint32_t projection_type;      /* @352 0 perspective / 1 orthographic */
+    float p00_or_width_recipx2;    /* @356 */
+    float p11_or_height_recipx2;   /* @360 */
+    float z_near;                  /* @364 */
+    float z_far;                   /* @368 */
+    float lod_base;                /* @372 */
+    float lod_step;                /* @376 */
+    uint32_t min_mesh_lod;         /* @380 */
+    float lod_target_pos_view_space[3]; /* @384 */
+    uint32_t max_mesh_lod;         /* @396 */
+} OrbitGpuCullInfo;
+ORBIT_STATIC_ASSERT(sizeof(OrbitGpuCullInfo) == 400, "GpuCullInfo is 400 B");
+ORBIT_STATIC_ASSERT(offsetof(OrbitGpuCullInfo, cull_planes) == 128, "cull_planes @128");
+ORBIT_STATIC_ASSERT(offsetof(OrbitGpuCullInfo, cull_plane_count) == 320, "cull_plane_count @320");
+ORBIT_STATIC_ASSERT(offsetof(OrbitGpuCullInfo, occlusion_pass) == 332, "occlusion_pass @332");
+ORBIT_STATIC_ASSERT(offsetof(OrbitGpuCullInfo, projection_type) == 352, "projection_type @352");
+ORBIT_STATIC_ASSERT(offsetof(OrbitGpuCullInfo, lod_target_pos_view_space) == 384, "lod_target @384");
+ORBIT_STATIC_ASSERT(offsetof(OrbitGpuCullInfo, max_mesh_lod) == 396, "max_mesh_lod @396");
+
+/* ------------------------------------------------------------------------ */
+/* Light-cluster layouts                                                     */
+/* ------------------------------------------------------------------------ */
+
+/* types.glsl:251-255: bit patterns of floats, u32-compared */
+typedef struct OrbitClusterDepthBounds {
+    uint32_t min_depth; /* bits(1 - depth) maximised  (mark_active.comp:33) */
+    uint32_t max_depth; /* bits(depth) maximised      (mark_active.comp:34) */
+} OrbitClusterDepthBounds;
+
+/* CompactedClusterIndexList (types.glsl:270-276): also indirect args */
+#define ORBIT_COMPACT_HEADER 16u /* wg_x, wg_y, wg_z, cluster_count; indices @16 */
+/* ClusterLightIndices (types.glsl:246-249): u32 light_count @0, indices @4 */
+#define ORBIT_LIGHT_INDEX_HEADER 4u
+
+/* mark_active.comp:8-23 push-constant block, 56 B, with the three bindless
+ * indices (depth_buffer, mask, bounds) kept in place. */
+typedef struct OrbitMarkActivePush {
+    uint32_t cluster_count[3];
+    uint32_t tile_size_px;
+    uint32_t screen_size[2];
+    float z_near;
+    float z_far;
+    float z_scale;
+    float z_bias;
+    uint32_t depth_buffer;
+    uint32_t depth_buffer_sample_count;
+    uint32_t depth_slice_mask_buffer;
+    uint32_t depth_bounds_buffer;
+} OrbitMarkActivePush;
+ORBIT_STATIC_ASSERT(sizeof(OrbitMarkActivePush) == 56, "mark_active push block is 56 B");
+
+/* ClusterCullInfo, cluster.rs:186-207 == ClusterLightCullInfoBuffer,
+ * light_culling.comp:8-26 */
+typedef struct OrbitClusterCullInfo {
+    float world_to_view_matrix[16];  /* @0   */
+    float screen_to_view_matrix[16]; /* @64  inverse projection */
+    uint32_t cluster_count[3];       /* @128 */
+    uint32_t tile_size_px;           /* @140 */
+    uint32_t screen_size[2];         /* @144 */
+    float z_near;                    /* @152 */
+    float z_far;                     /* @156 */
+    uint32_t unique_cluster_buffer;  /* @160 bindless indices, unused by HIP */
+    uint32_t cluster_offset_image;   /* @164 */
+    uint32_t light_index_buffer;     /* @168 */
+    uint32_t depth_bounds_buffer;    /* @172 */
+    uint32_t global_light_count;     /* @176 */
+    uint32_t global_light_list;      /* @180 */
+    uint32_t _padding[2];            /* @184 */
+} OrbitClusterCullInfo;
+ORBIT_STATIC_ASSERT(sizeof(OrbitClusterCullInfo) == 192, "ClusterCullInfo is 192 B");
+ORBIT_STATIC_ASSERT(offsetof(OrbitClusterCullInfo, cluster_count) == 128, "cluster_count @128");
+ORBIT_STATIC_ASSERT(offsetof(OrbitClusterCullInfo, global_light_count) == 176, "light count @176");
+
+/* GpuClusterInfoBuffer, cluster.rs:322-335 == ClusterBuffer, types.glsl:42-53 */
+typedef struct OrbitGpuClusterInfoBuffer {
+    uint32_t cluster_count[3];
+    uint32_t tile_size_px;
+    uint32_t screen_size[2];
+    uint32_t z_slice_count;
+    float z_scale;
+    float z_bias;
+    float luminance_cutoff;
+    uint32_t light_offset_image;
+    uint32_t light_index_list;
+    uint32_t tile_depth_slice_mask_buffer;
+} OrbitGpuClusterInfoBuffer;
+ORBIT_STATIC_ASSERT(sizeof(OrbitGpuClusterInfoBuffer) == 52, "GpuClusterInfoBuffer is 52 B");
+
+/* ------------------------------------------------------------------------ */
+/* Context                                                                   */
+/* ------------------------------------------------------------------------ */
+
+/* Runtime capacities replace the reference's compile-time constants
+ * (draw_gen.rs:15-16, scene.rs:303-304, assets/mod.rs:197-205).  They size the
+ * context's private scan scratch only; caller buffers stay caller-owned. */
+typedef struct OrbitCaps {
+    uint32_t max_entities;   /* scene.rs:303   MAX_INSTANCE_COUNT   = 100_000   */
+    uint32_t max_dispatches; /* draw_gen.rs:16 MAX_MESHLET_DISPATCH = 1_000_000 */
+    uint32_t max_draws;      /* draw_gen.rs:15 MAX_DRAW_COUNT       = 1_000_000 */
+    uint32_t max_lights;     /* scene.rs:304   MAX_LIGHT_COUNT      = 2_000     */
+    uint32_t max_clusters;   /* tiles_x * tiles_y * max(4, z_slices): cluster.rs:53-56 */
+    uint32_t dispatch_size;  /* spec constant 0 of both cull shaders; must be 32 */
+    uint32_t reserved[2];
+} OrbitCaps;
+
+typedef struct OrbitCtx OrbitCtx;
+
+uint32_t orbit_abi_version(void);
+/* Fills `caps` with the reference's constants listed above. */
+void orbit_default_caps(OrbitCaps *caps);
+/* Creates a context on HIP device `device_id`.  Fails with ORBIT_E_NO_DEVICE
+ * when no GPU is usable — there is no host fallback. */
+int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps, OrbitCtx **out_ctx);
+int32_t orbit_ctx_destroy(OrbitCtx *ctx);
+/* Message for the last failing call on this thread / context (never NULL). */
+const char *orbit_last_error(const OrbitCtx *ctx);
+/* Device-latched status (ORBIT_OK / ORBIT_E_CAPACITY / ORBIT_E_TIMEOUT).
+ * `sync` != 0 first waits for `stream` to drain.  Clears the latch. */
+int32_t orbit_ctx_status(OrbitCtx *ctx, void *stream, int32_t sync);
+
+/* ------------------------------------------------------------------------ */
+/* entity_cull  — replaces the clear + ComputePass recorded by              */
+/* create_meshlet_dispatch_command (draw_gen.rs:327-380) and the first half */
+/* of create_draw_commands (draw_gen.rs:283-307); device code restates      */
+/* shaders/entity_cull.comp:104-245.                                        */
+/* ------------------------------------------------------------------------ */
+
+/* Raw device pointers in the push-constant order of entity_cull.comp:17-23
+ * (== draw_gen.rs:372-376); the three CullInfo-carried resources follow. */
+typedef struct OrbitEntityCullBufs {
+    const void *entity_draw_buffer;  /* EntityDrawBuffer */
+    const void *mesh_info_buffer;    /* OrbitMeshInfo[] */
+    void *meshlet_dispatch_buffer;   /* MeshletDispatchBuffer, written */
+    const void *entity_buffer;       /* OrbitEntityData[] */
+    uint32_t *visibility_buffer;     /* entity bitset; required iff occlusion_pass != 0 */
+    const float *depth_pyramid;      /* R32F mip chain (orbit_depth_pyramid_desc); pass 2 */
+    uint32_t depth_pyramid_size[2];  /* mip-0 width, height = textureSize(.., 0) */
+    uint32_t dispatch_capacity;      /* records the dispatch buffer can hold */
+    uint32_t _pad;
+} OrbitEntityCullBufs;
+
+/* The library performs the {0,1,1} header clear itself (draw_gen.rs:356-363).
+ * `cull_info` is a HOST pointer to the 400-B block CullInfo::to_gpu built.
+ * Grid = ceil(entity_draw_count / 256) like draw_gen.rs:377; the in-buffer
+ * `count` bounds the work like entity_cull.comp:106. */
+int32_t orbit_entity_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info,
+                          const OrbitEntityCullBufs *bufs, uint32_t entity_draw_count,
+                          void *stream);
+/* Same over the entity-draw range [draw_first, draw_first + draw_count) only:
+ * the per-rank shard of the multi-GPU path.  draw_first must
+ * be a multiple of 32 so that entity-visibility words stay rank-private. */
+int32_t orbit_entity_cull_range(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info,
+                                const OrbitEntityCullBufs *bufs, uint32_t draw_first,
+                                uint32_t draw_count, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* meshlet_cull — replaces create_meshlet_draw_commands (draw_gen.rs:382-435)*/
+/* and the second half of create_draw_commands; device code restates        */
+/* shaders/meshlet_cull.comp:108-255.                                       */
+/* ------------------------------------------------------------------------ */
+
+/* push-constant order of meshlet_cull.comp:16-23 (== draw_gen.rs:426-431) */
+typedef struct OrbitMeshletCullBufs {
+    const void *meshlet_dispatch_buffer; /* read: header x = record count (device side) */
+    const void *meshlet_buffer;          /* OrbitMeshlet[] */
+    void *draw_commands_buffer;          /* MeshletDrawCommandBuffer, written */
+    const void *entity_buffer;           /* OrbitEntityData[] */
+    const void *material_buffer;         /* OrbitMaterialData[] */
+    uint32_t *meshlet_visibility_buffer; /* required iff cull_info says present */
+    const float *depth_pyramid;
+    uint32_t depth_pyramid_size[2];
+    uint32_t dispatch_capacity; /* upper bound of records in the dispatch buffer */
+    uint32_t draw_capacity;     /* commands the draw buffer can hold */
+} OrbitMeshletCullBufs;
+
+/* The record count is read on the device from the dispatch header — the
+ * equivalent of vkCmdDispatchIndirect (draw_gen.rs:432); no host readback.
+ * The `count = 0` clear (draw_gen.rs:411-417) is performed by the library. */
+int32_t orbit_meshlet_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info,
+                           const OrbitMeshletCullBufs *bufs, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* depth_reduce — replaces DepthPyramid::{new,resize,update}                 */
+/* (draw_gen.rs:456-566); device code restates shaders/depth_reduce.comp and */
+/* the ReduceMin sampler (src/graphics/device.rs:1404-1420).                 */
+/* ------------------------------------------------------------------------ */
+
+#define ORBIT_MAX_PYRAMID_MIPS 16
+typedef struct OrbitDepthPyramidDesc {
+    uint32_t width, height; /* mip 0: next_pow2(screen)/2, draw_gen.rs:458 */
+    uint32_t mip_levels;    /* math.rs:18-20 */
+    uint32_t total_texels;  /* sum over mips; buffer size = 4 * total_texels */
+    uint32_t mip_offset[ORBIT_MAX_PYRAMID_MIPS]; /* texel offset of each level */
+    uint32_t mip_width[ORBIT_MAX_PYRAMID_MIPS];  /* max(dim >> k, 1), image.rs:533 */
+    uint32_t mip_height[ORBIT_MAX_PYRAMID_MIPS];
+} OrbitDepthPyramidDesc;
+
+/* Host-only: pyramid geometry for a screen_width x screen_height depth buffer. */
+int32_t orbit_depth_pyramid_desc(uint32_t screen_width, uint32_t screen_height,
+                                 OrbitDepthPyramidDesc *desc);
+/* Same but from the mip-0 size (what the cull kernels get as textureSize). */
+int32_t orbit_depth_pyramid_desc_from_mip0(uint32_t mip0_width, uint32_t mip0_height,
+                                           OrbitDepthPyramidDesc *desc);
+/* All mips in one launch (the reference loops <= 12 dispatches with barriers,
+ * draw_gen.rs:538-564).  `depth` is the W x H reverse-Z D32F buffer, row-major. */
+int32_t orbit_depth_reduce(OrbitCtx *ctx, const float *depth, uint32_t screen_width,
+                           uint32_t screen_height, float *pyramid, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* light_cluster — replaces compute_clusters and its three stages            */
+/* (cluster.rs:368-591); device code restates shaders/light_cluster/ (the .comp files). */
+/* ------------------------------------------------------------------------ */
+
+/* mark_active_clusters (cluster.rs:399-477).  `depth` is W x H x samples
+ * floats, sample index fastest.  Both outputs are fully (re)written, which
+ * subsumes the zero-fill of cluster.rs:439-456. */
+int32_t orbit_cluster_mark(OrbitCtx *ctx, const OrbitMarkActivePush *push, const float *depth,
+                           uint32_t *tile_depth_slice_mask, /* tiles_x * tiles_y words */
+                           OrbitClusterDepthBounds *depth_bounds, /* cx*cy*cz entries */
+                           void *stream);
+
+/* compact_active_clusters (cluster.rs:479-517).  Output order is ascending
+ * linear cluster index; header = {ceil(n/256), 1, 1, n}. */
+int32_t orbit_cluster_compact(OrbitCtx *ctx, const uint32_t cluster_count[3],
+                              const uint32_t *tile_depth_slice_mask,
+                              void *unique_cluster_buffer, uint32_t index_capacity,
+                              void *stream);
+
+/* cluster_light_assignment (cluster.rs:519-591).  `info` is a HOST pointer.
+ * `cluster_offset_image` is the RG32UI 3-D image as cx*cy*cz (offset,count)
+ * pairs in linear-index order; only active clusters are written, like the
+ * reference's imageStore (light_culling.comp:150). */
+int32_t orbit_cluster_assign(OrbitCtx *ctx, const OrbitClusterCullInfo *info,
+                             const void *unique_cluster_buffer,
+                             const OrbitClusterDepthBounds *depth_bounds,
+                             const OrbitLightData *lights,
+                             void *light_index_buffer, uint32_t light_index_capacity,
+                             uint32_t *cluster_offset_image, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* Multi-GPU helpers.  The exchange itself runs over RCCL    */
+/* through torch.distributed on the host side (orbit_amd/dist.py); these are */
+/* the device-side pieces.                                                   */
+/* ------------------------------------------------------------------------ */
+
+/* Contiguous, 32-aligned entity-draw range owned by `rank` of `world`. */
+void orbit_shard_range(uint32_t entity_draw_count, uint32_t rank, uint32_t world,
+                       uint32_t *begin, uint32_t *end);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBIT_ABI_H */

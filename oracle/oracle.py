@@ -1,0 +1,168 @@
+"""ctypes binding of the CPU oracle (``oracle/orbit_oracle.c``).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, ``__graft_entry__.smoke()`` and
+``bench.py``'s cpu_baseline leg — never by anything under ``orbit_amd/``.
+All arguments are host numpy arrays; outputs are fresh numpy arrays.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborbit_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(
+            os.path.join(_HERE, "orbit_oracle.c")):
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.orbit_log2f.restype = C.c_float
+        _lib.orbit_log2f.argtypes = [C.c_float]
+        _lib.oracle_hiz_sample.restype = C.c_float
+        _lib.oracle_hiz_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float]
+        for n in ("oracle_entity_cull", "oracle_meshlet_cull", "oracle_cluster_compact", "oracle_cluster_assign",
+                  "oracle_sphere_frustum_cull", "oracle_mip_levels_from_size"):
+            getattr(_lib, n).restype = C.c_uint32
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _bytes(a):
+    return np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+
+
+class PyramidDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("mip_levels", C.c_uint32),
+                ("total_texels", C.c_uint32), ("mip_offset", C.c_uint32 * 16), ("mip_width", C.c_uint32 * 16),
+                ("mip_height", C.c_uint32 * 16)]
+
+
+def log2f(x):
+    return float(lib().orbit_log2f(C.c_float(x)))
+
+
+def depth_pyramid_desc(sw, sh):
+    d = PyramidDesc()
+    lib().oracle_depth_pyramid_desc(C.c_uint32(sw), C.c_uint32(sh), C.byref(d))
+    return d
+
+
+def frustum_planes_from_matrix(m):
+    m = np.ascontiguousarray(m, dtype=np.float32).reshape(16)
+    out = np.zeros((6, 4), dtype=np.float32)
+    lib().oracle_frustum_planes_from_matrix(_p(m), _p(out))
+    return out
+
+
+def depth_reduce(depth, sw, sh):
+    depth = np.ascontiguousarray(depth, dtype=np.float32)
+    d = depth_pyramid_desc(sw, sh)
+    pyr = np.zeros(d.total_texels, dtype=np.float32)
+    lib().oracle_depth_reduce(_p(depth), C.c_uint32(sw), C.c_uint32(sh), _p(pyr))
+    return pyr, d
+
+
+def hiz_sample(pyr, w0, h0, u, v, lod):
+    pyr = np.ascontiguousarray(pyr, dtype=np.float32)
+    return float(lib().oracle_hiz_sample(_p(pyr), w0, h0, C.c_float(u), C.c_float(v), C.c_float(lod)))
+
+
+def entity_cull(cull_info, entity_draw_buffer, entity_draw_count, mesh_infos, entities, dispatch_capacity,
+                visibility=None, pyramid=None, pyramid_size=(0, 0), draw_first=0):
+    """Returns (dispatch_buffer bytes, visibility words (copy, updated in pass 2), dropped)."""
+    ci = _bytes(cull_info)
+    assert ci.nbytes == 400
+    edb = _bytes(entity_draw_buffer)
+    mi, en = _bytes(mesh_infos), _bytes(entities)
+    out = np.zeros(12 + 16 * dispatch_capacity, dtype=np.uint8)
+    vis = None if visibility is None else np.array(visibility, dtype=np.uint32, copy=True)
+    pyr = None if pyramid is None else np.ascontiguousarray(pyramid, dtype=np.float32)
+    dropped = lib().oracle_entity_cull(_p(ci), _p(edb), C.c_uint32(draw_first), C.c_uint32(entity_draw_count), _p(mi),
+                                       _p(en), _p(out), C.c_uint32(dispatch_capacity), _p(vis), _p(pyr),
+                                       C.c_uint32(pyramid_size[0]), C.c_uint32(pyramid_size[1]))
+    return out, vis, int(dropped)
+
+
+def meshlet_cull(cull_info, dispatch_buffer, meshlets, draw_capacity, entities, materials, meshlet_visibility=None,
+                 pyramid=None, pyramid_size=(0, 0)):
+    """Returns (draw_buffer bytes, meshlet visibility words (copy), dropped)."""
+    ci = _bytes(cull_info)
+    assert ci.nbytes == 400
+    db, ml, en, mt = _bytes(dispatch_buffer), _bytes(meshlets), _bytes(entities), _bytes(materials)
+    out = np.zeros(4 + 28 * draw_capacity, dtype=np.uint8)
+    vis = None if meshlet_visibility is None else np.array(meshlet_visibility, dtype=np.uint32, copy=True)
+    pyr = None if pyramid is None else np.ascontiguousarray(pyramid, dtype=np.float32)
+    dropped = lib().oracle_meshlet_cull(_p(ci), _p(db), _p(ml), _p(out), C.c_uint32(draw_capacity), _p(en), _p(mt),
+                                        _p(vis), _p(pyr), C.c_uint32(pyramid_size[0]), C.c_uint32(pyramid_size[1]))
+    return out, vis, int(dropped)
+
+
+def cluster_grid_info(near, far, z_slices):
+    zs, zb = C.c_float(), C.c_float()
+    lib().oracle_cluster_grid_info(C.c_float(near), C.c_float(far), C.c_uint32(z_slices), C.byref(zs), C.byref(zb))
+    return zs.value, zb.value
+
+
+def cluster_mark(push, depth):
+    pc = _bytes(push)
+    assert pc.nbytes == 56
+    cc = pc[:12].view("<u4")
+    depth = np.ascontiguousarray(depth, dtype=np.float32)
+    masks = np.zeros(int(cc[0]) * int(cc[1]), dtype=np.uint32)
+    bounds = np.zeros((int(cc[0]) * int(cc[1]) * int(cc[2]), 2), dtype=np.uint32)
+    lib().oracle_cluster_mark(_p(pc), _p(depth), _p(masks), _p(bounds))
+    return masks, bounds
+
+
+def cluster_compact(cluster_count, masks, index_capacity):
+    cc = np.asarray(cluster_count, dtype=np.uint32)
+    masks = np.ascontiguousarray(masks, dtype=np.uint32)
+    out = np.zeros(16 + 4 * index_capacity, dtype=np.uint8)
+    dropped = lib().oracle_cluster_compact(_p(cc), _p(masks), _p(out), C.c_uint32(index_capacity))
+    return out, int(dropped)
+
+
+def cluster_aabb(info, bounds, cluster_index):
+    ib = _bytes(info)
+    bounds = np.ascontiguousarray(bounds, dtype=np.uint32)
+    mn, mx = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    lib().oracle_cluster_aabb(_p(ib), _p(bounds), C.c_uint32(cluster_index), _p(mn), _p(mx))
+    return mn, mx
+
+
+def cluster_assign(info, unique, bounds, lights, light_index_capacity, total_clusters, offset_image=None):
+    ib = _bytes(info)
+    assert ib.nbytes == 192
+    un, lt = _bytes(unique), _bytes(lights)
+    bounds = np.ascontiguousarray(bounds, dtype=np.uint32)
+    out = np.zeros(4 + 4 * light_index_capacity, dtype=np.uint8)
+    img = np.zeros((total_clusters, 2), dtype=np.uint32) if offset_image is None else np.array(
+        offset_image, dtype=np.uint32, copy=True)
+    dropped = lib().oracle_cluster_assign(_p(ib), _p(un), _p(bounds), _p(lt), _p(out),
+                                          C.c_uint32(light_index_capacity), _p(img))
+    return out, img, int(dropped)
+
+
+def sphere_frustum_cull(view, planes, spheres):
+    view = np.ascontiguousarray(view, dtype=np.float32).reshape(16)
+    planes = np.ascontiguousarray(planes, dtype=np.float32).reshape(-1, 4)
+    spheres = np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 4)
+    n = len(spheres)
+    bits = np.zeros((n + 31) // 32, dtype=np.uint32)
+    cnt = lib().oracle_sphere_frustum_cull(_p(view), _p(planes), C.c_uint32(len(planes)), _p(spheres), C.c_uint32(n),
+                                           _p(bits))
+    return bits, int(cnt)

@@ -1,0 +1,101 @@
+"""ctypes binding of ``liborbit_cull.so`` (the C ABI of ``include/orbit_abi.h``).
+
+There is exactly one compute path: the HIP library.  If it is missing or no
+gfx950 device is usable, loading / context creation raises — nothing here falls
+back to a host implementation.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborbit_cull.so")
+
+OK, E_INVALID, E_PLANES, E_CAPACITY, E_HIP, E_NO_DEVICE, E_TIMEOUT, E_MISSING = 0, -1, -2, -3, -4, -5, -6, -7
+ERROR_NAMES = {
+    E_INVALID: "ORBIT_E_INVALID", E_PLANES: "ORBIT_E_PLANES", E_CAPACITY: "ORBIT_E_CAPACITY", E_HIP: "ORBIT_E_HIP",
+    E_NO_DEVICE: "ORBIT_E_NO_DEVICE", E_TIMEOUT: "ORBIT_E_TIMEOUT", E_MISSING: "ORBIT_E_MISSING",
+}
+
+MAX_PYRAMID_MIPS = 16
+
+
+class OrbitError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"{ERROR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+class Caps(C.Structure):
+    _fields_ = [("max_entities", C.c_uint32), ("max_dispatches", C.c_uint32), ("max_draws", C.c_uint32),
+                ("max_lights", C.c_uint32), ("max_clusters", C.c_uint32), ("dispatch_size", C.c_uint32),
+                ("reserved", C.c_uint32 * 2)]
+
+
+class EntityCullBufs(C.Structure):
+    _fields_ = [("entity_draw_buffer", C.c_void_p), ("mesh_info_buffer", C.c_void_p),
+                ("meshlet_dispatch_buffer", C.c_void_p), ("entity_buffer", C.c_void_p),
+                ("visibility_buffer", C.c_void_p), ("depth_pyramid", C.c_void_p),
+                ("depth_pyramid_size", C.c_uint32 * 2), ("dispatch_capacity", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class MeshletCullBufs(C.Structure):
+    _fields_ = [("meshlet_dispatch_buffer", C.c_void_p), ("meshlet_buffer", C.c_void_p),
+                ("draw_commands_buffer", C.c_void_p), ("entity_buffer", C.c_void_p), ("material_buffer", C.c_void_p),
+                ("meshlet_visibility_buffer", C.c_void_p), ("depth_pyramid", C.c_void_p),
+                ("depth_pyramid_size", C.c_uint32 * 2), ("dispatch_capacity", C.c_uint32),
+                ("draw_capacity", C.c_uint32)]
+
+
+class DepthPyramidDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("mip_levels", C.c_uint32),
+                ("total_texels", C.c_uint32), ("mip_offset", C.c_uint32 * MAX_PYRAMID_MIPS),
+                ("mip_width", C.c_uint32 * MAX_PYRAMID_MIPS), ("mip_height", C.c_uint32 * MAX_PYRAMID_MIPS)]
+
+
+# every symbol include/orbit_abi.h declares: (restype, argtypes)
+SYMBOLS = {
+    "orbit_abi_version": (C.c_uint32, []),
+    "orbit_default_caps": (None, [C.POINTER(Caps)]),
+    "orbit_ctx_create": (C.c_int32, [C.c_int32, C.POINTER(Caps), C.POINTER(C.c_void_p)]),
+    "orbit_ctx_destroy": (C.c_int32, [C.c_void_p]),
+    "orbit_last_error": (C.c_char_p, [C.c_void_p]),
+    "orbit_ctx_status": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "orbit_entity_cull": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(EntityCullBufs), C.c_uint32, C.c_void_p]),
+    "orbit_entity_cull_range": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(EntityCullBufs), C.c_uint32,
+                                            C.c_uint32, C.c_void_p]),
+    "orbit_meshlet_cull": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(MeshletCullBufs), C.c_void_p]),
+    "orbit_depth_pyramid_desc": (C.c_int32, [C.c_uint32, C.c_uint32, C.POINTER(DepthPyramidDesc)]),
+    "orbit_depth_pyramid_desc_from_mip0": (C.c_int32, [C.c_uint32, C.c_uint32, C.POINTER(DepthPyramidDesc)]),
+    "orbit_depth_reduce": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "orbit_cluster_mark": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orbit_cluster_compact": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32 * 3), C.c_void_p, C.c_void_p, C.c_uint32,
+                                          C.c_void_p]),
+    "orbit_cluster_assign": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_uint32, C.c_void_p, C.c_void_p]),
+    "orbit_shard_range": (None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library once; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(f"{LIB_PATH} is missing: build it with `make -C orbit_amd/csrc` or "
+                      "`python -c 'import __graft_entry__ as g; g.build()'` (there is no fallback path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc, ctx=None):
+    if rc != OK:
+        msg = load().orbit_last_error(ctx)
+        raise OrbitError(rc, msg.decode() if msg else "")

@@ -1,0 +1,461 @@
+// abi.hip — implementation of the C ABI declared in include/orbit_abi.h.
+//
+// Argument validation mirrors the reference's host-side failure modes
+// (assert!/unwrap in src/passes/draw_gen.rs:123-133,247,334,390) as status
+// codes; nothing unwinds across the boundary.  There is no host fallback: a
+// missing device or an unloadable code object is ORBIT_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "kernels.h"
+
+using namespace orbit;
+
+struct OrbitCtx {
+    int device = 0;
+    uint32_t num_cus = 0;
+    OrbitCaps caps{};
+    std::mutex mu; // entry points are thread-safe per ctx (pass closures are Send + Sync, context.rs:617-620)
+    // scratch (device)
+    uint8_t *arena = nullptr;
+    size_t arena_bytes = 0;
+    OrbitMeshletDispatch *e_proto = nullptr;
+    uint32_t *e_block_sums = nullptr, *e_block_base = nullptr, *e_total = nullptr;
+    uint32_t *m_tile_counts = nullptr, *m_tile_base = nullptr, *m_total = nullptr;
+    uint64_t *m_scan_state = nullptr;
+    uint32_t *m_ticket = nullptr;
+    uint32_t *c_chunk = nullptr; // compact: counts | bases | total
+    float4 *a_view_lights = nullptr;
+    uint32_t *a_light_flags = nullptr, *a_counts = nullptr, *a_block_sums = nullptr, *a_block_base = nullptr,
+             *a_total = nullptr;
+    int32_t *status = nullptr;
+    char err[512] = {0};
+};
+
+namespace {
+
+thread_local char g_err[512] = "no error";
+
+int32_t fail(OrbitCtx *ctx, int32_t code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    snprintf(g_err, sizeof(g_err), "%s", buf);
+    if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", buf);
+    return code;
+}
+
+int32_t hip_fail(OrbitCtx *ctx, hipError_t e, const char *what) {
+    return fail(ctx, ORBIT_E_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+uint32_t mip_levels_from_size(uint32_t max_size) { // src/math.rs:18-20
+    uint32_t l = 0;
+    while ((max_size >> (l + 1)) != 0) l++;
+    return l + 1;
+}
+
+uint32_t next_pow2(uint32_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+void fill_pyramid_desc(uint32_t w0, uint32_t h0, OrbitDepthPyramidDesc *d) {
+    memset(d, 0, sizeof(*d));
+    d->width = w0;
+    d->height = h0;
+    d->mip_levels = mip_levels_from_size(w0 > h0 ? w0 : h0);
+    uint32_t off = 0;
+    for (uint32_t k = 0; k < d->mip_levels && k < ORBIT_MAX_PYRAMID_MIPS; k++) {
+        d->mip_offset[k] = off;
+        d->mip_width[k] = (w0 >> k) ? (w0 >> k) : 1; // image.rs:533
+        d->mip_height[k] = (h0 >> k) ? (h0 >> k) : 1;
+        off += d->mip_width[k] * d->mip_height[k];
+    }
+    d->total_texels = off;
+}
+
+int32_t check_cull_info(OrbitCtx *ctx, const OrbitGpuCullInfo *ci) {
+    if (!ci) return fail(ctx, ORBIT_E_INVALID, "cull_info is NULL");
+    if (ci->cull_plane_count > ORBIT_MAX_CULL_PLANES) // assert!, draw_gen.rs:247,334,390
+        return fail(ctx, ORBIT_E_PLANES, "cull_plane_count %u > %d", ci->cull_plane_count, ORBIT_MAX_CULL_PLANES);
+    if (ci->projection_type > 1) return fail(ctx, ORBIT_E_INVALID, "projection_type %u", ci->projection_type);
+    if (ci->occlusion_pass > 2) return fail(ctx, ORBIT_E_INVALID, "occlusion_pass %u", ci->occlusion_pass);
+    return ORBIT_OK;
+}
+
+PyramidView make_pyramid_view(const float *texels, const uint32_t size[2]) {
+    PyramidView v;
+    v.texels = texels;
+    v.w0 = size[0];
+    v.h0 = size[1];
+    v.mips = (size[0] | size[1]) ? mip_levels_from_size(size[0] > size[1] ? size[0] : size[1]) : 0;
+    return v;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t orbit_abi_version(void) { return ORBIT_ABI_VERSION; }
+
+void orbit_default_caps(OrbitCaps *caps) {
+    if (!caps) return;
+    memset(caps, 0, sizeof(*caps));
+    caps->max_entities = 100000;    // src/scene.rs:303
+    caps->max_dispatches = 1000000; // src/passes/draw_gen.rs:16
+    caps->max_draws = 1000000;      // src/passes/draw_gen.rs:15
+    caps->max_lights = 2000;        // src/scene.rs:304
+    caps->max_clusters = 240 * 135 * 32; // 1920x1080, 8 px tiles, 32 slices (cluster.rs:23-33)
+    caps->dispatch_size = ORBIT_MESHLET_DISPATCH_SIZE;
+}
+
+const char *orbit_last_error(const OrbitCtx *ctx) { return ctx ? ctx->err : g_err; }
+
+int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx **out_ctx) {
+    if (!out_ctx) return fail(nullptr, ORBIT_E_INVALID, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    OrbitCaps caps;
+    if (caps_in) caps = *caps_in;
+    else orbit_default_caps(&caps);
+    if (caps.dispatch_size != ORBIT_MESHLET_DISPATCH_SIZE)
+        return fail(nullptr, ORBIT_E_INVALID,
+                    "dispatch_size %u: only 32 keeps the reference's visibility-word addressing consistent "
+                    "(src/graphics/device.rs:369-372)",
+                    caps.dispatch_size);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev)
+        return fail(nullptr, ORBIT_E_NO_DEVICE, "no usable HIP device %d (count %d): %s; there is no CPU fallback",
+                    device_id, ndev, e == hipSuccess ? "ok" : hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceProperties");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, ORBIT_E_NO_DEVICE, "device %d is %s; this library carries gfx950 code objects only",
+                    device_id, prop.gcnArchName);
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
+
+    OrbitCtx *ctx = new (std::nothrow) OrbitCtx();
+    if (!ctx) return fail(nullptr, ORBIT_E_HIP, "out of host memory");
+    ctx->device = device_id;
+    ctx->num_cus = (uint32_t)prop.multiProcessorCount;
+    ctx->caps = caps;
+
+    // one arena for all scan scratch, carved at 256-B alignment
+    const size_t ent = align_up((size_t)caps.max_entities, 256);
+    const size_t eblocks = ent / 256 + 1;
+    const size_t mtiles = ((size_t)caps.max_dispatches + kTileRecords - 1) / kTileRecords + 1;
+    const size_t cchunks = ((size_t)caps.max_clusters / 1024 + 64) * 32;
+    const size_t ablocks = (size_t)caps.max_clusters / 256 + 2;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t o = off;
+        off = align_up(off + bytes, 256);
+        return o;
+    };
+    const size_t o_status = carve(256);
+    const size_t o_eproto = carve(ent * sizeof(OrbitMeshletDispatch));
+    const size_t o_ebs = carve(eblocks * 4), o_ebb = carve(eblocks * 4), o_et = carve(256);
+    const size_t o_mtc = carve(mtiles * 4), o_mtb = carve(mtiles * 4), o_mt = carve(256);
+    const size_t o_mss = carve(mtiles * 8), o_mtk = carve(256);
+    const size_t o_cc = carve((2 * cchunks + 64) * 4);
+    const size_t o_avl = carve((size_t)caps.max_lights * 16 + 1024);
+    const size_t o_alf = carve(((size_t)caps.max_lights / 32 + 64) * 4);
+    const size_t o_acn = carve(((size_t)caps.max_clusters + 256) * 4);
+    const size_t o_abs = carve(ablocks * 4), o_abb = carve(ablocks * 4), o_at = carve(256);
+    ctx->arena_bytes = off;
+    e = hipMalloc((void **)&ctx->arena, ctx->arena_bytes);
+    if (e != hipSuccess) {
+        delete ctx;
+        return hip_fail(nullptr, e, "hipMalloc(scratch arena)");
+    }
+    e = hipMemset(ctx->arena, 0, ctx->arena_bytes);
+    if (e != hipSuccess) {
+        (void)hipFree(ctx->arena);
+        delete ctx;
+        return hip_fail(nullptr, e, "hipMemset(scratch arena)");
+    }
+    uint8_t *a = ctx->arena;
+    ctx->status = (int32_t *)(a + o_status);
+    ctx->e_proto = (OrbitMeshletDispatch *)(a + o_eproto);
+    ctx->e_block_sums = (uint32_t *)(a + o_ebs);
+    ctx->e_block_base = (uint32_t *)(a + o_ebb);
+    ctx->e_total = (uint32_t *)(a + o_et);
+    ctx->m_tile_counts = (uint32_t *)(a + o_mtc);
+    ctx->m_tile_base = (uint32_t *)(a + o_mtb);
+    ctx->m_total = (uint32_t *)(a + o_mt);
+    ctx->m_scan_state = (uint64_t *)(a + o_mss);
+    ctx->m_ticket = (uint32_t *)(a + o_mtk);
+    ctx->c_chunk = (uint32_t *)(a + o_cc);
+    ctx->a_view_lights = (float4 *)(a + o_avl);
+    ctx->a_light_flags = (uint32_t *)(a + o_alf);
+    ctx->a_counts = (uint32_t *)(a + o_acn);
+    ctx->a_block_sums = (uint32_t *)(a + o_abs);
+    ctx->a_block_base = (uint32_t *)(a + o_abb);
+    ctx->a_total = (uint32_t *)(a + o_at);
+    snprintf(ctx->err, sizeof(ctx->err), "no error");
+    *out_ctx = ctx;
+    return ORBIT_OK;
+}
+
+int32_t orbit_ctx_destroy(OrbitCtx *ctx) {
+    if (!ctx) return ORBIT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    delete ctx;
+    return ORBIT_OK;
+}
+
+int32_t orbit_ctx_status(OrbitCtx *ctx, void *stream, int32_t sync) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipStream_t s = (hipStream_t)stream;
+    if (sync) {
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return hip_fail(ctx, e, "hipStreamSynchronize");
+    }
+    int32_t v = 0;
+    hipError_t e = hipMemcpy(&v, ctx->status, 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipMemcpy(status)");
+    if (v != 0) {
+        e = hipMemset(ctx->status, 0, 4);
+        if (e != hipSuccess) return hip_fail(ctx, e, "hipMemset(status)");
+        return fail(ctx, v, v == ORBIT_E_CAPACITY ? "an append overflowed a caller buffer (entries dropped)"
+                                                   : "device-latched error %d", v);
+    }
+    return ORBIT_OK;
+}
+
+// ------------------------------------------------------------------ entity_cull
+static int32_t entity_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitEntityCullBufs *b,
+                                uint32_t draw_first, uint32_t entity_draw_count, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    int32_t rc = check_cull_info(ctx, ci);
+    if (rc) return rc;
+    if (!b) return fail(ctx, ORBIT_E_INVALID, "bufs is NULL");
+    if (!b->entity_draw_buffer || !b->mesh_info_buffer || !b->meshlet_dispatch_buffer || !b->entity_buffer)
+        return fail(ctx, ORBIT_E_MISSING, "entity_cull: a required buffer is NULL");
+    if (ci->occlusion_pass != 0 && !b->visibility_buffer)
+        return fail(ctx, ORBIT_E_MISSING, "occlusion_pass %u needs visibility_buffer", ci->occlusion_pass);
+    if (ci->occlusion_pass == 2 && (!b->depth_pyramid || !b->depth_pyramid_size[0] || !b->depth_pyramid_size[1]))
+        return fail(ctx, ORBIT_E_MISSING, "occlusion_pass 2 needs depth_pyramid");
+    if (draw_first % 32u) return fail(ctx, ORBIT_E_INVALID, "draw_first %u is not a multiple of 32", draw_first);
+    if (entity_draw_count > ctx->caps.max_entities)
+        return fail(ctx, ORBIT_E_CAPACITY, "entity_draw_count %u > caps.max_entities %u", entity_draw_count,
+                    ctx->caps.max_entities);
+    EntityCullParams p;
+    p.ci = *ci;
+    p.entity_draw_buffer = (const uint8_t *)b->entity_draw_buffer;
+    p.mesh_infos = (const OrbitMeshInfo *)b->mesh_info_buffer;
+    p.dispatch_buffer = (uint8_t *)b->meshlet_dispatch_buffer;
+    p.entities = (const OrbitEntityData *)b->entity_buffer;
+    p.visibility = b->visibility_buffer;
+    p.pyr = make_pyramid_view(b->depth_pyramid, b->depth_pyramid_size);
+    p.draw_first = draw_first;
+    const uint64_t limit = (uint64_t)draw_first + ((uint64_t)entity_draw_count + 255u) / 256u * 256u;
+    p.draw_limit = limit > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)limit;
+    p.dispatch_capacity = b->dispatch_capacity;
+    p.proto = ctx->e_proto;
+    p.block_sums = ctx->e_block_sums;
+    p.block_base = ctx->e_block_base;
+    p.total = ctx->e_total;
+    p.status = ctx->status;
+    hipError_t e = launch_entity_cull(p, entity_draw_count, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch entity_cull");
+    return ORBIT_OK;
+}
+
+int32_t orbit_entity_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info, const OrbitEntityCullBufs *bufs,
+                          uint32_t entity_draw_count, void *stream) {
+    return entity_cull_impl(ctx, cull_info, bufs, 0u, entity_draw_count, stream);
+}
+
+int32_t orbit_entity_cull_range(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info, const OrbitEntityCullBufs *bufs,
+                                uint32_t draw_first, uint32_t draw_count, void *stream) {
+    return entity_cull_impl(ctx, cull_info, bufs, draw_first, draw_count, stream);
+}
+
+// ----------------------------------------------------------------- meshlet_cull
+int32_t orbit_meshlet_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    int32_t rc = check_cull_info(ctx, ci);
+    if (rc) return rc;
+    if (!b) return fail(ctx, ORBIT_E_INVALID, "bufs is NULL");
+    if (!b->meshlet_dispatch_buffer || !b->meshlet_buffer || !b->draw_commands_buffer || !b->entity_buffer ||
+        !b->material_buffer)
+        return fail(ctx, ORBIT_E_MISSING, "meshlet_cull: a required buffer is NULL");
+    const bool meshlet_occ = ci->meshlet_visibility_buffer != ORBIT_NONE;
+    if (meshlet_occ && ci->occlusion_pass != 0 && !b->meshlet_visibility_buffer)
+        return fail(ctx, ORBIT_E_MISSING, "cull_info declares a meshlet visibility buffer but the pointer is NULL");
+    if (meshlet_occ && ci->occlusion_pass == 2 &&
+        (!b->depth_pyramid || !b->depth_pyramid_size[0] || !b->depth_pyramid_size[1]))
+        return fail(ctx, ORBIT_E_MISSING, "occlusion_pass 2 needs depth_pyramid");
+    if (b->dispatch_capacity > ctx->caps.max_dispatches)
+        return fail(ctx, ORBIT_E_CAPACITY, "dispatch_capacity %u > caps.max_dispatches %u", b->dispatch_capacity,
+                    ctx->caps.max_dispatches);
+    MeshletCullParams p;
+    p.ci = *ci;
+    p.dispatch_buffer = (const uint8_t *)b->meshlet_dispatch_buffer;
+    p.meshlets = (const OrbitMeshlet *)b->meshlet_buffer;
+    p.draw_buffer = (uint8_t *)b->draw_commands_buffer;
+    p.entities = (const OrbitEntityData *)b->entity_buffer;
+    p.materials = (const OrbitMaterialData *)b->material_buffer;
+    p.meshlet_visibility = b->meshlet_visibility_buffer;
+    p.pyr = make_pyramid_view(b->depth_pyramid, b->depth_pyramid_size);
+    p.dispatch_capacity = b->dispatch_capacity;
+    p.draw_capacity = b->draw_capacity;
+    p.tile_counts = ctx->m_tile_counts;
+    p.tile_base = ctx->m_tile_base;
+    p.total = ctx->m_total;
+    p.scan_state = ctx->m_scan_state;
+    p.ticket = ctx->m_ticket;
+    p.status = ctx->status;
+    hipError_t e = launch_meshlet_cull(p, ctx->num_cus, 0, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_cull");
+    return ORBIT_OK;
+}
+
+// ----------------------------------------------------------------- depth_reduce
+int32_t orbit_depth_pyramid_desc(uint32_t sw, uint32_t sh, OrbitDepthPyramidDesc *desc) {
+    if (!desc || sw == 0 || sh == 0) return fail(nullptr, ORBIT_E_INVALID, "depth_pyramid_desc: bad argument");
+    uint32_t w0 = next_pow2(sw) / 2, h0 = next_pow2(sh) / 2; // draw_gen.rs:458
+    if (w0 == 0) w0 = 1;
+    if (h0 == 0) h0 = 1;
+    fill_pyramid_desc(w0, h0, desc);
+    return ORBIT_OK;
+}
+
+int32_t orbit_depth_pyramid_desc_from_mip0(uint32_t w0, uint32_t h0, OrbitDepthPyramidDesc *desc) {
+    if (!desc || w0 == 0 || h0 == 0) return fail(nullptr, ORBIT_E_INVALID, "depth_pyramid_desc: bad argument");
+    fill_pyramid_desc(w0, h0, desc);
+    return ORBIT_OK;
+}
+
+int32_t orbit_depth_reduce(OrbitCtx *ctx, const float *depth, uint32_t sw, uint32_t sh, float *pyramid,
+                           void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!depth || !pyramid) return fail(ctx, ORBIT_E_MISSING, "depth_reduce: NULL buffer");
+    OrbitDepthPyramidDesc d;
+    int32_t rc = orbit_depth_pyramid_desc(sw, sh, &d);
+    if (rc) return rc;
+    DepthReduceParams p;
+    p.depth = depth;
+    p.pyramid = pyramid;
+    p.screen_w = sw;
+    p.screen_h = sh;
+    p.w0 = d.width;
+    p.h0 = d.height;
+    p.mips = d.mip_levels;
+    memcpy(p.mip_offset, d.mip_offset, sizeof(p.mip_offset));
+    hipError_t e = launch_depth_reduce(p, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch depth_reduce");
+    return ORBIT_OK;
+}
+
+// ---------------------------------------------------------------- light_cluster
+int32_t orbit_cluster_mark(OrbitCtx *ctx, const OrbitMarkActivePush *push, const float *depth,
+                           uint32_t *tile_depth_slice_mask, OrbitClusterDepthBounds *depth_bounds, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!push || !depth || !tile_depth_slice_mask || !depth_bounds)
+        return fail(ctx, ORBIT_E_MISSING, "cluster_mark: NULL argument");
+    if (push->cluster_count[2] > 32 || push->tile_size_px == 0 || push->depth_buffer_sample_count == 0)
+        return fail(ctx, ORBIT_E_INVALID, "cluster_mark: z slices %u (> 32), tile %u or samples %u invalid",
+                    push->cluster_count[2], push->tile_size_px, push->depth_buffer_sample_count);
+    ClusterMarkParams p;
+    p.pc = *push;
+    p.depth = depth;
+    p.masks = tile_depth_slice_mask;
+    p.bounds = depth_bounds;
+    hipError_t e = launch_cluster_mark(p, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch cluster_mark");
+    return ORBIT_OK;
+}
+
+int32_t orbit_cluster_compact(OrbitCtx *ctx, const uint32_t cluster_count[3], const uint32_t *masks,
+                              void *unique_cluster_buffer, uint32_t index_capacity, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!cluster_count || !masks || !unique_cluster_buffer)
+        return fail(ctx, ORBIT_E_MISSING, "cluster_compact: NULL argument");
+    const uint64_t total = (uint64_t)cluster_count[0] * cluster_count[1] * cluster_count[2];
+    if (cluster_count[2] > 32 || total > ctx->caps.max_clusters)
+        return fail(ctx, ORBIT_E_CAPACITY, "cluster grid %ux%ux%u exceeds caps.max_clusters %u or 32 slices",
+                    cluster_count[0], cluster_count[1], cluster_count[2], ctx->caps.max_clusters);
+    ClusterCompactParams p;
+    memcpy(p.cc, cluster_count, 12);
+    p.masks = masks;
+    p.unique = (uint8_t *)unique_cluster_buffer;
+    p.index_capacity = index_capacity;
+    p.chunk_counts = ctx->c_chunk;
+    p.status = ctx->status;
+    hipError_t e = launch_cluster_compact(p, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch cluster_compact");
+    return ORBIT_OK;
+}
+
+int32_t orbit_cluster_assign(OrbitCtx *ctx, const OrbitClusterCullInfo *info, const void *unique_cluster_buffer,
+                             const OrbitClusterDepthBounds *depth_bounds, const OrbitLightData *lights,
+                             void *light_index_buffer, uint32_t light_index_capacity, uint32_t *cluster_offset_image,
+                             void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!info || !unique_cluster_buffer || !depth_bounds || !light_index_buffer || !cluster_offset_image)
+        return fail(ctx, ORBIT_E_MISSING, "cluster_assign: NULL argument");
+    if (info->global_light_count > 0 && !lights) return fail(ctx, ORBIT_E_MISSING, "cluster_assign: lights is NULL");
+    if (info->global_light_count > ctx->caps.max_lights)
+        return fail(ctx, ORBIT_E_CAPACITY, "light count %u > caps.max_lights %u", info->global_light_count,
+                    ctx->caps.max_lights);
+    const uint64_t total = (uint64_t)info->cluster_count[0] * info->cluster_count[1] * info->cluster_count[2];
+    if (total > ctx->caps.max_clusters)
+        return fail(ctx, ORBIT_E_CAPACITY, "cluster grid exceeds caps.max_clusters %u", ctx->caps.max_clusters);
+    ClusterAssignParams p;
+    p.info = *info;
+    p.unique = (const uint8_t *)unique_cluster_buffer;
+    p.bounds = depth_bounds;
+    p.lights = lights;
+    p.light_index_buffer = (uint8_t *)light_index_buffer;
+    p.light_index_capacity = light_index_capacity;
+    p.offset_image = cluster_offset_image;
+    p.max_clusters = (uint32_t)total;
+    p.view_lights = ctx->a_view_lights;
+    p.light_flags = ctx->a_light_flags;
+    p.counts = ctx->a_counts;
+    p.block_sums = ctx->a_block_sums;
+    p.block_base = ctx->a_block_base;
+    p.total = ctx->a_total;
+    p.status = ctx->status;
+    hipError_t e = launch_cluster_assign(p, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch cluster_assign");
+    return ORBIT_OK;
+}
+
+// ------------------------------------------------------------------- multi-GPU
+void orbit_shard_range(uint32_t n, uint32_t rank, uint32_t world, uint32_t *begin, uint32_t *end) {
+    // contiguous ranges cut at multiples of 32 so entity-bitset words are rank-private
+    if (world == 0) world = 1;
+    const uint64_t words = ((uint64_t)n + 31u) / 32u;
+    uint64_t b = words * rank / world * 32u, e = words * (rank + 1ull) / world * 32u;
+    if (b > n) b = n;
+    if (e > n) e = n;
+    if (begin) *begin = (uint32_t)b;
+    if (end) *end = (uint32_t)e;
+}
+
+} // extern "C"

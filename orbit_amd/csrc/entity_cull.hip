@@ -1,0 +1,192 @@
+// entity_cull.hip — per-entity frustum / HiZ cull, LOD pick and deterministic
+// emission of MeshletDispatch records for gfx950.
+//
+// Restates shaders/entity_cull.comp:104-245 (reference repo) under the launch
+// protocol of src/passes/draw_gen.rs:327-380.  Differences in *how*, not *what*:
+//   - the record append is a prefix sum (eval -> scan -> emit), so the record
+//     sequence is the canonical ascending-gID order instead of atomics order;
+//   - visibility words are written from wave64 ballots split into two 32-bit
+//     words (the reference's `gl_SubgroupSize == 32` addressing made explicit);
+//   - the {0,1,1} header clear (draw_gen.rs:356-363) is fused into the emit.
+#include "kernels.h"
+#include "scan.h"
+
+namespace orbit {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// One thread per entity-draw: evaluates the shader body up to the record
+// emission, stores a proto-record (meshlet_count == 0 when nothing is drawn).
+__global__ __launch_bounds__(kBlock) void entity_cull_eval(const EntityCullParams p) {
+    __shared__ uint32_t smem[kBlock / 64 + 1];
+    const OrbitGpuCullInfo &ci = p.ci;
+    const uint32_t local = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t g = p.draw_first + local;
+    const uint32_t count = *reinterpret_cast<const uint32_t *>(p.entity_draw_buffer);
+    const uint32_t end = min(count, p.draw_limit);
+    const bool active = g < end; // entity_cull.comp:106
+    const bool meshlet_occ = ci.meshlet_visibility_buffer != ORBIT_NONE;
+
+    bool visible = false;
+    OrbitMeshletDispatch pr = {0u, 0u, 0u, 0u};
+    if (active) {
+        const OrbitEntityDraw *draws =
+            reinterpret_cast<const OrbitEntityDraw *>(p.entity_draw_buffer + ORBIT_ENTITY_DRAW_HEADER);
+        const OrbitEntityDraw ed = draws[g];
+        const OrbitMeshInfo *mi = p.mesh_infos + ed.mesh_index;
+        const float4 bs = *reinterpret_cast<const float4 *>(mi->bounding_sphere);
+        const float4 *mm = reinterpret_cast<const float4 *>(p.entities[ed.entity_index].model_matrix);
+        const float4 c0 = mm[0], c1 = mm[1], c2 = mm[2], c3 = mm[3];
+
+        visible = true;
+        bool visible_in_buffer = true;
+        if (ci.occlusion_pass == 1 || ci.occlusion_pass == 2)
+            visible_in_buffer = (p.visibility[g / 32] & (1u << (g % 32))) != 0; // :117-120
+        if (ci.occlusion_pass == 1) visible = visible_in_buffer;                // :123
+
+        // view * model, transform_sphere (:37-43,:131-134)
+        float m0[4], m1[4], m2[4], m3[4];
+        mat4_mul_col(ci.view_matrix, c0.x, c0.y, c0.z, c0.w, m0);
+        mat4_mul_col(ci.view_matrix, c1.x, c1.y, c1.z, c1.w, m1);
+        mat4_mul_col(ci.view_matrix, c2.x, c2.y, c2.z, c2.w, m2);
+        mat4_mul_col(ci.view_matrix, c3.x, c3.y, c3.z, c3.w, m3);
+        float pv[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) pv[r] = ((m0[r] * bs.x + m1[r] * bs.y) + m2[r] * bs.z) + m3[r] * 1.0f;
+        Sphere s;
+        s.x = pv[0] / pv[3];
+        s.y = pv[1] / pv[3];
+        s.z = pv[2] / pv[3];
+        const float dx = dot3(m0[0], m0[1], m0[2], m0[0], m0[1], m0[2]);
+        const float dy = dot3(m1[0], m1[1], m1[2], m1[0], m1[1], m1[2]);
+        const float dz = dot3(m2[0], m2[1], m2[2], m2[0], m2[1], m2[2]);
+        s.r = bs.w * sqrtf(gmax(dx, gmax(dy, dz)));
+
+        if (visible) visible = plane_test(ci, s);                                        // :137-144
+        if (ci.occlusion_pass == 2 && visible) visible = occlusion_test(ci, s, p.pyr);  // :147-191
+
+        bool should_draw = visible;
+        if (ci.occlusion_pass == 2) should_draw = visible && (!visible_in_buffer || meshlet_occ); // :198-200
+
+        if (should_draw) { // :203-209
+            const float ex = ci.lod_target_pos_view_space[0] - s.x;
+            const float ey = ci.lod_target_pos_view_space[1] - s.y;
+            const float ez = ci.lod_target_pos_view_space[2] - s.z;
+            const float lod_distance = sqrtf(dot3(ex, ey, ez, ex, ey, ez)) - s.r;
+            const float lod_f = log2c(gmax(lod_distance, 0.0f) / ci.lod_base) / log2c(ci.lod_step);
+            uint32_t lod = f2u_sat(gmax(lod_f + 1.0f, 0.0f));
+            lod = min(max(lod, ci.min_mesh_lod), ci.max_mesh_lod);
+            lod = min(lod, mi->lod_count - 1u);
+            lod = min(lod, (uint32_t)ORBIT_MAX_MESH_LODS - 1u);
+            const OrbitMeshLod ml = mi->mesh_lods[lod];
+            pr.entity_index = ed.entity_index;
+            pr.meshlet_offset = ml.meshlet_offset;
+            pr.meshlet_count = ml.meshlet_count;
+            pr.visibility_offset = ed.visibility_offset;
+        }
+    }
+
+    // entity visibility bitset, pass 2 only (:226-243): word = g/32, bit = g%32.
+    if (ci.occlusion_pass == 2) {
+        const uint64_t b = __ballot(active && visible);
+        const uint32_t lane = threadIdx.x & 63;
+        const uint32_t wave_g = g - lane;
+        if (lane == 0 && wave_g < end) p.visibility[wave_g / 32] = (uint32_t)b;
+        if (lane == 32 && wave_g + 32 < end) p.visibility[wave_g / 32 + 1] = (uint32_t)(b >> 32);
+    }
+
+    p.proto[local] = pr;
+    const uint32_t n = (pr.meshlet_count + ORBIT_MESHLET_DISPATCH_SIZE - 1u) / ORBIT_MESHLET_DISPATCH_SIZE; // :210
+    uint32_t total;
+    (void)block_exclusive_scan<kBlock / 64>(n, smem, &total);
+    if (threadIdx.x == 0) p.block_sums[blockIdx.x] = total;
+}
+
+// Expands proto-records into ceil(m/S) MeshletDispatch records each, at the
+// scanned offsets (:211-223).  Block 0 also writes the {x,1,1} header.
+__global__ __launch_bounds__(kBlock) void entity_cull_emit(const EntityCullParams p) {
+    __shared__ uint32_t smem[kBlock / 64 + 1];
+    const uint32_t local = blockIdx.x * kBlock + threadIdx.x;
+    const OrbitMeshletDispatch pr = p.proto[local];
+    const uint32_t S = ORBIT_MESHLET_DISPATCH_SIZE;
+    const uint32_t n = (pr.meshlet_count + S - 1u) / S;
+    uint32_t block_total;
+    const uint32_t offset = p.block_base[blockIdx.x] + block_exclusive_scan<kBlock / 64>(n, smem, &block_total);
+    OrbitMeshletDispatch *out = reinterpret_cast<OrbitMeshletDispatch *>(p.dispatch_buffer + ORBIT_DISPATCH_HEADER);
+    uint32_t vis_off = pr.visibility_offset;
+    for (uint32_t j = 0; j < n; j++) {
+        OrbitMeshletDispatch r;
+        r.entity_index = pr.entity_index;
+        r.meshlet_offset = pr.meshlet_offset + S * j;
+        r.meshlet_count = min(pr.meshlet_count - S * j, S);
+        r.visibility_offset = vis_off;
+        if (offset + j < p.dispatch_capacity) out[offset + j] = r;
+        vis_off += r.meshlet_count / S; // :222
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t total = *p.total;
+        uint32_t *hdr = reinterpret_cast<uint32_t *>(p.dispatch_buffer);
+        hdr[0] = min(total, p.dispatch_capacity);
+        hdr[1] = 1u;
+        hdr[2] = 1u;
+        if (total > p.dispatch_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+    }
+}
+
+__global__ void write_dispatch_header(uint32_t *hdr, uint32_t x) {
+    hdr[0] = x;
+    hdr[1] = 1u;
+    hdr[2] = 1u;
+}
+
+// Single-block exclusive scan with carry over chunks of 1024.
+__global__ __launch_bounds__(1024) void scan_exclusive_kernel(const uint32_t *in, uint32_t *out, uint32_t n,
+                                                              const uint32_t *n_src, uint32_t div, uint32_t *total) {
+    __shared__ uint32_t smem[1024 / 64 + 1];
+    if (n_src) n = min((*n_src + div - 1u) / div, n);
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? in[i] : 0u;
+        uint32_t chunk_total;
+        const uint32_t ex = block_exclusive_scan<16>(v, smem, &chunk_total);
+        if (i < n) out[i] = carry + ex;
+        carry += chunk_total;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+} // namespace
+
+hipError_t launch_scan_exclusive(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, hipStream_t s) {
+    hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, s, in, out, n, (const uint32_t *)nullptr, 1u,
+                       total);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_exclusive_indirect(const uint32_t *in, uint32_t *out, const uint32_t *n_src, uint32_t div,
+                                          uint32_t n_max, uint32_t *total, hipStream_t s) {
+    hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, s, in, out, n_max, n_src, div, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_count, hipStream_t s) {
+    const uint32_t blocks = (entity_draw_count + kBlock - 1) / kBlock;
+    if (blocks == 0) {
+        // nothing to test: the pre-clear {0,1,1} is the whole effect (draw_gen.rs:361-362)
+        hipLaunchKernelGGL(write_dispatch_header, dim3(1), dim3(1), 0, s,
+                           reinterpret_cast<uint32_t *>(p.dispatch_buffer), 0u);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(entity_cull_eval, dim3(blocks), dim3(kBlock), 0, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = launch_scan_exclusive(p.block_sums, p.block_base, blocks, p.total, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(entity_cull_emit, dim3(blocks), dim3(kBlock), 0, s, p);
+    return hipGetLastError();
+}
+
+} // namespace orbit

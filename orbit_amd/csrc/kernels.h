@@ -1,0 +1,112 @@
+// kernels.h — host-callable launchers of the gfx950 kernels (internal to the
+// library; the public surface is include/orbit_abi.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/orbit_abi.h"
+#include "orbit_device.h"
+
+namespace orbit {
+
+// Meshlet-cull wave tile: 16 dispatch records (= 8 rows of 2 records on the
+// 64 lanes of a wave, one meshlet per lane per row) = 512 meshlets.
+constexpr uint32_t kTileRecords = 16;
+constexpr uint32_t kTileRows = 8;
+
+struct EntityCullParams {
+    OrbitGpuCullInfo ci;
+    const uint8_t *entity_draw_buffer;
+    const OrbitMeshInfo *mesh_infos;
+    uint8_t *dispatch_buffer;
+    const OrbitEntityData *entities;
+    uint32_t *visibility;
+    PyramidView pyr;
+    uint32_t draw_first;      // first entity-draw of this launch (multiple of 32)
+    uint32_t draw_limit;      // draw_first + 256 * ceil(entity_draw_count / 256)
+    uint32_t dispatch_capacity;
+    // context scratch
+    OrbitMeshletDispatch *proto; // one proto-record per entity-draw of the launch
+    uint32_t *block_sums;
+    uint32_t *block_base;
+    uint32_t *total;
+    int32_t *status;
+};
+
+struct MeshletCullParams {
+    OrbitGpuCullInfo ci;
+    const uint8_t *dispatch_buffer;
+    const OrbitMeshlet *meshlets;
+    uint8_t *draw_buffer;
+    const OrbitEntityData *entities;
+    const OrbitMaterialData *materials;
+    uint32_t *meshlet_visibility;
+    PyramidView pyr;
+    uint32_t dispatch_capacity;
+    uint32_t draw_capacity;
+    // context scratch
+    uint32_t *tile_counts;
+    uint32_t *tile_base;
+    uint32_t *total;
+    uint64_t *scan_state; // single-pass mode: one {status,value} granule per wave tile
+    uint32_t *ticket;     // single-pass mode: {ticket, done, epoch}
+    int32_t *status;
+};
+
+struct DepthReduceParams {
+    const float *depth;
+    float *pyramid;
+    uint32_t screen_w, screen_h;
+    uint32_t w0, h0, mips;
+    uint32_t mip_offset[ORBIT_MAX_PYRAMID_MIPS];
+};
+
+struct ClusterMarkParams {
+    OrbitMarkActivePush pc;
+    const float *depth;
+    uint32_t *masks;
+    OrbitClusterDepthBounds *bounds;
+};
+
+struct ClusterCompactParams {
+    uint32_t cc[3];
+    const uint32_t *masks;
+    uint8_t *unique;
+    uint32_t index_capacity;
+    uint32_t *chunk_counts; // cz * nchunks
+    int32_t *status;
+};
+
+struct ClusterAssignParams {
+    OrbitClusterCullInfo info;
+    const uint8_t *unique;
+    const OrbitClusterDepthBounds *bounds;
+    const OrbitLightData *lights;
+    uint8_t *light_index_buffer;
+    uint32_t light_index_capacity;
+    uint32_t *offset_image;
+    uint32_t max_clusters;
+    // context scratch
+    float4 *view_lights;     // (x, y, z, r*r) per light in view space
+    uint32_t *light_flags;   // bit i set = light i is a point light
+    uint32_t *counts;        // per active cluster
+    uint32_t *block_sums;
+    uint32_t *block_base;
+    uint32_t *total;
+    int32_t *status;
+};
+
+hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_count, hipStream_t s);
+hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, int mode, hipStream_t s);
+hipError_t launch_depth_reduce(const DepthReduceParams &p, hipStream_t s);
+hipError_t launch_cluster_mark(const ClusterMarkParams &p, hipStream_t s);
+hipError_t launch_cluster_compact(const ClusterCompactParams &p, hipStream_t s);
+hipError_t launch_cluster_assign(const ClusterAssignParams &p, hipStream_t s);
+
+// Exclusive scan of `n` words by one 1024-thread block; *total = sum.
+hipError_t launch_scan_exclusive(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, hipStream_t s);
+// Same, with n read on the device: n = min(ceil(*n_src / div), n_max).
+hipError_t launch_scan_exclusive_indirect(const uint32_t *in, uint32_t *out, const uint32_t *n_src, uint32_t div,
+                                          uint32_t n_max, uint32_t *total, hipStream_t s);
+
+} // namespace orbit

@@ -1,0 +1,338 @@
+// light_cluster.hip — clustered light binning for gfx950: mark active clusters,
+// ordered compaction, light assignment.
+//
+// Restates shaders/light_cluster/{mark_active,active_cluster_compaction,
+// light_culling}.comp + cluster_common.glsl (reference repo) under the host
+// protocol of src/passes/cluster.rs:368-591.  MI355X-first structure:
+//   mark    : one WAVE owns one screen tile, so the per-tile slice mask and the
+//             per-cluster depth bounds are wave reductions written once — the
+//             reference issues 3 global atomics per pixel (mark_active.comp:33-55)
+//             into zero-filled buffers; here every word is written exactly once,
+//             which also subsumes the zero-fill (cluster.rs:439-456).
+//   compact : prefix-sum append in ascending linear cluster index (canonical
+//             order), header written last (active_cluster_compaction.comp:33-43).
+//   assign  : lights are transformed to view space ONCE (the reference redoes
+//             world_to_view x position per cluster per light,
+//             light_culling.comp:111) and staged through LDS in tiles; ranges
+//             are allocated by prefix sum in compacted-list order.
+#include "kernels.h"
+#include "scan.h"
+
+namespace orbit {
+
+namespace {
+
+__device__ __forceinline__ uint32_t wave_reduce_or(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v |= __shfl_xor(v, d, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------- mark_active
+// mark_active.comp:27-57.  Lane L (< cz) accumulates the bounds of slice L.
+__global__ __launch_bounds__(256) void cluster_mark_kernel(const ClusterMarkParams p) {
+    const OrbitMarkActivePush &pc = p.pc;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t cx = pc.cluster_count[0], cy = pc.cluster_count[1], cz = pc.cluster_count[2];
+    const uint32_t tile = blockIdx.x * 4 + wave;
+    if (tile >= cx * cy) return; // wave-uniform
+    const uint32_t tx = tile % cx, ty = tile / cx;
+    const uint32_t ts = pc.tile_size_px, sc = pc.depth_buffer_sample_count;
+    const uint32_t W = pc.screen_size[0], H = pc.screen_size[1];
+    uint32_t acc_min = 0, acc_max = 0, tile_mask = 0;
+    const uint32_t items = ts * ts * sc;
+    for (uint32_t base = 0; base < items; base += 64) {
+        const uint32_t it = base + lane;
+        const uint32_t pix = it / sc, smp = it % sc;
+        const uint32_t px = tx * ts + pix % ts, py = ty * ts + pix / ts;
+        const bool valid = it < items && px < W && py < H; // mark_active.comp:40
+        uint32_t slice = 0xFFFFFFFFu, bmin = 0, bmax = 0, bit = 0;
+        if (valid) {
+            const float d = p.depth[((size_t)py * W + px) * sc + smp];
+            const float linear_z = pc.z_near / d;                       // :28
+            slice = f2u_sat(log2c(linear_z) * pc.z_scale + pc.z_bias); // cluster_common.glsl:18-20
+            bit = shl1(slice);                                          // :30
+            bmin = __float_as_uint(1.0f - d);                           // :33
+            bmax = __float_as_uint(d);                                  // :34
+        }
+        const uint32_t chunk_mask = wave_reduce_or(bit);
+        tile_mask |= chunk_mask;
+        uint32_t todo = chunk_mask;
+        if (cz < 32u) todo &= (1u << cz) - 1u; // :31 slice < cluster_count.z
+        while (todo) {
+            const uint32_t s = (uint32_t)__builtin_ctz(todo);
+            todo &= todo - 1u;
+            const bool mine = valid && slice == s;
+            const uint32_t m1 = wave_reduce_max(mine ? bmin : 0u);
+            const uint32_t m2 = wave_reduce_max(mine ? bmax : 0u);
+            if ((uint32_t)lane == s) {
+                acc_min = max(acc_min, m1);
+                acc_max = max(acc_max, m2);
+            }
+        }
+    }
+    if ((uint32_t)lane < cz) {
+        OrbitClusterDepthBounds b;
+        b.min_depth = acc_min;
+        b.max_depth = acc_max;
+        p.bounds[tile + (size_t)lane * cx * cy] = b;
+    }
+    if (lane == 0) p.masks[tile] = tile_mask;
+}
+
+// -------------------------------------------------- active_cluster_compaction
+// One 1024-thread block per (chunk of 1024 tiles, z slice).
+template <bool EMIT>
+__global__ __launch_bounds__(1024) void cluster_compact_kernel(const ClusterCompactParams p, const uint32_t *chunk_base,
+                                                               const uint32_t *total) {
+    __shared__ uint32_t smem[1024 / 64 + 1];
+    const uint32_t tiles = p.cc[0] * p.cc[1];
+    const uint32_t z = blockIdx.y, chunk = blockIdx.x;
+    const uint32_t i = chunk * 1024 + threadIdx.x;
+    const uint32_t active = (i < tiles && (p.masks[i] & shl1(z))) ? 1u : 0u; // cluster_common.glsl:31-34
+    uint32_t block_total;
+    const uint32_t ex = block_exclusive_scan<16>(active, smem, &block_total);
+    const uint32_t slot_index = z * gridDim.x + chunk;
+    if (!EMIT) {
+        if (threadIdx.x == 0) p.chunk_counts[slot_index] = block_total;
+    } else {
+        uint32_t *idx = reinterpret_cast<uint32_t *>(p.unique + ORBIT_COMPACT_HEADER);
+        const uint32_t pos = chunk_base[slot_index] + ex;
+        if (active && pos < p.index_capacity) idx[pos] = i + z * tiles; // cluster_common.glsl:1-4
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            const uint32_t n = min(*total, p.index_capacity);
+            uint32_t *hdr = reinterpret_cast<uint32_t *>(p.unique);
+            hdr[0] = (n + 255u) / 256u; // active_cluster_compaction.comp:38-41
+            hdr[1] = 1u;
+            hdr[2] = 1u;
+            hdr[3] = n;
+            if (*total > p.index_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+        }
+    }
+}
+
+// -------------------------------------------------------------- light_culling
+__global__ __launch_bounds__(256) void light_prepare_kernel(const ClusterAssignParams p) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t n = p.info.global_light_count;
+    bool point = false;
+    if (i < n) {
+        const OrbitLightData &l = p.lights[i];
+        point = l.light_type == ORBIT_LIGHT_TYPE_POINT;
+        const float *m = p.info.world_to_view_matrix;
+        const float x = l.position[0], y = l.position[1], z = l.position[2];
+        float4 v;
+        v.x = ((m[0] * x + m[4] * y) + m[8] * z) + m[12] * 1.0f; // light_culling.comp:111
+        v.y = ((m[1] * x + m[5] * y) + m[9] * z) + m[13] * 1.0f;
+        v.z = ((m[2] * x + m[6] * y) + m[10] * z) + m[14] * 1.0f;
+        v.w = l.outer_radius * l.outer_radius;                     // sphere.w * sphere.w, :103
+        p.view_lights[i] = v;
+    }
+    const uint64_t b = __ballot(point);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_i = i - lane;
+    if (lane == 0 && wave_i < n) p.light_flags[wave_i / 32] = (uint32_t)b;
+    if (lane == 32 && wave_i + 32 < n) p.light_flags[wave_i / 32 + 1] = (uint32_t)(b >> 32);
+}
+
+struct Aabb3 {
+    float mn[3], mx[3];
+};
+
+// screen_to_view, light_culling.comp:34-48
+__device__ __forceinline__ void screen_to_view(const OrbitClusterCullInfo &in, float sx, float sy, float out[3]) {
+    const float tx = sx / (float)in.screen_size[0], ty = sy / (float)in.screen_size[1];
+    const float c0 = tx * 2.0f - 1.0f, c1 = (1.0f - ty) * 2.0f - 1.0f, c2 = 1.0f, c3 = 1.0f;
+    const float *m = in.screen_to_view_matrix;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = ((m[0 + r] * c0 + m[4 + r] * c1) + m[8 + r] * c2) + m[12 + r] * c3;
+    out[0] = v[0] / v[3];
+    out[1] = v[1] / v[3];
+    out[2] = v[2] / v[3];
+}
+
+// line_intersection_to_z_plane with a = eye = 0, light_culling.comp:50-60
+__device__ __forceinline__ void line_z(const float b[3], float zd, float out[3]) {
+    const float ab0 = b[0] - 0.0f, ab1 = b[1] - 0.0f, ab2 = b[2] - 0.0f;
+    const float dna = (0.0f * 0.0f + 0.0f * 0.0f) + -1.0f * 0.0f;
+    const float dnab = (0.0f * ab0 + 0.0f * ab1) + -1.0f * ab2;
+    const float t = (zd - dna) / dnab;
+    out[0] = 0.0f + t * ab0;
+    out[1] = 0.0f + t * ab1;
+    out[2] = 0.0f + t * ab2;
+}
+
+// compute_cluster_volume, light_culling.comp:62-90
+__device__ __forceinline__ Aabb3 cluster_aabb(const ClusterAssignParams &p, uint32_t cluster_index) {
+    const OrbitClusterCullInfo &in = p.info;
+    const uint32_t cx = in.cluster_count[0], cy = in.cluster_count[1];
+    uint32_t idx = cluster_index;
+    const uint32_t z = idx / (cx * cy);
+    idx -= z * cx * cy;
+    const uint32_t y = idx / cx;
+    idx -= y * cx;
+    const uint32_t x = idx;
+    const float minx = (float)(x * in.tile_size_px), miny = (float)(y * in.tile_size_px);
+    const float maxx = gmin(minx + (float)in.tile_size_px, (float)in.screen_size[0]);
+    const float maxy = gmin(miny + (float)in.tile_size_px, (float)in.screen_size[1]);
+    float minv[3], maxv[3];
+    screen_to_view(in, minx, miny, minv);
+    screen_to_view(in, maxx, maxy, maxv);
+    const OrbitClusterDepthBounds db = p.bounds[cluster_index];
+    const float min_depth = 1.0f - __uint_as_float(db.min_depth); // :72
+    const float max_depth = __uint_as_float(db.max_depth);        // :73
+    const float cnear = in.z_near / max_depth, cfar = in.z_near / min_depth;
+    float q[4][3];
+    line_z(minv, cnear, q[0]);
+    line_z(minv, cfar, q[1]);
+    line_z(maxv, cnear, q[2]);
+    line_z(maxv, cfar, q[3]);
+    Aabb3 a;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        a.mn[i] = gmin(gmin(q[0][i], q[1][i]), gmin(q[2][i], q[3][i]));
+        a.mx[i] = gmax(gmax(q[0][i], q[1][i]), gmax(q[2][i], q[3][i]));
+    }
+    return a;
+}
+
+// aabb_sphere_test, light_culling.comp:92-104 (l.w already holds r*r)
+__device__ __forceinline__ bool sphere_hits(const Aabb3 &a, const float4 l) {
+    float sq = 0.0f;
+    if (l.x < a.mn[0]) sq += (a.mn[0] - l.x) * (a.mn[0] - l.x);
+    if (l.x > a.mx[0]) sq += (l.x - a.mx[0]) * (l.x - a.mx[0]);
+    if (l.y < a.mn[1]) sq += (a.mn[1] - l.y) * (a.mn[1] - l.y);
+    if (l.y > a.mx[1]) sq += (l.y - a.mx[1]) * (l.y - a.mx[1]);
+    if (l.z < a.mn[2]) sq += (a.mn[2] - l.z) * (a.mn[2] - l.z);
+    if (l.z > a.mx[2]) sq += (l.z - a.mx[2]) * (l.z - a.mx[2]);
+    return sq <= l.w;
+}
+
+constexpr uint32_t kLightTile = 1024;
+
+// One thread per active cluster; lights staged through LDS in tiles.
+// WRITE = false: count pass (:128-135); WRITE = true: index pass (:138-150).
+template <bool WRITE>
+__global__ __launch_bounds__(256) void cluster_assign_kernel(const ClusterAssignParams p) {
+    __shared__ float4 s_light[kLightTile];
+    __shared__ uint32_t s_flags[kLightTile / 32];
+    __shared__ uint32_t smem[256 / 64 + 1];
+    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.unique);
+    const uint32_t n = min(hdr[3], p.max_clusters);
+    if (blockIdx.x * 256u >= n) { // block-uniform: nothing here (grid is a capacity bound)
+        if (!WRITE && threadIdx.x == 0) p.block_sums[blockIdx.x] = 0u;
+        return;
+    }
+    const uint32_t u = blockIdx.x * 256 + threadIdx.x;
+    const bool active = u < n; // :123
+    uint32_t ci = 0;
+    Aabb3 box = {};
+    if (active) {
+        ci = reinterpret_cast<const uint32_t *>(p.unique + ORBIT_COMPACT_HEADER)[u];
+        box = cluster_aabb(p, ci);
+    }
+    const uint32_t nl = p.info.global_light_count;
+    uint32_t count = 0, limit = 0, offset = 0;
+    uint32_t *out = reinterpret_cast<uint32_t *>(p.light_index_buffer + ORBIT_LIGHT_INDEX_HEADER);
+    if (WRITE) {
+        uint32_t block_total;
+        const uint32_t c = active ? p.counts[u] : 0u;
+        offset = p.block_base[blockIdx.x] + block_exclusive_scan<4>(c, smem, &block_total);
+        limit = c;
+    }
+    for (uint32_t base = 0; base < nl; base += kLightTile) {
+        const uint32_t tile_n = min(kLightTile, nl - base);
+        for (uint32_t i = threadIdx.x; i < tile_n; i += 256) s_light[i] = p.view_lights[base + i];
+        if (threadIdx.x < (tile_n + 31) / 32) s_flags[threadIdx.x] = p.light_flags[base / 32 + threadIdx.x];
+        __syncthreads();
+        if (active) {
+            for (uint32_t i = 0; i < tile_n; i++) {
+                const bool point = (s_flags[i >> 5] >> (i & 31)) & 1u;
+                const bool hit = !point || sphere_hits(box, s_light[i]); // :108-119
+                if (hit) {
+                    if (WRITE) {
+                        if (count < limit) { // while (light_counter < light_count), :140
+                            if (offset + count < p.light_index_capacity) out[offset + count] = base + i;
+                        }
+                    }
+                    count++;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!WRITE) {
+        const uint32_t c = min(count, ORBIT_MAX_LIGHTS_PER_CLUSTER); // :135
+        if (active) p.counts[u] = c;
+        uint32_t block_total;
+        (void)block_exclusive_scan<4>(active ? c : 0u, smem, &block_total);
+        if (threadIdx.x == 0) p.block_sums[blockIdx.x] = block_total;
+    } else {
+        if (active) { // imageStore(cluster_offset_image, cluster_id, (offset, count)), :149-150
+            p.offset_image[2 * (size_t)ci + 0] = offset;
+            p.offset_image[2 * (size_t)ci + 1] = limit;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const uint32_t total = *p.total;
+            *reinterpret_cast<uint32_t *>(p.light_index_buffer) = total; // atomicAdd total, :136
+            if (total > p.light_index_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+        }
+    }
+}
+
+// header for an empty active list: light_count = 0 (cluster.rs:575-581)
+__global__ void write_word(uint32_t *p, uint32_t v) { *p = v; }
+
+} // namespace
+
+hipError_t launch_cluster_mark(const ClusterMarkParams &p, hipStream_t s) {
+    const uint32_t tiles = p.pc.cluster_count[0] * p.pc.cluster_count[1];
+    if (tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(cluster_mark_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_cluster_compact(const ClusterCompactParams &p, hipStream_t s) {
+    const uint32_t tiles = p.cc[0] * p.cc[1];
+    const uint32_t nchunks = (tiles + 1023) / 1024;
+    const uint32_t cz = p.cc[2];
+    uint32_t *chunk_base = p.chunk_counts + (size_t)cz * nchunks;
+    uint32_t *total = chunk_base + (size_t)cz * nchunks;
+    if (nchunks == 0 || cz == 0) {
+        hipLaunchKernelGGL(write_word, dim3(1), dim3(1), 0, s, reinterpret_cast<uint32_t *>(p.unique) + 3, 0u);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(cluster_compact_kernel<false>, dim3(nchunks, cz), dim3(1024), 0, s, p,
+                       (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = launch_scan_exclusive(p.chunk_counts, chunk_base, cz * nchunks, total, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cluster_compact_kernel<true>, dim3(nchunks, cz), dim3(1024), 0, s, p,
+                       (const uint32_t *)chunk_base, (const uint32_t *)total);
+    return hipGetLastError();
+}
+
+hipError_t launch_cluster_assign(const ClusterAssignParams &p, hipStream_t s) {
+    const uint32_t nl = p.info.global_light_count;
+    if (nl > 0) {
+        hipLaunchKernelGGL(light_prepare_kernel, dim3((nl + 255) / 256), dim3(256), 0, s, p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t blocks = (p.max_clusters + 255) / 256;
+    if (blocks == 0) {
+        hipLaunchKernelGGL(write_word, dim3(1), dim3(1), 0, s, reinterpret_cast<uint32_t *>(p.light_index_buffer), 0u);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(cluster_assign_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = launch_scan_exclusive(p.block_sums, p.block_base, blocks, p.total, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cluster_assign_kernel<true>, dim3(blocks), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+} // namespace orbit

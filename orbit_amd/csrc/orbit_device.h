@@ -1,0 +1,206 @@
+// orbit_device.h — device-side scalar semantics shared by all gfx950 kernels.
+//
+// Everything that decides a visibility bit is written here once, in the
+// canonical arithmetic of DESIGN.md §"Canonical arithmetic": IEEE binary32,
+// round-to-nearest, NO contraction (the translation units are built with
+// -ffp-contract=off), fixed left-to-right association, GLSL min/max/clamp
+// semantics, correctly rounded '/' and sqrtf (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt), software log2.
+//
+// Reference arithmetic restated: shaders/entity_cull.comp:28-102,
+// shaders/meshlet_cull.comp:28-106 (paths relative to the reference repo).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/orbit_abi.h"
+
+#define ORBIT_WAVE 64
+
+namespace orbit {
+
+// GLSL: max(x,y) = y if x < y else x ; min(x,y) = y if y < x else x.
+__device__ __forceinline__ float gmax(float x, float y) { return (x < y) ? y : x; }
+__device__ __forceinline__ float gmin(float x, float y) { return (y < x) ? y : x; }
+__device__ __forceinline__ float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
+
+// uint(float): saturating, NaN -> 0.
+__device__ __forceinline__ uint32_t f2u_sat(float f) {
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+}
+// float texel index -> int in [0, hi]; NaN -> 0.
+__device__ __forceinline__ int f2i_clamp(float f, int hi) {
+    if (!(f >= 0.0f)) return 0;
+    if (f > (float)hi) return hi;
+    return (int)f;
+}
+// 1u << s, 0 for s >= 32 (gfx950 would wrap the shift count: mask explicitly).
+__device__ __forceinline__ uint32_t shl1(uint32_t s) { return s < 32u ? (1u << s) : 0u; }
+
+__device__ __forceinline__ float dot2(float ax, float ay, float bx, float by) { return ax * bx + ay * by; }
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return (ax * bx + ay * by) + az * bz;
+}
+
+// Canonical software log2: same specification as oracle/orbit_oracle.c
+// orbit_log2f (exponent + degree-9 Horner polynomial, mul/add only).
+__device__ __forceinline__ float log2c(float x) {
+    uint32_t b = __float_as_uint(x);
+    if ((b & 0x7FFFFFFFu) > 0x7F800000u) return x;
+    if ((b & 0x7FFFFFFFu) == 0u) return -__builtin_inff();
+    if (b & 0x80000000u) return __uint_as_float(0x7FC00000u);
+    if (b == 0x7F800000u) return x;
+    int e = 0;
+    if (b < 0x00800000u) {
+        x = x * 16777216.0f;
+        b = __float_as_uint(x);
+        e = -24;
+    }
+    e += (int)(b >> 23) - 127;
+    float m = __uint_as_float((b & 0x007FFFFFu) | 0x3F800000u);
+    if (m > 1.41421354f) {
+        m = m * 0.5f;
+        e += 1;
+    }
+    const float f = m - 1.0f;
+    float p = -0x1.cebep-4f;
+    p = p * f; p = p + 0x1.80ab18p-3f;
+    p = p * f; p = p + -0x1.865ffcp-3f;
+    p = p * f; p = p + 0x1.a265fcp-3f;
+    p = p * f; p = p + -0x1.eac694p-3f;
+    p = p * f; p = p + 0x1.2782e6p-2f;
+    p = p * f; p = p + -0x1.715a68p-2f;
+    p = p * f; p = p + 0x1.ec708p-2f;
+    p = p * f; p = p + -0x1.71547p-1f;
+    p = p * f; p = p + 0x1.715476p+0f;
+    const float r = p * f;
+    return r + (float)e;
+}
+
+// int8 / 127.0 correctly rounded without the IEEE-division expansion: one
+// Newton step on the reciprocal estimate with explicit fused ops.  q0 = i*r is
+// within 1 ulp of i/127; rem = i - q0*127 is exact in an fma; q1 = q0 + rem*r
+// is the correctly rounded quotient (Markstein).  Verified exhaustively for all
+// 256 inputs against the oracle's '/' in tests/test_gpu_parity.py.
+__device__ __forceinline__ float snorm8_div127(int i) {
+    const float fi = (float)i;
+    const float r = 0x1.020408p-7f; // fl(1/127)
+    const float q0 = fi * r;
+    const float rem = __builtin_fmaf(-q0, 127.0f, fi);
+    return __builtin_fmaf(rem, r, q0);
+}
+
+// Pyramid geometry handed to the kernels by value (host-computed).
+struct PyramidView {
+    const float *texels;
+    uint32_t w0, h0, mips;
+};
+
+// 2x2 clamped footprint minimum of one w x h level (ReduceMin sampler model,
+// src/graphics/device.rs:1404-1420).
+__device__ __forceinline__ float footprint_min(const float *img, uint32_t w, uint32_t h, float u, float v) {
+    const float x = u * (float)w - 0.5f;
+    const float y = v * (float)h - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const int x0 = f2i_clamp(fx, (int)w - 1), x1 = f2i_clamp(fx + 1.0f, (int)w - 1);
+    const int y0 = f2i_clamp(fy, (int)h - 1), y1 = f2i_clamp(fy + 1.0f, (int)h - 1);
+    const float a = img[(size_t)y0 * w + x0], b = img[(size_t)y0 * w + x1];
+    const float c = img[(size_t)y1 * w + x0], d = img[(size_t)y1 * w + x1];
+    return gmin(gmin(a, b), gmin(c, d));
+}
+
+// textureLod(pyramid, ReduceMin, uv, lod), NEAREST mip mode:
+// level = clamp(ceil(lod + 0.5) - 1, 0, mips - 1).
+__device__ __forceinline__ float hiz_sample(const PyramidView &p, float u, float v, float lod) {
+    const float lf = ceilf(lod + 0.5f) - 1.0f;
+    const int level = f2i_clamp(lf, (int)p.mips - 1);
+    // texel offset of `level` in the packed mip chain (level k is
+    // max(dim >> k, 1), src/graphics/image.rs:533); summed here instead of
+    // indexed from a kernarg table, which would need a per-lane waterfall.
+    uint32_t off = 0;
+    for (int k = 0; k < level; k++) off += max(p.w0 >> k, 1u) * max(p.h0 >> k, 1u);
+    const uint32_t w = max(p.w0 >> level, 1u), h = max(p.h0 >> level, 1u);
+    return footprint_min(p.texels + off, w, h, u, v);
+}
+
+struct Sphere {
+    float x, y, z, r;
+};
+
+// project_sphere, entity_cull.comp:83-102 / meshlet_cull.comp:83-102.
+__device__ __forceinline__ void project_sphere(const Sphere &s, float p00, float p11, float aabb[4]) {
+    const float r = s.r;
+    const float cxx = -s.x, cxy = -s.z;
+    const float vxx = sqrtf(dot2(cxx, cxy, cxx, cxy) - r * r), vxy = r;
+    const float minx_x = vxx * cxx + (-vxy) * cxy, minx_y = vxy * cxx + vxx * cxy;
+    const float maxx_x = vxx * cxx + vxy * cxy, maxx_y = (-vxy) * cxx + vxx * cxy;
+    const float cyx = -s.y, cyy = -s.z;
+    const float vyx = sqrtf(dot2(cyx, cyy, cyx, cyy) - r * r), vyy = r;
+    const float miny_x = vyx * cyx + (-vyy) * cyy, miny_y = vyy * cyx + vyx * cyy;
+    const float maxy_x = vyx * cyx + vyy * cyy, maxy_y = (-vyy) * cyx + vyx * cyy;
+    const float a0 = minx_x / minx_y * p00, a1 = miny_x / miny_y * p11;
+    const float a2 = maxx_x / maxx_y * p00, a3 = maxy_x / maxy_y * p11;
+    aabb[0] = a0 * 0.5f + 0.5f;
+    aabb[1] = a3 * -0.5f + 0.5f;
+    aabb[2] = a2 * 0.5f + 0.5f;
+    aabb[3] = a1 * -0.5f + 0.5f;
+}
+
+// Pass-2 HiZ test, entity_cull.comp:146-191 == meshlet_cull.comp:160-205.
+// Flips s.z in the perspective branch; the flip persists for the caller.
+__device__ __forceinline__ bool occlusion_test(const OrbitGpuCullInfo &ci, Sphere &s, const PyramidView &pyr) {
+    bool cullable = true;
+    float aabb[4], closest;
+    if (ci.projection_type == 0) {
+        s.z = -s.z;
+        cullable = s.z >= s.r + ci.z_near;
+        project_sphere(s, ci.p00_or_width_recipx2, ci.p11_or_height_recipx2, aabb);
+        closest = ci.z_near / (s.z - s.r);
+    } else {
+        const float sr = ci.p00_or_width_recipx2;
+        const float cx = s.x * sr, cy = s.y * sr;
+        const float bs = sr * s.r;
+        const float b0 = cx + bs * -1.0f, b1 = cy + bs * -1.0f, b2 = cx + bs * 1.0f, b3 = cy + bs * 1.0f;
+        aabb[0] = gclamp(b0, -1.0f, 1.0f) * 0.5f + 0.5f;
+        aabb[1] = gclamp(b1, -1.0f, 1.0f) * -0.5f + 0.5f;
+        aabb[2] = gclamp(b2, -1.0f, 1.0f) * 0.5f + 0.5f;
+        aabb[3] = gclamp(b3, -1.0f, 1.0f) * -0.5f + 0.5f;
+        const float closest_z = s.z + s.r;
+        const float r = 1.0f / (ci.z_far - ci.z_near);
+        closest = closest_z * r + (r * ci.z_far);
+    }
+    if (!cullable) return true;
+    const float width = (aabb[2] - aabb[0]) * (float)pyr.w0;
+    const float height = (aabb[3] - aabb[1]) * (float)pyr.h0;
+    const float u = (aabb[0] + aabb[2]) * 0.5f, v = (aabb[1] + aabb[3]) * 0.5f;
+    const float sampled = hiz_sample(pyr, u, v, log2c(gmax(width, height)));
+    return closest >= sampled;
+}
+
+// Plane loop, entity_cull.comp:137-144 == meshlet_cull.comp:139-146.  The
+// CullInfo lives in the kernarg segment, so plane loads are scalar loads.
+__device__ __forceinline__ bool plane_test(const OrbitGpuCullInfo &ci, const Sphere &s) {
+    bool visible = true;
+    const uint32_t n = ci.cull_plane_count;
+    for (uint32_t i = 0; i < n; i++) {
+        const float d = dot3(ci.cull_planes[i][0], ci.cull_planes[i][1], ci.cull_planes[i][2], s.x, s.y, s.z) +
+                        ci.cull_planes[i][3];
+        visible = visible && (d > -s.r);
+    }
+    return visible;
+}
+
+// One column of (A * B): A column-major in registers/SGPRs, b = column of B.
+__device__ __forceinline__ void mat4_mul_col(const float *a, float b0, float b1, float b2, float b3, float out[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) out[r] = ((a[0 + r] * b0 + a[4 + r] * b1) + a[8 + r] * b2) + a[12 + r] * b3;
+}
+
+// Latched device status word (orbit_ctx_status): first error wins.
+__device__ __forceinline__ void latch_status(int32_t *status, int32_t code) {
+    atomicCAS((int *)status, 0, code);
+}
+
+} // namespace orbit

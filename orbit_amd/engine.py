@@ -1,0 +1,145 @@
+"""Thin object wrapper over the C ABI for callers that hold torch tensors.
+
+torch is plumbing here (device memory + streams); every method forwards raw
+device pointers to ``liborbit_cull.so`` and enqueues on the current HIP stream.
+Argument order follows the push-constant order of the reference shaders, as in
+``include/orbit_abi.h``.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, layouts
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(stream):
+    import torch
+
+    s = torch.cuda.current_stream() if stream is None else stream
+    return C.c_void_p(s.cuda_stream)
+
+
+def _host_bytes(x, nbytes):
+    a = np.ascontiguousarray(x).view(np.uint8).reshape(-1)
+    if a.nbytes != nbytes:
+        raise ValueError(f"expected a {nbytes}-byte host block, got {a.nbytes}")
+    return a
+
+
+def depth_pyramid_desc(screen_width, screen_height):
+    """DepthPyramid::new geometry (src/passes/draw_gen.rs:457-459)."""
+    d = _lib.DepthPyramidDesc()
+    _lib.check(_lib.load().orbit_depth_pyramid_desc(screen_width, screen_height, C.byref(d)))
+    return d
+
+
+def shard_range(entity_draw_count, rank, world):
+    b, e = C.c_uint32(), C.c_uint32()
+    _lib.load().orbit_shard_range(entity_draw_count, rank, world, C.byref(b), C.byref(e))
+    return b.value, e.value
+
+
+class Engine:
+    """One ``OrbitCtx``: scan scratch sized from ``caps`` on one gfx950 device."""
+
+    def __init__(self, device_index=0, **caps):
+        lib = _lib.load()
+        c = _lib.Caps()
+        lib.orbit_default_caps(C.byref(c))
+        for k, v in caps.items():
+            if not hasattr(c, k):
+                raise TypeError(f"unknown capacity {k}")
+            setattr(c, k, int(v))
+        self.caps = c
+        self._ctx = C.c_void_p()
+        _lib.check(lib.orbit_ctx_create(device_index, C.byref(c), C.byref(self._ctx)))
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.orbit_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def status(self, stream=None, sync=True):
+        """Raises OrbitError for a device-latched condition (capacity overflow, timeout)."""
+        _lib.check(self._lib.orbit_ctx_status(self._ctx, _stream(stream), 1 if sync else 0), self._ctx)
+
+    # -- entity_cull: create_meshlet_dispatch_command body (draw_gen.rs:327-380)
+    def entity_cull(self, cull_info, entity_draw_buffer, mesh_info_buffer, meshlet_dispatch_buffer, entity_buffer,
+                    entity_draw_count, dispatch_capacity, visibility_buffer=None, depth_pyramid=None,
+                    depth_pyramid_size=(0, 0), draw_first=None, stream=None):
+        ci = _host_bytes(cull_info, 400)
+        b = _lib.EntityCullBufs()
+        b.entity_draw_buffer = _ptr(entity_draw_buffer)
+        b.mesh_info_buffer = _ptr(mesh_info_buffer)
+        b.meshlet_dispatch_buffer = _ptr(meshlet_dispatch_buffer)
+        b.entity_buffer = _ptr(entity_buffer)
+        b.visibility_buffer = _ptr(visibility_buffer)
+        b.depth_pyramid = _ptr(depth_pyramid)
+        b.depth_pyramid_size[0], b.depth_pyramid_size[1] = depth_pyramid_size
+        b.dispatch_capacity = dispatch_capacity
+        if draw_first is None:
+            rc = self._lib.orbit_entity_cull(self._ctx, ci.ctypes.data_as(C.c_void_p), C.byref(b), entity_draw_count,
+                                             _stream(stream))
+        else:
+            rc = self._lib.orbit_entity_cull_range(self._ctx, ci.ctypes.data_as(C.c_void_p), C.byref(b), draw_first,
+                                                   entity_draw_count, _stream(stream))
+        _lib.check(rc, self._ctx)
+
+    # -- meshlet_cull: create_meshlet_draw_commands body (draw_gen.rs:382-435)
+    def meshlet_cull(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, draw_commands_buffer, entity_buffer,
+                     material_buffer, dispatch_capacity, draw_capacity, meshlet_visibility_buffer=None,
+                     depth_pyramid=None, depth_pyramid_size=(0, 0), stream=None):
+        ci = _host_bytes(cull_info, 400)
+        b = _lib.MeshletCullBufs()
+        b.meshlet_dispatch_buffer = _ptr(meshlet_dispatch_buffer)
+        b.meshlet_buffer = _ptr(meshlet_buffer)
+        b.draw_commands_buffer = _ptr(draw_commands_buffer)
+        b.entity_buffer = _ptr(entity_buffer)
+        b.material_buffer = _ptr(material_buffer)
+        b.meshlet_visibility_buffer = _ptr(meshlet_visibility_buffer)
+        b.depth_pyramid = _ptr(depth_pyramid)
+        b.depth_pyramid_size[0], b.depth_pyramid_size[1] = depth_pyramid_size
+        b.dispatch_capacity = dispatch_capacity
+        b.draw_capacity = draw_capacity
+        _lib.check(self._lib.orbit_meshlet_cull(self._ctx, ci.ctypes.data_as(C.c_void_p), C.byref(b),
+                                                _stream(stream)), self._ctx)
+
+    # -- DepthPyramid::update (draw_gen.rs:510-566)
+    def depth_reduce(self, depth, screen_width, screen_height, pyramid, stream=None):
+        _lib.check(self._lib.orbit_depth_reduce(self._ctx, _ptr(depth), screen_width, screen_height, _ptr(pyramid),
+                                                _stream(stream)), self._ctx)
+
+    # -- compute_clusters stages (cluster.rs:399-591)
+    def cluster_mark(self, push, depth, tile_depth_slice_mask, depth_bounds, stream=None):
+        pc = _host_bytes(push, layouts.MARK_ACTIVE_PUSH.itemsize)
+        _lib.check(self._lib.orbit_cluster_mark(self._ctx, pc.ctypes.data_as(C.c_void_p), _ptr(depth),
+                                                _ptr(tile_depth_slice_mask), _ptr(depth_bounds), _stream(stream)),
+                   self._ctx)
+
+    def cluster_compact(self, cluster_count, tile_depth_slice_mask, unique_cluster_buffer, index_capacity,
+                        stream=None):
+        cc = (C.c_uint32 * 3)(*[int(v) for v in cluster_count])
+        _lib.check(self._lib.orbit_cluster_compact(self._ctx, C.byref(cc), _ptr(tile_depth_slice_mask),
+                                                   _ptr(unique_cluster_buffer), index_capacity, _stream(stream)),
+                   self._ctx)
+
+    def cluster_assign(self, info, unique_cluster_buffer, depth_bounds, lights, light_index_buffer,
+                       light_index_capacity, cluster_offset_image, stream=None):
+        ib = _host_bytes(info, layouts.CLUSTER_CULL_INFO.itemsize)
+        _lib.check(self._lib.orbit_cluster_assign(self._ctx, ib.ctypes.data_as(C.c_void_p),
+                                                  _ptr(unique_cluster_buffer), _ptr(depth_bounds), _ptr(lights),
+                                                  _ptr(light_index_buffer), light_index_capacity,
+                                                  _ptr(cluster_offset_image), _stream(stream)), self._ctx)

@@ -1,0 +1,264 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle,
+bit-exact on identical seeded inputs.  Run with ``-m gpu`` on an MI355X."""
+import numpy as np
+import pytest
+
+import scenes as sc
+from orbit_amd import layouts as L
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def engine(torch_mod):
+    from orbit_amd.engine import Engine
+
+    e = Engine(0, max_entities=300_000, max_dispatches=2_000_000, max_draws=4_000_000, max_lights=12_000,
+               max_clusters=240 * 135 * 32)
+    yield e
+    e.close()
+
+
+def dev(torch, a):
+    a = np.ascontiguousarray(a)
+    return torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).cuda()
+
+
+def host(t, dtype=np.uint8):
+    return t.cpu().numpy().view(dtype)
+
+
+class GpuScene:
+    def __init__(self, torch, scene):
+        self.scene = scene
+        self.draws = dev(torch, scene.entity_draw_buffer())
+        self.mesh_infos = dev(torch, scene.mesh_infos)
+        self.entities = dev(torch, scene.entities)
+        self.meshlets = dev(torch, scene.meshlets)
+        self.materials = dev(torch, scene.materials)
+
+
+def run_gpu(torch, engine, gs, ci, evis=None, mvis=None, pyr=None, psize=(0, 0), disp_cap=None, draw_cap=None,
+            entity_draw_count=None):
+    s = gs.scene
+    disp_cap = s.max_dispatches() + 8 if disp_cap is None else disp_cap
+    n = s.entity_draw_count if entity_draw_count is None else entity_draw_count
+    disp = torch.full((L.DISPATCH_HEADER + 16 * disp_cap + 256,), 0xAB, dtype=torch.uint8, device="cuda")
+    evis_d = None if evis is None else dev(torch, evis)
+    mvis_d = None if mvis is None else dev(torch, mvis)
+    pyr_d = None if pyr is None else dev(torch, pyr)
+    engine.entity_cull(ci, gs.draws, gs.mesh_infos, disp, gs.entities, n, disp_cap, visibility_buffer=evis_d,
+                       depth_pyramid=pyr_d, depth_pyramid_size=psize)
+    draw_cap = s.lod0_meshlets + 8 if draw_cap is None else draw_cap
+    draw = torch.full((L.DRAW_HEADER + 28 * draw_cap + 256,), 0xCD, dtype=torch.uint8, device="cuda")
+    engine.meshlet_cull(ci, disp, gs.meshlets, draw, gs.entities, gs.materials, disp_cap, draw_cap,
+                        meshlet_visibility_buffer=mvis_d, depth_pyramid=pyr_d, depth_pyramid_size=psize)
+    torch.cuda.synchronize()
+    return (host(disp), host(draw), None if evis_d is None else host(evis_d, np.uint32),
+            None if mvis_d is None else host(mvis_d, np.uint32))
+
+
+def run_oracle(oracle, scene, ci, evis=None, mvis=None, pyr=None, psize=(0, 0), disp_cap=None, draw_cap=None,
+               entity_draw_count=None):
+    disp_cap = scene.max_dispatches() + 8 if disp_cap is None else disp_cap
+    n = scene.entity_draw_count if entity_draw_count is None else entity_draw_count
+    disp, evis_o, d1 = oracle.entity_cull(ci, scene.entity_draw_buffer(), n, scene.mesh_infos, scene.entities,
+                                          disp_cap, evis, pyr, psize)
+    draw_cap = scene.lod0_meshlets + 8 if draw_cap is None else draw_cap
+    draw, mvis_o, d2 = oracle.meshlet_cull(ci, disp, scene.meshlets, draw_cap, scene.entities, scene.materials, mvis,
+                                           pyr, psize)
+    return disp, draw, evis_o, mvis_o, d1, d2
+
+
+def assert_same(gpu, ref):
+    gdisp, gdraw, gevis, gmvis = gpu
+    odisp, odraw, oevis, omvis = ref[:4]
+    gh, grecs = L.dispatch_buffer_records(gdisp)
+    oh, orecs = L.dispatch_buffer_records(odisp)
+    assert list(gh) == list(oh)
+    assert np.array_equal(grecs.view(np.uint32), orecs.view(np.uint32)), "dispatch records differ"
+    gn, gcmds = L.draw_buffer_commands(gdraw)
+    on, ocmds = L.draw_buffer_commands(odraw)
+    assert gn == on
+    assert np.array_equal(gcmds.view(np.uint32), ocmds.view(np.uint32)), "draw commands differ"
+    if oevis is not None:
+        assert np.array_equal(gevis, oevis), "entity visibility bitset differs"
+    if omvis is not None:
+        assert np.array_equal(gmvis, omvis), "meshlet visibility bitset differs"
+    return grecs, gcmds
+
+
+# ----------------------------------------------------------------------------- pass 0
+@pytest.mark.parametrize("seed,n,lods", [(1, 300, 1), (2, 1000, 3), (3, 37, 1), (4, 5000, 2)])
+def test_pass0(torch_mod, engine, oracle, seed, n, lods):
+    scene = sc.make_scene(seed, n, n_meshes=max(1, n // 3), lods=lods)
+    cam = sc.default_camera(rot=(0.6, 0.8))
+    ci = sc.make_cull_info(cam.view, cam.planes, lod_base=8.0)
+    gs = GpuScene(torch_mod, scene)
+    recs, cmds = assert_same(run_gpu(torch_mod, engine, gs, ci), run_oracle(oracle, scene, ci))
+    assert len(cmds) > 0
+
+
+def test_pass0_no_planes_ragged_records(torch_mod, engine, oracle):
+    scene = sc.make_scene(5, 257, meshlets_per_mesh=(1, 70))  # ragged: 1..70 meshlets -> partial records
+    cam = sc.default_camera()
+    ci = sc.make_cull_info(cam.view, np.zeros((0, 4), np.float32), alpha_mode_flag=L.ALPHA_ALL)
+    gs = GpuScene(torch_mod, scene)
+    recs, cmds = assert_same(run_gpu(torch_mod, engine, gs, ci), run_oracle(oracle, scene, ci))
+    assert len(recs) == scene.max_dispatches()
+
+
+def test_empty_inputs(torch_mod, engine, oracle):
+    scene = sc.make_scene(6, 40)
+    cam = sc.default_camera()
+    ci = sc.make_cull_info(cam.view, cam.planes)
+    gs = GpuScene(torch_mod, scene)
+    # entity_draw_count = 0: only the {0,1,1} clear happens; meshlet cull then writes count = 0
+    gpu = run_gpu(torch_mod, engine, gs, ci, entity_draw_count=0)
+    assert list(gpu[0][:12].view(np.uint32)) == [0, 1, 1]
+    assert int(gpu[1][:4].view(np.uint32)[0]) == 0
+    # in-buffer count smaller than the dispatch size bounds the work (entity_cull.comp:106)
+    gs.draws = dev(torch_mod, scene.entity_draw_buffer(count=17))
+    disp, draw, _, _ = run_gpu(torch_mod, engine, gs, ci)
+    od, _, _ = oracle.entity_cull(ci, scene.entity_draw_buffer(count=17), scene.entity_draw_count, scene.mesh_infos,
+                                  scene.entities, scene.max_dispatches() + 8)
+    assert np.array_equal(disp[:12 + 16 * int(od[:4].view(np.uint32)[0])], od[:12 + 16 * int(od[:4].view(np.uint32)[0])])
+    # everything behind the camera: zero survivors
+    ci_none = sc.make_cull_info(sc.translation(0, 0, 1e6), cam.planes)
+    gpu = run_gpu(torch_mod, engine, GpuScene(torch_mod, scene), ci_none)
+    assert list(gpu[0][:12].view(np.uint32)) == [0, 1, 1] and int(gpu[1][:4].view(np.uint32)[0]) == 0
+
+
+# ----------------------------------------------------------------------------- two-pass HiZ
+@pytest.mark.parametrize("size", [(320, 180), (1920, 1080)])
+def test_two_pass_sequence(torch_mod, engine, oracle, size):
+    torch = torch_mod
+    W, H = size
+    scene = sc.make_scene(11, 2000, n_meshes=300, extent=(60.0, 12.0, 60.0))
+    cam = sc.default_camera()
+    rng = np.random.default_rng(5)
+    evis = rng.integers(0, 2 ** 32, (scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+    mvis = rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32)
+    gs = GpuScene(torch, scene)
+    ci1 = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=1)
+    assert_same(run_gpu(torch, engine, gs, ci1, evis, mvis), run_oracle(oracle, scene, ci1, evis, mvis))
+    depth = sc.make_depth(9, W, H, cam)
+    opyr, d = oracle.depth_reduce(depth, W, H)
+    gpyr = torch.zeros(d.total_texels, dtype=torch.float32, device="cuda")
+    engine.depth_reduce(dev(torch, depth), W, H, gpyr)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(gpyr, np.uint32), opyr.view(np.uint32)), "depth pyramid differs"
+    ci2 = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=2, p00=cam.p00, p11=cam.p11, z_near=cam.z_near)
+    ps = (d.width, d.height)
+    recs, cmds = assert_same(run_gpu(torch, engine, gs, ci2, evis, mvis, opyr, ps),
+                             run_oracle(oracle, scene, ci2, evis, mvis, opyr, ps))
+    assert len(cmds) > 0
+    # frame 0 (all-zero bitsets) and entity-only occlusion
+    ze, zm = np.zeros_like(evis), np.zeros_like(mvis)
+    assert_same(run_gpu(torch, engine, gs, ci2, ze, zm, opyr, ps), run_oracle(oracle, scene, ci2, ze, zm, opyr, ps))
+    ci2e = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=2, meshlet_visibility=False, p00=cam.p00,
+                             p11=cam.p11, z_near=cam.z_near)
+    assert_same(run_gpu(torch, engine, gs, ci2e, evis, None, opyr, ps),
+                run_oracle(oracle, scene, ci2e, evis, None, opyr, ps))
+
+
+@pytest.mark.parametrize("size", [(96, 54), (130, 40), (64, 64), (17, 9), (200, 3), (2560, 1080), (1, 1)])
+def test_depth_reduce(torch_mod, engine, oracle, size):
+    torch = torch_mod
+    W, H = size
+    cam = sc.default_camera(aspect=W / H)
+    depth = sc.make_depth(5, W, H, cam, n_occluders=12)
+    opyr, d = oracle.depth_reduce(depth, W, H)
+    gpyr = torch.full((d.total_texels,), -1.0, dtype=torch.float32, device="cuda")
+    engine.depth_reduce(dev(torch, depth), W, H, gpyr)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(gpyr, np.uint32), opyr.view(np.uint32))
+
+
+def test_orthographic(torch_mod, engine, oracle):
+    torch = torch_mod
+    scene = sc.make_scene(13, 700, extent=(20.0, 6.0, 20.0))
+    proj = sc.orthographic_rh(-25, 25, -25, 25, 0.1, 80.0)
+    planes = np.concatenate([sc.frustum_planes(proj, 6), sc.default_camera().planes[:3]])
+    view = sc.translation(0.0, 0.0, -40.0)
+    gs = GpuScene(torch, scene)
+    ci = sc.make_cull_info(view, planes, projection_type=1, lod_target=(1.0, 2.0, 3.0))
+    assert_same(run_gpu(torch, engine, gs, ci), run_oracle(oracle, scene, ci))
+    W = H = 128
+    depth = np.full((H, W), 0.5, dtype=np.float32)
+    depth[:, : W // 2] = 0.9
+    opyr, d = oracle.depth_reduce(depth, W, H)
+    evis = np.zeros((scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+    mvis = np.zeros(scene.vis_words, dtype=np.uint32)
+    ci2 = sc.make_cull_info(view, planes, occlusion_pass=2, projection_type=1, p00=2.0 / 50.0, p11=2.0 / 50.0,
+                            z_near=0.1, z_far=80.0)
+    ps = (d.width, d.height)
+    assert_same(run_gpu(torch, engine, gs, ci2, evis, mvis, opyr, ps),
+                run_oracle(oracle, scene, ci2, evis, mvis, opyr, ps))
+
+
+def test_capacity_overflow(torch_mod, engine, oracle):
+    from orbit_amd._lib import E_CAPACITY, OrbitError
+
+    torch = torch_mod
+    scene = sc.make_scene(14, 200)
+    cam = sc.default_camera()
+    ci = sc.make_cull_info(cam.view, np.zeros((0, 4), np.float32), alpha_mode_flag=L.ALPHA_ALL)
+    gs = GpuScene(torch, scene)
+    disp, draw, _, _ = run_gpu(torch, engine, gs, ci, disp_cap=50, draw_cap=100)
+    ref = run_oracle(oracle, scene, ci, disp_cap=50, draw_cap=100)
+    assert ref[4] > 0 and ref[5] > 0
+    assert np.array_equal(disp[:12 + 16 * 50], ref[0][:12 + 16 * 50])
+    assert np.array_equal(draw[:4 + 28 * 100], ref[1][:4 + 28 * 100])
+    assert np.all(disp[12 + 16 * 50:] == 0xAB) and np.all(draw[4 + 28 * 100:] == 0xCD)  # no OOB write
+    with pytest.raises(OrbitError) as ei:
+        engine.status()
+    assert ei.value.code == E_CAPACITY
+    engine.status()  # latch cleared
+
+
+def test_argument_errors(torch_mod, engine):
+    from orbit_amd._lib import E_MISSING, E_PLANES, OrbitError
+
+    torch = torch_mod
+    scene = sc.make_scene(15, 10)
+    cam = sc.default_camera()
+    gs = GpuScene(torch, scene)
+    disp = torch.zeros(12 + 16 * 64, dtype=torch.uint8, device="cuda")
+    ci = sc.make_cull_info(cam.view, cam.planes)
+    ci["cull_plane_count"] = 13  # assert!(planes <= 12), draw_gen.rs:334
+    with pytest.raises(OrbitError) as ei:
+        engine.entity_cull(ci, gs.draws, gs.mesh_infos, disp, gs.entities, 10, 64)
+    assert ei.value.code == E_PLANES
+    ci1 = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=1)
+    with pytest.raises(OrbitError) as ei:  # .unwrap() on a missing visibility buffer, draw_gen.rs:125-128
+        engine.entity_cull(ci1, gs.draws, gs.mesh_infos, disp, gs.entities, 10, 64)
+    assert ei.value.code == E_MISSING
+
+
+def test_large_scene_properties(torch_mod, engine, oracle):
+    """A scene too large for the numpy cross-check: oracle equality plus size-independent
+    properties (idempotence, determinism across launches, count == popcount)."""
+    torch = torch_mod
+    scene = sc.make_scene(21, 60_000, n_meshes=2000, meshlets_per_mesh=(8, 64), extent=(400.0, 60.0, 400.0),
+                          layout="lattice")
+    cam = sc.default_camera()
+    ci = sc.make_cull_info(cam.view, cam.planes)
+    gs = GpuScene(torch, scene)
+    a = run_gpu(torch, engine, gs, ci)
+    b = run_gpu(torch, engine, gs, ci)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])  # deterministic sequence
+    recs, cmds = assert_same(a, run_oracle(oracle, scene, ci))
+    assert len(cmds) > 10_000
+    # commands are in canonical (record, lane) order: meshlet_index ascending within an entity run
+    key = cmds["cmd_first_instance"].astype(np.int64) * (1 << 32) + cmds["meshlet_index"]
+    runs = np.flatnonzero(np.diff(cmds["cmd_first_instance"]) != 0)
+    assert np.all(np.diff(key)[np.setdiff1d(np.arange(len(key) - 1), runs)] > 0)

@@ -1,0 +1,221 @@
+"""CPU suite: pins the C oracle against an independent numpy restatement,
+structural properties and the committed golden fixtures.
+
+The reference holds no golden vectors for this path, so these tests are the
+oracle's pin; the GPU parity tests (test_gpu_parity.py) then compare the HIP
+engine with the oracle.
+"""
+import numpy as np
+import pytest
+
+import np_restatement as npr
+import scenes as sc
+from orbit_amd import layouts as L
+
+
+def popcount(words):
+    return int(sum(bin(int(w)).count("1") for w in np.asarray(words).reshape(-1)))
+
+
+# ----------------------------------------------------------------------------- log2
+def test_log2_spec(oracle):
+    xs = np.concatenate([np.exp2(np.arange(-126, 128, dtype=np.float64)).astype(np.float32),
+                         np.random.default_rng(0).uniform(1e-6, 1e6, 5000).astype(np.float32),
+                         np.array([1e-40, 3e-39, 0.0, np.inf], dtype=np.float32)])
+    got = np.array([oracle.log2f(float(x)) for x in xs], dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), npr.log2c(xs).view(np.uint32))  # two restatements agree bitwise
+    finite = np.isfinite(got) & (xs > 0)
+    ref = np.log2(xs[finite].astype(np.float64))
+    assert np.all(np.abs(got[finite].astype(np.float64) - ref) <= 1.5e-6 + np.abs(ref) * 2.0 ** -23)
+    p2 = np.exp2(np.arange(-126, 128, dtype=np.float64)).astype(np.float32)
+    assert [oracle.log2f(float(x)) for x in p2] == list(range(-126, 128))  # exact at powers of two
+    assert oracle.log2f(0.0) == -np.inf and np.isnan(oracle.log2f(-1.0)) and oracle.log2f(np.inf) == np.inf
+
+
+def test_snorm8_division_identity():
+    """The device computes int8/127 as q0 + fma(-q0,127,i)*r (Markstein); emulate the
+    fused ops in float64 (exact here) and compare with the oracle's IEEE division."""
+    r = np.float32(1) / np.float32(127)
+    assert float(r).hex() == "0x1.0204080000000p-7"
+    for i in range(-128, 128):
+        fi = np.float32(i)
+        q0 = np.float32(fi * r)
+        rem = np.float32(np.float64(fi) - np.float64(q0) * 127.0)
+        q1 = np.float32(np.float64(q0) + np.float64(rem) * np.float64(r))
+        assert q1 == np.float32(fi / np.float32(127.0)), i
+
+
+# ----------------------------------------------------------------------------- host derivations
+def test_frustum_planes(oracle):
+    cam = sc.default_camera()
+    got = oracle.frustum_planes_from_matrix(sc.mat4_cols(cam.proj))
+    assert np.array_equal(got[:5].view(np.uint32), sc.frustum_planes(cam.proj, 5).view(np.uint32))
+    # infinite reverse-Z: plane 4 is (0,0,-1,near), a plane behind the eye
+    assert np.allclose(got[4], [0, 0, -1, cam.z_near])
+
+
+@pytest.mark.parametrize("size,expect", [((1920, 1080), (1024, 1024, 11)), ((2560, 1080), (2048, 1024, 12)),
+                                         ((640, 360), (512, 256, 10)), ((1, 1), (1, 1, 1)), ((33, 2), (32, 1, 6))])
+def test_pyramid_desc(oracle, size, expect):
+    d = oracle.depth_pyramid_desc(*size)
+    assert (d.width, d.height, d.mip_levels) == expect
+    assert d.total_texels == sum(max(d.width >> k, 1) * max(d.height >> k, 1) for k in range(d.mip_levels))
+
+
+# ----------------------------------------------------------------------------- depth_reduce
+@pytest.mark.parametrize("size", [(96, 54), (130, 40), (64, 64), (17, 9), (200, 3)])
+def test_depth_reduce_vs_numpy(oracle, size):
+    w, h = size
+    cam = sc.default_camera(aspect=w / h)
+    depth = sc.make_depth(5, w, h, cam, n_occluders=12)
+    pyr, d = oracle.depth_reduce(depth, w, h)
+    ref, _ = npr.depth_reduce(depth, w, h)
+    assert np.array_equal(pyr.view(np.uint32), ref.view(np.uint32))
+    # structure: levels >= 1 are exact 2x2 block minima; the top level is the global min of level 0
+    for k in range(1, d.mip_levels):
+        sw_, sh_ = d.mip_width[k - 1], d.mip_height[k - 1]
+        src = pyr[d.mip_offset[k - 1]:d.mip_offset[k - 1] + sw_ * sh_].reshape(sh_, sw_)
+        dw, dh = d.mip_width[k], d.mip_height[k]
+        dst = pyr[d.mip_offset[k]:d.mip_offset[k] + dw * dh].reshape(dh, dw)
+        for y in range(dh):
+            for x in range(dw):
+                blk = src[min(2 * y, sh_ - 1):min(2 * y + 1, sh_ - 1) + 1, min(2 * x, sw_ - 1):min(2 * x + 1, sw_ - 1) + 1]
+                assert dst[y, x] == blk.min()
+    lvl0 = pyr[:d.mip_width[0] * d.mip_height[0]]
+    assert pyr[-1] == lvl0.min()
+    assert lvl0.min() >= depth.min()  # min-reduction never invents a farther depth
+
+
+# ----------------------------------------------------------------------------- cull: oracle vs numpy restatement
+def _run_both(oracle, scene, ci, evis=None, mvis=None, pyr=None, psize=(0, 0)):
+    cap = scene.max_dispatches() + 8
+    disp, evis_o, dropped = oracle.entity_cull(ci, scene.entity_draw_buffer(), scene.entity_draw_count,
+                                               scene.mesh_infos, scene.entities, cap, evis, pyr, psize)
+    assert dropped == 0
+    hdr, recs = L.dispatch_buffer_records(disp)
+    vis_n, should_n, recs_n, evis_n = npr.entity_cull(ci, scene.entity_draws, scene.entity_draw_count,
+                                                      scene.entity_draw_count, scene.mesh_infos, scene.entities, evis,
+                                                      pyr, psize)
+    assert list(hdr) == [len(recs_n), 1, 1]
+    assert np.array_equal(recs.view(np.uint32), recs_n.view(np.uint32))
+    if evis_n is not None:
+        assert np.array_equal(evis_o, evis_n)
+    draw_cap = int(recs["meshlet_count"].sum()) + 8
+    draw, mvis_o, dropped = oracle.meshlet_cull(ci, disp, scene.meshlets, draw_cap, scene.entities, scene.materials,
+                                                mvis, pyr, psize)
+    assert dropped == 0
+    n, cmds = L.draw_buffer_commands(draw)
+    cmds_n, mvis_n = npr.meshlet_cull(ci, recs_n, scene.meshlets, scene.entities, scene.materials, mvis, pyr, psize)
+    assert n == len(cmds_n)
+    assert np.array_equal(cmds.view(np.uint32), cmds_n.view(np.uint32))
+    if mvis_n is not None:
+        assert np.array_equal(mvis_o, mvis_n)
+    return recs, cmds, evis_o, mvis_o
+
+
+@pytest.mark.parametrize("seed,lods,shuffle", [(1, 1, True), (2, 3, True), (3, 1, False)])
+def test_pass0_frustum_cone(oracle, seed, lods, shuffle):
+    scene = sc.make_scene(seed, 300, n_meshes=90, lods=lods, shuffle=shuffle)
+    cam = sc.default_camera(rot=(0.8, 0.6))
+    ci = sc.make_cull_info(cam.view, cam.planes, lod_base=8.0)
+    recs, cmds, _, _ = _run_both(oracle, scene, ci)
+    assert 0 < len(cmds) < int(recs["meshlet_count"].sum())
+    if lods > 1:  # distant entities pick coarser LODs
+        offs = scene.mesh_infos["mesh_lods"][:, 0, 0]
+        assert np.any(~np.isin(recs["meshlet_offset"] - recs["meshlet_offset"] % 1, offs))
+
+
+def test_pass0_no_planes_all_alpha(oracle):
+    scene = sc.make_scene(4, 64, meshlets_per_mesh=(1, 70))
+    cam = sc.default_camera()
+    ci = sc.make_cull_info(cam.view, np.zeros((0, 4), np.float32), alpha_mode_flag=L.ALPHA_ALL)
+    recs, cmds, _, _ = _run_both(oracle, scene, ci)
+    assert len(recs) == scene.max_dispatches()  # frustum_culling = false -> every entity emits
+
+
+def test_two_pass_sequence(oracle):
+    """pass 1 (VisibilityRead) -> depth_reduce -> pass 2 (VisibilityWrite), forward.rs:266-403."""
+    W, H = 320, 180
+    scene = sc.make_scene(11, 400, n_meshes=100, extent=(40.0, 10.0, 40.0))
+    cam = sc.default_camera()
+    rng = np.random.default_rng(5)
+    evis = rng.integers(0, 2 ** 32, (scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+    mvis = rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32)
+    ci1 = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=1)
+    recs1, cmds1, _, _ = _run_both(oracle, scene, ci1, evis, mvis)
+    depth = sc.make_depth(9, W, H, cam)
+    pyr, d = oracle.depth_reduce(depth, W, H)
+    ci2 = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=2, p00=cam.p00, p11=cam.p11, z_near=cam.z_near)
+    recs2, cmds2, evis2, mvis2 = _run_both(oracle, scene, ci2, evis, mvis, pyr, (d.width, d.height))
+    # pass 2 only draws meshlets that were NOT visible last frame (meshlet_cull.comp:210-213)
+    drawn1 = set(zip(cmds1["cmd_first_instance"].tolist(), cmds1["meshlet_index"].tolist()))
+    drawn2 = set(zip(cmds2["cmd_first_instance"].tolist(), cmds2["meshlet_index"].tolist()))
+    assert drawn1.isdisjoint(drawn2)
+    assert len(drawn2) > 0 and popcount(evis2) > 0 and popcount(mvis2) >= len(cmds2)
+    # occlusion actually culls something relative to frustum+cone only
+    ci0 = sc.make_cull_info(cam.view, cam.planes, alpha_mode_flag=L.ALPHA_ALL)
+    _, cmds0, _, _ = _run_both(oracle, scene, ci0)
+    zero_e, zero_m = np.zeros_like(evis), np.zeros_like(mvis)
+    _, cmds2z, _, mvis2z = _run_both(oracle, scene, ci2, zero_e, zero_m, pyr, (d.width, d.height))
+    assert popcount(mvis2z) == len(cmds2z) < len(cmds0)  # frame 0: everything visible is newly visible
+
+
+def test_pass2_without_meshlet_occlusion(oracle):
+    W, H = 256, 128
+    scene = sc.make_scene(12, 150)
+    cam = sc.default_camera(aspect=2.0)
+    depth = sc.make_depth(2, W, H, cam)
+    pyr, d = oracle.depth_reduce(depth, W, H)
+    evis = np.zeros((scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+    ci2 = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=2, meshlet_visibility=False, p00=cam.p00,
+                            p11=cam.p11, z_near=cam.z_near)
+    _run_both(oracle, scene, ci2, evis, None, pyr, (d.width, d.height))
+
+
+def test_orthographic_shadow_cascade(oracle):
+    """The shadow renderer's CullInfo shape: ortho projection, 6 + k planes, no occlusion
+    (shadow_renderer.rs:622-712) and the ortho HiZ branch (entity_cull.comp:165-175)."""
+    scene = sc.make_scene(13, 250, extent=(20.0, 6.0, 20.0))
+    proj = sc.orthographic_rh(-25, 25, -25, 25, 0.1, 80.0)
+    planes = np.concatenate([sc.frustum_planes(proj, 6), sc.default_camera().planes[:3]])
+    view = sc.translation(0.0, 0.0, -40.0)
+    ci = sc.make_cull_info(view, planes, projection_type=1, lod_target=(1.0, 2.0, 3.0), lod_range=(0, 8))
+    assert int(ci["cull_plane_count"]) == 9
+    _run_both(oracle, scene, ci)
+    W = H = 128
+    depth = np.full((H, W), 0.5, dtype=np.float32)
+    depth[:, : W // 2] = 0.9
+    pyr, d = oracle.depth_reduce(depth, W, H)
+    evis = np.zeros((scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+    mvis = np.zeros(scene.vis_words, dtype=np.uint32)
+    ci2 = sc.make_cull_info(view, planes, occlusion_pass=2, projection_type=1, p00=2.0 / 50.0, p11=2.0 / 50.0,
+                            z_near=0.1, z_far=80.0)
+    _run_both(oracle, scene, ci2, evis, mvis, pyr, (d.width, d.height))
+
+
+def test_config1_sphere_frustum(oracle):
+    """BASELINE.json configs[0]: 8k spheres, frustum only (plumbing, CPU)."""
+    n = 8192
+    i = np.arange(n)
+    spheres = np.stack([sc.rnd_range(69, 1, i, -128, 128), sc.rnd_range(69, 2, i, -128, 128),
+                        sc.rnd_range(69, 3, i, -128, 128), sc.rnd_range(69, 4, i, 0.25, 4.0)], axis=1)
+    cam = sc.default_camera()
+    bits, cnt = oracle.sphere_frustum_cull(sc.mat4_cols(cam.view), cam.planes, spheres)
+    c = spheres[:, :3] + cam.view[:3, 3]
+    keep = np.ones(n, dtype=bool)
+    for pl in cam.planes:
+        d = ((pl[0] * c[:, 0] + pl[1] * c[:, 1]).astype(np.float32) + pl[2] * c[:, 2]).astype(np.float32) + pl[3]
+        keep &= d > -spheres[:, 3]
+    assert cnt == int(keep.sum()) == popcount(bits)
+    assert 0.1 * n < cnt < 0.4 * n  # 90-degree frustum in a cube: roughly a quarter survives
+    assert np.array_equal(np.unpackbits(bits.view(np.uint8), bitorder="little")[:n].astype(bool), keep)
+
+
+def test_capacity_overflow_is_reported(oracle):
+    scene = sc.make_scene(14, 50)
+    cam = sc.default_camera()
+    ci = sc.make_cull_info(cam.view, np.zeros((0, 4), np.float32))
+    disp, _, dropped = oracle.entity_cull(ci, scene.entity_draw_buffer(), scene.entity_draw_count, scene.mesh_infos,
+                                          scene.entities, 10)
+    hdr, recs = L.dispatch_buffer_records(disp)
+    assert hdr[0] == 10 and dropped == scene.max_dispatches() - 10
