@@ -262,3 +262,72 @@ def test_large_scene_properties(torch_mod, engine, oracle):
     key = cmds["cmd_first_instance"].astype(np.int64) * (1 << 32) + cmds["meshlet_index"]
     runs = np.flatnonzero(np.diff(cmds["cmd_first_instance"]) != 0)
     assert np.all(np.diff(key)[np.setdiff1d(np.arange(len(key) - 1), runs)] > 0)
+
+
+# ----------------------------------------------------------------------------- light clusters
+def cluster_inputs(oracle, seed, W, H, n_lights, tile_px=8, z_slices=32, far=200.0, samples=1, point_fraction=1.0):
+    cam = sc.default_camera(aspect=W / H)
+    depth = sc.make_depth(seed, W, H, cam, n_occluders=40, ground=(seed % 2 == 0))
+    if samples > 1:
+        jit = sc.rnd_range(seed, 90, np.arange(W * H * samples), 0.9, 1.1).reshape(H, W, samples)
+        depth = (depth[:, :, None] * jit).astype(np.float32)
+    cx, cy = -(-W // tile_px), -(-H // tile_px)
+    zs, zb = oracle.cluster_grid_info(cam.z_near, far, z_slices)
+    push = np.zeros((), dtype=L.MARK_ACTIVE_PUSH)
+    push["cluster_count"] = (cx, cy, z_slices)
+    push["tile_size_px"] = tile_px
+    push["screen_size"] = (W, H)
+    push["z_near"], push["z_far"], push["z_scale"], push["z_bias"] = cam.z_near, far, zs, zb
+    push["depth_buffer_sample_count"] = samples
+    info = np.zeros((), dtype=L.CLUSTER_CULL_INFO)
+    info["world_to_view_matrix"] = sc.mat4_cols(cam.view)
+    info["screen_to_view_matrix"] = sc.mat4_cols(np.linalg.inv(cam.proj.astype(np.float64)).astype(np.float32))
+    info["cluster_count"] = (cx, cy, z_slices)
+    info["tile_size_px"] = tile_px
+    info["screen_size"] = (W, H)
+    info["z_near"], info["z_far"] = cam.z_near, far
+    info["global_light_count"] = n_lights
+    lights = sc.make_lights(seed, n_lights, point_fraction=point_fraction)
+    return push, depth, info, lights
+
+
+@pytest.mark.parametrize("W,H,n_lights,tile,zs,samples,pf", [
+    (320, 180, 200, 8, 32, 1, 1.0), (333, 187, 64, 16, 24, 1, 0.9), (256, 128, 300, 8, 32, 4, 1.0),
+    (1920, 1080, 1000, 8, 32, 1, 1.0), (64, 64, 0, 8, 8, 1, 1.0), (200, 120, 40, 64, 32, 1, 1.0)])
+def test_light_clusters(torch_mod, engine, oracle, W, H, n_lights, tile, zs, samples, pf):
+    torch = torch_mod
+    push, depth, info, lights = cluster_inputs(oracle, 4, W, H, n_lights, tile, zs, samples=samples, point_fraction=pf)
+    cc = [int(v) for v in push["cluster_count"]]
+    total = cc[0] * cc[1] * cc[2]
+    # mark
+    om, ob = oracle.cluster_mark(push, depth)
+    gm = torch.full((cc[0] * cc[1],), 0x7FFFFFFF, dtype=torch.int32, device="cuda")
+    gb = torch.full((total, 2), 0x7FFFFFFF, dtype=torch.int32, device="cuda")
+    engine.cluster_mark(push, dev(torch, depth), gm, gb)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(gm, np.uint32), om), "tile slice masks differ"
+    assert np.array_equal(host(gb, np.uint32).reshape(-1, 2), ob), "cluster depth bounds differ"
+    # compact
+    cap = cc[0] * cc[1] * max(4, cc[2])  # cluster.rs:53-56
+    ou, dropped = oracle.cluster_compact(cc, om, cap)
+    assert dropped == 0
+    gu = torch.full((L.COMPACT_HEADER + 4 * cap,), 0xEE, dtype=torch.uint8, device="cuda")
+    engine.cluster_compact(cc, gm, gu, cap)
+    torch.cuda.synchronize()
+    n_active = int(ou[12:16].view(np.uint32)[0])
+    assert np.array_equal(host(gu)[:16 + 4 * n_active], ou[:16 + 4 * n_active]), "compacted cluster list differs"
+    # assign
+    lcap = n_active * 256 + 16
+    ol, oimg, dropped = oracle.cluster_assign(info, ou, ob, lights, lcap, total)
+    assert dropped == 0
+    gl = torch.full((L.LIGHT_INDEX_HEADER + 4 * lcap,), 0xEE, dtype=torch.uint8, device="cuda")
+    gimg = torch.zeros((total, 2), dtype=torch.int32, device="cuda")
+    engine.cluster_assign(info, gu, gb, dev(torch, lights) if n_lights else None, gl, lcap, gimg)
+    torch.cuda.synchronize()
+    n_idx = int(ol[:4].view(np.uint32)[0])
+    assert int(host(gl)[:4].view(np.uint32)[0]) == n_idx
+    assert np.array_equal(host(gl)[:4 + 4 * n_idx], ol[:4 + 4 * n_idx]), "cluster light index lists differ"
+    assert np.array_equal(host(gimg, np.uint32).reshape(-1, 2), oimg), "(offset,count) image differs"
+    engine.status()
+    if n_lights >= 200:
+        assert n_idx > 0 and n_active > 0
