@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py — meshlets culled / s on BASELINE.json config 5 (50 M synthetic meshlets).
+
+One "step" = one pass of the hot path over the scene: entity_cull + meshlet_cull
+(frustum + normal cone, occlusion_pass 0) on this rank's entity shard and, for
+N > 1, the RCCL gather of the compacted visible list (orbit_amd/dist.py).
+Inputs are generated on the device and stay resident in HBM; the timed region is
+K steps between barrier + synchronize on both sides, max over ranks.
+
+Prints ONE JSON line on rank 0 (contract: see the task statement / DESIGN.md §Measurement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--entities", type=int, default=195_313, help="config 5: 195313 x 256 = 50 000 128 meshlets")
+    ap.add_argument("--meshlets-per-entity", type=int, default=256)
+    ap.add_argument("--survive", type=float, default=0.10, help="target survivor fraction (SURVEY.md §8d prices 10 %%)")
+    ap.add_argument("--cpu-sample-entities", type=int, default=65_536,
+                    help="entities of the scene the CPU oracle is timed on (rank 0, N=1 only); 0 disables")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather (cull only)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import scenes as sc  # camera / CullInfo builders (test-side helpers, numpy only)
+    from orbit_amd import dist as odist
+    from orbit_amd import layouts as L
+    from orbit_amd import synth
+    from orbit_amd.engine import Engine
+
+    spec = synth.C5Spec(entities=args.entities, meshlets_per_entity=args.meshlets_per_entity)
+    E, M = spec.entities, spec.meshlets_per_entity
+    b, e = odist.shard_ranges(E, world)[rank]
+    n_local_entities = e - b
+    n_local_meshlets = n_local_entities * M
+    rec_per_ent = spec.records_per_entity
+
+    t0 = time.time()
+    draws, mesh, ent, half = synth.gen_entity_tables(spec, dev)
+    meshlets = synth.gen_meshlets(spec, b, e, dev, half, survive_target=args.survive)
+    materials = synth.gen_materials(spec, dev)
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+    # shard passed under its global indices: base pointer = shard pointer - first_meshlet * 32
+    meshlets_base = meshlets.data_ptr() - b * M * 32
+
+    # camera outside the +-512 m box so that every entity passes the frustum: all E*M meshlets
+    # reach meshlet_cull (the HBM-bound case the metric is about)
+    cam = sc.default_camera(position=(0.0, 0.0, 1300.0))
+    ci = sc.make_cull_info(cam.view, cam.planes)
+
+    disp_cap = n_local_entities * rec_per_ent + 8
+    draw_cap = n_local_meshlets // 2 + 1024
+    eng = Engine(local_rank, max_entities=n_local_entities + 256, max_dispatches=disp_cap, max_draws=draw_cap)
+    disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device=dev)
+    draw = torch.zeros(L.DRAW_HEADER + 28 * draw_cap, dtype=torch.uint8, device=dev)
+    gathered = None
+    do_gather = world > 1 and not args.no_gather
+    if do_gather:
+        gathered = torch.zeros(L.DRAW_HEADER + 28 * (draw_cap * world), dtype=torch.uint8, device=dev)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        eng.entity_cull(ci, draws, mesh, disp, ent, n_local_entities, disp_cap, draw_first=b)
+        if i is not None:
+            ev[i][0].record()
+        eng.meshlet_cull(ci, disp, meshlets_base, draw, ent, materials, disp_cap, draw_cap)
+        if i is not None:
+            ev[i][1].record()
+        if do_gather:
+            odist.gather_visible(draw, gathered)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    eng.status()
+
+    kernel_ms = float(np.mean([a.elapsed_time(z) for a, z in ev]))
+    n_rec = int(disp[:4].view(torch.int32).item())
+    n_draw = int(draw[:4].view(torch.int32).item())
+    n_in = int(disp[L.DISPATCH_HEADER:L.DISPATCH_HEADER + 16 * n_rec].view(torch.int32).view(-1, 4)[:, 2].sum().item())
+    # cull-only rate of this rank (for the N>1 breakdown)
+    if world > 1:
+        agg = torch.tensor([n_in, n_draw], dtype=torch.int64, device=dev)
+        dist.all_reduce(agg)
+        tot_in, tot_draw = int(agg[0].item()), int(agg[1].item())
+        km = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+        kernel_ms_max = float(km.item())
+    else:
+        tot_in, tot_draw, kernel_ms_max = n_in, n_draw, kernel_ms
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = tot_in / (elapsed / args.steps)
+
+    # roofline of the dominant kernel (meshlet_cull), this rank: algorithmic bytes per launch
+    # B_m = 32 N_m + 16 N_d + 64 N_e + 28 N_draw + 4   (occlusion_pass 0)
+    alg_bytes = 32 * n_in + 16 * n_rec + 64 * n_local_entities + 28 * n_draw + 4
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and args.cpu_sample_entities > 0:
+        cpu_baseline = run_cpu_baseline(args, spec, ci, draws, mesh, ent, meshlets, materials, disp, draw, L)
+
+    if rank == 0:
+        out = {
+            "metric": "meshlets_culled_per_sec",
+            "value": value,
+            "unit": "meshlets/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"config5: {E} entities x {M} = {E * M} synthetic meshlets, entity_cull + meshlet_cull, "
+                            f"frustum + normal cone (occlusion_pass 0), all entities in view, "
+                            f"{100.0 * tot_draw / max(tot_in, 1):.1f}% survivors"
+                            + (", + RCCL gather of the visible list" if do_gather else ""),
+                "entities": E, "meshlets": E * M, "meshlets_into_meshlet_cull": tot_in, "survivors": tot_draw,
+                "sharding": f"entity ranges over {world} rank(s)", "gather": bool(do_gather),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "meshlet_cull", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms,
+            },
+            "cpu_baseline": cpu_baseline,
+            "cull_only_meshlets_per_sec": tot_in / (kernel_ms_max * 1e-3) if kernel_ms_max > 0 else None,
+            "scene_gen_s": gen_s,
+        }
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(args, spec, ci, draws, mesh, ent, meshlets, materials, disp, draw, L):
+    """Times the CPU oracle (scalar C port, 1 thread) on the first `cpu_sample_entities` of the
+    same scene and checks that the GPU's output prefix for those entities is bit-identical."""
+    from oracle import oracle
+
+    oracle.build()
+    M = spec.meshlets_per_entity
+    es = min(args.cpu_sample_entities, spec.entities) // 256 * 256
+    if es == 0:
+        return None
+    h_draws, h_mesh, h_ent = draws.cpu().numpy(), mesh.cpu().numpy(), ent.cpu().numpy()
+    h_meshlets = meshlets[:es * M * 32].cpu().numpy()
+    h_mat = materials.cpu().numpy()
+    cap_d = es * spec.records_per_entity + 8
+    t0 = time.perf_counter()
+    odisp, _, _ = oracle.entity_cull(ci, h_draws, es, h_mesh, h_ent, cap_d)
+    n_rec = int(odisp[:4].view(np.uint32)[0])
+    odraw, _, dropped = oracle.meshlet_cull(ci, odisp, h_meshlets, es * M, h_ent, h_mat)
+    cpu_s = time.perf_counter() - t0
+    n_in = int(odisp[12:12 + 16 * n_rec].view(np.uint32).reshape(-1, 4)[:, 2].sum())
+    n_draw = int(odraw[:4].view(np.uint32)[0])
+    # canonical order => the GPU's full-scene output starts with exactly these records / commands
+    g_disp = disp[12:12 + 16 * n_rec].cpu().numpy()
+    g_draw = draw[4:4 + 28 * n_draw].cpu().numpy()
+    same = bool(np.array_equal(g_disp, odisp[12:12 + 16 * n_rec]) and np.array_equal(g_draw, odraw[4:4 + 28 * n_draw]))
+    return {
+        "value": n_in / cpu_s, "unit": "meshlets/s", "cores": 1, "kind": "port",
+        "sample": f"first {es} of {spec.entities} entities ({n_in} meshlets into meshlet_cull) of the same scene, "
+                  f"oracle/orbit_oracle.c entity_cull + meshlet_cull, {cpu_s:.2f} s, host has {os.cpu_count()} cores",
+        "gpu_prefix_bit_identical": same,
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -34,6 +35,7 @@ struct OrbitCtx {
     uint32_t *a_light_flags = nullptr, *a_counts = nullptr, *a_block_sums = nullptr, *a_block_base = nullptr,
              *a_total = nullptr;
     int32_t *status = nullptr;
+    int meshlet_mode = 1; // 1 = single-pass look-back (default), 0 = count/scan/emit (ORBIT_MESHLET_TWO_PASS=1)
     char err[512] = {0};
 };
 
@@ -205,6 +207,16 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->a_block_sums = (uint32_t *)(a + o_abs);
     ctx->a_block_base = (uint32_t *)(a + o_abb);
     ctx->a_total = (uint32_t *)(a + o_at);
+    // the epoch word of the single-pass scan starts at 1 (zeroed granules carry epoch 0 = invalid)
+    const uint32_t ctl0[3] = {0u, 0u, 1u};
+    e = hipMemcpy(ctx->m_ticket, ctl0, sizeof(ctl0), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(ctx->arena);
+        delete ctx;
+        return hip_fail(nullptr, e, "hipMemcpy(scan control words)");
+    }
+    const char *two_pass = getenv("ORBIT_MESHLET_TWO_PASS");
+    ctx->meshlet_mode = (two_pass && two_pass[0] == '1') ? 0 : 1;
     snprintf(ctx->err, sizeof(ctx->err), "no error");
     *out_ctx = ctx;
     return ORBIT_OK;
@@ -325,7 +337,7 @@ int32_t orbit_meshlet_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbi
     p.scan_state = ctx->m_scan_state;
     p.ticket = ctx->m_ticket;
     p.status = ctx->status;
-    hipError_t e = launch_meshlet_cull(p, ctx->num_cus, 0, (hipStream_t)stream);
+    hipError_t e = launch_meshlet_cull(p, ctx->num_cus, ctx->meshlet_mode, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_cull");
     return ORBIT_OK;
 }

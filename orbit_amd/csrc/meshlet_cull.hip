@@ -38,10 +38,6 @@ struct __attribute__((aligned(16))) WaveTileLds {
     float scale[kTileRecords];    // largest_scale_from_matrix(mat3(M))
 };
 
-struct RowOut {
-    uint32_t vertex_offset, data_offset, packed; // retained Meshlet words 5..7
-};
-
 // One meshlet (one lane): meshlet_cull.comp:113-213.  Returns bit0 = visible,
 // bit1 = should_draw.
 __device__ __forceinline__ uint32_t eval_meshlet(const MeshletCullParams &p, const WaveTileLds &L, uint32_t rid,
@@ -129,11 +125,11 @@ __device__ __forceinline__ void tile_setup(const MeshletCullParams &p, WaveTileL
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Evaluates the 8 rows of a tile.  Fills should-draw masks and (MODE_EMIT)
-// the retained command words; writes the pass-2 visibility words.
-template <int MODE>
+// Evaluates the 8 rows of a tile.  Fills the should-draw masks; WRITE_VIS also
+// writes the pass-2 visibility words.
+template <bool WRITE_VIS>
 __device__ __forceinline__ uint32_t tile_rows(const MeshletCullParams &p, const WaveTileLds &L, int lane,
-                                              uint64_t draw_mask[kTileRows], RowOut keep[kTileRows]) {
+                                              uint64_t draw_mask[kTileRows]) {
     const OrbitGpuCullInfo &ci = p.ci;
     const bool meshlet_occ = ci.meshlet_visibility_buffer != ORBIT_NONE;
     const bool rw_vis = (ci.occlusion_pass == 1 || ci.occlusion_pass == 2) && meshlet_occ;
@@ -170,10 +166,7 @@ __device__ __forceinline__ uint32_t tile_rows(const MeshletCullParams &p, const 
         const uint64_t mask = __ballot((res & 2u) != 0);
         draw_mask[r] = mask;
         total += (uint32_t)__popcll(mask);
-        if (MODE == MODE_EMIT) {
-            keep[r].vertex_offset = b[r].y;
-            keep[r].data_offset = b[r].z;
-            keep[r].packed = b[r].w;
+        if (WRITE_VIS) {
             // pass-2 visibility words (:233-254); records with no lane write nothing
             if (ci.occlusion_pass == 2 && meshlet_occ && ml == 0 && rec.z > 0)
                 p.meshlet_visibility[rec.w] = half ? (uint32_t)(vis_mask >> 32) : (uint32_t)vis_mask;
@@ -183,8 +176,11 @@ __device__ __forceinline__ uint32_t tile_rows(const MeshletCullParams &p, const 
 }
 
 // Writes the tile's surviving commands at [base, base + total) (:216-230).
+// The survivor's command words (Meshlet bytes 16..31) are re-read here: they
+// were streamed a few microseconds ago and are L2/MALL resident, and not
+// carrying them across the look-back keeps the kernel at 4 waves per SIMD.
 __device__ __forceinline__ void tile_emit(const MeshletCullParams &p, const WaveTileLds &L, int lane, uint32_t base,
-                                          const uint64_t draw_mask[kTileRows], const RowOut keep[kTileRows]) {
+                                          const uint64_t draw_mask[kTileRows]) {
     uint32_t *out = reinterpret_cast<uint32_t *>(p.draw_buffer + ORBIT_DRAW_HEADER);
     const uint32_t half = lane >> 5, ml = lane & 31;
     uint32_t row_base = base;
@@ -195,16 +191,17 @@ __device__ __forceinline__ void tile_emit(const MeshletCullParams &p, const Wave
             const uint32_t slot = row_base + lane_prefix(mask);
             if (slot < p.draw_capacity) {
                 const uint4 rec = L.rec[2 * r + half];
-                const uint32_t vertex_count = (keep[r].packed >> 16) & 0xFFu;
-                const uint32_t triangle_count = keep[r].packed >> 24;
+                const uint4 b = reinterpret_cast<const uint4 *>(p.meshlets + (rec.y + ml))[1];
+                const uint32_t vertex_count = (b.w >> 16) & 0xFFu;
+                const uint32_t triangle_count = b.w >> 24;
                 uint32_t *c = out + (size_t)slot * 7u;
-                c[0] = triangle_count * 3u;                         // cmd_index_count
-                c[1] = 1u;                                          // cmd_instance_count
-                c[2] = (keep[r].data_offset + vertex_count) * 4u;   // cmd_first_index
-                c[3] = keep[r].data_offset;                         // cmd_vertex_offset = int(data_offset)
-                c[4] = rec.x;                                       // cmd_first_instance = entity_index
-                c[5] = keep[r].vertex_offset;                       // meshlet_vertex_offset
-                c[6] = rec.y + ml;                                  // meshlet_index
+                c[0] = triangle_count * 3u;           // cmd_index_count
+                c[1] = 1u;                            // cmd_instance_count
+                c[2] = (b.z + vertex_count) * 4u;     // cmd_first_index
+                c[3] = b.z;                           // cmd_vertex_offset = int(data_offset)
+                c[4] = rec.x;                         // cmd_first_instance = entity_index
+                c[5] = b.y;                           // meshlet_vertex_offset
+                c[6] = rec.y + ml;                    // meshlet_index
             }
         }
         row_base += (uint32_t)__popcll(mask);
@@ -221,12 +218,11 @@ __global__ __launch_bounds__(kBlock) void meshlet_cull_two_pass(const MeshletCul
     for (uint32_t tile = blockIdx.x * kWavesPerBlock + wave; tile < ntiles; tile += gridDim.x * kWavesPerBlock) {
         tile_setup(p, L, tile, nrec, lane);
         uint64_t draw_mask[kTileRows];
-        RowOut keep[kTileRows];
-        const uint32_t total = tile_rows<MODE>(p, L, lane, draw_mask, keep);
+        const uint32_t total = tile_rows<MODE == MODE_EMIT>(p, L, lane, draw_mask);
         if (MODE == MODE_COUNT) {
             if (lane == 0) p.tile_counts[tile] = total;
         } else {
-            tile_emit(p, L, lane, p.tile_base[tile], draw_mask, keep);
+            tile_emit(p, L, lane, p.tile_base[tile], draw_mask);
         }
         __builtin_amdgcn_wave_barrier(); // LDS slab is reused by the next tile
     }
@@ -238,12 +234,139 @@ __global__ __launch_bounds__(kBlock) void meshlet_cull_two_pass(const MeshletCul
     }
 }
 
+// ---------------------------------------------------------------------------
+// Single-pass mode: one launch, ordered compaction by a decoupled look-back
+// scan over per-wave-tile granules.
+//
+//  * tile order comes from a ticket per BLOCK iteration (kSpWaves adjacent wave
+//    tiles per ticket): one returning atomic on one address saturates near 88/us
+//    on MI355X (MI355X_MICROARCH.md "dequeue"), so a ticket per 512-meshlet wave
+//    tile (98 k at 50 M meshlets) would cost more than the whole kernel; a ticket
+//    per 8192 meshlets is ~20/us.  A block that waits on tile j only ever waits
+//    on tickets drawn before its own, i.e. on running or finished blocks — no
+//    residency or dispatch-order assumption.
+//  * granule = one naturally aligned 8-byte {epoch:30 | status:2 | value:32}
+//    written by ONE relaxed agent-scope store and polled with relaxed
+//    agent-scope loads (cdna_hip_programming.md Guideline 16, recipe R2: the
+//    data is the flag, no fence).  The epoch (a device word bumped by the last
+//    block to finish) makes stale granules of earlier launches read as INVALID,
+//    so no per-launch memset and the launch is graph-replay safe.
+//  * every spin is bounded; on give-up ORBIT_E_TIMEOUT is latched and the tile
+//    proceeds with base 0 (wrong output, flagged) instead of hanging the GPU.
+constexpr int kSpWaves = 16;
+constexpr int kSpBlock = kSpWaves * 64;
+constexpr uint32_t ST_INVALID = 0u, ST_AGG = 1u, ST_PREFIX = 2u;
+constexpr uint32_t kSpinLimit = 1u << 22;
+
+__device__ __forceinline__ uint64_t make_granule(uint32_t epoch, uint32_t status, uint32_t value) {
+    return ((uint64_t)epoch << 34) | ((uint64_t)status << 32) | (uint64_t)value;
+}
+
+// Exclusive prefix of wave tile `w` (> 0): sums predecessor aggregates back to
+// the nearest published inclusive prefix, 64 granules per step.
+__device__ __forceinline__ uint32_t look_back(const MeshletCullParams &p, uint32_t w, uint32_t epoch, int lane) {
+    uint32_t exclusive = 0;
+    int64_t pos = (int64_t)w - 1; // nearest predecessor handled by lane 0
+    uint32_t spins = 0;
+    for (;;) {
+        const int64_t idx = pos - lane;
+        const bool in_range = idx >= 0;
+        uint64_t g = 0;
+        if (in_range) g = __hip_atomic_load(p.scan_state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t st = (uint32_t)(g >> 32) & 3u;
+        if ((uint32_t)(g >> 34) != epoch) st = ST_INVALID;
+        if (!in_range) st = ST_PREFIX; // "before tile 0": an inclusive prefix of 0
+        const uint32_t val = in_range ? (uint32_t)g : 0u;
+        const uint64_t m_prefix = __ballot(st == ST_PREFIX);
+        const uint64_t m_invalid = __ballot(st == ST_INVALID);
+        const int first_prefix = m_prefix ? (int)__builtin_ctzll(m_prefix) : 64;
+        const int first_invalid = m_invalid ? (int)__builtin_ctzll(m_invalid) : 64;
+        if (first_invalid < first_prefix) { // a needed predecessor has not published yet
+            if (++spins > kSpinLimit) {
+                if (lane == 0) latch_status(p.status, ORBIT_E_TIMEOUT);
+                return 0u;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        const uint32_t contrib = (lane <= first_prefix) ? val : 0u;
+        exclusive += wave_reduce_add(contrib);
+        if (first_prefix < 64) return exclusive;
+        pos -= 64;
+    }
+}
+
+__global__ __launch_bounds__(kSpBlock) void meshlet_cull_single_pass(const MeshletCullParams p) {
+    __shared__ WaveTileLds lds[kSpWaves];
+    __shared__ uint32_t s_ticket;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    WaveTileLds &L = lds[wave];
+    const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
+    const uint32_t ntiles = (nrec + kTileRecords - 1) / kTileRecords;
+    const uint32_t nrows = (ntiles + kSpWaves - 1) / kSpWaves;
+    uint32_t *ctl = p.ticket; // {ticket, done, epoch}
+    const uint32_t epoch = ctl[2];
+    for (;;) {
+        __syncthreads(); // previous iteration has consumed s_ticket
+        if (threadIdx.x == 0) s_ticket = atomicAdd(&ctl[0], 1u);
+        __syncthreads();
+        const uint32_t row = s_ticket;
+        if (row >= nrows) {
+            if (row == 0 && threadIdx.x == 0) *reinterpret_cast<uint32_t *>(p.draw_buffer) = 0u; // no records
+            break;
+        }
+        const uint32_t w = row * kSpWaves + wave;
+        if (w < ntiles) { // wave-uniform
+            tile_setup(p, L, w, nrec, lane);
+            uint64_t draw_mask[kTileRows];
+            const uint32_t total = tile_rows<true>(p, L, lane, draw_mask);
+            uint32_t base = 0;
+            if (w > 0) {
+                if (lane == 0)
+                    __hip_atomic_store(p.scan_state + w, make_granule(epoch, ST_AGG, total), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                base = look_back(p, w, epoch, lane);
+            }
+            const uint32_t inclusive = base + total;
+            if (lane == 0)
+                __hip_atomic_store(p.scan_state + w, make_granule(epoch, ST_PREFIX, inclusive), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            tile_emit(p, L, lane, base, draw_mask);
+            if (w == ntiles - 1 && lane == 0) {
+                // `count` header: subsumes the fill_buffer(count = 0) of draw_gen.rs:411-417
+                *reinterpret_cast<uint32_t *>(p.draw_buffer) = min(inclusive, p.draw_capacity);
+                if (inclusive > p.draw_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+            }
+        }
+    }
+    // self-cleaning control words: the last block to leave resets the ticket and
+    // bumps the epoch, so the next launch (stream-ordered) starts clean.
+    if (threadIdx.x == 0) {
+        const uint32_t done = atomicAdd(&ctl[1], 1u);
+        if (done == gridDim.x - 1) {
+            uint32_t next = (epoch + 1u) & 0x3FFFFFFFu;
+            if (next == 0u) next = 1u; // epoch 0 is what a zero-initialised granule carries
+            __hip_atomic_store(&ctl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl[2], next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 } // namespace
 
 hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, int mode, hipStream_t s) {
-    (void)mode;
-    // persistent-style grid: enough blocks to fill the chip, grid-stride over tiles
     const uint32_t max_tiles = (p.dispatch_capacity + kTileRecords - 1) / kTileRecords;
+    if (mode == 1) {
+        // persistent blocks, one 1024-thread block per CU (<= 128 VGPRs), looping over tickets
+        uint32_t blocks = num_cus;
+        const uint32_t need = (max_tiles + kSpWaves - 1) / kSpWaves;
+        if (blocks > need) blocks = need;
+        if (blocks == 0) blocks = 1;
+        hipLaunchKernelGGL(meshlet_cull_single_pass, dim3(blocks), dim3(kSpBlock), 0, s, p);
+        return hipGetLastError();
+    }
+    // two-pass fallback (count -> scan -> emit): persistent-style grid, grid-stride over tiles
     uint32_t blocks = num_cus * 8u;
     const uint32_t need = (max_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     if (blocks > need) blocks = need;

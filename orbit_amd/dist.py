@@ -1,0 +1,72 @@
+"""Multi-GPU sharding of the cull path: one process per GPU,
+contiguous 32-aligned entity-draw ranges per rank, and a rank-ordered gather of
+the compacted visible list over RCCL (torch.distributed backend "nccl" on ROCm;
+"gloo" in the CPU tests).
+
+The reference is single-GPU (no collective anywhere); the exchange step exists
+only because the sharded engine must hand one canonical MeshletDrawCommandBuffer
+to the renderer.  Because every rank's survivor list is already in canonical
+(record, lane) order and the shards are contiguous in entity order, concatenating
+the per-rank lists in rank order IS the single-GPU sequence.
+
+Pattern: all_gather of the 4-byte counts, then a grouped send/recv in which each
+rank pushes its variable-sized list straight into `draws + prefix[rank]` of every
+peer — on a fully connected xGMI node that drives all 7 links of a GPU at once,
+which a ring all-gather (per-link bound) would not.
+"""
+import torch
+import torch.distributed as dist
+
+from . import layouts as L
+
+
+def shard_ranges(entity_draw_count, world):
+    """[begin, end) per rank, cut at multiples of 32 so entity-bitset words are rank-private.
+    Mirrors orbit_shard_range() of the C ABI (pure integer math, no device needed)."""
+    words = (entity_draw_count + 31) // 32
+    out = []
+    for r in range(world):
+        b = min(words * r // world * 32, entity_draw_count)
+        e = min(words * (r + 1) // world * 32, entity_draw_count)
+        out.append((b, e))
+    return out
+
+
+def gather_visible(local_draw_buffer, out_draw_buffer, group=None):
+    """Rank-ordered all-gather of MeshletDrawCommandBuffers.
+
+    local_draw_buffer : uint8 tensor, this rank's buffer (u32 count @0, 28-B commands @4)
+    out_draw_buffer   : uint8 tensor large enough for the concatenation; receives
+                        count @0 and all ranks' commands @4 in rank order.
+    Returns the per-rank counts (python list).  One host sync (the counts) is
+    inherent: RCCL needs message sizes on the host.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    mine = local_draw_buffer[:4].view(torch.int32).to(torch.int64)
+    counts_t = torch.empty(world, dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(counts_t, mine, group=group)
+    counts = [int(c) for c in counts_t.cpu().tolist()]
+    total = sum(counts)
+    need = L.DRAW_HEADER + 28 * total
+    if out_draw_buffer.numel() < need:
+        raise ValueError(f"gather_visible: output holds {out_draw_buffer.numel()} B, needs {need} B")
+    prefix = [0]
+    for c in counts:
+        prefix.append(prefix[-1] + c)
+    out_draw_buffer[:4].view(torch.int32)[0] = total
+    my_bytes = local_draw_buffer[L.DRAW_HEADER:L.DRAW_HEADER + 28 * counts[rank]]
+    ops = []
+    for peer in range(world):
+        if peer == rank:
+            continue
+        if counts[rank] > 0:
+            ops.append(dist.P2POp(dist.isend, my_bytes, peer, group))
+        if counts[peer] > 0:
+            dst = out_draw_buffer[L.DRAW_HEADER + 28 * prefix[peer]:L.DRAW_HEADER + 28 * prefix[peer + 1]]
+            ops.append(dist.P2POp(dist.irecv, dst, peer, group))
+    out_draw_buffer[L.DRAW_HEADER + 28 * prefix[rank]:L.DRAW_HEADER + 28 * prefix[rank + 1]].copy_(my_bytes)
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return counts

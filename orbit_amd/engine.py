@@ -13,8 +13,12 @@ from . import _lib, layouts
 
 
 def _ptr(t):
+    """Device pointer of a torch tensor, or a raw integer address (used to pass a
+    shard of a large buffer under its global indices: base = shard_ptr - first * stride)."""
     if t is None:
         return None
+    if isinstance(t, int):
+        return C.c_void_p(t)
     return C.c_void_p(t.data_ptr())
 
 
