@@ -97,7 +97,8 @@ def main():
         eng.entity_cull(ci, draws, mesh, disp, ent, n_local_entities, disp_cap, draw_first=b)
         if i is not None:
             ev[i][0].record()
-        eng.meshlet_cull(ci, disp, meshlets_base, draw, ent, materials, disp_cap, draw_cap)
+        eng.meshlet_cull(ci, disp, meshlets_base, draw, ent, materials, disp_cap, draw_cap,
+                         material_count=spec.materials)
         if i is not None:
             ev[i][1].record()
         if do_gather:

@@ -374,6 +374,10 @@ typedef struct OrbitMeshletCullBufs {
     uint32_t depth_pyramid_size[2];
     uint32_t dispatch_capacity; /* upper bound of records in the dispatch buffer */
     uint32_t draw_capacity;     /* commands the draw buffer can hold */
+    uint32_t material_count;    /* entries in material_buffer (assets/mod.rs: materials arena);
+                                   0 = unknown.  Only an optimisation hint: when given (<= 4096)
+                                   the alpha modes are staged in LDS instead of gathered. */
+    uint32_t _pad;
 } OrbitMeshletCullBufs;
 
 /* The record count is read on the device from the dispatch header — the

@@ -43,7 +43,7 @@ class MeshletCullBufs(C.Structure):
                 ("draw_commands_buffer", C.c_void_p), ("entity_buffer", C.c_void_p), ("material_buffer", C.c_void_p),
                 ("meshlet_visibility_buffer", C.c_void_p), ("depth_pyramid", C.c_void_p),
                 ("depth_pyramid_size", C.c_uint32 * 2), ("dispatch_capacity", C.c_uint32),
-                ("draw_capacity", C.c_uint32)]
+                ("draw_capacity", C.c_uint32), ("material_count", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 class DepthPyramidDesc(C.Structure):

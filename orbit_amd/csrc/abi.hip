@@ -27,6 +27,8 @@ struct OrbitCtx {
     size_t arena_bytes = 0;
     OrbitMeshletDispatch *e_proto = nullptr;
     uint32_t *e_block_sums = nullptr, *e_block_base = nullptr, *e_total = nullptr;
+    uint32_t *m_tile_payload = nullptr;
+    uint32_t *m_tile_masks = nullptr, *m_chunk_sums = nullptr, *m_chunk_base = nullptr;
     uint32_t *m_tile_counts = nullptr, *m_tile_base = nullptr, *m_total = nullptr;
     uint64_t *m_scan_state = nullptr;
     uint32_t *m_ticket = nullptr;
@@ -35,7 +37,10 @@ struct OrbitCtx {
     uint32_t *a_light_flags = nullptr, *a_counts = nullptr, *a_block_sums = nullptr, *a_block_base = nullptr,
              *a_total = nullptr;
     int32_t *status = nullptr;
-    int meshlet_mode = 1; // 1 = single-pass look-back (default), 0 = count/scan/emit (ORBIT_MESHLET_TWO_PASS=1)
+    uint32_t debug_flags = 0;
+    unsigned long long *debug_cycles = nullptr;
+    void *zero_page = nullptr;
+    int meshlet_mode = 0; // 0 = eval/scan/emit (default), 1 = single-launch look-back (ORBIT_MESHLET_LOOKBACK=1)
     char err[512] = {0};
 };
 
@@ -168,10 +173,16 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
         return o;
     };
     const size_t o_status = carve(256);
+    const size_t o_dbg = carve(256);
+    const size_t o_zero = carve(256);
     const size_t o_eproto = carve(ent * sizeof(OrbitMeshletDispatch));
     const size_t o_ebs = carve(eblocks * 4), o_ebb = carve(eblocks * 4), o_et = carve(256);
     const size_t o_mtc = carve(mtiles * 4), o_mtb = carve(mtiles * 4), o_mt = carve(256);
     const size_t o_mss = carve(mtiles * 8), o_mtk = carve(256);
+    const size_t o_mtm = carve(mtiles * 64);
+    const size_t o_mtp = carve(mtiles * 128 * 12);
+    const size_t mchunks = mtiles / kScanChunk + 2;
+    const size_t o_mcs = carve(mchunks * 4), o_mcb = carve(mchunks * 4);
     const size_t o_cc = carve((2 * cchunks + 64) * 4);
     const size_t o_avl = carve((size_t)caps.max_lights * 16 + 1024);
     const size_t o_alf = carve(((size_t)caps.max_lights / 32 + 64) * 4);
@@ -191,6 +202,8 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     }
     uint8_t *a = ctx->arena;
     ctx->status = (int32_t *)(a + o_status);
+    ctx->debug_cycles = (unsigned long long *)(a + o_dbg);
+    ctx->zero_page = (void *)(a + o_zero);
     ctx->e_proto = (OrbitMeshletDispatch *)(a + o_eproto);
     ctx->e_block_sums = (uint32_t *)(a + o_ebs);
     ctx->e_block_base = (uint32_t *)(a + o_ebb);
@@ -200,6 +213,10 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->m_total = (uint32_t *)(a + o_mt);
     ctx->m_scan_state = (uint64_t *)(a + o_mss);
     ctx->m_ticket = (uint32_t *)(a + o_mtk);
+    ctx->m_tile_masks = (uint32_t *)(a + o_mtm);
+    ctx->m_tile_payload = (uint32_t *)(a + o_mtp);
+    ctx->m_chunk_sums = (uint32_t *)(a + o_mcs);
+    ctx->m_chunk_base = (uint32_t *)(a + o_mcb);
     ctx->c_chunk = (uint32_t *)(a + o_cc);
     ctx->a_view_lights = (float4 *)(a + o_avl);
     ctx->a_light_flags = (uint32_t *)(a + o_alf);
@@ -215,8 +232,10 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
         delete ctx;
         return hip_fail(nullptr, e, "hipMemcpy(scan control words)");
     }
-    const char *two_pass = getenv("ORBIT_MESHLET_TWO_PASS");
-    ctx->meshlet_mode = (two_pass && two_pass[0] == '1') ? 0 : 1;
+    const char *lookback = getenv("ORBIT_MESHLET_LOOKBACK");
+    ctx->meshlet_mode = (lookback && lookback[0] == '1') ? 1 : 0;
+    const char *dbg = getenv("ORBIT_SP_DEBUG");
+    ctx->debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u;
     snprintf(ctx->err, sizeof(ctx->err), "no error");
     *out_ctx = ctx;
     return ORBIT_OK;
@@ -248,6 +267,15 @@ int32_t orbit_ctx_status(OrbitCtx *ctx, void *stream, int32_t sync) {
         return fail(ctx, v, v == ORBIT_E_CAPACITY ? "an append overflowed a caller buffer (entries dropped)"
                                                    : "device-latched error %d", v);
     }
+    return ORBIT_OK;
+}
+
+// perf triage only (not part of the public ABI): reads and clears the per-phase cycle sums
+int32_t orbit_debug_read_cycles(OrbitCtx *ctx, unsigned long long out[8]) {
+    if (!ctx || !out) return ORBIT_E_INVALID;
+    if (hipDeviceSynchronize() != hipSuccess) return ORBIT_E_HIP;
+    if (hipMemcpy(out, ctx->debug_cycles, 64, hipMemcpyDeviceToHost) != hipSuccess) return ORBIT_E_HIP;
+    if (hipMemset(ctx->debug_cycles, 0, 64) != hipSuccess) return ORBIT_E_HIP;
     return ORBIT_OK;
 }
 
@@ -331,11 +359,19 @@ int32_t orbit_meshlet_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbi
     p.pyr = make_pyramid_view(b->depth_pyramid, b->depth_pyramid_size);
     p.dispatch_capacity = b->dispatch_capacity;
     p.draw_capacity = b->draw_capacity;
+    p.material_count = b->material_count;
     p.tile_counts = ctx->m_tile_counts;
+    p.tile_masks = ctx->m_tile_masks;
+    p.tile_payload = ctx->m_tile_payload;
     p.tile_base = ctx->m_tile_base;
+    p.chunk_sums = ctx->m_chunk_sums;
+    p.chunk_base = ctx->m_chunk_base;
     p.total = ctx->m_total;
     p.scan_state = ctx->m_scan_state;
     p.ticket = ctx->m_ticket;
+    p.debug_flags = ctx->debug_flags;
+    p.debug_cycles = ctx->debug_cycles;
+    p.zero_page = ctx->zero_page;
     p.status = ctx->status;
     hipError_t e = launch_meshlet_cull(p, ctx->num_cus, ctx->meshlet_mode, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_cull");

@@ -44,12 +44,20 @@ struct MeshletCullParams {
     PyramidView pyr;
     uint32_t dispatch_capacity;
     uint32_t draw_capacity;
+    uint32_t material_count; // 0 = unknown (gather alpha modes), else entries in `materials`
     // context scratch
     uint32_t *tile_counts;
-    uint32_t *tile_base;
+    uint32_t *tile_payload; // 128 x 3 words per wave tile: survivors' Meshlet words 5..7 in tile-local order
+    uint32_t *tile_masks; // 16 words (8 x 64-bit should-draw ballots) per wave tile
+    uint32_t *tile_base;   // chunk-local exclusive prefix of tile_counts
+    uint32_t *chunk_sums;  // per kScanChunk tiles
+    uint32_t *chunk_base;
     uint32_t *total;
     uint64_t *scan_state; // single-pass mode: one {status,value} granule per wave tile
     uint32_t *ticket;     // single-pass mode: {ticket, done, epoch}
+    const void *zero_page; // 256 zero bytes of context scratch: target of inactive lanes' loads
+    unsigned long long *debug_cycles; // ORBIT_SP_DEBUG & 8: per-phase s_memtime sums (8 slots)
+    uint32_t debug_flags; // ORBIT_SP_DEBUG (perf triage only): 8 = per-phase cycle stamps (pass 0 only)
     int32_t *status;
 };
 
@@ -105,6 +113,12 @@ hipError_t launch_cluster_assign(const ClusterAssignParams &p, hipStream_t s);
 
 // Exclusive scan of `n` words by one 1024-thread block; *total = sum.
 hipError_t launch_scan_exclusive(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, hipStream_t s);
+// Two-level variant for long inputs: out_local[i] is the exclusive prefix inside
+// chunk i / kScanChunk, chunk_base[c] the exclusive prefix of chunk c; n as below.
+constexpr uint32_t kScanChunk = 4096;
+hipError_t launch_scan_two_level(const uint32_t *in, uint32_t *out_local, const uint32_t *n_src, uint32_t div,
+                                 uint32_t n_max, uint32_t *chunk_sums, uint32_t *chunk_base, uint32_t *total,
+                                 hipStream_t s);
 // Same, with n read on the device: n = min(ceil(*n_src / div), n_max).
 hipError_t launch_scan_exclusive_indirect(const uint32_t *in, uint32_t *out, const uint32_t *n_src, uint32_t div,
                                           uint32_t n_max, uint32_t *total, hipStream_t s);

@@ -18,8 +18,8 @@
 //   visibility = the two 32-bit halves of the wave64 ballot are the two records'
 //                visibility words (word = visibility_offset + lane/32, S = 32).
 //
-// Tile bases come from either (mode 0) a count launch + scan + emit launch,
-// or (mode 1) a single launch with a decoupled look-back over tile granules.
+// Tile bases come from (mode 0, default) an eval launch + scan + emit launch, or
+// (mode 1, ORBIT_MESHLET_LOOKBACK=1) a single launch with a decoupled look-back.
 #include "kernels.h"
 #include "scan.h"
 
@@ -27,22 +27,80 @@ namespace orbit {
 
 namespace {
 
-constexpr int kWavesPerBlock = 4;
-constexpr int kBlock = kWavesPerBlock * 64;
-
-enum { MODE_COUNT = 0, MODE_EMIT = 1 };
+// survivors per tile whose command words are cached by meshlet_eval for the emit launch
+constexpr uint32_t kPayloadCap = 128;
 
 struct __attribute__((aligned(16))) WaveTileLds {
     float4 mcol[kTileRecords][4]; // view x model, column-major, per record
     uint4 rec[kTileRecords];      // MeshletDispatch
     float scale[kTileRecords];    // largest_scale_from_matrix(mat3(M))
+    uint64_t draw_mask[kTileRows]; // should-draw ballots of the tile's rows (kept here, not in SGPRs)
 };
 
+// The cull planes live in LDS (one copy per block, written once): a row reads
+// them as back-to-back broadcast ds_read_b128 instead of one scalar load + full
+// wait per plane per row.
+struct __attribute__((aligned(16))) PlaneLds {
+    float4 plane[ORBIT_MAX_CULL_PLANES];
+};
+
+__device__ __forceinline__ void planes_to_lds(const OrbitGpuCullInfo &ci, PlaneLds &P) {
+    if (threadIdx.x < ORBIT_MAX_CULL_PLANES) {
+        const float *pl = ci.cull_planes[threadIdx.x];
+        P.plane[threadIdx.x] = make_float4(pl[0], pl[1], pl[2], pl[3]);
+    }
+}
+
+// Plane loop, meshlet_cull.comp:139-146, planes from LDS in batches of three
+// back-to-back broadcast reads (one wait per batch); a plane past the count
+// contributes `true` through a scalar mask, never through its arithmetic.
+__device__ __forceinline__ bool plane_test_lds(const PlaneLds &P, uint32_t n, const Sphere &s) {
+    bool visible = true;
+#pragma unroll
+    for (uint32_t base = 0; base < ORBIT_MAX_CULL_PLANES; base += 3) {
+        if (base < n) { // wave-uniform
+            float4 pl[3];
+#pragma unroll
+            for (uint32_t i = 0; i < 3; i++) pl[i] = P.plane[base + i];
+#pragma unroll
+            for (uint32_t i = 0; i < 3; i++) {
+                const float d = dot3(pl[i].x, pl[i].y, pl[i].z, s.x, s.y, s.z) + pl[i].w;
+                visible = visible && ((d > -s.r) || (base + i >= n));
+            }
+        }
+    }
+    return visible;
+}
+
+// NR rows of a tile in flight: 2 x 16 B per lane per row (+ previous-frame words).
+template <int NR>
+struct RowRegs {
+    uint4 a[NR], b[NR];
+    uint32_t prev[NR];
+};
+using TileRegs = RowRegs<kTileRows>;
+
+// materials[i].alpha_mode (:124): from a per-block LDS table when the caller
+// states the material count (<= kAlphaTable entries), else a global gather.
+constexpr uint32_t kAlphaTable = 4096;
+struct AlphaLds {
+    uint8_t mode[kAlphaTable];
+};
+
+__device__ __forceinline__ bool alpha_table_fill(const MeshletCullParams &p, AlphaLds &A) {
+    const bool use = p.material_count != 0u && p.material_count <= kAlphaTable;
+    if (use)
+        for (uint32_t i = threadIdx.x; i < p.material_count; i += blockDim.x)
+            A.mode[i] = (uint8_t)min(p.materials[i].alpha_mode, 255u); // >= 32 shifts to 0 either way (shl1)
+    return use;
+}
+
 // One meshlet (one lane): meshlet_cull.comp:113-213.  Returns bit0 = visible,
-// bit1 = should_draw.
-__device__ __forceinline__ uint32_t eval_meshlet(const MeshletCullParams &p, const WaveTileLds &L, uint32_t rid,
-                                                 const uint4 &a, const uint4 &b, bool visible_in_buffer,
-                                                 bool meshlet_occ) {
+// bit1 = should_draw.  PASS = cull_info.occlusion_pass (compile-time).
+template <int PASS>
+__device__ __forceinline__ uint32_t eval_meshlet(const MeshletCullParams &p, const WaveTileLds &L,
+                                                 const PlaneLds &P, uint32_t rid, const uint4 &a, const uint4 &b,
+                                                 uint32_t alpha_mode, bool visible_in_buffer, bool meshlet_occ) {
     const OrbitGpuCullInfo &ci = p.ci;
     const float4 m0 = L.mcol[rid][0], m1 = L.mcol[rid][1], m2 = L.mcol[rid][2], m3 = L.mcol[rid][3];
     const float cx = __uint_as_float(a.x), cy = __uint_as_float(a.y), cz = __uint_as_float(a.z);
@@ -71,13 +129,10 @@ __device__ __forceinline__ uint32_t eval_meshlet(const MeshletCullParams &p, con
     const float axy = ((m0.y * ax + m1.y * ay) + m2.y * az) + m3.y * 0.0f;
     const float axz = ((m0.z * ax + m1.z * ay) + m2.z * az) + m3.z * 0.0f;
 
-    const uint32_t material_index = b.w & 0xFFFFu;
-    const uint32_t alpha_mode = p.materials[material_index].alpha_mode; // :124
-
     bool visible = true;
-    if (ci.occlusion_pass == 1) visible = visible_in_buffer; // :137
-    if (visible) visible = plane_test(ci, s);                 // :139-146
-    if (visible) {                                            // :148-158
+    if (PASS == 1) visible = visible_in_buffer;   // :137
+    if (visible) visible = plane_test_lds(P, ci.cull_plane_count, s); // :139-146
+    if (visible) {                                 // :148-158
         float camx = 0.0f, camy = 0.0f, camz = 0.0f;
         if (ci.projection_type == 1) {
             camx = s.x - 0.0f;
@@ -88,27 +143,241 @@ __device__ __forceinline__ uint32_t eval_meshlet(const MeshletCullParams &p, con
         const bool cull = dot3(dx, dy, dz, axx, axy, axz) >= cutoff * sqrtf(dot3(dx, dy, dz, dx, dy, dz)) + s.r;
         visible = !cull;
     }
-    if (meshlet_occ && ci.occlusion_pass == 2 && visible) visible = occlusion_test(ci, s, p.pyr); // :161-205
+    if (PASS == 2 && meshlet_occ && visible) visible = occlusion_test(ci, s, p.pyr); // :161-205
 
     bool should_draw = visible && ((shl1(alpha_mode) & ci.alpha_mode_flag) != 0); // :207
-    if ((ci.occlusion_pass == 2 && meshlet_occ) && !((shl1(alpha_mode) & ci.noskip_alphamode) != 0))
+    if ((PASS == 2 && meshlet_occ) && !((shl1(alpha_mode) & ci.noskip_alphamode) != 0))
         should_draw = visible && !visible_in_buffer; // :210-213
     return (visible ? 1u : 0u) | (should_draw ? 2u : 0u);
 }
 
-// Builds the tile's 16 (view x model) matrices with all 64 lanes.
-__device__ __forceinline__ void tile_setup(const MeshletCullParams &p, WaveTileLds &L, uint32_t tile, uint32_t nrec,
-                                           int lane) {
+// Issues the meshlet loads of rows R0 .. R0+NR-1 of a tile (2 x 16 B per lane per row).
+template <int PASS, int R0, int NR>
+__device__ __forceinline__ void rows_load(const MeshletCullParams &p, const WaveTileLds &L, int lane,
+                                          RowRegs<NR> &t) {
+    const bool meshlet_occ = p.ci.meshlet_visibility_buffer != ORBIT_NONE;
+    const bool rw_vis = PASS != 0 && meshlet_occ;
+    const uint32_t half = lane >> 5, ml = lane & 31;
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        const uint4 rec = L.rec[2 * (R0 + k) + half];
+        // straight-line loads (exact vmcnt accounting): lanes past meshlet_count (:111) read the zero page
+        const bool active = ml < rec.z;
+        const uint4 *src = active ? reinterpret_cast<const uint4 *>(p.meshlets + (rec.y + ml))
+                                  : reinterpret_cast<const uint4 *>(p.zero_page);
+        t.a[k] = src[0];
+        t.b[k] = src[1];
+        t.prev[k] = 0u;
+        if (PASS != 0) { // word = visibility_offset + lane/32, :129-134
+            const uint32_t *vp = (rw_vis && active) ? p.meshlet_visibility + rec.w
+                                                    : reinterpret_cast<const uint32_t *>(p.zero_page);
+            t.prev[k] = *vp;
+        }
+    }
+}
+
+// Evaluates rows R0 .. R0+NR-1 of a tile: should-draw ballots into the slab,
+// survivor payload (optional), pass-2 visibility words (WRITE_VIS).  `total` is
+// the tile's running survivor count; the new count is returned.
+template <int PASS, bool WRITE_VIS, int R0, int NR>
+__device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
+                                              const AlphaLds *A, int lane, const RowRegs<NR> &t, uint32_t total,
+                                              uint32_t *payload) {
+    const bool meshlet_occ = p.ci.meshlet_visibility_buffer != ORBIT_NONE;
+    const bool rw_vis = PASS != 0 && meshlet_occ;
+    const uint32_t half = lane >> 5, ml = lane & 31;
+    // Inactive lanes carry material 0 from the zero page (in bounds; result unused).
+    uint32_t alpha[NR];
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        const uint32_t mi = t.b[k].w & 0xFFFFu;
+        alpha[k] = A ? (uint32_t)A->mode[mi & (kAlphaTable - 1u)] : p.materials[mi].alpha_mode;
+    }
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        const int r = R0 + k;
+        const uint32_t rid = 2 * r + half;
+        const uint4 rec = L.rec[rid];
+        const bool active = ml < rec.z;
+        uint32_t res = 0;
+        if (active) {
+            const bool visible_in_buffer = rw_vis ? ((t.prev[k] >> ml) & 1u) != 0 : true;
+            res = eval_meshlet<PASS>(p, L, P, rid, t.a[k], t.b[k], alpha[k], visible_in_buffer, meshlet_occ);
+        }
+        const uint64_t mask = __ballot((res & 2u) != 0);
+        if (lane == 0) L.draw_mask[r] = mask;
+        if (payload && ((mask >> lane) & 1ull)) {
+            // survivor payload: Meshlet words 5..7 at the tile-local rank, so the emit
+            // launch reads them back contiguously instead of gathering 16 B per survivor
+            const uint32_t rank = total + lane_prefix(mask);
+            if (rank < kPayloadCap) {
+                uint32_t *dst = payload + (size_t)rank * 3u;
+                dst[0] = t.b[k].y;
+                dst[1] = t.b[k].z;
+                dst[2] = t.b[k].w;
+            }
+        }
+        total += (uint32_t)__popcll(mask);
+        if (PASS == 2 && WRITE_VIS) {
+            // pass-2 visibility words (:233-254); records with no lane write nothing
+            const uint64_t vis_mask = __ballot((res & 1u) != 0);
+            if (meshlet_occ && ml == 0 && rec.z > 0)
+                p.meshlet_visibility[rec.w] = half ? (uint32_t)(vis_mask >> 32) : (uint32_t)vis_mask;
+        }
+    }
+    return total;
+}
+
+// Whole-tile forms (look-back kernel).
+template <int PASS>
+__device__ __forceinline__ void tile_load(const MeshletCullParams &p, const WaveTileLds &L, int lane, TileRegs &t) {
+    rows_load<PASS, 0, kTileRows>(p, L, lane, t);
+}
+template <int PASS, bool WRITE_VIS>
+__device__ __forceinline__ uint32_t tile_eval(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
+                                              const AlphaLds *A, int lane, const TileRegs &t) {
+    return rows_eval<PASS, WRITE_VIS, 0, kTileRows>(p, L, P, A, lane, t, 0u, nullptr);
+}
+
+// Writes the tile's surviving commands at [base, base + total) (:216-230).
+// The survivor's command words (Meshlet bytes 16..31) are re-read here: they
+// were streamed a few microseconds ago and are L2/MALL resident, and not
+// carrying them across the look-back keeps the registers free for the next
+// tile's loads, which are already in flight at this point.
+__device__ __forceinline__ void tile_emit(const MeshletCullParams &p, const WaveTileLds &L, int lane,
+                                          uint32_t base) {
+    uint32_t *out = reinterpret_cast<uint32_t *>(p.draw_buffer + ORBIT_DRAW_HEADER);
+    const uint32_t half = lane >> 5, ml = lane & 31;
+    uint32_t row_base = base;
+#pragma unroll
+    for (int r = 0; r < (int)kTileRows; r++) {
+        const uint64_t mask = L.draw_mask[r]; // uniform address: broadcast read
+        if ((mask >> lane) & 1ull) {
+            const uint32_t slot = row_base + lane_prefix(mask);
+            if (slot < p.draw_capacity) {
+                const uint4 rec = L.rec[2 * r + half];
+                const uint4 b = reinterpret_cast<const uint4 *>(p.meshlets + (rec.y + ml))[1];
+                const uint32_t vertex_count = (b.w >> 16) & 0xFFu;
+                const uint32_t triangle_count = b.w >> 24;
+                uint32_t *c = out + (size_t)slot * 7u;
+                c[0] = triangle_count * 3u;       // cmd_index_count
+                c[1] = 1u;                        // cmd_instance_count
+                c[2] = (b.z + vertex_count) * 4u; // cmd_first_index
+                c[3] = b.z;                       // cmd_vertex_offset = int(data_offset)
+                c[4] = rec.x;                     // cmd_first_instance = entity_index
+                c[5] = b.y;                       // meshlet_vertex_offset
+                c[6] = rec.y + ml;                // meshlet_index
+            }
+        }
+        row_base += (uint32_t)__popcll(mask);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Mode 1: one launch, ordered compaction by a decoupled look-back scan over
+// per-wave-tile granules.
+//
+//  * tile order comes from a ticket per BLOCK iteration (kSpWaves adjacent wave
+//    tiles per ticket): one returning atomic on one address saturates near 88/us
+//    on MI355X (MI355X_MICROARCH.md "dequeue"), so a ticket per 512-meshlet wave
+//    tile (98 k at 50 M meshlets) would cost more than the whole kernel; a ticket
+//    per 8192 meshlets is ~20/us.  A wave that waits on tile j only ever waits
+//    on tickets drawn before its own, i.e. on running or finished blocks — no
+//    residency or dispatch-order assumption.
+//  * the waves of a block are autonomous: there is no block barrier in the loop.
+//    The ticket of block iteration i is drawn by whichever wave needs it first
+//    and handed to the other waves through a small LDS ring.
+//  * software pipeline per wave: the NEXT tile's records, matrices and all of
+//    its meshlet loads are issued BEFORE the current tile's look-back, so the
+//    look-back latency and the dependent-load chain of the next tile overlap.
+//  * granule = one naturally aligned 8-byte {epoch:30 | status:2 | value:32}
+//    written by ONE relaxed agent-scope store and polled with relaxed
+//    agent-scope loads (cdna_hip_programming.md Guideline 16, recipe R2: the
+//    data is the flag, no fence).  The epoch (a device word bumped by the last
+//    block to finish) makes stale granules of earlier launches read as INVALID,
+//    so no per-launch memset and the launch is graph-replay safe.
+//  * every spin is bounded; on give-up ORBIT_E_TIMEOUT is latched and the tile
+//    proceeds with base 0 (wrong output, flagged) instead of hanging the GPU.
+constexpr int kSpWaves = 16; // waves per block = wave tiles per ticket
+constexpr int kSpBlock = kSpWaves * 64;
+constexpr int kRing = 8; // ticket ring depth (power of two); the pipeline looks 3 tickets ahead
+constexpr uint32_t ST_INVALID = 0u, ST_AGG = 1u, ST_PREFIX = 2u;
+constexpr uint32_t kSpinLimit = 1u << 22;
+
+struct TicketRing {
+    uint32_t seq[kRing];  // 2*(it+1) = READY for block iteration it, 2*(it+1)-1 = being drawn
+    uint32_t val[kRing];  // the ticket (tile row)
+    uint32_t cons[kRing]; // waves that have read val for the current occupant
+    uint32_t exited;
+};
+
+#define LDS_LOAD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define LDS_STORE(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+
+// Ticket (tile row) of block iteration `it`, identical for every wave of the block.
+__device__ __forceinline__ uint32_t ring_get(TicketRing &R, uint32_t it, uint32_t *global_ticket, int lane,
+                                             int32_t *status) {
+    uint32_t row = 0;
+    if (lane == 0) {
+        const uint32_t slot = it & (kRing - 1);
+        const uint32_t ready = 2u * (it + 1u), drawing = ready - 1u;
+        const uint32_t prev_ready = it >= (uint32_t)kRing ? 2u * (it - kRing + 1u) : 0u;
+        uint32_t spins = 0;
+        for (;;) {
+            const uint32_t s = LDS_LOAD(&R.seq[slot]);
+            if (s == ready) break;
+            if (s == prev_ready && (it < (uint32_t)kRing || LDS_LOAD(&R.cons[slot]) == (uint32_t)kSpWaves)) {
+                // the slot's previous occupant has been read by every wave: claim the draw
+                if (atomicCAS(&R.seq[slot], prev_ready, drawing) == prev_ready) {
+                    LDS_STORE(&R.cons[slot], 0u);
+                    const uint32_t t = atomicAdd(global_ticket, 1u);
+                    LDS_STORE(&R.val[slot], t);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    LDS_STORE(&R.seq[slot], ready);
+                    break;
+                }
+            }
+            if (++spins > kSpinLimit) {
+                latch_status(status, ORBIT_E_TIMEOUT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        row = LDS_LOAD(&R.val[slot]);
+        atomicAdd(&R.cons[slot], 1u);
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)row);
+}
+
+__device__ __forceinline__ uint64_t make_granule(uint32_t epoch, uint32_t status, uint32_t value) {
+    return ((uint64_t)epoch << 34) | ((uint64_t)status << 32) | (uint64_t)value;
+}
+
+// Split tile setup (see the pipeline in the kernel): record load, model-column
+// load, (view x model) product + LDS slab write.
+__device__ __forceinline__ uint4 setup_load_rec(const MeshletCullParams &p, uint32_t tile, bool tile_valid,
+                                                uint32_t nrec, int lane) {
     const OrbitMeshletDispatch *recs =
         reinterpret_cast<const OrbitMeshletDispatch *>(p.dispatch_buffer + ORBIT_DISPATCH_HEADER);
+    const uint32_t rec_index = tile * kTileRecords + (uint32_t)(lane >> 2);
+    // unconditional load (exact vmcnt accounting): lanes without a record read the zero page
+    const bool has = tile_valid && rec_index < nrec;
+    const uint4 *src = has ? reinterpret_cast<const uint4 *>(recs + rec_index)
+                           : reinterpret_cast<const uint4 *>(p.zero_page);
+    return *src;
+}
+
+__device__ __forceinline__ float4 setup_load_mat(const MeshletCullParams &p, const uint4 &rec, int lane) {
+    // meshlet_count == 0 marks "no record" (zero page above): read zeros instead of entity 0
+    const float4 *src = rec.z != 0u ? reinterpret_cast<const float4 *>(p.entities[rec.x].model_matrix) + (lane & 3)
+                                    : reinterpret_cast<const float4 *>(p.zero_page);
+    return *src;
+}
+
+__device__ __forceinline__ void setup_write(const MeshletCullParams &p, WaveTileLds &L, const uint4 &rec,
+                                            const float4 &mc, int lane) {
     const uint32_t rid = lane >> 2, col = lane & 3;
-    const uint32_t rec_index = tile * kTileRecords + rid;
-    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-    float4 mc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (rec_index < nrec) {
-        rec = *reinterpret_cast<const uint4 *>(recs + rec_index);
-        mc = reinterpret_cast<const float4 *>(p.entities[rec.x].model_matrix)[col];
-    }
     float o[4];
     mat4_mul_col(p.ci.view_matrix, mc.x, mc.y, mc.z, mc.w, o);
     L.mcol[rid][col] = make_float4(o[0], o[1], o[2], o[3]);
@@ -125,154 +394,22 @@ __device__ __forceinline__ void tile_setup(const MeshletCullParams &p, WaveTileL
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Evaluates the 8 rows of a tile.  Fills the should-draw masks; WRITE_VIS also
-// writes the pass-2 visibility words.
-template <bool WRITE_VIS>
-__device__ __forceinline__ uint32_t tile_rows(const MeshletCullParams &p, const WaveTileLds &L, int lane,
-                                              uint64_t draw_mask[kTileRows]) {
-    const OrbitGpuCullInfo &ci = p.ci;
-    const bool meshlet_occ = ci.meshlet_visibility_buffer != ORBIT_NONE;
-    const bool rw_vis = (ci.occlusion_pass == 1 || ci.occlusion_pass == 2) && meshlet_occ;
-    const uint32_t half = lane >> 5, ml = lane & 31;
-    uint32_t total = 0;
-
-    // issue all meshlet loads of the tile first: 16 x 16 B per lane in flight
-    uint4 a[kTileRows], b[kTileRows];
-    uint32_t prev[kTileRows];
-#pragma unroll
-    for (int r = 0; r < (int)kTileRows; r++) {
-        const uint4 rec = L.rec[2 * r + half];
-        a[r] = make_uint4(0u, 0u, 0u, 0u);
-        b[r] = make_uint4(0u, 0u, 0u, 0u);
-        prev[r] = 0u;
-        if (ml < rec.z) { // :111
-            const uint4 *src = reinterpret_cast<const uint4 *>(p.meshlets + (rec.y + ml));
-            a[r] = src[0];
-            b[r] = src[1];
-            if (rw_vis) prev[r] = p.meshlet_visibility[rec.w]; // word = visibility_offset + lane/32, :129-134
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < (int)kTileRows; r++) {
-        const uint32_t rid = 2 * r + half;
-        const uint4 rec = L.rec[rid];
-        const bool active = ml < rec.z;
-        uint32_t res = 0;
-        if (active) {
-            const bool visible_in_buffer = rw_vis ? ((prev[r] >> ml) & 1u) != 0 : true;
-            res = eval_meshlet(p, L, rid, a[r], b[r], visible_in_buffer, meshlet_occ);
-        }
-        const uint64_t vis_mask = __ballot((res & 1u) != 0);
-        const uint64_t mask = __ballot((res & 2u) != 0);
-        draw_mask[r] = mask;
-        total += (uint32_t)__popcll(mask);
-        if (WRITE_VIS) {
-            // pass-2 visibility words (:233-254); records with no lane write nothing
-            if (ci.occlusion_pass == 2 && meshlet_occ && ml == 0 && rec.z > 0)
-                p.meshlet_visibility[rec.w] = half ? (uint32_t)(vis_mask >> 32) : (uint32_t)vis_mask;
-        }
-    }
-    return total;
+// First look-back window: granules w-1-lane (lane 0 = nearest predecessor).
+__device__ __forceinline__ uint64_t look_back_issue(const MeshletCullParams &p, uint32_t w, int lane) {
+    int64_t idx = (int64_t)w - 1 - lane;
+    if (idx < 0) idx = 0; // out-of-range lanes are masked by the resolver; keep the load unconditional
+    return __hip_atomic_load(p.scan_state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Writes the tile's surviving commands at [base, base + total) (:216-230).
-// The survivor's command words (Meshlet bytes 16..31) are re-read here: they
-// were streamed a few microseconds ago and are L2/MALL resident, and not
-// carrying them across the look-back keeps the kernel at 4 waves per SIMD.
-__device__ __forceinline__ void tile_emit(const MeshletCullParams &p, const WaveTileLds &L, int lane, uint32_t base,
-                                          const uint64_t draw_mask[kTileRows]) {
-    uint32_t *out = reinterpret_cast<uint32_t *>(p.draw_buffer + ORBIT_DRAW_HEADER);
-    const uint32_t half = lane >> 5, ml = lane & 31;
-    uint32_t row_base = base;
-#pragma unroll
-    for (int r = 0; r < (int)kTileRows; r++) {
-        const uint64_t mask = draw_mask[r];
-        if ((mask >> lane) & 1ull) {
-            const uint32_t slot = row_base + lane_prefix(mask);
-            if (slot < p.draw_capacity) {
-                const uint4 rec = L.rec[2 * r + half];
-                const uint4 b = reinterpret_cast<const uint4 *>(p.meshlets + (rec.y + ml))[1];
-                const uint32_t vertex_count = (b.w >> 16) & 0xFFu;
-                const uint32_t triangle_count = b.w >> 24;
-                uint32_t *c = out + (size_t)slot * 7u;
-                c[0] = triangle_count * 3u;           // cmd_index_count
-                c[1] = 1u;                            // cmd_instance_count
-                c[2] = (b.z + vertex_count) * 4u;     // cmd_first_index
-                c[3] = b.z;                           // cmd_vertex_offset = int(data_offset)
-                c[4] = rec.x;                         // cmd_first_instance = entity_index
-                c[5] = b.y;                           // meshlet_vertex_offset
-                c[6] = rec.y + ml;                    // meshlet_index
-            }
-        }
-        row_base += (uint32_t)__popcll(mask);
-    }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void meshlet_cull_two_pass(const MeshletCullParams p) {
-    __shared__ WaveTileLds lds[kWavesPerBlock];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    WaveTileLds &L = lds[wave];
-    const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
-    const uint32_t ntiles = (nrec + kTileRecords - 1) / kTileRecords;
-    for (uint32_t tile = blockIdx.x * kWavesPerBlock + wave; tile < ntiles; tile += gridDim.x * kWavesPerBlock) {
-        tile_setup(p, L, tile, nrec, lane);
-        uint64_t draw_mask[kTileRows];
-        const uint32_t total = tile_rows<MODE == MODE_EMIT>(p, L, lane, draw_mask);
-        if (MODE == MODE_COUNT) {
-            if (lane == 0) p.tile_counts[tile] = total;
-        } else {
-            tile_emit(p, L, lane, p.tile_base[tile], draw_mask);
-        }
-        __builtin_amdgcn_wave_barrier(); // LDS slab is reused by the next tile
-    }
-    if (MODE == MODE_EMIT && blockIdx.x == 0 && threadIdx.x == 0) {
-        // `count` header: subsumes the fill_buffer(count = 0) of draw_gen.rs:411-417
-        const uint32_t total = *p.total;
-        *reinterpret_cast<uint32_t *>(p.draw_buffer) = min(total, p.draw_capacity);
-        if (total > p.draw_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Single-pass mode: one launch, ordered compaction by a decoupled look-back
-// scan over per-wave-tile granules.
-//
-//  * tile order comes from a ticket per BLOCK iteration (kSpWaves adjacent wave
-//    tiles per ticket): one returning atomic on one address saturates near 88/us
-//    on MI355X (MI355X_MICROARCH.md "dequeue"), so a ticket per 512-meshlet wave
-//    tile (98 k at 50 M meshlets) would cost more than the whole kernel; a ticket
-//    per 8192 meshlets is ~20/us.  A block that waits on tile j only ever waits
-//    on tickets drawn before its own, i.e. on running or finished blocks — no
-//    residency or dispatch-order assumption.
-//  * granule = one naturally aligned 8-byte {epoch:30 | status:2 | value:32}
-//    written by ONE relaxed agent-scope store and polled with relaxed
-//    agent-scope loads (cdna_hip_programming.md Guideline 16, recipe R2: the
-//    data is the flag, no fence).  The epoch (a device word bumped by the last
-//    block to finish) makes stale granules of earlier launches read as INVALID,
-//    so no per-launch memset and the launch is graph-replay safe.
-//  * every spin is bounded; on give-up ORBIT_E_TIMEOUT is latched and the tile
-//    proceeds with base 0 (wrong output, flagged) instead of hanging the GPU.
-constexpr int kSpWaves = 16;
-constexpr int kSpBlock = kSpWaves * 64;
-constexpr uint32_t ST_INVALID = 0u, ST_AGG = 1u, ST_PREFIX = 2u;
-constexpr uint32_t kSpinLimit = 1u << 22;
-
-__device__ __forceinline__ uint64_t make_granule(uint32_t epoch, uint32_t status, uint32_t value) {
-    return ((uint64_t)epoch << 34) | ((uint64_t)status << 32) | (uint64_t)value;
-}
-
-// Exclusive prefix of wave tile `w` (> 0): sums predecessor aggregates back to
-// the nearest published inclusive prefix, 64 granules per step.
-__device__ __forceinline__ uint32_t look_back(const MeshletCullParams &p, uint32_t w, uint32_t epoch, int lane) {
+// Exclusive prefix of wave tile `w` (> 0) given the already loaded first window.
+__device__ __forceinline__ uint32_t look_back_resolve(const MeshletCullParams &p, uint32_t w, uint32_t epoch,
+                                                      int lane, uint64_t g) {
     uint32_t exclusive = 0;
-    int64_t pos = (int64_t)w - 1; // nearest predecessor handled by lane 0
+    int64_t pos = (int64_t)w - 1;
     uint32_t spins = 0;
     for (;;) {
         const int64_t idx = pos - lane;
         const bool in_range = idx >= 0;
-        uint64_t g = 0;
-        if (in_range) g = __hip_atomic_load(p.scan_state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t st = (uint32_t)(g >> 32) & 3u;
         if ((uint32_t)(g >> 34) != epoch) st = ST_INVALID;
         if (!in_range) st = ST_PREFIX; // "before tile 0": an inclusive prefix of 0
@@ -281,81 +418,334 @@ __device__ __forceinline__ uint32_t look_back(const MeshletCullParams &p, uint32
         const uint64_t m_invalid = __ballot(st == ST_INVALID);
         const int first_prefix = m_prefix ? (int)__builtin_ctzll(m_prefix) : 64;
         const int first_invalid = m_invalid ? (int)__builtin_ctzll(m_invalid) : 64;
-        if (first_invalid < first_prefix) { // a needed predecessor has not published yet
+        if (first_invalid < first_prefix) { // a needed predecessor has not published yet: re-read the window
             if (++spins > kSpinLimit) {
                 if (lane == 0) latch_status(p.status, ORBIT_E_TIMEOUT);
                 return 0u;
             }
-            __builtin_amdgcn_s_sleep(2);
-            continue;
+            __builtin_amdgcn_s_sleep(1);
+        } else {
+            const uint32_t contrib = (lane <= first_prefix) ? val : 0u;
+            exclusive += wave_reduce_add(contrib);
+            if (first_prefix < 64) return exclusive;
+            pos -= 64;
         }
-        const uint32_t contrib = (lane <= first_prefix) ? val : 0u;
-        exclusive += wave_reduce_add(contrib);
-        if (first_prefix < 64) return exclusive;
-        pos -= 64;
+        g = 0;
+        if (pos - lane >= 0)
+            g = __hip_atomic_load(p.scan_state + (pos - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
+// Software pipeline of one wave (tile i = current):
+//
+//     eval(i)                       needs data(i) in registers, slab(i)
+//     publish AGG(i)
+//     issue  look-back window(i)    |  small, latency-critical loads FIRST: vmcnt
+//     issue  matrix loads (i+2)     |  retires in order, so they can be waited
+//     issue  record load  (i+3)     |  for without waiting for the bulk loads
+//     issue  data loads   (i+1)     16 x 16 B per lane, in flight across everything below
+//     write  slab(i+2)              (view x model) products -> LDS
+//     resolve look-back(i), publish PREFIX(i), emit(i)
+//
+// so the dependent chain record -> matrix -> meshlets -> ... of a tile is spread
+// over three iterations and every load has a full iteration to land; the only
+// exposed latency per tile is the look-back round trip, with data(i+1) in flight.
+template <int PASS, bool PROF>
 __global__ __launch_bounds__(kSpBlock) void meshlet_cull_single_pass(const MeshletCullParams p) {
-    __shared__ WaveTileLds lds[kSpWaves];
-    __shared__ uint32_t s_ticket;
+    __shared__ WaveTileLds lds[kSpWaves][3];
+    __shared__ TicketRing ring;
+    __shared__ PlaneLds planes;
+    __shared__ AlphaLds alpha_tab;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    WaveTileLds &L = lds[wave];
+    if (threadIdx.x < (int)(sizeof(TicketRing) / 4)) reinterpret_cast<uint32_t *>(&ring)[threadIdx.x] = 0u;
+    planes_to_lds(p.ci, planes);
+    const AlphaLds *alpha = alpha_table_fill(p, alpha_tab) ? &alpha_tab : nullptr;
+    __syncthreads();
     const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
     const uint32_t ntiles = (nrec + kTileRecords - 1) / kTileRecords;
     const uint32_t nrows = (ntiles + kSpWaves - 1) / kSpWaves;
     uint32_t *ctl = p.ticket; // {ticket, done, epoch}
     const uint32_t epoch = ctl[2];
-    for (;;) {
-        __syncthreads(); // previous iteration has consumed s_ticket
-        if (threadIdx.x == 0) s_ticket = atomicAdd(&ctl[0], 1u);
-        __syncthreads();
-        const uint32_t row = s_ticket;
-        if (row >= nrows) {
-            if (row == 0 && threadIdx.x == 0) *reinterpret_cast<uint32_t *>(p.draw_buffer) = 0u; // no records
-            break;
+
+    unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1;
+#define STAMP(k)                               \
+    if (PROF) {                                \
+        t1 = __builtin_amdgcn_s_memtime();     \
+        __builtin_amdgcn_s_waitcnt(0xC07F);    \
+        tc[k] += t1 - t0;                      \
+        t0 = t1;                               \
+    }
+
+    // ---- prologue: fill the pipeline (tiles 0, 1, 2 of this wave)
+    uint32_t it = 0;
+    uint32_t row0 = ring_get(ring, 0, &ctl[0], lane, p.status);
+    uint32_t row1 = ring_get(ring, 1, &ctl[0], lane, p.status);
+    uint32_t row2 = ring_get(ring, 2, &ctl[0], lane, p.status);
+    if (row0 == 0 && nrows == 0 && threadIdx.x == 0) *reinterpret_cast<uint32_t *>(p.draw_buffer) = 0u; // no records
+    uint32_t w0 = row0 * kSpWaves + wave, w1 = row1 * kSpWaves + wave, w2 = row2 * kSpWaves + wave;
+    bool v0 = row0 < nrows && w0 < ntiles, v1 = row1 < nrows && w1 < ntiles, v2 = row2 < nrows && w2 < ntiles;
+    TileRegs t;
+    uint4 rec2;
+    {
+        const uint4 r0 = setup_load_rec(p, w0, v0, nrec, lane);
+        const uint4 r1 = setup_load_rec(p, w1, v1, nrec, lane);
+        rec2 = setup_load_rec(p, w2, v2, nrec, lane);
+        const float4 m0 = setup_load_mat(p, r0, lane);
+        const float4 m1 = setup_load_mat(p, r1, lane);
+        setup_write(p, lds[wave][0], r0, m0, lane);
+        setup_write(p, lds[wave][1], r1, m1, lane);
+        tile_load<PASS>(p, lds[wave][0], lane, t);
+    }
+    if (PROF) {
+        t0 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
+    while (row0 < nrows) {
+        const uint32_t row3 = ring_get(ring, it + 3, &ctl[0], lane, p.status);
+        const uint32_t w3 = row3 * kSpWaves + wave;
+        const bool v3 = row3 < nrows && w3 < ntiles;
+        STAMP(0)
+        WaveTileLds &L = lds[wave][it % 3];
+        uint32_t total = 0;
+        if (v0) {
+            total = tile_eval<PASS, true>(p, L, planes, alpha, lane, t);
+            if (w0 > 0 && lane == 0)
+                __hip_atomic_store(p.scan_state + w0, make_granule(epoch, ST_AGG, total), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         }
-        const uint32_t w = row * kSpWaves + wave;
-        if (w < ntiles) { // wave-uniform
-            tile_setup(p, L, w, nrec, lane);
-            uint64_t draw_mask[kTileRows];
-            const uint32_t total = tile_rows<true>(p, L, lane, draw_mask);
-            uint32_t base = 0;
-            if (w > 0) {
-                if (lane == 0)
-                    __hip_atomic_store(p.scan_state + w, make_granule(epoch, ST_AGG, total), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                base = look_back(p, w, epoch, lane);
-            }
+        STAMP(1)
+        // small latency-critical loads first, bulk loads after (vmcnt retires in order)
+        uint64_t g = 0;
+        g = look_back_issue(p, v0 ? w0 : 0u, lane);
+        const float4 mat2 = setup_load_mat(p, rec2, lane);
+        const uint4 rec3 = setup_load_rec(p, w3, v3, nrec, lane);
+        tile_load<PASS>(p, lds[wave][(it + 1) % 3], lane, t); // slab of an absent tile holds zero records
+        setup_write(p, lds[wave][(it + 2) % 3], rec2, mat2, lane);
+        STAMP(2)
+        if (v0) {
+            const uint32_t base = w0 > 0 ? look_back_resolve(p, w0, epoch, lane, g) : 0u;
             const uint32_t inclusive = base + total;
             if (lane == 0)
-                __hip_atomic_store(p.scan_state + w, make_granule(epoch, ST_PREFIX, inclusive), __ATOMIC_RELAXED,
+                __hip_atomic_store(p.scan_state + w0, make_granule(epoch, ST_PREFIX, inclusive), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
-            tile_emit(p, L, lane, base, draw_mask);
-            if (w == ntiles - 1 && lane == 0) {
+            STAMP(3)
+            tile_emit(p, L, lane, base);
+            if (w0 == ntiles - 1 && lane == 0) {
                 // `count` header: subsumes the fill_buffer(count = 0) of draw_gen.rs:411-417
                 *reinterpret_cast<uint32_t *>(p.draw_buffer) = min(inclusive, p.draw_capacity);
                 if (inclusive > p.draw_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
             }
         }
+        STAMP(4)
+        row0 = row1; row1 = row2; row2 = row3;
+        w0 = w1; w1 = w2; w2 = w3;
+        v0 = v1; v1 = v2; v2 = v3;
+        rec2 = rec3;
+        it++;
     }
-    // self-cleaning control words: the last block to leave resets the ticket and
-    // bumps the epoch, so the next launch (stream-ordered) starts clean.
-    if (threadIdx.x == 0) {
-        const uint32_t done = atomicAdd(&ctl[1], 1u);
-        if (done == gridDim.x - 1) {
-            uint32_t next = (epoch + 1u) & 0x3FFFFFFFu;
-            if (next == 0u) next = 1u; // epoch 0 is what a zero-initialised granule carries
-            __hip_atomic_store(&ctl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ctl[2], next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (PROF && lane == 0) {
+        for (int k = 0; k < 5; k++) atomicAdd(p.debug_cycles + k, tc[k]);
+        atomicAdd(p.debug_cycles + 7, 1ull);
+    }
+    // self-cleaning control words: the last wave of the last block to leave resets
+    // the ticket and bumps the epoch, so the next launch (stream-ordered) starts clean.
+    if (lane == 0) {
+        if (atomicAdd(&ring.exited, 1u) == (uint32_t)kSpWaves - 1u) {
+            const uint32_t done = atomicAdd(&ctl[1], 1u);
+            if (done == gridDim.x - 1) {
+                uint32_t next = (epoch + 1u) & 0x3FFFFFFFu;
+                if (next == 0u) next = 1u; // epoch 0 is what a zero-initialised granule carries
+                __hip_atomic_store(&ctl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ctl[2], next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
 
-} // namespace
+// ---------------------------------------------------------------------------
+// Mode 0 (default): eval launch -> scan -> emit launch.
+//
+//   meshlet_eval : streams records, matrices and meshlets through the software
+//                  pipeline below and writes, per wave tile, the 8 should-draw
+//                  ballots (64 B) and their popcount.  No inter-wave dependency
+//                  of any kind: tiles are assigned statically (grid stride), so
+//                  waves drift out of phase and one wave's evaluation overlaps
+//                  another's loads.  Pass-2 visibility words are written here.
+//   scan         : exclusive prefix over the tile counts (scan.h / entity_cull.hip).
+//   meshlet_emit : per tile, re-reads only the survivors' command words and
+//                  writes the 28-B commands at the scanned offsets.
+//
+// Software pipeline of one wave in meshlet_eval.  A tile's 8 rows are handled as
+// four quarter tiles (2 rows) through two register sets A/B, so that meshlet
+// loads are in flight during every evaluation:
+//     eval rows 0-1 (A) ; load A <- rows 4-5          | tile i
+//     eval rows 2-3 (B) ; load B <- rows 6-7          |
+//     issue matrix loads (i+2), record load (i+3)     | small, one iteration ahead
+//     eval rows 4-5 (A) ; load A <- rows 0-1 of i+1   |
+//     eval rows 6-7 (B) ; load B <- rows 2-3 of i+1   |
+//     write slab(i+2) ; store masks(i), count(i)
+// The dependent chain record -> matrix -> meshlets of a tile is spread over three
+// iterations; all loads are unconditional (inactive lanes read a zero page) so
+// that the compiler's vmcnt accounting stays exact.
+constexpr int kEvWaves = 4;
 
-hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, int mode, hipStream_t s) {
+template <int PASS>
+__global__ __launch_bounds__(kEvWaves * 64) void meshlet_eval_kernel(const MeshletCullParams p) {
+    __shared__ WaveTileLds lds[kEvWaves][3];
+    __shared__ PlaneLds planes;
+    __shared__ AlphaLds alpha_tab;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    planes_to_lds(p.ci, planes);
+    const AlphaLds *alpha = alpha_table_fill(p, alpha_tab) ? &alpha_tab : nullptr;
+    __syncthreads();
+    const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
+    const uint32_t ntiles = (nrec + kTileRecords - 1) / kTileRecords;
+    const uint32_t stride = gridDim.x * kEvWaves;
+    uint32_t w0 = blockIdx.x * kEvWaves + wave, w1 = w0 + stride, w2 = w1 + stride;
+    // two quarter-tile register sets: while one is evaluated the other is in flight
+    RowRegs<2> qa, qb;
+    uint4 rec2;
+    {
+        const uint4 r0 = setup_load_rec(p, w0, w0 < ntiles, nrec, lane);
+        const uint4 r1 = setup_load_rec(p, w1, w1 < ntiles, nrec, lane);
+        rec2 = setup_load_rec(p, w2, w2 < ntiles, nrec, lane);
+        const float4 m0 = setup_load_mat(p, r0, lane);
+        const float4 m1 = setup_load_mat(p, r1, lane);
+        setup_write(p, lds[wave][0], r0, m0, lane);
+        setup_write(p, lds[wave][1], r1, m1, lane);
+        rows_load<PASS, 0, 2>(p, lds[wave][0], lane, qa);
+        rows_load<PASS, 2, 2>(p, lds[wave][0], lane, qb);
+    }
+    uint32_t it = 0;
+    while (w0 < ntiles) {
+        const uint32_t w3 = w2 + stride;
+        WaveTileLds &L = lds[wave][it % 3];
+        WaveTileLds &Ln = lds[wave][(it + 1) % 3]; // slab of an absent tile holds zero records
+        uint32_t *payload = p.tile_payload + (size_t)w0 * (kPayloadCap * 3u);
+        uint32_t total = 0;
+        total = rows_eval<PASS, true, 0, 2>(p, L, planes, alpha, lane, qa, total, payload);
+        rows_load<PASS, 4, 2>(p, L, lane, qa);
+        total = rows_eval<PASS, true, 2, 2>(p, L, planes, alpha, lane, qb, total, payload);
+        rows_load<PASS, 6, 2>(p, L, lane, qb);
+        const float4 mat2 = setup_load_mat(p, rec2, lane);
+        const uint4 rec3 = setup_load_rec(p, w3, w3 < ntiles, nrec, lane);
+        total = rows_eval<PASS, true, 4, 2>(p, L, planes, alpha, lane, qa, total, payload);
+        rows_load<PASS, 0, 2>(p, Ln, lane, qa);
+        total = rows_eval<PASS, true, 6, 2>(p, L, planes, alpha, lane, qb, total, payload);
+        rows_load<PASS, 2, 2>(p, Ln, lane, qb);
+        setup_write(p, lds[wave][(it + 2) % 3], rec2, mat2, lane); // also fences the mask writes of this tile
+        if (lane < 2 * (int)kTileRows)
+            p.tile_masks[(size_t)w0 * (2 * kTileRows) + lane] = reinterpret_cast<const uint32_t *>(L.draw_mask)[lane];
+        if (lane == 0) p.tile_counts[w0] = total;
+        w0 = w1;
+        w1 = w2;
+        w2 = w3;
+        rec2 = rec3;
+        it++;
+    }
+}
+
+// One wave per tile (grid stride): commands of the tile's survivors at the
+// scanned offset (:216-230).  Two memory round trips per tile: (1) masks, the
+// tile's 16 records, count and base — independent loads, prefetched for tile
+// i+1 while tile i is written; (2) Meshlet bytes 16..31 of the survivors only.
+struct EmitTile {
+    uint32_t mword; // lanes 0..15: the 8 x 64-bit ballots
+    uint4 rec;      // lanes 0..15: the tile's dispatch records
+    uint32_t count, base;
+};
+
+__device__ __forceinline__ EmitTile emit_prefetch(const MeshletCullParams &p, uint32_t tile, uint32_t ntiles,
+                                                  uint32_t nrec, int lane) {
+    EmitTile e;
+    const uint4 *recs = reinterpret_cast<const uint4 *>(p.dispatch_buffer + ORBIT_DISPATCH_HEADER);
+    const bool tv = tile < ntiles;
+    const uint32_t t = tv ? tile : 0u;
+    const uint32_t ri = t * kTileRecords + (lane & 15);
+    e.mword = p.tile_masks[(size_t)t * (2 * kTileRows) + (lane & 15)];
+    e.rec = *((tv && ri < nrec) ? recs + ri : reinterpret_cast<const uint4 *>(p.zero_page));
+    e.count = tv ? p.tile_counts[t] : 0u;
+    e.base = p.tile_base[t] + p.chunk_base[t / kScanChunk];
+    return e;
+}
+
+// Lane = survivor, not meshlet: at ~10 % survival a row has ~6 survivors, and a
+// lane-per-meshlet emit spends its time issuing 56 mostly-empty masked stores
+// per tile.  The tile's survivors are first compacted into a wave-private LDS
+// list of (row, lane) codes (ballot rank = list position, i.e. canonical
+// order), then each lane takes one list entry: one survivor-word load and seven
+// stores per 64 survivors.
+__global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullParams p) {
+    __shared__ uint16_t s_list[4][kTileRows * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint16_t *list = s_list[wave];
+    const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
+    const uint32_t ntiles = (nrec + kTileRecords - 1) / kTileRecords;
+    uint32_t *out = reinterpret_cast<uint32_t *>(p.draw_buffer + ORBIT_DRAW_HEADER);
+    const uint32_t stride = gridDim.x * 4;
+    uint32_t tile = blockIdx.x * 4 + wave;
+    EmitTile cur = emit_prefetch(p, tile, ntiles, nrec, lane);
+    for (; tile < ntiles; tile += stride) {
+        const EmitTile nxt = emit_prefetch(p, tile + stride, ntiles, nrec, lane);
+        const uint32_t n = cur.count;
+        if (n != 0u) { // wave-uniform
+            uint32_t row_base = 0;
+#pragma unroll
+            for (int r = 0; r < (int)kTileRows; r++) {
+                const uint32_t lo = (uint32_t)__shfl((int)cur.mword, 2 * r, 64);
+                const uint32_t hi = (uint32_t)__shfl((int)cur.mword, 2 * r + 1, 64);
+                const uint64_t mask = ((uint64_t)hi << 32) | lo;
+                if ((mask >> lane) & 1ull) list[row_base + lane_prefix(mask)] = (uint16_t)(r * 64 + lane);
+                row_base += (uint32_t)__popcll(mask);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t j0 = 0; j0 < n; j0 += 64) { // one trip unless more than 64 survivors
+                const uint32_t j = j0 + lane;
+                const uint32_t slot = cur.base + j;
+                const bool keep = j < n && slot < p.draw_capacity;
+                const uint32_t code = keep ? list[j] : 0u;
+                const int src = (int)((code >> 6) * 2 + ((code >> 5) & 1u)); // record 2r + half
+                const uint32_t ent = (uint32_t)__shfl((int)cur.rec.x, src, 64);
+                const uint32_t mi = (uint32_t)__shfl((int)cur.rec.y, src, 64) + (code & 31u);
+                uint4 b;
+                if (n <= kPayloadCap) { // wave-uniform: contiguous payload written by meshlet_eval
+                    const uint32_t *src = keep ? p.tile_payload + ((size_t)tile * kPayloadCap + j) * 3u
+                                               : reinterpret_cast<const uint32_t *>(p.zero_page);
+                    b = make_uint4(0u, src[0], src[1], src[2]);
+                } else { // dense tile: gather Meshlet bytes 16..31 of the survivors
+                    b = *(keep ? reinterpret_cast<const uint4 *>(p.meshlets + mi) + 1
+                               : reinterpret_cast<const uint4 *>(p.zero_page));
+                }
+                if (keep) {
+                    const uint32_t vertex_count = (b.w >> 16) & 0xFFu;
+                    const uint32_t triangle_count = b.w >> 24;
+                    uint32_t *c = out + (size_t)slot * 7u;
+                    c[0] = triangle_count * 3u;       // cmd_index_count
+                    c[1] = 1u;                        // cmd_instance_count
+                    c[2] = (b.z + vertex_count) * 4u; // cmd_first_index
+                    c[3] = b.z;                       // cmd_vertex_offset = int(data_offset)
+                    c[4] = ent;                       // cmd_first_instance = entity_index
+                    c[5] = b.y;                       // meshlet_vertex_offset
+                    c[6] = mi;                        // meshlet_index
+                }
+            }
+            __builtin_amdgcn_wave_barrier(); // list is reused by the next tile
+        }
+        cur = nxt;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // `count` header: subsumes the fill_buffer(count = 0) of draw_gen.rs:411-417
+        const uint32_t total = *p.total;
+        *reinterpret_cast<uint32_t *>(p.draw_buffer) = min(total, p.draw_capacity);
+        if (total > p.draw_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+    }
+}
+
+template <int PASS>
+hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, int mode, hipStream_t s) {
     const uint32_t max_tiles = (p.dispatch_capacity + kTileRecords - 1) / kTileRecords;
     if (mode == 1) {
         // persistent blocks, one 1024-thread block per CU (<= 128 VGPRs), looping over tickets
@@ -363,23 +753,40 @@ hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, int
         const uint32_t need = (max_tiles + kSpWaves - 1) / kSpWaves;
         if (blocks > need) blocks = need;
         if (blocks == 0) blocks = 1;
-        hipLaunchKernelGGL(meshlet_cull_single_pass, dim3(blocks), dim3(kSpBlock), 0, s, p);
+        if (PASS == 0 && (p.debug_flags & 8u))
+            hipLaunchKernelGGL((meshlet_cull_single_pass<PASS == 0 ? 0 : PASS, PASS == 0>), dim3(blocks),
+                               dim3(kSpBlock), 0, s, p);
+        else
+            hipLaunchKernelGGL((meshlet_cull_single_pass<PASS, false>), dim3(blocks), dim3(kSpBlock), 0, s, p);
         return hipGetLastError();
     }
-    // two-pass fallback (count -> scan -> emit): persistent-style grid, grid-stride over tiles
-    uint32_t blocks = num_cus * 8u;
-    const uint32_t need = (max_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    // eval -> scan -> emit
+    uint32_t blocks = num_cus * 4u; // 16 waves per CU at <= 128 VGPRs
+    const uint32_t need = (max_tiles + kEvWaves - 1) / kEvWaves;
     if (blocks > need) blocks = need;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(meshlet_cull_two_pass<MODE_COUNT>, dim3(blocks), dim3(kBlock), 0, s, p);
+    hipLaunchKernelGGL(meshlet_eval_kernel<PASS>, dim3(blocks), dim3(kEvWaves * 64), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = launch_scan_exclusive_indirect(p.tile_counts, p.tile_base,
-                                       reinterpret_cast<const uint32_t *>(p.dispatch_buffer), kTileRecords, max_tiles,
-                                       p.total, s);
+    e = launch_scan_two_level(p.tile_counts, p.tile_base, reinterpret_cast<const uint32_t *>(p.dispatch_buffer),
+                              kTileRecords, max_tiles, p.chunk_sums, p.chunk_base, p.total, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(meshlet_cull_two_pass<MODE_EMIT>, dim3(blocks), dim3(kBlock), 0, s, p);
+    uint32_t eblocks = num_cus * 8u;
+    const uint32_t eneed = (max_tiles + 3) / 4;
+    if (eblocks > eneed) eblocks = eneed;
+    if (eblocks == 0) eblocks = 1;
+    hipLaunchKernelGGL(meshlet_emit_kernel, dim3(eblocks), dim3(256), 0, s, p);
     return hipGetLastError();
+}
+
+} // namespace
+
+hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, int mode, hipStream_t s) {
+    switch (p.ci.occlusion_pass) {
+    case 0: return launch_pass<0>(p, num_cus, mode, s);
+    case 1: return launch_pass<1>(p, num_cus, mode, s);
+    default: return launch_pass<2>(p, num_cus, mode, s);
+    }
 }
 
 } // namespace orbit

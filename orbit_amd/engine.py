@@ -105,7 +105,7 @@ class Engine:
     # -- meshlet_cull: create_meshlet_draw_commands body (draw_gen.rs:382-435)
     def meshlet_cull(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, draw_commands_buffer, entity_buffer,
                      material_buffer, dispatch_capacity, draw_capacity, meshlet_visibility_buffer=None,
-                     depth_pyramid=None, depth_pyramid_size=(0, 0), stream=None):
+                     depth_pyramid=None, depth_pyramid_size=(0, 0), material_count=0, stream=None):
         ci = _host_bytes(cull_info, 400)
         b = _lib.MeshletCullBufs()
         b.meshlet_dispatch_buffer = _ptr(meshlet_dispatch_buffer)
@@ -118,6 +118,7 @@ class Engine:
         b.depth_pyramid_size[0], b.depth_pyramid_size[1] = depth_pyramid_size
         b.dispatch_capacity = dispatch_capacity
         b.draw_capacity = draw_capacity
+        b.material_count = material_count
         _lib.check(self._lib.orbit_meshlet_cull(self._ctx, ci.ctypes.data_as(C.c_void_p), C.byref(b),
                                                 _stream(stream)), self._ctx)
 
