@@ -35,8 +35,9 @@ def parse():
     ap.add_argument("--entities", type=int, default=195_313, help="config 5: 195313 x 256 = 50 000 128 meshlets")
     ap.add_argument("--meshlets-per-entity", type=int, default=256)
     ap.add_argument("--survive", type=float, default=0.10, help="target survivor fraction (SURVEY.md §8d prices 10 %%)")
-    ap.add_argument("--cpu-sample-entities", type=int, default=65_536,
+    ap.add_argument("--cpu-sample-entities", type=int, default=195_072,
                     help="entities of the scene the CPU oracle is timed on (rank 0, N=1 only); 0 disables")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="minimum CPU time spent in the oracle baseline")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather (cull only)")
     return ap.parse_args()
 
@@ -107,6 +108,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    eng.profile(True)  # HIP events around the dominant kernel (meshlet_eval), on the launch stream
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -123,8 +125,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     eng.status()
+    eval_ms, eval_launches = eng.profile_read()
+    eng.profile(False)
+    assert eval_launches == args.steps, (eval_launches, args.steps)
 
-    kernel_ms = float(np.mean([a.elapsed_time(z) for a, z in ev]))
+    kernel_ms = float(np.mean([a.elapsed_time(z) for a, z in ev]))  # whole meshlet_cull op (eval + scan + emit)
     n_rec = int(disp[:4].view(torch.int32).item())
     n_draw = int(draw[:4].view(torch.int32).item())
     n_in = int(disp[L.DISPATCH_HEADER:L.DISPATCH_HEADER + 16 * n_rec].view(torch.int32).view(-1, 4)[:, 2].sum().item())
@@ -142,10 +147,14 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = tot_in / (elapsed / args.steps)
 
-    # roofline of the dominant kernel (meshlet_cull), this rank: algorithmic bytes per launch
-    # B_m = 32 N_m + 16 N_d + 64 N_e + 28 N_draw + 4   (occlusion_pass 0)
-    alg_bytes = 32 * n_in + 16 * n_rec + 64 * n_local_entities + 28 * n_draw + 4
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    # Roofline of the dominant kernel (meshlet_eval, the streaming evaluation), this rank.
+    # B_m = 32 N_m + 16 N_d + 64 N_e + 28 N_draw + 4 for the whole op (occlusion_pass 0);
+    # the eval launch carries the read side (32 N_m + 16 N_d + 64 N_e = 32.75 B per meshlet here), the emit
+    # launch the 28 N_draw + 4 written bytes (DESIGN.md "Algorithmic bytes").
+    alg_bytes = 32 * n_in + 16 * n_rec + 64 * n_local_entities
+    achieved = alg_bytes / (eval_ms * 1e-3) / 1e9
+    op_bytes = alg_bytes + 28 * n_draw + 4
+    traffic = load_traffic(E, M)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_sample_entities > 0:
@@ -174,9 +183,11 @@ def main():
                 "sharding": f"entity ranges over {world} rank(s)", "gather": bool(do_gather),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "meshlet_cull", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms,
+                "bound": "hbm", "kernel": "meshlet_eval_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": eval_ms, "launches_timed": eval_launches,
+                "op": {"name": "meshlet_cull (eval + scan + emit)", "algorithmic_bytes": op_bytes,
+                       "avg_ms": kernel_ms, "achieved": op_bytes / (kernel_ms * 1e-3) / 1e9},
             },
             "cpu_baseline": cpu_baseline,
             "cull_only_meshlets_per_sec": tot_in / (kernel_ms_max * 1e-3) if kernel_ms_max > 0 else None,
@@ -186,6 +197,20 @@ def main():
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def load_traffic(entities, meshlets_per_entity):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, written by tools/traffic.py); None when absent or for another workload."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("entities") == entities and t.get("meshlets_per_entity") == meshlets_per_entity:
+            return t.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 def run_cpu_baseline(args, spec, ci, draws, mesh, ent, meshlets, materials, disp, draw, L):
@@ -202,11 +227,14 @@ def run_cpu_baseline(args, spec, ci, draws, mesh, ent, meshlets, materials, disp
     h_meshlets = meshlets[:es * M * 32].cpu().numpy()
     h_mat = materials.cpu().numpy()
     cap_d = es * spec.records_per_entity + 8
-    t0 = time.perf_counter()
-    odisp, _, _ = oracle.entity_cull(ci, h_draws, es, h_mesh, h_ent, cap_d)
-    n_rec = int(odisp[:4].view(np.uint32)[0])
-    odraw, _, dropped = oracle.meshlet_cull(ci, odisp, h_meshlets, es * M, h_ent, h_mat)
-    cpu_s = time.perf_counter() - t0
+    cpu_s, reps = 0.0, 0
+    while cpu_s < args.cpu_seconds and reps < 64:
+        t0 = time.perf_counter()
+        odisp, _, _ = oracle.entity_cull(ci, h_draws, es, h_mesh, h_ent, cap_d)
+        n_rec = int(odisp[:4].view(np.uint32)[0])
+        odraw, _, dropped = oracle.meshlet_cull(ci, odisp, h_meshlets, es * M // 2 + 1024, h_ent, h_mat)
+        cpu_s += time.perf_counter() - t0
+        reps += 1
     n_in = int(odisp[12:12 + 16 * n_rec].view(np.uint32).reshape(-1, 4)[:, 2].sum())
     n_draw = int(odraw[:4].view(np.uint32)[0])
     # canonical order => the GPU's full-scene output starts with exactly these records / commands
@@ -214,9 +242,10 @@ def run_cpu_baseline(args, spec, ci, draws, mesh, ent, meshlets, materials, disp
     g_draw = draw[4:4 + 28 * n_draw].cpu().numpy()
     same = bool(np.array_equal(g_disp, odisp[12:12 + 16 * n_rec]) and np.array_equal(g_draw, odraw[4:4 + 28 * n_draw]))
     return {
-        "value": n_in / cpu_s, "unit": "meshlets/s", "cores": 1, "kind": "port",
+        "value": n_in * reps / cpu_s, "unit": "meshlets/s", "cores": 1, "kind": "port",
         "sample": f"first {es} of {spec.entities} entities ({n_in} meshlets into meshlet_cull) of the same scene, "
-                  f"oracle/orbit_oracle.c entity_cull + meshlet_cull, {cpu_s:.2f} s, host has {os.cpu_count()} cores",
+                  f"{reps} passes of oracle/orbit_oracle.c entity_cull + meshlet_cull in {cpu_s:.2f} s, "
+                  f"1 thread of a {os.cpu_count()}-core host",
         "gpu_prefix_bit_identical": same,
     }
 

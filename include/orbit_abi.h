@@ -445,6 +445,15 @@ int32_t orbit_cluster_assign(OrbitCtx *ctx, const OrbitClusterCullInfo *info,
                              uint32_t *cluster_offset_image, void *stream);
 
 /* ------------------------------------------------------------------------ */
+/* Measurement hook (bench.py).  While enabled, every orbit_meshlet_cull     */
+/* records a HIP event pair on the caller's stream around the op's dominant  */
+/* kernel (the streaming meshlet evaluation); profile_read waits for the     */
+/* recorded pairs and returns their mean duration.  Never on by default.     */
+/* ------------------------------------------------------------------------ */
+int32_t orbit_ctx_profile(OrbitCtx *ctx, int32_t enable);
+int32_t orbit_ctx_profile_read(OrbitCtx *ctx, float *avg_ms, uint32_t *launches);
+
+/* ------------------------------------------------------------------------ */
 /* Multi-GPU helpers.  The exchange itself runs over RCCL    */
 /* through torch.distributed on the host side (orbit_amd/dist.py); these are */
 /* the device-side pieces.                                                   */

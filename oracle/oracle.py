@@ -82,8 +82,9 @@ def hiz_sample(pyr, w0, h0, u, v, lod):
 
 
 def entity_cull(cull_info, entity_draw_buffer, entity_draw_count, mesh_infos, entities, dispatch_capacity,
-                visibility=None, pyramid=None, pyramid_size=(0, 0), draw_first=0):
-    """Returns (dispatch_buffer bytes, visibility words (copy, updated in pass 2), dropped)."""
+                visibility=None, pyramid=None, pyramid_size=(0, 0), draw_first=None):
+    """Returns (dispatch_buffer bytes, visibility words (copy, updated in pass 2), dropped).
+    draw_first=None: whole-buffer call (reference grid); else the exact shard [draw_first, +count)."""
     ci = _bytes(cull_info)
     assert ci.nbytes == 400
     edb = _bytes(entity_draw_buffer)
@@ -91,7 +92,9 @@ def entity_cull(cull_info, entity_draw_buffer, entity_draw_count, mesh_infos, en
     out = np.zeros(12 + 16 * dispatch_capacity, dtype=np.uint8)
     vis = None if visibility is None else np.array(visibility, dtype=np.uint32, copy=True)
     pyr = None if pyramid is None else np.ascontiguousarray(pyramid, dtype=np.float32)
-    dropped = lib().oracle_entity_cull(_p(ci), _p(edb), C.c_uint32(draw_first), C.c_uint32(entity_draw_count), _p(mi),
+    exact = 0 if draw_first is None else 1
+    dropped = lib().oracle_entity_cull(_p(ci), _p(edb), C.c_uint32(draw_first or 0), C.c_uint32(entity_draw_count),
+                                       C.c_uint32(exact), _p(mi),
                                        _p(en), _p(out), C.c_uint32(dispatch_capacity), _p(vis), _p(pyr),
                                        C.c_uint32(pyramid_size[0]), C.c_uint32(pyramid_size[1]))
     return out, vis, int(dropped)

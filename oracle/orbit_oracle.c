@@ -307,7 +307,7 @@ static void wr32(uint8_t *p, uint32_t v) { memcpy(p, &v, 4); }
  * the grid of draw_gen.rs:377.  Returns the number of records that did not fit
  * `dispatch_capacity` (0 = ok); the header x still counts only stored records. */
 uint32_t oracle_entity_cull(const OrbitGpuCullInfo *ci, const uint8_t *entity_draw_buffer,
-                            uint32_t draw_first, uint32_t entity_draw_count,
+                            uint32_t draw_first, uint32_t entity_draw_count, uint32_t exact_range,
                             const OrbitMeshInfo *mesh_infos, const OrbitEntityData *entities,
                             uint8_t *dispatch_buffer, uint32_t dispatch_capacity,
                             uint32_t *visibility, const float *pyr, uint32_t pw, uint32_t ph) {
@@ -316,9 +316,12 @@ uint32_t oracle_entity_cull(const OrbitGpuCullInfo *ci, const uint8_t *entity_dr
     OrbitMeshletDispatch *out = (OrbitMeshletDispatch *)(dispatch_buffer + ORBIT_DISPATCH_HEADER);
     uint32_t total = 0, dropped = 0;
     int meshlet_occ = ci->meshlet_visibility_buffer != ORBIT_NONE;
+    /* !exact_range: the reference's grid, ceil(n/256) workgroups of 256 (draw_gen.rs:377), bounded by
+     * the in-buffer count (entity_cull.comp:106).  exact_range: the shard [first, first + n) of the
+     * multi-GPU path (orbit_entity_cull_range). */
     uint32_t groups = (entity_draw_count + 255u) / 256u;
-    uint32_t end = draw_first + groups * 256u;
-    if (end > count) end = count;
+    uint64_t end64 = exact_range ? (uint64_t)draw_first + entity_draw_count : (uint64_t)groups * 256u;
+    uint32_t end = end64 > count ? count : (uint32_t)end64;
     /* pass 2 rewrites whole 32-bit words from ballots; inactive lanes give 0 */
     uint32_t word = 0;
     for (uint32_t g = draw_first; g < end; g++) {

@@ -72,6 +72,8 @@ SYMBOLS = {
                                           C.c_void_p]),
     "orbit_cluster_assign": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_uint32, C.c_void_p, C.c_void_p]),
+    "orbit_ctx_profile": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "orbit_ctx_profile_read": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "orbit_shard_range": (None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }
 

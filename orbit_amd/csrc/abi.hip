@@ -12,6 +12,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <vector>
 
 #include "kernels.h"
 
@@ -40,6 +41,10 @@ struct OrbitCtx {
     uint32_t debug_flags = 0;
     unsigned long long *debug_cycles = nullptr;
     void *zero_page = nullptr;
+    // measurement hook: HIP event pairs around the dominant kernel (meshlet_eval)
+    bool profiling = false;
+    std::vector<hipEvent_t> prof_events; // pairs, in record order
+    size_t prof_used = 0;
     int meshlet_mode = 0; // 0 = eval/scan/emit (default), 1 = single-launch look-back (ORBIT_MESHLET_LOOKBACK=1)
     char err[512] = {0};
 };
@@ -245,6 +250,7 @@ int32_t orbit_ctx_destroy(OrbitCtx *ctx) {
     if (!ctx) return ORBIT_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    for (hipEvent_t ev : ctx->prof_events) (void)hipEventDestroy(ev);
     if (ctx->arena) (void)hipFree(ctx->arena);
     delete ctx;
     return ORBIT_OK;
@@ -270,6 +276,35 @@ int32_t orbit_ctx_status(OrbitCtx *ctx, void *stream, int32_t sync) {
     return ORBIT_OK;
 }
 
+// ------------------------------------------------------------- measurement hooks
+int32_t orbit_ctx_profile(OrbitCtx *ctx, int32_t enable) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->profiling = enable != 0;
+    ctx->prof_used = 0;
+    return ORBIT_OK;
+}
+
+int32_t orbit_ctx_profile_read(OrbitCtx *ctx, float *avg_ms, uint32_t *launches) {
+    if (!ctx || !avg_ms || !launches) return fail(ctx, ORBIT_E_INVALID, "profile_read: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    double sum = 0.0;
+    uint32_t n = 0;
+    for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
+        hipError_t e = hipEventSynchronize(ctx->prof_events[i + 1]);
+        if (e != hipSuccess) return hip_fail(ctx, e, "hipEventSynchronize");
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, ctx->prof_events[i], ctx->prof_events[i + 1]);
+        if (e != hipSuccess) return hip_fail(ctx, e, "hipEventElapsedTime");
+        sum += ms;
+        n++;
+    }
+    *avg_ms = n ? (float)(sum / n) : 0.f;
+    *launches = n;
+    ctx->prof_used = 0;
+    return ORBIT_OK;
+}
+
 // perf triage only (not part of the public ABI): reads and clears the per-phase cycle sums
 int32_t orbit_debug_read_cycles(OrbitCtx *ctx, unsigned long long out[8]) {
     if (!ctx || !out) return ORBIT_E_INVALID;
@@ -281,7 +316,7 @@ int32_t orbit_debug_read_cycles(OrbitCtx *ctx, unsigned long long out[8]) {
 
 // ------------------------------------------------------------------ entity_cull
 static int32_t entity_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitEntityCullBufs *b,
-                                uint32_t draw_first, uint32_t entity_draw_count, void *stream) {
+                                uint32_t draw_first, uint32_t entity_draw_count, bool exact_range, void *stream) {
     if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
     int32_t rc = check_cull_info(ctx, ci);
@@ -306,7 +341,10 @@ static int32_t entity_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const
     p.visibility = b->visibility_buffer;
     p.pyr = make_pyramid_view(b->depth_pyramid, b->depth_pyramid_size);
     p.draw_first = draw_first;
-    const uint64_t limit = (uint64_t)draw_first + ((uint64_t)entity_draw_count + 255u) / 256u * 256u;
+    // whole-buffer call: the reference's grid of ceil(n/256) x 256 invocations (draw_gen.rs:377);
+    // range call: exactly [draw_first, draw_first + n) so that shards never overlap
+    const uint64_t limit = exact_range ? (uint64_t)draw_first + entity_draw_count
+                                       : ((uint64_t)entity_draw_count + 255u) / 256u * 256u;
     p.draw_limit = limit > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)limit;
     p.dispatch_capacity = b->dispatch_capacity;
     p.proto = ctx->e_proto;
@@ -321,12 +359,12 @@ static int32_t entity_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const
 
 int32_t orbit_entity_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info, const OrbitEntityCullBufs *bufs,
                           uint32_t entity_draw_count, void *stream) {
-    return entity_cull_impl(ctx, cull_info, bufs, 0u, entity_draw_count, stream);
+    return entity_cull_impl(ctx, cull_info, bufs, 0u, entity_draw_count, false, stream);
 }
 
 int32_t orbit_entity_cull_range(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info, const OrbitEntityCullBufs *bufs,
                                 uint32_t draw_first, uint32_t draw_count, void *stream) {
-    return entity_cull_impl(ctx, cull_info, bufs, draw_first, draw_count, stream);
+    return entity_cull_impl(ctx, cull_info, bufs, draw_first, draw_count, true, stream);
 }
 
 // ----------------------------------------------------------------- meshlet_cull
@@ -373,7 +411,20 @@ int32_t orbit_meshlet_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbi
     p.debug_cycles = ctx->debug_cycles;
     p.zero_page = ctx->zero_page;
     p.status = ctx->status;
-    hipError_t e = launch_meshlet_cull(p, ctx->num_cus, ctx->meshlet_mode, (hipStream_t)stream);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (ctx->profiling) {
+        if (ctx->prof_used + 2 > ctx->prof_events.size()) {
+            for (int i = 0; i < 2; i++) {
+                hipEvent_t ev;
+                if (hipEventCreate(&ev) != hipSuccess) return fail(ctx, ORBIT_E_HIP, "hipEventCreate");
+                ctx->prof_events.push_back(ev);
+            }
+        }
+        ev0 = ctx->prof_events[ctx->prof_used];
+        ev1 = ctx->prof_events[ctx->prof_used + 1];
+        ctx->prof_used += 2;
+    }
+    hipError_t e = launch_meshlet_cull(p, ctx->num_cus, ctx->meshlet_mode, (hipStream_t)stream, ev0, ev1);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_cull");
     return ORBIT_OK;
 }

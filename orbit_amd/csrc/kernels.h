@@ -105,7 +105,9 @@ struct ClusterAssignParams {
 };
 
 hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_count, hipStream_t s);
-hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, int mode, hipStream_t s);
+// ev0/ev1 (optional): recorded on `s` immediately before / after the dominant kernel of the op
+hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, int mode, hipStream_t s,
+                               hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t launch_depth_reduce(const DepthReduceParams &p, hipStream_t s);
 hipError_t launch_cluster_mark(const ClusterMarkParams &p, hipStream_t s);
 hipError_t launch_cluster_compact(const ClusterCompactParams &p, hipStream_t s);

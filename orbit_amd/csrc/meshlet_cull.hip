@@ -745,7 +745,8 @@ __global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullPara
 }
 
 template <int PASS>
-hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, int mode, hipStream_t s) {
+hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, int mode, hipStream_t s, hipEvent_t ev0,
+                       hipEvent_t ev1) {
     const uint32_t max_tiles = (p.dispatch_capacity + kTileRecords - 1) / kTileRecords;
     if (mode == 1) {
         // persistent blocks, one 1024-thread block per CU (<= 128 VGPRs), looping over tickets
@@ -753,11 +754,13 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, int mode, h
         const uint32_t need = (max_tiles + kSpWaves - 1) / kSpWaves;
         if (blocks > need) blocks = need;
         if (blocks == 0) blocks = 1;
+        if (ev0) (void)hipEventRecord(ev0, s);
         if (PASS == 0 && (p.debug_flags & 8u))
             hipLaunchKernelGGL((meshlet_cull_single_pass<PASS == 0 ? 0 : PASS, PASS == 0>), dim3(blocks),
                                dim3(kSpBlock), 0, s, p);
         else
             hipLaunchKernelGGL((meshlet_cull_single_pass<PASS, false>), dim3(blocks), dim3(kSpBlock), 0, s, p);
+        if (ev1) (void)hipEventRecord(ev1, s);
         return hipGetLastError();
     }
     // eval -> scan -> emit
@@ -765,7 +768,9 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, int mode, h
     const uint32_t need = (max_tiles + kEvWaves - 1) / kEvWaves;
     if (blocks > need) blocks = need;
     if (blocks == 0) blocks = 1;
+    if (ev0) (void)hipEventRecord(ev0, s);
     hipLaunchKernelGGL(meshlet_eval_kernel<PASS>, dim3(blocks), dim3(kEvWaves * 64), 0, s, p);
+    if (ev1) (void)hipEventRecord(ev1, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     e = launch_scan_two_level(p.tile_counts, p.tile_base, reinterpret_cast<const uint32_t *>(p.dispatch_buffer),
@@ -781,11 +786,12 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, int mode, h
 
 } // namespace
 
-hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, int mode, hipStream_t s) {
+hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, int mode, hipStream_t s, hipEvent_t ev0,
+                               hipEvent_t ev1) {
     switch (p.ci.occlusion_pass) {
-    case 0: return launch_pass<0>(p, num_cus, mode, s);
-    case 1: return launch_pass<1>(p, num_cus, mode, s);
-    default: return launch_pass<2>(p, num_cus, mode, s);
+    case 0: return launch_pass<0>(p, num_cus, mode, s, ev0, ev1);
+    case 1: return launch_pass<1>(p, num_cus, mode, s, ev0, ev1);
+    default: return launch_pass<2>(p, num_cus, mode, s, ev0, ev1);
     }
 }
 

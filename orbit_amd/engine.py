@@ -80,6 +80,15 @@ class Engine:
         """Raises OrbitError for a device-latched condition (capacity overflow, timeout)."""
         _lib.check(self._lib.orbit_ctx_status(self._ctx, _stream(stream), 1 if sync else 0), self._ctx)
 
+    def profile(self, enable=True):
+        """HIP-event timing of the dominant kernel of meshlet_cull (measurement hook)."""
+        _lib.check(self._lib.orbit_ctx_profile(self._ctx, 1 if enable else 0), self._ctx)
+
+    def profile_read(self):
+        ms, n = C.c_float(), C.c_uint32()
+        _lib.check(self._lib.orbit_ctx_profile_read(self._ctx, C.byref(ms), C.byref(n)), self._ctx)
+        return ms.value, n.value
+
     # -- entity_cull: create_meshlet_dispatch_command body (draw_gen.rs:327-380)
     def entity_cull(self, cull_info, entity_draw_buffer, mesh_info_buffer, meshlet_dispatch_buffer, entity_buffer,
                     entity_draw_count, dispatch_capacity, visibility_buffer=None, depth_pyramid=None,

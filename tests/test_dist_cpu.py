@@ -1,0 +1,66 @@
+"""world_size-2 gloo test of the rank-ordered visible-list gather (orbit_amd/dist.py): the
+concatenation of per-shard oracle outputs over contiguous 32-aligned entity ranges must be
+the single-process canonical sequence, and the gather must reproduce it on every rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import scenes as sc
+from orbit_amd import layouts as L
+from orbit_amd.dist import gather_visible, shard_ranges
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, seed, n_entities, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+
+    scene = sc.make_scene(seed, n_entities, n_meshes=40)
+    cam = sc.default_camera()
+    ci = sc.make_cull_info(cam.view, cam.planes)
+    b, e = shard_ranges(scene.entity_draw_count, world)[rank]
+    cap = scene.max_dispatches() + 8
+    disp, _, _ = oracle.entity_cull(ci, scene.entity_draw_buffer(), e - b, scene.mesh_infos, scene.entities, cap,
+                                    draw_first=b)
+    draw, _, _ = oracle.meshlet_cull(ci, disp, scene.meshlets, scene.lod0_meshlets + 8, scene.entities,
+                                     scene.materials)
+    local = torch.from_numpy(draw.copy())
+    out = torch.zeros(L.DRAW_HEADER + 28 * (scene.lod0_meshlets + 8), dtype=torch.uint8)
+    counts = gather_visible(local, out)
+    assert counts[rank] == int(draw[:4].view(np.uint32)[0])
+    np.save(os.path.join(out_dir, f"gathered_{rank}.npy"), out.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_entities", [257, 64])
+def test_gather_visible_gloo_world2(tmp_path, oracle, n_entities):
+    world, seed = 2, 31
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, seed, n_entities, str(tmp_path)), nprocs=world, join=True)
+    scene = sc.make_scene(seed, n_entities, n_meshes=40)
+    cam = sc.default_camera()
+    ci = sc.make_cull_info(cam.view, cam.planes)
+    disp, _, _ = oracle.entity_cull(ci, scene.entity_draw_buffer(), scene.entity_draw_count, scene.mesh_infos,
+                                    scene.entities, scene.max_dispatches() + 8)
+    ref, _, _ = oracle.meshlet_cull(ci, disp, scene.meshlets, scene.lod0_meshlets + 8, scene.entities,
+                                    scene.materials)
+    n = int(ref[:4].view(np.uint32)[0])
+    assert n > 0
+    for r in range(world):
+        got = np.load(tmp_path / f"gathered_{r}.npy")
+        assert int(got[:4].view(np.uint32)[0]) == n
+        assert np.array_equal(got[:4 + 28 * n], ref[:4 + 28 * n]), f"rank {r}: gathered list != single-process list"
