@@ -1,0 +1,90 @@
+//! Reference-side binding of the MI355X cull engine (`include/orbit_abi.h`).
+//!
+//! This is the file a maintainer of Thefefe/orbit adds as `src/passes/orbit_hip.rs`; it is NOT
+//! compiled in this repository (no Rust toolchain in the build image) and contains no logic:
+//! `extern "C"` declarations mirroring the header, `#[repr(C)]` structs that are byte-identical to
+//! the existing `GpuCullInfo` / `ClusterCullInfo`, and the two-line bodies that replace the
+//! Vulkan recording in `src/passes/draw_gen.rs` and `src/passes/cluster.rs`.
+#![allow(non_camel_case_types, dead_code)]
+use std::ffi::{c_char, c_void};
+
+#[repr(C)]
+pub struct OrbitCtx { _private: [u8; 0] }
+
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct OrbitCaps {
+    pub max_entities: u32, pub max_dispatches: u32, pub max_draws: u32, pub max_lights: u32,
+    pub max_clusters: u32, pub dispatch_size: u32, pub reserved: [u32; 2],
+}
+
+/// push-constant order of shaders/entity_cull.comp:17-23 (== draw_gen.rs:372-376)
+#[repr(C)]
+pub struct OrbitEntityCullBufs {
+    pub entity_draw_buffer: *const c_void, pub mesh_info_buffer: *const c_void,
+    pub meshlet_dispatch_buffer: *mut c_void, pub entity_buffer: *const c_void,
+    pub visibility_buffer: *mut u32, pub depth_pyramid: *const f32,
+    pub depth_pyramid_size: [u32; 2], pub dispatch_capacity: u32, pub _pad: u32,
+}
+
+/// push-constant order of shaders/meshlet_cull.comp:16-23 (== draw_gen.rs:426-431)
+#[repr(C)]
+pub struct OrbitMeshletCullBufs {
+    pub meshlet_dispatch_buffer: *const c_void, pub meshlet_buffer: *const c_void,
+    pub draw_commands_buffer: *mut c_void, pub entity_buffer: *const c_void,
+    pub material_buffer: *const c_void, pub meshlet_visibility_buffer: *mut u32,
+    pub depth_pyramid: *const f32, pub depth_pyramid_size: [u32; 2],
+    pub dispatch_capacity: u32, pub draw_capacity: u32, pub material_count: u32, pub _pad: u32,
+}
+
+#[link(name = "orbit_cull")]
+extern "C" {
+    pub fn orbit_abi_version() -> u32;
+    pub fn orbit_default_caps(caps: *mut OrbitCaps);
+    pub fn orbit_ctx_create(device_id: i32, caps: *const OrbitCaps, out: *mut *mut OrbitCtx) -> i32;
+    pub fn orbit_ctx_destroy(ctx: *mut OrbitCtx) -> i32;
+    pub fn orbit_last_error(ctx: *const OrbitCtx) -> *const c_char;
+    pub fn orbit_ctx_status(ctx: *mut OrbitCtx, stream: *mut c_void, sync: i32) -> i32;
+    /// `cull_info` = `bytemuck::bytes_of(&GpuCullInfo)` (400 B, draw_gen.rs:208-237), a HOST pointer
+    pub fn orbit_entity_cull(ctx: *mut OrbitCtx, cull_info: *const c_void, bufs: *const OrbitEntityCullBufs,
+                             entity_draw_count: u32, stream: *mut c_void) -> i32;
+    pub fn orbit_entity_cull_range(ctx: *mut OrbitCtx, cull_info: *const c_void, bufs: *const OrbitEntityCullBufs,
+                                   draw_first: u32, draw_count: u32, stream: *mut c_void) -> i32;
+    pub fn orbit_meshlet_cull(ctx: *mut OrbitCtx, cull_info: *const c_void, bufs: *const OrbitMeshletCullBufs,
+                              stream: *mut c_void) -> i32;
+    pub fn orbit_depth_reduce(ctx: *mut OrbitCtx, depth: *const f32, screen_w: u32, screen_h: u32,
+                              pyramid: *mut f32, stream: *mut c_void) -> i32;
+    pub fn orbit_cluster_mark(ctx: *mut OrbitCtx, push: *const c_void, depth: *const f32, masks: *mut u32,
+                              bounds: *mut c_void, stream: *mut c_void) -> i32;
+    pub fn orbit_cluster_compact(ctx: *mut OrbitCtx, cluster_count: *const [u32; 3], masks: *const u32,
+                                 unique: *mut c_void, index_capacity: u32, stream: *mut c_void) -> i32;
+    pub fn orbit_cluster_assign(ctx: *mut OrbitCtx, info: *const c_void, unique: *const c_void, bounds: *const c_void,
+                                lights: *const c_void, light_index_buffer: *mut c_void, light_index_capacity: u32,
+                                cluster_offset_image: *mut u32, stream: *mut c_void) -> i32;
+}
+
+/// Turns a non-zero status into the panic the Vulkan path produced (assert!/unwrap, draw_gen.rs:247).
+pub fn check(ctx: *const OrbitCtx, rc: i32) {
+    if rc != 0 {
+        let msg = unsafe { std::ffi::CStr::from_ptr(orbit_last_error(ctx)) }.to_string_lossy().into_owned();
+        panic!("orbit_hip error {rc}: {msg}");
+    }
+}
+
+// --- body swap in src/passes/draw_gen.rs::create_meshlet_dispatch_command (lines 354-377) -----------------
+//
+//     let gpu_cull_info_data = cull_info.to_gpu(context);                       // unchanged (draw_gen.rs:347)
+//     context.add_pass(format!("{draw_commands_name}_entity_culling_hip"))
+//         .with_dependency(meshlet_dispatch_buffer, AccessKind::ComputeShaderWrite)
+//         .record_custom(move |_cmd, graph| {
+//             let bufs = OrbitEntityCullBufs {
+//                 entity_draw_buffer: graph.hip_ptr(scene.entity_draw_buffer),   // VK_KHR_external_memory_fd
+//                 mesh_info_buffer: graph.hip_ptr(assets.mesh_info_buffer),      //   import, SURVEY.md §8f rank 1
+//                 meshlet_dispatch_buffer: graph.hip_ptr_mut(meshlet_dispatch_buffer),
+//                 entity_buffer: graph.hip_ptr(scene.entity_buffer),
+//                 visibility_buffer: visibility.map_or(null_mut(), |b| graph.hip_ptr_mut(b) as *mut u32),
+//                 depth_pyramid: pyramid.map_or(null(), |i| graph.hip_image_ptr(i)),
+//                 depth_pyramid_size: pyramid_size, dispatch_capacity: MAX_MESHLET_DISPATCH_COUNT as u32, _pad: 0 };
+//             check(ctx, unsafe { orbit_entity_cull(ctx, bytes_of(&gpu_cull_info_data).as_ptr() as _, &bufs,
+//                                                   scene.entity_draw_count as u32, hip_stream) });
+//         });
+//     // the fill_buffer clears (draw_gen.rs:356-363) disappear: the library writes the {n,1,1} header itself.
