@@ -1,0 +1,229 @@
+// orbit_host_c.cpp — flat C exports of the C++ host mirror (see orbit_host_c.h).
+#include "orbit_host_c.h"
+
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+
+#include "orbit_host.hpp"
+
+using namespace orbit;
+using namespace orbit::passes;
+
+namespace {
+thread_local std::string g_err = "no error";
+
+struct HostCtx {
+    std::unique_ptr<graphics::Context> ctx;
+    std::map<std::string, std::unique_ptr<DepthPyramid>> pyramids;
+};
+
+camera::Projection to_projection(const OrbitHostProjection &p) {
+    return p.kind == 0 ? camera::Projection::perspective(p.fov, p.near_clip)
+                       : camera::Projection::orthographic(p.half_width, p.near_clip, p.far_clip);
+}
+
+CullInfo to_cull_info(const OrbitHostCullInfo &h) {
+    CullInfo ci;
+    ci.view_matrix = Mat4::from_cols_array(h.view_matrix);
+    for (uint32_t i = 0; i < h.plane_count && i < 16; i++)
+        ci.view_space_cull_planes.push_back({h.view_space_cull_planes[i][0], h.view_space_cull_planes[i][1],
+                                             h.view_space_cull_planes[i][2], h.view_space_cull_planes[i][3]});
+    ci.projection = to_projection(h.projection);
+    ci.occlusion_culling.kind = (OcclusionCullInfo::Kind)h.occlusion_kind;
+    ci.occlusion_culling.visibility_buffer.ptr = h.visibility_buffer;
+    ci.occlusion_culling.meshlet_visibility_buffer.ptr = h.meshlet_visibility_buffer;
+    ci.occlusion_culling.depth_pyramid.ptr = h.depth_pyramid;
+    ci.occlusion_culling.depth_pyramid.width = h.depth_pyramid_size[0];
+    ci.occlusion_culling.depth_pyramid.height = h.depth_pyramid_size[1];
+    ci.occlusion_culling.noskip_alphamode.bits = h.noskip_alphamode;
+    ci.occlusion_culling.aspect_ratio = h.aspect_ratio;
+    ci.alpha_mode_filter.bits = h.alpha_mode_filter;
+    ci.lod_range_start = h.lod_range[0];
+    ci.lod_range_end = h.lod_range[1];
+    ci.lod_base = h.lod_base;
+    ci.lod_step = h.lod_step;
+    ci.lod_target_pos_view_space = {h.lod_target_pos_view_space[0], h.lod_target_pos_view_space[1],
+                                    h.lod_target_pos_view_space[2]};
+    return ci;
+}
+AssetGraphData to_assets(const OrbitHostAssets &a) {
+    AssetGraphData o;
+    o.meshlet_buffer.ptr = a.meshlet_buffer;
+    o.mesh_info_buffer.ptr = a.mesh_info_buffer;
+    o.materials_buffer.ptr = a.materials_buffer;
+    o.material_count = a.material_count;
+    return o;
+}
+SceneGraphData to_scene(const OrbitHostScene &s) {
+    SceneGraphData o;
+    o.entity_draw_count = s.entity_draw_count;
+    o.entity_draw_buffer.ptr = s.entity_draw_buffer;
+    o.entity_buffer.ptr = s.entity_buffer;
+    o.light_data_buffer.ptr = s.light_data_buffer;
+    o.meshlet_visibility_buffer.ptr = s.meshlet_visibility_buffer;
+    o.light_count = s.light_count;
+    return o;
+}
+OrbitHostBuffer to_buf(const graphics::GraphBufferHandle &h) { return {h.ptr, (uint64_t)h.size}; }
+
+template <class F>
+int32_t guarded(F &&f) {
+    try {
+        f();
+        return ORBIT_OK;
+    } catch (const Panic &p) {
+        g_err = p.what();
+        return ORBIT_HOST_PANIC;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return ORBIT_HOST_PANIC;
+    }
+}
+} // namespace
+
+extern "C" {
+
+const char *orbit_host_last_error(void) { return g_err.c_str(); }
+
+void orbit_host_perspective_infinite_reverse_rh(float fov_y, float aspect, float z_near, float out[16]) {
+    std::memcpy(out, Mat4::perspective_infinite_reverse_rh(fov_y, aspect, z_near).c, 64);
+}
+void orbit_host_orthographic_rh(float l, float r, float b, float t, float n, float f, float out[16]) {
+    std::memcpy(out, Mat4::orthographic_rh(l, r, b, t, n, f).c, 64);
+}
+void orbit_host_projection_compute_matrix(const OrbitHostProjection *p, float aspect, float out[16]) {
+    std::memcpy(out, to_projection(*p).compute_matrix(aspect).c, 64);
+}
+void orbit_host_mat4_inverse(const float in[16], float out[16]) {
+    std::memcpy(out, Mat4::from_cols_array(in).inverse().c, 64);
+}
+void orbit_host_frustum_planes_from_matrix(const float m[16], float out[6][4], int32_t normalize) {
+    Vec4 pl[6];
+    math::frustum_planes_from_matrix(Mat4::from_cols_array(m), pl);
+    for (int i = 0; i < 6; i++) {
+        const Vec4 p = normalize ? math::normalize_plane(pl[i]) : pl[i];
+        out[i][0] = p.x, out[i][1] = p.y, out[i][2] = p.z, out[i][3] = p.w;
+    }
+}
+uint32_t orbit_host_mip_levels_from_size(uint32_t max_size) { return math::mip_levels_from_size(max_size); }
+int32_t orbit_host_project_sphere_clip_space(const float s[4], float znear, float p00, float p11, float aabb[4]) {
+    Vec4 a;
+    if (!math::project_sphere_clip_space({s[0], s[1], s[2], s[3]}, znear, p00, p11, &a)) return 0;
+    aabb[0] = a.x, aabb[1] = a.y, aabb[2] = a.z, aabb[3] = a.w;
+    return 1;
+}
+int32_t orbit_host_cull_info_to_gpu(const OrbitHostCullInfo *ci, OrbitGpuCullInfo *out) {
+    return guarded([&] { *out = to_cull_info(*ci).to_gpu(); });
+}
+void orbit_host_cluster_settings_derive(const OrbitHostClusterSettings *s, float z_near, OrbitHostClusterDerived *out) {
+    ClusterSettings cs;
+    cs.px_size_power = s->px_size_power;
+    cs.set_resolution(s->screen_resolution[0], s->screen_resolution[1]);
+    cs.z_slice_count = s->z_slice_count;
+    cs.far_plane = s->far_plane;
+    cs.luminance_cutoff = s->luminance_cutoff;
+    size_t t[2], c[3];
+    cs.tile_counts(t);
+    cs.cluster_counts(c);
+    out->tile_counts[0] = t[0], out->tile_counts[1] = t[1];
+    for (int i = 0; i < 3; i++) out->cluster_counts[i] = c[i];
+    out->linear_cluster_count = cs.linear_cluster_count();
+    out->linear_max_allocated_cluster_count = cs.linear_max_allocated_cluster_count();
+    out->tile_px_size = cs.tile_px_size();
+    const auto zz = cs.cluster_grid_info(z_near);
+    out->z_scale = zz.first, out->z_bias = zz.second;
+}
+
+void *orbit_host_context_create(int32_t device, void *stream, const OrbitCaps *caps) {
+    HostCtx *h = nullptr;
+    const int32_t rc = guarded([&] {
+        h = new HostCtx();
+        h->ctx.reset(new graphics::Context(device, stream, caps));
+    });
+    if (rc != ORBIT_OK) {
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+void orbit_host_context_destroy(void *hctx) { delete (HostCtx *)hctx; }
+
+int32_t orbit_host_create_meshlet_dispatch_command(void *hctx, const char *name, const OrbitHostAssets *assets,
+                                                   const OrbitHostScene *scene, const OrbitHostCullInfo *ci,
+                                                   OrbitGpuCullInfo *out_cull_info, OrbitHostBuffer *out_dispatch) {
+    return guarded([&] {
+        auto r = create_meshlet_dispatch_command(*((HostCtx *)hctx)->ctx, name, to_assets(*assets), to_scene(*scene),
+                                                 to_cull_info(*ci));
+        if (out_cull_info) *out_cull_info = r.first;
+        *out_dispatch = to_buf(r.second);
+    });
+}
+int32_t orbit_host_create_meshlet_draw_commands(void *hctx, const char *name, const OrbitHostAssets *assets,
+                                                const OrbitHostScene *scene, const OrbitHostCullInfo *ci,
+                                                const OrbitHostBuffer *dispatch, OrbitHostBuffer *out_draws) {
+    return guarded([&] {
+        graphics::GraphBufferHandle d;
+        d.ptr = dispatch->ptr;
+        d.size = dispatch->size;
+        *out_draws = to_buf(create_meshlet_draw_commands(*((HostCtx *)hctx)->ctx, name, to_assets(*assets),
+                                                         to_scene(*scene), to_cull_info(*ci), d));
+    });
+}
+int32_t orbit_host_create_draw_commands(void *hctx, const char *name, const OrbitHostAssets *assets,
+                                        const OrbitHostScene *scene, const OrbitHostCullInfo *ci,
+                                        OrbitHostBuffer *out_draws) {
+    return guarded([&] {
+        *out_draws = to_buf(create_draw_commands(*((HostCtx *)hctx)->ctx, name, to_assets(*assets), to_scene(*scene),
+                                                 to_cull_info(*ci), nullptr));
+    });
+}
+int32_t orbit_host_depth_pyramid_update(void *hctx, const char *name, const float *depth, uint32_t width,
+                                        uint32_t height, float **out_pyramid, uint32_t out_size_mips[3]) {
+    return guarded([&] {
+        HostCtx *h = (HostCtx *)hctx;
+        auto &p = h->pyramids[name];
+        if (!p) p.reset(new DepthPyramid(*h->ctx, name, width, height));
+        p->resize(*h->ctx, width, height);
+        graphics::GraphImageHandle d;
+        d.ptr = const_cast<float *>(depth);
+        d.width = width;
+        d.height = height;
+        p->update(*h->ctx, d);
+        const graphics::GraphImageHandle cur = p->get_current();
+        *out_pyramid = cur.ptr;
+        out_size_mips[0] = cur.width, out_size_mips[1] = cur.height, out_size_mips[2] = cur.mip_levels;
+    });
+}
+int32_t orbit_host_compute_clusters(void *hctx, const OrbitHostClusterSettings *s, const float view_matrix[16],
+                                    const OrbitHostProjection *projection, float aspect_ratio, const float *depth,
+                                    uint32_t depth_size[2], uint32_t samples, const OrbitHostScene *scene,
+                                    OrbitHostClusterOut *out) {
+    return guarded([&] {
+        ClusterSettings cs;
+        cs.px_size_power = s->px_size_power;
+        cs.set_resolution(s->screen_resolution[0], s->screen_resolution[1]);
+        cs.z_slice_count = s->z_slice_count;
+        cs.far_plane = s->far_plane;
+        cs.luminance_cutoff = s->luminance_cutoff;
+        Camera cam;
+        cam.view_matrix = Mat4::from_cols_array(view_matrix);
+        cam.projection = to_projection(*projection);
+        cam.aspect_ratio = aspect_ratio;
+        graphics::GraphImageHandle d;
+        d.ptr = const_cast<float *>(depth);
+        d.width = depth_size[0];
+        d.height = depth_size[1];
+        d.samples = samples;
+        const GraphClusterInfo r = compute_clusters(*((HostCtx *)hctx)->ctx, cs, cam, d, to_scene(*scene));
+        out->tile_depth_slice_mask = to_buf(r.tile_depth_slice_mask);
+        out->depth_bounds = to_buf(r.depth_bounds);
+        out->unique_cluster_buffer = to_buf(r.unique_cluster_buffer);
+        out->light_offset_image = to_buf(r.light_offset_image);
+        out->light_index_list = to_buf(r.light_index_list);
+        out->info = r.info;
+    });
+}
+
+} // extern "C"

@@ -1,0 +1,88 @@
+"""CPU tests of the C++ host mirror (orbit_amd/host) against the tests' own numpy helpers and
+the oracle: the parameter derivations of src/math.rs, src/camera.rs, CullInfo::to_gpu and
+ClusterSettings, with the reference's names."""
+import numpy as np
+import pytest
+
+import scenes as sc
+from orbit_amd import layouts as L, passes
+
+
+def test_projection_matrices():
+    fov, aspect, near = float(np.deg2rad(np.float32(90.0))), 16.0 / 9.0, 0.01
+    got = passes.perspective_infinite_reverse_rh(fov, aspect, near)
+    assert np.allclose(got, sc.mat4_cols(sc.perspective_infinite_reverse_rh(fov, aspect, near)), rtol=1e-6)
+    assert got[11] == -1.0 and got[14] == np.float32(near) and got[10] == 0.0 and got[15] == 0.0
+    o = passes.orthographic_rh(-25, 25, -10, 10, 80.0, 0.1)
+    assert np.allclose(o, sc.mat4_cols(sc.orthographic_rh(-25, 25, -10, 10, 80.0, 0.1)), rtol=1e-6)
+    # Projection::compute_matrix swaps far and near for reverse-Z (camera.rs:91-96)
+    p = passes.projection_compute_matrix(passes.Projection.Orthographic(25.0, 0.1, 80.0), 2.5)
+    assert np.allclose(p, passes.orthographic_rh(-25, 25, -10, 10, 80.0, 0.1))
+
+
+def test_mat4_inverse_and_planes(oracle):
+    cam = sc.default_camera(rot=(0.6, 0.8))
+    proj = sc.mat4_cols(cam.proj)
+    inv = passes.mat4_inverse(proj).reshape(4, 4).T
+    assert np.allclose(inv @ cam.proj, np.eye(4), atol=1e-5)
+    planes = passes.frustum_planes_from_matrix(proj)
+    assert np.allclose(planes, oracle.frustum_planes_from_matrix(proj), rtol=1e-6, atol=1e-7)
+    assert np.allclose(planes[:5], sc.frustum_planes(cam.proj, 5), rtol=1e-6, atol=1e-7)
+    raw = passes.frustum_planes_from_matrix(proj, normalize=False)
+    assert np.allclose(raw[4], [0, 0, -1, cam.z_near])  # r3 + r2 of the infinite reverse-Z matrix
+
+
+@pytest.mark.parametrize("n,expect", [(1, 1), (2, 2), (1024, 11), (2048, 12), (3, 2)])
+def test_mip_levels(n, expect, oracle):
+    assert passes.mip_levels_from_size(n) == expect
+
+
+def test_project_sphere_clip_space():
+    assert passes.project_sphere_clip_space((0, 0, 0.5, 1.0), 0.01, 1.0, 1.0) is None  # c.z < r + znear
+    a = passes.project_sphere_clip_space((0.0, 0.0, 10.0, 1.0), 0.01, 1.0, 1.0)
+    assert a is not None and a[0] < 0 < a[2] and np.isclose(a[0], -a[2]) and np.isclose(a[1], -a[3])
+
+
+def test_cull_info_to_gpu_matches_layout():
+    cam = sc.default_camera()
+    view = sc.mat4_cols(cam.view)
+    proj = passes.Projection.Perspective(cam.fov, cam.z_near)
+    # OcclusionCullInfo::None, forward.rs:266-284 without occlusion
+    g0 = passes.cull_info_to_gpu(passes.CullInfo(view, cam.planes, proj))
+    ref0 = sc.make_cull_info(cam.view, cam.planes)
+    for f in ("view_matrix", "cull_planes", "cull_plane_count", "alpha_mode_flag", "occlusion_pass",
+              "visibility_buffer", "meshlet_visibility_buffer", "depth_pyramid", "projection_type", "lod_base",
+              "lod_step", "min_mesh_lod", "max_mesh_lod", "p00_or_width_recipx2", "z_near"):
+        assert np.array_equal(g0[f], ref0[f]), f
+    assert g0["visibility_buffer"] == L.NONE and g0["p00_or_width_recipx2"] == 0.0  # filled only for VisibilityWrite
+    # VisibilityWrite, forward.rs:371-389
+    ci2 = passes.CullInfo(view, cam.planes, proj, occlusion_kind=passes.VISIBILITY_WRITE, visibility_buffer=0x1000,
+                          meshlet_visibility_buffer=0x2000, depth_pyramid=0x3000, depth_pyramid_size=(1024, 1024),
+                          aspect_ratio=cam.aspect, lod_range=(1, 6), lod_target_pos_view_space=(1, 2, 3))
+    g2 = passes.cull_info_to_gpu(ci2)
+    assert g2["occlusion_pass"] == 2 and g2["visibility_buffer"] != L.NONE and g2["depth_pyramid"] != L.NONE
+    assert np.isclose(g2["p00_or_width_recipx2"], cam.p00, rtol=1e-6) and np.isclose(g2["p11_or_height_recipx2"], cam.p11)
+    assert g2["z_near"] == np.float32(cam.z_near) and (g2["min_mesh_lod"], g2["max_mesh_lod"]) == (1, 5)
+    assert list(g2["lod_target_pos_view_space"]) == [1, 2, 3]
+    # meshlet_visibility_buffer: Option::None -> u32::MAX (draw_gen.rs:143)
+    g2n = passes.cull_info_to_gpu(passes.CullInfo(view, cam.planes, proj, occlusion_kind=passes.VISIBILITY_WRITE,
+                                                  visibility_buffer=0x1000, depth_pyramid=0x3000))
+    assert g2n["meshlet_visibility_buffer"] == L.NONE
+    # orthographic VisibilityWrite: 2/width, 2/height, z_far (draw_gen.rs:186-198)
+    go = passes.cull_info_to_gpu(passes.CullInfo(view, cam.planes, passes.Projection.Orthographic(25.0, 0.1, 80.0),
+                                                 occlusion_kind=passes.VISIBILITY_WRITE, visibility_buffer=1,
+                                                 depth_pyramid=1, aspect_ratio=2.0))
+    assert go["projection_type"] == 1 and np.isclose(go["p00_or_width_recipx2"], 2.0 / 50.0)
+    assert np.isclose(go["p11_or_height_recipx2"], 2.0 / 25.0) and go["z_far"] == np.float32(80.0)
+
+
+def test_cluster_settings(oracle):
+    s = passes.ClusterSettings(screen_resolution=(1920, 1080))
+    d = passes.cluster_settings_derive(s, 0.01)
+    assert list(d.tile_counts) == [240, 135] and list(d.cluster_counts) == [240, 135, 32]
+    assert d.linear_cluster_count == 1_036_800 == d.linear_max_allocated_cluster_count and d.tile_px_size == 8
+    zs, zb = oracle.cluster_grid_info(0.01, 200.0, 32)
+    assert np.isclose(d.z_scale, zs, rtol=1e-5) and np.isclose(d.z_bias, zb, rtol=1e-5)
+    s2 = passes.ClusterSettings(px_size_power=6, screen_resolution=(333, 65), z_slice_count=2)
+    d2 = passes.cluster_settings_derive(s2, 0.1)
+    assert list(d2.tile_counts) == [6, 2] and d2.linear_max_allocated_cluster_count == 6 * 2 * 4  # max(4, z) slices
