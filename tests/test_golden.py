@@ -1,0 +1,110 @@
+"""Golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py): the oracle must
+keep reproducing them on CPU, and the HIP engine must reproduce them on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from orbit_amd import layouts as L
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CULL = ["cull_small.npz", "cull_ragged.npz"]
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLD, name)))
+
+
+@pytest.mark.parametrize("name", CULL)
+def test_oracle_reproduces_cull_fixture(oracle, name):
+    g = load(name)
+    n, (cap_d, cap_c), ps = int(g["entity_draw_count"]), g["caps"], tuple(int(v) for v in g["pyramid_size"])
+    pyr, _ = oracle.depth_reduce(g["depth"], g["depth"].shape[1], g["depth"].shape[0])
+    assert np.array_equal(pyr.view(np.uint32), g["pyramid"].view(np.uint32))
+    for p in (0, 1, 2):
+        ci = g[f"ci{p}"]
+        disp, ev, _ = oracle.entity_cull(ci, g["entity_draw_buffer"], n, g["mesh_infos"], g["entities"], int(cap_d),
+                                         g["evis"] if p else None, g["pyramid"] if p == 2 else None, ps)
+        draw, mv, _ = oracle.meshlet_cull(ci, disp, g["meshlets"], int(cap_c), g["entities"], g["materials"],
+                                          g["mvis"] if p else None, g["pyramid"] if p == 2 else None, ps)
+        assert np.array_equal(disp[:len(g[f"disp{p}"])], g[f"disp{p}"])
+        assert np.array_equal(draw[:len(g[f"draw{p}"])], g[f"draw{p}"])
+        if p == 2:
+            assert np.array_equal(ev, g["evis_out"]) and np.array_equal(mv, g["mvis_out"])
+
+
+def test_oracle_reproduces_cluster_fixture(oracle):
+    g = load("cluster_small.npz")
+    cc = [int(v) for v in g["push"][:12].view(np.uint32)]
+    masks, bounds = oracle.cluster_mark(g["push"], g["depth"])
+    assert np.array_equal(masks, g["masks"]) and np.array_equal(bounds, g["bounds"])
+    unique, _ = oracle.cluster_compact(cc, masks, cc[0] * cc[1] * cc[2])
+    assert np.array_equal(unique[:len(g["unique"])], g["unique"])
+    na = int(unique[12:16].view(np.uint32)[0])
+    lidx, img, _ = oracle.cluster_assign(g["info"], unique, bounds, g["lights"], na * 256 + 8, cc[0] * cc[1] * cc[2])
+    assert np.array_equal(lidx[:len(g["light_indices"])], g["light_indices"]) and np.array_equal(img, g["offset_image"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CULL)
+def test_gpu_reproduces_cull_fixture(name):
+    import torch
+
+    from orbit_amd.engine import Engine
+
+    g = load(name)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).cuda()
+    n, (cap_d, cap_c), ps = int(g["entity_draw_count"]), [int(v) for v in g["caps"]], tuple(int(v) for v in g["pyramid_size"])
+    eng = Engine(0)
+    H, W = g["depth"].shape
+    gpyr = torch.zeros(len(g["pyramid"]), dtype=torch.float32, device="cuda")
+    eng.depth_reduce(dev(g["depth"]), W, H, gpyr)
+    torch.cuda.synchronize()
+    assert np.array_equal(gpyr.cpu().numpy().view(np.uint32), g["pyramid"].view(np.uint32))
+    bufs = {k: dev(g[k]) for k in ("entity_draw_buffer", "mesh_infos", "entities", "meshlets", "materials")}
+    for p in (0, 1, 2):
+        ci = g[f"ci{p}"]
+        evis, mvis = (dev(g["evis"]), dev(g["mvis"])) if p else (None, None)
+        disp = torch.zeros(12 + 16 * cap_d, dtype=torch.uint8, device="cuda")
+        draw = torch.zeros(4 + 28 * cap_c, dtype=torch.uint8, device="cuda")
+        kw = dict(depth_pyramid=gpyr if p == 2 else None, depth_pyramid_size=ps if p == 2 else (0, 0))
+        eng.entity_cull(ci, bufs["entity_draw_buffer"], bufs["mesh_infos"], disp, bufs["entities"], n, cap_d,
+                        visibility_buffer=evis, **kw)
+        eng.meshlet_cull(ci, disp, bufs["meshlets"], draw, bufs["entities"], bufs["materials"], cap_d, cap_c,
+                         meshlet_visibility_buffer=mvis, material_count=len(g["materials"]) // 80, **kw)
+        torch.cuda.synchronize()
+        assert np.array_equal(disp.cpu().numpy()[:len(g[f"disp{p}"])], g[f"disp{p}"])
+        assert np.array_equal(draw.cpu().numpy()[:len(g[f"draw{p}"])], g[f"draw{p}"])
+        if p == 2:
+            assert np.array_equal(evis.cpu().numpy().view(np.uint32), g["evis_out"])
+            assert np.array_equal(mvis.cpu().numpy().view(np.uint32), g["mvis_out"])
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_cluster_fixture():
+    import torch
+
+    from orbit_amd.engine import Engine
+
+    g = load("cluster_small.npz")
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).cuda()
+    cc = [int(v) for v in g["push"][:12].view(np.uint32)]
+    total = cc[0] * cc[1] * cc[2]
+    eng = Engine(0)
+    gm = torch.zeros(cc[0] * cc[1], dtype=torch.int32, device="cuda")
+    gb = torch.zeros((total, 2), dtype=torch.int32, device="cuda")
+    eng.cluster_mark(g["push"], dev(g["depth"]), gm, gb)
+    gu = torch.zeros(16 + 4 * total, dtype=torch.uint8, device="cuda")
+    eng.cluster_compact(cc, gm, gu, total)
+    na = (len(g["unique"]) - 16) // 4
+    gl = torch.zeros(4 + 4 * (na * 256 + 8), dtype=torch.uint8, device="cuda")
+    gimg = torch.zeros((total, 2), dtype=torch.int32, device="cuda")
+    eng.cluster_assign(g["info"], gu, gb, dev(g["lights"]), gl, na * 256 + 8, gimg)
+    torch.cuda.synchronize()
+    assert np.array_equal(gm.cpu().numpy().view(np.uint32), g["masks"])
+    assert np.array_equal(gb.cpu().numpy().view(np.uint32), g["bounds"])
+    assert np.array_equal(gu.cpu().numpy()[:len(g["unique"])], g["unique"])
+    assert np.array_equal(gl.cpu().numpy()[:len(g["light_indices"])], g["light_indices"])
+    assert np.array_equal(gimg.cpu().numpy().view(np.uint32), g["offset_image"])
+    eng.close()

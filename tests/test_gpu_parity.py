@@ -331,3 +331,37 @@ def test_light_clusters(torch_mod, engine, oracle, W, H, n_lights, tile, zs, sam
     engine.status()
     if n_lights >= 200:
         assert n_idx > 0 and n_active > 0
+
+
+# ----------------------------------------------------------------------------- sharded ranges
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_ranges_concatenate_to_the_canonical_list(torch_mod, engine, oracle, world):
+    """Each rank culls its 32-aligned entity range through orbit_entity_cull_range and holds only its
+    meshlet shard (passed under global indices via a shifted base pointer, as bench.py does); the
+    rank-order concatenation must be the single-GPU sequence."""
+    from orbit_amd.dist import shard_ranges
+
+    torch = torch_mod
+    scene = sc.make_scene(23, 700, meshlets_per_mesh=(8, 40), shuffle=False)  # identity map: meshlets follow entities
+    cam = sc.default_camera()
+    ci = sc.make_cull_info(cam.view, cam.planes)
+    gs = GpuScene(torch, scene)
+    ref = run_oracle(oracle, scene, ci)
+    on, ocmds = L.draw_buffer_commands(ref[1])
+    lod0 = scene.mesh_infos["mesh_lods"][:, 0]
+    parts = []
+    for b, e in shard_ranges(scene.entity_draw_count, world):
+        m0 = int(lod0[b, 0]) if b < scene.entity_draw_count else 0
+        m1 = int(lod0[e - 1, 0] + lod0[e - 1, 1]) if e > b else m0
+        shard = dev(torch, scene.meshlets[m0:m1]) if m1 > m0 else torch.zeros(32, dtype=torch.uint8, device="cuda")
+        base = shard.data_ptr() - m0 * 32  # global meshlet indices land inside the shard
+        cap_d, cap_c = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
+        disp = torch.zeros(L.DISPATCH_HEADER + 16 * cap_d, dtype=torch.uint8, device="cuda")
+        draw = torch.zeros(L.DRAW_HEADER + 28 * cap_c, dtype=torch.uint8, device="cuda")
+        engine.entity_cull(ci, gs.draws, gs.mesh_infos, disp, gs.entities, e - b, cap_d, draw_first=b)
+        engine.meshlet_cull(ci, disp, base, draw, gs.entities, gs.materials, cap_d, cap_c)
+        torch.cuda.synchronize()
+        n, cmds = L.draw_buffer_commands(host(draw))
+        parts.append(cmds)
+    got = np.concatenate(parts)
+    assert len(got) == on and np.array_equal(got.view(np.uint32), ocmds.view(np.uint32))
