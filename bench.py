@@ -39,6 +39,7 @@ def parse():
                     help="entities of the scene the CPU oracle is timed on (rank 0, N=1 only); 0 disables")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="minimum CPU time spent in the oracle baseline")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather (cull only)")
+    ap.add_argument("--planes", type=int, default=5, help="cull planes used (5 = forward.rs:268; fewer only for triage)")
     return ap.parse_args()
 
 
@@ -80,7 +81,7 @@ def main():
     # camera outside the +-512 m box so that every entity passes the frustum: all E*M meshlets
     # reach meshlet_cull (the HBM-bound case the metric is about)
     cam = sc.default_camera(position=(0.0, 0.0, 1300.0))
-    ci = sc.make_cull_info(cam.view, cam.planes)
+    ci = sc.make_cull_info(cam.view, cam.planes[:args.planes])
 
     disp_cap = n_local_entities * rec_per_ent + 8
     draw_cap = n_local_meshlets // 2 + 1024

@@ -590,7 +590,7 @@ __global__ __launch_bounds__(kSpBlock) void meshlet_cull_single_pass(const Meshl
 // that the compiler's vmcnt accounting stays exact.
 constexpr int kEvWaves = 4;
 
-template <int PASS>
+template <int PASS, bool PROF>
 __global__ __launch_bounds__(kEvWaves * 64) void meshlet_eval_kernel(const MeshletCullParams p) {
     __shared__ WaveTileLds lds[kEvWaves][3];
     __shared__ PlaneLds planes;
@@ -618,6 +618,18 @@ __global__ __launch_bounds__(kEvWaves * 64) void meshlet_eval_kernel(const Meshl
         rows_load<PASS, 2, 2>(p, lds[wave][0], lane, qb);
     }
     uint32_t it = 0;
+    unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1;
+#define EV_STAMP(k)                            \
+    if (PROF) {                                \
+        t1 = __builtin_amdgcn_s_memtime();     \
+        __builtin_amdgcn_s_waitcnt(0xC07F);    \
+        tc[k] += t1 - t0;                      \
+        t0 = t1;                               \
+    }
+    if (PROF) {
+        t0 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
     while (w0 < ntiles) {
         const uint32_t w3 = w2 + stride;
         WaveTileLds &L = lds[wave][it % 3];
@@ -626,23 +638,32 @@ __global__ __launch_bounds__(kEvWaves * 64) void meshlet_eval_kernel(const Meshl
         uint32_t total = 0;
         total = rows_eval<PASS, true, 0, 2>(p, L, planes, alpha, lane, qa, total, payload);
         rows_load<PASS, 4, 2>(p, L, lane, qa);
+        EV_STAMP(0)
         total = rows_eval<PASS, true, 2, 2>(p, L, planes, alpha, lane, qb, total, payload);
         rows_load<PASS, 6, 2>(p, L, lane, qb);
         const float4 mat2 = setup_load_mat(p, rec2, lane);
         const uint4 rec3 = setup_load_rec(p, w3, w3 < ntiles, nrec, lane);
+        EV_STAMP(1)
         total = rows_eval<PASS, true, 4, 2>(p, L, planes, alpha, lane, qa, total, payload);
         rows_load<PASS, 0, 2>(p, Ln, lane, qa);
+        EV_STAMP(2)
         total = rows_eval<PASS, true, 6, 2>(p, L, planes, alpha, lane, qb, total, payload);
         rows_load<PASS, 2, 2>(p, Ln, lane, qb);
+        EV_STAMP(3)
         setup_write(p, lds[wave][(it + 2) % 3], rec2, mat2, lane); // also fences the mask writes of this tile
         if (lane < 2 * (int)kTileRows)
             p.tile_masks[(size_t)w0 * (2 * kTileRows) + lane] = reinterpret_cast<const uint32_t *>(L.draw_mask)[lane];
         if (lane == 0) p.tile_counts[w0] = total;
+        EV_STAMP(4)
         w0 = w1;
         w1 = w2;
         w2 = w3;
         rec2 = rec3;
         it++;
+    }
+    if (PROF && lane == 0) {
+        for (int k = 0; k < 5; k++) atomicAdd(p.debug_cycles + k, tc[k]);
+        atomicAdd(p.debug_cycles + 7, 1ull);
     }
 }
 
@@ -769,7 +790,11 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, int mode, h
     if (blocks > need) blocks = need;
     if (blocks == 0) blocks = 1;
     if (ev0) (void)hipEventRecord(ev0, s);
-    hipLaunchKernelGGL(meshlet_eval_kernel<PASS>, dim3(blocks), dim3(kEvWaves * 64), 0, s, p);
+    if (PASS == 0 && (p.debug_flags & 8u))
+        hipLaunchKernelGGL((meshlet_eval_kernel<PASS == 0 ? 0 : PASS, PASS == 0>), dim3(blocks), dim3(kEvWaves * 64), 0,
+                           s, p);
+    else
+        hipLaunchKernelGGL((meshlet_eval_kernel<PASS, false>), dim3(blocks), dim3(kEvWaves * 64), 0, s, p);
     if (ev1) (void)hipEventRecord(ev1, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
