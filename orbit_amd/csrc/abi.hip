@@ -170,7 +170,6 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t eblocks = ent / 256 + 1;
     const size_t mtiles = ((size_t)caps.max_dispatches + kTileRecords - 1) / kTileRecords + 1;
     const size_t cchunks = ((size_t)caps.max_clusters / 1024 + 64) * 32;
-    const size_t ablocks = (size_t)caps.max_clusters / 256 + 2;
     size_t off = 0;
     auto carve = [&](size_t bytes) {
         const size_t o = off;
@@ -192,7 +191,9 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t o_avl = carve((size_t)caps.max_lights * 16 + 1024);
     const size_t o_alf = carve(((size_t)caps.max_lights / 32 + 64) * 4);
     const size_t o_acn = carve(((size_t)caps.max_clusters + 256) * 4);
-    const size_t o_abs = carve(ablocks * 4), o_abb = carve(ablocks * 4), o_at = carve(256);
+    // assign: block_sums holds chunk sums | chunk bases of the two-level scan; block_base one word per cluster
+    const size_t o_abs = carve((2 * ((size_t)caps.max_clusters / kScanChunk + 2) + 64) * 4);
+    const size_t o_abb = carve(((size_t)caps.max_clusters + 256) * 4), o_at = carve(256);
     ctx->arena_bytes = off;
     e = hipMalloc((void **)&ctx->arena, ctx->arena_bytes);
     if (e != hipSuccess) {

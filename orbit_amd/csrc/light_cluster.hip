@@ -209,76 +209,116 @@ __device__ __forceinline__ bool sphere_hits(const Aabb3 &a, const float4 l) {
     return sq <= l.w;
 }
 
-constexpr uint32_t kLightTile = 1024;
+constexpr uint32_t kLightTile = 1024;  // lights staged in LDS per step (16 KB)
+constexpr int kClustersPerWave = 4;    // cluster AABBs held in scalar registers per wave
+constexpr int kAssignWaves = 4;
+constexpr int kClustersPerBlock = kClustersPerWave * kAssignWaves;
 
-// One thread per active cluster; lights staged through LDS in tiles.
-// WRITE = false: count pass (:128-135); WRITE = true: index pass (:138-150).
+// Lane = light.  A wave owns 4 active clusters whose AABBs sit in SGPRs; every step it reads 64
+// view-space lights from the LDS tile (one conflict-free ds_read_b128 per lane), tests them against
+// the 4 boxes, and turns the hit ballots into counts (WRITE = false, light_culling.comp:128-135) or
+// into ascending index writes at the scanned offset (WRITE = true, :138-147).  The reference runs
+// one thread per cluster and re-reads every light from memory twice per cluster.
 template <bool WRITE>
-__global__ __launch_bounds__(256) void cluster_assign_kernel(const ClusterAssignParams p) {
+__global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const ClusterAssignParams p) {
     __shared__ float4 s_light[kLightTile];
     __shared__ uint32_t s_flags[kLightTile / 32];
-    __shared__ uint32_t smem[256 / 64 + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.unique);
     const uint32_t n = min(hdr[3], p.max_clusters);
-    if (blockIdx.x * 256u >= n) { // block-uniform: nothing here (grid is a capacity bound)
-        if (!WRITE && threadIdx.x == 0) p.block_sums[blockIdx.x] = 0u;
-        return;
-    }
-    const uint32_t u = blockIdx.x * 256 + threadIdx.x;
-    const bool active = u < n; // :123
-    uint32_t ci = 0;
+    const uint32_t block_first = blockIdx.x * kClustersPerBlock;
+    if (block_first >= n) return; // block-uniform (the grid is a capacity bound)
+    const uint32_t u0 = block_first + wave * kClustersPerWave;
+    const uint32_t *unique_idx = reinterpret_cast<const uint32_t *>(p.unique + ORBIT_COMPACT_HEADER);
+
+    // lanes 0..3 build the AABBs of the wave's clusters; broadcast through readlane into SGPRs
     Aabb3 box = {};
-    if (active) {
-        ci = reinterpret_cast<const uint32_t *>(p.unique + ORBIT_COMPACT_HEADER)[u];
-        box = cluster_aabb(p, ci);
+    uint32_t my_ci = 0, my_limit = 0, my_offset = 0;
+    if (lane < kClustersPerWave && u0 + lane < n) {
+        my_ci = unique_idx[u0 + lane];
+        box = cluster_aabb(p, my_ci);
+        if (WRITE) {
+            my_limit = p.counts[u0 + lane];
+            my_offset = p.block_base[u0 + lane]; // exclusive prefix of the capped counts (scan of p.counts)
+        }
     }
-    const uint32_t nl = p.info.global_light_count;
-    uint32_t count = 0, limit = 0, offset = 0;
+    float mn[kClustersPerWave][3], mx[kClustersPerWave][3];
+    uint32_t offset[kClustersPerWave], limit[kClustersPerWave], count[kClustersPerWave];
+    bool valid[kClustersPerWave];
+#pragma unroll
+    for (int c = 0; c < kClustersPerWave; c++) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            mn[c][i] = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(box.mn[i]), c));
+            mx[c][i] = __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(box.mx[i]), c));
+        }
+        offset[c] = (uint32_t)__builtin_amdgcn_readlane((int)my_offset, c);
+        limit[c] = (uint32_t)__builtin_amdgcn_readlane((int)my_limit, c);
+        count[c] = 0;
+        valid[c] = u0 + c < n;
+    }
     uint32_t *out = reinterpret_cast<uint32_t *>(p.light_index_buffer + ORBIT_LIGHT_INDEX_HEADER);
-    if (WRITE) {
-        uint32_t block_total;
-        const uint32_t c = active ? p.counts[u] : 0u;
-        offset = p.block_base[blockIdx.x] + block_exclusive_scan<4>(c, smem, &block_total);
-        limit = c;
-    }
+    const uint32_t nl = p.info.global_light_count;
     for (uint32_t base = 0; base < nl; base += kLightTile) {
         const uint32_t tile_n = min(kLightTile, nl - base);
-        for (uint32_t i = threadIdx.x; i < tile_n; i += 256) s_light[i] = p.view_lights[base + i];
+        __syncthreads(); // previous tile fully consumed
+        for (uint32_t i = threadIdx.x; i < tile_n; i += kAssignWaves * 64) s_light[i] = p.view_lights[base + i];
         if (threadIdx.x < (tile_n + 31) / 32) s_flags[threadIdx.x] = p.light_flags[base / 32 + threadIdx.x];
         __syncthreads();
-        if (active) {
-            for (uint32_t i = 0; i < tile_n; i++) {
-                const bool point = (s_flags[i >> 5] >> (i & 31)) & 1u;
-                const bool hit = !point || sphere_hits(box, s_light[i]); // :108-119
-                if (hit) {
-                    if (WRITE) {
-                        if (count < limit) { // while (light_counter < light_count), :140
-                            if (offset + count < p.light_index_capacity) out[offset + count] = base + i;
-                        }
+        for (uint32_t b0 = 0; b0 < tile_n; b0 += 64) {
+            const uint32_t li = b0 + lane;
+            const bool in_tile = li < tile_n;
+            const float4 l = s_light[in_tile ? li : 0];
+            const bool point = (s_flags[(in_tile ? li : 0) >> 5] >> (li & 31)) & 1u;
+#pragma unroll
+            for (int c = 0; c < kClustersPerWave; c++) {
+                if (!valid[c]) continue; // wave-uniform
+                Aabb3 a;
+#pragma unroll
+                for (int i = 0; i < 3; i++) a.mn[i] = mn[c][i], a.mx[i] = mx[c][i];
+                const bool hit = in_tile && (!point || sphere_hits(a, l)); // :108-119
+                const uint64_t m = __ballot(hit);
+                if (WRITE) {
+                    if (hit) {
+                        const uint32_t k = count[c] + lane_prefix(m);
+                        if (k < limit[c] && offset[c] + k < p.light_index_capacity) // while (counter < light_count), :140
+                            out[offset[c] + k] = base + li;
                     }
-                    count++;
                 }
+                count[c] += (uint32_t)__popcll(m);
             }
         }
-        __syncthreads();
     }
-    if (!WRITE) {
-        const uint32_t c = min(count, ORBIT_MAX_LIGHTS_PER_CLUSTER); // :135
-        if (active) p.counts[u] = c;
-        uint32_t block_total;
-        (void)block_exclusive_scan<4>(active ? c : 0u, smem, &block_total);
-        if (threadIdx.x == 0) p.block_sums[blockIdx.x] = block_total;
-    } else {
-        if (active) { // imageStore(cluster_offset_image, cluster_id, (offset, count)), :149-150
-            p.offset_image[2 * (size_t)ci + 0] = offset;
-            p.offset_image[2 * (size_t)ci + 1] = limit;
-        }
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            const uint32_t total = *p.total;
-            *reinterpret_cast<uint32_t *>(p.light_index_buffer) = total; // atomicAdd total, :136
-            if (total > p.light_index_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+#pragma unroll
+    for (int c = 0; c < kClustersPerWave; c++) {
+        if (!valid[c] || lane != 0) continue;
+        if (!WRITE) {
+            p.counts[u0 + c] = min(count[c], ORBIT_MAX_LIGHTS_PER_CLUSTER); // :135
+        } else {
+            // imageStore(cluster_offset_image, cluster_id, (offset, count)), :149-150
+            const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)my_ci, c);
+            p.offset_image[2 * (size_t)ci + 0] = offset[c];
+            p.offset_image[2 * (size_t)ci + 1] = limit[c];
         }
     }
+    if (WRITE && blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t total = *p.total;
+        *reinterpret_cast<uint32_t *>(p.light_index_buffer) = total; // atomicAdd total, :136
+        if (total > p.light_index_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+    }
+}
+
+// block_base[i] += chunk_base[i / kScanChunk]: makes the two-level scan's output a plain exclusive prefix
+__global__ __launch_bounds__(256) void cluster_assign_add_chunk_base(const ClusterAssignParams p) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < p.max_clusters) p.block_base[i] += (p.block_sums + (p.max_clusters / kScanChunk + 2))[i / kScanChunk];
+}
+
+// zeroes the counts of the capacity-bound tail so that the scan over all max_clusters entries is exact
+__global__ __launch_bounds__(256) void cluster_assign_clear_tail(const ClusterAssignParams p) {
+    const uint32_t n = min(reinterpret_cast<const uint32_t *>(p.unique)[3], p.max_clusters);
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n && i < p.max_clusters) p.counts[i] = 0u;
 }
 
 // header for an empty active list: light_count = 0 (cluster.rs:575-581)
@@ -321,17 +361,21 @@ hipError_t launch_cluster_assign(const ClusterAssignParams &p, hipStream_t s) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    const uint32_t blocks = (p.max_clusters + 255) / 256;
-    if (blocks == 0) {
+    if (p.max_clusters == 0) {
         hipLaunchKernelGGL(write_word, dim3(1), dim3(1), 0, s, reinterpret_cast<uint32_t *>(p.light_index_buffer), 0u);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(cluster_assign_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
+    const uint32_t blocks = (p.max_clusters + kClustersPerBlock - 1) / kClustersPerBlock;
+    hipLaunchKernelGGL(cluster_assign_clear_tail, dim3((p.max_clusters + 255) / 256), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(cluster_assign_kernel<false>, dim3(blocks), dim3(kAssignWaves * 64), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = launch_scan_exclusive(p.block_sums, p.block_base, blocks, p.total, s);
+    // exclusive scan of the per-cluster counts: chunk-local prefixes + chunk bases, folded into block_base
+    e = launch_scan_two_level(p.counts, p.block_base, nullptr, 1u, p.max_clusters, p.block_sums,
+                              p.block_sums + (p.max_clusters / kScanChunk + 2), p.total, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cluster_assign_kernel<true>, dim3(blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(cluster_assign_add_chunk_base, dim3((p.max_clusters + 255) / 256), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(cluster_assign_kernel<true>, dim3(blocks), dim3(kAssignWaves * 64), 0, s, p);
     return hipGetLastError();
 }
 
