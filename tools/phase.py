@@ -23,7 +23,7 @@ lib.orbit_debug_read_cycles(eng._ctx, out)
 n = 5
 for _ in range(n): eng.meshlet_cull(ci, disp, ml, draw, ent, mat, dc, cc)
 lib.orbit_debug_read_cycles(eng._ctx, out)
-names = ["evalQ0+loadA", "evalQ1+loadB+mat/rec", "evalQ2+loadA'", "evalQ3+loadB'", "slab write+mask store"] if not os.environ.get("ORBIT_MESHLET_LOOKBACK") else ["ticket", "eval(+wait loads)", "prefetch issue", "look-back", "emit"]
+names = ["wait for data", "rows_eval", "rows_load issue", "(unused)", "slab write+mask store"] if not os.environ.get("ORBIT_MESHLET_LOOKBACK") else ["ticket", "eval(+wait loads)", "prefetch issue", "look-back", "emit"]
 tot = sum(out[k] for k in range(5)); waves = out[7]
 print("waves", waves // n, "cycles/wave", tot / waves)
 for k in range(5): print(f"  {names[k]:20s} {100.0 * out[k] / tot:5.1f}%   {out[k] / waves / 100.0:8.2f} us/wave (100 MHz ticks?)")

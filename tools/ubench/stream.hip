@@ -1,0 +1,63 @@
+// Micro-benchmark: HBM streaming read bandwidth on MI355X as a function of 16-B loads in flight per lane,
+// with the meshlet_eval access pattern (lane reads 32 contiguous bytes = 2 x dwordx4, rows of 2 KiB per wave).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+template <int ROWS>  // rows (2 x dwordx4 per lane) in flight per wave
+__global__ __launch_bounds__(256) void stream_kernel(const uint4 *src, size_t n_rows, unsigned *sink) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t stride = (size_t)gridDim.x * 4;
+    unsigned acc = 0;
+    // each "row" = 64 lanes x 32 B; a wave takes ROWS consecutive rows per step
+    for (size_t r0 = wave * ROWS; r0 + ROWS <= n_rows; r0 += stride * ROWS) {
+        uint4 a[ROWS], b[ROWS];
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) {
+            const uint4 *p = src + ((r0 + k) * 64 + lane) * 2;
+            a[k] = p[0];
+            b[k] = p[1];
+        }
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) acc += a[k].x ^ b[k].w;
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+
+template <int ROWS>
+float run(const uint4 *src, size_t n_rows, unsigned *sink, int blocks) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(stream_kernel<ROWS>, dim3(blocks), dim3(256), 0, 0, src, n_rows, sink);
+    hipEventRecord(e0);
+    for (int i = 0; i < 10; i++) hipLaunchKernelGGL(stream_kernel<ROWS>, dim3(blocks), dim3(256), 0, 0, src, n_rows, sink);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms / 10;
+}
+
+int main() {
+    const size_t bytes = 1600ull << 20;
+    const size_t n_rows = bytes / 2048;
+    uint4 *src;
+    unsigned *sink;
+    hipMalloc(&src, bytes);
+    hipMalloc(&sink, 4);
+    hipMemset(src, 1, bytes);
+    for (int bpc : {4, 5, 6, 8}) {
+        const int blocks = 256 * bpc;
+        printf("blocks/CU %d (waves/CU %d):", bpc, bpc * 4);
+        printf(" rows=1 %.0f", bytes / (run<1>(src, n_rows, sink, blocks) * 1e-3) / 1e9);
+        printf(" rows=2 %.0f", bytes / (run<2>(src, n_rows, sink, blocks) * 1e-3) / 1e9);
+        printf(" rows=3 %.0f", bytes / (run<3>(src, n_rows, sink, blocks) * 1e-3) / 1e9);
+        printf(" rows=4 %.0f", bytes / (run<4>(src, n_rows, sink, blocks) * 1e-3) / 1e9);
+        printf(" rows=6 %.0f", bytes / (run<6>(src, n_rows, sink, blocks) * 1e-3) / 1e9);
+        printf(" rows=8 %.0f GB/s\n", bytes / (run<8>(src, n_rows, sink, blocks) * 1e-3) / 1e9);
+    }
+    return 0;
+}
