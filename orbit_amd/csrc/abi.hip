@@ -28,7 +28,7 @@ struct OrbitCtx {
     size_t arena_bytes = 0;
     OrbitMeshletDispatch *e_proto = nullptr;
     uint32_t *e_block_sums = nullptr, *e_block_base = nullptr, *e_total = nullptr;
-    uint32_t *m_tile_payload = nullptr;
+    uint4 *m_tile_payload = nullptr;
     uint32_t *m_tile_masks = nullptr, *m_chunk_sums = nullptr, *m_chunk_base = nullptr;
     uint32_t *m_tile_counts = nullptr, *m_tile_base = nullptr, *m_total = nullptr;
     uint64_t *m_scan_state = nullptr;
@@ -184,7 +184,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t o_mtc = carve(mtiles * 4), o_mtb = carve(mtiles * 4), o_mt = carve(256);
     const size_t o_mss = carve(mtiles * 8), o_mtk = carve(256);
     const size_t o_mtm = carve(mtiles * 64);
-    const size_t o_mtp = carve(mtiles * 128 * 12);
+    const size_t o_mtp = carve(mtiles * 128 * 16);
     const size_t mchunks = mtiles / kScanChunk + 2;
     const size_t o_mcs = carve(mchunks * 4), o_mcb = carve(mchunks * 4);
     const size_t o_cc = carve((2 * cchunks + 64) * 4);
@@ -220,7 +220,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->m_scan_state = (uint64_t *)(a + o_mss);
     ctx->m_ticket = (uint32_t *)(a + o_mtk);
     ctx->m_tile_masks = (uint32_t *)(a + o_mtm);
-    ctx->m_tile_payload = (uint32_t *)(a + o_mtp);
+    ctx->m_tile_payload = (uint4 *)(a + o_mtp);
     ctx->m_chunk_sums = (uint32_t *)(a + o_mcs);
     ctx->m_chunk_base = (uint32_t *)(a + o_mcb);
     ctx->c_chunk = (uint32_t *)(a + o_cc);

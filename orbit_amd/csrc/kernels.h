@@ -47,7 +47,7 @@ struct MeshletCullParams {
     uint32_t material_count; // 0 = unknown (gather alpha modes), else entries in `materials`
     // context scratch
     uint32_t *tile_counts;
-    uint32_t *tile_payload; // 128 x 3 words per wave tile: survivors' Meshlet words 5..7 in tile-local order
+    uint4 *tile_payload;    // 128 x 16 B per wave tile: survivors' Meshlet bytes 16..31 in tile-local order
     uint32_t *tile_masks; // 16 words (8 x 64-bit should-draw ballots) per wave tile
     uint32_t *tile_base;   // chunk-local exclusive prefix of tile_counts
     uint32_t *chunk_sums;  // per kScanChunk tiles

@@ -33,6 +33,7 @@ constexpr uint32_t kPayloadCap = 128;
 struct __attribute__((aligned(16))) WaveTileLds {
     float4 mcol[kTileRecords][4]; // view x model, column-major, per record
     uint4 rec[kTileRecords];      // MeshletDispatch
+    float4 tzero[kTileRecords];   // column 3 x 0.0f: the w = 0 term of the cone-axis transform (:121)
     float scale[kTileRecords];    // largest_scale_from_matrix(mat3(M))
     uint64_t draw_mask[kTileRows]; // should-draw ballots of the tile's rows (kept here, not in SGPRs)
 };
@@ -52,7 +53,8 @@ __device__ __forceinline__ void planes_to_lds(const OrbitGpuCullInfo &ci, PlaneL
 }
 
 // Plane loop, meshlet_cull.comp:139-146, planes from LDS in batches of three
-// back-to-back broadcast reads (one wait per batch); a plane past the count
+// back-to-back broadcast reads (one wait per batch).  Straight-line: the three
+// distances of a batch are independent chains, and a plane past the count
 // contributes `true` through a scalar mask, never through its arithmetic.
 __device__ __forceinline__ bool plane_test_lds(const PlaneLds &P, uint32_t n, const Sphere &s) {
     bool visible = true;
@@ -62,11 +64,13 @@ __device__ __forceinline__ bool plane_test_lds(const PlaneLds &P, uint32_t n, co
             float4 pl[3];
 #pragma unroll
             for (uint32_t i = 0; i < 3; i++) pl[i] = P.plane[base + i];
+            bool in[3];
 #pragma unroll
             for (uint32_t i = 0; i < 3; i++) {
                 const float d = dot3(pl[i].x, pl[i].y, pl[i].z, s.x, s.y, s.z) + pl[i].w;
-                visible = visible && ((d > -s.r) || (base + i >= n));
+                in[i] = (d > -s.r) | (base + i >= n);
             }
+            visible = visible & in[0] & in[1] & in[2];
         }
     }
     return visible;
@@ -80,27 +84,39 @@ struct RowRegs {
 };
 using TileRegs = RowRegs<kTileRows>;
 
-// materials[i].alpha_mode (:124): from a per-block LDS table when the caller
-// states the material count (<= kAlphaTable entries), else a global gather.
+// materials[i].alpha_mode (:124) is only ever used as (1 << alpha_mode) & flag
+// (:207, :210), so the per-block LDS table (filled when the caller states a
+// material count <= kAlphaTable) holds the two predicate bits per material;
+// without the table they come from a global gather per meshlet.
 constexpr uint32_t kAlphaTable = 4096;
 struct AlphaLds {
-    uint8_t mode[kAlphaTable];
+    uint8_t bits[kAlphaTable];
 };
+
+// bit0: (1 << mode) & alpha_mode_flag != 0 (:207), bit1: (1 << mode) & noskip_alphamode != 0 (:210)
+__device__ __forceinline__ uint32_t alpha_bits(const OrbitGpuCullInfo &ci, uint32_t alpha_mode) {
+    const uint32_t m = shl1(alpha_mode);
+    return ((m & ci.alpha_mode_flag) != 0u ? 1u : 0u) | ((m & ci.noskip_alphamode) != 0u ? 2u : 0u);
+}
 
 __device__ __forceinline__ bool alpha_table_fill(const MeshletCullParams &p, AlphaLds &A) {
     const bool use = p.material_count != 0u && p.material_count <= kAlphaTable;
     if (use)
         for (uint32_t i = threadIdx.x; i < p.material_count; i += blockDim.x)
-            A.mode[i] = (uint8_t)min(p.materials[i].alpha_mode, 255u); // >= 32 shifts to 0 either way (shl1)
+            A.bits[i] = (uint8_t)alpha_bits(p.ci, p.materials[i].alpha_mode);
     return use;
 }
 
-// One meshlet (one lane): meshlet_cull.comp:113-213.  Returns bit0 = visible,
-// bit1 = should_draw.  PASS = cull_info.occlusion_pass (compile-time).
-template <int PASS>
-__device__ __forceinline__ uint32_t eval_meshlet(const MeshletCullParams &p, const WaveTileLds &L,
-                                                 const PlaneLds &P, uint32_t rid, const uint4 &a, const uint4 &b,
-                                                 uint32_t alpha_mode, bool visible_in_buffer, bool meshlet_occ) {
+struct MeshletVerdict {
+    bool visible, should_draw;
+};
+
+// One meshlet (one lane): meshlet_cull.comp:113-213.  PASS = cull_info.occlusion_pass
+// and PROJ = cull_info.projection_type are compile-time (PROJ < 0: read at run time).
+template <int PASS, int PROJ>
+__device__ __forceinline__ MeshletVerdict eval_meshlet(const MeshletCullParams &p, const WaveTileLds &L,
+                                                       const PlaneLds &P, uint32_t rid, const uint4 &a, const uint4 &b,
+                                                       uint32_t abits, bool visible_in_buffer, bool meshlet_occ) {
     const OrbitGpuCullInfo &ci = p.ci;
     const float4 m0 = L.mcol[rid][0], m1 = L.mcol[rid][1], m2 = L.mcol[rid][2], m3 = L.mcol[rid][3];
     const float cx = __uint_as_float(a.x), cy = __uint_as_float(a.y), cz = __uint_as_float(a.z);
@@ -120,35 +136,42 @@ __device__ __forceinline__ uint32_t eval_meshlet(const MeshletCullParams &p, con
     s.z = pz;
     s.r = __uint_as_float(a.w) * L.scale[rid];
 
-    // cone axis / cutoff (:121-122): int(i8) / 127.0
-    const int ax_i = (int)(int8_t)(b.x & 0xFF), ay_i = (int)(int8_t)((b.x >> 8) & 0xFF);
-    const int az_i = (int)(int8_t)((b.x >> 16) & 0xFF), co_i = (int)(int8_t)(b.x >> 24);
-    const float ax = snorm8_div127(ax_i), ay = snorm8_div127(ay_i), az = snorm8_div127(az_i);
-    const float cutoff = snorm8_div127(co_i);
-    const float axx = ((m0.x * ax + m1.x * ay) + m2.x * az) + m3.x * 0.0f;
-    const float axy = ((m0.y * ax + m1.y * ay) + m2.y * az) + m3.y * 0.0f;
-    const float axz = ((m0.z * ax + m1.z * ay) + m2.z * az) + m3.z * 0.0f;
-
     bool visible = true;
     if (PASS == 1) visible = visible_in_buffer;   // :137
-    if (visible) visible = plane_test_lds(P, ci.cull_plane_count, s); // :139-146
-    if (visible) {                                 // :148-158
-        float camx = 0.0f, camy = 0.0f, camz = 0.0f;
-        if (ci.projection_type == 1) {
-            camx = s.x - 0.0f;
-            camy = s.y - 0.0f;
-            camz = s.z - -1.0f;
+    // The cone test (:148-158) does not depend on the plane loop: both are evaluated
+    // and combined, which gives the scheduler two independent chains per meshlet.
+    bool cull;
+    {
+        // cone axis / cutoff (:121-122): int(i8) / 127.0, axis = (M * vec4(a, 0)).xyz
+        const int ax_i = (int)(int8_t)(b.x & 0xFF), ay_i = (int)(int8_t)((b.x >> 8) & 0xFF);
+        const int az_i = (int)(int8_t)((b.x >> 16) & 0xFF), co_i = (int)(int8_t)(b.x >> 24);
+        const float ax = snorm8_div127(ax_i), ay = snorm8_div127(ay_i), az = snorm8_div127(az_i);
+        const float cutoff = snorm8_div127(co_i);
+        const float4 tz = L.tzero[rid]; // m3 * 0.0f
+        const float axx = ((m0.x * ax + m1.x * ay) + m2.x * az) + tz.x;
+        const float axy = ((m0.y * ax + m1.y * ay) + m2.y * az) + tz.y;
+        const float axz = ((m0.z * ax + m1.z * ay) + m2.z * az) + tz.z;
+        const bool ortho = PROJ < 0 ? ci.projection_type == 1 : PROJ == 1;
+        float dx, dy, dz;
+        if (ortho) { // camera_position = center - (0, 0, -1)
+            const float camx = s.x - 0.0f, camy = s.y - 0.0f, camz = s.z - -1.0f;
+            dx = s.x - camx;
+            dy = s.y - camy;
+            dz = s.z - camz;
+        } else { // camera_position = 0
+            dx = s.x - 0.0f;
+            dy = s.y - 0.0f;
+            dz = s.z - 0.0f;
         }
-        const float dx = s.x - camx, dy = s.y - camy, dz = s.z - camz;
-        const bool cull = dot3(dx, dy, dz, axx, axy, axz) >= cutoff * sqrtf(dot3(dx, dy, dz, dx, dy, dz)) + s.r;
-        visible = !cull;
+        cull = dot3(dx, dy, dz, axx, axy, axz) >= cutoff * sqrtf(dot3(dx, dy, dz, dx, dy, dz)) + s.r;
     }
+    if (visible) visible = plane_test_lds(P, ci.cull_plane_count, s); // :139-146
+    visible = visible && !cull;
     if (PASS == 2 && meshlet_occ && visible) visible = occlusion_test(ci, s, p.pyr); // :161-205
 
-    bool should_draw = visible && ((shl1(alpha_mode) & ci.alpha_mode_flag) != 0); // :207
-    if ((PASS == 2 && meshlet_occ) && !((shl1(alpha_mode) & ci.noskip_alphamode) != 0))
-        should_draw = visible && !visible_in_buffer; // :210-213
-    return (visible ? 1u : 0u) | (should_draw ? 2u : 0u);
+    bool should_draw = visible && (abits & 1u) != 0; // :207
+    if ((PASS == 2 && meshlet_occ) && (abits & 2u) == 0) should_draw = visible && !visible_in_buffer; // :210-213
+    return {visible, should_draw};
 }
 
 // Issues the meshlet loads of rows R0 .. R0+NR-1 of a tile (2 x 16 B per lane per row).
@@ -179,19 +202,19 @@ __device__ __forceinline__ void rows_load(const MeshletCullParams &p, const Wave
 // Evaluates rows R0 .. R0+NR-1 of a tile: should-draw ballots into the slab,
 // survivor payload (optional), pass-2 visibility words (WRITE_VIS).  `total` is
 // the tile's running survivor count; the new count is returned.
-template <int PASS, bool WRITE_VIS, int R0, int NR>
+template <int PASS, int PROJ, bool WRITE_VIS, int R0, int NR>
 __device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
                                               const AlphaLds *A, int lane, const RowRegs<NR> &t, uint32_t total,
-                                              uint32_t *payload) {
+                                              uint4 *payload) {
     const bool meshlet_occ = p.ci.meshlet_visibility_buffer != ORBIT_NONE;
     const bool rw_vis = PASS != 0 && meshlet_occ;
     const uint32_t half = lane >> 5, ml = lane & 31;
     // Inactive lanes carry material 0 from the zero page (in bounds; result unused).
-    uint32_t alpha[NR];
+    uint32_t abits[NR];
 #pragma unroll
     for (int k = 0; k < NR; k++) {
         const uint32_t mi = t.b[k].w & 0xFFFFu;
-        alpha[k] = A ? (uint32_t)A->mode[mi & (kAlphaTable - 1u)] : p.materials[mi].alpha_mode;
+        abits[k] = A ? (uint32_t)A->bits[mi & (kAlphaTable - 1u)] : alpha_bits(p.ci, p.materials[mi].alpha_mode);
     }
 #pragma unroll
     for (int k = 0; k < NR; k++) {
@@ -199,28 +222,23 @@ __device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTi
         const uint32_t rid = 2 * r + half;
         const uint4 rec = L.rec[rid];
         const bool active = ml < rec.z;
-        uint32_t res = 0;
+        MeshletVerdict v = {false, false};
         if (active) {
             const bool visible_in_buffer = rw_vis ? ((t.prev[k] >> ml) & 1u) != 0 : true;
-            res = eval_meshlet<PASS>(p, L, P, rid, t.a[k], t.b[k], alpha[k], visible_in_buffer, meshlet_occ);
+            v = eval_meshlet<PASS, PROJ>(p, L, P, rid, t.a[k], t.b[k], abits[k], visible_in_buffer, meshlet_occ);
         }
-        const uint64_t mask = __ballot((res & 2u) != 0);
+        const uint64_t mask = __ballot(v.should_draw);
         if (lane == 0) L.draw_mask[r] = mask;
-        if (payload && ((mask >> lane) & 1ull)) {
-            // survivor payload: Meshlet words 5..7 at the tile-local rank, so the emit
+        if (payload && v.should_draw) {
+            // survivor payload: Meshlet bytes 16..31 at the tile-local rank, so the emit
             // launch reads them back contiguously instead of gathering 16 B per survivor
             const uint32_t rank = total + lane_prefix(mask);
-            if (rank < kPayloadCap) {
-                uint32_t *dst = payload + (size_t)rank * 3u;
-                dst[0] = t.b[k].y;
-                dst[1] = t.b[k].z;
-                dst[2] = t.b[k].w;
-            }
+            if (rank < kPayloadCap) payload[rank] = t.b[k];
         }
         total += (uint32_t)__popcll(mask);
         if (PASS == 2 && WRITE_VIS) {
             // pass-2 visibility words (:233-254); records with no lane write nothing
-            const uint64_t vis_mask = __ballot((res & 1u) != 0);
+            const uint64_t vis_mask = __ballot(v.visible);
             if (meshlet_occ && ml == 0 && rec.z > 0)
                 p.meshlet_visibility[rec.w] = half ? (uint32_t)(vis_mask >> 32) : (uint32_t)vis_mask;
         }
@@ -236,7 +254,7 @@ __device__ __forceinline__ void tile_load(const MeshletCullParams &p, const Wave
 template <int PASS, bool WRITE_VIS>
 __device__ __forceinline__ uint32_t tile_eval(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
                                               const AlphaLds *A, int lane, const TileRegs &t) {
-    return rows_eval<PASS, WRITE_VIS, 0, kTileRows>(p, L, P, A, lane, t, 0u, nullptr);
+    return rows_eval<PASS, -1, WRITE_VIS, 0, kTileRows>(p, L, P, A, lane, t, 0u, nullptr);
 }
 
 // Writes the tile's surviving commands at [base, base + total) (:216-230).
@@ -381,6 +399,7 @@ __device__ __forceinline__ void setup_write(const MeshletCullParams &p, WaveTile
     float o[4];
     mat4_mul_col(p.ci.view_matrix, mc.x, mc.y, mc.z, mc.w, o);
     L.mcol[rid][col] = make_float4(o[0], o[1], o[2], o[3]);
+    if (col == 3) L.tzero[rid] = make_float4(o[0] * 0.0f, o[1] * 0.0f, o[2] * 0.0f, 0.0f);
     const float d = dot3(o[0], o[1], o[2], o[0], o[1], o[2]);
     const float d0 = __shfl(d, (int)(rid * 4 + 0), 64);
     const float d1 = __shfl(d, (int)(rid * 4 + 1), 64);
@@ -589,9 +608,10 @@ __global__ __launch_bounds__(kSpBlock) void meshlet_cull_single_pass(const Meshl
 // iterations; all loads are unconditional (inactive lanes read a zero page) so
 // that the compiler's vmcnt accounting stays exact.
 constexpr int kEvWaves = 4;
+constexpr int kEvWavesPerSimd = 4; // resident waves per SIMD: compiled for (128 VGPRs) and launched at
 
-template <int PASS, bool PROF>
-__global__ __launch_bounds__(kEvWaves * 64) void meshlet_eval_kernel(const MeshletCullParams p) {
+template <int PASS, int PROJ, bool PROF>
+__global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_kernel(const MeshletCullParams p) {
     __shared__ WaveTileLds lds[kEvWaves][3];
     __shared__ PlaneLds planes;
     __shared__ AlphaLds alpha_tab;
@@ -634,20 +654,20 @@ __global__ __launch_bounds__(kEvWaves * 64) void meshlet_eval_kernel(const Meshl
         const uint32_t w3 = w2 + stride;
         WaveTileLds &L = lds[wave][it % 3];
         WaveTileLds &Ln = lds[wave][(it + 1) % 3]; // slab of an absent tile holds zero records
-        uint32_t *payload = p.tile_payload + (size_t)w0 * (kPayloadCap * 3u);
+        uint4 *payload = p.tile_payload + (size_t)w0 * kPayloadCap;
         uint32_t total = 0;
-        total = rows_eval<PASS, true, 0, 2>(p, L, planes, alpha, lane, qa, total, payload);
+        total = rows_eval<PASS, PROJ, true, 0, 2>(p, L, planes, alpha, lane, qa, total, payload);
         rows_load<PASS, 4, 2>(p, L, lane, qa);
         EV_STAMP(0)
-        total = rows_eval<PASS, true, 2, 2>(p, L, planes, alpha, lane, qb, total, payload);
+        total = rows_eval<PASS, PROJ, true, 2, 2>(p, L, planes, alpha, lane, qb, total, payload);
         rows_load<PASS, 6, 2>(p, L, lane, qb);
         const float4 mat2 = setup_load_mat(p, rec2, lane);
         const uint4 rec3 = setup_load_rec(p, w3, w3 < ntiles, nrec, lane);
         EV_STAMP(1)
-        total = rows_eval<PASS, true, 4, 2>(p, L, planes, alpha, lane, qa, total, payload);
+        total = rows_eval<PASS, PROJ, true, 4, 2>(p, L, planes, alpha, lane, qa, total, payload);
         rows_load<PASS, 0, 2>(p, Ln, lane, qa);
         EV_STAMP(2)
-        total = rows_eval<PASS, true, 6, 2>(p, L, planes, alpha, lane, qb, total, payload);
+        total = rows_eval<PASS, PROJ, true, 6, 2>(p, L, planes, alpha, lane, qb, total, payload);
         rows_load<PASS, 2, 2>(p, Ln, lane, qb);
         EV_STAMP(3)
         setup_write(p, lds[wave][(it + 2) % 3], rec2, mat2, lane); // also fences the mask writes of this tile
@@ -733,9 +753,8 @@ __global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullPara
                 const uint32_t mi = (uint32_t)__shfl((int)cur.rec.y, src, 64) + (code & 31u);
                 uint4 b;
                 if (n <= kPayloadCap) { // wave-uniform: contiguous payload written by meshlet_eval
-                    const uint32_t *src = keep ? p.tile_payload + ((size_t)tile * kPayloadCap + j) * 3u
-                                               : reinterpret_cast<const uint32_t *>(p.zero_page);
-                    b = make_uint4(0u, src[0], src[1], src[2]);
+                    b = *(keep ? p.tile_payload + ((size_t)tile * kPayloadCap + j)
+                               : reinterpret_cast<const uint4 *>(p.zero_page));
                 } else { // dense tile: gather Meshlet bytes 16..31 of the survivors
                     b = *(keep ? reinterpret_cast<const uint4 *>(p.meshlets + mi) + 1
                                : reinterpret_cast<const uint4 *>(p.zero_page));
@@ -785,16 +804,23 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, int mode, h
         return hipGetLastError();
     }
     // eval -> scan -> emit
-    uint32_t blocks = num_cus * 4u; // 16 waves per CU at <= 128 VGPRs
+    uint32_t blocks = num_cus * (uint32_t)kEvWavesPerSimd; // 4-wave blocks: one wave per SIMD each
     const uint32_t need = (max_tiles + kEvWaves - 1) / kEvWaves;
     if (blocks > need) blocks = need;
     if (blocks == 0) blocks = 1;
     if (ev0) (void)hipEventRecord(ev0, s);
-    if (PASS == 0 && (p.debug_flags & 8u))
-        hipLaunchKernelGGL((meshlet_eval_kernel<PASS == 0 ? 0 : PASS, PASS == 0>), dim3(blocks), dim3(kEvWaves * 64), 0,
-                           s, p);
-    else
-        hipLaunchKernelGGL((meshlet_eval_kernel<PASS, false>), dim3(blocks), dim3(kEvWaves * 64), 0, s, p);
+    const dim3 grid(blocks), block(kEvWaves * 64);
+    const bool ortho = p.ci.projection_type == 1;
+    if (PASS == 0 && (p.debug_flags & 8u)) { // phase-stamped build (tools/phase.py), pass 0 only
+        if (ortho)
+            hipLaunchKernelGGL((meshlet_eval_kernel<PASS == 0 ? 0 : PASS, 1, PASS == 0>), grid, block, 0, s, p);
+        else
+            hipLaunchKernelGGL((meshlet_eval_kernel<PASS == 0 ? 0 : PASS, 0, PASS == 0>), grid, block, 0, s, p);
+    } else if (ortho) {
+        hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 1, false>), grid, block, 0, s, p);
+    } else {
+        hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 0, false>), grid, block, 0, s, p);
+    }
     if (ev1) (void)hipEventRecord(ev1, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

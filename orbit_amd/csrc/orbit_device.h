@@ -79,17 +79,17 @@ __device__ __forceinline__ float log2c(float x) {
     return r + (float)e;
 }
 
-// int8 / 127.0 correctly rounded without the IEEE-division expansion: one
-// Newton step on the reciprocal estimate with explicit fused ops.  q0 = i*r is
-// within 1 ulp of i/127; rem = i - q0*127 is exact in an fma; q1 = q0 + rem*r
-// is the correctly rounded quotient (Markstein).  Verified exhaustively for all
-// 256 inputs against the oracle's '/' in tests/test_gpu_parity.py.
+// int8 / 127.0 correctly rounded in two VALU ops instead of the IEEE-division
+// expansion.  1/127 = 2^-7 + 2^-14 + 2^-21 + ... is split as r_hi (3 terms, 15
+// significant bits) + r_lo (the next 24 bits); i * r_hi is exact for |i| <= 128
+// and fma(i, r_lo, i * r_hi) rounds i * (r_hi + r_lo) once.  |r_hi + r_lo -
+// 1/127| < 2^-56, and no i/127 lies that close to a rounding boundary (its
+// binary expansion has period 7): verified exhaustively for all 256 inputs
+// against exact rationals (tests/test_oracle_cpu.py) and against the oracle's
+// '/' on the device (tests/test_gpu_parity.py).
 __device__ __forceinline__ float snorm8_div127(int i) {
     const float fi = (float)i;
-    const float r = 0x1.020408p-7f; // fl(1/127)
-    const float q0 = fi * r;
-    const float rem = __builtin_fmaf(-q0, 127.0f, fi);
-    return __builtin_fmaf(rem, r, q0);
+    return __builtin_fmaf(fi, 0x1.020408p-28f, fi * 0x1.0204p-7f);
 }
 
 // Pyramid geometry handed to the kernels by value (host-computed).

@@ -116,6 +116,36 @@ def test_pass0_no_planes_ragged_records(torch_mod, engine, oracle):
     assert len(recs) == scene.max_dispatches()
 
 
+def test_cone_bytes_and_matrix_edge_cases(torch_mod, engine, oracle):
+    """Every int8 value in each cone byte (the device divides by 127 with a two-op
+    fma form), plus projective (w != 1), non-finite and zero model matrices."""
+    scene = sc.make_scene(11, 600, meshlets_per_mesh=(20, 64))
+    rng = np.random.default_rng(11)
+    m = scene.meshlets
+    vals = np.arange(-128, 128, dtype=np.int8)
+    for c in range(3):
+        col = rng.integers(-128, 128, len(m)).astype(np.int8)
+        col[:256] = rng.permutation(vals)
+        m["cone_axis"][:, c] = col
+    cut = rng.integers(-128, 128, len(m)).astype(np.int8)
+    cut[:256] = rng.permutation(vals)
+    m["cone_cutoff"] = cut
+    mats = scene.entities["model_matrix"].reshape(-1, 16)
+    mats[3, 3] = 0.5                      # projective rows: transform_sphere divides by w
+    mats[4, 7] = 0.25
+    mats[5, 15] = 2.0
+    mats[6, 12] = np.inf                  # non-finite translation: NaN through the w = 0 axis term
+    mats[7, 13] = np.nan
+    mats[8, :] = 0.0                      # zero matrix: w = 0 -> division by zero
+    mats[9, 0] = -0.0
+    cam = sc.default_camera(rot=(0.3, -0.4))
+    for planes in (cam.planes, np.zeros((0, 4), np.float32)):
+        ci = sc.make_cull_info(cam.view, planes, alpha_mode_flag=L.ALPHA_ALL)
+        gs = GpuScene(torch_mod, scene)
+        recs, cmds = assert_same(run_gpu(torch_mod, engine, gs, ci), run_oracle(oracle, scene, ci))
+        assert len(cmds) > 0
+
+
 def test_empty_inputs(torch_mod, engine, oracle):
     scene = sc.make_scene(6, 40)
     cam = sc.default_camera()

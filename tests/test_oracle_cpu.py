@@ -32,17 +32,38 @@ def test_log2_spec(oracle):
     assert oracle.log2f(0.0) == -np.inf and np.isnan(oracle.log2f(-1.0)) and oracle.log2f(np.inf) == np.inf
 
 
+def _round_f32(fr):
+    """Exact rational -> nearest float32 (ties to even), normal range."""
+    from fractions import Fraction
+    if fr == 0:
+        return 0.0
+    sign, a = (-1 if fr < 0 else 1), abs(fr)
+    e = a.numerator.bit_length() - a.denominator.bit_length()
+    while Fraction(2) ** e > a:
+        e -= 1
+    while Fraction(2) ** (e + 1) <= a:
+        e += 1
+    q = a / Fraction(2) ** (e - 23)
+    n = q.numerator // q.denominator
+    rem = q - n
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and n % 2 == 1):
+        n += 1
+    return sign * float(Fraction(n) * Fraction(2) ** (e - 23))
+
+
 def test_snorm8_division_identity():
-    """The device computes int8/127 as q0 + fma(-q0,127,i)*r (Markstein); emulate the
-    fused ops in float64 (exact here) and compare with the oracle's IEEE division."""
-    r = np.float32(1) / np.float32(127)
-    assert float(r).hex() == "0x1.0204080000000p-7"
+    """The device computes int8/127 as fma(i, r_lo, i * r_hi) (orbit_device.h snorm8_div127):
+    i * r_hi must be exact and the single fma rounding must equal IEEE i / 127 for all 256 inputs.
+    Checked with exact rationals."""
+    from fractions import Fraction
+    r_hi, r_lo = float.fromhex("0x1.0204p-7"), float.fromhex("0x1.020408p-28")
+    assert np.float32(r_hi) == r_hi and np.float32(r_lo) == r_lo
     for i in range(-128, 128):
-        fi = np.float32(i)
-        q0 = np.float32(fi * r)
-        rem = np.float32(np.float64(fi) - np.float64(q0) * 127.0)
-        q1 = np.float32(np.float64(q0) + np.float64(rem) * np.float64(r))
-        assert q1 == np.float32(fi / np.float32(127.0)), i
+        t = Fraction(i) * Fraction(r_hi)
+        assert _round_f32(t) == float(t), i                           # i * r_hi is exact in f32
+        got = _round_f32(Fraction(i) * Fraction(r_lo) + t)            # one rounding in the fma
+        assert got == _round_f32(Fraction(i, 127)), i                 # == correctly rounded quotient
+        assert got == float(np.float32(i) / np.float32(127.0)), i     # == the oracle's '/'
 
 
 # ----------------------------------------------------------------------------- host derivations
