@@ -104,29 +104,64 @@ __global__ __launch_bounds__(kBlock) void entity_cull_eval(const EntityCullParam
     if (threadIdx.x == 0) p.block_sums[blockIdx.x] = total;
 }
 
+// Sum of v over the block (every thread gets it).  `smem` holds NW words.
+template <int NW>
+__device__ __forceinline__ uint32_t block_reduce_add(uint32_t v, uint32_t *smem) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t w = wave_reduce_add(v);
+    if (lane == 0) smem[wave] = w;
+    __syncthreads();
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) sum += smem[i];
+    __syncthreads();
+    return sum;
+}
+
 // Expands proto-records into ceil(m/S) MeshletDispatch records each, at the
-// scanned offsets (:211-223).  Block 0 also writes the {x,1,1} header.
+// scanned offsets (:211-223).  The block's base is the sum of the preceding
+// blocks' record counts, reduced here (a few KB from L2) instead of by a scan
+// launch in between; block 0 reduces all of them for the {x,1,1} header.
+// Thread = output record (owner found by bisection over the block's offsets in
+// LDS): consecutive lanes store consecutive 16-B records, where a thread-per-
+// entity loop stores 16 B every n x 16 B.
 __global__ __launch_bounds__(kBlock) void entity_cull_emit(const EntityCullParams p) {
     __shared__ uint32_t smem[kBlock / 64 + 1];
+    __shared__ uint32_t s_off[kBlock];
+    __shared__ OrbitMeshletDispatch s_proto[kBlock];
     const uint32_t local = blockIdx.x * kBlock + threadIdx.x;
     const OrbitMeshletDispatch pr = p.proto[local];
     const uint32_t S = ORBIT_MESHLET_DISPATCH_SIZE;
     const uint32_t n = (pr.meshlet_count + S - 1u) / S;
+    const uint32_t preceding = blockIdx.x == 0 ? gridDim.x : blockIdx.x; // block 0: grand total
+    uint32_t part = 0;
+    for (uint32_t i = threadIdx.x; i < preceding; i += kBlock) part += p.block_sums[i];
+    const uint32_t reduced = block_reduce_add<kBlock / 64>(part, smem);
+    const uint32_t block_base = blockIdx.x == 0 ? 0u : reduced;
     uint32_t block_total;
-    const uint32_t offset = p.block_base[blockIdx.x] + block_exclusive_scan<kBlock / 64>(n, smem, &block_total);
+    s_off[threadIdx.x] = block_exclusive_scan<kBlock / 64>(n, smem, &block_total);
+    s_proto[threadIdx.x] = pr;
+    __syncthreads();
     OrbitMeshletDispatch *out = reinterpret_cast<OrbitMeshletDispatch *>(p.dispatch_buffer + ORBIT_DISPATCH_HEADER);
-    uint32_t vis_off = pr.visibility_offset;
-    for (uint32_t j = 0; j < n; j++) {
-        OrbitMeshletDispatch r;
-        r.entity_index = pr.entity_index;
-        r.meshlet_offset = pr.meshlet_offset + S * j;
-        r.meshlet_count = min(pr.meshlet_count - S * j, S);
-        r.visibility_offset = vis_off;
-        if (offset + j < p.dispatch_capacity) out[offset + j] = r;
-        vis_off += r.meshlet_count / S; // :222
+    for (uint32_t r = threadIdx.x; r < block_total; r += kBlock) {
+        // owner = last entity whose offset is <= r (entities without records share the next one's offset)
+        uint32_t lo = 0, hi = kBlock;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_off[mid] <= r) lo = mid; else hi = mid;
+        }
+        const OrbitMeshletDispatch o = s_proto[lo];
+        const uint32_t j = r - s_off[lo];
+        OrbitMeshletDispatch rec;
+        rec.entity_index = o.entity_index;
+        rec.meshlet_offset = o.meshlet_offset + S * j;
+        rec.meshlet_count = min(o.meshlet_count - S * j, S);
+        rec.visibility_offset = o.visibility_offset + j; // :222: every record before j is full (count / S == 1)
+        if (block_base + r < p.dispatch_capacity) out[block_base + r] = rec;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint32_t total = *p.total;
+        const uint32_t total = reduced;
+        *p.total = total;
         uint32_t *hdr = reinterpret_cast<uint32_t *>(p.dispatch_buffer);
         hdr[0] = min(total, p.dispatch_capacity);
         hdr[1] = 1u;
@@ -185,13 +220,20 @@ __global__ __launch_bounds__(1024) void scan_chunks_kernel(const uint32_t *in, u
 
 } // namespace
 
+hipError_t launch_scan_chunks(const uint32_t *in, uint32_t *out_local, const uint32_t *n_src, uint32_t div,
+                              uint32_t n_max, uint32_t *chunk_sums, hipStream_t s) {
+    const uint32_t chunks = (n_max + kScanChunk - 1) / kScanChunk;
+    if (chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(scan_chunks_kernel, dim3(chunks), dim3(1024), 0, s, in, out_local, n_max, n_src, div, chunk_sums);
+    return hipGetLastError();
+}
+
 hipError_t launch_scan_two_level(const uint32_t *in, uint32_t *out_local, const uint32_t *n_src, uint32_t div,
                                  uint32_t n_max, uint32_t *chunk_sums, uint32_t *chunk_base, uint32_t *total,
                                  hipStream_t s) {
     const uint32_t chunks = (n_max + kScanChunk - 1) / kScanChunk;
     if (chunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(scan_chunks_kernel, dim3(chunks), dim3(1024), 0, s, in, out_local, n_max, n_src, div, chunk_sums);
-    hipError_t e = hipGetLastError();
+    const hipError_t e = launch_scan_chunks(in, out_local, n_src, div, n_max, chunk_sums, s);
     if (e != hipSuccess) return e;
     return launch_scan_exclusive(chunk_sums, chunk_base, chunks, total, s);
 }
@@ -218,8 +260,6 @@ hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_co
     }
     hipLaunchKernelGGL(entity_cull_eval, dim3(blocks), dim3(kBlock), 0, s, p);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    e = launch_scan_exclusive(p.block_sums, p.block_base, blocks, p.total, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(entity_cull_emit, dim3(blocks), dim3(kBlock), 0, s, p);
     return hipGetLastError();

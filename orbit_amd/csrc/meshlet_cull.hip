@@ -111,6 +111,13 @@ struct MeshletVerdict {
     bool visible, should_draw;
 };
 
+// Survivor payload (16 B): meshlet index, Meshlet::vertex_offset, Meshlet::data_offset, and
+// {triangle_count:8 | vertex_count:8 | tile-local record id:16} (the material index is not part
+// of a command, its bits carry the record id that leads to the entity index).
+__device__ __forceinline__ uint4 make_payload(uint32_t meshlet_index, uint32_t rid, const uint4 &b) {
+    return make_uint4(meshlet_index, b.y, b.z, (b.w & 0xFFFF0000u) | rid);
+}
+
 // One meshlet (one lane): meshlet_cull.comp:113-213.  PASS = cull_info.occlusion_pass
 // and PROJ = cull_info.projection_type are compile-time (PROJ < 0: read at run time).
 template <int PASS, int PROJ>
@@ -230,10 +237,10 @@ __device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTi
         const uint64_t mask = __ballot(v.should_draw);
         if (lane == 0) L.draw_mask[r] = mask;
         if (payload && v.should_draw) {
-            // survivor payload: Meshlet bytes 16..31 at the tile-local rank, so the emit
-            // launch reads them back contiguously instead of gathering 16 B per survivor
+            // survivor payload at the tile-local rank: everything the command needs except its
+            // slot, so the emit launch reads one contiguous run per tile and rebuilds nothing
             const uint32_t rank = total + lane_prefix(mask);
-            if (rank < kPayloadCap) payload[rank] = t.b[k];
+            if (rank < kPayloadCap) payload[rank] = make_payload(rec.y + ml, rid, t.b[k]);
         }
         total += (uint32_t)__popcll(mask);
         if (PASS == 2 && WRITE_VIS) {
@@ -688,12 +695,12 @@ __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_k
 }
 
 // One wave per tile (grid stride): commands of the tile's survivors at the
-// scanned offset (:216-230).  Two memory round trips per tile: (1) masks, the
-// tile's 16 records, count and base — independent loads, prefetched for tile
-// i+1 while tile i is written; (2) Meshlet bytes 16..31 of the survivors only.
+// scanned offset (:216-230).  Everything a tile needs is loaded ahead of its
+// turn, so no memory round trip is exposed between tiles: the 16 records, count
+// and chunk-local base two tiles ahead; the survivor payload (whose extent
+// needs the count) one tile ahead.
 struct EmitTile {
-    uint32_t mword; // lanes 0..15: the 8 x 64-bit ballots
-    uint4 rec;      // lanes 0..15: the tile's dispatch records
+    uint4 rec; // lanes 0..15: the tile's dispatch records
     uint32_t count, base;
 };
 
@@ -704,83 +711,129 @@ __device__ __forceinline__ EmitTile emit_prefetch(const MeshletCullParams &p, ui
     const bool tv = tile < ntiles;
     const uint32_t t = tv ? tile : 0u;
     const uint32_t ri = t * kTileRecords + (lane & 15);
-    e.mword = p.tile_masks[(size_t)t * (2 * kTileRows) + (lane & 15)];
     e.rec = *((tv && ri < nrec) ? recs + ri : reinterpret_cast<const uint4 *>(p.zero_page));
     e.count = tv ? p.tile_counts[t] : 0u;
-    e.base = p.tile_base[t] + p.chunk_base[t / kScanChunk];
+    e.base = p.tile_base[t]; // exclusive prefix inside the tile's scan chunk
     return e;
 }
 
-// Lane = survivor, not meshlet: at ~10 % survival a row has ~6 survivors, and a
-// lane-per-meshlet emit spends its time issuing 56 mostly-empty masked stores
-// per tile.  The tile's survivors are first compacted into a wave-private LDS
-// list of (row, lane) codes (ballot rank = list position, i.e. canonical
-// order), then each lane takes one list entry: one survivor-word load and seven
-// stores per 64 survivors.
+// Payload entries [first, first + 64) of a tile; lanes past the count read the zero page.
+__device__ __forceinline__ uint4 emit_load_payload(const MeshletCullParams &p, uint32_t tile, uint32_t count,
+                                                   uint32_t first, int lane) {
+    const uint32_t j = first + (uint32_t)lane;
+    const bool has = j < count && count <= kPayloadCap;
+    return *(has ? p.tile_payload + ((size_t)tile * kPayloadCap + j) : reinterpret_cast<const uint4 *>(p.zero_page));
+}
+
+constexpr uint32_t kEmitChunkTable = 1024; // chunk bases kept in LDS (4 Mi tiles = 64 Mi dispatch records)
+
+// Lane = survivor.  A tile with at most kPayloadCap survivors (the common case:
+// ~50 at 10 % survival) is one contiguous payload run written by meshlet_eval in
+// command order; the lane turns its entry into the 7 command words, and the run
+// of 7-dword structs goes out through LDS so that each of the 7 stores covers
+// 256 contiguous bytes instead of 64 addresses 28 B apart.  A denser tile is
+// rebuilt from its ballots: survivors compacted into an LDS list of (row, lane)
+// codes (ballot rank = list position, i.e. canonical order), Meshlet bytes
+// 16..31 gathered.  The second scan level (chunk sums -> chunk bases, at most a
+// few dozen values) is redone by every block in LDS instead of being a launch.
 __global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullParams p) {
     __shared__ uint16_t s_list[4][kTileRows * 64];
+    __shared__ uint32_t s_cmd[4][64 * 7];
+    __shared__ uint32_t s_chunk_base[kEmitChunkTable];
+    __shared__ uint32_t s_scan[256 / 64 + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint16_t *list = s_list[wave];
+    uint32_t *cmd = s_cmd[wave];
     const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
     const uint32_t ntiles = (nrec + kTileRecords - 1) / kTileRecords;
+    const uint32_t nchunks = (ntiles + kScanChunk - 1) / kScanChunk;
+    uint32_t grand_total = 0;
+    for (uint32_t c0 = 0; c0 < nchunks; c0 += 256) { // block-uniform trip count
+        const uint32_t c = c0 + threadIdx.x;
+        const uint32_t v = c < nchunks ? p.chunk_sums[c] : 0u;
+        uint32_t sub;
+        const uint32_t ex = block_exclusive_scan<4>(v, s_scan, &sub);
+        if (c < nchunks && c < kEmitChunkTable) s_chunk_base[c] = grand_total + ex;
+        grand_total += sub;
+    }
+    __syncthreads();
     uint32_t *out = reinterpret_cast<uint32_t *>(p.draw_buffer + ORBIT_DRAW_HEADER);
     const uint32_t stride = gridDim.x * 4;
     uint32_t tile = blockIdx.x * 4 + wave;
     EmitTile cur = emit_prefetch(p, tile, ntiles, nrec, lane);
+    EmitTile nxt = emit_prefetch(p, tile + stride, ntiles, nrec, lane);
+    uint4 cur_pay = emit_load_payload(p, tile, cur.count, 0u, lane);
     for (; tile < ntiles; tile += stride) {
-        const EmitTile nxt = emit_prefetch(p, tile + stride, ntiles, nrec, lane);
+        const EmitTile nn = emit_prefetch(p, tile + 2 * stride, ntiles, nrec, lane);
+        const uint4 nxt_pay = emit_load_payload(p, tile + stride, nxt.count, 0u, lane);
         const uint32_t n = cur.count;
         if (n != 0u) { // wave-uniform
-            uint32_t row_base = 0;
+            const uint32_t base = cur.base + s_chunk_base[tile / kScanChunk];
+            const bool dense = n > kPayloadCap; // wave-uniform
+            if (dense) {
+                const uint32_t mword = p.tile_masks[(size_t)tile * (2 * kTileRows) + (lane & 15)];
+                uint32_t row_base = 0;
 #pragma unroll
-            for (int r = 0; r < (int)kTileRows; r++) {
-                const uint32_t lo = (uint32_t)__shfl((int)cur.mword, 2 * r, 64);
-                const uint32_t hi = (uint32_t)__shfl((int)cur.mword, 2 * r + 1, 64);
-                const uint64_t mask = ((uint64_t)hi << 32) | lo;
-                if ((mask >> lane) & 1ull) list[row_base + lane_prefix(mask)] = (uint16_t)(r * 64 + lane);
-                row_base += (uint32_t)__popcll(mask);
+                for (int r = 0; r < (int)kTileRows; r++) {
+                    const uint32_t lo = (uint32_t)__shfl((int)mword, 2 * r, 64);
+                    const uint32_t hi = (uint32_t)__shfl((int)mword, 2 * r + 1, 64);
+                    const uint64_t mask = ((uint64_t)hi << 32) | lo;
+                    if ((mask >> lane) & 1ull) list[row_base + lane_prefix(mask)] = (uint16_t)(r * 64 + lane);
+                    row_base += (uint32_t)__popcll(mask);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (uint32_t j0 = 0; j0 < n; j0 += 64) { // one trip unless more than 64 survivors
                 const uint32_t j = j0 + lane;
-                const uint32_t slot = cur.base + j;
-                const bool keep = j < n && slot < p.draw_capacity;
-                const uint32_t code = keep ? list[j] : 0u;
-                const int src = (int)((code >> 6) * 2 + ((code >> 5) & 1u)); // record 2r + half
-                const uint32_t ent = (uint32_t)__shfl((int)cur.rec.x, src, 64);
-                const uint32_t mi = (uint32_t)__shfl((int)cur.rec.y, src, 64) + (code & 31u);
-                uint4 b;
-                if (n <= kPayloadCap) { // wave-uniform: contiguous payload written by meshlet_eval
-                    b = *(keep ? p.tile_payload + ((size_t)tile * kPayloadCap + j)
-                               : reinterpret_cast<const uint4 *>(p.zero_page));
-                } else { // dense tile: gather Meshlet bytes 16..31 of the survivors
-                    b = *(keep ? reinterpret_cast<const uint4 *>(p.meshlets + mi) + 1
-                               : reinterpret_cast<const uint4 *>(p.zero_page));
+                uint4 pay; // payload layout (make_payload)
+                if (dense) {
+                    const uint32_t code = j < n ? list[j] : 0u;
+                    const uint32_t rid = (code >> 6) * 2u + ((code >> 5) & 1u); // record 2r + half
+                    const uint32_t mi = (uint32_t)__shfl((int)cur.rec.y, (int)rid, 64) + (code & 31u);
+                    const uint4 b = *(j < n ? reinterpret_cast<const uint4 *>(p.meshlets + mi) + 1
+                                            : reinterpret_cast<const uint4 *>(p.zero_page));
+                    pay = make_payload(mi, rid, b);
+                } else {
+                    pay = j0 == 0u ? cur_pay : emit_load_payload(p, tile, n, j0, lane);
                 }
-                if (keep) {
-                    const uint32_t vertex_count = (b.w >> 16) & 0xFFu;
-                    const uint32_t triangle_count = b.w >> 24;
-                    uint32_t *c = out + (size_t)slot * 7u;
-                    c[0] = triangle_count * 3u;       // cmd_index_count
-                    c[1] = 1u;                        // cmd_instance_count
-                    c[2] = (b.z + vertex_count) * 4u; // cmd_first_index
-                    c[3] = b.z;                       // cmd_vertex_offset = int(data_offset)
-                    c[4] = ent;                       // cmd_first_instance = entity_index
-                    c[5] = b.y;                       // meshlet_vertex_offset
-                    c[6] = mi;                        // meshlet_index
+                const uint32_t ent = (uint32_t)__shfl((int)cur.rec.x, (int)(pay.w & 0xFFFFu), 64);
+                const uint32_t vertex_count = (pay.w >> 16) & 0xFFu;
+                const uint32_t triangle_count = pay.w >> 24;
+                uint32_t *c = cmd + lane * 7;
+                c[0] = triangle_count * 3u;         // cmd_index_count
+                c[1] = 1u;                          // cmd_instance_count
+                c[2] = (pay.z + vertex_count) * 4u; // cmd_first_index
+                c[3] = pay.z;                       // cmd_vertex_offset = int(data_offset)
+                c[4] = ent;                         // cmd_first_instance = entity_index
+                c[5] = pay.y;                       // meshlet_vertex_offset
+                c[6] = pay.x;                       // meshlet_index
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t first = base + j0; // slot of the trip's first command
+                const uint32_t room = first < p.draw_capacity ? p.draw_capacity - first : 0u;
+                const uint32_t words = min(min(n - j0, 64u), room) * 7u;
+                uint32_t *dst = out + (size_t)first * 7u;
+#pragma unroll
+                for (uint32_t k = 0; k < 7; k++) {
+                    const uint32_t w = k * 64u + (uint32_t)lane;
+                    if (w < words) dst[w] = cmd[w];
                 }
+                __builtin_amdgcn_wave_barrier(); // cmd is rewritten by the next trip
             }
             __builtin_amdgcn_wave_barrier(); // list is reused by the next tile
         }
         cur = nxt;
+        cur_pay = nxt_pay;
+        nxt = nn;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // `count` header: subsumes the fill_buffer(count = 0) of draw_gen.rs:411-417
-        const uint32_t total = *p.total;
-        *reinterpret_cast<uint32_t *>(p.draw_buffer) = min(total, p.draw_capacity);
-        if (total > p.draw_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+        *p.total = grand_total;
+        *reinterpret_cast<uint32_t *>(p.draw_buffer) = min(grand_total, p.draw_capacity);
+        if (grand_total > p.draw_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
     }
 }
 
@@ -824,9 +877,11 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, int mode, h
     if (ev1) (void)hipEventRecord(ev1, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = launch_scan_two_level(p.tile_counts, p.tile_base, reinterpret_cast<const uint32_t *>(p.dispatch_buffer),
-                              kTileRecords, max_tiles, p.chunk_sums, p.chunk_base, p.total, s);
+    // first scan level only (chunk-local prefixes + chunk sums); meshlet_emit redoes the second in LDS
+    e = launch_scan_chunks(p.tile_counts, p.tile_base, reinterpret_cast<const uint32_t *>(p.dispatch_buffer),
+                           kTileRecords, max_tiles, p.chunk_sums, s);
     if (e != hipSuccess) return e;
+    if ((max_tiles + kScanChunk - 1) / kScanChunk > kEmitChunkTable) return hipErrorInvalidValue;
     uint32_t eblocks = num_cus * 8u;
     const uint32_t eneed = (max_tiles + 3) / 4;
     if (eblocks > eneed) eblocks = eneed;

@@ -146,6 +146,28 @@ def test_cone_bytes_and_matrix_edge_cases(torch_mod, engine, oracle):
         assert len(cmds) > 0
 
 
+def test_dense_and_sparse_tiles(torch_mod, engine, oracle):
+    """Wave tiles with more survivors than the payload holds (emit rebuilds them from the
+    ballots) next to sparse and empty ones, in one list."""
+    scene = sc.make_scene(12, 900, meshlets_per_mesh=(1, 64))
+    m = scene.meshlets
+    third = len(m) // 3
+    m["cone_cutoff"][:third] = 127          # never cone-culled: dense tiles
+    m["cone_cutoff"][2 * third:] = -128     # nearly always cone-culled: empty tiles
+    cam = sc.default_camera()
+    ci = sc.make_cull_info(cam.view, np.zeros((0, 4), np.float32), alpha_mode_flag=L.ALPHA_ALL)
+    gs = GpuScene(torch_mod, scene)
+    recs, cmds = assert_same(run_gpu(torch_mod, engine, gs, ci), run_oracle(oracle, scene, ci))
+    assert len(cmds) > third // 2
+    # capacity cut inside a dense tile: the written prefix is identical, the overflow is reported
+    cap = len(cmds) - 77
+    g = run_gpu(torch_mod, engine, gs, ci, draw_cap=cap)
+    o = run_oracle(oracle, scene, ci, draw_cap=cap)
+    assert_same(g, o)
+    with pytest.raises(Exception):
+        engine.status()
+
+
 def test_empty_inputs(torch_mod, engine, oracle):
     scene = sc.make_scene(6, 40)
     cam = sc.default_camera()
