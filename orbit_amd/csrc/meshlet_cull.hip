@@ -52,26 +52,31 @@ __device__ __forceinline__ void planes_to_lds(const OrbitGpuCullInfo &ci, PlaneL
     }
 }
 
-// Plane loop, meshlet_cull.comp:139-146, planes from LDS in batches of three
-// back-to-back broadcast reads (one wait per batch).  Straight-line: the three
-// distances of a batch are independent chains, and a plane past the count
-// contributes `true` through a scalar mask, never through its arithmetic.
+// Plane loop, meshlet_cull.comp:139-146, planes from LDS in batches of up to
+// three back-to-back broadcast reads (one wait per batch).  Straight-line: the
+// distances of a batch are independent chains.  The batch shape follows the
+// (wave-uniform) plane count, so no plane past the count is ever evaluated.
+template <uint32_t N>
+__device__ __forceinline__ bool plane_batch(const PlaneLds &P, uint32_t base, const Sphere &s) {
+    float4 pl[N];
+#pragma unroll
+    for (uint32_t i = 0; i < N; i++) pl[i] = P.plane[base + i];
+    bool in = true;
+#pragma unroll
+    for (uint32_t i = 0; i < N; i++) {
+        const float d = dot3(pl[i].x, pl[i].y, pl[i].z, s.x, s.y, s.z) + pl[i].w;
+        in = in & (d > -s.r);
+    }
+    return in;
+}
+
 __device__ __forceinline__ bool plane_test_lds(const PlaneLds &P, uint32_t n, const Sphere &s) {
     bool visible = true;
 #pragma unroll
     for (uint32_t base = 0; base < ORBIT_MAX_CULL_PLANES; base += 3) {
-        if (base < n) { // wave-uniform
-            float4 pl[3];
-#pragma unroll
-            for (uint32_t i = 0; i < 3; i++) pl[i] = P.plane[base + i];
-            bool in[3];
-#pragma unroll
-            for (uint32_t i = 0; i < 3; i++) {
-                const float d = dot3(pl[i].x, pl[i].y, pl[i].z, s.x, s.y, s.z) + pl[i].w;
-                in[i] = (d > -s.r) | (base + i >= n);
-            }
-            visible = visible & in[0] & in[1] & in[2];
-        }
+        if (base + 3 <= n) visible = visible & plane_batch<3>(P, base, s);
+        else if (base + 2 == n) visible = visible & plane_batch<2>(P, base, s);
+        else if (base + 1 == n) visible = visible & plane_batch<1>(P, base, s);
     }
     return visible;
 }
@@ -602,14 +607,15 @@ __global__ __launch_bounds__(kSpBlock) void meshlet_cull_single_pass(const Meshl
 //   meshlet_emit : per tile, re-reads only the survivors' command words and
 //                  writes the 28-B commands at the scanned offsets.
 //
-// Software pipeline of one wave in meshlet_eval.  A tile's 8 rows are handled as
-// four quarter tiles (2 rows) through two register sets A/B, so that meshlet
-// loads are in flight during every evaluation:
-//     eval rows 0-1 (A) ; load A <- rows 4-5          | tile i
-//     eval rows 2-3 (B) ; load B <- rows 6-7          |
-//     issue matrix loads (i+2), record load (i+3)     | small, one iteration ahead
-//     eval rows 4-5 (A) ; load A <- rows 0-1 of i+1   |
-//     eval rows 6-7 (B) ; load B <- rows 2-3 of i+1   |
+// Software pipeline of one wave in meshlet_eval.  A tile's 8 rows go through two
+// single-row register sets A/B, so that one row's meshlet loads are in flight
+// during every evaluation (16 waves per CU x 2 KiB is more than the bytes in
+// flight that HBM latency x bandwidth asks of a CU):
+//     eval row 0 (A) ; load A <- row 2      eval row 1 (B) ; load B <- row 3
+//     eval row 2 (A) ; load A <- row 4      eval row 3 (B) ; load B <- row 5
+//     issue matrix loads (i+2), record load (i+3)      | small, one iteration ahead
+//     eval row 4 (A) ; load A <- row 6      eval row 5 (B) ; load B <- row 7
+//     eval row 6 (A) ; load A <- row 0 of i+1   eval row 7 (B) ; load B <- row 1 of i+1
 //     write slab(i+2) ; store masks(i), count(i)
 // The dependent chain record -> matrix -> meshlets of a tile is spread over three
 // iterations; all loads are unconditional (inactive lanes read a zero page) so
@@ -630,8 +636,8 @@ __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_k
     const uint32_t ntiles = (nrec + kTileRecords - 1) / kTileRecords;
     const uint32_t stride = gridDim.x * kEvWaves;
     uint32_t w0 = blockIdx.x * kEvWaves + wave, w1 = w0 + stride, w2 = w1 + stride;
-    // two quarter-tile register sets: while one is evaluated the other is in flight
-    RowRegs<2> qa, qb;
+    // two single-row register sets: while one row is evaluated the next row's loads are in flight
+    RowRegs<1> qa, qb;
     uint4 rec2;
     {
         const uint4 r0 = setup_load_rec(p, w0, w0 < ntiles, nrec, lane);
@@ -641,8 +647,8 @@ __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_k
         const float4 m1 = setup_load_mat(p, r1, lane);
         setup_write(p, lds[wave][0], r0, m0, lane);
         setup_write(p, lds[wave][1], r1, m1, lane);
-        rows_load<PASS, 0, 2>(p, lds[wave][0], lane, qa);
-        rows_load<PASS, 2, 2>(p, lds[wave][0], lane, qb);
+        rows_load<PASS, 0, 1>(p, lds[wave][0], lane, qa);
+        rows_load<PASS, 1, 1>(p, lds[wave][0], lane, qb);
     }
     uint32_t it = 0;
     unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1;
@@ -663,19 +669,27 @@ __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_k
         WaveTileLds &Ln = lds[wave][(it + 1) % 3]; // slab of an absent tile holds zero records
         uint4 *payload = p.tile_payload + (size_t)w0 * kPayloadCap;
         uint32_t total = 0;
-        total = rows_eval<PASS, PROJ, true, 0, 2>(p, L, planes, alpha, lane, qa, total, payload);
-        rows_load<PASS, 4, 2>(p, L, lane, qa);
+        total = rows_eval<PASS, PROJ, true, 0, 1>(p, L, planes, alpha, lane, qa, total, payload);
+        rows_load<PASS, 2, 1>(p, L, lane, qa);
+        total = rows_eval<PASS, PROJ, true, 1, 1>(p, L, planes, alpha, lane, qb, total, payload);
+        rows_load<PASS, 3, 1>(p, L, lane, qb);
         EV_STAMP(0)
-        total = rows_eval<PASS, PROJ, true, 2, 2>(p, L, planes, alpha, lane, qb, total, payload);
-        rows_load<PASS, 6, 2>(p, L, lane, qb);
+        total = rows_eval<PASS, PROJ, true, 2, 1>(p, L, planes, alpha, lane, qa, total, payload);
+        rows_load<PASS, 4, 1>(p, L, lane, qa);
+        total = rows_eval<PASS, PROJ, true, 3, 1>(p, L, planes, alpha, lane, qb, total, payload);
+        rows_load<PASS, 5, 1>(p, L, lane, qb);
         const float4 mat2 = setup_load_mat(p, rec2, lane);
         const uint4 rec3 = setup_load_rec(p, w3, w3 < ntiles, nrec, lane);
         EV_STAMP(1)
-        total = rows_eval<PASS, PROJ, true, 4, 2>(p, L, planes, alpha, lane, qa, total, payload);
-        rows_load<PASS, 0, 2>(p, Ln, lane, qa);
+        total = rows_eval<PASS, PROJ, true, 4, 1>(p, L, planes, alpha, lane, qa, total, payload);
+        rows_load<PASS, 6, 1>(p, L, lane, qa);
+        total = rows_eval<PASS, PROJ, true, 5, 1>(p, L, planes, alpha, lane, qb, total, payload);
+        rows_load<PASS, 7, 1>(p, L, lane, qb);
         EV_STAMP(2)
-        total = rows_eval<PASS, PROJ, true, 6, 2>(p, L, planes, alpha, lane, qb, total, payload);
-        rows_load<PASS, 2, 2>(p, Ln, lane, qb);
+        total = rows_eval<PASS, PROJ, true, 6, 1>(p, L, planes, alpha, lane, qa, total, payload);
+        rows_load<PASS, 0, 1>(p, Ln, lane, qa);
+        total = rows_eval<PASS, PROJ, true, 7, 1>(p, L, planes, alpha, lane, qb, total, payload);
+        rows_load<PASS, 1, 1>(p, Ln, lane, qb);
         EV_STAMP(3)
         setup_write(p, lds[wave][(it + 2) % 3], rec2, mat2, lane); // also fences the mask writes of this tile
         if (lane < 2 * (int)kTileRows)
