@@ -13,8 +13,11 @@
 //             order), header written last (active_cluster_compaction.comp:33-43).
 //   assign  : lights are transformed to view space ONCE (the reference redoes
 //             world_to_view x position per cluster per light,
-//             light_culling.comp:111) and staged through LDS in tiles; ranges
-//             are allocated by prefix sum in compacted-list order.
+//             light_culling.comp:111).  Lane = light: a wave takes 4 active
+//             clusters whose AABBs are wave-uniform (SGPRs), the sphere-vs-AABB
+//             hits of 64 lights are one ballot -> popcount in the count pass,
+//             ballot-ranked ordered writes in the write pass; ranges are
+//             allocated by prefix sum in compacted-list order.
 #include "kernels.h"
 #include "scan.h"
 
