@@ -45,16 +45,34 @@ def parse():
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL writes its version banner to
+    # stdout, C-buffered, i.e. after anything Python printed): keep the real stdout aside for the JSON line and
+    # point fd 1 at stderr for everything else, in every rank.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    # Dry-run knobs for boxes with fewer GPUs than ranks (never set by the driver): all ranks on device 0 and a
+    # gloo process group exercise the N>1 control flow (sharding, barriers, reductions, JSON); gloo cannot move
+    # device buffers point-to-point, so the visible-list gather is skipped there.  ORBIT_BENCH_FORCE_DIST=1 runs
+    # the RCCL group and the gather with a world of one.
+    backend = os.environ.get("ORBIT_BENCH_BACKEND", "nccl")
+    device_index = 0 if os.environ.get("ORBIT_BENCH_ONE_DEVICE") == "1" else local_rank
+    use_dist = world > 1 or os.environ.get("ORBIT_BENCH_FORCE_DIST") == "1"
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": dev} if backend == "nccl" else {}))
+        else:
+            dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     import scenes as sc  # camera / CullInfo builders (test-side helpers, numpy only)
     from orbit_amd import dist as odist
@@ -85,43 +103,76 @@ def main():
 
     disp_cap = n_local_entities * rec_per_ent + 8
     draw_cap = n_local_meshlets // 2 + 1024
-    eng = Engine(local_rank, max_entities=n_local_entities + 256, max_dispatches=disp_cap, max_draws=draw_cap)
+    eng = Engine(device_index, max_entities=n_local_entities + 256, max_dispatches=disp_cap, max_draws=draw_cap)
     disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device=dev)
-    draw = torch.zeros(L.DRAW_HEADER + 28 * draw_cap, dtype=torch.uint8, device=dev)
+    do_gather = use_dist and backend == "nccl" and not args.no_gather
+    # N > 1: two draw buffers, so that the gather of step i-1 (RCCL, side stream) overlaps the cull of step i
+    draw_bufs = [torch.zeros(L.DRAW_HEADER + 28 * draw_cap, dtype=torch.uint8, device=dev)
+                 for _ in range(2 if do_gather else 1)]
+    draw = draw_bufs[0]
     gathered = None
-    do_gather = world > 1 and not args.no_gather
+    side = None
     if do_gather:
         gathered = torch.zeros(L.DRAW_HEADER + 28 * (draw_cap * world), dtype=torch.uint8, device=dev)
+        side = torch.cuda.Stream(device=dev)
+    cull_done = [torch.cuda.Event() for _ in draw_bufs]    # per draw buffer: its cull has been enqueued/finished
+    gather_done = [torch.cuda.Event() for _ in draw_bufs]  # per draw buffer: its gather has read it
+    pending = []  # draw-buffer slots culled but not yet gathered (at most one)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
+    def gather(slot):
+        # counts download, RCCL send/recv and the local copy all go through the side stream, which waits only
+        # for the cull that filled this slot — not for the cull enqueued after it
+        with torch.cuda.stream(side):
+            side.wait_event(cull_done[slot])
+            odist.gather_visible(draw_bufs[slot], gathered)
+            gather_done[slot].record(side)
+
+    step_no = [0]
+
     def step(i=None):
+        slot = step_no[0] % len(draw_bufs)
+        step_no[0] += 1
         eng.entity_cull(ci, draws, mesh, disp, ent, n_local_entities, disp_cap, draw_first=b)
         if i is not None:
             ev[i][0].record()
-        eng.meshlet_cull(ci, disp, meshlets_base, draw, ent, materials, disp_cap, draw_cap,
+        if do_gather:
+            torch.cuda.current_stream().wait_event(gather_done[slot])  # slot last read by the gather two steps ago
+        eng.meshlet_cull(ci, disp, meshlets_base, draw_bufs[slot], ent, materials, disp_cap, draw_cap,
                          material_count=spec.materials)
         if i is not None:
             ev[i][1].record()
         if do_gather:
-            odist.gather_visible(draw, gathered)
+            cull_done[slot].record()
+            if pending:
+                gather(pending.pop())  # previous step's list travels while this step's cull runs
+            pending.append(slot)
+
+    def drain():
+        if do_gather:
+            while pending:
+                gather(pending.pop())
+            torch.cuda.current_stream().wait_stream(side)
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     eng.profile(True)  # HIP events around the dominant kernel (meshlet_eval), on the launch stream
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    drain()  # every one of the K visible lists has been gathered inside the timed region
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -132,10 +183,19 @@ def main():
 
     kernel_ms = float(np.mean([a.elapsed_time(z) for a, z in ev]))  # whole meshlet_cull op (eval + scan + emit)
     n_rec = int(disp[:4].view(torch.int32).item())
+    draw = draw_bufs[(step_no[0] - 1) % len(draw_bufs)]  # the last step's list
     n_draw = int(draw[:4].view(torch.int32).item())
+    if do_gather:  # the gathered list holds this rank's commands at its rank-order position
+        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([n_draw], dtype=torch.int64, device=dev))
+        first = int(sum(int(c.item()) for c in counts[:rank]))
+        mine = gathered[L.DRAW_HEADER + 28 * first:L.DRAW_HEADER + 28 * (first + n_draw)]
+        assert torch.equal(mine, draw[L.DRAW_HEADER:L.DRAW_HEADER + 28 * n_draw]), "gathered list != local list"
+        assert int(gathered[:4].view(torch.int32).item()) == int(sum(int(c.item()) for c in counts))
+
     n_in = int(disp[L.DISPATCH_HEADER:L.DISPATCH_HEADER + 16 * n_rec].view(torch.int32).view(-1, 4)[:, 2].sum().item())
     # cull-only rate of this rank (for the N>1 breakdown)
-    if world > 1:
+    if use_dist:
         agg = torch.tensor([n_in, n_draw], dtype=torch.int64, device=dev)
         dist.all_reduce(agg)
         tot_in, tot_draw = int(agg[0].item()), int(agg[1].item())
@@ -155,7 +215,7 @@ def main():
     alg_bytes = 32 * n_in + 16 * n_rec + 64 * n_local_entities
     achieved = alg_bytes / (eval_ms * 1e-3) / 1e9
     op_bytes = alg_bytes + 28 * n_draw + 4
-    traffic = load_traffic(E, M)
+    traffic = load_traffic(E, M) if world == 1 else None  # the PMC passes were taken on the whole scene at N=1
 
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_sample_entities > 0:
@@ -194,9 +254,9 @@ def main():
             "cull_only_meshlets_per_sec": tot_in / (kernel_ms_max * 1e-3) if kernel_ms_max > 0 else None,
             "scene_gen_s": gen_s,
         }
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
