@@ -60,6 +60,16 @@ extern "C" {
     pub fn orbit_cluster_assign(ctx: *mut OrbitCtx, info: *const c_void, unique: *const c_void, bounds: *const c_void,
                                 lights: *const c_void, light_index_buffer: *mut c_void, light_index_capacity: u32,
                                 cluster_offset_image: *mut u32, stream: *mut c_void) -> i32;
+    /// compute_clusters (cluster.rs:368-397): the three stages in one call.
+    pub fn orbit_compute_clusters(ctx: *mut OrbitCtx, push: *const c_void, info: *const c_void, depth: *const f32,
+                                  lights: *const c_void, masks: *mut u32, bounds: *mut c_void, unique: *mut c_void,
+                                  index_capacity: u32, light_index_buffer: *mut c_void, light_index_capacity: u32,
+                                  cluster_offset_image: *mut u32, stream: *mut c_void) -> i32;
+    /// Sharded engine only: rank-ordered all-gather of the visible lists over the caller's ncclComm_t.
+    pub fn orbit_shard_range(entity_draw_count: u32, rank: u32, world: u32, begin: *mut u32, end: *mut u32);
+    pub fn orbit_gather_visible(ctx: *mut OrbitCtx, nccl_comm: *mut c_void, rank: u32, world: u32,
+                                local_draw_buffer: *const c_void, out_draw_buffer: *mut c_void, out_capacity: u32,
+                                stream: *mut c_void) -> i32;
 }
 
 /// Turns a non-zero status into the panic the Vulkan path produced (assert!/unwrap, draw_gen.rs:247).

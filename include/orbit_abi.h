@@ -54,8 +54,9 @@ enum {
     ORBIT_E_HIP = -4,      /* a HIP runtime call failed */
     ORBIT_E_NO_DEVICE = -5,/* no gfx950 device / kernels not loadable: there is NO CPU fallback */
     ORBIT_E_TIMEOUT = -6,  /* a bounded in-kernel wait gave up (latched on device) */
-    ORBIT_E_MISSING = -7   /* a resource the CullInfo declares present was passed as NULL
+    ORBIT_E_MISSING = -7,  /* a resource the CullInfo declares present was passed as NULL
                               (.unwrap() at draw_gen.rs:123-133) */
+    ORBIT_E_COMM = -8      /* RCCL is not loadable in this process or one of its calls failed */
 };
 
 /* ------------------------------------------------------------------------ */
@@ -444,6 +445,20 @@ int32_t orbit_cluster_assign(OrbitCtx *ctx, const OrbitClusterCullInfo *info,
                              void *light_index_buffer, uint32_t light_index_capacity,
                              uint32_t *cluster_offset_image, void *stream);
 
+/* compute_clusters (cluster.rs:368-397): the three stages above in the
+ * reference's order on one stream — mark_active_clusters, then
+ * compact_active_clusters on its mask, then cluster_light_assignment on the
+ * compacted list and the depth bounds.  `push` and `info` are HOST pointers
+ * and must describe the same cluster grid. */
+int32_t orbit_compute_clusters(OrbitCtx *ctx, const OrbitMarkActivePush *push,
+                               const OrbitClusterCullInfo *info, const float *depth,
+                               const OrbitLightData *lights,
+                               uint32_t *tile_depth_slice_mask,
+                               OrbitClusterDepthBounds *depth_bounds,
+                               void *unique_cluster_buffer, uint32_t index_capacity,
+                               void *light_index_buffer, uint32_t light_index_capacity,
+                               uint32_t *cluster_offset_image, void *stream);
+
 /* ------------------------------------------------------------------------ */
 /* Measurement hook (bench.py).  While enabled, every orbit_meshlet_cull     */
 /* records a HIP event pair on the caller's stream around the op's dominant  */
@@ -454,14 +469,33 @@ int32_t orbit_ctx_profile(OrbitCtx *ctx, int32_t enable);
 int32_t orbit_ctx_profile_read(OrbitCtx *ctx, float *avg_ms, uint32_t *launches);
 
 /* ------------------------------------------------------------------------ */
-/* Multi-GPU helpers.  The exchange itself runs over RCCL    */
-/* through torch.distributed on the host side (orbit_amd/dist.py); these are */
-/* the device-side pieces.                                                   */
+/* Multi-GPU helpers: one process per GPU, contiguous entity */
+/* ranges per rank, one exchange step over RCCL.                             */
 /* ------------------------------------------------------------------------ */
 
 /* Contiguous, 32-aligned entity-draw range owned by `rank` of `world`. */
 void orbit_shard_range(uint32_t entity_draw_count, uint32_t rank, uint32_t world,
                        uint32_t *begin, uint32_t *end);
+
+/* Rank-ordered all-gather of the ranks' MeshletDrawCommandBuffers: because
+ * every rank's list is in canonical order and the shards are contiguous in
+ * entity order, the concatenation in rank order IS the single-GPU list
+ * (the reference is single-GPU; this is the exchange step of the sharded
+ * engine).
+ *   nccl_comm         the caller's ncclComm_t (RCCL), `rank` of `world` in it
+ *   local_draw_buffer this rank's buffer (count @0, 28-B commands @4)
+ *   out_draw_buffer   receives count @0 and all commands @4, rank order
+ *   out_capacity      commands `out_draw_buffer` can hold
+ * RCCL is resolved from the library already loaded in the process (the one
+ * that made `nccl_comm`); there is no link-time dependency.  The counts are
+ * all-gathered first and read on the host (message sizes): ONE stream
+ * synchronisation per call, the only entry point that has one.  The lists
+ * travel as grouped send/recv straight into out + prefix[rank] (direct
+ * fan-out over the point-to-point xGMI links).  ORBIT_E_CAPACITY if the
+ * concatenation does not fit (nothing is written past out_capacity). */
+int32_t orbit_gather_visible(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint32_t world,
+                             const void *local_draw_buffer, void *out_draw_buffer,
+                             uint32_t out_capacity, void *stream);
 
 #ifdef __cplusplus
 }

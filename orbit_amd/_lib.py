@@ -10,10 +10,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liborbit_cull.so")
 
-OK, E_INVALID, E_PLANES, E_CAPACITY, E_HIP, E_NO_DEVICE, E_TIMEOUT, E_MISSING = 0, -1, -2, -3, -4, -5, -6, -7
+OK, E_INVALID, E_PLANES, E_CAPACITY, E_HIP, E_NO_DEVICE, E_TIMEOUT, E_MISSING, E_COMM = 0, -1, -2, -3, -4, -5, -6, -7, -8
 ERROR_NAMES = {
     E_INVALID: "ORBIT_E_INVALID", E_PLANES: "ORBIT_E_PLANES", E_CAPACITY: "ORBIT_E_CAPACITY", E_HIP: "ORBIT_E_HIP",
     E_NO_DEVICE: "ORBIT_E_NO_DEVICE", E_TIMEOUT: "ORBIT_E_TIMEOUT", E_MISSING: "ORBIT_E_MISSING",
+    E_COMM: "ORBIT_E_COMM",
 }
 
 MAX_PYRAMID_MIPS = 16
@@ -72,9 +73,14 @@ SYMBOLS = {
                                           C.c_void_p]),
     "orbit_cluster_assign": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_uint32, C.c_void_p, C.c_void_p]),
+    "orbit_compute_clusters": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                           C.c_void_p]),
     "orbit_ctx_profile": (C.c_int32, [C.c_void_p, C.c_int32]),
     "orbit_ctx_profile_read": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "orbit_shard_range": (None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "orbit_gather_visible": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                         C.c_uint32, C.c_void_p]),
 }
 
 _lib = None

@@ -4,7 +4,9 @@
 // (assert!/unwrap in src/passes/draw_gen.rs:123-133,247,334,390) as status
 // codes; nothing unwinds across the boundary.  There is no host fallback: a
 // missing device or an unloadable code object is ORBIT_E_NO_DEVICE.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types and prototypes only: the symbols are resolved with dlsym (orbit_gather_visible)
 
 #include <cstdarg>
 #include <cstdio>
@@ -37,6 +39,7 @@ struct OrbitCtx {
     float4 *a_view_lights = nullptr;
     uint32_t *a_light_flags = nullptr, *a_counts = nullptr, *a_block_sums = nullptr, *a_block_base = nullptr,
              *a_total = nullptr;
+    uint32_t *g_counts = nullptr; // gather_visible: per-rank command counts
     int32_t *status = nullptr;
     uint32_t debug_flags = 0;
     unsigned long long *debug_cycles = nullptr;
@@ -179,6 +182,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t o_status = carve(256);
     const size_t o_dbg = carve(256);
     const size_t o_zero = carve(256);
+    const size_t o_gc = carve(256);
     const size_t o_eproto = carve(ent * sizeof(OrbitMeshletDispatch));
     const size_t o_ebs = carve(eblocks * 4), o_ebb = carve(eblocks * 4), o_et = carve(256);
     const size_t o_mtc = carve(mtiles * 4), o_mtb = carve(mtiles * 4), o_mt = carve(256);
@@ -230,6 +234,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->a_block_sums = (uint32_t *)(a + o_abs);
     ctx->a_block_base = (uint32_t *)(a + o_abb);
     ctx->a_total = (uint32_t *)(a + o_at);
+    ctx->g_counts = (uint32_t *)(a + o_gc);
     // the epoch word of the single-pass scan starts at 1 (zeroed granules carry epoch 0 = invalid)
     const uint32_t ctl0[3] = {0u, 0u, 1u};
     e = hipMemcpy(ctx->m_ticket, ctl0, sizeof(ctl0), hipMemcpyHostToDevice);
@@ -546,6 +551,32 @@ int32_t orbit_cluster_assign(OrbitCtx *ctx, const OrbitClusterCullInfo *info, co
     return ORBIT_OK;
 }
 
+int32_t orbit_compute_clusters(OrbitCtx *ctx, const OrbitMarkActivePush *push, const OrbitClusterCullInfo *info,
+                               const float *depth, const OrbitLightData *lights, uint32_t *tile_depth_slice_mask,
+                               OrbitClusterDepthBounds *depth_bounds, void *unique_cluster_buffer,
+                               uint32_t index_capacity, void *light_index_buffer, uint32_t light_index_capacity,
+                               uint32_t *cluster_offset_image, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    if (!push || !info) {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        return fail(ctx, ORBIT_E_MISSING, "compute_clusters: NULL parameter block");
+    }
+    for (int i = 0; i < 3; i++)
+        if (push->cluster_count[i] != info->cluster_count[i]) {
+            std::lock_guard<std::mutex> lock(ctx->mu);
+            return fail(ctx, ORBIT_E_INVALID, "compute_clusters: cluster_count[%d] differs between push (%u) and info (%u)",
+                        i, push->cluster_count[i], info->cluster_count[i]);
+        }
+    // stream order is the only dependency between the stages (cluster.rs:380-395)
+    int32_t rc = orbit_cluster_mark(ctx, push, depth, tile_depth_slice_mask, depth_bounds, stream);
+    if (rc != ORBIT_OK) return rc;
+    rc = orbit_cluster_compact(ctx, push->cluster_count, tile_depth_slice_mask, unique_cluster_buffer, index_capacity,
+                               stream);
+    if (rc != ORBIT_OK) return rc;
+    return orbit_cluster_assign(ctx, info, unique_cluster_buffer, depth_bounds, lights, light_index_buffer,
+                                light_index_capacity, cluster_offset_image, stream);
+}
+
 // ------------------------------------------------------------------- multi-GPU
 void orbit_shard_range(uint32_t n, uint32_t rank, uint32_t world, uint32_t *begin, uint32_t *end) {
     // contiguous ranges cut at multiples of 32 so entity-bitset words are rank-private
@@ -556,6 +587,118 @@ void orbit_shard_range(uint32_t n, uint32_t rank, uint32_t world, uint32_t *begi
     if (e > n) e = n;
     if (begin) *begin = (uint32_t)b;
     if (end) *end = (uint32_t)e;
+}
+
+} // extern "C"
+
+namespace {
+
+// RCCL entry points, resolved from the copy already loaded in the process (the one the caller's
+// communicator belongs to); liborbit_cull.so itself does not link RCCL.
+struct Rccl {
+    decltype(&ncclAllGather) all_gather = nullptr;
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    bool ok = false;
+};
+
+const Rccl &rccl() {
+    static const Rccl table = [] {
+        Rccl t;
+        void *h = nullptr;
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+            if (h) break;
+        }
+        if (!h)
+            for (const char *name : {"librccl.so.1", "librccl.so"}) {
+                h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (h) break;
+            }
+        if (!h) return t;
+        t.all_gather = (decltype(t.all_gather))dlsym(h, "ncclAllGather");
+        t.send = (decltype(t.send))dlsym(h, "ncclSend");
+        t.recv = (decltype(t.recv))dlsym(h, "ncclRecv");
+        t.group_start = (decltype(t.group_start))dlsym(h, "ncclGroupStart");
+        t.group_end = (decltype(t.group_end))dlsym(h, "ncclGroupEnd");
+        t.error_string = (decltype(t.error_string))dlsym(h, "ncclGetErrorString");
+        t.ok = t.all_gather && t.send && t.recv && t.group_start && t.group_end && t.error_string;
+        return t;
+    }();
+    return table;
+}
+
+constexpr uint32_t kMaxGatherWorld = 64; // counts scratch: one 256-B carve
+
+__global__ void write_u32_kernel(uint32_t *dst, uint32_t v) { *dst = v; }
+
+} // namespace
+
+extern "C" {
+
+int32_t orbit_gather_visible(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint32_t world,
+                             const void *local_draw_buffer, void *out_draw_buffer, uint32_t out_capacity,
+                             void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!nccl_comm || !local_draw_buffer || !out_draw_buffer)
+        return fail(ctx, ORBIT_E_MISSING, "gather_visible: NULL argument");
+    if (world == 0 || world > kMaxGatherWorld || rank >= world)
+        return fail(ctx, ORBIT_E_INVALID, "gather_visible: rank %u of world %u (max %u)", rank, world, kMaxGatherWorld);
+    const Rccl &nc = rccl();
+    if (!nc.ok) return fail(ctx, ORBIT_E_COMM, "gather_visible: librccl is not loadable in this process");
+    ncclComm_t comm = (ncclComm_t)nccl_comm;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipSetDevice");
+#define ORBIT_NCCL(call, what)                                                                  \
+    do {                                                                                        \
+        const ncclResult_t r_ = (call);                                                         \
+        if (r_ != ncclSuccess) return fail(ctx, ORBIT_E_COMM, "%s: %s", what, nc.error_string(r_)); \
+    } while (0)
+    // 1. counts of all ranks (4 B each), device -> host: the message sizes
+    ORBIT_NCCL(nc.all_gather(local_draw_buffer, ctx->g_counts, 1, ncclUint32, comm, s), "ncclAllGather(counts)");
+    uint32_t counts[kMaxGatherWorld];
+    e = hipMemcpyAsync(counts, ctx->g_counts, world * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipMemcpyAsync(counts)");
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipStreamSynchronize(counts)");
+    uint64_t prefix[kMaxGatherWorld + 1];
+    prefix[0] = 0;
+    for (uint32_t r = 0; r < world; r++) prefix[r + 1] = prefix[r] + counts[r];
+    if (prefix[world] > out_capacity)
+        return fail(ctx, ORBIT_E_CAPACITY, "gather_visible: %llu commands > out_capacity %u",
+                    (unsigned long long)prefix[world], out_capacity);
+    // 2. header = total; 3. every list straight into out + prefix[rank]
+    uint8_t *out = (uint8_t *)out_draw_buffer;
+    const uint8_t *mine = (const uint8_t *)local_draw_buffer + ORBIT_DRAW_HEADER;
+    hipLaunchKernelGGL(write_u32_kernel, dim3(1), dim3(1), 0, s, (uint32_t *)out, (uint32_t)prefix[world]);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch write_u32");
+    const size_t stride = sizeof(OrbitMeshletDrawCommand);
+    if (counts[rank] > 0) {
+        e = hipMemcpyAsync(out + ORBIT_DRAW_HEADER + stride * prefix[rank], mine, stride * counts[rank],
+                           hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return hip_fail(ctx, e, "hipMemcpyAsync(own list)");
+    }
+    if (world > 1) {
+        ORBIT_NCCL(nc.group_start(), "ncclGroupStart");
+        for (uint32_t peer = 0; peer < world; peer++) {
+            if (peer == rank) continue;
+            if (counts[rank] > 0)
+                ORBIT_NCCL(nc.send(mine, stride * counts[rank], ncclUint8, (int)peer, comm, s), "ncclSend");
+            if (counts[peer] > 0)
+                ORBIT_NCCL(nc.recv(out + ORBIT_DRAW_HEADER + stride * prefix[peer], stride * counts[peer], ncclUint8,
+                                   (int)peer, comm, s),
+                           "ncclRecv");
+        }
+        ORBIT_NCCL(nc.group_end(), "ncclGroupEnd");
+    }
+#undef ORBIT_NCCL
+    return ORBIT_OK;
 }
 
 } // extern "C"

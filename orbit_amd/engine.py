@@ -136,6 +136,23 @@ class Engine:
         _lib.check(self._lib.orbit_depth_reduce(self._ctx, _ptr(depth), screen_width, screen_height, _ptr(pyramid),
                                                 _stream(stream)), self._ctx)
 
+    def gather_visible(self, nccl_comm, rank, world, local_draw_buffer, out_draw_buffer, out_capacity, stream=None):
+        """Rank-ordered all-gather of the visible lists over the caller's RCCL communicator
+        (`nccl_comm`: the ncclComm_t as an integer / c_void_p).  One stream sync (message sizes)."""
+        comm = nccl_comm if isinstance(nccl_comm, C.c_void_p) else C.c_void_p(int(nccl_comm))
+        _lib.check(self._lib.orbit_gather_visible(self._ctx, comm, rank, world, _ptr(local_draw_buffer),
+                                                  _ptr(out_draw_buffer), out_capacity, _stream(stream)), self._ctx)
+
+    def compute_clusters(self, push, info, depth, lights, tile_depth_slice_mask, depth_bounds, unique_cluster_buffer,
+                         index_capacity, light_index_buffer, light_index_capacity, cluster_offset_image, stream=None):
+        """compute_clusters (cluster.rs:368-397): mark -> compact -> assign in one call."""
+        pc = _host_bytes(push, layouts.MARK_ACTIVE_PUSH.itemsize)
+        ib = _host_bytes(info, layouts.CLUSTER_CULL_INFO.itemsize)
+        _lib.check(self._lib.orbit_compute_clusters(
+            self._ctx, pc.ctypes.data_as(C.c_void_p), ib.ctypes.data_as(C.c_void_p), _ptr(depth), _ptr(lights),
+            _ptr(tile_depth_slice_mask), _ptr(depth_bounds), _ptr(unique_cluster_buffer), index_capacity,
+            _ptr(light_index_buffer), light_index_capacity, _ptr(cluster_offset_image), _stream(stream)), self._ctx)
+
     # -- compute_clusters stages (cluster.rs:399-591)
     def cluster_mark(self, push, depth, tile_depth_slice_mask, depth_bounds, stream=None):
         pc = _host_bytes(push, layouts.MARK_ACTIVE_PUSH.itemsize)

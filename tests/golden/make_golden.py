@@ -73,8 +73,28 @@ def cluster_case(name, seed, W, H, n_lights):
                         offset_image=img)
 
 
+def config1_case(name):
+    """BASELINE.json configs[0] / SURVEY.md §8d C1: 8192 spheres, centre ~ U[-128,128]^3 (app.rs:658), radius ~
+    U[0.25,4], camera at (0,2,0) looking down -z, fov 90 deg, near 0.01, 16:9 (app.rs:744-752), planes =
+    frustum_planes_from_matrix(projection)[0..5] (forward.rs:264,268), test dot(n,c)+d > -r (math.rs).  splitmix64
+    streams of seed 69 (tests/scenes.py).  Stored: the inputs' defining parameters, the 256-word bitset, the count."""
+    n = 8192
+    i = np.arange(n)
+    spheres = np.stack([sc.rnd_range(69, 1, i, -128, 128), sc.rnd_range(69, 2, i, -128, 128),
+                        sc.rnd_range(69, 3, i, -128, 128), sc.rnd_range(69, 4, i, 0.25, 4.0)], axis=1)
+    cam = sc.default_camera()
+    bits, cnt = oracle.sphere_frustum_cull(sc.mat4_cols(cam.view), cam.planes, spheres)
+    np.savez_compressed(os.path.join(OUT, name), view=sc.mat4_cols(cam.view), planes=cam.planes,
+                        first_spheres=spheres[:16], sphere_sum=spheres.astype(np.float64).sum(axis=0),
+                        bitset=bits, count=np.uint32(cnt))
+
+
 if __name__ == "__main__":
     oracle.build()
+    if len(sys.argv) > 1 and sys.argv[1] == "config1":  # add the C1 fixture without rewriting the others
+        config1_case("config1_spheres.npz")
+        sys.exit(0)
+    config1_case("config1_spheres.npz")
     cull_case("cull_small.npz", 101, 180, 2, 160, 90)
     cull_case("cull_ragged.npz", 102, 45, 1, 96, 54)
     cluster_case("cluster_small.npz", 103, 160, 90, 120)

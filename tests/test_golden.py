@@ -33,6 +33,33 @@ def test_oracle_reproduces_cull_fixture(oracle, name):
             assert np.array_equal(ev, g["evis_out"]) and np.array_equal(mv, g["mvis_out"])
 
 
+def test_oracle_reproduces_config1_fixture(oracle):
+    """BASELINE.json configs[0]: 8k spheres, frustum-only cull on the CPU (plumbing, no GPU)."""
+    import scenes as sc
+
+    g = load("config1_spheres.npz")
+    n = 8192
+    i = np.arange(n)
+    spheres = np.stack([sc.rnd_range(69, 1, i, -128, 128), sc.rnd_range(69, 2, i, -128, 128),
+                        sc.rnd_range(69, 3, i, -128, 128), sc.rnd_range(69, 4, i, 0.25, 4.0)], axis=1)
+    assert np.array_equal(spheres[:16], g["first_spheres"])  # the generator still makes the fixture's inputs
+    assert np.array_equal(spheres.astype(np.float64).sum(axis=0), g["sphere_sum"])
+    cam = sc.default_camera()
+    assert np.array_equal(sc.mat4_cols(cam.view), g["view"]) and np.array_equal(cam.planes, g["planes"])
+    bits, cnt = oracle.sphere_frustum_cull(g["view"], g["planes"], spheres)
+    assert len(bits) == 256 and cnt == int(g["count"]) and np.array_equal(bits, g["bitset"])
+
+
+def test_host_mirror_derives_config1_planes():
+    """The C++ host mirror (camera.rs / math.rs restated) derives the fixture's five view-space planes."""
+    from orbit_amd import passes
+
+    g = load("config1_spheres.npz")
+    proj = passes.projection_compute_matrix(passes.Projection.Perspective(float(np.float32(np.pi / 2)), 0.01), 16.0 / 9.0)
+    planes = passes.frustum_planes_from_matrix(proj)[:5]
+    assert np.array_equal(planes.view(np.uint32), np.ascontiguousarray(g["planes"], np.float32).view(np.uint32))
+
+
 def test_oracle_reproduces_cluster_fixture(oracle):
     g = load("cluster_small.npz")
     cc = [int(v) for v in g["push"][:12].view(np.uint32)]

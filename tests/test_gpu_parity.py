@@ -383,6 +383,16 @@ def test_light_clusters(torch_mod, engine, oracle, W, H, n_lights, tile, zs, sam
     engine.status()
     if n_lights >= 200:
         assert n_idx > 0 and n_active > 0
+    # compute_clusters: the same three stages behind one call produce the same five buffers
+    gm2, gb2 = torch.full_like(gm, 0x55), torch.full_like(gb, 0x55)
+    gu2, gl2, gimg2 = torch.full_like(gu, 0xEE), torch.full_like(gl, 0xEE), torch.zeros_like(gimg)
+    engine.compute_clusters(push, info, dev(torch, depth), dev(torch, lights) if n_lights else None, gm2, gb2, gu2, cap,
+                            gl2, lcap, gimg2)
+    torch.cuda.synchronize()
+    engine.status()
+    assert torch.equal(gm2, gm) and torch.equal(gb2, gb) and torch.equal(gimg2, gimg)
+    assert torch.equal(gu2[:16 + 4 * n_active], gu[:16 + 4 * n_active])
+    assert torch.equal(gl2[:4 + 4 * n_idx], gl[:4 + 4 * n_idx])
 
 
 # ----------------------------------------------------------------------------- sharded ranges
