@@ -36,6 +36,7 @@ struct __attribute__((aligned(16))) WaveTileLds {
     float4 tzero[kTileRecords];   // column 3 x 0.0f: the w = 0 term of the cone-axis transform (:121)
     float scale[kTileRecords];    // largest_scale_from_matrix(mat3(M))
     uint64_t draw_mask[kTileRows]; // should-draw ballots of the tile's rows (kept here, not in SGPRs)
+    uint64_t vis_mask[kTileRows];  // pass 2 with meshlet occlusion: visible ballots, assembled by the candidate flushes
 };
 
 // The cull planes live in LDS (one copy per block, written once): a row reads
@@ -125,10 +126,11 @@ __device__ __forceinline__ uint4 make_payload(uint32_t meshlet_index, uint32_t r
 
 // One meshlet (one lane): meshlet_cull.comp:113-213.  PASS = cull_info.occlusion_pass
 // and PROJ = cull_info.projection_type are compile-time (PROJ < 0: read at run time).
+// Geometry part (:117-158): view-space sphere `s`, pass-1 gate, plane loop, cone test.
 template <int PASS, int PROJ>
-__device__ __forceinline__ MeshletVerdict eval_meshlet(const MeshletCullParams &p, const WaveTileLds &L,
-                                                       const PlaneLds &P, uint32_t rid, const uint4 &a, const uint4 &b,
-                                                       uint32_t abits, bool visible_in_buffer, bool meshlet_occ) {
+__device__ __forceinline__ bool eval_geometry(const MeshletCullParams &p, const WaveTileLds &L, const PlaneLds &P,
+                                              uint32_t rid, const uint4 &a, const uint4 &b, bool visible_in_buffer,
+                                              Sphere &s) {
     const OrbitGpuCullInfo &ci = p.ci;
     const float4 m0 = L.mcol[rid][0], m1 = L.mcol[rid][1], m2 = L.mcol[rid][2], m3 = L.mcol[rid][3];
     const float cx = __uint_as_float(a.x), cy = __uint_as_float(a.y), cz = __uint_as_float(a.z);
@@ -142,7 +144,6 @@ __device__ __forceinline__ MeshletVerdict eval_meshlet(const MeshletCullParams &
         py = py / pw;
         pz = pz / pw;
     }
-    Sphere s;
     s.x = px;
     s.y = py;
     s.z = pz;
@@ -178,12 +179,24 @@ __device__ __forceinline__ MeshletVerdict eval_meshlet(const MeshletCullParams &
         cull = dot3(dx, dy, dz, axx, axy, axz) >= cutoff * sqrtf(dot3(dx, dy, dz, dx, dy, dz)) + s.r;
     }
     if (visible) visible = plane_test_lds(P, ci.cull_plane_count, s); // :139-146
-    visible = visible && !cull;
-    if (PASS == 2 && meshlet_occ && visible) visible = occlusion_test(ci, s, p.pyr); // :161-205
+    return visible && !cull;
+}
 
-    bool should_draw = visible && (abits & 1u) != 0; // :207
-    if ((PASS == 2 && meshlet_occ) && (abits & 2u) == 0) should_draw = visible && !visible_in_buffer; // :210-213
-    return {visible, should_draw};
+// :207-213 from the final `visible`, the material's predicate bits and last frame's bit.
+__device__ __forceinline__ bool should_draw_of(bool visible, uint32_t abits, bool visible_in_buffer, bool occ2) {
+    bool should_draw = visible && (abits & 1u) != 0;                                 // :207
+    if (occ2 && (abits & 2u) == 0) should_draw = visible && !visible_in_buffer;      // :210-213
+    return should_draw;
+}
+
+template <int PASS, int PROJ>
+__device__ __forceinline__ MeshletVerdict eval_meshlet(const MeshletCullParams &p, const WaveTileLds &L,
+                                                       const PlaneLds &P, uint32_t rid, const uint4 &a, const uint4 &b,
+                                                       uint32_t abits, bool visible_in_buffer, bool meshlet_occ) {
+    Sphere s;
+    bool visible = eval_geometry<PASS, PROJ>(p, L, P, rid, a, b, visible_in_buffer, s);
+    if (PASS == 2 && meshlet_occ && visible) visible = occlusion_test(p.ci, s, p.pyr); // :161-205
+    return {visible, should_draw_of(visible, abits, visible_in_buffer, PASS == 2 && meshlet_occ)};
 }
 
 // Issues the meshlet loads of rows R0 .. R0+NR-1 of a tile (2 x 16 B per lane per row).
@@ -256,6 +269,108 @@ __device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTi
         }
     }
     return total;
+}
+
+// ---------------------------------------------------------------------------
+// Pass 2 with meshlet occlusion: the HiZ test (:161-205) is by far the longest
+// part of the evaluation (projected bounds with four IEEE divisions, log2, four
+// texel gathers), and only the ~10 % of the lanes that survive planes + cone run
+// it — inline, every 64-meshlet row would issue it for a handful of lanes.
+// Instead the survivors of the geometry tests ("candidates") are appended, in
+// canonical (row, lane) order, to a wave-private LDS ring with what the rest of
+// the decision needs (view-space sphere, Meshlet words 5..7, predicate bits);
+// whenever the ring holds >= kCandFlush of them, up to 64 are tested at once
+// with full lanes, the results OR-ed into the tile's per-row masks and the
+// drawn ones appended to the payload.  Ring order == canonical order, so the
+// payload ranks are the same as with the inline test.
+constexpr uint32_t kCandRing = 96, kCandFlush = 32; // < kCandFlush left after a flush, + one row of 64 <= kCandRing
+
+template <uint32_t N>
+struct __attribute__((aligned(16))) CandLds {
+    float4 sphere[N]; // view-space centre, radius
+    uint4 info[N];    // {code, Meshlet words 5, 6, 7}; code = row*64+lane | a1<<9 | a2<<10 | visible_in_buffer<<11
+};
+
+struct CandState {
+    uint32_t head = 0, count = 0; // ring window (wave-uniform)
+    uint32_t total = 0;           // survivors of the tile so far
+};
+
+__device__ __forceinline__ uint32_t ring_wrap(uint32_t i) { return i >= kCandRing ? i - kCandRing : i; }
+
+// Tests the first n (<= 64) candidates of the ring; lane j takes candidate j.
+template <uint32_t N>
+__device__ __forceinline__ void cand_flush(const MeshletCullParams &p, WaveTileLds &L, const CandLds<N> &C, int lane,
+                                           CandState &cs, uint32_t n, uint4 *payload) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool valid = (uint32_t)lane < n;
+    const uint32_t slot = ring_wrap(cs.head + (uint32_t)lane);
+    const float4 sp = C.sphere[slot];
+    const uint4 info = C.info[slot];
+    bool visible = false;
+    if (valid) {
+        Sphere s;
+        s.x = sp.x, s.y = sp.y, s.z = sp.z, s.r = sp.w;
+        visible = occlusion_test(p.ci, s, p.pyr); // :161-205
+    }
+    const uint32_t code = info.x;
+    const uint32_t abits = (code >> 9) & 3u;
+    const bool should_draw = should_draw_of(visible, abits, ((code >> 11) & 1u) != 0, true);
+    const uint32_t word = (code >> 5) & 15u, bit = 1u << (code & 31u); // record 2*row + half, lane within the record
+    if (visible) atomicOr(reinterpret_cast<uint32_t *>(L.vis_mask) + word, bit);
+    if (should_draw) atomicOr(reinterpret_cast<uint32_t *>(L.draw_mask) + word, bit);
+    const uint64_t dm = __ballot(should_draw);
+    if (payload && should_draw) {
+        const uint32_t rank = cs.total + lane_prefix(dm);
+        if (rank < kPayloadCap)
+            payload[rank] = make_payload(L.rec[word].y + (code & 31u), word, info);
+    }
+    cs.total += (uint32_t)__popcll(dm);
+    cs.head = ring_wrap(cs.head + n);
+    cs.count -= n;
+}
+
+// One row of a tile in pass 2 with meshlet occlusion: geometry tests, candidates into the ring.
+template <int PROJ, int R, uint32_t N>
+__device__ __forceinline__ void row_eval_occ(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
+                                             const AlphaLds *A, CandLds<N> &C, int lane, const RowRegs<1> &t,
+                                             CandState &cs, uint4 *payload) {
+    const uint32_t half = lane >> 5, ml = lane & 31;
+    const uint32_t rid = 2 * R + half;
+    const uint4 rec = L.rec[rid];
+    const uint32_t mi = t.b[0].w & 0xFFFFu;
+    const uint32_t abits = A ? (uint32_t)A->bits[mi & (kAlphaTable - 1u)] : alpha_bits(p.ci, p.materials[mi].alpha_mode);
+    const bool active = ml < rec.z;
+    const bool visible_in_buffer = ((t.prev[0] >> ml) & 1u) != 0;
+    Sphere s;
+    s.x = s.y = s.z = s.r = 0.0f;
+    bool cand = false;
+    if (active) cand = eval_geometry<2, PROJ>(p, L, P, rid, t.a[0], t.b[0], visible_in_buffer, s);
+    const uint64_t mask = __ballot(cand);
+    if (cand) {
+        const uint32_t slot = ring_wrap(ring_wrap(cs.head + cs.count) + lane_prefix(mask));
+        C.sphere[slot] = make_float4(s.x, s.y, s.z, s.r);
+        C.info[slot] = make_uint4((uint32_t)(R * 64 + lane) | (abits << 9) | ((visible_in_buffer ? 1u : 0u) << 11),
+                                  t.b[0].y, t.b[0].z, t.b[0].w);
+    }
+    cs.count += (uint32_t)__popcll(mask);
+    if (cs.count >= kCandFlush) cand_flush(p, L, C, lane, cs, min(cs.count, 64u), payload);
+}
+
+// End of a tile: remaining candidates, then the pass-2 visibility words (:233-254) of its 16 records.
+template <uint32_t N>
+__device__ __forceinline__ void tile_finish_occ(const MeshletCullParams &p, WaveTileLds &L, const CandLds<N> &C,
+                                                int lane, CandState &cs, uint4 *payload) {
+    if (cs.count > 0) cand_flush(p, L, C, lane, cs, cs.count, payload);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < (int)kTileRecords) {
+        const uint4 rec = L.rec[lane];
+        if (rec.z > 0) p.meshlet_visibility[rec.w] = reinterpret_cast<const uint32_t *>(L.vis_mask)[lane];
+    }
 }
 
 // Whole-tile forms (look-back kernel).
@@ -420,6 +535,7 @@ __device__ __forceinline__ void setup_write(const MeshletCullParams &p, WaveTile
         L.scale[rid] = sqrtf(gmax(d0, gmax(d1, d2)));
         L.rec[rid] = rec;
     }
+    if (lane < (int)kTileRows) L.draw_mask[lane] = 0ull, L.vis_mask[lane] = 0ull; // the candidate flushes OR into them
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -628,7 +744,10 @@ __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_k
     __shared__ WaveTileLds lds[kEvWaves][3];
     __shared__ PlaneLds planes;
     __shared__ AlphaLds alpha_tab;
+    __shared__ CandLds<(PASS == 2 ? kCandRing : 1u)> cand_ring[kEvWaves]; // pass 2 only
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // pass 2 with meshlet occlusion: HiZ tests run on compacted candidates (cand_flush), not per row
+    const bool occ2 = PASS == 2 && p.ci.meshlet_visibility_buffer != ORBIT_NONE;
     planes_to_lds(p.ci, planes);
     const AlphaLds *alpha = alpha_table_fill(p, alpha_tab) ? &alpha_tab : nullptr;
     __syncthreads();
@@ -668,33 +787,44 @@ __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_k
         WaveTileLds &L = lds[wave][it % 3];
         WaveTileLds &Ln = lds[wave][(it + 1) % 3]; // slab of an absent tile holds zero records
         uint4 *payload = p.tile_payload + (size_t)w0 * kPayloadCap;
-        uint32_t total = 0;
-        total = rows_eval<PASS, PROJ, true, 0, 1>(p, L, planes, alpha, lane, qa, total, payload);
+        CandState cs; // cs.total = the tile's running survivor count
+#define EV_ROW(R, Q)                                                                                        \
+    if constexpr (PASS == 2) {                                                                              \
+        if (occ2) row_eval_occ<PROJ, R>(p, L, planes, alpha, cand_ring[wave], lane, Q, cs, payload);        \
+        else cs.total = rows_eval<PASS, PROJ, true, R, 1>(p, L, planes, alpha, lane, Q, cs.total, payload); \
+    } else {                                                                                                \
+        cs.total = rows_eval<PASS, PROJ, true, R, 1>(p, L, planes, alpha, lane, Q, cs.total, payload);      \
+    }
+        EV_ROW(0, qa)
         rows_load<PASS, 2, 1>(p, L, lane, qa);
-        total = rows_eval<PASS, PROJ, true, 1, 1>(p, L, planes, alpha, lane, qb, total, payload);
+        EV_ROW(1, qb)
         rows_load<PASS, 3, 1>(p, L, lane, qb);
         EV_STAMP(0)
-        total = rows_eval<PASS, PROJ, true, 2, 1>(p, L, planes, alpha, lane, qa, total, payload);
+        EV_ROW(2, qa)
         rows_load<PASS, 4, 1>(p, L, lane, qa);
-        total = rows_eval<PASS, PROJ, true, 3, 1>(p, L, planes, alpha, lane, qb, total, payload);
+        EV_ROW(3, qb)
         rows_load<PASS, 5, 1>(p, L, lane, qb);
         const float4 mat2 = setup_load_mat(p, rec2, lane);
         const uint4 rec3 = setup_load_rec(p, w3, w3 < ntiles, nrec, lane);
         EV_STAMP(1)
-        total = rows_eval<PASS, PROJ, true, 4, 1>(p, L, planes, alpha, lane, qa, total, payload);
+        EV_ROW(4, qa)
         rows_load<PASS, 6, 1>(p, L, lane, qa);
-        total = rows_eval<PASS, PROJ, true, 5, 1>(p, L, planes, alpha, lane, qb, total, payload);
+        EV_ROW(5, qb)
         rows_load<PASS, 7, 1>(p, L, lane, qb);
         EV_STAMP(2)
-        total = rows_eval<PASS, PROJ, true, 6, 1>(p, L, planes, alpha, lane, qa, total, payload);
+        EV_ROW(6, qa)
         rows_load<PASS, 0, 1>(p, Ln, lane, qa);
-        total = rows_eval<PASS, PROJ, true, 7, 1>(p, L, planes, alpha, lane, qb, total, payload);
+        EV_ROW(7, qb)
         rows_load<PASS, 1, 1>(p, Ln, lane, qb);
         EV_STAMP(3)
+        if constexpr (PASS == 2) {
+            if (occ2) tile_finish_occ(p, L, cand_ring[wave], lane, cs, payload);
+        }
+#undef EV_ROW
         setup_write(p, lds[wave][(it + 2) % 3], rec2, mat2, lane); // also fences the mask writes of this tile
         if (lane < 2 * (int)kTileRows)
             p.tile_masks[(size_t)w0 * (2 * kTileRows) + lane] = reinterpret_cast<const uint32_t *>(L.draw_mask)[lane];
-        if (lane == 0) p.tile_counts[w0] = total;
+        if (lane == 0) p.tile_counts[w0] = cs.total;
         EV_STAMP(4)
         w0 = w1;
         w1 = w2;
