@@ -37,6 +37,7 @@ struct __attribute__((aligned(16))) WaveTileLds {
     float scale[kTileRecords];    // largest_scale_from_matrix(mat3(M))
     uint64_t draw_mask[kTileRows]; // should-draw ballots of the tile's rows (kept here, not in SGPRs)
     uint64_t vis_mask[kTileRows];  // pass 2 with meshlet occlusion: visible ballots, assembled by the candidate flushes
+    uint32_t prev[kTileRecords];   // pass 1: last frame's visibility word of each record
 };
 
 // The cull planes live in LDS (one copy per block, written once): a row reads
@@ -521,7 +522,7 @@ __device__ __forceinline__ float4 setup_load_mat(const MeshletCullParams &p, con
 }
 
 __device__ __forceinline__ void setup_write(const MeshletCullParams &p, WaveTileLds &L, const uint4 &rec,
-                                            const float4 &mc, int lane) {
+                                            const float4 &mc, int lane, uint32_t prev_word = 0u) {
     const uint32_t rid = lane >> 2, col = lane & 3;
     float o[4];
     mat4_mul_col(p.ci.view_matrix, mc.x, mc.y, mc.z, mc.w, o);
@@ -534,6 +535,7 @@ __device__ __forceinline__ void setup_write(const MeshletCullParams &p, WaveTile
     if (col == 0) {
         L.scale[rid] = sqrtf(gmax(d0, gmax(d1, d2)));
         L.rec[rid] = rec;
+        L.prev[rid] = prev_word;
     }
     if (lane < (int)kTileRows) L.draw_mask[lane] = 0ull, L.vis_mask[lane] = 0ull; // the candidate flushes OR into them
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -838,6 +840,162 @@ __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_k
     }
 }
 
+// ---------------------------------------------------------------------------
+// Pass 1 (occlusion_pass == 1, :137): only meshlets that were visible last frame
+// are processed at all, and which those are is known from 4 bytes per record
+// before any meshlet is read.  So pass 1 is list-driven instead of streaming:
+// per wave tile the set bits of the 16 visibility words become a candidate list
+// in canonical (row, lane) order (LDS), and the tile is evaluated in chunks of
+// 64 candidates — gathered 32-B meshlet reads for the candidates only (dense
+// runs coalesce exactly like the streamed rows), full lanes in the evaluation.
+// At 10 % visibility that is ~40 % of the streamed bytes and one evaluation per
+// tile instead of eight.  Outputs (ballots, count, payload) and the scan + emit
+// that follow are those of the other passes.
+//
+// Pipeline of one wave: records 3 tiles ahead, matrices + visibility words 2
+// ahead, slab 1 ahead (as in meshlet_eval); the work items are (tile, chunk)
+// pairs through two register sets — while item k is evaluated the gathers of
+// item k+1 (next chunk, or chunk 0 of the next tile, whose list is built first)
+// are in flight.
+struct Pass1Item {
+    uint4 a, b;    // the candidate's Meshlet
+    uint32_t code; // row*64 + lane of the candidate, ~0u = none
+};
+
+__device__ __forceinline__ uint32_t pass1_load_prev(const MeshletCullParams &p, const uint4 &rec, int lane) {
+    const bool rw_vis = p.ci.meshlet_visibility_buffer != ORBIT_NONE;
+    const uint32_t *src = (rw_vis && rec.z != 0u && (lane & 3) == 0) ? p.meshlet_visibility + rec.w
+                                                                    : reinterpret_cast<const uint32_t *>(p.zero_page);
+    const uint32_t w = *src;
+    return rw_vis ? w : 0xFFFFFFFFu; // no meshlet visibility buffer: visible_in_buffer stays true (:128)
+}
+
+// Candidate list of a tile: lanes whose last-frame bit is set (:129-137), canonical order.
+__device__ __forceinline__ uint32_t pass1_build_list(const WaveTileLds &L, uint16_t *list, int lane) {
+    const uint32_t half = lane >> 5, ml = lane & 31;
+    uint32_t n = 0;
+#pragma unroll
+    for (int r = 0; r < (int)kTileRows; r++) {
+        const uint32_t rid = 2 * r + half;
+        const bool c = ml < L.rec[rid].z && ((L.prev[rid] >> ml) & 1u) != 0;
+        const uint64_t mask = __ballot(c);
+        if (c) list[n + lane_prefix(mask)] = (uint16_t)(r * 64 + lane);
+        n += (uint32_t)__popcll(mask);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return n;
+}
+
+__device__ __forceinline__ Pass1Item pass1_load(const MeshletCullParams &p, const WaveTileLds &L,
+                                                const uint16_t *list, uint32_t n, uint32_t chunk, int lane) {
+    Pass1Item it;
+    const uint32_t j = chunk * 64u + (uint32_t)lane;
+    const bool valid = j < n;
+    it.code = valid ? (uint32_t)list[j] : ~0u;
+    const uint32_t rid = (it.code >> 5) & 15u, ml = it.code & 31u;
+    // unconditional loads (exact vmcnt accounting): lanes without a candidate read the zero page
+    const uint4 *src = valid ? reinterpret_cast<const uint4 *>(p.meshlets + (L.rec[rid].y + ml))
+                             : reinterpret_cast<const uint4 *>(p.zero_page);
+    it.a = src[0];
+    it.b = src[1];
+    return it;
+}
+
+template <int PROJ>
+__device__ __forceinline__ uint32_t pass1_eval(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
+                                               const AlphaLds *A, int lane, const Pass1Item &it, uint32_t total,
+                                               uint4 *payload) {
+    const bool valid = it.code != ~0u;
+    const uint32_t rid = (it.code >> 5) & 15u, ml = it.code & 31u;
+    const uint32_t mi = it.b.w & 0xFFFFu; // zero page for lanes without a candidate: material 0, unused
+    const uint32_t abits = A ? (uint32_t)A->bits[mi & (kAlphaTable - 1u)] : alpha_bits(p.ci, p.materials[mi].alpha_mode);
+    bool should_draw = false;
+    if (valid) {
+        Sphere s;
+        const bool visible = eval_geometry<1, PROJ>(p, L, P, rid, it.a, it.b, true, s); // candidates have the bit set
+        should_draw = should_draw_of(visible, abits, true, false);
+    }
+    if (should_draw) atomicOr(reinterpret_cast<uint32_t *>(L.draw_mask) + rid, 1u << ml);
+    const uint64_t dm = __ballot(should_draw);
+    if (should_draw) {
+        const uint32_t rank = total + lane_prefix(dm);
+        if (rank < kPayloadCap) payload[rank] = make_payload(L.rec[rid].y + ml, rid, it.b);
+    }
+    return total + (uint32_t)__popcll(dm);
+}
+
+template <int PROJ>
+__global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_pass1_kernel(const MeshletCullParams p) {
+    __shared__ WaveTileLds lds[kEvWaves][3];
+    __shared__ PlaneLds planes;
+    __shared__ AlphaLds alpha_tab;
+    __shared__ uint16_t s_list[kEvWaves][2][kTileRows * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    planes_to_lds(p.ci, planes);
+    const AlphaLds *alpha = alpha_table_fill(p, alpha_tab) ? &alpha_tab : nullptr;
+    __syncthreads();
+    const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
+    const uint32_t ntiles = (nrec + kTileRecords - 1) / kTileRecords;
+    const uint32_t stride = gridDim.x * kEvWaves;
+    uint32_t w0 = blockIdx.x * kEvWaves + wave, w1 = w0 + stride, w2 = w1 + stride;
+    uint16_t *list_cur = s_list[wave][0], *list_next = s_list[wave][1];
+    uint4 rec2;
+    uint32_t n_cur;
+    Pass1Item cur;
+    {
+        const uint4 r0 = setup_load_rec(p, w0, w0 < ntiles, nrec, lane);
+        const uint4 r1 = setup_load_rec(p, w1, w1 < ntiles, nrec, lane);
+        rec2 = setup_load_rec(p, w2, w2 < ntiles, nrec, lane);
+        const float4 m0 = setup_load_mat(p, r0, lane);
+        const uint32_t p0 = pass1_load_prev(p, r0, lane);
+        const float4 m1 = setup_load_mat(p, r1, lane);
+        const uint32_t p1 = pass1_load_prev(p, r1, lane);
+        setup_write(p, lds[wave][0], r0, m0, lane, p0);
+        setup_write(p, lds[wave][1], r1, m1, lane, p1);
+        n_cur = pass1_build_list(lds[wave][0], list_cur, lane); // absent tile: zero records, empty list
+        cur = pass1_load(p, lds[wave][0], list_cur, n_cur, 0u, lane);
+    }
+    uint32_t it = 0;
+    while (w0 < ntiles) {
+        const uint32_t w3 = w2 + stride;
+        WaveTileLds &L = lds[wave][it % 3];
+        WaveTileLds &Ln = lds[wave][(it + 1) % 3]; // slab of an absent tile holds zero records
+        uint4 *payload = p.tile_payload + (size_t)w0 * kPayloadCap;
+        const float4 mat2 = setup_load_mat(p, rec2, lane);
+        const uint32_t prev2 = pass1_load_prev(p, rec2, lane);
+        const uint4 rec3 = setup_load_rec(p, w3, w3 < ntiles, nrec, lane);
+        uint32_t total = 0, n_next = 0;
+        for (uint32_t chunk = 0;; chunk++) { // at least one trip: an empty tile still hands over to the next one
+            const bool last = (chunk + 1u) * 64u >= n_cur;
+            Pass1Item next;
+            if (!last) {
+                next = pass1_load(p, L, list_cur, n_cur, chunk + 1u, lane);
+            } else {
+                n_next = pass1_build_list(Ln, list_next, lane);
+                next = pass1_load(p, Ln, list_next, n_next, 0u, lane);
+            }
+            total = pass1_eval<PROJ>(p, L, planes, alpha, lane, cur, total, payload);
+            cur = next;
+            if (last) break;
+        }
+        setup_write(p, lds[wave][(it + 2) % 3], rec2, mat2, lane, prev2); // also fences the mask atomics of this tile
+        if (lane < 2 * (int)kTileRows)
+            p.tile_masks[(size_t)w0 * (2 * kTileRows) + lane] = reinterpret_cast<const uint32_t *>(L.draw_mask)[lane];
+        if (lane == 0) p.tile_counts[w0] = total;
+        uint16_t *t = list_cur;
+        list_cur = list_next;
+        list_next = t;
+        n_cur = n_next;
+        w0 = w1;
+        w1 = w2;
+        w2 = w3;
+        rec2 = rec3;
+        it++;
+    }
+}
+
 // One wave per tile (grid stride): commands of the tile's survivors at the
 // scanned offset (:216-230).  Everything a tile needs is loaded ahead of its
 // turn, so no memory round trip is exposed between tiles: the 16 records, count
@@ -1008,15 +1166,27 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, int mode, h
     if (ev0) (void)hipEventRecord(ev0, s);
     const dim3 grid(blocks), block(kEvWaves * 64);
     const bool ortho = p.ci.projection_type == 1;
-    if (PASS == 0 && (p.debug_flags & 8u)) { // phase-stamped build (tools/phase.py), pass 0 only
+    if constexpr (PASS == 1) { // list-driven: only last frame's visible meshlets are read
         if (ortho)
-            hipLaunchKernelGGL((meshlet_eval_kernel<PASS == 0 ? 0 : PASS, 1, PASS == 0>), grid, block, 0, s, p);
+            hipLaunchKernelGGL((meshlet_pass1_kernel<1>), grid, block, 0, s, p);
         else
-            hipLaunchKernelGGL((meshlet_eval_kernel<PASS == 0 ? 0 : PASS, 0, PASS == 0>), grid, block, 0, s, p);
-    } else if (ortho) {
-        hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 1, false>), grid, block, 0, s, p);
+            hipLaunchKernelGGL((meshlet_pass1_kernel<0>), grid, block, 0, s, p);
+    } else if constexpr (PASS == 0) {
+        if (p.debug_flags & 8u) { // phase-stamped build (tools/phase.py)
+            if (ortho)
+                hipLaunchKernelGGL((meshlet_eval_kernel<0, 1, true>), grid, block, 0, s, p);
+            else
+                hipLaunchKernelGGL((meshlet_eval_kernel<0, 0, true>), grid, block, 0, s, p);
+        } else if (ortho) {
+            hipLaunchKernelGGL((meshlet_eval_kernel<0, 1, false>), grid, block, 0, s, p);
+        } else {
+            hipLaunchKernelGGL((meshlet_eval_kernel<0, 0, false>), grid, block, 0, s, p);
+        }
     } else {
-        hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 0, false>), grid, block, 0, s, p);
+        if (ortho)
+            hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 1, false>), grid, block, 0, s, p);
+        else
+            hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 0, false>), grid, block, 0, s, p);
     }
     if (ev1) (void)hipEventRecord(ev1, s);
     hipError_t e = hipGetLastError();

@@ -220,6 +220,16 @@ def test_two_pass_sequence(torch_mod, engine, oracle, size):
                              p11=cam.p11, z_near=cam.z_near)
     assert_same(run_gpu(torch, engine, gs, ci2e, evis, None, opyr, ps),
                 run_oracle(oracle, scene, ci2e, evis, None, opyr, ps))
+    # pass 1 is list-driven on the device: no meshlet visibility buffer (every meshlet of a drawn entity is a
+    # candidate), all bits set (dense lists, several chunks per wave tile), ~3 % set and none set
+    ci1e = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=1, meshlet_visibility=False)
+    assert_same(run_gpu(torch, engine, gs, ci1e, evis, None), run_oracle(oracle, scene, ci1e, evis, None))
+    ones_e = np.full_like(evis, 0xFFFFFFFF)
+    for m in (np.full_like(mvis, 0xFFFFFFFF), mvis & rng.integers(0, 2 ** 32, len(mvis), dtype=np.uint32)
+              & rng.integers(0, 2 ** 32, len(mvis), dtype=np.uint32)
+              & rng.integers(0, 2 ** 32, len(mvis), dtype=np.uint32)
+              & rng.integers(0, 2 ** 32, len(mvis), dtype=np.uint32), zm):
+        assert_same(run_gpu(torch, engine, gs, ci1, ones_e, m), run_oracle(oracle, scene, ci1, ones_e, m))
 
 
 @pytest.mark.parametrize("size", [(96, 54), (130, 40), (64, 64), (17, 9), (200, 3), (2560, 1080), (1, 1)])
