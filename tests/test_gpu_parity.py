@@ -405,6 +405,75 @@ def test_light_clusters(torch_mod, engine, oracle, W, H, n_lights, tile, zs, sam
     assert torch.equal(gl2[:4 + 4 * n_idx], gl[:4 + 4 * n_idx])
 
 
+# ----------------------------------------------------------------------------- graph capture
+def test_two_pass_frame_is_graph_capturable(torch_mod, engine, oracle):
+    """Every cull entry point only enqueues on the caller's stream (no allocation, no host sync), so a whole
+    two-pass frame can be captured into a HIP graph and replayed: same bytes as the eager run and as the oracle."""
+    torch = torch_mod
+    W, H = 320, 180
+    scene = sc.make_scene(31, 600, n_meshes=120, extent=(40.0, 10.0, 40.0))
+    cam = sc.default_camera()
+    rng = np.random.default_rng(31)
+    evis0 = rng.integers(0, 2 ** 32, (scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+    mvis0 = rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32)
+    depth = sc.make_depth(9, W, H, cam)
+    d = oracle.depth_pyramid_desc(W, H)
+    ps = (d.width, d.height)
+    ci1 = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=1)
+    ci2 = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=2, p00=cam.p00, p11=cam.p11, z_near=cam.z_near)
+    gs = GpuScene(torch, scene)
+    cap_d, cap_c = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
+    n = scene.entity_draw_count
+    gdepth = dev(torch, depth)
+    bufs = dict(disp=torch.zeros(L.DISPATCH_HEADER + 16 * cap_d, dtype=torch.uint8, device="cuda"),
+                draw1=torch.zeros(L.DRAW_HEADER + 28 * cap_c, dtype=torch.uint8, device="cuda"),
+                draw2=torch.zeros(L.DRAW_HEADER + 28 * cap_c, dtype=torch.uint8, device="cuda"),
+                evis=dev(torch, evis0), mvis=dev(torch, mvis0),
+                pyr=torch.zeros(d.total_texels, dtype=torch.float32, device="cuda"))
+
+    def frame():
+        b = bufs
+        engine.entity_cull(ci1, gs.draws, gs.mesh_infos, b["disp"], gs.entities, n, cap_d, visibility_buffer=b["evis"])
+        engine.meshlet_cull(ci1, b["disp"], gs.meshlets, b["draw1"], gs.entities, gs.materials, cap_d, cap_c,
+                            meshlet_visibility_buffer=b["mvis"])
+        engine.depth_reduce(gdepth, W, H, b["pyr"])
+        engine.entity_cull(ci2, gs.draws, gs.mesh_infos, b["disp"], gs.entities, n, cap_d, visibility_buffer=b["evis"],
+                           depth_pyramid=b["pyr"], depth_pyramid_size=ps)
+        engine.meshlet_cull(ci2, b["disp"], gs.meshlets, b["draw2"], gs.entities, gs.materials, cap_d, cap_c,
+                            meshlet_visibility_buffer=b["mvis"], depth_pyramid=b["pyr"], depth_pyramid_size=ps)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        frame()  # warm-up outside the capture (code objects loaded)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        frame()
+    # replay from the original bitsets
+    bufs["evis"].copy_(dev(torch, evis0))
+    bufs["mvis"].copy_(dev(torch, mvis0))
+    g.replay()
+    torch.cuda.synchronize()
+    engine.status()
+    opyr, _ = oracle.depth_reduce(depth, W, H)
+    o1 = run_oracle(oracle, scene, ci1, evis0, mvis0)
+    o2 = run_oracle(oracle, scene, ci2, evis0, mvis0, opyr, ps)
+    n1, c1 = L.draw_buffer_commands(host(bufs["draw1"]))
+    on1, oc1 = L.draw_buffer_commands(o1[1])
+    assert n1 == on1 and np.array_equal(c1.view(np.uint32), oc1.view(np.uint32))
+    n2, c2 = L.draw_buffer_commands(host(bufs["draw2"]))
+    on2, oc2 = L.draw_buffer_commands(o2[1])
+    assert n2 == on2 and np.array_equal(c2.view(np.uint32), oc2.view(np.uint32))
+    assert np.array_equal(host(bufs["evis"], np.uint32), o2[2]) and np.array_equal(host(bufs["mvis"], np.uint32), o2[3])
+    # a second replay continues from the bitsets the first one left (frame n+1), like an eager frame would
+    g.replay()
+    torch.cuda.synchronize()
+    o3 = run_oracle(oracle, scene, ci2, o2[2], o2[3], opyr, ps)
+    assert np.array_equal(host(bufs["evis"], np.uint32), o3[2]) and np.array_equal(host(bufs["mvis"], np.uint32), o3[3])
+
+
 # ----------------------------------------------------------------------------- sharded ranges
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_ranges_concatenate_to_the_canonical_list(torch_mod, engine, oracle, world):

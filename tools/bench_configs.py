@@ -52,6 +52,12 @@ def main():
                 eng.entity_cull(ci2, g[0], g[1], disp, g[2], s.entity_draw_count, cap_d, visibility_buffer=evis, depth_pyramid=pyr, depth_pyramid_size=ps)
                 eng.meshlet_cull(ci2, disp, g[3], draw, g[2], g[4], cap_d, cap_c, meshlet_visibility_buffer=mvis, depth_pyramid=pyr, depth_pyramid_size=ps, material_count=len(s.materials))
             out[name]["two_pass_frame_ms"] = timeit(frame)
+            # the same frame captured once into a HIP graph and replayed (12 launches, no per-call host work)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                frame()
+            out[name]["two_pass_frame_graph_ms"] = timeit(graph.replay)
             # config 4: + 10k point lights, 240x135x32 clusters
             nl = 10_000
             lights = sc.make_lights(4, nl); glights = dev(lights)
