@@ -53,7 +53,7 @@ enum {
     ORBIT_E_CAPACITY = -3, /* an append would overflow a caller buffer (latched on device) */
     ORBIT_E_HIP = -4,      /* a HIP runtime call failed */
     ORBIT_E_NO_DEVICE = -5,/* no gfx950 device / kernels not loadable: there is NO CPU fallback */
-    ORBIT_E_TIMEOUT = -6,  /* a bounded in-kernel wait gave up (latched on device) */
+    ORBIT_E_TIMEOUT = -6,  /* reserved: a bounded in-kernel wait gave up (no current kernel waits) */
     ORBIT_E_MISSING = -7,  /* a resource the CullInfo declares present was passed as NULL
                               (.unwrap() at draw_gen.rs:123-133) */
     ORBIT_E_COMM = -8      /* RCCL is not loadable in this process or one of its calls failed */

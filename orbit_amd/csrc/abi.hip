@@ -29,12 +29,10 @@ struct OrbitCtx {
     uint8_t *arena = nullptr;
     size_t arena_bytes = 0;
     OrbitMeshletDispatch *e_proto = nullptr;
-    uint32_t *e_block_sums = nullptr, *e_block_base = nullptr, *e_total = nullptr;
+    uint32_t *e_block_sums = nullptr, *e_total = nullptr;
     uint4 *m_tile_payload = nullptr;
-    uint32_t *m_tile_masks = nullptr, *m_chunk_sums = nullptr, *m_chunk_base = nullptr;
+    uint32_t *m_tile_masks = nullptr, *m_chunk_sums = nullptr;
     uint32_t *m_tile_counts = nullptr, *m_tile_base = nullptr, *m_total = nullptr;
-    uint64_t *m_scan_state = nullptr;
-    uint32_t *m_ticket = nullptr;
     uint32_t *c_chunk = nullptr; // compact: counts | bases | total
     float4 *a_view_lights = nullptr;
     uint32_t *a_light_flags = nullptr, *a_counts = nullptr, *a_block_sums = nullptr, *a_block_base = nullptr,
@@ -48,7 +46,6 @@ struct OrbitCtx {
     bool profiling = false;
     std::vector<hipEvent_t> prof_events; // pairs, in record order
     size_t prof_used = 0;
-    int meshlet_mode = 0; // 0 = eval/scan/emit (default), 1 = single-launch look-back (ORBIT_MESHLET_LOOKBACK=1)
     char err[512] = {0};
 };
 
@@ -184,13 +181,12 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t o_zero = carve(256);
     const size_t o_gc = carve(256);
     const size_t o_eproto = carve(ent * sizeof(OrbitMeshletDispatch));
-    const size_t o_ebs = carve(eblocks * 4), o_ebb = carve(eblocks * 4), o_et = carve(256);
+    const size_t o_ebs = carve(eblocks * 4), o_et = carve(256);
     const size_t o_mtc = carve(mtiles * 4), o_mtb = carve(mtiles * 4), o_mt = carve(256);
-    const size_t o_mss = carve(mtiles * 8), o_mtk = carve(256);
     const size_t o_mtm = carve(mtiles * 64);
     const size_t o_mtp = carve(mtiles * 128 * 16);
     const size_t mchunks = mtiles / kScanChunk + 2;
-    const size_t o_mcs = carve(mchunks * 4), o_mcb = carve(mchunks * 4);
+    const size_t o_mcs = carve(mchunks * 4);
     const size_t o_cc = carve((2 * cchunks + 64) * 4);
     const size_t o_avl = carve((size_t)caps.max_lights * 16 + 1024);
     const size_t o_alf = carve(((size_t)caps.max_lights / 32 + 64) * 4);
@@ -216,17 +212,13 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->zero_page = (void *)(a + o_zero);
     ctx->e_proto = (OrbitMeshletDispatch *)(a + o_eproto);
     ctx->e_block_sums = (uint32_t *)(a + o_ebs);
-    ctx->e_block_base = (uint32_t *)(a + o_ebb);
     ctx->e_total = (uint32_t *)(a + o_et);
     ctx->m_tile_counts = (uint32_t *)(a + o_mtc);
     ctx->m_tile_base = (uint32_t *)(a + o_mtb);
     ctx->m_total = (uint32_t *)(a + o_mt);
-    ctx->m_scan_state = (uint64_t *)(a + o_mss);
-    ctx->m_ticket = (uint32_t *)(a + o_mtk);
     ctx->m_tile_masks = (uint32_t *)(a + o_mtm);
     ctx->m_tile_payload = (uint4 *)(a + o_mtp);
     ctx->m_chunk_sums = (uint32_t *)(a + o_mcs);
-    ctx->m_chunk_base = (uint32_t *)(a + o_mcb);
     ctx->c_chunk = (uint32_t *)(a + o_cc);
     ctx->a_view_lights = (float4 *)(a + o_avl);
     ctx->a_light_flags = (uint32_t *)(a + o_alf);
@@ -235,16 +227,6 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->a_block_base = (uint32_t *)(a + o_abb);
     ctx->a_total = (uint32_t *)(a + o_at);
     ctx->g_counts = (uint32_t *)(a + o_gc);
-    // the epoch word of the single-pass scan starts at 1 (zeroed granules carry epoch 0 = invalid)
-    const uint32_t ctl0[3] = {0u, 0u, 1u};
-    e = hipMemcpy(ctx->m_ticket, ctl0, sizeof(ctl0), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        (void)hipFree(ctx->arena);
-        delete ctx;
-        return hip_fail(nullptr, e, "hipMemcpy(scan control words)");
-    }
-    const char *lookback = getenv("ORBIT_MESHLET_LOOKBACK");
-    ctx->meshlet_mode = (lookback && lookback[0] == '1') ? 1 : 0;
     const char *dbg = getenv("ORBIT_SP_DEBUG");
     ctx->debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u;
     snprintf(ctx->err, sizeof(ctx->err), "no error");
@@ -355,7 +337,6 @@ static int32_t entity_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const
     p.dispatch_capacity = b->dispatch_capacity;
     p.proto = ctx->e_proto;
     p.block_sums = ctx->e_block_sums;
-    p.block_base = ctx->e_block_base;
     p.total = ctx->e_total;
     p.status = ctx->status;
     hipError_t e = launch_entity_cull(p, entity_draw_count, (hipStream_t)stream);
@@ -409,10 +390,7 @@ int32_t orbit_meshlet_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbi
     p.tile_payload = ctx->m_tile_payload;
     p.tile_base = ctx->m_tile_base;
     p.chunk_sums = ctx->m_chunk_sums;
-    p.chunk_base = ctx->m_chunk_base;
     p.total = ctx->m_total;
-    p.scan_state = ctx->m_scan_state;
-    p.ticket = ctx->m_ticket;
     p.debug_flags = ctx->debug_flags;
     p.debug_cycles = ctx->debug_cycles;
     p.zero_page = ctx->zero_page;
@@ -430,7 +408,7 @@ int32_t orbit_meshlet_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbi
         ev1 = ctx->prof_events[ctx->prof_used + 1];
         ctx->prof_used += 2;
     }
-    hipError_t e = launch_meshlet_cull(p, ctx->num_cus, ctx->meshlet_mode, (hipStream_t)stream, ev0, ev1);
+    hipError_t e = launch_meshlet_cull(p, ctx->num_cus, (hipStream_t)stream, ev0, ev1);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_cull");
     return ORBIT_OK;
 }

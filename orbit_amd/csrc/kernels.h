@@ -27,8 +27,7 @@ struct EntityCullParams {
     uint32_t dispatch_capacity;
     // context scratch
     OrbitMeshletDispatch *proto; // one proto-record per entity-draw of the launch
-    uint32_t *block_sums;
-    uint32_t *block_base;
+    uint32_t *block_sums; // records per block of 256 entity-draws; the emit launch prefix-sums them itself
     uint32_t *total;
     int32_t *status;
 };
@@ -47,14 +46,11 @@ struct MeshletCullParams {
     uint32_t material_count; // 0 = unknown (gather alpha modes), else entries in `materials`
     // context scratch
     uint32_t *tile_counts;
-    uint4 *tile_payload;    // 128 x 16 B per wave tile: survivors' Meshlet bytes 16..31 in tile-local order
+    uint4 *tile_payload;   // 128 x 16 B per wave tile: survivors in tile-local order (make_payload, meshlet_cull.hip)
     uint32_t *tile_masks; // 16 words (8 x 64-bit should-draw ballots) per wave tile
     uint32_t *tile_base;   // chunk-local exclusive prefix of tile_counts
-    uint32_t *chunk_sums;  // per kScanChunk tiles
-    uint32_t *chunk_base;
+    uint32_t *chunk_sums;  // per kScanChunk tiles; the emit launch prefix-sums them itself (LDS)
     uint32_t *total;
-    uint64_t *scan_state; // single-pass mode: one {status,value} granule per wave tile
-    uint32_t *ticket;     // single-pass mode: {ticket, done, epoch}
     const void *zero_page; // 256 zero bytes of context scratch: target of inactive lanes' loads
     unsigned long long *debug_cycles; // ORBIT_SP_DEBUG & 8: per-phase s_memtime sums (8 slots)
     uint32_t debug_flags; // ORBIT_SP_DEBUG (perf triage only): 8 = per-phase cycle stamps (pass 0 only)
@@ -106,7 +102,7 @@ struct ClusterAssignParams {
 
 hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_count, hipStream_t s);
 // ev0/ev1 (optional): recorded on `s` immediately before / after the dominant kernel of the op
-hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, int mode, hipStream_t s,
+hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, hipStream_t s,
                                hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t launch_depth_reduce(const DepthReduceParams &p, hipStream_t s);
 hipError_t launch_cluster_mark(const ClusterMarkParams &p, hipStream_t s);

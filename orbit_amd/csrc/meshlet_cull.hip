@@ -18,8 +18,9 @@
 //   visibility = the two 32-bit halves of the wave64 ballot are the two records'
 //                visibility words (word = visibility_offset + lane/32, S = 32).
 //
-// Tile bases come from (mode 0, default) an eval launch + scan + emit launch, or
-// (mode 1, ORBIT_MESHLET_LOOKBACK=1) a single launch with a decoupled look-back.
+// Tile bases come from a prefix sum over per-tile survivor counts: eval launch
+// -> scan -> emit launch.  (A single-launch variant with a decoupled look-back
+// was measured slower on MI355X and removed: profiles/r01_notes.md.)
 #include "kernels.h"
 #include "scan.h"
 
@@ -89,7 +90,6 @@ struct RowRegs {
     uint4 a[NR], b[NR];
     uint32_t prev[NR];
 };
-using TileRegs = RowRegs<kTileRows>;
 
 // materials[i].alpha_mode (:124) is only ever used as (1 << alpha_mode) & flag
 // (:207, :210), so the per-block LDS table (filled when the caller states a
@@ -374,134 +374,8 @@ __device__ __forceinline__ void tile_finish_occ(const MeshletCullParams &p, Wave
     }
 }
 
-// Whole-tile forms (look-back kernel).
-template <int PASS>
-__device__ __forceinline__ void tile_load(const MeshletCullParams &p, const WaveTileLds &L, int lane, TileRegs &t) {
-    rows_load<PASS, 0, kTileRows>(p, L, lane, t);
-}
-template <int PASS, bool WRITE_VIS>
-__device__ __forceinline__ uint32_t tile_eval(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
-                                              const AlphaLds *A, int lane, const TileRegs &t) {
-    return rows_eval<PASS, -1, WRITE_VIS, 0, kTileRows>(p, L, P, A, lane, t, 0u, nullptr);
-}
-
-// Writes the tile's surviving commands at [base, base + total) (:216-230).
-// The survivor's command words (Meshlet bytes 16..31) are re-read here: they
-// were streamed a few microseconds ago and are L2/MALL resident, and not
-// carrying them across the look-back keeps the registers free for the next
-// tile's loads, which are already in flight at this point.
-__device__ __forceinline__ void tile_emit(const MeshletCullParams &p, const WaveTileLds &L, int lane,
-                                          uint32_t base) {
-    uint32_t *out = reinterpret_cast<uint32_t *>(p.draw_buffer + ORBIT_DRAW_HEADER);
-    const uint32_t half = lane >> 5, ml = lane & 31;
-    uint32_t row_base = base;
-#pragma unroll
-    for (int r = 0; r < (int)kTileRows; r++) {
-        const uint64_t mask = L.draw_mask[r]; // uniform address: broadcast read
-        if ((mask >> lane) & 1ull) {
-            const uint32_t slot = row_base + lane_prefix(mask);
-            if (slot < p.draw_capacity) {
-                const uint4 rec = L.rec[2 * r + half];
-                const uint4 b = reinterpret_cast<const uint4 *>(p.meshlets + (rec.y + ml))[1];
-                const uint32_t vertex_count = (b.w >> 16) & 0xFFu;
-                const uint32_t triangle_count = b.w >> 24;
-                uint32_t *c = out + (size_t)slot * 7u;
-                c[0] = triangle_count * 3u;       // cmd_index_count
-                c[1] = 1u;                        // cmd_instance_count
-                c[2] = (b.z + vertex_count) * 4u; // cmd_first_index
-                c[3] = b.z;                       // cmd_vertex_offset = int(data_offset)
-                c[4] = rec.x;                     // cmd_first_instance = entity_index
-                c[5] = b.y;                       // meshlet_vertex_offset
-                c[6] = rec.y + ml;                // meshlet_index
-            }
-        }
-        row_base += (uint32_t)__popcll(mask);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Mode 1: one launch, ordered compaction by a decoupled look-back scan over
-// per-wave-tile granules.
-//
-//  * tile order comes from a ticket per BLOCK iteration (kSpWaves adjacent wave
-//    tiles per ticket): one returning atomic on one address saturates near 88/us
-//    on MI355X (MI355X_MICROARCH.md "dequeue"), so a ticket per 512-meshlet wave
-//    tile (98 k at 50 M meshlets) would cost more than the whole kernel; a ticket
-//    per 8192 meshlets is ~20/us.  A wave that waits on tile j only ever waits
-//    on tickets drawn before its own, i.e. on running or finished blocks — no
-//    residency or dispatch-order assumption.
-//  * the waves of a block are autonomous: there is no block barrier in the loop.
-//    The ticket of block iteration i is drawn by whichever wave needs it first
-//    and handed to the other waves through a small LDS ring.
-//  * software pipeline per wave: the NEXT tile's records, matrices and all of
-//    its meshlet loads are issued BEFORE the current tile's look-back, so the
-//    look-back latency and the dependent-load chain of the next tile overlap.
-//  * granule = one naturally aligned 8-byte {epoch:30 | status:2 | value:32}
-//    written by ONE relaxed agent-scope store and polled with relaxed
-//    agent-scope loads (cdna_hip_programming.md Guideline 16, recipe R2: the
-//    data is the flag, no fence).  The epoch (a device word bumped by the last
-//    block to finish) makes stale granules of earlier launches read as INVALID,
-//    so no per-launch memset and the launch is graph-replay safe.
-//  * every spin is bounded; on give-up ORBIT_E_TIMEOUT is latched and the tile
-//    proceeds with base 0 (wrong output, flagged) instead of hanging the GPU.
-constexpr int kSpWaves = 16; // waves per block = wave tiles per ticket
-constexpr int kSpBlock = kSpWaves * 64;
-constexpr int kRing = 8; // ticket ring depth (power of two); the pipeline looks 3 tickets ahead
-constexpr uint32_t ST_INVALID = 0u, ST_AGG = 1u, ST_PREFIX = 2u;
-constexpr uint32_t kSpinLimit = 1u << 22;
-
-struct TicketRing {
-    uint32_t seq[kRing];  // 2*(it+1) = READY for block iteration it, 2*(it+1)-1 = being drawn
-    uint32_t val[kRing];  // the ticket (tile row)
-    uint32_t cons[kRing]; // waves that have read val for the current occupant
-    uint32_t exited;
-};
-
-#define LDS_LOAD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define LDS_STORE(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-
-// Ticket (tile row) of block iteration `it`, identical for every wave of the block.
-__device__ __forceinline__ uint32_t ring_get(TicketRing &R, uint32_t it, uint32_t *global_ticket, int lane,
-                                             int32_t *status) {
-    uint32_t row = 0;
-    if (lane == 0) {
-        const uint32_t slot = it & (kRing - 1);
-        const uint32_t ready = 2u * (it + 1u), drawing = ready - 1u;
-        const uint32_t prev_ready = it >= (uint32_t)kRing ? 2u * (it - kRing + 1u) : 0u;
-        uint32_t spins = 0;
-        for (;;) {
-            const uint32_t s = LDS_LOAD(&R.seq[slot]);
-            if (s == ready) break;
-            if (s == prev_ready && (it < (uint32_t)kRing || LDS_LOAD(&R.cons[slot]) == (uint32_t)kSpWaves)) {
-                // the slot's previous occupant has been read by every wave: claim the draw
-                if (atomicCAS(&R.seq[slot], prev_ready, drawing) == prev_ready) {
-                    LDS_STORE(&R.cons[slot], 0u);
-                    const uint32_t t = atomicAdd(global_ticket, 1u);
-                    LDS_STORE(&R.val[slot], t);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    LDS_STORE(&R.seq[slot], ready);
-                    break;
-                }
-            }
-            if (++spins > kSpinLimit) {
-                latch_status(status, ORBIT_E_TIMEOUT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        row = LDS_LOAD(&R.val[slot]);
-        atomicAdd(&R.cons[slot], 1u);
-    }
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)row);
-}
-
-__device__ __forceinline__ uint64_t make_granule(uint32_t epoch, uint32_t status, uint32_t value) {
-    return ((uint64_t)epoch << 34) | ((uint64_t)status << 32) | (uint64_t)value;
-}
-
-// Split tile setup (see the pipeline in the kernel): record load, model-column
-// load, (view x model) product + LDS slab write.
+// Tile setup, split so that each step's loads can be issued well before they are consumed (see the
+// pipelines of the kernels): record load, model-column load, (view x model) product + LDS slab write.
 __device__ __forceinline__ uint4 setup_load_rec(const MeshletCullParams &p, uint32_t tile, bool tile_valid,
                                                 uint32_t nrec, int lane) {
     const OrbitMeshletDispatch *recs =
@@ -543,177 +417,8 @@ __device__ __forceinline__ void setup_write(const MeshletCullParams &p, WaveTile
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// First look-back window: granules w-1-lane (lane 0 = nearest predecessor).
-__device__ __forceinline__ uint64_t look_back_issue(const MeshletCullParams &p, uint32_t w, int lane) {
-    int64_t idx = (int64_t)w - 1 - lane;
-    if (idx < 0) idx = 0; // out-of-range lanes are masked by the resolver; keep the load unconditional
-    return __hip_atomic_load(p.scan_state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Exclusive prefix of wave tile `w` (> 0) given the already loaded first window.
-__device__ __forceinline__ uint32_t look_back_resolve(const MeshletCullParams &p, uint32_t w, uint32_t epoch,
-                                                      int lane, uint64_t g) {
-    uint32_t exclusive = 0;
-    int64_t pos = (int64_t)w - 1;
-    uint32_t spins = 0;
-    for (;;) {
-        const int64_t idx = pos - lane;
-        const bool in_range = idx >= 0;
-        uint32_t st = (uint32_t)(g >> 32) & 3u;
-        if ((uint32_t)(g >> 34) != epoch) st = ST_INVALID;
-        if (!in_range) st = ST_PREFIX; // "before tile 0": an inclusive prefix of 0
-        const uint32_t val = in_range ? (uint32_t)g : 0u;
-        const uint64_t m_prefix = __ballot(st == ST_PREFIX);
-        const uint64_t m_invalid = __ballot(st == ST_INVALID);
-        const int first_prefix = m_prefix ? (int)__builtin_ctzll(m_prefix) : 64;
-        const int first_invalid = m_invalid ? (int)__builtin_ctzll(m_invalid) : 64;
-        if (first_invalid < first_prefix) { // a needed predecessor has not published yet: re-read the window
-            if (++spins > kSpinLimit) {
-                if (lane == 0) latch_status(p.status, ORBIT_E_TIMEOUT);
-                return 0u;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        } else {
-            const uint32_t contrib = (lane <= first_prefix) ? val : 0u;
-            exclusive += wave_reduce_add(contrib);
-            if (first_prefix < 64) return exclusive;
-            pos -= 64;
-        }
-        g = 0;
-        if (pos - lane >= 0)
-            g = __hip_atomic_load(p.scan_state + (pos - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// Software pipeline of one wave (tile i = current):
-//
-//     eval(i)                       needs data(i) in registers, slab(i)
-//     publish AGG(i)
-//     issue  look-back window(i)    |  small, latency-critical loads FIRST: vmcnt
-//     issue  matrix loads (i+2)     |  retires in order, so they can be waited
-//     issue  record load  (i+3)     |  for without waiting for the bulk loads
-//     issue  data loads   (i+1)     16 x 16 B per lane, in flight across everything below
-//     write  slab(i+2)              (view x model) products -> LDS
-//     resolve look-back(i), publish PREFIX(i), emit(i)
-//
-// so the dependent chain record -> matrix -> meshlets -> ... of a tile is spread
-// over three iterations and every load has a full iteration to land; the only
-// exposed latency per tile is the look-back round trip, with data(i+1) in flight.
-template <int PASS, bool PROF>
-__global__ __launch_bounds__(kSpBlock) void meshlet_cull_single_pass(const MeshletCullParams p) {
-    __shared__ WaveTileLds lds[kSpWaves][3];
-    __shared__ TicketRing ring;
-    __shared__ PlaneLds planes;
-    __shared__ AlphaLds alpha_tab;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < (int)(sizeof(TicketRing) / 4)) reinterpret_cast<uint32_t *>(&ring)[threadIdx.x] = 0u;
-    planes_to_lds(p.ci, planes);
-    const AlphaLds *alpha = alpha_table_fill(p, alpha_tab) ? &alpha_tab : nullptr;
-    __syncthreads();
-    const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
-    const uint32_t ntiles = (nrec + kTileRecords - 1) / kTileRecords;
-    const uint32_t nrows = (ntiles + kSpWaves - 1) / kSpWaves;
-    uint32_t *ctl = p.ticket; // {ticket, done, epoch}
-    const uint32_t epoch = ctl[2];
-
-    unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1;
-#define STAMP(k)                               \
-    if (PROF) {                                \
-        t1 = __builtin_amdgcn_s_memtime();     \
-        __builtin_amdgcn_s_waitcnt(0xC07F);    \
-        tc[k] += t1 - t0;                      \
-        t0 = t1;                               \
-    }
-
-    // ---- prologue: fill the pipeline (tiles 0, 1, 2 of this wave)
-    uint32_t it = 0;
-    uint32_t row0 = ring_get(ring, 0, &ctl[0], lane, p.status);
-    uint32_t row1 = ring_get(ring, 1, &ctl[0], lane, p.status);
-    uint32_t row2 = ring_get(ring, 2, &ctl[0], lane, p.status);
-    if (row0 == 0 && nrows == 0 && threadIdx.x == 0) *reinterpret_cast<uint32_t *>(p.draw_buffer) = 0u; // no records
-    uint32_t w0 = row0 * kSpWaves + wave, w1 = row1 * kSpWaves + wave, w2 = row2 * kSpWaves + wave;
-    bool v0 = row0 < nrows && w0 < ntiles, v1 = row1 < nrows && w1 < ntiles, v2 = row2 < nrows && w2 < ntiles;
-    TileRegs t;
-    uint4 rec2;
-    {
-        const uint4 r0 = setup_load_rec(p, w0, v0, nrec, lane);
-        const uint4 r1 = setup_load_rec(p, w1, v1, nrec, lane);
-        rec2 = setup_load_rec(p, w2, v2, nrec, lane);
-        const float4 m0 = setup_load_mat(p, r0, lane);
-        const float4 m1 = setup_load_mat(p, r1, lane);
-        setup_write(p, lds[wave][0], r0, m0, lane);
-        setup_write(p, lds[wave][1], r1, m1, lane);
-        tile_load<PASS>(p, lds[wave][0], lane, t);
-    }
-    if (PROF) {
-        t0 = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-    }
-    while (row0 < nrows) {
-        const uint32_t row3 = ring_get(ring, it + 3, &ctl[0], lane, p.status);
-        const uint32_t w3 = row3 * kSpWaves + wave;
-        const bool v3 = row3 < nrows && w3 < ntiles;
-        STAMP(0)
-        WaveTileLds &L = lds[wave][it % 3];
-        uint32_t total = 0;
-        if (v0) {
-            total = tile_eval<PASS, true>(p, L, planes, alpha, lane, t);
-            if (w0 > 0 && lane == 0)
-                __hip_atomic_store(p.scan_state + w0, make_granule(epoch, ST_AGG, total), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
-        STAMP(1)
-        // small latency-critical loads first, bulk loads after (vmcnt retires in order)
-        uint64_t g = 0;
-        g = look_back_issue(p, v0 ? w0 : 0u, lane);
-        const float4 mat2 = setup_load_mat(p, rec2, lane);
-        const uint4 rec3 = setup_load_rec(p, w3, v3, nrec, lane);
-        tile_load<PASS>(p, lds[wave][(it + 1) % 3], lane, t); // slab of an absent tile holds zero records
-        setup_write(p, lds[wave][(it + 2) % 3], rec2, mat2, lane);
-        STAMP(2)
-        if (v0) {
-            const uint32_t base = w0 > 0 ? look_back_resolve(p, w0, epoch, lane, g) : 0u;
-            const uint32_t inclusive = base + total;
-            if (lane == 0)
-                __hip_atomic_store(p.scan_state + w0, make_granule(epoch, ST_PREFIX, inclusive), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            STAMP(3)
-            tile_emit(p, L, lane, base);
-            if (w0 == ntiles - 1 && lane == 0) {
-                // `count` header: subsumes the fill_buffer(count = 0) of draw_gen.rs:411-417
-                *reinterpret_cast<uint32_t *>(p.draw_buffer) = min(inclusive, p.draw_capacity);
-                if (inclusive > p.draw_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
-            }
-        }
-        STAMP(4)
-        row0 = row1; row1 = row2; row2 = row3;
-        w0 = w1; w1 = w2; w2 = w3;
-        v0 = v1; v1 = v2; v2 = v3;
-        rec2 = rec3;
-        it++;
-    }
-    if (PROF && lane == 0) {
-        for (int k = 0; k < 5; k++) atomicAdd(p.debug_cycles + k, tc[k]);
-        atomicAdd(p.debug_cycles + 7, 1ull);
-    }
-    // self-cleaning control words: the last wave of the last block to leave resets
-    // the ticket and bumps the epoch, so the next launch (stream-ordered) starts clean.
-    if (lane == 0) {
-        if (atomicAdd(&ring.exited, 1u) == (uint32_t)kSpWaves - 1u) {
-            const uint32_t done = atomicAdd(&ctl[1], 1u);
-            if (done == gridDim.x - 1) {
-                uint32_t next = (epoch + 1u) & 0x3FFFFFFFu;
-                if (next == 0u) next = 1u; // epoch 0 is what a zero-initialised granule carries
-                __hip_atomic_store(&ctl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&ctl[2], next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
-// Mode 0 (default): eval launch -> scan -> emit launch.
+// eval launch -> scan -> emit launch.
 //
 //   meshlet_eval : streams records, matrices and meshlets through the software
 //                  pipeline below and writes, per wave tile, the 8 should-draw
@@ -1140,24 +845,8 @@ __global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullPara
 }
 
 template <int PASS>
-hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, int mode, hipStream_t s, hipEvent_t ev0,
-                       hipEvent_t ev1) {
+hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     const uint32_t max_tiles = (p.dispatch_capacity + kTileRecords - 1) / kTileRecords;
-    if (mode == 1) {
-        // persistent blocks, one 1024-thread block per CU (<= 128 VGPRs), looping over tickets
-        uint32_t blocks = num_cus;
-        const uint32_t need = (max_tiles + kSpWaves - 1) / kSpWaves;
-        if (blocks > need) blocks = need;
-        if (blocks == 0) blocks = 1;
-        if (ev0) (void)hipEventRecord(ev0, s);
-        if (PASS == 0 && (p.debug_flags & 8u))
-            hipLaunchKernelGGL((meshlet_cull_single_pass<PASS == 0 ? 0 : PASS, PASS == 0>), dim3(blocks),
-                               dim3(kSpBlock), 0, s, p);
-        else
-            hipLaunchKernelGGL((meshlet_cull_single_pass<PASS, false>), dim3(blocks), dim3(kSpBlock), 0, s, p);
-        if (ev1) (void)hipEventRecord(ev1, s);
-        return hipGetLastError();
-    }
     // eval -> scan -> emit
     uint32_t blocks = num_cus * (uint32_t)kEvWavesPerSimd; // 4-wave blocks: one wave per SIMD each
     const uint32_t need = (max_tiles + kEvWaves - 1) / kEvWaves;
@@ -1206,12 +895,12 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, int mode, h
 
 } // namespace
 
-hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, int mode, hipStream_t s, hipEvent_t ev0,
+hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, hipStream_t s, hipEvent_t ev0,
                                hipEvent_t ev1) {
     switch (p.ci.occlusion_pass) {
-    case 0: return launch_pass<0>(p, num_cus, mode, s, ev0, ev1);
-    case 1: return launch_pass<1>(p, num_cus, mode, s, ev0, ev1);
-    default: return launch_pass<2>(p, num_cus, mode, s, ev0, ev1);
+    case 0: return launch_pass<0>(p, num_cus, s, ev0, ev1);
+    case 1: return launch_pass<1>(p, num_cus, s, ev0, ev1);
+    default: return launch_pass<2>(p, num_cus, s, ev0, ev1);
     }
 }
 

@@ -1,4 +1,5 @@
-"""perf triage: per-phase wave-cycle shares of meshlet_cull_single_pass (ORBIT_SP_DEBUG=8)."""
+"""perf triage: per-phase wave-cycle shares of meshlet_eval_kernel (pass 0; ORBIT_SP_DEBUG=8 selects the
+phase-stamped build of the kernel, the stamps are read with the non-public orbit_debug_read_cycles)."""
 import ctypes as C, os, sys
 os.environ["ORBIT_SP_DEBUG"] = str(8 | int(os.environ.get("EXTRA_FLAGS", "0")))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,7 +24,7 @@ lib.orbit_debug_read_cycles(eng._ctx, out)
 n = 5
 for _ in range(n): eng.meshlet_cull(ci, disp, ml, draw, ent, mat, dc, cc)
 lib.orbit_debug_read_cycles(eng._ctx, out)
-names = ["wait for data", "rows_eval", "rows_load issue", "(unused)", "slab write+mask store"] if not os.environ.get("ORBIT_MESHLET_LOOKBACK") else ["ticket", "eval(+wait loads)", "prefetch issue", "look-back", "emit"]
+names = ["rows 0-1", "rows 2-3 + setup loads", "rows 4-5", "rows 6-7", "slab write + mask store"]
 tot = sum(out[k] for k in range(5)); waves = out[7]
 print("waves", waves // n, "cycles/wave", tot / waves)
 for k in range(5): print(f"  {names[k]:20s} {100.0 * out[k] / tot:5.1f}%   {out[k] / waves / 100.0:8.2f} us/wave (100 MHz ticks?)")
