@@ -405,6 +405,59 @@ def test_light_clusters(torch_mod, engine, oracle, W, H, n_lights, tile, zs, sam
     assert torch.equal(gl2[:4 + 4 * n_idx], gl[:4 + 4 * n_idx])
 
 
+# ----------------------------------------------------------------------------- randomized parameter sweep
+@pytest.mark.parametrize("seed", range(24))
+def test_randomized_parameters(torch_mod, engine, oracle, seed):
+    """Differential sweep over the CullInfo parameter space: every plane count 0..12 (the device shapes its plane
+    batches by the count), all passes, both projections, alpha masks, LOD windows, with and without meshlet
+    visibility; random planes through the scene so that plane culling actually splits it."""
+    torch = torch_mod
+    rng = np.random.default_rng(1000 + seed)
+    W, H = 256, 144
+    scene = sc.make_scene(100 + seed, int(rng.integers(40, 500)), n_meshes=int(rng.integers(5, 60)),
+                          lods=int(rng.integers(1, 4)), meshlets_per_mesh=(1, int(rng.integers(2, 90))),
+                          extent=(30.0, 10.0, 30.0))
+    cam = sc.default_camera(rot=(float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-3.1, 3.1))))
+    n_planes = seed % 13
+    base = list(cam.planes) if rng.random() < 0.5 else []
+    planes = []
+    for i in range(n_planes):
+        if i < len(base):
+            planes.append(base[i])
+        else:  # a random view-space plane close to the scene centre
+            nrm = rng.normal(size=3)
+            nrm /= np.linalg.norm(nrm)
+            planes.append(np.array([*nrm, rng.uniform(10.0, 45.0)], dtype=np.float32))
+    planes = np.asarray(planes, dtype=np.float32).reshape(-1, 4)
+    ortho = bool(rng.random() < 0.3)
+    occlusion_pass = int(rng.integers(0, 3))
+    mv = bool(rng.random() < 0.7)
+    kw = dict(occlusion_pass=occlusion_pass, projection_type=1 if ortho else 0,
+              alpha_mode_flag=int(rng.integers(0, 8)), noskip_alphamode=int(rng.integers(0, 8)), meshlet_visibility=mv,
+              lod_base=float(rng.uniform(2.0, 40.0)), lod_step=float(rng.uniform(1.3, 3.0)),
+              lod_target=tuple(float(v) for v in rng.uniform(-10, 10, 3)))
+    lo = int(rng.integers(0, 3))
+    kw["lod_range"] = (lo, int(rng.integers(lo + 1, 9)))
+    if occlusion_pass == 2:
+        kw.update(p00=2.0 / 40.0, p11=2.0 / 40.0, z_near=0.1, z_far=90.0) if ortho else kw.update(
+            p00=cam.p00, p11=cam.p11, z_near=cam.z_near)
+    ci = sc.make_cull_info(cam.view, planes, **kw)
+    evis = mvis = pyr = None
+    ps = (0, 0)
+    if occlusion_pass:
+        evis = rng.integers(0, 2 ** 32, (scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+        if mv:
+            mvis = rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32)
+            if rng.random() < 0.5:
+                mvis &= rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32)
+    if occlusion_pass == 2:
+        pyr, d = oracle.depth_reduce(sc.make_depth(seed, W, H, cam), W, H)
+        ps = (d.width, d.height)
+    gs = GpuScene(torch, scene)
+    assert_same(run_gpu(torch, engine, gs, ci, evis, mvis, pyr, ps), run_oracle(oracle, scene, ci, evis, mvis, pyr, ps))
+    engine.status()
+
+
 # ----------------------------------------------------------------------------- graph capture
 def test_two_pass_frame_is_graph_capturable(torch_mod, engine, oracle):
     """Every cull entry point only enqueues on the caller's stream (no allocation, no host sync), so a whole
