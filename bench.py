@@ -275,8 +275,9 @@ def load_traffic(entities, meshlets_per_entity):
 
 
 def run_cpu_baseline(args, spec, ci, draws, mesh, ent, meshlets, materials, disp, draw, L):
-    """Times the CPU oracle (scalar C port, 1 thread) on the first `cpu_sample_entities` of the
-    same scene and checks that the GPU's output prefix for those entities is bit-identical."""
+    """Times the CPU oracle on all host cores (oracle/orbit_oracle_mt.c: the scalar C port on contiguous shards,
+    one OpenMP thread each) on the first `cpu_sample_entities` of the same scene, and checks that the GPU's output
+    prefix for those entities is bit-identical.  A single-thread pass over 1/16 of the sample is reported beside."""
     from oracle import oracle
 
     oracle.build()
@@ -284,29 +285,38 @@ def run_cpu_baseline(args, spec, ci, draws, mesh, ent, meshlets, materials, disp
     es = min(args.cpu_sample_entities, spec.entities) // 256 * 256
     if es == 0:
         return None
+    threads = oracle.max_threads()
     h_draws, h_mesh, h_ent = draws.cpu().numpy(), mesh.cpu().numpy(), ent.cpu().numpy()
     h_meshlets = meshlets[:es * M * 32].cpu().numpy()
     h_mat = materials.cpu().numpy()
-    cap_d = es * spec.records_per_entity + 8
+    cap_d, cap_c = es * spec.records_per_entity + 8, es * M // 2 + 1024
     cpu_s, reps = 0.0, 0
-    while cpu_s < args.cpu_seconds and reps < 64:
+    while (cpu_s < args.cpu_seconds / 4 or reps < 3) and reps < 200:
         t0 = time.perf_counter()
-        odisp, _, _ = oracle.entity_cull(ci, h_draws, es, h_mesh, h_ent, cap_d)
-        n_rec = int(odisp[:4].view(np.uint32)[0])
-        odraw, _, dropped = oracle.meshlet_cull(ci, odisp, h_meshlets, es * M // 2 + 1024, h_ent, h_mat)
+        odisp, odraw, _, _, _ = oracle.cull_frame_mt(ci, h_draws, es, h_mesh, h_ent, h_meshlets, h_mat, cap_d, cap_c,
+                                                     threads)
         cpu_s += time.perf_counter() - t0
         reps += 1
+    n_rec = int(odisp[:4].view(np.uint32)[0])
     n_in = int(odisp[12:12 + 16 * n_rec].view(np.uint32).reshape(-1, 4)[:, 2].sum())
     n_draw = int(odraw[:4].view(np.uint32)[0])
     # canonical order => the GPU's full-scene output starts with exactly these records / commands
     g_disp = disp[12:12 + 16 * n_rec].cpu().numpy()
     g_draw = draw[4:4 + 28 * n_draw].cpu().numpy()
     same = bool(np.array_equal(g_disp, odisp[12:12 + 16 * n_rec]) and np.array_equal(g_draw, odraw[4:4 + 28 * n_draw]))
+    # one thread, 1/16 of the sample
+    e1 = max(256, es // 16 // 256 * 256)
+    t0 = time.perf_counter()
+    d1, _, _ = oracle.entity_cull(ci, h_draws, e1, h_mesh, h_ent, e1 * spec.records_per_entity + 8)
+    oracle.meshlet_cull(ci, d1, h_meshlets, e1 * M // 2 + 1024, h_ent, h_mat)
+    t1 = time.perf_counter() - t0
+    n1 = int(d1[12:12 + 16 * int(d1[:4].view(np.uint32)[0])].view(np.uint32).reshape(-1, 4)[:, 2].sum())
     return {
-        "value": n_in * reps / cpu_s, "unit": "meshlets/s", "cores": 1, "kind": "port",
+        "value": n_in * reps / cpu_s, "unit": "meshlets/s", "cores": threads, "kind": "port",
         "sample": f"first {es} of {spec.entities} entities ({n_in} meshlets into meshlet_cull) of the same scene, "
-                  f"{reps} passes of oracle/orbit_oracle.c entity_cull + meshlet_cull in {cpu_s:.2f} s, "
-                  f"1 thread of a {os.cpu_count()}-core host",
+                  f"{reps} frames of oracle/orbit_oracle.c entity_cull + meshlet_cull on {threads} OpenMP threads "
+                  f"(contiguous shards, oracle/orbit_oracle_mt.c) in {cpu_s:.2f} s wall on a {os.cpu_count()}-core host",
+        "single_thread_value": n1 / t1,
         "gpu_prefix_bit_identical": same,
     }
 

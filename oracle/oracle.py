@@ -16,8 +16,8 @@ _lib = None
 
 
 def build(force=False):
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(
-            os.path.join(_HERE, "orbit_oracle.c")):
+    srcs = [os.path.join(_HERE, f) for f in ("orbit_oracle.c", "orbit_oracle_mt.c")]
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
 
 
@@ -112,6 +112,35 @@ def meshlet_cull(cull_info, dispatch_buffer, meshlets, draw_capacity, entities, 
     dropped = lib().oracle_meshlet_cull(_p(ci), _p(db), _p(ml), _p(out), C.c_uint32(draw_capacity), _p(en), _p(mt),
                                         _p(vis), _p(pyr), C.c_uint32(pyramid_size[0]), C.c_uint32(pyramid_size[1]))
     return out, vis, int(dropped)
+
+
+def max_threads():
+    return int(lib().oracle_mt_max_threads())
+
+
+def cull_frame_mt(cull_info, entity_draw_buffer, entity_draw_count, mesh_infos, entities, meshlets, materials,
+                  dispatch_capacity, draw_capacity, threads, visibility=None, meshlet_visibility=None, pyramid=None,
+                  pyramid_size=(0, 0)):
+    """entity_cull + meshlet_cull of one frame on `threads` OpenMP threads (orbit_oracle_mt.c: the sequential oracle
+    on contiguous shards, concatenated).  Returns (dispatch bytes, draw bytes, entity vis, meshlet vis, dropped[2])."""
+    ci = _bytes(cull_info)
+    assert ci.nbytes == 400
+    edb, mi, en = _bytes(entity_draw_buffer), _bytes(mesh_infos), _bytes(entities)
+    ml, mt = _bytes(meshlets), _bytes(materials)
+    disp = np.zeros(12 + 16 * dispatch_capacity, dtype=np.uint8)
+    draw = np.zeros(4 + 28 * draw_capacity, dtype=np.uint8)
+    ev = None if visibility is None else np.array(visibility, dtype=np.uint32, copy=True)
+    mv = None if meshlet_visibility is None else np.array(meshlet_visibility, dtype=np.uint32, copy=True)
+    pyr = None if pyramid is None else np.ascontiguousarray(pyramid, dtype=np.float32)
+    dropped = (C.c_uint32 * 2)()
+    f = lib().oracle_cull_frame_mt
+    f.restype = C.c_int32
+    rc = f(_p(ci), _p(edb), C.c_uint32(entity_draw_count), _p(mi), _p(en), _p(ml), _p(mt), _p(disp),
+           C.c_uint32(dispatch_capacity), _p(draw), C.c_uint32(draw_capacity), _p(ev), _p(mv), _p(pyr),
+           C.c_uint32(pyramid_size[0]), C.c_uint32(pyramid_size[1]), C.c_int(threads), dropped)
+    if rc != 0:
+        raise MemoryError("oracle_cull_frame_mt: allocation failed")
+    return disp, draw, ev, mv, (int(dropped[0]), int(dropped[1]))
 
 
 def cluster_grid_info(near, far, z_slices):

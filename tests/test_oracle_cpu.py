@@ -214,6 +214,36 @@ def test_orthographic_shadow_cascade(oracle):
     _run_both(oracle, scene, ci2, evis, mvis, pyr, (d.width, d.height))
 
 
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_multithreaded_oracle_equals_sequential(oracle, threads):
+    """orbit_oracle_mt.c (cpu_baseline on all cores) composes the sequential oracle over shards: same bytes, all
+    passes, including capacity cuts."""
+    scene = sc.make_scene(77, 700, n_meshes=90, lods=2, meshlets_per_mesh=(1, 80))
+    cam = sc.default_camera(rot=(0.2, 0.5))
+    rng = np.random.default_rng(77)
+    evis = rng.integers(0, 2 ** 32, (scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+    mvis = rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32)
+    W, H = 160, 90
+    pyr, d = oracle.depth_reduce(sc.make_depth(7, W, H, cam), W, H)
+    ps = (d.width, d.height)
+    n = scene.entity_draw_count
+    args = (scene.entity_draw_buffer(), n, scene.mesh_infos, scene.entities)
+    for p in (0, 1, 2):
+        ci = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=p, p00=cam.p00, p11=cam.p11, z_near=cam.z_near,
+                               lod_base=8.0)
+        for cap_d, cap_c in ((scene.max_dispatches() + 8, scene.lod0_meshlets + 8), (40, 100)):
+            disp, ev, dd = oracle.entity_cull(ci, *args, cap_d, evis if p else None, pyr if p == 2 else None, ps)
+            draw, mv, dc = oracle.meshlet_cull(ci, disp, scene.meshlets, cap_c, scene.entities, scene.materials,
+                                               mvis if p else None, pyr if p == 2 else None, ps)
+            mdisp, mdraw, mev, mmv, dropped = oracle.cull_frame_mt(
+                ci, *args, scene.meshlets, scene.materials, cap_d, cap_c, threads, evis if p else None,
+                mvis if p else None, pyr if p == 2 else None, ps)
+            assert np.array_equal(mdisp, disp) and np.array_equal(mdraw, draw), (p, cap_d)
+            assert dropped == (dd, dc)
+            if p:
+                assert np.array_equal(mev, ev) and np.array_equal(mmv, mv)
+
+
 def test_config1_sphere_frustum(oracle):
     """BASELINE.json configs[0]: 8k spheres, frustum only (plumbing, CPU)."""
     n = 8192
