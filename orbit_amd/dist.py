@@ -32,6 +32,29 @@ def shard_ranges(entity_draw_count, world):
     return out
 
 
+def warm_up(device, group=None):
+    """Creates the collective and the point-to-point channels of gather_visible (RCCL sets them up lazily on
+    first use, which costs far more than a frame): one count all-gather and a 4-byte exchange with every peer."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    mine = torch.full((1,), rank, dtype=torch.int64, device=device)
+    counts = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(counts, mine, group=group)
+    send = torch.full((4,), rank, dtype=torch.uint8, device=device)
+    recv = torch.zeros(world, 4, dtype=torch.uint8, device=device)
+    ops = []
+    for peer in range(world):
+        if peer != rank:
+            ops.append(dist.P2POp(dist.isend, send, peer, group))
+            ops.append(dist.P2POp(dist.irecv, recv[peer], peer, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    return [int(c) for c in counts.cpu().tolist()] == list(range(world))
+
+
 def gather_visible(local_draw_buffer, out_draw_buffer, group=None):
     """Rank-ordered all-gather of MeshletDrawCommandBuffers.
 

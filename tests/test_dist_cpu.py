@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 import scenes as sc
 from orbit_amd import layouts as L
-from orbit_amd.dist import gather_visible, shard_ranges
+from orbit_amd.dist import gather_visible, shard_ranges, warm_up
 
 
 def _free_port():
@@ -39,6 +39,7 @@ def _worker(rank, world, port, seed, n_entities, out_dir):
                                      scene.materials)
     local = torch.from_numpy(draw.copy())
     out = torch.zeros(L.DRAW_HEADER + 28 * (scene.lod0_meshlets + 8), dtype=torch.uint8)
+    assert warm_up(torch.device("cpu"))
     counts = gather_visible(local, out)
     assert counts[rank] == int(draw[:4].view(np.uint32)[0])
     np.save(os.path.join(out_dir, f"gathered_{rank}.npy"), out.numpy())
