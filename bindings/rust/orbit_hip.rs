@@ -60,6 +60,10 @@ extern "C" {
     pub fn orbit_cluster_assign(ctx: *mut OrbitCtx, info: *const c_void, unique: *const c_void, bounds: *const c_void,
                                 lights: *const c_void, light_index_buffer: *mut c_void, light_index_capacity: u32,
                                 cluster_offset_image: *mut u32, stream: *mut c_void) -> i32;
+    /// Mesh-shading path: per dispatch record the EmitMeshTasksEXT count + MeshTaskPayload (44 B) that the task
+    /// shaders (forward_depth_prepass.task, forward.task) compute; a task shader then only loads its record.
+    pub fn orbit_meshlet_task_cull(ctx: *mut OrbitCtx, cull_info: *const c_void, bufs: *const c_void,
+                                   task_records: *mut c_void, stream: *mut c_void) -> i32;
     /// compute_clusters (cluster.rs:368-397): the three stages in one call.
     pub fn orbit_compute_clusters(ctx: *mut OrbitCtx, push: *const c_void, info: *const c_void, depth: *const f32,
                                   lights: *const c_void, masks: *mut u32, bounds: *mut c_void, unique: *mut c_void,

@@ -186,6 +186,21 @@ typedef struct OrbitMeshletDrawCommand {
     uint32_t meshlet_index;
 } OrbitMeshletDrawCommand;
 ORBIT_STATIC_ASSERT(sizeof(OrbitMeshletDrawCommand) == 28, "MeshletDrawCommand is 28 B");
+
+/* Mesh-shading path: what a task-shader workgroup hands to its mesh shaders —
+ * MeshTaskPayload (types.glsl:196-200) and the EmitMeshTasksEXT count
+ * (forward_depth_prepass.task:255-257) — one per MeshletDispatch record. */
+typedef struct OrbitMeshTaskPayload {
+    uint32_t entity_index;
+    uint32_t meshlet_offset;
+    uint8_t meshlet_indices[32]; /* lanes of the record that are drawn, ascending; 0 past the count */
+} OrbitMeshTaskPayload;
+typedef struct OrbitMeshTaskRecord {
+    uint32_t task_mesh_count;
+    OrbitMeshTaskPayload payload;
+} OrbitMeshTaskRecord;
+ORBIT_STATIC_ASSERT(sizeof(OrbitMeshTaskPayload) == 40, "MeshTaskPayload is 40 B");
+ORBIT_STATIC_ASSERT(sizeof(OrbitMeshTaskRecord) == 44, "task record is 44 B");
 /* MeshletDrawCommandBuffer (types.glsl:191-194): u32 count @0, draws[] @4. */
 #define ORBIT_DRAW_HEADER 4u
 
@@ -386,6 +401,21 @@ typedef struct OrbitMeshletCullBufs {
  * The `count = 0` clear (draw_gen.rs:411-417) is performed by the library. */
 int32_t orbit_meshlet_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info,
                            const OrbitMeshletCullBufs *bufs, void *stream);
+
+/* Mesh-shading path.  When mesh shading is on, the renderer
+ * skips create_meshlet_draw_commands and culls meshlets in the task shader,
+ * one workgroup per MeshletDispatch record
+ * (shaders/forward/forward_depth_prepass.task:115-257, forward.task, fed by the
+ * dispatch buffer of create_meshlet_dispatch_command).  This entry point
+ * computes what those workgroups compute — per record the EmitMeshTasksEXT
+ * count and the MeshTaskPayload — into `task_records` (dispatch_capacity
+ * entries, dispatch order), so that a task shader only has to load its record.
+ * Same decision as orbit_meshlet_cull; as in the task shaders, lanes past a
+ * record's meshlet_count report `visible` in the pass-2 visibility words.
+ * bufs->draw_commands_buffer / draw_capacity are not used (may be NULL / 0). */
+int32_t orbit_meshlet_task_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info,
+                                const OrbitMeshletCullBufs *bufs,
+                                OrbitMeshTaskRecord *task_records, void *stream);
 
 /* ------------------------------------------------------------------------ */
 /* depth_reduce — replaces DepthPyramid::{new,resize,update}                 */

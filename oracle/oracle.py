@@ -114,6 +114,24 @@ def meshlet_cull(cull_info, dispatch_buffer, meshlets, draw_capacity, entities, 
     return out, vis, int(dropped)
 
 
+def meshlet_task_cull(cull_info, dispatch_buffer, meshlets, entities, materials, meshlet_visibility=None,
+                      pyramid=None, pyramid_size=(0, 0)):
+    """Task-shader path (forward_depth_prepass.task): returns (44-B task records as a structured array,
+    meshlet visibility words (copy))."""
+    from orbit_amd import layouts as L
+
+    ci = _bytes(cull_info)
+    assert ci.nbytes == 400
+    db, ml, en, mt = _bytes(dispatch_buffer), _bytes(meshlets), _bytes(entities), _bytes(materials)
+    nrec = int(db[:4].view("<u4")[0])
+    out = np.zeros(nrec, dtype=L.MESH_TASK_RECORD)
+    vis = None if meshlet_visibility is None else np.array(meshlet_visibility, dtype=np.uint32, copy=True)
+    pyr = None if pyramid is None else np.ascontiguousarray(pyramid, dtype=np.float32)
+    lib().oracle_meshlet_task_cull(_p(ci), _p(db), _p(ml), _p(en), _p(mt), _p(vis), _p(pyr),
+                                   C.c_uint32(pyramid_size[0]), C.c_uint32(pyramid_size[1]), _p(out))
+    return out, vis
+
+
 def max_threads():
     return int(lib().oracle_mt_max_threads())
 

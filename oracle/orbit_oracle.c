@@ -451,6 +451,79 @@ uint32_t oracle_meshlet_cull(const OrbitGpuCullInfo *ci, const uint8_t *dispatch
     return dropped;
 }
 
+/* ---- task-shader cull (mesh-shading path) ----------------------------------------- */
+
+/* shaders/forward/forward_depth_prepass.task:115-257 (== forward/forward.task:106-248): the same per-meshlet
+ * decision as meshlet_cull.comp, one workgroup of S lanes per MeshletDispatch record, but the survivors stay with
+ * their record — MeshTaskPayload{entity_index, meshlet_offset, meshlet_indices[]} (types.glsl:196-200) and
+ * EmitMeshTasksEXT(task_mesh_count, 1, 1) — instead of being appended to a global list.  One OrbitMeshTaskRecord per
+ * record, in dispatch order.  Differences from meshlet_cull.comp that are reproduced literally:
+ *   - lanes past meshlet_count do not return: their `visible` stays true (:124) and is written to the visibility
+ *     word in pass 2 (:232-254, canonical #else addressing word = offset + lane/32, bit = lane%32);
+ *   - payload slots are claimed with atomicAdd(task_mesh_count) (:226): canonical order = ascending lane;
+ *     slots past the count are never written by the shader: canonical value 0. */
+void oracle_meshlet_task_cull(const OrbitGpuCullInfo *ci, const uint8_t *dispatch_buffer, const OrbitMeshlet *meshlets,
+                              const OrbitEntityData *entities, const OrbitMaterialData *materials,
+                              uint32_t *meshlet_visibility, const float *pyr, uint32_t pw, uint32_t ph,
+                              OrbitMeshTaskRecord *records) {
+    uint32_t nrec = rd32(dispatch_buffer);
+    const OrbitMeshletDispatch *recs = (const OrbitMeshletDispatch *)(dispatch_buffer + ORBIT_DISPATCH_HEADER);
+    int meshlet_occ = ci->meshlet_visibility_buffer != ORBIT_NONE;
+    for (uint32_t ri = 0; ri < nrec; ri++) {
+        OrbitMeshletDispatch rec = recs[ri];
+        OrbitMeshTaskRecord out;
+        memset(&out, 0, sizeof(out));
+        float mv[16];
+        mat4_mul(ci->view_matrix, entities[rec.entity_index].model_matrix, mv);
+        uint32_t ballot = 0, prev_word = 0;
+        int rw = meshlet_occ && (ci->occlusion_pass == 1 || ci->occlusion_pass == 2);
+        if (rw) prev_word = meshlet_visibility[rec.visibility_offset]; /* lane/32 == 0 for S=32 */
+        for (uint32_t lane = 0; lane < S_DISPATCH; lane++) {
+            int visible = 1; /* :124, also for lanes past the count */
+            if (lane < rec.meshlet_count) {
+                uint32_t meshlet_index = rec.meshlet_offset + lane;
+                const OrbitMeshlet *m = &meshlets[meshlet_index];
+                float sphere[4];
+                transform_sphere(mv, m->bounding_sphere, sphere);
+                float ax[4] = {(float)(int)m->cone_axis[0] / 127.0f, (float)(int)m->cone_axis[1] / 127.0f,
+                               (float)(int)m->cone_axis[2] / 127.0f, 0.0f};
+                float axis[4];
+                mat4_mul_vec4(mv, ax, axis);
+                float cutoff = (float)(int)m->cone_cutoff / 127.0f;
+                uint32_t alpha_mode = materials[m->material_index].alpha_mode;
+                int visible_in_buffer = 1;
+                if (rw) visible_in_buffer = (prev_word & (1u << (lane % 32))) != 0;
+                if (ci->occlusion_pass == 1) visible = visible_in_buffer;
+                if (visible) visible = plane_test(ci, sphere);
+                if (visible) {
+                    float cam[3] = {0.0f, 0.0f, 0.0f};
+                    if (ci->projection_type == 1) {
+                        cam[0] = sphere[0] - 0.0f;
+                        cam[1] = sphere[1] - 0.0f;
+                        cam[2] = sphere[2] - -1.0f;
+                    }
+                    if (ci->projection_type <= 1) {
+                        float d[3] = {sphere[0] - cam[0], sphere[1] - cam[1], sphere[2] - cam[2]};
+                        int cull = dot3(d, axis) >= cutoff * sqrtf(dot3(d, d)) + sphere[3];
+                        visible = !cull;
+                    }
+                }
+                if (meshlet_occ && ci->occlusion_pass == 2 && visible)
+                    visible = occlusion_test(ci, sphere, pyr, pw, ph);
+                int should_draw = visible && ((shl1(alpha_mode) & ci->alpha_mode_flag) != 0);
+                if ((ci->occlusion_pass == 2 && meshlet_occ) && !((shl1(alpha_mode) & ci->noskip_alphamode) != 0))
+                    should_draw = visible && !visible_in_buffer;
+                if (should_draw) out.payload.meshlet_indices[out.task_mesh_count++] = (uint8_t)lane; /* :225-228 */
+            }
+            ballot |= (uint32_t)visible << lane;
+        }
+        if (meshlet_occ && ci->occlusion_pass == 2) meshlet_visibility[rec.visibility_offset] = ballot;
+        out.payload.meshlet_offset = rec.meshlet_offset; /* :255-256 */
+        out.payload.entity_index = rec.entity_index;
+        records[ri] = out;
+    }
+}
+
 /* ---- light clusters ------------------------------------------------------------ */
 
 /* cluster_grid_info, src/passes/cluster.rs:63-72 with the canonical log2. */

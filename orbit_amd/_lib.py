@@ -65,6 +65,7 @@ SYMBOLS = {
     "orbit_entity_cull_range": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(EntityCullBufs), C.c_uint32,
                                             C.c_uint32, C.c_void_p]),
     "orbit_meshlet_cull": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(MeshletCullBufs), C.c_void_p]),
+    "orbit_meshlet_task_cull": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(MeshletCullBufs), C.c_void_p, C.c_void_p]),
     "orbit_depth_pyramid_desc": (C.c_int32, [C.c_uint32, C.c_uint32, C.POINTER(DepthPyramidDesc)]),
     "orbit_depth_pyramid_desc_from_mip0": (C.c_int32, [C.c_uint32, C.c_uint32, C.POINTER(DepthPyramidDesc)]),
     "orbit_depth_reduce": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),

@@ -355,14 +355,21 @@ int32_t orbit_entity_cull_range(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info
 }
 
 // ----------------------------------------------------------------- meshlet_cull
-int32_t orbit_meshlet_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b, void *stream) {
+} // extern "C"
+
+namespace {
+
+// orbit_meshlet_cull (task_records == nullptr: survivors -> MeshletDrawCommandBuffer) and
+// orbit_meshlet_task_cull (survivors stay with their record: one OrbitMeshTaskRecord each).
+int32_t meshlet_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
+                          OrbitMeshTaskRecord *task_records, bool task_path, void *stream) {
     if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
     int32_t rc = check_cull_info(ctx, ci);
     if (rc) return rc;
     if (!b) return fail(ctx, ORBIT_E_INVALID, "bufs is NULL");
-    if (!b->meshlet_dispatch_buffer || !b->meshlet_buffer || !b->draw_commands_buffer || !b->entity_buffer ||
-        !b->material_buffer)
+    if (!b->meshlet_dispatch_buffer || !b->meshlet_buffer || !b->entity_buffer || !b->material_buffer ||
+        (task_path ? (void *)task_records : b->draw_commands_buffer) == nullptr)
         return fail(ctx, ORBIT_E_MISSING, "meshlet_cull: a required buffer is NULL");
     const bool meshlet_occ = ci->meshlet_visibility_buffer != ORBIT_NONE;
     if (meshlet_occ && ci->occlusion_pass != 0 && !b->meshlet_visibility_buffer)
@@ -385,6 +392,7 @@ int32_t orbit_meshlet_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbi
     p.dispatch_capacity = b->dispatch_capacity;
     p.draw_capacity = b->draw_capacity;
     p.material_count = b->material_count;
+    p.task_records = task_records;
     p.tile_counts = ctx->m_tile_counts;
     p.tile_masks = ctx->m_tile_masks;
     p.tile_payload = ctx->m_tile_payload;
@@ -411,6 +419,19 @@ int32_t orbit_meshlet_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbi
     hipError_t e = launch_meshlet_cull(p, ctx->num_cus, (hipStream_t)stream, ev0, ev1);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_cull");
     return ORBIT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t orbit_meshlet_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b, void *stream) {
+    return meshlet_cull_impl(ctx, ci, b, nullptr, false, stream);
+}
+
+int32_t orbit_meshlet_task_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
+                                OrbitMeshTaskRecord *task_records, void *stream) {
+    return meshlet_cull_impl(ctx, ci, b, task_records, true, stream);
 }
 
 // ----------------------------------------------------------------- depth_reduce

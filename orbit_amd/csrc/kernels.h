@@ -44,6 +44,9 @@ struct MeshletCullParams {
     uint32_t dispatch_capacity;
     uint32_t draw_capacity;
     uint32_t material_count; // 0 = unknown (gather alpha modes), else entries in `materials`
+    // mesh-shading path (orbit_meshlet_task_cull): non-null = survivors stay with their record, one
+    // OrbitMeshTaskRecord per dispatch record, and no draw list is produced
+    OrbitMeshTaskRecord *task_records;
     // context scratch
     uint32_t *tile_counts;
     uint4 *tile_payload;   // 128 x 16 B per wave tile: survivors in tile-local order (make_payload, meshlet_cull.hip)

@@ -370,7 +370,10 @@ __device__ __forceinline__ void tile_finish_occ(const MeshletCullParams &p, Wave
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (lane < (int)kTileRecords) {
         const uint4 rec = L.rec[lane];
-        if (rec.z > 0) p.meshlet_visibility[rec.w] = reinterpret_cast<const uint32_t *>(L.vis_mask)[lane];
+        uint32_t word = reinterpret_cast<const uint32_t *>(L.vis_mask)[lane];
+        // task shaders keep `visible = true` in lanes past the count and write it (forward_depth_prepass.task:124,232)
+        if (p.task_records && rec.z < 32u) word |= ~0u << rec.z;
+        if (rec.z > 0) p.meshlet_visibility[rec.w] = word;
     }
 }
 
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_k
         const uint32_t w3 = w2 + stride;
         WaveTileLds &L = lds[wave][it % 3];
         WaveTileLds &Ln = lds[wave][(it + 1) % 3]; // slab of an absent tile holds zero records
-        uint4 *payload = p.tile_payload + (size_t)w0 * kPayloadCap;
+        uint4 *payload = p.task_records ? nullptr : p.tile_payload + (size_t)w0 * kPayloadCap;
         CandState cs; // cs.total = the tile's running survivor count
 #define EV_ROW(R, Q)                                                                                        \
     if constexpr (PASS == 2) {                                                                              \
@@ -624,7 +627,7 @@ __device__ __forceinline__ uint32_t pass1_eval(const MeshletCullParams &p, WaveT
     }
     if (should_draw) atomicOr(reinterpret_cast<uint32_t *>(L.draw_mask) + rid, 1u << ml);
     const uint64_t dm = __ballot(should_draw);
-    if (should_draw) {
+    if (payload && should_draw) {
         const uint32_t rank = total + lane_prefix(dm);
         if (rank < kPayloadCap) payload[rank] = make_payload(L.rec[rid].y + ml, rid, it.b);
     }
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_pass1_
         const uint32_t w3 = w2 + stride;
         WaveTileLds &L = lds[wave][it % 3];
         WaveTileLds &Ln = lds[wave][(it + 1) % 3]; // slab of an absent tile holds zero records
-        uint4 *payload = p.tile_payload + (size_t)w0 * kPayloadCap;
+        uint4 *payload = p.task_records ? nullptr : p.tile_payload + (size_t)w0 * kPayloadCap;
         const float4 mat2 = setup_load_mat(p, rec2, lane);
         const uint32_t prev2 = pass1_load_prev(p, rec2, lane);
         const uint4 rec3 = setup_load_rec(p, w3, w3 < ntiles, nrec, lane);
@@ -844,6 +847,31 @@ __global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullPara
     }
 }
 
+// Mesh-shading path: one OrbitMeshTaskRecord per dispatch record from the record's should-draw ballot
+// (forward_depth_prepass.task:225-228,255-257).  Thread = record; the drawn lanes in ascending order.
+__global__ __launch_bounds__(256) void task_records_kernel(const MeshletCullParams p) {
+    const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= nrec) return;
+    const uint4 rec = reinterpret_cast<const uint4 *>(p.dispatch_buffer + ORBIT_DISPATCH_HEADER)[r];
+    uint32_t m = p.tile_masks[r]; // word r = tile r/16, record r%16
+    const uint32_t count = (uint32_t)__popc(m);
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        if (m != 0u) {
+            w[k / 4] |= (uint32_t)__builtin_ctz(m) << (8 * (k % 4));
+            m &= m - 1u;
+        }
+    }
+    uint32_t *out = reinterpret_cast<uint32_t *>(p.task_records + r);
+    out[0] = count;
+    out[1] = rec.x; // entity_index
+    out[2] = rec.y; // meshlet_offset
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[3 + k] = w[k];
+}
+
 template <int PASS>
 hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     const uint32_t max_tiles = (p.dispatch_capacity + kTileRecords - 1) / kTileRecords;
@@ -880,6 +908,11 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t
     if (ev1) (void)hipEventRecord(ev1, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (p.task_records) { // mesh-shading path: expand the per-record ballots, no draw list
+        const uint32_t tblocks = (p.dispatch_capacity + 255u) / 256u;
+        if (tblocks) hipLaunchKernelGGL(task_records_kernel, dim3(tblocks), dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
     // first scan level only (chunk-local prefixes + chunk sums); meshlet_emit redoes the second in LDS
     e = launch_scan_chunks(p.tile_counts, p.tile_base, reinterpret_cast<const uint32_t *>(p.dispatch_buffer),
                            kTileRecords, max_tiles, p.chunk_sums, s);

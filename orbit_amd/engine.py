@@ -114,7 +114,7 @@ class Engine:
     # -- meshlet_cull: create_meshlet_draw_commands body (draw_gen.rs:382-435)
     def meshlet_cull(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, draw_commands_buffer, entity_buffer,
                      material_buffer, dispatch_capacity, draw_capacity, meshlet_visibility_buffer=None,
-                     depth_pyramid=None, depth_pyramid_size=(0, 0), material_count=0, stream=None):
+                     depth_pyramid=None, depth_pyramid_size=(0, 0), material_count=0, stream=None, task_records=None):
         ci = _host_bytes(cull_info, 400)
         b = _lib.MeshletCullBufs()
         b.meshlet_dispatch_buffer = _ptr(meshlet_dispatch_buffer)
@@ -128,8 +128,18 @@ class Engine:
         b.dispatch_capacity = dispatch_capacity
         b.draw_capacity = draw_capacity
         b.material_count = material_count
+        if task_records is not None:
+            _lib.check(self._lib.orbit_meshlet_task_cull(self._ctx, ci.ctypes.data_as(C.c_void_p), C.byref(b),
+                                                         _ptr(task_records), _stream(stream)), self._ctx)
+            return
         _lib.check(self._lib.orbit_meshlet_cull(self._ctx, ci.ctypes.data_as(C.c_void_p), C.byref(b),
                                                 _stream(stream)), self._ctx)
+
+    def meshlet_task_cull(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, task_records, entity_buffer,
+                          material_buffer, dispatch_capacity, **kw):
+        """Mesh-shading path (forward_depth_prepass.task): one 44-B OrbitMeshTaskRecord per dispatch record."""
+        self.meshlet_cull(cull_info, meshlet_dispatch_buffer, meshlet_buffer, None, entity_buffer, material_buffer,
+                          dispatch_capacity, 0, task_records=task_records, **kw)
 
     # -- DepthPyramid::update (draw_gen.rs:510-566)
     def depth_reduce(self, depth, screen_width, screen_height, pyramid, stream=None):

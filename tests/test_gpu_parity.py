@@ -405,6 +405,59 @@ def test_light_clusters(torch_mod, engine, oracle, W, H, n_lights, tile, zs, sam
     assert torch.equal(gl2[:4 + 4 * n_idx], gl[:4 + 4 * n_idx])
 
 
+# ----------------------------------------------------------------------------- mesh-shading (task) path
+@pytest.mark.parametrize("occlusion_pass,ortho", [(0, False), (1, False), (2, False), (2, True), (0, True)])
+def test_task_records(torch_mod, engine, oracle, occlusion_pass, ortho):
+    """orbit_meshlet_task_cull against the restated task shader (forward_depth_prepass.task:115-257)."""
+    torch = torch_mod
+    scene = sc.make_scene(61 + occlusion_pass, 900, n_meshes=140, lods=2, meshlets_per_mesh=(1, 70),
+                          extent=(20.0, 6.0, 20.0))
+    rng = np.random.default_rng(61)
+    evis = mvis = pyr = None
+    ps = (0, 0)
+    cam = sc.default_camera(rot=(0.4, 0.9))
+    if ortho:  # the shadow-cascade style view of test_orthographic
+        proj = sc.orthographic_rh(-25, 25, -25, 25, 0.1, 80.0)
+        view, planes = sc.translation(0.0, 0.0, -40.0), sc.frustum_planes(proj, 6)
+        kw = dict(projection_type=1)
+        if occlusion_pass == 2:
+            kw.update(p00=2.0 / 50.0, p11=2.0 / 50.0, z_near=0.1, z_far=80.0)
+    else:
+        view, planes = cam.view, cam.planes
+        kw = dict(p00=cam.p00, p11=cam.p11, z_near=cam.z_near) if occlusion_pass == 2 else {}
+    ci = sc.make_cull_info(view, planes, occlusion_pass=occlusion_pass, noskip_alphamode=L.ALPHA_MASKED, **kw)
+    if occlusion_pass:
+        evis = rng.integers(0, 2 ** 32, (scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+        mvis = rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32)
+    if occlusion_pass == 2:
+        W, H = 320, 180
+        pyr, d = oracle.depth_reduce(sc.make_depth(5, W, H, cam), W, H)
+        ps = (d.width, d.height)
+    gs = GpuScene(torch, scene)
+    cap_d = scene.max_dispatches() + 8
+    disp = torch.full((L.DISPATCH_HEADER + 16 * cap_d + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+    evis_d = None if evis is None else dev(torch, evis)
+    mvis_d = None if mvis is None else dev(torch, mvis)
+    pyr_d = None if pyr is None else dev(torch, pyr)
+    engine.entity_cull(ci, gs.draws, gs.mesh_infos, disp, gs.entities, scene.entity_draw_count, cap_d,
+                       visibility_buffer=evis_d, depth_pyramid=pyr_d, depth_pyramid_size=ps)
+    task = torch.full((44 * cap_d + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+    engine.meshlet_task_cull(ci, disp, gs.meshlets, task, gs.entities, gs.materials, cap_d,
+                             meshlet_visibility_buffer=mvis_d, depth_pyramid=pyr_d, depth_pyramid_size=ps)
+    torch.cuda.synchronize()
+    engine.status()
+    odisp, _, _ = oracle.entity_cull(ci, scene.entity_draw_buffer(), scene.entity_draw_count, scene.mesh_infos,
+                                     scene.entities, cap_d, evis, pyr, ps)
+    orecs, omv = oracle.meshlet_task_cull(ci, odisp, scene.meshlets, scene.entities, scene.materials, mvis, pyr, ps)
+    n = len(orecs)
+    assert n > 0 and int(orecs["task_mesh_count"].sum()) > 0
+    got = host(task)[:44 * n].view(L.MESH_TASK_RECORD)
+    assert np.array_equal(got.view(np.uint8), orecs.view(np.uint8)), "task records differ"
+    assert bool((host(task)[44 * n:] == 0xEE).all())  # nothing written past the records
+    if mvis is not None:
+        assert np.array_equal(host(mvis_d, np.uint32), omv), "meshlet visibility words differ"
+
+
 # ----------------------------------------------------------------------------- randomized parameter sweep
 @pytest.mark.parametrize("seed", range(24))
 def test_randomized_parameters(torch_mod, engine, oracle, seed):

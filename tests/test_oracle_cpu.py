@@ -244,6 +244,51 @@ def test_multithreaded_oracle_equals_sequential(oracle, threads):
                 assert np.array_equal(mev, ev) and np.array_equal(mmv, mv)
 
 
+def test_task_path_agrees_with_the_draw_command_path(oracle):
+    """forward_depth_prepass.task and meshlet_cull.comp take the same per-meshlet decision: the task records'
+    (record, lane) survivors are exactly the draw commands, and the pass-2 visibility words differ only in the
+    lanes past a record's meshlet_count (the task shader leaves `visible = true` there)."""
+    scene = sc.make_scene(91, 300, n_meshes=50, lods=2, meshlets_per_mesh=(1, 75))
+    cam = sc.default_camera(rot=(0.1, -0.7))
+    rng = np.random.default_rng(91)
+    evis = rng.integers(0, 2 ** 32, (scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+    mvis = rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32)
+    W, H = 160, 90
+    pyr, d = oracle.depth_reduce(sc.make_depth(3, W, H, cam), W, H)
+    ps = (d.width, d.height)
+    for p in (0, 1, 2):
+        ci = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=p, p00=cam.p00, p11=cam.p11, z_near=cam.z_near,
+                               lod_base=8.0)
+        disp, _, _ = oracle.entity_cull(ci, scene.entity_draw_buffer(), scene.entity_draw_count, scene.mesh_infos,
+                                        scene.entities, scene.max_dispatches() + 8, evis if p else None,
+                                        pyr if p == 2 else None, ps)
+        draw, mv, _ = oracle.meshlet_cull(ci, disp, scene.meshlets, scene.lod0_meshlets + 8, scene.entities,
+                                          scene.materials, mvis if p else None, pyr if p == 2 else None, ps)
+        recs_t, mv_t = oracle.meshlet_task_cull(ci, disp, scene.meshlets, scene.entities, scene.materials,
+                                                mvis if p else None, pyr if p == 2 else None, ps)
+        _, recs = L.dispatch_buffer_records(disp)
+        n, cmds = L.draw_buffer_commands(draw)
+        assert len(recs_t) == len(recs) and int(recs_t["task_mesh_count"].sum()) == n > 0
+        k = 0
+        for r, t in zip(recs, recs_t):
+            assert t["entity_index"] == r["entity_index"] and t["meshlet_offset"] == r["meshlet_offset"]
+            c = int(t["task_mesh_count"])
+            lanes = t["meshlet_indices"][:c].astype(np.int64)
+            assert np.all(np.diff(lanes) > 0) and np.all(lanes < r["meshlet_count"]) and not t["meshlet_indices"][c:].any()
+            assert np.array_equal(cmds["meshlet_index"][k:k + c], r["meshlet_offset"] + lanes)
+            assert np.all(cmds["cmd_first_instance"][k:k + c] == r["entity_index"])
+            k += c
+        assert k == n
+        if p == 2:
+            inactive = np.zeros_like(mv)
+            for r in recs:
+                if r["meshlet_count"] < 32:
+                    inactive[r["visibility_offset"]] = (0xFFFFFFFF << int(r["meshlet_count"])) & 0xFFFFFFFF
+            touched = np.zeros(len(mv), dtype=bool)
+            touched[recs["visibility_offset"]] = True
+            assert np.array_equal(mv_t[touched], (mv | inactive)[touched]) and np.array_equal(mv_t[~touched], mv[~touched])
+
+
 def test_config1_sphere_frustum(oracle):
     """BASELINE.json configs[0]: 8k spheres, frustum only (plumbing, CPU)."""
     n = 8192

@@ -82,6 +82,22 @@ out = {"workload": f"config5 two-pass: {E} entities x {M} meshlets, 1080p depth 
        "pass1_draws": n1, "pass2_draws": n2,
        "visible_entities": int(np.unpackbits(evis.cpu().numpy().view(np.uint8)).sum()),
        "visible_meshlets": int(np.unpackbits(mvis.cpu().numpy().view(np.uint8)).sum())}
+# mesh-shading path on the same scene: entity_cull + orbit_meshlet_task_cull, pass 0 (one 44-B record per dispatch
+# record instead of the compacted draw list: no scan, no emit)
+ci0 = sc.make_cull_info(cam.view, cam.planes)
+task = torch.zeros(44 * disp_cap, dtype=torch.uint8, device=dev)
+tt = []
+for f in range(12):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    eng.entity_cull(ci0, draws, mesh, disp, ent, E, disp_cap)
+    eng.meshlet_task_cull(ci0, disp, meshlets, task, ent, materials, disp_cap, material_count=spec.materials)
+    b.record()
+    torch.cuda.synchronize()
+    if f >= 2:
+        tt.append(a.elapsed_time(b))
+out["task_path_pass0_ms"] = float(np.median(tt))
+out["task_path_meshlets_per_s"] = E * M / (out["task_path_pass0_ms"] * 1e-3)
 if args.check:
     from oracle import oracle
     t0 = time.time()
@@ -97,6 +113,10 @@ if args.check:
     assert int(oc2[:4].view(np.uint32)[0]) == n2 and np.array_equal(h(draw2)[:4 + 28 * n2], oc2[:4 + 28 * n2]), "pass-2 draws differ"
     assert np.array_equal(h(evis).view(np.uint32), oe2), "entity visibility differs"
     assert np.array_equal(h(mvis).view(np.uint32), om2), "meshlet visibility differs"
+    od0, _, _ = oracle.entity_cull(ci0, edb, E, mi, en, disp_cap)
+    ot0, _ = oracle.meshlet_task_cull(ci0, od0, ml, en, mt)
+    assert np.array_equal(h(task)[:44 * len(ot0)], ot0.view(np.uint8).reshape(-1)), "task records differ"
+    out["task_survivors"] = int(ot0["task_mesh_count"].sum())
     out["oracle_bit_identical"] = True
     out["oracle_seconds"] = time.time() - t0
 print(json.dumps(out, indent=1))
