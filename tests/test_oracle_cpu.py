@@ -289,6 +289,67 @@ def test_task_path_agrees_with_the_draw_command_path(oracle):
             assert np.array_equal(mv_t[touched], (mv | inactive)[touched]) and np.array_equal(mv_t[~touched], mv[~touched])
 
 
+def test_cluster_lists_serve_the_fragment_shader_walk(oracle):
+    """End-to-end property of the three cluster stages, from the consumer's side (forward.frag:352-363): a fragment
+    at pixel (x, y) with depth d looks up tile = xy / tile_px, slice = linear_z_to_depth_slice(z_near / d), reads
+    (offset, count) from the RG32UI image and walks light_indices[offset : offset + count].  Every point light whose
+    sphere contains the fragment's view-space position must be in that walk (culling is conservative), lists are
+    ascending and duplicate-free, non-point lights are in every active cluster."""
+    W, H, tile, cz, far = 320, 180, 8, 32, 200.0
+    cam = sc.default_camera(aspect=W / H)
+    depth = sc.make_depth(8, W, H, cam, n_occluders=40)
+    cx, cy = -(-W // tile), -(-H // tile)
+    zs, zb = oracle.cluster_grid_info(cam.z_near, far, cz)
+    push = np.zeros((), dtype=L.MARK_ACTIVE_PUSH)
+    push["cluster_count"], push["tile_size_px"], push["screen_size"] = (cx, cy, cz), tile, (W, H)
+    push["z_near"], push["z_far"], push["z_scale"], push["z_bias"] = cam.z_near, far, zs, zb
+    push["depth_buffer_sample_count"] = 1
+    info = np.zeros((), dtype=L.CLUSTER_CULL_INFO)
+    info["world_to_view_matrix"] = sc.mat4_cols(cam.view)
+    inv_proj = np.linalg.inv(cam.proj.astype(np.float64))
+    info["screen_to_view_matrix"] = sc.mat4_cols(inv_proj.astype(np.float32))
+    info["cluster_count"], info["tile_size_px"], info["screen_size"] = (cx, cy, cz), tile, (W, H)
+    n_lights = 600
+    info["z_near"], info["z_far"], info["global_light_count"] = cam.z_near, far, n_lights
+    lights = sc.make_lights(8, n_lights, extent=(60.0, 15.0, 60.0), point_fraction=0.97)
+    masks, bounds = oracle.cluster_mark(push, depth)
+    total = cx * cy * cz
+    unique, _ = oracle.cluster_compact((cx, cy, cz), masks, total)
+    n_active = int(unique[12:16].view(np.uint32)[0])
+    lidx, img, dropped = oracle.cluster_assign(info, unique, bounds, lights, n_active * 256 + 8, total)
+    assert dropped == 0 and n_active > 100
+    indices = lidx[4:].view(np.uint32)
+    view = cam.view.astype(np.float64)
+    lpos = (view[:3, :3] @ lights["position"].astype(np.float64).T).T + view[:3, 3]
+    is_point = lights["light_type"] == L.LIGHT_TYPE_POINT
+    rng = np.random.default_rng(8)
+    checked = inside = 0
+    for _ in range(4000):
+        x, y = int(rng.integers(0, W)), int(rng.integers(0, H))
+        d = float(depth[y, x])
+        if d <= 0.0:
+            continue  # sky: no fragment
+        z = np.float32(cam.z_near) / np.float32(d)
+        sl = int(np.uint32(max(np.float32(oracle.log2f(float(z))) * np.float32(zs) + np.float32(zb), 0)))  # cluster_common.glsl:18-20
+        if sl >= cz:
+            continue  # beyond the cluster far plane: imageLoad outside the image returns 0 lights (and mark skips it)
+        assert (int(masks[(y // tile) * cx + x // tile]) >> sl) & 1  # the fragment's cluster is active
+        off, cnt = (int(v) for v in img[(x // tile) + (y // tile) * cx + sl * cx * cy])
+        walk = indices[off:off + min(cnt, 256)]
+        assert np.all(np.diff(walk.astype(np.int64)) > 0)  # ascending, no duplicates
+        assert set(np.flatnonzero(~is_point)).issubset(set(walk.tolist()))
+        # fragment position in view space: unproject the pixel centre at NDC z = depth (reverse-Z, infinite far)
+        ndc = np.array([(x + 0.5) / W * 2.0 - 1.0, 1.0 - (y + 0.5) / H * 2.0, d, 1.0])
+        pv = inv_proj @ ndc
+        pv = pv[:3] / pv[3]
+        dist = np.linalg.norm(lpos - pv, axis=1)
+        must = np.flatnonzero(is_point & (dist < 0.98 * lights["outer_radius"]))
+        inside += len(must)
+        assert set(must.tolist()).issubset(set(walk.tolist())), (x, y, sl, must, walk)
+        checked += 1
+    assert checked > 1500 and inside > 50  # the property was exercised, not vacuous
+
+
 def test_config1_sphere_frustum(oracle):
     """BASELINE.json configs[0]: 8k spheres, frustum only (plumbing, CPU)."""
     n = 8192
