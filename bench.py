@@ -39,6 +39,9 @@ def parse():
                     help="entities of the scene the CPU oracle is timed on (rank 0, N=1 only); 0 disables")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="minimum CPU time spent in the oracle baseline")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather (cull only)")
+    ap.add_argument("--exchange", choices=("visible", "commands"), default="visible",
+                    help="N>1 exchange format: 8-B visible items expanded on every GPU against the replicated "
+                         "meshlet buffer (default), or the 28-B commands themselves")
     ap.add_argument("--planes", type=int, default=5, help="cull planes used (5 = forward.rs:268; fewer only for triage)")
     return ap.parse_args()
 
@@ -87,14 +90,22 @@ def main():
     n_local_meshlets = n_local_entities * M
     rec_per_ent = spec.records_per_entity
 
+    do_gather = use_dist and backend == "nccl" and not args.no_gather
+    # Exchange format of the sharded engine.  "visible": every rank culls its entity range into 8-B
+    # {meshlet_index, entity_index} items, the lists are all-gathered and every GPU expands the result into the
+    # 28-B commands itself — which needs the meshlet buffer (static geometry, 1.6 GB of 288 GB) on every GPU; a
+    # rank still STREAMS only its own shard through meshlet_cull.  "commands": the 28-B lists travel as they are
+    # and a rank holds only its meshlet shard.
+    visible_exchange = do_gather and args.exchange == "visible"
     t0 = time.time()
     draws, mesh, ent, half = synth.gen_entity_tables(spec, dev)
-    meshlets = synth.gen_meshlets(spec, b, e, dev, half, survive_target=args.survive)
+    mb, me = (0, E) if visible_exchange else (b, e)
+    meshlets = synth.gen_meshlets(spec, mb, me, dev, half, survive_target=args.survive)
     materials = synth.gen_materials(spec, dev)
     torch.cuda.synchronize()
     gen_s = time.time() - t0
-    # shard passed under its global indices: base pointer = shard pointer - first_meshlet * 32
-    meshlets_base = meshlets.data_ptr() - b * M * 32
+    # buffer passed under global meshlet indices: base pointer = pointer - first_meshlet * 32
+    meshlets_base = meshlets.data_ptr() - mb * M * 32
 
     # camera outside the +-512 m box so that every entity passes the frustum: all E*M meshlets
     # reach meshlet_cull (the HBM-bound case the metric is about)
@@ -105,15 +116,17 @@ def main():
     draw_cap = n_local_meshlets // 2 + 1024
     eng = Engine(device_index, max_entities=n_local_entities + 256, max_dispatches=disp_cap, max_draws=draw_cap)
     disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device=dev)
-    do_gather = use_dist and backend == "nccl" and not args.no_gather
-    # N > 1: two draw buffers, so that the gather of step i-1 (RCCL, side stream) overlaps the cull of step i
-    draw_bufs = [torch.zeros(L.DRAW_HEADER + 28 * draw_cap, dtype=torch.uint8, device=dev)
+    # N > 1: two local list buffers, so that the exchange of step i-1 (RCCL, side stream) overlaps the cull of step i
+    hdr, item = (L.VISIBLE_HEADER, 8) if visible_exchange else (L.DRAW_HEADER, 28)
+    draw_bufs = [torch.zeros(hdr + item * draw_cap, dtype=torch.uint8, device=dev)
                  for _ in range(2 if do_gather else 1)]
     draw = draw_bufs[0]
-    gathered = None
+    gathered = gathered_vis = None
     side = None
     if do_gather:
         gathered = torch.zeros(L.DRAW_HEADER + 28 * (draw_cap * world), dtype=torch.uint8, device=dev)
+        if visible_exchange:
+            gathered_vis = torch.zeros(L.VISIBLE_HEADER + 8 * (draw_cap * world), dtype=torch.uint8, device=dev)
         side = torch.cuda.Stream(device=dev)
     cull_done = [torch.cuda.Event() for _ in draw_bufs]    # per draw buffer: its cull has been enqueued/finished
     gather_done = [torch.cuda.Event() for _ in draw_bufs]  # per draw buffer: its gather has read it
@@ -126,8 +139,13 @@ def main():
         # for the cull that filled this slot — not for the cull enqueued after it
         with torch.cuda.stream(side):
             side.wait_event(cull_done[slot])
-            odist.gather_visible(draw_bufs[slot], gathered)
-            gather_done[slot].record(side)
+            if visible_exchange:
+                odist.gather_visible(draw_bufs[slot], gathered_vis, header=L.VISIBLE_HEADER, stride=8)
+                gather_done[slot].record(side)  # the local list has been read
+                eng.expand_visible(gathered_vis, meshlets_base, gathered, draw_cap * world, stream=side)
+            else:
+                odist.gather_visible(draw_bufs[slot], gathered)
+                gather_done[slot].record(side)
 
     step_no = [0]
 
@@ -139,8 +157,12 @@ def main():
             ev[i][0].record()
         if do_gather:
             torch.cuda.current_stream().wait_event(gather_done[slot])  # slot last read by the gather two steps ago
-        eng.meshlet_cull(ci, disp, meshlets_base, draw_bufs[slot], ent, materials, disp_cap, draw_cap,
-                         material_count=spec.materials)
+        if visible_exchange:
+            eng.meshlet_cull_visible(ci, disp, meshlets_base, draw_bufs[slot], ent, materials, disp_cap, draw_cap,
+                                     material_count=spec.materials)
+        else:
+            eng.meshlet_cull(ci, disp, meshlets_base, draw_bufs[slot], ent, materials, disp_cap, draw_cap,
+                             material_count=spec.materials)
         if i is not None:
             ev[i][1].record()
         if do_gather:
@@ -192,7 +214,13 @@ def main():
         dist.all_gather(counts, torch.tensor([n_draw], dtype=torch.int64, device=dev))
         first = int(sum(int(c.item()) for c in counts[:rank]))
         mine = gathered[L.DRAW_HEADER + 28 * first:L.DRAW_HEADER + 28 * (first + n_draw)]
-        assert torch.equal(mine, draw[L.DRAW_HEADER:L.DRAW_HEADER + 28 * n_draw]), "gathered list != local list"
+        if visible_exchange:  # commands expanded from the gathered items: their (meshlet, entity) are this rank's items
+            cmds = mine.view(torch.int32).view(-1, 7)
+            items = draw[L.VISIBLE_HEADER:L.VISIBLE_HEADER + 8 * n_draw].view(torch.int32).view(-1, 2)
+            assert torch.equal(cmds[:, 6], items[:, 0]) and torch.equal(cmds[:, 4], items[:, 1]), \
+                "expanded list != local visible list"
+        else:
+            assert torch.equal(mine, draw[L.DRAW_HEADER:L.DRAW_HEADER + 28 * n_draw]), "gathered list != local list"
         assert int(gathered[:4].view(torch.int32).item()) == int(sum(int(c.item()) for c in counts))
 
     n_in = int(disp[L.DISPATCH_HEADER:L.DISPATCH_HEADER + 16 * n_rec].view(torch.int32).view(-1, 4)[:, 2].sum().item())
@@ -241,9 +269,12 @@ def main():
                 "workload": f"config5: {E} entities x {M} = {E * M} synthetic meshlets, entity_cull + meshlet_cull, "
                             f"frustum + normal cone (occlusion_pass 0), all entities in view, "
                             f"{100.0 * tot_draw / max(tot_in, 1):.1f}% survivors"
-                            + (", + RCCL gather of the visible list" if do_gather else ""),
+                            + ((", + RCCL all-gather of the visible list (8-B items, expanded to commands on every GPU)"
+                                if visible_exchange else ", + RCCL all-gather of the 28-B command lists")
+                               if do_gather else ""),
                 "entities": E, "meshlets": E * M, "meshlets_into_meshlet_cull": tot_in, "survivors": tot_draw,
                 "sharding": f"entity ranges over {world} rank(s)", "gather": bool(do_gather),
+                "exchange": (args.exchange if do_gather else None),
             },
             "roofline": {
                 "bound": "hbm", "kernel": "meshlet_eval_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -74,6 +74,14 @@ extern "C" {
     pub fn orbit_gather_visible(ctx: *mut OrbitCtx, nccl_comm: *mut c_void, rank: u32, world: u32,
                                 local_draw_buffer: *const c_void, out_draw_buffer: *mut c_void, out_capacity: u32,
                                 stream: *mut c_void) -> i32;
+    /// Compact exchange (8 B per survivor): cull into a visible list, all-gather, expand on every GPU.
+    pub fn orbit_meshlet_cull_visible(ctx: *mut OrbitCtx, cull_info: *const c_void, bufs: *const c_void,
+                                      visible_buffer: *mut c_void, visible_capacity: u32, stream: *mut c_void) -> i32;
+    pub fn orbit_gather_visible_meshlets(ctx: *mut OrbitCtx, nccl_comm: *mut c_void, rank: u32, world: u32,
+                                         local_visible_buffer: *const c_void, out_visible_buffer: *mut c_void,
+                                         out_capacity: u32, stream: *mut c_void) -> i32;
+    pub fn orbit_expand_visible(ctx: *mut OrbitCtx, visible_buffer: *const c_void, meshlet_buffer: *const c_void,
+                                draw_commands_buffer: *mut c_void, draw_capacity: u32, stream: *mut c_void) -> i32;
 }
 
 /// Turns a non-zero status into the panic the Vulkan path produced (assert!/unwrap, draw_gen.rs:247).

@@ -204,6 +204,17 @@ ORBIT_STATIC_ASSERT(sizeof(OrbitMeshTaskRecord) == 44, "task record is 44 B");
 /* MeshletDrawCommandBuffer (types.glsl:191-194): u32 count @0, draws[] @4. */
 #define ORBIT_DRAW_HEADER 4u
 
+/* Compact visible list of the sharded engine (no reference counterpart: the
+ * reference is single-GPU): what identifies a MeshletDrawCommand given the
+ * meshlet buffer — 8 B instead of 28 B on the xGMI links.  Buffer layout:
+ * {u32 count; u32 0} @0, items[] @8, in canonical command order. */
+typedef struct OrbitVisibleMeshlet {
+    uint32_t meshlet_index; /* MeshletDrawCommand::meshlet_index */
+    uint32_t entity_index;  /* MeshletDrawCommand::cmd_first_instance */
+} OrbitVisibleMeshlet;
+ORBIT_STATIC_ASSERT(sizeof(OrbitVisibleMeshlet) == 8, "visible item is 8 B");
+#define ORBIT_VISIBLE_HEADER 8u
+
 /* GpuCullInfo, draw_gen.rs:208-237 == CullInfo, types.glsl:202-228 */
 typedef struct OrbitGpuCullInfo {
     float view_matrix[16];         /* @0   */
@@ -526,6 +537,27 @@ void orbit_shard_range(uint32_t entity_draw_count, uint32_t rank, uint32_t world
 int32_t orbit_gather_visible(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint32_t world,
                              const void *local_draw_buffer, void *out_draw_buffer,
                              uint32_t out_capacity, void *stream);
+
+/* The same exchange with 8 B instead of 28 B per survivor on the links, for
+ * nodes whose GPUs all hold the meshlet buffer (static geometry, 32 B per
+ * meshlet): every rank culls its entity range into a compact visible list,
+ * the lists are all-gathered in rank order, and each GPU expands the result
+ * into the canonical MeshletDrawCommandBuffer itself.
+ *   orbit_meshlet_cull_visible  orbit_meshlet_cull, but `visible_buffer`
+ *       ({count, 0} @0, OrbitVisibleMeshlet[] @8, visible_capacity items)
+ *       replaces bufs->draw_commands_buffer / draw_capacity (not used);
+ *   orbit_gather_visible_meshlets  orbit_gather_visible on such buffers;
+ *   orbit_expand_visible  visible list -> MeshletDrawCommandBuffer, the
+ *       command words read from `meshlet_buffer` under global indices;
+ *       ORBIT_E_CAPACITY is latched if the list does not fit. */
+int32_t orbit_meshlet_cull_visible(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info,
+                                   const OrbitMeshletCullBufs *bufs, void *visible_buffer,
+                                   uint32_t visible_capacity, void *stream);
+int32_t orbit_gather_visible_meshlets(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint32_t world,
+                                      const void *local_visible_buffer, void *out_visible_buffer,
+                                      uint32_t out_capacity, void *stream);
+int32_t orbit_expand_visible(OrbitCtx *ctx, const void *visible_buffer, const void *meshlet_buffer,
+                             void *draw_commands_buffer, uint32_t draw_capacity, void *stream);
 
 #ifdef __cplusplus
 }

@@ -362,14 +362,15 @@ namespace {
 // orbit_meshlet_cull (task_records == nullptr: survivors -> MeshletDrawCommandBuffer) and
 // orbit_meshlet_task_cull (survivors stay with their record: one OrbitMeshTaskRecord each).
 int32_t meshlet_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
-                          OrbitMeshTaskRecord *task_records, bool task_path, void *stream) {
+                          OrbitMeshTaskRecord *task_records, bool task_path, void *stream,
+                          void *visible_buffer = nullptr, uint32_t visible_capacity = 0, bool visible_path = false) {
     if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
     int32_t rc = check_cull_info(ctx, ci);
     if (rc) return rc;
     if (!b) return fail(ctx, ORBIT_E_INVALID, "bufs is NULL");
     if (!b->meshlet_dispatch_buffer || !b->meshlet_buffer || !b->entity_buffer || !b->material_buffer ||
-        (task_path ? (void *)task_records : b->draw_commands_buffer) == nullptr)
+        (task_path ? (void *)task_records : visible_path ? visible_buffer : b->draw_commands_buffer) == nullptr)
         return fail(ctx, ORBIT_E_MISSING, "meshlet_cull: a required buffer is NULL");
     const bool meshlet_occ = ci->meshlet_visibility_buffer != ORBIT_NONE;
     if (meshlet_occ && ci->occlusion_pass != 0 && !b->meshlet_visibility_buffer)
@@ -384,13 +385,14 @@ int32_t meshlet_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbit
     p.ci = *ci;
     p.dispatch_buffer = (const uint8_t *)b->meshlet_dispatch_buffer;
     p.meshlets = (const OrbitMeshlet *)b->meshlet_buffer;
-    p.draw_buffer = (uint8_t *)b->draw_commands_buffer;
+    p.draw_buffer = (uint8_t *)(visible_path ? visible_buffer : b->draw_commands_buffer);
     p.entities = (const OrbitEntityData *)b->entity_buffer;
     p.materials = (const OrbitMaterialData *)b->material_buffer;
     p.meshlet_visibility = b->meshlet_visibility_buffer;
     p.pyr = make_pyramid_view(b->depth_pyramid, b->depth_pyramid_size);
     p.dispatch_capacity = b->dispatch_capacity;
-    p.draw_capacity = b->draw_capacity;
+    p.draw_capacity = visible_path ? visible_capacity : b->draw_capacity;
+    p.visible_list = visible_path ? 1u : 0u;
     p.material_count = b->material_count;
     p.task_records = task_records;
     p.tile_counts = ctx->m_tile_counts;
@@ -432,6 +434,24 @@ int32_t orbit_meshlet_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbi
 int32_t orbit_meshlet_task_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
                                 OrbitMeshTaskRecord *task_records, void *stream) {
     return meshlet_cull_impl(ctx, ci, b, task_records, true, stream);
+}
+
+int32_t orbit_meshlet_cull_visible(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
+                                   void *visible_buffer, uint32_t visible_capacity, void *stream) {
+    return meshlet_cull_impl(ctx, ci, b, nullptr, false, stream, visible_buffer, visible_capacity, true);
+}
+
+int32_t orbit_expand_visible(OrbitCtx *ctx, const void *visible_buffer, const void *meshlet_buffer,
+                             void *draw_commands_buffer, uint32_t draw_capacity, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!visible_buffer || !meshlet_buffer || !draw_commands_buffer)
+        return fail(ctx, ORBIT_E_MISSING, "expand_visible: NULL argument");
+    const hipError_t e = launch_visible_expand((const uint8_t *)visible_buffer, (const OrbitMeshlet *)meshlet_buffer,
+                                               (uint8_t *)draw_commands_buffer, draw_capacity, ctx->num_cus,
+                                               ctx->zero_page, ctx->status, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch visible_expand");
+    return ORBIT_OK;
 }
 
 // ----------------------------------------------------------------- depth_reduce
@@ -638,9 +658,13 @@ __global__ void write_u32_kernel(uint32_t *dst, uint32_t v) { *dst = v; }
 
 extern "C" {
 
-int32_t orbit_gather_visible(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint32_t world,
-                             const void *local_draw_buffer, void *out_draw_buffer, uint32_t out_capacity,
-                             void *stream) {
+} // extern "C"
+
+namespace {
+
+// Rank-ordered all-gather of {u32 count @0 | header_bytes | items of `stride` bytes} buffers.
+int32_t gather_lists(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint32_t world, const void *local_draw_buffer,
+                     void *out_draw_buffer, uint32_t out_capacity, void *stream, size_t header_bytes, size_t stride) {
     if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (!nccl_comm || !local_draw_buffer || !out_draw_buffer)
@@ -673,13 +697,17 @@ int32_t orbit_gather_visible(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint
                     (unsigned long long)prefix[world], out_capacity);
     // 2. header = total; 3. every list straight into out + prefix[rank]
     uint8_t *out = (uint8_t *)out_draw_buffer;
-    const uint8_t *mine = (const uint8_t *)local_draw_buffer + ORBIT_DRAW_HEADER;
+    const uint8_t *mine = (const uint8_t *)local_draw_buffer + header_bytes;
     hipLaunchKernelGGL(write_u32_kernel, dim3(1), dim3(1), 0, s, (uint32_t *)out, (uint32_t)prefix[world]);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(ctx, e, "launch write_u32");
-    const size_t stride = sizeof(OrbitMeshletDrawCommand);
+    if (header_bytes > 4) { // second header word of the visible list
+        hipLaunchKernelGGL(write_u32_kernel, dim3(1), dim3(1), 0, s, (uint32_t *)out + 1, 0u);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(ctx, e, "launch write_u32");
+    }
     if (counts[rank] > 0) {
-        e = hipMemcpyAsync(out + ORBIT_DRAW_HEADER + stride * prefix[rank], mine, stride * counts[rank],
+        e = hipMemcpyAsync(out + header_bytes + stride * prefix[rank], mine, stride * counts[rank],
                            hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) return hip_fail(ctx, e, "hipMemcpyAsync(own list)");
     }
@@ -690,7 +718,7 @@ int32_t orbit_gather_visible(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint
             if (counts[rank] > 0)
                 ORBIT_NCCL(nc.send(mine, stride * counts[rank], ncclUint8, (int)peer, comm, s), "ncclSend");
             if (counts[peer] > 0)
-                ORBIT_NCCL(nc.recv(out + ORBIT_DRAW_HEADER + stride * prefix[peer], stride * counts[peer], ncclUint8,
+                ORBIT_NCCL(nc.recv(out + header_bytes + stride * prefix[peer], stride * counts[peer], ncclUint8,
                                    (int)peer, comm, s),
                            "ncclRecv");
         }
@@ -698,6 +726,24 @@ int32_t orbit_gather_visible(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint
     }
 #undef ORBIT_NCCL
     return ORBIT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t orbit_gather_visible(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint32_t world,
+                             const void *local_draw_buffer, void *out_draw_buffer, uint32_t out_capacity,
+                             void *stream) {
+    return gather_lists(ctx, nccl_comm, rank, world, local_draw_buffer, out_draw_buffer, out_capacity, stream,
+                        ORBIT_DRAW_HEADER, sizeof(OrbitMeshletDrawCommand));
+}
+
+int32_t orbit_gather_visible_meshlets(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint32_t world,
+                                      const void *local_visible_buffer, void *out_visible_buffer,
+                                      uint32_t out_capacity, void *stream) {
+    return gather_lists(ctx, nccl_comm, rank, world, local_visible_buffer, out_visible_buffer, out_capacity, stream,
+                        ORBIT_VISIBLE_HEADER, sizeof(OrbitVisibleMeshlet));
 }
 
 } // extern "C"

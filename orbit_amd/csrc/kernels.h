@@ -47,6 +47,9 @@ struct MeshletCullParams {
     // mesh-shading path (orbit_meshlet_task_cull): non-null = survivors stay with their record, one
     // OrbitMeshTaskRecord per dispatch record, and no draw list is produced
     OrbitMeshTaskRecord *task_records;
+    // sharded engine (orbit_meshlet_cull_visible): draw_buffer is an OrbitVisibleMeshlet buffer (8-B header, 8 B per
+    // survivor) and draw_capacity its capacity
+    uint32_t visible_list;
     // context scratch
     uint32_t *tile_counts;
     uint4 *tile_payload;   // 128 x 16 B per wave tile: survivors in tile-local order (make_payload, meshlet_cull.hip)
@@ -107,6 +110,9 @@ hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_co
 // ev0/ev1 (optional): recorded on `s` immediately before / after the dominant kernel of the op
 hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, hipStream_t s,
                                hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, uint8_t *draw_buffer,
+                                 uint32_t draw_capacity, uint32_t num_cus, const void *zero_page, int32_t *status,
+                                 hipStream_t s);
 hipError_t launch_depth_reduce(const DepthReduceParams &p, hipStream_t s);
 hipError_t launch_cluster_mark(const ClusterMarkParams &p, hipStream_t s);
 hipError_t launch_cluster_compact(const ClusterCompactParams &p, hipStream_t s);

@@ -746,6 +746,10 @@ constexpr uint32_t kEmitChunkTable = 1024; // chunk bases kept in LDS (4 Mi tile
 // codes (ballot rank = list position, i.e. canonical order), Meshlet bytes
 // 16..31 gathered.  The second scan level (chunk sums -> chunk bases, at most a
 // few dozen values) is redone by every block in LDS instead of being a launch.
+// VISIBLE: instead of the 28-B commands the launch writes the compact visible list — 8 B per survivor
+// {meshlet_index, entity_index} after an 8-B {count, 0} header — which is what the sharded engine sends over
+// xGMI (visible_expand_kernel turns the gathered lists into commands on the receiving GPU).
+template <bool VISIBLE>
 __global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullParams p) {
     __shared__ uint16_t s_list[4][kTileRows * 64];
     __shared__ uint32_t s_cmd[4][64 * 7];
@@ -809,6 +813,12 @@ __global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullPara
                     pay = j0 == 0u ? cur_pay : emit_load_payload(p, tile, n, j0, lane);
                 }
                 const uint32_t ent = (uint32_t)__shfl((int)cur.rec.x, (int)(pay.w & 0xFFFFu), 64);
+                if (VISIBLE) {
+                    const uint32_t slot = base + j;
+                    if (j < n && slot < p.draw_capacity)
+                        reinterpret_cast<uint2 *>(p.draw_buffer + ORBIT_VISIBLE_HEADER)[slot] = make_uint2(pay.x, ent);
+                    continue;
+                }
                 const uint32_t vertex_count = (pay.w >> 16) & 0xFFu;
                 const uint32_t triangle_count = pay.w >> 24;
                 uint32_t *c = cmd + lane * 7;
@@ -843,7 +853,54 @@ __global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullPara
         // `count` header: subsumes the fill_buffer(count = 0) of draw_gen.rs:411-417
         *p.total = grand_total;
         *reinterpret_cast<uint32_t *>(p.draw_buffer) = min(grand_total, p.draw_capacity);
+        if (VISIBLE) reinterpret_cast<uint32_t *>(p.draw_buffer)[1] = 0u;
         if (grand_total > p.draw_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+    }
+}
+
+// Visible list -> MeshletDrawCommandBuffer (meshlet_cull.comp:216-230 for survivors that were culled on another GPU):
+// lane = survivor, Meshlet bytes 16..31 gathered from the (replicated) meshlet buffer, commands staged through LDS
+// so that every store covers 256 contiguous bytes.  Grid-stride over chunks of 64 survivors per wave.
+__global__ __launch_bounds__(256) void visible_expand_kernel(const uint8_t *visible, const OrbitMeshlet *meshlets,
+                                                             uint8_t *draw_buffer, uint32_t draw_capacity,
+                                                             const void *zero_page, int32_t *status) {
+    __shared__ uint32_t s_cmd[4][64 * 7];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *cmd = s_cmd[wave];
+    const uint32_t total = *reinterpret_cast<const uint32_t *>(visible);
+    const uint32_t n = min(total, draw_capacity);
+    const uint2 *items = reinterpret_cast<const uint2 *>(visible + ORBIT_VISIBLE_HEADER);
+    uint32_t *out = reinterpret_cast<uint32_t *>(draw_buffer + ORBIT_DRAW_HEADER);
+    const uint32_t stride = gridDim.x * 4u * 64u;
+    for (uint32_t first = (blockIdx.x * 4u + wave) * 64u; first < n; first += stride) {
+        const uint32_t i = first + (uint32_t)lane;
+        const bool valid = i < n;
+        const uint2 it = valid ? items[i] : make_uint2(0u, 0u);
+        const uint4 b = *(valid ? reinterpret_cast<const uint4 *>(meshlets + it.x) + 1
+                                : reinterpret_cast<const uint4 *>(zero_page));
+        uint32_t *c = cmd + lane * 7;
+        c[0] = (b.w >> 24) * 3u;                    // cmd_index_count = triangle_count * 3
+        c[1] = 1u;                                  // cmd_instance_count
+        c[2] = (b.z + ((b.w >> 16) & 0xFFu)) * 4u;  // cmd_first_index = (data_offset + vertex_count) * 4
+        c[3] = b.z;                                 // cmd_vertex_offset = int(data_offset)
+        c[4] = it.y;                                // cmd_first_instance = entity_index
+        c[5] = b.y;                                 // meshlet_vertex_offset
+        c[6] = it.x;                                // meshlet_index
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t words = min(n - first, 64u) * 7u;
+        uint32_t *dst = out + (size_t)first * 7u;
+#pragma unroll
+        for (uint32_t k = 0; k < 7; k++) {
+            const uint32_t w = k * 64u + (uint32_t)lane;
+            if (w < words) dst[w] = cmd[w];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *reinterpret_cast<uint32_t *>(draw_buffer) = n;
+        if (total > draw_capacity) latch_status(status, ORBIT_E_CAPACITY);
     }
 }
 
@@ -922,11 +979,26 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t
     const uint32_t eneed = (max_tiles + 3) / 4;
     if (eblocks > eneed) eblocks = eneed;
     if (eblocks == 0) eblocks = 1;
-    hipLaunchKernelGGL(meshlet_emit_kernel, dim3(eblocks), dim3(256), 0, s, p);
+    if (p.visible_list)
+        hipLaunchKernelGGL(meshlet_emit_kernel<true>, dim3(eblocks), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(meshlet_emit_kernel<false>, dim3(eblocks), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
 } // namespace
+
+hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, uint8_t *draw_buffer,
+                                 uint32_t draw_capacity, uint32_t num_cus, const void *zero_page, int32_t *status,
+                                 hipStream_t s) {
+    uint32_t blocks = num_cus * 8u;
+    const uint32_t need = (draw_capacity + 255u) / 256u;
+    if (blocks > need) blocks = need;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(visible_expand_kernel, dim3(blocks), dim3(256), 0, s, visible, meshlets, draw_buffer,
+                       draw_capacity, zero_page, status);
+    return hipGetLastError();
+}
 
 hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, hipStream_t s, hipEvent_t ev0,
                                hipEvent_t ev1) {

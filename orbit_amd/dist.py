@@ -55,8 +55,9 @@ def warm_up(device, group=None):
     return [int(c) for c in counts.cpu().tolist()] == list(range(world))
 
 
-def gather_visible(local_draw_buffer, out_draw_buffer, group=None):
-    """Rank-ordered all-gather of MeshletDrawCommandBuffers.
+def gather_visible(local_draw_buffer, out_draw_buffer, group=None, header=L.DRAW_HEADER, stride=28):
+    """Rank-ordered all-gather of MeshletDrawCommandBuffers (header 4, stride 28: the defaults) or of compact
+    visible lists (header=L.VISIBLE_HEADER, stride=8: orbit_meshlet_cull_visible / orbit_expand_visible).
 
     local_draw_buffer : uint8 tensor, this rank's buffer (u32 count @0, 28-B commands @4)
     out_draw_buffer   : uint8 tensor large enough for the concatenation; receives
@@ -71,14 +72,16 @@ def gather_visible(local_draw_buffer, out_draw_buffer, group=None):
     dist.all_gather_into_tensor(counts_t, mine, group=group)
     counts = [int(c) for c in counts_t.cpu().tolist()]
     total = sum(counts)
-    need = L.DRAW_HEADER + 28 * total
+    need = header + stride * total
     if out_draw_buffer.numel() < need:
         raise ValueError(f"gather_visible: output holds {out_draw_buffer.numel()} B, needs {need} B")
     prefix = [0]
     for c in counts:
         prefix.append(prefix[-1] + c)
     out_draw_buffer[:4].view(torch.int32)[0] = total
-    my_bytes = local_draw_buffer[L.DRAW_HEADER:L.DRAW_HEADER + 28 * counts[rank]]
+    if header > 4:
+        out_draw_buffer[4:header].zero_()
+    my_bytes = local_draw_buffer[header:header + stride * counts[rank]]
     ops = []
     for peer in range(world):
         if peer == rank:
@@ -86,9 +89,9 @@ def gather_visible(local_draw_buffer, out_draw_buffer, group=None):
         if counts[rank] > 0:
             ops.append(dist.P2POp(dist.isend, my_bytes, peer, group))
         if counts[peer] > 0:
-            dst = out_draw_buffer[L.DRAW_HEADER + 28 * prefix[peer]:L.DRAW_HEADER + 28 * prefix[peer + 1]]
+            dst = out_draw_buffer[header + stride * prefix[peer]:header + stride * prefix[peer + 1]]
             ops.append(dist.P2POp(dist.irecv, dst, peer, group))
-    out_draw_buffer[L.DRAW_HEADER + 28 * prefix[rank]:L.DRAW_HEADER + 28 * prefix[rank + 1]].copy_(my_bytes)
+    out_draw_buffer[header + stride * prefix[rank]:header + stride * prefix[rank + 1]].copy_(my_bytes)
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()

@@ -114,7 +114,8 @@ class Engine:
     # -- meshlet_cull: create_meshlet_draw_commands body (draw_gen.rs:382-435)
     def meshlet_cull(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, draw_commands_buffer, entity_buffer,
                      material_buffer, dispatch_capacity, draw_capacity, meshlet_visibility_buffer=None,
-                     depth_pyramid=None, depth_pyramid_size=(0, 0), material_count=0, stream=None, task_records=None):
+                     depth_pyramid=None, depth_pyramid_size=(0, 0), material_count=0, stream=None, task_records=None,
+                     visible_buffer=None):
         ci = _host_bytes(cull_info, 400)
         b = _lib.MeshletCullBufs()
         b.meshlet_dispatch_buffer = _ptr(meshlet_dispatch_buffer)
@@ -128,6 +129,11 @@ class Engine:
         b.dispatch_capacity = dispatch_capacity
         b.draw_capacity = draw_capacity
         b.material_count = material_count
+        if visible_buffer is not None:  # sharded engine: compact visible list, draw_capacity = its capacity
+            _lib.check(self._lib.orbit_meshlet_cull_visible(self._ctx, ci.ctypes.data_as(C.c_void_p), C.byref(b),
+                                                            _ptr(visible_buffer), draw_capacity, _stream(stream)),
+                       self._ctx)
+            return
         if task_records is not None:
             _lib.check(self._lib.orbit_meshlet_task_cull(self._ctx, ci.ctypes.data_as(C.c_void_p), C.byref(b),
                                                          _ptr(task_records), _stream(stream)), self._ctx)
@@ -145,6 +151,25 @@ class Engine:
     def depth_reduce(self, depth, screen_width, screen_height, pyramid, stream=None):
         _lib.check(self._lib.orbit_depth_reduce(self._ctx, _ptr(depth), screen_width, screen_height, _ptr(pyramid),
                                                 _stream(stream)), self._ctx)
+
+    def meshlet_cull_visible(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, visible_buffer, entity_buffer,
+                             material_buffer, dispatch_capacity, visible_capacity, **kw):
+        """orbit_meshlet_cull_visible: survivors as {count, 0} + 8-B {meshlet_index, entity_index} items."""
+        self.meshlet_cull(cull_info, meshlet_dispatch_buffer, meshlet_buffer, None, entity_buffer, material_buffer,
+                          dispatch_capacity, visible_capacity, visible_buffer=visible_buffer, **kw)
+
+    def expand_visible(self, visible_buffer, meshlet_buffer, draw_commands_buffer, draw_capacity, stream=None):
+        """orbit_expand_visible: visible list -> MeshletDrawCommandBuffer (command words from the meshlet buffer)."""
+        _lib.check(self._lib.orbit_expand_visible(self._ctx, _ptr(visible_buffer), _ptr(meshlet_buffer),
+                                                  _ptr(draw_commands_buffer), draw_capacity, _stream(stream)),
+                   self._ctx)
+
+    def gather_visible_meshlets(self, nccl_comm, rank, world, local_visible_buffer, out_visible_buffer, out_capacity,
+                                stream=None):
+        comm = nccl_comm if isinstance(nccl_comm, C.c_void_p) else C.c_void_p(int(nccl_comm))
+        _lib.check(self._lib.orbit_gather_visible_meshlets(self._ctx, comm, rank, world, _ptr(local_visible_buffer),
+                                                           _ptr(out_visible_buffer), out_capacity, _stream(stream)),
+                   self._ctx)
 
     def gather_visible(self, nccl_comm, rank, world, local_draw_buffer, out_draw_buffer, out_capacity, stream=None):
         """Rank-ordered all-gather of the visible lists over the caller's RCCL communicator

@@ -43,6 +43,16 @@ def _worker(rank, world, port, seed, n_entities, out_dir):
     counts = gather_visible(local, out)
     assert counts[rank] == int(draw[:4].view(np.uint32)[0])
     np.save(os.path.join(out_dir, f"gathered_{rank}.npy"), out.numpy())
+    # the compact exchange format (8 B per survivor after an 8-B header) through the same collective pattern
+    n, cmds = L.draw_buffer_commands(draw)
+    vis = np.zeros(L.VISIBLE_HEADER + 8 * n, dtype=np.uint8)
+    vis[:4].view(np.uint32)[0] = n
+    v = vis[8:].view(L.VISIBLE_MESHLET)
+    v["meshlet_index"], v["entity_index"] = cmds["meshlet_index"], cmds["cmd_first_instance"]
+    out_v = torch.full((L.VISIBLE_HEADER + 8 * (scene.lod0_meshlets + 8),), 0x77, dtype=torch.uint8)
+    counts_v = gather_visible(torch.from_numpy(vis), out_v, header=L.VISIBLE_HEADER, stride=8)
+    assert counts_v == counts
+    np.save(os.path.join(out_dir, f"gathered_vis_{rank}.npy"), out_v.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,3 +75,10 @@ def test_gather_visible_gloo_world2(tmp_path, oracle, n_entities):
         got = np.load(tmp_path / f"gathered_{r}.npy")
         assert int(got[:4].view(np.uint32)[0]) == n
         assert np.array_equal(got[:4 + 28 * n], ref[:4 + 28 * n]), f"rank {r}: gathered list != single-process list"
+        gv = np.load(tmp_path / f"gathered_vis_{r}.npy")
+        _, cmds = L.draw_buffer_commands(ref)
+        assert [int(v) for v in gv[:8].view(np.uint32)] == [n, 0]
+        items = gv[8:8 + 8 * n].view(L.VISIBLE_MESHLET)
+        assert np.array_equal(items["meshlet_index"], cmds["meshlet_index"])
+        assert np.array_equal(items["entity_index"], cmds["cmd_first_instance"])
+        assert np.all(gv[8 + 8 * n:] == 0x77)

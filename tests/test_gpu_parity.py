@@ -612,3 +612,61 @@ def test_sharded_ranges_concatenate_to_the_canonical_list(torch_mod, engine, ora
         parts.append(cmds)
     got = np.concatenate(parts)
     assert len(got) == on and np.array_equal(got.view(np.uint32), ocmds.view(np.uint32))
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_compact_visible_lists_expand_to_the_canonical_list(torch_mod, engine, oracle, world):
+    """The 8-B-per-survivor exchange format of the sharded engine: every rank's orbit_meshlet_cull_visible list is
+    {meshlet_index, entity_index} of its commands in canonical order; the rank-order concatenation, expanded against
+    the full meshlet buffer by orbit_expand_visible, is the single-GPU MeshletDrawCommandBuffer — also when the
+    capacities cut it."""
+    from orbit_amd._lib import E_CAPACITY, OrbitError
+    from orbit_amd.dist import shard_ranges
+
+    torch = torch_mod
+    scene = sc.make_scene(29, 800, meshlets_per_mesh=(1, 70), lods=2)
+    cam = sc.default_camera(rot=(0.2, 0.4))
+    ci = sc.make_cull_info(cam.view, cam.planes, alpha_mode_flag=L.ALPHA_ALL)
+    gs = GpuScene(torch, scene)
+    ref = run_oracle(oracle, scene, ci)
+    on, ocmds = L.draw_buffer_commands(ref[1])
+    assert on > 500
+    cap_d, cap_c = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
+    items = []
+    for b, e in shard_ranges(scene.entity_draw_count, world):
+        disp = torch.zeros(L.DISPATCH_HEADER + 16 * cap_d, dtype=torch.uint8, device="cuda")
+        vis = torch.full((L.VISIBLE_HEADER + 8 * cap_c + 64,), 0xCD, dtype=torch.uint8, device="cuda")
+        engine.entity_cull(ci, gs.draws, gs.mesh_infos, disp, gs.entities, e - b, cap_d, draw_first=b)
+        engine.meshlet_cull_visible(ci, disp, gs.meshlets, vis, gs.entities, gs.materials, cap_d, cap_c)
+        torch.cuda.synchronize()
+        hv = host(vis)
+        n, pad = (int(v) for v in hv[:8].view(np.uint32))
+        assert pad == 0 and bool((hv[8 + 8 * n:] == 0xCD).all())
+        items.append(hv[8:8 + 8 * n].view(L.VISIBLE_MESHLET))
+    got = np.concatenate(items)
+    assert len(got) == on
+    assert np.array_equal(got["meshlet_index"], ocmds["meshlet_index"])
+    assert np.array_equal(got["entity_index"], ocmds["cmd_first_instance"])
+    # the gathered list, expanded on "the receiving GPU"
+    allvis = np.zeros(L.VISIBLE_HEADER + 8 * on, dtype=np.uint8)
+    allvis[:4].view(np.uint32)[0] = on
+    allvis[8:] = got.view(np.uint8)
+    gvis = dev(torch, allvis)
+    draw = torch.full((L.DRAW_HEADER + 28 * cap_c + 64,), 0xCD, dtype=torch.uint8, device="cuda")
+    engine.expand_visible(gvis, gs.meshlets, draw, cap_c)
+    torch.cuda.synchronize()
+    engine.status()
+    n, cmds = L.draw_buffer_commands(host(draw))
+    assert n == on and np.array_equal(cmds.view(np.uint32), ocmds.view(np.uint32))
+    assert bool((host(draw)[4 + 28 * on:] == 0xCD).all())
+    # capacity cut in the expansion: prefix written, overflow latched
+    cut = on - 33
+    draw2 = torch.full((L.DRAW_HEADER + 28 * cut + 64,), 0xCD, dtype=torch.uint8, device="cuda")
+    engine.expand_visible(gvis, gs.meshlets, draw2, cut)
+    torch.cuda.synchronize()
+    n2, cmds2 = L.draw_buffer_commands(host(draw2))
+    assert n2 == cut and np.array_equal(cmds2.view(np.uint32), ocmds[:cut].view(np.uint32))
+    assert bool((host(draw2)[4 + 28 * cut:] == 0xCD).all())
+    with pytest.raises(OrbitError) as ei:
+        engine.status()
+    assert ei.value.code == E_CAPACITY
