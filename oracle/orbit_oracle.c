@@ -553,7 +553,10 @@ void oracle_cluster_mark(const OrbitMarkActivePush *pc, const float *depth, uint
                 bitmask |= shl1(slice);
                 if (slice < cz) {
                     size_t ci = tx + (size_t)ty * cx + (size_t)slice * cx * cy;
-                    bounds[ci].min_depth = umax(bounds[ci].min_depth, f2bits(1.0f - d));
+                    float inv = 1.0f - d;
+                    /* sign / payload of an arithmetic NaN is implementation-defined (x86 keeps the operand's,
+                     * gfx950 returns the negated one): canonical quiet NaN 0x7fc00000 */
+                    bounds[ci].min_depth = umax(bounds[ci].min_depth, inv != inv ? 0x7fc00000u : f2bits(inv));
                     bounds[ci].max_depth = umax(bounds[ci].max_depth, f2bits(d));
                 }
             }

@@ -13,11 +13,14 @@
 //             order), header written last (active_cluster_compaction.comp:33-43).
 //   assign  : lights are transformed to view space ONCE (the reference redoes
 //             world_to_view x position per cluster per light,
-//             light_culling.comp:111).  Lane = light: a wave takes 4 active
-//             clusters whose AABBs are wave-uniform (SGPRs), the sphere-vs-AABB
-//             hits of 64 lights are one ballot -> popcount in the count pass,
-//             ballot-ranked ordered writes in the write pass; ranges are
-//             allocated by prefix sum in compacted-list order.
+//             light_culling.comp:111).  A block owns 16 consecutive entries
+//             of the compacted list (neighbours along x) and first filters
+//             the lights against the UNION of their AABBs (thread = light,
+//             ordered LDS candidate list; sound because the sphere test is
+//             monotone in the box); then lane = candidate: a wave tests its 4
+//             clusters (AABBs in SGPRs), the hit ballots become popcounts in
+//             the count pass and ballot-ranked ordered writes in the write
+//             pass; ranges are allocated by prefix sum in compacted order.
 #include "kernels.h"
 #include "scan.h"
 
@@ -55,7 +58,9 @@ __global__ __launch_bounds__(256) void cluster_mark_kernel(const ClusterMarkPara
             const float linear_z = pc.z_near / d;                       // :28
             slice = f2u_sat(log2c(linear_z) * pc.z_scale + pc.z_bias); // cluster_common.glsl:18-20
             bit = shl1(slice);                                          // :30
-            bmin = __float_as_uint(1.0f - d);                           // :33
+            const float inv = 1.0f - d;                                 // :33
+            // the sign / payload of a NaN produced by arithmetic is implementation-defined: canonical quiet NaN
+            bmin = inv != inv ? 0x7fc00000u : __float_as_uint(inv);
             bmax = __float_as_uint(d);                                  // :34
         }
         const uint32_t chunk_mask = wave_reduce_or(bit);
@@ -212,20 +217,30 @@ __device__ __forceinline__ bool sphere_hits(const Aabb3 &a, const float4 l) {
     return sq <= l.w;
 }
 
-constexpr uint32_t kLightTile = 1024;  // lights staged in LDS per step (16 KB)
+constexpr uint32_t kLightTile = 4096;  // lights filtered per step; their candidates (indices) live in LDS (16 KB)
 constexpr int kClustersPerWave = 4;    // cluster AABBs held in scalar registers per wave
 constexpr int kAssignWaves = 4;
 constexpr int kClustersPerBlock = kClustersPerWave * kAssignWaves;
+constexpr uint32_t kNotPoint = 1u << 31; // candidate index flag: not a point light -> in every cluster (:116-118)
 
-// Lane = light.  A wave owns 4 active clusters whose AABBs sit in SGPRs; every step it reads 64
-// view-space lights from the LDS tile (one conflict-free ds_read_b128 per lane), tests them against
-// the 4 boxes, and turns the hit ballots into counts (WRITE = false, light_culling.comp:128-135) or
-// into ascending index writes at the scanned offset (WRITE = true, :138-147).  The reference runs
-// one thread per cluster and re-reads every light from memory twice per cluster.
+// A block owns 16 consecutive entries of the compacted list — ascending linear index, i.e. mostly neighbours
+// along x in one (y, z) row — and works in two phases per 1024 lights:
+//   filter : thread = light against the UNION of the block's 16 AABBs; survivors are appended in ascending light
+//            order to an LDS candidate list (ballot ranks + a 4-wave prefix).  The union contains every member
+//            box, and aabb_sphere_test is monotone in the box (each clamp distance, each square and each partial
+//            sum can only shrink when the box grows, also in floating point), so no light that hits a member box
+//            is ever filtered out; a block whose boxes contain a NaN does not filter at all.
+//   test   : lane = candidate.  A wave holds the AABBs of its 4 clusters in SGPRs, tests 64 candidates per step
+//            and turns the hit ballots into counts (WRITE = false, light_culling.comp:128-135) or into ascending
+//            index writes at the scanned offset (WRITE = true, :138-147).
+// The reference runs one thread per cluster over all lights, re-reading each 64-B light from memory twice and
+// redoing world_to_view x position per (cluster, light); with 10 k lights and 34 k active clusters the filter
+// leaves the exact test with a few per cent of the 6.8e8 (cluster, light) pairs.
 template <bool WRITE>
 __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const ClusterAssignParams p) {
-    __shared__ float4 s_light[kLightTile];
-    __shared__ uint32_t s_flags[kLightTile / 32];
+    __shared__ uint32_t s_cand_idx[kLightTile]; // a segment per wave, sized for "every light passes"
+    __shared__ float s_box[kClustersPerBlock][6];
+    __shared__ uint32_t s_wave_cnt[kAssignWaves];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.unique);
     const uint32_t n = min(hdr[3], p.max_clusters);
@@ -237,13 +252,21 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
     // lanes 0..3 build the AABBs of the wave's clusters; broadcast through readlane into SGPRs
     Aabb3 box = {};
     uint32_t my_ci = 0, my_limit = 0, my_offset = 0;
-    if (lane < kClustersPerWave && u0 + lane < n) {
+    const bool owns = lane < kClustersPerWave && u0 + lane < n;
+    if (owns) {
         my_ci = unique_idx[u0 + lane];
         box = cluster_aabb(p, my_ci);
         if (WRITE) {
             my_limit = p.counts[u0 + lane];
             my_offset = p.block_base[u0 + lane]; // exclusive prefix of the capped counts (scan of p.counts)
         }
+    }
+    if (lane < kClustersPerWave) {
+        float *bx = s_box[wave * kClustersPerWave + lane];
+        // an absent cluster contributes the empty box (+inf, -inf): neutral in the union
+        const float inf = __uint_as_float(0x7f800000u);
+#pragma unroll
+        for (int i = 0; i < 3; i++) bx[i] = owns ? box.mn[i] : inf, bx[3 + i] = owns ? box.mx[i] : -inf;
     }
     float mn[kClustersPerWave][3], mx[kClustersPerWave][3];
     uint32_t offset[kClustersPerWave], limit[kClustersPerWave], count[kClustersPerWave];
@@ -260,37 +283,94 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
         count[c] = 0;
         valid[c] = u0 + c < n;
     }
+    __syncthreads();
+    // union of the block's boxes (every thread computes the same six values), and whether any box holds a NaN
+    Aabb3 uni;
+    bool any_nan = false;
+#pragma unroll
+    for (int i = 0; i < 3; i++) uni.mn[i] = s_box[0][i], uni.mx[i] = s_box[0][3 + i];
+    for (int c = 0; c < kClustersPerBlock; c++) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float lo = s_box[c][i], hi = s_box[c][3 + i];
+            any_nan = any_nan || lo != lo || hi != hi;
+            uni.mn[i] = lo < uni.mn[i] ? lo : uni.mn[i];
+            uni.mx[i] = hi > uni.mx[i] ? hi : uni.mx[i];
+        }
+    }
     uint32_t *out = reinterpret_cast<uint32_t *>(p.light_index_buffer + ORBIT_LIGHT_INDEX_HEADER);
     const uint32_t nl = p.info.global_light_count;
+    // A wave filters a contiguous quarter of each 4096-light tile into its own segment of the candidate list
+    // (segment order == light order, no block barrier inside the filter), in groups of 4 x 64 lights whose loads are
+    // issued together and one group ahead.  Candidates are light indices; the test phase re-reads the few survivors'
+    // 16 B from L2.
+    constexpr uint32_t kSeg = kLightTile / kAssignWaves, kRounds = 4, kGroups = kSeg / (64 * kRounds);
+    float4 lt[kRounds];
+    uint32_t pt = 0; // bit r: light of round r is a point light
+    auto load_group = [&](uint32_t first) { // lights first + r*64 + lane of this wave
+        pt = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < kRounds; r++) {
+            const uint32_t li = first + r * 64u + (uint32_t)lane;
+            const uint32_t gi = li < nl ? li : 0u; // in-bounds dummy, masked by the range check in the filter
+            lt[r] = p.view_lights[gi];
+            pt |= ((p.light_flags[gi >> 5] >> (gi & 31)) & 1u) << r;
+        }
+    };
+    if (nl > 0) load_group(wave * kSeg);
     for (uint32_t base = 0; base < nl; base += kLightTile) {
-        const uint32_t tile_n = min(kLightTile, nl - base);
-        __syncthreads(); // previous tile fully consumed
-        for (uint32_t i = threadIdx.x; i < tile_n; i += kAssignWaves * 64) s_light[i] = p.view_lights[base + i];
-        if (threadIdx.x < (tile_n + 31) / 32) s_flags[threadIdx.x] = p.light_flags[base / 32 + threadIdx.x];
-        __syncthreads();
-        for (uint32_t b0 = 0; b0 < tile_n; b0 += 64) {
-            const uint32_t li = b0 + lane;
-            const bool in_tile = li < tile_n;
-            const float4 l = s_light[in_tile ? li : 0];
-            const bool point = (s_flags[(in_tile ? li : 0) >> 5] >> (li & 31)) & 1u;
+        // ---- filter: this wave's segment
+        uint32_t seg_n = 0; // wave-uniform
+        for (uint32_t g = 0; g < kGroups; g++) {
+            const uint32_t first = base + wave * kSeg + g * (64u * kRounds);
+            float4 cur[kRounds];
+            const uint32_t cur_pt = pt;
 #pragma unroll
-            for (int c = 0; c < kClustersPerWave; c++) {
-                if (!valid[c]) continue; // wave-uniform
-                Aabb3 a;
+            for (uint32_t r = 0; r < kRounds; r++) cur[r] = lt[r];
+            // next group of this tile, or the first group of the next tile
+            const uint32_t next = g + 1 < kGroups ? first + 64u * kRounds : base + kLightTile + wave * kSeg;
+            if (next < nl) load_group(next);
 #pragma unroll
-                for (int i = 0; i < 3; i++) a.mn[i] = mn[c][i], a.mx[i] = mx[c][i];
-                const bool hit = in_tile && (!point || sphere_hits(a, l)); // :108-119
-                const uint64_t m = __ballot(hit);
-                if (WRITE) {
-                    if (hit) {
-                        const uint32_t k = count[c] + lane_prefix(m);
-                        if (k < limit[c] && offset[c] + k < p.light_index_capacity) // while (counter < light_count), :140
-                            out[offset[c] + k] = base + li;
-                    }
-                }
-                count[c] += (uint32_t)__popcll(m);
+            for (uint32_t r = 0; r < kRounds; r++) {
+                const uint32_t li = first + r * 64u + (uint32_t)lane;
+                const bool point = (cur_pt >> r) & 1u;
+                const bool pass = li < nl && (!point || any_nan || sphere_hits(uni, cur[r]));
+                const uint64_t m = __ballot(pass);
+                if (pass) s_cand_idx[wave * kSeg + seg_n + lane_prefix(m)] = li | (point ? 0u : kNotPoint);
+                seg_n += (uint32_t)__popcll(m);
             }
         }
+        if (lane == 0) s_wave_cnt[wave] = seg_n;
+        __syncthreads(); // all segments complete
+        // ---- test: the wave's clusters against the candidates, segment by segment (ascending light order)
+        for (uint32_t seg = 0; seg < (uint32_t)kAssignWaves; seg++) {
+            const uint32_t cnt = s_wave_cnt[seg];
+            for (uint32_t b0 = 0; b0 < cnt; b0 += 64) {
+                const uint32_t ci = b0 + lane;
+                const bool in_list = ci < cnt;
+                const uint32_t tag = s_cand_idx[seg * kSeg + (in_list ? ci : 0)];
+                const bool point = (tag & kNotPoint) == 0u;
+                const float4 l = p.view_lights[tag & ~kNotPoint];
+#pragma unroll
+                for (int c = 0; c < kClustersPerWave; c++) {
+                    if (!valid[c]) continue; // wave-uniform
+                    Aabb3 a;
+#pragma unroll
+                    for (int i = 0; i < 3; i++) a.mn[i] = mn[c][i], a.mx[i] = mx[c][i];
+                    const bool hit = in_list && (!point || sphere_hits(a, l)); // :108-119
+                    const uint64_t m = __ballot(hit);
+                    if (WRITE) {
+                        if (hit) {
+                            const uint32_t k = count[c] + lane_prefix(m);
+                            if (k < limit[c] && offset[c] + k < p.light_index_capacity) // while (counter < light_count), :140
+                                out[offset[c] + k] = tag & ~kNotPoint;
+                        }
+                    }
+                    count[c] += (uint32_t)__popcll(m);
+                }
+            }
+        }
+        __syncthreads(); // candidates consumed before the next tile's filter overwrites them
     }
 #pragma unroll
     for (int c = 0; c < kClustersPerWave; c++) {

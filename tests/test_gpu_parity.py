@@ -357,8 +357,26 @@ def cluster_inputs(oracle, seed, W, H, n_lights, tile_px=8, z_slices=32, far=200
     (320, 180, 200, 8, 32, 1, 1.0), (333, 187, 64, 16, 24, 1, 0.9), (256, 128, 300, 8, 32, 4, 1.0),
     (1920, 1080, 1000, 8, 32, 1, 1.0), (64, 64, 0, 8, 8, 1, 1.0), (200, 120, 40, 64, 32, 1, 1.0)])
 def test_light_clusters(torch_mod, engine, oracle, W, H, n_lights, tile, zs, samples, pf):
+    _light_clusters(torch_mod, engine, oracle, W, H, n_lights, tile, zs, samples, pf, poison=False)
+
+
+def test_light_clusters_with_non_finite_inputs(torch_mod, engine, oracle):
+    """NaN / inf / negative depth samples and non-finite light positions and radii: cluster AABBs with NaN
+    components (the union-box light filter must not apply to those blocks), lights that every comparison accepts."""
+    _light_clusters(torch_mod, engine, oracle, 320, 180, 300, 8, 32, 1, 0.95, poison=True)
+
+
+def _light_clusters(torch_mod, engine, oracle, W, H, n_lights, tile, zs, samples, pf, poison):
     torch = torch_mod
     push, depth, info, lights = cluster_inputs(oracle, 4, W, H, n_lights, tile, zs, samples=samples, point_fraction=pf)
+    if poison:
+        rng = np.random.default_rng(4)
+        flat = depth.reshape(-1)
+        for val in (np.nan, np.inf, -np.inf, -0.25, 0.0, 1.0, 3.0):
+            flat[rng.integers(0, len(flat), 200)] = val
+        for k, val in enumerate((np.nan, np.inf, -np.inf)):
+            lights["position"][10 + k, k % 3] = val
+        lights["outer_radius"][20], lights["outer_radius"][21], lights["outer_radius"][22] = np.nan, np.inf, 0.0
     cc = [int(v) for v in push["cluster_count"]]
     total = cc[0] * cc[1] * cc[2]
     # mark
