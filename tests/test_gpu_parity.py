@@ -366,9 +366,18 @@ def test_light_clusters_with_non_finite_inputs(torch_mod, engine, oracle):
     _light_clusters(torch_mod, engine, oracle, 320, 180, 300, 8, 32, 1, 0.95, poison=True)
 
 
-def _light_clusters(torch_mod, engine, oracle, W, H, n_lights, tile, zs, samples, pf, poison):
+def test_light_clusters_many_lights_and_saturated_clusters(torch_mod, engine, oracle):
+    """More lights than one filter tile holds (the device filters 4096 lights per step) and radii large enough that
+    clusters exceed the 256-light cap (light_culling.comp:135): counts saturate, lists keep the first 256 in order."""
+    _light_clusters(torch_mod, engine, oracle, 192, 108, 9000, 8, 32, 1, 0.98, poison=False, radius_scale=1.0)
+    _light_clusters(torch_mod, engine, oracle, 128, 72, 5000, 16, 16, 1, 1.0, poison=False, radius_scale=12.0)
+
+
+def _light_clusters(torch_mod, engine, oracle, W, H, n_lights, tile, zs, samples, pf, poison, radius_scale=None):
     torch = torch_mod
     push, depth, info, lights = cluster_inputs(oracle, 4, W, H, n_lights, tile, zs, samples=samples, point_fraction=pf)
+    if radius_scale is not None:
+        lights["outer_radius"] *= np.float32(radius_scale)
     if poison:
         rng = np.random.default_rng(4)
         flat = depth.reshape(-1)
@@ -400,6 +409,8 @@ def _light_clusters(torch_mod, engine, oracle, W, H, n_lights, tile, zs, samples
     lcap = n_active * 256 + 16
     ol, oimg, dropped = oracle.cluster_assign(info, ou, ob, lights, lcap, total)
     assert dropped == 0
+    if radius_scale is not None and radius_scale > 1.0:
+        assert int(oimg[:, 1].max()) == 256  # the cap is reached
     gl = torch.full((L.LIGHT_INDEX_HEADER + 4 * lcap,), 0xEE, dtype=torch.uint8, device="cuda")
     gimg = torch.zeros((total, 2), dtype=torch.int32, device="cuda")
     engine.cluster_assign(info, gu, gb, dev(torch, lights) if n_lights else None, gl, lcap, gimg)
@@ -411,6 +422,22 @@ def _light_clusters(torch_mod, engine, oracle, W, H, n_lights, tile, zs, samples
     engine.status()
     if n_lights >= 200:
         assert n_idx > 0 and n_active > 0
+    if n_idx > 64:  # the reference's index list can overflow (cluster.rs:546-553): cut it, nothing written past, flagged
+        from orbit_amd._lib import E_CAPACITY, OrbitError
+
+        cut = n_idx - 37
+        ol3, oimg3, dropped3 = oracle.cluster_assign(info, ou, ob, lights, cut, total)
+        gl3 = torch.full((L.LIGHT_INDEX_HEADER + 4 * cut + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+        gimg3 = torch.zeros_like(gimg)
+        engine.cluster_assign(info, gu, gb, dev(torch, lights), gl3, cut, gimg3)
+        torch.cuda.synchronize()
+        assert dropped3 > 0
+        assert np.array_equal(host(gl3)[:4 + 4 * cut], ol3[:4 + 4 * cut]), "cut light index list differs"
+        assert bool((host(gl3)[4 + 4 * cut:] == 0xEE).all())
+        assert np.array_equal(host(gimg3, np.uint32).reshape(-1, 2), oimg3)
+        with pytest.raises(OrbitError) as ei:
+            engine.status()
+        assert ei.value.code == E_CAPACITY
     # compute_clusters: the same three stages behind one call produce the same five buffers
     gm2, gb2 = torch.full_like(gm, 0x55), torch.full_like(gb, 0x55)
     gu2, gl2, gimg2 = torch.full_like(gu, 0xEE), torch.full_like(gl, 0xEE), torch.zeros_like(gimg)
