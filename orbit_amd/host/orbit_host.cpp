@@ -150,6 +150,49 @@ bool project_sphere_clip_space(const Vec4 &s, float znear, float p00, float p11,
 } // namespace math
 
 // ------------------------------------------------------------------------- camera
+namespace math {
+
+float frustum_split(float near, float far, float lambda, float ratio) { // src/math.rs:64-69
+    const float uniform = near + (far - near) * ratio;
+    const float log = near * std::pow(far / near, ratio);
+    return log * lambda + (1.0f - lambda) * uniform;
+}
+
+void perspective_corners(float fovy, float aspect_ratio, float near, float far, Vec4 out[8]) { // src/math.rs:149-168
+    const float tan_half_h = std::tan(fovy / 2.0f) * aspect_ratio;
+    const float tan_half_v = std::tan(fovy / 2.0f);
+    const float xn = near * tan_half_h, yn = near * tan_half_v, xf = far * tan_half_h, yf = far * tan_half_v;
+    const Vec4 c[8] = {{-xn, -yn, -near, 1.0f}, {xn, -yn, -near, 1.0f}, {xn, yn, -near, 1.0f}, {-xn, yn, -near, 1.0f},
+                       {-xf, -yf, -far, 1.0f},  {xf, -yf, -far, 1.0f},  {xf, yf, -far, 1.0f},  {-xf, yf, -far, 1.0f}};
+    for (int i = 0; i < 8; i++) out[i] = c[i];
+}
+
+Mat4 mat4_from_quat(const Quat &q) { // glam Mat4::from_quat (quat_to_axes)
+    const float x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+    const float xx = q.x * x2, xy = q.x * y2, xz = q.x * z2, yy = q.y * y2, yz = q.y * z2, zz = q.z * z2;
+    const float wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
+    Mat4 m = Mat4::identity();
+    m.c[0] = 1.0f - (yy + zz), m.c[1] = xy + wz, m.c[2] = xz - wy;
+    m.c[4] = xy - wz, m.c[5] = 1.0f - (xx + zz), m.c[6] = yz + wx;
+    m.c[8] = xz + wy, m.c[9] = yz - wx, m.c[10] = 1.0f - (xx + yy);
+    return m;
+}
+
+Mat4 mat4_from_translation(const Vec3 &t) {
+    Mat4 m = Mat4::identity();
+    m.c[12] = t.x, m.c[13] = t.y, m.c[14] = t.z;
+    return m;
+}
+
+Mat4 mat4_from_scale_rotation_translation(const Vec3 &s, const Quat &q, const Vec3 &t) {
+    Mat4 m = mat4_from_quat(q);
+    for (int r = 0; r < 3; r++) m.c[r] *= s.x, m.c[4 + r] *= s.y, m.c[8 + r] *= s.z;
+    m.c[12] = t.x, m.c[13] = t.y, m.c[14] = t.z;
+    return m;
+}
+
+} // namespace math
+
 namespace camera {
 Projection Projection::perspective(float fov, float near_clip) {
     Projection p;
@@ -466,6 +509,101 @@ GraphClusterInfo compute_clusters(graphics::Context &context, const ClusterSetti
     out.info.z_scale = zz.first;
     out.info.z_bias = zz.second;
     out.info.luminance_cutoff = settings.luminance_cutoff;
+    return out;
+}
+
+Mat4 Transform::compute_matrix() const { return math::mat4_from_scale_rotation_translation(scale, orientation, position); }
+
+Mat4 SceneCamera::compute_matrix() const { // camera.rs:124-129
+    return projection.compute_matrix(aspect_ratio).mul(transform.compute_matrix().inverse());
+}
+
+ShadowCascade shadow_cascade(const ShadowSettings &settings, const LodSettings &lod, const Quat &direction,
+                             const SceneCamera &camera, size_t cascade_index, bool frustum_culling) {
+    if (camera.projection.kind != camera::Projection::Perspective) throw Panic("not yet implemented"); // todo!(), :468
+    if (cascade_index >= MAX_SHADOW_CASCADE_COUNT) throw Panic("cascade_index out of range");
+    const float fov = camera.projection.fov, near_clip_cam = camera.projection.near_clip;
+    const float far_clip_cam = settings.max_shadow_distance;
+    const float lambda = settings.cascade_split_lambda;
+    const float near_split_ratio = (float)cascade_index / (float)MAX_SHADOW_CASCADE_COUNT;
+    const float far_split_ratio = (float)(cascade_index + 1) / (float)MAX_SHADOW_CASCADE_COUNT;
+    const float near = math::frustum_split(near_clip_cam, far_clip_cam, lambda, near_split_ratio);
+    const float far = math::frustum_split(near_clip_cam, far_clip_cam, lambda, far_split_ratio);
+
+    Mat4 light_matrix = math::mat4_from_quat(direction.inverse()); // :461,479
+    const Mat4 view_to_world = camera.transform.compute_matrix();
+    const Mat4 view_to_light = light_matrix.mul(view_to_world);
+
+    Vec4 corners[8];
+    math::perspective_corners(fov, camera.aspect_ratio, near, far, corners);
+    float center[4] = {0, 0, 0, 0}, mn[3], mx[3];
+    for (int i = 0; i < 8; i++) { // :483-497
+        Vec4 v = view_to_light.mul_vec4(corners[i]);
+        v = {v.x / v.w, v.y / v.w, v.z / v.w, v.w / v.w};
+        corners[i] = v;
+        const float c[3] = {v.x, v.y, v.z};
+        for (int k = 0; k < 3; k++) {
+            if (i == 0) mn[k] = mx[k] = c[k];
+            mn[k] = std::fmin(mn[k], c[k]);
+            mx[k] = std::fmax(mx[k], c[k]);
+        }
+        center[0] += v.x, center[1] += v.y, center[2] += v.z, center[3] += v.w;
+    }
+    for (float &c : center) c /= 8.0f;
+    float radius_sqr = 0.0f;
+    for (int i = 0; i < 8; i++) { // :499-506
+        const float dx = corners[i].x - center[0], dy = corners[i].y - center[1], dz = corners[i].z - center[2];
+        radius_sqr = std::fmax(radius_sqr, dx * dx + dy * dy + dz * dz);
+    }
+    const float radius = std::sqrt(radius_sqr);
+
+    // forward offset (:513-527): lerp(min, max, (sign + 1) / 2) - radius * sign per component
+    const float fs[3] = {view_to_light.c[8], view_to_light.c[9], view_to_light.c[10]}; // z_axis
+    float modified[3];
+    const float texel = radius * 2.0f / (float)settings.shadow_resolution; // :529
+    for (int k = 0; k < 3; k++) {
+        const float lo = mn[k] - center[k], hi = mx[k] - center[k];
+        const float a = (fs[k] + 1.0f) / 2.0f;
+        const float offset = (lo + (hi - lo) * a) - radius * fs[k];
+        modified[k] = std::floor((center[k] + offset) / texel) * texel; // :534-535
+    }
+    light_matrix = math::mat4_from_translation({-modified[0], -modified[1], -modified[2]}).mul(light_matrix); // :543
+    const float max_extent = radius, min_extent = -radius;
+    const float near_clip = min_extent - 80.0f, far_clip = max_extent; // :545-546
+
+    ShadowCascade out;
+    out.shadow_map_world_size = radius * 2.0f;
+    out.light_projection_matrix = // :548-555 (reverse z: far and near swapped)
+        Mat4::orthographic_rh(min_extent, max_extent, min_extent, max_extent, far_clip, near_clip).mul(light_matrix);
+
+    // culling planes (:623-651)
+    Vec4 light_planes[6], cam_planes[6];
+    math::frustum_planes_from_matrix(
+        Mat4::orthographic_rh(min_extent, max_extent, min_extent, max_extent, near_clip, far_clip), light_planes);
+    const Mat4 light_to_world = light_matrix.inverse();
+    const Mat4 camera_clip_to_light = camera.compute_matrix().mul(light_to_world);
+    math::frustum_planes_from_matrix(camera_clip_to_light, cam_planes);
+    CullInfo &ci = out.cull_info;
+    if (frustum_culling) { // :685
+        for (int i = 0; i < 6; i++) ci.view_space_cull_planes.push_back(math::normalize_plane(light_planes[i]));
+        for (int i = 0; i < 5; i++) { // .take(5).filter(dot(plane.xyz, Z) >= 0)
+            const Vec4 p = math::normalize_plane(cam_planes[i]);
+            if (p.z >= 0.0f) ci.view_space_cull_planes.push_back(p);
+        }
+    }
+    ci.view_matrix = light_matrix;
+    ci.projection = camera::Projection::orthographic(radius, near_clip, far_clip); // :687-691
+    ci.occlusion_culling = OcclusionCullInfo{};
+    ci.alpha_mode_filter.bits = AlphaModeFlags::OPAQUE | AlphaModeFlags::MASKED;
+    if (cascade_index <= 1) { // :699-702
+        ci.lod_range_start = lod.min_mesh_lod, ci.lod_range_end = lod.max_mesh_lod + 1;
+    } else {
+        ci.lod_range_start = 2, ci.lod_range_end = lod.max_mesh_lod + 1;
+    }
+    ci.lod_base = lod.lod_base, ci.lod_step = lod.lod_step;
+    const Vec3 &cp = camera.transform.position; // light_matrix.transform_point3(camera position), :705
+    const Vec4 t = light_matrix.mul_vec4({cp.x, cp.y, cp.z, 1.0f});
+    ci.lod_target_pos_view_space = {t.x, t.y, t.z};
     return out;
 }
 

@@ -46,8 +46,18 @@ struct Mat4 {
     Vec4 col(int i) const { return {c[4 * i], c[4 * i + 1], c[4 * i + 2], c[4 * i + 3]}; }
 };
 
+struct Quat { // glam::Quat (x, y, z, w)
+    float x = 0, y = 0, z = 0, w = 1;
+    Quat inverse() const { return {-x, -y, -z, w}; } // unit quaternions: the conjugate
+};
+
 namespace math {
 uint32_t mip_levels_from_size(uint32_t max_size);                                  // src/math.rs:18-20
+float frustum_split(float near, float far, float lambda, float ratio);             // src/math.rs:64-69
+void perspective_corners(float fovy, float aspect_ratio, float near, float far, Vec4 out[8]); // :149-168
+Mat4 mat4_from_quat(const Quat &q);                                                // glam Mat4::from_quat
+Mat4 mat4_from_translation(const Vec3 &t);                                         // glam Mat4::from_translation
+Mat4 mat4_from_scale_rotation_translation(const Vec3 &s, const Quat &q, const Vec3 &t);
 void frustum_planes_from_matrix(const Mat4 &m, Vec4 planes[6]);                    // src/math.rs:71-84
 Vec4 normalize_plane(const Vec4 &p);                                               // src/math.rs:86-89
 float largest_scale_from_matrix(const Mat4 &m);                                    // src/math.rs:132-138
@@ -179,6 +189,45 @@ class DepthPyramid {
 // draw_gen.rs:569-628
 void update_multiple_depth_pyramids(graphics::Context &context, DepthPyramid *const *depth_pyramids,
                                     const graphics::GraphImageHandle *depth_buffers, size_t count);
+
+// scene.rs:20-57
+struct Transform {
+    Vec3 position;
+    Quat orientation;
+    Vec3 scale{1.0f, 1.0f, 1.0f};
+    Mat4 compute_matrix() const; // Mat4::from_scale_rotation_translation
+};
+
+// camera.rs:115-142 with its transform (the cascade builder needs view-to-world)
+struct SceneCamera {
+    Transform transform;
+    camera::Projection projection;
+    float aspect_ratio = 1.0f;
+    Mat4 compute_matrix() const; // projection * inverse(transform)
+};
+
+// shadow_renderer.rs:27,44-73
+constexpr size_t MAX_SHADOW_CASCADE_COUNT = 4;
+struct ShadowSettings {
+    uint32_t shadow_resolution = 2048;
+    float cascade_split_lambda = 0.80f;
+    float max_shadow_distance = 32.0f;
+};
+// the slice of app.rs Settings the cascade CullInfo reads (app.rs:370-372)
+struct LodSettings {
+    size_t min_mesh_lod = 0, max_mesh_lod = 7;
+    float lod_base = 16.0f, lod_step = 2.0f;
+};
+struct ShadowCascade {
+    CullInfo cull_info;             // what render_shadow_map hands to the cull passes (:688-706)
+    Mat4 light_projection_matrix;   // projection_matrix * light_matrix (:552)
+    float shadow_map_world_size = 0; // radius * 2 (:511)
+};
+// The per-cascade part of ShadowRenderer::render_cascaded_shadow (shadow_renderer.rs:466-706): split distances,
+// texel-snapped light-space bounding sphere of the sub-frustum, and the orthographic CullInfo with the six light
+// planes plus the camera's planes that face the light (up to 11 planes).
+ShadowCascade shadow_cascade(const ShadowSettings &settings, const LodSettings &lod, const Quat &direction,
+                             const SceneCamera &camera, size_t cascade_index, bool frustum_culling = true);
 
 // cluster.rs:14-72
 struct ClusterSettings {

@@ -117,6 +117,48 @@ int32_t orbit_host_project_sphere_clip_space(const float s[4], float znear, floa
 int32_t orbit_host_cull_info_to_gpu(const OrbitHostCullInfo *ci, OrbitGpuCullInfo *out) {
     return guarded([&] { *out = to_cull_info(*ci).to_gpu(); });
 }
+int32_t orbit_host_shadow_cascade(const OrbitHostShadowCascadeIn *in, OrbitHostCullInfo *h, float out_lpm[16],
+                                  float *out_world_size) {
+    return guarded([&] {
+        ShadowSettings ss;
+        ss.shadow_resolution = in->shadow_resolution;
+        ss.cascade_split_lambda = in->cascade_split_lambda;
+        ss.max_shadow_distance = in->max_shadow_distance;
+        LodSettings lod;
+        lod.min_mesh_lod = in->min_mesh_lod, lod.max_mesh_lod = in->max_mesh_lod;
+        lod.lod_base = in->lod_base, lod.lod_step = in->lod_step;
+        SceneCamera cam;
+        cam.transform.position = {in->camera_position[0], in->camera_position[1], in->camera_position[2]};
+        cam.transform.orientation = {in->camera_orientation[0], in->camera_orientation[1], in->camera_orientation[2],
+                                     in->camera_orientation[3]};
+        cam.projection = camera::Projection::perspective(in->camera_fov, in->camera_near_clip);
+        cam.aspect_ratio = in->camera_aspect_ratio;
+        const Quat dir{in->direction[0], in->direction[1], in->direction[2], in->direction[3]};
+        const ShadowCascade c = shadow_cascade(ss, lod, dir, cam, in->cascade_index, in->frustum_culling != 0);
+        memset(h, 0, sizeof(*h));
+        memcpy(h->view_matrix, c.cull_info.view_matrix.c, sizeof(h->view_matrix));
+        h->plane_count = (uint32_t)c.cull_info.view_space_cull_planes.size();
+        for (uint32_t i = 0; i < h->plane_count && i < 16; i++) {
+            const Vec4 &p = c.cull_info.view_space_cull_planes[i];
+            h->view_space_cull_planes[i][0] = p.x, h->view_space_cull_planes[i][1] = p.y;
+            h->view_space_cull_planes[i][2] = p.z, h->view_space_cull_planes[i][3] = p.w;
+        }
+        h->projection.kind = 1;
+        h->projection.half_width = c.cull_info.projection.half_width;
+        h->projection.near_clip = c.cull_info.projection.near_clip;
+        h->projection.far_clip = c.cull_info.projection.far_clip;
+        h->occlusion_kind = 0;
+        h->aspect_ratio = 1.0f;
+        h->alpha_mode_filter = c.cull_info.alpha_mode_filter.bits;
+        h->lod_range[0] = (uint32_t)c.cull_info.lod_range_start, h->lod_range[1] = (uint32_t)c.cull_info.lod_range_end;
+        h->lod_base = c.cull_info.lod_base, h->lod_step = c.cull_info.lod_step;
+        h->lod_target_pos_view_space[0] = c.cull_info.lod_target_pos_view_space.x;
+        h->lod_target_pos_view_space[1] = c.cull_info.lod_target_pos_view_space.y;
+        h->lod_target_pos_view_space[2] = c.cull_info.lod_target_pos_view_space.z;
+        memcpy(out_lpm, c.light_projection_matrix.c, 16 * sizeof(float));
+        *out_world_size = c.shadow_map_world_size;
+    });
+}
 void orbit_host_cluster_settings_derive(const OrbitHostClusterSettings *s, float z_near, OrbitHostClusterDerived *out) {
     ClusterSettings cs;
     cs.px_size_power = s->px_size_power;

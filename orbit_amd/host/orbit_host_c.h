@@ -74,6 +74,20 @@ uint32_t orbit_host_mip_levels_from_size(uint32_t max_size);
 int32_t orbit_host_project_sphere_clip_space(const float sphere[4], float znear, float p00, float p11, float aabb[4]);
 /* CullInfo::to_gpu */
 int32_t orbit_host_cull_info_to_gpu(const OrbitHostCullInfo *ci, OrbitGpuCullInfo *out);
+/* ShadowRenderer::render_cascaded_shadow, per-cascade CullInfo (shadow_renderer.rs:466-706).  direction and the
+ * camera orientation are unit quaternions (x, y, z, w); the camera must be perspective {fov, near_clip}. */
+typedef struct OrbitHostShadowCascadeIn {
+    uint32_t shadow_resolution;
+    float cascade_split_lambda, max_shadow_distance;
+    uint32_t min_mesh_lod, max_mesh_lod;
+    float lod_base, lod_step;
+    float direction[4];
+    float camera_position[3], camera_orientation[4];
+    float camera_fov, camera_near_clip, camera_aspect_ratio;
+    uint32_t cascade_index, frustum_culling;
+} OrbitHostShadowCascadeIn;
+int32_t orbit_host_shadow_cascade(const OrbitHostShadowCascadeIn *in, OrbitHostCullInfo *out_cull_info,
+                                  float out_light_projection_matrix[16], float *out_world_size);
 /* ClusterSettings methods */
 void orbit_host_cluster_settings_derive(const OrbitHostClusterSettings *s, float z_near, OrbitHostClusterDerived *out);
 

@@ -44,6 +44,15 @@ class HostCullInfo(C.Structure):
                 ("lod_target_pos_view_space", C.c_float * 3)]
 
 
+class HostShadowCascadeIn(C.Structure):
+    _fields_ = [("shadow_resolution", C.c_uint32), ("cascade_split_lambda", C.c_float),
+                ("max_shadow_distance", C.c_float), ("min_mesh_lod", C.c_uint32), ("max_mesh_lod", C.c_uint32),
+                ("lod_base", C.c_float), ("lod_step", C.c_float), ("direction", C.c_float * 4),
+                ("camera_position", C.c_float * 3), ("camera_orientation", C.c_float * 4), ("camera_fov", C.c_float),
+                ("camera_near_clip", C.c_float), ("camera_aspect_ratio", C.c_float), ("cascade_index", C.c_uint32),
+                ("frustum_culling", C.c_uint32)]
+
+
 class HostAssets(C.Structure):
     _fields_ = [("meshlet_buffer", C.c_void_p), ("mesh_info_buffer", C.c_void_p), ("materials_buffer", C.c_void_p),
                 ("material_count", C.c_uint32)]
@@ -183,6 +192,22 @@ def CullInfo(view_matrix, view_space_cull_planes, projection, occlusion_kind=OCC
     ci.lod_base, ci.lod_step = lod_base, lod_step
     ci.lod_target_pos_view_space = (C.c_float * 3)(*lod_target_pos_view_space)
     return ci
+
+
+def shadow_cascade(direction, camera_position, camera_orientation, camera_fov, camera_near_clip, camera_aspect_ratio,
+                   cascade_index, shadow_resolution=2048, cascade_split_lambda=0.80, max_shadow_distance=32.0,
+                   min_mesh_lod=0, max_mesh_lod=7, lod_base=16.0, lod_step=2.0, frustum_culling=True):
+    """ShadowRenderer::render_cascaded_shadow for one cascade (shadow_renderer.rs:466-706): returns
+    (HostCullInfo, light_projection_matrix[16], shadow_map_world_size).  Quaternions are (x, y, z, w)."""
+    a = HostShadowCascadeIn(shadow_resolution, cascade_split_lambda, max_shadow_distance, min_mesh_lod, max_mesh_lod,
+                            lod_base, lod_step, (C.c_float * 4)(*direction), (C.c_float * 3)(*camera_position),
+                            (C.c_float * 4)(*camera_orientation), camera_fov, camera_near_clip, camera_aspect_ratio,
+                            cascade_index, 1 if frustum_culling else 0)
+    ci = HostCullInfo()
+    lpm = (C.c_float * 16)()
+    ws = C.c_float()
+    _check(lib().orbit_host_shadow_cascade(C.byref(a), C.byref(ci), lpm, C.byref(ws)))
+    return ci, np.array(lpm, dtype=np.float32), float(ws.value)
 
 
 def cull_info_to_gpu(ci):

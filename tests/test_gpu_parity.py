@@ -503,6 +503,27 @@ def test_task_records(torch_mod, engine, oracle, occlusion_pass, ortho):
         assert np.array_equal(host(mvis_d, np.uint32), omv), "meshlet visibility words differ"
 
 
+# ----------------------------------------------------------------------------- shadow cascades
+@pytest.mark.parametrize("cascade", range(4))
+def test_shadow_cascade_cull(torch_mod, engine, oracle, cascade):
+    """The renderer's own cascade math (shadow_renderer.rs:466-706 through the host mirror) produces the orthographic
+    CullInfo with up to 11 planes and a LOD window per cascade; both cull stages with it, against the oracle."""
+    from orbit_amd import passes
+
+    scene = sc.make_scene(71, 1500, n_meshes=200, lods=4, meshlets_per_mesh=(1, 60), extent=(30.0, 6.0, 30.0))
+    q = lambda pitch, yaw: (float(np.cos(pitch / 2) * np.sin(yaw / 2)), float(np.sin(pitch / 2) * np.cos(yaw / 2)),
+                            float(-np.sin(pitch / 2) * np.sin(yaw / 2)), float(np.cos(pitch / 2) * np.cos(yaw / 2)))
+    hci, _, _ = passes.shadow_cascade(q(0.4, -0.9), (2.0, 3.0, 8.0), q(0.3, -0.1), float(np.float32(np.pi / 2)), 0.01,
+                                      16.0 / 9.0, cascade, lod_base=6.0)
+    assert hci.plane_count >= 6
+    ci = passes.cull_info_to_gpu(hci)
+    assert int(ci["projection_type"]) == 1 and int(ci["cull_plane_count"]) == hci.plane_count
+    gs = GpuScene(torch_mod, scene)
+    recs, cmds = assert_same(run_gpu(torch_mod, engine, gs, ci), run_oracle(oracle, scene, ci))
+    if cascade >= 2:
+        assert len(cmds) > 0  # the far cascades cover the scene
+
+
 # ----------------------------------------------------------------------------- randomized parameter sweep
 @pytest.mark.parametrize("seed", range(24))
 def test_randomized_parameters(torch_mod, engine, oracle, seed):

@@ -86,3 +86,53 @@ def test_cluster_settings(oracle):
     s2 = passes.ClusterSettings(px_size_power=6, screen_resolution=(333, 65), z_slice_count=2)
     d2 = passes.cluster_settings_derive(s2, 0.1)
     assert list(d2.tile_counts) == [6, 2] and d2.linear_max_allocated_cluster_count == 6 * 2 * 4  # max(4, z) slices
+
+
+def _quat_yxz(pitch, yaw):
+    """glam Quat::from_euler(YXZ, pitch, yaw, 0) as (x, y, z, w): rotation about Y by `pitch`, then X by `yaw`."""
+    cy, sy, cx, sx = np.cos(pitch / 2), np.sin(pitch / 2), np.cos(yaw / 2), np.sin(yaw / 2)
+    return (float(cy * sx), float(sy * cx), float(-sy * sx), float(cy * cx))
+
+
+@pytest.mark.parametrize("cascade", range(4))
+def test_shadow_cascade_cull_info(cascade):
+    """ShadowRenderer::render_cascaded_shadow (shadow_renderer.rs:466-706) restated in the host mirror: the CullInfo of a
+    cascade is orthographic, carries the six planes of the light's box plus the camera planes that face the light
+    (<= 11), keeps the cascade's sub-frustum inside, and snaps the light-space origin to shadow-map texels."""
+    cam_pos, cam_q = (3.0, 2.0, -5.0), _quat_yxz(0.7, -0.2)
+    direction = _quat_yxz(0.3, -1.0)  # a sun direction
+    fov, near, aspect = float(np.float32(np.pi / 2)), 0.01, 16.0 / 9.0
+    ci, lpm, world_size = passes.shadow_cascade(direction, cam_pos, cam_q, fov, near, aspect, cascade)
+    n = ci.plane_count
+    assert 6 <= n <= 11 and ci.projection.kind == 1 and ci.occlusion_kind == 0
+    assert ci.alpha_mode_filter == L.ALPHA_OPAQUE | L.ALPHA_MASKED
+    assert tuple(ci.lod_range) == ((0, 8) if cascade <= 1 else (2, 8))
+    radius = ci.projection.half_width
+    assert world_size == pytest.approx(2 * radius) and ci.projection.near_clip == pytest.approx(-radius - 80.0)
+    planes = np.array(ci.view_space_cull_planes, dtype=np.float64)[:n]
+    assert np.allclose(np.linalg.norm(planes[:, :3], axis=1), 1.0, atol=1e-5)
+    assert np.all(planes[6:, 2] >= 0.0)  # only camera planes that face the light are kept (:637)
+    # texel snapping: the light-space translation is a multiple of the texel size (:529-535)
+    light = np.array(ci.view_matrix, dtype=np.float64).reshape(4, 4).T  # [row, col]
+    texel = 2 * radius / 2048
+    assert np.allclose(np.round(light[:3, 3] / texel), light[:3, 3] / texel, atol=2e-3)
+    # the cascade's sub-frustum (camera space -> world -> light) is inside every culling plane and inside the box
+    lam, far_clip = 0.80, 32.0
+    split = lambda r: near * (far_clip / near) ** r * lam + (1 - lam) * (near + (far_clip - near) * r)
+    zn, zf = split(cascade / 4), split((cascade + 1) / 4)
+    th, tv = np.tan(fov / 2) * aspect, np.tan(fov / 2)
+    corners = np.array([[sx * z * th, sy * z * tv, -z, 1.0] for z in (zn, zf) for sx in (-1, 1) for sy in (-1, 1)])
+    x, y, z, w = cam_q
+    rot = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                    [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                    [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    world = corners[:, :3] @ rot.T + np.array(cam_pos)
+    ls = world @ light[:3, :3].T + light[:3, 3]
+    assert np.all(np.abs(ls[:, :2]) <= radius * 1.001 + 2 * texel)
+    d = ls @ planes[:, :3].T + planes[:, 3]
+    # the near plane of the light box is documented as wrong in the reference ("only the near plane is wrong, but we
+    # don't use that", :629-631): exclude the two z planes of the box, check the rest
+    keep = [i for i in range(n) if i not in (4, 5)]
+    assert np.all(d[:, keep] >= -radius * 1e-3 - 2 * texel)
+    gpu = passes.cull_info_to_gpu(ci)
+    assert gpu["projection_type"] == 1 and gpu["cull_plane_count"] == n
