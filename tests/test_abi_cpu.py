@@ -107,3 +107,28 @@ def test_product_never_touches_the_oracle():
                 for line in text.splitlines():
                     code = line.split("//")[0].split("#")[0] if not f.endswith(".py") else line.split("#")[0]
                     assert not re.search(r"(import|from|include|dlopen|CDLL).*\boracle\b", code), (f, line)
+
+
+def test_orbitscene_round_trip(tmp_path):
+    """The `.orbitscene` dump format (real-asset path): sections come back typed and byte-identical."""
+    import scenes as sc
+    from orbit_amd import orbitscene
+
+    s = sc.make_scene(5, 60)
+    cam = sc.default_camera()
+    ci = sc.make_cull_info(cam.view, cam.planes)
+    depth = sc.make_depth(1, 64, 36, cam)
+    p = tmp_path / "s.orbitscene"
+    orbitscene.write(p, entity_draws=s.entity_draw_buffer(), mesh_infos=s.mesh_infos, entities=s.entities,
+                     meshlets=s.meshlets, materials=s.materials, cull_info=ci, depth=depth,
+                     screen=np.array([64, 36], np.uint32), vendor_note=np.frombuffer(b"hello", np.uint8))
+    d = orbitscene.read(p)
+    assert d["meshlets"].dtype == L.MESHLET and np.array_equal(d["meshlets"], s.meshlets)
+    assert np.array_equal(d["mesh_infos"], s.mesh_infos) and np.array_equal(d["entities"], s.entities)
+    assert np.array_equal(d["materials"], s.materials)
+    assert np.array_equal(d["entity_draws"], np.ascontiguousarray(s.entity_draw_buffer()).view(np.uint8).reshape(-1))
+    assert d["cull_info"].tobytes() == ci.tobytes() and d["depth"].shape == (36, 64) and np.array_equal(d["depth"], depth)
+    assert d["vendor_note"].tobytes() == b"hello"
+    (tmp_path / "bad").write_bytes(b"not a scene file at all")
+    with pytest.raises(ValueError):
+        orbitscene.read(tmp_path / "bad")
