@@ -5,7 +5,9 @@
 #include <cstdlib>
 #include <vector>
 
-template <int ROWS>  // rows (2 x dwordx4 per lane) in flight per wave
+// LINEAR: the two loads of a row are two fully contiguous 1 KiB reads (lane * 16 B) instead of the
+// record-interleaved pattern of meshlet_eval (lane * 32 B and lane * 32 B + 16)
+template <int ROWS, bool LINEAR = false>  // rows (2 x dwordx4 per lane) in flight per wave
 __global__ __launch_bounds__(256) void stream_kernel(const uint4 *src, size_t n_rows, unsigned *sink) {
     const int lane = threadIdx.x & 63;
     const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -16,9 +18,15 @@ __global__ __launch_bounds__(256) void stream_kernel(const uint4 *src, size_t n_
         uint4 a[ROWS], b[ROWS];
 #pragma unroll
         for (int k = 0; k < ROWS; k++) {
-            const uint4 *p = src + ((r0 + k) * 64 + lane) * 2;
-            a[k] = p[0];
-            b[k] = p[1];
+            if (LINEAR) {
+                const uint4 *p = src + (r0 + k) * 128 + lane;
+                a[k] = p[0];
+                b[k] = p[64];
+            } else {
+                const uint4 *p = src + ((r0 + k) * 64 + lane) * 2;
+                a[k] = p[0];
+                b[k] = p[1];
+            }
         }
 #pragma unroll
         for (int k = 0; k < ROWS; k++) acc += a[k].x ^ b[k].w;
@@ -26,14 +34,14 @@ __global__ __launch_bounds__(256) void stream_kernel(const uint4 *src, size_t n_
     if (acc == 0x12345678u) *sink = acc;
 }
 
-template <int ROWS>
+template <int ROWS, bool LINEAR = false>
 float run(const uint4 *src, size_t n_rows, unsigned *sink, int blocks) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(stream_kernel<ROWS>, dim3(blocks), dim3(256), 0, 0, src, n_rows, sink);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((stream_kernel<ROWS, LINEAR>), dim3(blocks), dim3(256), 0, 0, src, n_rows, sink);
     hipEventRecord(e0);
-    for (int i = 0; i < 10; i++) hipLaunchKernelGGL(stream_kernel<ROWS>, dim3(blocks), dim3(256), 0, 0, src, n_rows, sink);
+    for (int i = 0; i < 10; i++) hipLaunchKernelGGL((stream_kernel<ROWS, LINEAR>), dim3(blocks), dim3(256), 0, 0, src, n_rows, sink);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -58,6 +66,10 @@ int main() {
         printf(" rows=4 %.0f", bytes / (run<4>(src, n_rows, sink, blocks) * 1e-3) / 1e9);
         printf(" rows=6 %.0f", bytes / (run<6>(src, n_rows, sink, blocks) * 1e-3) / 1e9);
         printf(" rows=8 %.0f GB/s\n", bytes / (run<8>(src, n_rows, sink, blocks) * 1e-3) / 1e9);
+        printf("   linear 1 KiB loads:   rows=1 %.0f rows=2 %.0f rows=4 %.0f GB/s\n",
+               bytes / (run<1, true>(src, n_rows, sink, blocks) * 1e-3) / 1e9,
+               bytes / (run<2, true>(src, n_rows, sink, blocks) * 1e-3) / 1e9,
+               bytes / (run<4, true>(src, n_rows, sink, blocks) * 1e-3) / 1e9);
     }
     return 0;
 }
