@@ -47,7 +47,7 @@ class GpuScene:
 
 
 def run_gpu(torch, engine, gs, ci, evis=None, mvis=None, pyr=None, psize=(0, 0), disp_cap=None, draw_cap=None,
-            entity_draw_count=None):
+            entity_draw_count=None, material_count=0):
     s = gs.scene
     disp_cap = s.max_dispatches() + 8 if disp_cap is None else disp_cap
     n = s.entity_draw_count if entity_draw_count is None else entity_draw_count
@@ -60,7 +60,8 @@ def run_gpu(torch, engine, gs, ci, evis=None, mvis=None, pyr=None, psize=(0, 0),
     draw_cap = s.lod0_meshlets + 8 if draw_cap is None else draw_cap
     draw = torch.full((L.DRAW_HEADER + 28 * draw_cap + 256,), 0xCD, dtype=torch.uint8, device="cuda")
     engine.meshlet_cull(ci, disp, gs.meshlets, draw, gs.entities, gs.materials, disp_cap, draw_cap,
-                        meshlet_visibility_buffer=mvis_d, depth_pyramid=pyr_d, depth_pyramid_size=psize)
+                        meshlet_visibility_buffer=mvis_d, depth_pyramid=pyr_d, depth_pyramid_size=psize,
+                        material_count=material_count)  # 0: alpha modes gathered; > 0: staged in LDS by the kernels
     torch.cuda.synchronize()
     return (host(disp), host(draw), None if evis_d is None else host(evis_d, np.uint32),
             None if mvis_d is None else host(mvis_d, np.uint32))
@@ -573,7 +574,9 @@ def test_randomized_parameters(torch_mod, engine, oracle, seed):
         pyr, d = oracle.depth_reduce(sc.make_depth(seed, W, H, cam), W, H)
         ps = (d.width, d.height)
     gs = GpuScene(torch, scene)
-    assert_same(run_gpu(torch, engine, gs, ci, evis, mvis, pyr, ps), run_oracle(oracle, scene, ci, evis, mvis, pyr, ps))
+    mc = len(scene.materials) if seed % 2 else 0  # both alpha-mode paths of the kernels
+    assert_same(run_gpu(torch, engine, gs, ci, evis, mvis, pyr, ps, material_count=mc),
+                run_oracle(oracle, scene, ci, evis, mvis, pyr, ps))
     engine.status()
 
 
