@@ -36,7 +36,9 @@ struct OrbitCtx {
     uint32_t *c_chunk = nullptr; // compact: counts | bases | total
     float4 *a_view_lights = nullptr;
     uint32_t *a_light_flags = nullptr, *a_counts = nullptr, *a_block_sums = nullptr, *a_block_base = nullptr,
-             *a_total = nullptr;
+             *a_total = nullptr, *a_coarse = nullptr, *a_coarse_counts = nullptr;
+    float *a_aabb = nullptr, *a_group_box = nullptr;
+    uint32_t a_coarse_seg = 0;
     uint32_t *g_counts = nullptr; // gather_visible: per-rank command counts
     int32_t *status = nullptr;
     uint32_t debug_flags = 0;
@@ -194,6 +196,11 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     // assign: block_sums holds chunk sums | chunk bases of the two-level scan; block_base one word per cluster
     const size_t o_abs = carve((2 * ((size_t)caps.max_clusters / kScanChunk + 2) + 64) * 4);
     const size_t o_abb = carve(((size_t)caps.max_clusters + 256) * 4), o_at = carve(256);
+    // light assignment: cached cluster AABBs, and per group of 256 active clusters the coarse candidate lists
+    const size_t agroups = (size_t)caps.max_clusters / 256 + 1;
+    const size_t aseg = (((size_t)caps.max_lights + 15) / 16 + 63) / 64 * 64;
+    const size_t o_aab = carve(((size_t)caps.max_clusters + 256) * 6 * 4);
+    const size_t o_aco = carve(agroups * 16 * aseg * 4), o_acc = carve(agroups * 16 * 4), o_agb = carve(agroups * 32);
     ctx->arena_bytes = off;
     e = hipMalloc((void **)&ctx->arena, ctx->arena_bytes);
     if (e != hipSuccess) {
@@ -226,6 +233,11 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->a_block_sums = (uint32_t *)(a + o_abs);
     ctx->a_block_base = (uint32_t *)(a + o_abb);
     ctx->a_total = (uint32_t *)(a + o_at);
+    ctx->a_aabb = (float *)(a + o_aab);
+    ctx->a_coarse = (uint32_t *)(a + o_aco);
+    ctx->a_coarse_counts = (uint32_t *)(a + o_acc);
+    ctx->a_group_box = (float *)(a + o_agb);
+    ctx->a_coarse_seg = (uint32_t)aseg;
     ctx->g_counts = (uint32_t *)(a + o_gc);
     const char *dbg = getenv("ORBIT_SP_DEBUG");
     ctx->debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u;
@@ -561,6 +573,11 @@ int32_t orbit_cluster_assign(OrbitCtx *ctx, const OrbitClusterCullInfo *info, co
     p.view_lights = ctx->a_view_lights;
     p.light_flags = ctx->a_light_flags;
     p.counts = ctx->a_counts;
+    p.aabb = ctx->a_aabb;
+    p.coarse = ctx->a_coarse;
+    p.coarse_counts = ctx->a_coarse_counts;
+    p.group_box = ctx->a_group_box;
+    p.coarse_seg = ctx->a_coarse_seg;
     p.block_sums = ctx->a_block_sums;
     p.block_base = ctx->a_block_base;
     p.total = ctx->a_total;

@@ -100,6 +100,11 @@ struct ClusterAssignParams {
     float4 *view_lights;     // (x, y, z, r*r) per light in view space
     uint32_t *light_flags;   // bit i set = light i is a point light
     uint32_t *counts;        // per active cluster
+    float *aabb;             // 6 floats per active cluster (compacted order), written by the coarse launch
+    uint32_t *coarse;        // per group of 256 active clusters: 16 segments x coarse_seg candidate light indices
+    uint32_t *coarse_counts; // 16 per group
+    float *group_box;        // 8 floats per group: union AABB (6), any-NaN flag, unused
+    uint32_t coarse_seg;     // capacity of one segment (= lights per wave of the coarse filter, a multiple of 64)
     uint32_t *block_sums;
     uint32_t *block_base;
     uint32_t *total;

@@ -13,14 +13,14 @@
 //             order), header written last (active_cluster_compaction.comp:33-43).
 //   assign  : lights are transformed to view space ONCE (the reference redoes
 //             world_to_view x position per cluster per light,
-//             light_culling.comp:111).  A block owns 16 consecutive entries
-//             of the compacted list (neighbours along x) and first filters
-//             the lights against the UNION of their AABBs (thread = light,
-//             ordered LDS candidate list; sound because the sphere test is
-//             monotone in the box); then lane = candidate: a wave tests its 4
-//             clusters (AABBs in SGPRs), the hit ballots become popcounts in
-//             the count pass and ballot-ranked ordered writes in the write
-//             pass; ranges are allocated by prefix sum in compacted order.
+//             light_culling.comp:111) and cluster AABBs are computed once;
+//             then three conservative levels — all lights against the union
+//             box of 256 consecutive active clusters, those candidates
+//             against the union box of a block's 16 clusters, the survivors
+//             (lane = candidate) against the 4 AABBs a wave keeps in SGPRs:
+//             hit ballots become popcounts in the count pass and
+//             ballot-ranked ordered writes in the write pass; ranges are
+//             allocated by prefix sum in compacted order.
 #include "kernels.h"
 #include "scan.h"
 
@@ -217,53 +217,183 @@ __device__ __forceinline__ bool sphere_hits(const Aabb3 &a, const float4 l) {
     return sq <= l.w;
 }
 
-constexpr uint32_t kLightTile = 4096;  // lights filtered per step; their candidates (indices) live in LDS (16 KB)
+constexpr uint32_t kLightTile = 1024;  // coarse candidates a block filters per step; survivors live in LDS (20 KB)
 constexpr int kClustersPerWave = 4;    // cluster AABBs held in scalar registers per wave
 constexpr int kAssignWaves = 4;
 constexpr int kClustersPerBlock = kClustersPerWave * kAssignWaves;
+constexpr uint32_t kGroupClusters = 256; // coarse level: one candidate list per 256 consecutive active clusters
 constexpr uint32_t kNotPoint = 1u << 31; // candidate index flag: not a point light -> in every cluster (:116-118)
 
-// A block owns 16 consecutive entries of the compacted list — ascending linear index, i.e. mostly neighbours
-// along x in one (y, z) row — and works in two phases per 1024 lights:
-//   filter : thread = light against the UNION of the block's 16 AABBs; survivors are appended in ascending light
-//            order to an LDS candidate list (ballot ranks + a 4-wave prefix).  The union contains every member
-//            box, and aabb_sphere_test is monotone in the box (each clamp distance, each square and each partial
-//            sum can only shrink when the box grows, also in floating point), so no light that hits a member box
-//            is ever filtered out; a block whose boxes contain a NaN does not filter at all.
+// The assignment is a three-level cull of the (cluster, light) pairs, every level conservative for the next:
+//   coarse : a block owns 256 consecutive entries of the compacted list.  It computes their AABBs once
+//            (compute_cluster_volume, :62-90 — cached for the later launches), takes the UNION of the boxes and
+//            filters ALL lights against it: wave w takes the w-th quarter of the lights and appends the survivors,
+//            in light order, to its own segment of the group's candidate list (no barrier in the filter).
+//   filter : a block of the count / write launches owns 16 consecutive entries (neighbours along x); wave w
+//            filters coarse segment w against the union of those 16 boxes into an LDS segment.
 //   test   : lane = candidate.  A wave holds the AABBs of its 4 clusters in SGPRs, tests 64 candidates per step
 //            and turns the hit ballots into counts (WRITE = false, light_culling.comp:128-135) or into ascending
 //            index writes at the scanned offset (WRITE = true, :138-147).
-// The reference runs one thread per cluster over all lights, re-reading each 64-B light from memory twice and
-// redoing world_to_view x position per (cluster, light); with 10 k lights and 34 k active clusters the filter
-// leaves the exact test with a few per cent of the 6.8e8 (cluster, light) pairs.
+// A union contains every member box, and aabb_sphere_test is monotone in the box (each clamp distance, each square
+// and each partial sum can only shrink when the box grows, also in floating point), so no light that hits a member
+// box is ever filtered out; a union over boxes that contain a NaN does not filter at all.  Segment order == light
+// order, so the per-cluster lists come out ascending.  The reference runs one thread per cluster over all lights,
+// re-reading each 64-B light twice and redoing world_to_view x position per (cluster, light).
+struct BoxUnion {
+    Aabb3 box;
+    bool any_nan;
+};
+
+__device__ __forceinline__ void union_add(BoxUnion &u, const float lo[3], const float hi[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        u.any_nan = u.any_nan || lo[i] != lo[i] || hi[i] != hi[i];
+        u.box.mn[i] = lo[i] < u.box.mn[i] ? lo[i] : u.box.mn[i];
+        u.box.mx[i] = hi[i] > u.box.mx[i] ? hi[i] : u.box.mx[i];
+    }
+}
+
+constexpr uint32_t kCoarseSplit = 4;                    // blocks that share the lights of one group
+constexpr uint32_t kCoarseSegs = kCoarseSplit * 4;      // = waves per group = segments of its candidate list
+
+// coarse, part 1: AABBs of 256 consecutive active clusters (cached for every later launch) and their union.
+__global__ __launch_bounds__(256) void cluster_aabb_kernel(const ClusterAssignParams p) {
+    __shared__ float s_box[4][8];
+    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.unique);
+    const uint32_t n = min(hdr[3], p.max_clusters);
+    const uint32_t first = blockIdx.x * kGroupClusters;
+    if (first >= n) return; // block-uniform (the grid is a capacity bound)
+    const uint32_t *unique_idx = reinterpret_cast<const uint32_t *>(p.unique + ORBIT_COMPACT_HEADER);
+    const uint32_t u = first + threadIdx.x;
+    const float inf = __uint_as_float(0x7f800000u);
+    float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf}; // absent cluster: the empty box, neutral in the union
+    if (u < n) {
+        const Aabb3 box = cluster_aabb(p, unique_idx[u]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            lo[i] = box.mn[i], hi[i] = box.mx[i];
+            p.aabb[6 * (size_t)u + i] = box.mn[i];
+            p.aabb[6 * (size_t)u + 3 + i] = box.mx[i];
+        }
+    }
+    // union over the block: butterfly over the lanes, then over the four waves.  With a NaN anywhere the filter is
+    // bypassed (flag), so what the selects make of a NaN operand does not matter.
+    bool nan = false;
+#pragma unroll
+    for (int i = 0; i < 3; i++) nan = nan || lo[i] != lo[i] || hi[i] != hi[i];
+    const bool wave_nan = __ballot(nan) != 0ull;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float ol = __shfl_xor(lo[i], d, 64), oh = __shfl_xor(hi[i], d, 64);
+            lo[i] = ol < lo[i] ? ol : lo[i];
+            hi[i] = oh > hi[i] ? oh : hi[i];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) s_box[wave][i] = lo[i], s_box[wave][3 + i] = hi[i];
+        s_box[wave][6] = wave_nan ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        BoxUnion un;
+        un.any_nan = false;
+#pragma unroll
+        for (int i = 0; i < 3; i++) un.box.mn[i] = inf, un.box.mx[i] = -inf;
+        for (int w = 0; w < 4; w++) {
+            union_add(un, &s_box[w][0], &s_box[w][3]);
+            un.any_nan = un.any_nan || s_box[w][6] != 0.0f;
+        }
+        float *g = p.group_box + 8 * (size_t)blockIdx.x;
+#pragma unroll
+        for (int i = 0; i < 3; i++) g[i] = un.box.mn[i], g[3 + i] = un.box.mx[i];
+        g[6] = un.any_nan ? 1.0f : 0.0f;
+    }
+}
+
+// coarse, part 2: kCoarseSplit blocks per group; wave s of a group (s < kCoarseSegs) filters lights
+// [s * seg, (s + 1) * seg) against the group's union box into segment s of the group's list, in light order.
+__global__ __launch_bounds__(256) void cluster_coarse_kernel(const ClusterAssignParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.unique);
+    const uint32_t n = min(hdr[3], p.max_clusters);
+    const uint32_t group = blockIdx.x / kCoarseSplit;
+    if (group * kGroupClusters >= n) return; // block-uniform
+    const float *g = p.group_box + 8 * (size_t)group;
+    BoxUnion un;
+#pragma unroll
+    for (int i = 0; i < 3; i++) un.box.mn[i] = g[i], un.box.mx[i] = g[3 + i];
+    un.any_nan = g[6] != 0.0f;
+    const uint32_t nl = p.info.global_light_count, seg = p.coarse_seg;
+    const uint32_t sidx = (blockIdx.x % kCoarseSplit) * 4 + wave;
+    uint32_t *out = p.coarse + ((size_t)group * kCoarseSegs + sidx) * seg;
+    uint32_t cnt = 0;
+    const uint32_t begin = sidx * seg, end = min(begin + seg, nl);
+    for (uint32_t b0 = begin; b0 < end; b0 += 256) { // 4 loads per lane issued together
+        float4 l[4];
+        uint32_t pt = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < 4; r++) {
+            const uint32_t li = b0 + r * 64u + (uint32_t)lane;
+            const uint32_t gi = li < end ? li : 0u;
+            l[r] = p.view_lights[gi];
+            pt |= ((p.light_flags[gi >> 5] >> (gi & 31)) & 1u) << r;
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < 4; r++) {
+            const uint32_t li = b0 + r * 64u + (uint32_t)lane;
+            const bool point = (pt >> r) & 1u;
+            const bool pass = li < end && (!point || un.any_nan || sphere_hits(un.box, l[r]));
+            const uint64_t m = __ballot(pass);
+            if (pass) out[cnt + lane_prefix(m)] = li | (point ? 0u : kNotPoint);
+            cnt += (uint32_t)__popcll(m);
+        }
+    }
+    if (lane == 0) p.coarse_counts[group * kCoarseSegs + sidx] = cnt;
+}
+
 template <bool WRITE>
 __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const ClusterAssignParams p) {
-    __shared__ uint32_t s_cand_idx[kLightTile]; // a segment per wave, sized for "every light passes"
+    __shared__ float4 s_cand[kLightTile];       // a segment per wave: view-space light ...
+    __shared__ uint32_t s_cand_idx[kLightTile]; // ... and its index | kNotPoint
     __shared__ float s_box[kClustersPerBlock][6];
     __shared__ uint32_t s_wave_cnt[kAssignWaves];
+    __shared__ uint32_t s_cpre[kCoarseSegs + 1]; // prefix of the group's segment counts
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.unique);
     const uint32_t n = min(hdr[3], p.max_clusters);
     const uint32_t block_first = blockIdx.x * kClustersPerBlock;
     if (block_first >= n) return; // block-uniform (the grid is a capacity bound)
     const uint32_t u0 = block_first + wave * kClustersPerWave;
+    if (wave == 0) { // exclusive prefix of the 16 segment counts (one load per lane, wave scan)
+        const uint32_t *cc = p.coarse_counts + (size_t)(block_first / kGroupClusters) * kCoarseSegs;
+        const uint32_t v = lane < (int)kCoarseSegs ? cc[lane] : 0u;
+        const uint32_t inc = wave_inclusive_scan(v);
+        if (lane < (int)kCoarseSegs) s_cpre[lane] = inc - v;
+        if (lane == (int)kCoarseSegs - 1) s_cpre[kCoarseSegs] = inc;
+    }
     const uint32_t *unique_idx = reinterpret_cast<const uint32_t *>(p.unique + ORBIT_COMPACT_HEADER);
 
-    // lanes 0..3 build the AABBs of the wave's clusters; broadcast through readlane into SGPRs
+    // lanes 0..3 fetch the cached AABBs of the wave's clusters; broadcast through readlane into SGPRs
     Aabb3 box = {};
     uint32_t my_ci = 0, my_limit = 0, my_offset = 0;
     const bool owns = lane < kClustersPerWave && u0 + lane < n;
     if (owns) {
         my_ci = unique_idx[u0 + lane];
-        box = cluster_aabb(p, my_ci);
+#pragma unroll
+        for (int i = 0; i < 3; i++) box.mn[i] = p.aabb[6 * (size_t)(u0 + lane) + i], box.mx[i] = p.aabb[6 * (size_t)(u0 + lane) + 3 + i];
         if (WRITE) {
             my_limit = p.counts[u0 + lane];
-            my_offset = p.block_base[u0 + lane]; // exclusive prefix of the capped counts (scan of p.counts)
+            // exclusive prefix of the capped counts: chunk-local prefix + chunk base of the two-level scan
+            my_offset = p.block_base[u0 + lane] +
+                        (p.block_sums + (p.max_clusters / kScanChunk + 2))[(u0 + lane) / kScanChunk];
         }
     }
     if (lane < kClustersPerWave) {
         float *bx = s_box[wave * kClustersPerWave + lane];
-        // an absent cluster contributes the empty box (+inf, -inf): neutral in the union
         const float inf = __uint_as_float(0x7f800000u);
 #pragma unroll
         for (int i = 0; i < 3; i++) bx[i] = owns ? box.mn[i] : inf, bx[3 + i] = owns ? box.mx[i] : -inf;
@@ -284,63 +414,62 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
         valid[c] = u0 + c < n;
     }
     __syncthreads();
-    // union of the block's boxes (every thread computes the same six values), and whether any box holds a NaN
-    Aabb3 uni;
-    bool any_nan = false;
+    BoxUnion un;
+    un.any_nan = false;
+    {
+        const float inf = __uint_as_float(0x7f800000u);
 #pragma unroll
-    for (int i = 0; i < 3; i++) uni.mn[i] = s_box[0][i], uni.mx[i] = s_box[0][3 + i];
-    for (int c = 0; c < kClustersPerBlock; c++) {
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const float lo = s_box[c][i], hi = s_box[c][3 + i];
-            any_nan = any_nan || lo != lo || hi != hi;
-            uni.mn[i] = lo < uni.mn[i] ? lo : uni.mn[i];
-            uni.mx[i] = hi > uni.mx[i] ? hi : uni.mx[i];
-        }
+        for (int i = 0; i < 3; i++) un.box.mn[i] = inf, un.box.mx[i] = -inf;
     }
+    for (int c = 0; c < kClustersPerBlock; c++) union_add(un, &s_box[c][0], &s_box[c][3]);
+
     uint32_t *out = reinterpret_cast<uint32_t *>(p.light_index_buffer + ORBIT_LIGHT_INDEX_HEADER);
-    const uint32_t nl = p.info.global_light_count;
-    // A wave filters a contiguous quarter of each 4096-light tile into its own segment of the candidate list
-    // (segment order == light order, no block barrier inside the filter), in groups of 4 x 64 lights whose loads are
-    // issued together and one group ahead.  Candidates are light indices; the test phase re-reads the few survivors'
-    // 16 B from L2.
-    constexpr uint32_t kSeg = kLightTile / kAssignWaves, kRounds = 4, kGroups = kSeg / (64 * kRounds);
-    float4 lt[kRounds];
-    uint32_t pt = 0; // bit r: light of round r is a point light
-    auto load_group = [&](uint32_t first) { // lights first + r*64 + lane of this wave
-        pt = 0;
+    // The group's candidates in light order = its coarse segments back to back.  A step takes the next
+    // kLightTile entries of that sequence; wave w filters the w-th quarter of the step into LDS segment w.
+    constexpr uint32_t kSeg = kLightTile / kAssignWaves;
+    const uint32_t group = block_first / kGroupClusters;
+    const uint32_t *cbase = p.coarse + (size_t)group * kCoarseSegs * p.coarse_seg;
+    const uint32_t ctotal = s_cpre[kCoarseSegs];
+    auto coarse_at = [&](uint32_t k) -> uint32_t { // k-th candidate of the group, k < ctotal
+        uint32_t sg = 0; // last segment whose prefix is <= k (bisection over the 16 prefixes)
 #pragma unroll
-        for (uint32_t r = 0; r < kRounds; r++) {
-            const uint32_t li = first + r * 64u + (uint32_t)lane;
-            const uint32_t gi = li < nl ? li : 0u; // in-bounds dummy, masked by the range check in the filter
-            lt[r] = p.view_lights[gi];
-            pt |= ((p.light_flags[gi >> 5] >> (gi & 31)) & 1u) << r;
-        }
+        for (uint32_t half = kCoarseSegs / 2; half >= 1; half /= 2) sg += s_cpre[sg + half] <= k ? half : 0u;
+        return cbase[(size_t)sg * p.coarse_seg + (k - s_cpre[sg])];
     };
-    if (nl > 0) load_group(wave * kSeg);
-    for (uint32_t base = 0; base < nl; base += kLightTile) {
-        // ---- filter: this wave's segment
+    // one step = 1024 coarse candidates = one group of 4 (index, light) load pairs per lane; the next step's
+    // loads are issued before this step's test phase
+    uint32_t tag[4];
+    float4 l[4];
+    auto load_step = [&](uint32_t step0) {
+        const uint32_t s_begin = step0 + wave * kSeg, s_end = min(s_begin + kSeg, ctotal);
+#pragma unroll
+        for (uint32_t r = 0; r < 4; r++) {
+            const uint32_t k = s_begin + r * 64u + (uint32_t)lane;
+            tag[r] = k < s_end ? coarse_at(k) : 0u;
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < 4; r++) l[r] = p.view_lights[tag[r] & ~kNotPoint];
+    };
+    if (ctotal > 0) load_step(0);
+    for (uint32_t step0 = 0; step0 < ctotal; step0 += kLightTile) { // block-uniform trip count
+        // ---- filter: this wave's quarter of the step
         uint32_t seg_n = 0; // wave-uniform
-        for (uint32_t g = 0; g < kGroups; g++) {
-            const uint32_t first = base + wave * kSeg + g * (64u * kRounds);
-            float4 cur[kRounds];
-            const uint32_t cur_pt = pt;
+        const uint32_t s_begin = step0 + wave * kSeg, s_end = min(s_begin + kSeg, ctotal);
 #pragma unroll
-            for (uint32_t r = 0; r < kRounds; r++) cur[r] = lt[r];
-            // next group of this tile, or the first group of the next tile
-            const uint32_t next = g + 1 < kGroups ? first + 64u * kRounds : base + kLightTile + wave * kSeg;
-            if (next < nl) load_group(next);
-#pragma unroll
-            for (uint32_t r = 0; r < kRounds; r++) {
-                const uint32_t li = first + r * 64u + (uint32_t)lane;
-                const bool point = (cur_pt >> r) & 1u;
-                const bool pass = li < nl && (!point || any_nan || sphere_hits(uni, cur[r]));
-                const uint64_t m = __ballot(pass);
-                if (pass) s_cand_idx[wave * kSeg + seg_n + lane_prefix(m)] = li | (point ? 0u : kNotPoint);
-                seg_n += (uint32_t)__popcll(m);
+        for (uint32_t r = 0; r < 4; r++) {
+            const uint32_t k = s_begin + r * 64u + (uint32_t)lane;
+            const bool point = (tag[r] & kNotPoint) == 0u;
+            const bool pass = k < s_end && (!point || un.any_nan || sphere_hits(un.box, l[r]));
+            const uint64_t m = __ballot(pass);
+            if (pass) {
+                const uint32_t pos = wave * kSeg + seg_n + lane_prefix(m);
+                s_cand[pos] = l[r];
+                s_cand_idx[pos] = tag[r];
             }
+            seg_n += (uint32_t)__popcll(m);
         }
         if (lane == 0) s_wave_cnt[wave] = seg_n;
+        if (step0 + kLightTile < ctotal) load_step(step0 + kLightTile); // in flight during the test phase
         __syncthreads(); // all segments complete
         // ---- test: the wave's clusters against the candidates, segment by segment (ascending light order)
         for (uint32_t seg = 0; seg < (uint32_t)kAssignWaves; seg++) {
@@ -348,29 +477,29 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
             for (uint32_t b0 = 0; b0 < cnt; b0 += 64) {
                 const uint32_t ci = b0 + lane;
                 const bool in_list = ci < cnt;
-                const uint32_t tag = s_cand_idx[seg * kSeg + (in_list ? ci : 0)];
-                const bool point = (tag & kNotPoint) == 0u;
-                const float4 l = p.view_lights[tag & ~kNotPoint];
+                const float4 cl = s_cand[seg * kSeg + (in_list ? ci : 0)];
+                const uint32_t ctag = s_cand_idx[seg * kSeg + (in_list ? ci : 0)];
+                const bool point = (ctag & kNotPoint) == 0u;
 #pragma unroll
                 for (int c = 0; c < kClustersPerWave; c++) {
                     if (!valid[c]) continue; // wave-uniform
                     Aabb3 a;
 #pragma unroll
                     for (int i = 0; i < 3; i++) a.mn[i] = mn[c][i], a.mx[i] = mx[c][i];
-                    const bool hit = in_list && (!point || sphere_hits(a, l)); // :108-119
+                    const bool hit = in_list && (!point || sphere_hits(a, cl)); // :108-119
                     const uint64_t m = __ballot(hit);
                     if (WRITE) {
                         if (hit) {
                             const uint32_t k = count[c] + lane_prefix(m);
                             if (k < limit[c] && offset[c] + k < p.light_index_capacity) // while (counter < light_count), :140
-                                out[offset[c] + k] = tag & ~kNotPoint;
+                                out[offset[c] + k] = ctag & ~kNotPoint;
                         }
                     }
                     count[c] += (uint32_t)__popcll(m);
                 }
             }
         }
-        __syncthreads(); // candidates consumed before the next tile's filter overwrites them
+        __syncthreads(); // candidates consumed before the next step's filter overwrites them
     }
 #pragma unroll
     for (int c = 0; c < kClustersPerWave; c++) {
@@ -389,19 +518,6 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
         *reinterpret_cast<uint32_t *>(p.light_index_buffer) = total; // atomicAdd total, :136
         if (total > p.light_index_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
     }
-}
-
-// block_base[i] += chunk_base[i / kScanChunk]: makes the two-level scan's output a plain exclusive prefix
-__global__ __launch_bounds__(256) void cluster_assign_add_chunk_base(const ClusterAssignParams p) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < p.max_clusters) p.block_base[i] += (p.block_sums + (p.max_clusters / kScanChunk + 2))[i / kScanChunk];
-}
-
-// zeroes the counts of the capacity-bound tail so that the scan over all max_clusters entries is exact
-__global__ __launch_bounds__(256) void cluster_assign_clear_tail(const ClusterAssignParams p) {
-    const uint32_t n = min(reinterpret_cast<const uint32_t *>(p.unique)[3], p.max_clusters);
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n && i < p.max_clusters) p.counts[i] = 0u;
 }
 
 // header for an empty active list: light_count = 0 (cluster.rs:575-581)
@@ -449,15 +565,17 @@ hipError_t launch_cluster_assign(const ClusterAssignParams &p, hipStream_t s) {
         return hipGetLastError();
     }
     const uint32_t blocks = (p.max_clusters + kClustersPerBlock - 1) / kClustersPerBlock;
-    hipLaunchKernelGGL(cluster_assign_clear_tail, dim3((p.max_clusters + 255) / 256), dim3(256), 0, s, p);
+    const uint32_t groups = (p.max_clusters + kGroupClusters - 1) / kGroupClusters;
+    hipLaunchKernelGGL(cluster_aabb_kernel, dim3(groups), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(cluster_coarse_kernel, dim3(groups * kCoarseSplit), dim3(256), 0, s, p);
     hipLaunchKernelGGL(cluster_assign_kernel<false>, dim3(blocks), dim3(kAssignWaves * 64), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // exclusive scan of the per-cluster counts: chunk-local prefixes + chunk bases, folded into block_base
-    e = launch_scan_two_level(p.counts, p.block_base, nullptr, 1u, p.max_clusters, p.block_sums,
-                              p.block_sums + (p.max_clusters / kScanChunk + 2), p.total, s);
+    // exclusive scan of the counts of the n active clusters (n read on the device from the compacted header):
+    // chunk-local prefixes in block_base, chunk bases behind the chunk sums; the write launch adds the two
+    e = launch_scan_two_level(p.counts, p.block_base, reinterpret_cast<const uint32_t *>(p.unique) + 3, 1u,
+                              p.max_clusters, p.block_sums, p.block_sums + (p.max_clusters / kScanChunk + 2), p.total, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cluster_assign_add_chunk_base, dim3((p.max_clusters + 255) / 256), dim3(256), 0, s, p);
     hipLaunchKernelGGL(cluster_assign_kernel<true>, dim3(blocks), dim3(kAssignWaves * 64), 0, s, p);
     return hipGetLastError();
 }
