@@ -13,6 +13,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The built libraries are git-ignored: in a fresh checkout build them before the first test imports them
+    (hipcc cross-compiles gfx950 without a GPU; a few minutes once, nothing when they are up to date)."""
+    import subprocess
+
+    missing = [d for d, so in (("orbit_amd/csrc", "orbit_amd/liborbit_cull.so"), ("orbit_amd/host", "orbit_amd/liborbit_host.so"))
+               if not os.path.exists(os.path.join(ROOT, so))]
+    for d in missing:
+        subprocess.run(["make", "-C", os.path.join(ROOT, d), "-j8", "-s"], check=True)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as o
