@@ -21,6 +21,15 @@
 // Tile bases come from a prefix sum over per-tile survivor counts: eval launch
 // -> scan -> emit launch.  (A single-launch variant with a decoupled look-back
 // was measured slower on MI355X and removed: profiles/r01_notes.md.)
+//
+//   pass 0 / 2 : meshlet_eval_kernel streams every meshlet of every record; in
+//                pass 2 the HiZ test runs on candidates compacted in LDS.
+//   pass 1     : meshlet_pass1_kernel is list-driven — only meshlets whose
+//                last-frame bit is set are read at all.
+//   outputs    : MeshletDrawCommandBuffer (meshlet_emit_kernel<false>), the
+//                sharded engine's 8-B visible list (<true>) with
+//                visible_expand_kernel on the receiving side, or per-record
+//                task payloads for the mesh-shading path (task_records_kernel).
 #include "kernels.h"
 #include "scan.h"
 
