@@ -89,10 +89,11 @@ __global__ __launch_bounds__(256) void cluster_mark_kernel(const ClusterMarkPara
 }
 
 // -------------------------------------------------- active_cluster_compaction
-// One 1024-thread block per (chunk of 1024 tiles, z slice).
+// One 1024-thread block per (chunk of 1024 tiles, z slice).  The emit launch sums the counts of the preceding
+// (slice, chunk) slots itself — at most a few thousand words from L2 — instead of a scan launch in between; block
+// (0, 0) sums all of them for the header.
 template <bool EMIT>
-__global__ __launch_bounds__(1024) void cluster_compact_kernel(const ClusterCompactParams p, const uint32_t *chunk_base,
-                                                               const uint32_t *total) {
+__global__ __launch_bounds__(1024) void cluster_compact_kernel(const ClusterCompactParams p) {
     __shared__ uint32_t smem[1024 / 64 + 1];
     const uint32_t tiles = p.cc[0] * p.cc[1];
     const uint32_t z = blockIdx.y, chunk = blockIdx.x;
@@ -105,16 +106,28 @@ __global__ __launch_bounds__(1024) void cluster_compact_kernel(const ClusterComp
         if (threadIdx.x == 0) p.chunk_counts[slot_index] = block_total;
     } else {
         uint32_t *idx = reinterpret_cast<uint32_t *>(p.unique + ORBIT_COMPACT_HEADER);
-        const uint32_t pos = chunk_base[slot_index] + ex;
+        const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+        const uint32_t slots = gridDim.x * gridDim.y, upto = first ? slots : slot_index;
+        uint32_t part = 0;
+        for (uint32_t k = threadIdx.x; k < upto; k += 1024) part += p.chunk_counts[k];
+        part = wave_reduce_add(part);
+        __syncthreads(); // smem of the scan above is free again
+        if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = part;
+        __syncthreads();
+        uint32_t preceding = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) preceding += smem[w];
+        const uint32_t total = preceding; // meaningful in block (0, 0) only
+        const uint32_t pos = (first ? 0u : preceding) + ex;
         if (active && pos < p.index_capacity) idx[pos] = i + z * tiles; // cluster_common.glsl:1-4
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-            const uint32_t n = min(*total, p.index_capacity);
+        if (first && threadIdx.x == 0) {
+            const uint32_t n = min(total, p.index_capacity);
             uint32_t *hdr = reinterpret_cast<uint32_t *>(p.unique);
             hdr[0] = (n + 255u) / 256u; // active_cluster_compaction.comp:38-41
             hdr[1] = 1u;
             hdr[2] = 1u;
             hdr[3] = n;
-            if (*total > p.index_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+            if (total > p.index_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
         }
     }
 }
@@ -536,20 +549,14 @@ hipError_t launch_cluster_compact(const ClusterCompactParams &p, hipStream_t s) 
     const uint32_t tiles = p.cc[0] * p.cc[1];
     const uint32_t nchunks = (tiles + 1023) / 1024;
     const uint32_t cz = p.cc[2];
-    uint32_t *chunk_base = p.chunk_counts + (size_t)cz * nchunks;
-    uint32_t *total = chunk_base + (size_t)cz * nchunks;
     if (nchunks == 0 || cz == 0) {
         hipLaunchKernelGGL(write_word, dim3(1), dim3(1), 0, s, reinterpret_cast<uint32_t *>(p.unique) + 3, 0u);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(cluster_compact_kernel<false>, dim3(nchunks, cz), dim3(1024), 0, s, p,
-                       (const uint32_t *)nullptr, (const uint32_t *)nullptr);
-    hipError_t e = hipGetLastError();
+    hipLaunchKernelGGL(cluster_compact_kernel<false>, dim3(nchunks, cz), dim3(1024), 0, s, p);
+    const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = launch_scan_exclusive(p.chunk_counts, chunk_base, cz * nchunks, total, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cluster_compact_kernel<true>, dim3(nchunks, cz), dim3(1024), 0, s, p,
-                       (const uint32_t *)chunk_base, (const uint32_t *)total);
+    hipLaunchKernelGGL(cluster_compact_kernel<true>, dim3(nchunks, cz), dim3(1024), 0, s, p);
     return hipGetLastError();
 }
 
