@@ -100,6 +100,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise OSError(f"{LIB_PATH} is missing: build it with `make -C orbit_amd/csrc` or "
                       "`python -c 'import __graft_entry__ as g; g.build()'` (there is no fallback path)")
+    try:
+        # torch ships its own libamdhip64; if it is going to be used in this process it has to be the copy the
+        # library binds to as well (two HIP runtimes in one process: the second one finds no device)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
