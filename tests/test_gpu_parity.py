@@ -504,6 +504,23 @@ def test_task_records(torch_mod, engine, oracle, occlusion_pass, ortho):
         assert np.array_equal(host(mvis_d, np.uint32), omv), "meshlet visibility words differ"
 
 
+# ----------------------------------------------------------------------------- LOD arithmetic edge cases
+@pytest.mark.parametrize("lod_base,lod_step,target", [
+    (16.0, 1.0, (0.0, 0.0, 0.0)),      # log2(lod_step) == 0: division by zero in the LOD formula (entity_cull.comp:206)
+    (0.0, 2.0, (0.0, 0.0, 0.0)),       # lod_base == 0: distance / 0
+    (1e-30, 1.0001, (1e20, 0.0, 0.0)), # huge LOD values: uint() saturation
+    (16.0, 0.5, (5.0, 5.0, 5.0)),      # lod_step < 1: negative log
+    (float("nan"), 2.0, (0.0, 0.0, 0.0)), (16.0, 2.0, (float("inf"), 0.0, float("nan")))])
+def test_lod_selection_edge_cases(torch_mod, engine, oracle, lod_base, lod_step, target):
+    scene = sc.make_scene(81, 500, n_meshes=60, lods=5, meshlets_per_mesh=(1, 50))
+    cam = sc.default_camera(rot=(0.1, 0.2))
+    for lod_range in ((0, 8), (1, 3), (4, 5)):
+        ci = sc.make_cull_info(cam.view, cam.planes, lod_base=lod_base, lod_step=lod_step, lod_target=target,
+                               lod_range=lod_range)
+        gs = GpuScene(torch_mod, scene)
+        assert_same(run_gpu(torch_mod, engine, gs, ci), run_oracle(oracle, scene, ci))
+
+
 # ----------------------------------------------------------------------------- shadow cascades
 @pytest.mark.parametrize("cascade", range(4))
 def test_shadow_cascade_cull(torch_mod, engine, oracle, cascade):
