@@ -34,6 +34,53 @@ __global__ __launch_bounds__(256) void stream_kernel(const uint4 *src, size_t n_
     if (acc == 0x12345678u) *sink = acc;
 }
 
+// TILED: the access order of meshlet_eval — a wave walks the 8 consecutive rows of a 16-KiB tile one after the other
+// (two row buffers), then jumps a whole grid stride of tiles; at any moment neighbouring waves touch addresses 16 KiB
+// apart, not adjacent rows.
+// ROTATE: wave w starts its tile at row w % 8 and wraps around, so that concurrently running waves are at different
+// 2-KiB offsets inside their 16-KiB tiles.
+template <bool ROTATE>
+__global__ __launch_bounds__(256) void stream_tiled_kernel(const uint4 *src, size_t n_rows, unsigned *sink) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t stride = (size_t)gridDim.x * 4;
+    const size_t n_tiles = n_rows / 8;
+    unsigned acc = 0;
+    for (size_t t = wave; t < n_tiles; t += stride) {
+        const uint4 *p = src + (t * 8 * 64 + lane) * 2;
+        const int r0 = ROTATE ? (int)(wave & 7) : 0;
+        uint4 a0 = p[r0 * 128], b0 = p[r0 * 128 + 1];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint4 a1 = a0, b1 = b0;
+            if (r < 7) {
+                const int rr = (r0 + r + 1) & 7;
+                a1 = p[rr * 128];
+                b1 = p[rr * 128 + 1];
+            }
+            acc += a0.x ^ b0.w;
+            a0 = a1;
+            b0 = b1;
+        }
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+
+template <bool ROTATE>
+float run_tiled(const uint4 *src, size_t n_rows, unsigned *sink, int blocks) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(stream_tiled_kernel<ROTATE>, dim3(blocks), dim3(256), 0, 0, src, n_rows, sink);
+    hipEventRecord(e0);
+    for (int i = 0; i < 10; i++) hipLaunchKernelGGL(stream_tiled_kernel<ROTATE>, dim3(blocks), dim3(256), 0, 0, src, n_rows, sink);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms / 10;
+}
+
 template <int ROWS, bool LINEAR = false>
 float run(const uint4 *src, size_t n_rows, unsigned *sink, int blocks) {
     hipEvent_t e0, e1;
@@ -66,6 +113,9 @@ int main() {
         printf(" rows=4 %.0f", bytes / (run<4>(src, n_rows, sink, blocks) * 1e-3) / 1e9);
         printf(" rows=6 %.0f", bytes / (run<6>(src, n_rows, sink, blocks) * 1e-3) / 1e9);
         printf(" rows=8 %.0f GB/s\n", bytes / (run<8>(src, n_rows, sink, blocks) * 1e-3) / 1e9);
+        printf("   tile order (8 rows of a 16-KiB tile per wave, then a grid stride): %.0f GB/s; rotated start row: %.0f GB/s\n",
+               bytes / (run_tiled<false>(src, n_rows, sink, blocks) * 1e-3) / 1e9,
+               bytes / (run_tiled<true>(src, n_rows, sink, blocks) * 1e-3) / 1e9);
         printf("   linear 1 KiB loads:   rows=1 %.0f rows=2 %.0f rows=4 %.0f GB/s\n",
                bytes / (run<1, true>(src, n_rows, sink, blocks) * 1e-3) / 1e9,
                bytes / (run<2, true>(src, n_rows, sink, blocks) * 1e-3) / 1e9,
