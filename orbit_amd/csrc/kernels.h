@@ -134,8 +134,5 @@ hipError_t launch_scan_two_level(const uint32_t *in, uint32_t *out_local, const 
 // First level only (out_local and chunk_sums); the consumer scans the chunk sums itself.
 hipError_t launch_scan_chunks(const uint32_t *in, uint32_t *out_local, const uint32_t *n_src, uint32_t div,
                               uint32_t n_max, uint32_t *chunk_sums, hipStream_t s);
-// Same, with n read on the device: n = min(ceil(*n_src / div), n_max).
-hipError_t launch_scan_exclusive_indirect(const uint32_t *in, uint32_t *out, const uint32_t *n_src, uint32_t div,
-                                          uint32_t n_max, uint32_t *total, hipStream_t s);
 
 } // namespace orbit

@@ -1,0 +1,81 @@
+// scan.hip — device-wide exclusive prefix sums used by the ordered compactions.
+//
+// Every append on the path is a prefix sum (canonical sequential order, never atomics): a single-block scan for short
+// inputs and a two-level form for long ones — chunk-local prefixes + chunk sums per block, then a scan of the (few)
+// chunk sums which most consumers redo themselves in LDS instead of paying a launch for it.
+#include "kernels.h"
+#include "scan.h"
+
+namespace orbit {
+
+namespace {
+
+// Single-block exclusive scan with carry over chunks of 1024.
+__global__ __launch_bounds__(1024) void scan_exclusive_kernel(const uint32_t *in, uint32_t *out, uint32_t n,
+                                                              const uint32_t *n_src, uint32_t div, uint32_t *total) {
+    __shared__ uint32_t smem[1024 / 64 + 1];
+    if (n_src) n = min((*n_src + div - 1u) / div, n);
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? in[i] : 0u;
+        uint32_t chunk_total;
+        const uint32_t ex = block_exclusive_scan<16>(v, smem, &chunk_total);
+        if (i < n) out[i] = carry + ex;
+        carry += chunk_total;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+// Two-level scan for long inputs: each block scans a chunk of kScanChunk words
+// (exclusive, chunk-local) and emits the chunk sum; a second single-block launch
+// scans the chunk sums.  Consumers add chunk_base[i / kScanChunk] themselves.
+__global__ __launch_bounds__(1024) void scan_chunks_kernel(const uint32_t *in, uint32_t *out, uint32_t n,
+                                                           const uint32_t *n_src, uint32_t div, uint32_t *chunk_sums) {
+    __shared__ uint32_t smem[1024 / 64 + 1];
+    if (n_src) n = min((*n_src + div - 1u) / div, n);
+    const uint32_t base = blockIdx.x * kScanChunk;
+    if (base >= n) { // block-uniform
+        if (threadIdx.x == 0) chunk_sums[blockIdx.x] = 0u;
+        return;
+    }
+    uint32_t carry = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kScanChunk / 1024; k++) {
+        const uint32_t i = base + k * 1024 + threadIdx.x;
+        const uint32_t v = i < n ? in[i] : 0u;
+        uint32_t sub_total;
+        const uint32_t ex = block_exclusive_scan<16>(v, smem, &sub_total);
+        if (i < n) out[i] = carry + ex;
+        carry += sub_total;
+    }
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = carry;
+}
+
+} // namespace
+
+hipError_t launch_scan_chunks(const uint32_t *in, uint32_t *out_local, const uint32_t *n_src, uint32_t div,
+                              uint32_t n_max, uint32_t *chunk_sums, hipStream_t s) {
+    const uint32_t chunks = (n_max + kScanChunk - 1) / kScanChunk;
+    if (chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(scan_chunks_kernel, dim3(chunks), dim3(1024), 0, s, in, out_local, n_max, n_src, div, chunk_sums);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_two_level(const uint32_t *in, uint32_t *out_local, const uint32_t *n_src, uint32_t div,
+                                 uint32_t n_max, uint32_t *chunk_sums, uint32_t *chunk_base, uint32_t *total,
+                                 hipStream_t s) {
+    const uint32_t chunks = (n_max + kScanChunk - 1) / kScanChunk;
+    if (chunks == 0) return hipSuccess;
+    const hipError_t e = launch_scan_chunks(in, out_local, n_src, div, n_max, chunk_sums, s);
+    if (e != hipSuccess) return e;
+    return launch_scan_exclusive(chunk_sums, chunk_base, chunks, total, s);
+}
+
+hipError_t launch_scan_exclusive(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, hipStream_t s) {
+    hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, s, in, out, n, (const uint32_t *)nullptr, 1u,
+                       total);
+    return hipGetLastError();
+}
+
+} // namespace orbit

@@ -7,6 +7,6 @@ make -C orbit_amd/csrc -s -j4 || exit 1
 mkdir -p tools/variants
 /opt/rocm/bin/hipcc $flags "$@" -c orbit_amd/csrc/meshlet_cull.hip -o tools/variants/$name.o || exit 1
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/variants/$name.so tools/variants/$name.o \
-    orbit_amd/csrc/abi.o orbit_amd/csrc/entity_cull.o orbit_amd/csrc/depth_reduce.o orbit_amd/csrc/light_cluster.o || exit 1
+    orbit_amd/csrc/abi.o orbit_amd/csrc/scan.o orbit_amd/csrc/entity_cull.o orbit_amd/csrc/depth_reduce.o orbit_amd/csrc/light_cluster.o || exit 1
 rm -f tools/variants/$name.o
 echo "built tools/variants/$name.so"
