@@ -248,6 +248,26 @@ def test_depth_reduce(torch_mod, engine, oracle, size):
     assert np.array_equal(host(gpyr, np.uint32), opyr.view(np.uint32))
 
 
+@pytest.mark.parametrize("seed", range(max(16, int(os.environ.get("ORBIT_FUZZ_SEEDS", "16")) // 4)))
+def test_randomized_depth_reduce(torch_mod, engine, oracle, seed):
+    """Random screen sizes down to 1 x 1 and extreme aspect ratios; arbitrary float bit patterns in the depth buffer
+    (NaN, inf, negatives, denormals): the ReduceMin selects must pick the same words as the oracle."""
+    torch = torch_mod
+    rng = np.random.default_rng(7000 + seed)
+    W = int(rng.choice([1, 2, 3, 17, 64, 255, 257, int(rng.integers(1, 700))]))
+    H = int(rng.choice([1, 2, 5, 33, 128, 129, int(rng.integers(1, 400))]))
+    depth = rng.random((H, W), dtype=np.float32)
+    if seed % 2:
+        bits = rng.integers(0, 2 ** 32, (H, W), dtype=np.uint32)
+        pick = rng.random((H, W)) < 0.3
+        depth = np.where(pick, bits.view(np.float32), depth).astype(np.float32)
+    opyr, d = oracle.depth_reduce(depth, W, H)
+    gpyr = torch.full((d.total_texels,), -1.0, dtype=torch.float32, device="cuda")
+    engine.depth_reduce(dev(torch, depth), W, H, gpyr)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(gpyr, np.uint32), opyr.view(np.uint32)), (W, H)
+
+
 def test_orthographic(torch_mod, engine, oracle):
     torch = torch_mod
     scene = sc.make_scene(13, 700, extent=(20.0, 6.0, 20.0))
