@@ -66,6 +66,76 @@ __global__ __launch_bounds__(256) void stream_tiled_kernel(const uint4 *src, siz
     if (acc == 0x12345678u) *sink = acc;
 }
 
+
+// BLOCK-TILE: the assignment a row-interleaved meshlet_eval would use — a block of 8 waves owns one 16-KiB tile per
+// step (wave = row), blocks take tiles grid-stride, one block barrier per step (the slab hand-over), next tile's row
+// in flight during the "evaluation" of the current one.  TR = rows per tile for the plain tile order (TR < 8 probes
+// whether smaller wave tiles recover the row-interleaved rate).
+template <bool BARRIER>
+__global__ __launch_bounds__(512) void stream_blocktile_kernel(const uint4 *src, size_t n_rows, unsigned *sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t n_tiles = n_rows / 8;
+    unsigned acc = 0;
+    size_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const uint4 *p = src + ((t * 8 + wave) * 64 + lane) * 2;
+    uint4 a0 = p[0], b0 = p[1];
+    for (; t < n_tiles; t += gridDim.x) {
+        const size_t tn = t + gridDim.x;
+        uint4 a1 = a0, b1 = b0;
+        if (tn < n_tiles) {
+            const uint4 *q = src + ((tn * 8 + wave) * 64 + lane) * 2;
+            a1 = q[0];
+            b1 = q[1];
+        }
+        acc += a0.x ^ b0.w;
+        if (BARRIER) __syncthreads();
+        a0 = a1;
+        b0 = b1;
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+
+template <int TR>
+__global__ __launch_bounds__(256) void stream_tiled_n_kernel(const uint4 *src, size_t n_rows, unsigned *sink) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t stride = (size_t)gridDim.x * 4;
+    const size_t n_tiles = n_rows / TR;
+    unsigned acc = 0;
+    for (size_t t = wave; t < n_tiles; t += stride) {
+        const uint4 *p = src + (t * TR * 64 + lane) * 2;
+        uint4 a0 = p[0], b0 = p[1];
+#pragma unroll
+        for (int r = 0; r < TR; r++) {
+            uint4 a1 = a0, b1 = b0;
+            if (r < TR - 1) {
+                a1 = p[(r + 1) * 128];
+                b1 = p[(r + 1) * 128 + 1];
+            }
+            acc += a0.x ^ b0.w;
+            a0 = a1;
+            b0 = b1;
+        }
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+
+template <typename K>
+float time_kernel(K launch) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 3; i++) launch();
+    hipEventRecord(e0);
+    for (int i = 0; i < 10; i++) launch();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms / 10;
+}
+
 template <bool ROTATE>
 float run_tiled(const uint4 *src, size_t n_rows, unsigned *sink, int blocks) {
     hipEvent_t e0, e1;
@@ -116,6 +186,18 @@ int main() {
         printf("   tile order (8 rows of a 16-KiB tile per wave, then a grid stride): %.0f GB/s; rotated start row: %.0f GB/s\n",
                bytes / (run_tiled<false>(src, n_rows, sink, blocks) * 1e-3) / 1e9,
                bytes / (run_tiled<true>(src, n_rows, sink, blocks) * 1e-3) / 1e9);
+        {
+            const int b8 = blocks / 2; // 8-wave blocks, same waves per CU
+            auto gb = [&](float ms) { return bytes / (ms * 1e-3) / 1e9; };
+            printf("   block-tile (8-wave block = tile, wave = row): barrier %.0f, no barrier %.0f GB/s\n",
+                   gb(time_kernel([&] { hipLaunchKernelGGL(stream_blocktile_kernel<true>, dim3(b8), dim3(512), 0, 0, src, n_rows, sink); })),
+                   gb(time_kernel([&] { hipLaunchKernelGGL(stream_blocktile_kernel<false>, dim3(b8), dim3(512), 0, 0, src, n_rows, sink); })));
+            printf("   tile order with TR rows per tile: TR=2 %.0f TR=4 %.0f TR=8 %.0f TR=16 %.0f GB/s\n",
+                   gb(time_kernel([&] { hipLaunchKernelGGL(stream_tiled_n_kernel<2>, dim3(blocks), dim3(256), 0, 0, src, n_rows, sink); })),
+                   gb(time_kernel([&] { hipLaunchKernelGGL(stream_tiled_n_kernel<4>, dim3(blocks), dim3(256), 0, 0, src, n_rows, sink); })),
+                   gb(time_kernel([&] { hipLaunchKernelGGL(stream_tiled_n_kernel<8>, dim3(blocks), dim3(256), 0, 0, src, n_rows, sink); })),
+                   gb(time_kernel([&] { hipLaunchKernelGGL(stream_tiled_n_kernel<16>, dim3(blocks), dim3(256), 0, 0, src, n_rows, sink); })));
+        }
         printf("   linear 1 KiB loads:   rows=1 %.0f rows=2 %.0f rows=4 %.0f GB/s\n",
                bytes / (run<1, true>(src, n_rows, sink, blocks) * 1e-3) / 1e9,
                bytes / (run<2, true>(src, n_rows, sink, blocks) * 1e-3) / 1e9,
