@@ -869,7 +869,30 @@ __global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullPara
 
 // Visible list -> MeshletDrawCommandBuffer (meshlet_cull.comp:216-230 for survivors that were culled on another GPU):
 // lane = survivor, Meshlet bytes 16..31 gathered from the (replicated) meshlet buffer, commands staged through LDS
-// so that every store covers 256 contiguous bytes.  Grid-stride over chunks of 64 survivors per wave.
+// so that every store covers 256 contiguous bytes.  Grid-stride over chunks of 64 survivors per wave, software
+// pipelined: the items of chunk i+2 and the gathers of chunk i+1 are in flight while chunk i is written.  All loads
+// are unconditional (lanes past the list read the zero page) and the stores are buffer stores whose offset is out
+// of range for the words past the list, so the code is straight-line and every vmcnt wait is exact.
+struct ExpandChunk {
+    uint2 item;  // {meshlet_index, entity_index}
+    bool valid;
+};
+
+__device__ __forceinline__ ExpandChunk expand_load_items(const uint2 *items, uint32_t first, uint32_t n, int lane,
+                                                         const void *zero_page) {
+    ExpandChunk c;
+    const uint32_t i = first + (uint32_t)lane;
+    c.valid = first < n && i < n; // first can wrap past 2^32 only with n near 2^32: excluded by draw_capacity
+    c.item = *(c.valid ? items + i : reinterpret_cast<const uint2 *>(zero_page));
+    return c;
+}
+
+__device__ __forceinline__ uint4 expand_gather(const OrbitMeshlet *meshlets, const ExpandChunk &c,
+                                               const void *zero_page) {
+    return *(c.valid ? reinterpret_cast<const uint4 *>(meshlets + c.item.x) + 1
+                     : reinterpret_cast<const uint4 *>(zero_page));
+}
+
 __global__ __launch_bounds__(256) void visible_expand_kernel(const uint8_t *visible, const OrbitMeshlet *meshlets,
                                                              uint8_t *draw_buffer, uint32_t draw_capacity,
                                                              const void *zero_page, int32_t *status) {
@@ -879,33 +902,39 @@ __global__ __launch_bounds__(256) void visible_expand_kernel(const uint8_t *visi
     const uint32_t total = *reinterpret_cast<const uint32_t *>(visible);
     const uint32_t n = min(total, draw_capacity);
     const uint2 *items = reinterpret_cast<const uint2 *>(visible + ORBIT_VISIBLE_HEADER);
-    uint32_t *out = reinterpret_cast<uint32_t *>(draw_buffer + ORBIT_DRAW_HEADER);
+    uint8_t *out = draw_buffer + ORBIT_DRAW_HEADER;
     const uint32_t stride = gridDim.x * 4u * 64u;
-    for (uint32_t first = (blockIdx.x * 4u + wave) * 64u; first < n; first += stride) {
-        const uint32_t i = first + (uint32_t)lane;
-        const bool valid = i < n;
-        const uint2 it = valid ? items[i] : make_uint2(0u, 0u);
-        const uint4 b = *(valid ? reinterpret_cast<const uint4 *>(meshlets + it.x) + 1
-                                : reinterpret_cast<const uint4 *>(zero_page));
+    // wave-uniform, and provably so for the compiler (buffer descriptors live in SGPRs)
+    uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 4u + wave) * 64u));
+    ExpandChunk c0 = expand_load_items(items, first, n, lane, zero_page);
+    ExpandChunk c1 = expand_load_items(items, first + stride, n, lane, zero_page);
+    uint4 b0 = expand_gather(meshlets, c0, zero_page);
+    for (; first < n; first += stride) {
+        const ExpandChunk c2 = expand_load_items(items, first + 2u * stride, n, lane, zero_page);
+        const uint4 b1 = expand_gather(meshlets, c1, zero_page);
         uint32_t *c = cmd + lane * 7;
-        c[0] = (b.w >> 24) * 3u;                    // cmd_index_count = triangle_count * 3
-        c[1] = 1u;                                  // cmd_instance_count
-        c[2] = (b.z + ((b.w >> 16) & 0xFFu)) * 4u;  // cmd_first_index = (data_offset + vertex_count) * 4
-        c[3] = b.z;                                 // cmd_vertex_offset = int(data_offset)
-        c[4] = it.y;                                // cmd_first_instance = entity_index
-        c[5] = b.y;                                 // meshlet_vertex_offset
-        c[6] = it.x;                                // meshlet_index
+        c[0] = (b0.w >> 24) * 3u;                     // cmd_index_count = triangle_count * 3
+        c[1] = 1u;                                    // cmd_instance_count
+        c[2] = (b0.z + ((b0.w >> 16) & 0xFFu)) * 4u;  // cmd_first_index = (data_offset + vertex_count) * 4
+        c[3] = b0.z;                                  // cmd_vertex_offset = int(data_offset)
+        c[4] = c0.item.y;                             // cmd_first_instance = entity_index
+        c[5] = b0.y;                                  // meshlet_vertex_offset
+        c[6] = c0.item.x;                             // meshlet_index
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t words = min(n - first, 64u) * 7u;
-        uint32_t *dst = out + (size_t)first * 7u;
+        // the chunk's commands as one range-checked window: words past the list fall outside and are dropped
+        const uint32_t bytes = min(n - first, 64u) * 28u;
+        const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)first * 28u, 0, bytes, 0x00020000);
 #pragma unroll
         for (uint32_t k = 0; k < 7; k++) {
             const uint32_t w = k * 64u + (uint32_t)lane;
-            if (w < words) dst[w] = cmd[w];
+            __builtin_amdgcn_raw_buffer_store_b32(cmd[w], win, w * 4u, 0, 0);
         }
-        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_wave_barrier(); // cmd is rewritten by the next chunk
+        c0 = c1;
+        c1 = c2;
+        b0 = b1;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *reinterpret_cast<uint32_t *>(draw_buffer) = n;
