@@ -7,6 +7,7 @@
 #include <string>
 
 #include "orbit_host.hpp"
+#include "orbit_scene.hpp"
 
 using namespace orbit;
 using namespace orbit::passes;
@@ -80,6 +81,23 @@ int32_t guarded(F &&f) {
         g_err = e.what();
         return ORBIT_HOST_PANIC;
     }
+}
+} // namespace
+
+namespace {
+collections::Index to_index(OrbitHostArenaIndex i) { return {i.generation, i.slot}; }
+OrbitHostArenaIndex from_index(collections::Index i) { return {i.generation, i.slot}; }
+Quat to_quat(const float q[4]) {
+    Quat o;
+    o.x = q[0], o.y = q[1], o.z = q[2], o.w = q[3];
+    return o;
+}
+passes::Transform to_transform(const float position[3], const float orientation[4], const float scale[3]) {
+    passes::Transform t;
+    t.position = {position[0], position[1], position[2]};
+    t.orientation = to_quat(orientation);
+    t.scale = {scale[0], scale[1], scale[2]};
+    return t;
 }
 } // namespace
 
@@ -266,6 +284,117 @@ int32_t orbit_host_compute_clusters(void *hctx, const OrbitHostClusterSettings *
         out->light_index_list = to_buf(r.light_index_list);
         out->info = r.info;
     });
+}
+
+// ---------------------------------------------------------------- scene side (orbit_scene.hpp), host only
+void *orbit_host_arena_create(void) { return new collections::Arena<int64_t>(); }
+void orbit_host_arena_destroy(void *arena) { delete (collections::Arena<int64_t> *)arena; }
+OrbitHostArenaIndex orbit_host_arena_insert(void *arena, int64_t value) {
+    return from_index(((collections::Arena<int64_t> *)arena)->insert(value));
+}
+int32_t orbit_host_arena_get(const void *arena, OrbitHostArenaIndex index, int64_t *out) {
+    const int64_t *v = ((const collections::Arena<int64_t> *)arena)->get(to_index(index));
+    if (v && out) *out = *v;
+    return v ? 1 : 0;
+}
+int32_t orbit_host_arena_remove(void *arena, OrbitHostArenaIndex index, int64_t *out) {
+    const std::optional<int64_t> v = ((collections::Arena<int64_t> *)arena)->remove(to_index(index));
+    if (v && out) *out = *v;
+    return v ? 1 : 0;
+}
+int32_t orbit_host_arena_has_index(const void *arena, OrbitHostArenaIndex index) {
+    return ((const collections::Arena<int64_t> *)arena)->has_index(to_index(index)) ? 1 : 0;
+}
+uint64_t orbit_host_arena_len(const void *arena) { return ((const collections::Arena<int64_t> *)arena)->len(); }
+uint64_t orbit_host_arena_iter(const void *arena, OrbitHostArenaIndex *indices, int64_t *values, uint64_t capacity) {
+    uint64_t n = 0;
+    ((const collections::Arena<int64_t> *)arena)->for_each([&](collections::Index i, const int64_t &v) {
+        if (n < capacity) {
+            indices[n] = from_index(i);
+            values[n] = v;
+            n++;
+        }
+    });
+    return n;
+}
+
+void *orbit_host_freelist_create(uint64_t size) { return new collections::FreeListAllocator((size_t)size); }
+void orbit_host_freelist_destroy(void *alloc) { delete (collections::FreeListAllocator *)alloc; }
+int32_t orbit_host_freelist_allocate(void *alloc, uint64_t size, OrbitHostArenaIndex *out_index, uint64_t out_range[2]) {
+    const auto r = ((collections::FreeListAllocator *)alloc)->allocate((size_t)size);
+    if (!r) return 0;
+    *out_index = from_index(r->first);
+    out_range[0] = r->second.start;
+    out_range[1] = r->second.end;
+    return 1;
+}
+void orbit_host_freelist_deallocate(void *alloc, OrbitHostArenaIndex index) {
+    ((collections::FreeListAllocator *)alloc)->deallocate(to_index(index));
+}
+uint64_t orbit_host_freelist_blocks(const void *alloc, uint64_t *ranges, int32_t *is_free, uint64_t capacity) {
+    const auto blocks = ((const collections::FreeListAllocator *)alloc)->blocks_in_address_order();
+    for (uint64_t i = 0; i < blocks.size() && i < capacity; i++) {
+        ranges[2 * i] = blocks[i].first.start;
+        ranges[2 * i + 1] = blocks[i].first.end;
+        is_free[i] = blocks[i].second ? 1 : 0;
+    }
+    return blocks.size();
+}
+
+void *orbit_host_scene_create(uint64_t visibility_chunk_count) {
+    return visibility_chunk_count ? new scene::SceneData((size_t)visibility_chunk_count) : new scene::SceneData();
+}
+void orbit_host_scene_destroy(void *sc) { delete (scene::SceneData *)sc; }
+int64_t orbit_host_scene_add_entity(void *sc, const OrbitHostEntity *e) {
+    if (!sc || !e) return -1;
+    scene::EntityData d;
+    d.transform = to_transform(e->position, e->orientation, e->scale);
+    if (e->name) d.name = e->name, d.has_name = true;
+    if (e->mesh >= 0) d.mesh = (uint32_t)e->mesh;
+    if (e->has_light) {
+        scene::Light l;
+        l.color = {e->light.color[0], e->light.color[1], e->light.color[2]};
+        l.intensity = e->light.intensity;
+        l.kind = (scene::LightKind)e->light.kind;
+        l.param = e->light.param;
+        l.irradiance_map_index = e->light.irradiance_map_index;
+        l.prefiltered_map_index = e->light.prefiltered_map_index;
+        l.cast_shadows = e->light.cast_shadows != 0;
+        d.light = l;
+    }
+    return (int64_t)((scene::SceneData *)sc)->add_entity(std::move(d));
+}
+int32_t orbit_host_scene_set_transform(void *sc, uint64_t entity, const float position[3], const float orientation[4],
+                                       const float scale[3]) {
+    return guarded([&] {
+        scene::SceneData *s = (scene::SceneData *)sc;
+        if (entity >= s->entities.size()) throw Panic("set_transform: entity index out of range");
+        s->entities[entity].transform = to_transform(position, orientation, scale);
+    });
+}
+int32_t orbit_host_scene_update(void *sc, const OrbitMeshInfo *mesh_infos, uint64_t mesh_info_count,
+                                float luminance_cutoff, uint64_t frame_index) {
+    return guarded([&] {
+        ((scene::SceneData *)sc)->update_scene(mesh_infos, (size_t)mesh_info_count, luminance_cutoff, (size_t)frame_index);
+    });
+}
+const void *orbit_host_scene_entity_draws(const void *sc, uint64_t *count) {
+    const scene::SceneData *s = (const scene::SceneData *)sc;
+    *count = s->entity_draw_cache.size();
+    return s->entity_draw_cache.data();
+}
+const OrbitEntityData *orbit_host_scene_entity_data(const void *sc, uint64_t *count) {
+    const scene::SceneData *s = (const scene::SceneData *)sc;
+    *count = s->entity_data_cache.size();
+    return s->entity_data_cache.data();
+}
+const OrbitLightData *orbit_host_scene_light_data(const void *sc, uint64_t *count) {
+    const scene::SceneData *s = (const scene::SceneData *)sc;
+    *count = s->light_data_cache.size();
+    return s->light_data_cache.data();
+}
+uint64_t orbit_host_scene_shadow_command_count(const void *sc) {
+    return ((const scene::SceneData *)sc)->shadow_commands.size();
 }
 
 } // extern "C"

@@ -110,6 +110,57 @@ int32_t orbit_host_compute_clusters(void *hctx, const OrbitHostClusterSettings *
                                     const OrbitHostProjection *projection, float aspect_ratio, const float *depth,
                                     uint32_t depth_size[2], uint32_t samples, const OrbitHostScene *scene,
                                     OrbitHostClusterOut *out);
+
+/* ---- scene side (orbit_scene.hpp): collections::{Arena, FreeListAllocator}, scene::SceneData (host only) ---- */
+typedef struct OrbitHostArenaIndex {
+    uint32_t generation, slot;
+} OrbitHostArenaIndex;
+/* Arena<i64>: arena.rs:98-330 */
+void *orbit_host_arena_create(void);
+void orbit_host_arena_destroy(void *arena);
+OrbitHostArenaIndex orbit_host_arena_insert(void *arena, int64_t value);
+int32_t orbit_host_arena_get(const void *arena, OrbitHostArenaIndex index, int64_t *out);    /* 1 = Some */
+int32_t orbit_host_arena_remove(void *arena, OrbitHostArenaIndex index, int64_t *out);       /* 1 = Some */
+int32_t orbit_host_arena_has_index(const void *arena, OrbitHostArenaIndex index);
+uint64_t orbit_host_arena_len(const void *arena);
+/* occupied entries in iteration order; returns how many were written (<= capacity) */
+uint64_t orbit_host_arena_iter(const void *arena, OrbitHostArenaIndex *indices, int64_t *values, uint64_t capacity);
+/* FreeListAllocator: freelist_alloc.rs:22-121 */
+void *orbit_host_freelist_create(uint64_t size);
+void orbit_host_freelist_destroy(void *alloc);
+int32_t orbit_host_freelist_allocate(void *alloc, uint64_t size, OrbitHostArenaIndex *out_index,
+                                     uint64_t out_range[2]); /* 1 = Some, 0 = None */
+void orbit_host_freelist_deallocate(void *alloc, OrbitHostArenaIndex index);
+/* blocks in address order: ranges[2*i], ranges[2*i+1], is_free[i]; returns the block count */
+uint64_t orbit_host_freelist_blocks(const void *alloc, uint64_t *ranges, int32_t *is_free, uint64_t capacity);
+
+typedef struct OrbitHostLight {
+    float color[3], intensity;
+    uint32_t kind; /* 0 Sky, 1 Directional, 2 Point (scene.rs:136-141) */
+    float param;   /* Directional: angular_size, Point: inner_radius */
+    uint32_t irradiance_map_index, prefiltered_map_index; /* Sky */
+    uint32_t cast_shadows;
+} OrbitHostLight;
+typedef struct OrbitHostEntity {
+    float position[3], orientation[4], scale[3]; /* Transform, scene.rs:20-24; quaternion (x, y, z, w) */
+    int32_t mesh;                                /* MeshHandle slot, -1 = None */
+    int32_t has_light;
+    OrbitHostLight light;
+    const char *name; /* NULL = None */
+} OrbitHostEntity;
+/* SceneData (scene.rs:358-492); visibility_chunk_count 0 = MESHLET_VISIBILITY_BUFFER_CHUNK_COUNT */
+void *orbit_host_scene_create(uint64_t visibility_chunk_count);
+void orbit_host_scene_destroy(void *scene);
+int64_t orbit_host_scene_add_entity(void *scene, const OrbitHostEntity *entity);
+int32_t orbit_host_scene_set_transform(void *scene, uint64_t entity, const float position[3],
+                                       const float orientation[4], const float scale[3]);
+int32_t orbit_host_scene_update(void *scene, const OrbitMeshInfo *mesh_infos, uint64_t mesh_info_count,
+                                float luminance_cutoff, uint64_t frame_index);
+/* the caches update_scene filled: pointers stay valid until the next update / destroy */
+const void *orbit_host_scene_entity_draws(const void *scene, uint64_t *count);   /* {instance, mesh, vis_offset}[] */
+const OrbitEntityData *orbit_host_scene_entity_data(const void *scene, uint64_t *count);
+const OrbitLightData *orbit_host_scene_light_data(const void *scene, uint64_t *count);
+uint64_t orbit_host_scene_shadow_command_count(const void *scene);
 #ifdef __cplusplus
 }
 #endif

@@ -396,9 +396,13 @@ def test_light_clusters_many_lights_and_saturated_clusters(torch_mod, engine, or
     _light_clusters(torch_mod, engine, oracle, 128, 72, 5000, 16, 16, 1, 1.0, poison=False, radius_scale=12.0)
 
 
-def _light_clusters(torch_mod, engine, oracle, W, H, n_lights, tile, zs, samples, pf, poison, radius_scale=None):
+def _light_clusters(torch_mod, engine, oracle, W, H, n_lights, tile, zs, samples, pf, poison, radius_scale=None,
+                    lights_override=None):
     torch = torch_mod
     push, depth, info, lights = cluster_inputs(oracle, 4, W, H, n_lights, tile, zs, samples=samples, point_fraction=pf)
+    if lights_override is not None:  # LightData[] produced elsewhere (tests/test_scene_gpu.py)
+        assert len(lights_override) == n_lights
+        lights = np.ascontiguousarray(lights_override, dtype=L.LIGHT)
     if radius_scale is not None:
         lights["outer_radius"] *= np.float32(radius_scale)
     if poison:

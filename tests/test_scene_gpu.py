@@ -1,0 +1,90 @@
+"""The scene-side producers feeding the device path: entities go through SceneData::update_scene (C++ host mirror of
+src/scene.rs:404-492), its three caches are uploaded as they are, and entity_cull + meshlet_cull (+ the cluster
+passes for the lights) must agree bit-exactly with the oracle run on the same bytes."""
+import numpy as np
+import pytest
+
+import scenes as sc
+from orbit_amd import layouts as L
+from orbit_amd import scene as S
+from test_gpu_parity import GpuScene, assert_same, dev, host, run_gpu, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def engine(torch_mod):
+    from orbit_amd.engine import Engine
+
+    e = Engine(0, max_entities=20000, max_dispatches=200000, max_draws=400000, max_lights=4096)
+    yield e
+    e.close()
+
+
+def _random_unit_quats(rng, n):
+    q = rng.normal(size=(n, 4)).astype(np.float32)
+    return (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+
+
+def build_scene(seed, n_entities, n_meshes, n_lights):
+    base = sc.make_scene(seed, n_meshes, meshlets_per_mesh=(1, 90))  # meshes / meshlets / materials only
+    rng = np.random.default_rng(seed)
+    sd = S.SceneData()
+    quats = _random_unit_quats(rng, n_entities)
+    for i in range(n_entities):
+        pos = rng.uniform((-40, -6, -40), (40, 10, 40)).astype(np.float32)
+        scale = np.float32(rng.choice([0.5, 1.0, 2.0]))
+        has_mesh = rng.random() < 0.9
+        light = None
+        if i < n_lights:
+            light = dict(kind=S.POINT, intensity=float(rng.uniform(1, 6)), param=0.1,
+                         color=tuple(rng.uniform(0, 1, 3)))
+        sd.add_entity(position=pos, orientation=quats[i], scale=(scale, scale, scale),
+                      mesh=int(rng.integers(n_meshes)) if has_mesh else None, light=light)
+    sd.update_scene(base.mesh_infos, luminance_cutoff=0.25)
+    draws, ents = sd.entity_draw_cache(), sd.entity_data_cache()
+    counts = base.mesh_infos["mesh_lods"][draws["mesh_index"], 0, 1].astype(np.int64)
+    words = (counts + 31) // 32
+    # a10: without frees the allocator is the running prefix sum of ceil(meshlets / 32)
+    assert draws["visibility_offset"].tolist() == np.concatenate([[0], np.cumsum(words)])[:-1].tolist()
+    scene = sc.Scene(draws, ents, base.mesh_infos, base.meshlets, base.materials, int(words.sum()), int(counts.sum()),
+                     dict(seed=seed))
+    return scene, sd.light_data_cache()
+
+
+@pytest.mark.parametrize("seed,n", [(1, 900), (2, 3000)])
+def test_scene_data_feeds_the_cull_path(torch_mod, engine, oracle, seed, n):
+    torch = torch_mod
+    scene, _ = build_scene(seed, n, n_meshes=max(8, n // 10), n_lights=0)
+    cam = sc.default_camera(rot=(0.8, 0.6))
+    gs = GpuScene(torch, scene)
+    ci0 = sc.make_cull_info(cam.view, cam.planes)
+    recs, cmds = assert_same(run_gpu(torch, engine, gs, ci0), run_oracle(oracle, scene, ci0))
+    assert len(cmds) > 0
+    # pass 2 writes the visibility words at the allocator's offsets
+    W, H = 256, 144
+    depth = sc.make_depth(7, W, H, cam)
+    opyr, d = oracle.depth_reduce(depth, W, H)
+    ps = (d.width, d.height)
+    evis = np.zeros((scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+    mvis = np.zeros(scene.vis_words, dtype=np.uint32)
+    ci2 = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=2, p00=cam.p00, p11=cam.p11, z_near=cam.z_near)
+    assert_same(run_gpu(torch, engine, gs, ci2, evis, mvis, opyr, ps), run_oracle(oracle, scene, ci2, evis, mvis, opyr, ps))
+
+
+def test_scene_lights_feed_the_cluster_path(torch_mod, engine, oracle):
+    torch = torch_mod
+    _, lights = build_scene(5, 600, n_meshes=40, n_lights=500)
+    assert len(lights) == 500 and (lights["light_type"] == L.LIGHT_TYPE_POINT).all()
+    import test_gpu_parity as T
+
+    T._light_clusters(torch, engine, oracle, 320, 180, len(lights), 8, 32, 1, 1.0, poison=False, lights_override=lights)
