@@ -36,7 +36,7 @@ struct OrbitCtx {
     uint32_t *c_chunk = nullptr; // compact: counts | bases | total
     float4 *a_view_lights = nullptr;
     uint32_t *a_light_flags = nullptr, *a_counts = nullptr, *a_block_sums = nullptr, *a_block_base = nullptr,
-             *a_total = nullptr, *a_coarse = nullptr, *a_coarse_counts = nullptr;
+             *a_total = nullptr, *a_coarse = nullptr, *a_coarse_counts = nullptr, *a_hit_cache = nullptr;
     float *a_aabb = nullptr, *a_group_box = nullptr;
     uint32_t a_coarse_seg = 0;
     uint32_t *g_counts = nullptr; // gather_visible: per-rank command counts
@@ -201,6 +201,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t aseg = (((size_t)caps.max_lights + 15) / 16 + 63) / 64 * 64;
     const size_t o_aab = carve(((size_t)caps.max_clusters + 256) * 6 * 4);
     const size_t o_aco = carve(agroups * 16 * aseg * 4), o_acc = carve(agroups * 16 * 4), o_agb = carve(agroups * 32);
+    const size_t o_ahc = carve(((size_t)caps.max_clusters + 256) * kHitCache * 4);
     ctx->arena_bytes = off;
     e = hipMalloc((void **)&ctx->arena, ctx->arena_bytes);
     if (e != hipSuccess) {
@@ -235,6 +236,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->a_total = (uint32_t *)(a + o_at);
     ctx->a_aabb = (float *)(a + o_aab);
     ctx->a_coarse = (uint32_t *)(a + o_aco);
+    ctx->a_hit_cache = (uint32_t *)(a + o_ahc);
     ctx->a_coarse_counts = (uint32_t *)(a + o_acc);
     ctx->a_group_box = (float *)(a + o_agb);
     ctx->a_coarse_seg = (uint32_t)aseg;
@@ -575,6 +577,7 @@ int32_t orbit_cluster_assign(OrbitCtx *ctx, const OrbitClusterCullInfo *info, co
     p.counts = ctx->a_counts;
     p.aabb = ctx->a_aabb;
     p.coarse = ctx->a_coarse;
+    p.hit_cache = ctx->a_hit_cache;
     p.coarse_counts = ctx->a_coarse_counts;
     p.group_box = ctx->a_group_box;
     p.coarse_seg = ctx->a_coarse_seg;
@@ -582,7 +585,7 @@ int32_t orbit_cluster_assign(OrbitCtx *ctx, const OrbitClusterCullInfo *info, co
     p.block_base = ctx->a_block_base;
     p.total = ctx->a_total;
     p.status = ctx->status;
-    hipError_t e = launch_cluster_assign(p, (hipStream_t)stream);
+    hipError_t e = launch_cluster_assign(p, ctx->num_cus, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch cluster_assign");
     return ORBIT_OK;
 }

@@ -87,6 +87,7 @@ struct ClusterCompactParams {
     int32_t *status;
 };
 
+constexpr uint32_t kHitCache = 16;
 struct ClusterAssignParams {
     OrbitClusterCullInfo info;
     const uint8_t *unique;
@@ -100,6 +101,7 @@ struct ClusterAssignParams {
     float4 *view_lights;     // (x, y, z, r*r) per light in view space
     uint32_t *light_flags;   // bit i set = light i is a point light
     uint32_t *counts;        // per active cluster
+    uint32_t *hit_cache;     // per active cluster: its first kHitCache light indices, kept by the counting launch
     float *aabb;             // 6 floats per active cluster (compacted order), written by the coarse launch
     uint32_t *coarse;        // per group of 256 active clusters: 16 segments x coarse_seg candidate light indices
     uint32_t *coarse_counts; // 16 per group
@@ -121,7 +123,7 @@ hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *mes
 hipError_t launch_depth_reduce(const DepthReduceParams &p, hipStream_t s);
 hipError_t launch_cluster_mark(const ClusterMarkParams &p, hipStream_t s);
 hipError_t launch_cluster_compact(const ClusterCompactParams &p, hipStream_t s);
-hipError_t launch_cluster_assign(const ClusterAssignParams &p, hipStream_t s);
+hipError_t launch_cluster_assign(const ClusterAssignParams &p, uint32_t num_cus, hipStream_t s);
 
 // Exclusive scan of `n` words by one 1024-thread block; *total = sum.
 hipError_t launch_scan_exclusive(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, hipStream_t s);

@@ -274,8 +274,10 @@ __global__ __launch_bounds__(256) void cluster_aabb_kernel(const ClusterAssignPa
     __shared__ float s_box[4][8];
     const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.unique);
     const uint32_t n = min(hdr[3], p.max_clusters);
-    const uint32_t first = blockIdx.x * kGroupClusters;
-    if (first >= n) return; // block-uniform (the grid is a capacity bound)
+    // grid-stride over the groups that exist (n is only known on the device; a grid sized by the capacity would
+    // spend its time launching empty blocks)
+    for (uint32_t grp = blockIdx.x; grp * kGroupClusters < n; grp += gridDim.x) {
+    const uint32_t first = grp * kGroupClusters;
     const uint32_t *unique_idx = reinterpret_cast<const uint32_t *>(p.unique + ORBIT_COMPACT_HEADER);
     const uint32_t u = first + threadIdx.x;
     const float inf = __uint_as_float(0x7f800000u);
@@ -320,10 +322,12 @@ __global__ __launch_bounds__(256) void cluster_aabb_kernel(const ClusterAssignPa
             union_add(un, &s_box[w][0], &s_box[w][3]);
             un.any_nan = un.any_nan || s_box[w][6] != 0.0f;
         }
-        float *g = p.group_box + 8 * (size_t)blockIdx.x;
+        float *g = p.group_box + 8 * (size_t)grp;
 #pragma unroll
         for (int i = 0; i < 3; i++) g[i] = un.box.mn[i], g[3 + i] = un.box.mx[i];
         g[6] = un.any_nan ? 1.0f : 0.0f;
+    }
+    __syncthreads(); // s_box is rewritten by the next group
     }
 }
 
@@ -333,15 +337,15 @@ __global__ __launch_bounds__(256) void cluster_coarse_kernel(const ClusterAssign
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.unique);
     const uint32_t n = min(hdr[3], p.max_clusters);
-    const uint32_t group = blockIdx.x / kCoarseSplit;
-    if (group * kGroupClusters >= n) return; // block-uniform
+    for (uint32_t vb = blockIdx.x; (vb / kCoarseSplit) * kGroupClusters < n; vb += gridDim.x) { // as in cluster_aabb_kernel
+    const uint32_t group = vb / kCoarseSplit;
     const float *g = p.group_box + 8 * (size_t)group;
     BoxUnion un;
 #pragma unroll
     for (int i = 0; i < 3; i++) un.box.mn[i] = g[i], un.box.mx[i] = g[3 + i];
     un.any_nan = g[6] != 0.0f;
     const uint32_t nl = p.info.global_light_count, seg = p.coarse_seg;
-    const uint32_t sidx = (blockIdx.x % kCoarseSplit) * 4 + wave;
+    const uint32_t sidx = (vb % kCoarseSplit) * 4 + wave;
     uint32_t *out = p.coarse + ((size_t)group * kCoarseSegs + sidx) * seg;
     uint32_t cnt = 0;
     const uint32_t begin = sidx * seg, end = min(begin + seg, nl);
@@ -366,6 +370,7 @@ __global__ __launch_bounds__(256) void cluster_coarse_kernel(const ClusterAssign
         }
     }
     if (lane == 0) p.coarse_counts[group * kCoarseSegs + sidx] = cnt;
+    }
 }
 
 template <bool WRITE>
@@ -378,8 +383,9 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.unique);
     const uint32_t n = min(hdr[3], p.max_clusters);
-    const uint32_t block_first = blockIdx.x * kClustersPerBlock;
-    if (block_first >= n) return; // block-uniform (the grid is a capacity bound)
+    // grid-stride over the blocks of 16 active clusters that exist (see cluster_aabb_kernel)
+    for (uint32_t block_first = blockIdx.x * kClustersPerBlock; block_first < n;
+         block_first += gridDim.x * kClustersPerBlock) {
     const uint32_t u0 = block_first + wave * kClustersPerWave;
     if (wave == 0) { // exclusive prefix of the 16 segment counts (one load per lane, wave scan)
         const uint32_t *cc = p.coarse_counts + (size_t)(block_first / kGroupClusters) * kCoarseSegs;
@@ -403,6 +409,26 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
             // exclusive prefix of the capped counts: chunk-local prefix + chunk base of the two-level scan
             my_offset = p.block_base[u0 + lane] +
                         (p.block_sums + (p.max_clusters / kScanChunk + 2))[(u0 + lane) / kScanChunk];
+        }
+    }
+    if (WRITE) {
+        // A block whose clusters all found at most kHitCache lights copies the indices the counting launch kept
+        // (the common case by far: a cluster holds a handful of lights) instead of testing everything again.
+        if (__syncthreads_or(owns && my_limit > kHitCache) == 0) {
+            const uint32_t c = (uint32_t)lane / kHitCache, k = (uint32_t)lane % kHitCache; // 4 clusters x 16 slots
+            static_assert(kClustersPerWave * kHitCache == 64, "one lane per (cluster, slot)");
+            const uint32_t lim = (uint32_t)__shfl((int)my_limit, (int)c, 64);
+            const uint32_t off = (uint32_t)__shfl((int)my_offset, (int)c, 64);
+            const uint32_t ci = (uint32_t)__shfl((int)my_ci, (int)c, 64);
+            uint32_t *out = reinterpret_cast<uint32_t *>(p.light_index_buffer + ORBIT_LIGHT_INDEX_HEADER);
+            if (u0 + c < n) {
+                if (k < lim && off + k < p.light_index_capacity) out[off + k] = p.hit_cache[(size_t)(u0 + c) * kHitCache + k];
+                if (k == 0) { // imageStore(cluster_offset_image, cluster_id, (offset, count)), :149-150
+                    p.offset_image[2 * (size_t)ci + 0] = off;
+                    p.offset_image[2 * (size_t)ci + 1] = lim;
+                }
+            }
+            continue; // block-uniform; nothing below the barrier above reads LDS on this path
         }
     }
     if (lane < kClustersPerWave) {
@@ -501,11 +527,13 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
                     for (int i = 0; i < 3; i++) a.mn[i] = mn[c][i], a.mx[i] = mx[c][i];
                     const bool hit = in_list && (!point || sphere_hits(a, cl)); // :108-119
                     const uint64_t m = __ballot(hit);
-                    if (WRITE) {
-                        if (hit) {
-                            const uint32_t k = count[c] + lane_prefix(m);
+                    if (hit) {
+                        const uint32_t k = count[c] + lane_prefix(m);
+                        if (WRITE) {
                             if (k < limit[c] && offset[c] + k < p.light_index_capacity) // while (counter < light_count), :140
                                 out[offset[c] + k] = ctag & ~kNotPoint;
+                        } else if (k < kHitCache) {
+                            p.hit_cache[(size_t)(u0 + c) * kHitCache + k] = ctag & ~kNotPoint;
                         }
                     }
                     count[c] += (uint32_t)__popcll(m);
@@ -525,6 +553,8 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
             p.offset_image[2 * (size_t)ci + 0] = offset[c];
             p.offset_image[2 * (size_t)ci + 1] = limit[c];
         }
+    }
+    __syncthreads(); // s_cpre / s_box are rewritten by the next block of clusters
     }
     if (WRITE && blockIdx.x == 0 && threadIdx.x == 0) {
         const uint32_t total = *p.total;
@@ -560,7 +590,7 @@ hipError_t launch_cluster_compact(const ClusterCompactParams &p, hipStream_t s) 
     return hipGetLastError();
 }
 
-hipError_t launch_cluster_assign(const ClusterAssignParams &p, hipStream_t s) {
+hipError_t launch_cluster_assign(const ClusterAssignParams &p, uint32_t num_cus, hipStream_t s) {
     const uint32_t nl = p.info.global_light_count;
     if (nl > 0) {
         hipLaunchKernelGGL(light_prepare_kernel, dim3((nl + 255) / 256), dim3(256), 0, s, p);
@@ -571,10 +601,12 @@ hipError_t launch_cluster_assign(const ClusterAssignParams &p, hipStream_t s) {
         hipLaunchKernelGGL(write_word, dim3(1), dim3(1), 0, s, reinterpret_cast<uint32_t *>(p.light_index_buffer), 0u);
         return hipGetLastError();
     }
-    const uint32_t blocks = (p.max_clusters + kClustersPerBlock - 1) / kClustersPerBlock;
+    // the number of active clusters is only known on the device: grids are bounded by the chip, not by the capacity,
+    // and the kernels stride over the work that exists
     const uint32_t groups = (p.max_clusters + kGroupClusters - 1) / kGroupClusters;
-    hipLaunchKernelGGL(cluster_aabb_kernel, dim3(groups), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(cluster_coarse_kernel, dim3(groups * kCoarseSplit), dim3(256), 0, s, p);
+    const uint32_t blocks = min((p.max_clusters + kClustersPerBlock - 1) / kClustersPerBlock, num_cus * 16u);
+    hipLaunchKernelGGL(cluster_aabb_kernel, dim3(min(groups, num_cus * 4u)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(cluster_coarse_kernel, dim3(min(groups * kCoarseSplit, num_cus * 8u)), dim3(256), 0, s, p);
     hipLaunchKernelGGL(cluster_assign_kernel<false>, dim3(blocks), dim3(kAssignWaves * 64), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -83,6 +83,14 @@ def main():
             torch.cuda.synchronize()
             c4["active_clusters"] = int(gu[12:16].view(torch.int32).item()); c4["light_indices"] = int(gl[:4].view(torch.int32).item())
             c4["sphere_tests_per_s"] = 2.0 * c4["active_clusters"] * nl / (c4["assign_ms"] * 1e-3)
+            # distribution of lights per active cluster (compacted order) and per block of 16: what the hit cache sees
+            na = c4["active_clusters"]
+            uidx = gu[16:16 + 4 * na].view(torch.int32).long()
+            cnt = gimg.view(torch.int32).view(-1, 2)[uidx, 1].cpu().numpy()
+            pad = np.zeros((-len(cnt)) % 16, dtype=cnt.dtype)
+            bmax = np.concatenate([cnt, pad]).reshape(-1, 16).max(axis=1)
+            c4["lights_per_cluster"] = {"mean": float(cnt.mean()), "p99": int(np.percentile(cnt, 99)), "max": int(cnt.max()),
+                                        "blocks_over_16": int((bmax > 16).sum()), "blocks": int(len(bmax))}
             out["config4"] = c4
     try: eng.status()
     except Exception as e: out["status"] = str(e)
