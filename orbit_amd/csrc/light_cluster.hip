@@ -231,6 +231,7 @@ __device__ __forceinline__ bool sphere_hits(const Aabb3 &a, const float4 l) {
 }
 
 constexpr uint32_t kLightTile = 1024;  // coarse candidates a block filters per step; survivors live in LDS (20 KB)
+// 4 waves x 4 clusters: 8 x 2 and 16 x 1 (same 16 clusters per block) measured 14 % and 40 % slower (r01_notes.md)
 constexpr int kClustersPerWave = 4;    // cluster AABBs held in scalar registers per wave
 constexpr int kAssignWaves = 4;
 constexpr int kClustersPerBlock = kClustersPerWave * kAssignWaves;
@@ -415,13 +416,13 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
         // A block whose clusters all found at most kHitCache lights copies the indices the counting launch kept
         // (the common case by far: a cluster holds a handful of lights) instead of testing everything again.
         if (__syncthreads_or(owns && my_limit > kHitCache) == 0) {
-            const uint32_t c = (uint32_t)lane / kHitCache, k = (uint32_t)lane % kHitCache; // 4 clusters x 16 slots
-            static_assert(kClustersPerWave * kHitCache == 64, "one lane per (cluster, slot)");
+            const uint32_t c = (uint32_t)lane / kHitCache, k = (uint32_t)lane % kHitCache; // (cluster, slot) per lane
+            static_assert(kClustersPerWave * kHitCache <= 64, "one lane per (cluster, slot)");
             const uint32_t lim = (uint32_t)__shfl((int)my_limit, (int)c, 64);
             const uint32_t off = (uint32_t)__shfl((int)my_offset, (int)c, 64);
             const uint32_t ci = (uint32_t)__shfl((int)my_ci, (int)c, 64);
             uint32_t *out = reinterpret_cast<uint32_t *>(p.light_index_buffer + ORBIT_LIGHT_INDEX_HEADER);
-            if (u0 + c < n) {
+            if (c < (uint32_t)kClustersPerWave && u0 + c < n) {
                 if (k < lim && off + k < p.light_index_capacity) out[off + k] = p.hit_cache[(size_t)(u0 + c) * kHitCache + k];
                 if (k == 0) { // imageStore(cluster_offset_image, cluster_id, (offset, count)), :149-150
                     p.offset_image[2 * (size_t)ci + 0] = off;
@@ -477,17 +478,18 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
     };
     // one step = 1024 coarse candidates = one group of 4 (index, light) load pairs per lane; the next step's
     // loads are issued before this step's test phase
-    uint32_t tag[4];
-    float4 l[4];
+    constexpr uint32_t kLoads = kSeg / 64u; // candidates per lane per step
+    uint32_t tag[kLoads];
+    float4 l[kLoads];
     auto load_step = [&](uint32_t step0) {
         const uint32_t s_begin = step0 + wave * kSeg, s_end = min(s_begin + kSeg, ctotal);
 #pragma unroll
-        for (uint32_t r = 0; r < 4; r++) {
+        for (uint32_t r = 0; r < kLoads; r++) {
             const uint32_t k = s_begin + r * 64u + (uint32_t)lane;
             tag[r] = k < s_end ? coarse_at(k) : 0u;
         }
 #pragma unroll
-        for (uint32_t r = 0; r < 4; r++) l[r] = p.view_lights[tag[r] & ~kNotPoint];
+        for (uint32_t r = 0; r < kLoads; r++) l[r] = p.view_lights[tag[r] & ~kNotPoint];
     };
     if (ctotal > 0) load_step(0);
     for (uint32_t step0 = 0; step0 < ctotal; step0 += kLightTile) { // block-uniform trip count
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
         uint32_t seg_n = 0; // wave-uniform
         const uint32_t s_begin = step0 + wave * kSeg, s_end = min(s_begin + kSeg, ctotal);
 #pragma unroll
-        for (uint32_t r = 0; r < 4; r++) {
+        for (uint32_t r = 0; r < kLoads; r++) {
             const uint32_t k = s_begin + r * 64u + (uint32_t)lane;
             const bool point = (tag[r] & kNotPoint) == 0u;
             const bool pass = k < s_end && (!point || un.any_nan || sphere_hits(un.box, l[r]));
