@@ -247,6 +247,23 @@ def main():
     op_bytes = alg_bytes + 28 * n_draw + 4
     traffic = load_traffic(E, M) if world == 1 else None  # the PMC passes were taken on the whole scene at N=1
 
+    # Box reference (not part of any metric): what a plain streaming read of the same bytes reaches on THIS box right
+    # now.  Boxes of the pool differ by up to 30 % (profiles/r01_notes.md, "Measurement hygiene"); the ratio below is
+    # comparable across them, the absolute numbers are not.
+    stream_ref = None
+    if rank == 0 and world == 1:
+        words = meshlets.view(torch.float32)  # the value is irrelevant (NaN bit patterns included), only the read
+        se = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(7)]
+        for a, z in se:
+            a.record()
+            words.sum()
+            z.record()
+        torch.cuda.synchronize()
+        sms = float(np.median([a.elapsed_time(z) for a, z in se[2:]]))
+        stream_ref = {"GBps": words.numel() * 4 / (sms * 1e-3) / 1e9,
+                      "what": f"torch.sum over the {words.numel() * 4 / 1e9:.2f} GB meshlet buffer viewed as f32, median of 5",
+                      "meshlet_eval_vs_stream": achieved / (words.numel() * 4 / (sms * 1e-3) / 1e9)}
+
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_sample_entities > 0:
         cpu_baseline = run_cpu_baseline(args, spec, ci, draws, mesh, ent, meshlets, materials, disp, draw, L)
@@ -280,6 +297,7 @@ def main():
                 "bound": "hbm", "kernel": "meshlet_eval_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": eval_ms, "launches_timed": eval_launches,
+                "box_stream_reference": stream_ref,
                 "op": {"name": "meshlet_cull (eval + scan + emit)", "algorithmic_bytes": op_bytes,
                        "avg_ms": kernel_ms, "achieved": op_bytes / (kernel_ms * 1e-3) / 1e9},
             },
