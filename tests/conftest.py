@@ -18,7 +18,8 @@ def pytest_sessionstart(session):
     (hipcc cross-compiles gfx950 without a GPU; a few minutes once, nothing when they are up to date)."""
     import subprocess
 
-    missing = [d for d, so in (("orbit_amd/csrc", "orbit_amd/liborbit_cull.so"), ("orbit_amd/host", "orbit_amd/liborbit_host.so"))
+    missing = [d for d, so in (("orbit_amd/csrc", "orbit_amd/liborbit_cull.so"), ("orbit_amd/host", "orbit_amd/liborbit_host.so"),
+                               ("examples", "examples/native_frame"))
                if not os.path.exists(os.path.join(ROOT, so))]
     for d in missing:
         subprocess.run(["make", "-C", os.path.join(ROOT, d), "-j8", "-s"], check=True)
