@@ -121,6 +121,80 @@ __global__ __launch_bounds__(256) void stream_tiled_n_kernel(const uint4 *src, s
     if (acc == 0x12345678u) *sink = acc;
 }
 
+
+// PAYLOAD: does a small store per tile beside the stream cost what meshlet_eval's survivor payload costs (8 %)?
+//   MODE 0: tile-order stream only (as stream_tiled_n_kernel<8>)
+//   MODE 1: + one 784-B store per tile (49 lanes x 16 B at tile * 2 KiB), issued by the streaming wave itself
+//   MODE 2: the same bytes, issued by a fifth wave of the block that follows the streaming waves' progress through
+//           an LDS counter (the streaming waves issue no store at all)
+template <int MODE>
+__global__ __launch_bounds__(320) void stream_payload_kernel(const uint4 *src, size_t n_rows, uint4 *pay, unsigned *sink) {
+    __shared__ unsigned s_done[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t stride = (size_t)gridDim.x * 4;
+    const size_t n_tiles = n_rows / 8;
+    if (threadIdx.x < 4) s_done[threadIdx.x] = 0;
+    __syncthreads();
+    if (wave == 4) {
+        if (MODE != 2) return;
+        unsigned seen[4] = {0, 0, 0, 0};
+        size_t t[4];
+        for (int w = 0; w < 4; w++) t[w] = (size_t)blockIdx.x * 4 + w;
+        bool live = true;
+        while (live) {
+            live = false;
+            for (int w = 0; w < 4; w++) {
+                if (t[w] >= n_tiles) continue;
+                live = true;
+                const unsigned d = *(volatile unsigned *)&s_done[w];
+                while (seen[w] < d) {
+                    if (lane < 49) pay[t[w] * 128 + lane] = make_uint4(lane, seen[w], d, 7);
+                    seen[w]++;
+                    t[w] += stride;
+                }
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        return;
+    }
+    unsigned acc = 0;
+    const size_t wg = (size_t)blockIdx.x * 4 + wave;
+    for (size_t t = wg; t < n_tiles; t += stride) {
+        const uint4 *p = src + (t * 8 * 64 + lane) * 2;
+        uint4 a0 = p[0], b0 = p[1];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint4 a1 = a0, b1 = b0;
+            if (r < 7) {
+                a1 = p[(r + 1) * 128];
+                b1 = p[(r + 1) * 128 + 1];
+            }
+            acc += a0.x ^ b0.w;
+            a0 = a1;
+            b0 = b1;
+        }
+        if (MODE == 1 && lane < 49) pay[t * 128 + lane] = make_uint4(acc, lane, 3, 7);
+        if (MODE == 2 && lane == 0) atomicAdd(&s_done[wave], 1u);
+        if (MODE == 3 && lane < 49) { // non-temporal
+            typedef unsigned v4 __attribute__((ext_vector_type(4)));
+            v4 v = {acc, (unsigned)lane, 3u, 7u};
+            __builtin_nontemporal_store(v, reinterpret_cast<v4 *>(pay + t * 128 + lane));
+        }
+        if (MODE == 4 && lane < 49) reinterpret_cast<unsigned *>(pay + t * 128)[lane] = acc; // 196 B per tile
+        if (MODE == 5) { // the stores of 8 tiles issued together, every 8th tile
+            const size_t it = (t - wg) / stride;
+            if ((it & 7) == 7 && lane < 49)
+                for (int k = 0; k < 8; k++) pay[(t - (size_t)k * stride) * 128 + lane] = make_uint4(acc, lane, k, 7);
+        }
+        if (MODE == 6 && lane < 49) { // dense: a wave's records back to back
+            const size_t it = (t - wg) / stride, per_wave = n_tiles / stride + 1;
+            pay[(wg * per_wave + it) * 49 + lane] = make_uint4(acc, lane, 3, 7);
+        }
+        if (MODE == 7 && lane < 49) pay[(t & 1023) * 128 + lane] = make_uint4(acc, lane, 3, 7); // 2 MB window: stays in L2
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+
 template <typename K>
 float time_kernel(K launch) {
     hipEvent_t e0, e1;
@@ -197,6 +271,22 @@ int main() {
                    gb(time_kernel([&] { hipLaunchKernelGGL(stream_tiled_n_kernel<4>, dim3(blocks), dim3(256), 0, 0, src, n_rows, sink); })),
                    gb(time_kernel([&] { hipLaunchKernelGGL(stream_tiled_n_kernel<8>, dim3(blocks), dim3(256), 0, 0, src, n_rows, sink); })),
                    gb(time_kernel([&] { hipLaunchKernelGGL(stream_tiled_n_kernel<16>, dim3(blocks), dim3(256), 0, 0, src, n_rows, sink); })));
+        }
+        if (bpc == 4) {
+            uint4 *pay;
+            hipMalloc(&pay, (bytes / 16384 + 1) * 2048);
+            auto gb = [&](float ms) { return bytes / (ms * 1e-3) / 1e9; };
+            printf("   + payload store per tile (784 B): none %.0f, own wave %.0f, fifth wave %.0f GB/s (read bytes only)\n",
+                   gb(time_kernel([&] { hipLaunchKernelGGL(stream_payload_kernel<0>, dim3(blocks), dim3(320), 0, 0, src, n_rows, pay, sink); })),
+                   gb(time_kernel([&] { hipLaunchKernelGGL(stream_payload_kernel<1>, dim3(blocks), dim3(320), 0, 0, src, n_rows, pay, sink); })),
+                   gb(time_kernel([&] { hipLaunchKernelGGL(stream_payload_kernel<2>, dim3(blocks), dim3(320), 0, 0, src, n_rows, pay, sink); })));
+            printf("     own wave: non-temporal %.0f, 196 B %.0f, 8 tiles batched %.0f, dense per wave %.0f, 2-MB window (L2-resident) %.0f GB/s\n",
+                   gb(time_kernel([&] { hipLaunchKernelGGL(stream_payload_kernel<3>, dim3(blocks), dim3(320), 0, 0, src, n_rows, pay, sink); })),
+                   gb(time_kernel([&] { hipLaunchKernelGGL(stream_payload_kernel<4>, dim3(blocks), dim3(320), 0, 0, src, n_rows, pay, sink); })),
+                   gb(time_kernel([&] { hipLaunchKernelGGL(stream_payload_kernel<5>, dim3(blocks), dim3(320), 0, 0, src, n_rows, pay, sink); })),
+                   gb(time_kernel([&] { hipLaunchKernelGGL(stream_payload_kernel<6>, dim3(blocks), dim3(320), 0, 0, src, n_rows, pay, sink); })),
+                   gb(time_kernel([&] { hipLaunchKernelGGL(stream_payload_kernel<7>, dim3(blocks), dim3(320), 0, 0, src, n_rows, pay, sink); })));
+            hipFree(pay);
         }
         printf("   linear 1 KiB loads:   rows=1 %.0f rows=2 %.0f rows=4 %.0f GB/s\n",
                bytes / (run<1, true>(src, n_rows, sink, blocks) * 1e-3) / 1e9,
