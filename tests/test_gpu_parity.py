@@ -65,6 +65,9 @@ def run_gpu(torch, engine, gs, ci, evis=None, mvis=None, pyr=None, psize=(0, 0),
                         meshlet_visibility_buffer=mvis_d, depth_pyramid=pyr_d, depth_pyramid_size=psize,
                         material_count=material_count)  # 0: alpha modes gathered; > 0: staged in LDS by the kernels
     torch.cuda.synchronize()
+    # red zones: nothing may be written past the capacities handed to the library
+    assert bool((disp[L.DISPATCH_HEADER + 16 * disp_cap:] == 0xAB).all()), "write past the dispatch capacity"
+    assert bool((draw[L.DRAW_HEADER + 28 * draw_cap:] == 0xCD).all()), "write past the draw capacity"
     return (host(disp), host(draw), None if evis_d is None else host(evis_d, np.uint32),
             None if mvis_d is None else host(mvis_d, np.uint32))
 
