@@ -28,64 +28,84 @@ namespace orbit {
 
 namespace {
 
-__device__ __forceinline__ uint32_t wave_reduce_or(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v |= __shfl_xor(v, d, 64);
-    return v;
-}
-
 // ---------------------------------------------------------------- mark_active
-// mark_active.comp:27-57.  Lane L (< cz) accumulates the bounds of slice L.
+// mark_active.comp:27-57.  Lane L (< cz) accumulates the bounds of slice L.  A wave takes kMarkTiles consecutive tiles
+// and issues the first 64 depth loads of all of them before it evaluates any: the kernel is a short chain of
+// load -> log2 -> ballots -> stores per tile, so memory-level parallelism per wave is what shortens it.
+constexpr uint32_t kMarkTiles = 4;
+
 __global__ __launch_bounds__(256) void cluster_mark_kernel(const ClusterMarkParams p) {
     const OrbitMarkActivePush &pc = p.pc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t cx = pc.cluster_count[0], cy = pc.cluster_count[1], cz = pc.cluster_count[2];
-    const uint32_t tile = blockIdx.x * 4 + wave;
-    if (tile >= cx * cy) return; // wave-uniform
-    const uint32_t tx = tile % cx, ty = tile / cx;
+    const uint32_t tile0 = (blockIdx.x * 4 + wave) * kMarkTiles;
+    if (tile0 >= cx * cy) return; // wave-uniform
     const uint32_t ts = pc.tile_size_px, sc = pc.depth_buffer_sample_count;
     const uint32_t W = pc.screen_size[0], H = pc.screen_size[1];
-    uint32_t acc_min = 0, acc_max = 0, tile_mask = 0;
     const uint32_t items = ts * ts * sc;
-    for (uint32_t base = 0; base < items; base += 64) {
-        const uint32_t it = base + lane;
+    // sample `it` of tile `tile`: its address, or none (mark_active.comp:40)
+    auto sample = [&](uint32_t tile, uint32_t it, size_t &index) -> bool {
+        const uint32_t tx = tile % cx, ty = tile / cx;
         const uint32_t pix = it / sc, smp = it % sc;
         const uint32_t px = tx * ts + pix % ts, py = ty * ts + pix / ts;
-        const bool valid = it < items && px < W && py < H; // mark_active.comp:40
-        uint32_t slice = 0xFFFFFFFFu, bmin = 0, bmax = 0, bit = 0;
-        if (valid) {
-            const float d = p.depth[((size_t)py * W + px) * sc + smp];
-            const float linear_z = pc.z_near / d;                       // :28
-            slice = f2u_sat(log2c(linear_z) * pc.z_scale + pc.z_bias); // cluster_common.glsl:18-20
-            bit = shl1(slice);                                          // :30
-            const float inv = 1.0f - d;                                 // :33
-            // the sign / payload of a NaN produced by arithmetic is implementation-defined: canonical quiet NaN
-            bmin = inv != inv ? 0x7fc00000u : __float_as_uint(inv);
-            bmax = __float_as_uint(d);                                  // :34
-        }
-        const uint32_t chunk_mask = wave_reduce_or(bit);
-        tile_mask |= chunk_mask;
-        uint32_t todo = chunk_mask;
-        if (cz < 32u) todo &= (1u << cz) - 1u; // :31 slice < cluster_count.z
-        while (todo) {
-            const uint32_t s = (uint32_t)__builtin_ctz(todo);
-            todo &= todo - 1u;
-            const bool mine = valid && slice == s;
-            const uint32_t m1 = wave_reduce_max(mine ? bmin : 0u);
-            const uint32_t m2 = wave_reduce_max(mine ? bmax : 0u);
-            if ((uint32_t)lane == s) {
-                acc_min = max(acc_min, m1);
-                acc_max = max(acc_max, m2);
+        index = ((size_t)py * W + px) * sc + smp;
+        return tile < cx * cy && it < items && px < W && py < H;
+    };
+    float first[kMarkTiles];
+    bool first_valid[kMarkTiles];
+#pragma unroll
+    for (uint32_t t = 0; t < kMarkTiles; t++) {
+        size_t index;
+        first_valid[t] = sample(tile0 + t, (uint32_t)lane, index);
+        first[t] = first_valid[t] ? p.depth[index] : 0.0f;
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < kMarkTiles; t++) {
+        const uint32_t tile = tile0 + t;
+        if (tile >= cx * cy) break; // wave-uniform
+        uint32_t acc_min = 0, acc_max = 0, tile_mask = 0;
+        for (uint32_t base = 0; base < items; base += 64) {
+            bool valid = first_valid[t];
+            float d = first[t];
+            if (base != 0) {
+                size_t index;
+                valid = sample(tile, base + (uint32_t)lane, index);
+                d = valid ? p.depth[index] : 0.0f;
+            }
+            uint32_t slice = 0xFFFFFFFFu, bmin = 0, bmax = 0, bit = 0;
+            if (valid) {
+                const float linear_z = pc.z_near / d;                       // :28
+                slice = f2u_sat(log2c(linear_z) * pc.z_scale + pc.z_bias); // cluster_common.glsl:18-20
+                bit = shl1(slice);                                          // :30
+                const float inv = 1.0f - d;                                 // :33
+                // the sign / payload of a NaN produced by arithmetic is implementation-defined: canonical quiet NaN
+                bmin = inv != inv ? 0x7fc00000u : __float_as_uint(inv);
+                bmax = __float_as_uint(d);                                  // :34
+            }
+            const uint32_t chunk_mask = wave_reduce_or(bit);
+            tile_mask |= chunk_mask;
+            uint32_t todo = chunk_mask;
+            if (cz < 32u) todo &= (1u << cz) - 1u; // :31 slice < cluster_count.z
+            while (todo) {
+                const uint32_t s = (uint32_t)__builtin_ctz(todo);
+                todo &= todo - 1u;
+                const bool mine = valid && slice == s;
+                const uint32_t m1 = wave_reduce_max(mine ? bmin : 0u);
+                const uint32_t m2 = wave_reduce_max(mine ? bmax : 0u);
+                if ((uint32_t)lane == s) {
+                    acc_min = max(acc_min, m1);
+                    acc_max = max(acc_max, m2);
+                }
             }
         }
+        if ((uint32_t)lane < cz) {
+            OrbitClusterDepthBounds b;
+            b.min_depth = acc_min;
+            b.max_depth = acc_max;
+            p.bounds[tile + (size_t)lane * cx * cy] = b;
+        }
+        if (lane == 0) p.masks[tile] = tile_mask;
     }
-    if ((uint32_t)lane < cz) {
-        OrbitClusterDepthBounds b;
-        b.min_depth = acc_min;
-        b.max_depth = acc_max;
-        p.bounds[tile + (size_t)lane * cx * cy] = b;
-    }
-    if (lane == 0) p.masks[tile] = tile_mask;
 }
 
 // -------------------------------------------------- active_cluster_compaction
@@ -573,7 +593,8 @@ __global__ void write_word(uint32_t *p, uint32_t v) { *p = v; }
 hipError_t launch_cluster_mark(const ClusterMarkParams &p, hipStream_t s) {
     const uint32_t tiles = p.pc.cluster_count[0] * p.pc.cluster_count[1];
     if (tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(cluster_mark_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, p);
+    const uint32_t per_block = 4 * kMarkTiles;
+    hipLaunchKernelGGL(cluster_mark_kernel, dim3((tiles + per_block - 1) / per_block), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

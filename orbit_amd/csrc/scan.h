@@ -13,31 +13,52 @@ __device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// Inclusive wave64 scan (sum) via cross-lane shuffles.
+// Cross-lane steps through DPP (data-parallel primitives of the VALU: no LDS round trip, where a __shfl is a
+// ds_bpermute with ~100 cycles of latency per step).  The six steps below leave in lane i the combination of lanes
+// 0..i: row_shr 1/2/4/8 scan inside each row of 16 lanes, row_bcast15 adds row 0 to row 1 and row 2 to row 3,
+// row_bcast31 adds rows 0-1 to rows 2-3.  Lanes without a source (and rows masked off) take `identity`.
+// All 64 lanes must be active at the call (wave-uniform control flow).
+#define ORBIT_DPP_STEP(OP, ctrl, row_mask) \
+    v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, ctrl, row_mask, 0xF, false))
+#define ORBIT_DPP_SCAN(OP)          \
+    ORBIT_DPP_STEP(OP, 0x111, 0xF); \
+    ORBIT_DPP_STEP(OP, 0x112, 0xF); \
+    ORBIT_DPP_STEP(OP, 0x114, 0xF); \
+    ORBIT_DPP_STEP(OP, 0x118, 0xF); \
+    ORBIT_DPP_STEP(OP, 0x142, 0xA); \
+    ORBIT_DPP_STEP(OP, 0x143, 0xC)
+
+__device__ __forceinline__ uint32_t dpp_op_add(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t dpp_op_max(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t dpp_op_or(uint32_t a, uint32_t b) { return a | b; }
+
+// Inclusive wave64 scan (sum).
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
+    const uint32_t identity = 0u;
+    ORBIT_DPP_SCAN(dpp_op_add);
     return v;
 }
 
+// Wave-wide reductions: the scan's last lane holds the total.
 __device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    const uint32_t identity = 0u;
+    ORBIT_DPP_SCAN(dpp_op_add);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 __device__ __forceinline__ uint32_t wave_reduce_max(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t t = __shfl_xor(v, d, 64);
-        v = v > t ? v : t;
-    }
-    return v;
+    const uint32_t identity = 0u;
+    ORBIT_DPP_SCAN(dpp_op_max);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+
+__device__ __forceinline__ uint32_t wave_reduce_or(uint32_t v) {
+    const uint32_t identity = 0u;
+    ORBIT_DPP_SCAN(dpp_op_or);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+#undef ORBIT_DPP_SCAN
+#undef ORBIT_DPP_STEP
 
 // Exclusive scan over a block of NW waves; returns the exclusive prefix of
 // `v` and stores the block total in *total.  `smem` holds NW+1 words.
