@@ -802,3 +802,56 @@ def test_compact_visible_lists_expand_to_the_canonical_list(torch_mod, engine, o
     with pytest.raises(OrbitError) as ei:
         engine.status()
     assert ei.value.code == E_CAPACITY
+
+
+def test_null_arguments_are_status_codes_not_crashes(torch_mod):
+    """Every entry point of include/orbit_abi.h called with NULL handles / buffers: a status code comes back (the
+    reference's unwrap / assert panics, as values across the C boundary), nothing is launched, nothing crashes."""
+    import ctypes as C
+
+    from orbit_amd import _lib
+
+    lib = _lib.load()
+    caps = _lib.Caps()
+    lib.orbit_default_caps(C.byref(caps))
+    ctx = C.c_void_p()
+    assert lib.orbit_ctx_create(0, C.byref(caps), C.byref(ctx)) == _lib.OK
+    try:
+        ci = sc.make_cull_info(sc.default_camera().view, sc.default_camera().planes)
+        cip = ci.ctypes.data_as(C.c_void_p)
+        eb, mb = _lib.EntityCullBufs(), _lib.MeshletCullBufs()  # all-NULL buffer sets
+        bad = (_lib.E_INVALID, _lib.E_MISSING)
+        some = C.c_void_p(ctx.value)  # any non-NULL pointer for arguments that are checked for NULL only
+        calls = [
+            lambda: lib.orbit_entity_cull(None, cip, C.byref(eb), 1, None),
+            lambda: lib.orbit_entity_cull(ctx, None, C.byref(eb), 1, None),
+            lambda: lib.orbit_entity_cull(ctx, cip, None, 1, None),
+            lambda: lib.orbit_entity_cull(ctx, cip, C.byref(eb), 1, None),
+            lambda: lib.orbit_entity_cull_range(ctx, cip, C.byref(eb), 0, 1, None),
+            lambda: lib.orbit_meshlet_cull(ctx, cip, None, None),
+            lambda: lib.orbit_meshlet_cull(ctx, cip, C.byref(mb), None),
+            lambda: lib.orbit_meshlet_cull(None, cip, C.byref(mb), None),
+            lambda: lib.orbit_meshlet_task_cull(ctx, cip, C.byref(mb), None, None),
+            lambda: lib.orbit_meshlet_cull_visible(ctx, cip, C.byref(mb), None, 16, None),
+            lambda: lib.orbit_expand_visible(ctx, None, None, None, 16, None),
+            lambda: lib.orbit_expand_visible(None, some, some, some, 16, None),
+            lambda: lib.orbit_depth_reduce(ctx, None, 64, 64, None, None),
+            lambda: lib.orbit_depth_reduce(ctx, some, 0, 64, some, None),
+            lambda: lib.orbit_depth_pyramid_desc(0, 0, None),
+            lambda: lib.orbit_cluster_mark(ctx, None, None, None, None, None),
+            lambda: lib.orbit_cluster_compact(ctx, None, None, None, 0, None),
+            lambda: lib.orbit_cluster_assign(ctx, None, None, None, None, None, 0, None, None),
+            lambda: lib.orbit_compute_clusters(ctx, None, None, None, None, None, None, None, 0, None, 0, None, None),
+            lambda: lib.orbit_gather_visible(ctx, None, 0, 1, None, None, 0, None),
+            lambda: lib.orbit_gather_visible_meshlets(ctx, None, 0, 1, None, None, 0, None),
+            lambda: lib.orbit_ctx_profile_read(ctx, None, None),
+            lambda: lib.orbit_ctx_status(None, None, 0),
+        ]
+        for i, call in enumerate(calls):
+            rc = call()
+            assert rc in bad, (i, rc)
+            assert lib.orbit_last_error(ctx)  # a message is always available
+        assert lib.orbit_ctx_status(ctx, None, 1) == _lib.OK  # and nothing was latched on the device
+    finally:
+        assert lib.orbit_ctx_destroy(ctx) == _lib.OK
+    assert lib.orbit_ctx_destroy(None) == _lib.OK  # destroying nothing is not an error
