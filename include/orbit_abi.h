@@ -335,6 +335,14 @@ typedef struct OrbitCaps {
 
 typedef struct OrbitCtx OrbitCtx;
 
+/* Concurrency contract.  Calls on one context may come from any thread (they are serialised inside the library) and
+ * only ENQUEUE work on the caller's stream.  The context owns one set of scratch buffers, so the cull / cluster entry
+ * points of ONE context must all be ordered on the device — use one stream per context, or order the streams with
+ * events — exactly as the reference's passes are ordered by its render graph.  Work that may overlap (a second view
+ * culled on another stream, the per-rank contexts of the sharded engine) takes one context per stream; contexts are
+ * independent.  orbit_expand_visible and the orbit_gather_visible* calls touch none of the cull scratch and
+ * may run on a side stream of the same context (bench.py does: the exchange of step i overlaps the cull of step i+1). */
+
 uint32_t orbit_abi_version(void);
 /* Fills `caps` with the reference's constants listed above. */
 void orbit_default_caps(OrbitCaps *caps);
