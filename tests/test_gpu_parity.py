@@ -855,3 +855,49 @@ def test_null_arguments_are_status_codes_not_crashes(torch_mod):
     finally:
         assert lib.orbit_ctx_destroy(ctx) == _lib.OK
     assert lib.orbit_ctx_destroy(None) == _lib.OK  # destroying nothing is not an error
+
+
+def test_two_contexts_overlap_on_two_streams(torch_mod, oracle):
+    """The concurrency contract of include/orbit_abi.h: one context per stream, contexts independent.  Two contexts
+    cull two different scenes, frame after frame, on two streams with nothing ordering them, from two host threads;
+    every frame of both equals the oracle."""
+    import threading
+
+    from orbit_amd.engine import Engine
+
+    torch = torch_mod
+    cam = sc.default_camera(rot=(0.6, 0.8))
+    ci = sc.make_cull_info(cam.view, cam.planes)
+    jobs = []
+    for seed, n in ((41, 20_000), (42, 9_000)):
+        scene = sc.make_scene(seed, n, n_meshes=max(50, n // 20), meshlets_per_mesh=(4, 64), extent=(200.0, 30.0, 200.0))
+        gs = GpuScene(torch, scene)
+        cap_d, cap_c = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
+        eng = Engine(0, max_entities=n + 256, max_dispatches=cap_d, max_draws=cap_c)
+        stream = torch.cuda.Stream()
+        outs = [(torch.zeros(L.DISPATCH_HEADER + 16 * cap_d, dtype=torch.uint8, device="cuda"),
+                 torch.zeros(L.DRAW_HEADER + 28 * cap_c, dtype=torch.uint8, device="cuda")) for _ in range(6)]
+        jobs.append((scene, gs, eng, stream, cap_d, cap_c, outs))
+    torch.cuda.synchronize()
+
+    def run(job):
+        scene, gs, eng, stream, cap_d, cap_c, outs = job
+        for disp, draw in outs:
+            eng.entity_cull(ci, gs.draws, gs.mesh_infos, disp, gs.entities, scene.entity_draw_count, cap_d, stream=stream)
+            eng.meshlet_cull(ci, disp, gs.meshlets, draw, gs.entities, gs.materials, cap_d, cap_c, stream=stream)
+
+    threads = [threading.Thread(target=run, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    try:
+        for scene, gs, eng, stream, cap_d, cap_c, outs in jobs:
+            ref = run_oracle(oracle, scene, ci)
+            for disp, draw in outs:
+                assert_same((host(disp), host(draw), None, None), ref)
+            eng.status()
+    finally:
+        for j in jobs:
+            j[2].close()
