@@ -186,6 +186,14 @@ def cluster_compact(cluster_count, masks, index_capacity):
     return out, int(dropped)
 
 
+def project_sphere(sphere, p00, p11):
+    """project_sphere (entity_cull.comp:83-102) of a view-space sphere with z already negated -> uv-space aabb[4]."""
+    s4 = np.ascontiguousarray(sphere, dtype=np.float32)
+    out = np.zeros(4, dtype=np.float32)
+    lib().oracle_project_sphere(_p(s4), C.c_float(p00), C.c_float(p11), _p(out))
+    return out
+
+
 def cluster_aabb(info, bounds, cluster_index):
     ib = _bytes(info)
     bounds = np.ascontiguousarray(bounds, dtype=np.uint32)

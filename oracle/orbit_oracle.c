@@ -11,7 +11,10 @@
  * built or run here (Rust + Vulkan; no cargo, no ICD).  The oracle is pinned
  * instead by (1) an independent numpy restatement of the predicates
  * (tests/np_restatement.py), (2) property tests, (3) golden fixtures generated
- * by this file (tests/golden/, script tests/golden/make_golden.py).
+ * by this file (tests/golden/, script tests/golden/make_golden.py), (4) the
+ * reference's own CPU twins of two pieces of the path (math.rs:170-199,
+ * cluster.rs:150-184) restated in orbit_amd/host and compared with this file
+ * (tests/test_host_cpu.py).
  *
  * Canonical execution model: sequential schedule in
  * ascending invocation order, subgroup = dispatch size S = 32, IEEE-754 binary32
@@ -253,6 +256,12 @@ static void project_sphere(const float *s, float p00, float p11, float *aabb) {
     aabb[1] = a3 * -0.5f + 0.5f;
     aabb[2] = a2 * 0.5f + 0.5f;
     aabb[3] = a1 * -0.5f + 0.5f;
+}
+
+/* Test hook: project_sphere on its own, so that it can be compared with the host mirror of the reference's CPU twin
+ * math::project_sphere_clip_space (src/math.rs:170-199), which is the same construction before the uv remap. */
+void oracle_project_sphere(const float *sphere, float p00, float p11, float *aabb_uv) {
+    project_sphere(sphere, p00, p11, aabb_uv);
 }
 
 /* Pass-2 occlusion test shared by entity_cull.comp:146-191 and

@@ -411,6 +411,47 @@ void ClusterSettings::cluster_counts(size_t out[3]) const {
     tile_counts(out);
     out[2] = z_slice_count;
 }
+Vec3 screen_to_view(const Mat4 &m, const float screen_size[2], const Vec4 &screen_pos) { // cluster.rs:134-141
+    const float tx = screen_pos.x / screen_size[0], ty = screen_pos.y / screen_size[1];
+    const float nx = tx * 2.0f - 1.0f, ny = (1.0f - ty) * 2.0f - 1.0f;
+    const Vec4 view = m.mul_vec4(Vec4{nx, ny, screen_pos.z, screen_pos.w});
+    return {view.x / view.w, view.y / view.w, view.z / view.w};
+}
+
+namespace {
+Vec3 line_intersection_to_z_plane(const Vec3 &a, const Vec3 &b, float z_distance) { // cluster.rs:143-148
+    const Vec3 normal{0.0f, 0.0f, -1.0f};
+    const Vec3 ab{b.x - a.x, b.y - a.y, b.z - a.z};
+    const float na = normal.x * a.x + normal.y * a.y + normal.z * a.z;
+    const float nab = normal.x * ab.x + normal.y * ab.y + normal.z * ab.z;
+    const float t = (z_distance - na) / nab;
+    return {a.x + t * ab.x, a.y + t * ab.y, a.z + t * ab.z};
+}
+} // namespace
+
+Aabb compute_cluster_aabb(const Mat4 &matrix, const float screen_size[2], float tile_size_px,
+                          const float cluster_count[3], float z_near, float z_far, const float cluster_id[3]) {
+    // cluster.rs:150-184
+    const Vec3 eye_pos{0.0f, 0.0f, 0.0f};
+    const float min_ss[2] = {cluster_id[0] * tile_size_px, cluster_id[1] * tile_size_px};
+    const float max_ss[2] = {std::fmin(min_ss[0] + tile_size_px, screen_size[0]),
+                             std::fmin(min_ss[1] + tile_size_px, screen_size[1])};
+    const Vec3 min_vs = screen_to_view(matrix, screen_size, Vec4{min_ss[0], min_ss[1], 1.0f, 1.0f});
+    const Vec3 max_vs = screen_to_view(matrix, screen_size, Vec4{max_ss[0], max_ss[1], 1.0f, 1.0f});
+    const float cluster_near = z_near * std::pow(z_far / z_near, cluster_id[2] / cluster_count[2]);
+    const float cluster_far = z_near * std::pow(z_far / z_near, (cluster_id[2] + 1.0f) / cluster_count[2]);
+    const Vec3 pts[4] = {line_intersection_to_z_plane(eye_pos, min_vs, cluster_near),
+                         line_intersection_to_z_plane(eye_pos, min_vs, cluster_far),
+                         line_intersection_to_z_plane(eye_pos, max_vs, cluster_near),
+                         line_intersection_to_z_plane(eye_pos, max_vs, cluster_far)};
+    Aabb out{pts[0], pts[0]};
+    for (int i = 1; i < 4; i++) {
+        out.min = {std::fmin(out.min.x, pts[i].x), std::fmin(out.min.y, pts[i].y), std::fmin(out.min.z, pts[i].z)};
+        out.max = {std::fmax(out.max.x, pts[i].x), std::fmax(out.max.y, pts[i].y), std::fmax(out.max.z, pts[i].z)};
+    }
+    return out;
+}
+
 std::pair<float, float> ClusterSettings::cluster_grid_info(float near) const {
     const float far = far_plane, num_slices = (float)z_slice_count;
     const float log_f_n = std::log2(far / near);

@@ -253,6 +253,17 @@ struct Camera { // camera.rs:115-142, with the view matrix given directly
     float z_near() const { return projection.z_near(); }
 };
 
+// The reference's CPU twin of the cluster volume (cluster.rs:134-184, drawn by debug_cluster_volumes :250-320): the
+// view-space AABB of cluster `cluster_id` with the ANALYTIC near/far of its depth slice.  light_culling.comp:62-90
+// builds the same box from the MEASURED depth bounds of the slice, which lie inside the analytic ones — so this box
+// contains the device's (tests/test_host_cpu.py).
+struct Aabb {
+    Vec3 min, max;
+};
+Vec3 screen_to_view(const Mat4 &screen_to_view_matrix, const float screen_size[2], const Vec4 &screen_pos); // :134-141
+Aabb compute_cluster_aabb(const Mat4 &inverse_projection, const float screen_size[2], float tile_size_px,
+                          const float cluster_count[3], float z_near, float z_far, const float cluster_id[3]);
+
 struct GraphClusterInfo { // cluster.rs:362-366
     graphics::GraphBufferHandle light_offset_image; // RG32UI 3-D image as (offset,count) pairs
     graphics::GraphBufferHandle light_index_list;

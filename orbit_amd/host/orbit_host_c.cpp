@@ -196,6 +196,14 @@ void orbit_host_cluster_settings_derive(const OrbitHostClusterSettings *s, float
     out->z_scale = zz.first, out->z_bias = zz.second;
 }
 
+void orbit_host_compute_cluster_aabb(const float inverse_projection[16], const float screen_size[2], float tile_size_px,
+                                     const float cluster_count[3], float z_near, float z_far, const float cluster_id[3],
+                                     float out[6]) {
+    const Aabb a = compute_cluster_aabb(Mat4::from_cols_array(inverse_projection), screen_size, tile_size_px,
+                                        cluster_count, z_near, z_far, cluster_id);
+    out[0] = a.min.x, out[1] = a.min.y, out[2] = a.min.z, out[3] = a.max.x, out[4] = a.max.y, out[5] = a.max.z;
+}
+
 void *orbit_host_context_create(int32_t device, void *stream, const OrbitCaps *caps) {
     HostCtx *h = nullptr;
     const int32_t rc = guarded([&] {

@@ -91,6 +91,11 @@ int32_t orbit_host_shadow_cascade(const OrbitHostShadowCascadeIn *in, OrbitHostC
 /* ClusterSettings methods */
 void orbit_host_cluster_settings_derive(const OrbitHostClusterSettings *s, float z_near, OrbitHostClusterDerived *out);
 
+/* compute_cluster_aabb, cluster.rs:150-184 (the reference's CPU twin of the cluster volume): out = min xyz, max xyz */
+void orbit_host_compute_cluster_aabb(const float inverse_projection[16], const float screen_size[2], float tile_size_px,
+                                     const float cluster_count[3], float z_near, float z_far, const float cluster_id[3],
+                                     float out_min_max[6]);
+
 /* graphics::Context slice + passes (need a GPU) */
 void *orbit_host_context_create(int32_t device, void *stream, const OrbitCaps *caps);
 void orbit_host_context_destroy(void *hctx);

@@ -232,6 +232,17 @@ def cluster_settings_derive(settings, z_near):
     return d
 
 
+def compute_cluster_aabb(inverse_projection, screen_size, tile_size_px, cluster_count, z_near, z_far, cluster_id):
+    """compute_cluster_aabb (cluster.rs:150-184), the reference's CPU twin of the cluster volume -> (min[3], max[3])."""
+    out = (C.c_float * 6)()
+    lib().orbit_host_compute_cluster_aabb(_mat(inverse_projection), (C.c_float * 2)(*[float(v) for v in screen_size]),
+                                          C.c_float(tile_size_px), (C.c_float * 3)(*[float(v) for v in cluster_count]),
+                                          C.c_float(z_near), C.c_float(z_far),
+                                          (C.c_float * 3)(*[float(v) for v in cluster_id]), out)
+    a = np.array(out, dtype=np.float32)
+    return a[:3], a[3:]
+
+
 # ----------------------------------------------------------------------------- graphics::Context slice + passes
 class Context:
     def __init__(self, device=0, stream=None, **caps):

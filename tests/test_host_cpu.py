@@ -136,3 +136,61 @@ def test_shadow_cascade_cull_info(cascade):
     assert np.all(d[:, keep] >= -radius * 1e-3 - 2 * texel)
     gpu = passes.cull_info_to_gpu(ci)
     assert gpu["projection_type"] == 1 and gpu["cull_plane_count"] == n
+
+
+@pytest.mark.parametrize("W,H,tile", [(320, 180, 8), (333, 187, 16)])
+def test_reference_cpu_twin_of_the_cluster_volume_contains_the_shader_box(oracle, W, H, tile):
+    """cluster.rs:150-184 `compute_cluster_aabb` is the reference's own CPU restatement of the cluster volume (its
+    debug draw), with the ANALYTIC near/far of the depth slice; light_culling.comp:62-90 builds the box from the
+    MEASURED depth bounds of the slice, which lie inside the analytic ones.  So the oracle's box of every active
+    cluster must lie inside the twin's box (up to rounding) — a check of the restatement against reference code that
+    does not come from the shader text."""
+    import test_gpu_parity as T
+
+    zs, far = 32, 200.0
+    push, depth, info, _ = T.cluster_inputs(oracle, 6, W, H, 0, tile, zs, far=far)
+    masks, bounds = oracle.cluster_mark(push, depth)
+    cx, cy, cz = (int(v) for v in push["cluster_count"])
+    inv_proj = np.asarray(info["screen_to_view_matrix"], dtype=np.float32)
+    z_near = float(push["z_near"])
+    checked = 0
+    rng = np.random.default_rng(1)
+    tiles = rng.permutation(cx * cy)[:400]
+    for t in tiles:
+        for z in range(cz):
+            if not (int(masks[t]) >> z) & 1:
+                continue
+            ci = int(t) + z * cx * cy
+            omn, omx = oracle.cluster_aabb(info, bounds, ci)
+            tmn, tmx = passes.compute_cluster_aabb(inv_proj, (W, H), tile, (cx, cy, cz), z_near, far,
+                                                   (int(t) % cx, int(t) // cx, z))
+            assert np.all(np.isfinite(omn)) and np.all(np.isfinite(omx))
+            span = np.maximum(np.abs(tmn), np.abs(tmx)) + 1e-3
+            tol = 2e-4 * span  # the slice edges are pow() in the twin and log2() on the device
+            assert np.all(omn >= tmn - tol) and np.all(omx <= tmx + tol), (ci, omn, omx, tmn, tmx)
+            checked += 1
+    assert checked > 300
+
+
+def test_shader_project_sphere_equals_the_reference_cpu_twin(oracle):
+    """math::project_sphere_clip_space (src/math.rs:170-199) is the reference's CPU twin of project_sphere
+    (entity_cull.comp:83-98): the same construction, stopping before the clip -> uv remap.  The host mirror restates
+    the Rust, the oracle restates the GLSL; remapping the former must give the latter bit for bit."""
+    rng = np.random.default_rng(8)
+    n_some = 0
+    for _ in range(3000):
+        r = np.float32(rng.uniform(0.05, 5.0))
+        c = np.array([rng.uniform(-40, 40), rng.uniform(-20, 20), rng.uniform(0.0, 80.0)], dtype=np.float32)
+        p00, p11 = np.float32(rng.uniform(0.5, 2.0)), np.float32(rng.uniform(0.5, 3.0))
+        znear = np.float32(0.01)
+        twin = passes.project_sphere_clip_space((c[0], c[1], c[2], r), znear, p00, p11)
+        if twin is None:
+            assert c[2] < r + znear  # the same near-plane gate as entity_cull.comp:161-163 (`cullable`)
+            continue
+        n_some += 1
+        twin = np.asarray(twin, dtype=np.float32)
+        h, mh = np.float32(0.5), np.float32(-0.5)
+        uv = np.array([twin[0] * h + h, twin[3] * mh + h, twin[2] * h + h, twin[1] * mh + h], dtype=np.float32)
+        got = oracle.project_sphere(np.array([c[0], c[1], c[2], r], dtype=np.float32), p00, p11)
+        assert np.array_equal(got.view(np.uint32), uv.view(np.uint32)), (c, r, got, uv)
+    assert n_some > 2000
