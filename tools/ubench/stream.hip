@@ -1,5 +1,7 @@
 // Micro-benchmark: HBM streaming read bandwidth on MI355X as a function of 16-B loads in flight per lane,
 // with the meshlet_eval access pattern (lane reads 32 contiguous bytes = 2 x dwordx4, rows of 2 KiB per wave).
+// build (here, cross-compiles): hipcc -O3 -w --offload-arch=gfx950 tools/ubench/stream.hip -o tools/ubench/stream.bin
+// run (GPU box):                 ./tools/ubench/stream.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
