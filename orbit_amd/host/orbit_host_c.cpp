@@ -7,6 +7,7 @@
 #include <string>
 
 #include "orbit_host.hpp"
+#include "orbit_assets.hpp"
 #include "orbit_scene.hpp"
 
 using namespace orbit;
@@ -403,6 +404,29 @@ const OrbitLightData *orbit_host_scene_light_data(const void *sc, uint64_t *coun
 }
 uint64_t orbit_host_scene_shadow_command_count(const void *sc) {
     return ((const scene::SceneData *)sc)->shadow_commands.size();
+}
+
+// ---------------------------------------------------------------- asset side (orbit_assets.hpp), host only
+int32_t orbit_host_compute_meshlets(const float *positions, uint64_t vertex_count, const uint32_t *indices,
+                                    uint64_t index_count, uint32_t material, uint32_t vertex_offset,
+                                    uint32_t data_offset_base, OrbitMeshlet *out_meshlets, uint32_t *out_meshlet_data,
+                                    uint64_t *meshlet_count, uint64_t *meshlet_data_words) {
+    return guarded([&] {
+        std::vector<uint32_t> data(data_offset_base, 0u); // earlier meshes' data: only its length matters here
+        std::vector<OrbitMeshlet> meshlets;
+        assets::compute_meshlets(positions, (size_t)vertex_count, indices, (size_t)index_count, (uint16_t)material,
+                                 vertex_offset, data, meshlets);
+        *meshlet_count = meshlets.size();
+        *meshlet_data_words = data.size() - data_offset_base;
+        if (out_meshlets && out_meshlet_data) {
+            std::memcpy(out_meshlets, meshlets.data(), meshlets.size() * sizeof(OrbitMeshlet));
+            std::memcpy(out_meshlet_data, data.data() + data_offset_base, (data.size() - data_offset_base) * 4);
+        }
+    });
+}
+void orbit_host_compute_mesh_bounds(const float *positions, uint64_t vertex_count, float aabb_min[3], float aabb_max[3],
+                                    float bounding_sphere[4]) {
+    assets::compute_mesh_bounds(positions, (size_t)vertex_count, aabb_min, aabb_max, bounding_sphere);
 }
 
 } // extern "C"

@@ -166,6 +166,17 @@ const void *orbit_host_scene_entity_draws(const void *scene, uint64_t *count);  
 const OrbitEntityData *orbit_host_scene_entity_data(const void *scene, uint64_t *count);
 const OrbitLightData *orbit_host_scene_light_data(const void *scene, uint64_t *count);
 uint64_t orbit_host_scene_shadow_command_count(const void *scene);
+
+/* ---- asset side (orbit_assets.hpp): mesh -> Meshlet[] + meshlet data, mesh bounds (host only) ---- */
+/* assets::mesh::compute_meshlets (mesh.rs:292-338).  Two-call protocol: with out_meshlets == NULL only the counts are
+ * returned; then call again with buffers of those sizes.  positions: xyz per vertex. */
+int32_t orbit_host_compute_meshlets(const float *positions, uint64_t vertex_count, const uint32_t *indices,
+                                    uint64_t index_count, uint32_t material, uint32_t vertex_offset,
+                                    uint32_t data_offset_base, OrbitMeshlet *out_meshlets, uint32_t *out_meshlet_data,
+                                    uint64_t *meshlet_count, uint64_t *meshlet_data_words);
+/* gltf_loader.rs:480-506 */
+void orbit_host_compute_mesh_bounds(const float *positions, uint64_t vertex_count, float aabb_min[3], float aabb_max[3],
+                                    float bounding_sphere[4]);
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,159 @@
+"""Asset side of the host mirror (orbit_amd/host/orbit_assets.hpp): triangle mesh -> Meshlet[] + meshlet data as
+assets::mesh::compute_meshlets lays them out (src/assets/mesh.rs:292-338), with meshoptimizer's cluster bounds
+restated.  Nothing in the reference pins these numbers ("parity unpinned"), so the checks are against the geometry:
+the partition is exact, the sphere holds its vertices, and — the point of the normal cone — a meshlet that the cull
+path's cone test rejects (oracle = the restated shader) has no triangle facing the camera."""
+import numpy as np
+import pytest
+
+import scenes as sc
+from orbit_amd import assets, layouts as L
+
+
+def uv_sphere(n_lat=24, n_lon=48, radius=1.0):
+    lat = np.linspace(0, np.pi, n_lat + 1)
+    lon = np.linspace(0, 2 * np.pi, n_lon, endpoint=False)
+    pos = np.array([[np.sin(a) * np.cos(b), np.cos(a), np.sin(a) * np.sin(b)] for a in lat for b in lon], dtype=np.float32)
+    pos *= radius
+    idx = []
+    for i in range(n_lat):
+        for j in range(n_lon):
+            a, b = i * n_lon + j, i * n_lon + (j + 1) % n_lon
+            c, d = a + n_lon, b + n_lon
+            idx += [a, b, c, b, d, c]  # outward-facing (counter-clockwise seen from outside)
+    return pos, np.array(idx, dtype=np.uint32)
+
+
+def torus(n_major=160, n_minor=24, R=2.0, r=0.6):
+    u = np.linspace(0, 2 * np.pi, n_major, endpoint=False)
+    v = np.linspace(0, 2 * np.pi, n_minor, endpoint=False)
+    pos = np.array([[(R + r * np.cos(b)) * np.cos(a), r * np.sin(b), (R + r * np.cos(b)) * np.sin(a)]
+                    for a in u for b in v], dtype=np.float32)
+    idx = []
+    for j in range(n_minor):  # strips along the major circle: a meshlet of 64 triangles spans 72 degrees of it
+        for i in range(n_major):
+            a, b = i * n_minor + j, i * n_minor + (j + 1) % n_minor
+            c, d = ((i + 1) % n_major) * n_minor + j, ((i + 1) % n_major) * n_minor + (j + 1) % n_minor
+            idx += [a, b, c, b, d, c]
+    return pos, np.array(idx, dtype=np.uint32)
+
+
+MESHES = {"sphere": uv_sphere, "torus": torus}
+
+
+def _outward(pos, idx):
+    """Flip the winding if the generator's triangles face inwards (the tests want closed, outward-facing surfaces)."""
+    tri = pos[idx.reshape(-1, 3)]
+    n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    vol = np.einsum("ij,ij->i", tri[:, 0], n).sum()  # 6 x signed volume
+    return idx if vol > 0 else idx.reshape(-1, 3)[:, ::-1].reshape(-1).copy()
+
+
+@pytest.mark.parametrize("name", list(MESHES))
+def test_meshlets_partition_the_mesh_within_the_limits(name):
+    pos, idx = MESHES[name]()
+    idx = _outward(pos, idx)
+    meshlets, data = assets.compute_meshlets(pos, idx, material=5, vertex_offset=1000, data_offset_base=77)
+    assert (meshlets["vertex_count"] <= assets.MAX_MESHLET_VERTICES).all()
+    assert (meshlets["triangle_count"] <= assets.MAX_MESHLET_TRIANGLES).all() and (meshlets["triangle_count"] > 0).all()
+    assert (meshlets["material_index"] == 5).all() and (meshlets["vertex_offset"] == 1000).all()
+    # data layout: vertex indices, then u8 corners padded to a whole word; offsets continue from the base (mesh.rs:311-317)
+    at = 77
+    tris = []
+    shifted = np.concatenate([np.zeros(77, np.uint32), data])
+    for m in meshlets:
+        assert int(m["data_offset"]) == at
+        at += int(m["vertex_count"]) + (3 * int(m["triangle_count"]) + 3) // 4
+        tris.append(assets.meshlet_triangles(m, shifted))
+    assert at == 77 + len(data)
+    got = np.concatenate(tris)
+    assert np.array_equal(got, idx.reshape(-1, 3))  # every triangle once, in mesh order, corners in order
+    assert len(meshlets) >= len(idx) // 3 // 64
+
+
+@pytest.mark.parametrize("name", list(MESHES))
+def test_sphere_contains_the_meshlet_and_the_mesh_bounds_contain_the_mesh(name):
+    pos, idx = MESHES[name]()
+    meshlets, data = assets.compute_meshlets(pos, _outward(pos, idx))
+    for m in meshlets:
+        v = pos[assets.meshlet_triangles(m, data).reshape(-1)]
+        c, r = m["bounding_sphere"][:3], m["bounding_sphere"][3]
+        assert np.all(np.linalg.norm(v - c, axis=1) <= r * (1 + 1e-5) + 1e-6)
+    mn, mx, sp = assets.compute_mesh_bounds(pos)
+    assert np.array_equal(mn, pos.min(axis=0)) and np.array_equal(mx, pos.max(axis=0))
+    assert np.allclose(sp[:3], (mn + mx) * np.float32(0.5))
+    assert np.all(np.linalg.norm(pos - sp[:3], axis=1) <= sp[3] * (1 + 1e-6))
+
+
+def _one_entity_scene(pos, idx, model):
+    meshlets, data = assets.compute_meshlets(pos, idx)
+    mn, mx, sp = assets.compute_mesh_bounds(pos)
+    mi = np.zeros(1, dtype=L.MESH_INFO)
+    mi["bounding_sphere"][0] = sp
+    mi["aabb_min"][0, :3], mi["aabb_max"][0, :3] = mn, mx
+    mi["lod_count"] = 1
+    mi["mesh_lods"][0, 0] = (0, len(meshlets))
+    ents = np.zeros(1, dtype=L.ENTITY_DATA)
+    ents["model_matrix"][0] = sc.mat4_cols(model)
+    ents["normal_matrix"][0] = np.eye(4, dtype=np.float32).reshape(16)
+    draws = np.zeros(1, dtype=L.ENTITY_DRAW)
+    mats = np.zeros(1, dtype=L.MATERIAL)
+    scene = sc.Scene(draws, ents, mi, meshlets, mats, (len(meshlets) + 31) // 32, len(meshlets))
+    return scene, data
+
+
+def _cone_trial(oracle, pos, idx, rng, scale):
+    """One random rigid placement (+ uniform scale) and camera: -> (rejected meshlets, rejected ones that still have a
+    triangle facing the camera)."""
+    ang = rng.uniform(0, 2 * np.pi)
+    c, s = np.cos(ang), np.sin(ang)
+    model = np.eye(4, dtype=np.float32)
+    model[:3, :3] = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], dtype=np.float32) * np.float32(scale)
+    model[:3, 3] = rng.uniform(-5, 5, 3)
+    scene, data = _one_entity_scene(pos, idx, model)
+    cam_pos = rng.uniform(-12, 12, 3).astype(np.float32)
+    cam = sc.default_camera(position=tuple(cam_pos), rot=(np.cos(ang * 0.7), np.sin(ang * 0.7)))
+    ci = sc.make_cull_info(cam.view, np.zeros((0, 4), np.float32), alpha_mode_flag=L.ALPHA_ALL)  # cone test only
+    disp, _, _ = oracle.entity_cull(ci, scene.entity_draw_buffer(), 1, scene.mesh_infos, scene.entities, 64)
+    draw, _, _ = oracle.meshlet_cull(ci, disp, scene.meshlets, len(scene.meshlets) + 8, scene.entities, scene.materials)
+    _, cmds = L.draw_buffer_commands(draw)
+    drawn = set(int(v) for v in cmds["meshlet_index"])
+    world = (pos @ model[:3, :3].T + model[:3, 3]).astype(np.float64)
+    rejected = wrong = 0
+    for mi_, m in enumerate(scene.meshlets):
+        if mi_ in drawn:
+            continue
+        tri = world[assets.meshlet_triangles(m, data)]
+        nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+        facing = np.einsum("ij,ij->i", nrm, cam_pos.astype(np.float64) - tri[:, 0]) > 1e-9 * np.abs(nrm).max()
+        rejected += 1
+        wrong += bool(facing.any())
+    return rejected, wrong
+
+
+@pytest.mark.parametrize("name", list(MESHES))
+def test_cone_rejected_meshlets_have_no_triangle_facing_the_camera(oracle, name):
+    """Rigid motion and uniform scale <= 1: whatever the cone test (meshlet_cull.comp:104-106,148-158, restated by the
+    oracle) rejects is entirely back-facing."""
+    pos, idx = MESHES[name]()
+    idx = _outward(pos, idx)
+    rng = np.random.default_rng(3)
+    total = 0
+    for trial in range(12):
+        rejected, wrong = _cone_trial(oracle, pos, idx, rng, scale=rng.choice([0.5, 1.0]))
+        assert wrong == 0, (name, trial, "cone test rejected a meshlet with a front-facing triangle")
+        total += rejected
+    assert total > 30  # the test really rejected something (a closed surface hides about half of itself)
+
+
+def test_reference_cone_test_over_culls_scaled_up_entities(oracle):
+    """Reference behaviour, reproduced bit for bit by the engine and surfaced by the geometry: meshlet_cull.comp:121
+    transforms the cone axis by the model matrix WITHOUT renormalising it, so for an entity scaled by k > 1 the left
+    side of `dot(c, axis) >= cutoff * |c| + r` grows by k while the cutoff term does not — the test then also rejects
+    meshlets that face the camera.  (meshoptimizer's formula assumes a unit axis.)  The drop-in keeps the behaviour;
+    this test documents it."""
+    pos, idx = uv_sphere()
+    idx = _outward(pos, idx)
+    rng = np.random.default_rng(3)
+    wrong = sum(_cone_trial(oracle, pos, idx, rng, scale=3.0)[1] for _ in range(12))
+    assert wrong > 0

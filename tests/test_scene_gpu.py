@@ -88,3 +88,62 @@ def test_scene_lights_feed_the_cluster_path(torch_mod, engine, oracle):
     import test_gpu_parity as T
 
     T._light_clusters(torch, engine, oracle, 320, 180, len(lights), 8, 32, 1, 1.0, poison=False, lights_override=lights)
+
+
+def build_geometry_scene(seed, n_entities):
+    """Real triangle meshes (tests/test_assets_cpu.py generators) -> Meshlet[] / MeshInfo[] through the asset mirror,
+    entities through SceneData: every input buffer of the cull path produced by the host-side producers."""
+    import test_assets_cpu as A
+    from orbit_amd import assets
+
+    meshes = [A.uv_sphere(24, 48, 1.0), A.torus(), A.uv_sphere(10, 16, 0.4)]
+    infos = np.zeros(len(meshes), dtype=L.MESH_INFO)
+    all_meshlets, all_data, vertex_offset = [], [], 0
+    for k, (pos, idx) in enumerate(meshes):
+        idx = A._outward(pos, idx)
+        m, d = assets.compute_meshlets(pos, idx, material=k % 3, vertex_offset=vertex_offset,
+                                       data_offset_base=sum(len(x) for x in all_data))
+        mn, mx, sp = assets.compute_mesh_bounds(pos)
+        infos["bounding_sphere"][k] = sp
+        infos["aabb_min"][k, :3], infos["aabb_max"][k, :3] = mn, mx
+        infos["vertex_offset"][k] = vertex_offset
+        infos["lod_count"][k] = 1
+        infos["mesh_lods"][k, 0] = (sum(len(x) for x in all_meshlets), len(m))
+        all_meshlets.append(m)
+        all_data.append(d)
+        vertex_offset += len(pos)
+    meshlets = np.concatenate(all_meshlets)
+    rng = np.random.default_rng(seed)
+    sd = S.SceneData()
+    quats = _random_unit_quats(rng, n_entities)
+    for i in range(n_entities):
+        k = np.float32(rng.choice([0.5, 1.0, 2.0]))
+        sd.add_entity(position=rng.uniform((-30, -4, -30), (30, 8, 30)), orientation=quats[i], scale=(k, k, k),
+                      mesh=int(rng.integers(len(meshes))))
+    sd.update_scene(infos)
+    draws, ents = sd.entity_draw_cache(), sd.entity_data_cache()
+    counts = infos["mesh_lods"][draws["mesh_index"], 0, 1].astype(np.int64)
+    mats = np.zeros(3, dtype=L.MATERIAL)
+    mats["alpha_mode"] = (0, 1, 2)
+    return sc.Scene(draws, ents, infos, meshlets, mats, int(((counts + 31) // 32).sum()), int(counts.sum()), dict(seed=seed))
+
+
+def test_real_geometry_through_every_producer(torch_mod, engine, oracle):
+    torch = torch_mod
+    scene = build_geometry_scene(9, 700)
+    cam = sc.default_camera(rot=(0.8, 0.6))
+    gs = GpuScene(torch, scene)
+    ci0 = sc.make_cull_info(cam.view, cam.planes)
+    recs, cmds = assert_same(run_gpu(torch, engine, gs, ci0), run_oracle(oracle, scene, ci0))
+    # closed surfaces: the normal cones reject a good part of what the frustum keeps
+    ci_nocone = sc.make_cull_info(cam.view, cam.planes, alpha_mode_flag=L.ALPHA_ALL)
+    assert 0 < len(cmds) < scene.lod0_meshlets
+    W, H = 256, 144
+    depth = sc.make_depth(11, W, H, cam)
+    opyr, d = oracle.depth_reduce(depth, W, H)
+    ps = (d.width, d.height)
+    evis = np.zeros((scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+    mvis = np.zeros(scene.vis_words, dtype=np.uint32)
+    ci2 = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=2, p00=cam.p00, p11=cam.p11, z_near=cam.z_near)
+    assert_same(run_gpu(torch, engine, gs, ci2, evis, mvis, opyr, ps), run_oracle(oracle, scene, ci2, evis, mvis, opyr, ps))
+    assert_same(run_gpu(torch, engine, gs, ci_nocone), run_oracle(oracle, scene, ci_nocone))
