@@ -157,3 +157,41 @@ def test_reference_cone_test_over_culls_scaled_up_entities(oracle):
     rng = np.random.default_rng(3)
     wrong = sum(_cone_trial(oracle, pos, idx, rng, scale=3.0)[1] for _ in range(12))
     assert wrong > 0
+
+
+@pytest.mark.parametrize("name", list(MESHES))
+def test_nothing_potentially_visible_is_culled(oracle, name):
+    """Frustum and cone together, from the geometry's side: a meshlet with a triangle that faces the camera and has a
+    vertex inside the view frustum may show up on screen, so the cull path (planes of frustum_planes_from_matrix +
+    cone test, scale <= 1) must draw it."""
+    pos, idx = MESHES[name]()
+    idx = _outward(pos, idx)
+    rng = np.random.default_rng(5)
+    must_total = 0
+    for trial in range(10):
+        ang = rng.uniform(0, 2 * np.pi)
+        c, s, k = np.cos(ang), np.sin(ang), rng.choice([0.5, 1.0])
+        model = np.eye(4, dtype=np.float32)
+        model[:3, :3] = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], dtype=np.float32) * np.float32(k)
+        model[:3, 3] = rng.uniform(-3, 3, 3)
+        scene, data = _one_entity_scene(pos, idx, model)
+        cam_pos = rng.uniform(-6, 6, 3).astype(np.float32)
+        cam = sc.default_camera(position=tuple(cam_pos), rot=(np.cos(ang * 0.3), np.sin(ang * 0.3)))
+        ci = sc.make_cull_info(cam.view, cam.planes, alpha_mode_flag=L.ALPHA_ALL)
+        disp, _, _ = oracle.entity_cull(ci, scene.entity_draw_buffer(), 1, scene.mesh_infos, scene.entities, 64)
+        draw, _, _ = oracle.meshlet_cull(ci, disp, scene.meshlets, len(scene.meshlets) + 8, scene.entities, scene.materials)
+        _, cmds = L.draw_buffer_commands(draw)
+        drawn = set(int(v) for v in cmds["meshlet_index"])
+        world = (pos @ model[:3, :3].T + model[:3, 3]).astype(np.float64)
+        view = (world @ cam.view[:3, :3].astype(np.float64).T) + cam.view[:3, 3].astype(np.float64)
+        planes = np.asarray(cam.planes, dtype=np.float64)
+        inside = np.all(view @ planes[:, :3].T + planes[:, 3] > 1e-6, axis=1)  # strictly inside every plane
+        for mi_, m in enumerate(scene.meshlets):
+            t = assets.meshlet_triangles(m, data)
+            tri = world[t]
+            nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+            facing = np.einsum("ij,ij->i", nrm, cam_pos.astype(np.float64) - tri[:, 0]) > 1e-9 * np.abs(nrm).max()
+            if (facing & inside[t].any(axis=1)).any():
+                must_total += 1
+                assert mi_ in drawn, (name, trial, mi_, "a potentially visible meshlet was culled")
+    assert must_total > 20
