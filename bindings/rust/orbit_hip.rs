@@ -37,6 +37,15 @@ pub struct OrbitMeshletCullBufs {
 }
 
 #[link(name = "orbit_cull")]
+pub const ORBIT_MAX_PYRAMID_MIPS: usize = 16;
+/// Geometry of the R32F mip chain `DepthPyramid::new` allocates (draw_gen.rs:456-494); buffer = 4 * total_texels bytes.
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct OrbitDepthPyramidDesc {
+    pub width: u32, pub height: u32, pub mip_levels: u32, pub total_texels: u32,
+    pub mip_offset: [u32; ORBIT_MAX_PYRAMID_MIPS], pub mip_width: [u32; ORBIT_MAX_PYRAMID_MIPS],
+    pub mip_height: [u32; ORBIT_MAX_PYRAMID_MIPS],
+}
+
 extern "C" {
     pub fn orbit_abi_version() -> u32;
     pub fn orbit_default_caps(caps: *mut OrbitCaps);
@@ -51,6 +60,12 @@ extern "C" {
                                    draw_first: u32, draw_count: u32, stream: *mut c_void) -> i32;
     pub fn orbit_meshlet_cull(ctx: *mut OrbitCtx, cull_info: *const c_void, bufs: *const OrbitMeshletCullBufs,
                               stream: *mut c_void) -> i32;
+    /// Host only: pyramid geometry for a screen size / from the mip-0 size the cull kernels see.
+    pub fn orbit_depth_pyramid_desc(screen_w: u32, screen_h: u32, desc: *mut OrbitDepthPyramidDesc) -> i32;
+    pub fn orbit_depth_pyramid_desc_from_mip0(mip0_w: u32, mip0_h: u32, desc: *mut OrbitDepthPyramidDesc) -> i32;
+    /// Measurement hooks: HIP events around the dominant kernel on the launch stream.
+    pub fn orbit_ctx_profile(ctx: *mut OrbitCtx, enable: i32) -> i32;
+    pub fn orbit_ctx_profile_read(ctx: *mut OrbitCtx, avg_ms: *mut f32, launches: *mut u32) -> i32;
     pub fn orbit_depth_reduce(ctx: *mut OrbitCtx, depth: *const f32, screen_w: u32, screen_h: u32,
                               pyramid: *mut f32, stream: *mut c_void) -> i32;
     pub fn orbit_cluster_mark(ctx: *mut OrbitCtx, push: *const c_void, depth: *const f32, masks: *mut u32,
