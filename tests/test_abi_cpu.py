@@ -132,3 +132,16 @@ def test_orbitscene_round_trip(tmp_path):
     (tmp_path / "bad").write_bytes(b"not a scene file at all")
     with pytest.raises(ValueError):
         orbitscene.read(tmp_path / "bad")
+
+
+def test_rust_binding_declares_every_entry_point():
+    """bindings/rust/orbit_hip.rs is the text a maintainer adds on the reference side (no Rust toolchain here, so it
+    is not compiled): at least its `extern "C"` block must name every function of include/orbit_abi.h."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "orbit_abi.h")).read()
+    rust = open(os.path.join(root, "bindings", "rust", "orbit_hip.rs")).read()
+    declared = set(re.findall(r"\b(orbit_[a-z0-9_]+)\s*\(", header))
+    bound = set(re.findall(r"\bfn (orbit_[a-z0-9_]+)", rust))
+    assert declared and declared <= bound, sorted(declared - bound)
