@@ -195,3 +195,20 @@ def test_nothing_potentially_visible_is_culled(oracle, name):
                 must_total += 1
                 assert mi_ in drawn, (name, trial, mi_, "a potentially visible meshlet was culled")
     assert must_total > 20
+
+
+@pytest.mark.parametrize("seed,entities,spread,zfar", [(5, 80, 3.0, 12.0), (2, 150, 2.0, 30.0)])
+def test_hiz_never_rejects_a_meshlet_that_owns_a_pixel(oracle, seed, entities, spread, zfar):
+    """The whole occlusion chain against exact depth (tools/hiz_geometry_check.py): real meshes are rasterised in
+    numpy, the depth goes through depth_reduce, every meshlet through the pass-2 test (entity stage + meshlet stage,
+    frame-0 bitsets).  A meshlet that is the nearest surface at some pixel centre is visible by construction and must
+    be drawn; the test must also have rejected a good part of the hidden ones, or it proves nothing."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import hiz_geometry_check as hz
+
+    r = hz.check(seed, entities, 320, 180, spread, zfar)
+    assert r["visible_but_rejected"] == 0, r
+    assert r["visible"] >= 60 and r["drawn"] < 0.8 * r["instances"], r
