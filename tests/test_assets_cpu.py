@@ -212,3 +212,21 @@ def test_hiz_never_rejects_a_meshlet_that_owns_a_pixel(oracle, seed, entities, s
     r = hz.check(seed, entities, 320, 180, spread, zfar)
     assert r["visible_but_rejected"] == 0, r
     assert r["visible"] >= 60 and r["drawn"] < 0.8 * r["instances"], r
+
+
+def test_two_pass_culling_does_not_change_the_picture(oracle):
+    """The two-pass protocol over a moving camera, judged by the image (tools/hiz_geometry_check.py::frame_sequence):
+    pass 1 redraws last frame's visible set, its rasterised depth feeds depth_reduce, pass 2 adds what became visible
+    and rewrites the bits.  Rasterising only what the two passes drew gives, pixel for pixel, the depth image of
+    rasterising every meshlet — in every frame — while the passes skip a part of the scene."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import hiz_geometry_check as hz
+
+    rows = hz.frame_sequence(seed=3, frames=4)
+    assert all(r["wrong_pixels"] == 0 for r in rows), rows
+    assert rows[0]["pass1"] == 0 and rows[0]["pass2"] > 0          # frame 0: everything is new
+    assert any(r["pass2"] > 0 for r in rows[2:])                   # the camera motion disoccludes something later
+    assert any(r["pass1"] + r["pass2"] < r["instances"] for r in rows[2:])  # and occlusion really skips work

@@ -123,6 +123,63 @@ def check(seed=1, n_entities=40, W=320, H=180, spread=8.0, zfar=30.0):
                 drawn=len(drawn), visible_but_rejected=len(lost), examples=lost[:5])
 
 
+def frame_sequence(seed=3, n_entities=40, W=240, H=135, spread=3.0, zfar=14.0, frames=3):
+    """The two-pass protocol over a camera path, judged by the picture: per frame pass 1 redraws what last frame's
+    bits say, its depth (rasterised from exactly those meshlets) feeds depth_reduce, pass 2 adds what became visible
+    and rewrites the bits (forward.rs:213-430).  Rasterising the union of the two draw lists must give the same depth
+    image as rasterising everything — culling may not change the picture."""
+    scene, data, geo, models = build(seed, n_entities, spread, zfar)
+    evis = np.zeros((scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+    mvis = np.zeros(scene.vis_words, dtype=np.uint32)
+    cap_d, cap_c = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
+    report = []
+    for f in range(frames):
+        ang = 0.12 * f  # the camera turns and strafes a little every frame
+        cam = sc.default_camera(position=(0.6 * f, 1.0, 2.0), rot=(np.cos(ang), np.sin(ang)), aspect=W / H)
+        vp = cam.proj.astype(np.float64) @ cam.view.astype(np.float64)
+        tris, owners = {}, []
+        for e, model in enumerate(models):
+            mesh = int(scene.entity_draws["mesh_index"][e])
+            pos, _ = geo[mesh]
+            world = np.c_[pos.astype(np.float64) @ model[:3, :3].astype(np.float64).T + model[:3, 3], np.ones(len(pos))]
+            clip = world @ vp.T
+            first, count = (int(v) for v in scene.mesh_infos["mesh_lods"][mesh, 0])
+            for m in range(first, first + count):
+                tris[(e, m)] = clip[assets.meshlet_triangles(scene.meshlets[m], data)]
+        assert all((t[:, :, 3] > cam.z_near).all() for t in tris.values()), "geometry must stay in front of the near plane"
+
+        def raster(keys):
+            keys = sorted(keys)
+            if not keys:
+                return np.zeros((H, W), dtype=np.float32)
+            tt = np.concatenate([tris[k] for k in keys])
+            oo = np.concatenate([np.full(len(tris[k]), i) for i, k in enumerate(keys)])
+            return rasterise(tt, oo, W, H)[0]
+
+        def cull(occlusion_pass, pyr=None, psize=(0, 0)):
+            nonlocal evis, mvis
+            kw = dict(p00=cam.p00, p11=cam.p11, z_near=cam.z_near) if occlusion_pass == 2 else {}
+            ci = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=occlusion_pass, alpha_mode_flag=L.ALPHA_ALL, **kw)
+            disp, e_out, _ = oracle.entity_cull(ci, scene.entity_draw_buffer(), scene.entity_draw_count, scene.mesh_infos,
+                                                scene.entities, cap_d, evis, pyr, psize)
+            draw, m_out, _ = oracle.meshlet_cull(ci, disp, scene.meshlets, cap_c, scene.entities, scene.materials, mvis,
+                                                 pyr, psize)
+            if occlusion_pass == 2:
+                evis, mvis = e_out, m_out
+            _, cmds = L.draw_buffer_commands(draw)
+            return set((int(e), int(m)) for e, m in zip(cmds["cmd_first_instance"], cmds["meshlet_index"]))
+
+        drawn1 = cull(1)
+        depth1 = raster(drawn1)
+        opyr, d = oracle.depth_reduce(depth1, W, H)
+        drawn2 = cull(2, opyr, (d.width, d.height))
+        assert not (drawn1 & drawn2), "pass 2 redrew something pass 1 had drawn"
+        picture, reference = raster(drawn1 | drawn2), raster(tris.keys())
+        report.append(dict(frame=f, instances=len(tris), pass1=len(drawn1), pass2=len(drawn2),
+                           wrong_pixels=int((picture.view(np.uint32) != reference.view(np.uint32)).sum())))
+    return report
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=1)
@@ -134,3 +191,5 @@ if __name__ == "__main__":
     a = ap.parse_args()
     oracle.build()
     print(check(a.seed, a.entities, a.width, a.height, a.spread, a.zfar))
+    for row in frame_sequence(a.seed):
+        print(row)
