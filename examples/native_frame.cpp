@@ -6,8 +6,11 @@
 // depth_reduce when the dump carries a depth buffer (draw_gen.rs:510-566).  The outputs are written to a file so that
 // tests/test_native_example_gpu.py can compare them bit-exactly with the CPU oracle run on the same dump.
 //
-//   usage: native_frame <scene.orbitscene> <out.bin>
+//   usage: native_frame <scene.orbitscene> <out.bin> [replays]
 //   out.bin: u64 sizes[3] {dispatch buffer, draw buffer, pyramid}, then the three blobs
+//   replays > 0: the frame is also captured into a HIP graph (every entry point only enqueues on the caller's stream,
+//   so stream capture just works) and replayed that many times; eager and replayed times per frame are printed.
+//   The outputs written are those of the LAST execution, whichever way it ran.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -92,7 +95,8 @@ std::vector<uint8_t> to_host(const void *d, size_t bytes) {
 } // namespace
 
 int main(int argc, char **argv) {
-    if (argc != 3) die("usage: native_frame <scene.orbitscene> <out.bin>");
+    if (argc != 3 && argc != 4) die("usage: native_frame <scene.orbitscene> <out.bin> [replays]");
+    const int replays = argc == 4 ? std::atoi(argv[3]) : 0;
     const std::vector<uint8_t> raw = read_file(argv[1]);
     const std::map<std::string, Section> sec = parse_scene(raw);
     for (const char *need : {"entity_draws", "mesh_infos", "entities", "meshlets", "materials", "cull_info"})
@@ -140,6 +144,20 @@ int main(int argc, char **argv) {
     hip_check(hipMemset(d_disp, 0, disp_bytes), "hipMemset: ");
     hip_check(hipMemset(d_cmds, 0, draw_bytes), "hipMemset: ");
 
+    // depth pyramid of the dumped frame, if any
+    void *d_depth = nullptr, *d_pyr = nullptr;
+    size_t pyr_bytes = 0;
+    uint32_t wh[2] = {0, 0};
+    if (sec.count("depth") && sec.count("screen")) {
+        std::memcpy(wh, sec.at("screen").data, 8);
+        if ((size_t)wh[0] * wh[1] * 4 != sec.at("depth").size) die("depth section does not match screen");
+        OrbitDepthPyramidDesc desc;
+        orbit_check(ctx, orbit_depth_pyramid_desc(wh[0], wh[1], &desc), "orbit_depth_pyramid_desc");
+        pyr_bytes = 4 * (size_t)desc.total_texels;
+        d_depth = to_device(sec.at("depth"));
+        hip_check(hipMalloc(&d_pyr, pyr_bytes), "hipMalloc: ");
+    }
+
     OrbitEntityCullBufs eb;
     std::memset(&eb, 0, sizeof(eb));
     eb.entity_draw_buffer = d_draws;
@@ -147,7 +165,6 @@ int main(int argc, char **argv) {
     eb.meshlet_dispatch_buffer = d_disp;
     eb.entity_buffer = d_ent;
     eb.dispatch_capacity = caps.max_dispatches;
-    orbit_check(ctx, orbit_entity_cull(ctx, &ci, &eb, n_draws, stream), "orbit_entity_cull");
     OrbitMeshletCullBufs mb;
     std::memset(&mb, 0, sizeof(mb));
     mb.meshlet_dispatch_buffer = d_disp;
@@ -158,24 +175,45 @@ int main(int argc, char **argv) {
     mb.dispatch_capacity = caps.max_dispatches;
     mb.draw_capacity = caps.max_draws;
     mb.material_count = (uint32_t)(sec.at("materials").size / 80);
-    orbit_check(ctx, orbit_meshlet_cull(ctx, &ci, &mb, stream), "orbit_meshlet_cull");
-
-    // depth pyramid of the dumped frame, if any
-    void *d_depth = nullptr, *d_pyr = nullptr;
-    size_t pyr_bytes = 0;
-    if (sec.count("depth") && sec.count("screen")) {
-        uint32_t wh[2];
-        std::memcpy(wh, sec.at("screen").data, 8);
-        if ((size_t)wh[0] * wh[1] * 4 != sec.at("depth").size) die("depth section does not match screen");
-        OrbitDepthPyramidDesc desc;
-        orbit_check(ctx, orbit_depth_pyramid_desc(wh[0], wh[1], &desc), "orbit_depth_pyramid_desc");
-        pyr_bytes = 4 * (size_t)desc.total_texels;
-        d_depth = to_device(sec.at("depth"));
-        hip_check(hipMalloc(&d_pyr, pyr_bytes), "hipMalloc: ");
-        orbit_check(ctx, orbit_depth_reduce(ctx, (const float *)d_depth, wh[0], wh[1], (float *)d_pyr, stream),
-                    "orbit_depth_reduce");
-    }
+    auto frame = [&] { // the calls of one frame, in the reference's order; nothing here allocates or synchronises
+        orbit_check(ctx, orbit_entity_cull(ctx, &ci, &eb, n_draws, stream), "orbit_entity_cull");
+        orbit_check(ctx, orbit_meshlet_cull(ctx, &ci, &mb, stream), "orbit_meshlet_cull");
+        if (d_pyr)
+            orbit_check(ctx, orbit_depth_reduce(ctx, (const float *)d_depth, wh[0], wh[1], (float *)d_pyr, stream),
+                        "orbit_depth_reduce");
+    };
+    frame();
     orbit_check(ctx, orbit_ctx_status(ctx, stream, 1), "orbit_ctx_status");
+    if (replays > 0) {
+        hipEvent_t e0, e1;
+        hip_check(hipEventCreate(&e0), "hipEventCreate: ");
+        hip_check(hipEventCreate(&e1), "hipEventCreate: ");
+        float eager_ms = 0, graph_ms = 0;
+        hip_check(hipEventRecord(e0, stream), "hipEventRecord: ");
+        for (int i = 0; i < replays; i++) frame();
+        hip_check(hipEventRecord(e1, stream), "hipEventRecord: ");
+        hip_check(hipEventSynchronize(e1), "hipEventSynchronize: ");
+        hip_check(hipEventElapsedTime(&eager_ms, e0, e1), "hipEventElapsedTime: ");
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        hip_check(hipStreamBeginCapture(stream, hipStreamCaptureModeGlobal), "hipStreamBeginCapture: ");
+        frame();
+        hip_check(hipStreamEndCapture(stream, &graph), "hipStreamEndCapture: ");
+        hip_check(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0), "hipGraphInstantiate: ");
+        hip_check(hipGraphLaunch(exec, stream), "hipGraphLaunch: "); // first launch uploads the graph
+        hip_check(hipEventRecord(e0, stream), "hipEventRecord: ");
+        for (int i = 0; i < replays; i++) hip_check(hipGraphLaunch(exec, stream), "hipGraphLaunch: ");
+        hip_check(hipEventRecord(e1, stream), "hipEventRecord: ");
+        hip_check(hipEventSynchronize(e1), "hipEventSynchronize: ");
+        hip_check(hipEventElapsedTime(&graph_ms, e0, e1), "hipEventElapsedTime: ");
+        orbit_check(ctx, orbit_ctx_status(ctx, stream, 1), "orbit_ctx_status");
+        std::printf("frame: eager %.1f us, graph replay %.1f us (x%d)\n", 1e3 * eager_ms / replays, 1e3 * graph_ms / replays,
+                    replays);
+        (void)hipGraphExecDestroy(exec);
+        (void)hipGraphDestroy(graph);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
 
     const std::vector<uint8_t> h_disp = to_host(d_disp, disp_bytes), h_cmds = to_host(d_cmds, draw_bytes);
     const std::vector<uint8_t> h_pyr = to_host(d_pyr, pyr_bytes);

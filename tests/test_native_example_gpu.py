@@ -34,8 +34,9 @@ def test_native_process_matches_the_oracle(tmp_path, oracle):
     orbitscene.write(dump, entity_draws=scene.entity_draw_buffer(), mesh_infos=scene.mesh_infos,
                      entities=scene.entities, meshlets=scene.meshlets, materials=scene.materials,
                      cull_info=np.asarray(ci).reshape(1), depth=depth, screen=np.array([W, H], dtype=np.uint32))
-    r = subprocess.run([BIN, dump, out], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([BIN, dump, out, "20"], capture_output=True, text=True, timeout=120)  # 20 eager + 20 graph replays
     assert r.returncode == 0, r.stderr
+    assert "graph replay" in r.stdout, r.stdout  # the frame was captured and replayed; outputs below are the replay's
     raw = open(out, "rb").read()
     n_disp, n_draw, n_pyr = struct.unpack_from("<QQQ", raw, 0)
     gdisp = np.frombuffer(raw, np.uint8, n_disp, 24)
