@@ -17,8 +17,8 @@
  *    allocation); ordering between calls is stream order, exactly like the
  *    render graph's barrier-separated batches (src/graphics/graph.rs:874-1050).
  *  - return value: 0 = ORBIT_OK, < 0 = ORBIT_E_*; text via orbit_last_error().
- *    Conditions only detectable on the device (capacity overflow, a bounded
- *    spin that gave up) are latched in the context and read with
+ *    Conditions only detectable on the device (an append past a caller
+ *    buffer's capacity) are latched in the context and read with
  *    orbit_ctx_status().
  */
 #ifndef ORBIT_ABI_H
