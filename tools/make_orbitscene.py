@@ -1,0 +1,61 @@
+"""Writes a sample `.orbitscene` (orbit_amd/orbitscene.py) built entirely by the host-side producers: procedural
+triangle meshes -> meshlets (orbit_amd/assets.py), entities -> EntityDrawBuffer / EntityData[] / LightData[]
+(orbit_amd/scene.py), the main view's GpuCullInfo and an analytic depth buffer.  Feed it to
+`examples/native_frame sample.orbitscene out.bin 100` or `python tools/run_orbitscene.py sample.orbitscene` (GPU box).
+usage: python tools/make_orbitscene.py sample.orbitscene [--entities N] [--seed S]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import scenes as sc  # noqa: E402
+import test_assets_cpu as A  # noqa: E402
+from orbit_amd import assets, layouts as L, orbitscene, scene as S  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("path")
+    ap.add_argument("--entities", type=int, default=2000)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    meshes = [A.uv_sphere(24, 48, 1.0), A.torus(), A.uv_sphere(10, 16, 0.4)]
+    infos = np.zeros(len(meshes), dtype=L.MESH_INFO)
+    all_m, all_d, vertex_offset = [], [], 0
+    for k, (pos, idx) in enumerate(meshes):
+        m, d = assets.compute_meshlets(pos, A._outward(pos, idx), material=k, vertex_offset=vertex_offset,
+                                       data_offset_base=sum(len(x) for x in all_d))
+        mn, mx, sp = assets.compute_mesh_bounds(pos)
+        infos["bounding_sphere"][k] = sp
+        infos["aabb_min"][k, :3], infos["aabb_max"][k, :3] = mn, mx
+        infos["vertex_offset"][k], infos["lod_count"][k] = vertex_offset, 1
+        infos["mesh_lods"][k, 0] = (sum(len(x) for x in all_m), len(m))
+        all_m.append(m)
+        all_d.append(d)
+        vertex_offset += len(pos)
+    sd = S.SceneData()
+    q = rng.normal(size=(a.entities, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    for i in range(a.entities):
+        k = float(rng.choice([0.5, 1.0]))
+        light = dict(kind=S.POINT, intensity=float(rng.uniform(1, 6)), param=0.1) if i % 10 == 0 else None
+        sd.add_entity(position=rng.uniform((-60, -4, -60), (60, 10, 60)), orientation=q[i], scale=(k, k, k),
+                      mesh=int(rng.integers(len(meshes))), light=light)
+    sd.update_scene(infos)
+    mats = np.zeros(len(meshes), dtype=L.MATERIAL)
+    cam = sc.default_camera(rot=(0.8, 0.6))
+    W, H = 1920, 1080
+    orbitscene.write(a.path, entity_draws=sd.entity_draw_buffer_bytes(), mesh_infos=infos,
+                     entities=sd.entity_data_cache(), meshlets=np.concatenate(all_m), materials=mats,
+                     lights=sd.light_data_cache(), cull_info=np.asarray(sc.make_cull_info(cam.view, cam.planes)).reshape(1),
+                     depth=sc.make_depth(a.seed, W, H, cam), screen=np.array([W, H], dtype=np.uint32),
+                     meshlet_data=np.concatenate(all_d))
+    print(f"{a.path}: {a.entities} entities, {sum(len(x) for x in all_m)} meshlets in {len(meshes)} meshes, "
+          f"{len(sd.light_data_cache())} lights, {W}x{H} depth")
+
+
+main()
