@@ -10,43 +10,7 @@ import scenes as sc
 from orbit_amd import assets, layouts as L
 
 
-def uv_sphere(n_lat=24, n_lon=48, radius=1.0):
-    lat = np.linspace(0, np.pi, n_lat + 1)
-    lon = np.linspace(0, 2 * np.pi, n_lon, endpoint=False)
-    pos = np.array([[np.sin(a) * np.cos(b), np.cos(a), np.sin(a) * np.sin(b)] for a in lat for b in lon], dtype=np.float32)
-    pos *= radius
-    idx = []
-    for i in range(n_lat):
-        for j in range(n_lon):
-            a, b = i * n_lon + j, i * n_lon + (j + 1) % n_lon
-            c, d = a + n_lon, b + n_lon
-            idx += [a, b, c, b, d, c]  # outward-facing (counter-clockwise seen from outside)
-    return pos, np.array(idx, dtype=np.uint32)
-
-
-def torus(n_major=160, n_minor=24, R=2.0, r=0.6):
-    u = np.linspace(0, 2 * np.pi, n_major, endpoint=False)
-    v = np.linspace(0, 2 * np.pi, n_minor, endpoint=False)
-    pos = np.array([[(R + r * np.cos(b)) * np.cos(a), r * np.sin(b), (R + r * np.cos(b)) * np.sin(a)]
-                    for a in u for b in v], dtype=np.float32)
-    idx = []
-    for j in range(n_minor):  # strips along the major circle: a meshlet of 64 triangles spans 72 degrees of it
-        for i in range(n_major):
-            a, b = i * n_minor + j, i * n_minor + (j + 1) % n_minor
-            c, d = ((i + 1) % n_major) * n_minor + j, ((i + 1) % n_major) * n_minor + (j + 1) % n_minor
-            idx += [a, b, c, b, d, c]
-    return pos, np.array(idx, dtype=np.uint32)
-
-
-MESHES = {"sphere": uv_sphere, "torus": torus}
-
-
-def _outward(pos, idx):
-    """Flip the winding if the generator's triangles face inwards (the tests want closed, outward-facing surfaces)."""
-    tri = pos[idx.reshape(-1, 3)]
-    n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
-    vol = np.einsum("ij,ij->i", tri[:, 0], n).sum()  # 6 x signed volume
-    return idx if vol > 0 else idx.reshape(-1, 3)[:, ::-1].reshape(-1).copy()
+uv_sphere, torus, MESHES, _outward = sc.uv_sphere, sc.torus, sc.MESHES, sc.outward_winding
 
 
 @pytest.mark.parametrize("name", list(MESHES))

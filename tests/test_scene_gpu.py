@@ -91,16 +91,15 @@ def test_scene_lights_feed_the_cluster_path(torch_mod, engine, oracle):
 
 
 def build_geometry_scene(seed, n_entities):
-    """Real triangle meshes (tests/test_assets_cpu.py generators) -> Meshlet[] / MeshInfo[] through the asset mirror,
+    """Real triangle meshes (tests/scenes.py generators) -> Meshlet[] / MeshInfo[] through the asset mirror,
     entities through SceneData: every input buffer of the cull path produced by the host-side producers."""
-    import test_assets_cpu as A
     from orbit_amd import assets
 
-    meshes = [A.uv_sphere(24, 48, 1.0), A.torus(), A.uv_sphere(10, 16, 0.4)]
+    meshes = [sc.uv_sphere(24, 48, 1.0), sc.torus(), sc.uv_sphere(10, 16, 0.4)]
     infos = np.zeros(len(meshes), dtype=L.MESH_INFO)
     all_meshlets, all_data, vertex_offset = [], [], 0
     for k, (pos, idx) in enumerate(meshes):
-        idx = A._outward(pos, idx)
+        idx = sc.outward_winding(pos, idx)
         m, d = assets.compute_meshlets(pos, idx, material=k % 3, vertex_offset=vertex_offset,
                                        data_offset_base=sum(len(x) for x in all_data))
         mn, mx, sp = assets.compute_mesh_bounds(pos)

@@ -13,7 +13,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import scenes as sc  # noqa: E402
-import test_assets_cpu as A  # noqa: E402
 from oracle import oracle  # noqa: E402
 from orbit_amd import assets, layouts as L  # noqa: E402
 
@@ -53,11 +52,11 @@ def rasterise(tris_clip, tri_owner, W, H):
 
 def build(seed, n_entities, spread=8.0, zfar=30.0):
     rng = np.random.default_rng(seed)
-    meshes = [A.uv_sphere(12, 24, 1.0), A.torus(48, 12), A.uv_sphere(8, 12, 0.5)]
+    meshes = [sc.uv_sphere(12, 24, 1.0), sc.torus(48, 12), sc.uv_sphere(8, 12, 0.5)]
     infos = np.zeros(len(meshes), dtype=L.MESH_INFO)
     all_m, all_d, geo = [], [], []
     for k, (pos, idx) in enumerate(meshes):
-        idx = A._outward(pos, idx)
+        idx = sc.outward_winding(pos, idx)
         m, d = assets.compute_meshlets(pos, idx, data_offset_base=sum(len(x) for x in all_d))
         mn, mx, sp = assets.compute_mesh_bounds(pos)
         infos["bounding_sphere"][k] = sp

@@ -12,7 +12,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import scenes as sc  # noqa: E402
-import test_assets_cpu as A  # noqa: E402
 from orbit_amd import assets, layouts as L, orbitscene, scene as S  # noqa: E402
 
 
@@ -23,11 +22,11 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
-    meshes = [A.uv_sphere(24, 48, 1.0), A.torus(), A.uv_sphere(10, 16, 0.4)]
+    meshes = [sc.uv_sphere(24, 48, 1.0), sc.torus(), sc.uv_sphere(10, 16, 0.4)]
     infos = np.zeros(len(meshes), dtype=L.MESH_INFO)
     all_m, all_d, vertex_offset = [], [], 0
     for k, (pos, idx) in enumerate(meshes):
-        m, d = assets.compute_meshlets(pos, A._outward(pos, idx), material=k, vertex_offset=vertex_offset,
+        m, d = assets.compute_meshlets(pos, sc.outward_winding(pos, idx), material=k, vertex_offset=vertex_offset,
                                        data_offset_base=sum(len(x) for x in all_d))
         mn, mx, sp = assets.compute_mesh_bounds(pos)
         infos["bounding_sphere"][k] = sp
