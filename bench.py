@@ -16,9 +16,8 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for _p in (ROOT, os.path.join(ROOT, "tests")):
-    if _p not in sys.path:
-        sys.path.insert(0, _p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 import numpy as np
 import torch
@@ -35,7 +34,7 @@ def parse():
     ap.add_argument("--entities", type=int, default=195_313, help="config 5: 195313 x 256 = 50 000 128 meshlets")
     ap.add_argument("--meshlets-per-entity", type=int, default=256)
     ap.add_argument("--survive", type=float, default=0.10, help="target survivor fraction (SURVEY.md §8d prices 10 %%)")
-    ap.add_argument("--cpu-sample-entities", type=int, default=195_072,
+    ap.add_argument("--cpu-sample-entities", type=int, default=195_313,
                     help="entities of the scene the CPU oracle is timed on (rank 0, N=1 only); 0 disables")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="minimum CPU time spent in the oracle baseline")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather (cull only)")
@@ -46,8 +45,38 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: this process touches no GPU (importing torch does
+    not initialise HIP) and starts one fresh child per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set — the
+    environment `python -m torch.distributed.run --nproc-per-node N` would have given them.  Rank 0's stdout (the ONE
+    JSON line) is forwarded; the exit code is non-zero if any rank failed.  Nothing is re-executed in a process that
+    has initialised the GPU."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.buffer.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit(f"bench.py: rank(s) failed (rank, exit code): {bad}")
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
     # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL writes its version banner to
     # stdout, C-buffered, i.e. after anything Python printed): keep the real stdout aside for the JSON line and
     # point fd 1 at stderr for everything else, in every rank.
@@ -58,13 +87,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N ranks for --gpus N")
     # Dry-run knobs for boxes with fewer GPUs than ranks (never set by the driver): all ranks on device 0 and a
     # gloo process group exercise the N>1 control flow (sharding, barriers, reductions, JSON); gloo cannot move
     # device buffers point-to-point, so the visible-list gather is skipped there.  ORBIT_BENCH_FORCE_DIST=1 runs
-    # the RCCL group and the gather with a world of one.
+    # the RCCL group and the gather with a world of one.  ORBIT_BENCH_DRY_RANKS=1 (CPU test of the launcher): the
+    # ranks rendezvous over gloo, exchange their shard ranges and stop before any device work.
     backend = os.environ.get("ORBIT_BENCH_BACKEND", "nccl")
+    if os.environ.get("ORBIT_BENCH_DRY_RANKS") == "1":
+        return dry_ranks(args, rank, world, json_fd)
     device_index = 0 if os.environ.get("ORBIT_BENCH_ONE_DEVICE") == "1" else local_rank
     use_dist = world > 1 or os.environ.get("ORBIT_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(device_index)
@@ -77,10 +108,9 @@ def main():
         else:
             dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
-    import scenes as sc  # camera / CullInfo builders (test-side helpers, numpy only)
     from orbit_amd import dist as odist
     from orbit_amd import layouts as L
-    from orbit_amd import synth
+    from orbit_amd import camera, synth
     from orbit_amd.engine import Engine
 
     spec = synth.C5Spec(entities=args.entities, meshlets_per_entity=args.meshlets_per_entity)
@@ -109,8 +139,8 @@ def main():
 
     # camera outside the +-512 m box so that every entity passes the frustum: all E*M meshlets
     # reach meshlet_cull (the HBM-bound case the metric is about)
-    cam = sc.default_camera(position=(0.0, 0.0, 1300.0))
-    ci = sc.make_cull_info(cam.view, cam.planes[:args.planes])
+    # the renderer's default camera moved to (0, 0, 1300), through the product's host mirror (orbit_amd/camera.py)
+    ci = camera.frame_cull_info((0.0, 0.0, 1300.0), n_planes=args.planes)
 
     disp_cap = n_local_entities * rec_per_ent + 8
     draw_cap = n_local_meshlets // 2 + 1024
@@ -296,6 +326,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "meshlet_eval_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": ("profiles/traffic.json (rocprofv3 --pmc passes of an earlier run of this workload, "
+                                   "tools/traffic.sh; not measured in this run)" if traffic is not None else None),
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": eval_ms, "launches_timed": eval_launches,
                 "box_stream_reference": stream_ref,
                 "op": {"name": "meshlet_cull (eval + scan + emit)", "algorithmic_bytes": op_bytes,
@@ -308,6 +340,28 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     eng.close()
     if use_dist:
+        dist.destroy_process_group()
+
+
+def dry_ranks(args, rank, world, json_fd):
+    """Launcher test (CPU): rendezvous, shard ranges, one reduction, rank 0's JSON line."""
+    from orbit_amd import dist as odist
+
+    if world > 1:
+        dist.init_process_group("gloo")
+    b, e = odist.shard_ranges(args.entities, world)[rank]
+    mine = torch.tensor([b, e], dtype=torch.int64)
+    allr = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(allr, mine)
+        dist.barrier()
+    else:
+        allr = [mine]
+    if rank == 0:
+        out = {"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "shards": [[int(t[0]), int(t[1])] for t in allr]}
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if world > 1:
         dist.destroy_process_group()
 
 
@@ -327,26 +381,29 @@ def load_traffic(entities, meshlets_per_entity):
 
 def run_cpu_baseline(args, spec, ci, draws, mesh, ent, meshlets, materials, disp, draw, L):
     """Times the CPU oracle on all host cores (oracle/orbit_oracle_mt.c: the scalar C port on contiguous shards,
-    one OpenMP thread each) on the first `cpu_sample_entities` of the same scene, and checks that the GPU's output
-    prefix for those entities is bit-identical.  A single-thread pass over 1/16 of the sample is reported beside."""
+    one OpenMP thread each; built here with -O3 -march=native -ffp-contract=off) on the first
+    `cpu_sample_entities` of the same scene (default: all of them), and REQUIRES the GPU's output for those entities
+    to be bit-identical (canonical order: the sample's records / commands are a prefix of the full-scene output).
+    A single-thread pass over 1/16 of the sample is reported beside."""
     from oracle import oracle
 
     oracle.build()
     M = spec.meshlets_per_entity
-    es = min(args.cpu_sample_entities, spec.entities) // 256 * 256
-    if es == 0:
+    es = min(args.cpu_sample_entities, spec.entities)
+    if es <= 0:
         return None
     threads = oracle.max_threads()
     h_draws, h_mesh, h_ent = draws.cpu().numpy(), mesh.cpu().numpy(), ent.cpu().numpy()
     h_meshlets = meshlets[:es * M * 32].cpu().numpy()
     h_mat = materials.cpu().numpy()
     cap_d, cap_c = es * spec.records_per_entity + 8, es * M // 2 + 1024
-    cpu_s, reps = 0.0, 0
+    cpu_s, reps, out = 0.0, 0, None
     while (cpu_s < args.cpu_seconds / 4 or reps < 3) and reps < 200:
         t0 = time.perf_counter()
         odisp, odraw, _, _, _ = oracle.cull_frame_mt(ci, h_draws, es, h_mesh, h_ent, h_meshlets, h_mat, cap_d, cap_c,
-                                                     threads)
+                                                     threads, native=True, out=out)
         cpu_s += time.perf_counter() - t0
+        out = (odisp, odraw)
         reps += 1
     n_rec = int(odisp[:4].view(np.uint32)[0])
     n_in = int(odisp[12:12 + 16 * n_rec].view(np.uint32).reshape(-1, 4)[:, 2].sum())
@@ -355,20 +412,26 @@ def run_cpu_baseline(args, spec, ci, draws, mesh, ent, meshlets, materials, disp
     g_disp = disp[12:12 + 16 * n_rec].cpu().numpy()
     g_draw = draw[4:4 + 28 * n_draw].cpu().numpy()
     same = bool(np.array_equal(g_disp, odisp[12:12 + 16 * n_rec]) and np.array_equal(g_draw, odraw[4:4 + 28 * n_draw]))
+    if es == spec.entities:  # whole scene: the counts must agree as well
+        same = same and n_rec == int(disp[:4].view(torch.int32).item()) and n_draw == int(draw[:4].view(torch.int32).item())
+    if not same:
+        raise SystemExit("bench.py: GPU output differs from the CPU oracle on the bench scene — no metric is reported")
     # one thread, 1/16 of the sample
     e1 = max(256, es // 16 // 256 * 256)
     t0 = time.perf_counter()
-    d1, _, _ = oracle.entity_cull(ci, h_draws, e1, h_mesh, h_ent, e1 * spec.records_per_entity + 8)
-    oracle.meshlet_cull(ci, d1, h_meshlets, e1 * M // 2 + 1024, h_ent, h_mat)
+    d1, _, _, _, _ = oracle.cull_frame_mt(ci, h_draws, e1, h_mesh, h_ent, h_meshlets, h_mat,
+                                          e1 * spec.records_per_entity + 8, e1 * M // 2 + 1024, 1, native=True)
     t1 = time.perf_counter() - t0
     n1 = int(d1[12:12 + 16 * int(d1[:4].view(np.uint32)[0])].view(np.uint32).reshape(-1, 4)[:, 2].sum())
     return {
         "value": n_in * reps / cpu_s, "unit": "meshlets/s", "cores": threads, "kind": "port",
-        "sample": f"first {es} of {spec.entities} entities ({n_in} meshlets into meshlet_cull) of the same scene, "
-                  f"{reps} frames of oracle/orbit_oracle.c entity_cull + meshlet_cull on {threads} OpenMP threads "
-                  f"(contiguous shards, oracle/orbit_oracle_mt.c) in {cpu_s:.2f} s wall on a {os.cpu_count()}-core host",
+        "sample": f"{'all' if es == spec.entities else 'first'} {es} of {spec.entities} entities ({n_in} meshlets into "
+                  f"meshlet_cull) of the same scene, {reps} frames of oracle/orbit_oracle.c entity_cull + meshlet_cull "
+                  f"on {threads} OpenMP threads (contiguous shards, oracle/orbit_oracle_mt.c) in {cpu_s:.2f} s wall on a "
+                  f"{os.cpu_count()}-core host; gcc {oracle.NATIVE_CFLAGS}",
+        "flags": oracle.NATIVE_CFLAGS,
         "single_thread_value": n1 / t1,
-        "gpu_prefix_bit_identical": same,
+        "gpu_output_bit_identical": same,
     }
 
 

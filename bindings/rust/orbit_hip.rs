@@ -36,7 +36,6 @@ pub struct OrbitMeshletCullBufs {
     pub dispatch_capacity: u32, pub draw_capacity: u32, pub material_count: u32, pub _pad: u32,
 }
 
-#[link(name = "orbit_cull")]
 pub const ORBIT_MAX_PYRAMID_MIPS: usize = 16;
 /// Geometry of the R32F mip chain `DepthPyramid::new` allocates (draw_gen.rs:456-494); buffer = 4 * total_texels bytes.
 #[repr(C)] #[derive(Clone, Copy)]
@@ -46,6 +45,7 @@ pub struct OrbitDepthPyramidDesc {
     pub mip_height: [u32; ORBIT_MAX_PYRAMID_MIPS],
 }
 
+#[link(name = "orbit_cull")]
 extern "C" {
     pub fn orbit_abi_version() -> u32;
     pub fn orbit_default_caps(caps: *mut OrbitCaps);

@@ -21,6 +21,20 @@ def build(force=False):
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
 
 
+NATIVE_LIB_PATH = os.path.join(_HERE, "liborbit_oracle_native.so")
+NATIVE_CFLAGS = "-O3 -march=native -ffp-contract=off -fno-fast-math -fopenmp"  # oracle/Makefile NATIVE_CFLAGS
+_native = None
+
+
+def lib_native():
+    """The same sources built -O3 -march=native ON THIS HOST (cpu_baseline of bench.py; SURVEY.md §8d flags)."""
+    global _native
+    if _native is None:
+        subprocess.run(["make", "-C", _HERE, "-s", "-B", "native"], check=True)  # always for this host's CPU
+        _native = C.CDLL(NATIVE_LIB_PATH)
+    return _native
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -138,20 +152,23 @@ def max_threads():
 
 def cull_frame_mt(cull_info, entity_draw_buffer, entity_draw_count, mesh_infos, entities, meshlets, materials,
                   dispatch_capacity, draw_capacity, threads, visibility=None, meshlet_visibility=None, pyramid=None,
-                  pyramid_size=(0, 0)):
+                  pyramid_size=(0, 0), native=False, out=None):
     """entity_cull + meshlet_cull of one frame on `threads` OpenMP threads (orbit_oracle_mt.c: the sequential oracle
     on contiguous shards, concatenated).  Returns (dispatch bytes, draw bytes, entity vis, meshlet vis, dropped[2])."""
     ci = _bytes(cull_info)
     assert ci.nbytes == 400
     edb, mi, en = _bytes(entity_draw_buffer), _bytes(mesh_infos), _bytes(entities)
     ml, mt = _bytes(meshlets), _bytes(materials)
-    disp = np.zeros(12 + 16 * dispatch_capacity, dtype=np.uint8)
-    draw = np.zeros(4 + 28 * draw_capacity, dtype=np.uint8)
+    if out is None:  # `out` = (dispatch, draw) buffers of a previous call, reused by timing loops
+        disp = np.zeros(12 + 16 * dispatch_capacity, dtype=np.uint8)
+        draw = np.zeros(4 + 28 * draw_capacity, dtype=np.uint8)
+    else:
+        disp, draw = out
     ev = None if visibility is None else np.array(visibility, dtype=np.uint32, copy=True)
     mv = None if meshlet_visibility is None else np.array(meshlet_visibility, dtype=np.uint32, copy=True)
     pyr = None if pyramid is None else np.ascontiguousarray(pyramid, dtype=np.float32)
     dropped = (C.c_uint32 * 2)()
-    f = lib().oracle_cull_frame_mt
+    f = (lib_native() if native else lib()).oracle_cull_frame_mt
     f.restype = C.c_int32
     rc = f(_p(ci), _p(edb), C.c_uint32(entity_draw_count), _p(mi), _p(en), _p(ml), _p(mt), _p(disp),
            C.c_uint32(dispatch_capacity), _p(draw), C.c_uint32(draw_capacity), _p(ev), _p(mv), _p(pyr),

@@ -147,6 +147,9 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
                     "dispatch_size %u: only 32 keeps the reference's visibility-word addressing consistent "
                     "(src/graphics/device.rs:369-372)",
                     caps.dispatch_size);
+    if (caps.max_dispatches > max_dispatch_capacity())
+        return fail(nullptr, ORBIT_E_CAPACITY, "caps.max_dispatches %u > %u (chunk-base table of the emit launch)",
+                    caps.max_dispatches, max_dispatch_capacity());
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev)
@@ -733,16 +736,24 @@ int32_t gather_lists(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint32_t wor
     }
     if (world > 1) {
         ORBIT_NCCL(nc.group_start(), "ncclGroupStart");
-        for (uint32_t peer = 0; peer < world; peer++) {
+        // an error inside the group must still close it (an open group would swallow the communicator's next calls)
+        ncclResult_t bad = ncclSuccess;
+        const char *bad_what = "";
+        for (uint32_t peer = 0; peer < world && bad == ncclSuccess; peer++) {
             if (peer == rank) continue;
-            if (counts[rank] > 0)
-                ORBIT_NCCL(nc.send(mine, stride * counts[rank], ncclUint8, (int)peer, comm, s), "ncclSend");
-            if (counts[peer] > 0)
-                ORBIT_NCCL(nc.recv(out + header_bytes + stride * prefix[peer], stride * counts[peer], ncclUint8,
-                                   (int)peer, comm, s),
-                           "ncclRecv");
+            if (counts[rank] > 0) {
+                bad = nc.send(mine, stride * counts[rank], ncclUint8, (int)peer, comm, s);
+                bad_what = "ncclSend";
+            }
+            if (bad == ncclSuccess && counts[peer] > 0) {
+                bad = nc.recv(out + header_bytes + stride * prefix[peer], stride * counts[peer], ncclUint8, (int)peer,
+                              comm, s);
+                bad_what = "ncclRecv";
+            }
         }
-        ORBIT_NCCL(nc.group_end(), "ncclGroupEnd");
+        const ncclResult_t ended = nc.group_end();
+        if (bad != ncclSuccess) return fail(ctx, ORBIT_E_COMM, "%s: %s", bad_what, nc.error_string(bad));
+        ORBIT_NCCL(ended, "ncclGroupEnd");
     }
 #undef ORBIT_NCCL
     return ORBIT_OK;

@@ -117,6 +117,9 @@ hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_co
 // ev0/ev1 (optional): recorded on `s` immediately before / after the dominant kernel of the op
 hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, hipStream_t s,
                                hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// Largest dispatch capacity launch_meshlet_cull accepts (the emit launch keeps one base per scan chunk in LDS);
+// checked by orbit_ctx_create against caps.max_dispatches, so no launch is ever enqueued for a larger one.
+uint32_t max_dispatch_capacity();
 hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, uint8_t *draw_buffer,
                                  uint32_t draw_capacity, uint32_t num_cus, const void *zero_page, int32_t *status,
                                  hipStream_t s);

@@ -970,12 +970,17 @@ __global__ __launch_bounds__(256) void task_records_kernel(const MeshletCullPara
 template <int PASS>
 hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     const uint32_t max_tiles = (p.dispatch_capacity + kTileRecords - 1) / kTileRecords;
+    // nothing is enqueued for a capacity the emit launch cannot address (orbit_ctx_create rejects such caps already)
+    if ((max_tiles + kScanChunk - 1) / kScanChunk > kEmitChunkTable) return hipErrorInvalidValue;
     // eval -> scan -> emit
     uint32_t blocks = num_cus * (uint32_t)kEvWavesPerSimd; // 4-wave blocks: one wave per SIMD each
     const uint32_t need = (max_tiles + kEvWaves - 1) / kEvWaves;
     if (blocks > need) blocks = need;
     if (blocks == 0) blocks = 1;
-    if (ev0) (void)hipEventRecord(ev0, s);
+    if (ev0) {
+        const hipError_t ee = hipEventRecord(ev0, s);
+        if (ee != hipSuccess) return ee;
+    }
     const dim3 grid(blocks), block(kEvWaves * 64);
     const bool ortho = p.ci.projection_type == 1;
     if constexpr (PASS == 1) { // list-driven: only last frame's visible meshlets are read
@@ -1000,9 +1005,12 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t
         else
             hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 0, false>), grid, block, 0, s, p);
     }
-    if (ev1) (void)hipEventRecord(ev1, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (ev1) {
+        e = hipEventRecord(ev1, s);
+        if (e != hipSuccess) return e;
+    }
     if (p.task_records) { // mesh-shading path: expand the per-record ballots, no draw list
         const uint32_t tblocks = (p.dispatch_capacity + 255u) / 256u;
         if (tblocks) hipLaunchKernelGGL(task_records_kernel, dim3(tblocks), dim3(256), 0, s, p);
@@ -1012,7 +1020,6 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t
     e = launch_scan_chunks(p.tile_counts, p.tile_base, reinterpret_cast<const uint32_t *>(p.dispatch_buffer),
                            kTileRecords, max_tiles, p.chunk_sums, s);
     if (e != hipSuccess) return e;
-    if ((max_tiles + kScanChunk - 1) / kScanChunk > kEmitChunkTable) return hipErrorInvalidValue;
     uint32_t eblocks = num_cus * 8u;
     const uint32_t eneed = (max_tiles + 3) / 4;
     if (eblocks > eneed) eblocks = eneed;
@@ -1025,6 +1032,11 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t
 }
 
 } // namespace
+
+uint32_t max_dispatch_capacity() {
+    const uint64_t cap = (uint64_t)kEmitChunkTable * kScanChunk * kTileRecords;
+    return cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
+}
 
 hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, uint8_t *draw_buffer,
                                  uint32_t draw_capacity, uint32_t num_cus, const void *zero_page, int32_t *status,

@@ -1,4 +1,26 @@
 // orbit_assets.cpp — see orbit_assets.hpp.
+//
+// DERIVED WORK NOTICE.  compute_bounding_sphere() and compute_meshlet_bounds() below follow meshoptimizer's
+// computeBoundingSphere / meshopt_computeClusterBounds (clusterizer.cpp; the crate the reference pins is
+// meshopt 0.2.0, Cargo.toml:37) closely enough — same algorithm, thresholds and several identifiers — to count
+// as derived from it.  meshoptimizer is distributed under the MIT License; its notice is reproduced here and in
+// THIRD_PARTY.md at the repo root:
+//
+//   MIT License
+//   Copyright (c) 2016-2024 Arseny Kapoulkine
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated
+//   documentation files (the "Software"), to deal in the Software without restriction, including without
+//   limitation the rights to use, copy, modify, merge, publish, distribute, sublicense, and/or sell copies of the
+//   Software, and to permit persons to whom the Software is furnished to do so, subject to the following
+//   conditions: The above copyright notice and this permission notice shall be included in all copies or
+//   substantial portions of the Software.
+//   THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED
+//   TO THE WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT. IN NO EVENT SHALL
+//   THE AUTHORS OR COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF
+//   CONTRACT, TORT OR OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER
+//   DEALINGS IN THE SOFTWARE.
+//
+// The greedy meshlet partition in this file is this project's own and is not derived from meshoptimizer.
 #include "orbit_assets.hpp"
 
 #include <cmath>

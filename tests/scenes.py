@@ -378,3 +378,41 @@ def outward_winding(pos, idx):
     n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
     vol = np.einsum("ij,ij->i", tri[:, 0], n).sum()  # 6 x signed volume
     return idx if vol > 0 else idx.reshape(-1, 3)[:, ::-1].reshape(-1).copy()
+
+
+# ----------------------------------------------------------------------------- BASELINE config 1 as a scene
+def config1_spheres(n=8192):
+    """The 8192 spheres of BASELINE.json configs[0] / SURVEY.md §8d C1 (splitmix64 streams of seed 69; the inputs of
+    tests/golden/config1_spheres.npz)."""
+    i = np.arange(n)
+    return np.stack([rnd_range(69, 1, i, -128, 128), rnd_range(69, 2, i, -128, 128), rnd_range(69, 3, i, -128, 128),
+                     rnd_range(69, 4, i, 0.25, 4.0)], axis=1).astype(np.float32)
+
+
+def config1_scene(spheres, placement="model"):
+    """The C1 spheres as one-meshlet entities for entity_cull: entity i draws mesh i whose
+    bounding sphere is sphere i — placed either by the entity's model matrix (translation, mesh sphere at the
+    origin: SURVEY §8d "model = translation") or by the mesh's own bounding-sphere centre under an identity model.
+    Returns (entity_draw_buffer bytes, MeshInfo[], EntityData[], Meshlet[], Material[])."""
+    n = len(spheres)
+    draws = np.zeros(n, dtype=L.ENTITY_DRAW)
+    draws["entity_index"] = draws["mesh_index"] = draws["visibility_offset"] = np.arange(n)
+    mesh = np.zeros(n, dtype=L.MESH_INFO)
+    ent = np.zeros(n, dtype=L.ENTITY_DATA)
+    eye = mat4_cols(mat4_identity())
+    ent["model_matrix"] = eye
+    ent["normal_matrix"] = eye
+    if placement == "model":
+        ent["model_matrix"][:, 12:15] = spheres[:, :3]
+        mesh["bounding_sphere"][:, 3] = spheres[:, 3]
+    else:
+        mesh["bounding_sphere"] = spheres
+    mesh["lod_count"] = 1
+    mesh["mesh_lods"][:, 0, 0] = np.arange(n)  # meshlet_offset
+    mesh["mesh_lods"][:, 0, 1] = 1             # meshlet_count
+    meshlets = np.zeros(n, dtype=L.MESHLET)
+    meshlets["bounding_sphere"] = mesh["bounding_sphere"]
+    meshlets["cone_cutoff"] = 127
+    meshlets["vertex_count"], meshlets["triangle_count"] = 3, 1
+    materials = np.zeros(1, dtype=L.MATERIAL)
+    return L.entity_draw_buffer(draws), mesh, ent, meshlets, materials

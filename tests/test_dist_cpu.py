@@ -82,3 +82,30 @@ def test_gather_visible_gloo_world2(tmp_path, oracle, n_entities):
         assert np.array_equal(items["meshlet_index"], cmds["meshlet_index"])
         assert np.array_equal(items["entity_index"], cmds["cmd_first_instance"])
         assert np.all(gv[8 + 8 * n:] == 0x77)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_launches_its_own_ranks(world):
+    """`python bench.py --gpus N` outside torch.distributed.run starts N fresh rank processes itself (before anything
+    touches a GPU), forwards rank 0's ONE JSON line and fails if a rank fails.  ORBIT_BENCH_DRY_RANKS=1 stops the ranks
+    after the gloo rendezvous and the exchange of their shard ranges (no device here)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["ORBIT_BENCH_DRY_RANKS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["steps"] == 2
+    assert [tuple(s) for s in out["shards"]] == shard_ranges(195_313, world)
+    # a world that does not match --gpus is an error, not something silently ignored
+    env2 = dict(env, WORLD_SIZE=str(world + 1), RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world)], env=env2,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r2.returncode != 0 and b"WORLD_SIZE" in r2.stderr

@@ -50,6 +50,32 @@ def test_oracle_reproduces_config1_fixture(oracle):
     assert len(bits) == 256 and cnt == int(g["count"]) and np.array_equal(bits, g["bitset"])
 
 
+@pytest.mark.parametrize("placement", ["model", "mesh"])
+def test_oracle_entity_cull_reproduces_config1_fixture(oracle, placement):
+    """Config 1 through the cull path itself: the fixture's spheres as one-meshlet entities
+    through oracle entity_cull (entity_cull.comp:138-143).  The entities of the dispatch records are exactly the
+    fixture's set bits; in pass 2 against an all-far pyramid the entity bitset written IS the fixture bitset."""
+    import scenes as sc
+
+    g = load("config1_spheres.npz")
+    spheres = sc.config1_spheres()
+    edb, mesh, ent, _, _ = sc.config1_scene(spheres, placement)
+    n = len(spheres)
+    cam = sc.default_camera()
+    ci = sc.make_cull_info(cam.view, g["planes"])
+    disp, _, dropped = oracle.entity_cull(ci, edb, n, mesh, ent, n + 8)
+    assert dropped == 0
+    _, recs = L.dispatch_buffer_records(disp)
+    want = np.flatnonzero(np.unpackbits(g["bitset"].view(np.uint8), bitorder="little")[:n])
+    assert len(recs) == int(g["count"]) and np.array_equal(recs["entity_index"], want)
+    assert bool((recs["meshlet_count"] == 1).all()) and np.array_equal(recs["meshlet_offset"], want)
+    ci2 = sc.make_cull_info(cam.view, g["planes"], occlusion_pass=2, p00=cam.p00, p11=cam.p11, z_near=cam.z_near)
+    d = oracle.depth_pyramid_desc(64, 64)
+    pyr = np.zeros(d.total_texels, np.float32)  # reverse-Z 0 = infinitely far: nothing is occluded
+    _, ev, _ = oracle.entity_cull(ci2, edb, n, mesh, ent, n + 8, np.zeros(256, np.uint32), pyr, (d.width, d.height))
+    assert np.array_equal(ev, g["bitset"])
+
+
 def test_host_mirror_derives_config1_planes():
     """The C++ host mirror (camera.rs / math.rs restated) derives the fixture's five view-space planes."""
     from orbit_amd import passes
@@ -134,4 +160,56 @@ def test_gpu_reproduces_cluster_fixture():
     assert np.array_equal(gu.cpu().numpy()[:len(g["unique"])], g["unique"])
     assert np.array_equal(gl.cpu().numpy()[:len(g["light_indices"])], g["light_indices"])
     assert np.array_equal(gimg.cpu().numpy().view(np.uint32), g["offset_image"])
+    eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("placement", ["model", "mesh"])
+def test_gpu_config1_through_entity_cull(placement):
+    """BASELINE.json configs[0] through the PRODUCT: the fixture's 8192 spheres as one-meshlet
+    entities through orbit_entity_cull + orbit_meshlet_cull.  The dispatch records name exactly the fixture's set bits
+    (entity_cull.comp:138-143 with the planes of math.rs:71-89), the draw list holds one command per visible sphere
+    (meshlet sphere == entity sphere, no cone), and in pass 2 against an all-far pyramid the entity-visibility words
+    the device writes ARE the fixture's 256-word bitset."""
+    import scenes as sc
+    import torch
+
+    from orbit_amd.engine import Engine, depth_pyramid_desc
+
+    g = load("config1_spheres.npz")
+    spheres = sc.config1_spheres()
+    assert np.array_equal(spheres[:16], g["first_spheres"])
+    edb, mesh, ent, meshlets, materials = sc.config1_scene(spheres, placement)
+    n = len(spheres)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).cuda()
+    cam = sc.default_camera()
+    want = np.flatnonzero(np.unpackbits(g["bitset"].view(np.uint8), bitorder="little")[:n])
+    assert len(want) == int(g["count"])
+    eng = Engine(0)
+    b = [dev(a) for a in (edb, mesh, ent, meshlets, materials)]
+    cap = n + 8
+    disp = torch.zeros(12 + 16 * cap, dtype=torch.uint8, device="cuda")
+    draw = torch.zeros(4 + 28 * cap, dtype=torch.uint8, device="cuda")
+    ci = sc.make_cull_info(cam.view, g["planes"])
+    eng.entity_cull(ci, b[0], b[1], disp, b[2], n, cap)
+    eng.meshlet_cull(ci, disp, b[3], draw, b[2], b[4], cap, cap, material_count=1)
+    torch.cuda.synchronize()
+    eng.status()
+    head, recs = L.dispatch_buffer_records(disp.cpu().numpy())
+    assert list(head) == [len(want), 1, 1]
+    assert np.array_equal(recs["entity_index"], want) and np.array_equal(recs["meshlet_offset"], want)
+    assert bool((recs["meshlet_count"] == 1).all())
+    nd, cmds = L.draw_buffer_commands(draw.cpu().numpy())
+    assert nd == len(want) and np.array_equal(cmds["cmd_first_instance"], want)
+    assert np.array_equal(cmds["meshlet_index"], want)
+    # pass 2, nothing occluding: the device's entity bitset == the fixture's bitset, word for word
+    d = depth_pyramid_desc(64, 64)
+    pyr = torch.zeros(d.total_texels, dtype=torch.float32, device="cuda")
+    evis = torch.zeros(256, dtype=torch.int32, device="cuda")
+    ci2 = sc.make_cull_info(cam.view, g["planes"], occlusion_pass=2, p00=cam.p00, p11=cam.p11, z_near=cam.z_near,
+                            meshlet_visibility=False)
+    eng.entity_cull(ci2, b[0], b[1], disp, b[2], n, cap, visibility_buffer=evis, depth_pyramid=pyr,
+                    depth_pyramid_size=(d.width, d.height))
+    torch.cuda.synchronize()
+    assert np.array_equal(evis.cpu().numpy().view(np.uint32), g["bitset"])
     eng.close()

@@ -145,3 +145,72 @@ def test_config5_properties(torch_mod, oracle, entities):
         assert torch.equal(torch.cat(parts), cmds)
     finally:
         f.close()
+
+
+def test_config5_two_pass_frame_against_the_oracle(torch_mod, oracle):
+    """Config 5 at its full size through the two-pass HiZ frame, bit-exact against the oracle (run on all host cores,
+    oracle/orbit_oracle_mt.c): steady-state frame = pass-1 cull from last frame's bits, depth_reduce of a 1080p
+    depth buffer (a wall 950 m in front of the camera over 60 % of the screen), pass-2 cull.  Compared: the
+    pyramid, both draw lists, both dispatch lists and the entity / meshlet visibility words after the frame."""
+    torch = torch_mod
+    from orbit_amd.engine import depth_pyramid_desc
+
+    f = Frame(torch, 195_313)
+    try:
+        E, M = f.spec.entities, f.spec.meshlets_per_entity
+        cam, dev = f.cam, torch.device("cuda", 0)
+        W, H = 1920, 1080
+        depth = torch.zeros(H, W, dtype=torch.float32, device=dev)
+        depth[:, : int(0.6 * W)] = cam.z_near / 950.0
+        d = depth_pyramid_desc(W, H)
+        ps = (d.width, d.height)
+        ci1 = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=1)
+        ci2 = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=2, p00=cam.p00, p11=cam.p11, z_near=cam.z_near)
+        disp1 = torch.zeros(L.DISPATCH_HEADER + 16 * f.disp_cap, dtype=torch.uint8, device=dev)
+        disp2 = torch.zeros_like(disp1)
+        draw1 = torch.zeros(L.DRAW_HEADER + 28 * f.draw_cap, dtype=torch.uint8, device=dev)
+        draw2 = torch.zeros_like(draw1)
+        kw = dict(material_count=f.spec.materials, meshlet_visibility_buffer=f.mvis)
+
+        def frame():
+            f.eng.entity_cull(ci1, f.draws, f.mesh, disp1, f.ent, E, f.disp_cap, visibility_buffer=f.evis)
+            f.eng.meshlet_cull(ci1, disp1, f.meshlets, draw1, f.ent, f.materials, f.disp_cap, f.draw_cap, **kw)
+            f.eng.depth_reduce(depth, W, H, f.pyr)
+            f.eng.entity_cull(ci2, f.draws, f.mesh, disp2, f.ent, E, f.disp_cap, visibility_buffer=f.evis,
+                              depth_pyramid=f.pyr, depth_pyramid_size=ps)
+            f.eng.meshlet_cull(ci2, disp2, f.meshlets, draw2, f.ent, f.materials, f.disp_cap, f.draw_cap,
+                               depth_pyramid=f.pyr, depth_pyramid_size=ps, **kw)
+            torch.cuda.synchronize()
+            f.eng.status()
+
+        f.evis.zero_()
+        f.mvis.zero_()
+        for _ in range(3):  # frame 0 (everything newly visible) and two steady-state frames
+            prev_e = f.evis.cpu().numpy().view(np.uint32).copy()
+            prev_m = f.mvis.cpu().numpy().view(np.uint32).copy()
+            frame()
+        h = lambda t: t.cpu().numpy()
+        n1, n2 = int(draw1[:4].view(torch.int32).item()), int(draw2[:4].view(torch.int32).item())
+        assert n1 > 1_000_000  # the steady state really redraws last frame's meshlets in pass 1
+        edb, mi, en, ml, mt = (h(t) for t in (f.draws, f.mesh, f.ent, f.meshlets, f.materials))
+        o_pyr, _ = oracle.depth_reduce(h(depth), W, H)
+        assert np.array_equal(o_pyr.view(np.uint32), h(f.pyr).view(np.uint32)), "pyramid differs"
+        threads = oracle.max_threads()
+        od1, oc1, oe1, om1, dr1 = oracle.cull_frame_mt(ci1, edb, E, mi, en, ml, mt, f.disp_cap, f.draw_cap, threads,
+                                                       visibility=prev_e, meshlet_visibility=prev_m)
+        assert dr1 == (0, 0)
+        assert np.array_equal(h(disp1), od1), "pass-1 dispatch records differ"
+        assert int(oc1[:4].view(np.uint32)[0]) == n1 and np.array_equal(h(draw1)[:4 + 28 * n1], oc1[:4 + 28 * n1]), \
+            "pass-1 draws differ"
+        od2, oc2, oe2, om2, dr2 = oracle.cull_frame_mt(ci2, edb, E, mi, en, ml, mt, f.disp_cap, f.draw_cap, threads,
+                                                       visibility=oe1, meshlet_visibility=om1, pyramid=o_pyr,
+                                                       pyramid_size=ps)
+        assert dr2 == (0, 0)
+        nr2 = int(od2[:4].view(np.uint32)[0])
+        assert np.array_equal(h(disp2)[:12 + 16 * nr2], od2[:12 + 16 * nr2]), "pass-2 dispatch records differ"
+        assert int(oc2[:4].view(np.uint32)[0]) == n2 and np.array_equal(h(draw2)[:4 + 28 * n2], oc2[:4 + 28 * n2]), \
+            "pass-2 draws differ"
+        assert np.array_equal(h(f.evis).view(np.uint32), oe2), "entity visibility differs"
+        assert np.array_equal(h(f.mvis).view(np.uint32), om2), "meshlet visibility differs"
+    finally:
+        f.close()

@@ -399,6 +399,14 @@ def test_light_clusters_many_lights_and_saturated_clusters(torch_mod, engine, or
     _light_clusters(torch_mod, engine, oracle, 128, 72, 5000, 16, 16, 1, 1.0, poison=False, radius_scale=12.0)
 
 
+def test_light_clusters_config4_full_size(torch_mod, engine, oracle):
+    """BASELINE.json configs[3] at its full size: 1920x1080 depth, 10 000 point lights with
+    outer_r = sqrt(I / 0.25), default cluster settings => 240 x 135 x 32 = 1 036 800 clusters, 8-px tiles, far 200.
+    Tile masks, depth bounds, the compacted list, every cluster's (offset, count) and the ascending light index
+    lists against the oracle (mark_active.comp, active_cluster_compaction.comp, light_culling.comp:121-151)."""
+    _light_clusters(torch_mod, engine, oracle, 1920, 1080, 10_000, 8, 32, 1, 1.0, poison=False)
+
+
 def _light_clusters(torch_mod, engine, oracle, W, H, n_lights, tile, zs, samples, pf, poison, radius_scale=None,
                     lights_override=None):
     torch = torch_mod

@@ -244,6 +244,32 @@ def test_multithreaded_oracle_equals_sequential(oracle, threads):
                 assert np.array_equal(mev, ev) and np.array_equal(mmv, mv)
 
 
+def test_native_flags_build_of_the_oracle_is_byte_identical(oracle):
+    """bench.py's cpu_baseline runs the oracle built -O3 -march=native -ffp-contract=off: without
+    contraction the optimiser may vectorise but every operation stays a correctly rounded IEEE one — same bytes as
+    the -O2 build the parity tests use, all passes."""
+    scene = sc.make_scene(78, 500, n_meshes=70, lods=2, meshlets_per_mesh=(1, 80))
+    cam = sc.default_camera(rot=(0.2, 0.5))
+    rng = np.random.default_rng(78)
+    evis = rng.integers(0, 2 ** 32, (scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+    mvis = rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32)
+    W, H = 160, 90
+    pyr, d = oracle.depth_reduce(sc.make_depth(8, W, H, cam), W, H)
+    ps = (d.width, d.height)
+    args = (scene.entity_draw_buffer(), scene.entity_draw_count, scene.mesh_infos, scene.entities, scene.meshlets,
+            scene.materials, scene.max_dispatches() + 8, scene.lod0_meshlets + 8, 4)
+    for p in (0, 1, 2):
+        ci = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=p, p00=cam.p00, p11=cam.p11, z_near=cam.z_near,
+                               lod_base=8.0)
+        kw = dict(visibility=evis if p else None, meshlet_visibility=mvis if p else None,
+                  pyramid=pyr if p == 2 else None, pyramid_size=ps)
+        a = oracle.cull_frame_mt(ci, *args, **kw)
+        b = oracle.cull_frame_mt(ci, *args, native=True, **kw)
+        for x, y in zip(a[:4], b[:4]):
+            assert (x is None and y is None) or np.array_equal(x, y), p
+        assert a[4] == b[4]
+
+
 def test_task_path_agrees_with_the_draw_command_path(oracle):
     """forward_depth_prepass.task and meshlet_cull.comp take the same per-meshlet decision: the task records'
     (record, lane) survivors are exactly the draw commands, and the pass-2 visibility words differ only in the
