@@ -191,7 +191,7 @@ def test_config5_two_pass_frame_against_the_oracle(torch_mod, oracle):
             frame()
         h = lambda t: t.cpu().numpy()
         n1, n2 = int(draw1[:4].view(torch.int32).item()), int(draw2[:4].view(torch.int32).item())
-        assert n1 > 1_000_000  # the steady state really redraws last frame's meshlets in pass 1
+        assert n1 > 500_000  # the steady state really redraws last frame's meshlets in pass 1
         edb, mi, en, ml, mt = (h(t) for t in (f.draws, f.mesh, f.ent, f.meshlets, f.materials))
         o_pyr, _ = oracle.depth_reduce(h(depth), W, H)
         assert np.array_equal(o_pyr.view(np.uint32), h(f.pyr).view(np.uint32)), "pyramid differs"
