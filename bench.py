@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--exchange", choices=("visible", "commands"), default="visible",
                     help="N>1 exchange format: 8-B visible items expanded on every GPU against the replicated "
                          "meshlet buffer (default), or the 28-B commands themselves")
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="frame slots (OrbitCtx + stream + buffers each) the steps go round-robin over; 1 = strictly serial")
+    ap.add_argument("--time-every", type=int, default=3,
+                    help="the dominant kernel of every n-th launch per frame slot is timed with HIP events")
     ap.add_argument("--planes", type=int, default=5, help="cull planes used (5 = forward.rs:268; fewer only for triage)")
     return ap.parse_args()
 
@@ -144,68 +148,68 @@ def main():
 
     disp_cap = n_local_entities * rec_per_ent + 8
     draw_cap = n_local_meshlets // 2 + 1024
-    eng = Engine(device_index, max_entities=n_local_entities + 256, max_dispatches=disp_cap, max_draws=draw_cap)
-    disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device=dev)
-    # N > 1: two local list buffers, so that the exchange of step i-1 (RCCL, side stream) overlaps the cull of step i
+    # Frames in flight.  The renderer keeps FRAME_COUNT = 2 frames in flight with per-frame transient buffers
+    # (context.rs:1275-1316); here every frame slot owns an OrbitCtx (scan scratch), a stream, a dispatch buffer and
+    # a list buffer, and the K steps go round-robin over the slots.  What overlaps: frame k+1's entity cull (small,
+    # latency-bound) runs under frame k's scan / emit, and — N > 1 — the exchange of frame k's list under the cull of
+    # frame k+1, and the head of frame k+1's streaming evaluation under frame k's scan / emit and the tail of its
+    # evaluation (tools/bench_pipeline.py, in-process alternation: 0.419 -> 0.402 ms per frame with two slots; ordering
+    # the evaluations with events instead: 0.434, worse than serial).  With more than one slot the evaluations of
+    # consecutive frames share the device for part of their run, so the HIP-event duration of a single launch is
+    # no longer that kernel's own time: the default is ONE slot — strictly serial frames, step time = frame latency,
+    # clean per-kernel durations; `--frames-in-flight 2` is there to measure the overlap.
+    F = max(1, args.frames_in_flight)
     hdr, item = (L.VISIBLE_HEADER, 8) if visible_exchange else (L.DRAW_HEADER, 28)
-    draw_bufs = [torch.zeros(hdr + item * draw_cap, dtype=torch.uint8, device=dev)
-                 for _ in range(2 if do_gather else 1)]
-    draw = draw_bufs[0]
+
+    class Slot:
+        def __init__(self):
+            self.eng = Engine(device_index, max_entities=n_local_entities + 256, max_dispatches=disp_cap,
+                              max_draws=draw_cap)
+            self.stream = torch.cuda.Stream(device=dev)
+            self.disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device=dev)
+            self.draw = torch.zeros(hdr + item * draw_cap, dtype=torch.uint8, device=dev)
+
+    slots = [Slot() for _ in range(F)]
     gathered = gathered_vis = None
-    side = None
     if do_gather:
         gathered = torch.zeros(L.DRAW_HEADER + 28 * (draw_cap * world), dtype=torch.uint8, device=dev)
         if visible_exchange:
             gathered_vis = torch.zeros(L.VISIBLE_HEADER + 8 * (draw_cap * world), dtype=torch.uint8, device=dev)
-        side = torch.cuda.Stream(device=dev)
-    cull_done = [torch.cuda.Event() for _ in draw_bufs]    # per draw buffer: its cull has been enqueued/finished
-    gather_done = [torch.cuda.Event() for _ in draw_bufs]  # per draw buffer: its gather has read it
-    pending = []  # draw-buffer slots culled but not yet gathered (at most one)
+    pending = []  # slots culled but not yet exchanged (at most one)
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-
-    def gather(slot):
-        # counts download, RCCL send/recv and the local copy all go through the side stream, which waits only
-        # for the cull that filled this slot — not for the cull enqueued after it
-        with torch.cuda.stream(side):
-            side.wait_event(cull_done[slot])
+    def gather(s):
+        # counts download, RCCL send/recv, the local copy and the expansion go through the slot's own stream, behind
+        # its cull — not behind the cull enqueued after it on the next slot's stream
+        with torch.cuda.stream(s.stream):
             if visible_exchange:
-                odist.gather_visible(draw_bufs[slot], gathered_vis, header=L.VISIBLE_HEADER, stride=8)
-                gather_done[slot].record(side)  # the local list has been read
-                eng.expand_visible(gathered_vis, meshlets_base, gathered, draw_cap * world, stream=side)
+                odist.gather_visible(s.draw, gathered_vis, header=L.VISIBLE_HEADER, stride=8)
+                s.eng.expand_visible(gathered_vis, meshlets_base, gathered, draw_cap * world, stream=s.stream)
             else:
-                odist.gather_visible(draw_bufs[slot], gathered)
-                gather_done[slot].record(side)
+                odist.gather_visible(s.draw, gathered)
 
     step_no = [0]
 
     def step(i=None):
-        slot = step_no[0] % len(draw_bufs)
+        s = slots[step_no[0] % F]
         step_no[0] += 1
-        eng.entity_cull(ci, draws, mesh, disp, ent, n_local_entities, disp_cap, draw_first=b)
-        if i is not None:
-            ev[i][0].record()
+        with torch.cuda.stream(s.stream):
+            s.eng.entity_cull(ci, draws, mesh, s.disp, ent, n_local_entities, disp_cap, draw_first=b, stream=s.stream)
+            if visible_exchange:
+                s.eng.meshlet_cull_visible(ci, s.disp, meshlets_base, s.draw, ent, materials, disp_cap, draw_cap,
+                                           material_count=spec.materials, stream=s.stream)
+            else:
+                s.eng.meshlet_cull(ci, s.disp, meshlets_base, s.draw, ent, materials, disp_cap, draw_cap,
+                                   material_count=spec.materials, stream=s.stream)
         if do_gather:
-            torch.cuda.current_stream().wait_event(gather_done[slot])  # slot last read by the gather two steps ago
-        if visible_exchange:
-            eng.meshlet_cull_visible(ci, disp, meshlets_base, draw_bufs[slot], ent, materials, disp_cap, draw_cap,
-                                     material_count=spec.materials)
-        else:
-            eng.meshlet_cull(ci, disp, meshlets_base, draw_bufs[slot], ent, materials, disp_cap, draw_cap,
-                             material_count=spec.materials)
-        if i is not None:
-            ev[i][1].record()
-        if do_gather:
-            cull_done[slot].record()
             if pending:
                 gather(pending.pop())  # previous step's list travels while this step's cull runs
-            pending.append(slot)
+            pending.append(s)
 
     def drain():
-        if do_gather:
-            while pending:
-                gather(pending.pop())
-            torch.cuda.current_stream().wait_stream(side)
+        while pending:
+            gather(pending.pop())
+        for s in slots:
+            torch.cuda.current_stream().wait_stream(s.stream)
 
     if do_gather:  # RCCL channel set-up is not part of any step, warm or timed
         assert odist.warm_up(dev)
@@ -213,14 +217,18 @@ def main():
         step()
     drain()
     torch.cuda.synchronize()
-    eng.profile(True)  # HIP events around the dominant kernel (meshlet_eval), on the launch stream
+    # HIP events around the dominant kernel (meshlet_eval), recorded by the library on the launch stream.  An event
+    # pair costs ~7 us of stream time (it keeps the next launch from being prefetched: tools/t_host.py), so every
+    # `--time-every`-th launch per slot is timed, not all of them, and no other event is recorded inside the region.
+    for s in slots:
+        s.eng.profile(True, every=args.time_every)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    drain()  # every one of the K visible lists has been gathered inside the timed region
+    drain()  # every one of the K lists has been produced (and, N > 1, exchanged) inside the timed region
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -230,14 +238,40 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    eng.status()
-    eval_ms, eval_launches = eng.profile_read()
-    eng.profile(False)
-    assert eval_launches == args.steps, (eval_launches, args.steps)
+    eval_sum, eval_launches = 0.0, 0
+    for s in slots:
+        s.eng.status()
+        ms, n = s.eng.profile_read()
+        eval_sum += ms * n
+        eval_launches += n
+        s.eng.profile(False)
+    assert eval_launches >= 1, "no launch of the dominant kernel was timed"
+    eval_ms = eval_sum / eval_launches
 
-    kernel_ms = float(np.mean([a.elapsed_time(z) for a, z in ev]))  # whole meshlet_cull op (eval + scan + emit)
+    # one frame alone on an idle device (no other frame in flight): the latency a single cull costs
+    serial, op_ms = [], []
+    for _ in range(5):
+        a, m, z = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        s0 = slots[0]
+        with torch.cuda.stream(s0.stream):
+            a.record(s0.stream)
+            s0.eng.entity_cull(ci, draws, mesh, s0.disp, ent, n_local_entities, disp_cap, draw_first=b, stream=s0.stream)
+            m.record(s0.stream)
+            if visible_exchange:
+                s0.eng.meshlet_cull_visible(ci, s0.disp, meshlets_base, s0.draw, ent, materials, disp_cap, draw_cap,
+                                            material_count=spec.materials, stream=s0.stream)
+            else:
+                s0.eng.meshlet_cull(ci, s0.disp, meshlets_base, s0.draw, ent, materials, disp_cap, draw_cap,
+                                    material_count=spec.materials, stream=s0.stream)
+            z.record(s0.stream)
+        torch.cuda.synchronize()
+        serial.append(a.elapsed_time(z))
+        op_ms.append(m.elapsed_time(z))
+    frame_latency_ms = float(np.median(serial))
+    kernel_ms = float(np.median(op_ms))  # whole meshlet_cull op (eval + scan + emit) of a frame alone on the device
+    last = slots[0]  # the latency frames above ran on slot 0: its buffers hold the most recent result
+    disp, draw = last.disp, last.draw
     n_rec = int(disp[:4].view(torch.int32).item())
-    draw = draw_bufs[(step_no[0] - 1) % len(draw_bufs)]  # the last step's list
     n_draw = int(draw[:4].view(torch.int32).item())
     if do_gather:  # the gathered list holds this rank's commands at its rank-order position
         counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
@@ -252,6 +286,8 @@ def main():
         else:
             assert torch.equal(mine, draw[L.DRAW_HEADER:L.DRAW_HEADER + 28 * n_draw]), "gathered list != local list"
         assert int(gathered[:4].view(torch.int32).item()) == int(sum(int(c.item()) for c in counts))
+    for s in slots[1:]:  # every slot computed the same frame
+        assert torch.equal(s.draw[:hdr + item * n_draw], draw[:hdr + item * n_draw]), "frame slots disagree"
 
     n_in = int(disp[L.DISPATCH_HEADER:L.DISPATCH_HEADER + 16 * n_rec].view(torch.int32).view(-1, 4)[:, 2].sum().item())
     # cull-only rate of this rank (for the N>1 breakdown)
@@ -321,6 +357,7 @@ def main():
                                if do_gather else ""),
                 "entities": E, "meshlets": E * M, "meshlets_into_meshlet_cull": tot_in, "survivors": tot_draw,
                 "sharding": f"entity ranges over {world} rank(s)", "gather": bool(do_gather),
+                "frames_in_flight": F,
                 "exchange": (args.exchange if do_gather else None),
             },
             "roofline": {
@@ -334,11 +371,13 @@ def main():
                        "avg_ms": kernel_ms, "achieved": op_bytes / (kernel_ms * 1e-3) / 1e9},
             },
             "cpu_baseline": cpu_baseline,
+            "frame_latency_ms": frame_latency_ms,
             "cull_only_meshlets_per_sec": tot_in / (kernel_ms_max * 1e-3) if kernel_ms_max > 0 else None,
             "scene_gen_s": gen_s,
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    eng.close()
+    for s in slots:
+        s.eng.close()
     if use_dist:
         dist.destroy_process_group()
 

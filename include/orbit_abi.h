@@ -513,6 +513,9 @@ int32_t orbit_compute_clusters(OrbitCtx *ctx, const OrbitMarkActivePush *push,
 /* records a HIP event pair on the caller's stream around the op's dominant  */
 /* kernel (the streaming meshlet evaluation); profile_read waits for the     */
 /* recorded pairs and returns their mean duration.  Never on by default.     */
+/* `enable` = n > 0 times every n-th call (an event pair costs a few          */
+/* microseconds of stream time: it keeps the next launch from being          */
+/* prefetched), 0 switches the hook off.                                     */
 /* ------------------------------------------------------------------------ */
 int32_t orbit_ctx_profile(OrbitCtx *ctx, int32_t enable);
 int32_t orbit_ctx_profile_read(OrbitCtx *ctx, float *avg_ms, uint32_t *launches);

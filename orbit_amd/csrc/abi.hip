@@ -39,13 +39,15 @@ struct OrbitCtx {
              *a_total = nullptr, *a_coarse = nullptr, *a_coarse_counts = nullptr, *a_hit_cache = nullptr;
     float *a_aabb = nullptr, *a_group_box = nullptr;
     uint32_t a_coarse_seg = 0;
+    uint32_t *m_tickets = nullptr;
     uint32_t *g_counts = nullptr; // gather_visible: per-rank command counts
     int32_t *status = nullptr;
     uint32_t debug_flags = 0;
     unsigned long long *debug_cycles = nullptr;
     void *zero_page = nullptr;
     // measurement hook: HIP event pairs around the dominant kernel (meshlet_eval)
-    bool profiling = false;
+    uint32_t profiling = 0;   // 0 off, n: every n-th meshlet cull is timed
+    uint32_t prof_calls = 0;
     std::vector<hipEvent_t> prof_events; // pairs, in record order
     size_t prof_used = 0;
     char err[512] = {0};
@@ -182,9 +184,10 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
         return o;
     };
     const size_t o_status = carve(256);
-    const size_t o_dbg = carve(256);
+    const size_t o_dbg = carve(256 + 16 * 8192); // phase sums + per-wave {begin, end} wall-clock stamps (triage builds)
     const size_t o_zero = carve(256);
     const size_t o_gc = carve(256);
+    const size_t o_tk = carve(kTicketPools * kTicketStride * 4);
     const size_t o_eproto = carve(ent * sizeof(OrbitMeshletDispatch));
     const size_t o_ebs = carve(eblocks * 4), o_et = carve(256);
     const size_t o_mtc = carve(mtiles * 4), o_mtb = carve(mtiles * 4), o_mt = carve(256);
@@ -244,6 +247,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->a_group_box = (float *)(a + o_agb);
     ctx->a_coarse_seg = (uint32_t)aseg;
     ctx->g_counts = (uint32_t *)(a + o_gc);
+    ctx->m_tickets = (uint32_t *)(a + o_tk);
     const char *dbg = getenv("ORBIT_SP_DEBUG");
     ctx->debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u;
     snprintf(ctx->err, sizeof(ctx->err), "no error");
@@ -285,8 +289,9 @@ int32_t orbit_ctx_status(OrbitCtx *ctx, void *stream, int32_t sync) {
 int32_t orbit_ctx_profile(OrbitCtx *ctx, int32_t enable) {
     if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
-    ctx->profiling = enable != 0;
+    ctx->profiling = enable > 0 ? (uint32_t)enable : 0u;
     ctx->prof_used = 0;
+    ctx->prof_calls = 0;
     return ORBIT_OK;
 }
 
@@ -307,6 +312,15 @@ int32_t orbit_ctx_profile_read(OrbitCtx *ctx, float *avg_ms, uint32_t *launches)
     *avg_ms = n ? (float)(sum / n) : 0.f;
     *launches = n;
     ctx->prof_used = 0;
+    return ORBIT_OK;
+}
+
+// perf triage only (not part of the public ABI): per-wave {begin, end} wall_clock64 stamps of the last phase-stamped
+// meshlet_eval launch (ORBIT_SP_DEBUG=8), 100 MHz ticks; out holds 2 * 8192 values
+int32_t orbit_debug_read_wave_stamps(OrbitCtx *ctx, unsigned long long *out) {
+    if (!ctx || !out) return ORBIT_E_INVALID;
+    if (hipDeviceSynchronize() != hipSuccess) return ORBIT_E_HIP;
+    if (hipMemcpy(out, ctx->debug_cycles + 32, 16 * 8192, hipMemcpyDeviceToHost) != hipSuccess) return ORBIT_E_HIP;
     return ORBIT_OK;
 }
 
@@ -418,12 +432,13 @@ int32_t meshlet_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbit
     p.tile_base = ctx->m_tile_base;
     p.chunk_sums = ctx->m_chunk_sums;
     p.total = ctx->m_total;
+    p.tickets = ctx->m_tickets;
     p.debug_flags = ctx->debug_flags;
     p.debug_cycles = ctx->debug_cycles;
     p.zero_page = ctx->zero_page;
     p.status = ctx->status;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (ctx->profiling) {
+    if (ctx->profiling && (ctx->prof_calls++ % ctx->profiling) == 0) {
         if (ctx->prof_used + 2 > ctx->prof_events.size()) {
             for (int i = 0; i < 2; i++) {
                 hipEvent_t ev;

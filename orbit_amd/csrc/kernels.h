@@ -13,6 +13,9 @@ namespace orbit {
 // 64 lanes of a wave, one meshlet per lane per row) = 512 meshlets.
 constexpr uint32_t kTileRecords = 16;
 constexpr uint32_t kTileRows = 8;
+// meshlet_eval hands tiles out through kTicketPools counters (one 256-B line each); zero between evaluations
+constexpr uint32_t kTicketPools = 8;
+constexpr uint32_t kTicketStride = 64; // words
 
 struct EntityCullParams {
     OrbitGpuCullInfo ci;
@@ -57,6 +60,7 @@ struct MeshletCullParams {
     uint32_t *tile_base;   // chunk-local exclusive prefix of tile_counts
     uint32_t *chunk_sums;  // per kScanChunk tiles; the emit launch prefix-sums them itself (LDS)
     uint32_t *total;
+    uint32_t *tickets;     // kTicketPools x kTicketStride words (meshlet_eval tile tickets)
     const void *zero_page; // 256 zero bytes of context scratch: target of inactive lanes' loads
     unsigned long long *debug_cycles; // ORBIT_SP_DEBUG & 8: per-phase s_memtime sums (8 slots)
     uint32_t debug_flags; // ORBIT_SP_DEBUG (perf triage only): 8 = per-phase cycle stamps (pass 0 only)
@@ -137,7 +141,9 @@ hipError_t launch_scan_two_level(const uint32_t *in, uint32_t *out_local, const 
                                  uint32_t n_max, uint32_t *chunk_sums, uint32_t *chunk_base, uint32_t *total,
                                  hipStream_t s);
 // First level only (out_local and chunk_sums); the consumer scans the chunk sums itself.
+// `clear` (optional): `clear_words` words zeroed by the launch as well (a fused memset for the caller's counters)
 hipError_t launch_scan_chunks(const uint32_t *in, uint32_t *out_local, const uint32_t *n_src, uint32_t div,
-                              uint32_t n_max, uint32_t *chunk_sums, hipStream_t s);
+                              uint32_t n_max, uint32_t *chunk_sums, hipStream_t s, uint32_t *clear = nullptr,
+                              uint32_t clear_words = 0);
 
 } // namespace orbit

@@ -472,8 +472,49 @@ __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_k
     __syncthreads();
     const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
     const uint32_t ntiles = (nrec + kTileRecords - 1) / kTileRecords;
-    const uint32_t stride = gridDim.x * kEvWaves;
-    uint32_t w0 = blockIdx.x * kEvWaves + wave, w1 = w0 + stride, w2 = w1 + stride;
+    // Tile assignment: a static grid-stride share first, tickets for the rest.  With 23 or 24 tiles per wave handed out
+    // statically the waves finish over a span of ~45 us (the SIMD arbiter favours older waves, CUs differ) and the last
+    // 6 % of the kernel run at falling occupancy (tools/wave_tail.py); handing every tile out through an atomic ticket
+    // removes the tail but costs more than it saves (+5 %: the returning atomic sits in the in-order vector-memory
+    // queue in front of the row loads, once per tile).  So every wave takes its first S tiles statically (tile
+    // k * stride + g, as before) and only the last ~3 tiles' worth per wave go through tickets — 3-4 atomics per wave:
+    // fast waves draw more of them.  One counter cannot serve the ~290 claims/us at the very end (a returning atomic
+    // on one address saturates near 88/us on MI355X), so there are kTicketPools: wave g draws from pool g % npools,
+    // ticket n of pool q is tile S * stride + n * npools + q; every pool is drained by 1/npools of the waves of all
+    // XCDs, so the pools run dry within a tile's time of each other and nobody steals.  A claim is made three tiles
+    // before its rows are read (records -> matrices -> slab -> rows); a wave whose ticket is past the end drains its
+    // pipeline and leaves.
+    const uint32_t stride = gridDim.x * kEvWaves, wave_g = blockIdx.x * kEvWaves + wave;
+    const bool static_share = (p.debug_flags & 64u) != 0; // triage: everything static, for A/B runs
+    const uint32_t full_rounds = ntiles / stride;
+    const uint32_t dyn_rounds = (p.debug_flags & 256u) ? 2u : (p.debug_flags & 512u) ? 4u : (p.debug_flags & 1024u) ? 1u : 3u;
+    const uint32_t n_static = static_share ? 0xFFFFFFFFu : ((p.debug_flags & 128u) ? 0u : (full_rounds > dyn_rounds ? full_rounds - dyn_rounds : 0u));
+    const uint32_t npools = min((uint32_t)kTicketPools, stride);
+    const uint32_t pool = wave_g % npools;
+    uint32_t *ticket_ctr = p.tickets + pool * kTicketStride;
+    uint32_t claims = 0; // claims made so far by this wave
+    auto claim = [&]() -> uint32_t { // lane 0's VGPR carries the claim; not read before ticket_tile()
+        uint32_t raw = claims;
+        if (claims >= n_static) {
+            raw = 0;
+            if (lane == 0) raw = atomicAdd(ticket_ctr, 1u);
+        }
+        claims++;
+        return raw;
+    };
+    auto ticket_tile = [&](uint32_t raw, uint32_t k) -> uint32_t { // k = index of the claim that returned `raw`
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw);
+        if (k < n_static) return t * stride + wave_g;
+        return t >= 0x08000000u ? 0xFFFFFFFFu : n_static * stride + t * npools + pool;
+    };
+    uint32_t w0, w1, w2, tk_raw;
+    {
+        const uint32_t t0 = claim(), t1 = claim(), t2 = claim();
+        tk_raw = claim();
+        w0 = ticket_tile(t0, 0u);
+        w1 = ticket_tile(t1, 1u);
+        w2 = ticket_tile(t2, 2u);
+    }
     // two single-row register sets: while one row is evaluated the next row's loads are in flight
     RowRegs<1> qa, qb;
     uint4 rec2;
@@ -491,18 +532,35 @@ __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_k
     uint32_t it = 0;
     unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1;
 #define EV_STAMP(k)                            \
-    if (PROF) {                                \
+    if (PROF && !(p.debug_flags & 16u)) {      \
         t1 = __builtin_amdgcn_s_memtime();     \
         __builtin_amdgcn_s_waitcnt(0xC07F);    \
         tc[k] += t1 - t0;                      \
         t0 = t1;                               \
     }
+    unsigned long long wall_begin = 0;
+    if (p.debug_flags & 16u) wall_begin = wall_clock64(); // per-wave life stamps (tools/wave_tail.py), any build
     if (PROF) {
         t0 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_waitcnt(0xC07F);
     }
+    // The SIMD's arbiter serves the oldest wave first, and the four waves of a SIMD belong to the four blocks a CU
+    // holds, dispatched one after the other: left alone, the first block's waves finish at half the kernel's
+    // duration and the rest of the kernel runs at 3, 2, 1 waves per SIMD (tools/wave_tail.py).  Every wave
+    // therefore rotates its priority once per tile, offset by its block's dispatch rank, so that over any four
+    // tiles each wave of a SIMD has held each priority once.
+    const uint32_t prio_rank = blockIdx.x / max(gridDim.x / (uint32_t)kEvWavesPerSimd, 1u);
     while (w0 < ntiles) {
-        const uint32_t w3 = w2 + stride;
+        if (!(p.debug_flags & 32u)) {
+            switch ((it + prio_rank) & 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        }
+        const uint32_t w3 = ticket_tile(tk_raw, claims - 1u); // claimed one tile ago
+        tk_raw = claim();                                     // the tile after it
         WaveTileLds &L = lds[wave][it % 3];
         WaveTileLds &Ln = lds[wave][(it + 1) % 3]; // slab of an absent tile holds zero records
         uint4 *payload = p.task_records ? nullptr : p.tile_payload + (size_t)w0 * kPayloadCap;
@@ -554,6 +612,13 @@ __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_k
     if (PROF && lane == 0) {
         for (int k = 0; k < 5; k++) atomicAdd(p.debug_cycles + k, tc[k]);
         atomicAdd(p.debug_cycles + 7, 1ull);
+    }
+    if ((p.debug_flags & 16u) && lane == 0) {
+        const uint32_t wg = blockIdx.x * kEvWaves + wave;
+        if (wg < 8192u) {
+            p.debug_cycles[32 + 2 * wg] = wall_begin;
+            p.debug_cycles[32 + 2 * wg + 1] = wall_clock64();
+        }
     }
 }
 
@@ -946,6 +1011,7 @@ __global__ __launch_bounds__(256) void visible_expand_kernel(const uint8_t *visi
 // (forward_depth_prepass.task:225-228,255-257).  Thread = record; the drawn lanes in ascending order.
 __global__ __launch_bounds__(256) void task_records_kernel(const MeshletCullParams p) {
     const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
+    if (blockIdx.x == 0 && threadIdx.x < kTicketPools) p.tickets[threadIdx.x * kTicketStride] = 0u; // next evaluation
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= nrec) return;
     const uint4 rec = reinterpret_cast<const uint4 *>(p.dispatch_buffer + ORBIT_DISPATCH_HEADER)[r];
@@ -989,7 +1055,7 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t
         else
             hipLaunchKernelGGL((meshlet_pass1_kernel<0>), grid, block, 0, s, p);
     } else if constexpr (PASS == 0) {
-        if (p.debug_flags & 8u) { // phase-stamped build (tools/phase.py)
+        if (p.debug_flags & 8u) { // phase-stamped build (tools/phase.py); | 16: only the per-wave wall-clock stamps
             if (ortho)
                 hipLaunchKernelGGL((meshlet_eval_kernel<0, 1, true>), grid, block, 0, s, p);
             else
@@ -1018,7 +1084,7 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t
     }
     // first scan level only (chunk-local prefixes + chunk sums); meshlet_emit redoes the second in LDS
     e = launch_scan_chunks(p.tile_counts, p.tile_base, reinterpret_cast<const uint32_t *>(p.dispatch_buffer),
-                           kTileRecords, max_tiles, p.chunk_sums, s);
+                           kTileRecords, max_tiles, p.chunk_sums, s, p.tickets, kTicketPools * kTicketStride);
     if (e != hipSuccess) return e;
     uint32_t eblocks = num_cus * 8u;
     const uint32_t eneed = (max_tiles + 3) / 4;

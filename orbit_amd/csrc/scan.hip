@@ -31,8 +31,11 @@ __global__ __launch_bounds__(1024) void scan_exclusive_kernel(const uint32_t *in
 // (exclusive, chunk-local) and emits the chunk sum; a second single-block launch
 // scans the chunk sums.  Consumers add chunk_base[i / kScanChunk] themselves.
 __global__ __launch_bounds__(1024) void scan_chunks_kernel(const uint32_t *in, uint32_t *out, uint32_t n,
-                                                           const uint32_t *n_src, uint32_t div, uint32_t *chunk_sums) {
+                                                           const uint32_t *n_src, uint32_t div, uint32_t *chunk_sums,
+                                                           uint32_t *clear, uint32_t clear_words) {
     __shared__ uint32_t smem[1024 / 64 + 1];
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < clear_words; i += 1024) clear[i] = 0u;
     if (n_src) n = min((*n_src + div - 1u) / div, n);
     const uint32_t base = blockIdx.x * kScanChunk;
     if (base >= n) { // block-uniform
@@ -55,10 +58,15 @@ __global__ __launch_bounds__(1024) void scan_chunks_kernel(const uint32_t *in, u
 } // namespace
 
 hipError_t launch_scan_chunks(const uint32_t *in, uint32_t *out_local, const uint32_t *n_src, uint32_t div,
-                              uint32_t n_max, uint32_t *chunk_sums, hipStream_t s) {
-    const uint32_t chunks = (n_max + kScanChunk - 1) / kScanChunk;
-    if (chunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(scan_chunks_kernel, dim3(chunks), dim3(1024), 0, s, in, out_local, n_max, n_src, div, chunk_sums);
+                              uint32_t n_max, uint32_t *chunk_sums, hipStream_t s, uint32_t *clear,
+                              uint32_t clear_words) {
+    uint32_t chunks = (n_max + kScanChunk - 1) / kScanChunk;
+    if (chunks == 0) {
+        if (!clear_words) return hipSuccess;
+        chunks = 1; // the clear must happen: block 0 finds its chunk empty
+    }
+    hipLaunchKernelGGL(scan_chunks_kernel, dim3(chunks), dim3(1024), 0, s, in, out_local, n_max, n_src, div, chunk_sums,
+                       clear, clear_words);
     return hipGetLastError();
 }
 

@@ -80,9 +80,9 @@ class Engine:
         """Raises OrbitError for a device-latched condition (capacity overflow, timeout)."""
         _lib.check(self._lib.orbit_ctx_status(self._ctx, _stream(stream), 1 if sync else 0), self._ctx)
 
-    def profile(self, enable=True):
-        """HIP-event timing of the dominant kernel of meshlet_cull (measurement hook)."""
-        _lib.check(self._lib.orbit_ctx_profile(self._ctx, 1 if enable else 0), self._ctx)
+    def profile(self, enable=True, every=1):
+        """HIP-event timing of the dominant kernel of meshlet_cull (measurement hook); every n-th call is timed."""
+        _lib.check(self._lib.orbit_ctx_profile(self._ctx, int(every) if enable else 0), self._ctx)
 
     def profile_read(self):
         ms, n = C.c_float(), C.c_uint32()
