@@ -38,6 +38,10 @@ def parse():
                     help="entities of the scene the CPU oracle is timed on (rank 0, N=1 only); 0 disables")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="minimum CPU time spent in the oracle baseline")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather (cull only)")
+    ap.add_argument("--transport", choices=("p2p", "rccl"), default="p2p",
+                    help="N>1: how the lists travel — p2p: direct stores into the peers' IPC-mapped buffers at "
+                         "device-computed offsets, no host round trip (default; falls back to rccl when IPC is not "
+                         "available); rccl: counts to the host, grouped RCCL send/recv")
     ap.add_argument("--exchange", choices=("visible", "commands"), default="visible",
                     help="N>1 exchange format: 8-B visible items expanded on every GPU against the replicated "
                          "meshlet buffer (default), or the 28-B commands themselves")
@@ -124,12 +128,15 @@ def main():
     n_local_meshlets = n_local_entities * M
     rec_per_ent = spec.records_per_entity
 
-    do_gather = use_dist and backend == "nccl" and not args.no_gather
-    # Exchange format of the sharded engine.  "visible": every rank culls its entity range into 8-B
-    # {meshlet_index, entity_index} items, the lists are all-gathered and every GPU expands the result into the
-    # 28-B commands itself — which needs the meshlet buffer (static geometry, 1.6 GB of 288 GB) on every GPU; a
-    # rank still STREAMS only its own shard through meshlet_cull.  "commands": the 28-B lists travel as they are
-    # and a rank holds only its meshlet shard.
+    # N > 1: the exchange step.  Transport "p2p" (default): no host round trip — counts all-gathered into a device
+    # tensor, every rank stores its list straight into every peer's buffer (IPC-mapped, xGMI) at device-computed
+    # offsets, one more fixed-size collective as completion (orbit_amd/dist.py P2PExchange, orbit_scatter_list).
+    # Transport "rccl": counts read on the host, grouped RCCL send/recv of the lists (needs the nccl backend).
+    # Format "visible" (default): 8-B {meshlet_index, entity_index} items travel and every GPU expands the gathered
+    # list into the 28-B commands itself — which needs the meshlet buffer (static geometry, 1.6 GB of 288 GB) on every
+    # GPU; a rank still STREAMS only its own shard through meshlet_cull.  Format "commands": the 28-B lists travel as
+    # they are and a rank holds only its meshlet shard.
+    do_gather = use_dist and not args.no_gather and (backend == "nccl" or args.transport == "p2p")
     visible_exchange = do_gather and args.exchange == "visible"
     t0 = time.time()
     draws, mesh, ent, half = synth.gen_entity_tables(spec, dev)
@@ -148,16 +155,15 @@ def main():
 
     disp_cap = n_local_entities * rec_per_ent + 8
     draw_cap = n_local_meshlets // 2 + 1024
-    # Frames in flight.  The renderer keeps FRAME_COUNT = 2 frames in flight with per-frame transient buffers
-    # (context.rs:1275-1316); here every frame slot owns an OrbitCtx (scan scratch), a stream, a dispatch buffer and
-    # a list buffer, and the K steps go round-robin over the slots.  What overlaps: frame k+1's entity cull (small,
-    # latency-bound) runs under frame k's scan / emit, and — N > 1 — the exchange of frame k's list under the cull of
-    # frame k+1, and the head of frame k+1's streaming evaluation under frame k's scan / emit and the tail of its
-    # evaluation (tools/bench_pipeline.py, in-process alternation: 0.419 -> 0.402 ms per frame with two slots; ordering
-    # the evaluations with events instead: 0.434, worse than serial).  With more than one slot the evaluations of
-    # consecutive frames share the device for part of their run, so the HIP-event duration of a single launch is
-    # no longer that kernel's own time: the default is ONE slot — strictly serial frames, step time = frame latency,
-    # clean per-kernel durations; `--frames-in-flight 2` is there to measure the overlap.
+    # Frame slots.  The renderer keeps FRAME_COUNT = 2 frames in flight with per-frame transient buffers
+    # (context.rs:1275-1316); here a frame slot owns an OrbitCtx (scan scratch), a stream, a dispatch buffer and its
+    # list buffers, and the K steps go round-robin over the slots.  With two slots frame k+1's entity cull and the head
+    # of its streaming evaluation run under frame k's scan / emit and the tail of its evaluation
+    # (tools/bench_pipeline.py, in-process alternation: 0.419 -> 0.402 ms per frame; ordering the evaluations with
+    # events instead: 0.434, worse than serial) — but then the evaluations of consecutive frames share the device for
+    # part of their run and the HIP-event duration of a launch is no longer that kernel's own time.  The default is
+    # ONE slot: strictly serial frames, step time = frame latency, clean per-kernel durations.
+    # N > 1: the exchange of step i runs on its own stream while step i+1 culls into the slot's other list buffer.
     F = max(1, args.frames_in_flight)
     hdr, item = (L.VISIBLE_HEADER, 8) if visible_exchange else (L.DRAW_HEADER, 28)
 
@@ -167,51 +173,91 @@ def main():
                               max_draws=draw_cap)
             self.stream = torch.cuda.Stream(device=dev)
             self.disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device=dev)
-            self.draw = torch.zeros(hdr + item * draw_cap, dtype=torch.uint8, device=dev)
+            self.lists = [torch.zeros(hdr + item * draw_cap, dtype=torch.uint8, device=dev)
+                          for _ in range(2 if do_gather else 1)]
+            self.cull_done = [torch.cuda.Event() for _ in self.lists]
+            self.xdone = [torch.cuda.Event() for _ in self.lists]
+            self.uses = 0
 
     slots = [Slot() for _ in range(F)]
-    gathered = gathered_vis = None
+    xstream = gathered = gathered_vis = exchange = None
+    transport = None
     if do_gather:
-        gathered = torch.zeros(L.DRAW_HEADER + 28 * (draw_cap * world), dtype=torch.uint8, device=dev)
+        xstream = torch.cuda.Stream(device=dev)
+        out_cap = draw_cap * world
+        transport = args.transport
+        if transport == "p2p":
+            ok = 1
+            try:
+                exchange = odist.P2PExchange(slots[0].eng, out_cap, hdr, item, dev)
+            except Exception as ex:  # IPC not available between these processes: every rank falls back together
+                print(f"bench.py: p2p exchange unavailable on rank {rank} ({ex}); falling back to RCCL send/recv",
+                      file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if backend != "nccl":
+                    raise SystemExit("bench.py: p2p exchange unavailable and the backend cannot move device lists")
+                transport, exchange = "rccl", None
+        if transport == "p2p":
+            first_out = exchange.out
+        else:
+            first_out = torch.zeros(hdr + item * out_cap, dtype=torch.uint8, device=dev)
         if visible_exchange:
-            gathered_vis = torch.zeros(L.VISIBLE_HEADER + 8 * (draw_cap * world), dtype=torch.uint8, device=dev)
-    pending = []  # slots culled but not yet exchanged (at most one)
+            gathered_vis = first_out
+            gathered = torch.zeros(L.DRAW_HEADER + 28 * out_cap, dtype=torch.uint8, device=dev)
+        else:
+            gathered = first_out
+    pending = []  # (slot, list index) culled but not yet exchanged (at most one)
 
-    def gather(s):
-        # counts download, RCCL send/recv, the local copy and the expansion go through the slot's own stream, behind
-        # its cull — not behind the cull enqueued after it on the next slot's stream
-        with torch.cuda.stream(s.stream):
-            if visible_exchange:
-                odist.gather_visible(s.draw, gathered_vis, header=L.VISIBLE_HEADER, stride=8)
-                s.eng.expand_visible(gathered_vis, meshlets_base, gathered, draw_cap * world, stream=s.stream)
+    def gather(s, k):
+        # the exchange (and the expansion) of one list on the exchange stream, behind the cull that wrote the list —
+        # not behind the cull enqueued after it
+        with torch.cuda.stream(xstream):
+            xstream.wait_event(s.cull_done[k])
+            if transport == "p2p":
+                exchange.exchange(s.lists[k], stream=xstream)
             else:
-                odist.gather_visible(s.draw, gathered)
+                odist.gather_visible(s.lists[k], first_out, header=hdr, stride=item)
+            s.xdone[k].record(xstream)  # the list buffer may be overwritten
+            if visible_exchange:
+                s.eng.expand_visible(gathered_vis, meshlets_base, gathered, out_cap, stream=xstream)
 
     step_no = [0]
+
+    def cull(s, k):
+        s.eng.entity_cull(ci, draws, mesh, s.disp, ent, n_local_entities, disp_cap, draw_first=b, stream=s.stream)
+        if visible_exchange:
+            s.eng.meshlet_cull_visible(ci, s.disp, meshlets_base, s.lists[k], ent, materials, disp_cap, draw_cap,
+                                       material_count=spec.materials, stream=s.stream)
+        else:
+            s.eng.meshlet_cull(ci, s.disp, meshlets_base, s.lists[k], ent, materials, disp_cap, draw_cap,
+                               material_count=spec.materials, stream=s.stream)
 
     def step(i=None):
         s = slots[step_no[0] % F]
         step_no[0] += 1
-        with torch.cuda.stream(s.stream):
-            s.eng.entity_cull(ci, draws, mesh, s.disp, ent, n_local_entities, disp_cap, draw_first=b, stream=s.stream)
-            if visible_exchange:
-                s.eng.meshlet_cull_visible(ci, s.disp, meshlets_base, s.draw, ent, materials, disp_cap, draw_cap,
-                                           material_count=spec.materials, stream=s.stream)
-            else:
-                s.eng.meshlet_cull(ci, s.disp, meshlets_base, s.draw, ent, materials, disp_cap, draw_cap,
-                                   material_count=spec.materials, stream=s.stream)
+        k = s.uses % len(s.lists)
+        s.uses += 1
         if do_gather:
+            s.stream.wait_event(s.xdone[k])  # the exchange that read this list buffer two uses ago
+        cull(s, k)
+        if do_gather:
+            s.cull_done[k].record(s.stream)
             if pending:
-                gather(pending.pop())  # previous step's list travels while this step's cull runs
-            pending.append(s)
+                gather(*pending.pop())  # previous step's list travels while this step's cull runs
+            pending.append((s, k))
 
     def drain():
         while pending:
-            gather(pending.pop())
+            gather(*pending.pop())
         for s in slots:
             torch.cuda.current_stream().wait_stream(s.stream)
+        if xstream is not None:
+            torch.cuda.current_stream().wait_stream(xstream)
 
-    if do_gather:  # RCCL channel set-up is not part of any step, warm or timed
+    if do_gather and transport == "rccl":  # RCCL channel set-up is not part of any step, warm or timed
         assert odist.warm_up(dev)
     for _ in range(args.warmup):
         step()
@@ -248,29 +294,39 @@ def main():
     assert eval_launches >= 1, "no launch of the dominant kernel was timed"
     eval_ms = eval_sum / eval_launches
 
-    # one frame alone on an idle device (no other frame in flight): the latency a single cull costs
-    serial, op_ms = [], []
+    # one frame alone on an idle device (nothing else in flight): the latency a single cull costs, and its parts
+    s0 = slots[0]
+    serial, op_ms, x_ms = [], [], []
     for _ in range(5):
         a, m, z = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        s0 = slots[0]
-        with torch.cuda.stream(s0.stream):
-            a.record(s0.stream)
-            s0.eng.entity_cull(ci, draws, mesh, s0.disp, ent, n_local_entities, disp_cap, draw_first=b, stream=s0.stream)
-            m.record(s0.stream)
-            if visible_exchange:
-                s0.eng.meshlet_cull_visible(ci, s0.disp, meshlets_base, s0.draw, ent, materials, disp_cap, draw_cap,
-                                            material_count=spec.materials, stream=s0.stream)
-            else:
-                s0.eng.meshlet_cull(ci, s0.disp, meshlets_base, s0.draw, ent, materials, disp_cap, draw_cap,
-                                    material_count=spec.materials, stream=s0.stream)
-            z.record(s0.stream)
+        a.record(s0.stream)
+        s0.eng.entity_cull(ci, draws, mesh, s0.disp, ent, n_local_entities, disp_cap, draw_first=b, stream=s0.stream)
+        m.record(s0.stream)
+        if visible_exchange:
+            s0.eng.meshlet_cull_visible(ci, s0.disp, meshlets_base, s0.lists[0], ent, materials, disp_cap, draw_cap,
+                                        material_count=spec.materials, stream=s0.stream)
+        else:
+            s0.eng.meshlet_cull(ci, s0.disp, meshlets_base, s0.lists[0], ent, materials, disp_cap, draw_cap,
+                                material_count=spec.materials, stream=s0.stream)
+        z.record(s0.stream)
         torch.cuda.synchronize()
         serial.append(a.elapsed_time(z))
         op_ms.append(m.elapsed_time(z))
+        if do_gather:  # the exchange (+ expansion) of that list alone
+            if use_dist:
+                dist.barrier()
+            xa, xz = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.cull_done[0].record(s0.stream)
+            xa.record(xstream)
+            gather(s0, 0)
+            xz.record(xstream)
+            torch.cuda.synchronize()
+            x_ms.append(xa.elapsed_time(xz))
     frame_latency_ms = float(np.median(serial))
     kernel_ms = float(np.median(op_ms))  # whole meshlet_cull op (eval + scan + emit) of a frame alone on the device
-    last = slots[0]  # the latency frames above ran on slot 0: its buffers hold the most recent result
-    disp, draw = last.disp, last.draw
+    exchange_ms = float(np.median(x_ms)) if x_ms else None
+
+    disp, draw = s0.disp, s0.lists[0]  # the latency frames above ran on slot 0: its buffers hold the last result
     n_rec = int(disp[:4].view(torch.int32).item())
     n_draw = int(draw[:4].view(torch.int32).item())
     if do_gather:  # the gathered list holds this rank's commands at its rank-order position
@@ -286,8 +342,17 @@ def main():
         else:
             assert torch.equal(mine, draw[L.DRAW_HEADER:L.DRAW_HEADER + 28 * n_draw]), "gathered list != local list"
         assert int(gathered[:4].view(torch.int32).item()) == int(sum(int(c.item()) for c in counts))
-    for s in slots[1:]:  # every slot computed the same frame
-        assert torch.equal(s.draw[:hdr + item * n_draw], draw[:hdr + item * n_draw]), "frame slots disagree"
+        # the whole gathered list is the same on every rank: a checksum of it must agree
+        total = int(gathered[:4].view(torch.int32).item())
+        words = gathered[L.DRAW_HEADER:L.DRAW_HEADER + 28 * total].view(torch.int32).to(torch.int64)
+        chk = torch.stack([words.sum(), (words * (torch.arange(words.numel(), device=dev) % 8191 + 1)).sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), "ranks hold different gathered lists"
+    for s in slots:  # every slot and list buffer computed the same frame
+        for l in s.lists:
+            assert torch.equal(l[:hdr + item * n_draw], draw[:hdr + item * n_draw]), "frame slots disagree"
 
     n_in = int(disp[L.DISPATCH_HEADER:L.DISPATCH_HEADER + 16 * n_rec].view(torch.int32).view(-1, 4)[:, 2].sum().item())
     # cull-only rate of this rank (for the N>1 breakdown)
@@ -295,11 +360,12 @@ def main():
         agg = torch.tensor([n_in, n_draw], dtype=torch.int64, device=dev)
         dist.all_reduce(agg)
         tot_in, tot_draw = int(agg[0].item()), int(agg[1].item())
-        km = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+        km = torch.tensor([kernel_ms, frame_latency_ms, exchange_ms or 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
-        kernel_ms_max = float(km.item())
+        kernel_ms_max, kernel_ms_max_frame = float(km[0].item()), float(km[1].item())
+        exchange_ms_max = float(km[2].item()) if exchange_ms is not None else None
     else:
-        tot_in, tot_draw, kernel_ms_max = n_in, n_draw, kernel_ms
+        tot_in, tot_draw, kernel_ms_max, kernel_ms_max_frame, exchange_ms_max = n_in, n_draw, kernel_ms, frame_latency_ms, None
 
     ms_per_step = elapsed / args.steps * 1e3
     value = tot_in / (elapsed / args.steps)
@@ -352,13 +418,15 @@ def main():
                 "workload": f"config5: {E} entities x {M} = {E * M} synthetic meshlets, entity_cull + meshlet_cull, "
                             f"frustum + normal cone (occlusion_pass 0), all entities in view, "
                             f"{100.0 * tot_draw / max(tot_in, 1):.1f}% survivors"
-                            + ((", + RCCL all-gather of the visible list (8-B items, expanded to commands on every GPU)"
-                                if visible_exchange else ", + RCCL all-gather of the 28-B command lists")
+                            + ((", + rank-ordered all-gather of the visible list (8-B items, expanded to commands on "
+                                "every GPU)" if visible_exchange else ", + rank-ordered all-gather of the 28-B command lists")
+                               + (" by direct xGMI stores at device-computed offsets, counts / completion over the "
+                                  "process group" if transport == "p2p" else " by RCCL send/recv")
                                if do_gather else ""),
                 "entities": E, "meshlets": E * M, "meshlets_into_meshlet_cull": tot_in, "survivors": tot_draw,
                 "sharding": f"entity ranges over {world} rank(s)", "gather": bool(do_gather),
                 "frames_in_flight": F,
-                "exchange": (args.exchange if do_gather else None),
+                "exchange": (args.exchange if do_gather else None), "transport": transport,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "meshlet_eval_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -372,10 +440,15 @@ def main():
             },
             "cpu_baseline": cpu_baseline,
             "frame_latency_ms": frame_latency_ms,
+            "per_rank": {"cull_ms_max": kernel_ms_max_frame, "exchange_ms_max": exchange_ms_max,
+                         "what": "one frame alone on each rank's device: entity_cull + meshlet_cull of its shard, "
+                                 "and the exchange (+ expansion) of its list; max over ranks"},
             "cull_only_meshlets_per_sec": tot_in / (kernel_ms_max * 1e-3) if kernel_ms_max > 0 else None,
             "scene_gen_s": gen_s,
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if exchange is not None:
+        exchange.close()
     for s in slots:
         s.eng.close()
     if use_dist:

@@ -97,6 +97,15 @@ extern "C" {
                                          out_capacity: u32, stream: *mut c_void) -> i32;
     pub fn orbit_expand_visible(ctx: *mut OrbitCtx, visible_buffer: *const c_void, meshlet_buffer: *const c_void,
                                 draw_commands_buffer: *mut c_void, draw_capacity: u32, stream: *mut c_void) -> i32;
+    // exchange without a host round trip: IPC-mapped peer buffers + a device-side rank-ordered scatter
+    pub fn orbit_p2p_alloc(ctx: *mut OrbitCtx, bytes: u64, out_ptr: *mut *mut c_void, out_handle: *mut [u8; 64]) -> i32;
+    pub fn orbit_p2p_free(ctx: *mut OrbitCtx, ptr: *mut c_void) -> i32;
+    pub fn orbit_p2p_open(ctx: *mut OrbitCtx, handle: *const [u8; 64], out_peer_ptr: *mut *mut c_void) -> i32;
+    pub fn orbit_p2p_close(ctx: *mut OrbitCtx, peer_ptr: *mut c_void) -> i32;
+    /// `counts`: DEVICE u32[world] (the all-gathered list lengths); `out_buffers`: HOST array of `world` device pointers
+    pub fn orbit_scatter_list(ctx: *mut OrbitCtx, local_list: *const c_void, counts: *const u32, rank: u32, world: u32,
+                              out_buffers: *const *mut c_void, out_capacity: u32, header_bytes: u32, stride: u32,
+                              stream: *mut c_void) -> i32;
 }
 
 /// Turns a non-zero status into the panic the Vulkan path produced (assert!/unwrap, draw_gen.rs:247).

@@ -570,6 +570,50 @@ int32_t orbit_gather_visible_meshlets(OrbitCtx *ctx, void *nccl_comm, uint32_t r
 int32_t orbit_expand_visible(OrbitCtx *ctx, const void *visible_buffer, const void *meshlet_buffer,
                              void *draw_commands_buffer, uint32_t draw_capacity, void *stream);
 
+/* ------------------------------------------------------------------------ */
+/* The same exchange without a host round trip (one node, one process per   */
+/* GPU, peers reachable over xGMI).  orbit_gather_visible* must read the    */
+/* message sizes on the host because RCCL send/recv take them as arguments; */
+/* here the bulk data does not go through RCCL at all: every rank copies    */
+/* its list straight into every peer's output buffer at the rank-ordered    */
+/* position, with the offsets computed on the device from the all-gathered  */
+/* counts.  Per step and rank: one fixed-size collective for the counts     */
+/* (4 B per rank, e.g. ncclAllGather / torch all_gather_into_tensor — its    */
+/* result stays on the device), orbit_scatter_list, and one fixed-size      */
+/* collective as the completion barrier (peers have finished writing into   */
+/* this rank's buffer once it returns, because every rank enqueues it       */
+/* behind its own scatter).  Nothing waits for the host.                    */
+/* ------------------------------------------------------------------------ */
+
+#define ORBIT_P2P_HANDLE_BYTES 64 /* hipIpcMemHandle_t */
+#define ORBIT_P2P_MAX_WORLD 16
+
+/* Exchange buffers: device memory of this context's GPU that peers may map.
+ * orbit_p2p_alloc returns the pointer and an opaque handle to send to the other
+ * processes (any host channel: a file, torch.distributed.all_gather_object);
+ * orbit_p2p_open maps a peer's buffer into this process (hipIpcOpenMemHandle;
+ * dmabuf IPC: HSA_ENABLE_IPC_MODE_LEGACY=0).  The buffers stay caller-visible
+ * for the life of the context; *_close / *_free undo the calls. */
+int32_t orbit_p2p_alloc(OrbitCtx *ctx, uint64_t bytes, void **out_ptr,
+                        uint8_t out_handle[ORBIT_P2P_HANDLE_BYTES]);
+int32_t orbit_p2p_free(OrbitCtx *ctx, void *ptr);
+int32_t orbit_p2p_open(OrbitCtx *ctx, const uint8_t handle[ORBIT_P2P_HANDLE_BYTES], void **out_peer_ptr);
+int32_t orbit_p2p_close(OrbitCtx *ctx, void *peer_ptr);
+
+/* Rank-ordered scatter of this rank's list into all `world` output buffers.
+ *   local_list   {u32 count @0 | header_bytes | items of `stride` bytes}: a MeshletDrawCommandBuffer
+ *                (header 4, stride 28) or a visible list (header 8, stride 8)
+ *   counts       DEVICE array of `world` u32: every rank's item count, in rank order (counts[rank] must equal
+ *                the local count; it is the all-gathered copy that fixes the offsets on every rank alike)
+ *   out_buffers  HOST array of `world` device pointers: rank r's output buffer as mapped in THIS process
+ *                (out_buffers[rank] = this rank's own buffer); same layout as local_list, `out_capacity` items
+ * Every rank writes its items at out_r + header_bytes + stride * (counts[0] + .. + counts[rank-1]) for all r, and the
+ * header {total, 0..} of its own buffer.  A concatenation that does not fit latches ORBIT_E_CAPACITY (nothing is
+ * written past out_capacity). */
+int32_t orbit_scatter_list(OrbitCtx *ctx, const void *local_list, const uint32_t *counts, uint32_t rank,
+                           uint32_t world, void *const *out_buffers, uint32_t out_capacity,
+                           uint32_t header_bytes, uint32_t stride, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

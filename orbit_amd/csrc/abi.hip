@@ -778,6 +778,88 @@ int32_t gather_lists(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint32_t wor
 
 extern "C" {
 
+// ------------------------------------------------------------------- exchange without a host round trip
+int32_t orbit_p2p_alloc(OrbitCtx *ctx, uint64_t bytes, void **out_ptr, uint8_t out_handle[ORBIT_P2P_HANDLE_BYTES]) {
+    static_assert(sizeof(hipIpcMemHandle_t) == ORBIT_P2P_HANDLE_BYTES, "handle size");
+    if (!ctx || !out_ptr || !out_handle || bytes == 0) return fail(ctx, ORBIT_E_INVALID, "p2p_alloc: bad argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    *out_ptr = nullptr;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipSetDevice");
+    void *ptr = nullptr;
+    e = hipMalloc(&ptr, bytes);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipMalloc(p2p buffer)");
+    e = hipMemset(ptr, 0, bytes);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t *>(out_handle), ptr);
+    if (e != hipSuccess) {
+        (void)hipFree(ptr);
+        return hip_fail(ctx, e, "hipIpcGetMemHandle (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)");
+    }
+    *out_ptr = ptr;
+    return ORBIT_OK;
+}
+
+int32_t orbit_p2p_free(OrbitCtx *ctx, void *ptr) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ptr) return ORBIT_OK;
+    const hipError_t e = hipFree(ptr);
+    return e == hipSuccess ? ORBIT_OK : hip_fail(ctx, e, "hipFree(p2p buffer)");
+}
+
+int32_t orbit_p2p_open(OrbitCtx *ctx, const uint8_t handle[ORBIT_P2P_HANDLE_BYTES], void **out_peer_ptr) {
+    if (!ctx || !handle || !out_peer_ptr) return fail(ctx, ORBIT_E_INVALID, "p2p_open: bad argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    *out_peer_ptr = nullptr;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipSetDevice");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    void *ptr = nullptr;
+    e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipIpcOpenMemHandle");
+    *out_peer_ptr = ptr;
+    return ORBIT_OK;
+}
+
+int32_t orbit_p2p_close(OrbitCtx *ctx, void *peer_ptr) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!peer_ptr) return ORBIT_OK;
+    const hipError_t e = hipIpcCloseMemHandle(peer_ptr);
+    return e == hipSuccess ? ORBIT_OK : hip_fail(ctx, e, "hipIpcCloseMemHandle");
+}
+
+int32_t orbit_scatter_list(OrbitCtx *ctx, const void *local_list, const uint32_t *counts, uint32_t rank, uint32_t world,
+                           void *const *out_buffers, uint32_t out_capacity, uint32_t header_bytes, uint32_t stride,
+                           void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!local_list || !counts || !out_buffers) return fail(ctx, ORBIT_E_MISSING, "scatter_list: NULL argument");
+    if (world == 0 || world > ORBIT_P2P_MAX_WORLD || rank >= world)
+        return fail(ctx, ORBIT_E_INVALID, "scatter_list: rank %u of world %u (max %u)", rank, world,
+                    (unsigned)ORBIT_P2P_MAX_WORLD);
+    if (header_bytes < 4 || header_bytes % 4u || stride == 0 || stride % 4u)
+        return fail(ctx, ORBIT_E_INVALID, "scatter_list: header %u / stride %u must be multiples of 4", header_bytes,
+                    stride);
+    ScatterListParams p{};
+    p.local_list = (const uint8_t *)local_list;
+    p.counts = counts;
+    for (uint32_t r = 0; r < world; r++) {
+        if (!out_buffers[r]) return fail(ctx, ORBIT_E_MISSING, "scatter_list: out_buffers[%u] is NULL", r);
+        p.out[r] = (uint8_t *)out_buffers[r];
+    }
+    p.rank = rank;
+    p.world = world;
+    p.out_capacity = out_capacity;
+    p.header_bytes = header_bytes;
+    p.stride = stride;
+    p.status = ctx->status;
+    const hipError_t e = launch_scatter_list(p, ctx->num_cus, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch scatter_list");
+    return ORBIT_OK;
+}
+
 int32_t orbit_gather_visible(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint32_t world,
                              const void *local_draw_buffer, void *out_draw_buffer, uint32_t out_capacity,
                              void *stream) {

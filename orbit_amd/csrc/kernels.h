@@ -127,6 +127,14 @@ uint32_t max_dispatch_capacity();
 hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, uint8_t *draw_buffer,
                                  uint32_t draw_capacity, uint32_t num_cus, const void *zero_page, int32_t *status,
                                  hipStream_t s);
+struct ScatterListParams {
+    const uint8_t *local_list;
+    const uint32_t *counts;
+    uint8_t *out[16]; // ORBIT_P2P_MAX_WORLD
+    uint32_t rank, world, out_capacity, header_bytes, stride;
+    int32_t *status;
+};
+hipError_t launch_scatter_list(const ScatterListParams &p, uint32_t num_cus, hipStream_t s);
 hipError_t launch_depth_reduce(const DepthReduceParams &p, hipStream_t s);
 hipError_t launch_cluster_mark(const ClusterMarkParams &p, hipStream_t s);
 hipError_t launch_cluster_compact(const ClusterCompactParams &p, hipStream_t s);

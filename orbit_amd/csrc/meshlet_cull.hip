@@ -1007,6 +1007,43 @@ __global__ __launch_bounds__(256) void visible_expand_kernel(const uint8_t *visi
     }
 }
 
+// Sharded engine, exchange without a host round trip (orbit_scatter_list): this rank's items go to every rank's
+// output buffer — peers' buffers are mapped over xGMI — at the position the all-gathered counts give them.  A plain
+// dword copy: list items start 4 (commands) or 8 (visible items) bytes into their buffers and land at 28- or 8-byte
+// multiples, so 4 B is the common alignment; a wave moves 4 x 256 contiguous bytes per trip, loads first.
+// blockIdx.y = destination rank: the copies to all peers run side by side, each on its own link.
+__global__ __launch_bounds__(256) void scatter_list_kernel(const ScatterListParams p) {
+    const uint32_t dst_rank = blockIdx.y;
+    uint32_t first = 0, total = 0;
+    for (uint32_t r = 0; r < p.world; r++) {
+        const uint32_t c = p.counts[r];
+        if (r < p.rank) first += c;
+        total += c;
+    }
+    const uint32_t mine = p.counts[p.rank];
+    const uint32_t room = first < p.out_capacity ? p.out_capacity - first : 0u;
+    const uint32_t n_items = min(mine, room);
+    const uint64_t words = (uint64_t)n_items * p.stride / 4u;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(p.local_list + p.header_bytes);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(p.out[dst_rank] + p.header_bytes + (uint64_t)first * p.stride);
+    const uint64_t step = (uint64_t)gridDim.x * 256u * 4u;
+    for (uint64_t w = ((uint64_t)blockIdx.x * 256u + (threadIdx.x & ~63u)) * 4u + (threadIdx.x & 63u); w < words;
+         w += step) {
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = w + 64u * k < words ? src[w + 64u * k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (w + 64u * k < words) dst[w + 64u * k] = v[k];
+    }
+    if (dst_rank == p.rank && blockIdx.x == 0 && threadIdx.x == 0) {
+        uint32_t *hdr = reinterpret_cast<uint32_t *>(p.out[p.rank]);
+        hdr[0] = min(total, p.out_capacity);
+        for (uint32_t k = 1; k < p.header_bytes / 4u; k++) hdr[k] = 0u;
+        if (total > p.out_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+    }
+}
+
 // Mesh-shading path: one OrbitMeshTaskRecord per dispatch record from the record's should-draw ballot
 // (forward_depth_prepass.task:225-228,255-257).  Thread = record; the drawn lanes in ascending order.
 __global__ __launch_bounds__(256) void task_records_kernel(const MeshletCullParams p) {
@@ -1098,6 +1135,13 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t
 }
 
 } // namespace
+
+hipError_t launch_scatter_list(const ScatterListParams &p, uint32_t num_cus, hipStream_t s) {
+    // enough blocks per destination to keep a link busy, few enough that `world` copies share the device
+    const uint32_t per_dst = max(num_cus * 2u / max(p.world, 1u), 8u);
+    hipLaunchKernelGGL(scatter_list_kernel, dim3(per_dst, p.world), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
 
 uint32_t max_dispatch_capacity() {
     const uint64_t cap = (uint64_t)kEmitChunkTable * kScanChunk * kTileRecords;

@@ -96,3 +96,77 @@ def gather_visible(local_draw_buffer, out_draw_buffer, group=None, header=L.DRAW
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return counts
+
+
+def device_view(ptr, nbytes, device):
+    """uint8 torch view of `nbytes` of device memory at raw pointer `ptr` (an exchange buffer of the library)."""
+    class _Holder:
+        pass
+
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
+    return torch.as_tensor(h, device=device)
+
+
+class P2PExchange:
+    """Rank-ordered all-gather of the ranks' lists WITHOUT a host round trip (include/orbit_abi.h,
+    orbit_scatter_list): the counts are all-gathered into a device tensor (fixed size, nothing is read back), every
+    rank copies its list straight into every peer's output buffer at out + header + stride * prefix[rank] — the
+    offsets are computed on the device, the peers' buffers are mapped over xGMI (IPC) — and a second fixed-size
+    collective is the completion barrier.  RCCL carries 2 x 4 B per rank and step; the lists travel as plain stores
+    on all links at once.
+
+    `transport` (tests): an object with the same `alloc / open / scatter` surface; the default drives the HIP library.
+    """
+
+    def __init__(self, engine, item_capacity, header, stride, device, group=None, transport=None):
+        self.group, self.header, self.stride, self.capacity = group, header, stride, int(item_capacity)
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device = device
+        self.t = transport if transport is not None else _HipTransport(engine, device)
+        nbytes = header + stride * self.capacity
+        self.out, handle = self.t.alloc(nbytes)  # uint8 tensor over this rank's output buffer
+        handles = [None] * self.world
+        dist.all_gather_object(handles, handle, group=group)
+        self.peers = [self.out if r == self.rank else self.t.open(handles[r], nbytes) for r in range(self.world)]
+        self.counts = torch.zeros(self.world, dtype=torch.int32, device=device)
+        self.token = torch.zeros(1, dtype=torch.int32, device=device)
+        dist.barrier(group=group)  # every peer has mapped every buffer before the first scatter
+
+    def exchange(self, local_list, stream=None):
+        """Enqueues one exchange of `local_list` ({count | header | items}); afterwards (in stream order) `self.out`
+        holds {total | header | all ranks' items in rank order}.  No host synchronisation."""
+        mine = local_list[:4].view(torch.int32)
+        dist.all_gather_into_tensor(self.counts, mine, group=self.group)       # 4 B per rank, stays on the device
+        self.t.scatter(local_list, self.counts, self.rank, self.world, self.peers, self.capacity, self.header,
+                       self.stride, stream)
+        dist.all_reduce(self.token, group=self.group)                          # completion: peers' scatters are done
+        return self.out
+
+    def close(self):
+        self.t.close()
+
+
+class _HipTransport:
+    def __init__(self, engine, device):
+        self.eng, self.device, self.own, self.opened = engine, device, [], []
+
+    def alloc(self, nbytes):
+        ptr, handle = self.eng.p2p_alloc(nbytes)
+        self.own.append(ptr)
+        return device_view(ptr, nbytes, self.device), handle
+
+    def open(self, handle, nbytes):
+        ptr = self.eng.p2p_open(handle)
+        self.opened.append(ptr)
+        return device_view(ptr, nbytes, self.device)
+
+    def scatter(self, local_list, counts, rank, world, peers, capacity, header, stride, stream):
+        self.eng.scatter_list(local_list, counts, rank, world, peers, capacity, header, stride, stream=stream)
+
+    def close(self):
+        for ptr in self.opened:
+            self.eng.p2p_close(ptr)
+        for ptr in self.own:
+            self.eng.p2p_free(ptr)
+        self.own, self.opened = [], []

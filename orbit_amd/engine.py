@@ -164,6 +164,32 @@ class Engine:
                                                   _ptr(draw_commands_buffer), draw_capacity, _stream(stream)),
                    self._ctx)
 
+    # -- exchange without a host round trip (orbit_p2p_* / orbit_scatter_list)
+    def p2p_alloc(self, nbytes):
+        """(device pointer, 64-byte IPC handle) of an exchange buffer peers can map."""
+        ptr, handle = C.c_void_p(), (C.c_uint8 * 64)()
+        _lib.check(self._lib.orbit_p2p_alloc(self._ctx, int(nbytes), C.byref(ptr), handle), self._ctx)
+        return int(ptr.value), bytes(handle)
+
+    def p2p_free(self, ptr):
+        _lib.check(self._lib.orbit_p2p_free(self._ctx, C.c_void_p(ptr)), self._ctx)
+
+    def p2p_open(self, handle):
+        ptr, h = C.c_void_p(), (C.c_uint8 * 64).from_buffer_copy(handle)
+        _lib.check(self._lib.orbit_p2p_open(self._ctx, h, C.byref(ptr)), self._ctx)
+        return int(ptr.value)
+
+    def p2p_close(self, ptr):
+        _lib.check(self._lib.orbit_p2p_close(self._ctx, C.c_void_p(ptr)), self._ctx)
+
+    def scatter_list(self, local_list, counts, rank, world, out_buffers, out_capacity, header_bytes, stride,
+                     stream=None):
+        """orbit_scatter_list: this rank's items into every rank's output buffer at the rank-ordered position;
+        `counts` is a DEVICE int32[world] tensor, `out_buffers` a list of device pointers (ints or tensors)."""
+        arr = (C.c_void_p * world)(*[_ptr(b) for b in out_buffers])
+        _lib.check(self._lib.orbit_scatter_list(self._ctx, _ptr(local_list), _ptr(counts), rank, world, arr,
+                                                out_capacity, header_bytes, stride, _stream(stream)), self._ctx)
+
     def gather_visible_meshlets(self, nccl_comm, rank, world, local_visible_buffer, out_visible_buffer, out_capacity,
                                 stream=None):
         comm = nccl_comm if isinstance(nccl_comm, C.c_void_p) else C.c_void_p(int(nccl_comm))

@@ -109,3 +109,98 @@ def test_bench_launches_its_own_ranks(world):
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world)], env=env2,
                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r2.returncode != 0 and b"WORLD_SIZE" in r2.stderr
+
+
+# ----------------------------------------------------------------------------- exchange without a host round trip
+class _ShmTransport:
+    """CPU stand-in for the HIP transport of dist.P2PExchange: exchange buffers are files in /dev/shm mapped by every
+    rank (the IPC mapping), the scatter is orbit_scatter_list restated with numpy (same offsets, same header rule)."""
+
+    def __init__(self, tag):
+        self.tag, self.paths = tag, []
+
+    def alloc(self, nbytes):
+        path = f"/dev/shm/orbit_test_{self.tag}_{os.getpid()}"
+        m = np.lib.format.open_memmap(path, mode="w+", dtype=np.uint8, shape=(nbytes,))
+        m[:] = 0x55
+        self.paths.append(path)
+        return torch.from_numpy(m), path
+
+    def open(self, handle, nbytes):
+        return torch.from_numpy(np.load(handle, mmap_mode="r+"))
+
+    def scatter(self, local_list, counts, rank, world, peers, capacity, header, stride, stream):
+        c = [int(v) for v in counts.tolist()]
+        first, total = sum(c[:rank]), sum(c)
+        n = min(c[rank], max(capacity - first, 0))
+        for r in range(world):
+            peers[r][header + stride * first:header + stride * (first + n)] = local_list[header:header + stride * n]
+        peers[rank][:header] = 0
+        peers[rank][:4].view(torch.int32)[0] = min(total, capacity)
+
+    def close(self):
+        for p in self.paths:
+            if os.path.exists(p):
+                os.remove(p)
+
+
+def _p2p_worker(rank, world, port, seed, n_entities, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+    from orbit_amd.dist import P2PExchange
+
+    scene = sc.make_scene(seed, n_entities, n_meshes=40)
+    cam = sc.default_camera()
+    ci = sc.make_cull_info(cam.view, cam.planes)
+    b, e = shard_ranges(scene.entity_draw_count, world)[rank]
+    cap = scene.max_dispatches() + 8
+    disp, _, _ = oracle.entity_cull(ci, scene.entity_draw_buffer(), e - b, scene.mesh_infos, scene.entities, cap,
+                                    draw_first=b)
+    draw, _, _ = oracle.meshlet_cull(ci, disp, scene.meshlets, scene.lod0_meshlets + 8, scene.entities,
+                                     scene.materials)
+    n, cmds = L.draw_buffer_commands(draw)
+    vis = np.zeros(L.VISIBLE_HEADER + 8 * max(n, 1), dtype=np.uint8)
+    vis[:4].view(np.uint32)[0] = n
+    v = vis[8:8 + 8 * n].view(L.VISIBLE_MESHLET)
+    v["meshlet_index"], v["entity_index"] = cmds["meshlet_index"], cmds["cmd_first_instance"]
+    capacity = scene.lod0_meshlets + 8
+    for name, local, header, stride in (("cmd", draw, L.DRAW_HEADER, 28), ("vis", vis, L.VISIBLE_HEADER, 8)):
+        t = _ShmTransport(f"{name}{rank}")
+        ex = P2PExchange(None, capacity, header, stride, torch.device("cpu"), transport=t)
+        for step in range(2):  # the buffers are reused step after step
+            out = ex.exchange(torch.from_numpy(local.copy()))
+            dist.barrier()
+        np.save(os.path.join(out_dir, f"p2p_{name}_{rank}.npy"), out.numpy().copy())
+        dist.barrier()
+        ex.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_entities", [(2, 257), (3, 300), (3, 40)])
+def test_p2p_exchange_protocol_gloo(tmp_path, oracle, world, n_entities):
+    """dist.P2PExchange (counts all-gather -> device-side offsets -> every rank writes its list into every peer's
+    buffer -> completion collective), both list formats, worlds of 2 and 3 (one shard may be empty): every rank ends
+    with the single-process canonical list."""
+    seed = 33
+    port = _free_port()
+    mp.spawn(_p2p_worker, args=(world, port, seed, n_entities, str(tmp_path)), nprocs=world, join=True)
+    scene = sc.make_scene(seed, n_entities, n_meshes=40)
+    cam = sc.default_camera()
+    ci = sc.make_cull_info(cam.view, cam.planes)
+    disp, _, _ = oracle.entity_cull(ci, scene.entity_draw_buffer(), scene.entity_draw_count, scene.mesh_infos,
+                                    scene.entities, scene.max_dispatches() + 8)
+    ref, _, _ = oracle.meshlet_cull(ci, disp, scene.meshlets, scene.lod0_meshlets + 8, scene.entities,
+                                    scene.materials)
+    n, cmds = L.draw_buffer_commands(ref)
+    assert n > 0
+    for r in range(world):
+        got = np.load(tmp_path / f"p2p_cmd_{r}.npy")
+        assert int(got[:4].view(np.uint32)[0]) == n
+        assert np.array_equal(got[:4 + 28 * n], ref[:4 + 28 * n]), f"rank {r}: exchanged list != single-process list"
+        assert np.all(got[4 + 28 * n:] == 0x55)  # nothing written past the list
+        gv = np.load(tmp_path / f"p2p_vis_{r}.npy")
+        assert [int(v) for v in gv[:8].view(np.uint32)] == [n, 0]
+        items = gv[8:8 + 8 * n].view(L.VISIBLE_MESHLET)
+        assert np.array_equal(items["meshlet_index"], cmds["meshlet_index"])
+        assert np.array_equal(items["entity_index"], cmds["cmd_first_instance"])
