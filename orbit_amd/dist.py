@@ -125,13 +125,30 @@ class P2PExchange:
         self.device = device
         self.t = transport if transport is not None else _HipTransport(engine, device)
         nbytes = header + stride * self.capacity
-        self.out, handle = self.t.alloc(nbytes)  # uint8 tensor over this rank's output buffer
+        # every step of the set-up is agreed on by all ranks (a rank that fails alone would leave the others waiting
+        # in the next collective): failure anywhere raises everywhere
+        err = None
+        try:
+            self.out, handle = self.t.alloc(nbytes)  # uint8 tensor over this rank's output buffer
+        except Exception as ex:  # noqa: BLE001 - reported below, on every rank
+            err, handle = ex, None
+        self._agree(err, "allocating / exporting the exchange buffer")
         handles = [None] * self.world
         dist.all_gather_object(handles, handle, group=group)
-        self.peers = [self.out if r == self.rank else self.t.open(handles[r], nbytes) for r in range(self.world)]
+        try:
+            self.peers = [self.out if r == self.rank else self.t.open(handles[r], nbytes) for r in range(self.world)]
+        except Exception as ex:  # noqa: BLE001
+            err = ex
+        self._agree(err, "mapping a peer's exchange buffer")
         self.counts = torch.zeros(self.world, dtype=torch.int32, device=device)
         self.token = torch.zeros(1, dtype=torch.int32, device=device)
         dist.barrier(group=group)  # every peer has mapped every buffer before the first scatter
+
+    def _agree(self, err, what):
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=self.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 0:
+            raise RuntimeError(f"P2PExchange: {what} failed on at least one rank" + (f" (here: {err})" if err else ""))
 
     def exchange(self, local_list, stream=None):
         """Enqueues one exchange of `local_list` ({count | header | items}); afterwards (in stream order) `self.out`

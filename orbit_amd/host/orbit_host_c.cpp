@@ -8,6 +8,7 @@
 
 #include "orbit_host.hpp"
 #include "orbit_assets.hpp"
+#include "orbit_gltf.hpp"
 #include "orbit_scene.hpp"
 
 using namespace orbit;
@@ -427,6 +428,77 @@ int32_t orbit_host_compute_meshlets(const float *positions, uint64_t vertex_coun
 void orbit_host_compute_mesh_bounds(const float *positions, uint64_t vertex_count, float aabb_min[3], float aabb_max[3],
                                     float bounding_sphere[4]) {
     assets::compute_mesh_bounds(positions, (size_t)vertex_count, aabb_min, aabb_max, bounding_sphere);
+}
+
+// ---------------------------------------------------------------- asset ingestion (orbit_gltf.hpp), host only
+void *orbit_host_gltf_load(const char *path) {
+    gltf_loader::LoadedScene *scene = nullptr;
+    const int32_t rc = guarded([&] {
+        if (!path) throw Panic("path is NULL");
+        auto s = std::make_unique<gltf_loader::LoadedScene>();
+        std::string err;
+        if (!gltf_loader::load_gltf(path, *s, err)) throw Panic("load_gltf: " + err);
+        scene = s.release();
+    });
+    return rc == 0 ? scene : nullptr;
+}
+void orbit_host_gltf_free(void *scene) { delete static_cast<gltf_loader::LoadedScene *>(scene); }
+void orbit_host_gltf_counts(const void *scene, OrbitHostGltfCounts *out) {
+    const auto &s = *static_cast<const gltf_loader::LoadedScene *>(scene);
+    out->meshes = s.assets.mesh_infos.size();
+    out->meshlets = s.assets.meshlets.size();
+    out->meshlet_data_words = s.assets.meshlet_data.size();
+    out->materials = s.assets.materials.size();
+    out->vertices = s.assets.vertex_positions.size() / 3;
+    out->entities = s.entities.size();
+}
+const OrbitMeshInfo *orbit_host_gltf_mesh_infos(const void *scene) {
+    return static_cast<const gltf_loader::LoadedScene *>(scene)->assets.mesh_infos.data();
+}
+const OrbitMeshlet *orbit_host_gltf_meshlets(const void *scene) {
+    return static_cast<const gltf_loader::LoadedScene *>(scene)->assets.meshlets.data();
+}
+const uint32_t *orbit_host_gltf_meshlet_data(const void *scene) {
+    return static_cast<const gltf_loader::LoadedScene *>(scene)->assets.meshlet_data.data();
+}
+const OrbitMaterialData *orbit_host_gltf_materials(const void *scene) {
+    return static_cast<const gltf_loader::LoadedScene *>(scene)->assets.materials.data();
+}
+const float *orbit_host_gltf_vertex_positions(const void *scene) {
+    return static_cast<const gltf_loader::LoadedScene *>(scene)->assets.vertex_positions.data();
+}
+uint64_t orbit_host_gltf_entities(const void *scene, OrbitHostGltfEntity *out, uint64_t capacity) {
+    const auto &s = *static_cast<const gltf_loader::LoadedScene *>(scene);
+    for (size_t i = 0; i < s.entities.size() && i < capacity; i++) {
+        const auto &e = s.entities[i];
+        out[i].mesh = e.mesh;
+        const float p[3] = {e.transform.position.x, e.transform.position.y, e.transform.position.z};
+        const float q[4] = {e.transform.orientation.x, e.transform.orientation.y, e.transform.orientation.z,
+                            e.transform.orientation.w};
+        const float sc[3] = {e.transform.scale.x, e.transform.scale.y, e.transform.scale.z};
+        std::memcpy(out[i].position, p, 12);
+        std::memcpy(out[i].orientation, q, 16);
+        std::memcpy(out[i].scale, sc, 12);
+    }
+    return s.entities.size();
+}
+uint64_t orbit_host_simplify_clustered(const float *positions, uint64_t vertex_count, const uint32_t *indices,
+                                       uint64_t index_count, uint64_t target_index_count, uint32_t *out,
+                                       uint64_t capacity, uint64_t *needed) {
+    std::vector<uint32_t> r;
+    assets::simplify_clustered(positions, (size_t)vertex_count, indices, (size_t)index_count,
+                               (size_t)target_index_count, r);
+    if (needed) *needed = r.size();
+    const size_t n = std::min<size_t>(r.size(), (size_t)capacity) / 3 * 3;
+    if (out && n) std::memcpy(out, r.data(), n * 4);
+    return n;
+}
+void orbit_host_transform_from_mat4(const float matrix[16], float position[3], float orientation[4], float scale[3]) {
+    const passes::Transform t = gltf_loader::transform_from_mat4(Mat4::from_cols_array(matrix));
+    position[0] = t.position.x, position[1] = t.position.y, position[2] = t.position.z;
+    orientation[0] = t.orientation.x, orientation[1] = t.orientation.y, orientation[2] = t.orientation.z;
+    orientation[3] = t.orientation.w;
+    scale[0] = t.scale.x, scale[1] = t.scale.y, scale[2] = t.scale.z;
 }
 
 } // extern "C"

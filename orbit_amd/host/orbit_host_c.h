@@ -177,6 +177,34 @@ int32_t orbit_host_compute_meshlets(const float *positions, uint64_t vertex_coun
 /* gltf_loader.rs:480-506 */
 void orbit_host_compute_mesh_bounds(const float *positions, uint64_t vertex_count, float aabb_min[3], float aabb_max[3],
                                     float bounding_sphere[4]);
+
+/* ---- asset ingestion (orbit_gltf.hpp): glTF 2.0 (.glb / .gltf) -> materials, meshes with their LOD chains, entities ----
+ * load_gltf (gltf_loader.rs:511-676) + GpuAssets::add_mesh (assets/mod.rs:325-476).  NULL + orbit_host_last_error()
+ * on failure.  The arrays stay valid until orbit_host_gltf_free. */
+typedef struct OrbitHostGltfCounts {
+    uint64_t meshes, meshlets, meshlet_data_words, materials, vertices, entities;
+} OrbitHostGltfCounts;
+typedef struct OrbitHostGltfEntity {
+    int32_t mesh;                                /* MeshHandle slot, -1 = None */
+    float position[3], orientation[4], scale[3]; /* Transform::from_mat4 of the node's world matrix */
+} OrbitHostGltfEntity;
+void *orbit_host_gltf_load(const char *path);
+void orbit_host_gltf_free(void *scene);
+void orbit_host_gltf_counts(const void *scene, OrbitHostGltfCounts *out);
+const OrbitMeshInfo *orbit_host_gltf_mesh_infos(const void *scene);
+const OrbitMeshlet *orbit_host_gltf_meshlets(const void *scene);
+const uint32_t *orbit_host_gltf_meshlet_data(const void *scene);
+const OrbitMaterialData *orbit_host_gltf_materials(const void *scene);
+const float *orbit_host_gltf_vertex_positions(const void *scene);
+/* copies the entities (capacity entries at most); returns their number */
+uint64_t orbit_host_gltf_entities(const void *scene, OrbitHostGltfEntity *out, uint64_t capacity);
+/* the LOD-chain pieces alone: meshopt::simplify's stand-in (vertex clustering); returns the indices written
+ * (<= capacity, whole triangles), *needed = the full result's length */
+uint64_t orbit_host_simplify_clustered(const float *positions, uint64_t vertex_count, const uint32_t *indices,
+                                       uint64_t index_count, uint64_t target_index_count, uint32_t *out,
+                                       uint64_t capacity, uint64_t *needed);
+/* Transform::from_mat4 (scene.rs:41-48) of a column-major matrix -> position[3], orientation[4] (x, y, z, w), scale[3] */
+void orbit_host_transform_from_mat4(const float matrix[16], float position[3], float orientation[4], float scale[3]);
 #ifdef __cplusplus
 }
 #endif
