@@ -24,6 +24,19 @@ pub struct OrbitEntityCullBufs {
     pub meshlet_dispatch_buffer: *mut c_void, pub entity_buffer: *const c_void,
     pub visibility_buffer: *mut u32, pub depth_pyramid: *const f32,
     pub depth_pyramid_size: [u32; 2], pub dispatch_capacity: u32, pub _pad: u32,
+    /// null: `depth_pyramid` is the packed chain; else a DEVICE array of mip levels (separate per-mip images)
+    pub depth_pyramid_levels: *const OrbitDepthPyramidLevel,
+}
+
+/// One mip of a pyramid that is not one packed buffer (linear-tiled image per level: INTEGRATION.md)
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct OrbitDepthPyramidLevel { pub texels: *mut f32, pub row_pitch: u32, pub _pad: u32 }
+
+/// One pyramid of orbit_depth_reduce_multi; exactly one of `pyramid` / `levels` (HOST array) is non-null
+#[repr(C)]
+pub struct OrbitDepthReduceItem {
+    pub depth: *const f32, pub screen_width: u32, pub screen_height: u32, pub depth_row_pitch: u32, pub _pad: u32,
+    pub pyramid: *mut f32, pub levels: *const OrbitDepthPyramidLevel,
 }
 
 /// push-constant order of shaders/meshlet_cull.comp:16-23 (== draw_gen.rs:426-431)
@@ -34,6 +47,7 @@ pub struct OrbitMeshletCullBufs {
     pub material_buffer: *const c_void, pub meshlet_visibility_buffer: *mut u32,
     pub depth_pyramid: *const f32, pub depth_pyramid_size: [u32; 2],
     pub dispatch_capacity: u32, pub draw_capacity: u32, pub material_count: u32, pub _pad: u32,
+    pub depth_pyramid_levels: *const OrbitDepthPyramidLevel,
 }
 
 pub const ORBIT_MAX_PYRAMID_MIPS: usize = 16;
@@ -68,6 +82,9 @@ extern "C" {
     pub fn orbit_ctx_profile_read(ctx: *mut OrbitCtx, avg_ms: *mut f32, launches: *mut u32) -> i32;
     pub fn orbit_depth_reduce(ctx: *mut OrbitCtx, depth: *const f32, screen_w: u32, screen_h: u32,
                               pyramid: *mut f32, stream: *mut c_void) -> i32;
+    /// update_multiple_depth_pyramids::<C> (draw_gen.rs:569-628): up to 8 pyramids in one launch pair
+    pub fn orbit_depth_reduce_multi(ctx: *mut OrbitCtx, items: *const OrbitDepthReduceItem, count: u32,
+                                    stream: *mut c_void) -> i32;
     pub fn orbit_cluster_mark(ctx: *mut OrbitCtx, push: *const c_void, depth: *const f32, masks: *mut u32,
                               bounds: *mut c_void, stream: *mut c_void) -> i32;
     pub fn orbit_cluster_compact(ctx: *mut OrbitCtx, cluster_count: *const [u32; 3], masks: *const u32,

@@ -34,7 +34,7 @@ extern "C" {
 #define ORBIT_STATIC_ASSERT(c, m) _Static_assert(c, m)
 #endif
 
-#define ORBIT_ABI_VERSION 1u
+#define ORBIT_ABI_VERSION 2u /* 2: *_CullBufs gained depth_pyramid_levels (per-mip images) */
 
 /* u32::MAX = "resource absent" (src/passes/draw_gen.rs:142-144,
  * shaders/meshlet_cull.comp:127). */
@@ -363,6 +363,18 @@ int32_t orbit_ctx_status(OrbitCtx *ctx, void *stream, int32_t sync);
 /* shaders/entity_cull.comp:104-245.                                        */
 /* ------------------------------------------------------------------------ */
 
+/* One level of a depth pyramid that is NOT one packed buffer: the reference's pyramid is a Vulkan image with a view
+ * per mip (draw_gen.rs:456-482); exported for HIP it becomes one linear-tiled image (or buffer) per level, each with
+ * its own base address and row pitch (vkGetImageSubresourceLayout::rowPitch / 4).  A DEVICE array of mip_levels such
+ * entries can stand in for the packed chain wherever a pyramid is read (the *_CullBufs below) or written
+ * (orbit_depth_reduce_levels).  INTEGRATION.md "Depth buffer and pyramid" has the Vulkan side. */
+typedef struct OrbitDepthPyramidLevel {
+    float *texels;       /* DEVICE pointer to the level's first texel */
+    uint32_t row_pitch;  /* texels per row, >= max(width >> level, 1) */
+    uint32_t _pad;
+} OrbitDepthPyramidLevel;
+ORBIT_STATIC_ASSERT(sizeof(OrbitDepthPyramidLevel) == 16, "pyramid level entry is 16 B");
+
 /* Raw device pointers in the push-constant order of entity_cull.comp:17-23
  * (== draw_gen.rs:372-376); the three CullInfo-carried resources follow. */
 typedef struct OrbitEntityCullBufs {
@@ -375,7 +387,10 @@ typedef struct OrbitEntityCullBufs {
     uint32_t depth_pyramid_size[2];  /* mip-0 width, height = textureSize(.., 0) */
     uint32_t dispatch_capacity;      /* records the dispatch buffer can hold */
     uint32_t _pad;
+    /* NULL: depth_pyramid is the packed chain.  Else a DEVICE array of mip levels (depth_pyramid is ignored). */
+    const OrbitDepthPyramidLevel *depth_pyramid_levels;
 } OrbitEntityCullBufs;
+ORBIT_STATIC_ASSERT(sizeof(OrbitEntityCullBufs) == 72, "EntityCullBufs is 72 B");
 
 /* The library performs the {0,1,1} header clear itself (draw_gen.rs:356-363).
  * `cull_info` is a HOST pointer to the 400-B block CullInfo::to_gpu built.
@@ -413,7 +428,10 @@ typedef struct OrbitMeshletCullBufs {
                                    0 = unknown.  Only an optimisation hint: when given (<= 4096)
                                    the alpha modes are staged in LDS instead of gathered. */
     uint32_t _pad;
+    /* NULL: depth_pyramid is the packed chain.  Else a DEVICE array of mip levels (depth_pyramid is ignored). */
+    const OrbitDepthPyramidLevel *depth_pyramid_levels;
 } OrbitMeshletCullBufs;
+ORBIT_STATIC_ASSERT(sizeof(OrbitMeshletCullBufs) == 88, "MeshletCullBufs is 88 B");
 
 /* The record count is read on the device from the dispatch header — the
  * equivalent of vkCmdDispatchIndirect (draw_gen.rs:432); no host readback.
@@ -462,6 +480,24 @@ int32_t orbit_depth_pyramid_desc_from_mip0(uint32_t mip0_width, uint32_t mip0_he
  * draw_gen.rs:538-564).  `depth` is the W x H reverse-Z D32F buffer, row-major. */
 int32_t orbit_depth_reduce(OrbitCtx *ctx, const float *depth, uint32_t screen_width,
                            uint32_t screen_height, float *pyramid, void *stream);
+
+/* One pyramid of a batch.  `depth_row_pitch` = texels per row of the depth buffer (0 = screen_width: tightly
+ * packed); exactly one of `pyramid` (packed chain) and `levels` (HOST array of the mip_levels the pyramid has for
+ * this screen size, orbit_depth_pyramid_desc; each entry holds DEVICE pointers) is non-NULL. */
+typedef struct OrbitDepthReduceItem {
+    const float *depth;
+    uint32_t screen_width, screen_height;
+    uint32_t depth_row_pitch;
+    uint32_t _pad;
+    float *pyramid;
+    const OrbitDepthPyramidLevel *levels;
+} OrbitDepthReduceItem;
+ORBIT_STATIC_ASSERT(sizeof(OrbitDepthReduceItem) == 40, "depth-reduce item is 40 B");
+#define ORBIT_MAX_PYRAMID_BATCH 8
+/* update_multiple_depth_pyramids::<C> (draw_gen.rs:569-628): `count` (<= 8) pyramids — the main view's and the
+ * shadow cascades' — in ONE launch pair instead of C x 12 dispatches; pyramids of different sizes may be mixed.
+ * Also the entry point for pyramids made of separate per-mip images (`levels`) and pitched depth buffers. */
+int32_t orbit_depth_reduce_multi(OrbitCtx *ctx, const OrbitDepthReduceItem *items, uint32_t count, void *stream);
 
 /* ------------------------------------------------------------------------ */
 /* light_cluster — replaces compute_clusters and its three stages            */

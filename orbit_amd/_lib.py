@@ -36,7 +36,8 @@ class EntityCullBufs(C.Structure):
     _fields_ = [("entity_draw_buffer", C.c_void_p), ("mesh_info_buffer", C.c_void_p),
                 ("meshlet_dispatch_buffer", C.c_void_p), ("entity_buffer", C.c_void_p),
                 ("visibility_buffer", C.c_void_p), ("depth_pyramid", C.c_void_p),
-                ("depth_pyramid_size", C.c_uint32 * 2), ("dispatch_capacity", C.c_uint32), ("_pad", C.c_uint32)]
+                ("depth_pyramid_size", C.c_uint32 * 2), ("dispatch_capacity", C.c_uint32), ("_pad", C.c_uint32),
+                ("depth_pyramid_levels", C.c_void_p)]
 
 
 class MeshletCullBufs(C.Structure):
@@ -44,7 +45,18 @@ class MeshletCullBufs(C.Structure):
                 ("draw_commands_buffer", C.c_void_p), ("entity_buffer", C.c_void_p), ("material_buffer", C.c_void_p),
                 ("meshlet_visibility_buffer", C.c_void_p), ("depth_pyramid", C.c_void_p),
                 ("depth_pyramid_size", C.c_uint32 * 2), ("dispatch_capacity", C.c_uint32),
-                ("draw_capacity", C.c_uint32), ("material_count", C.c_uint32), ("_pad", C.c_uint32)]
+                ("draw_capacity", C.c_uint32), ("material_count", C.c_uint32), ("_pad", C.c_uint32),
+                ("depth_pyramid_levels", C.c_void_p)]
+
+
+class DepthPyramidLevel(C.Structure):  # OrbitDepthPyramidLevel: one mip of a pyramid made of separate images
+    _fields_ = [("texels", C.c_void_p), ("row_pitch", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class DepthReduceItem(C.Structure):  # OrbitDepthReduceItem
+    _fields_ = [("depth", C.c_void_p), ("screen_width", C.c_uint32), ("screen_height", C.c_uint32),
+                ("depth_row_pitch", C.c_uint32), ("_pad", C.c_uint32), ("pyramid", C.c_void_p),
+                ("levels", C.POINTER(DepthPyramidLevel))]
 
 
 class DepthPyramidDesc(C.Structure):
@@ -67,6 +79,7 @@ SYMBOLS = {
     "orbit_meshlet_cull": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(MeshletCullBufs), C.c_void_p]),
     "orbit_meshlet_task_cull": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(MeshletCullBufs), C.c_void_p, C.c_void_p]),
     "orbit_depth_pyramid_desc": (C.c_int32, [C.c_uint32, C.c_uint32, C.POINTER(DepthPyramidDesc)]),
+    "orbit_depth_reduce_multi": (C.c_int32, [C.c_void_p, C.POINTER(DepthReduceItem), C.c_uint32, C.c_void_p]),
     "orbit_depth_pyramid_desc_from_mip0": (C.c_int32, [C.c_uint32, C.c_uint32, C.POINTER(DepthPyramidDesc)]),
     "orbit_depth_reduce": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "orbit_cluster_mark": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -110,9 +110,11 @@ int32_t check_cull_info(OrbitCtx *ctx, const OrbitGpuCullInfo *ci) {
     return ORBIT_OK;
 }
 
-PyramidView make_pyramid_view(const float *texels, const uint32_t size[2]) {
+PyramidView make_pyramid_view(const float *texels, const uint32_t size[2],
+                              const OrbitDepthPyramidLevel *levels = nullptr) {
     PyramidView v;
     v.texels = texels;
+    v.levels = levels;
     v.w0 = size[0];
     v.h0 = size[1];
     v.mips = (size[0] | size[1]) ? mip_levels_from_size(size[0] > size[1] ? size[0] : size[1]) : 0;
@@ -345,7 +347,8 @@ static int32_t entity_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const
         return fail(ctx, ORBIT_E_MISSING, "entity_cull: a required buffer is NULL");
     if (ci->occlusion_pass != 0 && !b->visibility_buffer)
         return fail(ctx, ORBIT_E_MISSING, "occlusion_pass %u needs visibility_buffer", ci->occlusion_pass);
-    if (ci->occlusion_pass == 2 && (!b->depth_pyramid || !b->depth_pyramid_size[0] || !b->depth_pyramid_size[1]))
+    if (ci->occlusion_pass == 2 &&
+        ((!b->depth_pyramid && !b->depth_pyramid_levels) || !b->depth_pyramid_size[0] || !b->depth_pyramid_size[1]))
         return fail(ctx, ORBIT_E_MISSING, "occlusion_pass 2 needs depth_pyramid");
     if (draw_first % 32u) return fail(ctx, ORBIT_E_INVALID, "draw_first %u is not a multiple of 32", draw_first);
     if (entity_draw_count > ctx->caps.max_entities)
@@ -358,7 +361,7 @@ static int32_t entity_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const
     p.dispatch_buffer = (uint8_t *)b->meshlet_dispatch_buffer;
     p.entities = (const OrbitEntityData *)b->entity_buffer;
     p.visibility = b->visibility_buffer;
-    p.pyr = make_pyramid_view(b->depth_pyramid, b->depth_pyramid_size);
+    p.pyr = make_pyramid_view(b->depth_pyramid, b->depth_pyramid_size, b->depth_pyramid_levels);
     p.draw_first = draw_first;
     // whole-buffer call: the reference's grid of ceil(n/256) x 256 invocations (draw_gen.rs:377);
     // range call: exactly [draw_first, draw_first + n) so that shards never overlap
@@ -407,7 +410,7 @@ int32_t meshlet_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbit
     if (meshlet_occ && ci->occlusion_pass != 0 && !b->meshlet_visibility_buffer)
         return fail(ctx, ORBIT_E_MISSING, "cull_info declares a meshlet visibility buffer but the pointer is NULL");
     if (meshlet_occ && ci->occlusion_pass == 2 &&
-        (!b->depth_pyramid || !b->depth_pyramid_size[0] || !b->depth_pyramid_size[1]))
+        ((!b->depth_pyramid && !b->depth_pyramid_levels) || !b->depth_pyramid_size[0] || !b->depth_pyramid_size[1]))
         return fail(ctx, ORBIT_E_MISSING, "occlusion_pass 2 needs depth_pyramid");
     if (b->dispatch_capacity > ctx->caps.max_dispatches)
         return fail(ctx, ORBIT_E_CAPACITY, "dispatch_capacity %u > caps.max_dispatches %u", b->dispatch_capacity,
@@ -420,7 +423,7 @@ int32_t meshlet_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbit
     p.entities = (const OrbitEntityData *)b->entity_buffer;
     p.materials = (const OrbitMaterialData *)b->material_buffer;
     p.meshlet_visibility = b->meshlet_visibility_buffer;
-    p.pyr = make_pyramid_view(b->depth_pyramid, b->depth_pyramid_size);
+    p.pyr = make_pyramid_view(b->depth_pyramid, b->depth_pyramid_size, b->depth_pyramid_levels);
     p.dispatch_capacity = b->dispatch_capacity;
     p.draw_capacity = visible_path ? visible_capacity : b->draw_capacity;
     p.visible_list = visible_path ? 1u : 0u;
@@ -502,26 +505,64 @@ int32_t orbit_depth_pyramid_desc_from_mip0(uint32_t w0, uint32_t h0, OrbitDepthP
     return ORBIT_OK;
 }
 
-int32_t orbit_depth_reduce(OrbitCtx *ctx, const float *depth, uint32_t sw, uint32_t sh, float *pyramid,
-                           void *stream) {
+int32_t orbit_depth_reduce_multi(OrbitCtx *ctx, const OrbitDepthReduceItem *items, uint32_t count, void *stream) {
     if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
-    if (!depth || !pyramid) return fail(ctx, ORBIT_E_MISSING, "depth_reduce: NULL buffer");
-    OrbitDepthPyramidDesc d;
-    int32_t rc = orbit_depth_pyramid_desc(sw, sh, &d);
-    if (rc) return rc;
-    DepthReduceParams p;
-    p.depth = depth;
-    p.pyramid = pyramid;
-    p.screen_w = sw;
-    p.screen_h = sh;
-    p.w0 = d.width;
-    p.h0 = d.height;
-    p.mips = d.mip_levels;
-    memcpy(p.mip_offset, d.mip_offset, sizeof(p.mip_offset));
-    hipError_t e = launch_depth_reduce(p, (hipStream_t)stream);
+    if (!items || count == 0) return fail(ctx, ORBIT_E_MISSING, "depth_reduce: no items");
+    if (count > ORBIT_MAX_PYRAMID_BATCH)
+        return fail(ctx, ORBIT_E_CAPACITY, "depth_reduce: %u pyramids in one batch (max %u)", count,
+                    (unsigned)ORBIT_MAX_PYRAMID_BATCH);
+    static_assert(ORBIT_MAX_PYRAMID_BATCH == kMaxPyramidBatch, "batch size");
+    DepthReduceBatch b{};
+    b.count = count;
+    for (uint32_t i = 0; i < count; i++) {
+        const OrbitDepthReduceItem &it = items[i];
+        if (!it.depth || (!it.pyramid) == (!it.levels))
+            return fail(ctx, ORBIT_E_MISSING, "depth_reduce item %u: depth, and exactly one of pyramid / levels", i);
+        OrbitDepthPyramidDesc d;
+        const int32_t rc = orbit_depth_pyramid_desc(it.screen_width, it.screen_height, &d);
+        if (rc) return rc;
+        DepthReduceParams &p = b.p[i];
+        p.depth = it.depth;
+        p.depth_pitch = it.depth_row_pitch ? it.depth_row_pitch : it.screen_width;
+        if (p.depth_pitch < it.screen_width)
+            return fail(ctx, ORBIT_E_INVALID, "depth_reduce item %u: row pitch %u < width %u", i, p.depth_pitch,
+                        it.screen_width);
+        p.screen_w = it.screen_width;
+        p.screen_h = it.screen_height;
+        p.w0 = d.width;
+        p.h0 = d.height;
+        p.mips = d.mip_levels;
+        for (uint32_t k = 0; k < d.mip_levels; k++) {
+            if (it.pyramid) {
+                p.level[k] = it.pyramid + d.mip_offset[k];
+                p.pitch[k] = d.mip_width[k];
+            } else {
+                if (!it.levels[k].texels || it.levels[k].row_pitch < d.mip_width[k])
+                    return fail(ctx, ORBIT_E_INVALID, "depth_reduce item %u: level %u is NULL or its pitch %u < %u", i, k,
+                                it.levels[k].row_pitch, d.mip_width[k]);
+                p.level[k] = it.levels[k].texels;
+                p.pitch[k] = it.levels[k].row_pitch;
+            }
+        }
+    }
+    const hipError_t e = launch_depth_reduce(b, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch depth_reduce");
     return ORBIT_OK;
+}
+
+int32_t orbit_depth_reduce(OrbitCtx *ctx, const float *depth, uint32_t sw, uint32_t sh, float *pyramid,
+                           void *stream) {
+    OrbitDepthReduceItem it{};
+    it.depth = depth;
+    it.screen_width = sw;
+    it.screen_height = sh;
+    it.pyramid = pyramid;
+    if (ctx && (!depth || !pyramid)) {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        return fail(ctx, ORBIT_E_MISSING, "depth_reduce: NULL buffer");
+    }
+    return orbit_depth_reduce_multi(ctx, &it, 1, stream);
 }
 
 // ---------------------------------------------------------------- light_cluster

@@ -6,7 +6,11 @@
 // the level below, level 0 of the screen depth buffer.  The reference issues
 // one dispatch + barrier per level (<= 12); here one kernel produces levels
 // 0..5 of each 32x32 level-0 tile through LDS, and one single-block kernel
-// finishes the remaining (<= 64x64-texel) tail.
+// finishes the remaining (<= 64x64-texel) tail.  Several pyramids (the frame's
+// main view and shadow cascades: update_multiple_depth_pyramids::<C>,
+// draw_gen.rs:569-628) share the two launches: blockIdx.z selects the pyramid.
+// Every level is addressed through its own base pointer and row pitch, so the
+// chain may be one packed buffer or separate per-mip (linear-tiled) images.
 //
 // For the power-of-two pyramid levels the footprint at u = (X+0.5)/w_dst is
 // exactly texels {2X, 2X+1} of the source (clamped when the source dimension
@@ -32,15 +36,17 @@ __device__ __forceinline__ float reduce4(const float *src, uint32_t pitch, int o
     return gmin(gmin(a, b), gmin(c, d));
 }
 
-__global__ __launch_bounds__(256) void depth_reduce_tiles(const DepthReduceParams p) {
+__global__ __launch_bounds__(256) void depth_reduce_tiles(const DepthReduceBatch batch) {
     __shared__ float buf0[kTile * kTile];
     __shared__ float buf1[(kTile / 2) * (kTile / 2)];
+    const DepthReduceParams &p = batch.p[blockIdx.z];
     const int t = threadIdx.x;
     const uint32_t ox0 = blockIdx.x * kTile, oy0 = blockIdx.y * kTile;
+    if (ox0 >= p.w0 || oy0 >= p.h0) return; // the grid covers the largest pyramid of the batch (block-uniform)
 
     // level 0: each thread produces a 2x2 quad of the tile
     {
-        float *dst = p.pyramid + p.mip_offset[0];
+        float *dst = p.level[0];
         const int qx = t & 15, qy = t >> 4;
 #pragma unroll
         for (int j = 0; j < 2; j++)
@@ -53,8 +59,8 @@ __global__ __launch_bounds__(256) void depth_reduce_tiles(const DepthReduceParam
                     // (vec2(pos) + 0.5) / vec2(dimensions), depth_reduce.comp:18
                     const float u = ((float)x + 0.5f) / (float)p.w0;
                     const float vv = ((float)y + 0.5f) / (float)p.h0;
-                    v = footprint_min(p.depth, p.screen_w, p.screen_h, u, vv);
-                    dst[(size_t)y * p.w0 + x] = v;
+                    v = footprint_min(p.depth, p.depth_pitch, p.screen_w, p.screen_h, u, vv);
+                    dst[(size_t)y * p.pitch[0] + x] = v;
                 }
                 buf0[ly * kTile + lx] = v;
             }
@@ -78,7 +84,7 @@ __global__ __launch_bounds__(256) void depth_reduce_tiles(const DepthReduceParam
             float v = 0.0f;
             if (X < dw && Y < dh) {
                 v = reduce4(src, spitch, (int)oxs, (int)oys, sw, sh, X, Y);
-                p.pyramid[p.mip_offset[k] + (size_t)Y * dw + X] = v;
+                p.level[k][(size_t)Y * p.pitch[k] + X] = v;
             }
             dstl[ly * tw + lx] = v;
         }
@@ -87,15 +93,16 @@ __global__ __launch_bounds__(256) void depth_reduce_tiles(const DepthReduceParam
 }
 
 // Levels kInBlockLevels.. from global memory, one block.
-__global__ __launch_bounds__(1024) void depth_reduce_tail(const DepthReduceParams p) {
+__global__ __launch_bounds__(1024) void depth_reduce_tail(const DepthReduceBatch batch) {
+    const DepthReduceParams &p = batch.p[blockIdx.x];
     for (uint32_t k = kInBlockLevels; k < p.mips; k++) {
-        const float *src = p.pyramid + p.mip_offset[k - 1];
-        float *dst = p.pyramid + p.mip_offset[k];
+        const float *src = p.level[k - 1];
+        float *dst = p.level[k];
         const uint32_t sw = max(p.w0 >> (k - 1), 1u), sh = max(p.h0 >> (k - 1), 1u);
         const uint32_t dw = max(p.w0 >> k, 1u), dh = max(p.h0 >> k, 1u);
         for (uint32_t i = threadIdx.x; i < dw * dh; i += blockDim.x) {
             const uint32_t X = i % dw, Y = i / dw;
-            dst[i] = reduce4(src, sw, 0, 0, sw, sh, X, Y);
+            dst[(size_t)Y * p.pitch[k] + X] = reduce4(src, p.pitch[k - 1], 0, 0, sw, sh, X, Y);
         }
         __syncthreads(); // workgroup-scope release/acquire: next level reads these stores
     }
@@ -103,13 +110,19 @@ __global__ __launch_bounds__(1024) void depth_reduce_tail(const DepthReduceParam
 
 } // namespace
 
-hipError_t launch_depth_reduce(const DepthReduceParams &p, hipStream_t s) {
-    const dim3 grid((p.w0 + kTile - 1) / kTile, (p.h0 + kTile - 1) / kTile);
-    hipLaunchKernelGGL(depth_reduce_tiles, grid, dim3(256), 0, s, p);
+hipError_t launch_depth_reduce(const DepthReduceBatch &b, hipStream_t s) {
+    if (b.count == 0 || b.count > kMaxPyramidBatch) return hipErrorInvalidValue;
+    uint32_t gx = 0, gy = 0, max_mips = 0;
+    for (uint32_t i = 0; i < b.count; i++) {
+        gx = max(gx, (b.p[i].w0 + kTile - 1) / kTile);
+        gy = max(gy, (b.p[i].h0 + kTile - 1) / kTile);
+        max_mips = max(max_mips, b.p[i].mips);
+    }
+    hipLaunchKernelGGL(depth_reduce_tiles, dim3(gx, gy, b.count), dim3(256), 0, s, b);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (p.mips > (uint32_t)kInBlockLevels) {
-        hipLaunchKernelGGL(depth_reduce_tail, dim3(1), dim3(1024), 0, s, p);
+    if (max_mips > (uint32_t)kInBlockLevels) { // pyramids without a tail fall through their (empty) level loop
+        hipLaunchKernelGGL(depth_reduce_tail, dim3(b.count), dim3(1024), 0, s, b);
         e = hipGetLastError();
     }
     return e;

@@ -67,12 +67,21 @@ struct MeshletCullParams {
     int32_t *status;
 };
 
+// One pyramid: every level has its own base pointer and row pitch (texels) — a packed chain is the special case
+// level[k] = pyramid + mip_offset[k], pitch[k] = max(w0 >> k, 1).
 struct DepthReduceParams {
     const float *depth;
-    float *pyramid;
+    uint32_t depth_pitch; // texels per row of the depth buffer
     uint32_t screen_w, screen_h;
     uint32_t w0, h0, mips;
-    uint32_t mip_offset[ORBIT_MAX_PYRAMID_MIPS];
+    float *level[ORBIT_MAX_PYRAMID_MIPS];
+    uint32_t pitch[ORBIT_MAX_PYRAMID_MIPS];
+};
+// update_multiple_depth_pyramids::<C> (draw_gen.rs:569-628): C pyramids, one launch pair (blockIdx.z = pyramid)
+constexpr uint32_t kMaxPyramidBatch = 8;
+struct DepthReduceBatch {
+    DepthReduceParams p[kMaxPyramidBatch];
+    uint32_t count;
 };
 
 struct ClusterMarkParams {
@@ -135,7 +144,7 @@ struct ScatterListParams {
     int32_t *status;
 };
 hipError_t launch_scatter_list(const ScatterListParams &p, uint32_t num_cus, hipStream_t s);
-hipError_t launch_depth_reduce(const DepthReduceParams &p, hipStream_t s);
+hipError_t launch_depth_reduce(const DepthReduceBatch &b, hipStream_t s);
 hipError_t launch_cluster_mark(const ClusterMarkParams &p, hipStream_t s);
 hipError_t launch_cluster_compact(const ClusterCompactParams &p, hipStream_t s);
 hipError_t launch_cluster_assign(const ClusterAssignParams &p, uint32_t num_cus, hipStream_t s);

@@ -92,22 +92,26 @@ __device__ __forceinline__ float snorm8_div127(int i) {
     return __builtin_fmaf(fi, 0x1.020408p-28f, fi * 0x1.0204p-7f);
 }
 
-// Pyramid geometry handed to the kernels by value (host-computed).
+// Pyramid geometry handed to the kernels by value (host-computed).  `texels` is the packed R32F mip chain; when
+// `levels` is non-null the chain is NOT packed: level k lives at levels[k].texels with levels[k].row_pitch texels per
+// row (a DEVICE table of `mips` entries: separate per-mip images, orbit_abi.h OrbitDepthPyramidLevel).
 struct PyramidView {
     const float *texels;
     uint32_t w0, h0, mips;
+    const OrbitDepthPyramidLevel *levels;
 };
 
 // 2x2 clamped footprint minimum of one w x h level (ReduceMin sampler model,
 // src/graphics/device.rs:1404-1420).
-__device__ __forceinline__ float footprint_min(const float *img, uint32_t w, uint32_t h, float u, float v) {
+__device__ __forceinline__ float footprint_min(const float *img, uint32_t pitch, uint32_t w, uint32_t h, float u,
+                                               float v) {
     const float x = u * (float)w - 0.5f;
     const float y = v * (float)h - 0.5f;
     const float fx = floorf(x), fy = floorf(y);
     const int x0 = f2i_clamp(fx, (int)w - 1), x1 = f2i_clamp(fx + 1.0f, (int)w - 1);
     const int y0 = f2i_clamp(fy, (int)h - 1), y1 = f2i_clamp(fy + 1.0f, (int)h - 1);
-    const float a = img[(size_t)y0 * w + x0], b = img[(size_t)y0 * w + x1];
-    const float c = img[(size_t)y1 * w + x0], d = img[(size_t)y1 * w + x1];
+    const float a = img[(size_t)y0 * pitch + x0], b = img[(size_t)y0 * pitch + x1];
+    const float c = img[(size_t)y1 * pitch + x0], d = img[(size_t)y1 * pitch + x1];
     return gmin(gmin(a, b), gmin(c, d));
 }
 
@@ -119,10 +123,14 @@ __device__ __forceinline__ float hiz_sample(const PyramidView &p, float u, float
     // texel offset of `level` in the packed mip chain (level k is
     // max(dim >> k, 1), src/graphics/image.rs:533); summed here instead of
     // indexed from a kernarg table, which would need a per-lane waterfall.
+    const uint32_t w = max(p.w0 >> level, 1u), h = max(p.h0 >> level, 1u);
+    if (p.levels) { // separate per-mip images: one 16-B table entry per lane (cached), then the pitched footprint
+        const OrbitDepthPyramidLevel lv = p.levels[level];
+        return footprint_min(lv.texels, lv.row_pitch, w, h, u, v);
+    }
     uint32_t off = 0;
     for (int k = 0; k < level; k++) off += max(p.w0 >> k, 1u) * max(p.h0 >> k, 1u);
-    const uint32_t w = max(p.w0 >> level, 1u), h = max(p.h0 >> level, 1u);
-    return footprint_min(p.texels + off, w, h, u, v);
+    return footprint_min(p.texels + off, w, w, h, u, v);
 }
 
 struct Sphere {

@@ -92,7 +92,7 @@ class Engine:
     # -- entity_cull: create_meshlet_dispatch_command body (draw_gen.rs:327-380)
     def entity_cull(self, cull_info, entity_draw_buffer, mesh_info_buffer, meshlet_dispatch_buffer, entity_buffer,
                     entity_draw_count, dispatch_capacity, visibility_buffer=None, depth_pyramid=None,
-                    depth_pyramid_size=(0, 0), draw_first=None, stream=None):
+                    depth_pyramid_size=(0, 0), draw_first=None, stream=None, depth_pyramid_levels=None):
         ci = _host_bytes(cull_info, 400)
         b = _lib.EntityCullBufs()
         b.entity_draw_buffer = _ptr(entity_draw_buffer)
@@ -103,6 +103,7 @@ class Engine:
         b.depth_pyramid = _ptr(depth_pyramid)
         b.depth_pyramid_size[0], b.depth_pyramid_size[1] = depth_pyramid_size
         b.dispatch_capacity = dispatch_capacity
+        b.depth_pyramid_levels = _ptr(depth_pyramid_levels)  # DEVICE array of OrbitDepthPyramidLevel, or None
         if draw_first is None:
             rc = self._lib.orbit_entity_cull(self._ctx, ci.ctypes.data_as(C.c_void_p), C.byref(b), entity_draw_count,
                                              _stream(stream))
@@ -115,7 +116,7 @@ class Engine:
     def meshlet_cull(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, draw_commands_buffer, entity_buffer,
                      material_buffer, dispatch_capacity, draw_capacity, meshlet_visibility_buffer=None,
                      depth_pyramid=None, depth_pyramid_size=(0, 0), material_count=0, stream=None, task_records=None,
-                     visible_buffer=None):
+                     visible_buffer=None, depth_pyramid_levels=None):
         ci = _host_bytes(cull_info, 400)
         b = _lib.MeshletCullBufs()
         b.meshlet_dispatch_buffer = _ptr(meshlet_dispatch_buffer)
@@ -129,6 +130,7 @@ class Engine:
         b.dispatch_capacity = dispatch_capacity
         b.draw_capacity = draw_capacity
         b.material_count = material_count
+        b.depth_pyramid_levels = _ptr(depth_pyramid_levels)
         if visible_buffer is not None:  # sharded engine: compact visible list, draw_capacity = its capacity
             _lib.check(self._lib.orbit_meshlet_cull_visible(self._ctx, ci.ctypes.data_as(C.c_void_p), C.byref(b),
                                                             _ptr(visible_buffer), draw_capacity, _stream(stream)),
@@ -151,6 +153,25 @@ class Engine:
     def depth_reduce(self, depth, screen_width, screen_height, pyramid, stream=None):
         _lib.check(self._lib.orbit_depth_reduce(self._ctx, _ptr(depth), screen_width, screen_height, _ptr(pyramid),
                                                 _stream(stream)), self._ctx)
+
+    def depth_reduce_multi(self, items, stream=None):
+        """orbit_depth_reduce_multi (update_multiple_depth_pyramids::<C>, draw_gen.rs:569-628): one launch pair for up
+        to 8 pyramids.  items: dicts with depth, width, height and either pyramid (packed chain) or levels (list of
+        (tensor-or-pointer, row_pitch) per mip: separate per-mip images); optional depth_row_pitch."""
+        arr = (_lib.DepthReduceItem * len(items))()
+        keep = []
+        for it, a in zip(items, arr):
+            a.depth = _ptr(it["depth"])
+            a.screen_width, a.screen_height = it["width"], it["height"]
+            a.depth_row_pitch = it.get("depth_row_pitch", 0)
+            a.pyramid = _ptr(it.get("pyramid"))
+            if it.get("levels") is not None:
+                lv = (_lib.DepthPyramidLevel * len(it["levels"]))()
+                for l, (t, pitch) in zip(lv, it["levels"]):
+                    l.texels, l.row_pitch = _ptr(t), pitch
+                keep.append(lv)
+                a.levels = lv
+        _lib.check(self._lib.orbit_depth_reduce_multi(self._ctx, arr, len(items), _stream(stream)), self._ctx)
 
     def meshlet_cull_visible(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, visible_buffer, entity_buffer,
                              material_buffer, dispatch_capacity, visible_capacity, **kw):

@@ -388,7 +388,21 @@ void DepthPyramid::update(graphics::Context &context, const GraphImageHandle &de
 }
 void update_multiple_depth_pyramids(graphics::Context &context, DepthPyramid *const *depth_pyramids,
                                     const GraphImageHandle *depth_buffers, size_t count) {
-    for (size_t i = 0; i < count; i++) depth_pyramids[i]->update(context, depth_buffers[i]);
+    // draw_gen.rs:569-628: the reference interleaves the C pyramids' dispatches level by level behind one barrier per
+    // level; here all of them are one launch pair (orbit_depth_reduce_multi, batches of <= 8)
+    for (size_t first = 0; first < count; first += ORBIT_MAX_PYRAMID_BATCH) {
+        OrbitDepthReduceItem items[ORBIT_MAX_PYRAMID_BATCH];
+        std::memset(items, 0, sizeof(items));
+        const size_t n = count - first < ORBIT_MAX_PYRAMID_BATCH ? count - first : ORBIT_MAX_PYRAMID_BATCH;
+        for (size_t i = 0; i < n; i++) {
+            depth_pyramids[first + i]->usable = true; // :511
+            items[i].depth = depth_buffers[first + i].ptr;
+            items[i].screen_width = depth_buffers[first + i].width;
+            items[i].screen_height = depth_buffers[first + i].height;
+            items[i].pyramid = depth_pyramids[first + i]->pyramid.ptr;
+        }
+        context.check(orbit_depth_reduce_multi(context.abi(), items, (uint32_t)n, context.stream()));
+    }
 }
 
 // ------------------------------------------------------------------------- passes::cluster

@@ -251,6 +251,81 @@ def test_depth_reduce(torch_mod, engine, oracle, size):
     assert np.array_equal(host(gpyr, np.uint32), opyr.view(np.uint32))
 
 
+def test_depth_reduce_multi_mixed_sizes(torch_mod, engine, oracle):
+    """update_multiple_depth_pyramids::<C> (draw_gen.rs:569-628) as ONE launch pair: the main view's pyramid and
+    shadow-cascade-sized ones, different sizes in one batch (with and without a tail level) — each bit-exact."""
+    torch = torch_mod
+    sizes = [(1920, 1080), (2048, 2048), (2048, 2048), (96, 54), (1, 1), (333, 77), (64, 64), (17, 9)]
+    items, outs = [], []
+    for k, (W, H) in enumerate(sizes):
+        cam = sc.default_camera(aspect=W / H)
+        depth = sc.make_depth(20 + k, W, H, cam, n_occluders=10)
+        opyr, d = oracle.depth_reduce(depth, W, H)
+        gpyr = torch.full((d.total_texels,), -1.0, dtype=torch.float32, device="cuda")
+        items.append(dict(depth=dev(torch, depth), width=W, height=H, pyramid=gpyr))
+        outs.append((gpyr, opyr))
+    engine.depth_reduce_multi(items)
+    torch.cuda.synchronize()
+    for k, (gpyr, opyr) in enumerate(outs):
+        assert np.array_equal(host(gpyr, np.uint32), opyr.view(np.uint32)), f"pyramid {k} {sizes[k]} differs"
+    from orbit_amd._lib import E_CAPACITY, OrbitError
+
+    with pytest.raises(OrbitError) as ei:
+        engine.depth_reduce_multi(items + items[:1])  # nine pyramids
+    assert ei.value.code == E_CAPACITY
+
+
+@pytest.mark.parametrize("size", [(640, 360), (130, 40)])
+def test_pyramid_of_separate_per_mip_images(torch_mod, engine, oracle, size):
+    """The pyramid as the reference holds it — an image with a view per mip (draw_gen.rs:456-482) — exported to HIP as
+    one linear image per level with its own base address and padded row pitch (OrbitDepthPyramidLevel), and a depth
+    buffer with a row pitch: orbit_depth_reduce_multi writes the levels, both cull stages sample them in pass 2 through
+    the device-side level table.  Level contents == the oracle's packed chain; cull outputs == the packed run's."""
+    torch = torch_mod
+    W, H = size
+    cam = sc.default_camera()
+    depth = sc.make_depth(9, W, H, cam)
+    opyr, d = oracle.depth_reduce(depth, W, H)
+    dpitch = W + 13
+    dbuf = torch.full((H, dpitch), float("nan"), dtype=torch.float32, device="cuda")
+    dbuf[:, :W] = torch.from_numpy(depth).cuda()
+    levels, table = [], np.zeros(d.mip_levels, dtype=[("texels", "<u8"), ("row_pitch", "<u4"), ("_pad", "<u4")])
+    for k in range(d.mip_levels):
+        pitch = d.mip_width[k] + (7 if k % 2 else 32)
+        t = torch.full((d.mip_height[k], pitch), -7.0, dtype=torch.float32, device="cuda")
+        levels.append((t, pitch))
+        table[k] = (t.data_ptr(), pitch, 0)
+    engine.depth_reduce_multi([dict(depth=dbuf, width=W, height=H, depth_row_pitch=dpitch, levels=levels)])
+    torch.cuda.synchronize()
+    for k, (t, pitch) in enumerate(levels):
+        w, h, off = d.mip_width[k], d.mip_height[k], d.mip_offset[k]
+        got = t.cpu().numpy()
+        assert np.array_equal(got[:, :w].view(np.uint32), opyr[off:off + w * h].reshape(h, w).view(np.uint32)), k
+        assert np.all(got[:, w:] == -7.0)  # the padding of every row is left alone
+    # pass 2 of both cull stages through the level table
+    scene = sc.make_scene(11, 1500, n_meshes=200, extent=(60.0, 12.0, 60.0))
+    rng = np.random.default_rng(6)
+    evis = rng.integers(0, 2 ** 32, (scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+    mvis = rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32)
+    gs = GpuScene(torch, scene)
+    ci2 = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=2, p00=cam.p00, p11=cam.p11, z_near=cam.z_near)
+    ps = (d.width, d.height)
+    ref = run_oracle(oracle, scene, ci2, evis, mvis, opyr, ps)
+    table_d = dev(torch, table)
+    disp_cap, draw_cap = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
+    disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device="cuda")
+    draw = torch.zeros(L.DRAW_HEADER + 28 * draw_cap, dtype=torch.uint8, device="cuda")
+    evis_d, mvis_d = dev(torch, evis), dev(torch, mvis)
+    engine.entity_cull(ci2, gs.draws, gs.mesh_infos, disp, gs.entities, scene.entity_draw_count, disp_cap,
+                       visibility_buffer=evis_d, depth_pyramid_size=ps, depth_pyramid_levels=table_d)
+    engine.meshlet_cull(ci2, disp, gs.meshlets, draw, gs.entities, gs.materials, disp_cap, draw_cap,
+                        meshlet_visibility_buffer=mvis_d, depth_pyramid_size=ps, depth_pyramid_levels=table_d)
+    torch.cuda.synchronize()
+    engine.status()
+    _, cmds = assert_same((host(disp), host(draw), host(evis_d, np.uint32), host(mvis_d, np.uint32)), ref)
+    assert len(cmds) > 0
+
+
 @pytest.mark.parametrize("seed", range(max(16, int(os.environ.get("ORBIT_FUZZ_SEEDS", "16")) // 4)))
 def test_randomized_depth_reduce(torch_mod, engine, oracle, seed):
     """Random screen sizes down to 1 x 1 and extreme aspect ratios; arbitrary float bit patterns in the depth buffer
