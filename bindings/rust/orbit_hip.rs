@@ -28,6 +28,13 @@ pub struct OrbitEntityCullBufs {
     pub depth_pyramid_levels: *const OrbitDepthPyramidLevel,
 }
 
+/// One view of orbit_cull_views (the frame's early pass and shadow cascades culled side by side)
+#[repr(C)]
+pub struct OrbitCullView {
+    pub cull_info: *const c_void, pub entity: OrbitEntityCullBufs, pub meshlet: OrbitMeshletCullBufs,
+    pub entity_draw_count: u32, pub skip_meshlet_stage: u32,
+}
+
 /// One mip of a pyramid that is not one packed buffer (linear-tiled image per level: INTEGRATION.md)
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct OrbitDepthPyramidLevel { pub texels: *mut f32, pub row_pitch: u32, pub _pad: u32 }
@@ -80,6 +87,7 @@ extern "C" {
     /// Measurement hooks: HIP events around the dominant kernel on the launch stream.
     pub fn orbit_ctx_profile(ctx: *mut OrbitCtx, enable: i32) -> i32;
     pub fn orbit_ctx_profile_read(ctx: *mut OrbitCtx, avg_ms: *mut f32, launches: *mut u32) -> i32;
+    pub fn orbit_cull_views(ctx: *mut OrbitCtx, views: *const OrbitCullView, count: u32, stream: *mut c_void) -> i32;
     pub fn orbit_depth_reduce(ctx: *mut OrbitCtx, depth: *const f32, screen_w: u32, screen_h: u32,
                               pyramid: *mut f32, stream: *mut c_void) -> i32;
     /// update_multiple_depth_pyramids::<C> (draw_gen.rs:569-628): up to 8 pyramids in one launch pair

@@ -455,6 +455,29 @@ int32_t orbit_meshlet_task_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info
                                 OrbitMeshTaskRecord *task_records, void *stream);
 
 /* ------------------------------------------------------------------------ */
+/* Several views in one call.  A frame of the reference culls the same scene */
+/* for the early forward pass and for each of the four shadow cascades        */
+/* (forward.rs:286-403, shadow_renderer.rs:391-403) — independent culls,      */
+/* each a chain of five short, latency-bound launches on a scene of a few     */
+/* thousand entities.  orbit_cull_views runs the views' chains side by side:  */
+/* view 0 on the caller's stream, the others on streams of the context that   */
+/* fork from it and join it again (events; legal inside a HIP-graph capture), */
+/* each with its own scan scratch, so that the frame costs about one chain    */
+/* instead of `count` of them.  Every view's outputs are exactly those of     */
+/* orbit_entity_cull + orbit_meshlet_cull on its buffers.                     */
+/* ------------------------------------------------------------------------ */
+typedef struct OrbitCullView {
+    const OrbitGpuCullInfo *cull_info; /* HOST, 400 B: this view's CullInfo::to_gpu */
+    OrbitEntityCullBufs entity;        /* its own dispatch buffer (and bitset / pyramid in the occlusion passes) */
+    OrbitMeshletCullBufs meshlet;      /* meshlet_dispatch_buffer = entity.meshlet_dispatch_buffer */
+    uint32_t entity_draw_count;
+    uint32_t skip_meshlet_stage;       /* != 0: mesh-shading path, only the dispatch records are produced */
+} OrbitCullView;
+#define ORBIT_MAX_CULL_VIEWS 8
+/* The views must not share output buffers; visibility buffers written by two views (occlusion_pass 2) must differ. */
+int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t count, void *stream);
+
+/* ------------------------------------------------------------------------ */
 /* depth_reduce — replaces DepthPyramid::{new,resize,update}                 */
 /* (draw_gen.rs:456-566); device code restates shaders/depth_reduce.comp and */
 /* the ReduceMin sampler (src/graphics/device.rs:1404-1420).                 */

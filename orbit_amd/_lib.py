@@ -49,6 +49,11 @@ class MeshletCullBufs(C.Structure):
                 ("depth_pyramid_levels", C.c_void_p)]
 
 
+class CullView(C.Structure):  # OrbitCullView
+    _fields_ = [("cull_info", C.c_void_p), ("entity", EntityCullBufs), ("meshlet", MeshletCullBufs),
+                ("entity_draw_count", C.c_uint32), ("skip_meshlet_stage", C.c_uint32)]
+
+
 class DepthPyramidLevel(C.Structure):  # OrbitDepthPyramidLevel: one mip of a pyramid made of separate images
     _fields_ = [("texels", C.c_void_p), ("row_pitch", C.c_uint32), ("_pad", C.c_uint32)]
 
@@ -79,6 +84,7 @@ SYMBOLS = {
     "orbit_meshlet_cull": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(MeshletCullBufs), C.c_void_p]),
     "orbit_meshlet_task_cull": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(MeshletCullBufs), C.c_void_p, C.c_void_p]),
     "orbit_depth_pyramid_desc": (C.c_int32, [C.c_uint32, C.c_uint32, C.POINTER(DepthPyramidDesc)]),
+    "orbit_cull_views": (C.c_int32, [C.c_void_p, C.POINTER(CullView), C.c_uint32, C.c_void_p]),
     "orbit_depth_reduce_multi": (C.c_int32, [C.c_void_p, C.POINTER(DepthReduceItem), C.c_uint32, C.c_void_p]),
     "orbit_depth_pyramid_desc_from_mip0": (C.c_int32, [C.c_uint32, C.c_uint32, C.POINTER(DepthPyramidDesc)]),
     "orbit_depth_reduce": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),

@@ -50,6 +50,11 @@ struct OrbitCtx {
     uint32_t prof_calls = 0;
     std::vector<hipEvent_t> prof_events; // pairs, in record order
     size_t prof_used = 0;
+    // orbit_cull_views: child contexts (own scratch) and streams for views 1.., created on first use
+    std::vector<OrbitCtx *> view_ctx;
+    std::vector<hipStream_t> view_streams;
+    std::vector<hipEvent_t> view_joins;
+    hipEvent_t view_fork = nullptr;
     char err[512] = {0};
 };
 
@@ -262,6 +267,10 @@ int32_t orbit_ctx_destroy(OrbitCtx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (hipEvent_t ev : ctx->prof_events) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->view_joins) (void)hipEventDestroy(ev);
+    if (ctx->view_fork) (void)hipEventDestroy(ctx->view_fork);
+    for (hipStream_t st : ctx->view_streams) (void)hipStreamDestroy(st);
+    for (OrbitCtx *child : ctx->view_ctx) (void)orbit_ctx_destroy(child);
     if (ctx->arena) (void)hipFree(ctx->arena);
     delete ctx;
     return ORBIT_OK;
@@ -278,6 +287,15 @@ int32_t orbit_ctx_status(OrbitCtx *ctx, void *stream, int32_t sync) {
     int32_t v = 0;
     hipError_t e = hipMemcpy(&v, ctx->status, 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return hip_fail(ctx, e, "hipMemcpy(status)");
+    for (OrbitCtx *child : ctx->view_ctx) { // latches of the views that ran on the children's scratch
+        int32_t cv = 0;
+        e = hipMemcpy(&cv, child->status, 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return hip_fail(ctx, e, "hipMemcpy(status)");
+        if (cv != 0) {
+            (void)hipMemset(child->status, 0, 4);
+            if (v == 0) v = cv;
+        }
+    }
     if (v != 0) {
         e = hipMemset(ctx->status, 0, 4);
         if (e != hipSuccess) return hip_fail(ctx, e, "hipMemset(status)");
@@ -464,6 +482,74 @@ extern "C" {
 
 int32_t orbit_meshlet_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b, void *stream) {
     return meshlet_cull_impl(ctx, ci, b, nullptr, false, stream);
+}
+
+int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t count, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    if (!views || count == 0) {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        return fail(ctx, ORBIT_E_MISSING, "cull_views: no views");
+    }
+    if (count > ORBIT_MAX_CULL_VIEWS) {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        return fail(ctx, ORBIT_E_CAPACITY, "cull_views: %u views (max %u)", count, (unsigned)ORBIT_MAX_CULL_VIEWS);
+    }
+    hipStream_t s0 = (hipStream_t)stream;
+    {
+        // side resources for views 1..: a child context (own scan scratch: the views run concurrently), a stream and
+        // a join event each; created once, on first use
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess) return hip_fail(ctx, e, "hipSetDevice");
+        if (!ctx->view_fork) {
+            e = hipEventCreateWithFlags(&ctx->view_fork, hipEventDisableTiming);
+            if (e != hipSuccess) return hip_fail(ctx, e, "hipEventCreate");
+        }
+        while (ctx->view_ctx.size() + 1 < count) {
+            OrbitCtx *child = nullptr;
+            const int32_t rc = orbit_ctx_create(ctx->device, &ctx->caps, &child);
+            if (rc != ORBIT_OK) return fail(ctx, rc, "cull_views: scratch for view %zu: %s", ctx->view_ctx.size() + 1, g_err);
+            hipStream_t st = nullptr;
+            hipEvent_t ev = nullptr;
+            e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e != hipSuccess) {
+                if (st) (void)hipStreamDestroy(st);
+                (void)orbit_ctx_destroy(child);
+                return hip_fail(ctx, e, "cull_views: stream / event for a view");
+            }
+            ctx->view_ctx.push_back(child);
+            ctx->view_streams.push_back(st);
+            ctx->view_joins.push_back(ev);
+        }
+        if (count > 1) {
+            e = hipEventRecord(ctx->view_fork, s0);
+            if (e != hipSuccess) return hip_fail(ctx, e, "hipEventRecord(fork)");
+        }
+    }
+    int32_t first_rc = ORBIT_OK;
+    for (uint32_t i = 0; i < count; i++) {
+        const OrbitCullView &v = views[i];
+        OrbitCtx *c = i == 0 ? ctx : ctx->view_ctx[i - 1];
+        hipStream_t s = i == 0 ? s0 : ctx->view_streams[i - 1];
+        if (i > 0) {
+            const hipError_t e = hipStreamWaitEvent(s, ctx->view_fork, 0);
+            if (e != hipSuccess) return hip_fail(ctx, e, "hipStreamWaitEvent(fork)");
+        }
+        int32_t rc = orbit_entity_cull(c, v.cull_info, &v.entity, v.entity_draw_count, s);
+        if (rc == ORBIT_OK && !v.skip_meshlet_stage) rc = orbit_meshlet_cull(c, v.cull_info, &v.meshlet, s);
+        if (rc != ORBIT_OK && first_rc == ORBIT_OK) {
+            first_rc = rc;
+            std::lock_guard<std::mutex> lock(ctx->mu);
+            if (c != ctx) snprintf(ctx->err, sizeof(ctx->err), "view %u: %s", i, c->err);
+        }
+        if (i > 0) { // joined even after an error: the caller's stream must not lose the side streams
+            hipError_t e = hipEventRecord(ctx->view_joins[i - 1], s);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s0, ctx->view_joins[i - 1], 0);
+            if (e != hipSuccess) return hip_fail(ctx, e, "cull_views: join");
+        }
+    }
+    return first_rc;
 }
 
 int32_t orbit_meshlet_task_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,

@@ -112,6 +112,40 @@ class Engine:
                                                    entity_draw_count, _stream(stream))
         _lib.check(rc, self._ctx)
 
+    # -- several views side by side (orbit_cull_views)
+    def cull_views(self, views, stream=None):
+        """views: list of dicts with the arguments of entity_cull + meshlet_cull for one view each:
+        cull_info, entity_draw_buffer, mesh_info_buffer, meshlet_dispatch_buffer, entity_buffer, entity_draw_count,
+        dispatch_capacity, meshlet_buffer, draw_commands_buffer, material_buffer, draw_capacity and optionally
+        visibility_buffer, meshlet_visibility_buffer, depth_pyramid, depth_pyramid_size, material_count,
+        skip_meshlet_stage."""
+        arr = (_lib.CullView * len(views))()
+        keep = []
+        for v, a in zip(views, arr):
+            ci = _host_bytes(v["cull_info"], 400)
+            keep.append(ci)
+            a.cull_info = ci.ctypes.data
+            e, m = a.entity, a.meshlet
+            e.entity_draw_buffer = _ptr(v["entity_draw_buffer"])
+            e.mesh_info_buffer = _ptr(v["mesh_info_buffer"])
+            e.meshlet_dispatch_buffer = m.meshlet_dispatch_buffer = _ptr(v["meshlet_dispatch_buffer"])
+            e.entity_buffer = m.entity_buffer = _ptr(v["entity_buffer"])
+            e.visibility_buffer = _ptr(v.get("visibility_buffer"))
+            e.depth_pyramid = m.depth_pyramid = _ptr(v.get("depth_pyramid"))
+            ps = v.get("depth_pyramid_size", (0, 0))
+            e.depth_pyramid_size[0], e.depth_pyramid_size[1] = ps
+            m.depth_pyramid_size[0], m.depth_pyramid_size[1] = ps
+            e.dispatch_capacity = m.dispatch_capacity = v["dispatch_capacity"]
+            m.meshlet_buffer = _ptr(v.get("meshlet_buffer"))
+            m.draw_commands_buffer = _ptr(v.get("draw_commands_buffer"))
+            m.material_buffer = _ptr(v.get("material_buffer"))
+            m.meshlet_visibility_buffer = _ptr(v.get("meshlet_visibility_buffer"))
+            m.draw_capacity = v.get("draw_capacity", 0)
+            m.material_count = v.get("material_count", 0)
+            a.entity_draw_count = v["entity_draw_count"]
+            a.skip_meshlet_stage = 1 if v.get("skip_meshlet_stage") else 0
+        _lib.check(self._lib.orbit_cull_views(self._ctx, arr, len(views), _stream(stream)), self._ctx)
+
     # -- meshlet_cull: create_meshlet_draw_commands body (draw_gen.rs:382-435)
     def meshlet_cull(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, draw_commands_buffer, entity_buffer,
                      material_buffer, dispatch_capacity, draw_capacity, meshlet_visibility_buffer=None,

@@ -984,3 +984,66 @@ def test_two_contexts_overlap_on_two_streams(torch_mod, oracle):
     finally:
         for j in jobs:
             j[2].close()
+
+
+# ----------------------------------------------------------------------------- several views in one call
+def test_cull_views_early_pass_and_cascades(torch_mod, oracle):
+    """orbit_cull_views: the culls one frame of the reference issues independently — the early forward pass
+    (VisibilityRead, perspective) and the four shadow cascades (orthographic, up to 11 planes:
+    shadow_renderer.rs:466-706 through the host mirror) — side by side in one call, plus a dispatch-only view (mesh
+    shading).  Every view's dispatch records, draw commands and bits equal the oracle's for that view; a second call
+    reuses the side streams and scratch."""
+    torch = torch_mod
+    from orbit_amd import passes
+    from orbit_amd.engine import Engine
+
+    scene = sc.make_scene(17, 2600, n_meshes=400, extent=(70.0, 15.0, 70.0))
+    gs = GpuScene(torch, scene)
+    cam = sc.default_camera()
+    rng = np.random.default_rng(17)
+    evis = rng.integers(0, 2 ** 32, (scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+    mvis = rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32)
+    cis = [sc.make_cull_info(cam.view, cam.planes, occlusion_pass=1)]
+    for cascade in range(4):
+        hci, _, _ = passes.shadow_cascade(direction=(-0.45, 0.2, 0.1, 0.86), camera_position=(0.0, 2.0, 0.0),
+                                          camera_orientation=(0.0, 0.0, 0.0, 1.0), camera_fov=float(cam.fov),
+                                          camera_near_clip=cam.z_near, camera_aspect_ratio=cam.aspect,
+                                          cascade_index=cascade, max_shadow_distance=80.0)
+        cis.append(passes.cull_info_to_gpu(hci))
+    cis.append(sc.make_cull_info(cam.view, cam.planes[:3]))  # dispatch-only view
+    eng = Engine(0, max_entities=8192, max_dispatches=40_000, max_draws=200_000)
+    disp_cap, draw_cap = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
+    views, bufs = [], []
+    for k, ci in enumerate(cis):
+        disp = torch.full((L.DISPATCH_HEADER + 16 * disp_cap,), 0xAB, dtype=torch.uint8, device="cuda")
+        draw = torch.full((L.DRAW_HEADER + 28 * draw_cap,), 0xCD, dtype=torch.uint8, device="cuda")
+        e_d, m_d = (dev(torch, evis), dev(torch, mvis)) if k == 0 else (None, None)
+        bufs.append((disp, draw, e_d, m_d))
+        views.append(dict(cull_info=ci, entity_draw_buffer=gs.draws, mesh_info_buffer=gs.mesh_infos,
+                          meshlet_dispatch_buffer=disp, entity_buffer=gs.entities,
+                          entity_draw_count=scene.entity_draw_count, dispatch_capacity=disp_cap,
+                          meshlet_buffer=gs.meshlets, draw_commands_buffer=draw, material_buffer=gs.materials,
+                          draw_capacity=draw_cap, visibility_buffer=e_d, meshlet_visibility_buffer=m_d,
+                          skip_meshlet_stage=(k == len(cis) - 1)))
+    for rep in range(2):
+        eng.cull_views(views)
+        torch.cuda.synchronize()
+        eng.status()
+        drawn = []
+        for k, (ci, (disp, draw, e_d, m_d)) in enumerate(zip(cis, bufs)):
+            ref = run_oracle(oracle, scene, ci, evis if k == 0 else None, mvis if k == 0 else None)
+            if k == len(cis) - 1:  # dispatch records only; the draw buffer was never touched
+                nrec = int(ref[0][:4].view(np.uint32)[0])
+                assert np.array_equal(host(disp)[:12 + 16 * nrec], ref[0][:12 + 16 * nrec])
+                assert bool((draw == 0xCD).all())
+                continue
+            _, cmds = assert_same((host(disp), host(draw), None if e_d is None else host(e_d, np.uint32),
+                                   None if m_d is None else host(m_d, np.uint32)), ref)
+            drawn.append(len(cmds))
+        assert drawn[0] > 0 and sum(drawn[1:]) > 0, drawn
+    from orbit_amd._lib import E_CAPACITY, OrbitError
+
+    with pytest.raises(OrbitError) as ei:
+        eng.cull_views(views + views[:3])
+    assert ei.value.code == E_CAPACITY
+    eng.close()
