@@ -459,12 +459,15 @@ int32_t orbit_meshlet_task_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info
 /* for the early forward pass and for each of the four shadow cascades        */
 /* (forward.rs:286-403, shadow_renderer.rs:391-403) — independent culls,      */
 /* each a chain of five short, latency-bound launches on a scene of a few     */
-/* thousand entities.  orbit_cull_views runs the views' chains side by side:  */
-/* view 0 on the caller's stream, the others on streams of the context that   */
-/* fork from it and join it again (events; legal inside a HIP-graph capture), */
-/* each with its own scan scratch, so that the frame costs about one chain    */
-/* instead of `count` of them.  Every view's outputs are exactly those of     */
-/* orbit_entity_cull + orbit_meshlet_cull on its buffers.                     */
+/* thousand entities.  orbit_cull_views puts them into ONE chain: every       */
+/* kernel of the path takes all views at once (blockIdx.y = view, parameter   */
+/* blocks from a table; the streaming evaluations are grouped by occlusion    */
+/* pass and projection type, so the early pass + four cascades are two        */
+/* launches), each view on its own scan scratch — 6 launches instead of 25.   */
+/* Every view's outputs are exactly those of orbit_entity_cull +              */
+/* orbit_meshlet_cull on its buffers.  Meant for scenes whose culls are bound */
+/* by launch latency; a 50 M-meshlet view belongs in the single-view calls    */
+/* (their kernels keep the parameters in scalar registers).                   */
 /* ------------------------------------------------------------------------ */
 typedef struct OrbitCullView {
     const OrbitGpuCullInfo *cull_info; /* HOST, 400 B: this view's CullInfo::to_gpu */

@@ -50,11 +50,8 @@ struct OrbitCtx {
     uint32_t prof_calls = 0;
     std::vector<hipEvent_t> prof_events; // pairs, in record order
     size_t prof_used = 0;
-    // orbit_cull_views: child contexts (own scratch) and streams for views 1.., created on first use
+    // orbit_cull_views: child contexts (own scan scratch) for views 1.., created on first use
     std::vector<OrbitCtx *> view_ctx;
-    std::vector<hipStream_t> view_streams;
-    std::vector<hipEvent_t> view_joins;
-    hipEvent_t view_fork = nullptr;
     char err[512] = {0};
 };
 
@@ -267,9 +264,6 @@ int32_t orbit_ctx_destroy(OrbitCtx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (hipEvent_t ev : ctx->prof_events) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : ctx->view_joins) (void)hipEventDestroy(ev);
-    if (ctx->view_fork) (void)hipEventDestroy(ctx->view_fork);
-    for (hipStream_t st : ctx->view_streams) (void)hipStreamDestroy(st);
     for (OrbitCtx *child : ctx->view_ctx) (void)orbit_ctx_destroy(child);
     if (ctx->arena) (void)hipFree(ctx->arena);
     delete ctx;
@@ -354,10 +348,11 @@ int32_t orbit_debug_read_cycles(OrbitCtx *ctx, unsigned long long out[8]) {
 }
 
 // ------------------------------------------------------------------ entity_cull
-static int32_t entity_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitEntityCullBufs *b,
-                                uint32_t draw_first, uint32_t entity_draw_count, bool exact_range, void *stream) {
-    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+// Validates one entity cull and fills its parameter block; `scratch` owns the scan scratch the launch will use
+// (`ctx` itself, or one of its view children), errors are reported on `ctx`.  Caller holds ctx->mu.
+static int32_t entity_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCullInfo *ci,
+                                  const OrbitEntityCullBufs *b, uint32_t draw_first, uint32_t entity_draw_count,
+                                  bool exact_range, EntityCullParams &p) {
     int32_t rc = check_cull_info(ctx, ci);
     if (rc) return rc;
     if (!b) return fail(ctx, ORBIT_E_INVALID, "bufs is NULL");
@@ -372,7 +367,6 @@ static int32_t entity_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const
     if (entity_draw_count > ctx->caps.max_entities)
         return fail(ctx, ORBIT_E_CAPACITY, "entity_draw_count %u > caps.max_entities %u", entity_draw_count,
                     ctx->caps.max_entities);
-    EntityCullParams p;
     p.ci = *ci;
     p.entity_draw_buffer = (const uint8_t *)b->entity_draw_buffer;
     p.mesh_infos = (const OrbitMeshInfo *)b->mesh_info_buffer;
@@ -387,11 +381,21 @@ static int32_t entity_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const
                                        : ((uint64_t)entity_draw_count + 255u) / 256u * 256u;
     p.draw_limit = limit > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)limit;
     p.dispatch_capacity = b->dispatch_capacity;
-    p.proto = ctx->e_proto;
-    p.block_sums = ctx->e_block_sums;
-    p.total = ctx->e_total;
-    p.status = ctx->status;
-    hipError_t e = launch_entity_cull(p, entity_draw_count, (hipStream_t)stream);
+    p.proto = scratch->e_proto;
+    p.block_sums = scratch->e_block_sums;
+    p.total = scratch->e_total;
+    p.status = scratch->status;
+    return ORBIT_OK;
+}
+
+static int32_t entity_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitEntityCullBufs *b,
+                                uint32_t draw_first, uint32_t entity_draw_count, bool exact_range, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    EntityCullParams p;
+    const int32_t rc = entity_cull_params(ctx, ctx, ci, b, draw_first, entity_draw_count, exact_range, p);
+    if (rc) return rc;
+    const hipError_t e = launch_entity_cull(p, entity_draw_count, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch entity_cull");
     return ORBIT_OK;
 }
@@ -413,11 +417,10 @@ namespace {
 
 // orbit_meshlet_cull (task_records == nullptr: survivors -> MeshletDrawCommandBuffer) and
 // orbit_meshlet_task_cull (survivors stay with their record: one OrbitMeshTaskRecord each).
-int32_t meshlet_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
-                          OrbitMeshTaskRecord *task_records, bool task_path, void *stream,
-                          void *visible_buffer = nullptr, uint32_t visible_capacity = 0, bool visible_path = false) {
-    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+// Validation + parameter block of one meshlet cull (see entity_cull_params).  Caller holds ctx->mu.
+int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
+                            OrbitMeshTaskRecord *task_records, bool task_path, void *visible_buffer,
+                            uint32_t visible_capacity, bool visible_path, MeshletCullParams &p) {
     int32_t rc = check_cull_info(ctx, ci);
     if (rc) return rc;
     if (!b) return fail(ctx, ORBIT_E_INVALID, "bufs is NULL");
@@ -433,7 +436,6 @@ int32_t meshlet_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbit
     if (b->dispatch_capacity > ctx->caps.max_dispatches)
         return fail(ctx, ORBIT_E_CAPACITY, "dispatch_capacity %u > caps.max_dispatches %u", b->dispatch_capacity,
                     ctx->caps.max_dispatches);
-    MeshletCullParams p;
     p.ci = *ci;
     p.dispatch_buffer = (const uint8_t *)b->meshlet_dispatch_buffer;
     p.meshlets = (const OrbitMeshlet *)b->meshlet_buffer;
@@ -447,17 +449,29 @@ int32_t meshlet_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbit
     p.visible_list = visible_path ? 1u : 0u;
     p.material_count = b->material_count;
     p.task_records = task_records;
-    p.tile_counts = ctx->m_tile_counts;
-    p.tile_masks = ctx->m_tile_masks;
-    p.tile_payload = ctx->m_tile_payload;
-    p.tile_base = ctx->m_tile_base;
-    p.chunk_sums = ctx->m_chunk_sums;
-    p.total = ctx->m_total;
-    p.tickets = ctx->m_tickets;
-    p.debug_flags = ctx->debug_flags;
-    p.debug_cycles = ctx->debug_cycles;
-    p.zero_page = ctx->zero_page;
-    p.status = ctx->status;
+    p.tile_counts = scratch->m_tile_counts;
+    p.tile_masks = scratch->m_tile_masks;
+    p.tile_payload = scratch->m_tile_payload;
+    p.tile_base = scratch->m_tile_base;
+    p.chunk_sums = scratch->m_chunk_sums;
+    p.total = scratch->m_total;
+    p.tickets = scratch->m_tickets;
+    p.debug_flags = scratch->debug_flags;
+    p.debug_cycles = scratch->debug_cycles;
+    p.zero_page = scratch->zero_page;
+    p.status = scratch->status;
+    return ORBIT_OK;
+}
+
+int32_t meshlet_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
+                          OrbitMeshTaskRecord *task_records, bool task_path, void *stream,
+                          void *visible_buffer = nullptr, uint32_t visible_capacity = 0, bool visible_path = false) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MeshletCullParams p;
+    const int32_t rc = meshlet_cull_params(ctx, ctx, ci, b, task_records, task_path, visible_buffer, visible_capacity,
+                                           visible_path, p);
+    if (rc) return rc;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ctx->profiling && (ctx->prof_calls++ % ctx->profiling) == 0) {
         if (ctx->prof_used + 2 > ctx->prof_events.size()) {
@@ -486,70 +500,42 @@ int32_t orbit_meshlet_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbi
 
 int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t count, void *stream) {
     if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
-    if (!views || count == 0) {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        return fail(ctx, ORBIT_E_MISSING, "cull_views: no views");
-    }
-    if (count > ORBIT_MAX_CULL_VIEWS) {
-        std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!views || count == 0) return fail(ctx, ORBIT_E_MISSING, "cull_views: no views");
+    if (count > ORBIT_MAX_CULL_VIEWS)
         return fail(ctx, ORBIT_E_CAPACITY, "cull_views: %u views (max %u)", count, (unsigned)ORBIT_MAX_CULL_VIEWS);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipSetDevice");
+    // scan scratch per view (views 1.. on child contexts), created once
+    while (ctx->view_ctx.size() + 1 < count) {
+        OrbitCtx *child = nullptr;
+        const int32_t rc = orbit_ctx_create(ctx->device, &ctx->caps, &child);
+        if (rc != ORBIT_OK) return fail(ctx, rc, "cull_views: scratch for view %zu: %s", ctx->view_ctx.size() + 1, g_err);
+        ctx->view_ctx.push_back(child);
     }
-    hipStream_t s0 = (hipStream_t)stream;
-    {
-        // side resources for views 1..: a child context (own scan scratch: the views run concurrently), a stream and
-        // a join event each; created once, on first use
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        hipError_t e = hipSetDevice(ctx->device);
-        if (e != hipSuccess) return hip_fail(ctx, e, "hipSetDevice");
-        if (!ctx->view_fork) {
-            e = hipEventCreateWithFlags(&ctx->view_fork, hipEventDisableTiming);
-            if (e != hipSuccess) return hip_fail(ctx, e, "hipEventCreate");
-        }
-        while (ctx->view_ctx.size() + 1 < count) {
-            OrbitCtx *child = nullptr;
-            const int32_t rc = orbit_ctx_create(ctx->device, &ctx->caps, &child);
-            if (rc != ORBIT_OK) return fail(ctx, rc, "cull_views: scratch for view %zu: %s", ctx->view_ctx.size() + 1, g_err);
-            hipStream_t st = nullptr;
-            hipEvent_t ev = nullptr;
-            e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-            if (e != hipSuccess) {
-                if (st) (void)hipStreamDestroy(st);
-                (void)orbit_ctx_destroy(child);
-                return hip_fail(ctx, e, "cull_views: stream / event for a view");
-            }
-            ctx->view_ctx.push_back(child);
-            ctx->view_streams.push_back(st);
-            ctx->view_joins.push_back(ev);
-        }
-        if (count > 1) {
-            e = hipEventRecord(ctx->view_fork, s0);
-            if (e != hipSuccess) return hip_fail(ctx, e, "hipEventRecord(fork)");
-        }
-    }
-    int32_t first_rc = ORBIT_OK;
+    // every view's parameter block, validated before anything is enqueued; the blocks travel by value in the
+    // kernels' argument segments (a few KB)
+    EntityCullViews ev{};
+    MeshletCullViews mv{};
+    uint32_t max_draws = 0, n_mesh = 0;
     for (uint32_t i = 0; i < count; i++) {
         const OrbitCullView &v = views[i];
-        OrbitCtx *c = i == 0 ? ctx : ctx->view_ctx[i - 1];
-        hipStream_t s = i == 0 ? s0 : ctx->view_streams[i - 1];
-        if (i > 0) {
-            const hipError_t e = hipStreamWaitEvent(s, ctx->view_fork, 0);
-            if (e != hipSuccess) return hip_fail(ctx, e, "hipStreamWaitEvent(fork)");
+        OrbitCtx *scratch = i == 0 ? ctx : ctx->view_ctx[i - 1];
+        int32_t rc = entity_cull_params(ctx, scratch, v.cull_info, &v.entity, 0u, v.entity_draw_count, false, ev.v[i]);
+        if (rc == ORBIT_OK && !v.skip_meshlet_stage) {
+            rc = meshlet_cull_params(ctx, scratch, v.cull_info, &v.meshlet, nullptr, false, nullptr, 0, false, mv.v[n_mesh]);
+            if (rc == ORBIT_OK && v.meshlet.meshlet_dispatch_buffer != v.entity.meshlet_dispatch_buffer)
+                rc = fail(ctx, ORBIT_E_INVALID, "view %u: the meshlet stage must read the entity stage's dispatch buffer", i);
+            n_mesh++;
         }
-        int32_t rc = orbit_entity_cull(c, v.cull_info, &v.entity, v.entity_draw_count, s);
-        if (rc == ORBIT_OK && !v.skip_meshlet_stage) rc = orbit_meshlet_cull(c, v.cull_info, &v.meshlet, s);
-        if (rc != ORBIT_OK && first_rc == ORBIT_OK) {
-            first_rc = rc;
-            std::lock_guard<std::mutex> lock(ctx->mu);
-            if (c != ctx) snprintf(ctx->err, sizeof(ctx->err), "view %u: %s", i, c->err);
-        }
-        if (i > 0) { // joined even after an error: the caller's stream must not lose the side streams
-            hipError_t e = hipEventRecord(ctx->view_joins[i - 1], s);
-            if (e == hipSuccess) e = hipStreamWaitEvent(s0, ctx->view_joins[i - 1], 0);
-            if (e != hipSuccess) return hip_fail(ctx, e, "cull_views: join");
-        }
+        if (rc != ORBIT_OK) return rc;
+        max_draws = v.entity_draw_count > max_draws ? v.entity_draw_count : max_draws;
     }
-    return first_rc;
+    e = launch_entity_cull_views(ev, count, max_draws, s);
+    if (e == hipSuccess) e = launch_meshlet_cull_views(mv, n_mesh, ctx->num_cus, s);
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch cull_views");
+    return ORBIT_OK;
 }
 
 int32_t orbit_meshlet_task_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,

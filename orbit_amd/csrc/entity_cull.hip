@@ -20,7 +20,10 @@ constexpr int kBlock = 256;
 
 // One thread per entity-draw: evaluates the shader body up to the record
 // emission, stores a proto-record (meshlet_count == 0 when nothing is drawn).
-__global__ __launch_bounds__(kBlock) void entity_cull_eval(const EntityCullParams p) {
+// The parameter block is the kernel's own argument (one view) or entry blockIdx.y of an array of them passed by value
+// (several views in one launch: orbit_cull_views).
+
+__device__ __forceinline__ void entity_cull_eval_body(const EntityCullParams &p) {
     __shared__ uint32_t smem[kBlock / 64 + 1];
     const OrbitGpuCullInfo &ci = p.ci;
     const uint32_t local = blockIdx.x * kBlock + threadIdx.x;
@@ -105,6 +108,11 @@ __global__ __launch_bounds__(kBlock) void entity_cull_eval(const EntityCullParam
     if (threadIdx.x == 0) p.block_sums[blockIdx.x] = total;
 }
 
+__global__ __launch_bounds__(kBlock) void entity_cull_eval(const EntityCullParams p) { entity_cull_eval_body(p); }
+__global__ __launch_bounds__(kBlock) void entity_cull_eval_views(const EntityCullViews all) {
+    entity_cull_eval_body(all.v[blockIdx.y]);
+}
+
 // Sum of v over the block (every thread gets it).  `smem` holds NW words.
 template <int NW>
 __device__ __forceinline__ uint32_t block_reduce_add(uint32_t v, uint32_t *smem) {
@@ -126,7 +134,7 @@ __device__ __forceinline__ uint32_t block_reduce_add(uint32_t v, uint32_t *smem)
 // Thread = output record (owner found by bisection over the block's offsets in
 // LDS): consecutive lanes store consecutive 16-B records, where a thread-per-
 // entity loop stores 16 B every n x 16 B.
-__global__ __launch_bounds__(kBlock) void entity_cull_emit(const EntityCullParams p) {
+__device__ __forceinline__ void entity_cull_emit_body(const EntityCullParams &p) {
     __shared__ uint32_t smem[kBlock / 64 + 1];
     __shared__ uint32_t s_off[kBlock];
     __shared__ OrbitMeshletDispatch s_proto[kBlock];
@@ -171,6 +179,11 @@ __global__ __launch_bounds__(kBlock) void entity_cull_emit(const EntityCullParam
     }
 }
 
+__global__ __launch_bounds__(kBlock) void entity_cull_emit(const EntityCullParams p) { entity_cull_emit_body(p); }
+__global__ __launch_bounds__(kBlock) void entity_cull_emit_views(const EntityCullViews all) {
+    entity_cull_emit_body(all.v[blockIdx.y]);
+}
+
 __global__ void write_dispatch_header(uint32_t *hdr, uint32_t x) {
     hdr[0] = x;
     hdr[1] = 1u;
@@ -191,6 +204,19 @@ hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_co
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(entity_cull_emit, dim3(blocks), dim3(kBlock), 0, s, p);
+    return hipGetLastError();
+}
+
+// Several views in one launch pair (orbit_cull_views): the grid covers the view with the most entity-draws, the other
+// views' surplus blocks find nothing active and write zero sums.
+hipError_t launch_entity_cull_views(const EntityCullViews &all, uint32_t n, uint32_t max_entity_draw_count,
+                                    hipStream_t s) {
+    uint32_t blocks = (max_entity_draw_count + kBlock - 1) / kBlock;
+    if (blocks == 0) blocks = 1; // emit block 0 still writes every view's {0,1,1} header
+    hipLaunchKernelGGL(entity_cull_eval_views, dim3(blocks, n), dim3(kBlock), 0, s, all);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(entity_cull_emit_views, dim3(blocks, n), dim3(kBlock), 0, s, all);
     return hipGetLastError();
 }
 

@@ -127,9 +127,22 @@ struct ClusterAssignParams {
 };
 
 hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_count, hipStream_t s);
+// orbit_cull_views: the parameter blocks of all views travel BY VALUE in the kernel-argument segment (a few KB: HIP on
+// gfx950 takes it — tools/ubench/kernarg_size.hip), so a view's block is read with scalar loads at a uniform offset
+// (blockIdx.y), exactly like the single-view kernels read theirs.
+struct EntityCullViews {
+    EntityCullParams v[ORBIT_MAX_CULL_VIEWS];
+};
+hipError_t launch_entity_cull_views(const EntityCullViews &all, uint32_t n, uint32_t max_entity_draw_count,
+                                    hipStream_t s);
 // ev0/ev1 (optional): recorded on `s` immediately before / after the dominant kernel of the op
 hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, hipStream_t s,
                                hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// orbit_cull_views: the meshlet stage of the n views all.v[0..n)
+struct MeshletCullViews {
+    MeshletCullParams v[ORBIT_MAX_CULL_VIEWS];
+};
+hipError_t launch_meshlet_cull_views(const MeshletCullViews &all, uint32_t n, uint32_t num_cus, hipStream_t s);
 // Largest dispatch capacity launch_meshlet_cull accepts (the emit launch keeps one base per scan chunk in LDS);
 // checked by orbit_ctx_create against caps.max_dispatches, so no launch is ever enqueued for a larger one.
 uint32_t max_dispatch_capacity();
@@ -157,6 +170,19 @@ constexpr uint32_t kScanChunk = 4096;
 hipError_t launch_scan_two_level(const uint32_t *in, uint32_t *out_local, const uint32_t *n_src, uint32_t div,
                                  uint32_t n_max, uint32_t *chunk_sums, uint32_t *chunk_base, uint32_t *total,
                                  hipStream_t s);
+// The first scan level of several inputs in one launch (blockIdx.y = input): orbit_cull_views
+struct ScanViews {
+    struct Item {
+        const uint32_t *in;
+        uint32_t *out_local;
+        const uint32_t *n_src;
+        uint32_t *chunk_sums;
+        uint32_t *clear;
+        uint32_t n_max;
+    } v[8];
+};
+hipError_t launch_scan_chunks_views(const ScanViews &sv, uint32_t count, uint32_t div, uint32_t n_max_all,
+                                    uint32_t clear_words, hipStream_t s);
 // First level only (out_local and chunk_sums); the consumer scans the chunk sums itself.
 // `clear` (optional): `clear_words` words zeroed by the launch as well (a fused memset for the caller's counters)
 hipError_t launch_scan_chunks(const uint32_t *in, uint32_t *out_local, const uint32_t *n_src, uint32_t div,

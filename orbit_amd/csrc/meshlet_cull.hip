@@ -458,8 +458,13 @@ __device__ __forceinline__ void setup_write(const MeshletCullParams &p, WaveTile
 constexpr int kEvWaves = 4;
 constexpr int kEvWavesPerSimd = 4; // resident waves per SIMD: compiled for (128 VGPRs) and launched at
 
+// Views of one launch of the *_views kernels (orbit_cull_views): blockIdx.y = slot, idx[slot] = entry of the table.
+struct ViewGroup {
+    uint8_t idx[ORBIT_MAX_CULL_VIEWS];
+};
+
 template <int PASS, int PROJ, bool PROF>
-__global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_kernel(const MeshletCullParams p) {
+__device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
     __shared__ WaveTileLds lds[kEvWaves][3];
     __shared__ PlaneLds planes;
     __shared__ AlphaLds alpha_tab;
@@ -622,6 +627,17 @@ __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_k
     }
 }
 
+template <int PASS, int PROJ, bool PROF>
+__global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_kernel(const MeshletCullParams p) {
+    meshlet_eval_body<PASS, PROJ, PROF>(p);
+}
+// several views in one launch (orbit_cull_views): the views' parameter blocks by value, blockIdx.y picks one
+template <int PASS, int PROJ>
+__global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_views_kernel(const MeshletCullViews all,
+                                                                                           const ViewGroup g) {
+    meshlet_eval_body<PASS, PROJ, false>(all.v[g.idx[blockIdx.y]]);
+}
+
 // ---------------------------------------------------------------------------
 // Pass 1 (occlusion_pass == 1, :137): only meshlets that were visible last frame
 // are processed at all, and which those are is known from 4 bytes per record
@@ -709,7 +725,7 @@ __device__ __forceinline__ uint32_t pass1_eval(const MeshletCullParams &p, WaveT
 }
 
 template <int PROJ>
-__global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_pass1_kernel(const MeshletCullParams p) {
+__device__ __forceinline__ void meshlet_pass1_body(const MeshletCullParams &p) {
     __shared__ WaveTileLds lds[kEvWaves][3];
     __shared__ PlaneLds planes;
     __shared__ AlphaLds alpha_tab;
@@ -778,6 +794,16 @@ __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_pass1_
     }
 }
 
+template <int PROJ>
+__global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_pass1_kernel(const MeshletCullParams p) {
+    meshlet_pass1_body<PROJ>(p);
+}
+template <int PROJ>
+__global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_pass1_views_kernel(const MeshletCullViews all,
+                                                                                            const ViewGroup g) {
+    meshlet_pass1_body<PROJ>(all.v[g.idx[blockIdx.y]]);
+}
+
 // One wave per tile (grid stride): commands of the tile's survivors at the
 // scanned offset (:216-230).  Everything a tile needs is loaded ahead of its
 // turn, so no memory round trip is exposed between tiles: the 16 records, count
@@ -824,7 +850,7 @@ constexpr uint32_t kEmitChunkTable = 1024; // chunk bases kept in LDS (4 Mi tile
 // {meshlet_index, entity_index} after an 8-B {count, 0} header — which is what the sharded engine sends over
 // xGMI (visible_expand_kernel turns the gathered lists into commands on the receiving GPU).
 template <bool VISIBLE>
-__global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullParams p) {
+__device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
     __shared__ uint16_t s_list[4][kTileRows * 64];
     __shared__ uint32_t s_cmd[4][64 * 7];
     __shared__ uint32_t s_chunk_base[kEmitChunkTable];
@@ -930,6 +956,12 @@ __global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullPara
         if (VISIBLE) reinterpret_cast<uint32_t *>(p.draw_buffer)[1] = 0u;
         if (grand_total > p.draw_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
     }
+}
+
+template <bool VISIBLE>
+__global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullParams p) { meshlet_emit_body<VISIBLE>(p); }
+__global__ __launch_bounds__(256) void meshlet_emit_views_kernel(const MeshletCullViews all) {
+    meshlet_emit_body<false>(all.v[blockIdx.y]);
 }
 
 // Visible list -> MeshletDrawCommandBuffer (meshlet_cull.comp:216-230 for survivors that were culled on another GPU):
@@ -1135,6 +1167,63 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t
 }
 
 } // namespace
+
+// orbit_cull_views, meshlet stage.  The evaluation launches are grouped by (occlusion pass, projection) — a frame's
+// early pass and its four cascades are two launches — scan and emit take all views at once.
+hipError_t launch_meshlet_cull_views(const MeshletCullViews &all, uint32_t n, uint32_t num_cus, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const MeshletCullParams *host = all.v;
+    uint32_t max_tiles_all = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t t = (host[i].dispatch_capacity + kTileRecords - 1) / kTileRecords;
+        if ((t + kScanChunk - 1) / kScanChunk > kEmitChunkTable) return hipErrorInvalidValue;
+        max_tiles_all = max(max_tiles_all, t);
+    }
+    bool done[ORBIT_MAX_CULL_VIEWS] = {};
+    for (uint32_t i = 0; i < n; i++) {
+        if (done[i]) continue;
+        const uint32_t pass = host[i].ci.occlusion_pass, proj = host[i].ci.projection_type;
+        ViewGroup g{};
+        uint32_t m = 0, need = 1;
+        for (uint32_t j = i; j < n; j++)
+            if (!done[j] && host[j].ci.occlusion_pass == pass && host[j].ci.projection_type == proj) {
+                done[j] = true;
+                g.idx[m++] = (uint8_t)j;
+                const uint32_t t = (host[j].dispatch_capacity + kTileRecords - 1) / kTileRecords;
+                need = max(need, (t + kEvWaves - 1) / kEvWaves);
+            }
+        // the views of a group share the device: each gets an equal part of the resident-wave budget
+        uint32_t blocks = max(num_cus * (uint32_t)kEvWavesPerSimd / m, 1u);
+        if (blocks > need) blocks = need;
+        const dim3 grid(blocks, m), block(kEvWaves * 64);
+        const bool ortho = proj == 1;
+        if (pass == 1) {
+            if (ortho) hipLaunchKernelGGL((meshlet_pass1_views_kernel<1>), grid, block, 0, s, all, g);
+            else hipLaunchKernelGGL((meshlet_pass1_views_kernel<0>), grid, block, 0, s, all, g);
+        } else if (pass == 0) {
+            if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<0, 1>), grid, block, 0, s, all, g);
+            else hipLaunchKernelGGL((meshlet_eval_views_kernel<0, 0>), grid, block, 0, s, all, g);
+        } else {
+            if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<2, 1>), grid, block, 0, s, all, g);
+            else hipLaunchKernelGGL((meshlet_eval_views_kernel<2, 0>), grid, block, 0, s, all, g);
+        }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    ScanViews sv{};
+    for (uint32_t i = 0; i < n; i++)
+        sv.v[i] = {host[i].tile_counts, host[i].tile_base, reinterpret_cast<const uint32_t *>(host[i].dispatch_buffer),
+                   host[i].chunk_sums, host[i].tickets,
+                   (host[i].dispatch_capacity + kTileRecords - 1) / kTileRecords};
+    hipError_t e = launch_scan_chunks_views(sv, n, kTileRecords, max_tiles_all, kTicketPools * kTicketStride, s);
+    if (e != hipSuccess) return e;
+    uint32_t eblocks = max(num_cus * 8u / n, 1u);
+    const uint32_t eneed = (max_tiles_all + 3) / 4;
+    if (eblocks > eneed) eblocks = eneed;
+    if (eblocks == 0) eblocks = 1;
+    hipLaunchKernelGGL(meshlet_emit_views_kernel, dim3(eblocks, n), dim3(256), 0, s, all);
+    return hipGetLastError();
+}
 
 hipError_t launch_scatter_list(const ScatterListParams &p, uint32_t num_cus, hipStream_t s) {
     // enough blocks per destination to keep a link busy, few enough that `world` copies share the device

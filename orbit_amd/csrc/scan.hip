@@ -30,9 +30,9 @@ __global__ __launch_bounds__(1024) void scan_exclusive_kernel(const uint32_t *in
 // Two-level scan for long inputs: each block scans a chunk of kScanChunk words
 // (exclusive, chunk-local) and emits the chunk sum; a second single-block launch
 // scans the chunk sums.  Consumers add chunk_base[i / kScanChunk] themselves.
-__global__ __launch_bounds__(1024) void scan_chunks_kernel(const uint32_t *in, uint32_t *out, uint32_t n,
-                                                           const uint32_t *n_src, uint32_t div, uint32_t *chunk_sums,
-                                                           uint32_t *clear, uint32_t clear_words) {
+__device__ __forceinline__ void scan_chunks_body(const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *n_src,
+                                                 uint32_t div, uint32_t *chunk_sums, uint32_t *clear,
+                                                 uint32_t clear_words) {
     __shared__ uint32_t smem[1024 / 64 + 1];
     if (blockIdx.x == 0)
         for (uint32_t i = threadIdx.x; i < clear_words; i += 1024) clear[i] = 0u;
@@ -55,6 +55,28 @@ __global__ __launch_bounds__(1024) void scan_chunks_kernel(const uint32_t *in, u
     if (threadIdx.x == 0) chunk_sums[blockIdx.x] = carry;
 }
 
+__global__ __launch_bounds__(1024) void scan_chunks_kernel(const uint32_t *in, uint32_t *out, uint32_t n,
+                                                           const uint32_t *n_src, uint32_t div, uint32_t *chunk_sums,
+                                                           uint32_t *clear, uint32_t clear_words) {
+    scan_chunks_body(in, out, n, n_src, div, chunk_sums, clear, clear_words);
+}
+
+__global__ __launch_bounds__(1024) void scan_chunks_views_kernel(const ScanViews sv, uint32_t div, uint32_t clear_words) {
+    const ScanViews::Item &v = sv.v[blockIdx.y];
+    scan_chunks_body(v.in, v.out_local, v.n_max, v.n_src, div, v.chunk_sums, v.clear, clear_words);
+}
+
+} // namespace
+
+hipError_t launch_scan_chunks_views(const ScanViews &sv, uint32_t count, uint32_t div, uint32_t n_max_all,
+                                    uint32_t clear_words, hipStream_t s) {
+    uint32_t chunks = (n_max_all + kScanChunk - 1) / kScanChunk;
+    if (chunks == 0) chunks = 1;
+    hipLaunchKernelGGL(scan_chunks_views_kernel, dim3(chunks, count), dim3(1024), 0, s, sv, div, clear_words);
+    return hipGetLastError();
+}
+
+namespace {
 } // namespace
 
 hipError_t launch_scan_chunks(const uint32_t *in, uint32_t *out_local, const uint32_t *n_src, uint32_t div,

