@@ -180,16 +180,22 @@ def main():
             self.uses = 0
 
     slots = [Slot() for _ in range(F)]
-    xstream = gathered = gathered_vis = exchange = None
+    # The exchange stage: two exchange buffers (alternating) and, for the 8-B format, a third stream for the expansion,
+    # so that three things overlap in steady state — the cull of step i+1 (slot stream), the wire of step i (exchange
+    # stream) and the expansion of step i-1 (expansion stream): step time = max(cull, wire, expansion), not their sum.
+    xstream = estream = gathered = None
+    exchanges, recv_bufs, x_events, e_events = [], [], [], []
     transport = None
     if do_gather:
         xstream = torch.cuda.Stream(device=dev)
+        estream = torch.cuda.Stream(device=dev)
         out_cap = draw_cap * world
         transport = args.transport
+        n_x = 2
         if transport == "p2p":
             ok = 1
             try:
-                exchange = odist.P2PExchange(slots[0].eng, out_cap, hdr, item, dev)
+                exchanges = [odist.P2PExchange(slots[0].eng, out_cap, hdr, item, dev) for _ in range(n_x)]
             except Exception as ex:  # IPC not available between these processes: every rank falls back together
                 print(f"bench.py: p2p exchange unavailable on rank {rank} ({ex}); falling back to RCCL send/recv",
                       file=sys.stderr)
@@ -199,30 +205,38 @@ def main():
             if int(flag.item()) == 0:
                 if backend != "nccl":
                     raise SystemExit("bench.py: p2p exchange unavailable and the backend cannot move device lists")
-                transport, exchange = "rccl", None
+                transport, exchanges = "rccl", []
         if transport == "p2p":
-            first_out = exchange.out
+            recv_bufs = [x.out for x in exchanges]
         else:
-            first_out = torch.zeros(hdr + item * out_cap, dtype=torch.uint8, device=dev)
+            recv_bufs = [torch.zeros(hdr + item * out_cap, dtype=torch.uint8, device=dev) for _ in range(n_x)]
+        x_events = [torch.cuda.Event() for _ in range(n_x)]  # exchange into recv_bufs[j] finished
+        e_events = [torch.cuda.Event() for _ in range(n_x)]  # expansion out of recv_bufs[j] finished
         if visible_exchange:
-            gathered_vis = first_out
             gathered = torch.zeros(L.DRAW_HEADER + 28 * out_cap, dtype=torch.uint8, device=dev)
-        else:
-            gathered = first_out
     pending = []  # (slot, list index) culled but not yet exchanged (at most one)
+    x_count = [0]
 
     def gather(s, k):
-        # the exchange (and the expansion) of one list on the exchange stream, behind the cull that wrote the list —
-        # not behind the cull enqueued after it
+        # the exchange of one list on the exchange stream, behind the cull that wrote the list — not behind the cull
+        # enqueued after it; the expansion (8-B format) follows on its own stream
+        j = x_count[0] % len(recv_bufs)
+        x_count[0] += 1
         with torch.cuda.stream(xstream):
             xstream.wait_event(s.cull_done[k])
+            xstream.wait_event(e_events[j])  # the expansion that read this receive buffer two exchanges ago
             if transport == "p2p":
-                exchange.exchange(s.lists[k], stream=xstream)
+                exchanges[j].exchange(s.lists[k], stream=xstream)
             else:
-                odist.gather_visible(s.lists[k], first_out, header=hdr, stride=item)
+                odist.gather_visible(s.lists[k], recv_bufs[j], header=hdr, stride=item)
             s.xdone[k].record(xstream)  # the list buffer may be overwritten
-            if visible_exchange:
-                s.eng.expand_visible(gathered_vis, meshlets_base, gathered, out_cap, stream=xstream)
+            x_events[j].record(xstream)
+        if visible_exchange:
+            with torch.cuda.stream(estream):
+                estream.wait_event(x_events[j])
+                s.eng.expand_visible(recv_bufs[j], meshlets_base, gathered, out_cap, stream=estream)
+                e_events[j].record(estream)
+        return j
 
     step_no = [0]
 
@@ -256,6 +270,7 @@ def main():
             torch.cuda.current_stream().wait_stream(s.stream)
         if xstream is not None:
             torch.cuda.current_stream().wait_stream(xstream)
+            torch.cuda.current_stream().wait_stream(estream)
 
     if do_gather and transport == "rccl":  # RCCL channel set-up is not part of any step, warm or timed
         assert odist.warm_up(dev)
@@ -296,7 +311,8 @@ def main():
 
     # one frame alone on an idle device (nothing else in flight): the latency a single cull costs, and its parts
     s0 = slots[0]
-    serial, op_ms, x_ms = [], [], []
+    serial, op_ms, x_ms, ex_ms = [], [], [], []
+    last_recv = 0
     for _ in range(5):
         a, m, z = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         a.record(s0.stream)
@@ -315,21 +331,28 @@ def main():
         if do_gather:  # the exchange (+ expansion) of that list alone
             if use_dist:
                 dist.barrier()
-            xa, xz = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            xa, xm, xz = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             s0.cull_done[0].record(s0.stream)
             xa.record(xstream)
-            gather(s0, 0)
-            xz.record(xstream)
+            last_recv = gather(s0, 0)
+            xm.record(xstream)
+            if visible_exchange:
+                xz.record(estream)
             torch.cuda.synchronize()
-            x_ms.append(xa.elapsed_time(xz))
+            x_ms.append(xa.elapsed_time(xm))
+            if visible_exchange:
+                ex_ms.append(xm.elapsed_time(xz))
     frame_latency_ms = float(np.median(serial))
     kernel_ms = float(np.median(op_ms))  # whole meshlet_cull op (eval + scan + emit) of a frame alone on the device
     exchange_ms = float(np.median(x_ms)) if x_ms else None
+    expand_ms = float(np.median(ex_ms)) if ex_ms else None
 
     disp, draw = s0.disp, s0.lists[0]  # the latency frames above ran on slot 0: its buffers hold the last result
     n_rec = int(disp[:4].view(torch.int32).item())
     n_draw = int(draw[:4].view(torch.int32).item())
     if do_gather:  # the gathered list holds this rank's commands at its rank-order position
+        if not visible_exchange:
+            gathered = recv_bufs[last_recv]
         counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
         dist.all_gather(counts, torch.tensor([n_draw], dtype=torch.int64, device=dev))
         first = int(sum(int(c.item()) for c in counts[:rank]))
@@ -360,12 +383,15 @@ def main():
         agg = torch.tensor([n_in, n_draw], dtype=torch.int64, device=dev)
         dist.all_reduce(agg)
         tot_in, tot_draw = int(agg[0].item()), int(agg[1].item())
-        km = torch.tensor([kernel_ms, frame_latency_ms, exchange_ms or 0.0], dtype=torch.float64, device=dev)
+        km = torch.tensor([kernel_ms, frame_latency_ms, exchange_ms or 0.0, expand_ms or 0.0], dtype=torch.float64,
+                          device=dev)
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
         kernel_ms_max, kernel_ms_max_frame = float(km[0].item()), float(km[1].item())
         exchange_ms_max = float(km[2].item()) if exchange_ms is not None else None
+        expand_ms_max = float(km[3].item()) if expand_ms is not None else None
     else:
-        tot_in, tot_draw, kernel_ms_max, kernel_ms_max_frame, exchange_ms_max = n_in, n_draw, kernel_ms, frame_latency_ms, None
+        tot_in, tot_draw, kernel_ms_max, kernel_ms_max_frame = n_in, n_draw, kernel_ms, frame_latency_ms
+        exchange_ms_max = expand_ms_max = None
 
     ms_per_step = elapsed / args.steps * 1e3
     value = tot_in / (elapsed / args.steps)
@@ -441,14 +467,16 @@ def main():
             "cpu_baseline": cpu_baseline,
             "frame_latency_ms": frame_latency_ms,
             "per_rank": {"cull_ms_max": kernel_ms_max_frame, "exchange_ms_max": exchange_ms_max,
-                         "what": "one frame alone on each rank's device: entity_cull + meshlet_cull of its shard, "
-                                 "and the exchange (+ expansion) of its list; max over ranks"},
+                         "expand_ms_max": expand_ms_max,
+                         "what": "one frame alone on each rank's device: entity_cull + meshlet_cull of its shard, the "
+                                 "exchange of its list, the expansion of the gathered list; max over ranks.  In the "
+                                 "timed region the three overlap (cull of step i+1, wire of step i, expansion of i-1)"},
             "cull_only_meshlets_per_sec": tot_in / (kernel_ms_max * 1e-3) if kernel_ms_max > 0 else None,
             "scene_gen_s": gen_s,
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if exchange is not None:
-        exchange.close()
+    for x in exchanges:
+        x.close()
     for s in slots:
         s.eng.close()
     if use_dist:
