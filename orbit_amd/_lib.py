@@ -117,6 +117,19 @@ SYMBOLS = {
 _lib = None
 
 
+def load_variant(path):
+    """A second build of the library under another path (A/B tools: tools/ab_libs.py); not cached."""
+    import torch  # noqa: F401  (same HIP runtime as the main copy)
+
+    lib = C.CDLL(path)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        if hasattr(lib, name):  # an older build may lack the newest entry points
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+    return lib
+
+
 def load():
     """Loads the shared library once; raises if it has not been built."""
     global _lib

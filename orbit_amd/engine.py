@@ -52,8 +52,8 @@ def shard_range(entity_draw_count, rank, world):
 class Engine:
     """One ``OrbitCtx``: scan scratch sized from ``caps`` on one gfx950 device."""
 
-    def __init__(self, device_index=0, **caps):
-        lib = _lib.load()
+    def __init__(self, device_index=0, _library=None, **caps):
+        lib = _lib.load() if _library is None else _library  # _library: a variant build (tools/ab_libs.py)
         c = _lib.Caps()
         lib.orbit_default_caps(C.byref(c))
         for k, v in caps.items():
