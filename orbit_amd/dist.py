@@ -174,9 +174,11 @@ class _HipTransport:
         return device_view(ptr, nbytes, self.device), handle
 
     def open(self, handle, nbytes):
+        # a peer's buffer stays a raw address: it lives on ANOTHER device, and a torch tensor built over it with this
+        # rank's device would be a local copy (torch looks the pointer's device up and converts), not a mapping
         ptr = self.eng.p2p_open(handle)
         self.opened.append(ptr)
-        return device_view(ptr, nbytes, self.device)
+        return ptr
 
     def scatter(self, local_list, counts, rank, world, peers, capacity, header, stride, stream):
         self.eng.scatter_list(local_list, counts, rank, world, peers, capacity, header, stride, stream=stream)
