@@ -213,3 +213,35 @@ def test_loaded_scene_through_the_oracle_picks_several_lods(loaded, oracle):
     assert len(lods) >= 4, lods  # instances from 4 m to 420 m: entity_cull.comp:204-209 selects across the chain
     draw, _, dropped = oracle.meshlet_cull(ci, disp, b["meshlets"], cap_c, b["entities"], b["materials"])
     assert dropped == 0 and int(draw[:4].view(np.uint32)[0]) > 100
+
+
+def test_loader_survives_damaged_files(loaded, tmp_path):
+    """Truncations and byte flips of the container, the JSON and the binary chunk: the loader either loads or reports
+    an error (the reference unwraps and panics), it never reads outside its buffers (run under ASan in
+    tools/README_sanitizers.txt)."""
+    path, _ = loaded
+    raw = bytearray(open(path, "rb").read())
+    json_len = struct.unpack_from("<I", raw, 12)[0]
+    rng = np.random.default_rng(99)
+    outcomes = {"ok": 0, "error": 0}
+    for k in range(120):
+        b = bytearray(raw)
+        mode = k % 4
+        if mode == 0:    # truncate anywhere
+            b = b[:int(rng.integers(0, len(b)))]
+        elif mode == 1:  # flip bytes inside the JSON chunk (numbers, brackets, names)
+            for _ in range(int(rng.integers(1, 6))):
+                b[20 + int(rng.integers(0, json_len))] = int(rng.integers(32, 127))
+        elif mode == 2:  # flip bytes of the headers / chunk table
+            b[int(rng.integers(0, 28))] = int(rng.integers(0, 256))
+        else:            # index data: out-of-range indices must be caught
+            off = 20 + json_len + 8 + int(rng.integers(0, len(b) - (20 + json_len + 8)))
+            b[off:off + 4] = struct.pack("<I", 0xFFFFFFF0)
+        f = tmp_path / "damaged.glb"
+        f.write_bytes(bytes(b))
+        try:
+            gltf.load(str(f))
+            outcomes["ok"] += 1
+        except Panic:
+            outcomes["error"] += 1
+    assert outcomes["error"] > 30 and outcomes["ok"] + outcomes["error"] == 120, outcomes
