@@ -929,6 +929,16 @@ def test_null_arguments_are_status_codes_not_crashes(torch_mod):
             lambda: lib.orbit_gather_visible_meshlets(ctx, None, 0, 1, None, None, 0, None),
             lambda: lib.orbit_ctx_profile_read(ctx, None, None),
             lambda: lib.orbit_ctx_status(None, None, 0),
+            lambda: lib.orbit_cull_views(ctx, None, 1, None),
+            lambda: lib.orbit_cull_views(None, None, 1, None),
+            lambda: lib.orbit_cull_views(ctx, C.cast(C.pointer(_lib.CullView()), C.POINTER(_lib.CullView)), 1, None),
+            lambda: lib.orbit_depth_reduce_multi(ctx, None, 1, None),
+            lambda: lib.orbit_depth_reduce_multi(ctx, C.cast(C.pointer(_lib.DepthReduceItem()), C.POINTER(_lib.DepthReduceItem)), 1, None),
+            lambda: lib.orbit_scatter_list(ctx, None, None, 0, 1, None, 0, 4, 28, None),
+            lambda: lib.orbit_scatter_list(ctx, some, some, 3, 2, some, 0, 4, 28, None),
+            lambda: lib.orbit_scatter_list(ctx, some, some, 0, 1, some, 0, 6, 28, None),
+            lambda: lib.orbit_p2p_alloc(ctx, 0, None, None),
+            lambda: lib.orbit_p2p_open(ctx, None, None),
         ]
         for i, call in enumerate(calls):
             rc = call()
@@ -1045,5 +1055,37 @@ def test_cull_views_early_pass_and_cascades(torch_mod, oracle):
 
     with pytest.raises(OrbitError) as ei:
         eng.cull_views(views + views[:3])
+    assert ei.value.code == E_CAPACITY
+    eng.close()
+
+
+def test_scatter_list_capacity_and_header(torch_mod):
+    """orbit_scatter_list with a world of one: the list lands at offset 0 behind a {total, 0} header; an output that
+    cannot hold the concatenation latches ORBIT_E_CAPACITY, the header is clamped and nothing is written past it."""
+    torch = torch_mod
+    from orbit_amd._lib import E_CAPACITY, OrbitError
+    from orbit_amd.engine import Engine
+
+    eng = Engine(0)
+    n = 1000
+    items = torch.arange(2 * n, dtype=torch.int32, device="cuda")
+    local = torch.zeros(L.VISIBLE_HEADER + 8 * n, dtype=torch.uint8, device="cuda")
+    local[:4].view(torch.int32)[0] = n
+    local[8:].view(torch.int32)[:] = items
+    counts = torch.tensor([n], dtype=torch.int32, device="cuda")
+    out = torch.full((L.VISIBLE_HEADER + 8 * n + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+    eng.scatter_list(local, counts, 0, 1, [out], n, L.VISIBLE_HEADER, 8)
+    torch.cuda.synchronize()
+    eng.status()
+    assert [int(v) for v in out[:8].view(torch.int32)] == [n, 0]
+    assert torch.equal(out[8:8 + 8 * n], local[8:]) and bool((out[8 + 8 * n:] == 0x5A).all())
+    out.fill_(0x5A)
+    eng.scatter_list(local, counts, 0, 1, [out], n - 100, L.VISIBLE_HEADER, 8)
+    torch.cuda.synchronize()
+    assert int(out[:4].view(torch.int32)[0]) == n - 100
+    assert torch.equal(out[8:8 + 8 * (n - 100)], local[8:8 + 8 * (n - 100)])
+    assert bool((out[8 + 8 * (n - 100):] == 0x5A).all())
+    with pytest.raises(OrbitError) as ei:
+        eng.status()
     assert ei.value.code == E_CAPACITY
     eng.close()
