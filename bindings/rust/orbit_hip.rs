@@ -14,7 +14,7 @@ pub struct OrbitCtx { _private: [u8; 0] }
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct OrbitCaps {
     pub max_entities: u32, pub max_dispatches: u32, pub max_draws: u32, pub max_lights: u32,
-    pub max_clusters: u32, pub dispatch_size: u32, pub reserved: [u32; 2],
+    pub max_clusters: u32, pub dispatch_size: u32, pub max_views: u32, pub reserved: u32,
 }
 
 /// push-constant order of shaders/entity_cull.comp:17-23 (== draw_gen.rs:372-376)

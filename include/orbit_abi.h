@@ -330,7 +330,10 @@ typedef struct OrbitCaps {
     uint32_t max_lights;     /* scene.rs:304   MAX_LIGHT_COUNT      = 2_000     */
     uint32_t max_clusters;   /* tiles_x * tiles_y * max(4, z_slices): cluster.rs:53-56 */
     uint32_t dispatch_size;  /* spec constant 0 of both cull shaders; must be 32 */
-    uint32_t reserved[2];
+    uint32_t max_views;      /* orbit_cull_views: scan scratch for this many views is allocated at context creation
+                                (0: for one view; more is then allocated on the first call that needs it — the only
+                                allocation an enqueue call can ever make) */
+    uint32_t reserved;
 } OrbitCaps;
 
 typedef struct OrbitCtx OrbitCtx;

@@ -29,7 +29,7 @@ class OrbitError(RuntimeError):
 class Caps(C.Structure):
     _fields_ = [("max_entities", C.c_uint32), ("max_dispatches", C.c_uint32), ("max_draws", C.c_uint32),
                 ("max_lights", C.c_uint32), ("max_clusters", C.c_uint32), ("dispatch_size", C.c_uint32),
-                ("reserved", C.c_uint32 * 2)]
+                ("max_views", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class EntityCullBufs(C.Structure):

@@ -255,6 +255,22 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const char *dbg = getenv("ORBIT_SP_DEBUG");
     ctx->debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u;
     snprintf(ctx->err, sizeof(ctx->err), "no error");
+    // scan scratch of views 1.. of orbit_cull_views, when the caller announced them
+    if (caps.max_views > ORBIT_MAX_CULL_VIEWS) {
+        (void)orbit_ctx_destroy(ctx);
+        return fail(nullptr, ORBIT_E_CAPACITY, "caps.max_views %u > %u", caps.max_views, (unsigned)ORBIT_MAX_CULL_VIEWS);
+    }
+    OrbitCaps child_caps = caps;
+    child_caps.max_views = 0;
+    for (uint32_t v = 1; v < caps.max_views; v++) {
+        OrbitCtx *child = nullptr;
+        const int32_t rc = orbit_ctx_create(device_id, &child_caps, &child);
+        if (rc != ORBIT_OK) {
+            (void)orbit_ctx_destroy(ctx);
+            return rc;
+        }
+        ctx->view_ctx.push_back(child);
+    }
     *out_ctx = ctx;
     return ORBIT_OK;
 }
@@ -510,7 +526,9 @@ int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t cou
     // scan scratch per view (views 1.. on child contexts), created once
     while (ctx->view_ctx.size() + 1 < count) {
         OrbitCtx *child = nullptr;
-        const int32_t rc = orbit_ctx_create(ctx->device, &ctx->caps, &child);
+        OrbitCaps child_caps = ctx->caps;
+        child_caps.max_views = 0;
+        const int32_t rc = orbit_ctx_create(ctx->device, &child_caps, &child);
         if (rc != ORBIT_OK) return fail(ctx, rc, "cull_views: scratch for view %zu: %s", ctx->view_ctx.size() + 1, g_err);
         ctx->view_ctx.push_back(child);
     }

@@ -1021,7 +1021,7 @@ def test_cull_views_early_pass_and_cascades(torch_mod, oracle):
                                           cascade_index=cascade, max_shadow_distance=80.0)
         cis.append(passes.cull_info_to_gpu(hci))
     cis.append(sc.make_cull_info(cam.view, cam.planes[:3]))  # dispatch-only view
-    eng = Engine(0, max_entities=8192, max_dispatches=40_000, max_draws=200_000)
+    eng = Engine(0, max_entities=8192, max_dispatches=40_000, max_draws=200_000, max_views=4)  # 4 up front, 2 lazily
     disp_cap, draw_cap = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
     views, bufs = [], []
     for k, ci in enumerate(cis):
