@@ -1089,3 +1089,73 @@ def test_scatter_list_capacity_and_header(torch_mod):
         eng.status()
     assert ei.value.code == E_CAPACITY
     eng.close()
+
+
+def test_views_and_batched_pyramids_replay_as_a_graph(torch_mod, oracle):
+    """orbit_cull_views and orbit_depth_reduce_multi only enqueue (the parameter blocks travel in the kernel-argument
+    segments, no staging copy, no host wait): captured once, replayed on changed inputs — every replay equals the
+    oracle for the inputs it found."""
+    torch = torch_mod
+    from orbit_amd.engine import Engine
+
+    scene = sc.make_scene(23, 900, n_meshes=150, extent=(50.0, 10.0, 50.0))
+    gs = GpuScene(torch, scene)
+    cams = [sc.default_camera(), sc.default_camera(rot=(0.6, 0.8)), sc.default_camera(position=(5.0, 3.0, 9.0))]
+    rng = np.random.default_rng(23)
+    n = scene.entity_draw_count
+    cap_d, cap_c = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
+    W, H = 200, 120
+    d = oracle.depth_pyramid_desc(W, H)
+    ps = (d.width, d.height)
+    eng = Engine(0, max_entities=4096, max_dispatches=20_000, max_draws=100_000, max_views=3)
+    depths = [torch.zeros(H, W, dtype=torch.float32, device="cuda") for _ in cams]
+    pyrs = [torch.zeros(d.total_texels, dtype=torch.float32, device="cuda") for _ in cams]
+    evis = [torch.zeros((n + 31) // 32, dtype=torch.int32, device="cuda") for _ in cams]
+    mvis = [torch.zeros(scene.vis_words, dtype=torch.int32, device="cuda") for _ in cams]
+    cis, views = [], []
+    for k, cam in enumerate(cams):
+        ci = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=2, p00=cam.p00, p11=cam.p11, z_near=cam.z_near)
+        cis.append(ci)
+        disp = torch.zeros(L.DISPATCH_HEADER + 16 * cap_d, dtype=torch.uint8, device="cuda")
+        draw = torch.zeros(L.DRAW_HEADER + 28 * cap_c, dtype=torch.uint8, device="cuda")
+        views.append(dict(cull_info=ci, entity_draw_buffer=gs.draws, mesh_info_buffer=gs.mesh_infos,
+                          meshlet_dispatch_buffer=disp, entity_buffer=gs.entities, entity_draw_count=n,
+                          dispatch_capacity=cap_d, meshlet_buffer=gs.meshlets, draw_commands_buffer=draw,
+                          material_buffer=gs.materials, draw_capacity=cap_c, visibility_buffer=evis[k],
+                          meshlet_visibility_buffer=mvis[k], depth_pyramid=pyrs[k], depth_pyramid_size=ps))
+    arr, keep = eng.prepare_views(views)
+    items = [dict(depth=depths[k], width=W, height=H, pyramid=pyrs[k]) for k in range(len(cams))]
+
+    def frame():
+        eng.depth_reduce_multi(items)
+        eng.cull_views_prepared(arr)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        frame()  # code objects loaded, view scratch in place
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        frame()
+    for rep in range(3):  # new depth buffers and new bitsets every replay
+        h_depth, h_e, h_m = [], [], []
+        for k, cam in enumerate(cams):
+            dd = sc.make_depth(100 * rep + k, W, H, cam, n_occluders=6 + 4 * rep)
+            he = rng.integers(0, 2 ** 32, (n + 31) // 32, dtype=np.uint32)
+            hm = rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32)
+            depths[k].copy_(torch.from_numpy(dd))
+            evis[k].copy_(torch.from_numpy(he.view(np.int32)))
+            mvis[k].copy_(torch.from_numpy(hm.view(np.int32)))
+            h_depth.append(dd), h_e.append(he), h_m.append(hm)
+        g.replay()
+        torch.cuda.synchronize()
+        eng.status()
+        for k in range(len(cams)):
+            opyr, _ = oracle.depth_reduce(h_depth[k], W, H)
+            assert np.array_equal(host(pyrs[k], np.uint32), opyr.view(np.uint32)), (rep, k)
+            ref = run_oracle(oracle, scene, cis[k], h_e[k], h_m[k], opyr, ps)
+            assert_same((host(views[k]["meshlet_dispatch_buffer"]), host(views[k]["draw_commands_buffer"]),
+                         host(evis[k], np.uint32), host(mvis[k], np.uint32)), ref)
+    eng.close()
