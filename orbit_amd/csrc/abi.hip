@@ -30,7 +30,7 @@ struct OrbitCtx {
     size_t arena_bytes = 0;
     OrbitMeshletDispatch *e_proto = nullptr;
     uint32_t *e_block_sums = nullptr, *e_total = nullptr;
-    uint4 *m_tile_payload = nullptr;
+    Payload *m_tile_payload = nullptr;
     uint32_t *m_tile_masks = nullptr, *m_chunk_sums = nullptr;
     uint32_t *m_tile_counts = nullptr, *m_tile_base = nullptr, *m_total = nullptr;
     uint32_t *c_chunk = nullptr; // compact: counts | bases | total
@@ -196,7 +196,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t o_ebs = carve(eblocks * 4), o_et = carve(256);
     const size_t o_mtc = carve(mtiles * 4), o_mtb = carve(mtiles * 4), o_mt = carve(256);
     const size_t o_mtm = carve(mtiles * 64);
-    const size_t o_mtp = carve(mtiles * 128 * 16);
+    const size_t o_mtp = carve(mtiles * 128 * sizeof(Payload));
     const size_t mchunks = mtiles / kScanChunk + 2;
     const size_t o_mcs = carve(mchunks * 4);
     const size_t o_cc = carve((2 * cchunks + 64) * 4);
@@ -235,7 +235,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->m_tile_base = (uint32_t *)(a + o_mtb);
     ctx->m_total = (uint32_t *)(a + o_mt);
     ctx->m_tile_masks = (uint32_t *)(a + o_mtm);
-    ctx->m_tile_payload = (uint4 *)(a + o_mtp);
+    ctx->m_tile_payload = (Payload *)(a + o_mtp);
     ctx->m_chunk_sums = (uint32_t *)(a + o_mcs);
     ctx->c_chunk = (uint32_t *)(a + o_cc);
     ctx->a_view_lights = (float4 *)(a + o_avl);

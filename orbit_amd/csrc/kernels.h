@@ -17,6 +17,11 @@ constexpr uint32_t kTileRows = 8;
 constexpr uint32_t kTicketPools = 8;
 constexpr uint32_t kTicketStride = 64; // words
 
+// what meshlet_eval keeps per survivor for the emit launch (meshlet_cull.hip make_payload)
+struct Payload {
+    uint32_t y, z, w; // Meshlet::vertex_offset, Meshlet::data_offset, {triangles:8 | vertices:8 | lane:5 << 4 | record:4}
+};
+
 struct EntityCullParams {
     OrbitGpuCullInfo ci;
     const uint8_t *entity_draw_buffer;
@@ -55,7 +60,7 @@ struct MeshletCullParams {
     uint32_t visible_list;
     // context scratch
     uint32_t *tile_counts;
-    uint4 *tile_payload;   // 128 x 16 B per wave tile: survivors in tile-local order (make_payload, meshlet_cull.hip)
+    Payload *tile_payload; // 128 x 12 B per wave tile: survivors in tile-local order (make_payload, meshlet_cull.hip)
     uint32_t *tile_masks; // 16 words (8 x 64-bit should-draw ballots) per wave tile
     uint32_t *tile_base;   // chunk-local exclusive prefix of tile_counts
     uint32_t *chunk_sums;  // per kScanChunk tiles; the emit launch prefix-sums them itself (LDS)

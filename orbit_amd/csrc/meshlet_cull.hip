@@ -127,11 +127,12 @@ struct MeshletVerdict {
     bool visible, should_draw;
 };
 
-// Survivor payload (16 B): meshlet index, Meshlet::vertex_offset, Meshlet::data_offset, and
-// {triangle_count:8 | vertex_count:8 | tile-local record id:16} (the material index is not part
-// of a command, its bits carry the record id that leads to the entity index).
-__device__ __forceinline__ uint4 make_payload(uint32_t meshlet_index, uint32_t rid, const uint4 &b) {
-    return make_uint4(meshlet_index, b.y, b.z, (b.w & 0xFFFF0000u) | rid);
+// Survivor payload (12 B): Meshlet::vertex_offset, Meshlet::data_offset, and
+// {triangle_count:8 | vertex_count:8 | lane within the record:5 << 4 | tile-local record id:4} — the material index is
+// not part of a command, its bits carry where the survivor sat in the tile, from which the emit launch gets the
+// meshlet index (record's meshlet_offset + lane) and the entity index (record's entity_index).
+__device__ __forceinline__ Payload make_payload(uint32_t ml, uint32_t rid, const uint4 &b) {
+    return Payload{b.y, b.z, (b.w & 0xFFFF0000u) | (ml << 4) | rid};
 }
 
 // One meshlet (one lane): meshlet_cull.comp:113-213.  PASS = cull_info.occlusion_pass
@@ -240,7 +241,7 @@ __device__ __forceinline__ void rows_load(const MeshletCullParams &p, const Wave
 template <int PASS, int PROJ, bool WRITE_VIS, int R0, int NR>
 __device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
                                               const AlphaLds *A, int lane, const RowRegs<NR> &t, uint32_t total,
-                                              uint4 *payload) {
+                                              Payload *payload) {
     const bool meshlet_occ = p.ci.meshlet_visibility_buffer != ORBIT_NONE;
     const bool rw_vis = PASS != 0 && meshlet_occ;
     const uint32_t half = lane >> 5, ml = lane & 31;
@@ -268,7 +269,7 @@ __device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTi
             // survivor payload at the tile-local rank: everything the command needs except its
             // slot, so the emit launch reads one contiguous run per tile and rebuilds nothing
             const uint32_t rank = total + lane_prefix(mask);
-            if (rank < kPayloadCap) payload[rank] = make_payload(rec.y + ml, rid, t.b[k]);
+            if (rank < kPayloadCap) payload[rank] = make_payload(ml, rid, t.b[k]);
         }
         total += (uint32_t)__popcll(mask);
         if (PASS == 2 && WRITE_VIS) {
@@ -311,7 +312,7 @@ __device__ __forceinline__ uint32_t ring_wrap(uint32_t i) { return i >= kCandRin
 // Tests the first n (<= 64) candidates of the ring; lane j takes candidate j.
 template <uint32_t N>
 __device__ __forceinline__ void cand_flush(const MeshletCullParams &p, WaveTileLds &L, const CandLds<N> &C, int lane,
-                                           CandState &cs, uint32_t n, uint4 *payload) {
+                                           CandState &cs, uint32_t n, Payload *payload) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -335,7 +336,7 @@ __device__ __forceinline__ void cand_flush(const MeshletCullParams &p, WaveTileL
     if (payload && should_draw) {
         const uint32_t rank = cs.total + lane_prefix(dm);
         if (rank < kPayloadCap)
-            payload[rank] = make_payload(L.rec[word].y + (code & 31u), word, info);
+            payload[rank] = make_payload(code & 31u, word, info);
     }
     cs.total += (uint32_t)__popcll(dm);
     cs.head = ring_wrap(cs.head + n);
@@ -346,7 +347,7 @@ __device__ __forceinline__ void cand_flush(const MeshletCullParams &p, WaveTileL
 template <int PROJ, int R, uint32_t N>
 __device__ __forceinline__ void row_eval_occ(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
                                              const AlphaLds *A, CandLds<N> &C, int lane, const RowRegs<1> &t,
-                                             CandState &cs, uint4 *payload) {
+                                             CandState &cs, Payload *payload) {
     const uint32_t half = lane >> 5, ml = lane & 31;
     const uint32_t rid = 2 * R + half;
     const uint4 rec = L.rec[rid];
@@ -372,7 +373,7 @@ __device__ __forceinline__ void row_eval_occ(const MeshletCullParams &p, WaveTil
 // End of a tile: remaining candidates, then the pass-2 visibility words (:233-254) of its 16 records.
 template <uint32_t N>
 __device__ __forceinline__ void tile_finish_occ(const MeshletCullParams &p, WaveTileLds &L, const CandLds<N> &C,
-                                                int lane, CandState &cs, uint4 *payload) {
+                                                int lane, CandState &cs, Payload *payload) {
     if (cs.count > 0) cand_flush(p, L, C, lane, cs, cs.count, payload);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -569,7 +570,7 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         tk_raw = claim();                                     // the tile after it
         WaveTileLds &L = lds[wave][it % 3];
         WaveTileLds &Ln = lds[wave][(it + 1) % 3]; // slab of an absent tile holds zero records
-        uint4 *payload = p.task_records ? nullptr : p.tile_payload + (size_t)w0 * kPayloadCap;
+        Payload *payload = p.task_records ? nullptr : p.tile_payload + (size_t)w0 * kPayloadCap;
         CandState cs; // cs.total = the tile's running survivor count
 #define EV_ROW(R, Q)                                                                                        \
     if constexpr (PASS == 2) {                                                                              \
@@ -705,7 +706,7 @@ __device__ __forceinline__ Pass1Item pass1_load(const MeshletCullParams &p, cons
 template <int PROJ>
 __device__ __forceinline__ uint32_t pass1_eval(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
                                                const AlphaLds *A, int lane, const Pass1Item &it, uint32_t total,
-                                               uint4 *payload) {
+                                               Payload *payload) {
     const bool valid = it.code != ~0u;
     const uint32_t rid = (it.code >> 5) & 15u, ml = it.code & 31u;
     const uint32_t mi = it.b.w & 0xFFFFu; // zero page for lanes without a candidate: material 0, unused
@@ -720,7 +721,7 @@ __device__ __forceinline__ uint32_t pass1_eval(const MeshletCullParams &p, WaveT
     const uint64_t dm = __ballot(should_draw);
     if (payload && should_draw) {
         const uint32_t rank = total + lane_prefix(dm);
-        if (rank < kPayloadCap) payload[rank] = make_payload(L.rec[rid].y + ml, rid, it.b);
+        if (rank < kPayloadCap) payload[rank] = make_payload(ml, rid, it.b);
     }
     return total + (uint32_t)__popcll(dm);
 }
@@ -761,7 +762,7 @@ __device__ __forceinline__ void meshlet_pass1_body(const MeshletCullParams &p) {
         const uint32_t w3 = w2 + stride;
         WaveTileLds &L = lds[wave][it % 3];
         WaveTileLds &Ln = lds[wave][(it + 1) % 3]; // slab of an absent tile holds zero records
-        uint4 *payload = p.task_records ? nullptr : p.tile_payload + (size_t)w0 * kPayloadCap;
+        Payload *payload = p.task_records ? nullptr : p.tile_payload + (size_t)w0 * kPayloadCap;
         const float4 mat2 = setup_load_mat(p, rec2, lane);
         const uint32_t prev2 = pass1_load_prev(p, rec2, lane);
         const uint4 rec3 = setup_load_rec(p, w3, w3 < ntiles, nrec, lane);
@@ -829,11 +830,11 @@ __device__ __forceinline__ EmitTile emit_prefetch(const MeshletCullParams &p, ui
 }
 
 // Payload entries [first, first + 64) of a tile; lanes past the count read the zero page.
-__device__ __forceinline__ uint4 emit_load_payload(const MeshletCullParams &p, uint32_t tile, uint32_t count,
+__device__ __forceinline__ Payload emit_load_payload(const MeshletCullParams &p, uint32_t tile, uint32_t count,
                                                    uint32_t first, int lane) {
     const uint32_t j = first + (uint32_t)lane;
     const bool has = j < count && count <= kPayloadCap;
-    return *(has ? p.tile_payload + ((size_t)tile * kPayloadCap + j) : reinterpret_cast<const uint4 *>(p.zero_page));
+    return *(has ? p.tile_payload + ((size_t)tile * kPayloadCap + j) : reinterpret_cast<const Payload *>(p.zero_page));
 }
 
 constexpr uint32_t kEmitChunkTable = 1024; // chunk bases kept in LDS (4 Mi tiles = 64 Mi dispatch records)
@@ -877,10 +878,10 @@ __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
     uint32_t tile = blockIdx.x * 4 + wave;
     EmitTile cur = emit_prefetch(p, tile, ntiles, nrec, lane);
     EmitTile nxt = emit_prefetch(p, tile + stride, ntiles, nrec, lane);
-    uint4 cur_pay = emit_load_payload(p, tile, cur.count, 0u, lane);
+    Payload cur_pay = emit_load_payload(p, tile, cur.count, 0u, lane);
     for (; tile < ntiles; tile += stride) {
         const EmitTile nn = emit_prefetch(p, tile + 2 * stride, ntiles, nrec, lane);
-        const uint4 nxt_pay = emit_load_payload(p, tile + stride, nxt.count, 0u, lane);
+        const Payload nxt_pay = emit_load_payload(p, tile + stride, nxt.count, 0u, lane);
         const uint32_t n = cur.count;
         if (n != 0u) { // wave-uniform
             const uint32_t base = cur.base + s_chunk_base[tile / kScanChunk];
@@ -902,22 +903,24 @@ __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
             }
             for (uint32_t j0 = 0; j0 < n; j0 += 64) { // one trip unless more than 64 survivors
                 const uint32_t j = j0 + lane;
-                uint4 pay; // payload layout (make_payload)
+                Payload pay; // payload layout (make_payload)
                 if (dense) {
                     const uint32_t code = j < n ? list[j] : 0u;
                     const uint32_t rid = (code >> 6) * 2u + ((code >> 5) & 1u); // record 2r + half
                     const uint32_t mi = (uint32_t)__shfl((int)cur.rec.y, (int)rid, 64) + (code & 31u);
                     const uint4 b = *(j < n ? reinterpret_cast<const uint4 *>(p.meshlets + mi) + 1
                                             : reinterpret_cast<const uint4 *>(p.zero_page));
-                    pay = make_payload(mi, rid, b);
+                    pay = make_payload(code & 31u, rid, b);
                 } else {
                     pay = j0 == 0u ? cur_pay : emit_load_payload(p, tile, n, j0, lane);
                 }
-                const uint32_t ent = (uint32_t)__shfl((int)cur.rec.x, (int)(pay.w & 0xFFFFu), 64);
+                const uint32_t pay_rid = pay.w & 15u;
+                const uint32_t ent = (uint32_t)__shfl((int)cur.rec.x, (int)pay_rid, 64);
+                const uint32_t pay_meshlet = (uint32_t)__shfl((int)cur.rec.y, (int)pay_rid, 64) + ((pay.w >> 4) & 31u);
                 if (VISIBLE) {
                     const uint32_t slot = base + j;
                     if (j < n && slot < p.draw_capacity)
-                        reinterpret_cast<uint2 *>(p.draw_buffer + ORBIT_VISIBLE_HEADER)[slot] = make_uint2(pay.x, ent);
+                        reinterpret_cast<uint2 *>(p.draw_buffer + ORBIT_VISIBLE_HEADER)[slot] = make_uint2(pay_meshlet, ent);
                     continue;
                 }
                 const uint32_t vertex_count = (pay.w >> 16) & 0xFFu;
@@ -929,7 +932,7 @@ __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
                 c[3] = pay.z;                       // cmd_vertex_offset = int(data_offset)
                 c[4] = ent;                         // cmd_first_instance = entity_index
                 c[5] = pay.y;                       // meshlet_vertex_offset
-                c[6] = pay.x;                       // meshlet_index
+                c[6] = pay_meshlet;                 // meshlet_index
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

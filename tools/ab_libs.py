@@ -1,7 +1,9 @@
 """In-process alternating A/B of two BUILDS of the library (the product and variants under tools/variants/, e.g. the
 previous commit built with `git stash; make; cp orbit_amd/liborbit_cull.so tools/variants/prev.so; git stash pop`):
 the same config-5 frame through an engine of each library in turn, HIP-event medians of the frame and of its parts.
-usage: python tools/ab_libs.py tools/variants/prev.so [more.so ...]      (the product library is always variant 0)"""
+usage: python tools/ab_libs.py tools/variants/prev.so [more.so ...]      (the product library is always variant 0)
+Give it at least two variants and run both orders, with a copy of the product as a control: on some boxes the FIRST
+engine of a process runs several per cent slower than the others whatever its code (profiles/r02_notes.md)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
