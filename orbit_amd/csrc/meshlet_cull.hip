@@ -606,7 +606,9 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         }
 #undef EV_ROW
         setup_write(p, lds[wave][(it + 2) % 3], rec2, mat2, lane); // also fences the mask writes of this tile
-        if (lane < 2 * (int)kTileRows)
+        // the ballots are read back only by the task-record launch and, in the emit launch, for tiles with more
+        // survivors than the payload holds: the common tile writes its count and nothing else
+        if ((p.task_records != nullptr || cs.total > kPayloadCap) && lane < 2 * (int)kTileRows)
             p.tile_masks[(size_t)w0 * (2 * kTileRows) + lane] = reinterpret_cast<const uint32_t *>(L.draw_mask)[lane];
         if (lane == 0) p.tile_counts[w0] = cs.total;
         EV_STAMP(4)
@@ -781,7 +783,7 @@ __device__ __forceinline__ void meshlet_pass1_body(const MeshletCullParams &p) {
             if (last) break;
         }
         setup_write(p, lds[wave][(it + 2) % 3], rec2, mat2, lane, prev2); // also fences the mask atomics of this tile
-        if (lane < 2 * (int)kTileRows)
+        if ((p.task_records != nullptr || total > kPayloadCap) && lane < 2 * (int)kTileRows) // see meshlet_eval
             p.tile_masks[(size_t)w0 * (2 * kTileRows) + lane] = reinterpret_cast<const uint32_t *>(L.draw_mask)[lane];
         if (lane == 0) p.tile_counts[w0] = total;
         uint16_t *t = list_cur;
