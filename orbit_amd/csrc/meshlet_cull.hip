@@ -493,9 +493,10 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
     const uint32_t stride = gridDim.x * kEvWaves, wave_g = blockIdx.x * kEvWaves + wave;
     const bool static_share = (p.debug_flags & 64u) != 0; // triage: everything static, for A/B runs
     const uint32_t full_rounds = ntiles / stride;
-    const uint32_t dyn_rounds = (p.debug_flags & 256u) ? 2u : (p.debug_flags & 512u) ? 4u : (p.debug_flags & 1024u) ? 1u : 3u;
+    // ticketed rounds: three on a long launch, fewer on a short one (a shard of the sharded engine has 2-3 rounds in all)
+    const uint32_t dyn_rounds = (p.debug_flags & 256u) ? 2u : (p.debug_flags & 512u) ? 4u : (p.debug_flags & 1024u) ? 1u : min(max(full_rounds / 4u, 1u), 3u);
     // a scene of at most one tile per wave has nothing to balance: static, no atomic in front of the first loads
-    const uint32_t n_static = (static_share || ntiles <= stride) ? 0xFFFFFFFFu : ((p.debug_flags & 128u) ? 0u : (full_rounds > dyn_rounds ? full_rounds - dyn_rounds : 0u));
+    const uint32_t n_static = (static_share || ntiles <= stride) ? 0xFFFFFFFFu : ((p.debug_flags & 128u) ? 0u : (full_rounds >= dyn_rounds ? full_rounds - dyn_rounds : 0u));
     const uint32_t npools = min((uint32_t)kTicketPools, stride);
     const uint32_t pool = wave_g % npools;
     uint32_t *ticket_ctr = p.tickets + pool * kTicketStride;
