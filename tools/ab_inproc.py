@@ -59,4 +59,4 @@ for r in range(R):
         eng.profile(True)
 for k, f in enumerate(flagsets):
     print(f"flags {f:4d}: frame median {np.median(tf[k]):.4f} ms (p10 {np.percentile(tf[k], 10):.4f}, p90 {np.percentile(tf[k], 90):.4f})"
-          f"   eval median {np.median(te[k]):.4f} ms (p10 {np.percentile(te[k], 10):.4f}, p90 {np.percentile(te[k], 90):.4f})")
+          f"   eval median {np.median(te[k]):.4f} ms   rest {np.median(np.array(tf[k]) - np.array(te[k])):.4f}")
