@@ -171,7 +171,7 @@ hipError_t launch_cluster_assign(const ClusterAssignParams &p, uint32_t num_cus,
 hipError_t launch_scan_exclusive(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, hipStream_t s);
 // Two-level variant for long inputs: out_local[i] is the exclusive prefix inside
 // chunk i / kScanChunk, chunk_base[c] the exclusive prefix of chunk c; n as below.
-constexpr uint32_t kScanChunk = 4096;
+constexpr uint32_t kScanChunk = 1024; // 4096 -> 1024: four times the blocks, one pass each: -2 us per scan (profiles/r02_notes.md)
 hipError_t launch_scan_two_level(const uint32_t *in, uint32_t *out_local, const uint32_t *n_src, uint32_t div,
                                  uint32_t n_max, uint32_t *chunk_sums, uint32_t *chunk_base, uint32_t *total,
                                  hipStream_t s);

@@ -840,7 +840,7 @@ __device__ __forceinline__ Payload emit_load_payload(const MeshletCullParams &p,
     return *(has ? p.tile_payload + ((size_t)tile * kPayloadCap + j) : reinterpret_cast<const Payload *>(p.zero_page));
 }
 
-constexpr uint32_t kEmitChunkTable = 1024; // chunk bases kept in LDS (4 Mi tiles = 64 Mi dispatch records)
+constexpr uint32_t kEmitChunkTable = 1024; // chunk bases kept in LDS (1 Mi tiles = 16 Mi dispatch records)
 
 // Lane = survivor.  A tile with at most kPayloadCap survivors (the common case:
 // ~50 at 10 % survival) is one contiguous payload run written by meshlet_eval in
