@@ -10,6 +10,8 @@ use std::ffi::{c_char, c_void};
 
 #[repr(C)]
 pub struct OrbitCtx { _private: [u8; 0] }
+#[repr(C)]
+pub struct OrbitMeshletStream { _private: [u8; 0] }
 
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct OrbitCaps {
@@ -122,6 +124,15 @@ extern "C" {
                                          out_capacity: u32, stream: *mut c_void) -> i32;
     pub fn orbit_expand_visible(ctx: *mut OrbitCtx, visible_buffer: *const c_void, meshlet_buffer: *const c_void,
                                 draw_commands_buffer: *mut c_void, draw_capacity: u32, stream: *mut c_void) -> i32;
+    // derived meshlet streams: GpuAssets::add_mesh calls `update` for the range it wrote (assets/mod.rs:441-445),
+    // every cull context binds the stream once
+    pub fn orbit_meshlet_stream_create(ctx: *mut OrbitCtx, first_meshlet: u64, capacity: u64,
+                                       out_stream: *mut *mut OrbitMeshletStream) -> i32;
+    pub fn orbit_meshlet_stream_update(ctx: *mut OrbitCtx, ms: *mut OrbitMeshletStream, meshlet_buffer: *const c_void,
+                                       first: u64, count: u64, stream: *mut c_void) -> i32;
+    pub fn orbit_meshlet_stream_destroy(ms: *mut OrbitMeshletStream) -> i32;
+    pub fn orbit_ctx_bind_meshlet_stream(ctx: *mut OrbitCtx, ms: *const OrbitMeshletStream) -> i32;
+    pub fn orbit_ctx_meshlet_stream_culls(ctx: *const OrbitCtx) -> u64;
     // exchange without a host round trip: IPC-mapped peer buffers + a device-side rank-ordered scatter
     pub fn orbit_p2p_alloc(ctx: *mut OrbitCtx, bytes: u64, out_ptr: *mut *mut c_void, out_handle: *mut [u8; 64]) -> i32;
     pub fn orbit_p2p_free(ctx: *mut OrbitCtx, ptr: *mut c_void) -> i32;

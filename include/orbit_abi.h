@@ -484,6 +484,50 @@ typedef struct OrbitCullView {
 int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t count, void *stream);
 
 /* ------------------------------------------------------------------------ */
+/* Derived meshlet streams — an MI355X-side copy of the static meshlet       */
+/* buffer in the layout the cull streams best.                               */
+/*                                                                           */
+/* GpuAssets::add_mesh writes a mesh's Meshlet records into meshlet_buffer   */
+/* once (src/assets/mod.rs:441-445); every frame's meshlet cull then streams */
+/* all 32 B of every dispatched meshlet, although the decision reads 22 of   */
+/* them (bounding sphere, cone, material index) and only the ~10 % that      */
+/* survive need the rest (vertex_offset, data_offset, counts) for their      */
+/* command.  A stream object keeps four derived arrays for a range of the    */
+/* buffer: spheres (16 B), cones (4 B), material indices (2 B) and command   */
+/* words (12 B) — 34 B of HBM per meshlet on top of the buffer itself.       */
+/* With a stream bound to a context, orbit_meshlet_cull / _task_cull /       */
+/* _cull_visible calls whose bufs->meshlet_buffer is the pointer the stream  */
+/* was last updated from evaluate occlusion passes 0 and 2 from the 22-B     */
+/* arrays and write no survivor payload; the emit launch gathers the         */
+/* survivors' 12 B (nothing for the visible list), and orbit_expand_visible  */
+/* gathers 12 B instead of touching the survivors' Meshlets.  Results are    */
+/* bit-identical to the plain path (every test of tests/test_gpu_parity.py   */
+/* runs both ways).  Pass 1 (list-driven gathers), orbit_cull_views and any  */
+/* call with another meshlet_buffer pointer read the Meshlet buffer as       */
+/* before.                                                                   */
+/*                                                                           */
+/*   create   arrays for global meshlet indices [first_meshlet,              */
+/*            first_meshlet + capacity) (device memory: 34 B x capacity)     */
+/*   update   re-derives [first, first + count) from `meshlet_buffer` (same  */
+/*            global indexing as bufs->meshlet_buffer), enqueued on `stream`;*/
+/*            call it wherever the renderer writes meshlets (add_mesh) —     */
+/*            meshlets changed without an update are culled from stale data  */
+/*   bind     NULL unbinds; the stream must outlive the binding; one stream  */
+/*            can be bound to any number of contexts of its device           */
+/* ------------------------------------------------------------------------ */
+typedef struct OrbitMeshletStream OrbitMeshletStream;
+int32_t orbit_meshlet_stream_create(OrbitCtx *ctx, uint64_t first_meshlet, uint64_t capacity,
+                                    OrbitMeshletStream **out_stream);
+int32_t orbit_meshlet_stream_update(OrbitCtx *ctx, OrbitMeshletStream *ms, const void *meshlet_buffer,
+                                    uint64_t first, uint64_t count, void *stream);
+int32_t orbit_meshlet_stream_destroy(OrbitMeshletStream *ms);
+int32_t orbit_ctx_bind_meshlet_stream(OrbitCtx *ctx, const OrbitMeshletStream *ms);
+/* Calls this context has served from a bound stream so far — meshlet culls of passes 0 and 2 and
+ * orbit_expand_visible (tests and integration checks: a call whose meshlet_buffer is not the stream's source
+ * silently takes the plain path). */
+uint64_t orbit_ctx_meshlet_stream_culls(const OrbitCtx *ctx);
+
+/* ------------------------------------------------------------------------ */
 /* depth_reduce — replaces DepthPyramid::{new,resize,update}                 */
 /* (draw_gen.rs:456-566); device code restates shaders/depth_reduce.comp and */
 /* the ReduceMin sampler (src/graphics/device.rs:1404-1420).                 */

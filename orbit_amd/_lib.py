@@ -110,6 +110,12 @@ SYMBOLS = {
     "orbit_p2p_free": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "orbit_p2p_open": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "orbit_p2p_close": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "orbit_meshlet_stream_create": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "orbit_meshlet_stream_update": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                                C.c_void_p]),
+    "orbit_meshlet_stream_destroy": (C.c_int32, [C.c_void_p]),
+    "orbit_ctx_bind_meshlet_stream": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "orbit_ctx_meshlet_stream_culls": (C.c_uint64, [C.c_void_p]),
     "orbit_scatter_list": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                        C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
 }

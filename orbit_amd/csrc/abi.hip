@@ -20,6 +20,17 @@
 
 using namespace orbit;
 
+// orbit_meshlet_stream_*: derived arrays of meshlets [first, first + capacity) of the buffer at `source`
+struct OrbitMeshletStream {
+    int device = 0;
+    uint64_t first = 0, capacity = 0;
+    uint4 *sphere = nullptr;
+    uint32_t *cone = nullptr;
+    uint16_t *mat = nullptr;
+    uint32_t *cmd = nullptr;
+    const void *source = nullptr; // Meshlet buffer of the last update; nullptr = never updated
+};
+
 struct OrbitCtx {
     int device = 0;
     uint32_t num_cus = 0;
@@ -52,6 +63,8 @@ struct OrbitCtx {
     size_t prof_used = 0;
     // orbit_cull_views: child contexts (own scan scratch) for views 1.., created on first use
     std::vector<OrbitCtx *> view_ctx;
+    const OrbitMeshletStream *meshlet_stream = nullptr; // orbit_ctx_bind_meshlet_stream
+    uint64_t stream_culls = 0;                          // meshlet culls launched from it
     char err[512] = {0};
 };
 
@@ -455,6 +468,11 @@ int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCull
     p.ci = *ci;
     p.dispatch_buffer = (const uint8_t *)b->meshlet_dispatch_buffer;
     p.meshlets = (const OrbitMeshlet *)b->meshlet_buffer;
+    p.ms = MeshletStreamView{nullptr, nullptr, nullptr, nullptr};
+    if (const OrbitMeshletStream *ms = ctx->meshlet_stream; ms && ms->source == b->meshlet_buffer)
+        // arrays based at global meshlet index 0, like meshlet_buffer itself
+        p.ms = MeshletStreamView{ms->sphere - ms->first, ms->cone - ms->first, ms->mat - ms->first,
+                                 ms->cmd - 3u * ms->first};
     p.draw_buffer = (uint8_t *)(visible_path ? visible_buffer : b->draw_commands_buffer);
     p.entities = (const OrbitEntityData *)b->entity_buffer;
     p.materials = (const OrbitMaterialData *)b->material_buffer;
@@ -503,6 +521,7 @@ int32_t meshlet_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbit
     }
     hipError_t e = launch_meshlet_cull(p, ctx->num_cus, (hipStream_t)stream, ev0, ev1);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_cull");
+    if (p.ms.sphere && ci->occlusion_pass != 1) ctx->stream_culls++;
     return ORBIT_OK;
 }
 
@@ -556,6 +575,74 @@ int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t cou
     return ORBIT_OK;
 }
 
+int32_t orbit_meshlet_stream_create(OrbitCtx *ctx, uint64_t first_meshlet, uint64_t capacity,
+                                    OrbitMeshletStream **out_stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!out_stream) return fail(ctx, ORBIT_E_MISSING, "meshlet_stream_create: out_stream is NULL");
+    *out_stream = nullptr;
+    if (capacity == 0 || first_meshlet + capacity > 0x100000000ull) // meshlet indices are 32-bit (MeshletDispatch)
+        return fail(ctx, ORBIT_E_INVALID, "meshlet_stream_create: range [%llu, +%llu)", (unsigned long long)first_meshlet,
+                    (unsigned long long)capacity);
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipSetDevice");
+    OrbitMeshletStream *ms = new (std::nothrow) OrbitMeshletStream();
+    if (!ms) return fail(ctx, ORBIT_E_HIP, "out of host memory");
+    ms->device = ctx->device;
+    ms->first = first_meshlet;
+    ms->capacity = capacity;
+    e = hipMalloc((void **)&ms->sphere, capacity * sizeof(uint4));
+    if (e == hipSuccess) e = hipMalloc((void **)&ms->cone, capacity * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ms->mat, capacity * sizeof(uint16_t) + 256u);
+    if (e == hipSuccess) e = hipMalloc((void **)&ms->cmd, capacity * 12u);
+    if (e != hipSuccess) {
+        orbit_meshlet_stream_destroy(ms);
+        return hip_fail(ctx, e, "meshlet_stream_create: hipMalloc (36 B per meshlet)");
+    }
+    *out_stream = ms;
+    return ORBIT_OK;
+}
+
+int32_t orbit_meshlet_stream_update(OrbitCtx *ctx, OrbitMeshletStream *ms, const void *meshlet_buffer, uint64_t first,
+                                    uint64_t count, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ms || !meshlet_buffer) return fail(ctx, ORBIT_E_MISSING, "meshlet_stream_update: NULL argument");
+    if (ms->device != ctx->device) return fail(ctx, ORBIT_E_INVALID, "meshlet_stream_update: stream lives on device %d", ms->device);
+    if (first < ms->first || count > ms->capacity || first - ms->first > ms->capacity - count)
+        return fail(ctx, ORBIT_E_CAPACITY, "meshlet_stream_update: [%llu, +%llu) outside the stream's [%llu, +%llu)",
+                    (unsigned long long)first, (unsigned long long)count, (unsigned long long)ms->first,
+                    (unsigned long long)ms->capacity);
+    ms->source = meshlet_buffer;
+    const hipError_t e = launch_meshlet_stream_build((const OrbitMeshlet *)meshlet_buffer, first, count,
+                                                     ms->sphere - ms->first, ms->cone - ms->first,
+                                                     ms->mat - ms->first, ms->cmd - 3u * ms->first,
+                                                     (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_stream_build");
+    return ORBIT_OK;
+}
+
+int32_t orbit_meshlet_stream_destroy(OrbitMeshletStream *ms) {
+    if (!ms) return ORBIT_OK;
+    (void)hipFree(ms->sphere);
+    (void)hipFree(ms->cone);
+    (void)hipFree(ms->mat);
+    (void)hipFree(ms->cmd);
+    delete ms;
+    return ORBIT_OK;
+}
+
+int32_t orbit_ctx_bind_meshlet_stream(OrbitCtx *ctx, const OrbitMeshletStream *ms) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (ms && ms->device != ctx->device)
+        return fail(ctx, ORBIT_E_INVALID, "bind_meshlet_stream: stream lives on device %d", ms->device);
+    ctx->meshlet_stream = ms;
+    return ORBIT_OK;
+}
+
+uint64_t orbit_ctx_meshlet_stream_culls(const OrbitCtx *ctx) { return ctx ? ctx->stream_culls : 0; }
+
 int32_t orbit_meshlet_task_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
                                 OrbitMeshTaskRecord *task_records, void *stream) {
     return meshlet_cull_impl(ctx, ci, b, task_records, true, stream);
@@ -572,9 +659,13 @@ int32_t orbit_expand_visible(OrbitCtx *ctx, const void *visible_buffer, const vo
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (!visible_buffer || !meshlet_buffer || !draw_commands_buffer)
         return fail(ctx, ORBIT_E_MISSING, "expand_visible: NULL argument");
-    const hipError_t e = launch_visible_expand((const uint8_t *)visible_buffer, (const OrbitMeshlet *)meshlet_buffer,
+    // a bound stream that mirrors this meshlet buffer serves the survivors' command words (12-B gathers)
+    const OrbitMeshletStream *ms = ctx->meshlet_stream;
+    const uint32_t *cmd = (ms && ms->source == meshlet_buffer) ? ms->cmd - 3u * ms->first : nullptr;
+    const hipError_t e = launch_visible_expand((const uint8_t *)visible_buffer, (const OrbitMeshlet *)meshlet_buffer, cmd,
                                                (uint8_t *)draw_commands_buffer, draw_capacity, ctx->num_cus,
                                                ctx->zero_page, ctx->status, (hipStream_t)stream);
+    if (cmd) ctx->stream_culls++;
     if (e != hipSuccess) return hip_fail(ctx, e, "launch visible_expand");
     return ORBIT_OK;
 }

@@ -40,10 +40,22 @@ struct EntityCullParams {
     int32_t *status;
 };
 
+// Derived meshlet streams (orbit_meshlet_stream_*): the static 32-B Meshlet records re-laid out once, at upload, into
+// what the streaming evaluation reads for EVERY meshlet (bounding sphere; cone + the word with material index and
+// counts: 24 B) and what only a survivor's command needs (vertex_offset, data_offset, counts: 12 B, gathered by the
+// emit launch).  Pointers are based at global meshlet index 0; sphere == nullptr: no stream, evaluate the Meshlet buffer.
+struct MeshletStreamView {
+    const uint4 *sphere;  // Meshlet::bounding_sphere bits
+    const uint32_t *cone; // cone_axis | cone_cutoff << 24
+    const uint16_t *mat;  // material_index
+    const uint32_t *cmd;  // 3 words per meshlet: vertex_offset, data_offset, word 7 again
+};
+
 struct MeshletCullParams {
     OrbitGpuCullInfo ci;
     const uint8_t *dispatch_buffer;
     const OrbitMeshlet *meshlets;
+    MeshletStreamView ms;
     uint8_t *draw_buffer;
     const OrbitEntityData *entities;
     const OrbitMaterialData *materials;
@@ -151,9 +163,13 @@ hipError_t launch_meshlet_cull_views(const MeshletCullViews &all, uint32_t n, ui
 // Largest dispatch capacity launch_meshlet_cull accepts (the emit launch keeps one base per scan chunk in LDS);
 // checked by orbit_ctx_create against caps.max_dispatches, so no launch is ever enqueued for a larger one.
 uint32_t max_dispatch_capacity();
-hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, uint8_t *draw_buffer,
-                                 uint32_t draw_capacity, uint32_t num_cus, const void *zero_page, int32_t *status,
-                                 hipStream_t s);
+// meshlets[first, first + count) -> the three streams (a plain re-layout, one pass)
+hipError_t launch_meshlet_stream_build(const OrbitMeshlet *meshlets, uint64_t first, uint64_t count, uint4 *sphere,
+                                       uint32_t *cone, uint16_t *mat, uint32_t *cmd, hipStream_t s);
+// cmd_stream (optional): the derived command-word stream of `meshlets`, based at global meshlet index 0
+hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, const uint32_t *cmd_stream,
+                                 uint8_t *draw_buffer, uint32_t draw_capacity, uint32_t num_cus, const void *zero_page,
+                                 int32_t *status, hipStream_t s);
 struct ScatterListParams {
     const uint8_t *local_list;
     const uint32_t *counts;

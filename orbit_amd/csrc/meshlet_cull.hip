@@ -210,8 +210,9 @@ __device__ __forceinline__ MeshletVerdict eval_meshlet(const MeshletCullParams &
     return {visible, should_draw_of(visible, abits, visible_in_buffer, PASS == 2 && meshlet_occ)};
 }
 
-// Issues the meshlet loads of rows R0 .. R0+NR-1 of a tile (2 x 16 B per lane per row).
-template <int PASS, int R0, int NR>
+// Issues the meshlet loads of rows R0 .. R0+NR-1 of a tile (2 x 16 B per lane per row; STREAM: 16 + 8 B from the
+// derived streams — words y/z of `b`, which only a command needs, stay zero).
+template <int PASS, int R0, int NR, bool STREAM = false>
 __device__ __forceinline__ void rows_load(const MeshletCullParams &p, const WaveTileLds &L, int lane,
                                           RowRegs<NR> &t) {
     const bool meshlet_occ = p.ci.meshlet_visibility_buffer != ORBIT_NONE;
@@ -222,10 +223,17 @@ __device__ __forceinline__ void rows_load(const MeshletCullParams &p, const Wave
         const uint4 rec = L.rec[2 * (R0 + k) + half];
         // straight-line loads (exact vmcnt accounting): lanes past meshlet_count (:111) read the zero page
         const bool active = ml < rec.z;
-        const uint4 *src = active ? reinterpret_cast<const uint4 *>(p.meshlets + (rec.y + ml))
-                                  : reinterpret_cast<const uint4 *>(p.zero_page);
-        t.a[k] = src[0];
-        t.b[k] = src[1];
+        if constexpr (STREAM) {
+            t.a[k] = *(active ? p.ms.sphere + (rec.y + ml) : reinterpret_cast<const uint4 *>(p.zero_page));
+            const uint32_t c = *(active ? p.ms.cone + (rec.y + ml) : reinterpret_cast<const uint32_t *>(p.zero_page));
+            const uint16_t m = *(active ? p.ms.mat + (rec.y + ml) : reinterpret_cast<const uint16_t *>(p.zero_page));
+            t.b[k] = make_uint4(c, 0u, 0u, (uint32_t)m);
+        } else {
+            const uint4 *src = active ? reinterpret_cast<const uint4 *>(p.meshlets + (rec.y + ml))
+                                      : reinterpret_cast<const uint4 *>(p.zero_page);
+            t.a[k] = src[0];
+            t.b[k] = src[1];
+        }
         t.prev[k] = 0u;
         if (PASS != 0) { // word = visibility_offset + lane/32, :129-134
             const uint32_t *vp = (rw_vis && active) ? p.meshlet_visibility + rec.w
@@ -464,7 +472,7 @@ struct ViewGroup {
     uint8_t idx[ORBIT_MAX_CULL_VIEWS];
 };
 
-template <int PASS, int PROJ, bool PROF>
+template <int PASS, int PROJ, bool PROF, bool STREAM = false>
 __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
     __shared__ WaveTileLds lds[kEvWaves][3];
     __shared__ PlaneLds planes;
@@ -524,6 +532,7 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         w2 = ticket_tile(t2, 2u);
     }
     // two single-row register sets: while one row is evaluated the next row's loads are in flight
+    // (STREAM: a row is 1.4 KiB instead of 2 KiB; sets of two rows each were measured — neutral, profiles/r02_notes.md)
     RowRegs<1> qa, qb;
     uint4 rec2;
     {
@@ -534,8 +543,8 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         const float4 m1 = setup_load_mat(p, r1, lane);
         setup_write(p, lds[wave][0], r0, m0, lane);
         setup_write(p, lds[wave][1], r1, m1, lane);
-        rows_load<PASS, 0, 1>(p, lds[wave][0], lane, qa);
-        rows_load<PASS, 1, 1>(p, lds[wave][0], lane, qb);
+        rows_load<PASS, 0, 1, STREAM>(p, lds[wave][0], lane, qa);
+        rows_load<PASS, 1, 1, STREAM>(p, lds[wave][0], lane, qb);
     }
     uint32_t it = 0;
     unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1;
@@ -571,7 +580,8 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         tk_raw = claim();                                     // the tile after it
         WaveTileLds &L = lds[wave][it % 3];
         WaveTileLds &Ln = lds[wave][(it + 1) % 3]; // slab of an absent tile holds zero records
-        Payload *payload = p.task_records ? nullptr : p.tile_payload + (size_t)w0 * kPayloadCap;
+        // no payload with the derived streams: the emit launch gathers the survivors' command words itself
+        Payload *payload = (STREAM || p.task_records) ? nullptr : p.tile_payload + (size_t)w0 * kPayloadCap;
         CandState cs; // cs.total = the tile's running survivor count
 #define EV_ROW(R, Q)                                                                                        \
     if constexpr (PASS == 2) {                                                                              \
@@ -581,26 +591,26 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         cs.total = rows_eval<PASS, PROJ, true, R, 1>(p, L, planes, alpha, lane, Q, cs.total, payload);      \
     }
         EV_ROW(0, qa)
-        rows_load<PASS, 2, 1>(p, L, lane, qa);
+        rows_load<PASS, 2, 1, STREAM>(p, L, lane, qa);
         EV_ROW(1, qb)
-        rows_load<PASS, 3, 1>(p, L, lane, qb);
+        rows_load<PASS, 3, 1, STREAM>(p, L, lane, qb);
         EV_STAMP(0)
         EV_ROW(2, qa)
-        rows_load<PASS, 4, 1>(p, L, lane, qa);
+        rows_load<PASS, 4, 1, STREAM>(p, L, lane, qa);
         EV_ROW(3, qb)
-        rows_load<PASS, 5, 1>(p, L, lane, qb);
+        rows_load<PASS, 5, 1, STREAM>(p, L, lane, qb);
         const float4 mat2 = setup_load_mat(p, rec2, lane);
         const uint4 rec3 = setup_load_rec(p, w3, w3 < ntiles, nrec, lane);
         EV_STAMP(1)
         EV_ROW(4, qa)
-        rows_load<PASS, 6, 1>(p, L, lane, qa);
+        rows_load<PASS, 6, 1, STREAM>(p, L, lane, qa);
         EV_ROW(5, qb)
-        rows_load<PASS, 7, 1>(p, L, lane, qb);
+        rows_load<PASS, 7, 1, STREAM>(p, L, lane, qb);
         EV_STAMP(2)
         EV_ROW(6, qa)
-        rows_load<PASS, 0, 1>(p, Ln, lane, qa);
+        rows_load<PASS, 0, 1, STREAM>(p, Ln, lane, qa);
         EV_ROW(7, qb)
-        rows_load<PASS, 1, 1>(p, Ln, lane, qb);
+        rows_load<PASS, 1, 1, STREAM>(p, Ln, lane, qb);
         EV_STAMP(3)
         if constexpr (PASS == 2) {
             if (occ2) tile_finish_occ(p, L, cand_ring[wave], lane, cs, payload);
@@ -609,7 +619,7 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         setup_write(p, lds[wave][(it + 2) % 3], rec2, mat2, lane); // also fences the mask writes of this tile
         // the ballots are read back only by the task-record launch and, in the emit launch, for tiles with more
         // survivors than the payload holds: the common tile writes its count and nothing else
-        if ((p.task_records != nullptr || cs.total > kPayloadCap) && lane < 2 * (int)kTileRows)
+        if ((STREAM || p.task_records != nullptr || cs.total > kPayloadCap) && lane < 2 * (int)kTileRows)
             p.tile_masks[(size_t)w0 * (2 * kTileRows) + lane] = reinterpret_cast<const uint32_t *>(L.draw_mask)[lane];
         if (lane == 0) p.tile_counts[w0] = cs.total;
         EV_STAMP(4)
@@ -632,9 +642,9 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
     }
 }
 
-template <int PASS, int PROJ, bool PROF>
+template <int PASS, int PROJ, bool PROF, bool STREAM = false>
 __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_kernel(const MeshletCullParams p) {
-    meshlet_eval_body<PASS, PROJ, PROF>(p);
+    meshlet_eval_body<PASS, PROJ, PROF, STREAM>(p);
 }
 // several views in one launch (orbit_cull_views): the views' parameter blocks by value, blockIdx.y picks one
 template <int PASS, int PROJ>
@@ -817,8 +827,10 @@ __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_pass1_
 struct EmitTile {
     uint4 rec; // lanes 0..15: the tile's dispatch records
     uint32_t count, base;
+    uint32_t mword; // STREAM: lanes 0..15: the tile's should-draw ballots (every tile is rebuilt from them)
 };
 
+template <bool STREAM>
 __device__ __forceinline__ EmitTile emit_prefetch(const MeshletCullParams &p, uint32_t tile, uint32_t ntiles,
                                                   uint32_t nrec, int lane) {
     EmitTile e;
@@ -829,6 +841,10 @@ __device__ __forceinline__ EmitTile emit_prefetch(const MeshletCullParams &p, ui
     e.rec = *((tv && ri < nrec) ? recs + ri : reinterpret_cast<const uint4 *>(p.zero_page));
     e.count = tv ? p.tile_counts[t] : 0u;
     e.base = p.tile_base[t]; // exclusive prefix inside the tile's scan chunk
+    e.mword = 0u;
+    if constexpr (STREAM)
+        e.mword = *(tv ? p.tile_masks + ((size_t)t * (2 * kTileRows) + (lane & 15))
+                       : reinterpret_cast<const uint32_t *>(p.zero_page));
     return e;
 }
 
@@ -854,7 +870,9 @@ constexpr uint32_t kEmitChunkTable = 1024; // chunk bases kept in LDS (1 Mi tile
 // VISIBLE: instead of the 28-B commands the launch writes the compact visible list — 8 B per survivor
 // {meshlet_index, entity_index} after an 8-B {count, 0} header — which is what the sharded engine sends over
 // xGMI (visible_expand_kernel turns the gathered lists into commands on the receiving GPU).
-template <bool VISIBLE>
+// STREAM (derived meshlet streams): meshlet_eval kept no payload; every tile is rebuilt from its ballots and the
+// survivors' three command words are gathered from the 12-B command stream (nothing at all for the visible list).
+template <bool VISIBLE, bool STREAM = false>
 __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
     __shared__ uint16_t s_list[4][kTileRows * 64];
     __shared__ uint32_t s_cmd[4][64 * 7];
@@ -879,18 +897,20 @@ __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
     uint32_t *out = reinterpret_cast<uint32_t *>(p.draw_buffer + ORBIT_DRAW_HEADER);
     const uint32_t stride = gridDim.x * 4;
     uint32_t tile = blockIdx.x * 4 + wave;
-    EmitTile cur = emit_prefetch(p, tile, ntiles, nrec, lane);
-    EmitTile nxt = emit_prefetch(p, tile + stride, ntiles, nrec, lane);
-    Payload cur_pay = emit_load_payload(p, tile, cur.count, 0u, lane);
+    EmitTile cur = emit_prefetch<STREAM>(p, tile, ntiles, nrec, lane);
+    EmitTile nxt = emit_prefetch<STREAM>(p, tile + stride, ntiles, nrec, lane);
+    Payload cur_pay = Payload{0u, 0u, 0u};
+    if constexpr (!STREAM) cur_pay = emit_load_payload(p, tile, cur.count, 0u, lane);
     for (; tile < ntiles; tile += stride) {
-        const EmitTile nn = emit_prefetch(p, tile + 2 * stride, ntiles, nrec, lane);
-        const Payload nxt_pay = emit_load_payload(p, tile + stride, nxt.count, 0u, lane);
+        const EmitTile nn = emit_prefetch<STREAM>(p, tile + 2 * stride, ntiles, nrec, lane);
+        Payload nxt_pay = Payload{0u, 0u, 0u};
+        if constexpr (!STREAM) nxt_pay = emit_load_payload(p, tile + stride, nxt.count, 0u, lane);
         const uint32_t n = cur.count;
         if (n != 0u) { // wave-uniform
             const uint32_t base = cur.base + s_chunk_base[tile / kScanChunk];
-            const bool dense = n > kPayloadCap; // wave-uniform
+            const bool dense = STREAM || n > kPayloadCap; // wave-uniform
             if (dense) {
-                const uint32_t mword = p.tile_masks[(size_t)tile * (2 * kTileRows) + (lane & 15)];
+                const uint32_t mword = STREAM ? cur.mword : p.tile_masks[(size_t)tile * (2 * kTileRows) + (lane & 15)];
                 uint32_t row_base = 0;
 #pragma unroll
                 for (int r = 0; r < (int)kTileRows; r++) {
@@ -911,8 +931,19 @@ __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
                     const uint32_t code = j < n ? list[j] : 0u;
                     const uint32_t rid = (code >> 6) * 2u + ((code >> 5) & 1u); // record 2r + half
                     const uint32_t mi = (uint32_t)__shfl((int)cur.rec.y, (int)rid, 64) + (code & 31u);
-                    const uint4 b = *(j < n ? reinterpret_cast<const uint4 *>(p.meshlets + mi) + 1
-                                            : reinterpret_cast<const uint4 *>(p.zero_page));
+                    uint4 b = make_uint4(0u, 0u, 0u, 0u);
+                    if constexpr (STREAM) {
+                        if constexpr (!VISIBLE) { // the visible list carries indices only
+                            const uint32_t *c3 = j < n ? p.ms.cmd + (size_t)mi * 3u
+                                                       : reinterpret_cast<const uint32_t *>(p.zero_page);
+                            b.y = c3[0];
+                            b.z = c3[1];
+                            b.w = c3[2];
+                        }
+                    } else {
+                        b = *(j < n ? reinterpret_cast<const uint4 *>(p.meshlets + mi) + 1
+                                    : reinterpret_cast<const uint4 *>(p.zero_page));
+                    }
                     pay = make_payload(code & 31u, rid, b);
                 } else {
                     pay = j0 == 0u ? cur_pay : emit_load_payload(p, tile, n, j0, lane);
@@ -965,8 +996,10 @@ __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
     }
 }
 
-template <bool VISIBLE>
-__global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullParams p) { meshlet_emit_body<VISIBLE>(p); }
+template <bool VISIBLE, bool STREAM = false>
+__global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullParams p) {
+    meshlet_emit_body<VISIBLE, STREAM>(p);
+}
 __global__ __launch_bounds__(256) void meshlet_emit_views_kernel(const MeshletCullViews all) {
     meshlet_emit_body<false>(all.v[blockIdx.y]);
 }
@@ -991,15 +1024,25 @@ __device__ __forceinline__ ExpandChunk expand_load_items(const uint2 *items, uin
     return c;
 }
 
-__device__ __forceinline__ uint4 expand_gather(const OrbitMeshlet *meshlets, const ExpandChunk &c,
+// STREAM: the three command words come from the derived 12-B stream (`cmd`, orbit_meshlet_stream_*) instead of bytes
+// 16..31 of the Meshlet: a third of the lines per survivor.
+template <bool STREAM>
+__device__ __forceinline__ uint4 expand_gather(const OrbitMeshlet *meshlets, const uint32_t *cmd, const ExpandChunk &c,
                                                const void *zero_page) {
-    return *(c.valid ? reinterpret_cast<const uint4 *>(meshlets + c.item.x) + 1
-                     : reinterpret_cast<const uint4 *>(zero_page));
+    if constexpr (STREAM) {
+        const uint32_t *c3 = c.valid ? cmd + (size_t)c.item.x * 3u : reinterpret_cast<const uint32_t *>(zero_page);
+        return make_uint4(0u, c3[0], c3[1], c3[2]);
+    } else {
+        return *(c.valid ? reinterpret_cast<const uint4 *>(meshlets + c.item.x) + 1
+                         : reinterpret_cast<const uint4 *>(zero_page));
+    }
 }
 
+template <bool STREAM>
 __global__ __launch_bounds__(256) void visible_expand_kernel(const uint8_t *visible, const OrbitMeshlet *meshlets,
-                                                             uint8_t *draw_buffer, uint32_t draw_capacity,
-                                                             const void *zero_page, int32_t *status) {
+                                                             const uint32_t *cmd_stream, uint8_t *draw_buffer,
+                                                             uint32_t draw_capacity, const void *zero_page,
+                                                             int32_t *status) {
     __shared__ uint32_t s_cmd[4][64 * 7];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t *cmd = s_cmd[wave];
@@ -1012,10 +1055,10 @@ __global__ __launch_bounds__(256) void visible_expand_kernel(const uint8_t *visi
     uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 4u + wave) * 64u));
     ExpandChunk c0 = expand_load_items(items, first, n, lane, zero_page);
     ExpandChunk c1 = expand_load_items(items, first + stride, n, lane, zero_page);
-    uint4 b0 = expand_gather(meshlets, c0, zero_page);
+    uint4 b0 = expand_gather<STREAM>(meshlets, cmd_stream, c0, zero_page);
     for (; first < n; first += stride) {
         const ExpandChunk c2 = expand_load_items(items, first + 2u * stride, n, lane, zero_page);
-        const uint4 b1 = expand_gather(meshlets, c1, zero_page);
+        const uint4 b1 = expand_gather<STREAM>(meshlets, cmd_stream, c1, zero_page);
         uint32_t *c = cmd + lane * 7;
         c[0] = (b0.w >> 24) * 3u;                     // cmd_index_count = triangle_count * 3
         c[1] = 1u;                                    // cmd_instance_count
@@ -1083,6 +1126,23 @@ __global__ __launch_bounds__(256) void scatter_list_kernel(const ScatterListPara
     }
 }
 
+// orbit_meshlet_stream_update: Meshlet records -> the derived streams (thread = meshlet; 32 B read, 36 B written).
+__global__ __launch_bounds__(256) void meshlet_stream_build_kernel(const OrbitMeshlet *meshlets, uint64_t first,
+                                                                   uint64_t count, uint4 *sphere, uint32_t *cone,
+                                                                   uint16_t *mat, uint32_t *cmd) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256u) {
+        const uint64_t m = first + i;
+        const uint4 *src = reinterpret_cast<const uint4 *>(meshlets + m);
+        const uint4 a = src[0], b = src[1];
+        sphere[m] = a;
+        cone[m] = b.x;
+        mat[m] = (uint16_t)(b.w & 0xFFFFu);
+        cmd[m * 3u] = b.y;
+        cmd[m * 3u + 1u] = b.z;
+        cmd[m * 3u + 2u] = b.w;
+    }
+}
+
 // Mesh-shading path: one OrbitMeshTaskRecord per dispatch record from the record's should-draw ballot
 // (forward_depth_prepass.task:225-228,255-257).  Thread = record; the drawn lanes in ascending order.
 __global__ __launch_bounds__(256) void task_records_kernel(const MeshletCullParams p) {
@@ -1130,6 +1190,11 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t
             hipLaunchKernelGGL((meshlet_pass1_kernel<1>), grid, block, 0, s, p);
         else
             hipLaunchKernelGGL((meshlet_pass1_kernel<0>), grid, block, 0, s, p);
+    } else if (p.ms.sphere != nullptr) { // derived streams: 24 B per meshlet, no payload
+        if (ortho)
+            hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 1, false, true>), grid, block, 0, s, p);
+        else
+            hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 0, false, true>), grid, block, 0, s, p);
     } else if constexpr (PASS == 0) {
         if (p.debug_flags & 8u) { // phase-stamped build (tools/phase.py); | 16: only the per-wave wall-clock stamps
             if (ortho)
@@ -1166,10 +1231,14 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t
     const uint32_t eneed = (max_tiles + 3) / 4;
     if (eblocks > eneed) eblocks = eneed;
     if (eblocks == 0) eblocks = 1;
-    if (p.visible_list)
-        hipLaunchKernelGGL(meshlet_emit_kernel<true>, dim3(eblocks), dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL(meshlet_emit_kernel<false>, dim3(eblocks), dim3(256), 0, s, p);
+    const bool stream = PASS != 1 && p.ms.sphere != nullptr; // the list-driven pass 1 keeps its payload
+    if (p.visible_list) {
+        if (stream) hipLaunchKernelGGL((meshlet_emit_kernel<true, true>), dim3(eblocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((meshlet_emit_kernel<true, false>), dim3(eblocks), dim3(256), 0, s, p);
+    } else {
+        if (stream) hipLaunchKernelGGL((meshlet_emit_kernel<false, true>), dim3(eblocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((meshlet_emit_kernel<false, false>), dim3(eblocks), dim3(256), 0, s, p);
+    }
     return hipGetLastError();
 }
 
@@ -1239,20 +1308,34 @@ hipError_t launch_scatter_list(const ScatterListParams &p, uint32_t num_cus, hip
     return hipGetLastError();
 }
 
+hipError_t launch_meshlet_stream_build(const OrbitMeshlet *meshlets, uint64_t first, uint64_t count, uint4 *sphere,
+                                       uint32_t *cone, uint16_t *mat, uint32_t *cmd, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    const uint64_t need = (count + 255u) / 256u;
+    const uint32_t blocks = (uint32_t)(need < 8192u ? need : 8192u);
+    hipLaunchKernelGGL(meshlet_stream_build_kernel, dim3(blocks), dim3(256), 0, s, meshlets, first, count, sphere, cone,
+                       mat, cmd);
+    return hipGetLastError();
+}
+
 uint32_t max_dispatch_capacity() {
     const uint64_t cap = (uint64_t)kEmitChunkTable * kScanChunk * kTileRecords;
     return cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
 }
 
-hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, uint8_t *draw_buffer,
-                                 uint32_t draw_capacity, uint32_t num_cus, const void *zero_page, int32_t *status,
-                                 hipStream_t s) {
+hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, const uint32_t *cmd_stream,
+                                 uint8_t *draw_buffer, uint32_t draw_capacity, uint32_t num_cus, const void *zero_page,
+                                 int32_t *status, hipStream_t s) {
     uint32_t blocks = num_cus * 8u;
     const uint32_t need = (draw_capacity + 255u) / 256u;
     if (blocks > need) blocks = need;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(visible_expand_kernel, dim3(blocks), dim3(256), 0, s, visible, meshlets, draw_buffer,
-                       draw_capacity, zero_page, status);
+    if (cmd_stream)
+        hipLaunchKernelGGL(visible_expand_kernel<true>, dim3(blocks), dim3(256), 0, s, visible, meshlets, cmd_stream,
+                           draw_buffer, draw_capacity, zero_page, status);
+    else
+        hipLaunchKernelGGL(visible_expand_kernel<false>, dim3(blocks), dim3(256), 0, s, visible, meshlets, cmd_stream,
+                           draw_buffer, draw_capacity, zero_page, status);
     return hipGetLastError();
 }
 

@@ -49,6 +49,35 @@ def shard_range(entity_draw_count, rank, world):
     return b.value, e.value
 
 
+class MeshletStream:
+    """Handle of an OrbitMeshletStream (include/orbit_abi.h, "Derived meshlet streams")."""
+
+    def __init__(self, engine, meshlet_buffer, first, count, stream=None):
+        self._engine, self._lib = engine, engine._lib
+        self._h = C.c_void_p()
+        self.first, self.capacity = int(first), int(count)
+        _lib.check(self._lib.orbit_meshlet_stream_create(engine._ctx, self.first, self.capacity, C.byref(self._h)),
+                   engine._ctx)
+        self.update(meshlet_buffer, first, count, stream)
+
+    def update(self, meshlet_buffer, first=None, count=None, stream=None):
+        first = self.first if first is None else int(first)
+        count = self.capacity if count is None else int(count)
+        _lib.check(self._lib.orbit_meshlet_stream_update(self._engine._ctx, self._h, _ptr(meshlet_buffer), first, count,
+                                                         _stream(stream)), self._engine._ctx)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.orbit_meshlet_stream_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Engine:
     """One ``OrbitCtx``: scan scratch sized from ``caps`` on one gfx950 device."""
 
@@ -247,6 +276,21 @@ class Engine:
 
     def p2p_close(self, ptr):
         _lib.check(self._lib.orbit_p2p_close(self._ctx, C.c_void_p(ptr)), self._ctx)
+
+    def meshlet_stream(self, meshlet_buffer, first, count, stream=None):
+        """orbit_meshlet_stream_create + _update: the derived streams of meshlets [first, first + count) of
+        `meshlet_buffer` (a device pointer / tensor indexed by GLOBAL meshlet index, like bufs.meshlet_buffer).
+        Bind the result with bind_meshlet_stream; call .update() after writing meshlets."""
+        return MeshletStream(self, meshlet_buffer, first, count, stream)
+
+    def bind_meshlet_stream(self, ms):
+        """orbit_ctx_bind_meshlet_stream (None unbinds).  The engine keeps the stream object alive."""
+        _lib.check(self._lib.orbit_ctx_bind_meshlet_stream(self._ctx, ms._h if ms is not None else None), self._ctx)
+        self._meshlet_stream = ms
+
+    def meshlet_stream_culls(self):
+        """orbit_ctx_meshlet_stream_culls: meshlet culls launched from a bound stream so far."""
+        return int(self._lib.orbit_ctx_meshlet_stream_culls(self._ctx))
 
     def scatter_list(self, local_list, counts, rank, world, out_buffers, out_capacity, header_bytes, stride,
                      stream=None):

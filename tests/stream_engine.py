@@ -1,0 +1,37 @@
+"""Test helper: an Engine whose meshlet culls run from a derived meshlet stream (include/orbit_abi.h, "Derived meshlet
+streams").  The whole parity suite of tests/test_gpu_parity.py runs a second time through it, so every scenario
+there is also a bit-exactness check of the stream path against the oracle."""
+from orbit_amd.engine import Engine, _host_bytes
+
+
+class StreamEngine(Engine):
+    """Before every meshlet cull the stream of the call's meshlet buffer is (re)built and bound.  Rebuilt every time:
+    the caching allocator hands the same address to different test scenes."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._ms, self._ms_key = None, None
+
+    def meshlet_cull(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, *a, **kw):
+        if isinstance(meshlet_buffer, int):  # a shard under global indices: extent unknown here -> plain path
+            self.bind_meshlet_stream(None)
+        else:
+            count = meshlet_buffer.numel() * meshlet_buffer.element_size() // 32
+            key = (meshlet_buffer.data_ptr(), count)
+            if count == 0:
+                self.bind_meshlet_stream(None)
+            elif key != self._ms_key:
+                self.bind_meshlet_stream(None)
+                if self._ms is not None:
+                    self._ms.close()
+                self._ms, self._ms_key = self.meshlet_stream(meshlet_buffer, 0, count, kw.get("stream")), key
+                self.bind_meshlet_stream(self._ms)
+            else:
+                self._ms.update(meshlet_buffer, stream=kw.get("stream"))
+                self.bind_meshlet_stream(self._ms)
+        before = self.meshlet_stream_culls()
+        super().meshlet_cull(cull_info, meshlet_dispatch_buffer, meshlet_buffer, *a, **kw)
+        # the library must have taken the stream path wherever the header says it does (passes 0 and 2)
+        occlusion_pass = int(_host_bytes(cull_info, 400)[332:336].view("<u4")[0])
+        expect = self._ms is not None and not isinstance(meshlet_buffer, int) and count != 0 and occlusion_pass != 1
+        assert (self.meshlet_stream_culls() - before == 1) == expect, "stream path taken / not taken unexpectedly"

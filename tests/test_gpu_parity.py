@@ -19,10 +19,13 @@ def torch_mod():
     return torch
 
 
-@pytest.fixture(scope="module")
-def engine(torch_mod):
+# every test that takes `engine` runs twice: from the 32-B Meshlet buffer, and from the derived meshlet streams
+@pytest.fixture(scope="module", params=["meshlet_buffer", "meshlet_stream"])
+def engine(torch_mod, request):
     from orbit_amd.engine import Engine
+    from stream_engine import StreamEngine
 
+    Engine = StreamEngine if request.param == "meshlet_stream" else Engine
     e = Engine(0, max_entities=300_000, max_dispatches=2_000_000, max_draws=4_000_000, max_lights=12_000,
                max_clusters=240 * 135 * 32)
     yield e

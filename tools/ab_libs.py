@@ -24,6 +24,13 @@ disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device=
 draw = torch.zeros(L.DRAW_HEADER + 28 * draw_cap, dtype=torch.uint8, device=dev)
 engs = [Engine(0, _library=None if p is None else _lib.load_variant(os.path.abspath(p)), max_entities=E + 256,
                max_dispatches=disp_cap, max_draws=draw_cap) for p in paths]
+# STREAM=1: every engine culls from derived meshlet streams built by its own library; STREAM=odd / even: only the
+# engines at odd / even positions do (same library twice = the stream path against the Meshlet-buffer path)
+smode = os.environ.get("STREAM", "0")
+with_stream = [smode == "1" or (smode == "odd" and k % 2 == 1) or (smode == "even" and k % 2 == 0) for k in range(len(engs))]
+for eng, w in zip(engs, with_stream):
+    if w:
+        eng.bind_meshlet_stream(eng.meshlet_stream(meshlets, 0, E * M))
 ref = None
 for eng in engs:
     for _ in range(3):
@@ -50,5 +57,5 @@ for r in range(R):
         tf[k].append(a.elapsed_time(z)); tm[k].append(m.elapsed_time(z))
         te[k].append(eng.profile_read()[0]); eng.profile(True)
 for k, p in enumerate(paths):
-    print(f"{'product' if p is None else os.path.basename(p):24s} frame {np.median(tf[k]):.4f} ms   meshlet_cull {np.median(tm[k]):.4f}   "
+    print(f"{('product' if p is None else os.path.basename(p)) + (' +stream' if with_stream[k] else ''):24s} frame {np.median(tf[k]):.4f} ms   meshlet_cull {np.median(tm[k]):.4f}   "
           f"eval {np.median(te[k]):.4f}   rest of meshlet_cull {np.median(np.array(tm[k]) - np.array(te[k])):.4f}   entity_cull {np.median(np.array(tf[k]) - np.array(tm[k])):.4f}")
