@@ -325,6 +325,20 @@ def main():
 
     # one frame alone on an idle device (nothing else in flight): the latency a single cull costs, and its parts
     s0 = slots[0]
+    # the same frame from the 32-B Meshlet buffer (stream unbound), for the record: 5 frames alone, outside any metric
+    buffer_path_latency_ms = None
+    if mstream is not None and not do_gather:
+        s0.eng.bind_meshlet_stream(None)
+        lat = []
+        for _ in range(6):
+            a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(s0.stream)
+            cull(s0, 0)
+            z.record(s0.stream)
+            torch.cuda.synchronize()
+            lat.append(a.elapsed_time(z))
+        buffer_path_latency_ms = float(np.median(lat[1:]))
+        s0.eng.bind_meshlet_stream(mstream)
     serial, op_ms, x_ms, ex_ms = [], [], [], []
     last_recv = 0
     for _ in range(5):
@@ -414,10 +428,14 @@ def main():
     # B_m = 32 N_m + 16 N_d + 64 N_e + 28 N_draw + 4 for the whole op (occlusion_pass 0);
     # the eval launch carries the read side (32 N_m + 16 N_d + 64 N_e = 32.75 B per meshlet here), the emit
     # launch the 28 N_draw + 4 written bytes (DESIGN.md "Algorithmic bytes").
-    alg_bytes = 32 * n_in + 16 * n_rec + 64 * n_local_entities
+    # From the derived meshlet streams the evaluation reads 22 B per meshlet (sphere 16, cone 4, material index 2)
+    # instead of the 32-B Meshlet, and the emit launch gathers 12 B of command words per survivor.
+    per_meshlet = 22 if mstream is not None else 32
+    alg_bytes = per_meshlet * n_in + 16 * n_rec + 64 * n_local_entities
     achieved = alg_bytes / (eval_ms * 1e-3) / 1e9
-    op_bytes = alg_bytes + 28 * n_draw + 4
-    traffic = load_traffic(E, M) if world == 1 else None  # the PMC passes were taken on the whole scene at N=1
+    op_bytes = alg_bytes + ((12 if mstream is not None and not visible_exchange else 0) + item) * n_draw + 4
+    # the PMC passes were taken on the whole scene at N=1
+    traffic = load_traffic(E, M, args.meshlet_source) if world == 1 else None
 
     # Box reference (not part of any metric): what a plain streaming read of the same bytes reaches on THIS box right
     # now.  Boxes of the pool differ by up to 30 % (profiles/r01_notes.md, "Measurement hygiene"); the ratio below is
@@ -467,19 +485,25 @@ def main():
                 "sharding": f"entity ranges over {world} rank(s)", "gather": bool(do_gather),
                 "frames_in_flight": F,
                 "exchange": (args.exchange if do_gather else None), "transport": transport,
+                "meshlet_source": (f"derived meshlet streams (22 B per meshlet evaluated, 12 B per survivor gathered; "
+                                   f"built once from the meshlet buffer before the timed region in "
+                                   f"{mstream_build_ms:.2f} ms, +34 B of HBM per meshlet)" if mstream is not None
+                                   else "the 32-B Meshlet buffer"),
             },
             "roofline": {
                 "bound": "hbm", "kernel": "meshlet_eval_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": ("profiles/traffic.json (rocprofv3 --pmc passes of an earlier run of this workload, "
+                "traffic_source": (f"profiles/{traffic_file(args.meshlet_source)} (rocprofv3 --pmc passes of an earlier run of this workload, "
                                    "tools/traffic.sh; not measured in this run)" if traffic is not None else None),
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": eval_ms, "launches_timed": eval_launches,
+                "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_meshlet": per_meshlet,
+                "avg_launch_ms": eval_ms, "launches_timed": eval_launches,
                 "box_stream_reference": stream_ref,
                 "op": {"name": "meshlet_cull (eval + scan + emit)", "algorithmic_bytes": op_bytes,
                        "avg_ms": kernel_ms, "achieved": op_bytes / (kernel_ms * 1e-3) / 1e9},
             },
             "cpu_baseline": cpu_baseline,
             "frame_latency_ms": frame_latency_ms,
+            "frame_latency_ms_from_meshlet_buffer": buffer_path_latency_ms,
             "per_rank": {"cull_ms_max": kernel_ms_max_frame, "exchange_ms_max": exchange_ms_max,
                          "expand_ms_max": expand_ms_max,
                          "what": "one frame alone on each rank's device: entity_cull + meshlet_cull of its shard, the "
@@ -519,10 +543,15 @@ def dry_ranks(args, rank, world, json_fd):
         dist.destroy_process_group()
 
 
-def load_traffic(entities, meshlets_per_entity):
+def traffic_file(meshlet_source):
+    return "traffic.json" if meshlet_source == "buffer" else "traffic_stream.json"
+
+
+def load_traffic(entities, meshlets_per_entity, meshlet_source):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/traffic.json, written by tools/traffic.py); None when absent or for another workload."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+    (profiles/traffic.json — Meshlet buffer — or profiles/traffic_stream.json — derived streams — written by
+    tools/traffic.py); None when absent or for another workload."""
+    path = os.path.join(ROOT, "profiles", traffic_file(meshlet_source))
     try:
         with open(path) as f:
             t = json.load(f)

@@ -40,7 +40,7 @@ def popcount32(torch, words):
 class Frame:
     """Device buffers of one config-5 scene and the launches over them."""
 
-    def __init__(self, torch, entities):
+    def __init__(self, torch, entities, meshlet_stream=False):
         from orbit_amd import synth
         from orbit_amd.engine import Engine
 
@@ -54,6 +54,8 @@ class Frame:
         self.disp_cap = E * spec.records_per_entity + 8
         self.draw_cap = E * M // 2 + 1024
         self.eng = Engine(0, max_entities=E + 256, max_dispatches=self.disp_cap, max_draws=self.draw_cap)
+        if meshlet_stream:  # passes 0 and 2 cull from the derived meshlet streams (include/orbit_abi.h)
+            self.eng.bind_meshlet_stream(self.eng.meshlet_stream(self.meshlets, 0, E * M))
         self.cam = sc.default_camera(position=(0.0, 0.0, 1300.0))
         self.evis = torch.zeros((E + 31) // 32, dtype=torch.int32, device=dev)
         self.mvis = torch.zeros(E * spec.vis_words_per_entity, dtype=torch.int32, device=dev)
@@ -97,10 +99,15 @@ class Frame:
         self.eng.close()
 
 
+SOURCES = [False, True]
+SOURCE_IDS = ["meshlet_buffer", "meshlet_stream"]
+
+
+@pytest.mark.parametrize("meshlet_stream", SOURCES, ids=SOURCE_IDS)
 @pytest.mark.parametrize("entities", [3000, 195_313])
-def test_config5_properties(torch_mod, oracle, entities):
+def test_config5_properties(torch_mod, oracle, entities, meshlet_stream):
     torch = torch_mod
-    f = Frame(torch, entities)
+    f = Frame(torch, entities, meshlet_stream)
     try:
         E, M = f.spec.entities, f.spec.meshlets_per_entity
         # P1 determinism
@@ -143,11 +150,13 @@ def test_config5_properties(torch_mod, oracle, entities):
             _, _, c = f.cull(0, first=b, count=e - b)
             parts.append(c.clone())
         assert torch.equal(torch.cat(parts), cmds)
+        assert (f.eng.meshlet_stream_culls() > 0) == meshlet_stream
     finally:
         f.close()
 
 
-def test_config5_two_pass_frame_against_the_oracle(torch_mod, oracle):
+@pytest.mark.parametrize("meshlet_stream", SOURCES, ids=SOURCE_IDS)
+def test_config5_two_pass_frame_against_the_oracle(torch_mod, oracle, meshlet_stream):
     """Config 5 at its full size through the two-pass HiZ frame, bit-exact against the oracle (run on all host cores,
     oracle/orbit_oracle_mt.c): steady-state frame = pass-1 cull from last frame's bits, depth_reduce of a 1080p
     depth buffer (a wall 950 m in front of the camera over 60 % of the screen), pass-2 cull.  Compared: the
@@ -155,7 +164,7 @@ def test_config5_two_pass_frame_against_the_oracle(torch_mod, oracle):
     torch = torch_mod
     from orbit_amd.engine import depth_pyramid_desc
 
-    f = Frame(torch, 195_313)
+    f = Frame(torch, 195_313, meshlet_stream)
     try:
         E, M = f.spec.entities, f.spec.meshlets_per_entity
         cam, dev = f.cam, torch.device("cuda", 0)
@@ -212,5 +221,6 @@ def test_config5_two_pass_frame_against_the_oracle(torch_mod, oracle):
             "pass-2 draws differ"
         assert np.array_equal(h(f.evis).view(np.uint32), oe2), "entity visibility differs"
         assert np.array_equal(h(f.mvis).view(np.uint32), om2), "meshlet visibility differs"
+        assert f.eng.meshlet_stream_culls() == (3 if meshlet_stream else 0)  # the three pass-2 culls
     finally:
         f.close()

@@ -1,0 +1,184 @@
+"""GPU tests of the derived meshlet streams' own surface (include/orbit_abi.h, "Derived meshlet streams").  That the
+stream path computes the same bits as the Meshlet-buffer path is covered by tests/test_gpu_parity.py, whose whole suite
+runs a second time through tests/stream_engine.py; here: ranges under global indices, partial updates, stale data,
+which calls take the path, argument errors."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import scenes as sc
+from orbit_amd import _lib, layouts as L
+from test_gpu_parity import GpuScene, assert_same, dev, host, run_gpu, run_oracle, torch_mod  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def engine(torch_mod):
+    from orbit_amd.engine import Engine
+
+    e = Engine(0, max_entities=50_000, max_dispatches=400_000, max_draws=1_000_000)
+    yield e
+    e.close()
+
+
+def _scene(seed=31, n=900):
+    scene = sc.make_scene(seed, n, meshlets_per_mesh=(3, 60), lods=2)
+    cam = sc.default_camera(rot=(0.1, 0.3))
+    return scene, sc.make_cull_info(cam.view, cam.planes)
+
+
+def test_bound_stream_serves_passes_0_and_2_and_is_bit_identical(torch_mod, engine, oracle):
+    torch = torch_mod
+    scene, ci = _scene()
+    gs = GpuScene(torch, scene)
+    ref = run_oracle(oracle, scene, ci)
+    plain = run_gpu(torch, engine, gs, ci)
+    assert engine.meshlet_stream_culls() == 0
+    ms = engine.meshlet_stream(gs.meshlets, 0, len(scene.meshlets))
+    engine.bind_meshlet_stream(ms)
+    got = run_gpu(torch, engine, gs, ci)
+    assert engine.meshlet_stream_culls() == 1
+    assert_same(got, ref)
+    assert np.array_equal(got[1], plain[1])
+    # LDS alpha table instead of the material gather
+    got = run_gpu(torch, engine, gs, ci, material_count=len(scene.materials))
+    assert engine.meshlet_stream_culls() == 2
+    assert_same(got, ref)
+    # another meshlet buffer (a copy at another address): the plain path, silently, same result
+    other = GpuScene(torch, scene)
+    got = run_gpu(torch, engine, other, ci)
+    assert engine.meshlet_stream_culls() == 2
+    assert_same(got, ref)
+    engine.bind_meshlet_stream(None)
+    run_gpu(torch, engine, gs, ci)
+    assert engine.meshlet_stream_culls() == 2
+    ms.close()
+
+
+def test_stale_stream_culls_stale_data_until_updated(torch_mod, engine, oracle):
+    """The contract of `update`: the stream is a copy.  Meshlets rewritten in place are culled from the old bytes
+    until orbit_meshlet_stream_update re-derives them (a partial range suffices)."""
+    torch = torch_mod
+    scene, ci = _scene(seed=37, n=400)
+    gs = GpuScene(torch, scene)
+    ms = engine.meshlet_stream(gs.meshlets, 0, len(scene.meshlets))
+    engine.bind_meshlet_stream(ms)
+    before = run_gpu(torch, engine, gs, ci)
+    assert_same(before, run_oracle(oracle, scene, ci))
+    # move the first third of the meshlets far behind the camera, in place (same device address)
+    k = len(scene.meshlets) // 3
+    scene.meshlets["bounding_sphere"][:k, :3] += np.float32(1.0e6)
+    gs.meshlets.copy_(dev(torch, scene.meshlets))
+    stale = run_gpu(torch, engine, gs, ci)
+    assert np.array_equal(stale[1], before[1]), "a stale stream must keep answering from its copy"
+    ms.update(gs.meshlets, 0, k)  # only the rewritten range
+    fresh = run_gpu(torch, engine, gs, ci)
+    ref = run_oracle(oracle, scene, ci)
+    assert_same(fresh, ref)
+    assert L.draw_buffer_commands(fresh[1])[0] < L.draw_buffer_commands(before[1])[0]
+    ms.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shard_streams_under_global_indices(torch_mod, engine, oracle, world):
+    """A rank of the sharded engine holds only its meshlet shard, passed under global indices through a shifted base
+    pointer; its stream covers [first_meshlet, first_meshlet + count) of that virtual buffer."""
+    from orbit_amd.dist import shard_ranges
+
+    torch = torch_mod
+    scene = sc.make_scene(23, 700, meshlets_per_mesh=(8, 40), shuffle=False)
+    cam = sc.default_camera()
+    ci = sc.make_cull_info(cam.view, cam.planes)
+    gs = GpuScene(torch, scene)
+    on, ocmds = L.draw_buffer_commands(run_oracle(oracle, scene, ci)[1])
+    lod0 = scene.mesh_infos["mesh_lods"][:, 0]
+    parts, served = [], 0
+    for b, e in shard_ranges(scene.entity_draw_count, world):
+        m0 = int(lod0[b, 0])
+        m1 = int(lod0[e - 1, 0] + lod0[e - 1, 1])
+        shard = dev(torch, scene.meshlets[m0:m1])
+        base = shard.data_ptr() - m0 * 32
+        ms = engine.meshlet_stream(base, m0, m1 - m0)
+        engine.bind_meshlet_stream(ms)
+        cap_d, cap_c = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
+        disp = torch.zeros(L.DISPATCH_HEADER + 16 * cap_d, dtype=torch.uint8, device="cuda")
+        draw = torch.zeros(L.DRAW_HEADER + 28 * cap_c, dtype=torch.uint8, device="cuda")
+        engine.entity_cull(ci, gs.draws, gs.mesh_infos, disp, gs.entities, e - b, cap_d, draw_first=b)
+        engine.meshlet_cull(ci, disp, base, draw, gs.entities, gs.materials, cap_d, cap_c)
+        torch.cuda.synchronize()
+        served += 1
+        assert engine.meshlet_stream_culls() == served
+        parts.append(L.draw_buffer_commands(host(draw))[1])
+        engine.bind_meshlet_stream(None)
+        ms.close()
+    got = np.concatenate(parts)
+    assert len(got) == on and np.array_equal(got.view(np.uint32), ocmds.view(np.uint32))
+
+
+def test_visible_list_and_expansion_from_the_stream(torch_mod, engine, oracle):
+    torch = torch_mod
+    scene, ci = _scene(seed=41, n=600)
+    gs = GpuScene(torch, scene)
+    on, ocmds = L.draw_buffer_commands(run_oracle(oracle, scene, ci)[1])
+    ms = engine.meshlet_stream(gs.meshlets, 0, len(scene.meshlets))
+    engine.bind_meshlet_stream(ms)
+    cap_d, cap_c = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
+    disp = torch.zeros(L.DISPATCH_HEADER + 16 * cap_d, dtype=torch.uint8, device="cuda")
+    vis = torch.full((L.VISIBLE_HEADER + 8 * cap_c + 64,), 0xCD, dtype=torch.uint8, device="cuda")
+    draw = torch.full((L.DRAW_HEADER + 28 * cap_c + 64,), 0xCD, dtype=torch.uint8, device="cuda")
+    engine.entity_cull(ci, gs.draws, gs.mesh_infos, disp, gs.entities, scene.entity_draw_count, cap_d)
+    engine.meshlet_cull_visible(ci, disp, gs.meshlets, vis, gs.entities, gs.materials, cap_d, cap_c)
+    engine.expand_visible(vis, gs.meshlets, draw, cap_c)
+    torch.cuda.synchronize()
+    engine.status()
+    assert engine.meshlet_stream_culls() == 2  # the cull and the expansion
+    n, cmds = L.draw_buffer_commands(host(draw))
+    assert n == on and np.array_equal(cmds.view(np.uint32), ocmds.view(np.uint32))
+    assert bool((host(draw)[4 + 28 * on:] == 0xCD).all())
+    ms.close()
+
+
+def test_pass1_keeps_reading_the_meshlet_buffer(torch_mod, engine, oracle):
+    torch = torch_mod
+    scene, _ = _scene(seed=43, n=500)
+    gs = GpuScene(torch, scene)
+    ms = engine.meshlet_stream(gs.meshlets, 0, len(scene.meshlets))
+    engine.bind_meshlet_stream(ms)
+    cam = sc.default_camera(rot=(0.1, 0.3))
+    evis = np.full((scene.entity_draw_count + 31) // 32, 0xFFFFFFFF, np.uint32)
+    mvis = np.full(scene.vis_words, 0x55555555, np.uint32)
+    ci1 = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=1)
+    got = run_gpu(torch, engine, gs, ci1, evis=evis, mvis=mvis)
+    assert engine.meshlet_stream_culls() == 0
+    assert_same(got, run_oracle(oracle, scene, ci1, evis=evis, mvis=mvis))
+    ms.close()
+
+
+def test_stream_argument_errors(torch_mod, engine):
+    torch = torch_mod
+    lib = engine._lib
+    h = C.c_void_p()
+    buf = torch.zeros(32 * 100, dtype=torch.uint8, device="cuda")
+    assert lib.orbit_meshlet_stream_create(None, 0, 10, C.byref(h)) == _lib.E_INVALID
+    assert lib.orbit_meshlet_stream_create(engine._ctx, 0, 10, None) == _lib.E_MISSING
+    assert lib.orbit_meshlet_stream_create(engine._ctx, 0, 0, C.byref(h)) == _lib.E_INVALID and not h.value
+    assert lib.orbit_meshlet_stream_create(engine._ctx, 2**32 - 5, 10, C.byref(h)) == _lib.E_INVALID  # 32-bit indices
+    assert lib.orbit_meshlet_stream_create(engine._ctx, 50, 100, C.byref(h)) == _lib.OK and h.value
+    p = C.c_void_p(buf.data_ptr() - 50 * 32)
+    assert lib.orbit_meshlet_stream_update(engine._ctx, None, p, 50, 100, None) == _lib.E_MISSING
+    assert lib.orbit_meshlet_stream_update(engine._ctx, h, None, 50, 100, None) == _lib.E_MISSING
+    assert lib.orbit_meshlet_stream_update(engine._ctx, h, p, 49, 10, None) == _lib.E_CAPACITY
+    assert lib.orbit_meshlet_stream_update(engine._ctx, h, p, 50, 101, None) == _lib.E_CAPACITY
+    assert lib.orbit_meshlet_stream_update(engine._ctx, h, p, 140, 11, None) == _lib.E_CAPACITY
+    assert b"outside the stream" in lib.orbit_last_error(engine._ctx)
+    assert lib.orbit_meshlet_stream_update(engine._ctx, h, p, 140, 10, None) == _lib.OK
+    assert lib.orbit_meshlet_stream_update(engine._ctx, h, p, 50, 0, None) == _lib.OK  # empty range: nothing enqueued
+    assert lib.orbit_ctx_bind_meshlet_stream(None, h) == _lib.E_INVALID
+    assert lib.orbit_ctx_bind_meshlet_stream(engine._ctx, h) == _lib.OK
+    assert lib.orbit_ctx_bind_meshlet_stream(engine._ctx, None) == _lib.OK
+    assert lib.orbit_ctx_meshlet_stream_culls(None) == 0
+    torch.cuda.synchronize()
+    assert lib.orbit_meshlet_stream_destroy(h) == _lib.OK
+    assert lib.orbit_meshlet_stream_destroy(None) == _lib.OK

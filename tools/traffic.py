@@ -5,7 +5,8 @@ Corrections follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: the counters ar
 streaming read (16 B per lane), so the read side is doubled; WRITE_SIZE is exact for
 16-B-per-lane streaming stores (other widths uncalibrated: stated in the output).
 
-usage: python tools/traffic.py <fetch_counter_csv> <write_counter_csv> <entities> <meshlets_per_entity>
+usage: python tools/traffic.py <fetch_counter_csv> <write_counter_csv> <entities> <meshlets_per_entity> [stream|buffer]
+-> gpurun_out/traffic.json (buffer) or gpurun_out/traffic_stream.json (stream: the derived meshlet streams)
 """
 import collections
 import csv
@@ -25,11 +26,13 @@ def mean_per_kernel(path, counter):
 
 def main():
     fetch_csv, write_csv, entities, mpe = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    source = sys.argv[5] if len(sys.argv) > 5 else "buffer"
     fetch = mean_per_kernel(fetch_csv, "FETCH_SIZE")
     write = mean_per_kernel(write_csv, "WRITE_SIZE")
-    out = {"entities": entities, "meshlets_per_entity": mpe, "kernels": {},
-           "corrections": "KiB -> bytes (x1024); FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B); "
-                          "WRITE_SIZE as reported"}
+    out = {"entities": entities, "meshlets_per_entity": mpe, "meshlet_source": source, "kernels": {},
+           "corrections": "KiB -> bytes (x1024); FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B; calibrated "
+                          "on wide streaming reads only — the x2 of a kernel that gathers, like the stream path's "
+                          "meshlet_emit, is an upper bound); WRITE_SIZE as reported"}
     for k in sorted(fetch):
         if "orbit" not in k:
             continue
@@ -43,7 +46,7 @@ def main():
     out["dominant_kernel"] = "meshlet_eval_kernel"
     out["hbm_bytes_per_launch"] = dom["hbm_bytes"] if dom else None
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "gpurun_out", "traffic.json"), "w") as f:
+    with open(os.path.join(root, "gpurun_out", "traffic.json" if source == "buffer" else "traffic_stream.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
 
