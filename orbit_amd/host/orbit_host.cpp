@@ -226,7 +226,24 @@ Context::Context(int device, void *stream, const OrbitCaps *caps) : stream_(stre
 }
 Context::~Context() {
     for (auto &kv : transients_) (void)hipFree(kv.second.ptr);
+    orbit_ctx_bind_meshlet_stream(ctx_, nullptr);
+    orbit_meshlet_stream_destroy(meshlet_stream_);
     orbit_ctx_destroy(ctx_);
+}
+void Context::sync_meshlet_stream(const GraphBufferHandle &meshlet_buffer, uint64_t first, uint64_t count,
+                                  uint64_t capacity) {
+    if (!meshlet_buffer.valid()) throw Panic("sync_meshlet_stream: no meshlet buffer");
+    if (meshlet_stream_ && capacity > meshlet_stream_capacity_) { // the asset buffer was re-created larger
+        check(orbit_ctx_bind_meshlet_stream(ctx_, nullptr));
+        orbit_meshlet_stream_destroy(meshlet_stream_);
+        meshlet_stream_ = nullptr;
+    }
+    if (!meshlet_stream_) {
+        check(orbit_meshlet_stream_create(ctx_, 0, capacity, &meshlet_stream_));
+        meshlet_stream_capacity_ = capacity;
+    }
+    check(orbit_meshlet_stream_update(ctx_, meshlet_stream_, meshlet_buffer.ptr, first, count, stream_));
+    check(orbit_ctx_bind_meshlet_stream(ctx_, meshlet_stream_));
 }
 GraphBufferHandle Context::create_transient(const std::string &name, size_t size) {
     auto it = transients_.find(name);

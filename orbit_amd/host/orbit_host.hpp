@@ -99,12 +99,20 @@ class Context {
     ~Context();
     Context(const Context &) = delete;
     GraphBufferHandle create_transient(const std::string &name, size_t size);
+    // Derived meshlet streams (include/orbit_abi.h): what GpuAssets::add_mesh calls right after
+    // queue_write_buffer(&self.meshlet_buffer, ..) (assets/mod.rs:441-445) for the range it wrote.  The stream is
+    // created on first use for `capacity` meshlets (the size of meshlet_buffer, MAX_MESHLET_COUNT, assets/mod.rs:202,272-276), re-derived for
+    // [first, first + count) on this context's stream and bound; culls of passes 0 and 2 then read it.
+    void sync_meshlet_stream(const GraphBufferHandle &meshlet_buffer, uint64_t first, uint64_t count,
+                             uint64_t capacity);
     OrbitCtx *abi() const { return ctx_; }
     void *stream() const { return stream_; }
     void check(int32_t rc) const; // non-zero status -> Panic with orbit_last_error
 
   private:
     OrbitCtx *ctx_ = nullptr;
+    OrbitMeshletStream *meshlet_stream_ = nullptr;
+    uint64_t meshlet_stream_capacity_ = 0;
     void *stream_ = nullptr;
     std::map<std::string, GraphBufferHandle> transients_;
 };

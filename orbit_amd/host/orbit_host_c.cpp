@@ -220,6 +220,16 @@ void *orbit_host_context_create(int32_t device, void *stream, const OrbitCaps *c
 }
 void orbit_host_context_destroy(void *hctx) { delete (HostCtx *)hctx; }
 
+int32_t orbit_host_sync_meshlet_stream(void *hctx, void *meshlet_buffer, uint64_t first, uint64_t count,
+                                       uint64_t capacity) {
+    return guarded([&] {
+        graphics::GraphBufferHandle h;
+        h.ptr = meshlet_buffer;
+        h.size = (size_t)capacity * sizeof(OrbitMeshlet);
+        ((HostCtx *)hctx)->ctx->sync_meshlet_stream(h, first, count, capacity);
+    });
+}
+
 int32_t orbit_host_create_meshlet_dispatch_command(void *hctx, const char *name, const OrbitHostAssets *assets,
                                                    const OrbitHostScene *scene, const OrbitHostCullInfo *ci,
                                                    OrbitGpuCullInfo *out_cull_info, OrbitHostBuffer *out_dispatch) {

@@ -99,6 +99,9 @@ void orbit_host_compute_cluster_aabb(const float inverse_projection[16], const f
 /* graphics::Context slice + passes (need a GPU) */
 void *orbit_host_context_create(int32_t device, void *stream, const OrbitCaps *caps);
 void orbit_host_context_destroy(void *hctx);
+/* Context::sync_meshlet_stream: derived meshlet streams of meshlets [first, first + count) re-derived and bound */
+int32_t orbit_host_sync_meshlet_stream(void *hctx, void *meshlet_buffer, uint64_t first, uint64_t count,
+                                       uint64_t capacity);
 int32_t orbit_host_create_meshlet_dispatch_command(void *hctx, const char *name, const OrbitHostAssets *assets,
                                                    const OrbitHostScene *scene, const OrbitHostCullInfo *ci,
                                                    OrbitGpuCullInfo *out_cull_info, OrbitHostBuffer *out_dispatch);

@@ -104,6 +104,8 @@ def lib():
         h.orbit_host_context_create.restype = C.c_void_p
         h.orbit_host_context_create.argtypes = [C.c_int32, C.c_void_p, C.c_void_p]
         h.orbit_host_context_destroy.argtypes = [C.c_void_p]
+        h.orbit_host_sync_meshlet_stream.restype = C.c_int32
+        h.orbit_host_sync_meshlet_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
         _host = h
     return _host
 
@@ -256,6 +258,11 @@ class Context:
         self._h = lib().orbit_host_context_create(device, C.c_void_p(s.cuda_stream), C.byref(c))
         if not self._h:
             raise Panic(lib().orbit_host_last_error().decode())
+
+    def sync_meshlet_stream(self, meshlet_buffer, first, count, capacity=None):
+        """Context::sync_meshlet_stream (orbit_host.hpp): the add_mesh-side hook of the derived meshlet streams."""
+        cap = (meshlet_buffer.numel() * meshlet_buffer.element_size() // 32) if capacity is None else capacity
+        _check(lib().orbit_host_sync_meshlet_stream(C.c_void_p(self._h), _dptr(meshlet_buffer), first, count, cap))
 
     def close(self):
         if self._h:

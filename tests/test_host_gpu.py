@@ -26,7 +26,8 @@ def fetch(buf, nbytes):
     return passes.buffer_tensor(buf)[:nbytes].cpu().numpy()
 
 
-def test_frame_sequence_through_host_api(torch_mod, oracle):
+@pytest.mark.parametrize("meshlet_stream", [False, True], ids=["meshlet_buffer", "meshlet_stream"])
+def test_frame_sequence_through_host_api(torch_mod, oracle, meshlet_stream):
     torch = torch_mod
     W, H = 640, 360
     scene = sc.make_scene(41, 1500, n_meshes=200, extent=(50.0, 10.0, 50.0))
@@ -34,6 +35,8 @@ def test_frame_sequence_through_host_api(torch_mod, oracle):
     ctx = passes.Context(0)
     g = dict(draws=dev(torch, scene.entity_draw_buffer()), mesh=dev(torch, scene.mesh_infos),
              ent=dev(torch, scene.entities), mlt=dev(torch, scene.meshlets), mat=dev(torch, scene.materials))
+    if meshlet_stream:  # what GpuAssets::add_mesh does after uploading the meshlets (Context::sync_meshlet_stream)
+        ctx.sync_meshlet_stream(g["mlt"], 0, len(scene.meshlets))
     rng = np.random.default_rng(3)
     evis0 = rng.integers(0, 2 ** 32, (scene.entity_draw_count + 31) // 32, dtype=np.uint32)
     mvis0 = rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32)
