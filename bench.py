@@ -53,6 +53,12 @@ def parse():
                     help="what the streaming evaluation reads: the derived meshlet streams (24 B per meshlet, built "
                          "once from the meshlet buffer before the timed region; include/orbit_abi.h) or the 32-B "
                          "Meshlet buffer itself")
+    ap.add_argument("--settle-ms", type=float, default=60.0,
+                    help="device time spent on back-to-back frames BEFORE the warmup steps, so that the device is in "
+                         "its sustained power state when they start: from idle, the firmware's power controller "
+                         "overshoots for ~15 ms (frames 5-45 run up to 25 %% slower than both the first frames and "
+                         "the steady state, tools/sustained.sh) — exactly where 5 warmup + 20 timed steps would sit. "
+                         "Not steps: reported as config.settle_ms; 0 disables")
     ap.add_argument("--planes", type=int, default=5, help="cull planes used (5 = forward.rs:268; fewer only for triage)")
     return ap.parse_args()
 
@@ -288,6 +294,14 @@ def main():
 
     if do_gather and transport == "rccl":  # RCCL channel set-up is not part of any step, warm or timed
         assert odist.warm_up(dev)
+    # Power-state settle (see --settle-ms): the same frames, back to back, until the device has been busy that long.
+    settle_frames, t_settle = 0, time.perf_counter()
+    while args.settle_ms > 0 and (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        for _ in range(8):
+            step()
+        settle_frames += 8
+        drain()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     drain()
@@ -484,6 +498,7 @@ def main():
                 "entities": E, "meshlets": E * M, "meshlets_into_meshlet_cull": tot_in, "survivors": tot_draw,
                 "sharding": f"entity ranges over {world} rank(s)", "gather": bool(do_gather),
                 "frames_in_flight": F,
+                "settle_ms": args.settle_ms, "settle_frames": settle_frames,
                 "exchange": (args.exchange if do_gather else None), "transport": transport,
                 "meshlet_source": (f"derived meshlet streams (22 B per meshlet evaluated, 12 B per survivor gathered; "
                                    f"built once from the meshlet buffer before the timed region in "
