@@ -21,14 +21,14 @@ def mean_per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
             acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
 def main():
     fetch_csv, write_csv, entities, mpe = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
     source = sys.argv[5] if len(sys.argv) > 5 else "buffer"
-    fetch = mean_per_kernel(fetch_csv, "FETCH_SIZE")
-    write = mean_per_kernel(write_csv, "WRITE_SIZE")
+    fetch, launches = mean_per_kernel(fetch_csv, "FETCH_SIZE")
+    write, _ = mean_per_kernel(write_csv, "WRITE_SIZE")
     out = {"entities": entities, "meshlets_per_entity": mpe, "meshlet_source": source, "kernels": {},
            "corrections": "KiB -> bytes (x1024); FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B; calibrated "
                           "on wide streaming reads only — the x2 of a kernel that gathers, like the stream path's "
@@ -38,10 +38,15 @@ def main():
             continue
         m = re.search(r"(\w+)(?:<[^>]*>)?\((?:orbit::|unsigned|float)", k)
         name = m.group(1) if m else k
+        # template variants of one kernel (the stream run also times a few frames of the Meshlet-buffer path): the
+        # variant with the most launches is the run's own
+        if name in out["kernels"] and out["kernels"][name]["launches"] >= launches[k]:
+            continue
         rd = fetch[k] * 1024.0 * 2.0
         wr = write.get(k, 0.0) * 1024.0
         out["kernels"][name] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes": rd + wr,
-                                "raw_fetch_kib": fetch[k], "raw_write_kib": write.get(k, 0.0)}
+                                "raw_fetch_kib": fetch[k], "raw_write_kib": write.get(k, 0.0),
+                                "launches": launches[k], "kernel_name": k[:120]}
     dom = out["kernels"].get("meshlet_eval_kernel")
     out["dominant_kernel"] = "meshlet_eval_kernel"
     out["hbm_bytes_per_launch"] = dom["hbm_bytes"] if dom else None
