@@ -99,6 +99,17 @@ def test_no_device_is_a_loud_error_not_a_fallback():
         Engine(0)
 
 
+def test_meshlet_stream_entry_points_reject_null_without_a_device():
+    """The derived-meshlet-stream surface (include/orbit_abi.h) validates before it touches a device."""
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.orbit_meshlet_stream_create(None, 0, 16, C.byref(h)) == _lib.E_INVALID and not h.value
+    assert lib.orbit_meshlet_stream_update(None, None, None, 0, 0, None) == _lib.E_INVALID
+    assert lib.orbit_ctx_bind_meshlet_stream(None, None) == _lib.E_INVALID
+    assert lib.orbit_meshlet_stream_destroy(None) == _lib.OK
+    assert lib.orbit_ctx_meshlet_stream_culls(None) == 0
+
+
 def test_product_never_touches_the_oracle():
     """Nothing under orbit_amd/ may import, link or call oracle/ (task statement, section 3)."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "orbit_amd")):

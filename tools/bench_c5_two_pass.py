@@ -14,6 +14,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--entities", type=int, default=195_313)
 ap.add_argument("--frames", type=int, default=12)
 ap.add_argument("--check", action="store_true")
+ap.add_argument("--meshlet-source", choices=("stream", "buffer"), default="stream",
+                help="passes 0 and 2 cull from the derived meshlet streams (default) or from the 32-B Meshlet buffer")
 ap.add_argument("--wall-distance", type=float, default=950.0, help="occluder wall, metres in front of the camera")
 ap.add_argument("--wall-fraction", type=float, default=0.6, help="part of the screen width the wall covers")
 args = ap.parse_args()
@@ -35,6 +37,8 @@ ps = (d.width, d.height)
 rec = spec.records_per_entity
 disp_cap, draw_cap = E * rec + 8, E * M // 2 + 1024
 eng = Engine(0, max_entities=E + 256, max_dispatches=disp_cap, max_draws=draw_cap)
+if args.meshlet_source == "stream":
+    eng.bind_meshlet_stream(eng.meshlet_stream(meshlets, 0, E * M))
 disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device=dev)
 draw1 = torch.zeros(L.DRAW_HEADER + 28 * draw_cap, dtype=torch.uint8, device=dev)
 draw2 = torch.zeros_like(draw1)
@@ -77,6 +81,7 @@ ts = np.median(np.array(ts), axis=0)
 n1, n2 = int(draw1[:4].view(torch.int32).item()), int(draw2[:4].view(torch.int32).item())
 out = {"workload": f"config5 two-pass: {E} entities x {M} meshlets, 1080p depth (wall at {args.wall_distance:.0f} m over "
                    f"{100 * args.wall_fraction:.0f} % of the screen)",
+       "meshlet_source": args.meshlet_source,
        "pass1_cull_ms": float(ts[0]), "depth_reduce_ms": float(ts[1]), "pass2_cull_ms": float(ts[2]),
        "frame_ms": float(ts[3]), "meshlets_per_s_frame": E * M / (float(ts[3]) * 1e-3),
        "pass1_draws": n1, "pass2_draws": n2,
