@@ -61,7 +61,9 @@ __global__ __launch_bounds__(256) void eval_aos(const uint4 *src, size_t n_tiles
     }
 }
 
-template <int W>
+// OUT 0: ballots (lanes 0..7, 8 B each) and the count (lane 0) as two stores per tile (the product);
+//     1: one store: lanes 0..8 write 8 B each into a 72-B block (count in the ninth); 3: ballots only
+template <int W, int OUT = 0>
 __global__ __launch_bounds__(256) void eval_split(const uint4 *a1, const void *a2v, size_t n_tiles,
                                                   unsigned long long *masks, unsigned *counts) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -88,8 +90,15 @@ __global__ __launch_bounds__(256) void eval_split(const uint4 *a1, const void *a
             total += __popcll(m);
             s0 = s1; c0 = c1;
         }
-        if (lane < 8) masks[t * 8 + lane] = mine;
-        if (lane == 0) counts[t] = total;
+        if (OUT == 0) {
+            if (lane < 8) masks[t * 8 + lane] = mine;
+            if (lane == 0) counts[t] = total;
+        } else if (OUT == 1) {
+            if (lane == 8) mine = total;
+            if (lane < 9) masks[t * 9 + lane] = mine;
+        } else if (OUT == 3) {
+            if (lane < 8) masks[t * 8 + lane] = mine;
+        }
     }
 }
 
@@ -166,7 +175,7 @@ int main() {
     uint4 *aos, *a1; uint2 *a2; unsigned *a2n, *b, *counts, *offs, *out; P3 *pay; unsigned long long *masks;
     hipMalloc(&aos, n * 32); hipMalloc(&a1, n * 16); hipMalloc(&a2, n * 8); hipMalloc(&a2n, n * 4);
     hipMalloc(&b, n * 12); hipMalloc(&counts, n_tiles * 4); hipMalloc(&offs, n_tiles * 4);
-    hipMalloc(&pay, n_tiles * 128 * 12); hipMalloc(&masks, n_tiles * 64); hipMalloc(&out, (n / 8) * 28);
+    hipMalloc(&pay, n_tiles * 128 * 12); hipMalloc(&masks, n_tiles * 72); hipMalloc(&out, (n / 8) * 28);
     hipMemset(a2n, 0, n * 4);
     hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, aos, a1, a2, b, n);
     const int blocks = 256 * 4;
@@ -192,6 +201,9 @@ int main() {
         const float ea = time_kernel([&] { hipLaunchKernelGGL(eval_aos, dim3(blocks), dim3(256), 0, 0, aos, n_tiles, pay, counts); });
         const float e8 = time_kernel([&] { hipLaunchKernelGGL((eval_split<8>), dim3(blocks), dim3(256), 0, 0, a1, a2, n_tiles, masks, counts); });
         const float e4 = time_kernel([&] { hipLaunchKernelGGL((eval_split<4>), dim3(blocks), dim3(256), 0, 0, a1, a2n, n_tiles, masks, counts); });
+        const float o1 = time_kernel([&] { hipLaunchKernelGGL((eval_split<4, 1>), dim3(blocks), dim3(256), 0, 0, a1, a2n, n_tiles, masks, counts); });
+        const float o3 = time_kernel([&] { hipLaunchKernelGGL((eval_split<4, 3>), dim3(blocks), dim3(256), 0, 0, a1, a2n, n_tiles, masks, counts); });
+        printf("split 16+4, outputs per tile: ballots + count (2 stores) %.4f | one 72-B store %.4f | ballots only %.4f ms\n", e4, o1, o3);
         float mp[3], g12[3], g32[3];
         const int grids[3] = {blocks, blocks * 2, blocks * 4};
         for (int g = 0; g < 3; g++) {
