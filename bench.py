@@ -295,13 +295,26 @@ def main():
     if do_gather and transport == "rccl":  # RCCL channel set-up is not part of any step, warm or timed
         assert odist.warm_up(dev)
     # Power-state settle (see --settle-ms): the same frames, back to back, until the device has been busy that long.
-    settle_frames, t_settle = 0, time.perf_counter()
-    while args.settle_ms > 0 and (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
-        for _ in range(8):
+    # The frame count must be the same on every rank (a step of the sharded engine contains collectives), so it is
+    # derived from the slowest rank's time for the first eight frames, not from each rank's own clock.
+    settle_frames = 0
+    if args.settle_ms > 0:
+        for batch in range(2):  # eight cold frames (code objects, first touches), then eight that are timed
+            t_settle = time.perf_counter()
+            for _ in range(8):
+                step()
+            drain()
+            torch.cuda.synchronize()
+        per_frame = torch.tensor([(time.perf_counter() - t_settle) / 8], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(per_frame, op=dist.ReduceOp.MAX)
+        more = int(np.ceil(args.settle_ms * 1e-3 / max(float(per_frame.item()), 1e-6))) - 16
+        more = min(max(more, 0), 8192)
+        for _ in range(more):
             step()
-        settle_frames += 8
         drain()
         torch.cuda.synchronize()
+        settle_frames = 16 + more
     for _ in range(args.warmup):
         step()
     drain()

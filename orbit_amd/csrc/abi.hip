@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -28,7 +29,10 @@ struct OrbitMeshletStream {
     uint32_t *cone = nullptr;
     uint16_t *mat = nullptr;
     uint32_t *cmd = nullptr;
-    const void *source = nullptr; // Meshlet buffer of the last update; nullptr = never updated
+    // Meshlet buffer of the last update (nullptr = never updated).  Atomic: a stream may be bound to several contexts,
+    // each with its own lock; the device-side order of an update against the culls that read it is the caller's, like
+    // the order of the meshlet upload itself.
+    std::atomic<const void *> source{nullptr};
 };
 
 struct OrbitCtx {
@@ -469,7 +473,7 @@ int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCull
     p.dispatch_buffer = (const uint8_t *)b->meshlet_dispatch_buffer;
     p.meshlets = (const OrbitMeshlet *)b->meshlet_buffer;
     p.ms = MeshletStreamView{nullptr, nullptr, nullptr, nullptr};
-    if (const OrbitMeshletStream *ms = ctx->meshlet_stream; ms && ms->source == b->meshlet_buffer)
+    if (const OrbitMeshletStream *ms = ctx->meshlet_stream; ms && ms->source.load() == b->meshlet_buffer)
         // arrays based at global meshlet index 0, like meshlet_buffer itself
         p.ms = MeshletStreamView{ms->sphere - ms->first, ms->cone - ms->first, ms->mat - ms->first,
                                  ms->cmd - 3u * ms->first};
@@ -613,7 +617,7 @@ int32_t orbit_meshlet_stream_update(OrbitCtx *ctx, OrbitMeshletStream *ms, const
         return fail(ctx, ORBIT_E_CAPACITY, "meshlet_stream_update: [%llu, +%llu) outside the stream's [%llu, +%llu)",
                     (unsigned long long)first, (unsigned long long)count, (unsigned long long)ms->first,
                     (unsigned long long)ms->capacity);
-    ms->source = meshlet_buffer;
+    ms->source.store(meshlet_buffer);
     const hipError_t e = launch_meshlet_stream_build((const OrbitMeshlet *)meshlet_buffer, first, count,
                                                      ms->sphere - ms->first, ms->cone - ms->first,
                                                      ms->mat - ms->first, ms->cmd - 3u * ms->first,
@@ -661,7 +665,7 @@ int32_t orbit_expand_visible(OrbitCtx *ctx, const void *visible_buffer, const vo
         return fail(ctx, ORBIT_E_MISSING, "expand_visible: NULL argument");
     // a bound stream that mirrors this meshlet buffer serves the survivors' command words (12-B gathers)
     const OrbitMeshletStream *ms = ctx->meshlet_stream;
-    const uint32_t *cmd = (ms && ms->source == meshlet_buffer) ? ms->cmd - 3u * ms->first : nullptr;
+    const uint32_t *cmd = (ms && ms->source.load() == meshlet_buffer) ? ms->cmd - 3u * ms->first : nullptr;
     const hipError_t e = launch_visible_expand((const uint8_t *)visible_buffer, (const OrbitMeshlet *)meshlet_buffer, cmd,
                                                (uint8_t *)draw_commands_buffer, draw_capacity, ctx->num_cus,
                                                ctx->zero_page, ctx->status, (hipStream_t)stream);
