@@ -56,7 +56,8 @@ enum {
     ORBIT_E_TIMEOUT = -6,  /* reserved: a bounded in-kernel wait gave up (no current kernel waits) */
     ORBIT_E_MISSING = -7,  /* a resource the CullInfo declares present was passed as NULL
                               (.unwrap() at draw_gen.rs:123-133) */
-    ORBIT_E_COMM = -8      /* RCCL is not loadable in this process or one of its calls failed */
+    ORBIT_E_COMM = -8,     /* RCCL is not loadable in this process or one of its calls failed */
+    ORBIT_E_RANGE = -9     /* a culled / expanded meshlet lies outside the bound meshlet stream (latched on device) */
 };
 
 /* ------------------------------------------------------------------------ */
@@ -355,7 +356,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps, OrbitCtx **ou
 int32_t orbit_ctx_destroy(OrbitCtx *ctx);
 /* Message for the last failing call on this thread / context (never NULL). */
 const char *orbit_last_error(const OrbitCtx *ctx);
-/* Device-latched status (ORBIT_OK / ORBIT_E_CAPACITY / ORBIT_E_TIMEOUT).
+/* Device-latched status (ORBIT_OK / ORBIT_E_CAPACITY / ORBIT_E_RANGE / ORBIT_E_TIMEOUT).
  * `sync` != 0 first waits for `stream` to drain.  Clears the latch. */
 int32_t orbit_ctx_status(OrbitCtx *ctx, void *stream, int32_t sync);
 
@@ -513,7 +514,10 @@ int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t cou
 /*            call it wherever the renderer writes meshlets (add_mesh) —     */
 /*            meshlets changed without an update are culled from stale data  */
 /*   bind     NULL unbinds; the stream must outlive the binding; one stream  */
-/*            can be bound to any number of contexts of its device           */
+/*            can be bound to any number of contexts of its device.  The     */
+/*            stream must cover every meshlet the culls dispatch: a meshlet  */
+/*            outside its range is not read from it (the lane evaluates      */
+/*            zeros, the command carries zeros) and ORBIT_E_RANGE is latched */
 /* ------------------------------------------------------------------------ */
 typedef struct OrbitMeshletStream OrbitMeshletStream;
 int32_t orbit_meshlet_stream_create(OrbitCtx *ctx, uint64_t first_meshlet, uint64_t capacity,

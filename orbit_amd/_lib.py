@@ -10,11 +10,12 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liborbit_cull.so")
 
-OK, E_INVALID, E_PLANES, E_CAPACITY, E_HIP, E_NO_DEVICE, E_TIMEOUT, E_MISSING, E_COMM = 0, -1, -2, -3, -4, -5, -6, -7, -8
+OK, E_INVALID, E_PLANES, E_CAPACITY, E_HIP, E_NO_DEVICE, E_TIMEOUT, E_MISSING, E_COMM, E_RANGE = (
+    0, -1, -2, -3, -4, -5, -6, -7, -8, -9)
 ERROR_NAMES = {
     E_INVALID: "ORBIT_E_INVALID", E_PLANES: "ORBIT_E_PLANES", E_CAPACITY: "ORBIT_E_CAPACITY", E_HIP: "ORBIT_E_HIP",
     E_NO_DEVICE: "ORBIT_E_NO_DEVICE", E_TIMEOUT: "ORBIT_E_TIMEOUT", E_MISSING: "ORBIT_E_MISSING",
-    E_COMM: "ORBIT_E_COMM",
+    E_COMM: "ORBIT_E_COMM", E_RANGE: "ORBIT_E_RANGE",
 }
 
 MAX_PYRAMID_MIPS = 16

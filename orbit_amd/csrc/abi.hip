@@ -129,6 +129,12 @@ int32_t check_cull_info(OrbitCtx *ctx, const OrbitGpuCullInfo *ci) {
     return ORBIT_OK;
 }
 
+// arrays based at global meshlet index 0, like meshlet_buffer itself
+MeshletStreamView stream_view(const OrbitMeshletStream *ms) {
+    return MeshletStreamView{ms->sphere - ms->first, ms->cone - ms->first, ms->mat - ms->first,
+                             ms->cmd - 3u * ms->first, (uint32_t)ms->first, (uint32_t)ms->capacity};
+}
+
 PyramidView make_pyramid_view(const float *texels, const uint32_t size[2],
                               const OrbitDepthPyramidLevel *levels = nullptr) {
     PyramidView v;
@@ -327,7 +333,8 @@ int32_t orbit_ctx_status(OrbitCtx *ctx, void *stream, int32_t sync) {
         e = hipMemset(ctx->status, 0, 4);
         if (e != hipSuccess) return hip_fail(ctx, e, "hipMemset(status)");
         return fail(ctx, v, v == ORBIT_E_CAPACITY ? "an append overflowed a caller buffer (entries dropped)"
-                                                   : "device-latched error %d", v);
+                            : v == ORBIT_E_RANGE  ? "a meshlet outside the bound meshlet stream was culled or expanded"
+                                                  : "device-latched error %d", v);
     }
     return ORBIT_OK;
 }
@@ -472,11 +479,10 @@ int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCull
     p.ci = *ci;
     p.dispatch_buffer = (const uint8_t *)b->meshlet_dispatch_buffer;
     p.meshlets = (const OrbitMeshlet *)b->meshlet_buffer;
-    p.ms = MeshletStreamView{nullptr, nullptr, nullptr, nullptr};
+    p.ms = MeshletStreamView{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
     if (const OrbitMeshletStream *ms = ctx->meshlet_stream; ms && ms->source.load() == b->meshlet_buffer)
         // arrays based at global meshlet index 0, like meshlet_buffer itself
-        p.ms = MeshletStreamView{ms->sphere - ms->first, ms->cone - ms->first, ms->mat - ms->first,
-                                 ms->cmd - 3u * ms->first};
+        p.ms = stream_view(ms);
     p.draw_buffer = (uint8_t *)(visible_path ? visible_buffer : b->draw_commands_buffer);
     p.entities = (const OrbitEntityData *)b->entity_buffer;
     p.materials = (const OrbitMaterialData *)b->material_buffer;
@@ -585,7 +591,7 @@ int32_t orbit_meshlet_stream_create(OrbitCtx *ctx, uint64_t first_meshlet, uint6
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (!out_stream) return fail(ctx, ORBIT_E_MISSING, "meshlet_stream_create: out_stream is NULL");
     *out_stream = nullptr;
-    if (capacity == 0 || first_meshlet + capacity > 0x100000000ull) // meshlet indices are 32-bit (MeshletDispatch)
+    if (capacity == 0 || capacity > 0xFFFFFFFFull || first_meshlet + capacity > 0xFFFFFFFFull) // 32-bit meshlet indices
         return fail(ctx, ORBIT_E_INVALID, "meshlet_stream_create: range [%llu, +%llu)", (unsigned long long)first_meshlet,
                     (unsigned long long)capacity);
     hipError_t e = hipSetDevice(ctx->device);
@@ -665,11 +671,13 @@ int32_t orbit_expand_visible(OrbitCtx *ctx, const void *visible_buffer, const vo
         return fail(ctx, ORBIT_E_MISSING, "expand_visible: NULL argument");
     // a bound stream that mirrors this meshlet buffer serves the survivors' command words (12-B gathers)
     const OrbitMeshletStream *ms = ctx->meshlet_stream;
-    const uint32_t *cmd = (ms && ms->source.load() == meshlet_buffer) ? ms->cmd - 3u * ms->first : nullptr;
-    const hipError_t e = launch_visible_expand((const uint8_t *)visible_buffer, (const OrbitMeshlet *)meshlet_buffer, cmd,
+    const MeshletStreamView view = (ms && ms->source.load() == meshlet_buffer)
+                                       ? stream_view(ms)
+                                       : MeshletStreamView{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+    const hipError_t e = launch_visible_expand((const uint8_t *)visible_buffer, (const OrbitMeshlet *)meshlet_buffer, view,
                                                (uint8_t *)draw_commands_buffer, draw_capacity, ctx->num_cus,
                                                ctx->zero_page, ctx->status, (hipStream_t)stream);
-    if (cmd) ctx->stream_culls++;
+    if (view.cmd) ctx->stream_culls++;
     if (e != hipSuccess) return hip_fail(ctx, e, "launch visible_expand");
     return ORBIT_OK;
 }

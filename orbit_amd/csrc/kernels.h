@@ -49,6 +49,8 @@ struct MeshletStreamView {
     const uint32_t *cone; // cone_axis | cone_cutoff << 24
     const uint16_t *mat;  // material_index
     const uint32_t *cmd;  // 3 words per meshlet: vertex_offset, data_offset, word 7 again
+    uint32_t first, count; // global meshlet indices the arrays cover: [first, first + count)
+    __host__ __device__ bool covers(uint32_t meshlet) const { return meshlet - first < count; }
 };
 
 struct MeshletCullParams {
@@ -166,8 +168,8 @@ uint32_t max_dispatch_capacity();
 // meshlets[first, first + count) -> the three streams (a plain re-layout, one pass)
 hipError_t launch_meshlet_stream_build(const OrbitMeshlet *meshlets, uint64_t first, uint64_t count, uint4 *sphere,
                                        uint32_t *cone, uint16_t *mat, uint32_t *cmd, hipStream_t s);
-// cmd_stream (optional): the derived command-word stream of `meshlets`, based at global meshlet index 0
-hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, const uint32_t *cmd_stream,
+// ms.cmd (optional): the derived command-word stream of `meshlets`, based at global meshlet index 0
+hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, const MeshletStreamView &ms,
                                  uint8_t *draw_buffer, uint32_t draw_capacity, uint32_t num_cus, const void *zero_page,
                                  int32_t *status, hipStream_t s);
 struct ScatterListParams {

@@ -224,9 +224,12 @@ __device__ __forceinline__ void rows_load(const MeshletCullParams &p, const Wave
         // straight-line loads (exact vmcnt accounting): lanes past meshlet_count (:111) read the zero page
         const bool active = ml < rec.z;
         if constexpr (STREAM) {
-            t.a[k] = *(active ? p.ms.sphere + (rec.y + ml) : reinterpret_cast<const uint4 *>(p.zero_page));
-            const uint32_t c = *(active ? p.ms.cone + (rec.y + ml) : reinterpret_cast<const uint32_t *>(p.zero_page));
-            const uint16_t m = *(active ? p.ms.mat + (rec.y + ml) : reinterpret_cast<const uint16_t *>(p.zero_page));
+            // a meshlet the stream does not cover is not read from it: zeros, and the call's status says so
+            const bool in = active && p.ms.covers(rec.y + ml);
+            if (active && !in) latch_status(p.status, ORBIT_E_RANGE);
+            t.a[k] = *(in ? p.ms.sphere + (rec.y + ml) : reinterpret_cast<const uint4 *>(p.zero_page));
+            const uint32_t c = *(in ? p.ms.cone + (rec.y + ml) : reinterpret_cast<const uint32_t *>(p.zero_page));
+            const uint16_t m = *(in ? p.ms.mat + (rec.y + ml) : reinterpret_cast<const uint16_t *>(p.zero_page));
             t.b[k] = make_uint4(c, 0u, 0u, (uint32_t)m);
         } else {
             const uint4 *src = active ? reinterpret_cast<const uint4 *>(p.meshlets + (rec.y + ml))
@@ -934,8 +937,8 @@ __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
                     uint4 b = make_uint4(0u, 0u, 0u, 0u);
                     if constexpr (STREAM) {
                         if constexpr (!VISIBLE) { // the visible list carries indices only
-                            const uint32_t *c3 = j < n ? p.ms.cmd + (size_t)mi * 3u
-                                                       : reinterpret_cast<const uint32_t *>(p.zero_page);
+                            const uint32_t *c3 = (j < n && p.ms.covers(mi)) ? p.ms.cmd + (size_t)mi * 3u
+                                                                            : reinterpret_cast<const uint32_t *>(p.zero_page);
                             b.y = c3[0];
                             b.z = c3[1];
                             b.w = c3[2];
@@ -1027,10 +1030,12 @@ __device__ __forceinline__ ExpandChunk expand_load_items(const uint2 *items, uin
 // STREAM: the three command words come from the derived 12-B stream (`cmd`, orbit_meshlet_stream_*) instead of bytes
 // 16..31 of the Meshlet: a third of the lines per survivor.
 template <bool STREAM>
-__device__ __forceinline__ uint4 expand_gather(const OrbitMeshlet *meshlets, const uint32_t *cmd, const ExpandChunk &c,
-                                               const void *zero_page) {
+__device__ __forceinline__ uint4 expand_gather(const OrbitMeshlet *meshlets, const MeshletStreamView &ms,
+                                               const ExpandChunk &c, const void *zero_page, int32_t *status) {
     if constexpr (STREAM) {
-        const uint32_t *c3 = c.valid ? cmd + (size_t)c.item.x * 3u : reinterpret_cast<const uint32_t *>(zero_page);
+        const bool in = c.valid && ms.covers(c.item.x);
+        if (c.valid && !in) latch_status(status, ORBIT_E_RANGE);
+        const uint32_t *c3 = in ? ms.cmd + (size_t)c.item.x * 3u : reinterpret_cast<const uint32_t *>(zero_page);
         return make_uint4(0u, c3[0], c3[1], c3[2]);
     } else {
         return *(c.valid ? reinterpret_cast<const uint4 *>(meshlets + c.item.x) + 1
@@ -1040,7 +1045,7 @@ __device__ __forceinline__ uint4 expand_gather(const OrbitMeshlet *meshlets, con
 
 template <bool STREAM>
 __global__ __launch_bounds__(256) void visible_expand_kernel(const uint8_t *visible, const OrbitMeshlet *meshlets,
-                                                             const uint32_t *cmd_stream, uint8_t *draw_buffer,
+                                                             const MeshletStreamView ms, uint8_t *draw_buffer,
                                                              uint32_t draw_capacity, const void *zero_page,
                                                              int32_t *status) {
     __shared__ uint32_t s_cmd[4][64 * 7];
@@ -1055,10 +1060,10 @@ __global__ __launch_bounds__(256) void visible_expand_kernel(const uint8_t *visi
     uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 4u + wave) * 64u));
     ExpandChunk c0 = expand_load_items(items, first, n, lane, zero_page);
     ExpandChunk c1 = expand_load_items(items, first + stride, n, lane, zero_page);
-    uint4 b0 = expand_gather<STREAM>(meshlets, cmd_stream, c0, zero_page);
+    uint4 b0 = expand_gather<STREAM>(meshlets, ms, c0, zero_page, status);
     for (; first < n; first += stride) {
         const ExpandChunk c2 = expand_load_items(items, first + 2u * stride, n, lane, zero_page);
-        const uint4 b1 = expand_gather<STREAM>(meshlets, cmd_stream, c1, zero_page);
+        const uint4 b1 = expand_gather<STREAM>(meshlets, ms, c1, zero_page, status);
         uint32_t *c = cmd + lane * 7;
         c[0] = (b0.w >> 24) * 3u;                     // cmd_index_count = triangle_count * 3
         c[1] = 1u;                                    // cmd_instance_count
@@ -1323,18 +1328,18 @@ uint32_t max_dispatch_capacity() {
     return cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
 }
 
-hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, const uint32_t *cmd_stream,
+hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, const MeshletStreamView &ms,
                                  uint8_t *draw_buffer, uint32_t draw_capacity, uint32_t num_cus, const void *zero_page,
                                  int32_t *status, hipStream_t s) {
     uint32_t blocks = num_cus * 8u;
     const uint32_t need = (draw_capacity + 255u) / 256u;
     if (blocks > need) blocks = need;
     if (blocks == 0) blocks = 1;
-    if (cmd_stream)
-        hipLaunchKernelGGL(visible_expand_kernel<true>, dim3(blocks), dim3(256), 0, s, visible, meshlets, cmd_stream,
+    if (ms.cmd)
+        hipLaunchKernelGGL(visible_expand_kernel<true>, dim3(blocks), dim3(256), 0, s, visible, meshlets, ms,
                            draw_buffer, draw_capacity, zero_page, status);
     else
-        hipLaunchKernelGGL(visible_expand_kernel<false>, dim3(blocks), dim3(256), 0, s, visible, meshlets, cmd_stream,
+        hipLaunchKernelGGL(visible_expand_kernel<false>, dim3(blocks), dim3(256), 0, s, visible, meshlets, ms,
                            draw_buffer, draw_capacity, zero_page, status);
     return hipGetLastError();
 }

@@ -156,6 +156,37 @@ def test_pass1_keeps_reading_the_meshlet_buffer(torch_mod, engine, oracle):
     ms.close()
 
 
+def test_meshlet_outside_the_stream_latches_range_error(torch_mod, engine, oracle):
+    """A stream that does not cover what is culled: no out-of-range read, ORBIT_E_RANGE in the context's status; the
+    covered part of the scene is still culled correctly."""
+    from orbit_amd._lib import E_RANGE, OrbitError
+
+    torch = torch_mod
+    scene, ci = _scene(seed=47, n=300)
+    gs = GpuScene(torch, scene)
+    half = len(scene.meshlets) // 2
+    ms = engine.meshlet_stream(gs.meshlets, 0, half)
+    engine.bind_meshlet_stream(ms)
+    with pytest.raises(OrbitError) as ei:
+        run_gpu(torch, engine, gs, ci)
+        engine.status()
+    assert ei.value.code == E_RANGE
+    engine.status()  # the latch is cleared by the read
+    # expansion of a list that names a meshlet past the stream
+    vis = np.zeros(L.VISIBLE_HEADER + 8 * 2, dtype=np.uint8)
+    vis[:4].view(np.uint32)[0] = 2
+    vis[8:].view(np.uint32)[:] = [1, 0, half + 3, 0]
+    draw = torch.zeros(L.DRAW_HEADER + 28 * 4, dtype=torch.uint8, device="cuda")
+    engine.expand_visible(dev(torch, vis), gs.meshlets, draw, 4)
+    with pytest.raises(OrbitError) as ei:
+        engine.status()
+    assert ei.value.code == E_RANGE
+    n, cmds = L.draw_buffer_commands(host(draw))
+    m1 = scene.meshlets[1]
+    assert n == 2 and cmds[0]["meshlet_vertex_offset"] == m1["vertex_offset"] and cmds[1]["meshlet_index"] == half + 3
+    ms.close()
+
+
 def test_stream_argument_errors(torch_mod, engine):
     torch = torch_mod
     lib = engine._lib
@@ -165,6 +196,7 @@ def test_stream_argument_errors(torch_mod, engine):
     assert lib.orbit_meshlet_stream_create(engine._ctx, 0, 10, None) == _lib.E_MISSING
     assert lib.orbit_meshlet_stream_create(engine._ctx, 0, 0, C.byref(h)) == _lib.E_INVALID and not h.value
     assert lib.orbit_meshlet_stream_create(engine._ctx, 2**32 - 5, 10, C.byref(h)) == _lib.E_INVALID  # 32-bit indices
+    assert lib.orbit_meshlet_stream_create(engine._ctx, 0, 2**32, C.byref(h)) == _lib.E_INVALID
     assert lib.orbit_meshlet_stream_create(engine._ctx, 50, 100, C.byref(h)) == _lib.OK and h.value
     p = C.c_void_p(buf.data_ptr() - 50 * 32)
     assert lib.orbit_meshlet_stream_update(engine._ctx, None, p, 50, 100, None) == _lib.E_MISSING

@@ -102,6 +102,40 @@ __global__ __launch_bounds__(256) void eval_split(const uint4 *a1, const void *a
     }
 }
 
+// WIDE: the tile's 512 cones (2 KiB) come in as two dwordx4 loads per lane issued one tile ahead instead of one
+// dword load per row (8 per tile) — fewer, full-width requests for the same bytes.  (Bandwidth probe: the lane mapping
+// a real kernel would need — through LDS — is not reproduced, the words only feed the predicate.)
+__global__ __launch_bounds__(256) void eval_split_wide(const uint4 *a1, const uint4 *cones, size_t n_tiles,
+                                                       unsigned long long *masks, unsigned *counts) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t stride = (size_t)gridDim.x * 4;
+    size_t t = (size_t)blockIdx.x * 4 + wave;
+    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+    if (t < n_tiles) { c0 = cones[t * 128 + lane]; c1 = cones[t * 128 + 64 + lane]; }
+    for (; t < n_tiles; t += stride) {
+        const uint4 *p = a1 + t * 512 + lane;
+        uint4 s0 = p[0];
+        uint4 n0 = c0, n1 = c1;
+        if (t + stride < n_tiles) { n0 = cones[(t + stride) * 128 + lane]; n1 = cones[(t + stride) * 128 + 64 + lane]; }
+        const unsigned cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        unsigned total = 0;
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint4 s1 = s0;
+            if (r < 7) s1 = p[(r + 1) * 64];
+            const bool keep = ((s0.x + (cw[r] >> 31)) & 1023u) < kKeep;
+            const unsigned long long m = __ballot(keep);
+            if (lane == r) mine = m;
+            total += __popcll(m);
+            s0 = s1;
+        }
+        if (lane < 8) masks[t * 8 + lane] = mine;
+        if (lane == 0) counts[t] = total;
+        c0 = n0; c1 = n1;
+    }
+}
+
 struct Cmd { unsigned w[7]; };
 
 __device__ __forceinline__ void put_cmd(unsigned *out, size_t slot, unsigned y, unsigned z, unsigned w, unsigned idx) {
@@ -204,6 +238,8 @@ int main() {
         const float o1 = time_kernel([&] { hipLaunchKernelGGL((eval_split<4, 1>), dim3(blocks), dim3(256), 0, 0, a1, a2n, n_tiles, masks, counts); });
         const float o3 = time_kernel([&] { hipLaunchKernelGGL((eval_split<4, 3>), dim3(blocks), dim3(256), 0, 0, a1, a2n, n_tiles, masks, counts); });
         printf("split 16+4, outputs per tile: ballots + count (2 stores) %.4f | one 72-B store %.4f | ballots only %.4f ms\n", e4, o1, o3);
+        const float ew = time_kernel([&] { hipLaunchKernelGGL(eval_split_wide, dim3(blocks), dim3(256), 0, 0, a1, (const uint4 *)a2n, n_tiles, masks, counts); });
+        printf("split 16+4: cones as one dword load per row %.4f | as two dwordx4 loads per tile %.4f ms\n", e4, ew);
         float mp[3], g12[3], g32[3];
         const int grids[3] = {blocks, blocks * 2, blocks * 4};
         for (int g = 0; g < 3; g++) {
