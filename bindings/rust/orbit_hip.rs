@@ -170,3 +170,20 @@ pub fn check(ctx: *const OrbitCtx, rc: i32) {
 //                                                   scene.entity_draw_count as u32, hip_stream) });
 //         });
 //     // the fill_buffer clears (draw_gen.rs:356-363) disappear: the library writes the {n,1,1} header itself.
+
+// --- optional: derived meshlet streams, in src/assets/mod.rs ---------------------------------------------------
+//
+// GpuAssets::new (after meshlet_buffer is created, assets/mod.rs:272-276):
+//     let mut ms = std::ptr::null_mut();
+//     check(ctx, unsafe { orbit_meshlet_stream_create(ctx, 0, MAX_MESHLET_COUNT as u64, &mut ms) });
+//     // once per cull context (frame slot): orbit_ctx_bind_meshlet_stream(slot_ctx, ms)
+//
+// GpuAssets::add_mesh, right after the upload (assets/mod.rs:441-445):
+//     context.queue_write_buffer(&self.meshlet_buffer, meshlet_range.start * size_of::<GpuMeshlet>(), meshlet_bytes);
+//     // ordered behind that write like any reader of the buffer (same HIP stream / the imported semaphore):
+//     check(ctx, unsafe { orbit_meshlet_stream_update(ctx, ms, hip_ptr(&self.meshlet_buffer),
+//                                                     meshlet_range.start as u64, meshlets.len() as u64, hip_stream) });
+//
+// Nothing else changes: orbit_meshlet_cull keeps taking bufs.meshlet_buffer; when it is the pointer the stream was
+// updated from, passes 0 and 2 read the stream (22 B per meshlet instead of 32, no survivor payload).  A meshlet the
+// stream does not cover latches ORBIT_E_RANGE (orbit_ctx_status) instead of being read out of range.
