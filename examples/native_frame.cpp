@@ -6,7 +6,8 @@
 // depth_reduce when the dump carries a depth buffer (draw_gen.rs:510-566).  The outputs are written to a file so that
 // tests/test_native_example_gpu.py can compare them bit-exactly with the CPU oracle run on the same dump.
 //
-//   usage: native_frame <scene.orbitscene> <out.bin> [replays]
+//   usage: native_frame <scene.orbitscene> <out.bin> [replays] [--stream]
+//   --stream: cull from the derived meshlet streams (orbit_meshlet_stream_*), built once after the meshlet upload
 //   out.bin: u64 sizes[3] {dispatch buffer, draw buffer, pyramid}, then the three blobs
 //   replays > 0: the frame is also captured into a HIP graph (every entry point only enqueues on the caller's stream,
 //   so stream capture just works) and replayed that many times; eager and replayed times per frame are printed.
@@ -95,7 +96,12 @@ std::vector<uint8_t> to_host(const void *d, size_t bytes) {
 } // namespace
 
 int main(int argc, char **argv) {
-    if (argc != 3 && argc != 4) die("usage: native_frame <scene.orbitscene> <out.bin> [replays]");
+    bool use_stream = false;
+    if (argc > 3 && std::string(argv[argc - 1]) == "--stream") {
+        use_stream = true;
+        argc--;
+    }
+    if (argc != 3 && argc != 4) die("usage: native_frame <scene.orbitscene> <out.bin> [replays] [--stream]");
     const int replays = argc == 4 ? std::atoi(argv[3]) : 0;
     const std::vector<uint8_t> raw = read_file(argv[1]);
     const std::map<std::string, Section> sec = parse_scene(raw);
@@ -175,6 +181,15 @@ int main(int argc, char **argv) {
     mb.dispatch_capacity = caps.max_dispatches;
     mb.draw_capacity = caps.max_draws;
     mb.material_count = (uint32_t)(sec.at("materials").size / 80);
+    // what GpuAssets::add_mesh does after uploading meshlets (assets/mod.rs:441-445), when the streams are in use
+    OrbitMeshletStream *ms = nullptr;
+    if (use_stream) {
+        const uint64_t n_meshlets = sec.at("meshlets").size / sizeof(OrbitMeshlet);
+        orbit_check(ctx, orbit_meshlet_stream_create(ctx, 0, n_meshlets, &ms), "orbit_meshlet_stream_create");
+        orbit_check(ctx, orbit_meshlet_stream_update(ctx, ms, d_meshlets, 0, n_meshlets, stream),
+                    "orbit_meshlet_stream_update");
+        orbit_check(ctx, orbit_ctx_bind_meshlet_stream(ctx, ms), "orbit_ctx_bind_meshlet_stream");
+    }
     auto frame = [&] { // the calls of one frame, in the reference's order; nothing here allocates or synchronises
         orbit_check(ctx, orbit_entity_cull(ctx, &ci, &eb, n_draws, stream), "orbit_entity_cull");
         orbit_check(ctx, orbit_meshlet_cull(ctx, &ci, &mb, stream), "orbit_meshlet_cull");
@@ -222,6 +237,8 @@ int main(int argc, char **argv) {
     std::memcpy(&n_cmd, h_cmds.data(), 4);
     std::printf("entity draws %u -> dispatch records %u -> draw commands %u; pyramid %zu B\n", n_draws, n_rec, n_cmd,
                 pyr_bytes);
+    std::printf("meshlet culls served from the derived streams: %llu\n",
+                (unsigned long long)orbit_ctx_meshlet_stream_culls(ctx));
     FILE *f = std::fopen(argv[2], "wb");
     if (!f) die("cannot write ", argv[2]);
     const uint64_t sizes[3] = {h_disp.size(), h_cmds.size(), h_pyr.size()};
@@ -231,6 +248,8 @@ int main(int argc, char **argv) {
     if (!h_pyr.empty()) std::fwrite(h_pyr.data(), 1, h_pyr.size(), f);
     std::fclose(f);
 
+    orbit_ctx_bind_meshlet_stream(ctx, nullptr);
+    orbit_meshlet_stream_destroy(ms);
     orbit_ctx_destroy(ctx);
     for (void *p : {d_draws, d_mesh, d_ent, d_meshlets, d_mat, d_disp, d_cmds, d_depth, d_pyr})
         if (p) (void)hipFree(p);

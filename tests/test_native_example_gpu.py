@@ -18,7 +18,8 @@ BIN = os.path.join(ROOT, "examples", "native_frame")
 pytestmark = pytest.mark.gpu
 
 
-def test_native_process_matches_the_oracle(tmp_path, oracle):
+@pytest.mark.parametrize("stream", [False, True], ids=["meshlet_buffer", "meshlet_stream"])
+def test_native_process_matches_the_oracle(tmp_path, oracle, stream):
     import torch
 
     if not torch.cuda.is_available():
@@ -34,9 +35,13 @@ def test_native_process_matches_the_oracle(tmp_path, oracle):
     orbitscene.write(dump, entity_draws=scene.entity_draw_buffer(), mesh_infos=scene.mesh_infos,
                      entities=scene.entities, meshlets=scene.meshlets, materials=scene.materials,
                      cull_info=np.asarray(ci).reshape(1), depth=depth, screen=np.array([W, H], dtype=np.uint32))
-    r = subprocess.run([BIN, dump, out, "20"], capture_output=True, text=True, timeout=120)  # 20 eager + 20 graph replays
+    # 20 eager + 20 graph replays; --stream: the culls read the derived meshlet streams (also inside the captured graph)
+    r = subprocess.run([BIN, dump, out, "20"] + (["--stream"] if stream else []), capture_output=True, text=True,
+                       timeout=120)
     assert r.returncode == 0, r.stderr
     assert "graph replay" in r.stdout, r.stdout  # the frame was captured and replayed; outputs below are the replay's
+    served = int(r.stdout.split("served from the derived streams:")[1].split()[0])
+    assert (served > 0) == stream, r.stdout
     raw = open(out, "rb").read()
     n_disp, n_draw, n_pyr = struct.unpack_from("<QQQ", raw, 0)
     gdisp = np.frombuffer(raw, np.uint8, n_disp, 24)
