@@ -352,20 +352,6 @@ def main():
 
     # one frame alone on an idle device (nothing else in flight): the latency a single cull costs, and its parts
     s0 = slots[0]
-    # the same frame from the 32-B Meshlet buffer (stream unbound), for the record: 5 frames alone, outside any metric
-    buffer_path_latency_ms = None
-    if mstream is not None and not do_gather:
-        s0.eng.bind_meshlet_stream(None)
-        lat = []
-        for _ in range(6):
-            a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(s0.stream)
-            cull(s0, 0)
-            z.record(s0.stream)
-            torch.cuda.synchronize()
-            lat.append(a.elapsed_time(z))
-        buffer_path_latency_ms = float(np.median(lat[1:]))
-        s0.eng.bind_meshlet_stream(mstream)
     serial, op_ms, x_ms, ex_ms = [], [], [], []
     last_recv = 0
     for _ in range(5):
@@ -397,6 +383,32 @@ def main():
             x_ms.append(xa.elapsed_time(xm))
             if visible_exchange:
                 ex_ms.append(xm.elapsed_time(xz))
+    # the same frames from the 32-B Meshlet buffer (stream unbound), for the record, outside any metric
+    buffer_path_latency_ms = buffer_path_ms_per_step = None
+    if mstream is not None and not do_gather:
+        s0.eng.bind_meshlet_stream(None)
+        # K of them back to back (the timed region's loop, stream unbound; K more in front as its warm-up) ...
+        for _ in range(args.steps):
+            cull(s0, 0)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            cull(s0, 0)
+        torch.cuda.synchronize()
+        buffer_path_ms_per_step = (time.perf_counter() - tb) / args.steps * 1e3
+        # ... and five alone
+        lat = []
+        for _ in range(6):
+            a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(s0.stream)
+            cull(s0, 0)
+            z.record(s0.stream)
+            torch.cuda.synchronize()
+            lat.append(a.elapsed_time(z))
+        buffer_path_latency_ms = float(np.median(lat[1:]))
+        s0.eng.bind_meshlet_stream(mstream)
+        cull(s0, 0)  # slot 0's buffers hold the stream path's result again: that is what gets checked below
+        torch.cuda.synchronize()
     frame_latency_ms = float(np.median(serial))
     kernel_ms = float(np.median(op_ms))  # whole meshlet_cull op (eval + scan + emit) of a frame alone on the device
     exchange_ms = float(np.median(x_ms)) if x_ms else None
@@ -532,6 +544,7 @@ def main():
             "cpu_baseline": cpu_baseline,
             "frame_latency_ms": frame_latency_ms,
             "frame_latency_ms_from_meshlet_buffer": buffer_path_latency_ms,
+            "ms_per_step_from_meshlet_buffer": buffer_path_ms_per_step,
             "per_rank": {"cull_ms_max": kernel_ms_max_frame, "exchange_ms_max": exchange_ms_max,
                          "expand_ms_max": expand_ms_max,
                          "what": "one frame alone on each rank's device: entity_cull + meshlet_cull of its shard, the "
