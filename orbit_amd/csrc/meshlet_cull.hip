@@ -26,6 +26,10 @@
 //                pass 2 the HiZ test runs on candidates compacted in LDS.
 //   pass 1     : meshlet_pass1_kernel is list-driven — only meshlets whose
 //                last-frame bit is set are read at all.
+//   streams    : with derived meshlet streams bound (orbit_meshlet_stream_*; kernels.h
+//                MeshletStreamView) passes 0 / 2 read 22 B per meshlet instead of
+//                the 32-B Meshlet and keep no survivor payload; the emit launch
+//                gathers the survivors' 12 command bytes (template flag STREAM).
 //   outputs    : MeshletDrawCommandBuffer (meshlet_emit_kernel<false>), the
 //                sharded engine's 8-B visible list (<true>) with
 //                visible_expand_kernel on the receiving side, or per-record
@@ -210,8 +214,8 @@ __device__ __forceinline__ MeshletVerdict eval_meshlet(const MeshletCullParams &
     return {visible, should_draw_of(visible, abits, visible_in_buffer, PASS == 2 && meshlet_occ)};
 }
 
-// Issues the meshlet loads of rows R0 .. R0+NR-1 of a tile (2 x 16 B per lane per row; STREAM: 16 + 8 B from the
-// derived streams — words y/z of `b`, which only a command needs, stay zero).
+// Issues the meshlet loads of rows R0 .. R0+NR-1 of a tile (2 x 16 B per lane per row; STREAM: 16 + 4 + 2 B from the
+// derived streams — words y/z of `b` and the counts in w, which only a command needs, stay zero).
 template <int PASS, int R0, int NR, bool STREAM = false>
 __device__ __forceinline__ void rows_load(const MeshletCullParams &p, const WaveTileLds &L, int lane,
                                           RowRegs<NR> &t) {

@@ -1039,6 +1039,8 @@ def test_cull_views_early_pass_and_cascades(torch_mod, oracle):
                           draw_capacity=draw_cap, visibility_buffer=e_d, meshlet_visibility_buffer=m_d,
                           skip_meshlet_stage=(k == len(cis) - 1)))
     for rep in range(2):
+        if rep == 1:  # a bound meshlet stream changes nothing for the views (they read the Meshlet buffer)
+            eng.bind_meshlet_stream(eng.meshlet_stream(gs.meshlets, 0, len(scene.meshlets)))
         eng.cull_views(views)
         torch.cuda.synchronize()
         eng.status()
