@@ -136,6 +136,47 @@ __global__ __launch_bounds__(256) void eval_split_wide(const uint4 *a1, const ui
     }
 }
 
+// AoSoA: the same 16 + 4 B per meshlet, but interleaved per group of 32 meshlets (512 B of spheres, then 128 B of
+// cones: 640 B per group) instead of two arrays — one DRAM stream per wave instead of two.
+__global__ __launch_bounds__(256) void eval_split_aosoa(const unsigned char *g, size_t n_tiles,
+                                                        unsigned long long *masks, unsigned *counts) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t stride = (size_t)gridDim.x * 4;
+    for (size_t t = (size_t)blockIdx.x * 4 + wave; t < n_tiles; t += stride) {
+        // meshlet t*512 + r*64 + lane: group = t*16 + r*2 + lane/32, k = lane % 32
+        const unsigned char *base = g + (t * 16 + (lane >> 5)) * 640 + (lane & 31) * 16;
+        const unsigned char *cbase = g + (t * 16 + (lane >> 5)) * 640 + 512 + (lane & 31) * 4;
+        uint4 s0 = *(const uint4 *)base;
+        unsigned c0 = *(const unsigned *)cbase;
+        unsigned total = 0;
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint4 s1 = s0;
+            unsigned c1 = c0;
+            if (r < 7) {
+                s1 = *(const uint4 *)(base + (r + 1) * 1280);
+                c1 = *(const unsigned *)(cbase + (r + 1) * 1280);
+            }
+            const bool keep = ((s0.x + (c0 >> 31)) & 1023u) < kKeep;
+            const unsigned long long m = __ballot(keep);
+            if (lane == r) mine = m;
+            total += __popcll(m);
+            s0 = s1; c0 = c1;
+        }
+        if (lane < 8) masks[t * 8 + lane] = mine;
+        if (lane == 0) counts[t] = total;
+    }
+}
+
+__global__ void fill_aosoa(unsigned char *g, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t grp = i >> 5, k = i & 31;
+        *(uint4 *)(g + grp * 640 + k * 16) = make_uint4(hash32((unsigned)i), 1, 2, 3);
+        *(unsigned *)(g + grp * 640 + 512 + k * 4) = 0u;
+    }
+}
+
 struct Cmd { unsigned w[7]; };
 
 __device__ __forceinline__ void put_cmd(unsigned *out, size_t slot, unsigned y, unsigned z, unsigned w, unsigned idx) {
@@ -211,6 +252,9 @@ int main() {
     hipMalloc(&b, n * 12); hipMalloc(&counts, n_tiles * 4); hipMalloc(&offs, n_tiles * 4);
     hipMalloc(&pay, n_tiles * 128 * 12); hipMalloc(&masks, n_tiles * 72); hipMalloc(&out, (n / 8) * 28);
     hipMemset(a2n, 0, n * 4);
+    unsigned char *gso;
+    hipMalloc(&gso, n * 20);
+    hipLaunchKernelGGL(fill_aosoa, dim3(4096), dim3(256), 0, 0, gso, n);
     hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, aos, a1, a2, b, n);
     const int blocks = 256 * 4;
     hipLaunchKernelGGL(eval_aos, dim3(blocks), dim3(256), 0, 0, aos, n_tiles, pay, counts);
@@ -240,6 +284,8 @@ int main() {
         printf("split 16+4, outputs per tile: ballots + count (2 stores) %.4f | one 72-B store %.4f | ballots only %.4f ms\n", e4, o1, o3);
         const float ew = time_kernel([&] { hipLaunchKernelGGL(eval_split_wide, dim3(blocks), dim3(256), 0, 0, a1, (const uint4 *)a2n, n_tiles, masks, counts); });
         printf("split 16+4: cones as one dword load per row %.4f | as two dwordx4 loads per tile %.4f ms\n", e4, ew);
+        const float ea2 = time_kernel([&] { hipLaunchKernelGGL(eval_split_aosoa, dim3(blocks), dim3(256), 0, 0, gso, n_tiles, masks, counts); });
+        printf("split 16+4: two arrays %.4f | interleaved per 32 meshlets (640-B groups) %.4f ms\n", e4, ea2);
         float mp[3], g12[3], g32[3];
         const int grids[3] = {blocks, blocks * 2, blocks * 4};
         for (int g = 0; g < 3; g++) {
