@@ -274,10 +274,14 @@ __device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTi
         const uint4 rec = L.rec[rid];
         const bool active = ml < rec.z;
         MeshletVerdict v = {false, false};
+#ifdef ORBIT_TRIAGE_NO_EVAL // scratch builds only (tools/mkvariant_any.sh): a free predicate with the same survival ratio
+        if (active) v.visible = v.should_draw = ((t.a[k].x + (t.b[k].x >> 31)) % 1000u) < 95u;
+#else
         if (active) {
             const bool visible_in_buffer = rw_vis ? ((t.prev[k] >> ml) & 1u) != 0 : true;
             v = eval_meshlet<PASS, PROJ>(p, L, P, rid, t.a[k], t.b[k], abits[k], visible_in_buffer, meshlet_occ);
         }
+#endif
         const uint64_t mask = __ballot(v.should_draw);
         if (lane == 0) L.draw_mask[r] = mask;
         if (payload && v.should_draw) {
@@ -418,6 +422,9 @@ __device__ __forceinline__ uint4 setup_load_rec(const MeshletCullParams &p, uint
 
 __device__ __forceinline__ float4 setup_load_mat(const MeshletCullParams &p, const uint4 &rec, int lane) {
     // meshlet_count == 0 marks "no record" (zero page above): read zeros instead of entity 0
+#ifdef ORBIT_TRIAGE_NO_MAT
+    return *reinterpret_cast<const float4 *>(p.zero_page);
+#endif
     const float4 *src = rec.z != 0u ? reinterpret_cast<const float4 *>(p.entities[rec.x].model_matrix) + (lane & 3)
                                     : reinterpret_cast<const float4 *>(p.zero_page);
     return *src;

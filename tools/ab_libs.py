@@ -39,7 +39,7 @@ for eng in engs:
     torch.cuda.synchronize()
     n = int(draw[:4].view(torch.int32).item())
     cur = draw[:4 + 28 * n].clone()
-    assert ref is None or torch.equal(ref, cur), "builds disagree on the draw list"
+    assert ref is None or os.environ.get("CHECK", "1") == "0" or torch.equal(ref, cur), "builds disagree on the draw list"
     ref = cur
 R = int(os.environ.get("REPS", 30))
 tf, tm, te = [[] for _ in engs], [[] for _ in engs], [[] for _ in engs]
