@@ -503,9 +503,9 @@ int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t cou
 /* survivors' 12 B (nothing for the visible list), and orbit_expand_visible  */
 /* gathers 12 B instead of touching the survivors' Meshlets.  Results are    */
 /* bit-identical to the plain path (every test of tests/test_gpu_parity.py   */
-/* runs both ways).  Pass 1 (list-driven gathers), orbit_cull_views and any  */
-/* call with another meshlet_buffer pointer read the Meshlet buffer as       */
-/* before.                                                                   */
+/* runs both ways).  orbit_cull_views applies the same rule per view.  Pass 1 */
+/* (list-driven gathers) and any call with another meshlet_buffer pointer    */
+/* read the Meshlet buffer as before.                                        */
 /*                                                                           */
 /*   create   arrays for global meshlet indices [first_meshlet,              */
 /*            first_meshlet + capacity) (device memory: 34 B x capacity)     */
@@ -526,8 +526,8 @@ int32_t orbit_meshlet_stream_update(OrbitCtx *ctx, OrbitMeshletStream *ms, const
                                     uint64_t first, uint64_t count, void *stream);
 int32_t orbit_meshlet_stream_destroy(OrbitMeshletStream *ms);
 int32_t orbit_ctx_bind_meshlet_stream(OrbitCtx *ctx, const OrbitMeshletStream *ms);
-/* Calls this context has served from a bound stream so far — meshlet culls of passes 0 and 2 and
- * orbit_expand_visible (tests and integration checks: a call whose meshlet_buffer is not the stream's source
+/* Calls this context has served from a bound stream so far — meshlet culls of passes 0 and 2 (each such view of
+ * orbit_cull_views counts) and orbit_expand_visible (tests and integration checks: a call whose meshlet_buffer is not the stream's source
  * silently takes the plain path). */
 uint64_t orbit_ctx_meshlet_stream_culls(const OrbitCtx *ctx);
 

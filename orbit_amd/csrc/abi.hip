@@ -582,6 +582,8 @@ int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t cou
     e = launch_entity_cull_views(ev, count, max_draws, s);
     if (e == hipSuccess) e = launch_meshlet_cull_views(mv, n_mesh, ctx->num_cus, s);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch cull_views");
+    for (uint32_t i = 0; i < n_mesh; i++)
+        if (mv.v[i].ms.sphere && mv.v[i].ci.occlusion_pass != 1) ctx->stream_culls++;
     return ORBIT_OK;
 }
 

@@ -661,10 +661,10 @@ __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_k
     meshlet_eval_body<PASS, PROJ, PROF, STREAM>(p);
 }
 // several views in one launch (orbit_cull_views): the views' parameter blocks by value, blockIdx.y picks one
-template <int PASS, int PROJ>
+template <int PASS, int PROJ, bool STREAM>
 __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_views_kernel(const MeshletCullViews all,
                                                                                            const ViewGroup g) {
-    meshlet_eval_body<PASS, PROJ, false>(all.v[g.idx[blockIdx.y]]);
+    meshlet_eval_body<PASS, PROJ, false, STREAM>(all.v[g.idx[blockIdx.y]]);
 }
 
 // ---------------------------------------------------------------------------
@@ -1014,8 +1014,9 @@ template <bool VISIBLE, bool STREAM = false>
 __global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullParams p) {
     meshlet_emit_body<VISIBLE, STREAM>(p);
 }
-__global__ __launch_bounds__(256) void meshlet_emit_views_kernel(const MeshletCullViews all) {
-    meshlet_emit_body<false>(all.v[blockIdx.y]);
+template <bool STREAM>
+__global__ __launch_bounds__(256) void meshlet_emit_views_kernel(const MeshletCullViews all, const ViewGroup g) {
+    meshlet_emit_body<false, STREAM>(all.v[g.idx[blockIdx.y]]);
 }
 
 // Visible list -> MeshletDrawCommandBuffer (meshlet_cull.comp:216-230 for survivors that were culled on another GPU):
@@ -1271,14 +1272,18 @@ hipError_t launch_meshlet_cull_views(const MeshletCullViews &all, uint32_t n, ui
         if ((t + kScanChunk - 1) / kScanChunk > kEmitChunkTable) return hipErrorInvalidValue;
         max_tiles_all = max(max_tiles_all, t);
     }
+    // a view evaluates from the derived meshlet streams when its block carries them and its pass streams (0 / 2)
+    auto from_stream = [&](uint32_t i) { return host[i].ci.occlusion_pass != 1 && host[i].ms.sphere != nullptr; };
     bool done[ORBIT_MAX_CULL_VIEWS] = {};
     for (uint32_t i = 0; i < n; i++) {
         if (done[i]) continue;
         const uint32_t pass = host[i].ci.occlusion_pass, proj = host[i].ci.projection_type;
+        const bool stream = from_stream(i);
         ViewGroup g{};
         uint32_t m = 0, need = 1;
         for (uint32_t j = i; j < n; j++)
-            if (!done[j] && host[j].ci.occlusion_pass == pass && host[j].ci.projection_type == proj) {
+            if (!done[j] && host[j].ci.occlusion_pass == pass && host[j].ci.projection_type == proj &&
+                from_stream(j) == stream) {
                 done[j] = true;
                 g.idx[m++] = (uint8_t)j;
                 const uint32_t t = (host[j].dispatch_capacity + kTileRecords - 1) / kTileRecords;
@@ -1293,11 +1298,21 @@ hipError_t launch_meshlet_cull_views(const MeshletCullViews &all, uint32_t n, ui
             if (ortho) hipLaunchKernelGGL((meshlet_pass1_views_kernel<1>), grid, block, 0, s, all, g);
             else hipLaunchKernelGGL((meshlet_pass1_views_kernel<0>), grid, block, 0, s, all, g);
         } else if (pass == 0) {
-            if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<0, 1>), grid, block, 0, s, all, g);
-            else hipLaunchKernelGGL((meshlet_eval_views_kernel<0, 0>), grid, block, 0, s, all, g);
+            if (stream) {
+                if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<0, 1, true>), grid, block, 0, s, all, g);
+                else hipLaunchKernelGGL((meshlet_eval_views_kernel<0, 0, true>), grid, block, 0, s, all, g);
+            } else {
+                if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<0, 1, false>), grid, block, 0, s, all, g);
+                else hipLaunchKernelGGL((meshlet_eval_views_kernel<0, 0, false>), grid, block, 0, s, all, g);
+            }
         } else {
-            if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<2, 1>), grid, block, 0, s, all, g);
-            else hipLaunchKernelGGL((meshlet_eval_views_kernel<2, 0>), grid, block, 0, s, all, g);
+            if (stream) {
+                if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<2, 1, true>), grid, block, 0, s, all, g);
+                else hipLaunchKernelGGL((meshlet_eval_views_kernel<2, 0, true>), grid, block, 0, s, all, g);
+            } else {
+                if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<2, 1, false>), grid, block, 0, s, all, g);
+                else hipLaunchKernelGGL((meshlet_eval_views_kernel<2, 0, false>), grid, block, 0, s, all, g);
+            }
         }
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -1313,8 +1328,19 @@ hipError_t launch_meshlet_cull_views(const MeshletCullViews &all, uint32_t n, ui
     const uint32_t eneed = (max_tiles_all + 3) / 4;
     if (eblocks > eneed) eblocks = eneed;
     if (eblocks == 0) eblocks = 1;
-    hipLaunchKernelGGL(meshlet_emit_views_kernel, dim3(eblocks, n), dim3(256), 0, s, all);
-    return hipGetLastError();
+    // the emit launch of the views whose evaluation kept a payload, and of those that kept only ballots
+    for (int stream = 0; stream < 2; stream++) {
+        ViewGroup g{};
+        uint32_t m = 0;
+        for (uint32_t i = 0; i < n; i++)
+            if (from_stream(i) == (stream != 0)) g.idx[m++] = (uint8_t)i;
+        if (m == 0) continue;
+        if (stream) hipLaunchKernelGGL(meshlet_emit_views_kernel<true>, dim3(eblocks, m), dim3(256), 0, s, all, g);
+        else hipLaunchKernelGGL(meshlet_emit_views_kernel<false>, dim3(eblocks, m), dim3(256), 0, s, all, g);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_scatter_list(const ScatterListParams &p, uint32_t num_cus, hipStream_t s) {

@@ -1039,11 +1039,12 @@ def test_cull_views_early_pass_and_cascades(torch_mod, oracle):
                           draw_capacity=draw_cap, visibility_buffer=e_d, meshlet_visibility_buffer=m_d,
                           skip_meshlet_stage=(k == len(cis) - 1)))
     for rep in range(2):
-        if rep == 1:  # a bound meshlet stream changes nothing for the views (they read the Meshlet buffer)
+        if rep == 1:  # second call: the four pass-0 cascades cull from the derived meshlet streams, pass 1 does not
             eng.bind_meshlet_stream(eng.meshlet_stream(gs.meshlets, 0, len(scene.meshlets)))
         eng.cull_views(views)
         torch.cuda.synchronize()
         eng.status()
+        assert eng.meshlet_stream_culls() == (4 if rep == 1 else 0)
         drawn = []
         for k, (ci, (disp, draw, e_d, m_d)) in enumerate(zip(cis, bufs)):
             ref = run_oracle(oracle, scene, ci, evis if k == 0 else None, mvis if k == 0 else None)

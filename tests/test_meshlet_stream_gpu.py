@@ -156,6 +156,61 @@ def test_pass1_keeps_reading_the_meshlet_buffer(torch_mod, engine, oracle):
     ms.close()
 
 
+def test_cull_views_from_the_stream(torch_mod, oracle):
+    """orbit_cull_views with a bound stream: a late pass (occlusion_pass 2 with meshlet occlusion: HiZ candidates in the
+    LDS ring), a single-pass perspective view and a pass-1 view side by side — the first two evaluate from the
+    streams, pass 1 from the Meshlet buffer; every view equals the oracle."""
+    from orbit_amd.engine import Engine
+
+    torch = torch_mod
+    W, H = 320, 180
+    scene = sc.make_scene(11, 1800, n_meshes=250, extent=(60.0, 12.0, 60.0))
+    cam = sc.default_camera()
+    gs = GpuScene(torch, scene)
+    rng = np.random.default_rng(7)
+    evis = rng.integers(0, 2 ** 32, (scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+    mvis = rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32)
+    depth = sc.make_depth(9, W, H, cam)
+    opyr, d = oracle.depth_reduce(depth, W, H)
+    ps = (d.width, d.height)
+    cis = [sc.make_cull_info(cam.view, cam.planes, occlusion_pass=2, p00=cam.p00, p11=cam.p11, z_near=cam.z_near),
+           sc.make_cull_info(cam.view, cam.planes),
+           sc.make_cull_info(cam.view, cam.planes, occlusion_pass=1)]
+    eng = Engine(0, max_entities=8192, max_dispatches=40_000, max_draws=200_000, max_views=3)
+    eng.bind_meshlet_stream(eng.meshlet_stream(gs.meshlets, 0, len(scene.meshlets)))
+    disp_cap, draw_cap = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
+    pyr = dev(torch, opyr)
+    views, bufs = [], []
+    for ci in cis:
+        occ = int(ci["occlusion_pass"]) != 0
+        disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device="cuda")
+        draw = torch.zeros(L.DRAW_HEADER + 28 * draw_cap, dtype=torch.uint8, device="cuda")
+        e_d, m_d = (dev(torch, evis), dev(torch, mvis)) if occ else (None, None)
+        bufs.append((disp, draw, e_d, m_d))
+        v = dict(cull_info=ci, entity_draw_buffer=gs.draws, mesh_info_buffer=gs.mesh_infos,
+                 meshlet_dispatch_buffer=disp, entity_buffer=gs.entities, entity_draw_count=scene.entity_draw_count,
+                 dispatch_capacity=disp_cap, meshlet_buffer=gs.meshlets, draw_commands_buffer=draw,
+                 material_buffer=gs.materials, draw_capacity=draw_cap, visibility_buffer=e_d,
+                 meshlet_visibility_buffer=m_d, material_count=len(scene.materials))
+        if int(ci["occlusion_pass"]) == 2:
+            v.update(depth_pyramid=pyr, depth_pyramid_size=ps)
+        views.append(v)
+    eng.cull_views(views)
+    torch.cuda.synchronize()
+    eng.status()
+    assert eng.meshlet_stream_culls() == 2
+    n_drawn = []
+    for ci, (disp, draw, e_d, m_d) in zip(cis, bufs):
+        p = int(ci["occlusion_pass"])
+        ref = run_oracle(oracle, scene, ci, evis if p else None, mvis if p else None, opyr if p == 2 else None,
+                         ps if p == 2 else (0, 0))
+        _, cmds = assert_same((host(disp), host(draw), None if e_d is None else host(e_d, np.uint32),
+                               None if m_d is None else host(m_d, np.uint32)), ref)
+        n_drawn.append(len(cmds))
+    assert all(n > 0 for n in n_drawn), n_drawn
+    eng.close()
+
+
 def test_meshlet_outside_the_stream_latches_range_error(torch_mod, engine, oracle):
     """A stream that does not cover what is culled: no out-of-range read, ORBIT_E_RANGE in the context's status; the
     covered part of the scene is still culled correctly."""
