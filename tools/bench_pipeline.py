@@ -32,6 +32,10 @@ for _ in range(FMAX):
                       disp=torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device=dev),
                       draw=torch.zeros(L.DRAW_HEADER + 28 * draw_cap, dtype=torch.uint8, device=dev)))
 
+if os.environ.get("STREAM", "1") == "1":  # cull from the derived meshlet streams (one stream, bound to every slot)
+    ms = slots[0]["eng"].meshlet_stream(meshlets, 0, E * M)
+    for s in slots:
+        s["eng"].bind_meshlet_stream(ms)
 
 for s in slots:
     s["cull_done"] = torch.cuda.Event()
