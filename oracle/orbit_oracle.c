@@ -227,35 +227,40 @@ static float largest_scale_from_matrix(const float *m) {
     return sqrtf(gmax(dx, gmax(dy, dz)));
 }
 
-/* transform_sphere, entity_cull.comp:37-43 */
-static void transform_sphere(const float *m, const float *sphere, float *out) {
+/* transform_sphere, entity_cull.comp:37-43.  `scale` (optional) receives largest_scale_from_matrix: the compiled
+ * shaders contract sphere.w * scale into three fused operations of the occlusion test (occlusion_test below). */
+static void transform_sphere(const float *m, const float *sphere, float *out, float *scale) {
     float v[4] = {sphere[0], sphere[1], sphere[2], 1.0f}, p[4];
     mat4_mul_vec4(m, v, p);
     out[0] = p[0] / p[3];
     out[1] = p[1] / p[3];
     out[2] = p[2] / p[3];
-    out[3] = sphere[3] * largest_scale_from_matrix(m);
+    const float sc = largest_scale_from_matrix(m);
+    out[3] = sphere[3] * sc;
+    if (scale) *scale = sc;
 }
 
-/* project_sphere, entity_cull.comp:83-102 (Mara & McGuire 2013) */
+/* project_sphere, entity_cull.comp:83-102 (Mara & McGuire 2013), as compiled (entity_cull.comp.spv /
+ * meshlet_cull.comp.spv, identical in both): dot(c, c) - r * r is one fused operation fma(-r, r, dot(c, c)), and the
+ * remap aabb.xwzy * (0.5, -0.5, 0.5, -0.5) + 0.5 is one fused operation per component. */
 static void project_sphere(const float *s, float p00, float p11, float *aabb) {
     float r = s[3];
     float cxx = -s[0], cxy = -s[2];
-    float vxx = sqrtf(dot2(cxx, cxy, cxx, cxy) - r * r), vxy = r;
+    float vxx = sqrtf(fmaf(-r, r, dot2(cxx, cxy, cxx, cxy))), vxy = r;
     /* mat2(vx.x, vx.y, -vx.y, vx.x) * cx : columns (vx.x,vx.y), (-vx.y,vx.x) */
     float minx_x = vxx * cxx + (-vxy) * cxy, minx_y = vxy * cxx + vxx * cxy;
     float maxx_x = vxx * cxx + vxy * cxy, maxx_y = (-vxy) * cxx + vxx * cxy;
     float cyx = -s[1], cyy = -s[2];
-    float vyx = sqrtf(dot2(cyx, cyy, cyx, cyy) - r * r), vyy = r;
+    float vyx = sqrtf(fmaf(-r, r, dot2(cyx, cyy, cyx, cyy))), vyy = r;
     float miny_x = vyx * cyx + (-vyy) * cyy, miny_y = vyy * cyx + vyx * cyy;
     float maxy_x = vyx * cyx + vyy * cyy, maxy_y = (-vyy) * cyx + vyx * cyy;
     float a0 = minx_x / minx_y * p00, a1 = miny_x / miny_y * p11;
     float a2 = maxx_x / maxx_y * p00, a3 = maxy_x / maxy_y * p11;
     /* aabb.xwzy * (0.5,-0.5,0.5,-0.5) + 0.5 */
-    aabb[0] = a0 * 0.5f + 0.5f;
-    aabb[1] = a3 * -0.5f + 0.5f;
-    aabb[2] = a2 * 0.5f + 0.5f;
-    aabb[3] = a1 * -0.5f + 0.5f;
+    aabb[0] = fmaf(a0, 0.5f, 0.5f);
+    aabb[1] = fmaf(a3, -0.5f, 0.5f);
+    aabb[2] = fmaf(a2, 0.5f, 0.5f);
+    aabb[3] = fmaf(a1, -0.5f, 0.5f);
 }
 
 /* Test hook: project_sphere on its own, so that it can be compared with the host mirror of the reference's CPU twin
@@ -264,30 +269,33 @@ void oracle_project_sphere(const float *sphere, float p00, float p11, float *aab
     project_sphere(sphere, p00, p11, aabb_uv);
 }
 
-/* Pass-2 occlusion test shared by entity_cull.comp:146-191 and
- * meshlet_cull.comp:160-205.  Mutates sphere[2] in the perspective branch
- * (the mutation persists into the LOD distance, entity_cull.comp:155,204). */
-static int occlusion_test(const OrbitGpuCullInfo *ci, float *sphere, const float *pyr, uint32_t pw,
-                          uint32_t ph) {
+/* Pass-2 occlusion test shared by entity_cull.comp:146-191 and meshlet_cull.comp:160-205, operation by operation as
+ * the compiled shaders hold it (the two binaries agree).  spirv-opt's floating-point folding left its marks here:
+ * `sphere.w + z_near`, `sphere.z - sphere.w` and `sphere.z + sphere.w` are fused with the product sphere.w =
+ * radius * scale that feeds them (radius = the model-space radius, scale = largest_scale_from_matrix), the
+ * orthographic box is fma(size, (-1,-1,1,1), center), and closest_z * r + r * z_far became r * (closest_z + z_far).
+ * Mutates sphere[2] in the perspective branch (the mutation persists into the LOD distance, entity_cull.comp:155,204). */
+static int occlusion_test(const OrbitGpuCullInfo *ci, float *sphere, float radius, float scale, const float *pyr,
+                          uint32_t pw, uint32_t ph) {
     int cullable = 1;
     float aabb[4], closest;
     if (ci->projection_type == 0) {
         sphere[2] = -sphere[2];
-        cullable = sphere[2] >= sphere[3] + ci->z_near;
+        cullable = sphere[2] >= fmaf(radius, scale, ci->z_near);
         project_sphere(sphere, ci->p00_or_width_recipx2, ci->p11_or_height_recipx2, aabb);
-        closest = ci->z_near / (sphere[2] - sphere[3]);
+        closest = ci->z_near / fmaf(-radius, scale, sphere[2]);
     } else {
         float sr = ci->p00_or_width_recipx2; /* vec2(p00): both axes, quirk 9 */
         float cx = sphere[0] * sr, cy = sphere[1] * sr;
         float bs = sr * sphere[3];
-        float b0 = cx + bs * -1.0f, b1 = cy + bs * -1.0f, b2 = cx + bs * 1.0f, b3 = cy + bs * 1.0f;
-        aabb[0] = gclamp(b0, -1.0f, 1.0f) * 0.5f + 0.5f;
-        aabb[1] = gclamp(b1, -1.0f, 1.0f) * -0.5f + 0.5f;
-        aabb[2] = gclamp(b2, -1.0f, 1.0f) * 0.5f + 0.5f;
-        aabb[3] = gclamp(b3, -1.0f, 1.0f) * -0.5f + 0.5f;
-        float closest_z = sphere[2] + sphere[3];
+        float b0 = fmaf(bs, -1.0f, cx), b1 = fmaf(bs, -1.0f, cy), b2 = fmaf(bs, 1.0f, cx), b3 = fmaf(bs, 1.0f, cy);
+        aabb[0] = fmaf(gclamp(b0, -1.0f, 1.0f), 0.5f, 0.5f);
+        aabb[1] = fmaf(gclamp(b1, -1.0f, 1.0f), -0.5f, 0.5f);
+        aabb[2] = fmaf(gclamp(b2, -1.0f, 1.0f), 0.5f, 0.5f);
+        aabb[3] = fmaf(gclamp(b3, -1.0f, 1.0f), -0.5f, 0.5f);
+        float closest_z = fmaf(radius, scale, sphere[2]);
         float r = 1.0f / (ci->z_far - ci->z_near);
-        closest = closest_z * r + (r * ci->z_far);
+        closest = r * (closest_z + ci->z_far);
     }
     if (!cullable) return 1;
     float width = (aabb[2] - aabb[0]) * (float)pw;
@@ -295,6 +303,16 @@ static int occlusion_test(const OrbitGpuCullInfo *ci, float *sphere, const float
     float u = (aabb[0] + aabb[2]) * 0.5f, v = (aabb[1] + aabb[3]) * 0.5f;
     float sampled = oracle_hiz_sample(pyr, pw, ph, u, v, orbit_log2f(gmax(width, height)));
     return closest >= sampled;
+}
+
+/* int(i8) / 127.0 (meshlet_cull.comp:121-122) as the compiled shader evaluates it: spirv-opt folded the division
+ * by a constant into a multiplication by its reciprocal (meshlet_cull.comp.spv: OpFMul by 0x3C010204).  16 of the 256
+ * inputs differ from the IEEE quotient by one ulp. */
+static inline float snorm8(int8_t v) { return (float)(int)v * bits2f(0x3C010204u); }
+
+/* coneCull (meshlet_cull.comp:104-106) as compiled: dot(d, axis) >= fma(cutoff, length(d), radius) */
+static inline int cone_cull(const float *d, const float *axis, float cutoff, float radius) {
+    return dot3(d, axis) >= fmaf(cutoff, sqrtf(dot3(d, d)), radius);
 }
 
 static int plane_test(const OrbitGpuCullInfo *ci, const float *sphere) {
@@ -343,9 +361,10 @@ uint32_t oracle_entity_cull(const OrbitGpuCullInfo *ci, const uint8_t *entity_dr
         if (ci->occlusion_pass == 1) visible = visible_in_buffer;
         float mv[16], sphere[4];
         mat4_mul(ci->view_matrix, en->model_matrix, mv);
-        transform_sphere(mv, mi->bounding_sphere, sphere);
+        float scale;
+        transform_sphere(mv, mi->bounding_sphere, sphere, &scale);
         if (visible) visible = plane_test(ci, sphere);
-        if (ci->occlusion_pass == 2 && visible) visible = occlusion_test(ci, sphere, pyr, pw, ph);
+        if (ci->occlusion_pass == 2 && visible) visible = occlusion_test(ci, sphere, mi->bounding_sphere[3], scale, pyr, pw, ph);
         int should_draw = visible;
         if (ci->occlusion_pass == 2) should_draw = visible && (!visible_in_buffer || meshlet_occ);
         if (should_draw) {
@@ -409,12 +428,13 @@ uint32_t oracle_meshlet_cull(const OrbitGpuCullInfo *ci, const uint8_t *dispatch
             uint32_t meshlet_index = rec.meshlet_offset + lane;
             const OrbitMeshlet *m = &meshlets[meshlet_index];
             float sphere[4];
-            transform_sphere(mv, m->bounding_sphere, sphere);
-            float ax[4] = {(float)(int)m->cone_axis[0] / 127.0f, (float)(int)m->cone_axis[1] / 127.0f,
-                           (float)(int)m->cone_axis[2] / 127.0f, 0.0f};
+            float scale;
+            transform_sphere(mv, m->bounding_sphere, sphere, &scale);
+            float ax[4] = {snorm8(m->cone_axis[0]), snorm8(m->cone_axis[1]),
+                           snorm8(m->cone_axis[2]), 0.0f};
             float axis[4];
             mat4_mul_vec4(mv, ax, axis);
-            float cutoff = (float)(int)m->cone_cutoff / 127.0f;
+            float cutoff = snorm8(m->cone_cutoff);
             uint32_t alpha_mode = materials[m->material_index].alpha_mode;
             int visible = 1, visible_in_buffer = 1;
             if (rw) visible_in_buffer = (prev_word & (1u << (lane % 32))) != 0;
@@ -430,12 +450,12 @@ uint32_t oracle_meshlet_cull(const OrbitGpuCullInfo *ci, const uint8_t *dispatch
                 }
                 if (ci->projection_type <= 1) {
                     float d[3] = {sphere[0] - cam[0], sphere[1] - cam[1], sphere[2] - cam[2]};
-                    int cull = dot3(d, axis) >= cutoff * sqrtf(dot3(d, d)) + sphere[3];
+                    int cull = cone_cull(d, axis, cutoff, sphere[3]);
                     visible = !cull;
                 }
             }
             if (meshlet_occ && ci->occlusion_pass == 2 && visible)
-                visible = occlusion_test(ci, sphere, pyr, pw, ph);
+                visible = occlusion_test(ci, sphere, m->bounding_sphere[3], scale, pyr, pw, ph);
             int should_draw = visible && ((shl1(alpha_mode) & ci->alpha_mode_flag) != 0);
             if ((ci->occlusion_pass == 2 && meshlet_occ) && !((shl1(alpha_mode) & ci->noskip_alphamode) != 0))
                 should_draw = visible && !visible_in_buffer;
@@ -493,12 +513,13 @@ void oracle_meshlet_task_cull(const OrbitGpuCullInfo *ci, const uint8_t *dispatc
                 uint32_t meshlet_index = rec.meshlet_offset + lane;
                 const OrbitMeshlet *m = &meshlets[meshlet_index];
                 float sphere[4];
-                transform_sphere(mv, m->bounding_sphere, sphere);
-                float ax[4] = {(float)(int)m->cone_axis[0] / 127.0f, (float)(int)m->cone_axis[1] / 127.0f,
-                               (float)(int)m->cone_axis[2] / 127.0f, 0.0f};
+                float scale;
+                transform_sphere(mv, m->bounding_sphere, sphere, &scale);
+                float ax[4] = {snorm8(m->cone_axis[0]), snorm8(m->cone_axis[1]),
+                               snorm8(m->cone_axis[2]), 0.0f};
                 float axis[4];
                 mat4_mul_vec4(mv, ax, axis);
-                float cutoff = (float)(int)m->cone_cutoff / 127.0f;
+                float cutoff = snorm8(m->cone_cutoff);
                 uint32_t alpha_mode = materials[m->material_index].alpha_mode;
                 int visible_in_buffer = 1;
                 if (rw) visible_in_buffer = (prev_word & (1u << (lane % 32))) != 0;
@@ -513,12 +534,12 @@ void oracle_meshlet_task_cull(const OrbitGpuCullInfo *ci, const uint8_t *dispatc
                     }
                     if (ci->projection_type <= 1) {
                         float d[3] = {sphere[0] - cam[0], sphere[1] - cam[1], sphere[2] - cam[2]};
-                        int cull = dot3(d, axis) >= cutoff * sqrtf(dot3(d, d)) + sphere[3];
+                        int cull = cone_cull(d, axis, cutoff, sphere[3]);
                         visible = !cull;
                     }
                 }
                 if (meshlet_occ && ci->occlusion_pass == 2 && visible)
-                    visible = occlusion_test(ci, sphere, pyr, pw, ph);
+                    visible = occlusion_test(ci, sphere, m->bounding_sphere[3], scale, pyr, pw, ph);
                 int should_draw = visible && ((shl1(alpha_mode) & ci->alpha_mode_flag) != 0);
                 if ((ci->occlusion_pass == 2 && meshlet_occ) && !((shl1(alpha_mode) & ci->noskip_alphamode) != 0))
                     should_draw = visible && !visible_in_buffer;

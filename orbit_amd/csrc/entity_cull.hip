@@ -66,10 +66,11 @@ __device__ __forceinline__ void entity_cull_eval_body(const EntityCullParams &p)
         const float dx = dot3(m0[0], m0[1], m0[2], m0[0], m0[1], m0[2]);
         const float dy = dot3(m1[0], m1[1], m1[2], m1[0], m1[1], m1[2]);
         const float dz = dot3(m2[0], m2[1], m2[2], m2[0], m2[1], m2[2]);
-        s.r = bs.w * sqrtf(gmax(dx, gmax(dy, dz)));
+        const float scale = sqrtf(gmax(dx, gmax(dy, dz)));
+        s.r = bs.w * scale;
 
         if (visible) visible = plane_test(ci, s);                                        // :137-144
-        if (ci.occlusion_pass == 2 && visible) visible = occlusion_test(ci, s, p.pyr);  // :147-191
+        if (ci.occlusion_pass == 2 && visible) visible = occlusion_test(ci, s, bs.w, scale, p.pyr);  // :147-191
 
         bool should_draw = visible;
         if (ci.occlusion_pass == 2) should_draw = visible && (!visible_in_buffer || meshlet_occ); // :198-200

@@ -173,8 +173,8 @@ __device__ __forceinline__ bool eval_geometry(const MeshletCullParams &p, const 
         // cone axis / cutoff (:121-122): int(i8) / 127.0, axis = (M * vec4(a, 0)).xyz
         const int ax_i = (int)(int8_t)(b.x & 0xFF), ay_i = (int)(int8_t)((b.x >> 8) & 0xFF);
         const int az_i = (int)(int8_t)((b.x >> 16) & 0xFF), co_i = (int)(int8_t)(b.x >> 24);
-        const float ax = snorm8_div127(ax_i), ay = snorm8_div127(ay_i), az = snorm8_div127(az_i);
-        const float cutoff = snorm8_div127(co_i);
+        const float ax = snorm8(ax_i), ay = snorm8(ay_i), az = snorm8(az_i);
+        const float cutoff = snorm8(co_i);
         const float4 tz = L.tzero[rid]; // m3 * 0.0f
         const float axx = ((m0.x * ax + m1.x * ay) + m2.x * az) + tz.x;
         const float axy = ((m0.y * ax + m1.y * ay) + m2.y * az) + tz.y;
@@ -191,7 +191,8 @@ __device__ __forceinline__ bool eval_geometry(const MeshletCullParams &p, const 
             dy = s.y - 0.0f;
             dz = s.z - 0.0f;
         }
-        cull = dot3(dx, dy, dz, axx, axy, axz) >= cutoff * sqrtf(dot3(dx, dy, dz, dx, dy, dz)) + s.r;
+        // as compiled: dot(d, axis) >= fma(cutoff, length(d), radius)  (oracle/orbit_oracle.c cone_cull)
+        cull = dot3(dx, dy, dz, axx, axy, axz) >= __builtin_fmaf(cutoff, sqrtf(dot3(dx, dy, dz, dx, dy, dz)), s.r);
     }
     if (visible) visible = plane_test_lds(P, ci.cull_plane_count, s); // :139-146
     return visible && !cull;
@@ -210,7 +211,8 @@ __device__ __forceinline__ MeshletVerdict eval_meshlet(const MeshletCullParams &
                                                        uint32_t abits, bool visible_in_buffer, bool meshlet_occ) {
     Sphere s;
     bool visible = eval_geometry<PASS, PROJ>(p, L, P, rid, a, b, visible_in_buffer, s);
-    if (PASS == 2 && meshlet_occ && visible) visible = occlusion_test(p.ci, s, p.pyr); // :161-205
+    if (PASS == 2 && meshlet_occ && visible)
+        visible = occlusion_test(p.ci, s, __uint_as_float(a.w), L.scale[rid], p.pyr); // :161-205
     return {visible, should_draw_of(visible, abits, visible_in_buffer, PASS == 2 && meshlet_occ)};
 }
 
@@ -317,7 +319,7 @@ constexpr uint32_t kCandRing = 96, kCandFlush = 32; // < kCandFlush left after a
 
 template <uint32_t N>
 struct __attribute__((aligned(16))) CandLds {
-    float4 sphere[N]; // view-space centre, radius
+    float4 sphere[N]; // view-space centre, MODEL-space radius (x the record's scale = view-space radius)
     uint4 info[N];    // {code, Meshlet words 5, 6, 7}; code = row*64+lane | a1<<9 | a2<<10 | visible_in_buffer<<11
 };
 
@@ -341,9 +343,11 @@ __device__ __forceinline__ void cand_flush(const MeshletCullParams &p, WaveTileL
     const uint4 info = C.info[slot];
     bool visible = false;
     if (valid) {
+        // the ring holds the MODEL-space radius: the test fuses radius * scale into three of its sums
+        const float scale = L.scale[(info.x >> 5) & 15u];
         Sphere s;
-        s.x = sp.x, s.y = sp.y, s.z = sp.z, s.r = sp.w;
-        visible = occlusion_test(p.ci, s, p.pyr); // :161-205
+        s.x = sp.x, s.y = sp.y, s.z = sp.z, s.r = sp.w * scale;
+        visible = occlusion_test(p.ci, s, sp.w, scale, p.pyr); // :161-205
     }
     const uint32_t code = info.x;
     const uint32_t abits = (code >> 9) & 3u;
@@ -381,7 +385,7 @@ __device__ __forceinline__ void row_eval_occ(const MeshletCullParams &p, WaveTil
     const uint64_t mask = __ballot(cand);
     if (cand) {
         const uint32_t slot = ring_wrap(ring_wrap(cs.head + cs.count) + lane_prefix(mask));
-        C.sphere[slot] = make_float4(s.x, s.y, s.z, s.r);
+        C.sphere[slot] = make_float4(s.x, s.y, s.z, __uint_as_float(t.a[0].w)); // model-space radius (cand_flush)
         C.info[slot] = make_uint4((uint32_t)(R * 64 + lane) | (abits << 9) | ((visible_in_buffer ? 1u : 0u) << 11),
                                   t.b[0].y, t.b[0].z, t.b[0].w);
     }

@@ -79,18 +79,10 @@ __device__ __forceinline__ float log2c(float x) {
     return r + (float)e;
 }
 
-// int8 / 127.0 correctly rounded in two VALU ops instead of the IEEE-division
-// expansion.  1/127 = 2^-7 + 2^-14 + 2^-21 + ... is split as r_hi (3 terms, 15
-// significant bits) + r_lo (the next 24 bits); i * r_hi is exact for |i| <= 128
-// and fma(i, r_lo, i * r_hi) rounds i * (r_hi + r_lo) once.  |r_hi + r_lo -
-// 1/127| < 2^-56, and no i/127 lies that close to a rounding boundary (its
-// binary expansion has period 7): verified exhaustively for all 256 inputs
-// against exact rationals (tests/test_oracle_cpu.py) and against the oracle's
-// '/' on the device (tests/test_gpu_parity.py).
-__device__ __forceinline__ float snorm8_div127(int i) {
-    const float fi = (float)i;
-    return __builtin_fmaf(fi, 0x1.020408p-28f, fi * 0x1.0204p-7f);
-}
+// int(i8) / 127.0 (meshlet_cull.comp:121-122) AS COMPILED: the reference's shader binaries multiply by the rounded
+// reciprocal (meshlet_cull.comp.spv, OpFMul by 0x3C010204 — spirv-opt's reciprocal folding); 16 of the 256 inputs
+// differ from the IEEE quotient by one ulp, and the oracle follows the binary (oracle/orbit_oracle.c snorm8).
+__device__ __forceinline__ float snorm8(int i) { return (float)i * __uint_as_float(0x3C010204u); }
 
 // Pyramid geometry handed to the kernels by value (host-computed).  `texels` is the packed R32F mip chain; when
 // `levels` is non-null the chain is NOT packed: level k lives at levels[k].texels with levels[k].row_pitch texels per
@@ -137,47 +129,52 @@ struct Sphere {
     float x, y, z, r;
 };
 
-// project_sphere, entity_cull.comp:83-102 / meshlet_cull.comp:83-102.
+// project_sphere, entity_cull.comp:83-102 / meshlet_cull.comp:83-102, as the compiled shaders hold it (the fused
+// operations are spirv-opt's: oracle/orbit_oracle.c project_sphere).
 __device__ __forceinline__ void project_sphere(const Sphere &s, float p00, float p11, float aabb[4]) {
     const float r = s.r;
     const float cxx = -s.x, cxy = -s.z;
-    const float vxx = sqrtf(dot2(cxx, cxy, cxx, cxy) - r * r), vxy = r;
+    const float vxx = sqrtf(__builtin_fmaf(-r, r, dot2(cxx, cxy, cxx, cxy))), vxy = r;
     const float minx_x = vxx * cxx + (-vxy) * cxy, minx_y = vxy * cxx + vxx * cxy;
     const float maxx_x = vxx * cxx + vxy * cxy, maxx_y = (-vxy) * cxx + vxx * cxy;
     const float cyx = -s.y, cyy = -s.z;
-    const float vyx = sqrtf(dot2(cyx, cyy, cyx, cyy) - r * r), vyy = r;
+    const float vyx = sqrtf(__builtin_fmaf(-r, r, dot2(cyx, cyy, cyx, cyy))), vyy = r;
     const float miny_x = vyx * cyx + (-vyy) * cyy, miny_y = vyy * cyx + vyx * cyy;
     const float maxy_x = vyx * cyx + vyy * cyy, maxy_y = (-vyy) * cyx + vyx * cyy;
     const float a0 = minx_x / minx_y * p00, a1 = miny_x / miny_y * p11;
     const float a2 = maxx_x / maxx_y * p00, a3 = maxy_x / maxy_y * p11;
-    aabb[0] = a0 * 0.5f + 0.5f;
-    aabb[1] = a3 * -0.5f + 0.5f;
-    aabb[2] = a2 * 0.5f + 0.5f;
-    aabb[3] = a1 * -0.5f + 0.5f;
+    aabb[0] = __builtin_fmaf(a0, 0.5f, 0.5f);
+    aabb[1] = __builtin_fmaf(a3, -0.5f, 0.5f);
+    aabb[2] = __builtin_fmaf(a2, 0.5f, 0.5f);
+    aabb[3] = __builtin_fmaf(a1, -0.5f, 0.5f);
 }
 
-// Pass-2 HiZ test, entity_cull.comp:146-191 == meshlet_cull.comp:160-205.
+// Pass-2 HiZ test, entity_cull.comp:146-191 == meshlet_cull.comp:160-205, operation by operation as compiled
+// (oracle/orbit_oracle.c occlusion_test): `radius` is the model-space radius and `scale` the matrix's largest scale —
+// s.r = radius * scale — because three sums of the test are fused with that product in the reference's binaries.
 // Flips s.z in the perspective branch; the flip persists for the caller.
-__device__ __forceinline__ bool occlusion_test(const OrbitGpuCullInfo &ci, Sphere &s, const PyramidView &pyr) {
+__device__ __forceinline__ bool occlusion_test(const OrbitGpuCullInfo &ci, Sphere &s, float radius, float scale,
+                                               const PyramidView &pyr) {
     bool cullable = true;
     float aabb[4], closest;
     if (ci.projection_type == 0) {
         s.z = -s.z;
-        cullable = s.z >= s.r + ci.z_near;
+        cullable = s.z >= __builtin_fmaf(radius, scale, ci.z_near);
         project_sphere(s, ci.p00_or_width_recipx2, ci.p11_or_height_recipx2, aabb);
-        closest = ci.z_near / (s.z - s.r);
+        closest = ci.z_near / __builtin_fmaf(-radius, scale, s.z);
     } else {
         const float sr = ci.p00_or_width_recipx2;
         const float cx = s.x * sr, cy = s.y * sr;
         const float bs = sr * s.r;
-        const float b0 = cx + bs * -1.0f, b1 = cy + bs * -1.0f, b2 = cx + bs * 1.0f, b3 = cy + bs * 1.0f;
-        aabb[0] = gclamp(b0, -1.0f, 1.0f) * 0.5f + 0.5f;
-        aabb[1] = gclamp(b1, -1.0f, 1.0f) * -0.5f + 0.5f;
-        aabb[2] = gclamp(b2, -1.0f, 1.0f) * 0.5f + 0.5f;
-        aabb[3] = gclamp(b3, -1.0f, 1.0f) * -0.5f + 0.5f;
-        const float closest_z = s.z + s.r;
+        const float b0 = __builtin_fmaf(bs, -1.0f, cx), b1 = __builtin_fmaf(bs, -1.0f, cy);
+        const float b2 = __builtin_fmaf(bs, 1.0f, cx), b3 = __builtin_fmaf(bs, 1.0f, cy);
+        aabb[0] = __builtin_fmaf(gclamp(b0, -1.0f, 1.0f), 0.5f, 0.5f);
+        aabb[1] = __builtin_fmaf(gclamp(b1, -1.0f, 1.0f), -0.5f, 0.5f);
+        aabb[2] = __builtin_fmaf(gclamp(b2, -1.0f, 1.0f), 0.5f, 0.5f);
+        aabb[3] = __builtin_fmaf(gclamp(b3, -1.0f, 1.0f), -0.5f, 0.5f);
+        const float closest_z = __builtin_fmaf(radius, scale, s.z);
         const float r = 1.0f / (ci.z_far - ci.z_near);
-        closest = closest_z * r + (r * ci.z_far);
+        closest = r * (closest_z + ci.z_far);
     }
     if (!cullable) return true;
     const float width = (aabb[2] - aabb[0]) * (float)pyr.w0;

@@ -85,6 +85,29 @@ def mat_mul(a, b):
     return out
 
 
+def fma32(a, b, c):
+    """fma(a, b, c) rounded once to binary32 (what fmaf / v_fma_f32 compute): the product is exact in binary64, the
+    sum is rounded to 53 bits and then to 24 — the second rounding is repaired where the 53-bit sum sits exactly half
+    way between two binary32 values (TwoSum gives the sign of what the first rounding dropped)."""
+    a, b, c = (np.asarray(t, dtype=np.float32).astype(np.float64) for t in np.broadcast_arrays(a, b, c))
+    p = a * b
+    s = p + c
+    bb = s - p
+    err = (p - (s - bb)) + (c - bb)
+    r = s.astype(np.float32)
+    half = (np.ascontiguousarray(s).view(np.uint64) & np.uint64(0x1FFFFFFF)) == np.uint64(0x10000000)
+    fix = half & (err != 0) & np.isfinite(s) & (np.abs(s) >= 2.0 ** -126)
+    if np.any(fix):
+        r64 = r.astype(np.float64)
+        down = np.where(r64 > s, np.nextafter(r, np.float32(-np.inf)), r)
+        up = np.where(r64 > s, r, np.nextafter(r, np.float32(np.inf)))
+        r = np.where(fix, np.where(err > 0, up, down), r)
+    return r.astype(np.float32)
+
+
+RCP127 = np.frombuffer(np.array([0x3C010204], np.uint32).tobytes(), np.float32)[0]  # the compiled shaders' 1/127
+
+
 def transform_sphere(m, sph):
     one = np.ones(len(sph), dtype=np.float32)
     p = mat_vec(m, sph[:, 0], sph[:, 1], sph[:, 2], one)
@@ -94,6 +117,7 @@ def transform_sphere(m, sph):
     dy = dot3(m[:, 4], m[:, 5], m[:, 6], m[:, 4], m[:, 5], m[:, 6])
     dz = dot3(m[:, 8], m[:, 9], m[:, 10], m[:, 8], m[:, 9], m[:, 10])
     scale = np.sqrt(gmax(dx, gmax(dy, dz)), dtype=np.float32)
+    transform_sphere.last = (sph[:, 3].astype(np.float32), scale)  # model radius, scale: the occlusion test fuses them
     return x, y, z, (sph[:, 3] * scale).astype(np.float32)
 
 
@@ -162,19 +186,21 @@ def hiz_sample(pyr, w0, h0, u, v, lod):
     return gmin(gmin(a, b), gmin(c, d))
 
 
-def occlusion_test(ci, x, y, z, r, pyr, pw, ph):
-    """Returns (visible, z') — z' is the possibly flipped z (persists)."""
+def occlusion_test(ci, x, y, z, r, pyr, pw, ph, radius=None, scale=None):
+    """Returns (visible, z') — z' is the possibly flipped z (persists).  Operation by operation as the reference's
+    compiled shaders hold it (oracle/orbit_oracle.c occlusion_test): radius = model-space radius, r = radius * scale."""
     n = len(x)
+    if radius is None: radius, scale = transform_sphere.last
     with np.errstate(all="ignore"):
         if int(ci["projection_type"]) == 0:
             z = (-z).astype(np.float32)
             zn = F(ci["z_near"])
-            cullable = z >= (r + zn).astype(np.float32)
+            cullable = z >= fma32(radius, scale, zn)
             p00, p11 = F(ci["p00_or_width_recipx2"]), F(ci["p11_or_height_recipx2"])
 
             def bounds(c0, c1):
                 # cx = -C.xz ; vx = (sqrt(dot(cx,cx) - r*r), r)
-                vx = np.sqrt(((c0 * c0 + c1 * c1).astype(F) - (r * r).astype(F)).astype(F), dtype=F)
+                vx = np.sqrt(fma32(-r, r, (c0 * c0 + c1 * c1).astype(F)), dtype=F)
                 vy = r
                 mn_x = ((vx * c0).astype(F) + ((-vy) * c1).astype(F)).astype(F)
                 mn_y = ((vy * c0).astype(F) + (vx * c1).astype(F)).astype(F)
@@ -187,27 +213,25 @@ def occlusion_test(ci, x, y, z, r, pyr, pw, ph):
             a1 = ((miny_x / miny_y).astype(F) * p11).astype(F)
             a2 = ((maxx_x / maxx_y).astype(F) * p00).astype(F)
             a3 = ((maxy_x / maxy_y).astype(F) * p11).astype(F)
-            u0 = ((a0 * F(0.5)).astype(F) + F(0.5)).astype(F)
-            v0 = ((a3 * F(-0.5)).astype(F) + F(0.5)).astype(F)
-            u1 = ((a2 * F(0.5)).astype(F) + F(0.5)).astype(F)
-            v1 = ((a1 * F(-0.5)).astype(F) + F(0.5)).astype(F)
-            closest = (zn / (z - r).astype(F)).astype(F)
+            u0 = fma32(a0, F(0.5), F(0.5))
+            v0 = fma32(a3, F(-0.5), F(0.5))
+            u1 = fma32(a2, F(0.5), F(0.5))
+            v1 = fma32(a1, F(-0.5), F(0.5))
+            closest = (zn / fma32(-radius, scale, z)).astype(F)
         else:
             sr = F(ci["p00_or_width_recipx2"])
             cx, cy = (x * sr).astype(F), (y * sr).astype(F)
             bs = (sr * r).astype(F)
-            b0 = (cx + (bs * F(-1.0)).astype(F)).astype(F)
-            b1 = (cy + (bs * F(-1.0)).astype(F)).astype(F)
-            b2 = (cx + (bs * F(1.0)).astype(F)).astype(F)
-            b3 = (cy + (bs * F(1.0)).astype(F)).astype(F)
+            b0, b1 = fma32(bs, F(-1.0), cx), fma32(bs, F(-1.0), cy)
+            b2, b3 = fma32(bs, F(1.0), cx), fma32(bs, F(1.0), cy)
             cl = lambda t: gmin(gmax(t, F(-1.0)), F(1.0))
-            u0 = ((cl(b0) * F(0.5)).astype(F) + F(0.5)).astype(F)
-            v0 = ((cl(b1) * F(-0.5)).astype(F) + F(0.5)).astype(F)
-            u1 = ((cl(b2) * F(0.5)).astype(F) + F(0.5)).astype(F)
-            v1 = ((cl(b3) * F(-0.5)).astype(F) + F(0.5)).astype(F)
+            u0 = fma32(cl(b0), F(0.5), F(0.5))
+            v0 = fma32(cl(b1), F(-0.5), F(0.5))
+            u1 = fma32(cl(b2), F(0.5), F(0.5))
+            v1 = fma32(cl(b3), F(-0.5), F(0.5))
             cullable = np.ones(n, dtype=bool)
             rr = F(1.0) / (F(ci["z_far"]) - F(ci["z_near"]))
-            closest = (((z + r).astype(F) * rr).astype(F) + (rr * F(ci["z_far"]))).astype(F)
+            closest = (rr * (fma32(radius, scale, z) + F(ci["z_far"])).astype(F)).astype(F)
         width = ((u1 - u0).astype(F) * F(pw)).astype(F)
         height = ((v1 - v0).astype(F) * F(ph)).astype(F)
         u = ((u0 + u1).astype(F) * F(0.5)).astype(F)
@@ -291,9 +315,9 @@ def meshlet_cull(ci, records, meshlets, entities, materials, mvis, pyr=None, pyr
     m = meshlets[idx]
     mv = mat_mul(ci["view_matrix"], entities["model_matrix"][rec["entity_index"]])
     x, y, z, r = transform_sphere(mv, m["bounding_sphere"])
-    ax = (m["cone_axis"].astype(np.int32).astype(np.float32) / F(127.0)).astype(F)
+    ax = (m["cone_axis"].astype(np.int32).astype(np.float32) * RCP127).astype(F)
     axis = mat_vec(mv, ax[:, 0], ax[:, 1], ax[:, 2], np.zeros(len(ax), F))
-    cutoff = (m["cone_cutoff"].astype(np.int32).astype(np.float32) / F(127.0)).astype(F)
+    cutoff = (m["cone_cutoff"].astype(np.int32).astype(np.float32) * RCP127).astype(F)
     alpha = materials["alpha_mode"][m["material_index"]]
     rw = op in (1, 2) and meshlet_occ
     vib = np.ones(len(idx), dtype=bool)
@@ -308,7 +332,7 @@ def meshlet_cull(ci, records, meshlets, entities, materials, mvis, pyr=None, pyr
             camx = camy = camz = np.zeros(len(x), F)
         dx, dy, dz = (x - camx).astype(F), (y - camy).astype(F), (z - camz).astype(F)
         lhs = dot3(dx, dy, dz, axis[0], axis[1], axis[2])
-        rhs = ((cutoff * np.sqrt(dot3(dx, dy, dz, dx, dy, dz), dtype=F)).astype(F) + r).astype(F)
+        rhs = fma32(cutoff, np.sqrt(dot3(dx, dy, dz, dx, dy, dz), dtype=F), r)
         visible &= ~(lhs >= rhs)
     if meshlet_occ and op == 2:
         ov, _ = occlusion_test(ci, x, y, z, r, pyr, *pyr_size)
