@@ -1,0 +1,209 @@
+"""Generates tests/golden/spirv_cull.npz: inputs and OUTPUTS OF THE REFERENCE'S OWN COMPILED SHADERS for the cull path.
+
+Run in the build container only (it reads /root/reference/shaders/{entity_cull,meshlet_cull}.comp.spv, which do not
+travel): `python tests/golden/make_spirv_vectors.py`.  The binaries are executed by oracle/spirv_vm.py; what the
+interpreter decides itself is listed in its header (operation order inside Dot / MatrixTimesVector, log2, the ReduceMin
+sampler, invocation order of atomics — the oracle's documented canonical choices, passed in from the oracle).  Every
+other bit of the outputs is the reference binary's: which tests run, on what, in which arithmetic (including
+spirv-opt's reciprocal, fused and factored operations), the visibility-bit protocol, LOD selection, record and command
+contents.
+
+Cases: occlusion passes 0 / 1 / 2 x perspective / orthographic, each on a seeded "plain" scene and on a "knife-edge"
+scene — quantised geometry whose meshlet radii put the cone test within an ulp of equality and, in pass 2, a constant
+depth buffer bisected to the closest-depth of a group of identical spheres — on which the round-1 arithmetic (IEEE
+division by 127, unfused sums) provably differs from the binaries.
+The tests that consume the file: tests/test_spirv_vectors_cpu.py (oracle), tests/test_spirv_vectors_gpu.py (product)."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import scenes as sc  # noqa: E402
+from oracle import oracle, spirv_vm as vm  # noqa: E402
+from orbit_amd import layouts as L  # noqa: E402
+
+REF = "/root/reference/shaders/"
+F = np.float32
+W, H = 320, 180
+ORTHO = dict(p00=1.0 / 16, p11=1.0 / 16, z_near=0.7, z_far=61.3)
+RCP127 = np.frombuffer(np.array([0x3C010204], np.uint32).tobytes(), np.float32)[0]
+_mods = {}
+
+
+def module(name):
+    if name not in _mods:
+        _mods[name] = vm.Module(REF + name, spec={0: 32})  # constant_id 0 = MESHLET_DISPATCH_SIZE / local_size_x
+    return _mods[name]
+
+
+def log2(x):
+    return np.array([oracle.log2f(float(v)) for v in np.asarray(x).reshape(-1)], F).reshape(np.shape(x))
+
+
+def model_view(scene, cam, k):
+    ed = scene.entity_draws[k]
+    M = np.asarray(scene.entities["model_matrix"][ed["entity_index"]], F).reshape(4, 4).T
+    MV = (np.asarray(cam.view, np.float64) @ M.astype(np.float64)).astype(F)
+    scale = F(np.sqrt(max((MV[:3, 0] ** 2).sum(), (MV[:3, 1] ** 2).sum(), (MV[:3, 2] ** 2).sum())))
+    return ed, scene.mesh_infos[ed["mesh_index"]], MV, scale
+
+
+def quantise(scene, rng):
+    m = scene.meshlets
+    n = len(m)
+    m["bounding_sphere"][:, :3] = rng.integers(-12, 13, (n, 3)).astype(F) / 4
+    m["bounding_sphere"][:, 3] = rng.choice(np.array([0, .125, .25, .5, 1, 2], F), n)
+    m["cone_axis"][:] = rng.integers(-128, 128, (n, 3)).astype(np.int8)
+    m["cone_cutoff"][:] = rng.integers(-128, 128, n).astype(np.int8)
+    for k in range(len(scene.entities)):
+        M = np.eye(4, dtype=F)
+        perm, sg = rng.permutation(3), rng.choice([-1.0, 1.0], 3)
+        R = np.zeros((3, 3), F)
+        for i in range(3):
+            R[i, perm[i]] = sg[i]
+        M[:3, :3] = R * rng.choice(np.array([.5, 1, 2], F))
+        M[:3, 3] = rng.integers(-20, 21, 3).astype(F) / 2
+        scene.entities["model_matrix"][k] = sc.mat4_cols(M)
+    mi = scene.mesh_infos
+    mi["bounding_sphere"][:, :3] = rng.integers(-8, 9, (len(mi), 3)).astype(F) / 2
+    mi["bounding_sphere"][:, 3] = rng.choice(np.array([1, 2, 4, 8], F), len(mi))
+
+
+def cone_knife_edge(scene, cam, ortho):
+    """Model radii that put dot(d, axis) >= fma(cutoff, |d|, r) within an ulp of equality."""
+    ml = scene.meshlets
+    for k in range(scene.entity_draw_count):
+        _, mi, MV, scale = model_view(scene, cam, k)
+        for lod in range(int(mi["lod_count"])):
+            off, cnt = mi["mesh_lods"][lod]
+            for j in range(int(off), int(off + cnt)):
+                d = (MV[:3, :3] @ ml["bounding_sphere"][j, :3] + MV[:3, 3]).astype(F)
+                if ortho:
+                    d = np.array([0, 0, -1], F)
+                a = (MV[:3, :3] @ (ml["cone_axis"][j].astype(F) * RCP127)).astype(F)
+                r = F(d @ a) - F(ml["cone_cutoff"][j]) * RCP127 * F(np.sqrt(d @ d))
+                if r > 0 and scale > 0:
+                    ml["bounding_sphere"][j, 3] = F(r) / scale
+
+
+def depth_knife_edge(scene, cam, ci, ortho, seed, rng):
+    """Every meshlet of the largest entity becomes the same sphere (inexact radius x scale); returns a constant depth
+    buffer at the ORACLE's closest-depth of that sphere (found by bisection), or one ulp above it."""
+    best = max(range(scene.entity_draw_count),
+               key=lambda k: int(scene.mesh_infos[scene.entity_draws[k]["mesh_index"]]["mesh_lods"][0][1]))
+    ed = scene.entity_draws[best]
+    mi = scene.mesh_infos[ed["mesh_index"]]
+    M = np.eye(4, dtype=F)
+    M[:3, :3] *= F(1.3)
+    M[:3, 3] = (0.3, -0.2, -float(rng.integers(3, 9)) - 0.37)
+    scene.entities["model_matrix"][ed["entity_index"]] = sc.mat4_cols(M)
+    c0 = np.array([0.11, -0.07, 0.05, 0.0], F) * F(1 + seed % 7)
+    c0[3] = F(1.7) + F(0.37) * F(seed % 5)
+    mi["bounding_sphere"][:] = (0, 0, 0, 1.0)
+    scene.mesh_infos[ed["mesh_index"]] = mi
+    for lod in range(int(mi["lod_count"])):
+        off, cnt = mi["mesh_lods"][lod]
+        scene.meshlets["bounding_sphere"][int(off):int(off + cnt)] = c0
+        scene.meshlets["cone_cutoff"][int(off):int(off + cnt)] = 127
+        scene.meshlets["cone_axis"][int(off):int(off + cnt)] = (0, 0, 127)  # faces the camera: never cone-culled
+    cap_d, cap_c = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
+    ze, zm = np.zeros((scene.entity_draw_count + 31) // 32, np.uint32), np.zeros(scene.vis_words, np.uint32)
+    entity = int(ed["entity_index"])
+
+    def drawn(bits):
+        dc = np.full((H, W), np.frombuffer(np.array([bits], np.uint32).tobytes(), F)[0], F)
+        pyr, d = oracle.depth_reduce(dc, W, H)
+        d0, _, _ = oracle.entity_cull(ci, scene.entity_draw_buffer(), scene.entity_draw_count, scene.mesh_infos,
+                                      scene.entities, cap_d, ze, pyr, (d.width, d.height))
+        c, _, _ = oracle.meshlet_cull(ci, d0, scene.meshlets, cap_c, scene.entities, scene.materials, zm, pyr,
+                                      (d.width, d.height))
+        return int((L.draw_buffer_commands(c)[1]["cmd_first_instance"] == entity).sum())
+    lo, hi = 0, 0x3F800000
+    base = drawn(lo)
+    assert base > 0 and drawn(hi) < base, "the knife-edge group is not decided by the depth buffer"
+    while hi - lo > 1:
+        mid = (lo + hi) // 2
+        if drawn(mid) == base:
+            lo = mid
+        else:
+            hi = mid
+    return np.full((H, W), np.frombuffer(np.array([lo + (seed & 1)], np.uint32).tobytes(), F)[0], F)
+
+
+def case(seed, occlusion_pass, ortho, knife, n=140):
+    rng = np.random.default_rng(seed)
+    scene = sc.make_scene(seed, n, meshlets_per_mesh=(1, 70), lods=3)
+    cam = sc.default_camera(rot=(0.2, 0.4))
+    if knife:
+        quantise(scene, rng)
+        cam = sc.default_camera(position=(0.0, 0.0, float(rng.integers(4, 30))), rot=(1.0, 0.0))
+        cone_knife_edge(scene, cam, ortho)
+    kw = {}
+    if occlusion_pass == 2:
+        kw = ORTHO if ortho else dict(p00=cam.p00, p11=cam.p11, z_near=cam.z_near)
+    ci = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=occlusion_pass, projection_type=1 if ortho else 0, **kw)
+    depth = sc.make_depth(9 + seed, W, H, cam)
+    evis = rng.integers(0, 2 ** 32, (scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+    mvis = rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32)
+    if knife and occlusion_pass == 2:
+        depth = depth_knife_edge(scene, cam, ci, ortho, seed, rng)
+        evis[:], mvis[:] = 0, 0
+    pyr, dsc = oracle.depth_reduce(depth, W, H)
+    ps = (dsc.width, dsc.height)
+    cap_d, cap_c = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
+    # registry: one index space for all storage buffers (set 0, binding 0), textures and samplers apart
+    B = {}
+
+    def buf(i, a):
+        B[i] = np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()
+    civ = np.array(ci).copy().reshape(())
+    if occlusion_pass:
+        civ["visibility_buffer"], civ["meshlet_visibility_buffer"], civ["depth_pyramid"] = 6, 7, 11
+    buf(1, scene.entity_draw_buffer()), buf(2, scene.mesh_infos), buf(4, scene.entities), buf(5, civ.reshape(1))
+    B[3] = np.zeros(L.DISPATCH_HEADER + 16 * cap_d, np.uint8)
+    B[3][4:12] = np.array([1, 1], np.uint32).view(np.uint8)  # the clear of draw_gen.rs:356-363: {0, 1, 1}
+    buf(6, evis.copy()), buf(7, mvis.copy()), buf(8, scene.meshlets), buf(10, scene.materials)
+    B[9] = np.zeros(L.DRAW_HEADER + 28 * cap_c, np.uint8)
+    kwm = dict(images={11: {"size": lambda lod: (max(ps[0] >> lod, 1), max(ps[1] >> lod, 1))}},
+               samplers={k: {"id": k} for k in range(8)}, subgroup=32,
+               sample=lambda img, smp, u, v, lod: np.array(
+                   [oracle.hiz_sample(pyr, ps[0], ps[1], float(u), float(v), float(lod)), 0, 0, 0], F))
+    vm.Machine(module("entity_cull.comp.spv"), B, np.array([1, 2, 3, 4, 5], np.uint32).tobytes(), log2, **kwm).run(
+        (scene.entity_draw_count + 255) // 256, batch=8)
+    nrec = int(B[3][:4].view(np.uint32)[0])
+    vm.Machine(module("meshlet_cull.comp.spv"), B, np.array([3, 8, 9, 4, 5, 10], np.uint32).tobytes(), log2,
+               **kwm).run(nrec, batch=256)
+    ndraw = int(B[9][:4].view(np.uint32)[0])
+    assert nrec <= cap_d and ndraw <= cap_c
+    return dict(cull_info=np.array(ci).reshape(1), entity_draws=scene.entity_draw_buffer(),
+                mesh_infos=scene.mesh_infos, entities=scene.entities, meshlets=scene.meshlets,
+                materials=scene.materials, evis_in=evis, mvis_in=mvis, pyramid=pyr,
+                pyramid_size=np.array(ps, np.uint32), caps=np.array([cap_d, cap_c], np.uint32),
+                spv_dispatch=B[3][:L.DISPATCH_HEADER + 16 * nrec].copy(), spv_draw=B[9][:L.DRAW_HEADER + 28 * ndraw].copy(),
+                spv_evis=B[6].view(np.uint32).copy(), spv_mvis=B[7].view(np.uint32).copy())
+
+
+def main():
+    out, summary = {}, []
+    for occlusion_pass in (0, 1, 2):
+        for ortho in (False, True):
+            for knife in (False, True):
+                seed = 3 + 7 * occlusion_pass + (2 if ortho else 0) + (1 if knife else 0)
+                name = f"p{occlusion_pass}_{'ortho' if ortho else 'persp'}_{'knife' if knife else 'plain'}"
+                c = case(seed, occlusion_pass, ortho, knife)
+                for k, v in c.items():
+                    out[f"{name}/{k}"] = v
+                summary.append((name, int(c["spv_dispatch"][:4].view(np.uint32)[0]), int(c["spv_draw"][:4].view(np.uint32)[0])))
+    path = os.path.join(HERE, "spirv_cull.npz")
+    np.savez_compressed(path, **out)
+    for s in summary:
+        print("%-22s records %5d  draws %6d" % s)
+    print(path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()
