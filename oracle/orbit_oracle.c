@@ -579,7 +579,8 @@ void oracle_cluster_mark(const OrbitMarkActivePush *pc, const float *depth, uint
             for (uint32_t s = 0; s < sc; s++) {
                 float d = depth[((size_t)py * pc->screen_size[0] + px) * sc + s];
                 float linear_z = pc->z_near / d;
-                uint32_t slice = f2u_sat(orbit_log2f(linear_z) * pc->z_scale + pc->z_bias);
+                /* cluster_common.glsl:18-20 as compiled (mark_active.comp.spv): uint(fma(log2(z), z_scale, z_bias)) */
+                uint32_t slice = f2u_sat(fmaf(orbit_log2f(linear_z), pc->z_scale, pc->z_bias));
                 bitmask |= shl1(slice);
                 if (slice < cz) {
                     size_t ci = tx + (size_t)ty * cx + (size_t)slice * cx * cy;
@@ -676,8 +677,9 @@ static int light_in_cluster(const OrbitClusterCullInfo *in, const OrbitLightData
     float sq = 0.0f;
     for (int i = 0; i < 3; i++) {
         float v = c[i];
-        if (v < mn[i]) sq += (mn[i] - v) * (mn[i] - v);
-        if (v > mx[i]) sq += (v - mx[i]) * (v - mx[i]);
+        /* as compiled (light_culling.comp.spv): sqr_dist = fma(d, d, sqr_dist) */
+        if (v < mn[i]) sq = fmaf(mn[i] - v, mn[i] - v, sq);
+        if (v > mx[i]) sq = fmaf(v - mx[i], v - mx[i], sq);
     }
     return sq <= l->outer_radius * l->outer_radius;
 }

@@ -355,29 +355,37 @@ class Machine:
 
     # -- execution --------------------------------------------------------------------------------------------------
     def run(self, groups, local_size=None, batch=1):
-        """Dispatch: workgroups (x only) 0 .. groups-1.  `batch` workgroups are interpreted side by side (their
-        invocations are lanes of one SIMT group: same results, fewer numpy calls) — only for shaders without
-        workgroup-shared memory or barriers; atomics still see the invocations in global index order."""
+        """Dispatch of groups = nx or (nx, ny) workgroups.  `batch` workgroups (consecutive in x-major order) are
+        interpreted side by side (their invocations are lanes of one SIMT group: same results, fewer numpy calls) —
+        only for shaders without workgroup-shared memory or barriers; atomics still see the invocations in dispatch
+        order (workgroup by workgroup, local index ascending)."""
         m = self.m
+        if isinstance(groups, int): groups = (groups, 1)
         if local_size is None:
-            if m.local_size: local_size = m.local_size[0]
-            else: local_size = m.const_scalar(m.local_size_id[0])
-        assert self.S <= local_size and local_size % self.S == 0 or batch == 1
-        for g in range(0, groups, batch):
-            self.run_group(g, groups, local_size, min(batch, groups - g))
+            if m.local_size: local_size = m.local_size[:2]
+            else: local_size = (m.const_scalar(m.local_size_id[0]), m.const_scalar(m.local_size_id[1]))
+        if isinstance(local_size, int): local_size = (local_size, 1)
+        total = groups[0] * groups[1]
+        for g in range(0, total, batch):
+            self.run_group(g, groups, local_size, min(batch, total - g))
 
-    def run_group(self, g, groups, L, count=1):
+    def run_group(self, g, groups, local_size, count=1):
         m = self.m
+        lx, ly = local_size
+        L = lx * ly
         N = L * count
         self.N, self.vals = N, {}
         lanes = np.arange(N, dtype=U32)
         local = lanes % U32(L)
         wg = U32(g) + lanes // U32(L)
+        wgx, wgy = wg % U32(groups[0]), wg // U32(groups[0])
+        lix, liy = local % U32(lx), local // U32(lx)
         z = np.zeros(N, U32)
-        builtin = {"GlobalInvocationId": np.stack([lanes + U32(g * L), z, z], axis=1),
-                   "LocalInvocationId": np.stack([local, z, z], axis=1), "LocalInvocationIndex": local,
-                   "WorkgroupId": np.stack([wg, z, z], axis=1),
-                   "NumWorkgroups": np.stack([np.full(N, groups, U32), z + U32(1), z + U32(1)], axis=1),
+        one = z + U32(1)
+        builtin = {"GlobalInvocationId": np.stack([wgx * U32(lx) + lix, wgy * U32(ly) + liy, z], axis=1),
+                   "LocalInvocationId": np.stack([lix, liy, z], axis=1), "LocalInvocationIndex": local,
+                   "WorkgroupId": np.stack([wgx, wgy, z], axis=1),
+                   "NumWorkgroups": np.stack([z + U32(groups[0]), z + U32(groups[1]), one], axis=1),
                    "SubgroupSize": np.full(N, self.S, U32), "SubgroupLocalInvocationId": local % U32(self.S),
                    "SubgroupId": local // U32(self.S), "NumSubgroups": np.full(N, (L + self.S - 1) // self.S, U32)}
         # SpecConstantOps (only IAdd of a spec constant and a constant occurs)
@@ -476,7 +484,8 @@ class Machine:
         if n == "ImageWrite":
             img, coord, texel = V(a[0]), V(a[1]), V(a[2])
             for lane in np.flatnonzero(mask):
-                img["write"](int(coord[lane, 0]), int(coord[lane, 1]), texel[lane])
+                if coord.shape[1] == 3: img["write3"](coord[lane], texel[lane])
+                else: img["write"](int(coord[lane, 0]), int(coord[lane, 1]), texel[lane])
             return
         rt, rid, x = a[0], a[1], a[2:]
         t = m.types[rt]
@@ -682,8 +691,8 @@ class Machine:
         elif n == "ImageFetch":
             img, coord = V(x[0]), V(x[1])
             out = np.zeros((N, 4), F32)
-            for lane in np.flatnonzero(mask):
-                out[lane] = img["fetch"](int(coord[lane, 0]), int(coord[lane, 1]), x[2:])
+            act = np.flatnonzero(mask)
+            out[act] = img["fetch"](coord[act, 0].astype(np.int64), coord[act, 1].astype(np.int64))
             r = out
         else:
             raise NotImplementedError(n)

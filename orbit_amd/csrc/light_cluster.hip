@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256) void cluster_mark_kernel(const ClusterMarkPara
             uint32_t slice = 0xFFFFFFFFu, bmin = 0, bmax = 0, bit = 0;
             if (valid) {
                 const float linear_z = pc.z_near / d;                       // :28
-                slice = f2u_sat(log2c(linear_z) * pc.z_scale + pc.z_bias); // cluster_common.glsl:18-20
+                // cluster_common.glsl:18-20 as compiled (mark_active.comp.spv): one fused operation
+                slice = f2u_sat(__builtin_fmaf(log2c(linear_z), pc.z_scale, pc.z_bias));
                 bit = shl1(slice);                                          // :30
                 const float inv = 1.0f - d;                                 // :33
                 // the sign / payload of a NaN produced by arithmetic is implementation-defined: canonical quiet NaN
@@ -240,13 +241,14 @@ __device__ __forceinline__ Aabb3 cluster_aabb(const ClusterAssignParams &p, uint
 
 // aabb_sphere_test, light_culling.comp:92-104 (l.w already holds r*r)
 __device__ __forceinline__ bool sphere_hits(const Aabb3 &a, const float4 l) {
+    // as compiled (light_culling.comp.spv): sqr_dist = fma(d, d, sqr_dist) per term
     float sq = 0.0f;
-    if (l.x < a.mn[0]) sq += (a.mn[0] - l.x) * (a.mn[0] - l.x);
-    if (l.x > a.mx[0]) sq += (l.x - a.mx[0]) * (l.x - a.mx[0]);
-    if (l.y < a.mn[1]) sq += (a.mn[1] - l.y) * (a.mn[1] - l.y);
-    if (l.y > a.mx[1]) sq += (l.y - a.mx[1]) * (l.y - a.mx[1]);
-    if (l.z < a.mn[2]) sq += (a.mn[2] - l.z) * (a.mn[2] - l.z);
-    if (l.z > a.mx[2]) sq += (l.z - a.mx[2]) * (l.z - a.mx[2]);
+    if (l.x < a.mn[0]) sq = __builtin_fmaf(a.mn[0] - l.x, a.mn[0] - l.x, sq);
+    if (l.x > a.mx[0]) sq = __builtin_fmaf(l.x - a.mx[0], l.x - a.mx[0], sq);
+    if (l.y < a.mn[1]) sq = __builtin_fmaf(a.mn[1] - l.y, a.mn[1] - l.y, sq);
+    if (l.y > a.mx[1]) sq = __builtin_fmaf(l.y - a.mx[1], l.y - a.mx[1], sq);
+    if (l.z < a.mn[2]) sq = __builtin_fmaf(a.mn[2] - l.z, a.mn[2] - l.z, sq);
+    if (l.z > a.mx[2]) sq = __builtin_fmaf(l.z - a.mx[2], l.z - a.mx[2], sq);
     return sq <= l.w;
 }
 

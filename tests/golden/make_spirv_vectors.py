@@ -1,4 +1,4 @@
-"""Generates tests/golden/spirv_cull.npz: inputs and OUTPUTS OF THE REFERENCE'S OWN COMPILED SHADERS for the cull path.
+"""Generates tests/golden/spirv_cull.npz and spirv_cluster.npz: inputs and OUTPUTS OF THE REFERENCE'S OWN COMPILED SHADERS.
 
 Run in the build container only (it reads /root/reference/shaders/{entity_cull,meshlet_cull}.comp.spv, which do not
 travel): `python tests/golden/make_spirv_vectors.py`.  The binaries are executed by oracle/spirv_vm.py; what the
@@ -187,8 +187,75 @@ def case(seed, occlusion_pass, ortho, knife, n=140):
                 spv_evis=B[6].view(np.uint32).copy(), spv_mvis=B[7].view(np.uint32).copy())
 
 
+# ------------------------------------------------------------------------------------------------ light clusters
+CREF = REF + "light_cluster/"
+
+
+def cluster_case(seed, width, height, n_lights, quantised):
+    """mark_active.comp.spv and light_culling.comp.spv (active_cluster_compaction.comp is integer-only and its list
+    order is the atomics' — the oracle's list is handed to the last stage as input)."""
+    cam = sc.default_camera(aspect=width / height)
+    depth = sc.make_depth(seed, width, height, cam, n_occluders=40, ground=(seed % 2 == 0))
+    tile, zsl, far = 8, 32, 200.0
+    cx, cy = -(-width // tile), -(-height // tile)
+    zs, zb = oracle.cluster_grid_info(cam.z_near, far, zsl)
+    push = np.zeros((), dtype=L.MARK_ACTIVE_PUSH)
+    push["cluster_count"], push["tile_size_px"], push["screen_size"] = (cx, cy, zsl), tile, (width, height)
+    push["z_near"], push["z_far"], push["z_scale"], push["z_bias"] = cam.z_near, far, zs, zb
+    push["depth_buffer_sample_count"] = 1
+    info = np.zeros((), dtype=L.CLUSTER_CULL_INFO)
+    info["world_to_view_matrix"] = sc.mat4_cols(cam.view)
+    info["screen_to_view_matrix"] = sc.mat4_cols(np.linalg.inv(cam.proj.astype(np.float64)).astype(F))
+    info["cluster_count"], info["tile_size_px"], info["screen_size"] = (cx, cy, zsl), tile, (width, height)
+    info["z_near"], info["z_far"], info["global_light_count"] = cam.z_near, far, n_lights
+    lights = sc.make_lights(seed, n_lights)
+    if quantised:  # positions on a quarter-unit grid around the camera, few radii: exact ties in the sphere test
+        rng = np.random.default_rng(seed)
+        lights = lights.copy()
+        lights["position"][:] = (rng.integers(-24, 25, (n_lights, 3)) / 4).astype(F)
+        lights["outer_radius"][:] = rng.choice(np.array([0.5, 1, 2, 3, 5, 7.5], F), n_lights)
+    total = cx * cy * zsl
+    B = {1: np.zeros(4 * cx * cy, np.uint8), 2: np.zeros(8 * total, np.uint8)}
+    pv = np.array(push).copy().reshape(())
+    pv["depth_buffer"], pv["depth_slice_mask_buffer"], pv["depth_bounds_buffer"] = 7, 1, 2
+    fetch = lambda x, y: np.stack([depth[np.clip(y, 0, height - 1), np.clip(x, 0, width - 1)]]
+                                  + [np.zeros(len(x), F)] * 3, axis=1)
+    vm.Machine(vm.Module(CREF + "mark_active.comp.spv"), B, pv.tobytes(), log2,
+               images={7: {"size": lambda lod: (width, height), "fetch": fetch}}, samplers={k: {"id": k} for k in range(8)},
+               subgroup=32).run(((width + 7) // 8, (height + 7) // 8), batch=16)
+    masks, bounds = B[1].view(np.uint32).copy(), B[2].view(np.uint32).reshape(-1, 2).copy()
+    unique, _ = oracle.cluster_compact([cx, cy, zsl], masks, total)
+    na = int(unique[12:16].view(np.uint32)[0])
+    cap_l = 256 * na + 16
+    iv = np.array(info).copy().reshape(())
+    iv["unique_cluster_buffer"], iv["cluster_offset_image"], iv["light_index_buffer"] = 1, 9, 2
+    iv["depth_bounds_buffer"], iv["global_light_list"] = 3, 4
+    img = np.zeros((total, 2), np.uint32)
+
+    def write(coord, texel):
+        x, y, z = (int(v) for v in coord[:3])
+        img[x + y * cx + z * cx * cy] = (int(texel[0]), int(texel[1]))
+    B = {5: np.frombuffer(iv.tobytes(), np.uint8).copy(), 1: unique.copy(), 2: np.zeros(4 + 4 * cap_l, np.uint8),
+         3: np.ascontiguousarray(bounds).view(np.uint8).reshape(-1).copy(),
+         4: np.ascontiguousarray(lights).view(np.uint8).reshape(-1).copy()}
+    vm.Machine(vm.Module(CREF + "light_culling.comp.spv"), B, np.array([5], np.uint32).tobytes(), log2,
+               images={9: {"write3": write}}, samplers={}, subgroup=32).run((na + 255) // 256)
+    nl = int(B[2][:4].view(np.uint32)[0])
+    return dict(push=np.array(push).reshape(1), depth=depth, info=np.array(info).reshape(1), lights=lights,
+                unique=unique[:16 + 4 * na].copy(), spv_masks=masks, spv_bounds=bounds,
+                spv_light_list=B[2][:4 + 4 * nl].copy(), spv_offset_image=img)
+
+
 def main():
     out, summary = {}, []
+    cl = {}
+    for seed, quantised in ((1, False), (2, True), (4, True)):
+        c = cluster_case(seed, 96, 64, 120, quantised)
+        for k, v in c.items():
+            cl[f"s{seed}/{k}"] = v
+        print("cluster seed %d: active %d, light indices %d" % (seed, int(c["unique"][12:16].view(np.uint32)[0]),
+                                                                 int(c["spv_light_list"][:4].view(np.uint32)[0])))
+    np.savez_compressed(os.path.join(HERE, "spirv_cluster.npz"), **cl)
     for occlusion_pass in (0, 1, 2):
         for ortho in (False, True):
             for knife in (False, True):

@@ -54,3 +54,45 @@ def test_oracle_equals_the_reference_binaries(oracle, vectors, name):
     assert np.array_equal(oc[:L.DRAW_HEADER + 28 * ndraw], c["spv_draw"]), "draw commands differ from the binary's"
     if p:
         assert np.array_equal(oev, c["spv_evis"]) and np.array_equal(omv, c["spv_mvis"]), "visibility words differ"
+
+
+# ------------------------------------------------------------------------------------------------ light clusters
+CLUSTER_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spirv_cluster.npz")
+CLUSTER_CASES = ["s1", "s2", "s4"]
+
+
+@pytest.fixture(scope="module")
+def cluster_vectors():
+    return np.load(CLUSTER_GOLD)
+
+
+def load_cluster_case(v, name):
+    g = lambda k: v[f"{name}/{k}"]
+    return dict(push=g("push").view(L.MARK_ACTIVE_PUSH).reshape(()), depth=g("depth"),
+                info=g("info").view(L.CLUSTER_CULL_INFO).reshape(()), lights=g("lights").view(L.LIGHT),
+                unique=g("unique"), spv_masks=g("spv_masks"), spv_bounds=g("spv_bounds"),
+                spv_light_list=g("spv_light_list"), spv_offset_image=g("spv_offset_image"))
+
+
+@pytest.mark.parametrize("name", CLUSTER_CASES)
+def test_oracle_equals_the_cluster_binaries(oracle, cluster_vectors, name):
+    """mark_active.comp.spv and light_culling.comp.spv (tests/golden/make_spirv_vectors.py): slice masks, depth bounds,
+    the per-cluster light lists and the (offset, count) image.  The compacted list between the two is the oracle's
+    (the binary's order is the order of its atomics); that it holds exactly the clusters the binary's masks mark is
+    checked here."""
+    c = load_cluster_case(cluster_vectors, name)
+    om, ob = oracle.cluster_mark(c["push"], c["depth"])
+    assert np.array_equal(om, c["spv_masks"]) and np.array_equal(ob, c["spv_bounds"])
+    cc = [int(v) for v in c["push"]["cluster_count"]]
+    total = cc[0] * cc[1] * cc[2]
+    ou, dropped = oracle.cluster_compact(cc, om, total)
+    na = int(ou[12:16].view(np.uint32)[0])
+    assert dropped == 0 and np.array_equal(ou[:16 + 4 * na], c["unique"])
+    want = [x + y * cc[0] + z * cc[0] * cc[1] for y in range(cc[1]) for x in range(cc[0]) for z in range(cc[2])
+            if (int(c["spv_masks"][x + y * cc[0]]) >> z) & 1]
+    assert sorted(ou[16:16 + 4 * na].view(np.uint32).tolist()) == sorted(want)
+    nl = int(c["spv_light_list"][:4].view(np.uint32)[0])
+    ol, oimg, dropped = oracle.cluster_assign(c["info"], ou, ob, c["lights"], 256 * na + 16, total)
+    assert dropped == 0 and nl > 10 and np.array_equal(ol[:4 + 4 * nl], c["spv_light_list"])
+    active = ou[16:16 + 4 * na].view(np.uint32)
+    assert np.array_equal(oimg[active], c["spv_offset_image"][active])

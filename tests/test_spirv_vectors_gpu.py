@@ -45,3 +45,36 @@ def test_product_equals_the_reference_binaries(torch_mod, vectors, name, source)
         assert np.array_equal(host(evis, np.uint32), c["spv_evis"]) and np.array_equal(host(mvis, np.uint32), c["spv_mvis"])
     assert (eng.meshlet_stream_culls() > 0) == (source == "meshlet_stream" and p != 1)
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["s1", "s2", "s4"])
+def test_product_equals_the_cluster_binaries(torch_mod, name):
+    """cluster_mark / cluster_compact / cluster_assign through the C ABI against mark_active.comp.spv and
+    light_culling.comp.spv outputs (tests/golden/spirv_cluster.npz)."""
+    from orbit_amd.engine import Engine
+    from test_spirv_vectors_cpu import CLUSTER_GOLD, load_cluster_case
+
+    torch = torch_mod
+    c = load_cluster_case(np.load(CLUSTER_GOLD), name)
+    cc = [int(v) for v in c["push"]["cluster_count"]]
+    total = cc[0] * cc[1] * cc[2]
+    eng = Engine(0, max_lights=256, max_clusters=total)
+    gm = torch.zeros(cc[0] * cc[1], dtype=torch.int32, device="cuda")
+    gb = torch.zeros((total, 2), dtype=torch.int32, device="cuda")
+    eng.cluster_mark(c["push"], dev(torch, c["depth"]), gm, gb)
+    gu = torch.zeros(L.COMPACT_HEADER + 4 * total, dtype=torch.uint8, device="cuda")
+    eng.cluster_compact(cc, gm, gu, total)
+    na = int(c["unique"][12:16].view(np.uint32)[0])
+    lcap = 256 * na + 16
+    gl = torch.zeros(L.LIGHT_INDEX_HEADER + 4 * lcap, dtype=torch.uint8, device="cuda")
+    gimg = torch.zeros((total, 2), dtype=torch.int32, device="cuda")
+    eng.cluster_assign(c["info"], gu, gb, dev(torch, c["lights"]), gl, lcap, gimg)
+    torch.cuda.synchronize()
+    eng.status()
+    assert np.array_equal(host(gm, np.uint32), c["spv_masks"]) and np.array_equal(host(gb, np.uint32).reshape(-1, 2), c["spv_bounds"])
+    assert np.array_equal(host(gu)[:16 + 4 * na], c["unique"])
+    nl = int(c["spv_light_list"][:4].view(np.uint32)[0])
+    assert np.array_equal(host(gl)[:4 + 4 * nl], c["spv_light_list"])
+    active = c["unique"][16:16 + 4 * na].view(np.uint32)
+    assert np.array_equal(host(gimg, np.uint32).reshape(-1, 2)[active], c["spv_offset_image"][active])
+    eng.close()
