@@ -1,7 +1,7 @@
 /* orbit_oracle_mt.c — the CPU oracle over all host cores.
  *
  * TEST INFRASTRUCTURE ONLY (see orbit_oracle.c): used by bench.py's cpu_baseline leg and by
- * tests/.  PARITY UNPINNED like the oracle it wraps.
+ * tests/.  Pinned like the oracle it wraps (oracle/orbit_oracle.c header).
  *
  * Nothing is restated here: the frame (entity_cull + meshlet_cull, any occlusion pass) is
  * the sequential oracle run on contiguous shards by OpenMP threads and concatenated in
