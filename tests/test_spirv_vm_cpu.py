@@ -1,0 +1,58 @@
+"""The SPIR-V interpreter (oracle/spirv_vm.py) itself: its fused multiply-add is exactly rounded, and — where the
+reference's shader binaries are present (the build container; they do not travel) — re-running them reproduces the
+committed vectors byte for byte, i.e. tests/golden/spirv_*.npz are the interpreter's output on the reference's binaries,
+not hand-made data."""
+import os
+import sys
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+REF = "/root/reference/shaders/meshlet_cull.comp.spv"
+
+
+def _round_f32(q):
+    from test_oracle_cpu import _round_f32 as r
+    return r(q)
+
+
+def test_vm_fma32_is_correctly_rounded():
+    from oracle.spirv_vm import fma32
+
+    rng = np.random.default_rng(5)
+    a = (rng.integers(1, 2 ** 12, 3000) * 2 + 1).astype(np.float32)
+    b = (rng.integers(1, 2 ** 12, 3000) * 2 + 1).astype(np.float32)
+    c = rng.integers(-4, 5, 3000).astype(np.float32) * np.float32(2.0) ** rng.integers(-30, -20, 3000).astype(np.float32)
+    a[2000:], b[2000:], c[2000:] = (rng.standard_normal(1000).astype(np.float32) for _ in range(3))
+    got = fma32(a, b, c)
+    for k in range(len(a)):
+        want = _round_f32(Fraction(float(a[k])) * Fraction(float(b[k])) + Fraction(float(c[k])))
+        assert float(got[k]) == want, (k, a[k], b[k], c[k])
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference's shader binaries are not on this machine")
+@pytest.mark.parametrize("occlusion_pass,ortho,knife", [(0, False, True), (1, True, False), (2, True, True), (2, False, False)])
+def test_rerunning_the_binaries_reproduces_the_committed_cull_vectors(occlusion_pass, ortho, knife):
+    import make_spirv_vectors as gen
+
+    seed = 3 + 7 * occlusion_pass + (2 if ortho else 0) + (1 if knife else 0)
+    name = f"p{occlusion_pass}_{'ortho' if ortho else 'persp'}_{'knife' if knife else 'plain'}"
+    stored = np.load(os.path.join(HERE, "golden", "spirv_cull.npz"))
+    fresh = gen.case(seed, occlusion_pass, ortho, knife)
+    for k, v in fresh.items():
+        assert np.array_equal(np.ascontiguousarray(v).view(np.uint8).reshape(-1),
+                              np.ascontiguousarray(stored[f"{name}/{k}"]).view(np.uint8).reshape(-1)), (name, k)
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference's shader binaries are not on this machine")
+def test_rerunning_the_binaries_reproduces_a_committed_cluster_vector():
+    import make_spirv_vectors as gen
+
+    stored = np.load(os.path.join(HERE, "golden", "spirv_cluster.npz"))
+    fresh = gen.cluster_case(2, 96, 64, 120, True)
+    for k, v in fresh.items():
+        assert np.array_equal(np.ascontiguousarray(v).view(np.uint8).reshape(-1),
+                              np.ascontiguousarray(stored[f"s2/{k}"]).view(np.uint8).reshape(-1)), k
