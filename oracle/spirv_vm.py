@@ -47,7 +47,7 @@ OP = dict(
     BitCount=205, ControlBarrier=224, MemoryBarrier=225, AtomicIAdd=234, AtomicUMin=237, AtomicUMax=239, AtomicAnd=240,
     AtomicOr=241, Phi=245, LoopMerge=246, SelectionMerge=247, Label=248, Branch=249, BranchConditional=250, Switch=251,
     Return=253, Unreachable=255, ExecutionModeId=331, GroupNonUniformElect=333, GroupNonUniformBallot=339,
-    CopyLogical=400,
+    CopyLogical=400, SpecConstantComposite=51, EmitMeshTasksEXT=5294,
 )
 OPN = {v: k for k, v in OP.items()}
 DEC_SPEC_ID, DEC_ARRAY_STRIDE, DEC_MATRIX_STRIDE, DEC_BUILTIN, DEC_BINDING, DEC_SET, DEC_OFFSET = 1, 6, 7, 11, 33, 34, 35
@@ -56,6 +56,7 @@ BUILTIN = {24: "NumWorkgroups", 25: "WorkgroupSize", 26: "WorkgroupId", 27: "Loc
            28: "GlobalInvocationId", 29: "LocalInvocationIndex", 36: "SubgroupSize", 40: "SubgroupId",
            41: "SubgroupLocalInvocationId", 38: "NumSubgroups"}
 SC_UNIFORM_CONSTANT, SC_INPUT, SC_WORKGROUP, SC_PRIVATE, SC_FUNCTION, SC_PUSH, SC_STORAGE = 0, 1, 4, 6, 7, 9, 12
+SC_TASK_PAYLOAD = 5402  # TaskPayloadWorkgroupEXT: memory shared by the workgroup, handed to the mesh shaders
 
 
 class Module:
@@ -111,7 +112,7 @@ class Module:
                     if sid is not None and sid[0] in self.spec: val = self.spec[sid[0]]
                     elif key in self.spec: val = self.spec[key]
                 self.consts[a[1]] = (a[0], val)
-            elif n == "ConstantComposite": self.consts[a[1]] = (a[0], ("composite", a[2:]))
+            elif n in ("ConstantComposite", "SpecConstantComposite"): self.consts[a[1]] = (a[0], ("composite", a[2:]))
             elif n == "ConstantNull": self.consts[a[1]] = (a[0], ("null",))
             elif n == "Undef" and cur is None: self.consts[a[1]] = (a[0], ("null",))
             elif n == "SpecConstantOp": self.spec_ops.append(a)
@@ -366,6 +367,7 @@ class Machine:
             else: local_size = (m.const_scalar(m.local_size_id[0]), m.const_scalar(m.local_size_id[1]))
         if isinstance(local_size, int): local_size = (local_size, 1)
         total = groups[0] * groups[1]
+        self.emitted = []  # task shaders: (group counts, payload) per workgroup, in dispatch order
         for g in range(0, total, batch):
             self.run_group(g, groups, local_size, min(batch, total - g))
 
@@ -410,10 +412,11 @@ class Machine:
                 self.vals[vid] = {"registry": "buffer", "tid": pointee}
             elif sc == SC_UNIFORM_CONSTANT:
                 self.vals[vid] = {"registry": "handle", "tid": pointee}
-            elif sc == SC_WORKGROUP:
+            elif sc in (SC_WORKGROUP, SC_TASK_PAYLOAD):
                 assert count == 1, "workgroup-shared memory: one workgroup per SIMT group"
                 mem = np.zeros(max(m.size_of(pointee, False), 4), np.uint8)
                 self.vals[vid] = Ptr(mem, np.zeros(N, np.int64), pointee, False, False)
+                if sc == SC_TASK_PAYLOAD: self.payload_var = vid
             else:
                 raise NotImplementedError("storage class %d" % sc)
         pcs = np.zeros(N, np.int64)          # position of every lane's current block; -1 = returned
@@ -468,8 +471,20 @@ class Machine:
             if n in ("Return", "Unreachable"):
                 pcs[mask] = -1
                 return
+            if n == "EmitMeshTasksEXT":  # terminates the task shader: group counts + the payload as it stands
+                first = int(np.flatnonzero(mask)[0])
+                counts = tuple(int(self.val(a[k]).view(U32)[first]) for k in range(3))
+                pay = self.load(self.vals[self.payload_var], mask) if getattr(self, "payload_var", None) else None
+                self.emitted.append((counts, self.first_lane(pay, first)))
+                pcs[mask] = -1
+                return
             self.exec_inst(n, a, mask)
         raise RuntimeError("block %d has no terminator" % label)
+
+    def first_lane(self, v, lane):
+        if v is None: return None
+        if isinstance(v, list): return [self.first_lane(x, lane) for x in v]
+        return v[lane]
 
     def exec_inst(self, n, a, mask):
         m, N, V = self.m, self.N, self.val

@@ -1,7 +1,7 @@
 """Generates tests/golden/spirv_cull.npz and spirv_cluster.npz: inputs and OUTPUTS OF THE REFERENCE'S OWN COMPILED SHADERS.
 
-Run in the build container only (it reads /root/reference/shaders/{entity_cull,meshlet_cull}.comp.spv, which do not
-travel): `python tests/golden/make_spirv_vectors.py`.  The binaries are executed by oracle/spirv_vm.py; what the
+Run in the build container only (it reads /root/reference/shaders/{entity_cull,meshlet_cull}.comp.spv,
+forward/forward_depth_prepass.task.spv and light_cluster/{mark_active,light_culling}.comp.spv, which do not travel): `python tests/golden/make_spirv_vectors.py`.  The binaries are executed by oracle/spirv_vm.py; what the
 interpreter decides itself is listed in its header (operation order inside Dot / MatrixTimesVector, log2, the ReduceMin
 sampler, invocation order of atomics — the oracle's documented canonical choices, passed in from the oracle).  Every
 other bit of the outputs is the reference binary's: which tests run, on what, in which arithmetic (including
@@ -179,7 +179,22 @@ def case(seed, occlusion_pass, ortho, knife, n=140):
                **kwm).run(nrec, batch=256)
     ndraw = int(B[9][:4].view(np.uint32)[0])
     assert nrec <= cap_d and ndraw <= cap_c
-    return dict(cull_info=np.array(ci).reshape(1), entity_draws=scene.entity_draw_buffer(),
+    # the mesh-shading path: the task shader's binary on the same dispatch records (one workgroup per record), from
+    # the same visibility words the meshlet stage started from
+    T = dict(B)
+    T[7] = np.ascontiguousarray(mvis).view(np.uint8).reshape(-1).copy()
+    T[12], T[13] = np.zeros(64, np.uint8), np.zeros(64, np.uint8)  # vertex / meshlet-data buffers: not read by the task stage
+    tpush = np.zeros(64 + 28, np.uint8)  # mat4 view_proj (unused by the task stage), then the seven registry indices
+    tpush[64:].view(np.uint32)[:] = [3, 5, 12, 8, 13, 4, 10]
+    tm = vm.Machine(module("forward/forward_depth_prepass.task.spv"), T, tpush.tobytes(), log2, **kwm)
+    tm.run(nrec)
+    task = np.zeros(nrec, L.MESH_TASK_RECORD)
+    for k, (counts, pay) in enumerate(tm.emitted):
+        assert counts[1:] == (1, 1)
+        task[k]["task_mesh_count"], task[k]["entity_index"], task[k]["meshlet_offset"] = counts[0], int(pay[0]), int(pay[1])
+        task[k]["meshlet_indices"] = np.array([int(x) & 0xFF for x in pay[2]], np.uint8)
+    assert len(tm.emitted) == nrec
+    return dict(spv_task_records=task, spv_task_mvis=T[7].view(np.uint32).copy(),cull_info=np.array(ci).reshape(1), entity_draws=scene.entity_draw_buffer(),
                 mesh_infos=scene.mesh_infos, entities=scene.entities, meshlets=scene.meshlets,
                 materials=scene.materials, evis_in=evis, mvis_in=mvis, pyramid=pyr,
                 pyramid_size=np.array(ps, np.uint32), caps=np.array([cap_d, cap_c], np.uint32),
@@ -264,11 +279,12 @@ def main():
                 c = case(seed, occlusion_pass, ortho, knife)
                 for k, v in c.items():
                     out[f"{name}/{k}"] = v
-                summary.append((name, int(c["spv_dispatch"][:4].view(np.uint32)[0]), int(c["spv_draw"][:4].view(np.uint32)[0])))
+                summary.append((name, int(c["spv_dispatch"][:4].view(np.uint32)[0]), int(c["spv_draw"][:4].view(np.uint32)[0]),
+                                int(c["spv_task_records"]["task_mesh_count"].sum())))
     path = os.path.join(HERE, "spirv_cull.npz")
     np.savez_compressed(path, **out)
     for s in summary:
-        print("%-22s records %5d  draws %6d" % s)
+        print("%-22s records %5d  draws %6d  task survivors %6d" % s)
     print(path, os.path.getsize(path), "bytes")
 
 

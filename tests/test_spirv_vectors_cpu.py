@@ -26,7 +26,8 @@ def load_case(vectors, name):
                 entities=g("entities").view(L.ENTITY_DATA), meshlets=g("meshlets").view(L.MESHLET),
                 materials=g("materials").view(L.MATERIAL), evis=g("evis_in"), mvis=g("mvis_in"), pyr=g("pyramid"),
                 ps=tuple(int(v) for v in g("pyramid_size")), caps=tuple(int(v) for v in g("caps")),
-                spv_dispatch=g("spv_dispatch"), spv_draw=g("spv_draw"), spv_evis=g("spv_evis"), spv_mvis=g("spv_mvis"))
+                spv_dispatch=g("spv_dispatch"), spv_draw=g("spv_draw"), spv_evis=g("spv_evis"), spv_mvis=g("spv_mvis"),
+                spv_task_records=g("spv_task_records").view(L.MESH_TASK_RECORD), spv_task_mvis=g("spv_task_mvis"))
 
 
 def test_the_file_covers_every_pass_and_projection(vectors):
@@ -54,6 +55,22 @@ def test_oracle_equals_the_reference_binaries(oracle, vectors, name):
     assert np.array_equal(oc[:L.DRAW_HEADER + 28 * ndraw], c["spv_draw"]), "draw commands differ from the binary's"
     if p:
         assert np.array_equal(oev, c["spv_evis"]) and np.array_equal(omv, c["spv_mvis"]), "visibility words differ"
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_task_path_equals_the_task_shader_binary(oracle, vectors, name):
+    """forward/forward_depth_prepass.task.spv, one workgroup per dispatch record of the case: EmitMeshTasksEXT count and
+    MeshTaskPayload per record, and the pass-2 visibility words the task stage writes."""
+    c = load_case(vectors, name)
+    p = int(c["ci"]["occlusion_pass"])
+    pk = (c["pyr"], c["ps"]) if p == 2 else ()
+    recs, omv = oracle.meshlet_task_cull(c["ci"], c["spv_dispatch"], c["meshlets"], c["entities"], c["materials"],
+                                         c["mvis"] if p else None, *pk)
+    want = c["spv_task_records"]
+    assert len(recs) == len(want) and int(want["task_mesh_count"].sum()) == int(c["spv_draw"][:4].view(np.uint32)[0])
+    assert np.array_equal(recs.view(np.uint8), want.view(np.uint8)), "task records differ from the binary's"
+    if p == 2:
+        assert np.array_equal(omv, c["spv_task_mvis"])
 
 
 # ------------------------------------------------------------------------------------------------ light clusters

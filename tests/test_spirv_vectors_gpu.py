@@ -78,3 +78,34 @@ def test_product_equals_the_cluster_binaries(torch_mod, name):
     active = c["unique"][16:16 + 4 * na].view(np.uint32)
     assert np.array_equal(host(gimg, np.uint32).reshape(-1, 2)[active], c["spv_offset_image"][active])
     eng.close()
+
+
+@pytest.mark.parametrize("source", ["meshlet_buffer", "meshlet_stream"])
+@pytest.mark.parametrize("name", CASES)
+def test_product_task_path_equals_the_task_shader_binary(torch_mod, vectors, name, source):
+    """orbit_meshlet_task_cull against forward/forward_depth_prepass.task.spv's outputs."""
+    from orbit_amd.engine import Engine
+
+    torch = torch_mod
+    c = load_case(vectors, name)
+    p = int(c["ci"]["occlusion_pass"])
+    cap_d = c["caps"][0]
+    eng = Engine(0, max_entities=4096, max_dispatches=cap_d + 64, max_draws=1024)
+    g = {k: dev(torch, c[k]) for k in ("entities", "meshlets", "materials")}
+    if source == "meshlet_stream":
+        eng.bind_meshlet_stream(eng.meshlet_stream(g["meshlets"], 0, len(c["meshlets"])))
+    disp = torch.zeros(L.DISPATCH_HEADER + 16 * cap_d, dtype=torch.uint8, device="cuda")
+    disp[:len(c["spv_dispatch"])] = dev(torch, c["spv_dispatch"])
+    mvis = dev(torch, c["mvis"]) if p else None
+    pyr = dev(torch, c["pyr"]) if p == 2 else None
+    n = len(c["spv_task_records"])
+    task = torch.full((44 * cap_d + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+    eng.meshlet_task_cull(c["ci"], disp, g["meshlets"], task, g["entities"], g["materials"], cap_d,
+                          meshlet_visibility_buffer=mvis, depth_pyramid=pyr,
+                          depth_pyramid_size=c["ps"] if p == 2 else (0, 0))
+    torch.cuda.synchronize()
+    eng.status()
+    assert np.array_equal(host(task)[:44 * n], c["spv_task_records"].view(np.uint8).reshape(-1)), "task records differ"
+    if p == 2:
+        assert np.array_equal(host(mvis, np.uint32), c["spv_task_mvis"])
+    eng.close()
