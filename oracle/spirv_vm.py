@@ -356,38 +356,39 @@ class Machine:
 
     # -- execution --------------------------------------------------------------------------------------------------
     def run(self, groups, local_size=None, batch=1):
-        """Dispatch of groups = nx or (nx, ny) workgroups.  `batch` workgroups (consecutive in x-major order) are
+        """Dispatch of groups = nx, (nx, ny) or (nx, ny, nz) workgroups.  `batch` workgroups (consecutive in x-major order) are
         interpreted side by side (their invocations are lanes of one SIMT group: same results, fewer numpy calls) —
         only for shaders without workgroup-shared memory or barriers; atomics still see the invocations in dispatch
         order (workgroup by workgroup, local index ascending)."""
         m = self.m
-        if isinstance(groups, int): groups = (groups, 1)
+        if isinstance(groups, int): groups = (groups,)
+        groups = tuple(groups) + (1,) * (3 - len(groups))
         if local_size is None:
-            if m.local_size: local_size = m.local_size[:2]
-            else: local_size = (m.const_scalar(m.local_size_id[0]), m.const_scalar(m.local_size_id[1]))
-        if isinstance(local_size, int): local_size = (local_size, 1)
-        total = groups[0] * groups[1]
+            if m.local_size: local_size = m.local_size
+            else: local_size = tuple(m.const_scalar(i) for i in m.local_size_id)
+        if isinstance(local_size, int): local_size = (local_size,)
+        local_size = tuple(local_size) + (1,) * (3 - len(local_size))
+        total = groups[0] * groups[1] * groups[2]
         self.emitted = []  # task shaders: (group counts, payload) per workgroup, in dispatch order
         for g in range(0, total, batch):
             self.run_group(g, groups, local_size, min(batch, total - g))
 
     def run_group(self, g, groups, local_size, count=1):
         m = self.m
-        lx, ly = local_size
-        L = lx * ly
+        lx, ly, lz = local_size
+        L = lx * ly * lz
         N = L * count
         self.N, self.vals = N, {}
         lanes = np.arange(N, dtype=U32)
         local = lanes % U32(L)
         wg = U32(g) + lanes // U32(L)
-        wgx, wgy = wg % U32(groups[0]), wg // U32(groups[0])
-        lix, liy = local % U32(lx), local // U32(lx)
+        wgx, wgy, wgz = wg % U32(groups[0]), (wg // U32(groups[0])) % U32(groups[1]), wg // U32(groups[0] * groups[1])
+        lix, liy, liz = local % U32(lx), (local // U32(lx)) % U32(ly), local // U32(lx * ly)
         z = np.zeros(N, U32)
-        one = z + U32(1)
-        builtin = {"GlobalInvocationId": np.stack([wgx * U32(lx) + lix, wgy * U32(ly) + liy, z], axis=1),
-                   "LocalInvocationId": np.stack([lix, liy, z], axis=1), "LocalInvocationIndex": local,
-                   "WorkgroupId": np.stack([wgx, wgy, z], axis=1),
-                   "NumWorkgroups": np.stack([z + U32(groups[0]), z + U32(groups[1]), one], axis=1),
+        builtin = {"GlobalInvocationId": np.stack([wgx * U32(lx) + lix, wgy * U32(ly) + liy, wgz * U32(lz) + liz], axis=1),
+                   "LocalInvocationId": np.stack([lix, liy, liz], axis=1), "LocalInvocationIndex": local,
+                   "WorkgroupId": np.stack([wgx, wgy, wgz], axis=1),
+                   "NumWorkgroups": np.stack([z + U32(groups[0]), z + U32(groups[1]), z + U32(groups[2])], axis=1),
                    "SubgroupSize": np.full(N, self.S, U32), "SubgroupLocalInvocationId": local % U32(self.S),
                    "SubgroupId": local // U32(self.S), "NumSubgroups": np.full(N, (L + self.S - 1) // self.S, U32)}
         # SpecConstantOps (only IAdd of a spec constant and a constant occurs)

@@ -56,3 +56,28 @@ def test_rerunning_the_binaries_reproduces_a_committed_cluster_vector():
     for k, v in fresh.items():
         assert np.array_equal(np.ascontiguousarray(v).view(np.uint8).reshape(-1),
                               np.ascontiguousarray(stored[f"s2/{k}"]).view(np.uint8).reshape(-1)), k
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference's shader binaries are not on this machine")
+def test_the_compaction_binary_marks_the_same_clusters_with_the_same_header(oracle):
+    """active_cluster_compaction.comp.spv (integer-only; a 4x4x4-workgroup dispatch; the last workgroup writes the
+    indirect-dispatch header): the header {ceil(n / 256), 1, 1, n} and the SET of cluster indices equal the oracle's.
+    The order of the list is the order of the binary's atomic appends — nondeterministic on hardware, workgroup-major in
+    the interpreter — where the oracle's canonical order is ascending linear cluster index."""
+    import make_spirv_vectors as gen
+    from oracle import spirv_vm as vm
+    from orbit_amd import layouts as L
+
+    st = np.load(os.path.join(HERE, "golden", "spirv_cluster.npz"))
+    for name in ("s1", "s2", "s4"):
+        masks = st[f"{name}/spv_masks"]
+        cc = [int(v) for v in st[f"{name}/push"].view(L.MARK_ACTIVE_PUSH)[0]["cluster_count"]]
+        total = cc[0] * cc[1] * cc[2]
+        B = {1: masks.view(np.uint8).copy(), 2: np.zeros(16 + 4 * total, np.uint8)}
+        m = vm.Machine(vm.Module(gen.CREF + "active_cluster_compaction.comp.spv"), B,
+                       np.array(cc + [1, 2], np.uint32).tobytes(), gen.log2, subgroup=32)
+        m.run(((cc[0] + 3) // 4, (cc[1] + 3) // 4, (cc[2] + 3) // 4), batch=64)
+        ou, dropped = oracle.cluster_compact(cc, masks, total)
+        n = int(ou[12:16].view(np.uint32)[0])
+        assert dropped == 0 and n > 100 and np.array_equal(B[2][:16], ou[:16])
+        assert sorted(B[2][16:16 + 4 * n].view(np.uint32).tolist()) == ou[16:16 + 4 * n].view(np.uint32).tolist()
