@@ -117,8 +117,7 @@ def transform_sphere(m, sph):
     dy = dot3(m[:, 4], m[:, 5], m[:, 6], m[:, 4], m[:, 5], m[:, 6])
     dz = dot3(m[:, 8], m[:, 9], m[:, 10], m[:, 8], m[:, 9], m[:, 10])
     scale = np.sqrt(gmax(dx, gmax(dy, dz)), dtype=np.float32)
-    transform_sphere.last = (sph[:, 3].astype(np.float32), scale)  # model radius, scale: the occlusion test fuses them
-    return x, y, z, (sph[:, 3] * scale).astype(np.float32)
+    return x, y, z, (sph[:, 3] * scale).astype(np.float32), scale
 
 
 def plane_test(ci, x, y, z, r):
@@ -186,11 +185,10 @@ def hiz_sample(pyr, w0, h0, u, v, lod):
     return gmin(gmin(a, b), gmin(c, d))
 
 
-def occlusion_test(ci, x, y, z, r, pyr, pw, ph, radius=None, scale=None):
+def occlusion_test(ci, x, y, z, r, pyr, pw, ph, radius, scale):
     """Returns (visible, z') — z' is the possibly flipped z (persists).  Operation by operation as the reference's
     compiled shaders hold it (oracle/orbit_oracle.c occlusion_test): radius = model-space radius, r = radius * scale."""
     n = len(x)
-    if radius is None: radius, scale = transform_sphere.last
     with np.errstate(all="ignore"):
         if int(ci["projection_type"]) == 0:
             z = (-z).astype(np.float32)
@@ -266,10 +264,10 @@ def entity_cull(ci, scene_draws, count, entity_draw_count, mesh_infos, entities,
         vib = ((vis_words[g // 32] >> (g % 32).astype(np.uint32)) & 1).astype(bool)
     visible = vib.copy() if op == 1 else np.ones(end, dtype=bool)
     mv = mat_mul(ci["view_matrix"], en["model_matrix"])
-    x, y, z, r = transform_sphere(mv, mi["bounding_sphere"])
+    x, y, z, r, scale = transform_sphere(mv, mi["bounding_sphere"])
     visible &= np.where(visible, plane_test(ci, x, y, z, r), False)
     if op == 2:
-        ov, zf = occlusion_test(ci, x, y, z, r, pyr, *pyr_size)
+        ov, zf = occlusion_test(ci, x, y, z, r, pyr, *pyr_size, mi["bounding_sphere"][:, 3].astype(F), scale)
         z = np.where(visible, zf, z).astype(np.float32) if int(ci["projection_type"]) == 0 else z
         visible = np.where(visible, ov, False)
     should = visible.copy()
@@ -314,7 +312,7 @@ def meshlet_cull(ci, records, meshlets, entities, materials, mvis, pyr=None, pyr
     idx = rec["meshlet_offset"].astype(np.int64) + lane
     m = meshlets[idx]
     mv = mat_mul(ci["view_matrix"], entities["model_matrix"][rec["entity_index"]])
-    x, y, z, r = transform_sphere(mv, m["bounding_sphere"])
+    x, y, z, r, scale = transform_sphere(mv, m["bounding_sphere"])
     ax = (m["cone_axis"].astype(np.int32).astype(np.float32) * RCP127).astype(F)
     axis = mat_vec(mv, ax[:, 0], ax[:, 1], ax[:, 2], np.zeros(len(ax), F))
     cutoff = (m["cone_cutoff"].astype(np.int32).astype(np.float32) * RCP127).astype(F)
@@ -335,7 +333,7 @@ def meshlet_cull(ci, records, meshlets, entities, materials, mvis, pyr=None, pyr
         rhs = fma32(cutoff, np.sqrt(dot3(dx, dy, dz, dx, dy, dz), dtype=F), r)
         visible &= ~(lhs >= rhs)
     if meshlet_occ and op == 2:
-        ov, _ = occlusion_test(ci, x, y, z, r, pyr, *pyr_size)
+        ov, _ = occlusion_test(ci, x, y, z, r, pyr, *pyr_size, m["bounding_sphere"][:, 3].astype(F), scale)
         visible = np.where(visible, ov, False)
     shl = lambda a: np.where(a < 32, np.uint64(1) << a.astype(np.uint64), 0).astype(np.uint64)
     should = visible & ((shl(alpha) & np.uint64(int(ci["alpha_mode_flag"]))) != 0)
