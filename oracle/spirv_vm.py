@@ -64,7 +64,7 @@ class Module:
         raw = open(path, "rb").read()
         w = struct.unpack("<%dI" % (len(raw) // 4), raw)
         assert w[0] == 0x07230203, "not a SPIR-V module"
-        self.types, self.consts, self.names = {}, {}, {}
+        self.types, self.consts, self.names, self.member_names = {}, {}, {}, {}
         self.dec, self.mdec = {}, {}
         self.vars, self.blocks, self.order = {}, {}, []
         self.local_size, self.local_size_id = None, None
@@ -81,6 +81,9 @@ class Module:
                 self.mdec.setdefault(a[0], {}).setdefault(a[1], {})[a[2]] = a[3:]
             elif op == OP["Name"]:
                 self.names[a[0]] = b"".join(struct.pack("<I", x) for x in a[1:]).split(b"\0")[0].decode()
+            elif op == OP["MemberName"]:
+                self.member_names.setdefault(a[0], {})[a[1]] = b"".join(
+                    struct.pack("<I", x) for x in a[2:]).split(b"\0")[0].decode()
         cur = None
         self.spec_ops = []
         for op, a in insts:
@@ -151,6 +154,15 @@ class Module:
                 return self.mdec[tid][last][DEC_OFFSET][0] + self.size_of(t[1][last], True)
             return sum(self.size_of(m, False) for m in t[1])
         raise TypeError(t)
+
+    def push_constant_layout(self):
+        """{member name: (byte offset, byte size)} of the push-constant block, from the module's own decorations."""
+        for vid, (ptid, sc) in self.vars.items():
+            if sc == SC_PUSH:
+                tid = self.types[ptid][2]
+                return {self.member_names.get(tid, {}).get(k, str(k)): (self.mdec[tid][k][DEC_OFFSET][0], self.size_of(mt))
+                        for k, mt in enumerate(self.types[tid][1])}
+        return {}
 
     def const_scalar(self, cid):
         tid, v = self.consts[cid]

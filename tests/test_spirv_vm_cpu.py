@@ -81,3 +81,40 @@ def test_the_compaction_binary_marks_the_same_clusters_with_the_same_header(orac
         n = int(ou[12:16].view(np.uint32)[0])
         assert dropped == 0 and n > 100 and np.array_equal(B[2][:16], ou[:16])
         assert sorted(B[2][16:16 + 4 * n].view(np.uint32).tolist()) == ou[16:16 + 4 * n].view(np.uint32).tolist()
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference's shader binaries are not on this machine")
+@pytest.mark.parametrize("shader", ["forward/forward.task.spv", "shadow/shadow.task.spv"])
+def test_the_other_task_shaders_compute_the_same_task_records(shader):
+    """forward.task and shadow.task cull with the same functions as forward_depth_prepass.task (the one the committed
+    vectors come from): executed on a knife-edge case they must emit the same counts and payloads."""
+    import make_spirv_vectors as gen
+    from oracle import oracle, spirv_vm as vm
+    from orbit_amd import layouts as L
+
+    stored = np.load(os.path.join(HERE, "golden", "spirv_cull.npz"))
+    name = "p0_persp_knife"
+    g = lambda k: stored[f"{name}/{k}"]
+    B = {3: g("spv_dispatch").copy(), 4: g("entities").view(np.uint8).reshape(-1).copy(),
+         5: g("cull_info").view(np.uint8).reshape(-1).copy(), 7: g("mvis_in").view(np.uint8).reshape(-1).copy(),
+         8: g("meshlets").view(np.uint8).reshape(-1).copy(), 10: g("materials").view(np.uint8).reshape(-1).copy(),
+         12: np.zeros(64, np.uint8), 13: np.zeros(64, np.uint8)}
+    mod = vm.Module("/root/reference/shaders/" + shader, spec={0: 32})
+    # the registry indices go where the binary's own push-constant block has the members of those names
+    index = {"draw_command_buffer": 3, "cull_info_buffer": 5, "vertex_buffer": 12, "meshlet_buffer": 8,
+             "meshlet_data_buffer": 13, "entity_buffer": 4, "materials_buffer": 10}
+    layout = mod.push_constant_layout()
+    assert {"draw_command_buffer", "cull_info_buffer", "meshlet_buffer", "entity_buffer", "materials_buffer"} <= set(layout)
+    push = np.zeros(max(o + n for o, n in layout.values()), np.uint8)
+    for member, (off, size) in layout.items():
+        if size == 4:
+            push[off:off + 4].view(np.uint32)[0] = index.get(member, 12)  # anything else: an empty 64-byte buffer
+    nrec = int(B[3][:4].view(np.uint32)[0])
+    m = vm.Machine(mod, B, push.tobytes(), gen.log2, subgroup=32)
+    m.run(nrec)
+    want = g("spv_task_records").view(L.MESH_TASK_RECORD)
+    assert len(m.emitted) == nrec
+    for k, (counts, pay) in enumerate(m.emitted):
+        assert counts == (int(want[k]["task_mesh_count"]), 1, 1)
+        assert (int(pay[0]), int(pay[1])) == (int(want[k]["entity_index"]), int(want[k]["meshlet_offset"]))
+        assert [int(x) & 0xFF for x in pay[2]] == want[k]["meshlet_indices"].tolist()
