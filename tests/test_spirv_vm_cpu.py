@@ -118,3 +118,30 @@ def test_the_other_task_shaders_compute_the_same_task_records(shader):
         assert counts == (int(want[k]["task_mesh_count"]), 1, 1)
         assert (int(pay[0]), int(pay[1])) == (int(want[k]["entity_index"]), int(want[k]["meshlet_offset"]))
         assert [int(x) & 0xFF for x in pay[2]] == want[k]["meshlet_indices"].tolist()
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference's shader binaries are not on this machine")
+@pytest.mark.parametrize("placement", ["model", "mesh"])
+def test_config1_bitset_is_what_the_entity_cull_binary_keeps(placement):
+    """BASELINE config 1 (8 192 spheres, frustum only): the fixture's visibility bitset — generated by the oracle — is
+    exactly the set of entities entity_cull.comp.spv emits dispatch records for."""
+    import make_spirv_vectors as gen
+    import scenes as sc
+    from oracle import spirv_vm as vm
+    from orbit_amd import layouts as L
+
+    g = np.load(os.path.join(HERE, "golden", "config1_spheres.npz"))
+    spheres = sc.config1_spheres()
+    edb, mesh, ent, _, _ = sc.config1_scene(spheres, placement)
+    n = len(spheres)
+    ci = sc.make_cull_info(sc.default_camera().view, g["planes"])
+    B = {1: np.ascontiguousarray(edb).view(np.uint8).reshape(-1).copy(), 2: mesh.view(np.uint8).reshape(-1).copy(),
+         4: ent.view(np.uint8).reshape(-1).copy(), 5: np.array(ci).reshape(1).view(np.uint8).reshape(-1).copy(),
+         3: np.zeros(L.DISPATCH_HEADER + 16 * (n + 8), np.uint8)}
+    B[3][4:12] = np.array([1, 1], np.uint32).view(np.uint8)
+    vm.Machine(gen.module("entity_cull.comp.spv"), B, np.array([1, 2, 3, 4, 5], np.uint32).tobytes(), gen.log2,
+               subgroup=32).run((n + 255) // 256, batch=8)
+    hdr, recs = L.dispatch_buffer_records(B[3])
+    want = np.flatnonzero(np.unpackbits(g["bitset"].view(np.uint8), bitorder="little")[:n])
+    assert len(recs) == int(g["count"]) and np.array_equal(recs["entity_index"], want)
+    assert bool((recs["meshlet_count"] == 1).all()) and np.array_equal(recs["meshlet_offset"], want)
