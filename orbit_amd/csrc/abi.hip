@@ -609,7 +609,7 @@ int32_t orbit_meshlet_stream_create(OrbitCtx *ctx, uint64_t first_meshlet, uint6
     if (e == hipSuccess) e = hipMalloc((void **)&ms->cmd, capacity * 12u);
     if (e != hipSuccess) {
         orbit_meshlet_stream_destroy(ms);
-        return hip_fail(ctx, e, "meshlet_stream_create: hipMalloc (36 B per meshlet)");
+        return hip_fail(ctx, e, "meshlet_stream_create: hipMalloc (34 B per meshlet)");
     }
     *out_stream = ms;
     return ORBIT_OK;
