@@ -202,9 +202,14 @@ class Ptr:
 class Machine:
     """Runs entry point `main` of a Module for whole workgroups."""
 
-    def __init__(self, module, buffers, push, log2, images=None, samplers=None, sample=None, subgroup=32):
+    def __init__(self, module, buffers, push, log2, images=None, samplers=None, sample=None, subgroup=32,
+                 fused_dot=False):
+        """fused_dot: evaluate Dot / MatrixTimesVector / Length as fma chains (a0*b0, then fma(a1, b1, acc), ...) —
+        what AMD's and other drivers' compilers typically emit — instead of the canonical separately rounded sums.
+        Only tools/spirv_sensitivity.py uses it, to measure how much of the output depends on that driver choice."""
         self.m, self.buffers, self.push = module, buffers, np.frombuffer(bytes(push), np.uint8).copy()
         self.log2, self.images, self.samplers, self.sample, self.S = log2, images or {}, samplers or {}, sample, subgroup
+        self.fused_dot = fused_dot
 
     # -- values -----------------------------------------------------------------------------------------------------
     def const(self, cid, N):
@@ -326,17 +331,18 @@ class Machine:
         return sum(self.m.size_of(mt, False) for mt in self.m.types[tid][1][:k])
 
     # -- arithmetic -------------------------------------------------------------------------------------------------
-    @staticmethod
-    def dot(a, b):
-        acc = a[:, 0] * b[:, 0]
-        for k in range(1, a.shape[1]): acc = (acc + a[:, k] * b[:, k]).astype(F32)
+    def dot(self, a, b):
+        acc = (a[:, 0] * b[:, 0]).astype(F32)
+        for k in range(1, a.shape[1]):
+            acc = fma32(a[:, k], b[:, k], acc) if self.fused_dot else (acc + a[:, k] * b[:, k]).astype(F32)
         return acc.astype(F32)
 
     def mat_vec(self, M, v):  # M[lane, col, row]
         rows = []
         for r in range(M.shape[2]):
-            acc = M[:, 0, r] * v[:, 0]
-            for c in range(1, M.shape[1]): acc = (acc + M[:, c, r] * v[:, c]).astype(F32)
+            acc = (M[:, 0, r] * v[:, 0]).astype(F32)
+            for c in range(1, M.shape[1]):
+                acc = fma32(M[:, c, r], v[:, c], acc) if self.fused_dot else (acc + M[:, c, r] * v[:, c]).astype(F32)
             rows.append(acc.astype(F32))
         return np.stack(rows, axis=1)
 
