@@ -298,7 +298,24 @@ def main():
     # The frame count must be the same on every rank (a step of the sharded engine contains collectives), so it is
     # derived from the slowest rank's time for the first eight frames, not from each rank's own clock.
     settle_frames = 0
+    cold_ms_per_step = None
     if args.settle_ms > 0:
+        # for the record: the same W + K steps straight from idle, i.e. inside the transient (never the metric)
+        for _ in range(args.warmup):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        tc = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        cold = torch.tensor([(time.perf_counter() - tc) / args.steps * 1e3], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(cold, op=dist.ReduceOp.MAX)
+        cold_ms_per_step = float(cold.item())
         for batch in range(2):  # eight cold frames (code objects, first touches), then eight that are timed
             t_settle = time.perf_counter()
             for _ in range(8):
@@ -524,6 +541,7 @@ def main():
                 "sharding": f"entity ranges over {world} rank(s)", "gather": bool(do_gather),
                 "frames_in_flight": F,
                 "settle_ms": args.settle_ms, "settle_frames": settle_frames,
+                "ms_per_step_without_settle": cold_ms_per_step,
                 "exchange": (args.exchange if do_gather else None), "transport": transport,
                 "meshlet_source": (f"derived meshlet streams (22 B per meshlet evaluated, 12 B per survivor gathered; "
                                    f"built once from the meshlet buffer before the timed region in "
