@@ -726,7 +726,12 @@ class Machine:
             img, coord = V(x[0]), V(x[1])
             out = np.zeros((N, 4), F32)
             act = np.flatnonzero(mask)
-            out[act] = img["fetch"](coord[act, 0].astype(np.int64), coord[act, 1].astype(np.int64))
+            if len(x) > 2 and x[2] & 0x40:  # Sample image operand: a multisampled image
+                smp = V(x[3]).view(U32)
+                out[act] = img["fetch_ms"](coord[act, 0].astype(np.int64), coord[act, 1].astype(np.int64),
+                                           smp[act].astype(np.int64))
+            else:
+                out[act] = img["fetch"](coord[act, 0].astype(np.int64), coord[act, 1].astype(np.int64))
             r = out
         else:
             raise NotImplementedError(n)

@@ -206,18 +206,21 @@ def case(seed, occlusion_pass, ortho, knife, n=140):
 CREF = REF + "light_cluster/"
 
 
-def cluster_case(seed, width, height, n_lights, quantised):
+def cluster_case(seed, width, height, n_lights, quantised, samples=1):
     """mark_active.comp.spv and light_culling.comp.spv (active_cluster_compaction.comp is integer-only and its list
     order is the atomics' — the oracle's list is handed to the last stage as input)."""
     cam = sc.default_camera(aspect=width / height)
     depth = sc.make_depth(seed, width, height, cam, n_occluders=40, ground=(seed % 2 == 0))
+    if samples > 1:  # a multisampled depth buffer [h][w][samples] (cluster.rs:439-456)
+        jit = sc.rnd_range(seed, 90, np.arange(width * height * samples), 0.9, 1.1).reshape(height, width, samples)
+        depth = (depth[:, :, None] * jit).astype(F)
     tile, zsl, far = 8, 32, 200.0
     cx, cy = -(-width // tile), -(-height // tile)
     zs, zb = oracle.cluster_grid_info(cam.z_near, far, zsl)
     push = np.zeros((), dtype=L.MARK_ACTIVE_PUSH)
     push["cluster_count"], push["tile_size_px"], push["screen_size"] = (cx, cy, zsl), tile, (width, height)
     push["z_near"], push["z_far"], push["z_scale"], push["z_bias"] = cam.z_near, far, zs, zb
-    push["depth_buffer_sample_count"] = 1
+    push["depth_buffer_sample_count"] = samples
     info = np.zeros((), dtype=L.CLUSTER_CULL_INFO)
     info["world_to_view_matrix"] = sc.mat4_cols(cam.view)
     info["screen_to_view_matrix"] = sc.mat4_cols(np.linalg.inv(cam.proj.astype(np.float64)).astype(F))
@@ -233,10 +236,12 @@ def cluster_case(seed, width, height, n_lights, quantised):
     B = {1: np.zeros(4 * cx * cy, np.uint8), 2: np.zeros(8 * total, np.uint8)}
     pv = np.array(push).copy().reshape(())
     pv["depth_buffer"], pv["depth_slice_mask_buffer"], pv["depth_bounds_buffer"] = 7, 1, 2
-    fetch = lambda x, y: np.stack([depth[np.clip(y, 0, height - 1), np.clip(x, 0, width - 1)]]
-                                  + [np.zeros(len(x), F)] * 3, axis=1)
+    clipped = lambda x, y: (np.clip(y, 0, height - 1), np.clip(x, 0, width - 1))
+    fetch = lambda x, y: np.stack([depth[clipped(x, y)]] + [np.zeros(len(x), F)] * 3, axis=1)
+    fetch_ms = lambda x, y, k: np.stack([depth[clipped(x, y) + (k,)]] + [np.zeros(len(x), F)] * 3, axis=1)
     vm.Machine(vm.Module(CREF + "mark_active.comp.spv"), B, pv.tobytes(), log2,
-               images={7: {"size": lambda lod: (width, height), "fetch": fetch}}, samplers={k: {"id": k} for k in range(8)},
+               images={7: {"size": lambda lod: (width, height), "fetch": fetch, "fetch_ms": fetch_ms}},
+               samplers={k: {"id": k} for k in range(8)},
                subgroup=32).run(((width + 7) // 8, (height + 7) // 8), batch=16)
     masks, bounds = B[1].view(np.uint32).copy(), B[2].view(np.uint32).reshape(-1, 2).copy()
     unique, _ = oracle.cluster_compact([cx, cy, zsl], masks, total)
@@ -264,8 +269,8 @@ def cluster_case(seed, width, height, n_lights, quantised):
 def main():
     out, summary = {}, []
     cl = {}
-    for seed, quantised in ((1, False), (2, True), (4, True)):
-        c = cluster_case(seed, 96, 64, 120, quantised)
+    for seed, quantised, samples in ((1, False, 1), (2, True, 1), (4, True, 1), (5, False, 4)):
+        c = cluster_case(seed, 96, 64, 120, quantised, samples)
         for k, v in c.items():
             cl[f"s{seed}/{k}"] = v
         print("cluster seed %d: active %d, light indices %d" % (seed, int(c["unique"][12:16].view(np.uint32)[0]),
