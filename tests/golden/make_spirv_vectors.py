@@ -227,7 +227,7 @@ def cluster_case(seed, width, height, n_lights, quantised, samples=1):
     info["cluster_count"], info["tile_size_px"], info["screen_size"] = (cx, cy, zsl), tile, (width, height)
     info["z_near"], info["z_far"], info["global_light_count"] = cam.z_near, far, n_lights
     lights = sc.make_lights(seed, n_lights)
-    if quantised:  # positions on a quarter-unit grid around the camera, few radii: exact ties in the sphere test
+    if quantised is True:  # positions on a quarter-unit grid around the camera, few radii: exact ties in the sphere test
         rng = np.random.default_rng(seed)
         lights = lights.copy()
         lights["position"][:] = (rng.integers(-24, 25, (n_lights, 3)) / 4).astype(F)
@@ -246,6 +246,23 @@ def cluster_case(seed, width, height, n_lights, quantised, samples=1):
     masks, bounds = B[1].view(np.uint32).copy(), B[2].view(np.uint32).reshape(-1, 2).copy()
     unique, _ = oracle.cluster_compact([cx, cy, zsl], masks, total)
     na = int(unique[12:16].view(np.uint32)[0])
+    if quantised == "knife":
+        # lights whose radius puts the sphere-box test of one active cluster within an ulp of equality: centre beyond
+        # the box's max corner by an inexact offset, radius = sqrt of the squared distance (so r * r ~ sqr_dist)
+        rng = np.random.default_rng(seed)
+        lights = lights.copy()
+        view = np.asarray(cam.view, np.float64)
+        act = unique[16:16 + 4 * na].view(np.uint32)
+        for k in range(n_lights):
+            mn, mx = oracle.cluster_aabb(info, bounds, int(act[rng.integers(0, na)]))
+            off = rng.uniform(0.05, 1.5, 3).astype(F)
+            sel = rng.integers(0, 2, 3).astype(bool)  # some axes inside the slab (no contribution), at least one outside
+            sel[rng.integers(0, 3)] = True
+            centre = np.where(sel, mx + off, (mn + mx) * F(0.5)).astype(F)
+            d = np.where(sel, centre - mx, F(0)).astype(F)
+            lights["outer_radius"][k] = F(np.sqrt(np.float64(d[0]) ** 2 + np.float64(d[1]) ** 2 + np.float64(d[2]) ** 2))
+            world = np.linalg.inv(view) @ np.array([centre[0], centre[1], centre[2], 1.0])
+            lights["position"][k] = world[:3].astype(F)
     cap_l = 256 * na + 16
     iv = np.array(info).copy().reshape(())
     iv["unique_cluster_buffer"], iv["cluster_offset_image"], iv["light_index_buffer"] = 1, 9, 2
@@ -269,7 +286,7 @@ def cluster_case(seed, width, height, n_lights, quantised, samples=1):
 def main():
     out, summary = {}, []
     cl = {}
-    for seed, quantised, samples in ((1, False, 1), (2, True, 1), (4, True, 1), (5, False, 4)):
+    for seed, quantised, samples in ((1, False, 1), (2, True, 1), (4, True, 1), (5, False, 4), (6, "knife", 1)):
         c = cluster_case(seed, 96, 64, 120, quantised, samples)
         for k, v in c.items():
             cl[f"s{seed}/{k}"] = v

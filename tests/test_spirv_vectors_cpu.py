@@ -75,7 +75,7 @@ def test_oracle_task_path_equals_the_task_shader_binary(oracle, vectors, name):
 
 # ------------------------------------------------------------------------------------------------ light clusters
 CLUSTER_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spirv_cluster.npz")
-CLUSTER_CASES = ["s1", "s2", "s4", "s5"]  # s5: a 4-sample depth buffer
+CLUSTER_CASES = ["s1", "s2", "s4", "s5", "s6"]  # s5: a 4-sample depth buffer; s6: knife-edge light radii
 
 
 @pytest.fixture(scope="module")

@@ -47,7 +47,7 @@ def test_product_equals_the_reference_binaries(torch_mod, vectors, name, source)
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["s1", "s2", "s4", "s5"])
+@pytest.mark.parametrize("name", ["s1", "s2", "s4", "s5", "s6"])
 def test_product_equals_the_cluster_binaries(torch_mod, name):
     """cluster_mark / cluster_compact / cluster_assign through the C ABI against mark_active.comp.spv and
     light_culling.comp.spv outputs (tests/golden/spirv_cluster.npz)."""

@@ -69,7 +69,7 @@ def test_the_compaction_binary_marks_the_same_clusters_with_the_same_header(orac
     from orbit_amd import layouts as L
 
     st = np.load(os.path.join(HERE, "golden", "spirv_cluster.npz"))
-    for name in ("s1", "s2", "s4", "s5"):
+    for name in ("s1", "s2", "s4", "s5", "s6"):
         masks = st[f"{name}/spv_masks"]
         cc = [int(v) for v in st[f"{name}/push"].view(L.MARK_ACTIVE_PUSH)[0]["cluster_count"]]
         total = cc[0] * cc[1] * cc[2]
