@@ -31,7 +31,7 @@ def engine(torch_mod, request):
 
 @pytest.mark.parametrize("ortho", [False, True], ids=["persp", "ortho"])
 @pytest.mark.parametrize("occlusion_pass", [0, 1, 2])
-@pytest.mark.parametrize("seed", [31, 32, 33, 34])
+@pytest.mark.parametrize("seed", range(31, 31 + int(os.environ.get("ORBIT_KNIFE_SEEDS", "4"))))
 def test_knife_edge_scene(torch_mod, engine, oracle, seed, occlusion_pass, ortho):
     import make_spirv_vectors as gen
 
