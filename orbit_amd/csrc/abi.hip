@@ -29,6 +29,8 @@ struct OrbitMeshletStream {
     uint32_t *cone = nullptr;
     uint16_t *mat = nullptr;
     uint32_t *cmd = nullptr;
+    uint16_t *cnt = nullptr;
+    uint32_t *link = nullptr; // word 0 = meshlets (first & ~31) .. +31
     // Meshlet buffer of the last update (nullptr = never updated).  Atomic: a stream may be bound to several contexts,
     // each with its own lock; the device-side order of an update against the culls that read it is the caller's, like
     // the order of the meshlet upload itself.
@@ -131,8 +133,9 @@ int32_t check_cull_info(OrbitCtx *ctx, const OrbitGpuCullInfo *ci) {
 
 // arrays based at global meshlet index 0, like meshlet_buffer itself
 MeshletStreamView stream_view(const OrbitMeshletStream *ms) {
-    return MeshletStreamView{ms->sphere - ms->first, ms->cone - ms->first, ms->mat - ms->first,
-                             ms->cmd - 3u * ms->first, (uint32_t)ms->first, (uint32_t)ms->capacity};
+    return MeshletStreamView{ms->sphere - ms->first, ms->cone - ms->first,   ms->mat - ms->first,
+                             ms->cmd - 3u * ms->first, ms->cnt - ms->first,  ms->link - (ms->first >> 5),
+                             (uint32_t)ms->first,      (uint32_t)ms->capacity};
 }
 
 PyramidView make_pyramid_view(const float *texels, const uint32_t size[2],
@@ -479,7 +482,7 @@ int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCull
     p.ci = *ci;
     p.dispatch_buffer = (const uint8_t *)b->meshlet_dispatch_buffer;
     p.meshlets = (const OrbitMeshlet *)b->meshlet_buffer;
-    p.ms = MeshletStreamView{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+    p.ms = MeshletStreamView{};
     if (const OrbitMeshletStream *ms = ctx->meshlet_stream; ms && ms->source.load() == b->meshlet_buffer)
         // arrays based at global meshlet index 0, like meshlet_buffer itself
         p.ms = stream_view(ms);
@@ -607,9 +610,14 @@ int32_t orbit_meshlet_stream_create(OrbitCtx *ctx, uint64_t first_meshlet, uint6
     if (e == hipSuccess) e = hipMalloc((void **)&ms->cone, capacity * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&ms->mat, capacity * sizeof(uint16_t) + 256u);
     if (e == hipSuccess) e = hipMalloc((void **)&ms->cmd, capacity * 12u);
+    if (e == hipSuccess) e = hipMalloc((void **)&ms->cnt, capacity * sizeof(uint16_t) + 256u);
+    // one bit per meshlet in words aligned to global index 0, plus the word behind a record that ends the range
+    const size_t link_words = (size_t)(((first_meshlet + capacity + 31u) >> 5) - (first_meshlet >> 5)) + 2u;
+    if (e == hipSuccess) e = hipMalloc((void **)&ms->link, link_words * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(ms->link, 0, link_words * sizeof(uint32_t));
     if (e != hipSuccess) {
         orbit_meshlet_stream_destroy(ms);
-        return hip_fail(ctx, e, "meshlet_stream_create: hipMalloc (34 B per meshlet)");
+        return hip_fail(ctx, e, "meshlet_stream_create: hipMalloc (36.2 B per meshlet)");
     }
     *out_stream = ms;
     return ORBIT_OK;
@@ -626,9 +634,7 @@ int32_t orbit_meshlet_stream_update(OrbitCtx *ctx, OrbitMeshletStream *ms, const
                     (unsigned long long)first, (unsigned long long)count, (unsigned long long)ms->first,
                     (unsigned long long)ms->capacity);
     ms->source.store(meshlet_buffer);
-    const hipError_t e = launch_meshlet_stream_build((const OrbitMeshlet *)meshlet_buffer, first, count,
-                                                     ms->sphere - ms->first, ms->cone - ms->first,
-                                                     ms->mat - ms->first, ms->cmd - 3u * ms->first,
+    const hipError_t e = launch_meshlet_stream_build((const OrbitMeshlet *)meshlet_buffer, first, count, stream_view(ms),
                                                      (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_stream_build");
     return ORBIT_OK;
@@ -640,6 +646,8 @@ int32_t orbit_meshlet_stream_destroy(OrbitMeshletStream *ms) {
     (void)hipFree(ms->cone);
     (void)hipFree(ms->mat);
     (void)hipFree(ms->cmd);
+    (void)hipFree(ms->cnt);
+    (void)hipFree(ms->link);
     delete ms;
     return ORBIT_OK;
 }
@@ -675,7 +683,7 @@ int32_t orbit_expand_visible(OrbitCtx *ctx, const void *visible_buffer, const vo
     const OrbitMeshletStream *ms = ctx->meshlet_stream;
     const MeshletStreamView view = (ms && ms->source.load() == meshlet_buffer)
                                        ? stream_view(ms)
-                                       : MeshletStreamView{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+                                       : MeshletStreamView{};
     const hipError_t e = launch_visible_expand((const uint8_t *)visible_buffer, (const OrbitMeshlet *)meshlet_buffer, view,
                                                (uint8_t *)draw_commands_buffer, draw_capacity, ctx->num_cus,
                                                ctx->zero_page, ctx->status, (hipStream_t)stream);

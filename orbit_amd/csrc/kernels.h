@@ -41,17 +41,31 @@ struct EntityCullParams {
 };
 
 // Derived meshlet streams (orbit_meshlet_stream_*): the static 32-B Meshlet records re-laid out once, at upload, into
-// what the streaming evaluation reads for EVERY meshlet (bounding sphere; cone + the word with material index and
-// counts: 24 B) and what only a survivor's command needs (vertex_offset, data_offset, counts: 12 B, gathered by the
-// emit launch).  Pointers are based at global meshlet index 0; sphere == nullptr: no stream, evaluate the Meshlet buffer.
+// what the streaming evaluation reads for EVERY meshlet (bounding sphere 16 B, cone 4 B, material index 2 B: 22 B) and
+// what only a survivor's command needs.  The command words exist twice: `cmd` (12 B per meshlet: vertex_offset,
+// data_offset, word 7) for gathers, and the chain form the emit launch streams — `cnt` (2 B: vertex_count |
+// triangle_count << 8) plus one `link` bit per meshlet that says "this meshlet's vertex_offset equals its
+// predecessor's and its data_offset is the predecessor's plus the predecessor's data size", which is how
+// compute_meshlets / add_mesh lay a mesh out (src/assets/mesh.rs:309-316, assets/mod.rs:413-416).  Where the links
+// hold, a record's offsets follow from ONE gathered base and a prefix sum over 2-B counts; where they do not, the
+// survivor's 12 B are gathered from `cmd`.  Pointers are based at global meshlet index 0 (`link`: word 0 = meshlets
+// 0..31); sphere == nullptr: no stream, evaluate the Meshlet buffer.
 struct MeshletStreamView {
     const uint4 *sphere;  // Meshlet::bounding_sphere bits
     const uint32_t *cone; // cone_axis | cone_cutoff << 24
     const uint16_t *mat;  // material_index
     const uint32_t *cmd;  // 3 words per meshlet: vertex_offset, data_offset, word 7 again
+    const uint16_t *cnt;  // vertex_count | triangle_count << 8
+    const uint32_t *link; // bit (i & 31) of word (i >> 5): meshlet i continues meshlet i - 1's chain
     uint32_t first, count; // global meshlet indices the arrays cover: [first, first + count)
     __host__ __device__ bool covers(uint32_t meshlet) const { return meshlet - first < count; }
 };
+
+// words of meshlet data a meshlet occupies: its vertex indices, then its triangle bytes rounded up to words
+// (src/assets/mesh.rs:310-316)
+__host__ __device__ inline uint32_t meshlet_data_words(uint32_t vertex_count, uint32_t triangle_count) {
+    return vertex_count + ((triangle_count * 3u + 3u) >> 2);
+}
 
 struct MeshletCullParams {
     OrbitGpuCullInfo ci;
@@ -166,8 +180,10 @@ hipError_t launch_meshlet_cull_views(const MeshletCullViews &all, uint32_t n, ui
 // checked by orbit_ctx_create against caps.max_dispatches, so no launch is ever enqueued for a larger one.
 uint32_t max_dispatch_capacity();
 // meshlets[first, first + count) -> the three streams (a plain re-layout, one pass)
-hipError_t launch_meshlet_stream_build(const OrbitMeshlet *meshlets, uint64_t first, uint64_t count, uint4 *sphere,
-                                       uint32_t *cone, uint16_t *mat, uint32_t *cmd, hipStream_t s);
+// `ms`: the stream's arrays (writable through the const view) and its range; link bits are re-derived for
+// [first, first + count] — the meshlet after the range chains from the range's last one
+hipError_t launch_meshlet_stream_build(const OrbitMeshlet *meshlets, uint64_t first, uint64_t count,
+                                       const MeshletStreamView &ms, hipStream_t s);
 // ms.cmd (optional): the derived command-word stream of `meshlets`, based at global meshlet index 0
 hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, const MeshletStreamView &ms,
                                  uint8_t *draw_buffer, uint32_t draw_capacity, uint32_t num_cus, const void *zero_page,

@@ -888,10 +888,11 @@ constexpr uint32_t kEmitChunkTable = 1024; // chunk bases kept in LDS (1 Mi tile
 // VISIBLE: instead of the 28-B commands the launch writes the compact visible list — 8 B per survivor
 // {meshlet_index, entity_index} after an 8-B {count, 0} header — which is what the sharded engine sends over
 // xGMI (visible_expand_kernel turns the gathered lists into commands on the receiving GPU).
-// STREAM (derived meshlet streams): meshlet_eval kept no payload; every tile is rebuilt from its ballots and the
-// survivors' three command words are gathered from the 12-B command stream (nothing at all for the visible list).
+// STREAM (derived meshlet streams): meshlet_eval kept no payload; every tile is rebuilt from its ballots.  The visible
+// list needs nothing else (this body); draw commands come from meshlet_emit_chain_body below.
 template <bool VISIBLE, bool STREAM = false>
 __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
+    static_assert(VISIBLE || !STREAM, "draw commands from the streams: meshlet_emit_chain_body");
     __shared__ uint16_t s_list[4][kTileRows * 64];
     __shared__ uint32_t s_cmd[4][64 * 7];
     __shared__ uint32_t s_chunk_base[kEmitChunkTable];
@@ -949,19 +950,10 @@ __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
                     const uint32_t code = j < n ? list[j] : 0u;
                     const uint32_t rid = (code >> 6) * 2u + ((code >> 5) & 1u); // record 2r + half
                     const uint32_t mi = (uint32_t)__shfl((int)cur.rec.y, (int)rid, 64) + (code & 31u);
-                    uint4 b = make_uint4(0u, 0u, 0u, 0u);
-                    if constexpr (STREAM) {
-                        if constexpr (!VISIBLE) { // the visible list carries indices only
-                            const uint32_t *c3 = (j < n && p.ms.covers(mi)) ? p.ms.cmd + (size_t)mi * 3u
-                                                                            : reinterpret_cast<const uint32_t *>(p.zero_page);
-                            b.y = c3[0];
-                            b.z = c3[1];
-                            b.w = c3[2];
-                        }
-                    } else {
+                    uint4 b = make_uint4(0u, 0u, 0u, 0u); // STREAM: the visible list carries indices only
+                    if constexpr (!STREAM)
                         b = *(j < n ? reinterpret_cast<const uint4 *>(p.meshlets + mi) + 1
                                     : reinterpret_cast<const uint4 *>(p.zero_page));
-                    }
                     pay = make_payload(code & 31u, rid, b);
                 } else {
                     pay = j0 == 0u ? cur_pay : emit_load_payload(p, tile, n, j0, lane);
@@ -1014,13 +1006,254 @@ __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Draw commands from the derived streams.  meshlet_eval kept only ballots; a survivor's command needs its meshlet's
+// vertex_offset, data_offset and the two counts (:216-230).  Gathering them per survivor (12 B out of a 128-B line
+// each) moved 3x the bytes the commands hold; this body streams 2 B per meshlet of the records that have survivors
+// instead and derives the rest, because the uploader lays a mesh's meshlets out as a chain (kernels.h
+// MeshletStreamView): data_offset[i + 1] = data_offset[i] + vertex_count[i] + ceil(3 * triangle_count[i] / 4), one
+// vertex_offset per submesh.
+//   phase A  lane = meshlet (the evaluation's row layout): data sizes from the counts, prefix sum inside each record
+//            (DPP, two rows per scan as 16-bit halves), {prefix, counts} of every lane and the records' totals to LDS;
+//            the survivors' (row, lane) codes compacted from the ballots.
+//   phase B  lane = record: a record's base is the gathered {vertex_offset, data_offset} of its first meshlet where a
+//            chain starts (first record of the tile with survivors, a jump in meshlet_offset, a predecessor without
+//            survivors, a broken link since the predecessor's second meshlet: all known a tile ahead, so the gather
+//            is prefetched), else the predecessor's base + total — a segmented prefix sum over the 16 records.
+//   phase C  lane = survivor: offsets = record base + prefix, valid while the record's link bits up to the lane are
+//            all set; the few survivors behind a broken link gather their own 8 B.  Commands go out through LDS as
+//            contiguous words (as in meshlet_emit_body).
+// Pipeline per wave: records, count, base, ballots three tiles ahead; link words two; counts and chain-start bases one.
+struct __attribute__((aligned(16))) ChainLds {
+    uint4 rec[kTileRecords];      // phase B -> C: {data_offset base, vertex_offset, entity_index, meshlet_offset}
+    uint4 rs[kTileRecords];       // chain_stage: the records where every lane can index them: {entity, offset, count, ballot}
+    uint32_t row[kTileRows * 64]; // phase A -> C, per (row, lane): size prefix inside the record | counts << 16
+    uint32_t link[kTileRecords];  // link bits of the record's 32 lanes
+    uint32_t tot[kTileRows];      // [pair * 2 + half]: data words of the records of rows pair / pair + 4 (16:16)
+    uint32_t cmd[64 * 7];
+    uint16_t list[kTileRows * 64];
+};
+
+struct LinkStage {
+    uint32_t l0, l1; // lane = record: the two link words that cover its lanes
+};
+
+struct ChainStage {
+    uint32_t cnt[kTileRows]; // per row: this lane's meshlet's vertex_count | triangle_count << 8 (0: not loaded)
+    uint32_t link32;         // lane = record: bit l = link bit of meshlet (meshlet_offset + l)
+    uint32_t bv, bd;         // lane = record: vertex_offset / data_offset of its first meshlet (chain starts only)
+    uint32_t flags;          // lane = record: 1 = has survivors (counts loaded), 2 = chain start (bv, bd loaded)
+};
+
+// lane = record (lanes 16.. repeat lanes 0..15)
+__device__ __forceinline__ bool chain_has(const MeshletCullParams &p, const EmitTile &e) {
+    return e.mword != 0u && e.rec.z != 0u && p.ms.covers(e.rec.y);
+}
+
+__device__ __forceinline__ LinkStage link_stage(const MeshletCullParams &p, const EmitTile &e) {
+    const bool has = chain_has(p, e);
+    const uint32_t *lw = has ? p.ms.link + (e.rec.y >> 5) : reinterpret_cast<const uint32_t *>(p.zero_page);
+    return LinkStage{lw[0], lw[has ? 1 : 0]};
+}
+
+__device__ __forceinline__ ChainStage chain_stage(const MeshletCullParams &p, ChainLds &S, const EmitTile &e,
+                                                  const LinkStage &k, int lane) {
+    ChainStage s;
+    const uint32_t half = lane >> 5, ml = lane & 31;
+    if (lane < (int)kTileRecords) S.rs[lane] = make_uint4(e.rec.x, e.rec.y, e.rec.z, e.mword);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint16_t *zero16 = reinterpret_cast<const uint16_t *>(p.zero_page);
+    const uint32_t *zero32 = reinterpret_cast<const uint32_t *>(p.zero_page);
+#pragma unroll
+    for (int r = 0; r < (int)kTileRows; r++) {
+        const uint4 R = S.rs[2 * r + half];
+        const uint32_t m = R.y + ml;
+        // straight-line loads; records without survivors are not read at all
+        const bool ok = ml < R.z && R.w != 0u && p.ms.covers(m);
+        s.cnt[r] = (uint32_t) * (ok ? p.ms.cnt + m : zero16);
+    }
+    // lane = record; row_shr stays inside a row of 16 lanes.  A record continues its predecessor's chain when that
+    // one was read too, ends where this one begins, and every link from the predecessor's second meshlet to this
+    // record's first one holds; otherwise it starts a chain from the gathered offsets of its first meshlet.
+    const bool has = chain_has(p, e);
+    s.link32 = __funnelshift_r(k.l0, k.l1, e.rec.y & 31u);
+    const bool full = has && e.rec.z == 32u && (s.link32 | 1u) == 0xFFFFFFFFu; // the chain reaches the record's end
+    const uint32_t prev_y = row_shr1(e.rec.y, 0u), prev_full = row_shr1(full ? 1u : 0u, 0u);
+    const bool cont = has && prev_full != 0u && e.rec.y == prev_y + 32u && (s.link32 & 1u) != 0u;
+    const bool start = has && !cont;
+    s.flags = (has ? 1u : 0u) | (start ? 2u : 0u);
+    const uint32_t *bc = start ? p.ms.cmd + (size_t)e.rec.y * 3u : zero32;
+    s.bv = bc[0];
+    s.bd = bc[1];
+    return s;
+}
+
+// data sizes of two meshlets, packed 16:16, from their packed counts (meshlet_data_words, kernels.h)
+__device__ __forceinline__ uint32_t chain_size2(uint32_t c2) {
+    const uint32_t vc = c2 & 0x00FF00FFu, tc = (c2 >> 8) & 0x00FF00FFu;
+    return vc + (((tc * 3u + 0x00030003u) >> 2) & 0x3FFF3FFFu);
+}
+
+__device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams &p) {
+    __shared__ ChainLds s_chain[4];
+    __shared__ uint32_t s_chunk_base[kEmitChunkTable];
+    __shared__ uint32_t s_scan[256 / 64 + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    ChainLds &S = s_chain[wave];
+    const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
+    const uint32_t ntiles = (nrec + kTileRecords - 1) / kTileRecords;
+    const uint32_t nchunks = (ntiles + kScanChunk - 1) / kScanChunk;
+    uint32_t grand_total = 0;
+    for (uint32_t c0 = 0; c0 < nchunks; c0 += 256) { // block-uniform trip count
+        const uint32_t c = c0 + threadIdx.x;
+        const uint32_t v = c < nchunks ? p.chunk_sums[c] : 0u;
+        uint32_t sub;
+        const uint32_t ex = block_exclusive_scan<4>(v, s_scan, &sub);
+        if (c < nchunks && c < kEmitChunkTable) s_chunk_base[c] = grand_total + ex;
+        grand_total += sub;
+    }
+    __syncthreads();
+    uint32_t *out = reinterpret_cast<uint32_t *>(p.draw_buffer + ORBIT_DRAW_HEADER);
+    const uint32_t stride = gridDim.x * 4;
+    const uint32_t half = lane >> 5, ml = lane & 31;
+    uint32_t tile = blockIdx.x * 4 + wave;
+    EmitTile cur = emit_prefetch<true>(p, tile, ntiles, nrec, lane);
+    EmitTile nxt = emit_prefetch<true>(p, tile + stride, ntiles, nrec, lane);
+    EmitTile nn = emit_prefetch<true>(p, tile + 2 * stride, ntiles, nrec, lane);
+    ChainStage cs = chain_stage(p, S, cur, link_stage(p, cur), lane);
+    LinkStage nk = link_stage(p, nxt);
+    for (; tile < ntiles; tile += stride) {
+        // an absent tile has zero records: nothing is loaded for it
+        const EmitTile n3 = emit_prefetch<true>(p, tile + 3 * stride, ntiles, nrec, lane);
+        const LinkStage nnk = link_stage(p, nn);
+        const ChainStage ns = chain_stage(p, S, nxt, nk, lane);
+        const uint32_t n = cur.count;
+        if (n != 0u) { // wave-uniform
+            const uint32_t base = cur.base + s_chunk_base[tile / kScanChunk];
+            // ---- phase A
+#pragma unroll
+            for (int pr = 0; pr < (int)kTileRows / 2; pr++) {
+                const uint32_t ca = cs.cnt[pr], cb = cs.cnt[pr + 4];
+                const uint32_t size2 = chain_size2(ca | (cb << 16));
+                const uint32_t incl2 = half_inclusive_scan(size2);
+                const uint32_t excl2 = incl2 - size2;
+                S.row[pr * 64 + lane] = (excl2 & 0xFFFFu) | (ca << 16);
+                S.row[(pr + 4) * 64 + lane] = (excl2 >> 16) | (cb << 16);
+                if (ml == 31u) S.tot[pr * 2 + half] = incl2;
+            }
+            uint32_t row_base = 0;
+#pragma unroll
+            for (int r = 0; r < (int)kTileRows; r++) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)cur.mword, 2 * r);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)cur.mword, 2 * r + 1);
+                const uint64_t mask = ((uint64_t)hi << 32) | lo;
+                if ((mask >> lane) & 1ull) S.list[row_base + lane_prefix(mask)] = (uint16_t)(r * 64 + lane);
+                row_base += (uint32_t)__popcll(mask);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- phase B: lane = record
+            {
+                const uint32_t k = lane & 15u, krow = k >> 1;
+                const uint32_t tot = (S.tot[(krow & 3u) * 2u + (k & 1u)] >> (16u * (krow >> 2))) & 0xFFFFu;
+                const uint32_t prev_tot = row_shr1(tot, 0u);
+                const bool cont = (cs.flags & 3u) == 1u; // has survivors and continues the predecessor's chain
+                const uint32_t bv = cs.bv, bd = cs.bd;   // zero unless the record starts a chain
+                uint32_t f = cont ? 0u : 1u; // segment head
+                uint32_t a_d = f ? bd : prev_tot, a_v = f ? bv : 0u;
+#define ORBIT_SEG_STEP(ctrl)                                                                                    \
+    {                                                                                                           \
+        const uint32_t sd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a_d, ctrl, 0xF, 0xF, false);          \
+        const uint32_t sv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a_v, ctrl, 0xF, 0xF, false);          \
+        const uint32_t sf = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)f, ctrl, 0xF, 0xF, false);            \
+        a_d += f ? 0u : sd;                                                                                     \
+        a_v += f ? 0u : sv;                                                                                     \
+        f |= sf;                                                                                                \
+    }
+                ORBIT_SEG_STEP(0x111)
+                ORBIT_SEG_STEP(0x112)
+                ORBIT_SEG_STEP(0x114)
+                ORBIT_SEG_STEP(0x118)
+#undef ORBIT_SEG_STEP
+                if (lane < (int)kTileRecords) {
+                    S.rec[lane] = make_uint4(a_d, a_v, cur.rec.x, cur.rec.y);
+                    S.link[lane] = cs.link32;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- phase C: lane = survivor
+            for (uint32_t j0 = 0; j0 < n; j0 += 64) { // one trip unless more than 64 survivors
+                const uint32_t j = j0 + lane;
+                const uint32_t code = j < n ? S.list[j] : 0u; // row * 64 + lane of the survivor
+                const uint32_t rid = (code >> 5) & 15u, l = code & 31u;
+                const uint32_t pk = S.row[code];
+                const uint4 R = S.rec[rid];
+                const uint32_t lk = S.link[rid];
+                const uint32_t need = ((2u << l) - 1u) & ~1u; // links of lanes 1..l (l = 31: 2u << 31 = 0)
+                const uint32_t mi = R.w + l;
+                uint32_t data = R.x + (pk & 0xFFFFu), vtx = R.y;
+                const bool broken = j < n && (lk & need) != need && p.ms.covers(mi);
+                if (__ballot(broken) != 0ull) { // behind a submesh / allocation boundary inside the record
+                    if (broken) {
+                        const uint32_t *c2 = p.ms.cmd + (size_t)mi * 3u;
+                        vtx = c2[0];
+                        data = c2[1];
+                    }
+                }
+                uint32_t vertex_count = (pk >> 16) & 0xFFu, triangle_count = pk >> 24;
+                if (!p.ms.covers(mi)) vtx = data = vertex_count = triangle_count = 0u; // ORBIT_E_RANGE (latched by the evaluation)
+                uint32_t *c = S.cmd + lane * 7;
+                c[0] = triangle_count * 3u;         // cmd_index_count
+                c[1] = 1u;                          // cmd_instance_count
+                c[2] = (data + vertex_count) * 4u;  // cmd_first_index
+                c[3] = data;                        // cmd_vertex_offset = int(data_offset)
+                c[4] = R.z;                         // cmd_first_instance = entity_index
+                c[5] = vtx;                         // meshlet_vertex_offset
+                c[6] = mi;                          // meshlet_index
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t first = base + j0; // slot of the trip's first command
+                const uint32_t room = first < p.draw_capacity ? p.draw_capacity - first : 0u;
+                const uint32_t words = min(min(n - j0, 64u), room) * 7u;
+                uint32_t *dst = out + (size_t)first * 7u;
+#pragma unroll
+                for (uint32_t k = 0; k < 7; k++) {
+                    const uint32_t w = k * 64u + (uint32_t)lane;
+                    if (w < words) dst[w] = S.cmd[w];
+                }
+                __builtin_amdgcn_wave_barrier(); // cmd is rewritten by the next trip
+            }
+            __builtin_amdgcn_wave_barrier(); // list / row / rec are reused by the next tile
+        }
+        cur = nxt;
+        cs = ns;
+        nxt = nn;
+        nk = nnk;
+        nn = n3;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // `count` header: subsumes the fill_buffer(count = 0) of draw_gen.rs:411-417
+        *p.total = grand_total;
+        *reinterpret_cast<uint32_t *>(p.draw_buffer) = min(grand_total, p.draw_capacity);
+        if (grand_total > p.draw_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+    }
+}
+
 template <bool VISIBLE, bool STREAM = false>
 __global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullParams p) {
-    meshlet_emit_body<VISIBLE, STREAM>(p);
+    if constexpr (STREAM && !VISIBLE) meshlet_emit_chain_body(p);
+    else meshlet_emit_body<VISIBLE, STREAM>(p);
 }
 template <bool STREAM>
 __global__ __launch_bounds__(256) void meshlet_emit_views_kernel(const MeshletCullViews all, const ViewGroup g) {
-    meshlet_emit_body<false, STREAM>(all.v[g.idx[blockIdx.y]]);
+    if constexpr (STREAM) meshlet_emit_chain_body(all.v[g.idx[blockIdx.y]]);
+    else meshlet_emit_body<false, false>(all.v[g.idx[blockIdx.y]]);
 }
 
 // Visible list -> MeshletDrawCommandBuffer (meshlet_cull.comp:216-230 for survivors that were culled on another GPU):
@@ -1147,20 +1380,66 @@ __global__ __launch_bounds__(256) void scatter_list_kernel(const ScatterListPara
     }
 }
 
-// orbit_meshlet_stream_update: Meshlet records -> the derived streams (thread = meshlet; 32 B read, 36 B written).
+// orbit_meshlet_stream_update: Meshlet records -> the derived streams (thread = meshlet; 32 B read, 38 B written).
+// A wave owns 64 consecutive, 64-aligned global meshlet indices, i.e. two whole words of link bits: bits of meshlets
+// outside the updated range keep their value.  Link bit of meshlet i (kernels.h): i continues i - 1's chain.  It is
+// re-derived for i in [first, first + count] — the meshlet behind the range chains from the range's last one; its own
+// offsets (and those of the meshlet in front of the range) come from the stream's `cmd` copy, not from the buffer,
+// of which only [first, first + count) may be read.
+struct StreamBuildArrays {
+    uint4 *sphere;
+    uint32_t *cone;
+    uint16_t *mat;
+    uint32_t *cmd;
+    uint16_t *cnt;
+    uint32_t *link;
+    uint64_t s_first, s_end; // the stream's range
+};
+
 __global__ __launch_bounds__(256) void meshlet_stream_build_kernel(const OrbitMeshlet *meshlets, uint64_t first,
-                                                                   uint64_t count, uint4 *sphere, uint32_t *cone,
-                                                                   uint16_t *mat, uint32_t *cmd) {
-    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256u) {
-        const uint64_t m = first + i;
-        const uint4 *src = reinterpret_cast<const uint4 *>(meshlets + m);
-        const uint4 a = src[0], b = src[1];
-        sphere[m] = a;
-        cone[m] = b.x;
-        mat[m] = (uint16_t)(b.w & 0xFFFFu);
-        cmd[m * 3u] = b.y;
-        cmd[m * 3u + 1u] = b.z;
-        cmd[m * 3u + 2u] = b.w;
+                                                                   uint64_t count, const StreamBuildArrays A) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t lo = first & ~63ull, end = first + count;
+    for (uint64_t base = lo + ((uint64_t)blockIdx.x * 256u + (threadIdx.x & ~63u)); base <= end;
+         base += (uint64_t)gridDim.x * 256u) {
+        const uint64_t m = base + (uint64_t)lane;
+        const bool in = m >= first && m < end;
+        uint32_t vtx = 0, data = 0, w7 = 0;
+        if (in) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(meshlets + m);
+            const uint4 a = src[0], b = src[1];
+            A.sphere[m] = a;
+            A.cone[m] = b.x;
+            A.mat[m] = (uint16_t)(b.w & 0xFFFFu);
+            A.cmd[m * 3u] = b.y;
+            A.cmd[m * 3u + 1u] = b.z;
+            A.cmd[m * 3u + 2u] = b.w;
+            A.cnt[m] = (uint16_t)(b.w >> 16);
+            vtx = b.y, data = b.z, w7 = b.w;
+        } else if (m == end && m < A.s_end) { // derived earlier (or never: then the bit is as arbitrary as the rest)
+            vtx = A.cmd[m * 3u], data = A.cmd[m * 3u + 1u];
+        }
+        const bool in_stream = m >= A.s_first && m < A.s_end;
+        bool bit = false;
+        if (in_stream) bit = ((A.link[m >> 5] >> (m & 31u)) & 1u) != 0; // kept unless re-derived below
+        if (in_stream && m >= first && m <= end) {
+            bit = false;
+            if (m > A.s_first) {
+                uint32_t pv, pd, p7;
+                if (m > first) { // predecessor inside the updated range: from the buffer
+                    const uint4 pb = reinterpret_cast<const uint4 *>(meshlets + (m - 1u))[1];
+                    pv = pb.y, pd = pb.z, p7 = pb.w;
+                } else { // the meshlet in front of the range: the stream's own copy
+                    pv = A.cmd[(m - 1u) * 3u], pd = A.cmd[(m - 1u) * 3u + 1u], p7 = A.cmd[(m - 1u) * 3u + 2u];
+                }
+                bit = vtx == pv && data == pd + meshlet_data_words((p7 >> 16) & 0xFFu, p7 >> 24);
+            }
+        }
+        (void)w7;
+        const uint64_t mask = __ballot(bit);
+        // both words exist whenever any of their meshlets is in the stream (orbit_meshlet_stream_create)
+        if (lane == 0 && base + 32u > A.s_first && base < A.s_end) A.link[base >> 5] = (uint32_t)mask;
+        if (lane == 32 && base + 64u > A.s_first && base + 32u < A.s_end) A.link[(base >> 5) + 1u] = (uint32_t)(mask >> 32);
     }
 }
 
@@ -1253,6 +1532,8 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t
     if (eblocks > eneed) eblocks = eneed;
     if (eblocks == 0) eblocks = 1;
     const bool stream = PASS != 1 && p.ms.sphere != nullptr; // the list-driven pass 1 keeps its payload
+    // the chain emit's registers and LDS (26 KB per block) allow five resident blocks per CU
+    if (stream && !p.visible_list) eblocks = max(min(num_cus * 5u, eneed), 1u);
     if (p.visible_list) {
         if (stream) hipLaunchKernelGGL((meshlet_emit_kernel<true, true>), dim3(eblocks), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((meshlet_emit_kernel<true, false>), dim3(eblocks), dim3(256), 0, s, p);
@@ -1339,7 +1620,9 @@ hipError_t launch_meshlet_cull_views(const MeshletCullViews &all, uint32_t n, ui
         for (uint32_t i = 0; i < n; i++)
             if (from_stream(i) == (stream != 0)) g.idx[m++] = (uint8_t)i;
         if (m == 0) continue;
-        if (stream) hipLaunchKernelGGL(meshlet_emit_views_kernel<true>, dim3(eblocks, m), dim3(256), 0, s, all, g);
+        if (stream)
+            hipLaunchKernelGGL(meshlet_emit_views_kernel<true>, dim3(max(min(num_cus * 5u / n, eneed), 1u), m), dim3(256), 0,
+                               s, all, g);
         else hipLaunchKernelGGL(meshlet_emit_views_kernel<false>, dim3(eblocks, m), dim3(256), 0, s, all, g);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -1354,13 +1637,16 @@ hipError_t launch_scatter_list(const ScatterListParams &p, uint32_t num_cus, hip
     return hipGetLastError();
 }
 
-hipError_t launch_meshlet_stream_build(const OrbitMeshlet *meshlets, uint64_t first, uint64_t count, uint4 *sphere,
-                                       uint32_t *cone, uint16_t *mat, uint32_t *cmd, hipStream_t s) {
+hipError_t launch_meshlet_stream_build(const OrbitMeshlet *meshlets, uint64_t first, uint64_t count,
+                                       const MeshletStreamView &ms, hipStream_t s) {
     if (count == 0) return hipSuccess;
-    const uint64_t need = (count + 255u) / 256u;
+    const uint64_t need = (count + 64u + 255u) / 256u + 1u;
     const uint32_t blocks = (uint32_t)(need < 8192u ? need : 8192u);
-    hipLaunchKernelGGL(meshlet_stream_build_kernel, dim3(blocks), dim3(256), 0, s, meshlets, first, count, sphere, cone,
-                       mat, cmd);
+    const StreamBuildArrays A{const_cast<uint4 *>(ms.sphere),   const_cast<uint32_t *>(ms.cone),
+                              const_cast<uint16_t *>(ms.mat),   const_cast<uint32_t *>(ms.cmd),
+                              const_cast<uint16_t *>(ms.cnt),   const_cast<uint32_t *>(ms.link),
+                              (uint64_t)ms.first,               (uint64_t)ms.first + ms.count};
+    hipLaunchKernelGGL(meshlet_stream_build_kernel, dim3(blocks), dim3(256), 0, s, meshlets, first, count, A);
     return hipGetLastError();
 }
 

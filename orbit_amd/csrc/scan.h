@@ -39,6 +39,22 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
     return v;
 }
 
+// Inclusive scans (sum) of the two 32-lane halves of the wave, side by side: the first five steps of the above.
+__device__ __forceinline__ uint32_t half_inclusive_scan(uint32_t v) {
+    const uint32_t identity = 0u;
+    ORBIT_DPP_STEP(dpp_op_add, 0x111, 0xF);
+    ORBIT_DPP_STEP(dpp_op_add, 0x112, 0xF);
+    ORBIT_DPP_STEP(dpp_op_add, 0x114, 0xF);
+    ORBIT_DPP_STEP(dpp_op_add, 0x118, 0xF);
+    ORBIT_DPP_STEP(dpp_op_add, 0x142, 0xA);
+    return v;
+}
+
+// Lane i <- lane i - 1 of the same row of 16 lanes (row_shr:1); the row's first lane gets `first`.
+__device__ __forceinline__ uint32_t row_shr1(uint32_t v, uint32_t first) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x111, 0xF, 0xF, false);
+}
+
 // Wave-wide reductions: the scan's last lane holds the total.
 __device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
     const uint32_t identity = 0u;

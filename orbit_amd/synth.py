@@ -130,10 +130,18 @@ def gen_entity_tables(spec: C5Spec, device):
     return draws.view(torch.uint8), mesh.view(torch.uint8), ent.view(torch.uint8), half
 
 
-def gen_meshlets(spec: C5Spec, first_entity, last_entity, device, half, survive_target=0.10, chunk=2_000_000):
-    """Meshlet[] (32 B each) of entities [first_entity, last_entity), generated in chunks."""
+def gen_meshlets(spec: C5Spec, first_entity, last_entity, device, half, survive_target=0.10, chunk=2_000_000,
+                 layout="uploaded"):
+    """Meshlet[] (32 B each) of entities [first_entity, last_entity), generated in chunks.
+
+    layout "uploaded": vertex_offset / data_offset as compute_meshlets + GpuAssets::add_mesh produce them
+    (src/assets/mesh.rs:309-316, assets/mod.rs:413-416) — every entity's mesh is an allocation of its own
+    (80 data words per meshlet reserved), a meshlet's data follows its predecessor's (vertex_count +
+    ceil(3 * triangle_count / 4) words), vertex_offset is per submesh, two submeshes per mesh (the second one
+    starts at meshlet 25/64 * M, inside a dispatch record).  "scattered": offsets that follow no rule."""
     M, S = spec.meshlets_per_entity, spec.seed
     n = (last_entity - first_entity) * M
+    chunk = max(M, chunk // M * M)  # whole entities per chunk
     out = torch.empty(n, 8, dtype=torch.int32, device=device)
     # cone cutoff range chosen so that P(cone cull) ~= 1 - survive_target / 0.95 (alpha filter keeps 95 %)
     keep = min(1.0, survive_target / 0.95)
@@ -153,11 +161,20 @@ def gen_meshlets(spec: C5Spec, first_entity, last_entity, device, half, survive_
         q = (torch.clamp(v / nrm[:, None], -1.0, 1.0) * 127.0).to(torch.int32) & 0xFF  # trunc, math.rs:201-203
         cut = rnd_int(S, 17, mid, -127, hi_cut).to(torch.int32) & 0xFF
         o[:, 4] = q[:, 0] | (q[:, 1] << 8) | (q[:, 2] << 16) | (cut << 24)
-        o[:, 5] = (rnd_u64(S, 19, mid) & 0x00FFFFFF).to(torch.int32)
-        o[:, 6] = ((mid * 88) & 0x7FFFFFFF).to(torch.int32)
         mat = rnd_int(S, 20, mid, 0, spec.materials - 1)
         vc = rnd_int(S, 21, mid, 3, 64)
         tc = rnd_int(S, 22, mid, 1, 64)
+        if layout == "scattered":
+            o[:, 5] = (rnd_u64(S, 19, mid) & 0x00FFFFFF).to(torch.int32)
+            o[:, 6] = ((mid * 88) & 0x7FFFFFFF).to(torch.int32)
+        else:
+            ent, local = mid // M, mid % M
+            size = (vc + (tc * 3 + 3) // 4).view(-1, M)
+            data = ent * (M * 80) + (torch.cumsum(size, dim=1) - size).reshape(-1)
+            vtx = ent * 8192 + torch.where(local >= (M * 25) // 64, 4096, 0)
+            for col, v in ((5, vtx), (6, data)):
+                v = v & 0xFFFFFFFF
+                o[:, col] = torch.where(v >= (1 << 31), v - (1 << 32), v).to(torch.int32)
         packed = mat | (vc << 16) | (tc << 24)
         o[:, 7] = torch.where(packed >= (1 << 31), packed - (1 << 32), packed).to(torch.int32)
     return out.view(torch.uint8).reshape(-1)

@@ -19,7 +19,8 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 
 
 def cull_case(name, seed, n, lods, W, H):
-    scene = sc.make_scene(seed, n, n_meshes=max(1, n // 3), lods=lods, extent=(35.0, 8.0, 35.0))
+    scene = sc.make_scene(seed, n, n_meshes=max(1, n // 3), lods=lods, extent=(35.0, 8.0, 35.0),
+                          meshlet_layout="scattered")  # the layout the committed fixtures were made with
     cam = sc.default_camera(rot=(0.8, 0.6))
     rng = np.random.default_rng(seed)
     evis = rng.integers(0, 2 ** 32, (n + 31) // 32, dtype=np.uint32)

@@ -136,7 +136,8 @@ def depth_knife_edge(scene, cam, ci, ortho, seed, rng):
 
 def case(seed, occlusion_pass, ortho, knife, n=140):
     rng = np.random.default_rng(seed)
-    scene = sc.make_scene(seed, n, meshlets_per_mesh=(1, 70), lods=3)
+    scene = sc.make_scene(seed, n, meshlets_per_mesh=(1, 70), lods=3,
+                          meshlet_layout="scattered")  # the layout the committed vectors were made with
     cam = sc.default_camera(rot=(0.2, 0.4))
     if knife:
         quantise(scene, rng)

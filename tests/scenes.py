@@ -139,7 +139,8 @@ class Scene:
 
 
 def make_scene(seed, n_entities, n_meshes=None, meshlets_per_mesh=(4, 40), extent=(30.0, 12.0, 18.0), lods=1,
-               n_materials=25, layout="uniform", shuffle=True, mesh_radius=(1.0, 4.0), unit_scale=False):
+               n_materials=25, layout="uniform", shuffle=True, mesh_radius=(1.0, 4.0), unit_scale=False,
+               meshlet_layout="uploaded"):
     """A scene of `n_entities` entity-draws over `n_meshes` meshes (default: one mesh per entity).
 
     Meshlet spheres are clustered around their mesh centre; cone axes are random
@@ -185,11 +186,29 @@ def make_scene(seed, n_entities, n_meshes=None, meshlets_per_mesh=(4, 40), exten
     cut = rnd_int(S, 17, mid, -127, 127)
     degenerate = rnd_f32(S, 18, mid) < np.float32(0.3)
     meshlets["cone_cutoff"] = np.where(degenerate, 127, cut).astype(np.int8)
-    meshlets["vertex_offset"] = (rnd_u64(S, 19, mid) & np.uint64(0x00FFFFFF)).astype(np.uint32)
-    meshlets["data_offset"] = (mid * 88).astype(np.uint32)
     meshlets["material_index"] = rnd_int(S, 20, mid, 0, n_materials - 1).astype(np.uint16)
     meshlets["vertex_count"] = rnd_int(S, 21, mid, 3, 64).astype(np.uint8)
     meshlets["triangle_count"] = rnd_int(S, 22, mid, 1, 64).astype(np.uint8)
+    if meshlet_layout == "scattered":  # offsets that follow no rule at all
+        meshlets["vertex_offset"] = (rnd_u64(S, 19, mid) & np.uint64(0x00FFFFFF)).astype(np.uint32)
+        meshlets["data_offset"] = (mid * 88).astype(np.uint32)
+    else:
+        # "uploaded": as compute_meshlets / add_mesh lay a mesh out (src/assets/mesh.rs:309-316, assets/mod.rs:413-416):
+        # a meshlet's data follows its predecessor's, vertex_offset is per submesh, every (mesh, LOD) range is an
+        # allocation of its own — with submesh boundaries (5 %) and jumps in the data (3 %) inside the ranges, and
+        # 15 % of the meshes left scattered, so that every way the derived command chain can break occurs.
+        grp = np.repeat(np.arange(n_meshes * lods), flat)
+        first_of_grp = np.ones(n_meshlets, dtype=bool)
+        first_of_grp[1:] = grp[1:] != grp[:-1]
+        wild = (rnd_f32(S, 23, mesh_id) < np.float32(0.15))[owner]
+        new_sub = first_of_grp | wild | (rnd_f32(S, 24, mid) < np.float32(0.05))
+        jump = first_of_grp | wild | (rnd_f32(S, 25, mid) < np.float32(0.03))
+        size = meshlets["vertex_count"].astype(np.int64) + (meshlets["triangle_count"].astype(np.int64) * 3 + 3) // 4
+        gap = np.where(jump, rnd_int(S, 26, mid, 1, 1000), 0)
+        data = np.cumsum(gap) + np.concatenate([[0], np.cumsum(size)[:-1]])
+        meshlets["data_offset"] = (data & 0xFFFFFFFF).astype(np.uint32)
+        sub = np.cumsum(new_sub)
+        meshlets["vertex_offset"] = (rnd_u64(S, 19, sub) & np.uint64(0x00FFFFFF)).astype(np.uint32)
 
     materials = np.zeros(n_materials, dtype=L.MATERIAL)
     u = rnd_f32(S, 30, np.arange(n_materials))

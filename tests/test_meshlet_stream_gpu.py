@@ -269,3 +269,99 @@ def test_stream_argument_errors(torch_mod, engine):
     torch.cuda.synchronize()
     assert lib.orbit_meshlet_stream_destroy(h) == _lib.OK
     assert lib.orbit_meshlet_stream_destroy(None) == _lib.OK
+
+
+# ----------------------------------------------------------------------------- the derived command chain
+# The emit launch derives a survivor's vertex_offset / data_offset from one gathered base per chain and a prefix
+# sum over 2-B counts (orbit_amd/csrc/meshlet_cull.hip, meshlet_emit_chain_body), valid where the stream's link bits
+# hold; everywhere else it gathers.  The scenes of tests/scenes.py mix all of that ("uploaded" layout); these tests
+# put the breaks where the launch's cases meet.
+def _relayout(scene, seed, mode):
+    """Rewrites vertex_offset / data_offset of every meshlet; `mode` places the chain breaks."""
+    m = scene.meshlets
+    n = len(m)
+    mid = np.arange(n)
+    if mode == "max_counts":  # the largest data sizes a Meshlet can state: 255 + ceil(765 / 4) words
+        m["vertex_count"], m["triangle_count"] = 255, 255
+    size = m["vertex_count"].astype(np.int64) + (m["triangle_count"].astype(np.int64) * 3 + 3) // 4
+    lod0 = scene.mesh_infos["mesh_lods"][:, :, 0].reshape(-1)
+    starts = np.zeros(n, dtype=bool)
+    starts[lod0[lod0 < n]] = True  # every (mesh, LOD) range begins an allocation
+    if mode in ("one_chain", "max_counts"):
+        jump = np.zeros(n, dtype=bool)  # not even between meshes: the whole buffer is one chain
+        sub = np.zeros(n, dtype=bool)
+    elif mode == "record_boundaries":  # breaks exactly where a dispatch record ends (offset + 32 j)
+        rel = mid - np.maximum.accumulate(np.where(starts, mid, 0))
+        jump = starts | ((rel % 32 == 0) & (sc.rnd_f32(seed, 1, mid) < np.float32(0.5)))
+        sub = starts | ((rel % 32 == 0) & (sc.rnd_f32(seed, 2, mid) < np.float32(0.5)))
+    elif mode == "second_lane":  # the link of a record's lane 1 / lane 31: the ends of the per-lane mask
+        rel = mid - np.maximum.accumulate(np.where(starts, mid, 0))
+        jump = starts | (rel % 32 == 1) & (sc.rnd_f32(seed, 1, mid) < np.float32(0.5))
+        sub = starts | (rel % 32 == 31) & (sc.rnd_f32(seed, 2, mid) < np.float32(0.5))
+    else:
+        raise ValueError(mode)
+    gap = np.where(jump, sc.rnd_int(seed, 3, mid, 1, 5000), 0)
+    data = np.cumsum(gap) + np.concatenate([[0], np.cumsum(size)[:-1]]) + 0xFFFF0000  # wraps past 2^32 on the way
+    m["data_offset"] = (data & 0xFFFFFFFF).astype(np.uint32)
+    m["vertex_offset"] = (sc.rnd_u64(seed, 4, np.cumsum(sub)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+
+
+@pytest.mark.parametrize("mode", ["one_chain", "max_counts", "record_boundaries", "second_lane"])
+@pytest.mark.parametrize("lods", [1, 3])
+def test_command_chain_where_its_cases_meet(torch_mod, engine, oracle, mode, lods):
+    torch = torch_mod
+    scene = sc.make_scene(41, 700, n_meshes=90, meshlets_per_mesh=(1, 200), lods=lods)
+    _relayout(scene, 7, mode)
+    cam = sc.default_camera(rot=(0.1, 0.3))
+    ci = sc.make_cull_info(cam.view, cam.planes)
+    gs = GpuScene(torch, scene)
+    ref = run_oracle(oracle, scene, ci)
+    ms = engine.meshlet_stream(gs.meshlets, 0, len(scene.meshlets))
+    engine.bind_meshlet_stream(ms)
+    got = run_gpu(torch, engine, gs, ci)
+    assert engine.meshlet_stream_culls() == 1
+    assert_same(got, ref)
+    engine.bind_meshlet_stream(None)
+    ms.close()
+
+
+def test_partial_updates_keep_the_links_around_them(torch_mod, engine, oracle):
+    """Link bits live 32 to a word and the bit of the meshlet BEHIND an updated range depends on the range's last
+    meshlet: pieces updated in any order, and single meshlets rewritten later, must leave the stream as one full
+    update would."""
+    torch = torch_mod
+    scene = sc.make_scene(43, 500, n_meshes=70, meshlets_per_mesh=(1, 120), lods=2)
+    cam = sc.default_camera(rot=(0.1, 0.3))
+    ci = sc.make_cull_info(cam.view, cam.planes)
+    gs = GpuScene(torch, scene)
+    n = len(scene.meshlets)
+    rng = np.random.default_rng(5)
+    cuts = np.unique(np.concatenate([[0, n], rng.integers(1, n, 40)]))
+    pieces = list(zip(cuts[:-1], cuts[1:]))
+    rng.shuffle(pieces)
+    from orbit_amd.engine import MeshletStream
+
+    ms = MeshletStream.__new__(MeshletStream)  # create without the initial full update
+    ms._engine, ms._lib, ms._h, ms.first, ms.capacity = engine, engine._lib, C.c_void_p(), 0, n
+    _lib.check(engine._lib.orbit_meshlet_stream_create(engine._ctx, 0, n, C.byref(ms._h)), engine._ctx)
+    for a, b in pieces:
+        ms.update(gs.meshlets, int(a), int(b - a))
+    engine.bind_meshlet_stream(ms)
+    assert_same(run_gpu(torch, engine, gs, ci), run_oracle(oracle, scene, ci))
+    # rewrite single meshlets' offsets in place: breaks a chain in front of and behind each of them
+    for i in rng.integers(1, n - 1, 25):
+        scene.meshlets["data_offset"][i] += 17
+        scene.meshlets["vertex_offset"][i + 1] ^= 0x55
+    gs.meshlets.copy_(dev(torch, scene.meshlets))
+    rng.shuffle(pieces)
+    for a, b in pieces:  # the same pieces, another order
+        ms.update(gs.meshlets, int(a), int(b - a))
+    assert_same(run_gpu(torch, engine, gs, ci), run_oracle(oracle, scene, ci))
+    # and the minimal form: one meshlet rewritten, only that meshlet updated
+    j = int(rng.integers(40, n - 40))
+    scene.meshlets["data_offset"][j] += 3
+    gs.meshlets.copy_(dev(torch, scene.meshlets))
+    ms.update(gs.meshlets, j, 1)
+    assert_same(run_gpu(torch, engine, gs, ci), run_oracle(oracle, scene, ci))
+    engine.bind_meshlet_stream(None)
+    ms.close()
