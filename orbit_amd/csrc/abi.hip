@@ -596,7 +596,9 @@ int32_t orbit_meshlet_stream_create(OrbitCtx *ctx, uint64_t first_meshlet, uint6
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (!out_stream) return fail(ctx, ORBIT_E_MISSING, "meshlet_stream_create: out_stream is NULL");
     *out_stream = nullptr;
-    if (capacity == 0 || capacity > 0xFFFFFFFFull || first_meshlet + capacity > 0xFFFFFFFFull) // 32-bit meshlet indices
+    // 32-bit meshlet indices; the emit launch addresses the arrays through buffer resources (32-bit byte offsets:
+    // 12 B per meshlet < 4 GiB)
+    if (capacity == 0 || capacity > (1ull << 28) || first_meshlet + capacity > 0xFFFFFFFFull)
         return fail(ctx, ORBIT_E_INVALID, "meshlet_stream_create: range [%llu, +%llu)", (unsigned long long)first_meshlet,
                     (unsigned long long)capacity);
     hipError_t e = hipSetDevice(ctx->device);

@@ -1024,15 +1024,44 @@ __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
 //            all set; the few survivors behind a broken link gather their own 8 B.  Commands go out through LDS as
 //            contiguous words (as in meshlet_emit_body).
 // Pipeline per wave: records, count, base, ballots three tiles ahead; link words two; counts and chain-start bases one.
+// All loads are range-checked buffer loads (an offset outside the resource reads zero): no pointer selects, no
+// branches around loads, 32-bit address arithmetic, and the stream's coverage check comes for free.
 struct __attribute__((aligned(16))) ChainLds {
     uint4 rec[kTileRecords];      // phase B -> C: {data_offset base, vertex_offset, entity_index, meshlet_offset}
-    uint4 rs[kTileRecords];       // chain_stage: the records where every lane can index them: {entity, offset, count, ballot}
+    uint2 rs[kTileRecords];       // chain_stage: per record {byte offset of its first count, lanes to read}
     uint32_t row[kTileRows * 64]; // phase A -> C, per (row, lane): size prefix inside the record | counts << 16
     uint32_t link[kTileRecords];  // link bits of the record's 32 lanes
     uint32_t tot[kTileRows];      // [pair * 2 + half]: data words of the records of rows pair / pair + 4 (16:16)
     uint32_t cmd[64 * 7];
     uint16_t list[kTileRows * 64];
 };
+
+constexpr uint32_t kBufFlags = 0x00020000u; // raw buffer, 32-bit data format
+constexpr uint32_t kNoOffset = 0xFFFFFFF0u; // beyond every resource of this launch (orbit_meshlet_stream_create bounds them)
+
+struct ChainRsrc {
+    __amdgpu_buffer_rsrc_t recs, counts, bases, masks; // the dispatch records, the scan scratch
+    __amdgpu_buffer_rsrc_t cnt, link, cmd;             // the stream (based at its first meshlet)
+    uint32_t first, count, first_word;
+};
+
+struct ChainTile {
+    uint4 rec;      // lane = record (lanes 16.. repeat lanes 0..15)
+    uint32_t mword; // the record's should-draw ballot
+    uint32_t count, base;
+};
+
+__device__ __forceinline__ ChainTile chain_prefetch(const ChainRsrc &B, uint32_t tile, int lane) {
+    ChainTile e;
+    const uint32_t t = tile < 0x00FFFFFFu ? tile : 0x00FFFFFFu; // keeps t * 256 out of range instead of wrapping
+    const uint32_t k = (uint32_t)lane & 15u;
+    const uint32_t ro = (t * kTileRecords + k) * 16u;
+    e.rec = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(B.recs, ro, 0, 0));
+    e.mword = __builtin_amdgcn_raw_buffer_load_b32(B.masks, (t * kTileRecords + k) * 4u, 0, 0);
+    e.count = __builtin_amdgcn_raw_buffer_load_b32(B.counts, t * 4u, 0, 0);
+    e.base = __builtin_amdgcn_raw_buffer_load_b32(B.bases, t * 4u, 0, 0);
+    return e;
+}
 
 struct LinkStage {
     uint32_t l0, l1; // lane = record: the two link words that cover its lanes
@@ -1045,48 +1074,49 @@ struct ChainStage {
     uint32_t flags;          // lane = record: 1 = has survivors (counts loaded), 2 = chain start (bv, bd loaded)
 };
 
-// lane = record (lanes 16.. repeat lanes 0..15)
-__device__ __forceinline__ bool chain_has(const MeshletCullParams &p, const EmitTile &e) {
-    return e.mword != 0u && e.rec.z != 0u && p.ms.covers(e.rec.y);
+// lane = record: does the emit read this record at all?  Records without survivors are skipped; a record that begins
+// outside the stream reads zeros (ORBIT_E_RANGE is the evaluation's to latch).
+__device__ __forceinline__ bool chain_has(const ChainRsrc &B, const ChainTile &e) {
+    return e.mword != 0u && e.rec.z != 0u && e.rec.y - B.first < B.count;
 }
 
-__device__ __forceinline__ LinkStage link_stage(const MeshletCullParams &p, const EmitTile &e) {
-    const bool has = chain_has(p, e);
-    const uint32_t *lw = has ? p.ms.link + (e.rec.y >> 5) : reinterpret_cast<const uint32_t *>(p.zero_page);
-    return LinkStage{lw[0], lw[has ? 1 : 0]};
+__device__ __forceinline__ LinkStage link_stage(const ChainRsrc &B, const ChainTile &e) {
+    const uint32_t wo = chain_has(B, e) ? ((e.rec.y >> 5) - B.first_word) * 4u : kNoOffset;
+    LinkStage k;
+    k.l0 = __builtin_amdgcn_raw_buffer_load_b32(B.link, wo, 0, 0);
+    k.l1 = __builtin_amdgcn_raw_buffer_load_b32(B.link, wo, 0 + 4, 0);
+    return k;
 }
 
-__device__ __forceinline__ ChainStage chain_stage(const MeshletCullParams &p, ChainLds &S, const EmitTile &e,
+__device__ __forceinline__ ChainStage chain_stage(const ChainRsrc &B, ChainLds &S, const ChainTile &e,
                                                   const LinkStage &k, int lane) {
     ChainStage s;
-    const uint32_t half = lane >> 5, ml = lane & 31;
-    if (lane < (int)kTileRecords) S.rs[lane] = make_uint4(e.rec.x, e.rec.y, e.rec.z, e.mword);
+    const uint32_t half = (uint32_t)lane >> 5, ml = (uint32_t)lane & 31u;
+    const bool has = chain_has(B, e);
+    if (lane < (int)kTileRecords) S.rs[lane] = make_uint2((e.rec.y - B.first) * 2u, has ? e.rec.z : 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint16_t *zero16 = reinterpret_cast<const uint16_t *>(p.zero_page);
-    const uint32_t *zero32 = reinterpret_cast<const uint32_t *>(p.zero_page);
+    uint2 R[kTileRows];
+#pragma unroll
+    for (int r = 0; r < (int)kTileRows; r++) R[r] = S.rs[2 * r + half];
 #pragma unroll
     for (int r = 0; r < (int)kTileRows; r++) {
-        const uint4 R = S.rs[2 * r + half];
-        const uint32_t m = R.y + ml;
-        // straight-line loads; records without survivors are not read at all
-        const bool ok = ml < R.z && R.w != 0u && p.ms.covers(m);
-        s.cnt[r] = (uint32_t) * (ok ? p.ms.cnt + m : zero16);
+        const uint32_t off = ml < R[r].y ? R[r].x + ml * 2u : kNoOffset;
+        s.cnt[r] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(B.cnt, off, 0, 0);
     }
     // lane = record; row_shr stays inside a row of 16 lanes.  A record continues its predecessor's chain when that
     // one was read too, ends where this one begins, and every link from the predecessor's second meshlet to this
     // record's first one holds; otherwise it starts a chain from the gathered offsets of its first meshlet.
-    const bool has = chain_has(p, e);
     s.link32 = __funnelshift_r(k.l0, k.l1, e.rec.y & 31u);
     const bool full = has && e.rec.z == 32u && (s.link32 | 1u) == 0xFFFFFFFFu; // the chain reaches the record's end
     const uint32_t prev_y = row_shr1(e.rec.y, 0u), prev_full = row_shr1(full ? 1u : 0u, 0u);
     const bool cont = has && prev_full != 0u && e.rec.y == prev_y + 32u && (s.link32 & 1u) != 0u;
     const bool start = has && !cont;
     s.flags = (has ? 1u : 0u) | (start ? 2u : 0u);
-    const uint32_t *bc = start ? p.ms.cmd + (size_t)e.rec.y * 3u : zero32;
-    s.bv = bc[0];
-    s.bd = bc[1];
+    const uint32_t co = start ? (e.rec.y - B.first) * 12u : kNoOffset;
+    s.bv = __builtin_amdgcn_raw_buffer_load_b32(B.cmd, co, 0, 0);
+    s.bd = __builtin_amdgcn_raw_buffer_load_b32(B.cmd, co, 0 + 4, 0);
     return s;
 }
 
@@ -1115,23 +1145,38 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
         grand_total += sub;
     }
     __syncthreads();
+    ChainRsrc B;
+    B.recs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.dispatch_buffer) + ORBIT_DISPATCH_HEADER, 0,
+                                               nrec * 16u, kBufFlags);
+    B.masks = __builtin_amdgcn_make_buffer_rsrc(p.tile_masks, 0, ntiles * 64u, kBufFlags);
+    B.counts = __builtin_amdgcn_make_buffer_rsrc(p.tile_counts, 0, ntiles * 4u, kBufFlags);
+    B.bases = __builtin_amdgcn_make_buffer_rsrc(p.tile_base, 0, ntiles * 4u, kBufFlags);
+    B.first = p.ms.first;
+    B.count = p.ms.count;
+    B.first_word = p.ms.first >> 5;
+    B.cnt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.ms.cnt + p.ms.first), 0, p.ms.count * 2u, kBufFlags);
+    B.link = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.ms.link + B.first_word), 0,
+                                               (((p.ms.first + p.ms.count + 31u) >> 5) - B.first_word + 2u) * 4u, kBufFlags);
+    B.cmd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.ms.cmd + (size_t)p.ms.first * 3u), 0,
+                                              p.ms.count * 12u, kBufFlags);
     uint32_t *out = reinterpret_cast<uint32_t *>(p.draw_buffer + ORBIT_DRAW_HEADER);
     const uint32_t stride = gridDim.x * 4;
-    const uint32_t half = lane >> 5, ml = lane & 31;
+    const uint32_t half = (uint32_t)lane >> 5, ml = (uint32_t)lane & 31u;
     uint32_t tile = blockIdx.x * 4 + wave;
-    EmitTile cur = emit_prefetch<true>(p, tile, ntiles, nrec, lane);
-    EmitTile nxt = emit_prefetch<true>(p, tile + stride, ntiles, nrec, lane);
-    EmitTile nn = emit_prefetch<true>(p, tile + 2 * stride, ntiles, nrec, lane);
-    ChainStage cs = chain_stage(p, S, cur, link_stage(p, cur), lane);
-    LinkStage nk = link_stage(p, nxt);
+    ChainTile cur = chain_prefetch(B, tile, lane);
+    ChainTile nxt = chain_prefetch(B, tile + stride, lane);
+    ChainTile nn = chain_prefetch(B, tile + 2 * stride, lane);
+    ChainStage cs = chain_stage(B, S, cur, link_stage(B, cur), lane);
+    LinkStage nk = link_stage(B, nxt);
     for (; tile < ntiles; tile += stride) {
-        // an absent tile has zero records: nothing is loaded for it
-        const EmitTile n3 = emit_prefetch<true>(p, tile + 3 * stride, ntiles, nrec, lane);
-        const LinkStage nnk = link_stage(p, nn);
-        const ChainStage ns = chain_stage(p, S, nxt, nk, lane);
-        const uint32_t n = cur.count;
-        if (n != 0u) { // wave-uniform
-            const uint32_t base = cur.base + s_chunk_base[tile / kScanChunk];
+        // a tile past the end reads zero records: nothing else is loaded for it
+        const ChainTile n3 = chain_prefetch(B, tile + 3 * stride, lane);
+        const LinkStage nnk = link_stage(B, nn);
+        const ChainStage ns = chain_stage(B, S, nxt, nk, lane);
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.count);
+        if (n != 0u) {
+            // wave-uniform, and provably so for the compiler (the store window's descriptor lives in SGPRs)
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur.base + s_chunk_base[tile / kScanChunk]));
             // ---- phase A
 #pragma unroll
             for (int pr = 0; pr < (int)kTileRows / 2; pr++) {
@@ -1143,27 +1188,33 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
                 S.row[(pr + 4) * 64 + lane] = (excl2 >> 16) | (cb << 16);
                 if (ml == 31u) S.tot[pr * 2 + half] = incl2;
             }
-            uint32_t row_base = 0;
-#pragma unroll
-            for (int r = 0; r < (int)kTileRows; r++) {
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)cur.mword, 2 * r);
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)cur.mword, 2 * r + 1);
-                const uint64_t mask = ((uint64_t)hi << 32) | lo;
-                if ((mask >> lane) & 1ull) S.list[row_base + lane_prefix(mask)] = (uint16_t)(r * 64 + lane);
-                row_base += (uint32_t)__popcll(mask);
+            // the survivors' codes (record * 32 + lane = row * 64 + lane of the evaluation's layout) in canonical
+            // order: lane i owns byte i & 3 of record i >> 2's ballot and peels its bits off one per trip
+            {
+                const uint32_t w = (uint32_t)__shfl((int)cur.mword, lane >> 2, 64);
+                uint32_t byte = (w >> (8u * ((uint32_t)lane & 3u))) & 0xFFu;
+                const uint32_t pc = (uint32_t)__popc(byte);
+                uint32_t pos = wave_inclusive_scan(pc) - pc;
+                const uint32_t code0 = (uint32_t)lane * 8u;
+                while (__ballot(byte != 0u) != 0ull) {
+                    if (byte != 0u) {
+                        S.list[pos] = (uint16_t)(code0 + (uint32_t)__builtin_ctz(byte));
+                        pos++;
+                        byte &= byte - 1u;
+                    }
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // ---- phase B: lane = record
             {
-                const uint32_t k = lane & 15u, krow = k >> 1;
+                const uint32_t k = (uint32_t)lane & 15u, krow = k >> 1;
                 const uint32_t tot = (S.tot[(krow & 3u) * 2u + (k & 1u)] >> (16u * (krow >> 2))) & 0xFFFFu;
                 const uint32_t prev_tot = row_shr1(tot, 0u);
                 const bool cont = (cs.flags & 3u) == 1u; // has survivors and continues the predecessor's chain
-                const uint32_t bv = cs.bv, bd = cs.bd;   // zero unless the record starts a chain
-                uint32_t f = cont ? 0u : 1u; // segment head
-                uint32_t a_d = f ? bd : prev_tot, a_v = f ? bv : 0u;
+                uint32_t f = cont ? 0u : 1u;             // segment head
+                uint32_t a_d = f ? cs.bd : prev_tot, a_v = cs.bv; // bv / bd are zero unless the record starts a chain
 #define ORBIT_SEG_STEP(ctrl)                                                                                    \
     {                                                                                                           \
         const uint32_t sd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a_d, ctrl, 0xF, 0xF, false);          \
@@ -1188,25 +1239,25 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // ---- phase C: lane = survivor
             for (uint32_t j0 = 0; j0 < n; j0 += 64) { // one trip unless more than 64 survivors
-                const uint32_t j = j0 + lane;
-                const uint32_t code = j < n ? S.list[j] : 0u; // row * 64 + lane of the survivor
-                const uint32_t rid = (code >> 5) & 15u, l = code & 31u;
+                const uint32_t j = j0 + (uint32_t)lane;
+                const uint32_t code = j < n ? S.list[j] : 0u;
+                const uint32_t rid = code >> 5, l = code & 31u;
                 const uint32_t pk = S.row[code];
                 const uint4 R = S.rec[rid];
                 const uint32_t lk = S.link[rid];
                 const uint32_t need = ((2u << l) - 1u) & ~1u; // links of lanes 1..l (l = 31: 2u << 31 = 0)
                 const uint32_t mi = R.w + l;
                 uint32_t data = R.x + (pk & 0xFFFFu), vtx = R.y;
-                const bool broken = j < n && (lk & need) != need && p.ms.covers(mi);
+                const bool broken = j < n && (lk & need) != need;
                 if (__ballot(broken) != 0ull) { // behind a submesh / allocation boundary inside the record
-                    if (broken) {
-                        const uint32_t *c2 = p.ms.cmd + (size_t)mi * 3u;
-                        vtx = c2[0];
-                        data = c2[1];
-                    }
+                    const uint32_t co = broken ? (mi - B.first) * 12u : kNoOffset;
+                    const uint32_t gv = __builtin_amdgcn_raw_buffer_load_b32(B.cmd, co, 0, 0);
+                    const uint32_t gd = __builtin_amdgcn_raw_buffer_load_b32(B.cmd, co, 0 + 4, 0);
+                    vtx = broken ? gv : vtx;
+                    data = broken ? gd : data;
                 }
                 uint32_t vertex_count = (pk >> 16) & 0xFFu, triangle_count = pk >> 24;
-                if (!p.ms.covers(mi)) vtx = data = vertex_count = triangle_count = 0u; // ORBIT_E_RANGE (latched by the evaluation)
+                if (!p.ms.covers(mi)) vtx = data = 0u; // ORBIT_E_RANGE, latched by the evaluation: the command carries zeros
                 uint32_t *c = S.cmd + lane * 7;
                 c[0] = triangle_count * 3u;         // cmd_index_count
                 c[1] = 1u;                          // cmd_instance_count
@@ -1218,14 +1269,15 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // the trip's commands as one range-checked window: words past the list or the capacity are dropped
                 const uint32_t first = base + j0; // slot of the trip's first command
                 const uint32_t room = first < p.draw_capacity ? p.draw_capacity - first : 0u;
-                const uint32_t words = min(min(n - j0, 64u), room) * 7u;
-                uint32_t *dst = out + (size_t)first * 7u;
+                const uint32_t bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(min(min(n - j0, 64u), room) * 28u));
+                const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)first * 7u, 0, bytes, kBufFlags);
 #pragma unroll
                 for (uint32_t k = 0; k < 7; k++) {
                     const uint32_t w = k * 64u + (uint32_t)lane;
-                    if (w < words) dst[w] = S.cmd[w];
+                    __builtin_amdgcn_raw_buffer_store_b32(S.cmd[w], win, w * 4u, 0, 0);
                 }
                 __builtin_amdgcn_wave_barrier(); // cmd is rewritten by the next trip
             }
@@ -1247,13 +1299,21 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
 
 template <bool VISIBLE, bool STREAM = false>
 __global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullParams p) {
-    if constexpr (STREAM && !VISIBLE) meshlet_emit_chain_body(p);
-    else meshlet_emit_body<VISIBLE, STREAM>(p);
+    meshlet_emit_body<VISIBLE, STREAM>(p);
 }
 template <bool STREAM>
 __global__ __launch_bounds__(256) void meshlet_emit_views_kernel(const MeshletCullViews all, const ViewGroup g) {
-    if constexpr (STREAM) meshlet_emit_chain_body(all.v[g.idx[blockIdx.y]]);
-    else meshlet_emit_body<false, false>(all.v[g.idx[blockIdx.y]]);
+    meshlet_emit_body<false, STREAM>(all.v[g.idx[blockIdx.y]]);
+}
+// the chain emit is bound by instruction issue: kChainWavesPerSimd resident waves per SIMD (the register budget the
+// compiler gets) and exactly that many blocks per CU in the grid — a block more per CU would run as a second round
+constexpr int kChainWavesPerSimd = 5;
+__global__ __launch_bounds__(256, kChainWavesPerSimd) void meshlet_emit_chain_kernel(const MeshletCullParams p) {
+    meshlet_emit_chain_body(p);
+}
+__global__ __launch_bounds__(256, kChainWavesPerSimd) void meshlet_emit_chain_views_kernel(const MeshletCullViews all,
+                                                                                          const ViewGroup g) {
+    meshlet_emit_chain_body(all.v[g.idx[blockIdx.y]]);
 }
 
 // Visible list -> MeshletDrawCommandBuffer (meshlet_cull.comp:216-230 for survivors that were culled on another GPU):
@@ -1532,14 +1592,14 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t
     if (eblocks > eneed) eblocks = eneed;
     if (eblocks == 0) eblocks = 1;
     const bool stream = PASS != 1 && p.ms.sphere != nullptr; // the list-driven pass 1 keeps its payload
-    // the chain emit's registers and LDS (26 KB per block) allow five resident blocks per CU
-    if (stream && !p.visible_list) eblocks = max(min(num_cus * 5u, eneed), 1u);
     if (p.visible_list) {
         if (stream) hipLaunchKernelGGL((meshlet_emit_kernel<true, true>), dim3(eblocks), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((meshlet_emit_kernel<true, false>), dim3(eblocks), dim3(256), 0, s, p);
+    } else if (stream) {
+        const uint32_t cblocks = max(min(num_cus * (uint32_t)kChainWavesPerSimd, eneed), 1u);
+        hipLaunchKernelGGL(meshlet_emit_chain_kernel, dim3(cblocks), dim3(256), 0, s, p);
     } else {
-        if (stream) hipLaunchKernelGGL((meshlet_emit_kernel<false, true>), dim3(eblocks), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((meshlet_emit_kernel<false, false>), dim3(eblocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((meshlet_emit_kernel<false, false>), dim3(eblocks), dim3(256), 0, s, p);
     }
     return hipGetLastError();
 }
@@ -1621,8 +1681,8 @@ hipError_t launch_meshlet_cull_views(const MeshletCullViews &all, uint32_t n, ui
             if (from_stream(i) == (stream != 0)) g.idx[m++] = (uint8_t)i;
         if (m == 0) continue;
         if (stream)
-            hipLaunchKernelGGL(meshlet_emit_views_kernel<true>, dim3(max(min(num_cus * 5u / n, eneed), 1u), m), dim3(256), 0,
-                               s, all, g);
+            hipLaunchKernelGGL(meshlet_emit_chain_views_kernel,
+                               dim3(max(min(num_cus * (uint32_t)kChainWavesPerSimd / m, eneed), 1u), m), dim3(256), 0, s, all, g);
         else hipLaunchKernelGGL(meshlet_emit_views_kernel<false>, dim3(eblocks, m), dim3(256), 0, s, all, g);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
