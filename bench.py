@@ -50,9 +50,12 @@ def parse():
     ap.add_argument("--time-every", type=int, default=3,
                     help="the dominant kernel of every n-th launch per frame slot is timed with HIP events")
     ap.add_argument("--meshlet-source", choices=("stream", "buffer"), default="stream",
-                    help="what the streaming evaluation reads: the derived meshlet streams (24 B per meshlet, built "
-                         "once from the meshlet buffer before the timed region; include/orbit_abi.h) or the 32-B "
-                         "Meshlet buffer itself")
+                    help="what the streaming evaluation reads: the derived meshlet streams (22 B per meshlet — 20.25 B "
+                         "with their alpha classes — built once from the meshlet buffer before the timed region; "
+                         "include/orbit_abi.h) or the 32-B Meshlet buffer itself")
+    ap.add_argument("--no-alpha-classes", action="store_true",
+                    help="stream source without orbit_meshlet_stream_set_materials: the evaluation reads the 2-B "
+                         "material index of every meshlet (22 B per meshlet)")
     ap.add_argument("--settle-ms", type=float, default=60.0,
                     help="device time spent on back-to-back frames BEFORE the warmup steps, so that the device is in "
                          "its sustained power state when they start: from idle, the firmware's power controller "
@@ -196,6 +199,8 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         mstream = slots[0].eng.meshlet_stream(meshlets_base, mb * M, (me - mb) * M)
+        if not args.no_alpha_classes:  # as the renderer would after add_material: the evaluation reads no material index
+            mstream.set_materials(materials, spec.materials)
         torch.cuda.synchronize()
         mstream_build_ms = (time.perf_counter() - t0) * 1e3
         for s in slots:
@@ -485,11 +490,16 @@ def main():
     # the eval launch carries the read side (32 N_m + 16 N_d + 64 N_e = 32.75 B per meshlet here), the emit
     # launch the 28 N_draw + 4 written bytes (DESIGN.md "Algorithmic bytes").
     # From the derived meshlet streams the evaluation reads 22 B per meshlet (sphere 16, cone 4, material index 2)
-    # instead of the 32-B Meshlet, and the emit launch gathers 12 B of command words per survivor.
-    per_meshlet = 22 if mstream is not None else 32
+    # instead of the 32-B Meshlet, and the emit launch streams 2 B of counts per meshlet of the records that have
+    # survivors (the command chain) instead of a payload.
+    # (20.25 with the streams' alpha classes: two class bits instead of the 2-B material index)
+    per_meshlet = (20.25 if not args.no_alpha_classes else 22) if mstream is not None else 32
     alg_bytes = per_meshlet * n_in + 16 * n_rec + 64 * n_local_entities
     achieved = alg_bytes / (eval_ms * 1e-3) / 1e9
-    op_bytes = alg_bytes + ((12 if mstream is not None and not visible_exchange else 0) + item) * n_draw + 4
+    # the chain emit: records again, 2-B counts of every meshlet (records without survivors are skipped: a few %), 64-B
+    # ballots per tile, one link bit per meshlet
+    emit_read = (16 * n_rec + 2 * n_in + n_rec * 4 + n_in // 8) if (mstream is not None and not visible_exchange) else 0
+    op_bytes = alg_bytes + emit_read + item * n_draw + 4
     # the PMC passes were taken on the whole scene at N=1
     traffic = load_traffic(E, M, args.meshlet_source) if world == 1 else None
 
@@ -543,9 +553,11 @@ def main():
                 "settle_ms": args.settle_ms, "settle_frames": settle_frames,
                 "ms_per_step_without_settle": cold_ms_per_step,
                 "exchange": (args.exchange if do_gather else None), "transport": transport,
-                "meshlet_source": (f"derived meshlet streams (22 B per meshlet evaluated, 12 B per survivor gathered; "
-                                   f"built once from the meshlet buffer before the timed region in "
-                                   f"{mstream_build_ms:.2f} ms, +34 B of HBM per meshlet)" if mstream is not None
+                "meshlet_source": (f"derived meshlet streams ({per_meshlet:g} B per meshlet evaluated"
+                                   f"{' (alpha classes instead of material indices)' if not args.no_alpha_classes else ''}, "
+                                   f"commands derived from the 2-B count chain; built once from the meshlet buffer "
+                                   f"before the timed region in {mstream_build_ms:.2f} ms, +36.4 B of HBM per meshlet)"
+                                   if mstream is not None
                                    else "the 32-B Meshlet buffer"),
             },
             "roofline": {

@@ -16,7 +16,7 @@ pub struct OrbitMeshletStream { _private: [u8; 0] }
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct OrbitCaps {
     pub max_entities: u32, pub max_dispatches: u32, pub max_draws: u32, pub max_lights: u32,
-    pub max_clusters: u32, pub dispatch_size: u32, pub max_views: u32, pub reserved: u32,
+    pub max_clusters: u32, pub dispatch_size: u32, pub max_views: u32, pub validate_streams: u32,
 }
 
 /// push-constant order of shaders/entity_cull.comp:17-23 (== draw_gen.rs:372-376)
@@ -130,8 +130,13 @@ extern "C" {
                                        out_stream: *mut *mut OrbitMeshletStream) -> i32;
     pub fn orbit_meshlet_stream_update(ctx: *mut OrbitCtx, ms: *mut OrbitMeshletStream, meshlet_buffer: *const c_void,
                                        first: u64, count: u64, stream: *mut c_void) -> i32;
+    // GpuAssets::add_material calls `set_materials` after the upload (assets/mod.rs:520): the alpha classes
+    pub fn orbit_meshlet_stream_set_materials(ctx: *mut OrbitCtx, ms: *mut OrbitMeshletStream, material_buffer: *const c_void,
+                                              material_count: u32, stream: *mut c_void) -> i32;
+    pub fn orbit_meshlet_stream_validate(ctx: *mut OrbitCtx, ms: *mut OrbitMeshletStream, meshlet_buffer: *const c_void,
+                                         material_buffer: *const c_void, stream: *mut c_void) -> i32;
     pub fn orbit_meshlet_stream_destroy(ms: *mut OrbitMeshletStream) -> i32;
-    pub fn orbit_ctx_bind_meshlet_stream(ctx: *mut OrbitCtx, ms: *const OrbitMeshletStream) -> i32;
+    pub fn orbit_ctx_bind_meshlet_stream(ctx: *mut OrbitCtx, ms: *mut OrbitMeshletStream) -> i32;
     pub fn orbit_ctx_meshlet_stream_culls(ctx: *const OrbitCtx) -> u64;
     // exchange without a host round trip: IPC-mapped peer buffers + a device-side rank-ordered scatter
     pub fn orbit_p2p_alloc(ctx: *mut OrbitCtx, bytes: u64, out_ptr: *mut *mut c_void, out_handle: *mut [u8; 64]) -> i32;
@@ -184,6 +189,12 @@ pub fn check(ctx: *const OrbitCtx, rc: i32) {
 //     check(ctx, unsafe { orbit_meshlet_stream_update(ctx, ms, hip_ptr(&self.meshlet_buffer),
 //                                                     meshlet_range.start as u64, meshlets.len() as u64, hip_stream) });
 //
+// GpuAssets::add_material, right after the upload (assets/mod.rs:520-526):
+//     check(ctx, unsafe { orbit_meshlet_stream_set_materials(ctx, ms, hip_ptr(&self.materials_buffer),
+//                                                            self.material_indices.len() as u32, hip_stream) });
+//
 // Nothing else changes: orbit_meshlet_cull keeps taking bufs.meshlet_buffer; when it is the pointer the stream was
-// updated from, passes 0 and 2 read the stream (22 B per meshlet instead of 32, no survivor payload).  A meshlet the
-// stream does not cover latches ORBIT_E_RANGE (orbit_ctx_status) instead of being read out of range.
+// updated from, passes 0 and 2 read the stream (22 B per meshlet instead of 32 — 20.25 when bufs.material_buffer is
+// the pointer of set_materials — no survivor payload, commands derived from the 2-B count chain).  A meshlet the
+// stream does not cover latches ORBIT_E_RANGE (orbit_ctx_status) instead of being read out of range; a debug build of
+// the renderer creates its contexts with caps.validate_streams = 1 and gets ORBIT_E_STALE where an update is missing.

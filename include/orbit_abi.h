@@ -34,7 +34,8 @@ extern "C" {
 #define ORBIT_STATIC_ASSERT(c, m) _Static_assert(c, m)
 #endif
 
-#define ORBIT_ABI_VERSION 2u /* 2: *_CullBufs gained depth_pyramid_levels (per-mip images) */
+#define ORBIT_ABI_VERSION 3u /* 2: *_CullBufs gained depth_pyramid_levels (per-mip images); 3: meshlet streams carry the
+                                command chain and alpha classes, OrbitCaps.validate_streams, ORBIT_E_STALE */
 
 /* u32::MAX = "resource absent" (src/passes/draw_gen.rs:142-144,
  * shaders/meshlet_cull.comp:127). */
@@ -57,7 +58,9 @@ enum {
     ORBIT_E_MISSING = -7,  /* a resource the CullInfo declares present was passed as NULL
                               (.unwrap() at draw_gen.rs:123-133) */
     ORBIT_E_COMM = -8,     /* RCCL is not loadable in this process or one of its calls failed */
-    ORBIT_E_RANGE = -9     /* a culled / expanded meshlet lies outside the bound meshlet stream (latched on device) */
+    ORBIT_E_RANGE = -9,    /* a culled / expanded meshlet lies outside the bound meshlet stream (latched on device) */
+    ORBIT_E_STALE = -10    /* the bound meshlet stream no longer mirrors the meshlet buffer it was derived from
+                              (orbit_meshlet_stream_validate, or any cull with caps.validate_streams; latched) */
 };
 
 /* ------------------------------------------------------------------------ */
@@ -334,7 +337,9 @@ typedef struct OrbitCaps {
     uint32_t max_views;      /* orbit_cull_views: scan scratch for this many views is allocated at context creation
                                 (0: for one view; more is then allocated on the first call that needs it — the only
                                 allocation an enqueue call can ever make) */
-    uint32_t reserved;
+    uint32_t validate_streams; /* debug: != 0 makes every cull / expansion served from a bound meshlet stream first
+                                  compare the stream with the meshlet buffer (one extra pass over both, ORBIT_E_STALE
+                                  latched on a difference): finds a missing orbit_meshlet_stream_update */
 } OrbitCaps;
 
 typedef struct OrbitCtx OrbitCtx;
@@ -356,7 +361,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps, OrbitCtx **ou
 int32_t orbit_ctx_destroy(OrbitCtx *ctx);
 /* Message for the last failing call on this thread / context (never NULL). */
 const char *orbit_last_error(const OrbitCtx *ctx);
-/* Device-latched status (ORBIT_OK / ORBIT_E_CAPACITY / ORBIT_E_RANGE / ORBIT_E_TIMEOUT).
+/* Device-latched status (ORBIT_OK / ORBIT_E_CAPACITY / ORBIT_E_RANGE / ORBIT_E_STALE / ORBIT_E_TIMEOUT).
  * `sync` != 0 first waits for `stream` to drain.  Clears the latch. */
 int32_t orbit_ctx_status(OrbitCtx *ctx, void *stream, int32_t sync);
 
@@ -491,41 +496,78 @@ int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t cou
 /* GpuAssets::add_mesh writes a mesh's Meshlet records into meshlet_buffer   */
 /* once (src/assets/mod.rs:441-445); every frame's meshlet cull then streams */
 /* all 32 B of every dispatched meshlet, although the decision reads 22 of   */
-/* them (bounding sphere, cone, material index) and only the ~10 % that      */
-/* survive need the rest (vertex_offset, data_offset, counts) for their      */
-/* command.  A stream object keeps four derived arrays for a range of the    */
-/* buffer: spheres (16 B), cones (4 B), material indices (2 B) and command   */
-/* words (12 B) — 34 B of HBM per meshlet on top of the buffer itself.       */
+/* them (bounding sphere, cone, material index) — 20 and a quarter once the  */
+/* material's alpha_mode is known — and only the ~10 % that survive need the */
+/* rest (vertex_offset, data_offset, counts) for their command.  A stream    */
+/* object keeps derived arrays for a range of the buffer (36.4 B of HBM per  */
+/* meshlet on top of the buffer itself):                                     */
+/*   spheres 16 B, cones 4 B, material indices 2 B — what every meshlet's    */
+/*     test reads;                                                           */
+/*   alpha classes, 2 bits — the material's alpha_mode, so that the test     */
+/*     reads no material index (set_materials below);                        */
+/*   command words 12 B — gathered per survivor by orbit_expand_visible;     */
+/*   counts 2 B + 1 link bit — the command chain: compute_meshlets /         */
+/*     add_mesh lay a mesh's meshlets out so that a meshlet's data_offset is */
+/*     its predecessor's plus the predecessor's vertex_count +               */
+/*     ceil(3 * triangle_count / 4) words, with one vertex_offset per        */
+/*     submesh (src/assets/mesh.rs:309-316, assets/mod.rs:413-416); the link */
+/*     bit records where that holds, and the emit launch then derives a      */
+/*     survivor's offsets from one gathered base per chain and the counts    */
+/*     streamed at 2 B per meshlet instead of gathering 12 B per survivor.   */
+/*     Meshlets laid out any other way are served by gathers: the chain is   */
+/*     an acceleration, never an assumption.                                 */
 /* With a stream bound to a context, orbit_meshlet_cull / _task_cull /       */
 /* _cull_visible calls whose bufs->meshlet_buffer is the pointer the stream  */
-/* was last updated from evaluate occlusion passes 0 and 2 from the 22-B     */
-/* arrays and write no survivor payload; the emit launch gathers the         */
-/* survivors' 12 B (nothing for the visible list), and orbit_expand_visible  */
-/* gathers 12 B instead of touching the survivors' Meshlets.  Results are    */
-/* bit-identical to the plain path (every test of tests/test_gpu_parity.py   */
-/* runs both ways).  orbit_cull_views applies the same rule per view.  Pass 1 */
-/* (list-driven gathers) and any call with another meshlet_buffer pointer    */
-/* read the Meshlet buffer as before.                                        */
+/* was last updated from evaluate occlusion passes 0 and 2 from the arrays   */
+/* and write no survivor payload, and orbit_expand_visible gathers 12 B      */
+/* instead of touching the survivors' Meshlets.  Results are bit-identical   */
+/* to the plain path (every test of tests/test_gpu_parity.py runs all ways). */
+/* orbit_cull_views applies the same rule per view.  Pass 1 (list-driven     */
+/* gathers) and any call with another meshlet_buffer pointer read the        */
+/* Meshlet buffer as before.                                                 */
 /*                                                                           */
 /*   create   arrays for global meshlet indices [first_meshlet,              */
-/*            first_meshlet + capacity) (device memory: 34 B x capacity)     */
+/*            first_meshlet + capacity), capacity <= 2^28 (device memory:    */
+/*            36.4 B x capacity, zero-filled)                                */
 /*   update   re-derives [first, first + count) from `meshlet_buffer` (same  */
 /*            global indexing as bufs->meshlet_buffer), enqueued on `stream`;*/
 /*            call it wherever the renderer writes meshlets (add_mesh) —     */
 /*            meshlets changed without an update are culled from stale data  */
-/*   bind     NULL unbinds; the stream must outlive the binding; one stream  */
-/*            can be bound to any number of contexts of its device.  The     */
-/*            stream must cover every meshlet the culls dispatch: a meshlet  */
-/*            outside its range is not read from it (the lane evaluates      */
-/*            zeros, the command carries zeros) and ORBIT_E_RANGE is latched */
+/*            (caps.validate_streams / orbit_meshlet_stream_validate find    */
+/*            that).  Culls read the HULL of the ranges updated from the     */
+/*            same buffer pointer; meshlets inside it that no update reached */
+/*            are empty (zero) meshlets.  An update from another pointer     */
+/*            starts the range over.                                         */
+/*   set_materials  derives every meshlet's alpha class from                 */
+/*            material_buffer[material_index].alpha_mode (material_count     */
+/*            entries; indices beyond it and modes > 2 are looked up at cull */
+/*            time as before) and remembers the pointer: later updates       */
+/*            derive the classes of their range from it, and culls whose     */
+/*            bufs->material_buffer is that pointer read the classes instead */
+/*            of the material indices.  Call it wherever the renderer writes */
+/*            materials (add_material, assets/mod.rs:520); NULL forgets.     */
+/*   validate compares the stream with `meshlet_buffer` (and the classes     */
+/*            with `material_buffer`, may be NULL) over the readable range   */
+/*            and latches ORBIT_E_STALE in the context's status on any       */
+/*            difference.                                                    */
+/*   bind     NULL unbinds; one stream can be bound to any number of         */
+/*            contexts of its device, and cannot be destroyed while bound    */
+/*            (ORBIT_E_INVALID; destroying a context unbinds).  The stream   */
+/*            must cover every meshlet the culls dispatch: a meshlet outside */
+/*            its range is not read from it (the lane evaluates zeros, the   */
+/*            command carries zeros) and ORBIT_E_RANGE is latched            */
 /* ------------------------------------------------------------------------ */
 typedef struct OrbitMeshletStream OrbitMeshletStream;
 int32_t orbit_meshlet_stream_create(OrbitCtx *ctx, uint64_t first_meshlet, uint64_t capacity,
                                     OrbitMeshletStream **out_stream);
 int32_t orbit_meshlet_stream_update(OrbitCtx *ctx, OrbitMeshletStream *ms, const void *meshlet_buffer,
                                     uint64_t first, uint64_t count, void *stream);
+int32_t orbit_meshlet_stream_set_materials(OrbitCtx *ctx, OrbitMeshletStream *ms, const void *material_buffer,
+                                           uint32_t material_count, void *stream);
+int32_t orbit_meshlet_stream_validate(OrbitCtx *ctx, OrbitMeshletStream *ms, const void *meshlet_buffer,
+                                      const void *material_buffer, void *stream);
 int32_t orbit_meshlet_stream_destroy(OrbitMeshletStream *ms);
-int32_t orbit_ctx_bind_meshlet_stream(OrbitCtx *ctx, const OrbitMeshletStream *ms);
+int32_t orbit_ctx_bind_meshlet_stream(OrbitCtx *ctx, OrbitMeshletStream *ms);
 /* Calls this context has served from a bound stream so far — meshlet culls of passes 0 and 2 (each such view of
  * orbit_cull_views counts) and orbit_expand_visible (tests and integration checks: a call whose meshlet_buffer is not the stream's source
  * silently takes the plain path). */

@@ -10,12 +10,12 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liborbit_cull.so")
 
-OK, E_INVALID, E_PLANES, E_CAPACITY, E_HIP, E_NO_DEVICE, E_TIMEOUT, E_MISSING, E_COMM, E_RANGE = (
-    0, -1, -2, -3, -4, -5, -6, -7, -8, -9)
+OK, E_INVALID, E_PLANES, E_CAPACITY, E_HIP, E_NO_DEVICE, E_TIMEOUT, E_MISSING, E_COMM, E_RANGE, E_STALE = (
+    0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10)
 ERROR_NAMES = {
     E_INVALID: "ORBIT_E_INVALID", E_PLANES: "ORBIT_E_PLANES", E_CAPACITY: "ORBIT_E_CAPACITY", E_HIP: "ORBIT_E_HIP",
     E_NO_DEVICE: "ORBIT_E_NO_DEVICE", E_TIMEOUT: "ORBIT_E_TIMEOUT", E_MISSING: "ORBIT_E_MISSING",
-    E_COMM: "ORBIT_E_COMM", E_RANGE: "ORBIT_E_RANGE",
+    E_COMM: "ORBIT_E_COMM", E_RANGE: "ORBIT_E_RANGE", E_STALE: "ORBIT_E_STALE",
 }
 
 MAX_PYRAMID_MIPS = 16
@@ -30,7 +30,7 @@ class OrbitError(RuntimeError):
 class Caps(C.Structure):
     _fields_ = [("max_entities", C.c_uint32), ("max_dispatches", C.c_uint32), ("max_draws", C.c_uint32),
                 ("max_lights", C.c_uint32), ("max_clusters", C.c_uint32), ("dispatch_size", C.c_uint32),
-                ("max_views", C.c_uint32), ("reserved", C.c_uint32)]
+                ("max_views", C.c_uint32), ("validate_streams", C.c_uint32)]
 
 
 class EntityCullBufs(C.Structure):
@@ -114,6 +114,8 @@ SYMBOLS = {
     "orbit_meshlet_stream_create": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]),
     "orbit_meshlet_stream_update": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                                 C.c_void_p]),
+    "orbit_meshlet_stream_set_materials": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "orbit_meshlet_stream_validate": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orbit_meshlet_stream_destroy": (C.c_int32, [C.c_void_p]),
     "orbit_ctx_bind_meshlet_stream": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "orbit_ctx_meshlet_stream_culls": (C.c_uint64, [C.c_void_p]),

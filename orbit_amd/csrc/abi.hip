@@ -30,11 +30,15 @@ struct OrbitMeshletStream {
     uint16_t *mat = nullptr;
     uint32_t *cmd = nullptr;
     uint16_t *cnt = nullptr;
-    uint32_t *link = nullptr; // word 0 = meshlets (first & ~31) .. +31
-    // Meshlet buffer of the last update (nullptr = never updated).  Atomic: a stream may be bound to several contexts,
-    // each with its own lock; the device-side order of an update against the culls that read it is the caller's, like
-    // the order of the meshlet upload itself.
-    std::atomic<const void *> source{nullptr};
+    uint32_t *link = nullptr, *cls0 = nullptr, *cls1 = nullptr; // word 0 = meshlets (first & ~31) .. +31
+    // A stream may be bound to several contexts, each with its own lock: its own state has its own.  The device-side
+    // order of an update against the culls that read it is the caller's, like the order of the meshlet upload itself.
+    std::mutex mu;
+    const void *source = nullptr;          // Meshlet buffer of the updates so far (nullptr: never updated)
+    uint64_t valid_lo = 0, valid_hi = 0;   // hull of the ranges derived from `source`: what a cull may read
+    const void *materials = nullptr;       // orbit_meshlet_stream_set_materials: what the alpha classes mirror
+    uint32_t material_count = 0;
+    std::atomic<int> bindings{0};          // contexts it is bound to (orbit_meshlet_stream_destroy refuses while > 0)
 };
 
 struct OrbitCtx {
@@ -69,7 +73,7 @@ struct OrbitCtx {
     size_t prof_used = 0;
     // orbit_cull_views: child contexts (own scan scratch) for views 1.., created on first use
     std::vector<OrbitCtx *> view_ctx;
-    const OrbitMeshletStream *meshlet_stream = nullptr; // orbit_ctx_bind_meshlet_stream
+    OrbitMeshletStream *meshlet_stream = nullptr; // orbit_ctx_bind_meshlet_stream
     uint64_t stream_culls = 0;                          // meshlet culls launched from it
     char err[512] = {0};
 };
@@ -131,11 +135,31 @@ int32_t check_cull_info(OrbitCtx *ctx, const OrbitGpuCullInfo *ci) {
     return ORBIT_OK;
 }
 
-// arrays based at global meshlet index 0, like meshlet_buffer itself
-MeshletStreamView stream_view(const OrbitMeshletStream *ms) {
-    return MeshletStreamView{ms->sphere - ms->first, ms->cone - ms->first,   ms->mat - ms->first,
-                             ms->cmd - 3u * ms->first, ms->cnt - ms->first,  ms->link - (ms->first >> 5),
-                             (uint32_t)ms->first,      (uint32_t)ms->capacity};
+// The stream's arrays based at global meshlet index 0, like meshlet_buffer itself, over the range derived so far.
+MeshletStreamView stream_arrays(const OrbitMeshletStream *ms, uint64_t lo, uint64_t hi) {
+    MeshletStreamView v{};
+    v.sphere = ms->sphere - ms->first;
+    v.cone = ms->cone - ms->first;
+    v.mat = ms->mat - ms->first;
+    v.cmd = ms->cmd - 3u * ms->first;
+    v.cnt = ms->cnt - ms->first;
+    v.link = ms->link - (ms->first >> 5);
+    v.cls0 = ms->cls0 - (ms->first >> 5);
+    v.cls1 = ms->cls1 - (ms->first >> 5);
+    v.first = (uint32_t)lo;
+    v.count = (uint32_t)(hi - lo);
+    return v;
+}
+
+// What a cull of `meshlet_buffer` (with `material_buffer`) may take from the stream bound to its context: nothing
+// unless the stream mirrors that very buffer; the alpha classes only if they mirror that very material buffer.
+MeshletStreamView stream_view_for(OrbitMeshletStream *ms, const void *meshlet_buffer, const void *material_buffer) {
+    if (!ms) return MeshletStreamView{};
+    std::lock_guard<std::mutex> lock(ms->mu);
+    if (ms->source == nullptr || ms->source != meshlet_buffer || ms->valid_hi == ms->valid_lo) return MeshletStreamView{};
+    MeshletStreamView v = stream_arrays(ms, ms->valid_lo, ms->valid_hi);
+    if (ms->materials == nullptr || ms->materials != material_buffer) v.cls0 = v.cls1 = nullptr;
+    return v;
 }
 
 PyramidView make_pyramid_view(const float *texels, const uint32_t size[2],
@@ -278,8 +302,10 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->a_coarse_seg = (uint32_t)aseg;
     ctx->g_counts = (uint32_t *)(a + o_gc);
     ctx->m_tickets = (uint32_t *)(a + o_tk);
+#ifdef ORBIT_TRIAGE // perf-triage builds (tools/mkvariant_any.sh); the product library reads no environment variable
     const char *dbg = getenv("ORBIT_SP_DEBUG");
     ctx->debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u;
+#endif
     snprintf(ctx->err, sizeof(ctx->err), "no error");
     // scan scratch of views 1.. of orbit_cull_views, when the caller announced them
     if (caps.max_views > ORBIT_MAX_CULL_VIEWS) {
@@ -307,6 +333,7 @@ int32_t orbit_ctx_destroy(OrbitCtx *ctx) {
     (void)hipDeviceSynchronize();
     for (hipEvent_t ev : ctx->prof_events) (void)hipEventDestroy(ev);
     for (OrbitCtx *child : ctx->view_ctx) (void)orbit_ctx_destroy(child);
+    if (ctx->meshlet_stream) ctx->meshlet_stream->bindings.fetch_sub(1);
     if (ctx->arena) (void)hipFree(ctx->arena);
     delete ctx;
     return ORBIT_OK;
@@ -337,6 +364,7 @@ int32_t orbit_ctx_status(OrbitCtx *ctx, void *stream, int32_t sync) {
         if (e != hipSuccess) return hip_fail(ctx, e, "hipMemset(status)");
         return fail(ctx, v, v == ORBIT_E_CAPACITY ? "an append overflowed a caller buffer (entries dropped)"
                             : v == ORBIT_E_RANGE  ? "a meshlet outside the bound meshlet stream was culled or expanded"
+                            : v == ORBIT_E_STALE  ? "the bound meshlet stream no longer mirrors its meshlet buffer (update missing)"
                                                   : "device-latched error %d", v);
     }
     return ORBIT_OK;
@@ -482,10 +510,7 @@ int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCull
     p.ci = *ci;
     p.dispatch_buffer = (const uint8_t *)b->meshlet_dispatch_buffer;
     p.meshlets = (const OrbitMeshlet *)b->meshlet_buffer;
-    p.ms = MeshletStreamView{};
-    if (const OrbitMeshletStream *ms = ctx->meshlet_stream; ms && ms->source.load() == b->meshlet_buffer)
-        // arrays based at global meshlet index 0, like meshlet_buffer itself
-        p.ms = stream_view(ms);
+    p.ms = stream_view_for(ctx->meshlet_stream, b->meshlet_buffer, b->material_buffer);
     p.draw_buffer = (uint8_t *)(visible_path ? visible_buffer : b->draw_commands_buffer);
     p.entities = (const OrbitEntityData *)b->entity_buffer;
     p.materials = (const OrbitMaterialData *)b->material_buffer;
@@ -531,6 +556,12 @@ int32_t meshlet_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbit
         ev0 = ctx->prof_events[ctx->prof_used];
         ev1 = ctx->prof_events[ctx->prof_used + 1];
         ctx->prof_used += 2;
+    }
+    if (p.ms.sphere && ctx->caps.validate_streams && ci->occlusion_pass != 1) { // debug: is the stream still a mirror?
+        const hipError_t ve = launch_meshlet_stream_validate(p.meshlets, p.ms, p.ms.cls0 ? p.materials : nullptr,
+                                                             ctx->meshlet_stream->material_count, ctx->status,
+                                                             (hipStream_t)stream);
+        if (ve != hipSuccess) return hip_fail(ctx, ve, "launch meshlet_stream_validate");
     }
     hipError_t e = launch_meshlet_cull(p, ctx->num_cus, (hipStream_t)stream, ev0, ev1);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_cull");
@@ -599,8 +630,8 @@ int32_t orbit_meshlet_stream_create(OrbitCtx *ctx, uint64_t first_meshlet, uint6
     // 32-bit meshlet indices; the emit launch addresses the arrays through buffer resources (32-bit byte offsets:
     // 12 B per meshlet < 4 GiB)
     if (capacity == 0 || capacity > (1ull << 28) || first_meshlet + capacity > 0xFFFFFFFFull)
-        return fail(ctx, ORBIT_E_INVALID, "meshlet_stream_create: range [%llu, +%llu)", (unsigned long long)first_meshlet,
-                    (unsigned long long)capacity);
+        return fail(ctx, ORBIT_E_INVALID, "meshlet_stream_create: range [%llu, +%llu) (at most 2^28 meshlets per stream)",
+                    (unsigned long long)first_meshlet, (unsigned long long)capacity);
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return hip_fail(ctx, e, "hipSetDevice");
     OrbitMeshletStream *ms = new (std::nothrow) OrbitMeshletStream();
@@ -608,18 +639,29 @@ int32_t orbit_meshlet_stream_create(OrbitCtx *ctx, uint64_t first_meshlet, uint6
     ms->device = ctx->device;
     ms->first = first_meshlet;
     ms->capacity = capacity;
-    e = hipMalloc((void **)&ms->sphere, capacity * sizeof(uint4));
-    if (e == hipSuccess) e = hipMalloc((void **)&ms->cone, capacity * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&ms->mat, capacity * sizeof(uint16_t) + 256u);
-    if (e == hipSuccess) e = hipMalloc((void **)&ms->cmd, capacity * 12u);
-    if (e == hipSuccess) e = hipMalloc((void **)&ms->cnt, capacity * sizeof(uint16_t) + 256u);
     // one bit per meshlet in words aligned to global index 0, plus the word behind a record that ends the range
-    const size_t link_words = (size_t)(((first_meshlet + capacity + 31u) >> 5) - (first_meshlet >> 5)) + 2u;
-    if (e == hipSuccess) e = hipMalloc((void **)&ms->link, link_words * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(ms->link, 0, link_words * sizeof(uint32_t));
+    const size_t bit_words = (size_t)(((first_meshlet + capacity + 31u) >> 5) - (first_meshlet >> 5)) + 2u;
+    struct {
+        void **p;
+        size_t bytes;
+        int fill;
+    } arrays[] = {{(void **)&ms->sphere, capacity * sizeof(uint4), 0},
+                  {(void **)&ms->cone, capacity * sizeof(uint32_t), 0},
+                  {(void **)&ms->mat, capacity * sizeof(uint16_t) + 256u, 0},
+                  {(void **)&ms->cmd, capacity * 12u, 0},
+                  {(void **)&ms->cnt, capacity * sizeof(uint16_t) + 256u, 0},
+                  {(void **)&ms->link, bit_words * sizeof(uint32_t), 0},
+                  {(void **)&ms->cls0, bit_words * sizeof(uint32_t), 0xFF},  // class 3: look the material up
+                  {(void **)&ms->cls1, bit_words * sizeof(uint32_t), 0xFF}};
+    // Zero-filled: a meshlet inside the derived range that no update has reached (a gap between two uploads) is a
+    // defined, empty meshlet — never uninitialised memory.
+    for (auto &a : arrays) {
+        if (e == hipSuccess) e = hipMalloc(a.p, a.bytes);
+        if (e == hipSuccess) e = hipMemset(*a.p, a.fill, a.bytes);
+    }
     if (e != hipSuccess) {
         orbit_meshlet_stream_destroy(ms);
-        return hip_fail(ctx, e, "meshlet_stream_create: hipMalloc (36.2 B per meshlet)");
+        return hip_fail(ctx, e, "meshlet_stream_create: hipMalloc (36.4 B per meshlet)");
     }
     *out_stream = ms;
     return ORBIT_OK;
@@ -635,30 +677,88 @@ int32_t orbit_meshlet_stream_update(OrbitCtx *ctx, OrbitMeshletStream *ms, const
         return fail(ctx, ORBIT_E_CAPACITY, "meshlet_stream_update: [%llu, +%llu) outside the stream's [%llu, +%llu)",
                     (unsigned long long)first, (unsigned long long)count, (unsigned long long)ms->first,
                     (unsigned long long)ms->capacity);
-    ms->source.store(meshlet_buffer);
-    const hipError_t e = launch_meshlet_stream_build((const OrbitMeshlet *)meshlet_buffer, first, count, stream_view(ms),
+    std::lock_guard<std::mutex> slock(ms->mu);
+    // What was derived from another buffer says nothing about this one: the readable range starts over.  (The arrays
+    // keep the other buffer's values outside [first, first + count); they are outside the new range too.)
+    const bool same = ms->source == meshlet_buffer && ms->valid_hi > ms->valid_lo;
+    const uint64_t lo = same ? (first < ms->valid_lo ? first : ms->valid_lo) : first;
+    const uint64_t hi = same ? (first + count > ms->valid_hi ? first + count : ms->valid_hi) : first + count;
+    // the link bit in front of / behind the range looks at the neighbour's derived copy: only inside the same buffer's range
+    MeshletStreamView v = stream_arrays(ms, same ? ms->valid_lo : first, same ? ms->valid_hi : first + count);
+    if (v.first > first) v.count += v.first - (uint32_t)first, v.first = (uint32_t)first;
+    if ((uint64_t)v.first + v.count < first + count) v.count = (uint32_t)(first + count - v.first);
+    const hipError_t e = launch_meshlet_stream_build((const OrbitMeshlet *)meshlet_buffer, first, count, v,
+                                                     (const OrbitMaterialData *)ms->materials, ms->material_count,
                                                      (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_stream_build");
+    if (count != 0) { // the stream mirrors the buffer only once the launch is enqueued
+        ms->source = meshlet_buffer;
+        ms->valid_lo = lo;
+        ms->valid_hi = hi;
+    }
+    return ORBIT_OK;
+}
+
+int32_t orbit_meshlet_stream_set_materials(OrbitCtx *ctx, OrbitMeshletStream *ms, const void *material_buffer,
+                                           uint32_t material_count, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ms) return fail(ctx, ORBIT_E_MISSING, "meshlet_stream_set_materials: stream is NULL");
+    if (ms->device != ctx->device)
+        return fail(ctx, ORBIT_E_INVALID, "meshlet_stream_set_materials: stream lives on device %d", ms->device);
+    if (material_buffer && material_count == 0)
+        return fail(ctx, ORBIT_E_INVALID, "meshlet_stream_set_materials: material_count is 0");
+    std::lock_guard<std::mutex> slock(ms->mu);
+    // every meshlet the arrays hold, derived or not (the indices of never-derived ones are zero)
+    const hipError_t e = launch_meshlet_stream_classes(stream_arrays(ms, ms->first, ms->first + ms->capacity),
+                                                       (const OrbitMaterialData *)material_buffer,
+                                                       material_buffer ? material_count : 0u, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_stream_classes");
+    ms->materials = material_buffer;
+    ms->material_count = material_buffer ? material_count : 0u;
+    return ORBIT_OK;
+}
+
+int32_t orbit_meshlet_stream_validate(OrbitCtx *ctx, OrbitMeshletStream *ms, const void *meshlet_buffer,
+                                      const void *material_buffer, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ms || !meshlet_buffer) return fail(ctx, ORBIT_E_MISSING, "meshlet_stream_validate: NULL argument");
+    if (ms->device != ctx->device)
+        return fail(ctx, ORBIT_E_INVALID, "meshlet_stream_validate: stream lives on device %d", ms->device);
+    const MeshletStreamView v = stream_view_for(ms, meshlet_buffer, material_buffer);
+    if (!v.sphere) return ORBIT_OK; // mirrors another buffer (or nothing): no cull of this one reads it
+    const hipError_t e = launch_meshlet_stream_validate((const OrbitMeshlet *)meshlet_buffer, v,
+                                                        (const OrbitMaterialData *)material_buffer, ms->material_count,
+                                                        ctx->status, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_stream_validate");
     return ORBIT_OK;
 }
 
 int32_t orbit_meshlet_stream_destroy(OrbitMeshletStream *ms) {
     if (!ms) return ORBIT_OK;
+    if (ms->bindings.load() > 0)
+        return fail(nullptr, ORBIT_E_INVALID, "meshlet_stream_destroy: the stream is still bound to %d context(s)",
+                    ms->bindings.load());
     (void)hipFree(ms->sphere);
     (void)hipFree(ms->cone);
     (void)hipFree(ms->mat);
     (void)hipFree(ms->cmd);
     (void)hipFree(ms->cnt);
     (void)hipFree(ms->link);
+    (void)hipFree(ms->cls0);
+    (void)hipFree(ms->cls1);
     delete ms;
     return ORBIT_OK;
 }
 
-int32_t orbit_ctx_bind_meshlet_stream(OrbitCtx *ctx, const OrbitMeshletStream *ms) {
+int32_t orbit_ctx_bind_meshlet_stream(OrbitCtx *ctx, OrbitMeshletStream *ms) {
     if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (ms && ms->device != ctx->device)
         return fail(ctx, ORBIT_E_INVALID, "bind_meshlet_stream: stream lives on device %d", ms->device);
+    if (ms) ms->bindings.fetch_add(1);
+    if (ctx->meshlet_stream) ctx->meshlet_stream->bindings.fetch_sub(1);
     ctx->meshlet_stream = ms;
     return ORBIT_OK;
 }
@@ -682,10 +782,10 @@ int32_t orbit_expand_visible(OrbitCtx *ctx, const void *visible_buffer, const vo
     if (!visible_buffer || !meshlet_buffer || !draw_commands_buffer)
         return fail(ctx, ORBIT_E_MISSING, "expand_visible: NULL argument");
     // a bound stream that mirrors this meshlet buffer serves the survivors' command words (12-B gathers)
-    const OrbitMeshletStream *ms = ctx->meshlet_stream;
-    const MeshletStreamView view = (ms && ms->source.load() == meshlet_buffer)
-                                       ? stream_view(ms)
-                                       : MeshletStreamView{};
+    const MeshletStreamView view = stream_view_for(ctx->meshlet_stream, meshlet_buffer, nullptr);
+    if (view.sphere && ctx->caps.validate_streams)
+        (void)launch_meshlet_stream_validate((const OrbitMeshlet *)meshlet_buffer, view, nullptr, 0, ctx->status,
+                                             (hipStream_t)stream);
     const hipError_t e = launch_visible_expand((const uint8_t *)visible_buffer, (const OrbitMeshlet *)meshlet_buffer, view,
                                                (uint8_t *)draw_commands_buffer, draw_capacity, ctx->num_cus,
                                                ctx->zero_page, ctx->status, (hipStream_t)stream);

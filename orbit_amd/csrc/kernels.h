@@ -57,6 +57,11 @@ struct MeshletStreamView {
     const uint32_t *cmd;  // 3 words per meshlet: vertex_offset, data_offset, word 7 again
     const uint16_t *cnt;  // vertex_count | triangle_count << 8
     const uint32_t *link; // bit (i & 31) of word (i >> 5): meshlet i continues meshlet i - 1's chain
+    // Alpha classes (orbit_meshlet_stream_set_materials): the alpha_mode of the meshlet's material as two bit planes
+    // (class = bit of cls0 | bit of cls1 << 1, addressed like `link`); 0..2 = that alpha_mode, 3 = look the material
+    // up.  Non-null only for a cull whose material buffer is the one the classes were derived from: the evaluation
+    // then reads 20.25 B per meshlet instead of 22.
+    const uint32_t *cls0, *cls1;
     uint32_t first, count; // global meshlet indices the arrays cover: [first, first + count)
     __host__ __device__ bool covers(uint32_t meshlet) const { return meshlet - first < count; }
 };
@@ -181,9 +186,19 @@ hipError_t launch_meshlet_cull_views(const MeshletCullViews &all, uint32_t n, ui
 uint32_t max_dispatch_capacity();
 // meshlets[first, first + count) -> the three streams (a plain re-layout, one pass)
 // `ms`: the stream's arrays (writable through the const view) and its range; link bits are re-derived for
-// [first, first + count] — the meshlet after the range chains from the range's last one
+// [first, first + count] — the meshlet after the range chains from the range's last one.  `materials` (optional):
+// the buffer the range's alpha classes are derived from (none: class 3, "look the material up").
 hipError_t launch_meshlet_stream_build(const OrbitMeshlet *meshlets, uint64_t first, uint64_t count,
-                                       const MeshletStreamView &ms, hipStream_t s);
+                                       const MeshletStreamView &ms, const OrbitMaterialData *materials,
+                                       uint32_t material_count, hipStream_t s);
+// ORBIT_E_STALE into *status if a meshlet of the stream's range differs from its derived copy (or, with `materials`,
+// an alpha class from its material's alpha_mode): orbit_meshlet_stream_validate
+hipError_t launch_meshlet_stream_validate(const OrbitMeshlet *meshlets, const MeshletStreamView &ms,
+                                          const OrbitMaterialData *materials, uint32_t material_count, int32_t *status,
+                                          hipStream_t s);
+// the alpha classes of the whole stream, from its material indices (orbit_meshlet_stream_set_materials)
+hipError_t launch_meshlet_stream_classes(const MeshletStreamView &ms, const OrbitMaterialData *materials,
+                                         uint32_t material_count, hipStream_t s);
 // ms.cmd (optional): the derived command-word stream of `meshlets`, based at global meshlet index 0
 hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, const MeshletStreamView &ms,
                                  uint8_t *draw_buffer, uint32_t draw_capacity, uint32_t num_cus, const void *zero_page,

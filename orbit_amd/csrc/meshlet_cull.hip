@@ -52,6 +52,7 @@ struct __attribute__((aligned(16))) WaveTileLds {
     uint64_t draw_mask[kTileRows]; // should-draw ballots of the tile's rows (kept here, not in SGPRs)
     uint64_t vis_mask[kTileRows];  // pass 2 with meshlet occlusion: visible ballots, assembled by the candidate flushes
     uint32_t prev[kTileRecords];   // pass 1: last frame's visibility word of each record
+    uint2 amask[kTileRecords];     // alpha classes: per record {(:207) bits, (:210) bits} of its 32 lanes
 };
 
 // The cull planes live in LDS (one copy per block, written once): a row reads
@@ -125,6 +126,21 @@ __device__ __forceinline__ bool alpha_table_fill(const MeshletCullParams &p, Alp
         for (uint32_t i = threadIdx.x; i < p.material_count; i += blockDim.x)
             A.bits[i] = (uint8_t)alpha_bits(p.ci, p.materials[i].alpha_mode);
     return use;
+}
+
+// The two predicate bits of lane `ml` of record `rid`: from the material table / gather, or — STREAM with alpha classes
+// (a wave-uniform choice) — from the record's masks in the slab (setup_write_cls).
+template <bool STREAM>
+__device__ __forceinline__ uint32_t lane_alpha_bits(const MeshletCullParams &p, const WaveTileLds &L, const AlphaLds *A,
+                                                    uint32_t rid, uint32_t ml, uint32_t word7) {
+    const uint32_t mi = word7 & 0xFFFFu; // inactive lanes carry material 0 from the zero page (in bounds; unused)
+    uint32_t ab = A ? (uint32_t)A->bits[mi & (kAlphaTable - 1u)] : alpha_bits(p.ci, p.materials[mi].alpha_mode);
+    if constexpr (STREAM) {
+        const uint2 am = L.amask[rid];
+        const uint32_t ac = ((am.x >> ml) & 1u) | (((am.y >> ml) & 1u) << 1);
+        ab = p.ms.cls0 != nullptr ? ac : ab;
+    }
+    return ab;
 }
 
 struct MeshletVerdict {
@@ -235,7 +251,10 @@ __device__ __forceinline__ void rows_load(const MeshletCullParams &p, const Wave
             if (active && !in) latch_status(p.status, ORBIT_E_RANGE);
             t.a[k] = *(in ? p.ms.sphere + (rec.y + ml) : reinterpret_cast<const uint4 *>(p.zero_page));
             const uint32_t c = *(in ? p.ms.cone + (rec.y + ml) : reinterpret_cast<const uint32_t *>(p.zero_page));
-            const uint16_t m = *(in ? p.ms.mat + (rec.y + ml) : reinterpret_cast<const uint16_t *>(p.zero_page));
+            // with alpha classes the predicate bits come from the slab (setup_write_cls) and no material index is
+            // read: the load stays (straight-line code, the same kernel) but every lane aims it at the zero page
+            const uint16_t m = *((in && p.ms.cls0 == nullptr) ? p.ms.mat + (rec.y + ml)
+                                                              : reinterpret_cast<const uint16_t *>(p.zero_page));
             t.b[k] = make_uint4(c, 0u, 0u, (uint32_t)m);
         } else {
             const uint4 *src = active ? reinterpret_cast<const uint4 *>(p.meshlets + (rec.y + ml))
@@ -255,20 +274,16 @@ __device__ __forceinline__ void rows_load(const MeshletCullParams &p, const Wave
 // Evaluates rows R0 .. R0+NR-1 of a tile: should-draw ballots into the slab,
 // survivor payload (optional), pass-2 visibility words (WRITE_VIS).  `total` is
 // the tile's running survivor count; the new count is returned.
-template <int PASS, int PROJ, bool WRITE_VIS, int R0, int NR>
+template <int PASS, int PROJ, bool WRITE_VIS, int R0, int NR, bool STREAM = false>
 __device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
                                               const AlphaLds *A, int lane, const RowRegs<NR> &t, uint32_t total,
                                               Payload *payload) {
     const bool meshlet_occ = p.ci.meshlet_visibility_buffer != ORBIT_NONE;
     const bool rw_vis = PASS != 0 && meshlet_occ;
     const uint32_t half = lane >> 5, ml = lane & 31;
-    // Inactive lanes carry material 0 from the zero page (in bounds; result unused).
     uint32_t abits[NR];
 #pragma unroll
-    for (int k = 0; k < NR; k++) {
-        const uint32_t mi = t.b[k].w & 0xFFFFu;
-        abits[k] = A ? (uint32_t)A->bits[mi & (kAlphaTable - 1u)] : alpha_bits(p.ci, p.materials[mi].alpha_mode);
-    }
+    for (int k = 0; k < NR; k++) abits[k] = lane_alpha_bits<STREAM>(p, L, A, 2 * (R0 + k) + half, ml, t.b[k].w);
 #pragma unroll
     for (int k = 0; k < NR; k++) {
         const int r = R0 + k;
@@ -367,15 +382,14 @@ __device__ __forceinline__ void cand_flush(const MeshletCullParams &p, WaveTileL
 }
 
 // One row of a tile in pass 2 with meshlet occlusion: geometry tests, candidates into the ring.
-template <int PROJ, int R, uint32_t N>
+template <int PROJ, int R, uint32_t N, bool STREAM = false>
 __device__ __forceinline__ void row_eval_occ(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
                                              const AlphaLds *A, CandLds<N> &C, int lane, const RowRegs<1> &t,
                                              CandState &cs, Payload *payload) {
     const uint32_t half = lane >> 5, ml = lane & 31;
     const uint32_t rid = 2 * R + half;
     const uint4 rec = L.rec[rid];
-    const uint32_t mi = t.b[0].w & 0xFFFFu;
-    const uint32_t abits = A ? (uint32_t)A->bits[mi & (kAlphaTable - 1u)] : alpha_bits(p.ci, p.materials[mi].alpha_mode);
+    const uint32_t abits = lane_alpha_bits<STREAM>(p, L, A, rid, ml, t.b[0].w);
     const bool active = ml < rec.z;
     const bool visible_in_buffer = ((t.prev[0] >> ml) & 1u) != 0;
     Sphere s;
@@ -434,6 +448,53 @@ __device__ __forceinline__ float4 setup_load_mat(const MeshletCullParams &p, con
     return *src;
 }
 
+// Alpha classes of a record's lanes: the four lanes of the record load the two words of each bit plane that cover
+// meshlets [meshlet_offset, meshlet_offset + 32) (kernels.h MeshletStreamView).
+__device__ __forceinline__ uint32_t setup_load_cls(const MeshletCullParams &p, const uint4 &rec, int lane) {
+    const uint32_t col = lane & 3;
+    const uint32_t *plane = (col & 2u) ? p.ms.cls1 : p.ms.cls0;
+    // no classes (plane == nullptr), no record, a record outside the stream: the zero page
+    const uint32_t *src = (plane != nullptr && rec.z != 0u && p.ms.covers(rec.y)) ? plane + (rec.y >> 5) + (col & 1u)
+                                                                                  : reinterpret_cast<const uint32_t *>(p.zero_page);
+    return *src;
+}
+
+// -> the record's predicate masks in the slab: bit l of amask.x = (1 << alpha_mode) & alpha_mode_flag != 0 (:207) for
+// lane l, of amask.y the same for noskip_alphamode (:210).  Lanes of class 3 (a material outside the table the
+// classes were derived from, an alpha_mode the planes cannot hold) have their material looked up here, once per
+// tile and off the rows' path — rare.
+__device__ __forceinline__ void resolve_other_classes(const MeshletCullParams &p, const AlphaLds *A, const uint4 &rec,
+                                                   uint32_t other, uint32_t &b0, uint32_t &b1) {
+    while (other != 0u) {
+        const uint32_t l = (uint32_t)__builtin_ctz(other);
+        other &= other - 1u;
+        const uint32_t m = rec.y + l;
+        const uint32_t mi = p.ms.covers(m) ? (uint32_t)p.ms.mat[m] : 0u;
+        const uint32_t ab = A ? (uint32_t)A->bits[mi & (kAlphaTable - 1u)] : alpha_bits(p.ci, p.materials[mi].alpha_mode);
+        b0 |= (ab & 1u) << l;
+        b1 |= ((ab >> 1) & 1u) << l;
+    }
+}
+
+__device__ __forceinline__ void setup_write_cls(const MeshletCullParams &p, WaveTileLds &L, const AlphaLds *A,
+                                                const uint32_t *sel, const uint4 &rec, uint32_t cls_word, int lane) {
+    const uint32_t w0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cls_word, 0x00, 0xF, 0xF, false); // quad_perm broadcasts
+    const uint32_t w1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cls_word, 0x55, 0xF, 0xF, false);
+    const uint32_t w2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cls_word, 0xAA, 0xF, 0xF, false);
+    const uint32_t w3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cls_word, 0xFF, 0xF, 0xF, false);
+    const uint32_t sh = rec.y & 31u;
+    const uint32_t lo = __funnelshift_r(w0, w1, sh), hi = __funnelshift_r(w2, w3, sh);
+    const uint32_t c0 = ~(hi | lo), c1 = lo & ~hi, c2 = hi & ~lo;
+    // sel[2 c + k]: all ones if class c has predicate bit k (block-wide table: keeps the cull info's words out of the
+    // scalar registers the rows need)
+    uint32_t b0 = (c0 & sel[0]) | (c1 & sel[2]) | (c2 & sel[4]);
+    uint32_t b1 = (c0 & sel[1]) | (c1 & sel[3]) | (c2 & sel[5]);
+    // lanes past the record's count carry whatever class their bits say: they are never evaluated
+    const uint32_t other = (lane & 3) == 0 ? (hi & lo & (rec.z >= 32u ? 0xFFFFFFFFu : ((1u << rec.z) - 1u))) : 0u;
+    if (__ballot(other != 0u) != 0ull) resolve_other_classes(p, A, rec, other, b0, b1);
+    if ((lane & 3) == 0) L.amask[lane >> 2] = make_uint2(b0, b1);
+}
+
 __device__ __forceinline__ void setup_write(const MeshletCullParams &p, WaveTileLds &L, const uint4 &rec,
                                             const float4 &mc, int lane, uint32_t prev_word = 0u) {
     const uint32_t rid = lane >> 2, col = lane & 3;
@@ -490,6 +551,15 @@ struct ViewGroup {
     uint8_t idx[ORBIT_MAX_CULL_VIEWS];
 };
 
+// Triage switches (tools/: wave_tail.py, ab_inproc.py, phase.py) exist only in -DORBIT_TRIAGE builds of this file
+// (tools/mkvariant_any.sh); the product library's kernels take no debug input of any kind.
+#ifdef ORBIT_TRIAGE
+#define ORBIT_DBG(p, bits) (((p).debug_flags & (bits)) != 0u)
+#else
+#define ORBIT_DBG(p, bits) false
+#endif
+
+// STREAM: meshlets from the derived streams (predicate bits from their alpha classes when the view carries them)
 template <int PASS, int PROJ, bool PROF, bool STREAM = false>
 __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
     __shared__ WaveTileLds lds[kEvWaves][3];
@@ -499,7 +569,9 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // pass 2 with meshlet occlusion: HiZ tests run on compacted candidates (cand_flush), not per row
     const bool occ2 = PASS == 2 && p.ci.meshlet_visibility_buffer != ORBIT_NONE;
+    __shared__ uint32_t cls_sel[8]; // STREAM: [2 c + k] = all ones if alpha class c has predicate bit k (alpha_bits)
     planes_to_lds(p.ci, planes);
+    if (STREAM && threadIdx.x < 6) cls_sel[threadIdx.x] = ((alpha_bits(p.ci, threadIdx.x >> 1) >> (threadIdx.x & 1u)) & 1u) ? ~0u : 0u;
     const AlphaLds *alpha = alpha_table_fill(p, alpha_tab) ? &alpha_tab : nullptr;
     __syncthreads();
     const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
@@ -517,12 +589,12 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
     // before its rows are read (records -> matrices -> slab -> rows); a wave whose ticket is past the end drains its
     // pipeline and leaves.
     const uint32_t stride = gridDim.x * kEvWaves, wave_g = blockIdx.x * kEvWaves + wave;
-    const bool static_share = (p.debug_flags & 64u) != 0; // triage: everything static, for A/B runs
+    const bool static_share = ORBIT_DBG(p, 64u); // triage: everything static, for A/B runs
     const uint32_t full_rounds = ntiles / stride;
     // ticketed rounds: three on a long launch, fewer on a short one (a shard of the sharded engine has 2-3 rounds in all)
-    const uint32_t dyn_rounds = (p.debug_flags & 256u) ? 2u : (p.debug_flags & 512u) ? 4u : (p.debug_flags & 1024u) ? 1u : min(max(full_rounds / 4u, 1u), 3u);
+    const uint32_t dyn_rounds = ORBIT_DBG(p, 256u) ? 2u : ORBIT_DBG(p, 512u) ? 4u : ORBIT_DBG(p, 1024u) ? 1u : min(max(full_rounds / 4u, 1u), 3u);
     // a scene of at most one tile per wave has nothing to balance: static, no atomic in front of the first loads
-    const uint32_t n_static = (static_share || ntiles <= stride) ? 0xFFFFFFFFu : ((p.debug_flags & 128u) ? 0u : (full_rounds >= dyn_rounds ? full_rounds - dyn_rounds : 0u));
+    const uint32_t n_static = (static_share || ntiles <= stride) ? 0xFFFFFFFFu : (ORBIT_DBG(p, 128u) ? 0u : (full_rounds >= dyn_rounds ? full_rounds - dyn_rounds : 0u));
     const uint32_t npools = min((uint32_t)kTicketPools, stride);
     const uint32_t pool = wave_g % npools;
     uint32_t *ticket_ctr = p.tickets + pool * kTicketStride;
@@ -559,12 +631,18 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         rec2 = setup_load_rec(p, w2, w2 < ntiles, nrec, lane);
         const float4 m0 = setup_load_mat(p, r0, lane);
         const float4 m1 = setup_load_mat(p, r1, lane);
+        if constexpr (STREAM) {
+            const uint32_t c0 = setup_load_cls(p, r0, lane), c1 = setup_load_cls(p, r1, lane);
+            setup_write_cls(p, lds[wave][0], alpha, cls_sel, r0, c0, lane);
+            setup_write_cls(p, lds[wave][1], alpha, cls_sel, r1, c1, lane);
+        }
         setup_write(p, lds[wave][0], r0, m0, lane);
         setup_write(p, lds[wave][1], r1, m1, lane);
         rows_load<PASS, 0, 1, STREAM>(p, lds[wave][0], lane, qa);
         rows_load<PASS, 1, 1, STREAM>(p, lds[wave][0], lane, qb);
     }
     uint32_t it = 0;
+#ifdef ORBIT_TRIAGE
     unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1;
 #define EV_STAMP(k)                            \
     if (PROF && !(p.debug_flags & 16u)) {      \
@@ -574,11 +652,15 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         t0 = t1;                               \
     }
     unsigned long long wall_begin = 0;
-    if (p.debug_flags & 16u) wall_begin = wall_clock64(); // per-wave life stamps (tools/wave_tail.py), any build
+    if (p.debug_flags & 16u) wall_begin = wall_clock64(); // per-wave life stamps (tools/wave_tail.py)
     if (PROF) {
         t0 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_waitcnt(0xC07F);
     }
+#else
+#define EV_STAMP(k)
+    static_assert(!PROF, "phase stamps: -DORBIT_TRIAGE builds only");
+#endif
     // The SIMD's arbiter serves the oldest wave first, and the four waves of a SIMD belong to the four blocks a CU
     // holds, dispatched one after the other: left alone, the first block's waves finish at half the kernel's
     // duration and the rest of the kernel runs at 3, 2, 1 waves per SIMD (tools/wave_tail.py).  Every wave
@@ -586,7 +668,7 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
     // tiles each wave of a SIMD has held each priority once.
     const uint32_t prio_rank = blockIdx.x / max(gridDim.x / (uint32_t)kEvWavesPerSimd, 1u);
     while (w0 < ntiles) {
-        if (!(p.debug_flags & 32u)) {
+        if (!ORBIT_DBG(p, 32u)) {
             switch ((it + prio_rank) & 3u) {
             case 0: __builtin_amdgcn_s_setprio(0); break;
             case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -598,15 +680,15 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         tk_raw = claim();                                     // the tile after it
         WaveTileLds &L = lds[wave][it % 3];
         WaveTileLds &Ln = lds[wave][(it + 1) % 3]; // slab of an absent tile holds zero records
-        // no payload with the derived streams: the emit launch gathers the survivors' command words itself
+        // no payload with the derived streams: the emit launch derives the survivors' command words itself
         Payload *payload = (STREAM || p.task_records) ? nullptr : p.tile_payload + (size_t)w0 * kPayloadCap;
         CandState cs; // cs.total = the tile's running survivor count
-#define EV_ROW(R, Q)                                                                                        \
-    if constexpr (PASS == 2) {                                                                              \
-        if (occ2) row_eval_occ<PROJ, R>(p, L, planes, alpha, cand_ring[wave], lane, Q, cs, payload);        \
-        else cs.total = rows_eval<PASS, PROJ, true, R, 1>(p, L, planes, alpha, lane, Q, cs.total, payload); \
-    } else {                                                                                                \
-        cs.total = rows_eval<PASS, PROJ, true, R, 1>(p, L, planes, alpha, lane, Q, cs.total, payload);      \
+#define EV_ROW(R, Q)                                                                                                  \
+    if constexpr (PASS == 2) {                                                                                        \
+        if (occ2) row_eval_occ<PROJ, R, kCandRing, STREAM>(p, L, planes, alpha, cand_ring[wave], lane, Q, cs, payload);  \
+        else cs.total = rows_eval<PASS, PROJ, true, R, 1, STREAM>(p, L, planes, alpha, lane, Q, cs.total, payload);      \
+    } else {                                                                                                          \
+        cs.total = rows_eval<PASS, PROJ, true, R, 1, STREAM>(p, L, planes, alpha, lane, Q, cs.total, payload);           \
     }
         EV_ROW(0, qa)
         rows_load<PASS, 2, 1, STREAM>(p, L, lane, qa);
@@ -618,6 +700,8 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         EV_ROW(3, qb)
         rows_load<PASS, 5, 1, STREAM>(p, L, lane, qb);
         const float4 mat2 = setup_load_mat(p, rec2, lane);
+        uint32_t cls2 = 0u;
+        if constexpr (STREAM) cls2 = setup_load_cls(p, rec2, lane);
         const uint4 rec3 = setup_load_rec(p, w3, w3 < ntiles, nrec, lane);
         EV_STAMP(1)
         EV_ROW(4, qa)
@@ -634,6 +718,7 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
             if (occ2) tile_finish_occ(p, L, cand_ring[wave], lane, cs, payload);
         }
 #undef EV_ROW
+        if constexpr (STREAM) setup_write_cls(p, lds[wave][(it + 2) % 3], alpha, cls_sel, rec2, cls2, lane);
         setup_write(p, lds[wave][(it + 2) % 3], rec2, mat2, lane); // also fences the mask writes of this tile
         // the ballots are read back only by the task-record launch and, in the emit launch, for tiles with more
         // survivors than the payload holds: the common tile writes its count and nothing else
@@ -647,6 +732,8 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         rec2 = rec3;
         it++;
     }
+#undef EV_STAMP
+#ifdef ORBIT_TRIAGE
     if (PROF && lane == 0) {
         for (int k = 0; k < 5; k++) atomicAdd(p.debug_cycles + k, tc[k]);
         atomicAdd(p.debug_cycles + 7, 1ull);
@@ -658,6 +745,7 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
             p.debug_cycles[32 + 2 * wg + 1] = wall_clock64();
         }
     }
+#endif
 }
 
 template <int PASS, int PROJ, bool PROF, bool STREAM = false>
@@ -1452,9 +1540,19 @@ struct StreamBuildArrays {
     uint16_t *mat;
     uint32_t *cmd;
     uint16_t *cnt;
-    uint32_t *link;
+    uint32_t *link, *cls0, *cls1;
     uint64_t s_first, s_end; // the stream's range
+    const OrbitMaterialData *materials; // alpha classes come from here (nullptr: class 3 everywhere)
+    uint32_t material_count;
 };
+
+// alpha class of a meshlet (kernels.h MeshletStreamView): its material's alpha_mode where the two bit planes can hold
+// it, 3 = "look the material up" otherwise
+__device__ __forceinline__ uint32_t alpha_class(const StreamBuildArrays &A, uint32_t material_index) {
+    if (A.materials == nullptr || material_index >= A.material_count) return 3u;
+    const uint32_t mode = A.materials[material_index].alpha_mode;
+    return mode < 3u ? mode : 3u;
+}
 
 __global__ __launch_bounds__(256) void meshlet_stream_build_kernel(const OrbitMeshlet *meshlets, uint64_t first,
                                                                    uint64_t count, const StreamBuildArrays A) {
@@ -1464,7 +1562,7 @@ __global__ __launch_bounds__(256) void meshlet_stream_build_kernel(const OrbitMe
          base += (uint64_t)gridDim.x * 256u) {
         const uint64_t m = base + (uint64_t)lane;
         const bool in = m >= first && m < end;
-        uint32_t vtx = 0, data = 0, w7 = 0;
+        uint32_t vtx = 0, data = 0, cls = 3u;
         if (in) {
             const uint4 *src = reinterpret_cast<const uint4 *>(meshlets + m);
             const uint4 a = src[0], b = src[1];
@@ -1475,7 +1573,8 @@ __global__ __launch_bounds__(256) void meshlet_stream_build_kernel(const OrbitMe
             A.cmd[m * 3u + 1u] = b.z;
             A.cmd[m * 3u + 2u] = b.w;
             A.cnt[m] = (uint16_t)(b.w >> 16);
-            vtx = b.y, data = b.z, w7 = b.w;
+            vtx = b.y, data = b.z;
+            cls = alpha_class(A, b.w & 0xFFFFu);
         } else if (m == end && m < A.s_end) { // derived earlier (or never: then the bit is as arbitrary as the rest)
             vtx = A.cmd[m * 3u], data = A.cmd[m * 3u + 1u];
         }
@@ -1495,11 +1594,44 @@ __global__ __launch_bounds__(256) void meshlet_stream_build_kernel(const OrbitMe
                 bit = vtx == pv && data == pd + meshlet_data_words((p7 >> 16) & 0xFFu, p7 >> 24);
             }
         }
-        (void)w7;
-        const uint64_t mask = __ballot(bit);
+        // the class planes: meshlets outside the updated range keep their bits
+        bool p0 = (cls & 1u) != 0u, p1 = (cls & 2u) != 0u;
+        if (!in && in_stream) {
+            p0 = ((A.cls0[m >> 5] >> (m & 31u)) & 1u) != 0;
+            p1 = ((A.cls1[m >> 5] >> (m & 31u)) & 1u) != 0;
+        }
+        const uint64_t mask = __ballot(bit), m0 = __ballot(p0), m1 = __ballot(p1);
         // both words exist whenever any of their meshlets is in the stream (orbit_meshlet_stream_create)
-        if (lane == 0 && base + 32u > A.s_first && base < A.s_end) A.link[base >> 5] = (uint32_t)mask;
-        if (lane == 32 && base + 64u > A.s_first && base + 32u < A.s_end) A.link[(base >> 5) + 1u] = (uint32_t)(mask >> 32);
+        if (lane == 0 && base + 32u > A.s_first && base < A.s_end) {
+            A.link[base >> 5] = (uint32_t)mask;
+            A.cls0[base >> 5] = (uint32_t)m0;
+            A.cls1[base >> 5] = (uint32_t)m1;
+        }
+        if (lane == 32 && base + 64u > A.s_first && base + 32u < A.s_end) {
+            A.link[(base >> 5) + 1u] = (uint32_t)(mask >> 32);
+            A.cls0[(base >> 5) + 1u] = (uint32_t)(m0 >> 32);
+            A.cls1[(base >> 5) + 1u] = (uint32_t)(m1 >> 32);
+        }
+    }
+}
+
+// orbit_meshlet_stream_set_materials: the class planes of the whole stream from its material indices
+__global__ __launch_bounds__(256) void meshlet_stream_classes_kernel(const StreamBuildArrays A) {
+    const int lane = threadIdx.x & 63;
+    for (uint64_t base = (A.s_first & ~63ull) + ((uint64_t)blockIdx.x * 256u + (threadIdx.x & ~63u)); base < A.s_end;
+         base += (uint64_t)gridDim.x * 256u) {
+        const uint64_t m = base + (uint64_t)lane;
+        const bool in = m >= A.s_first && m < A.s_end;
+        const uint32_t cls = in ? alpha_class(A, (uint32_t)A.mat[m]) : 3u;
+        const uint64_t m0 = __ballot((cls & 1u) != 0u), m1 = __ballot((cls & 2u) != 0u);
+        if (lane == 0 && base + 32u > A.s_first) {
+            A.cls0[base >> 5] = (uint32_t)m0;
+            A.cls1[base >> 5] = (uint32_t)m1;
+        }
+        if (lane == 32 && base + 32u < A.s_end) {
+            A.cls0[(base >> 5) + 1u] = (uint32_t)(m0 >> 32);
+            A.cls1[(base >> 5) + 1u] = (uint32_t)(m1 >> 32);
+        }
     }
 }
 
@@ -1550,18 +1682,21 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t
             hipLaunchKernelGGL((meshlet_pass1_kernel<1>), grid, block, 0, s, p);
         else
             hipLaunchKernelGGL((meshlet_pass1_kernel<0>), grid, block, 0, s, p);
-    } else if (p.ms.sphere != nullptr) { // derived streams: 24 B per meshlet, no payload
+    } else if (p.ms.sphere != nullptr) { // derived streams: 22 B per meshlet (20.25 with alpha classes), no payload
         if (ortho)
             hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 1, false, true>), grid, block, 0, s, p);
         else
             hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 0, false, true>), grid, block, 0, s, p);
     } else if constexpr (PASS == 0) {
-        if (p.debug_flags & 8u) { // phase-stamped build (tools/phase.py); | 16: only the per-wave wall-clock stamps
+#ifdef ORBIT_TRIAGE
+        if (p.debug_flags & 8u) { // phase-stamped kernel (tools/phase.py); | 16: only the per-wave wall-clock stamps
             if (ortho)
                 hipLaunchKernelGGL((meshlet_eval_kernel<0, 1, true>), grid, block, 0, s, p);
             else
                 hipLaunchKernelGGL((meshlet_eval_kernel<0, 0, true>), grid, block, 0, s, p);
-        } else if (ortho) {
+        } else
+#endif
+        if (ortho) {
             hipLaunchKernelGGL((meshlet_eval_kernel<0, 1, false>), grid, block, 0, s, p);
         } else {
             hipLaunchKernelGGL((meshlet_eval_kernel<0, 0, false>), grid, block, 0, s, p);
@@ -1639,26 +1774,23 @@ hipError_t launch_meshlet_cull_views(const MeshletCullViews &all, uint32_t n, ui
         if (blocks > need) blocks = need;
         const dim3 grid(blocks, m), block(kEvWaves * 64);
         const bool ortho = proj == 1;
+#define ORBIT_EVAL_VIEWS(PASS)                                                                                        \
+    if (stream) {                                                                                                     \
+        if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<PASS, 1, true>), grid, block, 0, s, all, g);         \
+        else hipLaunchKernelGGL((meshlet_eval_views_kernel<PASS, 0, true>), grid, block, 0, s, all, g);               \
+    } else {                                                                                                          \
+        if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<PASS, 1, false>), grid, block, 0, s, all, g);        \
+        else hipLaunchKernelGGL((meshlet_eval_views_kernel<PASS, 0, false>), grid, block, 0, s, all, g);              \
+    }
         if (pass == 1) {
             if (ortho) hipLaunchKernelGGL((meshlet_pass1_views_kernel<1>), grid, block, 0, s, all, g);
             else hipLaunchKernelGGL((meshlet_pass1_views_kernel<0>), grid, block, 0, s, all, g);
         } else if (pass == 0) {
-            if (stream) {
-                if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<0, 1, true>), grid, block, 0, s, all, g);
-                else hipLaunchKernelGGL((meshlet_eval_views_kernel<0, 0, true>), grid, block, 0, s, all, g);
-            } else {
-                if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<0, 1, false>), grid, block, 0, s, all, g);
-                else hipLaunchKernelGGL((meshlet_eval_views_kernel<0, 0, false>), grid, block, 0, s, all, g);
-            }
+            ORBIT_EVAL_VIEWS(0)
         } else {
-            if (stream) {
-                if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<2, 1, true>), grid, block, 0, s, all, g);
-                else hipLaunchKernelGGL((meshlet_eval_views_kernel<2, 0, true>), grid, block, 0, s, all, g);
-            } else {
-                if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<2, 1, false>), grid, block, 0, s, all, g);
-                else hipLaunchKernelGGL((meshlet_eval_views_kernel<2, 0, false>), grid, block, 0, s, all, g);
-            }
+            ORBIT_EVAL_VIEWS(2)
         }
+#undef ORBIT_EVAL_VIEWS
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -1697,16 +1829,67 @@ hipError_t launch_scatter_list(const ScatterListParams &p, uint32_t num_cus, hip
     return hipGetLastError();
 }
 
+static StreamBuildArrays stream_build_arrays(const MeshletStreamView &ms, const OrbitMaterialData *materials,
+                                             uint32_t material_count) {
+    return StreamBuildArrays{const_cast<uint4 *>(ms.sphere),   const_cast<uint32_t *>(ms.cone),
+                             const_cast<uint16_t *>(ms.mat),   const_cast<uint32_t *>(ms.cmd),
+                             const_cast<uint16_t *>(ms.cnt),   const_cast<uint32_t *>(ms.link),
+                             const_cast<uint32_t *>(ms.cls0),  const_cast<uint32_t *>(ms.cls1),
+                             (uint64_t)ms.first,               (uint64_t)ms.first + ms.count,
+                             materials,                        material_count};
+}
+
 hipError_t launch_meshlet_stream_build(const OrbitMeshlet *meshlets, uint64_t first, uint64_t count,
-                                       const MeshletStreamView &ms, hipStream_t s) {
+                                       const MeshletStreamView &ms, const OrbitMaterialData *materials,
+                                       uint32_t material_count, hipStream_t s) {
     if (count == 0) return hipSuccess;
     const uint64_t need = (count + 64u + 255u) / 256u + 1u;
     const uint32_t blocks = (uint32_t)(need < 8192u ? need : 8192u);
-    const StreamBuildArrays A{const_cast<uint4 *>(ms.sphere),   const_cast<uint32_t *>(ms.cone),
-                              const_cast<uint16_t *>(ms.mat),   const_cast<uint32_t *>(ms.cmd),
-                              const_cast<uint16_t *>(ms.cnt),   const_cast<uint32_t *>(ms.link),
-                              (uint64_t)ms.first,               (uint64_t)ms.first + ms.count};
-    hipLaunchKernelGGL(meshlet_stream_build_kernel, dim3(blocks), dim3(256), 0, s, meshlets, first, count, A);
+    hipLaunchKernelGGL(meshlet_stream_build_kernel, dim3(blocks), dim3(256), 0, s, meshlets, first, count,
+                       stream_build_arrays(ms, materials, material_count));
+    return hipGetLastError();
+}
+
+// orbit_meshlet_stream_validate: thread = meshlet of the stream's range; the Meshlet as the arrays hold it against the
+// Meshlet in the buffer, the alpha class against the material's alpha_mode.
+__global__ __launch_bounds__(256) void meshlet_stream_validate_kernel(const OrbitMeshlet *meshlets, const StreamBuildArrays A,
+                                                                      int32_t *status) {
+    for (uint64_t m = A.s_first + (uint64_t)blockIdx.x * 256u + threadIdx.x; m < A.s_end; m += (uint64_t)gridDim.x * 256u) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(meshlets + m);
+        const uint4 a = src[0], b = src[1], sa = A.sphere[m];
+        bool same = a.x == sa.x && a.y == sa.y && a.z == sa.z && a.w == sa.w && b.x == A.cone[m] &&
+                    (b.w & 0xFFFFu) == (uint32_t)A.mat[m] && b.y == A.cmd[m * 3u] && b.z == A.cmd[m * 3u + 1u] &&
+                    b.w == A.cmd[m * 3u + 2u] && (b.w >> 16) == (uint32_t)A.cnt[m];
+        if (A.materials) {
+            const uint32_t cls = ((A.cls0[m >> 5] >> (m & 31u)) & 1u) | (((A.cls1[m >> 5] >> (m & 31u)) & 1u) << 1);
+            same = same && cls == alpha_class(A, b.w & 0xFFFFu);
+        }
+        if (m > A.s_first) { // the link bit against the two meshlets it relates
+            const uint4 pb = reinterpret_cast<const uint4 *>(meshlets + (m - 1u))[1];
+            const bool link = b.y == pb.y && b.z == pb.z + meshlet_data_words((pb.w >> 16) & 0xFFu, pb.w >> 24);
+            same = same && link == (((A.link[m >> 5] >> (m & 31u)) & 1u) != 0u);
+        }
+        if (!same) latch_status(status, ORBIT_E_STALE);
+    }
+}
+
+hipError_t launch_meshlet_stream_validate(const OrbitMeshlet *meshlets, const MeshletStreamView &ms,
+                                          const OrbitMaterialData *materials, uint32_t material_count, int32_t *status,
+                                          hipStream_t s) {
+    if (ms.count == 0) return hipSuccess;
+    const uint64_t need = ((uint64_t)ms.count + 255u) / 256u;
+    const uint32_t blocks = (uint32_t)(need < 8192u ? need : 8192u);
+    hipLaunchKernelGGL(meshlet_stream_validate_kernel, dim3(blocks), dim3(256), 0, s, meshlets,
+                       stream_build_arrays(ms, materials, material_count), status);
+    return hipGetLastError();
+}
+
+hipError_t launch_meshlet_stream_classes(const MeshletStreamView &ms, const OrbitMaterialData *materials,
+                                         uint32_t material_count, hipStream_t s) {
+    const uint64_t need = ((uint64_t)ms.count + 64u + 255u) / 256u + 1u;
+    const uint32_t blocks = (uint32_t)(need < 8192u ? need : 8192u);
+    hipLaunchKernelGGL(meshlet_stream_classes_kernel, dim3(blocks), dim3(256), 0, s,
+                       stream_build_arrays(ms, materials, material_count));
     return hipGetLastError();
 }
 

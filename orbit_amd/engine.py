@@ -66,9 +66,20 @@ class MeshletStream:
         _lib.check(self._lib.orbit_meshlet_stream_update(self._engine._ctx, self._h, _ptr(meshlet_buffer), first, count,
                                                          _stream(stream)), self._engine._ctx)
 
+    def set_materials(self, material_buffer, material_count, stream=None):
+        """orbit_meshlet_stream_set_materials: alpha classes from material_buffer[material_index].alpha_mode
+        (None forgets them).  Culls whose material buffer is this one then read no material index."""
+        _lib.check(self._lib.orbit_meshlet_stream_set_materials(self._engine._ctx, self._h, _ptr(material_buffer),
+                                                                int(material_count), _stream(stream)), self._engine._ctx)
+
+    def validate(self, meshlet_buffer, material_buffer=None, stream=None):
+        """orbit_meshlet_stream_validate: ORBIT_E_STALE is latched (Engine.status raises) if the stream differs."""
+        _lib.check(self._lib.orbit_meshlet_stream_validate(self._engine._ctx, self._h, _ptr(meshlet_buffer),
+                                                           _ptr(material_buffer), _stream(stream)), self._engine._ctx)
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            self._lib.orbit_meshlet_stream_destroy(self._h)
+            _lib.check(self._lib.orbit_meshlet_stream_destroy(self._h))
             self._h = C.c_void_p()
 
     def __del__(self):

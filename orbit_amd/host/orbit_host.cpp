@@ -227,23 +227,38 @@ Context::Context(int device, void *stream, const OrbitCaps *caps) : stream_(stre
 Context::~Context() {
     for (auto &kv : transients_) (void)hipFree(kv.second.ptr);
     orbit_ctx_bind_meshlet_stream(ctx_, nullptr);
+    if (meshlet_stream_) (void)orbit_ctx_bind_meshlet_stream(ctx_, nullptr);
     orbit_meshlet_stream_destroy(meshlet_stream_);
     orbit_ctx_destroy(ctx_);
 }
 void Context::sync_meshlet_stream(const GraphBufferHandle &meshlet_buffer, uint64_t first, uint64_t count,
                                   uint64_t capacity) {
     if (!meshlet_buffer.valid()) throw Panic("sync_meshlet_stream: no meshlet buffer");
-    if (meshlet_stream_ && capacity > meshlet_stream_capacity_) { // the asset buffer was re-created larger
+    if (first + count > capacity) throw Panic("sync_meshlet_stream: range beyond the buffer's capacity");
+    // A stream mirrors ONE buffer.  When the asset buffer was re-created (larger, or simply at another address) its
+    // contents moved with it: everything uploaded so far is re-derived from the new buffer, not only the new range —
+    // the library would otherwise (rightly) refuse to read the rest (ORBIT_E_RANGE).
+    const bool moved = meshlet_stream_ != nullptr && meshlet_stream_source_ != meshlet_buffer.ptr;
+    if (meshlet_stream_ && capacity > meshlet_stream_capacity_) {
         check(orbit_ctx_bind_meshlet_stream(ctx_, nullptr));
-        orbit_meshlet_stream_destroy(meshlet_stream_);
+        check(orbit_meshlet_stream_destroy(meshlet_stream_));
         meshlet_stream_ = nullptr;
     }
-    if (!meshlet_stream_) {
+    const bool fresh = meshlet_stream_ == nullptr;
+    if (fresh) {
         check(orbit_meshlet_stream_create(ctx_, 0, capacity, &meshlet_stream_));
         meshlet_stream_capacity_ = capacity;
     }
+    if ((fresh || moved) && meshlet_stream_populated_ > 0)
+        check(orbit_meshlet_stream_update(ctx_, meshlet_stream_, meshlet_buffer.ptr, 0, meshlet_stream_populated_, stream_));
     check(orbit_meshlet_stream_update(ctx_, meshlet_stream_, meshlet_buffer.ptr, first, count, stream_));
+    meshlet_stream_source_ = meshlet_buffer.ptr;
+    if (first + count > meshlet_stream_populated_) meshlet_stream_populated_ = first + count;
     check(orbit_ctx_bind_meshlet_stream(ctx_, meshlet_stream_));
+}
+void Context::sync_meshlet_stream_materials(const GraphBufferHandle &materials_buffer, uint32_t material_count) {
+    if (!meshlet_stream_) throw Panic("sync_meshlet_stream_materials: no meshlet stream yet");
+    check(orbit_meshlet_stream_set_materials(ctx_, meshlet_stream_, materials_buffer.ptr, material_count, stream_));
 }
 GraphBufferHandle Context::create_transient(const std::string &name, size_t size) {
     auto it = transients_.find(name);

@@ -103,8 +103,12 @@ class Context {
     // queue_write_buffer(&self.meshlet_buffer, ..) (assets/mod.rs:441-445) for the range it wrote.  The stream is
     // created on first use for `capacity` meshlets (the size of meshlet_buffer, MAX_MESHLET_COUNT, assets/mod.rs:202,272-276), re-derived for
     // [first, first + count) on this context's stream and bound; culls of passes 0 and 2 then read it.
+    // A buffer that moved (re-created larger: assets grow) has everything uploaded so far re-derived from its new
+    // address, not only the new range.
     void sync_meshlet_stream(const GraphBufferHandle &meshlet_buffer, uint64_t first, uint64_t count,
                              uint64_t capacity);
+    // what GpuAssets::add_material calls after its upload (assets/mod.rs:520-526): the stream's alpha classes
+    void sync_meshlet_stream_materials(const GraphBufferHandle &materials_buffer, uint32_t material_count);
     OrbitCtx *abi() const { return ctx_; }
     void *stream() const { return stream_; }
     void check(int32_t rc) const; // non-zero status -> Panic with orbit_last_error
@@ -113,6 +117,8 @@ class Context {
     OrbitCtx *ctx_ = nullptr;
     OrbitMeshletStream *meshlet_stream_ = nullptr;
     uint64_t meshlet_stream_capacity_ = 0;
+    uint64_t meshlet_stream_populated_ = 0;       // high-water mark of the meshlets uploaded so far
+    const void *meshlet_stream_source_ = nullptr; // the buffer they were derived from
     void *stream_ = nullptr;
     std::map<std::string, GraphBufferHandle> transients_;
 };

@@ -230,6 +230,15 @@ int32_t orbit_host_sync_meshlet_stream(void *hctx, void *meshlet_buffer, uint64_
     });
 }
 
+int32_t orbit_host_sync_meshlet_stream_materials(void *hctx, void *materials_buffer, uint32_t material_count) {
+    return guarded([&] {
+        graphics::GraphBufferHandle h;
+        h.ptr = materials_buffer;
+        h.size = (size_t)material_count * sizeof(OrbitMaterialData);
+        ((HostCtx *)hctx)->ctx->sync_meshlet_stream_materials(h, material_count);
+    });
+}
+
 int32_t orbit_host_create_meshlet_dispatch_command(void *hctx, const char *name, const OrbitHostAssets *assets,
                                                    const OrbitHostScene *scene, const OrbitHostCullInfo *ci,
                                                    OrbitGpuCullInfo *out_cull_info, OrbitHostBuffer *out_dispatch) {

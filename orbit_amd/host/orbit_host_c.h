@@ -102,6 +102,8 @@ void orbit_host_context_destroy(void *hctx);
 /* Context::sync_meshlet_stream: derived meshlet streams of meshlets [first, first + count) re-derived and bound */
 int32_t orbit_host_sync_meshlet_stream(void *hctx, void *meshlet_buffer, uint64_t first, uint64_t count,
                                        uint64_t capacity);
+/* Context::sync_meshlet_stream_materials: the stream's alpha classes from the materials buffer */
+int32_t orbit_host_sync_meshlet_stream_materials(void *hctx, void *materials_buffer, uint32_t material_count);
 int32_t orbit_host_create_meshlet_dispatch_command(void *hctx, const char *name, const OrbitHostAssets *assets,
                                                    const OrbitHostScene *scene, const OrbitHostCullInfo *ci,
                                                    OrbitGpuCullInfo *out_cull_info, OrbitHostBuffer *out_dispatch);

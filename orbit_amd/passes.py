@@ -106,6 +106,8 @@ def lib():
         h.orbit_host_context_destroy.argtypes = [C.c_void_p]
         h.orbit_host_sync_meshlet_stream.restype = C.c_int32
         h.orbit_host_sync_meshlet_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
+        h.orbit_host_sync_meshlet_stream_materials.restype = C.c_int32
+        h.orbit_host_sync_meshlet_stream_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         _host = h
     return _host
 
@@ -263,6 +265,10 @@ class Context:
         """Context::sync_meshlet_stream (orbit_host.hpp): the add_mesh-side hook of the derived meshlet streams."""
         cap = (meshlet_buffer.numel() * meshlet_buffer.element_size() // 32) if capacity is None else capacity
         _check(lib().orbit_host_sync_meshlet_stream(C.c_void_p(self._h), _dptr(meshlet_buffer), first, count, cap))
+
+    def sync_meshlet_stream_materials(self, materials_buffer, material_count):
+        """Context::sync_meshlet_stream_materials: the add_material-side hook (the stream's alpha classes)."""
+        _check(lib().orbit_host_sync_meshlet_stream_materials(C.c_void_p(self._h), _dptr(materials_buffer), material_count))
 
     def close(self):
         if self._h:

@@ -8,11 +8,23 @@ class StreamEngine(Engine):
     """Before every meshlet cull the stream of the call's meshlet buffer is (re)built and bound.  Rebuilt every time:
     the caching allocator hands the same address to different test scenes."""
 
-    def __init__(self, *a, **kw):
+    def __init__(self, *a, classes=False, **kw):
+        """classes: the stream also derives its alpha classes from the call's material buffer (orbit_meshlet_stream_
+        set_materials) — from the first two thirds of it, so that the remaining materials are looked up at cull time."""
         super().__init__(*a, **kw)
-        self._ms, self._ms_key = None, None
+        self._ms, self._ms_key, self._classes = None, None, classes
+
+    def _set_materials(self, material_buffer, stream):
+        if not self._classes or self._ms is None:
+            return
+        if material_buffer is None or isinstance(material_buffer, int):
+            self._ms.set_materials(None, 0, stream)
+        else:
+            n = material_buffer.numel() * material_buffer.element_size() // 80
+            self._ms.set_materials(material_buffer, max(1, n * 2 // 3), stream)
 
     def meshlet_cull(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, *a, **kw):
+        material_buffer = a[2] if len(a) > 2 else kw.get("material_buffer")
         if isinstance(meshlet_buffer, int):  # a shard under global indices: extent unknown here -> plain path
             self.bind_meshlet_stream(None)
         else:
@@ -25,8 +37,10 @@ class StreamEngine(Engine):
                 if self._ms is not None:
                     self._ms.close()
                 self._ms, self._ms_key = self.meshlet_stream(meshlet_buffer, 0, count, kw.get("stream")), key
+                self._set_materials(material_buffer, kw.get("stream"))
                 self.bind_meshlet_stream(self._ms)
             else:
+                self._set_materials(material_buffer, kw.get("stream"))  # before the update: it derives its range's classes
                 self._ms.update(meshlet_buffer, stream=kw.get("stream"))
                 self.bind_meshlet_stream(self._ms)
         before = self.meshlet_stream_culls()

@@ -19,15 +19,17 @@ def torch_mod():
     return torch
 
 
-# every test that takes `engine` runs twice: from the 32-B Meshlet buffer, and from the derived meshlet streams
-@pytest.fixture(scope="module", params=["meshlet_buffer", "meshlet_stream"])
+# every test that takes `engine` runs three times: from the 32-B Meshlet buffer, from the derived meshlet streams, and
+# from the streams with their alpha classes (no material index read; a third of the materials looked up at cull time)
+@pytest.fixture(scope="module", params=["meshlet_buffer", "meshlet_stream", "meshlet_stream_classes"])
 def engine(torch_mod, request):
     from orbit_amd.engine import Engine
     from stream_engine import StreamEngine
 
-    Engine = StreamEngine if request.param == "meshlet_stream" else Engine
-    e = Engine(0, max_entities=300_000, max_dispatches=2_000_000, max_draws=4_000_000, max_lights=12_000,
-               max_clusters=240 * 135 * 32)
+    kw = dict(max_entities=300_000, max_dispatches=2_000_000, max_draws=4_000_000, max_lights=12_000,
+              max_clusters=240 * 135 * 32)
+    e = Engine(0, **kw) if request.param == "meshlet_buffer" else StreamEngine(
+        0, classes=request.param == "meshlet_stream_classes", **kw)
     yield e
     e.close()
 

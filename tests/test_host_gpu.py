@@ -35,8 +35,17 @@ def test_frame_sequence_through_host_api(torch_mod, oracle, meshlet_stream):
     ctx = passes.Context(0)
     g = dict(draws=dev(torch, scene.entity_draw_buffer()), mesh=dev(torch, scene.mesh_infos),
              ent=dev(torch, scene.entities), mlt=dev(torch, scene.meshlets), mat=dev(torch, scene.materials))
-    if meshlet_stream:  # what GpuAssets::add_mesh does after uploading the meshlets (Context::sync_meshlet_stream)
-        ctx.sync_meshlet_stream(g["mlt"], 0, len(scene.meshlets))
+    if meshlet_stream:
+        # what GpuAssets::add_mesh does after uploading meshlets (Context::sync_meshlet_stream) — mesh by mesh into a
+        # buffer that is then re-created larger at another address (everything uploaded so far must follow
+        # the move, not only the newest range) — and what add_material does (the alpha classes)
+        n = len(scene.meshlets)
+        small = dev(torch, scene.meshlets[:n // 2])
+        ctx.sync_meshlet_stream(small, 0, n // 4, capacity=n // 2)
+        ctx.sync_meshlet_stream(small, n // 4, n // 2 - n // 4, capacity=n // 2)
+        ctx.sync_meshlet_stream(g["mlt"], n // 2, n - n // 2)  # the grown buffer: [0, n/2) re-derived from it too
+        ctx.sync_meshlet_stream_materials(g["mat"], len(scene.materials))
+        del small
     rng = np.random.default_rng(3)
     evis0 = rng.integers(0, 2 ** 32, (scene.entity_draw_count + 31) // 32, dtype=np.uint32)
     mvis0 = rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32)

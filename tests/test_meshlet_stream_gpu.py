@@ -365,3 +365,120 @@ def test_partial_updates_keep_the_links_around_them(torch_mod, engine, oracle):
     assert_same(run_gpu(torch, engine, gs, ci), run_oracle(oracle, scene, ci))
     engine.bind_meshlet_stream(None)
     ms.close()
+
+
+# ----------------------------------------------------------------------------- alpha classes, validation, lifetime
+def test_alpha_classes_follow_the_materials_and_fall_back(torch_mod, engine, oracle):
+    """set_materials: classes 0..2 are the material's alpha_mode; a material outside the table the classes were derived
+    from and an alpha_mode the two bit planes cannot hold (>= 3: `1 << mode` still decides, meshlet_cull.comp:207)
+    are looked up at cull time.  Same bits as the oracle in all cases, for both alpha filters of the renderer."""
+    torch = torch_mod
+    scene = sc.make_scene(47, 800, n_meshes=120, meshlets_per_mesh=(1, 90), lods=2)
+    scene.materials["alpha_mode"][3::5] = 3   # bit 3 of a flag word
+    scene.materials["alpha_mode"][4::7] = 40  # 1 << 40 is 0 in GLSL's 32-bit shift as the kernels define it (shl1)
+    cam = sc.default_camera(rot=(0.1, 0.3))
+    gs = GpuScene(torch, scene)
+    ms = engine.meshlet_stream(gs.meshlets, 0, len(scene.meshlets))
+    engine.bind_meshlet_stream(ms)
+    n_mat = len(scene.materials)
+    for flags, noskip in ((L.ALPHA_OPAQUE | L.ALPHA_MASKED, 0), (0xF, 0), (L.ALPHA_OPAQUE, L.ALPHA_MASKED | 8)):
+        ci = sc.make_cull_info(cam.view, cam.planes, alpha_mode_flag=flags, noskip_alphamode=noskip)
+        ref = run_oracle(oracle, scene, ci)
+        for count in (n_mat, n_mat // 2, 1):
+            ms.set_materials(gs.materials, count)
+            for mc in (0, n_mat):  # alpha modes gathered / staged in LDS for the looked-up lanes
+                assert_same(run_gpu(torch, engine, gs, ci, material_count=mc), ref)
+    # another material buffer (a copy): the classes are not its mirror -> material indices again, same result
+    other = dev(torch, scene.materials)
+    before = engine.meshlet_stream_culls()
+    disp_cap, draw_cap = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
+    disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device="cuda")
+    draw = torch.zeros(L.DRAW_HEADER + 28 * draw_cap, dtype=torch.uint8, device="cuda")
+    engine.entity_cull(ci, gs.draws, gs.mesh_infos, disp, gs.entities, scene.entity_draw_count, disp_cap)
+    engine.meshlet_cull(ci, disp, gs.meshlets, draw, gs.entities, other, disp_cap, draw_cap)
+    torch.cuda.synchronize()
+    assert engine.meshlet_stream_culls() == before + 1
+    n = L.draw_buffer_commands(ref[1])[0]
+    assert np.array_equal(host(draw)[:4 + 28 * n], ref[1][:4 + 28 * n])
+    ms.set_materials(None, 0)
+    assert_same(run_gpu(torch, engine, gs, ci), ref)
+    engine.bind_meshlet_stream(None)
+    ms.close()
+
+
+def test_validate_finds_a_missing_update(torch_mod, oracle):
+    """caps.validate_streams: every cull served from the stream first compares it with the meshlet buffer;
+    orbit_meshlet_stream_validate does the same on request.  A rewritten meshlet without an update -> ORBIT_E_STALE."""
+    from orbit_amd.engine import Engine
+
+    torch = torch_mod
+    scene, ci = _scene(seed=53, n=300)
+    gs = GpuScene(torch, scene)
+    eng = Engine(0, max_entities=50_000, max_dispatches=400_000, max_draws=1_000_000, validate_streams=1)
+    ms = eng.meshlet_stream(gs.meshlets, 0, len(scene.meshlets))
+    ms.set_materials(gs.materials, len(scene.materials))
+    eng.bind_meshlet_stream(ms)
+    assert_same(run_gpu(torch, eng, gs, ci), run_oracle(oracle, scene, ci))
+    eng.status()  # in step
+    for field, delta in (("data_offset", 1), ("bounding_sphere", np.float32(0.5)), ("triangle_count", 1)):
+        k = len(scene.meshlets) // 2
+        scene.meshlets[field][k] += delta
+        gs.meshlets.copy_(dev(torch, scene.meshlets))
+        run_gpu(torch, eng, gs, ci)
+        with pytest.raises(_lib.OrbitError) as err:
+            eng.status()
+        assert err.value.code == _lib.E_STALE
+        ms.update(gs.meshlets, k, 1)
+        assert_same(run_gpu(torch, eng, gs, ci), run_oracle(oracle, scene, ci))
+        eng.status()
+    # a material whose alpha_mode changed without set_materials
+    scene.materials["alpha_mode"][0] ^= 1
+    gs.materials.copy_(dev(torch, scene.materials))
+    ms.validate(gs.meshlets, gs.materials)
+    with pytest.raises(_lib.OrbitError) as err:
+        eng.status()
+    assert err.value.code == _lib.E_STALE
+    ms.set_materials(gs.materials, len(scene.materials))
+    ms.validate(gs.meshlets, gs.materials)
+    eng.status()
+    eng.bind_meshlet_stream(None)
+    ms.close()
+    eng.close()
+
+
+def test_a_bound_stream_cannot_be_destroyed(torch_mod, engine):
+    torch = torch_mod
+    scene, _ = _scene(seed=59, n=40)
+    gs = GpuScene(torch, scene)
+    ms = engine.meshlet_stream(gs.meshlets, 0, len(scene.meshlets))
+    engine.bind_meshlet_stream(ms)
+    with pytest.raises(_lib.OrbitError) as err:
+        ms.close()
+    assert err.value.code == _lib.E_INVALID
+    engine.bind_meshlet_stream(None)
+    ms.close()
+
+
+def test_a_new_source_buffer_starts_the_readable_range_over(torch_mod, engine, oracle):
+    """after an update from ANOTHER buffer pointer only the range derived from that pointer may be read —
+    a cull that dispatches meshlets outside it latches ORBIT_E_RANGE instead of answering from the old buffer's copy;
+    meshlets inside the hull of two updates that neither reached are empty (zero) meshlets, not stale ones."""
+    torch = torch_mod
+    scene, ci = _scene(seed=61, n=300)
+    gs = GpuScene(torch, scene)
+    n = len(scene.meshlets)
+    ms = engine.meshlet_stream(gs.meshlets, 0, n)
+    engine.bind_meshlet_stream(ms)
+    ref = run_oracle(oracle, scene, ci)
+    assert_same(run_gpu(torch, engine, gs, ci), ref)
+    other = GpuScene(torch, scene)  # the same meshlets at another address
+    ms.update(other.meshlets, 0, n // 4)  # only a quarter re-derived from the new pointer
+    run_gpu(torch, engine, other, ci)
+    with pytest.raises(_lib.OrbitError) as err:
+        engine.status()
+    assert err.value.code == _lib.E_RANGE
+    ms.update(other.meshlets, n // 4, n - n // 4)
+    assert_same(run_gpu(torch, engine, other, ci), ref)
+    engine.status()
+    engine.bind_meshlet_stream(None)
+    ms.close()
