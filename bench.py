@@ -362,6 +362,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if mstream is not None and not args.no_alpha_classes:
+        assert all(s.eng.meshlet_class_culls() >= args.steps // F for s in slots), "the alpha classes were not used"
     eval_sum, eval_launches = 0.0, 0
     for s in slots:
         s.eng.status()

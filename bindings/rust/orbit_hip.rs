@@ -138,6 +138,7 @@ extern "C" {
     pub fn orbit_meshlet_stream_destroy(ms: *mut OrbitMeshletStream) -> i32;
     pub fn orbit_ctx_bind_meshlet_stream(ctx: *mut OrbitCtx, ms: *mut OrbitMeshletStream) -> i32;
     pub fn orbit_ctx_meshlet_stream_culls(ctx: *const OrbitCtx) -> u64;
+    pub fn orbit_ctx_meshlet_class_culls(ctx: *const OrbitCtx) -> u64;
     // exchange without a host round trip: IPC-mapped peer buffers + a device-side rank-ordered scatter
     pub fn orbit_p2p_alloc(ctx: *mut OrbitCtx, bytes: u64, out_ptr: *mut *mut c_void, out_handle: *mut [u8; 64]) -> i32;
     pub fn orbit_p2p_free(ctx: *mut OrbitCtx, ptr: *mut c_void) -> i32;

@@ -544,7 +544,9 @@ int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t cou
 /*            time as before) and remembers the pointer: later updates       */
 /*            derive the classes of their range from it, and culls whose     */
 /*            bufs->material_buffer is that pointer read the classes instead */
-/*            of the material indices.  Call it wherever the renderer writes */
+/*            of the material indices — provided NO meshlet of the stream    */
+/*            needs the look-up; a stream that holds one keeps evaluating    */
+/*            through the indices.  Call it wherever the renderer writes     */
 /*            materials (add_material, assets/mod.rs:520); NULL forgets.     */
 /*   validate compares the stream with `meshlet_buffer` (and the classes     */
 /*            with `material_buffer`, may be NULL) over the readable range   */
@@ -572,6 +574,10 @@ int32_t orbit_ctx_bind_meshlet_stream(OrbitCtx *ctx, OrbitMeshletStream *ms);
  * orbit_cull_views counts) and orbit_expand_visible (tests and integration checks: a call whose meshlet_buffer is not the stream's source
  * silently takes the plain path). */
 uint64_t orbit_ctx_meshlet_stream_culls(const OrbitCtx *ctx);
+/* ... of which evaluated from the alpha classes (no material index read): culls whose material buffer the classes
+ * mirror, of a stream known to hold no meshlet of class 3 — "known" once the launch that derived the classes has
+ * finished (the library polls, never waits: culls enqueued before that read the material indices). */
+uint64_t orbit_ctx_meshlet_class_culls(const OrbitCtx *ctx);
 
 /* ------------------------------------------------------------------------ */
 /* depth_reduce — replaces DepthPyramid::{new,resize,update}                 */

@@ -38,6 +38,14 @@ struct OrbitMeshletStream {
     uint64_t valid_lo = 0, valid_hi = 0;   // hull of the ranges derived from `source`: what a cull may read
     const void *materials = nullptr;       // orbit_meshlet_stream_set_materials: what the alpha classes mirror
     uint32_t material_count = 0;
+    // "Some meshlet has class 3" (a material beyond the table, an alpha_mode > 2): written on the device by the launches
+    // that derive classes, copied to pinned host memory behind them.  A cull reads the classes only once that copy has
+    // landed and says no (hipEventQuery, never a wait); until then, and for streams with such meshlets, the
+    // evaluation goes through the material indices, which is always right.
+    uint32_t *d_other = nullptr, *h_other = nullptr;
+    hipEvent_t other_event = nullptr;
+    bool other_pending = false;  // a derivation is under way (or its outcome unknowable): do not trust the classes
+    bool other_recorded = false; // other_event was recorded for the pending derivation (on a stream that really runs)
     std::atomic<int> bindings{0};          // contexts it is bound to (orbit_meshlet_stream_destroy refuses while > 0)
 };
 
@@ -75,6 +83,7 @@ struct OrbitCtx {
     std::vector<OrbitCtx *> view_ctx;
     OrbitMeshletStream *meshlet_stream = nullptr; // orbit_ctx_bind_meshlet_stream
     uint64_t stream_culls = 0;                          // meshlet culls launched from it
+    uint64_t class_culls = 0;                           // ... of which with its alpha classes
     char err[512] = {0};
 };
 
@@ -158,8 +167,27 @@ MeshletStreamView stream_view_for(OrbitMeshletStream *ms, const void *meshlet_bu
     std::lock_guard<std::mutex> lock(ms->mu);
     if (ms->source == nullptr || ms->source != meshlet_buffer || ms->valid_hi == ms->valid_lo) return MeshletStreamView{};
     MeshletStreamView v = stream_arrays(ms, ms->valid_lo, ms->valid_hi);
-    if (ms->materials == nullptr || ms->materials != material_buffer) v.cls0 = v.cls1 = nullptr;
+    bool classes = ms->materials != nullptr && ms->materials == material_buffer;
+    // (no query while the flag's read-back was only captured into a graph, not run: other_recorded is false then)
+    if (classes && ms->other_pending && ms->other_recorded && hipEventQuery(ms->other_event) == hipSuccess)
+        ms->other_pending = false;
+    if (classes && (ms->other_pending || *ms->h_other != 0u)) classes = false;
+    if (!classes) v.cls0 = v.cls1 = nullptr;
     return v;
+}
+
+// Enqueues the read-back of the stream's class flag behind the launch that may have set it.  On a stream that is being
+// captured into a graph nothing runs now and an event query would invalidate the capture: the outcome stays unknown
+// (the culls keep reading material indices) until a derivation runs on a live stream.
+hipError_t read_back_class_flag(OrbitMeshletStream *ms, hipStream_t s) {
+    ms->other_pending = true;
+    ms->other_recorded = false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return hipSuccess;
+    hipError_t e = hipMemcpyAsync(ms->h_other, ms->d_other, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipEventRecord(ms->other_event, s);
+    if (e == hipSuccess) ms->other_recorded = true;
+    return e;
 }
 
 PyramidView make_pyramid_view(const float *texels, const uint32_t size[2],
@@ -565,7 +593,10 @@ int32_t meshlet_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbit
     }
     hipError_t e = launch_meshlet_cull(p, ctx->num_cus, (hipStream_t)stream, ev0, ev1);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_cull");
-    if (p.ms.sphere && ci->occlusion_pass != 1) ctx->stream_culls++;
+    if (p.ms.sphere && ci->occlusion_pass != 1) {
+        ctx->stream_culls++;
+        if (p.ms.cls0) ctx->class_culls++;
+    }
     return ORBIT_OK;
 }
 
@@ -617,7 +648,10 @@ int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t cou
     if (e == hipSuccess) e = launch_meshlet_cull_views(mv, n_mesh, ctx->num_cus, s);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch cull_views");
     for (uint32_t i = 0; i < n_mesh; i++)
-        if (mv.v[i].ms.sphere && mv.v[i].ci.occlusion_pass != 1) ctx->stream_culls++;
+        if (mv.v[i].ms.sphere && mv.v[i].ci.occlusion_pass != 1) {
+            ctx->stream_culls++;
+            if (mv.v[i].ms.cls0) ctx->class_culls++;
+        }
     return ORBIT_OK;
 }
 
@@ -659,6 +693,11 @@ int32_t orbit_meshlet_stream_create(OrbitCtx *ctx, uint64_t first_meshlet, uint6
         if (e == hipSuccess) e = hipMalloc(a.p, a.bytes);
         if (e == hipSuccess) e = hipMemset(*a.p, a.fill, a.bytes);
     }
+    if (e == hipSuccess) e = hipMalloc((void **)&ms->d_other, 256);
+    if (e == hipSuccess) e = hipMemset(ms->d_other, 0, 256);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ms->h_other, sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) *ms->h_other = 0u;
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ms->other_event, hipEventDisableTiming);
     if (e != hipSuccess) {
         orbit_meshlet_stream_destroy(ms);
         return hip_fail(ctx, e, "meshlet_stream_create: hipMalloc (36.4 B per meshlet)");
@@ -687,10 +726,14 @@ int32_t orbit_meshlet_stream_update(OrbitCtx *ctx, OrbitMeshletStream *ms, const
     MeshletStreamView v = stream_arrays(ms, same ? ms->valid_lo : first, same ? ms->valid_hi : first + count);
     if (v.first > first) v.count += v.first - (uint32_t)first, v.first = (uint32_t)first;
     if ((uint64_t)v.first + v.count < first + count) v.count = (uint32_t)(first + count - v.first);
-    const hipError_t e = launch_meshlet_stream_build((const OrbitMeshlet *)meshlet_buffer, first, count, v,
-                                                     (const OrbitMaterialData *)ms->materials, ms->material_count,
-                                                     (hipStream_t)stream);
+    hipError_t e = launch_meshlet_stream_build((const OrbitMeshlet *)meshlet_buffer, first, count, v,
+                                               (const OrbitMaterialData *)ms->materials, ms->material_count, ms->d_other,
+                                               (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_stream_build");
+    if (ms->materials != nullptr && count != 0) { // the range's classes were derived: did a class 3 appear?
+        e = read_back_class_flag(ms, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(ctx, e, "meshlet_stream_update: class flag read-back");
+    }
     if (count != 0) { // the stream mirrors the buffer only once the launch is enqueued
         ms->source = meshlet_buffer;
         ms->valid_lo = lo;
@@ -710,9 +753,14 @@ int32_t orbit_meshlet_stream_set_materials(OrbitCtx *ctx, OrbitMeshletStream *ms
         return fail(ctx, ORBIT_E_INVALID, "meshlet_stream_set_materials: material_count is 0");
     std::lock_guard<std::mutex> slock(ms->mu);
     // every meshlet the arrays hold, derived or not (the indices of never-derived ones are zero)
-    const hipError_t e = launch_meshlet_stream_classes(stream_arrays(ms, ms->first, ms->first + ms->capacity),
-                                                       (const OrbitMaterialData *)material_buffer,
-                                                       material_buffer ? material_count : 0u, (hipStream_t)stream);
+    ms->other_pending = true; // no cull trusts the classes until the flag of THIS derivation has come back
+    ms->other_recorded = false;
+    hipError_t e = hipMemsetAsync(ms->d_other, 0, sizeof(uint32_t), (hipStream_t)stream);
+    if (e == hipSuccess)
+        e = launch_meshlet_stream_classes(stream_arrays(ms, ms->first, ms->first + ms->capacity),
+                                          (const OrbitMaterialData *)material_buffer, material_buffer ? material_count : 0u,
+                                          ms->d_other, (hipStream_t)stream);
+    if (e == hipSuccess) e = read_back_class_flag(ms, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_stream_classes");
     ms->materials = material_buffer;
     ms->material_count = material_buffer ? material_count : 0u;
@@ -726,11 +774,17 @@ int32_t orbit_meshlet_stream_validate(OrbitCtx *ctx, OrbitMeshletStream *ms, con
     if (!ms || !meshlet_buffer) return fail(ctx, ORBIT_E_MISSING, "meshlet_stream_validate: NULL argument");
     if (ms->device != ctx->device)
         return fail(ctx, ORBIT_E_INVALID, "meshlet_stream_validate: stream lives on device %d", ms->device);
-    const MeshletStreamView v = stream_view_for(ms, meshlet_buffer, material_buffer);
+    MeshletStreamView v = stream_view_for(ms, meshlet_buffer, nullptr);
     if (!v.sphere) return ORBIT_OK; // mirrors another buffer (or nothing): no cull of this one reads it
+    // the classes are checked against the buffer they were derived from, whether or not a cull would read them yet
+    const bool classes = material_buffer != nullptr && ms->materials == material_buffer;
+    if (classes) {
+        const MeshletStreamView all = stream_arrays(ms, ms->first, ms->first + ms->capacity);
+        v.cls0 = all.cls0, v.cls1 = all.cls1;
+    }
     const hipError_t e = launch_meshlet_stream_validate((const OrbitMeshlet *)meshlet_buffer, v,
-                                                        (const OrbitMaterialData *)material_buffer, ms->material_count,
-                                                        ctx->status, (hipStream_t)stream);
+                                                        classes ? (const OrbitMaterialData *)material_buffer : nullptr,
+                                                        ms->material_count, ctx->status, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_stream_validate");
     return ORBIT_OK;
 }
@@ -748,6 +802,9 @@ int32_t orbit_meshlet_stream_destroy(OrbitMeshletStream *ms) {
     (void)hipFree(ms->link);
     (void)hipFree(ms->cls0);
     (void)hipFree(ms->cls1);
+    (void)hipFree(ms->d_other);
+    if (ms->h_other) (void)hipHostFree(ms->h_other);
+    if (ms->other_event) (void)hipEventDestroy(ms->other_event);
     delete ms;
     return ORBIT_OK;
 }
@@ -764,6 +821,7 @@ int32_t orbit_ctx_bind_meshlet_stream(OrbitCtx *ctx, OrbitMeshletStream *ms) {
 }
 
 uint64_t orbit_ctx_meshlet_stream_culls(const OrbitCtx *ctx) { return ctx ? ctx->stream_culls : 0; }
+uint64_t orbit_ctx_meshlet_class_culls(const OrbitCtx *ctx) { return ctx ? ctx->class_culls : 0; }
 
 int32_t orbit_meshlet_task_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
                                 OrbitMeshTaskRecord *task_records, void *stream) {

@@ -59,8 +59,9 @@ struct MeshletStreamView {
     const uint32_t *link; // bit (i & 31) of word (i >> 5): meshlet i continues meshlet i - 1's chain
     // Alpha classes (orbit_meshlet_stream_set_materials): the alpha_mode of the meshlet's material as two bit planes
     // (class = bit of cls0 | bit of cls1 << 1, addressed like `link`); 0..2 = that alpha_mode, 3 = look the material
-    // up.  Non-null only for a cull whose material buffer is the one the classes were derived from: the evaluation
-    // then reads 20.25 B per meshlet instead of 22.
+    // up.  Non-null only for a cull whose material buffer is the one the classes were derived from AND whose stream
+    // is known to hold no meshlet of class 3: the evaluation then reads 20.25 B per meshlet instead of 22 and never
+    // touches a material.
     const uint32_t *cls0, *cls1;
     uint32_t first, count; // global meshlet indices the arrays cover: [first, first + count)
     __host__ __device__ bool covers(uint32_t meshlet) const { return meshlet - first < count; }
@@ -190,7 +191,7 @@ uint32_t max_dispatch_capacity();
 // the buffer the range's alpha classes are derived from (none: class 3, "look the material up").
 hipError_t launch_meshlet_stream_build(const OrbitMeshlet *meshlets, uint64_t first, uint64_t count,
                                        const MeshletStreamView &ms, const OrbitMaterialData *materials,
-                                       uint32_t material_count, hipStream_t s);
+                                       uint32_t material_count, uint32_t *other, hipStream_t s);
 // ORBIT_E_STALE into *status if a meshlet of the stream's range differs from its derived copy (or, with `materials`,
 // an alpha class from its material's alpha_mode): orbit_meshlet_stream_validate
 hipError_t launch_meshlet_stream_validate(const OrbitMeshlet *meshlets, const MeshletStreamView &ms,
@@ -198,7 +199,7 @@ hipError_t launch_meshlet_stream_validate(const OrbitMeshlet *meshlets, const Me
                                           hipStream_t s);
 // the alpha classes of the whole stream, from its material indices (orbit_meshlet_stream_set_materials)
 hipError_t launch_meshlet_stream_classes(const MeshletStreamView &ms, const OrbitMaterialData *materials,
-                                         uint32_t material_count, hipStream_t s);
+                                         uint32_t material_count, uint32_t *other, hipStream_t s);
 // ms.cmd (optional): the derived command-word stream of `meshlets`, based at global meshlet index 0
 hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, const MeshletStreamView &ms,
                                  uint8_t *draw_buffer, uint32_t draw_capacity, uint32_t num_cus, const void *zero_page,

@@ -52,7 +52,7 @@ struct __attribute__((aligned(16))) WaveTileLds {
     uint64_t draw_mask[kTileRows]; // should-draw ballots of the tile's rows (kept here, not in SGPRs)
     uint64_t vis_mask[kTileRows];  // pass 2 with meshlet occlusion: visible ballots, assembled by the candidate flushes
     uint32_t prev[kTileRecords];   // pass 1: last frame's visibility word of each record
-    uint2 amask[kTileRecords];     // alpha classes: per record {(:207) bits, (:210) bits} of its 32 lanes
+    uint2 amask[kTileRecords];     // CLS: per record {(:207) bits, (:210) bits} of its 32 lanes, from their alpha classes
 };
 
 // The cull planes live in LDS (one copy per block, written once): a row reads
@@ -128,19 +128,18 @@ __device__ __forceinline__ bool alpha_table_fill(const MeshletCullParams &p, Alp
     return use;
 }
 
-// The two predicate bits of lane `ml` of record `rid`: from the material table / gather, or — STREAM with alpha classes
-// (a wave-uniform choice) — from the record's masks in the slab (setup_write_cls).
-template <bool STREAM>
+// The two predicate bits of lane `ml` of record `rid`: from the material table / gather, or — CLS — from the record's
+// masks in the slab (setup_write_cls).
+template <bool CLS>
 __device__ __forceinline__ uint32_t lane_alpha_bits(const MeshletCullParams &p, const WaveTileLds &L, const AlphaLds *A,
                                                     uint32_t rid, uint32_t ml, uint32_t word7) {
-    const uint32_t mi = word7 & 0xFFFFu; // inactive lanes carry material 0 from the zero page (in bounds; unused)
-    uint32_t ab = A ? (uint32_t)A->bits[mi & (kAlphaTable - 1u)] : alpha_bits(p.ci, p.materials[mi].alpha_mode);
-    if constexpr (STREAM) {
+    if constexpr (CLS) {
         const uint2 am = L.amask[rid];
-        const uint32_t ac = ((am.x >> ml) & 1u) | (((am.y >> ml) & 1u) << 1);
-        ab = p.ms.cls0 != nullptr ? ac : ab;
+        return ((am.x >> ml) & 1u) | (((am.y >> ml) & 1u) << 1);
+    } else {
+        const uint32_t mi = word7 & 0xFFFFu; // inactive lanes carry material 0 from the zero page (in bounds; unused)
+        return A ? (uint32_t)A->bits[mi & (kAlphaTable - 1u)] : alpha_bits(p.ci, p.materials[mi].alpha_mode);
     }
-    return ab;
 }
 
 struct MeshletVerdict {
@@ -181,6 +180,9 @@ __device__ __forceinline__ bool eval_geometry(const MeshletCullParams &p, const 
     s.r = __uint_as_float(a.w) * L.scale[rid];
 
     bool visible = true;
+    // keeps the scheduler from hoisting the cone test's and the plane loop's LDS reads above the sphere transform:
+    // without it the class variant of the evaluation holds 128 registers and spills (profiles/r03_notes.md)
+    __builtin_amdgcn_sched_barrier(0);
     if (PASS == 1) visible = visible_in_buffer;   // :137
     // The cone test (:148-158) does not depend on the plane loop: both are evaluated
     // and combined, which gives the scheduler two independent chains per meshlet.
@@ -234,7 +236,7 @@ __device__ __forceinline__ MeshletVerdict eval_meshlet(const MeshletCullParams &
 
 // Issues the meshlet loads of rows R0 .. R0+NR-1 of a tile (2 x 16 B per lane per row; STREAM: 16 + 4 + 2 B from the
 // derived streams — words y/z of `b` and the counts in w, which only a command needs, stay zero).
-template <int PASS, int R0, int NR, bool STREAM = false>
+template <int PASS, int R0, int NR, bool STREAM = false, bool CLS = false>
 __device__ __forceinline__ void rows_load(const MeshletCullParams &p, const WaveTileLds &L, int lane,
                                           RowRegs<NR> &t) {
     const bool meshlet_occ = p.ci.meshlet_visibility_buffer != ORBIT_NONE;
@@ -251,10 +253,8 @@ __device__ __forceinline__ void rows_load(const MeshletCullParams &p, const Wave
             if (active && !in) latch_status(p.status, ORBIT_E_RANGE);
             t.a[k] = *(in ? p.ms.sphere + (rec.y + ml) : reinterpret_cast<const uint4 *>(p.zero_page));
             const uint32_t c = *(in ? p.ms.cone + (rec.y + ml) : reinterpret_cast<const uint32_t *>(p.zero_page));
-            // with alpha classes the predicate bits come from the slab (setup_write_cls) and no material index is
-            // read: the load stays (straight-line code, the same kernel) but every lane aims it at the zero page
-            const uint16_t m = *((in && p.ms.cls0 == nullptr) ? p.ms.mat + (rec.y + ml)
-                                                              : reinterpret_cast<const uint16_t *>(p.zero_page));
+            uint16_t m = 0; // CLS: the predicate bits come from the alpha classes in the slab (setup_write_cls)
+            if constexpr (!CLS) m = *(in ? p.ms.mat + (rec.y + ml) : reinterpret_cast<const uint16_t *>(p.zero_page));
             t.b[k] = make_uint4(c, 0u, 0u, (uint32_t)m);
         } else {
             const uint4 *src = active ? reinterpret_cast<const uint4 *>(p.meshlets + (rec.y + ml))
@@ -274,7 +274,7 @@ __device__ __forceinline__ void rows_load(const MeshletCullParams &p, const Wave
 // Evaluates rows R0 .. R0+NR-1 of a tile: should-draw ballots into the slab,
 // survivor payload (optional), pass-2 visibility words (WRITE_VIS).  `total` is
 // the tile's running survivor count; the new count is returned.
-template <int PASS, int PROJ, bool WRITE_VIS, int R0, int NR, bool STREAM = false>
+template <int PASS, int PROJ, bool WRITE_VIS, int R0, int NR, bool CLS = false>
 __device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
                                               const AlphaLds *A, int lane, const RowRegs<NR> &t, uint32_t total,
                                               Payload *payload) {
@@ -283,7 +283,7 @@ __device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTi
     const uint32_t half = lane >> 5, ml = lane & 31;
     uint32_t abits[NR];
 #pragma unroll
-    for (int k = 0; k < NR; k++) abits[k] = lane_alpha_bits<STREAM>(p, L, A, 2 * (R0 + k) + half, ml, t.b[k].w);
+    for (int k = 0; k < NR; k++) abits[k] = lane_alpha_bits<CLS>(p, L, A, 2 * (R0 + k) + half, ml, t.b[k].w);
 #pragma unroll
     for (int k = 0; k < NR; k++) {
         const int r = R0 + k;
@@ -382,14 +382,14 @@ __device__ __forceinline__ void cand_flush(const MeshletCullParams &p, WaveTileL
 }
 
 // One row of a tile in pass 2 with meshlet occlusion: geometry tests, candidates into the ring.
-template <int PROJ, int R, uint32_t N, bool STREAM = false>
+template <int PROJ, int R, uint32_t N, bool CLS = false>
 __device__ __forceinline__ void row_eval_occ(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
                                              const AlphaLds *A, CandLds<N> &C, int lane, const RowRegs<1> &t,
                                              CandState &cs, Payload *payload) {
     const uint32_t half = lane >> 5, ml = lane & 31;
     const uint32_t rid = 2 * R + half;
     const uint4 rec = L.rec[rid];
-    const uint32_t abits = lane_alpha_bits<STREAM>(p, L, A, rid, ml, t.b[0].w);
+    const uint32_t abits = lane_alpha_bits<CLS>(p, L, A, rid, ml, t.b[0].w);
     const bool active = ml < rec.z;
     const bool visible_in_buffer = ((t.prev[0] >> ml) & 1u) != 0;
     Sphere s;
@@ -453,31 +453,16 @@ __device__ __forceinline__ float4 setup_load_mat(const MeshletCullParams &p, con
 __device__ __forceinline__ uint32_t setup_load_cls(const MeshletCullParams &p, const uint4 &rec, int lane) {
     const uint32_t col = lane & 3;
     const uint32_t *plane = (col & 2u) ? p.ms.cls1 : p.ms.cls0;
-    // no classes (plane == nullptr), no record, a record outside the stream: the zero page
-    const uint32_t *src = (plane != nullptr && rec.z != 0u && p.ms.covers(rec.y)) ? plane + (rec.y >> 5) + (col & 1u)
-                                                                                  : reinterpret_cast<const uint32_t *>(p.zero_page);
+    const uint32_t *src = (rec.z != 0u && p.ms.covers(rec.y)) ? plane + (rec.y >> 5) + (col & 1u)
+                                                              : reinterpret_cast<const uint32_t *>(p.zero_page);
     return *src;
 }
 
 // -> the record's predicate masks in the slab: bit l of amask.x = (1 << alpha_mode) & alpha_mode_flag != 0 (:207) for
-// lane l, of amask.y the same for noskip_alphamode (:210).  Lanes of class 3 (a material outside the table the
-// classes were derived from, an alpha_mode the planes cannot hold) have their material looked up here, once per
-// tile and off the rows' path — rare.
-__device__ __forceinline__ void resolve_other_classes(const MeshletCullParams &p, const AlphaLds *A, const uint4 &rec,
-                                                   uint32_t other, uint32_t &b0, uint32_t &b1) {
-    while (other != 0u) {
-        const uint32_t l = (uint32_t)__builtin_ctz(other);
-        other &= other - 1u;
-        const uint32_t m = rec.y + l;
-        const uint32_t mi = p.ms.covers(m) ? (uint32_t)p.ms.mat[m] : 0u;
-        const uint32_t ab = A ? (uint32_t)A->bits[mi & (kAlphaTable - 1u)] : alpha_bits(p.ci, p.materials[mi].alpha_mode);
-        b0 |= (ab & 1u) << l;
-        b1 |= ((ab >> 1) & 1u) << l;
-    }
-}
-
-__device__ __forceinline__ void setup_write_cls(const MeshletCullParams &p, WaveTileLds &L, const AlphaLds *A,
-                                                const uint32_t *sel, const uint4 &rec, uint32_t cls_word, int lane) {
+// lane l, of amask.y the same for noskip_alphamode (:210).  The library takes this path only for streams WITHOUT
+// meshlets of class 3 (abi.hip): nothing here ever looks a material up.
+__device__ __forceinline__ void setup_write_cls(WaveTileLds &L, const uint32_t *sel, const uint4 &rec, uint32_t cls_word,
+                                                int lane) {
     const uint32_t w0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cls_word, 0x00, 0xF, 0xF, false); // quad_perm broadcasts
     const uint32_t w1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cls_word, 0x55, 0xF, 0xF, false);
     const uint32_t w2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cls_word, 0xAA, 0xF, 0xF, false);
@@ -487,12 +472,8 @@ __device__ __forceinline__ void setup_write_cls(const MeshletCullParams &p, Wave
     const uint32_t c0 = ~(hi | lo), c1 = lo & ~hi, c2 = hi & ~lo;
     // sel[2 c + k]: all ones if class c has predicate bit k (block-wide table: keeps the cull info's words out of the
     // scalar registers the rows need)
-    uint32_t b0 = (c0 & sel[0]) | (c1 & sel[2]) | (c2 & sel[4]);
-    uint32_t b1 = (c0 & sel[1]) | (c1 & sel[3]) | (c2 & sel[5]);
-    // lanes past the record's count carry whatever class their bits say: they are never evaluated
-    const uint32_t other = (lane & 3) == 0 ? (hi & lo & (rec.z >= 32u ? 0xFFFFFFFFu : ((1u << rec.z) - 1u))) : 0u;
-    if (__ballot(other != 0u) != 0ull) resolve_other_classes(p, A, rec, other, b0, b1);
-    if ((lane & 3) == 0) L.amask[lane >> 2] = make_uint2(b0, b1);
+    if ((lane & 3) == 0)
+        L.amask[lane >> 2] = make_uint2((c0 & sel[0]) | (c1 & sel[2]) | (c2 & sel[4]), (c0 & sel[1]) | (c1 & sel[3]) | (c2 & sel[5]));
 }
 
 __device__ __forceinline__ void setup_write(const MeshletCullParams &p, WaveTileLds &L, const uint4 &rec,
@@ -559,8 +540,8 @@ struct ViewGroup {
 #define ORBIT_DBG(p, bits) false
 #endif
 
-// STREAM: meshlets from the derived streams (predicate bits from their alpha classes when the view carries them)
-template <int PASS, int PROJ, bool PROF, bool STREAM = false>
+// STREAM: meshlets from the derived streams; CLS (with STREAM): predicate bits from the streams' alpha classes
+template <int PASS, int PROJ, bool PROF, bool STREAM = false, bool CLS = false>
 __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
     __shared__ WaveTileLds lds[kEvWaves][3];
     __shared__ PlaneLds planes;
@@ -569,9 +550,9 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // pass 2 with meshlet occlusion: HiZ tests run on compacted candidates (cand_flush), not per row
     const bool occ2 = PASS == 2 && p.ci.meshlet_visibility_buffer != ORBIT_NONE;
-    __shared__ uint32_t cls_sel[8]; // STREAM: [2 c + k] = all ones if alpha class c has predicate bit k (alpha_bits)
+    __shared__ uint32_t cls_sel[CLS ? 8 : 1]; // [2 c + k] = all ones if alpha class c has predicate bit k (alpha_bits)
     planes_to_lds(p.ci, planes);
-    if (STREAM && threadIdx.x < 6) cls_sel[threadIdx.x] = ((alpha_bits(p.ci, threadIdx.x >> 1) >> (threadIdx.x & 1u)) & 1u) ? ~0u : 0u;
+    if (CLS && threadIdx.x < 6) cls_sel[threadIdx.x] = ((alpha_bits(p.ci, threadIdx.x >> 1) >> (threadIdx.x & 1u)) & 1u) ? ~0u : 0u;
     const AlphaLds *alpha = alpha_table_fill(p, alpha_tab) ? &alpha_tab : nullptr;
     __syncthreads();
     const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
@@ -631,15 +612,15 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         rec2 = setup_load_rec(p, w2, w2 < ntiles, nrec, lane);
         const float4 m0 = setup_load_mat(p, r0, lane);
         const float4 m1 = setup_load_mat(p, r1, lane);
-        if constexpr (STREAM) {
+        if constexpr (CLS) {
             const uint32_t c0 = setup_load_cls(p, r0, lane), c1 = setup_load_cls(p, r1, lane);
-            setup_write_cls(p, lds[wave][0], alpha, cls_sel, r0, c0, lane);
-            setup_write_cls(p, lds[wave][1], alpha, cls_sel, r1, c1, lane);
+            setup_write_cls(lds[wave][0], cls_sel, r0, c0, lane);
+            setup_write_cls(lds[wave][1], cls_sel, r1, c1, lane);
         }
         setup_write(p, lds[wave][0], r0, m0, lane);
         setup_write(p, lds[wave][1], r1, m1, lane);
-        rows_load<PASS, 0, 1, STREAM>(p, lds[wave][0], lane, qa);
-        rows_load<PASS, 1, 1, STREAM>(p, lds[wave][0], lane, qb);
+        rows_load<PASS, 0, 1, STREAM, CLS>(p, lds[wave][0], lane, qa);
+        rows_load<PASS, 1, 1, STREAM, CLS>(p, lds[wave][0], lane, qb);
     }
     uint32_t it = 0;
 #ifdef ORBIT_TRIAGE
@@ -685,40 +666,40 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         CandState cs; // cs.total = the tile's running survivor count
 #define EV_ROW(R, Q)                                                                                                  \
     if constexpr (PASS == 2) {                                                                                        \
-        if (occ2) row_eval_occ<PROJ, R, kCandRing, STREAM>(p, L, planes, alpha, cand_ring[wave], lane, Q, cs, payload);  \
-        else cs.total = rows_eval<PASS, PROJ, true, R, 1, STREAM>(p, L, planes, alpha, lane, Q, cs.total, payload);      \
+        if (occ2) row_eval_occ<PROJ, R, kCandRing, CLS>(p, L, planes, alpha, cand_ring[wave], lane, Q, cs, payload);  \
+        else cs.total = rows_eval<PASS, PROJ, true, R, 1, CLS>(p, L, planes, alpha, lane, Q, cs.total, payload);      \
     } else {                                                                                                          \
-        cs.total = rows_eval<PASS, PROJ, true, R, 1, STREAM>(p, L, planes, alpha, lane, Q, cs.total, payload);           \
+        cs.total = rows_eval<PASS, PROJ, true, R, 1, CLS>(p, L, planes, alpha, lane, Q, cs.total, payload);           \
     }
         EV_ROW(0, qa)
-        rows_load<PASS, 2, 1, STREAM>(p, L, lane, qa);
+        rows_load<PASS, 2, 1, STREAM, CLS>(p, L, lane, qa);
         EV_ROW(1, qb)
-        rows_load<PASS, 3, 1, STREAM>(p, L, lane, qb);
+        rows_load<PASS, 3, 1, STREAM, CLS>(p, L, lane, qb);
         EV_STAMP(0)
         EV_ROW(2, qa)
-        rows_load<PASS, 4, 1, STREAM>(p, L, lane, qa);
+        rows_load<PASS, 4, 1, STREAM, CLS>(p, L, lane, qa);
         EV_ROW(3, qb)
-        rows_load<PASS, 5, 1, STREAM>(p, L, lane, qb);
+        rows_load<PASS, 5, 1, STREAM, CLS>(p, L, lane, qb);
         const float4 mat2 = setup_load_mat(p, rec2, lane);
         uint32_t cls2 = 0u;
-        if constexpr (STREAM) cls2 = setup_load_cls(p, rec2, lane);
+        if constexpr (CLS) cls2 = setup_load_cls(p, rec2, lane);
         const uint4 rec3 = setup_load_rec(p, w3, w3 < ntiles, nrec, lane);
         EV_STAMP(1)
         EV_ROW(4, qa)
-        rows_load<PASS, 6, 1, STREAM>(p, L, lane, qa);
+        rows_load<PASS, 6, 1, STREAM, CLS>(p, L, lane, qa);
         EV_ROW(5, qb)
-        rows_load<PASS, 7, 1, STREAM>(p, L, lane, qb);
+        rows_load<PASS, 7, 1, STREAM, CLS>(p, L, lane, qb);
         EV_STAMP(2)
         EV_ROW(6, qa)
-        rows_load<PASS, 0, 1, STREAM>(p, Ln, lane, qa);
+        rows_load<PASS, 0, 1, STREAM, CLS>(p, Ln, lane, qa);
         EV_ROW(7, qb)
-        rows_load<PASS, 1, 1, STREAM>(p, Ln, lane, qb);
+        rows_load<PASS, 1, 1, STREAM, CLS>(p, Ln, lane, qb);
         EV_STAMP(3)
         if constexpr (PASS == 2) {
             if (occ2) tile_finish_occ(p, L, cand_ring[wave], lane, cs, payload);
         }
 #undef EV_ROW
-        if constexpr (STREAM) setup_write_cls(p, lds[wave][(it + 2) % 3], alpha, cls_sel, rec2, cls2, lane);
+        if constexpr (CLS) setup_write_cls(lds[wave][(it + 2) % 3], cls_sel, rec2, cls2, lane);
         setup_write(p, lds[wave][(it + 2) % 3], rec2, mat2, lane); // also fences the mask writes of this tile
         // the ballots are read back only by the task-record launch and, in the emit launch, for tiles with more
         // survivors than the payload holds: the common tile writes its count and nothing else
@@ -748,15 +729,15 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
 #endif
 }
 
-template <int PASS, int PROJ, bool PROF, bool STREAM = false>
+template <int PASS, int PROJ, bool PROF, bool STREAM = false, bool CLS = false>
 __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_kernel(const MeshletCullParams p) {
-    meshlet_eval_body<PASS, PROJ, PROF, STREAM>(p);
+    meshlet_eval_body<PASS, PROJ, PROF, STREAM, CLS>(p);
 }
 // several views in one launch (orbit_cull_views): the views' parameter blocks by value, blockIdx.y picks one
-template <int PASS, int PROJ, bool STREAM>
+template <int PASS, int PROJ, bool STREAM, bool CLS = false>
 __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_views_kernel(const MeshletCullViews all,
                                                                                            const ViewGroup g) {
-    meshlet_eval_body<PASS, PROJ, false, STREAM>(all.v[g.idx[blockIdx.y]]);
+    meshlet_eval_body<PASS, PROJ, false, STREAM, CLS>(all.v[g.idx[blockIdx.y]]);
 }
 
 // ---------------------------------------------------------------------------
@@ -1544,6 +1525,8 @@ struct StreamBuildArrays {
     uint64_t s_first, s_end; // the stream's range
     const OrbitMaterialData *materials; // alpha classes come from here (nullptr: class 3 everywhere)
     uint32_t material_count;
+    uint32_t *other; // set to 1 when a meshlet of class 3 is derived while `materials` is set (abi.hip: such a stream
+                     // evaluates through its material indices)
 };
 
 // alpha class of a meshlet (kernels.h MeshletStreamView): its material's alpha_mode where the two bit planes can hold
@@ -1575,6 +1558,7 @@ __global__ __launch_bounds__(256) void meshlet_stream_build_kernel(const OrbitMe
             A.cnt[m] = (uint16_t)(b.w >> 16);
             vtx = b.y, data = b.z;
             cls = alpha_class(A, b.w & 0xFFFFu);
+            if (cls == 3u && A.materials != nullptr) *A.other = 1u;
         } else if (m == end && m < A.s_end) { // derived earlier (or never: then the bit is as arbitrary as the rest)
             vtx = A.cmd[m * 3u], data = A.cmd[m * 3u + 1u];
         }
@@ -1623,6 +1607,7 @@ __global__ __launch_bounds__(256) void meshlet_stream_classes_kernel(const Strea
         const uint64_t m = base + (uint64_t)lane;
         const bool in = m >= A.s_first && m < A.s_end;
         const uint32_t cls = in ? alpha_class(A, (uint32_t)A.mat[m]) : 3u;
+        if (in && cls == 3u && A.materials != nullptr) *A.other = 1u;
         const uint64_t m0 = __ballot((cls & 1u) != 0u), m1 = __ballot((cls & 2u) != 0u);
         if (lane == 0 && base + 32u > A.s_first) {
             A.cls0[base >> 5] = (uint32_t)m0;
@@ -1682,7 +1667,12 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t
             hipLaunchKernelGGL((meshlet_pass1_kernel<1>), grid, block, 0, s, p);
         else
             hipLaunchKernelGGL((meshlet_pass1_kernel<0>), grid, block, 0, s, p);
-    } else if (p.ms.sphere != nullptr) { // derived streams: 22 B per meshlet (20.25 with alpha classes), no payload
+    } else if (p.ms.sphere != nullptr && p.ms.cls0 != nullptr) { // derived streams + alpha classes: 20.25 B per meshlet
+        if (ortho)
+            hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 1, false, true, true>), grid, block, 0, s, p);
+        else
+            hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 0, false, true, true>), grid, block, 0, s, p);
+    } else if (p.ms.sphere != nullptr) { // derived streams: 22 B per meshlet, no payload
         if (ortho)
             hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 1, false, true>), grid, block, 0, s, p);
         else
@@ -1752,18 +1742,22 @@ hipError_t launch_meshlet_cull_views(const MeshletCullViews &all, uint32_t n, ui
         if ((t + kScanChunk - 1) / kScanChunk > kEmitChunkTable) return hipErrorInvalidValue;
         max_tiles_all = max(max_tiles_all, t);
     }
-    // a view evaluates from the derived meshlet streams when its block carries them and its pass streams (0 / 2)
-    auto from_stream = [&](uint32_t i) { return host[i].ci.occlusion_pass != 1 && host[i].ms.sphere != nullptr; };
+    // a view evaluates from the derived meshlet streams when its block carries them and its pass streams (0 / 2):
+    // 0 = Meshlet buffer, 1 = streams, 2 = streams with alpha classes
+    auto source = [&](uint32_t i) -> int {
+        if (host[i].ci.occlusion_pass == 1 || host[i].ms.sphere == nullptr) return 0;
+        return host[i].ms.cls0 != nullptr ? 2 : 1;
+    };
+    auto from_stream = [&](uint32_t i) { return source(i) != 0; };
     bool done[ORBIT_MAX_CULL_VIEWS] = {};
     for (uint32_t i = 0; i < n; i++) {
         if (done[i]) continue;
         const uint32_t pass = host[i].ci.occlusion_pass, proj = host[i].ci.projection_type;
-        const bool stream = from_stream(i);
+        const int src = source(i);
         ViewGroup g{};
         uint32_t m = 0, need = 1;
         for (uint32_t j = i; j < n; j++)
-            if (!done[j] && host[j].ci.occlusion_pass == pass && host[j].ci.projection_type == proj &&
-                from_stream(j) == stream) {
+            if (!done[j] && host[j].ci.occlusion_pass == pass && host[j].ci.projection_type == proj && source(j) == src) {
                 done[j] = true;
                 g.idx[m++] = (uint8_t)j;
                 const uint32_t t = (host[j].dispatch_capacity + kTileRecords - 1) / kTileRecords;
@@ -1775,7 +1769,10 @@ hipError_t launch_meshlet_cull_views(const MeshletCullViews &all, uint32_t n, ui
         const dim3 grid(blocks, m), block(kEvWaves * 64);
         const bool ortho = proj == 1;
 #define ORBIT_EVAL_VIEWS(PASS)                                                                                        \
-    if (stream) {                                                                                                     \
+    if (src == 2) {                                                                                                   \
+        if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<PASS, 1, true, true>), grid, block, 0, s, all, g);   \
+        else hipLaunchKernelGGL((meshlet_eval_views_kernel<PASS, 0, true, true>), grid, block, 0, s, all, g);         \
+    } else if (src == 1) {                                                                                            \
         if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<PASS, 1, true>), grid, block, 0, s, all, g);         \
         else hipLaunchKernelGGL((meshlet_eval_views_kernel<PASS, 0, true>), grid, block, 0, s, all, g);               \
     } else {                                                                                                          \
@@ -1830,23 +1827,24 @@ hipError_t launch_scatter_list(const ScatterListParams &p, uint32_t num_cus, hip
 }
 
 static StreamBuildArrays stream_build_arrays(const MeshletStreamView &ms, const OrbitMaterialData *materials,
-                                             uint32_t material_count) {
+                                             uint32_t material_count, uint32_t *other = nullptr) {
     return StreamBuildArrays{const_cast<uint4 *>(ms.sphere),   const_cast<uint32_t *>(ms.cone),
                              const_cast<uint16_t *>(ms.mat),   const_cast<uint32_t *>(ms.cmd),
                              const_cast<uint16_t *>(ms.cnt),   const_cast<uint32_t *>(ms.link),
                              const_cast<uint32_t *>(ms.cls0),  const_cast<uint32_t *>(ms.cls1),
                              (uint64_t)ms.first,               (uint64_t)ms.first + ms.count,
-                             materials,                        material_count};
+                             materials,                        material_count,
+                             other};
 }
 
 hipError_t launch_meshlet_stream_build(const OrbitMeshlet *meshlets, uint64_t first, uint64_t count,
                                        const MeshletStreamView &ms, const OrbitMaterialData *materials,
-                                       uint32_t material_count, hipStream_t s) {
+                                       uint32_t material_count, uint32_t *other, hipStream_t s) {
     if (count == 0) return hipSuccess;
     const uint64_t need = (count + 64u + 255u) / 256u + 1u;
     const uint32_t blocks = (uint32_t)(need < 8192u ? need : 8192u);
     hipLaunchKernelGGL(meshlet_stream_build_kernel, dim3(blocks), dim3(256), 0, s, meshlets, first, count,
-                       stream_build_arrays(ms, materials, material_count));
+                       stream_build_arrays(ms, materials, material_count, other));
     return hipGetLastError();
 }
 
@@ -1885,11 +1883,11 @@ hipError_t launch_meshlet_stream_validate(const OrbitMeshlet *meshlets, const Me
 }
 
 hipError_t launch_meshlet_stream_classes(const MeshletStreamView &ms, const OrbitMaterialData *materials,
-                                         uint32_t material_count, hipStream_t s) {
+                                         uint32_t material_count, uint32_t *other, hipStream_t s) {
     const uint64_t need = ((uint64_t)ms.count + 64u + 255u) / 256u + 1u;
     const uint32_t blocks = (uint32_t)(need < 8192u ? need : 8192u);
     hipLaunchKernelGGL(meshlet_stream_classes_kernel, dim3(blocks), dim3(256), 0, s,
-                       stream_build_arrays(ms, materials, material_count));
+                       stream_build_arrays(ms, materials, material_count, other));
     return hipGetLastError();
 }
 

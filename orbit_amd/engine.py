@@ -78,7 +78,11 @@ class MeshletStream:
                                                            _ptr(material_buffer), _stream(stream)), self._engine._ctx)
 
     def close(self):
+        """orbit_meshlet_stream_destroy.  The library refuses while a context still has the stream bound; the engine
+        this handle came from is unbound here, other engines are the caller's to unbind first."""
         if getattr(self, "_h", None) is not None and self._h.value:
+            if getattr(self._engine, "_meshlet_stream", None) is self and getattr(self._engine, "_ctx", None):
+                self._engine.bind_meshlet_stream(None)
             _lib.check(self._lib.orbit_meshlet_stream_destroy(self._h))
             self._h = C.c_void_p()
 
@@ -107,8 +111,9 @@ class Engine:
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
-            self._lib.orbit_ctx_destroy(self._ctx)
+            self._lib.orbit_ctx_destroy(self._ctx)  # unbinds its meshlet stream
             self._ctx = C.c_void_p()
+            self._meshlet_stream = None
 
     def __del__(self):
         try:
@@ -302,6 +307,10 @@ class Engine:
     def meshlet_stream_culls(self):
         """orbit_ctx_meshlet_stream_culls: meshlet culls launched from a bound stream so far."""
         return int(self._lib.orbit_ctx_meshlet_stream_culls(self._ctx))
+
+    def meshlet_class_culls(self):
+        """orbit_ctx_meshlet_class_culls: ... of which evaluated from the stream's alpha classes."""
+        return int(self._lib.orbit_ctx_meshlet_class_culls(self._ctx))
 
     def scatter_list(self, local_list, counts, rank, world, out_buffers, out_capacity, header_bytes, stride,
                      stream=None):

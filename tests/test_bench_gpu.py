@@ -36,7 +36,7 @@ def test_bench_line_has_the_contract_fields(source):
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
-    per = 22 if source == "stream" else 32
+    per = 20.25 if source == "stream" else 32  # the stream source with its alpha classes (bench.py default)
     assert rf["algorithmic_bytes_per_meshlet"] == per and rf["launches_timed"] >= 1
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
     assert rf["traffic"] is None  # the committed PMC passes are of the full-size scene only

@@ -386,8 +386,34 @@ def test_alpha_classes_follow_the_materials_and_fall_back(torch_mod, engine, ora
         ref = run_oracle(oracle, scene, ci)
         for count in (n_mat, n_mat // 2, 1):
             ms.set_materials(gs.materials, count)
-            for mc in (0, n_mat):  # alpha modes gathered / staged in LDS for the looked-up lanes
+            torch.cuda.synchronize()
+            for mc in (0, n_mat):  # alpha modes gathered / staged in LDS
                 assert_same(run_gpu(torch, engine, gs, ci, material_count=mc), ref)
+    # a stream that holds meshlets of class 3 keeps evaluating through its material indices
+    assert engine.meshlet_class_culls() == 0 and engine.meshlet_stream_culls() == 18
+    # the same scene with plain alpha modes: now the classes decide — for every filter the renderer uses
+    scene.materials["alpha_mode"][3::5] = 1
+    scene.materials["alpha_mode"][4::7] = 2
+    gs.materials.copy_(dev(torch, scene.materials))
+    ms.set_materials(gs.materials, n_mat)
+    for flags, noskip in ((L.ALPHA_OPAQUE | L.ALPHA_MASKED, 0), (0xF, 0), (L.ALPHA_OPAQUE, L.ALPHA_MASKED | 8),
+                          (L.ALPHA_TRANSPARENT, 0)):
+        ci = sc.make_cull_info(cam.view, cam.planes, alpha_mode_flag=flags, noskip_alphamode=noskip)
+        ref = run_oracle(oracle, scene, ci)
+        before = engine.meshlet_class_culls()
+        got = run_gpu(torch, engine, gs, ci)  # enqueued right behind set_materials: the first one may not know yet
+        assert_same(got, ref)
+        torch.cuda.synchronize()
+        assert_same(run_gpu(torch, engine, gs, ci), ref)
+        assert engine.meshlet_class_culls() >= before + 1
+    # a table that ends before the last material: class 3 again, and the library notices
+    ms.set_materials(gs.materials, n_mat - 1)
+    torch.cuda.synchronize()
+    before = engine.meshlet_class_culls()
+    assert_same(run_gpu(torch, engine, gs, ci), ref)
+    assert engine.meshlet_class_culls() == before
+    ms.set_materials(gs.materials, n_mat)
+    torch.cuda.synchronize()
     # another material buffer (a copy): the classes are not its mirror -> material indices again, same result
     other = dev(torch, scene.materials)
     before = engine.meshlet_stream_culls()
@@ -452,11 +478,13 @@ def test_a_bound_stream_cannot_be_destroyed(torch_mod, engine):
     gs = GpuScene(torch, scene)
     ms = engine.meshlet_stream(gs.meshlets, 0, len(scene.meshlets))
     engine.bind_meshlet_stream(ms)
-    with pytest.raises(_lib.OrbitError) as err:
-        ms.close()
-    assert err.value.code == _lib.E_INVALID
+    assert engine._lib.orbit_meshlet_stream_destroy(ms._h) == _lib.E_INVALID  # refused, nothing freed
+    scene2, ci = _scene(seed=59, n=40)
+    run_gpu(torch, engine, gs, ci)  # still usable
+    assert engine.meshlet_stream_culls() >= 1
     engine.bind_meshlet_stream(None)
-    ms.close()
+    assert engine._lib.orbit_meshlet_stream_destroy(ms._h) == 0
+    ms._h = C.c_void_p()
 
 
 def test_a_new_source_buffer_starts_the_readable_range_over(torch_mod, engine, oracle):
