@@ -3,7 +3,9 @@
 
 One "step" = one pass of the hot path over the scene: entity_cull + meshlet_cull
 (frustum + normal cone, occlusion_pass 0) on this rank's entity shard and, for
-N > 1, the RCCL gather of the compacted visible list (orbit_amd/dist.py).
+N > 1, the rank-ordered all-gather of the compacted visible list (8-B items; orbit_amd/dist.py) —
+what BASELINE.json's north_star names.  Turning the gathered list into 28-B commands on every GPU is a
+separate, optional stage (--expand all), reported on its own.
 Inputs are generated on the device and stay resident in HBM; the timed region is
 K steps between barrier + synchronize on both sides, max over ranks.
 
@@ -45,6 +47,11 @@ def parse():
     ap.add_argument("--exchange", choices=("visible", "commands"), default="visible",
                     help="N>1 exchange format: 8-B visible items expanded on every GPU against the replicated "
                          "meshlet buffer (default), or the 28-B commands themselves")
+    ap.add_argument("--expand", choices=("none", "all"), default="none",
+                    help="N>1, exchange visible: what happens to the gathered 8-B list inside the step — none "
+                         "(default: the step is cull + all-gather, every rank then holds the whole visible list and "
+                         "issues its draws from it or from its own shard, SURVEY.md §8e), or all (every rank also "
+                         "expands the whole list into 28-B commands: N-independent work on every GPU)")
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="frame slots (OrbitCtx + stream + buffers each) the steps go round-robin over; 1 = strictly serial")
     ap.add_argument("--time-every", type=int, default=3,
@@ -75,9 +82,12 @@ def spawn_ranks(args):
     import socket
     import subprocess
 
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    # The listening socket stays open (SO_REUSEADDR) until the children exist, so the port cannot be handed to another
+    # process in between; torch's TCPStore binds with SO_REUSEADDR too.
+    sk = socket.socket()
+    sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
@@ -85,13 +95,39 @@ def spawn_ranks(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
+    sk.close()
+    # Rank 0's stdout is drained by a thread while ALL children are polled: the first rank that dies takes the others
+    # with it (they would otherwise sit in a rendezvous or a collective until the process group's timeout), and the
+    # whole job has a deadline.
+    import threading
+
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("ORBIT_BENCH_TIMEOUT_S", "1800"))
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad or time.time() > deadline:
+            failed = bad or [("deadline", -1)]
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.time() + 10
+            while any(p.poll() is None for p in procs) and time.time() < t_kill:
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
     rcs = [p.wait() for p in procs]
-    sys.stdout.buffer.write(out0)
+    reader.join(timeout=5)
+    sys.stdout.buffer.write(out0[0] if out0 else b"")
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    bad = failed or [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
-        raise SystemExit(f"bench.py: rank(s) failed (rank, exit code): {bad}")
+        raise SystemExit(f"bench.py: rank(s) failed (rank, exit code): {bad}; exit codes of all ranks: {rcs}")
 
 
 def main():
@@ -151,9 +187,10 @@ def main():
     # they are and a rank holds only its meshlet shard.
     do_gather = use_dist and not args.no_gather and (backend == "nccl" or args.transport == "p2p")
     visible_exchange = do_gather and args.exchange == "visible"
+    do_expand = visible_exchange and args.expand == "all"  # needs the whole meshlet buffer (+ stream) on every GPU
     t0 = time.time()
     draws, mesh, ent, half = synth.gen_entity_tables(spec, dev)
-    mb, me = (0, E) if visible_exchange else (b, e)
+    mb, me = (0, E) if do_expand else (b, e)
     meshlets = synth.gen_meshlets(spec, mb, me, dev, half, survive_target=args.survive)
     materials = synth.gen_materials(spec, dev)
     torch.cuda.synchronize()
@@ -237,7 +274,7 @@ def main():
             recv_bufs = [torch.zeros(hdr + item * out_cap, dtype=torch.uint8, device=dev) for _ in range(n_x)]
         x_events = [torch.cuda.Event() for _ in range(n_x)]  # exchange into recv_bufs[j] finished
         e_events = [torch.cuda.Event() for _ in range(n_x)]  # expansion out of recv_bufs[j] finished
-        if visible_exchange:
+        if do_expand:
             gathered = torch.zeros(L.DRAW_HEADER + 28 * out_cap, dtype=torch.uint8, device=dev)
     pending = []  # (slot, list index) culled but not yet exchanged (at most one)
     x_count = [0]
@@ -256,7 +293,7 @@ def main():
                 odist.gather_visible(s.lists[k], recv_bufs[j], header=hdr, stride=item)
             s.xdone[k].record(xstream)  # the list buffer may be overwritten
             x_events[j].record(xstream)
-        if visible_exchange:
+        if do_expand:
             with torch.cuda.stream(estream):
                 estream.wait_event(x_events[j])
                 s.eng.expand_visible(recv_bufs[j], meshlets_base, gathered, out_cap, stream=estream)
@@ -302,6 +339,33 @@ def main():
     # Power-state settle (see --settle-ms): the same frames, back to back, until the device has been busy that long.
     # The frame count must be the same on every rank (a step of the sharded engine contains collectives), so it is
     # derived from the slowest rank's time for the first eight frames, not from each rank's own clock.
+    # SURVEY.md §8d, literally: the 32-B Meshlet buffer (no derived stream), 5 warm-up steps from an idle device, then
+    # >= 20 steps each bracketed by its own HIP event pair on the launch stream; the median.  Never the headline
+    # (that is the settled stream path below), always in the line — N = 1 only (a step of N > 1 contains collectives).
+    protocol_8d = None
+    frames_before_timed = 0
+    if world == 1 and not use_dist:
+        s0 = slots[0]
+        if mstream is not None:
+            s0.eng.bind_meshlet_stream(None)
+        for _ in range(5):
+            cull(s0, 0)
+        n8 = max(20, args.steps)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n8)]
+        for a, z in evs:
+            a.record(s0.stream)
+            cull(s0, 0)
+            z.record(s0.stream)
+        torch.cuda.synchronize()
+        ms8 = sorted(a.elapsed_time(z) for a, z in evs)
+        protocol_8d = {"what": "SURVEY.md §8d as written: Meshlet buffer (32 B per meshlet, no derived stream, no "
+                               "update contract), 5 warm-up steps from idle, no settle phase, then one HIP event pair "
+                               "per step; median",
+                       "steps": n8, "warmup": 5, "ms_per_step_median": ms8[len(ms8) // 2], "ms_per_step_min": ms8[0],
+                       "ms_per_step_max": ms8[-1], "meshlets_per_sec": n_local_meshlets / (ms8[len(ms8) // 2] * 1e-3)}
+        frames_before_timed += 5 + n8
+        if mstream is not None:
+            s0.eng.bind_meshlet_stream(mstream)
     settle_frames = 0
     cold_ms_per_step = None
     if args.settle_ms > 0:
@@ -321,6 +385,7 @@ def main():
         if use_dist:
             dist.all_reduce(cold, op=dist.ReduceOp.MAX)
         cold_ms_per_step = float(cold.item())
+        frames_before_timed += args.warmup + args.steps
         for batch in range(2):  # eight cold frames (code objects, first touches), then eight that are timed
             t_settle = time.perf_counter()
             for _ in range(8):
@@ -337,6 +402,7 @@ def main():
         drain()
         torch.cuda.synchronize()
         settle_frames = 16 + more
+    frames_before_timed += settle_frames + args.warmup
     for _ in range(args.warmup):
         step()
     drain()
@@ -401,11 +467,11 @@ def main():
             xa.record(xstream)
             last_recv = gather(s0, 0)
             xm.record(xstream)
-            if visible_exchange:
+            if do_expand:
                 xz.record(estream)
             torch.cuda.synchronize()
             x_ms.append(xa.elapsed_time(xm))
-            if visible_exchange:
+            if do_expand:
                 ex_ms.append(xm.elapsed_time(xz))
     # the same frames from the 32-B Meshlet buffer (stream unbound), for the record, outside any metric
     buffer_path_latency_ms = buffer_path_ms_per_step = None
@@ -441,24 +507,27 @@ def main():
     disp, draw = s0.disp, s0.lists[0]  # the latency frames above ran on slot 0: its buffers hold the last result
     n_rec = int(disp[:4].view(torch.int32).item())
     n_draw = int(draw[:4].view(torch.int32).item())
-    if do_gather:  # the gathered list holds this rank's commands at its rank-order position
-        if not visible_exchange:
-            gathered = recv_bufs[last_recv]
+    if do_gather:  # the gathered list holds this rank's survivors at its rank-order position
         counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
         dist.all_gather(counts, torch.tensor([n_draw], dtype=torch.int64, device=dev))
         first = int(sum(int(c.item()) for c in counts[:rank]))
-        mine = gathered[L.DRAW_HEADER + 28 * first:L.DRAW_HEADER + 28 * (first + n_draw)]
-        if visible_exchange:  # commands expanded from the gathered items: their (meshlet, entity) are this rank's items
+        wire = recv_bufs[last_recv]  # what travelled: 8-B visible items or 28-B commands, rank order
+        assert torch.equal(wire[hdr + item * first:hdr + item * (first + n_draw)], draw[hdr:hdr + item * n_draw]), \
+            "gathered list != local list"
+        assert int(wire[:4].view(torch.int32).item()) == int(sum(int(c.item()) for c in counts))
+        g_hdr, g_item = hdr, item
+        if do_expand:  # commands expanded from the gathered items: their (meshlet, entity) are this rank's items
+            mine = gathered[L.DRAW_HEADER + 28 * first:L.DRAW_HEADER + 28 * (first + n_draw)]
             cmds = mine.view(torch.int32).view(-1, 7)
             items = draw[L.VISIBLE_HEADER:L.VISIBLE_HEADER + 8 * n_draw].view(torch.int32).view(-1, 2)
             assert torch.equal(cmds[:, 6], items[:, 0]) and torch.equal(cmds[:, 4], items[:, 1]), \
                 "expanded list != local visible list"
+            g_hdr, g_item = L.DRAW_HEADER, 28
         else:
-            assert torch.equal(mine, draw[L.DRAW_HEADER:L.DRAW_HEADER + 28 * n_draw]), "gathered list != local list"
-        assert int(gathered[:4].view(torch.int32).item()) == int(sum(int(c.item()) for c in counts))
+            gathered = wire
         # the whole gathered list is the same on every rank: a checksum of it must agree
         total = int(gathered[:4].view(torch.int32).item())
-        words = gathered[L.DRAW_HEADER:L.DRAW_HEADER + 28 * total].view(torch.int32).to(torch.int64)
+        words = gathered[g_hdr:g_hdr + g_item * total].view(torch.int32).to(torch.int64)
         chk = torch.stack([words.sum(), (words * (torch.arange(words.numel(), device=dev) % 8191 + 1)).sum()])
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -474,15 +543,25 @@ def main():
         agg = torch.tensor([n_in, n_draw], dtype=torch.int64, device=dev)
         dist.all_reduce(agg)
         tot_in, tot_draw = int(agg[0].item()), int(agg[1].item())
-        km = torch.tensor([kernel_ms, frame_latency_ms, exchange_ms or 0.0, expand_ms or 0.0], dtype=torch.float64,
-                          device=dev)
-        dist.all_reduce(km, op=dist.ReduceOp.MAX)
-        kernel_ms_max, kernel_ms_max_frame = float(km[0].item()), float(km[1].item())
-        exchange_ms_max = float(km[2].item()) if exchange_ms is not None else None
-        expand_ms_max = float(km[3].item()) if expand_ms is not None else None
+        km = torch.tensor([kernel_ms, frame_latency_ms, exchange_ms or 0.0, expand_ms or 0.0, float(n_in), float(n_draw)],
+                          dtype=torch.float64, device=dev)
+        per = [torch.zeros_like(km) for _ in range(world)]
+        dist.all_gather(per, km)
+        per = torch.stack(per).cpu().numpy()  # [rank, (meshlet_cull op, frame, exchange, expand, meshlets in, survivors)]
+        kernel_ms_max, kernel_ms_max_frame = float(per[:, 0].max()), float(per[:, 1].max())
+        exchange_ms_max = float(per[:, 2].max()) if exchange_ms is not None else None
+        expand_ms_max = float(per[:, 3].max()) if expand_ms is not None else None
+        per_rank_rows = {"cull_ms": [float(v) for v in per[:, 1]],
+                         "exchange_ms": [float(v) for v in per[:, 2]] if exchange_ms is not None else None,
+                         "expand_ms": [float(v) for v in per[:, 3]] if expand_ms is not None else None,
+                         "meshlets_in": [int(v) for v in per[:, 4]], "survivors": [int(v) for v in per[:, 5]]}
+        world_reported = dist.get_world_size()
     else:
         tot_in, tot_draw, kernel_ms_max, kernel_ms_max_frame = n_in, n_draw, kernel_ms, frame_latency_ms
         exchange_ms_max = expand_ms_max = None
+        per_rank_rows = {"cull_ms": [frame_latency_ms], "exchange_ms": None, "expand_ms": None,
+                         "meshlets_in": [n_in], "survivors": [n_draw]}
+        world_reported = 1
 
     ms_per_step = elapsed / args.steps * 1e3
     value = tot_in / (elapsed / args.steps)
@@ -503,7 +582,8 @@ def main():
     emit_read = (16 * n_rec + 2 * n_in + n_rec * 4 + n_in // 8) if (mstream is not None and not visible_exchange) else 0
     op_bytes = alg_bytes + emit_read + item * n_draw + 4
     # the PMC passes were taken on the whole scene at N=1
-    traffic = load_traffic(E, M, args.meshlet_source) if world == 1 else None
+    traffic, traffic_stamp = load_traffic(E, M, args.meshlet_source) if world == 1 else (None, None)
+    lib_sha = lib_sha256()
 
     # Box reference (not part of any metric): what a plain streaming read of the same bytes reaches on THIS box right
     # now.  Boxes of the pool differ by up to 30 % (profiles/r01_notes.md, "Measurement hygiene"); the ratio below is
@@ -553,7 +633,10 @@ def main():
                 "sharding": f"entity ranges over {world} rank(s)", "gather": bool(do_gather),
                 "frames_in_flight": F,
                 "settle_ms": args.settle_ms, "settle_frames": settle_frames,
+                "warmup_effective": frames_before_timed,  # every frame this process ran before the timed region
                 "ms_per_step_without_settle": cold_ms_per_step,
+                "world_size": world_reported, "backend": (backend if use_dist else None),
+                "expand": (args.expand if visible_exchange else None),
                 "exchange": (args.exchange if do_gather else None), "transport": transport,
                 "meshlet_source": (f"derived meshlet streams ({per_meshlet:g} B per meshlet evaluated"
                                    f"{' (alpha classes instead of material indices)' if not args.no_alpha_classes else ''}, "
@@ -567,6 +650,9 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": (f"profiles/{traffic_file(args.meshlet_source)} (rocprofv3 --pmc passes of an earlier run of this workload, "
                                    "tools/traffic.sh; not measured in this run)" if traffic is not None else None),
+                # is that file about THIS library?  (sha256 of liborbit_cull.so stamped into it by tools/traffic.py)
+                "traffic_current": (traffic_stamp == lib_sha) if traffic is not None else None,
+                "library_sha256": lib_sha,
                 "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_meshlet": per_meshlet,
                 "avg_launch_ms": eval_ms, "launches_timed": eval_launches,
                 "box_stream_reference": stream_ref,
@@ -574,14 +660,16 @@ def main():
                        "avg_ms": kernel_ms, "achieved": op_bytes / (kernel_ms * 1e-3) / 1e9},
             },
             "cpu_baseline": cpu_baseline,
+            "protocol_8d": protocol_8d,
             "frame_latency_ms": frame_latency_ms,
             "frame_latency_ms_from_meshlet_buffer": buffer_path_latency_ms,
             "ms_per_step_from_meshlet_buffer": buffer_path_ms_per_step,
-            "per_rank": {"cull_ms_max": kernel_ms_max_frame, "exchange_ms_max": exchange_ms_max,
-                         "expand_ms_max": expand_ms_max,
-                         "what": "one frame alone on each rank's device: entity_cull + meshlet_cull of its shard, the "
-                                 "exchange of its list, the expansion of the gathered list; max over ranks.  In the "
-                                 "timed region the three overlap (cull of step i+1, wire of step i, expansion of i-1)"},
+            "per_rank": dict(per_rank_rows, cull_ms_max=kernel_ms_max_frame, exchange_ms_max=exchange_ms_max,
+                             expand_ms_max=expand_ms_max,
+                             what="one frame alone on each rank's device, per rank: entity_cull + meshlet_cull of its "
+                                  "shard, the exchange of its list, the expansion of the gathered list (--expand all "
+                                  "only).  In the timed region they overlap (cull of step i+1, wire of step i, "
+                                  "expansion of i-1): step time = the slowest stage, not the sum"),
             "cull_only_meshlets_per_sec": tot_in / (kernel_ms_max * 1e-3) if kernel_ms_max > 0 else None,
             "scene_gen_s": gen_s,
         }
@@ -620,19 +708,29 @@ def traffic_file(meshlet_source):
     return "traffic.json" if meshlet_source == "buffer" else "traffic_stream.json"
 
 
+def lib_sha256():
+    import hashlib
+
+    try:
+        with open(os.path.join(ROOT, "orbit_amd", "liborbit_cull.so"), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        return None
+
+
 def load_traffic(entities, meshlets_per_entity, meshlet_source):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/traffic.json — Meshlet buffer — or profiles/traffic_stream.json — derived streams — written by
-    tools/traffic.py); None when absent or for another workload."""
+    """(HBM bytes per launch of the dominant kernel, sha256 of the library they were measured on) from the committed
+    rocprofv3 PMC passes (profiles/traffic.json — Meshlet buffer — or profiles/traffic_stream.json — derived streams —
+    written by tools/traffic.py); (None, None) when absent or for another workload."""
     path = os.path.join(ROOT, "profiles", traffic_file(meshlet_source))
     try:
         with open(path) as f:
             t = json.load(f)
         if t.get("entities") == entities and t.get("meshlets_per_entity") == meshlets_per_entity:
-            return t.get("hbm_bytes_per_launch")
+            return t.get("hbm_bytes_per_launch"), t.get("library_sha256")
     except (OSError, ValueError):
         pass
-    return None
+    return None, None
 
 
 def run_cpu_baseline(args, spec, ci, draws, mesh, ent, meshlets, materials, disp, draw, L):

@@ -419,20 +419,39 @@ struct Document {
         v.component_type = (int)a->index_or("componentType", 0);
         static const std::map<int, size_t> kSize = {{5120, 1}, {5121, 1}, {5122, 2}, {5123, 2}, {5125, 4}, {5126, 4}};
         if (!v.components || !kSize.count(v.component_type)) return err = "unsupported accessor type", false;
-        v.count = (size_t)a->index_or("count", 0);
+        // Every number below comes from the file: signed, unchecked, possibly huge.  They are range-checked as signed
+        // 64-bit values BEFORE any cast, and the extent test is written so that nothing can wrap.
+        const int64_t count = a->index_or("count", 0), a_off = a->index_or("byteOffset", 0);
         const Json *n = a->get("normalized");
         v.normalized = n && n->kind == Json::Bool && n->b;
         const Json *bv = at("bufferViews", a->index_or("bufferView", -1));
         if (!bv) return err = "accessor without bufferView", false;
         const int64_t buffer = bv->index_or("buffer", -1);
         if (buffer < 0 || (size_t)buffer >= buffers.size()) return err = "bufferView.buffer out of range", false;
-        const size_t elem = kSize.at(v.component_type) * (size_t)v.components;
-        const size_t offset = (size_t)bv->index_or("byteOffset", 0) + (size_t)a->index_or("byteOffset", 0);
-        v.stride = (size_t)bv->index_or("byteStride", 0);
-        if (v.stride == 0) v.stride = elem;
         const auto &buf = buffers[(size_t)buffer];
-        if (v.count && offset + (v.count - 1) * v.stride + elem > buf.size()) return err = "accessor exceeds its buffer", false;
-        v.base = buf.data() + offset;
+        const int64_t size = (int64_t)buf.size();
+        const int64_t v_off = bv->index_or("byteOffset", 0), v_len = bv->index_or("byteLength", -1);
+        const int64_t stride_in = bv->index_or("byteStride", 0);
+        const int64_t elem = (int64_t)(kSize.at(v.component_type) * (size_t)v.components);
+        if (count < 0 || a_off < 0 || v_off < 0) return err = "negative count / byteOffset", false;
+        // glTF 2.0 §5.11: byteStride in [4, 252], a multiple of 4; and it must hold an element
+        if (stride_in != 0 && (stride_in < 4 || stride_in > 252 || stride_in % 4 != 0 || stride_in < elem))
+            return err = "bufferView.byteStride out of range", false;
+        const int64_t stride = stride_in ? stride_in : elem;
+        // the view inside the buffer (byteLength is required by the format; honoured when present)
+        if (v_off > size) return err = "bufferView exceeds its buffer", false;
+        int64_t avail = size - v_off;
+        if (v_len >= 0) {
+            if (v_len > avail) return err = "bufferView exceeds its buffer", false;
+            avail = v_len;
+        }
+        // the accessor inside the view: a_off + (count - 1) * stride + elem <= avail, without forming the products
+        if (a_off > avail) return err = "accessor exceeds its bufferView", false;
+        avail -= a_off;
+        if (count > 0 && (elem > avail || (count - 1) > (avail - elem) / stride)) return err = "accessor exceeds its buffer", false;
+        v.count = (size_t)count;
+        v.stride = (size_t)stride;
+        v.base = buf.data() + (size_t)(v_off + a_off);
         return true;
     }
 };

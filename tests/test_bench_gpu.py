@@ -44,3 +44,44 @@ def test_bench_line_has_the_contract_fields(source):
     assert cb["kind"] == "port" and cb["unit"] == "meshlets/s" and cb["cores"] >= 1 and cb["value"] > 0
     assert cb["gpu_output_bit_identical"] is True and "sample" in cb
     assert ("derived meshlet streams" in d["config"]["meshlet_source"]) == (source == "stream")
+    p8 = d["protocol_8d"]  # SURVEY.md §8d literally: Meshlet buffer, 5 warm-ups, >= 20 event-timed steps, median
+    assert p8["warmup"] == 5 and p8["steps"] >= 20 and p8["ms_per_step_min"] <= p8["ms_per_step_median"] <= p8["ms_per_step_max"]
+    assert d["config"]["warmup_effective"] >= d["config"]["settle_frames"] + d["warmup"] + 25
+    assert len(d["roofline"]["library_sha256"]) == 64 and d["roofline"]["traffic_current"] is None
+
+
+def _run_ranks(extra, env):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--entities", "6000",
+                        "--settle-ms", "5"] + extra, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, ORBIT_BENCH_TIMEOUT_S="600", **env))
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("expand", ["none", "all"])
+def test_bench_two_ranks_on_one_device_whole_device_path(expand):
+    """`bench.py --gpus 2` as the driver starts it (bench.py spawns its ranks), both ranks on the box's one GPU: the
+    real exchange — HIP IPC mappings of the peers' buffers, the scatter kernel, the count / completion collectives
+    (over gloo: RCCL cannot put two ranks on one device) — then every rank's segment check and the cross-rank
+    checksum of the gathered list inside bench.py (it exits non-zero if they fail)."""
+    d = _run_ranks(["--gpus", "2", "--expand", expand], dict(ORBIT_BENCH_ONE_DEVICE="1", ORBIT_BENCH_BACKEND="gloo"))
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["world_size"] == 2 and c["gather"] is True and c["transport"] == "p2p"
+    assert c["exchange"] == "visible" and c["expand"] == expand and c["backend"] == "gloo"
+    pr = d["per_rank"]
+    assert len(pr["cull_ms"]) == 2 and len(pr["exchange_ms"]) == 2 and all(v > 0 for v in pr["cull_ms"] + pr["exchange_ms"])
+    assert (pr["expand_ms"] is None) == (expand == "none")
+    assert sum(pr["meshlets_in"]) == c["meshlets_into_meshlet_cull"] == 6000 * 256
+    assert sum(pr["survivors"]) == c["survivors"] > 0
+    assert abs(d["value"] - c["meshlets_into_meshlet_cull"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_rccl_transport_with_a_world_of_one():
+    """The RCCL send/recv transport (counts to the host, grouped send/recv) through a real communicator — of one rank,
+    all this box can hold."""
+    d = _run_ranks(["--gpus", "1", "--transport", "rccl", "--cpu-sample-entities", "0"], dict(ORBIT_BENCH_FORCE_DIST="1"))
+    c = d["config"]
+    assert c["gather"] is True and c["transport"] == "rccl" and c["world_size"] == 1 and c["backend"] == "nccl"
+    assert d["per_rank"]["exchange_ms"][0] > 0

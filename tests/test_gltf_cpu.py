@@ -245,3 +245,45 @@ def test_loader_survives_damaged_files(loaded, tmp_path):
         except Panic:
             outcomes["error"] += 1
     assert outcomes["error"] > 30 and outcomes["ok"] + outcomes["error"] == 120, outcomes
+
+
+def _write_glb(path, doc, blob):
+    js = json.dumps(doc).encode()
+    js += b" " * (-len(js) % 4)
+    with open(path, "wb") as f:
+        f.write(b"glTF" + struct.pack("<II", 2, 12 + 8 + len(js) + 8 + len(blob)))
+        f.write(struct.pack("<II", len(js), 0x4E4F534A) + js + struct.pack("<II", len(blob), 0x004E4942) + blob)
+
+
+@pytest.mark.parametrize("where,field,value", [
+    ("bufferViews", "byteStride", 2 ** 63),       # (count - 1) * stride wraps: the round-2 crash (ADVICE)
+    ("bufferViews", "byteStride", 2 ** 62),
+    ("bufferViews", "byteStride", 256),           # above glTF's 252
+    ("bufferViews", "byteStride", 6),             # not a multiple of 4
+    ("bufferViews", "byteStride", -4),
+    ("bufferViews", "byteOffset", -4),            # offset + ... wraps back into range
+    ("bufferViews", "byteOffset", 2 ** 63 - 8),
+    ("bufferViews", "byteLength", 8),             # a view too short for its accessor
+    ("bufferViews", "byteLength", 2 ** 40),       # a view longer than the buffer
+    ("accessors", "byteOffset", -16),
+    ("accessors", "byteOffset", 2 ** 63 - 1),
+    ("accessors", "count", -1),
+    ("accessors", "count", 2 ** 62),
+    ("accessors", "count", 2 ** 63 - 1),
+])
+def test_hostile_accessor_numbers_are_errors_not_wild_reads(tmp_path, where, field, value):
+    """Offsets, strides and counts of an accessor come from the file, signed and unchecked: each of these made the
+    extent test wrap (or would read through a wild pointer) before the checks in orbit_gltf.cpp Document::view."""
+    doc, blob = glb_tool().build()
+    hit = 0
+    for k, item in enumerate(doc[where]):
+        # the POSITION accessor of the first primitive and its view; and an index accessor / view
+        d = json.loads(json.dumps(doc))
+        d[where][k][field] = value
+        p = tmp_path / f"hostile_{where}_{field}_{k}.glb"
+        _write_glb(p, d, blob)
+        try:
+            gltf.load(str(p))
+        except Panic:
+            hit += 1
+    assert hit >= 1, "no variant was rejected"

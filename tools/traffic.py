@@ -29,7 +29,14 @@ def main():
     source = sys.argv[5] if len(sys.argv) > 5 else "buffer"
     fetch, launches = mean_per_kernel(fetch_csv, "FETCH_SIZE")
     write, _ = mean_per_kernel(write_csv, "WRITE_SIZE")
-    out = {"entities": entities, "meshlets_per_entity": mpe, "meshlet_source": source, "kernels": {},
+    import hashlib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "orbit_amd", "liborbit_cull.so"), "rb") as f:
+        lib_sha = hashlib.sha256(f.read()).hexdigest()
+    # what the counters were measured on: bench.py reports `traffic_current` by comparing this with the library it runs
+    out = {"entities": entities, "meshlets_per_entity": mpe, "meshlet_source": source, "library_sha256": lib_sha,
+           "git_commit": os.environ.get("ORBIT_GIT_COMMIT"), "kernels": {},
            "corrections": "KiB -> bytes (x1024); FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B; calibrated "
                           "on wide streaming reads only — the x2 of a kernel that gathers, like the stream path's "
                           "meshlet_emit, is an upper bound); WRITE_SIZE as reported"}
