@@ -1,4 +1,6 @@
-"""Generates tests/golden/spirv_cull.npz and spirv_cluster.npz: inputs and OUTPUTS OF THE REFERENCE'S OWN COMPILED SHADERS.
+"""Generates tests/golden/spirv_cull.npz and spirv_cluster.npz (no argument), spirv_pyramid.npz (`pyramid`: depth_reduce.comp.spv
+level by level) and spirv_compact.npz (`compact`: active_cluster_compaction.comp.spv): inputs and OUTPUTS OF THE
+REFERENCE'S OWN COMPILED SHADERS.
 
 Run in the build container only (it reads /root/reference/shaders/{entity_cull,meshlet_cull}.comp.spv,
 forward/forward_depth_prepass.task.spv and light_cluster/{mark_active,light_culling}.comp.spv, which do not travel): `python tests/golden/make_spirv_vectors.py`.  The binaries are executed by oracle/spirv_vm.py; what the
@@ -284,7 +286,111 @@ def cluster_case(seed, width, height, n_lights, quantised, samples=1):
                 spv_light_list=B[2][:4 + 4 * nl].copy(), spv_offset_image=img)
 
 
+def pyramid_depth(seed, sw, sh):
+    """The depth buffer of a pyramid case, from its seed alone (so that a large case needs no stored input): a
+    reverse-Z gradient, blocks of nearer geometry, noise, a quarter of the texels on a coarse grid (ties) and a few
+    exact zeros / ones."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:sh, 0:sw]
+    d = (0.05 + 0.6 * y / max(sh - 1, 1)).astype(F)
+    for _ in range(24):
+        w, h = int(rng.integers(4, max(5, sw // 3))), int(rng.integers(4, max(5, sh // 3)))
+        x0, y0 = int(rng.integers(0, sw)), int(rng.integers(0, sh))
+        d[y0:y0 + h, x0:x0 + w] = F(rng.uniform(0.0, 1.0))
+    d = (d + rng.uniform(-0.01, 0.01, d.shape).astype(F)).astype(F)
+    grid = rng.random(d.shape) < 0.25
+    d[grid] = (np.round(d[grid] * F(32)) / F(32)).astype(F)
+    d[rng.random(d.shape) < 0.001] = F(0)
+    d[rng.random(d.shape) < 0.001] = F(1)
+    return np.clip(d, 0, 1).astype(F)
+
+
+def pyramid_case(seed, sw, sh):
+    """depth_reduce.comp.spv dispatched level by level, as DepthPyramid::update does (draw_gen.rs:510-566): level 0
+    from the depth buffer, level k from level k - 1, each dispatch ceil(w / 16) x ceil(h / 16) workgroups of the
+    binary.  What the binary decides: which invocations write, the coordinate `(vec2(pos) + 0.5) / vec2(dimensions)`
+    in its own arithmetic, one sample at LOD 0, one store.  The sample itself is the reduce-min sampler model the
+    interpreter is handed (oracle_hiz_sample on the source image: driver-defined)."""
+    depth = pyramid_depth(seed, sw, sh)
+    npot = lambda v: 1 << max(int(v) - 1, 0).bit_length()
+    w0, h0 = max(npot(sw) // 2, 1), max(npot(sh) // 2, 1)  # draw_gen.rs:458
+    mips = int(np.floor(np.log2(max(w0, h0)))) + 1           # math.rs:18-20
+    mod = module("depth_reduce.comp.spv")
+    levels, src, src_w, src_h = [], np.ascontiguousarray(depth).reshape(-1), sw, sh
+    for k in range(mips):
+        w, h = max(w0 >> k, 1), max(h0 >> k, 1)
+        dst = np.full((h, w), np.nan, F)  # every texel must be written exactly once
+
+        def sample(img, smp, u, v, lod, src=src, src_w=src_w, src_h=src_h):
+            assert float(lod) == 0.0
+            return np.array([oracle.hiz_sample(src, src_w, src_h, float(u), float(v), 0.0), 0, 0, 0], F)
+
+        def write(x, y, texel, dst=dst):
+            assert np.isnan(dst[y, x]), "a texel written twice"
+            dst[y, x] = texel[0]
+        push = np.array([w, h, 1, 2], np.uint32).tobytes()  # dimensions, src_image, dst_image
+        vm.Machine(mod, {}, push, log2, images={1: {"size": lambda lod, s=(src_w, src_h): s}, 2: {"write": write}},
+                   samplers={k: {"id": k} for k in range(8)}, sample=sample, subgroup=32).run(
+            ((w + 15) // 16, (h + 15) // 16), batch=64)
+        assert not np.isnan(dst).any(), "a texel of the level was not written"
+        levels.append(dst)
+        src, src_w, src_h = dst.reshape(-1).copy(), w, h
+    return depth, (w0, h0, mips), np.concatenate([l.reshape(-1) for l in levels])
+
+
+def pyramid_main():
+    """tests/golden/spirv_pyramid.npz: small cases with inputs and the binary's pyramids (odd and non-power-of-two
+    screens, a screen smaller than a workgroup, one wider than high), and for the 1080p screen of BASELINE config 3
+    — whose level 0 is the 1920x1080 -> 1024x1024 fractional-footprint step — the seed and the SHA-256 of the binary's
+    pyramid (the input is pyramid_depth(seed, 1920, 1080); 13.9 MB of arrays stay out of the repository)."""
+    import hashlib
+
+    out = {}
+    for seed, (sw, sh) in ((11, (200, 120)), (12, (97, 61)), (13, (33, 257)), (14, (16, 9)), (15, (1, 1)), (16, (64, 64))):
+        depth, (w0, h0, mips), pyr = pyramid_case(seed, sw, sh)
+        out[f"{sw}x{sh}/depth"], out[f"{sw}x{sh}/spv_pyramid"] = depth, pyr
+        out[f"{sw}x{sh}/geometry"] = np.array([seed, sw, sh, w0, h0, mips], np.uint32)
+        print("pyramid %4dx%-4d -> %4dx%-4d, %2d mips, %7d texels" % (sw, sh, w0, h0, mips, pyr.size))
+    if "--no-1080p" not in sys.argv:
+        depth, (w0, h0, mips), pyr = pyramid_case(17, 1920, 1080)
+        out["1920x1080/geometry"] = np.array([17, 1920, 1080, w0, h0, mips], np.uint32)
+        out["1920x1080/spv_pyramid_sha256"] = np.frombuffer(hashlib.sha256(pyr.tobytes()).digest(), np.uint8)
+        out["1920x1080/depth_sha256"] = np.frombuffer(hashlib.sha256(depth.tobytes()).digest(), np.uint8)
+        print("pyramid 1920x1080 -> %dx%d, %d mips, sha256 %s" % (w0, h0, mips, hashlib.sha256(pyr.tobytes()).hexdigest()))
+    path = os.path.join(HERE, "spirv_pyramid.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
+def compact_main():
+    """tests/golden/spirv_compact.npz: active_cluster_compaction.comp.spv (integer-only; a 4x4x4-workgroup dispatch
+    whose last workgroup writes the indirect-dispatch header) on the tile masks the mark_active binary produced for
+    the five cluster scenes: the header {ceil(n / 256), 1, 1, n} and the list IN THE ORDER OF THE BINARY'S ATOMIC
+    APPENDS as the interpreter schedules them (workgroup-major).  On hardware that order is nondeterministic: the
+    list is compared as a multiset (the oracle's and the product's canonical order is ascending cluster index)."""
+    st = np.load(os.path.join(HERE, "spirv_cluster.npz"))
+    out = {}
+    for name in ("s1", "s2", "s4", "s5", "s6"):
+        masks = st[f"{name}/spv_masks"]
+        cc = [int(v) for v in st[f"{name}/push"].view(L.MARK_ACTIVE_PUSH)[0]["cluster_count"]]
+        total = cc[0] * cc[1] * cc[2]
+        B = {1: masks.view(np.uint8).copy(), 2: np.zeros(16 + 4 * total, np.uint8)}
+        vm.Machine(vm.Module(CREF + "active_cluster_compaction.comp.spv"), B, np.array(cc + [1, 2], np.uint32).tobytes(),
+                   log2, subgroup=32).run(((cc[0] + 3) // 4, (cc[1] + 3) // 4, (cc[2] + 3) // 4), batch=64)
+        n = int(B[2][12:16].view(np.uint32)[0])
+        out[f"{name}/cluster_count"], out[f"{name}/masks"] = np.array(cc, np.uint32), masks
+        out[f"{name}/spv_unique"] = B[2][:16 + 4 * n].copy()
+        print("compaction %s: %d active clusters of %d" % (name, n, total))
+    path = os.path.join(HERE, "spirv_compact.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "pyramid":
+        return pyramid_main()
+    if len(sys.argv) > 1 and sys.argv[1] == "compact":
+        return compact_main()
     out, summary = {}, []
     cl = {}
     for seed, quantised, samples in ((1, False, 1), (2, True, 1), (4, True, 1), (5, False, 4), (6, "knife", 1)):

@@ -113,3 +113,60 @@ def test_oracle_equals_the_cluster_binaries(oracle, cluster_vectors, name):
     assert dropped == 0 and nl > 10 and np.array_equal(ol[:4 + 4 * nl], c["spv_light_list"])
     active = ou[16:16 + 4 * na].view(np.uint32)
     assert np.array_equal(oimg[active], c["spv_offset_image"][active])
+
+
+# ----------------------------------------------------------------------------- depth_reduce.comp.spv, compaction binary
+PYR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spirv_pyramid.npz")
+COMPACT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spirv_compact.npz")
+PYR_SMALL = ["200x120", "97x61", "33x257", "16x9", "1x1", "64x64"]
+
+
+def pyramid_1080p_input():
+    """The 1920x1080 case's depth buffer, regenerated from its seed (13.9 MB of arrays are not stored); its SHA-256 is."""
+    import hashlib
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_spirv_vectors as gen
+
+    v = np.load(PYR)
+    seed, sw, sh, w0, h0, mips = (int(x) for x in v["1920x1080/geometry"])
+    depth = gen.pyramid_depth(seed, sw, sh)
+    assert hashlib.sha256(depth.tobytes()).digest() == v["1920x1080/depth_sha256"].tobytes(), "the generator changed"
+    return depth, (sw, sh, w0, h0, mips), v["1920x1080/spv_pyramid_sha256"].tobytes()
+
+
+@pytest.mark.parametrize("name", PYR_SMALL)
+def test_oracle_pyramid_equals_the_depth_reduce_binary(oracle, name):
+    """depth_reduce.comp.spv executed level by level (make_spirv_vectors.py pyramid): which invocations write, the
+    coordinate (vec2(pos) + 0.5) / vec2(dimensions) as the binary computes it, the chaining of the levels — on odd,
+    non-power-of-two, tiny and tall screens.  (The sampler's footprint is the model the interpreter was handed.)"""
+    v = np.load(PYR)
+    seed, sw, sh, w0, h0, mips = (int(x) for x in v[f"{name}/geometry"])
+    pyr, desc = oracle.depth_reduce(v[f"{name}/depth"], sw, sh)
+    assert (int(desc.width), int(desc.height), int(desc.mip_levels)) == (w0, h0, mips)
+    assert np.array_equal(pyr.view(np.uint32).reshape(-1), v[f"{name}/spv_pyramid"].view(np.uint32))
+
+
+def test_oracle_pyramid_1080p_equals_the_depth_reduce_binary(oracle):
+    """BASELINE config 3's screen: level 0 is the 1920x1080 -> 1024x1024 fractional-footprint step."""
+    import hashlib
+
+    depth, (sw, sh, w0, h0, mips), want = pyramid_1080p_input()
+    pyr, desc = oracle.depth_reduce(depth, sw, sh)
+    assert (int(desc.width), int(desc.height), int(desc.mip_levels)) == (w0, h0, mips) == (1024, 1024, 11)
+    assert hashlib.sha256(np.ascontiguousarray(pyr).tobytes()).digest() == want
+
+
+@pytest.mark.parametrize("name", ["s1", "s2", "s4", "s5", "s6"])
+def test_oracle_compaction_equals_the_binary_as_a_multiset(oracle, name):
+    """active_cluster_compaction.comp.spv: same header, same clusters.  The binary's list is in the order of its atomic
+    appends (nondeterministic on hardware); the oracle's is ascending — compared sorted."""
+    v = np.load(COMPACT)
+    cc = [int(x) for x in v[f"{name}/cluster_count"]]
+    spv = v[f"{name}/spv_unique"]
+    ou, dropped = oracle.cluster_compact(cc, v[f"{name}/masks"], cc[0] * cc[1] * cc[2])
+    n = int(spv[12:16].view(np.uint32)[0])
+    assert dropped == 0 and n > 100 and np.array_equal(ou[:16], spv[:16])
+    got, want = ou[16:16 + 4 * n].view(np.uint32), spv[16:16 + 4 * n].view(np.uint32)
+    assert np.array_equal(np.sort(want), got) and len(np.unique(want)) == n

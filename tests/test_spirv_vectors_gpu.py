@@ -109,3 +109,71 @@ def test_product_task_path_equals_the_task_shader_binary(torch_mod, vectors, nam
     if p == 2:
         assert np.array_equal(host(mvis, np.uint32), c["spv_task_mvis"])
     eng.close()
+
+
+# ----------------------------------------------------------------------------- depth_reduce / compaction binaries
+from test_spirv_vectors_cpu import COMPACT, PYR, PYR_SMALL, pyramid_1080p_input  # noqa: E402
+
+
+@pytest.mark.parametrize("name", PYR_SMALL)
+def test_product_pyramid_equals_the_depth_reduce_binary(torch_mod, name):
+    """orbit_depth_reduce against depth_reduce.comp.spv's own pyramids (tests/golden/spirv_pyramid.npz)."""
+    from orbit_amd.engine import Engine, depth_pyramid_desc
+
+    torch = torch_mod
+    v = np.load(PYR)
+    seed, sw, sh, w0, h0, mips = (int(x) for x in v[f"{name}/geometry"])
+    d = depth_pyramid_desc(sw, sh)
+    assert (d.width, d.height, d.mip_levels) == (w0, h0, mips)
+    eng = Engine(0)
+    pyr = torch.full((d.total_texels + 64,), -1.0, dtype=torch.float32, device="cuda")
+    eng.depth_reduce(dev(torch, v[f"{name}/depth"]), sw, sh, pyr)
+    torch.cuda.synchronize()
+    eng.status()
+    got = host(pyr, np.uint32)
+    assert np.array_equal(got[:d.total_texels], v[f"{name}/spv_pyramid"].view(np.uint32))
+    assert (got[d.total_texels:] == np.float32(-1.0).view(np.uint32)).all(), "written past the pyramid"
+    eng.close()
+
+
+def test_product_pyramid_1080p_equals_the_depth_reduce_binary(torch_mod):
+    """The 1920x1080 -> 1024x1024 level 0 (fractional footprint) and the ten levels above it."""
+    import hashlib
+
+    from orbit_amd.engine import Engine, depth_pyramid_desc
+
+    torch = torch_mod
+    depth, (sw, sh, w0, h0, mips), want = pyramid_1080p_input()
+    d = depth_pyramid_desc(sw, sh)
+    assert (d.width, d.height, d.mip_levels) == (w0, h0, mips)
+    eng = Engine(0)
+    pyr = torch.zeros(d.total_texels, dtype=torch.float32, device="cuda")
+    eng.depth_reduce(dev(torch, depth), sw, sh, pyr)
+    torch.cuda.synchronize()
+    eng.status()
+    assert hashlib.sha256(pyr.cpu().numpy().tobytes()).digest() == want
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["s1", "s2", "s4", "s5", "s6"])
+def test_product_compaction_equals_the_binary_as_a_multiset(torch_mod, name):
+    """orbit_cluster_compact against active_cluster_compaction.comp.spv: same header, same clusters (the binary's list
+    is in the order of its atomic appends; the product's is ascending)."""
+    from orbit_amd.engine import Engine
+
+    torch = torch_mod
+    v = np.load(COMPACT)
+    cc = [int(x) for x in v[f"{name}/cluster_count"]]
+    spv = v[f"{name}/spv_unique"]
+    total = cc[0] * cc[1] * cc[2]
+    eng = Engine(0, max_clusters=total)
+    out = torch.zeros(16 + 4 * total, dtype=torch.uint8, device="cuda")
+    eng.cluster_compact(cc, dev(torch, v[f"{name}/masks"]), out, total)
+    torch.cuda.synchronize()
+    eng.status()
+    got = host(out)
+    n = int(spv[12:16].view(np.uint32)[0])
+    assert np.array_equal(got[:16], spv[:16])
+    ids = got[16:16 + 4 * n].view(np.uint32)
+    assert np.array_equal(ids, np.sort(spv[16:16 + 4 * n].view(np.uint32))) and (np.diff(ids.astype(np.int64)) > 0).all()
+    eng.close()

@@ -145,3 +145,15 @@ def test_config1_bitset_is_what_the_entity_cull_binary_keeps(placement):
     want = np.flatnonzero(np.unpackbits(g["bitset"].view(np.uint8), bitorder="little")[:n])
     assert len(recs) == int(g["count"]) and np.array_equal(recs["entity_index"], want)
     assert bool((recs["meshlet_count"] == 1).all()) and np.array_equal(recs["meshlet_offset"], want)
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference's shader binaries are not on this machine")
+def test_rerunning_the_depth_reduce_binary_reproduces_the_committed_pyramids():
+    import make_spirv_vectors as gen
+
+    st = np.load(os.path.join(HERE, "golden", "spirv_pyramid.npz"))
+    for name in ("200x120", "33x257", "16x9"):
+        seed, sw, sh, w0, h0, mips = (int(x) for x in st[f"{name}/geometry"])
+        depth, geo, pyr = gen.pyramid_case(seed, sw, sh)
+        assert geo == (w0, h0, mips) and np.array_equal(depth, st[f"{name}/depth"])
+        assert np.array_equal(pyr.view(np.uint32), st[f"{name}/spv_pyramid"].view(np.uint32))
