@@ -203,13 +203,15 @@ class Machine:
     """Runs entry point `main` of a Module for whole workgroups."""
 
     def __init__(self, module, buffers, push, log2, images=None, samplers=None, sample=None, subgroup=32,
-                 fused_dot=False):
+                 fused_dot=False, unfused_fma=False):
         """fused_dot: evaluate Dot / MatrixTimesVector / Length as fma chains (a0*b0, then fma(a1, b1, acc), ...) —
         what AMD's and other drivers' compilers typically emit — instead of the canonical separately rounded sums.
-        Only tools/spirv_sensitivity.py uses it, to measure how much of the output depends on that driver choice."""
+        unfused_fma: evaluate GLSL.std.450 Fma as a rounded product followed by a rounded sum — what a driver MAY do
+        with an Fma that is not decorated NoContraction (the binaries' are not).
+        Only tools/spirv_sensitivity.py uses them, to measure how much of the output depends on those driver choices."""
         self.m, self.buffers, self.push = module, buffers, np.frombuffer(bytes(push), np.uint8).copy()
         self.log2, self.images, self.samplers, self.sample, self.S = log2, images or {}, samplers or {}, sample, subgroup
-        self.fused_dot = fused_dot
+        self.fused_dot, self.unfused_fma = fused_dot, unfused_fma
 
     # -- values -----------------------------------------------------------------------------------------------------
     def const(self, cid, N):
@@ -364,8 +366,10 @@ class Machine:
             return np.where(a[2] < t, a[2], t)
         if num == 44: return np.minimum(np.maximum(x, a[1]), a[2])
         if num == 45: return np.minimum(np.maximum(x, a[1]), a[2])
-        if num == 50: return fma32(x, a[1], a[2]) if x.ndim == 1 else np.stack(
-            [fma32(x[:, k], a[1][:, k], a[2][:, k]) for k in range(x.shape[1])], axis=1)
+        if num == 50:
+            if self.unfused_fma: return ((x * a[1]).astype(F32) + a[2]).astype(F32)
+            return fma32(x, a[1], a[2]) if x.ndim == 1 else np.stack(
+                [fma32(x[:, k], a[1][:, k], a[2][:, k]) for k in range(x.shape[1])], axis=1)
         if num == 66: return np.sqrt(self.dot(x, x)).astype(F32) if x.ndim == 2 else np.abs(x)
         if num == 67:
             d = (x - a[1]).astype(F32)
