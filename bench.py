@@ -60,6 +60,11 @@ def parse():
                     help="what the streaming evaluation reads: the derived meshlet streams (22 B per meshlet — 20.25 B "
                          "with their alpha classes — built once from the meshlet buffer before the timed region; "
                          "include/orbit_abi.h) or the 32-B Meshlet buffer itself")
+    ap.add_argument("--scene-shape", choices=("scattered", "coherent"), default="scattered",
+                    help="how the ~10 %% survivors lie: scattered uniformly over every entity's meshlets (default, the "
+                         "worst case for everything that touches survivors), or coherent — every entity a ball whose "
+                         "camera-facing cap survives: runs of neighbouring meshlets, records without any "
+                         "(orbit_amd/synth.py)")
     ap.add_argument("--no-alpha-classes", action="store_true",
                     help="stream source without orbit_meshlet_stream_set_materials: the evaluation reads the 2-B "
                          "material index of every meshlet (22 B per meshlet)")
@@ -191,7 +196,7 @@ def main():
     t0 = time.time()
     draws, mesh, ent, half = synth.gen_entity_tables(spec, dev)
     mb, me = (0, E) if do_expand else (b, e)
-    meshlets = synth.gen_meshlets(spec, mb, me, dev, half, survive_target=args.survive)
+    meshlets = synth.gen_meshlets(spec, mb, me, dev, half, survive_target=args.survive, shape=args.scene_shape)
     materials = synth.gen_materials(spec, dev)
     torch.cuda.synchronize()
     gen_s = time.time() - t0
@@ -623,13 +628,14 @@ def main():
             "config": {
                 "workload": f"config5: {E} entities x {M} = {E * M} synthetic meshlets, entity_cull + meshlet_cull, "
                             f"frustum + normal cone (occlusion_pass 0), all entities in view, "
-                            f"{100.0 * tot_draw / max(tot_in, 1):.1f}% survivors"
+                            f"{100.0 * tot_draw / max(tot_in, 1):.1f}% survivors ({args.scene_shape})"
                             + ((", + rank-ordered all-gather of the visible list (8-B items, expanded to commands on "
                                 "every GPU)" if visible_exchange else ", + rank-ordered all-gather of the 28-B command lists")
                                + (" by direct xGMI stores at device-computed offsets, counts / completion over the "
                                   "process group" if transport == "p2p" else " by RCCL send/recv")
                                if do_gather else ""),
                 "entities": E, "meshlets": E * M, "meshlets_into_meshlet_cull": tot_in, "survivors": tot_draw,
+                "scene_shape": args.scene_shape,
                 "sharding": f"entity ranges over {world} rank(s)", "gather": bool(do_gather),
                 "frames_in_flight": F,
                 "settle_ms": args.settle_ms, "settle_frames": settle_frames,

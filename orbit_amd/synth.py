@@ -131,14 +131,21 @@ def gen_entity_tables(spec: C5Spec, device):
 
 
 def gen_meshlets(spec: C5Spec, first_entity, last_entity, device, half, survive_target=0.10, chunk=2_000_000,
-                 layout="uploaded"):
+                 layout="uploaded", shape="scattered"):
     """Meshlet[] (32 B each) of entities [first_entity, last_entity), generated in chunks.
 
     layout "uploaded": vertex_offset / data_offset as compute_meshlets + GpuAssets::add_mesh produce them
     (src/assets/mesh.rs:309-316, assets/mod.rs:413-416) — every entity's mesh is an allocation of its own
     (80 data words per meshlet reserved), a meshlet's data follows its predecessor's (vertex_count +
     ceil(3 * triangle_count / 4) words), vertex_offset is per submesh, two submeshes per mesh (the second one
-    starts at meshlet 25/64 * M, inside a dispatch record).  "scattered": offsets that follow no rule."""
+    starts at meshlet 25/64 * M, inside a dispatch record).  "scattered": offsets that follow no rule.
+
+    shape "scattered" (the headline scene): centres, cone axes and cutoffs independent per meshlet, so the ~10 % that
+    survive are scattered uniformly over every entity's meshlets — the worst case for everything that touches
+    survivors.  "coherent": every entity is a ball whose meshlets follow a spiral from pole to pole (sqrt(pi M) / 2 turns) —
+    centre on the surface, cone axis = the outward normal, one cutoff for all — so that, as with a real mesh and a
+    real camera, the survivors are the cap that faces the camera: runs of neighbouring meshlets, whole records
+    with none."""
     M, S = spec.meshlets_per_entity, spec.seed
     n = (last_entity - first_entity) * M
     chunk = max(M, chunk // M * M)  # whole entities per chunk
@@ -152,14 +159,26 @@ def gen_meshlets(spec: C5Spec, first_entity, last_entity, device, half, survive_
         mid = torch.arange(first_entity * M + c0, first_entity * M + c1, dtype=torch.int64, device=device)
         o = out[c0:c1]
         of = o.view(torch.float32)
-        for a in range(3):
-            of[:, a] = (rnd_f32(S, 10 + a, mid) * 2.0 - 1.0) * half
-        of[:, 3] = 0.1 + rnd_f32(S, 13, mid) * 0.5
-        v = torch.stack([rnd_f32(S, 14 + a, mid) * 2.0 - 1.0 for a in range(3)], dim=1)
-        nrm = torch.sqrt((v * v).sum(dim=1))
-        nrm = torch.where(nrm == 0, torch.ones_like(nrm), nrm)
-        q = (torch.clamp(v / nrm[:, None], -1.0, 1.0) * 127.0).to(torch.int32) & 0xFF  # trunc, math.rs:201-203
-        cut = rnd_int(S, 17, mid, -127, hi_cut).to(torch.int32) & 0xFF
+        if shape == "coherent":
+            li = (mid % M).to(torch.float32)
+            zc = 1.0 - 2.0 * (li + 0.5) / M
+            rc = torch.sqrt(torch.clamp(1.0 - zc * zc, min=0.0))
+            phi = li * (2.0 * math.pi * round(math.sqrt(M * math.pi) / 2.0) / M)  # neighbours in index are neighbours on the ball
+            v = torch.stack([rc * torch.cos(phi), zc, rc * torch.sin(phi)], dim=1)
+            of[:, 0:3] = v * (0.8 * half)
+            of[:, 3] = 0.05 + rnd_f32(S, 13, mid) * 0.1
+            q = (torch.clamp(v, -1.0, 1.0) * 127.0).to(torch.int32) & 0xFF
+            # survivors: dot(view direction, normal) < cutoff, i.e. a cap of (1 + cutoff) / 2 of the ball
+            cut = torch.full_like(mid, max(-126, min(127, int(round((2.0 * keep - 1.0) * 127.0))))).to(torch.int32) & 0xFF
+        else:
+            for a in range(3):
+                of[:, a] = (rnd_f32(S, 10 + a, mid) * 2.0 - 1.0) * half
+            of[:, 3] = 0.1 + rnd_f32(S, 13, mid) * 0.5
+            v = torch.stack([rnd_f32(S, 14 + a, mid) * 2.0 - 1.0 for a in range(3)], dim=1)
+            nrm = torch.sqrt((v * v).sum(dim=1))
+            nrm = torch.where(nrm == 0, torch.ones_like(nrm), nrm)
+            q = (torch.clamp(v / nrm[:, None], -1.0, 1.0) * 127.0).to(torch.int32) & 0xFF  # trunc, math.rs:201-203
+            cut = rnd_int(S, 17, mid, -127, hi_cut).to(torch.int32) & 0xFF
         o[:, 4] = q[:, 0] | (q[:, 1] << 8) | (q[:, 2] << 16) | (cut << 24)
         mat = rnd_int(S, 20, mid, 0, spec.materials - 1)
         vc = rnd_int(S, 21, mid, 3, 64)

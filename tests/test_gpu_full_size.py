@@ -40,7 +40,7 @@ def popcount32(torch, words):
 class Frame:
     """Device buffers of one config-5 scene and the launches over them."""
 
-    def __init__(self, torch, entities, meshlet_stream=False):
+    def __init__(self, torch, entities, meshlet_stream=False, shape="scattered", classes=False):
         from orbit_amd import synth
         from orbit_amd.engine import Engine
 
@@ -49,13 +49,17 @@ class Frame:
         self.spec = spec = synth.C5Spec(entities=entities)
         E, M = spec.entities, spec.meshlets_per_entity
         self.draws, self.mesh, self.ent, half = synth.gen_entity_tables(spec, dev)
-        self.meshlets = synth.gen_meshlets(spec, 0, E, dev, half, survive_target=0.095)
+        self.meshlets = synth.gen_meshlets(spec, 0, E, dev, half, survive_target=0.095, shape=shape)
         self.materials = synth.gen_materials(spec, dev)
         self.disp_cap = E * spec.records_per_entity + 8
         self.draw_cap = E * M // 2 + 1024
         self.eng = Engine(0, max_entities=E + 256, max_dispatches=self.disp_cap, max_draws=self.draw_cap)
         if meshlet_stream:  # passes 0 and 2 cull from the derived meshlet streams (include/orbit_abi.h)
-            self.eng.bind_meshlet_stream(self.eng.meshlet_stream(self.meshlets, 0, E * M))
+            ms = self.eng.meshlet_stream(self.meshlets, 0, E * M)
+            if classes:  # ... and from their alpha classes: no material index is read
+                ms.set_materials(self.materials, spec.materials)
+                torch.cuda.synchronize()
+            self.eng.bind_meshlet_stream(ms)
         self.cam = sc.default_camera(position=(0.0, 0.0, 1300.0))
         self.evis = torch.zeros((E + 31) // 32, dtype=torch.int32, device=dev)
         self.mvis = torch.zeros(E * spec.vis_words_per_entity, dtype=torch.int32, device=dev)
@@ -153,6 +157,52 @@ def test_config5_properties(torch_mod, oracle, entities, meshlet_stream):
         assert (f.eng.meshlet_stream_culls() > 0) == meshlet_stream
     finally:
         f.close()
+
+
+@pytest.mark.parametrize("entities", [3000, 195_313])
+def test_config5_coherent_survivors(torch_mod, oracle, entities):
+    """The second scene shape of config 5 (orbit_amd/synth.py, shape "coherent": every entity a ball, survivors = the
+    cap that faces the camera, i.e. runs of neighbouring meshlets and records without any): from the derived streams
+    with their alpha classes the list equals the Meshlet-buffer path's — and the oracle's on the small scene —, is in
+    canonical order, and shards concatenate."""
+    torch = torch_mod
+    f = Frame(torch, entities, True, shape="coherent", classes=True)
+    g = Frame(torch, entities, False, shape="coherent") if entities <= 5000 else None
+    try:
+        E, M = f.spec.entities, f.spec.meshlets_per_entity
+        disp, draw, cmds = f.cull(0)
+        n0 = len(cmds)
+        assert 0.05 * E * M < n0 < 0.2 * E * M
+        assert f.eng.meshlet_class_culls() == 1
+        key = cmds[:, 4].to(torch.int64) * (1 << 32) + (cmds[:, 6].to(torch.int64) & 0xFFFFFFFF)
+        assert bool((key[1:] > key[:-1]).all())
+        # coherent: far fewer runs than survivors, and a good part of the records draws nothing
+        idx = cmds[:, 6].to(torch.int64)
+        runs = int((idx[1:] != idx[:-1] + 1).sum().item()) + 1
+        assert n0 / runs > 2.0
+        n_rec = int(disp[:4].view(torch.int32).item())
+        assert int(torch.unique(idx >> 5).numel()) < 0.8 * n_rec
+        if g is not None:
+            _, draw_b, cmds_b = g.cull(0)
+            assert torch.equal(cmds_b, cmds)
+            h = lambda t: t.cpu().numpy()
+            ci0 = f.ci(0)
+            odisp, _, _ = oracle.entity_cull(ci0, h(f.draws), E, h(f.mesh).view(L.MESH_INFO), h(f.ent).view(L.ENTITY_DATA),
+                                             f.disp_cap)
+            odraw, _, _ = oracle.meshlet_cull(ci0, odisp, h(f.meshlets).view(L.MESHLET), f.draw_cap,
+                                              h(f.ent).view(L.ENTITY_DATA), h(f.materials).view(L.MATERIAL))
+            assert np.array_equal(h(draw)[:L.DRAW_HEADER + 28 * n0], odraw[:L.DRAW_HEADER + 28 * n0])
+        from orbit_amd import dist as odist
+
+        parts = []
+        for b, e in odist.shard_ranges(E, 8):
+            _, _, c = f.cull(0, first=b, count=e - b)
+            parts.append(c.clone())
+        assert torch.equal(torch.cat(parts), cmds)
+    finally:
+        f.close()
+        if g is not None:
+            g.close()
 
 
 @pytest.mark.parametrize("meshlet_stream", SOURCES, ids=SOURCE_IDS)
