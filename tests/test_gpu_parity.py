@@ -1167,3 +1167,63 @@ def test_views_and_batched_pyramids_replay_as_a_graph(torch_mod, oracle):
             assert_same((host(views[k]["meshlet_dispatch_buffer"]), host(views[k]["draw_commands_buffer"]),
                          host(evis[k], np.uint32), host(mvis[k], np.uint32)), ref)
     eng.close()
+
+
+def test_cull_views_late_pass_views_with_their_own_pyramids(torch_mod, oracle):
+    """The late half of a frame as ONE chain: orbit_depth_reduce_multi builds the views' pyramids (one launch pair),
+    orbit_cull_views runs their pass-2 culls (VisibilityWrite: HiZ test, bits written) side by side — the main view
+    (perspective) and two orthographic views, each against its own pyramid and its own bitsets, from the Meshlet buffer
+    and from the derived streams.  Every view equals the oracle's single-view result."""
+    torch = torch_mod
+    from orbit_amd.engine import Engine, depth_pyramid_desc
+
+    scene = sc.make_scene(19, 1800, n_meshes=300, extent=(50.0, 10.0, 50.0))
+    gs = GpuScene(torch, scene)
+    cam = sc.default_camera()
+    rng = np.random.default_rng(19)
+    screens = [(640, 360), (256, 256), (200, 120)]
+    depths = [(rng.random((h, w)) * 0.02).astype(np.float32) for (w, h) in screens]
+    for dpt in depths:  # far everywhere (reverse-Z: small), a near wall over part of the screen
+        dpt[:, : dpt.shape[1] // 3] = 0.35
+    descs = [depth_pyramid_desc(w, h) for (w, h) in screens]
+    ortho = dict(projection_type=1, p00=1.0 / 40, p11=1.0 / 40, z_near=0.5, z_far=120.0)
+    cis = [sc.make_cull_info(cam.view, cam.planes, occlusion_pass=2, p00=cam.p00, p11=cam.p11, z_near=cam.z_near),
+           sc.make_cull_info(cam.view, cam.planes[:4], occlusion_pass=2, **ortho),
+           sc.make_cull_info(sc.translation(3.0, -1.0, -20.0), cam.planes[:2], occlusion_pass=2, **ortho)]
+    evis = [rng.integers(0, 2 ** 32, (scene.entity_draw_count + 31) // 32, dtype=np.uint32) for _ in cis]
+    mvis = [rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32) for _ in cis]
+    eng = Engine(0, max_entities=8192, max_dispatches=40_000, max_draws=200_000, max_views=3)
+    disp_cap, draw_cap = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
+    for source in ("meshlet_buffer", "meshlet_stream"):
+        if source == "meshlet_stream":
+            eng.bind_meshlet_stream(eng.meshlet_stream(gs.meshlets, 0, len(scene.meshlets)))
+        pyrs = [torch.zeros(d.total_texels, dtype=torch.float32, device="cuda") for d in descs]
+        gdepths = [dev(torch, d).view(torch.float32) for d in depths]
+        views, bufs = [], []
+        for k, ci in enumerate(cis):
+            disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device="cuda")
+            draw = torch.zeros(L.DRAW_HEADER + 28 * draw_cap, dtype=torch.uint8, device="cuda")
+            e_d, m_d = dev(torch, evis[k]), dev(torch, mvis[k])
+            bufs.append((disp, draw, e_d, m_d))
+            views.append(dict(cull_info=ci, entity_draw_buffer=gs.draws, mesh_info_buffer=gs.mesh_infos,
+                              meshlet_dispatch_buffer=disp, entity_buffer=gs.entities,
+                              entity_draw_count=scene.entity_draw_count, dispatch_capacity=disp_cap,
+                              meshlet_buffer=gs.meshlets, draw_commands_buffer=draw, material_buffer=gs.materials,
+                              draw_capacity=draw_cap, visibility_buffer=e_d, meshlet_visibility_buffer=m_d,
+                              depth_pyramid=pyrs[k], depth_pyramid_size=(descs[k].width, descs[k].height)))
+        # the chain: 2 launches for the three pyramids, then the views' culls
+        eng.depth_reduce_multi([dict(depth=gdepths[k], width=screens[k][0], height=screens[k][1], pyramid=pyrs[k])
+                                for k in range(3)])
+        eng.cull_views(views)
+        torch.cuda.synchronize()
+        eng.status()
+        drawn = []
+        for k, (ci, (disp, draw, e_d, m_d)) in enumerate(zip(cis, bufs)):
+            opyr, _ = oracle.depth_reduce(depths[k], *screens[k])
+            assert np.array_equal(host(pyrs[k], np.uint32), opyr.view(np.uint32).reshape(-1))
+            ref = run_oracle(oracle, scene, ci, evis[k], mvis[k], opyr, (descs[k].width, descs[k].height))
+            _, cmds = assert_same((host(disp), host(draw), host(e_d, np.uint32), host(m_d, np.uint32)), ref)
+            drawn.append(len(cmds))
+        assert all(n > 0 for n in drawn), drawn
+        assert eng.meshlet_stream_culls() == (3 if source == "meshlet_stream" else 0)
+    eng.close()
