@@ -1082,31 +1082,38 @@ __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
 // instead and derives the rest, because the uploader lays a mesh's meshlets out as a chain (kernels.h
 // MeshletStreamView): data_offset[i + 1] = data_offset[i] + vertex_count[i] + ceil(3 * triangle_count[i] / 4), one
 // vertex_offset per submesh.
-//   phase A  lane = meshlet (the evaluation's row layout): data sizes from the counts, prefix sum inside each record
-//            (DPP, two rows per scan as 16-bit halves), {prefix, counts} of every lane and the records' totals to LDS;
-//            the survivors' (row, lane) codes compacted from the ballots.
+// The launch is bound by vector-instruction issue (profiles/r03_notes.md), so a wave works on a GROUP of two
+// consecutive wave tiles — 32 dispatch records — at a time: everything that is per record runs on 32 lanes instead of
+// 16, and everything that is per tile is paid once per two.
+//   phase A  lane = two neighbouring meshlets of a record (a 16-lane DPP row = one record, four records per
+//            instruction): data sizes from the counts (one 4-B load per lane), prefix sum inside each record (four
+//            DPP steps, two quad-rows per scan as 16-bit halves), {prefix, counts} of every meshlet and the records'
+//            totals to LDS; the survivors' (record, lane) codes peeled off the ballots in canonical order.
 //   phase B  lane = record: a record's base is the gathered {vertex_offset, data_offset} of its first meshlet where a
-//            chain starts (first record of the tile with survivors, a jump in meshlet_offset, a predecessor without
-//            survivors, a broken link since the predecessor's second meshlet: all known a tile ahead, so the gather
-//            is prefetched), else the predecessor's base + total — a segmented prefix sum over the 16 records.
+//            chain starts (first record of the group with survivors, a jump in meshlet_offset, a predecessor without
+//            survivors, a broken link since the predecessor's second meshlet: all known a group ahead, so the gather
+//            is prefetched), else the predecessor's base + total — a segmented prefix sum over the 32 records.
 //   phase C  lane = survivor: offsets = record base + prefix, valid while the record's link bits up to the lane are
 //            all set; the few survivors behind a broken link gather their own 8 B.  Commands go out through LDS as
 //            contiguous words (as in meshlet_emit_body).
-// Pipeline per wave: records, count, base, ballots three tiles ahead; link words two; counts and chain-start bases one.
+// Pipeline per wave: records and ballots three groups ahead; link words two; counts and chain-start bases one.
 // All loads are range-checked buffer loads (an offset outside the resource reads zero): no pointer selects, no
 // branches around loads, 32-bit address arithmetic, and the stream's coverage check comes for free.
+constexpr uint32_t kGroupTiles = 2, kGroupRecords = kGroupTiles * kTileRecords; // 32 records = 1024 meshlets
+
 struct __attribute__((aligned(16))) ChainLds {
-    uint4 rec[kTileRecords];      // phase B -> C: {data_offset base, vertex_offset, entity_index, meshlet_offset}
-    uint2 rs[kTileRecords];       // chain_stage: per record {byte offset of its first count, lanes to read}
-    uint32_t row[kTileRows * 64]; // phase A -> C, per (row, lane): size prefix inside the record | counts << 16
-    uint32_t link[kTileRecords];  // link bits of the record's 32 lanes
-    uint32_t tot[kTileRows];      // [pair * 2 + half]: data words of the records of rows pair / pair + 4 (16:16)
+    uint4 rec[kGroupRecords];            // phase B -> C: {data_offset base, vertex_offset, entity_index, meshlet_offset}
+    uint32_t rs[kGroupRecords];          // chain_stage: per record the byte offset of its first count (or "none")
+    uint32_t row[kGroupRecords * 32];    // phase A -> C, per (record, lane): size prefix inside the record | counts << 16
+    uint32_t link[kGroupRecords];        // link bits of the record's 32 lanes
+    uint32_t tot[kGroupRecords / 2];     // [quad-row pair * 4 + sub]: data words of records 4 q + sub / 4 (q + 4) + sub (16:16)
     uint32_t cmd[64 * 7];
-    uint16_t list[kTileRows * 64];
+    uint16_t list[kGroupRecords * 32];
 };
 
 constexpr uint32_t kBufFlags = 0x00020000u; // raw buffer, 32-bit data format
-constexpr uint32_t kNoOffset = 0xFFFFFFF0u; // beyond every resource of this launch (orbit_meshlet_stream_create bounds them)
+constexpr uint32_t kNoOffset = 0xFFFFFF00u; // beyond every resource of this launch, also after a lane's +60 bytes
+                                            // (orbit_meshlet_stream_create bounds the stream's arrays)
 
 struct ChainRsrc {
     __amdgpu_buffer_rsrc_t recs, counts, bases, masks; // the dispatch records, the scan scratch
@@ -1114,21 +1121,22 @@ struct ChainRsrc {
     uint32_t first, count, first_word;
 };
 
-struct ChainTile {
-    uint4 rec;      // lane = record (lanes 16.. repeat lanes 0..15)
-    uint32_t mword; // the record's should-draw ballot
-    uint32_t count, base;
+struct ChainGroup {
+    uint32_t ent, y, z; // lane = record of the group (lanes 32.. repeat lanes 0..31): entity, meshlet offset, count
+    uint32_t mword;     // the record's should-draw ballot
+    uint32_t count;     // lane & 1: survivors of the group's tile (lane & 1)
+    uint32_t base;      // chunk-local output slot of the group's first survivor
 };
 
-__device__ __forceinline__ ChainTile chain_prefetch(const ChainRsrc &B, uint32_t tile, int lane) {
-    ChainTile e;
-    const uint32_t t = tile < 0x00FFFFFFu ? tile : 0x00FFFFFFu; // keeps t * 256 out of range instead of wrapping
-    const uint32_t k = (uint32_t)lane & 15u;
-    const uint32_t ro = (t * kTileRecords + k) * 16u;
-    e.rec = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(B.recs, ro, 0, 0));
-    e.mword = __builtin_amdgcn_raw_buffer_load_b32(B.masks, (t * kTileRecords + k) * 4u, 0, 0);
-    e.count = __builtin_amdgcn_raw_buffer_load_b32(B.counts, t * 4u, 0, 0);
-    e.base = __builtin_amdgcn_raw_buffer_load_b32(B.bases, t * 4u, 0, 0);
+__device__ __forceinline__ ChainGroup chain_prefetch(const ChainRsrc &B, uint32_t group, int lane) {
+    ChainGroup e;
+    const uint32_t g = group < 0x007FFFFFu ? group : 0x007FFFFFu; // keeps g * 512 out of range instead of wrapping
+    const uint32_t k = (uint32_t)lane & 31u;
+    const auto r = __builtin_amdgcn_raw_buffer_load_b96(B.recs, (g * kGroupRecords + k) * 16u, 0, 0);
+    e.ent = r[0], e.y = r[1], e.z = r[2];
+    e.mword = __builtin_amdgcn_raw_buffer_load_b32(B.masks, (g * kGroupRecords + k) * 4u, 0, 0);
+    e.count = __builtin_amdgcn_raw_buffer_load_b32(B.counts, (g * kGroupTiles + ((uint32_t)lane & 1u)) * 4u, 0, 0);
+    e.base = __builtin_amdgcn_raw_buffer_load_b32(B.bases, g * kGroupTiles * 4u, 0, 0);
     return e;
 }
 
@@ -1137,53 +1145,60 @@ struct LinkStage {
 };
 
 struct ChainStage {
-    uint32_t cnt[kTileRows]; // per row: this lane's meshlet's vertex_count | triangle_count << 8 (0: not loaded)
-    uint32_t link32;         // lane = record: bit l = link bit of meshlet (meshlet_offset + l)
-    uint32_t bv, bd;         // lane = record: vertex_offset / data_offset of its first meshlet (chain starts only)
-    uint32_t flags;          // lane = record: 1 = has survivors (counts loaded), 2 = chain start (bv, bd loaded)
+    uint32_t c2[kGroupRecords / 4]; // per quad-row: the counts of this lane's two meshlets (16:16; 0: not loaded)
+    uint32_t link32;                // lane = record: bit l = link bit of meshlet (meshlet_offset + l)
+    uint32_t bv, bd;                // lane = record: vertex_offset / data_offset of its first meshlet (chain starts only)
+    uint32_t flags;                 // lane = record: 1 = has survivors (counts loaded), 2 = chain start (bv, bd loaded)
 };
 
 // lane = record: does the emit read this record at all?  Records without survivors are skipped; a record that begins
 // outside the stream reads zeros (ORBIT_E_RANGE is the evaluation's to latch).
-__device__ __forceinline__ bool chain_has(const ChainRsrc &B, const ChainTile &e) {
-    return e.mword != 0u && e.rec.z != 0u && e.rec.y - B.first < B.count;
+__device__ __forceinline__ bool chain_has(const ChainRsrc &B, const ChainGroup &e) {
+    return e.mword != 0u && e.z != 0u && e.y - B.first < B.count;
 }
 
-__device__ __forceinline__ LinkStage link_stage(const ChainRsrc &B, const ChainTile &e) {
-    const uint32_t wo = chain_has(B, e) ? ((e.rec.y >> 5) - B.first_word) * 4u : kNoOffset;
+__device__ __forceinline__ LinkStage link_stage(const ChainRsrc &B, const ChainGroup &e) {
+    const uint32_t wo = chain_has(B, e) ? ((e.y >> 5) - B.first_word) * 4u : kNoOffset;
     LinkStage k;
     k.l0 = __builtin_amdgcn_raw_buffer_load_b32(B.link, wo, 0, 0);
     k.l1 = __builtin_amdgcn_raw_buffer_load_b32(B.link, wo, 0 + 4, 0);
     return k;
 }
 
-__device__ __forceinline__ ChainStage chain_stage(const ChainRsrc &B, ChainLds &S, const ChainTile &e,
+// Lane i <- lane i - 1 of the wave (wave_shr:1); lane 0 gets `first`.
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t first) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xF, 0xF, false);
+}
+
+__device__ __forceinline__ ChainStage chain_stage(const ChainRsrc &B, ChainLds &S, const ChainGroup &e,
                                                   const LinkStage &k, int lane) {
     ChainStage s;
-    const uint32_t half = (uint32_t)lane >> 5, ml = (uint32_t)lane & 31u;
     const bool has = chain_has(B, e);
-    if (lane < (int)kTileRecords) S.rs[lane] = make_uint2((e.rec.y - B.first) * 2u, has ? e.rec.z : 0u);
+    if (lane < (int)kGroupRecords) S.rs[lane] = has ? (e.y - B.first) * 2u : kNoOffset;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint2 R[kTileRows];
+    // quad-row q: the wave's four 16-lane rows are records 4 q .. 4 q + 3, lane i of a row holds meshlets 2 i, 2 i + 1.
+    // Lanes past a record's count read its neighbours' counts (or zeros past the stream): they feed nothing that is
+    // used — a prefix of lanes behind them, and the total of a record that, being short, starts no continuation.
+    const uint32_t sub = (uint32_t)lane >> 4, i4 = ((uint32_t)lane & 15u) * 4u;
+    uint32_t off[kGroupRecords / 4];
 #pragma unroll
-    for (int r = 0; r < (int)kTileRows; r++) R[r] = S.rs[2 * r + half];
+    for (int q = 0; q < (int)kGroupRecords / 4; q++) off[q] = S.rs[4 * q + sub];
 #pragma unroll
-    for (int r = 0; r < (int)kTileRows; r++) {
-        const uint32_t off = ml < R[r].y ? R[r].x + ml * 2u : kNoOffset;
-        s.cnt[r] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(B.cnt, off, 0, 0);
-    }
-    // lane = record; row_shr stays inside a row of 16 lanes.  A record continues its predecessor's chain when that
-    // one was read too, ends where this one begins, and every link from the predecessor's second meshlet to this
-    // record's first one holds; otherwise it starts a chain from the gathered offsets of its first meshlet.
-    s.link32 = __funnelshift_r(k.l0, k.l1, e.rec.y & 31u);
-    const bool full = has && e.rec.z == 32u && (s.link32 | 1u) == 0xFFFFFFFFu; // the chain reaches the record's end
-    const uint32_t prev_y = row_shr1(e.rec.y, 0u), prev_full = row_shr1(full ? 1u : 0u, 0u);
-    const bool cont = has && prev_full != 0u && e.rec.y == prev_y + 32u && (s.link32 & 1u) != 0u;
+    for (int q = 0; q < (int)kGroupRecords / 4; q++)
+        s.c2[q] = __builtin_amdgcn_raw_buffer_load_b32(B.cnt, off[q] + i4, 0, 0);
+    // lane = record.  A record continues its predecessor's chain when that one was read too, ends where this one
+    // begins, and every link from the predecessor's second meshlet to this record's first one holds; otherwise it
+    // starts a chain from the gathered offsets of its first meshlet.
+    s.link32 = __funnelshift_r(k.l0, k.l1, e.y & 31u);
+    const bool full = has && e.z == 32u && (s.link32 | 1u) == 0xFFFFFFFFu; // the chain reaches the record's end
+    const uint32_t prev_y = wave_shr1(e.y, 0u), prev_full = wave_shr1(full ? 1u : 0u, 0u);
+    const bool first = ((uint32_t)lane & 31u) == 0u; // (lane 32 repeats record 0)
+    const bool cont = has && !first && prev_full != 0u && e.y == prev_y + 32u && (s.link32 & 1u) != 0u;
     const bool start = has && !cont;
     s.flags = (has ? 1u : 0u) | (start ? 2u : 0u);
-    const uint32_t co = start ? (e.rec.y - B.first) * 12u : kNoOffset;
+    const uint32_t co = start ? (e.y - B.first) * 12u : kNoOffset;
     s.bv = __builtin_amdgcn_raw_buffer_load_b32(B.cmd, co, 0, 0);
     s.bd = __builtin_amdgcn_raw_buffer_load_b32(B.cmd, co, 0 + 4, 0);
     return s;
@@ -1195,6 +1210,17 @@ __device__ __forceinline__ uint32_t chain_size2(uint32_t c2) {
     return vc + (((tc * 3u + 0x00030003u) >> 2) & 0x3FFF3FFFu);
 }
 
+// Inclusive scan (sum) inside each row of 16 lanes: row_shr 1 / 2 / 4 / 8.
+__device__ __forceinline__ uint32_t row_inclusive_scan(uint32_t v) {
+#define ORBIT_ROW_STEP(ctrl) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xF, 0xF, false)
+    ORBIT_ROW_STEP(0x111);
+    ORBIT_ROW_STEP(0x112);
+    ORBIT_ROW_STEP(0x114);
+    ORBIT_ROW_STEP(0x118);
+#undef ORBIT_ROW_STEP
+    return v;
+}
+
 __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams &p) {
     __shared__ ChainLds s_chain[4];
     __shared__ uint32_t s_chunk_base[kEmitChunkTable];
@@ -1203,7 +1229,9 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
     ChainLds &S = s_chain[wave];
     const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
     const uint32_t ntiles = (nrec + kTileRecords - 1) / kTileRecords;
+    const uint32_t ngroups = (ntiles + kGroupTiles - 1) / kGroupTiles;
     const uint32_t nchunks = (ntiles + kScanChunk - 1) / kScanChunk;
+    static_assert(kScanChunk % kGroupTiles == 0, "a group's tiles share a scan chunk: its survivors are contiguous");
     uint32_t grand_total = 0;
     for (uint32_t c0 = 0; c0 < nchunks; c0 += 256) { // block-uniform trip count
         const uint32_t c = c0 + threadIdx.x;
@@ -1223,83 +1251,98 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
     B.first = p.ms.first;
     B.count = p.ms.count;
     B.first_word = p.ms.first >> 5;
-    B.cnt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.ms.cnt + p.ms.first), 0, p.ms.count * 2u, kBufFlags);
+    // + 2 bytes: the 4-B load of a lane whose first meshlet is the stream's last one (the arrays are padded)
+    B.cnt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.ms.cnt + p.ms.first), 0, p.ms.count * 2u + 2u, kBufFlags);
     B.link = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.ms.link + B.first_word), 0,
                                                (((p.ms.first + p.ms.count + 31u) >> 5) - B.first_word + 2u) * 4u, kBufFlags);
     B.cmd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.ms.cmd + (size_t)p.ms.first * 3u), 0,
                                               p.ms.count * 12u, kBufFlags);
     uint32_t *out = reinterpret_cast<uint32_t *>(p.draw_buffer + ORBIT_DRAW_HEADER);
     const uint32_t stride = gridDim.x * 4;
-    const uint32_t half = (uint32_t)lane >> 5, ml = (uint32_t)lane & 31u;
-    uint32_t tile = blockIdx.x * 4 + wave;
-    ChainTile cur = chain_prefetch(B, tile, lane);
-    ChainTile nxt = chain_prefetch(B, tile + stride, lane);
-    ChainTile nn = chain_prefetch(B, tile + 2 * stride, lane);
+    const uint32_t sub = (uint32_t)lane >> 4, i16 = (uint32_t)lane & 15u;
+    uint32_t group = blockIdx.x * 4 + wave;
+    ChainGroup cur = chain_prefetch(B, group, lane);
+    ChainGroup nxt = chain_prefetch(B, group + stride, lane);
+    ChainGroup nn = chain_prefetch(B, group + 2 * stride, lane);
     ChainStage cs = chain_stage(B, S, cur, link_stage(B, cur), lane);
     LinkStage nk = link_stage(B, nxt);
-    for (; tile < ntiles; tile += stride) {
-        // a tile past the end reads zero records: nothing else is loaded for it
-        const ChainTile n3 = chain_prefetch(B, tile + 3 * stride, lane);
+    for (; group < ngroups; group += stride) {
+        // a group past the end reads zero records: nothing else is loaded for it
+        const ChainGroup n3 = chain_prefetch(B, group + 3 * stride, lane);
         const LinkStage nnk = link_stage(B, nn);
         const ChainStage ns = chain_stage(B, S, nxt, nk, lane);
-        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.count);
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)cur.count, 0) +
+                           (uint32_t)__builtin_amdgcn_readlane((int)cur.count, 1);
         if (n != 0u) {
             // wave-uniform, and provably so for the compiler (the store window's descriptor lives in SGPRs)
-            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur.base + s_chunk_base[tile / kScanChunk]));
-            // ---- phase A
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane(
+                (int)(cur.base + s_chunk_base[group * kGroupTiles / kScanChunk]));
+            // ---- phase A: quad-rows q and q + 4 share a scan (16-bit halves: a record's sizes sum to < 2^14)
 #pragma unroll
-            for (int pr = 0; pr < (int)kTileRows / 2; pr++) {
-                const uint32_t ca = cs.cnt[pr], cb = cs.cnt[pr + 4];
-                const uint32_t size2 = chain_size2(ca | (cb << 16));
-                const uint32_t incl2 = half_inclusive_scan(size2);
-                const uint32_t excl2 = incl2 - size2;
-                S.row[pr * 64 + lane] = (excl2 & 0xFFFFu) | (ca << 16);
-                S.row[(pr + 4) * 64 + lane] = (excl2 >> 16) | (cb << 16);
-                if (ml == 31u) S.tot[pr * 2 + half] = incl2;
+            for (int q = 0; q < (int)kGroupRecords / 8; q++) {
+                const uint32_t ca = cs.c2[q], cb = cs.c2[q + 4];
+                const uint32_t sa = chain_size2(ca), sb = chain_size2(cb);         // {first, second} meshlet of the lane
+                const uint32_t pa = (sa & 0xFFFFu) + (sa >> 16), pb = (sb & 0xFFFFu) + (sb >> 16);
+                const uint32_t pair = pa | (pb << 16);
+                const uint32_t incl = row_inclusive_scan(pair);
+                const uint32_t excl = incl - pair;
+                const uint32_t ea = excl & 0xFFFFu, eb = excl >> 16;
+                // per meshlet: prefix | counts << 16 (the second meshlet's prefix includes the first one's size)
+                uint2 wa, wb;
+                wa.x = ea | (ca << 16);
+                wa.y = ((ea + (sa & 0xFFFFu)) & 0xFFFFu) | (ca & 0xFFFF0000u);
+                wb.x = eb | (cb << 16);
+                wb.y = ((eb + (sb & 0xFFFFu)) & 0xFFFFu) | (cb & 0xFFFF0000u);
+                *reinterpret_cast<uint2 *>(&S.row[q * 128 + lane * 2]) = wa;       // record 4 q + sub, lanes 2 i, 2 i + 1
+                *reinterpret_cast<uint2 *>(&S.row[(q + 4) * 128 + lane * 2]) = wb;
+                if (i16 == 15u) S.tot[q * 4 + sub] = incl;
             }
-            // the survivors' codes (record * 32 + lane = row * 64 + lane of the evaluation's layout) in canonical
-            // order: lane i owns byte i & 3 of record i >> 2's ballot and peels its bits off one per trip
+            // the survivors' codes (record * 32 + lane) in canonical order: lane i owns half a record's ballot and
+            // peels its bits off one per trip
             {
-                const uint32_t w = (uint32_t)__shfl((int)cur.mword, lane >> 2, 64);
-                uint32_t byte = (w >> (8u * ((uint32_t)lane & 3u))) & 0xFFu;
-                const uint32_t pc = (uint32_t)__popc(byte);
+                const uint32_t w = (uint32_t)__shfl((int)cur.mword, lane >> 1, 64);
+                uint32_t bits = (w >> (16u * ((uint32_t)lane & 1u))) & 0xFFFFu;
+                const uint32_t pc = (uint32_t)__popc(bits);
                 uint32_t pos = wave_inclusive_scan(pc) - pc;
-                const uint32_t code0 = (uint32_t)lane * 8u;
-                while (__ballot(byte != 0u) != 0ull) {
-                    if (byte != 0u) {
-                        S.list[pos] = (uint16_t)(code0 + (uint32_t)__builtin_ctz(byte));
+                const uint32_t code0 = (uint32_t)lane * 16u;
+                while (__ballot(bits != 0u) != 0ull) {
+                    if (bits != 0u) {
+                        S.list[pos] = (uint16_t)(code0 + (uint32_t)__builtin_ctz(bits));
                         pos++;
-                        byte &= byte - 1u;
+                        bits &= bits - 1u;
                     }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // ---- phase B: lane = record
+            // ---- phase B: lane = record (32 of them; lanes 32.. repeat)
             {
-                const uint32_t k = (uint32_t)lane & 15u, krow = k >> 1;
-                const uint32_t tot = (S.tot[(krow & 3u) * 2u + (k & 1u)] >> (16u * (krow >> 2))) & 0xFFFFu;
-                const uint32_t prev_tot = row_shr1(tot, 0u);
+                const uint32_t k = (uint32_t)lane & 31u, kq = k >> 2;
+                const uint32_t tot = (S.tot[(kq & 3u) * 4u + (k & 3u)] >> (16u * (kq >> 2))) & 0xFFFFu;
+                const uint32_t prev_tot = wave_shr1(tot, 0u);
                 const bool cont = (cs.flags & 3u) == 1u; // has survivors and continues the predecessor's chain
                 uint32_t f = cont ? 0u : 1u;             // segment head
                 uint32_t a_d = f ? cs.bd : prev_tot, a_v = cs.bv; // bv / bd are zero unless the record starts a chain
-#define ORBIT_SEG_STEP(ctrl)                                                                                    \
+#define ORBIT_SEG_STEP(ctrl, rows)                                                                              \
     {                                                                                                           \
-        const uint32_t sd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a_d, ctrl, 0xF, 0xF, false);          \
-        const uint32_t sv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a_v, ctrl, 0xF, 0xF, false);          \
-        const uint32_t sf = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)f, ctrl, 0xF, 0xF, false);            \
+        const uint32_t sd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a_d, ctrl, rows, 0xF, false);         \
+        const uint32_t sv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a_v, ctrl, rows, 0xF, false);         \
+        const uint32_t sf = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, ctrl, rows, 0xF, false);           \
         a_d += f ? 0u : sd;                                                                                     \
         a_v += f ? 0u : sv;                                                                                     \
         f |= sf;                                                                                                \
     }
-                ORBIT_SEG_STEP(0x111)
-                ORBIT_SEG_STEP(0x112)
-                ORBIT_SEG_STEP(0x114)
-                ORBIT_SEG_STEP(0x118)
+                // (a lane without a source in a step keeps what it has: record 16 has no predecessor in its row of 16
+                // lanes and is still no head — its segment arrives with the row_bcast15 step)
+                ORBIT_SEG_STEP(0x111, 0xF)
+                ORBIT_SEG_STEP(0x112, 0xF)
+                ORBIT_SEG_STEP(0x114, 0xF)
+                ORBIT_SEG_STEP(0x118, 0xF)
+                ORBIT_SEG_STEP(0x142, 0xA) // row_bcast15: records 16..31 continue from record 15 (lanes 48.. from 47)
 #undef ORBIT_SEG_STEP
-                if (lane < (int)kTileRecords) {
-                    S.rec[lane] = make_uint4(a_d, a_v, cur.rec.x, cur.rec.y);
+                if (lane < (int)kGroupRecords) {
+                    S.rec[lane] = make_uint4(a_d, a_v, cur.ent, cur.y);
                     S.link[lane] = cs.link32;
                 }
             }
@@ -1307,7 +1350,7 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // ---- phase C: lane = survivor
-            for (uint32_t j0 = 0; j0 < n; j0 += 64) { // one trip unless more than 64 survivors
+            for (uint32_t j0 = 0; j0 < n; j0 += 64) {
                 const uint32_t j = j0 + (uint32_t)lane;
                 const uint32_t code = j < n ? S.list[j] : 0u;
                 const uint32_t rid = code >> 5, l = code & 31u;
@@ -1326,7 +1369,8 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
                     data = broken ? gd : data;
                 }
                 uint32_t vertex_count = (pk >> 16) & 0xFFu, triangle_count = pk >> 24;
-                if (!p.ms.covers(mi)) vtx = data = 0u; // ORBIT_E_RANGE, latched by the evaluation: the command carries zeros
+                // ORBIT_E_RANGE (latched by the evaluation): the command of a meshlet outside the stream carries zeros
+                if (!p.ms.covers(mi)) vtx = data = vertex_count = triangle_count = 0u;
                 uint32_t *c = S.cmd + lane * 7;
                 c[0] = triangle_count * 3u;         // cmd_index_count
                 c[1] = 1u;                          // cmd_instance_count
@@ -1350,7 +1394,7 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
                 }
                 __builtin_amdgcn_wave_barrier(); // cmd is rewritten by the next trip
             }
-            __builtin_amdgcn_wave_barrier(); // list / row / rec are reused by the next tile
+            __builtin_amdgcn_wave_barrier(); // list / row / rec are reused by the next group
         }
         cur = nxt;
         cs = ns;
@@ -1376,7 +1420,7 @@ __global__ __launch_bounds__(256) void meshlet_emit_views_kernel(const MeshletCu
 }
 // the chain emit is bound by instruction issue: kChainWavesPerSimd resident waves per SIMD (the register budget the
 // compiler gets) and exactly that many blocks per CU in the grid — a block more per CU would run as a second round
-constexpr int kChainWavesPerSimd = 5;
+constexpr int kChainWavesPerSimd = 4;
 __global__ __launch_bounds__(256, kChainWavesPerSimd) void meshlet_emit_chain_kernel(const MeshletCullParams p) {
     meshlet_emit_chain_body(p);
 }
@@ -1721,7 +1765,8 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t
         if (stream) hipLaunchKernelGGL((meshlet_emit_kernel<true, true>), dim3(eblocks), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((meshlet_emit_kernel<true, false>), dim3(eblocks), dim3(256), 0, s, p);
     } else if (stream) {
-        const uint32_t cblocks = max(min(num_cus * (uint32_t)kChainWavesPerSimd, eneed), 1u);
+        // a wave per group of two tiles
+        const uint32_t cblocks = max(min(num_cus * (uint32_t)kChainWavesPerSimd, (eneed + kGroupTiles - 1) / kGroupTiles), 1u);
         hipLaunchKernelGGL(meshlet_emit_chain_kernel, dim3(cblocks), dim3(256), 0, s, p);
     } else {
         hipLaunchKernelGGL((meshlet_emit_kernel<false, false>), dim3(eblocks), dim3(256), 0, s, p);
@@ -1811,7 +1856,8 @@ hipError_t launch_meshlet_cull_views(const MeshletCullViews &all, uint32_t n, ui
         if (m == 0) continue;
         if (stream)
             hipLaunchKernelGGL(meshlet_emit_chain_views_kernel,
-                               dim3(max(min(num_cus * (uint32_t)kChainWavesPerSimd / m, eneed), 1u), m), dim3(256), 0, s, all, g);
+                               dim3(max(min(num_cus * (uint32_t)kChainWavesPerSimd / m, (eneed + kGroupTiles - 1) / kGroupTiles), 1u), m),
+                               dim3(256), 0, s, all, g);
         else hipLaunchKernelGGL(meshlet_emit_views_kernel<false>, dim3(eblocks, m), dim3(256), 0, s, all, g);
         e = hipGetLastError();
         if (e != hipSuccess) return e;

@@ -17,3 +17,4 @@ for k, d in agg.items():
     for c, v in d.items():
         print(f"   {c:28s} n={len(v):3d} mean={sum(v)/len(v):.4g}")
 PY
+rm -rf $out  # the raw counter CSVs are tens of MB: only the summary above is kept (gpurun_out/ is capped at 64 MiB)

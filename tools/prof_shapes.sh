@@ -12,6 +12,7 @@ import json,sys
 d=json.load(open(sys.argv[1]))
 print(sys.argv[2], sys.argv[3], 'ms/step %.4f' % d['ms_per_step'], 'eval_ms %.4f' % d['roofline']['avg_launch_ms'], 'survivors', d['config']['survivors'])
 PY
+    find $out -name "*kernel_trace.csv" -delete
     f=$(find $out -name "*kernel_stats.csv" | head -1); grep orbit $f | sed 's/orbit::(anonymous namespace):://; s/(orbit::[A-Za-z]*)//' | cut -d, -f1-4 | head -6
   done
 done

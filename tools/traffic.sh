@@ -8,3 +8,4 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/p
 f=$(find $R/gpurun_out/pmc_fetch_$src -name "*counter_collection.csv" | head -1)
 w=$(find $R/gpurun_out/pmc_write_$src -name "*counter_collection.csv" | head -1)
 python3 $R/tools/traffic.py $f $w 195313 256 $src
+rm -rf $R/gpurun_out/pmc_fetch_$src $R/gpurun_out/pmc_write_$src  # raw counter CSVs: tens of MB
