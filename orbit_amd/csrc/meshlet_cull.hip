@@ -34,6 +34,8 @@
 //                sharded engine's 8-B visible list (<true>) with
 //                visible_expand_kernel on the receiving side, or per-record
 //                task payloads for the mesh-shading path (task_records_kernel).
+#include <type_traits>
+
 #include "kernels.h"
 #include "scan.h"
 
@@ -1100,13 +1102,16 @@ __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
 // All loads are range-checked buffer loads (an offset outside the resource reads zero): no pointer selects, no
 // branches around loads, 32-bit address arithmetic, and the stream's coverage check comes for free.
 constexpr uint32_t kGroupTiles = 2, kGroupRecords = kGroupTiles * kTileRecords; // 32 records = 1024 meshlets
+constexpr uint32_t kSlowWords = 32; // 1024 iterations per wave: more than any grid the library launches leaves a wave
 
 struct __attribute__((aligned(16))) ChainLds {
     uint4 rec[kGroupRecords];            // phase B -> C: {data_offset base, vertex_offset, entity_index, meshlet_offset}
+    uint2 rec2[kGroupRecords];           // ... behind the record's first broken link: {data_offset base, vertex_offset}
     uint32_t rs[kGroupRecords];          // chain_stage: per record the byte offset of its first count (or "none")
     uint32_t row[kGroupRecords * 32];    // phase A -> C, per (record, lane): size prefix inside the record | counts << 16
     uint32_t link[kGroupRecords];        // link bits of the record's 32 lanes
     uint32_t tot[kGroupRecords / 2];     // [quad-row pair * 4 + sub]: data words of records 4 q + sub / 4 (q + 4) + sub (16:16)
+    uint32_t slow[kSlowWords];           // bit i: the wave's i-th group needs the general form (process<!FAST>)
     uint32_t cmd[64 * 7];
     uint16_t list[kGroupRecords * 32];
 };
@@ -1148,6 +1153,7 @@ struct ChainStage {
     uint32_t c2[kGroupRecords / 4]; // per quad-row: the counts of this lane's two meshlets (16:16; 0: not loaded)
     uint32_t link32;                // lane = record: bit l = link bit of meshlet (meshlet_offset + l)
     uint32_t bv, bd;                // lane = record: vertex_offset / data_offset of its first meshlet (chain starts only)
+    uint32_t bv2, bd2;              // lane = record: those of the meshlet behind the record's first broken link, if any
     uint32_t flags;                 // lane = record: 1 = has survivors (counts loaded), 2 = chain start (bv, bd loaded)
 };
 
@@ -1163,6 +1169,12 @@ __device__ __forceinline__ LinkStage link_stage(const ChainRsrc &B, const ChainG
     k.l0 = __builtin_amdgcn_raw_buffer_load_b32(B.link, wo, 0, 0);
     k.l1 = __builtin_amdgcn_raw_buffer_load_b32(B.link, wo, 0 + 4, 0);
     return k;
+}
+
+// First lane of a record (1..31) whose link bit is clear, 32 if the links of lanes 1..31 all hold.
+__device__ __forceinline__ uint32_t chain_first_break(uint32_t link32) {
+    const uint32_t open = ~link32 & 0xFFFFFFFEu;
+    return open != 0u ? (uint32_t)__builtin_ctz(open) : 32u;
 }
 
 // Lane i <- lane i - 1 of the wave (wave_shr:1); lane 0 gets `first`.
@@ -1201,6 +1213,12 @@ __device__ __forceinline__ ChainStage chain_stage(const ChainRsrc &B, ChainLds &
     const uint32_t co = start ? (e.y - B.first) * 12u : kNoOffset;
     s.bv = __builtin_amdgcn_raw_buffer_load_b32(B.cmd, co, 0, 0);
     s.bd = __builtin_amdgcn_raw_buffer_load_b32(B.cmd, co, 0 + 4, 0);
+    // A submesh or allocation boundary INSIDE the record restarts the chain there: the offsets of the meshlet behind the
+    // first broken link are gathered as well (none: nothing is read).  Survivors behind a second one gather their own.
+    const uint32_t brk = chain_first_break(s.link32);
+    const uint32_t co2 = (has && brk < 32u) ? (e.y + brk - B.first) * 12u : kNoOffset;
+    s.bv2 = __builtin_amdgcn_raw_buffer_load_b32(B.cmd, co2, 0, 0);
+    s.bd2 = __builtin_amdgcn_raw_buffer_load_b32(B.cmd, co2, 0 + 4, 0);
     return s;
 }
 
@@ -1260,70 +1278,69 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
     uint32_t *out = reinterpret_cast<uint32_t *>(p.draw_buffer + ORBIT_DRAW_HEADER);
     const uint32_t stride = gridDim.x * 4;
     const uint32_t sub = (uint32_t)lane >> 4, i16 = (uint32_t)lane & 15u;
-    uint32_t group = blockIdx.x * 4 + wave;
-    ChainGroup cur = chain_prefetch(B, group, lane);
-    ChainGroup nxt = chain_prefetch(B, group + stride, lane);
-    ChainGroup nn = chain_prefetch(B, group + 2 * stride, lane);
-    ChainStage cs = chain_stage(B, S, cur, link_stage(B, cur), lane);
-    LinkStage nk = link_stage(B, nxt);
-    for (; group < ngroups; group += stride) {
-        // a group past the end reads zero records: nothing else is loaded for it
-        const ChainGroup n3 = chain_prefetch(B, group + 3 * stride, lane);
-        const LinkStage nnk = link_stage(B, nn);
-        const ChainStage ns = chain_stage(B, S, nxt, nk, lane);
+    // One group's phases, from its prefetched records (`cur`) and staged counts / bases (`cs`).
+    // FAST (the pipelined loop): straight-line vector-memory code.  The wave's vector-memory operations retire in
+    // issue order, so waiting for a prefetched load also waits for every store issued before it — unless the compiler
+    // knows exactly how many operations lie in between.  Hence, in that loop, no load or store in any branch: the same
+    // fourteen stores per group whatever its survivors (a group without any stores into an empty window).  A group
+    // that needs more — over 128 survivors, or a survivor behind a SECOND boundary inside one record — stores nothing
+    // there, returns true, and is done again by the general form (!FAST) after the loop.
+    auto process = [&](auto fast_tag, const ChainGroup &cur, const ChainStage &cs, uint32_t group) -> bool {
+        constexpr bool FAST = decltype(fast_tag)::value;
         const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)cur.count, 0) +
                            (uint32_t)__builtin_amdgcn_readlane((int)cur.count, 1);
-        if (n != 0u) {
-            // wave-uniform, and provably so for the compiler (the store window's descriptor lives in SGPRs)
-            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane(
-                (int)(cur.base + s_chunk_base[group * kGroupTiles / kScanChunk]));
-            // ---- phase A: quad-rows q and q + 4 share a scan (16-bit halves: a record's sizes sum to < 2^14)
+        // wave-uniform, and provably so for the compiler (the store window's descriptor lives in SGPRs)
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)(cur.base + s_chunk_base[min(group * kGroupTiles / kScanChunk, kEmitChunkTable - 1u)]));
+        // ---- phase A: quad-rows q and q + 4 share a scan (16-bit halves: a record's sizes sum to < 2^14)
 #pragma unroll
-            for (int q = 0; q < (int)kGroupRecords / 8; q++) {
-                const uint32_t ca = cs.c2[q], cb = cs.c2[q + 4];
-                const uint32_t sa = chain_size2(ca), sb = chain_size2(cb);         // {first, second} meshlet of the lane
-                const uint32_t pa = (sa & 0xFFFFu) + (sa >> 16), pb = (sb & 0xFFFFu) + (sb >> 16);
-                const uint32_t pair = pa | (pb << 16);
-                const uint32_t incl = row_inclusive_scan(pair);
-                const uint32_t excl = incl - pair;
-                const uint32_t ea = excl & 0xFFFFu, eb = excl >> 16;
-                // per meshlet: prefix | counts << 16 (the second meshlet's prefix includes the first one's size)
-                uint2 wa, wb;
-                wa.x = ea | (ca << 16);
-                wa.y = ((ea + (sa & 0xFFFFu)) & 0xFFFFu) | (ca & 0xFFFF0000u);
-                wb.x = eb | (cb << 16);
-                wb.y = ((eb + (sb & 0xFFFFu)) & 0xFFFFu) | (cb & 0xFFFF0000u);
-                *reinterpret_cast<uint2 *>(&S.row[q * 128 + lane * 2]) = wa;       // record 4 q + sub, lanes 2 i, 2 i + 1
-                *reinterpret_cast<uint2 *>(&S.row[(q + 4) * 128 + lane * 2]) = wb;
-                if (i16 == 15u) S.tot[q * 4 + sub] = incl;
-            }
-            // the survivors' codes (record * 32 + lane) in canonical order: lane i owns half a record's ballot and
-            // peels its bits off one per trip
-            {
-                const uint32_t w = (uint32_t)__shfl((int)cur.mword, lane >> 1, 64);
-                uint32_t bits = (w >> (16u * ((uint32_t)lane & 1u))) & 0xFFFFu;
-                const uint32_t pc = (uint32_t)__popc(bits);
-                uint32_t pos = wave_inclusive_scan(pc) - pc;
-                const uint32_t code0 = (uint32_t)lane * 16u;
-                while (__ballot(bits != 0u) != 0ull) {
-                    if (bits != 0u) {
-                        S.list[pos] = (uint16_t)(code0 + (uint32_t)__builtin_ctz(bits));
-                        pos++;
-                        bits &= bits - 1u;
-                    }
+        for (int q = 0; q < (int)kGroupRecords / 8; q++) {
+            const uint32_t ca = cs.c2[q], cb = cs.c2[q + 4];
+            const uint32_t sa = chain_size2(ca), sb = chain_size2(cb);         // {first, second} meshlet of the lane
+            const uint32_t pa = (sa & 0xFFFFu) + (sa >> 16), pb = (sb & 0xFFFFu) + (sb >> 16);
+            const uint32_t pair = pa | (pb << 16);
+            const uint32_t incl = row_inclusive_scan(pair);
+            const uint32_t excl = incl - pair;
+            const uint32_t ea = excl & 0xFFFFu, eb = excl >> 16;
+            // per meshlet: prefix | counts << 16 (the second meshlet's prefix includes the first one's size)
+            uint2 wa, wb;
+            wa.x = ea | (ca << 16);
+            wa.y = ((ea + (sa & 0xFFFFu)) & 0xFFFFu) | (ca & 0xFFFF0000u);
+            wb.x = eb | (cb << 16);
+            wb.y = ((eb + (sb & 0xFFFFu)) & 0xFFFFu) | (cb & 0xFFFF0000u);
+            *reinterpret_cast<uint2 *>(&S.row[q * 128 + lane * 2]) = wa;       // record 4 q + sub, lanes 2 i, 2 i + 1
+            *reinterpret_cast<uint2 *>(&S.row[(q + 4) * 128 + lane * 2]) = wb;
+            if (i16 == 15u) S.tot[q * 4 + sub] = incl;
+        }
+        // the survivors' codes (record * 32 + lane) in canonical order: lane i owns half a record's ballot and
+        // peels its bits off one per trip
+        {
+            const uint32_t w = (uint32_t)__shfl((int)cur.mword, lane >> 1, 64);
+            uint32_t bits = (w >> (16u * ((uint32_t)lane & 1u))) & 0xFFFFu;
+            const uint32_t pc = (uint32_t)__popc(bits);
+            uint32_t pos = wave_inclusive_scan(pc) - pc;
+            const uint32_t code0 = (uint32_t)lane * 16u;
+            while (__ballot(bits != 0u) != 0ull) {
+                if (bits != 0u) {
+                    S.list[pos] = (uint16_t)(code0 + (uint32_t)__builtin_ctz(bits));
+                    pos++;
+                    bits &= bits - 1u;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // ---- phase B: lane = record (32 of them; lanes 32.. repeat)
-            {
-                const uint32_t k = (uint32_t)lane & 31u, kq = k >> 2;
-                const uint32_t tot = (S.tot[(kq & 3u) * 4u + (k & 3u)] >> (16u * (kq >> 2))) & 0xFFFFu;
-                const uint32_t prev_tot = wave_shr1(tot, 0u);
-                const bool cont = (cs.flags & 3u) == 1u; // has survivors and continues the predecessor's chain
-                uint32_t f = cont ? 0u : 1u;             // segment head
-                uint32_t a_d = f ? cs.bd : prev_tot, a_v = cs.bv; // bv / bd are zero unless the record starts a chain
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- phase B: lane = record (32 of them; lanes 32.. repeat)
+        {
+            const uint32_t k = (uint32_t)lane & 31u, kq = k >> 2;
+            const uint32_t tot = (S.tot[(kq & 3u) * 4u + (k & 3u)] >> (16u * (kq >> 2))) & 0xFFFFu;
+            const uint32_t prev_tot = wave_shr1(tot, 0u);
+            const uint32_t brk = chain_first_break(cs.link32);
+            const uint32_t brk_prefix = S.row[k * 32u + (brk & 31u)] & 0xFFFFu; // data words in front of that meshlet
+            const bool cont = (cs.flags & 3u) == 1u; // has survivors and continues the predecessor's chain
+            uint32_t f = cont ? 0u : 1u;             // segment head
+            uint32_t a_d = f ? cs.bd : prev_tot, a_v = cs.bv; // bv / bd are zero unless the record starts a chain
 #define ORBIT_SEG_STEP(ctrl, rows)                                                                              \
     {                                                                                                           \
         const uint32_t sd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a_d, ctrl, rows, 0xF, false);         \
@@ -1333,74 +1350,138 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
         a_v += f ? 0u : sv;                                                                                     \
         f |= sf;                                                                                                \
     }
-                // (a lane without a source in a step keeps what it has: record 16 has no predecessor in its row of 16
-                // lanes and is still no head — its segment arrives with the row_bcast15 step)
-                ORBIT_SEG_STEP(0x111, 0xF)
-                ORBIT_SEG_STEP(0x112, 0xF)
-                ORBIT_SEG_STEP(0x114, 0xF)
-                ORBIT_SEG_STEP(0x118, 0xF)
-                ORBIT_SEG_STEP(0x142, 0xA) // row_bcast15: records 16..31 continue from record 15 (lanes 48.. from 47)
+            // (a lane without a source in a step keeps what it has: record 16 has no predecessor in its row of 16
+            // lanes and is still no head — its segment arrives with the row_bcast15 step)
+            ORBIT_SEG_STEP(0x111, 0xF)
+            ORBIT_SEG_STEP(0x112, 0xF)
+            ORBIT_SEG_STEP(0x114, 0xF)
+            ORBIT_SEG_STEP(0x118, 0xF)
+            ORBIT_SEG_STEP(0x142, 0xA) // row_bcast15: records 16..31 continue from record 15 (lanes 48.. from 47)
 #undef ORBIT_SEG_STEP
-                if (lane < (int)kGroupRecords) {
-                    S.rec[lane] = make_uint4(a_d, a_v, cur.ent, cur.y);
-                    S.link[lane] = cs.link32;
-                }
+            if (lane < (int)kGroupRecords) {
+                S.rec[lane] = make_uint4(a_d, a_v, cur.ent, cur.y);
+                S.rec2[lane] = make_uint2(cs.bd2 - brk_prefix, cs.bv2);
+                S.link[lane] = cs.link32;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // ---- phase C: lane = survivor
-            for (uint32_t j0 = 0; j0 < n; j0 += 64) {
-                const uint32_t j = j0 + (uint32_t)lane;
-                const uint32_t code = j < n ? S.list[j] : 0u;
-                const uint32_t rid = code >> 5, l = code & 31u;
-                const uint32_t pk = S.row[code];
-                const uint4 R = S.rec[rid];
-                const uint32_t lk = S.link[rid];
-                const uint32_t need = ((2u << l) - 1u) & ~1u; // links of lanes 1..l (l = 31: 2u << 31 = 0)
-                const uint32_t mi = R.w + l;
-                uint32_t data = R.x + (pk & 0xFFFFu), vtx = R.y;
-                const bool broken = j < n && (lk & need) != need;
-                if (__ballot(broken) != 0ull) { // behind a submesh / allocation boundary inside the record
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- phase C: lane = survivor; one trip = up to 64 commands
+        // is survivor j behind a second broken link of its record?  (then only its own gathered words are right)
+        auto second_break = [&](uint32_t j) -> bool {
+            const uint32_t code = j < n ? S.list[j] : 0u;
+            const uint32_t lk = S.link[code >> 5], l = code & 31u;
+            const uint32_t brk = chain_first_break(lk);
+            const uint32_t need = ((2u << l) - 1u) & ~((2u << (brk & 31u)) - 1u); // links of lanes brk + 1 .. l
+            return j < n && l >= brk && (lk & need) != need;
+        };
+        bool slow = false;
+        if constexpr (FAST)
+            slow = n > 128u || __ballot(second_break((uint32_t)lane) || second_break(64u + (uint32_t)lane)) != 0ull;
+        auto trip = [&](uint32_t j0) {
+            const uint32_t j = j0 + (uint32_t)lane;
+            const uint32_t code = j < n ? S.list[j] : 0u;
+            const uint32_t rid = code >> 5, l = code & 31u;
+            const uint32_t pk = S.row[code];
+            const uint4 R = S.rec[rid];
+            const uint2 R2 = S.rec2[rid];
+            const uint32_t mi = R.w + l;
+            // in front of the record's first broken link: the record's base; behind it: the base gathered there
+            const bool behind = l >= chain_first_break(S.link[rid]);
+            uint32_t data = (behind ? R2.x : R.x) + (pk & 0xFFFFu), vtx = behind ? R2.y : R.y;
+            if constexpr (!FAST) {
+                const bool broken = second_break(j);
+                if (__ballot(broken) != 0ull) { // rare
                     const uint32_t co = broken ? (mi - B.first) * 12u : kNoOffset;
                     const uint32_t gv = __builtin_amdgcn_raw_buffer_load_b32(B.cmd, co, 0, 0);
                     const uint32_t gd = __builtin_amdgcn_raw_buffer_load_b32(B.cmd, co, 0 + 4, 0);
                     vtx = broken ? gv : vtx;
                     data = broken ? gd : data;
                 }
-                uint32_t vertex_count = (pk >> 16) & 0xFFu, triangle_count = pk >> 24;
-                // ORBIT_E_RANGE (latched by the evaluation): the command of a meshlet outside the stream carries zeros
-                if (!p.ms.covers(mi)) vtx = data = vertex_count = triangle_count = 0u;
-                uint32_t *c = S.cmd + lane * 7;
-                c[0] = triangle_count * 3u;         // cmd_index_count
-                c[1] = 1u;                          // cmd_instance_count
-                c[2] = (data + vertex_count) * 4u;  // cmd_first_index
-                c[3] = data;                        // cmd_vertex_offset = int(data_offset)
-                c[4] = R.z;                         // cmd_first_instance = entity_index
-                c[5] = vtx;                         // meshlet_vertex_offset
-                c[6] = mi;                          // meshlet_index
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // the trip's commands as one range-checked window: words past the list or the capacity are dropped
-                const uint32_t first = base + j0; // slot of the trip's first command
-                const uint32_t room = first < p.draw_capacity ? p.draw_capacity - first : 0u;
-                const uint32_t bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(min(min(n - j0, 64u), room) * 28u));
-                const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)first * 7u, 0, bytes, kBufFlags);
-#pragma unroll
-                for (uint32_t k = 0; k < 7; k++) {
-                    const uint32_t w = k * 64u + (uint32_t)lane;
-                    __builtin_amdgcn_raw_buffer_store_b32(S.cmd[w], win, w * 4u, 0, 0);
-                }
-                __builtin_amdgcn_wave_barrier(); // cmd is rewritten by the next trip
             }
-            __builtin_amdgcn_wave_barrier(); // list / row / rec are reused by the next group
+            uint32_t vertex_count = (pk >> 16) & 0xFFu, triangle_count = pk >> 24;
+            // ORBIT_E_RANGE (latched by the evaluation): the command of a meshlet outside the stream carries zeros
+            if (!p.ms.covers(mi)) vtx = data = vertex_count = triangle_count = 0u;
+            uint32_t *c = S.cmd + lane * 7;
+            c[0] = triangle_count * 3u;         // cmd_index_count
+            c[1] = 1u;                          // cmd_instance_count
+            c[2] = (data + vertex_count) * 4u;  // cmd_first_index
+            c[3] = data;                        // cmd_vertex_offset = int(data_offset)
+            c[4] = R.z;                         // cmd_first_instance = entity_index
+            c[5] = vtx;                         // meshlet_vertex_offset
+            c[6] = mi;                          // meshlet_index
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // the trip's commands as one range-checked window: words past the list or the capacity are dropped
+            const uint32_t first = base + j0; // slot of the trip's first command
+            const uint32_t room = first < p.draw_capacity ? p.draw_capacity - first : 0u;
+            const uint32_t left = (j0 < n && !slow) ? n - j0 : 0u;
+            const uint32_t bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(min(min(left, 64u), room) * 28u));
+            const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)first * 7u, 0, bytes, kBufFlags);
+#pragma unroll
+            for (uint32_t k = 0; k < 7; k++) {
+                const uint32_t w = k * 64u + (uint32_t)lane;
+                __builtin_amdgcn_raw_buffer_store_b32(S.cmd[w], win, w * 4u, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier(); // cmd is rewritten by the next trip
+        };
+        if constexpr (FAST) {
+            trip(0u);
+            trip(64u);
+        } else {
+            for (uint32_t j0 = 0u; j0 < n; j0 += 64u) trip(j0);
         }
+        __builtin_amdgcn_wave_barrier(); // list / row / rec are reused by the next group
+        return slow;
+    };
+
+    // The pipelined loop over the wave's groups: records and ballots three groups ahead, link words two, counts and
+    // bases one.  A group past the end reads zero records: nothing else is loaded for it.
+    const uint32_t group0 = blockIdx.x * 4 + wave;
+    uint32_t group = group0, it = 0;
+    ChainGroup cur = chain_prefetch(B, group, lane);
+    ChainGroup nxt = chain_prefetch(B, group + stride, lane);
+    ChainGroup nn = chain_prefetch(B, group + 2 * stride, lane);
+    ChainStage cs = chain_stage(B, S, cur, link_stage(B, cur), lane);
+    LinkStage nk = link_stage(B, nxt);
+    if (lane < (int)kSlowWords) S.slow[lane] = 0u;
+    auto step = [&]() __attribute__((always_inline)) {
+        const ChainGroup n3 = chain_prefetch(B, group + 3 * stride, lane);
+        const LinkStage nnk = link_stage(B, nn);
+        const ChainStage ns = chain_stage(B, S, nxt, nk, lane);
+        const bool slow = process(std::true_type{}, cur, cs, group);
+        // (the launchers size the grid so that a wave never has more than 32 * kSlowWords iterations)
+        if (slow && lane == 0) S.slow[(it >> 5) & (kSlowWords - 1u)] |= 1u << (it & 31u);
         cur = nxt;
         cs = ns;
         nxt = nn;
         nk = nnk;
         nn = n3;
+        group += stride;
+        it++;
+    };
+    // The first group outside the loop: the loop is then entered with its steady-state queue of loads and stores in
+    // flight, and the compiler's wait counts inside it are the steady state's (from the prologue alone the link
+    // words would look six operations old, and every iteration would drain its predecessor's stores to be safe).
+    if (group < ngroups) {
+        step();
+        while (group < ngroups) step();
+    }
+    // The groups the loop left: one at a time, loads awaited as they come.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t w = 0; w < kSlowWords; w++) {
+        uint32_t bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.slow[w]);
+        while (bits != 0u) {
+            const uint32_t g = group0 + (w * 32u + (uint32_t)__builtin_ctz(bits)) * stride;
+            bits &= bits - 1u;
+            const ChainGroup e = chain_prefetch(B, g, lane);
+            const ChainStage st = chain_stage(B, S, e, link_stage(B, e), lane);
+            process(std::false_type{}, e, st, g);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // `count` header: subsumes the fill_buffer(count = 0) of draw_gen.rs:411-417
@@ -1765,8 +1846,9 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t
         if (stream) hipLaunchKernelGGL((meshlet_emit_kernel<true, true>), dim3(eblocks), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((meshlet_emit_kernel<true, false>), dim3(eblocks), dim3(256), 0, s, p);
     } else if (stream) {
-        // a wave per group of two tiles
-        const uint32_t cblocks = max(min(num_cus * (uint32_t)kChainWavesPerSimd, (eneed + kGroupTiles - 1) / kGroupTiles), 1u);
+        // a wave per group of two tiles; never more than 32 * kSlowWords groups per wave
+        const uint32_t gneed = (eneed + kGroupTiles - 1) / kGroupTiles;
+        const uint32_t cblocks = max(max(min(num_cus * (uint32_t)kChainWavesPerSimd, gneed), (gneed + 32u * kSlowWords - 1u) / (32u * kSlowWords)), 1u);
         hipLaunchKernelGGL(meshlet_emit_chain_kernel, dim3(cblocks), dim3(256), 0, s, p);
     } else {
         hipLaunchKernelGGL((meshlet_emit_kernel<false, false>), dim3(eblocks), dim3(256), 0, s, p);
@@ -1856,7 +1938,8 @@ hipError_t launch_meshlet_cull_views(const MeshletCullViews &all, uint32_t n, ui
         if (m == 0) continue;
         if (stream)
             hipLaunchKernelGGL(meshlet_emit_chain_views_kernel,
-                               dim3(max(min(num_cus * (uint32_t)kChainWavesPerSimd / m, (eneed + kGroupTiles - 1) / kGroupTiles), 1u), m),
+                               dim3(max(max(min(num_cus * (uint32_t)kChainWavesPerSimd / m, (eneed + kGroupTiles - 1) / kGroupTiles),
+                                            ((eneed + kGroupTiles - 1) / kGroupTiles + 32u * kSlowWords - 1u) / (32u * kSlowWords)), 1u), m),
                                dim3(256), 0, s, all, g);
         else hipLaunchKernelGGL(meshlet_emit_views_kernel<false>, dim3(eblocks, m), dim3(256), 0, s, all, g);
         e = hipGetLastError();
