@@ -548,6 +548,22 @@ int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCull
     p.draw_capacity = visible_path ? visible_capacity : b->draw_capacity;
     p.visible_list = visible_path ? 1u : 0u;
     p.material_count = b->material_count;
+    {   // the symmetric five-plane frustum, recognised bit for bit (kernels.h MeshletCullParams::std_planes)
+        auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+        auto zero = [&](float f) { return (bits(f) & 0x7FFFFFFFu) == 0u; };
+        auto fin = [&](float f) { return (bits(f) & 0x7F800000u) != 0x7F800000u; };
+        const float(*pl)[4] = ci->cull_planes;
+        bool ok = ci->cull_plane_count == 5;
+        ok = ok && zero(pl[0][1]) && zero(pl[0][3]) && zero(pl[1][1]) && zero(pl[1][3]) &&
+             bits(pl[1][0]) == (bits(pl[0][0]) ^ 0x80000000u) && bits(pl[1][2]) == bits(pl[0][2]);
+        ok = ok && zero(pl[2][0]) && zero(pl[2][3]) && zero(pl[3][0]) && zero(pl[3][3]) &&
+             bits(pl[3][1]) == (bits(pl[2][1]) ^ 0x80000000u) && bits(pl[3][2]) == bits(pl[2][2]);
+        ok = ok && zero(pl[4][0]) && zero(pl[4][1]);
+        const float v[6] = {pl[0][0], pl[0][2], pl[2][1], pl[2][2], pl[4][2], pl[4][3]};
+        for (float f : v) ok = ok && fin(f);
+        p.std_planes = ok ? 1u : 0u;
+        for (int k = 0; k < 6; k++) p.stdp[k] = ok ? v[k] : 0.0f;
+    }
     p.task_records = task_records;
     p.tile_counts = scratch->m_tile_counts;
     p.tile_masks = scratch->m_tile_masks;

@@ -86,6 +86,12 @@ struct MeshletCullParams {
     uint32_t dispatch_capacity;
     uint32_t draw_capacity;
     uint32_t material_count; // 0 = unknown (gather alpha modes), else entries in `materials`
+    // The frustum a perspective camera hands the cull (forward.rs:264-268: left, right, bottom, top, near of
+    // frustum_planes_from_matrix) is (a,0,c,0), (-a,0,c,0), (0,b,c',0), (0,-b,c',0), (0,0,e,w) — recognised on the host,
+    // bit for bit.  For finite view-space centres the five plane tests then need 5 products and 5 sums instead of 15 +
+    // 15, with the same outcome (the dropped terms are +-0; meshlet_cull.hip planes_std).  std_planes = 0: any other set.
+    uint32_t std_planes;
+    float stdp[6]; // a, c, b, c', e, w
     // mesh-shading path (orbit_meshlet_task_cull): non-null = survivors stay with their record, one
     // OrbitMeshTaskRecord per dispatch record, and no draw list is produced
     OrbitMeshTaskRecord *task_records;

@@ -55,6 +55,10 @@ struct __attribute__((aligned(16))) WaveTileLds {
     uint64_t vis_mask[kTileRows];  // pass 2 with meshlet occlusion: visible ballots, assembled by the candidate flushes
     uint32_t prev[kTileRecords];   // pass 1: last frame's visibility word of each record
     uint2 amask[kTileRecords];     // CLS: per record {(:207) bits, (:210) bits} of its 32 lanes, from their alpha classes
+    // bit 8 r: both records of row r have an affine view x model matrix (last row 0 0 0 1) with a finite translation:
+    // for finite centres their w is exactly 1 and the w = 0 term of the cone-axis transform exactly +-0 (setup_write)
+    uint64_t affine_rows;
+    uint64_t pad_;
 };
 
 // The cull planes live in LDS (one copy per block, written once): a row reads
@@ -62,13 +66,35 @@ struct __attribute__((aligned(16))) WaveTileLds {
 // wait per plane per row.
 struct __attribute__((aligned(16))) PlaneLds {
     float4 plane[ORBIT_MAX_CULL_PLANES];
+    float4 std0; // the symmetric five-plane frustum (MeshletCullParams::std_planes): a, c, b, c'
+    float4 std1; //                                                                     e, w, -, -
 };
 
-__device__ __forceinline__ void planes_to_lds(const OrbitGpuCullInfo &ci, PlaneLds &P) {
+__device__ __forceinline__ void planes_to_lds(const MeshletCullParams &p, PlaneLds &P) {
     if (threadIdx.x < ORBIT_MAX_CULL_PLANES) {
-        const float *pl = ci.cull_planes[threadIdx.x];
+        const float *pl = p.ci.cull_planes[threadIdx.x];
         P.plane[threadIdx.x] = make_float4(pl[0], pl[1], pl[2], pl[3]);
     }
+    if (threadIdx.x == ORBIT_MAX_CULL_PLANES) {
+        P.std0 = make_float4(p.stdp[0], p.stdp[1], p.stdp[2], p.stdp[3]);
+        P.std1 = make_float4(p.stdp[4], p.stdp[5], 0.0f, 0.0f);
+    }
+}
+
+// The plane loop (:139-146) for the symmetric five-plane frustum and a FINITE view-space centre: left / right share
+// their products (((a x + 0 y) + c z) + 0 and ((-a x + 0 y) + c z) + 0 are t1 + t2 and t2 - t1 up to the sign of a
+// zero, which no comparison sees), so do bottom / top; the near plane is e z + w.
+__device__ __forceinline__ bool planes_std(const PlaneLds &P, const Sphere &s) {
+    const float4 k = P.std0;
+    const float4 n = P.std1;
+    const float t1 = k.x * s.x, t2 = k.y * s.z, t3 = k.z * s.y, t4 = k.w * s.z, t5 = n.x * s.z;
+    const float nr = -s.r;
+    bool in = (t1 + t2) > nr;
+    in = in & ((t2 - t1) > nr);
+    in = in & ((t3 + t4) > nr);
+    in = in & ((t4 - t3) > nr);
+    in = in & ((t5 + n.y) > nr);
+    return in;
 }
 
 // Plane loop, meshlet_cull.comp:139-146, planes from LDS in batches of up to
@@ -148,6 +174,12 @@ struct MeshletVerdict {
     bool visible, should_draw;
 };
 
+// wave-uniform, and a scalar for the compiler: row r's two records are affine with finite translations (setup_write)
+__device__ __forceinline__ bool row_is_affine(const WaveTileLds &L, int r) {
+    const uint32_t w = reinterpret_cast<const uint32_t *>(&L.affine_rows)[r >> 2];
+    return (((uint32_t)__builtin_amdgcn_readfirstlane((int)w) >> (8 * (r & 3))) & 1u) != 0u;
+}
+
 // Survivor payload (12 B): Meshlet::vertex_offset, Meshlet::data_offset, and
 // {triangle_count:8 | vertex_count:8 | lane within the record:5 << 4 | tile-local record id:4} — the material index is
 // not part of a command, its bits carry where the survivor sat in the tile, from which the emit launch gets the
@@ -159,10 +191,15 @@ __device__ __forceinline__ Payload make_payload(uint32_t ml, uint32_t rid, const
 // One meshlet (one lane): meshlet_cull.comp:113-213.  PASS = cull_info.occlusion_pass
 // and PROJ = cull_info.projection_type are compile-time (PROJ < 0: read at run time).
 // Geometry part (:117-158): view-space sphere `s`, pass-1 gate, plane loop, cone test.
+// `affine_row` (wave-uniform): both records of the row have an affine matrix with a finite translation (WaveTileLds::
+// affine_rows).  Then a FINITE centre has w = ((0 cx + 0 cy) + 0 cz) + 1 = 1 exactly — no w, no division — and the
+// w = 0 term of the cone-axis transform is +-0, which no comparison sees; and a finite view-space centre is what the
+// shortened plane tests of the symmetric frustum need (planes_std).  One non-finite lane (its products with 0 are NaN
+// in the reference's arithmetic) sends the whole row down the literal path.
 template <int PASS, int PROJ>
 __device__ __forceinline__ bool eval_geometry(const MeshletCullParams &p, const WaveTileLds &L, const PlaneLds &P,
                                               uint32_t rid, const uint4 &a, const uint4 &b, bool visible_in_buffer,
-                                              Sphere &s) {
+                                              Sphere &s, bool affine_row = false) {
     const OrbitGpuCullInfo &ci = p.ci;
     const float4 m0 = L.mcol[rid][0], m1 = L.mcol[rid][1], m2 = L.mcol[rid][2], m3 = L.mcol[rid][3];
     const float cx = __uint_as_float(a.x), cy = __uint_as_float(a.y), cz = __uint_as_float(a.z);
@@ -170,11 +207,16 @@ __device__ __forceinline__ bool eval_geometry(const MeshletCullParams &p, const 
     float px = ((m0.x * cx + m1.x * cy) + m2.x * cz) + m3.x * 1.0f;
     float py = ((m0.y * cx + m1.y * cy) + m2.y * cz) + m3.y * 1.0f;
     float pz = ((m0.z * cx + m1.z * cy) + m2.z * cz) + m3.z * 1.0f;
-    const float pw = ((m0.w * cx + m1.w * cy) + m2.w * cz) + m3.w * 1.0f;
-    if (pw != 1.0f) { // x / 1.0f == x bit-for-bit, so the affine case skips three IEEE divisions
-        px = px / pw;
-        py = py / pw;
-        pz = pz / pw;
+    // (a non-finite centre makes all three non-finite: each holds a product with it)
+    const bool nonfinite = !(__builtin_isfinite(px) && __builtin_isfinite(py) && __builtin_isfinite(pz));
+    const bool literal = !affine_row || __ballot(nonfinite) != 0ull; // wave-uniform
+    if (literal) {
+        const float pw = ((m0.w * cx + m1.w * cy) + m2.w * cz) + m3.w * 1.0f;
+        if (pw != 1.0f) { // x / 1.0f == x bit-for-bit, so the affine case skips three IEEE divisions
+            px = px / pw;
+            py = py / pw;
+            pz = pz / pw;
+        }
     }
     s.x = px;
     s.y = py;
@@ -195,10 +237,15 @@ __device__ __forceinline__ bool eval_geometry(const MeshletCullParams &p, const 
         const int az_i = (int)(int8_t)((b.x >> 16) & 0xFF), co_i = (int)(int8_t)(b.x >> 24);
         const float ax = snorm8(ax_i), ay = snorm8(ay_i), az = snorm8(az_i);
         const float cutoff = snorm8(co_i);
-        const float4 tz = L.tzero[rid]; // m3 * 0.0f
-        const float axx = ((m0.x * ax + m1.x * ay) + m2.x * az) + tz.x;
-        const float axy = ((m0.y * ax + m1.y * ay) + m2.y * az) + tz.y;
-        const float axz = ((m0.z * ax + m1.z * ay) + m2.z * az) + tz.z;
+        float axx = (m0.x * ax + m1.x * ay) + m2.x * az;
+        float axy = (m0.y * ax + m1.y * ay) + m2.y * az;
+        float axz = (m0.z * ax + m1.z * ay) + m2.z * az;
+        if (literal) {
+            const float4 tz = L.tzero[rid]; // m3 * 0.0f
+            axx += tz.x;
+            axy += tz.y;
+            axz += tz.z;
+        }
         const bool ortho = PROJ < 0 ? ci.projection_type == 1 : PROJ == 1;
         float dx, dy, dz;
         if (ortho) { // camera_position = center - (0, 0, -1)
@@ -214,7 +261,10 @@ __device__ __forceinline__ bool eval_geometry(const MeshletCullParams &p, const 
         // as compiled: dot(d, axis) >= fma(cutoff, length(d), radius)  (oracle/orbit_oracle.c cone_cull)
         cull = dot3(dx, dy, dz, axx, axy, axz) >= __builtin_fmaf(cutoff, sqrtf(dot3(dx, dy, dz, dx, dy, dz)), s.r);
     }
-    if (visible) visible = plane_test_lds(P, ci.cull_plane_count, s); // :139-146
+    if (visible) { // :139-146
+        if (p.std_planes != 0u && !literal) visible = planes_std(P, s);
+        else visible = plane_test_lds(P, ci.cull_plane_count, s);
+    }
     return visible && !cull;
 }
 
@@ -228,9 +278,10 @@ __device__ __forceinline__ bool should_draw_of(bool visible, uint32_t abits, boo
 template <int PASS, int PROJ>
 __device__ __forceinline__ MeshletVerdict eval_meshlet(const MeshletCullParams &p, const WaveTileLds &L,
                                                        const PlaneLds &P, uint32_t rid, const uint4 &a, const uint4 &b,
-                                                       uint32_t abits, bool visible_in_buffer, bool meshlet_occ) {
+                                                       uint32_t abits, bool visible_in_buffer, bool meshlet_occ,
+                                                       bool affine_row) {
     Sphere s;
-    bool visible = eval_geometry<PASS, PROJ>(p, L, P, rid, a, b, visible_in_buffer, s);
+    bool visible = eval_geometry<PASS, PROJ>(p, L, P, rid, a, b, visible_in_buffer, s, affine_row);
     if (PASS == 2 && meshlet_occ && visible)
         visible = occlusion_test(p.ci, s, __uint_as_float(a.w), L.scale[rid], p.pyr); // :161-205
     return {visible, should_draw_of(visible, abits, visible_in_buffer, PASS == 2 && meshlet_occ)};
@@ -298,7 +349,8 @@ __device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTi
 #else
         if (active) {
             const bool visible_in_buffer = rw_vis ? ((t.prev[k] >> ml) & 1u) != 0 : true;
-            v = eval_meshlet<PASS, PROJ>(p, L, P, rid, t.a[k], t.b[k], abits[k], visible_in_buffer, meshlet_occ);
+            v = eval_meshlet<PASS, PROJ>(p, L, P, rid, t.a[k], t.b[k], abits[k], visible_in_buffer, meshlet_occ,
+                                         row_is_affine(L, r));
         }
 #endif
         const uint64_t mask = __ballot(v.should_draw);
@@ -397,7 +449,7 @@ __device__ __forceinline__ void row_eval_occ(const MeshletCullParams &p, WaveTil
     Sphere s;
     s.x = s.y = s.z = s.r = 0.0f;
     bool cand = false;
-    if (active) cand = eval_geometry<2, PROJ>(p, L, P, rid, t.a[0], t.b[0], visible_in_buffer, s);
+    if (active) cand = eval_geometry<2, PROJ>(p, L, P, rid, t.a[0], t.b[0], visible_in_buffer, s, row_is_affine(L, R));
     const uint64_t mask = __ballot(cand);
     if (cand) {
         const uint32_t slot = ring_wrap(ring_wrap(cs.head + cs.count) + lane_prefix(mask));
@@ -494,6 +546,15 @@ __device__ __forceinline__ void setup_write(const MeshletCullParams &p, WaveTile
         L.rec[rid] = rec;
         L.prev[rid] = prev_word;
     }
+    {   // affine_rows (WaveTileLds): a column's w is 0 (1 for the translation, whose xyz must be finite: x * 0 == 0)
+        const bool okc = col == 3 ? (o[3] == 1.0f && o[0] * 0.0f == 0.0f && o[1] * 0.0f == 0.0f && o[2] * 0.0f == 0.0f)
+                                  : o[3] == 0.0f;
+        uint64_t m = __ballot(okc); // four bits per record, eight per row
+        m &= m >> 1;
+        m &= m >> 2;
+        m &= m >> 4; // bit 8 r: all eight
+        if (lane == 0) L.affine_rows = m;
+    }
     if (lane < (int)kTileRows) L.draw_mask[lane] = 0ull, L.vis_mask[lane] = 0ull; // the candidate flushes OR into them
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -553,7 +614,7 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
     // pass 2 with meshlet occlusion: HiZ tests run on compacted candidates (cand_flush), not per row
     const bool occ2 = PASS == 2 && p.ci.meshlet_visibility_buffer != ORBIT_NONE;
     __shared__ uint32_t cls_sel[CLS ? 8 : 1]; // [2 c + k] = all ones if alpha class c has predicate bit k (alpha_bits)
-    planes_to_lds(p.ci, planes);
+    planes_to_lds(p, planes);
     if (CLS && threadIdx.x < 6) cls_sel[threadIdx.x] = ((alpha_bits(p.ci, threadIdx.x >> 1) >> (threadIdx.x & 1u)) & 1u) ? ~0u : 0u;
     const AlphaLds *alpha = alpha_table_fill(p, alpha_tab) ? &alpha_tab : nullptr;
     __syncthreads();
@@ -835,7 +896,7 @@ __device__ __forceinline__ void meshlet_pass1_body(const MeshletCullParams &p) {
     __shared__ AlphaLds alpha_tab;
     __shared__ uint16_t s_list[kEvWaves][2][kTileRows * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    planes_to_lds(p.ci, planes);
+    planes_to_lds(p, planes);
     const AlphaLds *alpha = alpha_table_fill(p, alpha_tab) ? &alpha_tab : nullptr;
     __syncthreads();
     const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);

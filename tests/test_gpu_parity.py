@@ -1227,3 +1227,48 @@ def test_cull_views_late_pass_views_with_their_own_pyramids(torch_mod, oracle):
         assert all(n > 0 for n in drawn), drawn
         assert eng.meshlet_stream_culls() == (3 if source == "meshlet_stream" else 0)
     eng.close()
+
+
+def test_non_affine_matrices_and_non_finite_centres_take_the_literal_path(torch_mod, engine, oracle):
+    """The evaluation shortens its arithmetic where the outcome cannot change: rows whose records have affine
+    view x model matrices skip w and the division, and the symmetric five-plane frustum of a perspective camera is
+    tested with shared products — for FINITE centres only (a product of 0 with an infinity is a NaN in the reference's
+    arithmetic).  Here the inputs that must NOT take the short cuts are mixed into one scene: projective model matrices
+    (last row not 0 0 0 1), infinite / NaN translations, infinite / NaN meshlet centres and radii — and plane sets that
+    only look like the frustum (a non-zero y in the left plane, six planes, a shifted right plane)."""
+    torch = torch_mod
+    scene = sc.make_scene(83, 900, n_meshes=150, meshlets_per_mesh=(1, 70), extent=(40.0, 10.0, 40.0))
+    rng = np.random.default_rng(83)
+    ents = scene.entities["model_matrix"]
+    n = len(ents)
+    k = rng.permutation(n)
+    ents[k[:60], 3] = 0.001     # column 0, row 3: w picks up x
+    ents[k[60:120], 15] = 2.0   # w scale
+    ents[k[120:150], 7] = -0.002
+    ents[k[150:170], 12] = np.inf   # translation x
+    ents[k[170:190], 13] = np.nan
+    ents[k[190:200], 14] = -np.inf
+    m = scene.meshlets
+    j = rng.permutation(len(m))
+    m["bounding_sphere"][j[:200], 0] = np.inf
+    m["bounding_sphere"][j[200:400], 1] = np.nan
+    m["bounding_sphere"][j[400:500], 2] = -np.inf
+    m["bounding_sphere"][j[500:600], 3] = np.inf
+    m["bounding_sphere"][j[600:700], 3] = np.nan
+    cam = sc.default_camera(rot=(0.1, 0.3))
+    gs = GpuScene(torch, scene)
+    std = np.asarray(cam.planes[:5], np.float32).copy()
+    variants = [std]
+    v = std.copy(); v[0, 1] = 1e-3; variants.append(v)                  # the left plane tilts
+    v = std.copy(); v[1, 0] = np.nextafter(v[1, 0], np.float32(0)); variants.append(v)  # right is no mirror of left
+    v = std.copy(); v[4, 0] = 0.25; variants.append(v)                   # the near plane is no z-plane
+    v = std.copy(); v[2, 3] = 0.5; variants.append(v)                    # an offset on the bottom plane
+    variants.append(np.asarray(cam.planes[:6], np.float32))              # six planes
+    variants.append(std[[1, 0, 2, 3, 4]])                                # right before left: still the frustum
+    for planes in variants:
+        for occlusion_pass in (0, 1):
+            ci = sc.make_cull_info(cam.view, planes, occlusion_pass=occlusion_pass)
+            evis = rng.integers(0, 2 ** 32, (scene.entity_draw_count + 31) // 32, dtype=np.uint32) if occlusion_pass else None
+            mvis = rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32) if occlusion_pass else None
+            assert_same(run_gpu(torch, engine, gs, ci, evis, mvis, material_count=len(scene.materials)),
+                        run_oracle(oracle, scene, ci, evis, mvis))
