@@ -5,6 +5,8 @@ usage: python tools/ab_inproc.py 0 64 [more flag sets ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _triage; _triage.use_triage_library()  # -DORBIT_TRIAGE build (bash tools/mktriage.sh)
 import numpy as np, torch
 from orbit_amd import camera, layouts as L, synth
 from orbit_amd.engine import Engine

@@ -38,7 +38,10 @@ rec = spec.records_per_entity
 disp_cap, draw_cap = E * rec + 8, E * M // 2 + 1024
 eng = Engine(0, max_entities=E + 256, max_dispatches=disp_cap, max_draws=draw_cap)
 if args.meshlet_source == "stream":
-    eng.bind_meshlet_stream(eng.meshlet_stream(meshlets, 0, E * M))
+    ms = eng.meshlet_stream(meshlets, 0, E * M)
+    ms.set_materials(materials, spec.materials)  # the alpha classes: the evaluation reads no material index
+    torch.cuda.synchronize()
+    eng.bind_meshlet_stream(ms)
 disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device=dev)
 draw1 = torch.zeros(L.DRAW_HEADER + 28 * draw_cap, dtype=torch.uint8, device=dev)
 draw2 = torch.zeros_like(draw1)

@@ -4,6 +4,8 @@ import ctypes as C, os, sys
 os.environ["ORBIT_SP_DEBUG"] = str(8 | int(os.environ.get("EXTRA_FLAGS", "0")))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _triage; _triage.use_triage_library()  # -DORBIT_TRIAGE build (bash tools/mktriage.sh)
 import torch, numpy as np
 import scenes as sc
 from orbit_amd import synth, layouts as L, _lib

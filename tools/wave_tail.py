@@ -4,6 +4,8 @@ import ctypes as C, os, sys
 os.environ["ORBIT_SP_DEBUG"] = str(16 | int(os.environ.get("EXTRA_FLAGS", "0")))  # 16: per-wave wall-clock stamps  # 8: stamped build, 16: wall-clock stamps only (no per-phase waits)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _triage; _triage.use_triage_library()  # -DORBIT_TRIAGE build (bash tools/mktriage.sh)
 import torch, numpy as np
 from orbit_amd import camera, synth, _lib
 from orbit_amd.engine import Engine
