@@ -527,7 +527,7 @@ int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t cou
 /* Meshlet buffer as before.                                                 */
 /*                                                                           */
 /*   create   arrays for global meshlet indices [first_meshlet,              */
-/*            first_meshlet + capacity), capacity <= 2^28 (device memory:    */
+/*            first_meshlet + capacity), capacity <= 2^27 (device memory:    */
 /*            36.4 B x capacity, zero-filled)                                */
 /*   update   re-derives [first, first + count) from `meshlet_buffer` (same  */
 /*            global indexing as bufs->meshlet_buffer), enqueued on `stream`;*/

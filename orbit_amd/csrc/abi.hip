@@ -677,10 +677,10 @@ int32_t orbit_meshlet_stream_create(OrbitCtx *ctx, uint64_t first_meshlet, uint6
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (!out_stream) return fail(ctx, ORBIT_E_MISSING, "meshlet_stream_create: out_stream is NULL");
     *out_stream = nullptr;
-    // 32-bit meshlet indices; the emit launch addresses the arrays through buffer resources (32-bit byte offsets:
-    // 12 B per meshlet < 4 GiB)
-    if (capacity == 0 || capacity > (1ull << 28) || first_meshlet + capacity > 0xFFFFFFFFull)
-        return fail(ctx, ORBIT_E_INVALID, "meshlet_stream_create: range [%llu, +%llu) (at most 2^28 meshlets per stream)",
+    // 32-bit meshlet indices; the kernels address the arrays through buffer resources (32-bit byte offsets: 16 B per
+    // meshlet stay below 2 GiB, so the "no access" offset of meshlet_cull.hip lies outside every array)
+    if (capacity == 0 || capacity > (1ull << 27) || first_meshlet + capacity > 0xFFFFFFFFull)
+        return fail(ctx, ORBIT_E_INVALID, "meshlet_stream_create: range [%llu, +%llu) (at most 2^27 meshlets per stream)",
                     (unsigned long long)first_meshlet, (unsigned long long)capacity);
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return hip_fail(ctx, e, "hipSetDevice");

@@ -46,15 +46,36 @@ namespace {
 // survivors per tile whose command words are cached by meshlet_eval for the emit launch
 constexpr uint32_t kPayloadCap = 128;
 
+// Range-checked buffer accesses (no branch, no pointer select around a load: a lane that must not read is given an
+// offset outside the resource and gets zeros).
+constexpr uint32_t kBufFlags = 0x00020000u; // raw buffer, 32-bit data format
+constexpr uint32_t kNoOffset = 0xFFFFFF00u; // beyond every resource of this launch, also after a lane's +60 bytes
+                                            // (orbit_meshlet_stream_create bounds the stream's arrays: 2^27 meshlets)
+
+// The streams a row reads, as buffer resources based at the stream's first meshlet: a row's address arithmetic is
+// one subtraction, one select and a shift per array instead of a 64-bit pointer select per load.
+struct StreamRsrc {
+    __amdgpu_buffer_rsrc_t sphere, cone, mat;
+    uint32_t first, count;
+};
+
+// Everything a row's lanes read of their record sits behind ONE address (record-major, 112 B): a row's record is
+// 2 r + lane / 32, so every read is "the wave's (slab + half) base + a constant" and a row spends no vector
+// instruction on LDS addressing (field-major arrays cost one address computation per field and row).
+struct __attribute__((aligned(16))) RecordLds {
+    float4 mcol[4]; // view x model, column-major
+    uint4 rec;      // MeshletDispatch
+    float4 tzero;   // column 3 x 0.0f: the w = 0 term of the cone-axis transform (:121)
+    uint2 amask;    // CLS: {(:207) bits, (:210) bits} of the record's 32 lanes, from their alpha classes
+    float scale;    // largest_scale_from_matrix(mat3(M))
+    uint32_t prev;  // pass 1: last frame's visibility word of the record
+};
+static_assert(sizeof(RecordLds) == 112, "RecordLds layout");
+
 struct __attribute__((aligned(16))) WaveTileLds {
-    float4 mcol[kTileRecords][4]; // view x model, column-major, per record
-    uint4 rec[kTileRecords];      // MeshletDispatch
-    float4 tzero[kTileRecords];   // column 3 x 0.0f: the w = 0 term of the cone-axis transform (:121)
-    float scale[kTileRecords];    // largest_scale_from_matrix(mat3(M))
+    RecordLds r[kTileRecords];
     uint64_t draw_mask[kTileRows]; // should-draw ballots of the tile's rows (kept here, not in SGPRs)
     uint64_t vis_mask[kTileRows];  // pass 2 with meshlet occlusion: visible ballots, assembled by the candidate flushes
-    uint32_t prev[kTileRecords];   // pass 1: last frame's visibility word of each record
-    uint2 amask[kTileRecords];     // CLS: per record {(:207) bits, (:210) bits} of its 32 lanes, from their alpha classes
     // bit 8 r: both records of row r have an affine view x model matrix (last row 0 0 0 1) with a finite translation:
     // for finite centres their w is exactly 1 and the w = 0 term of the cone-axis transform exactly +-0 (setup_write)
     uint64_t affine_rows;
@@ -81,19 +102,26 @@ __device__ __forceinline__ void planes_to_lds(const MeshletCullParams &p, PlaneL
     }
 }
 
+// Verdicts are wave masks, not lane booleans: every comparison is balloted as it is made and the masks are combined
+// with scalar instructions (a lane boolean that is an AND / OR of several comparisons costs two vector instructions
+// to turn back into a ballot).  lane_of() is the way back where a lane predicate is needed: the mask IS the
+// predicate register, no instruction.
+__device__ __forceinline__ uint64_t ballot(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+__device__ __forceinline__ bool lane_of(uint64_t wave_mask) { return __builtin_amdgcn_inverse_ballot_w64(wave_mask); }
+
 // The plane loop (:139-146) for the symmetric five-plane frustum and a FINITE view-space centre: left / right share
 // their products (((a x + 0 y) + c z) + 0 and ((-a x + 0 y) + c z) + 0 are t1 + t2 and t2 - t1 up to the sign of a
 // zero, which no comparison sees), so do bottom / top; the near plane is e z + w.
-__device__ __forceinline__ bool planes_std(const PlaneLds &P, const Sphere &s) {
+__device__ __forceinline__ uint64_t planes_std(const PlaneLds &P, const Sphere &s) {
     const float4 k = P.std0;
     const float4 n = P.std1;
     const float t1 = k.x * s.x, t2 = k.y * s.z, t3 = k.z * s.y, t4 = k.w * s.z, t5 = n.x * s.z;
     const float nr = -s.r;
-    bool in = (t1 + t2) > nr;
-    in = in & ((t2 - t1) > nr);
-    in = in & ((t3 + t4) > nr);
-    in = in & ((t4 - t3) > nr);
-    in = in & ((t5 + n.y) > nr);
+    uint64_t in = ballot((t1 + t2) > nr);
+    in &= ballot((t2 - t1) > nr);
+    in &= ballot((t3 + t4) > nr);
+    in &= ballot((t4 - t3) > nr);
+    in &= ballot((t5 + n.y) > nr);
     return in;
 }
 
@@ -102,28 +130,43 @@ __device__ __forceinline__ bool planes_std(const PlaneLds &P, const Sphere &s) {
 // distances of a batch are independent chains.  The batch shape follows the
 // (wave-uniform) plane count, so no plane past the count is ever evaluated.
 template <uint32_t N>
-__device__ __forceinline__ bool plane_batch(const PlaneLds &P, uint32_t base, const Sphere &s) {
+__device__ __forceinline__ uint64_t plane_batch(const PlaneLds &P, uint32_t base, const Sphere &s) {
     float4 pl[N];
 #pragma unroll
     for (uint32_t i = 0; i < N; i++) pl[i] = P.plane[base + i];
-    bool in = true;
+    uint64_t in = ~0ull;
 #pragma unroll
     for (uint32_t i = 0; i < N; i++) {
         const float d = dot3(pl[i].x, pl[i].y, pl[i].z, s.x, s.y, s.z) + pl[i].w;
-        in = in & (d > -s.r);
+        in &= ballot(d > -s.r);
     }
     return in;
 }
 
-__device__ __forceinline__ bool plane_test_lds(const PlaneLds &P, uint32_t n, const Sphere &s) {
-    bool visible = true;
+__device__ __forceinline__ uint64_t plane_test_lds(const PlaneLds &P, uint32_t n, const Sphere &s) {
+    uint64_t visible = ~0ull;
 #pragma unroll
     for (uint32_t base = 0; base < ORBIT_MAX_CULL_PLANES; base += 3) {
-        if (base + 3 <= n) visible = visible & plane_batch<3>(P, base, s);
-        else if (base + 2 == n) visible = visible & plane_batch<2>(P, base, s);
-        else if (base + 1 == n) visible = visible & plane_batch<1>(P, base, s);
+        if (base + 3 <= n) visible &= plane_batch<3>(P, base, s);
+        else if (base + 2 == n) visible &= plane_batch<2>(P, base, s);
+        else if (base + 1 == n) visible &= plane_batch<1>(P, base, s);
     }
     return visible;
+}
+
+// sqrtf, correctly rounded (what -fhip-fp32-correctly-rounded-divide-sqrt makes of it), without the range scaling
+// and the zero / infinity fix-up where no lane of the wave needs them: v_sqrt_f32 is within one ulp, the two
+// neighbours are tested with exact fma residuals.  x in [2^-96, inf) is the range the compiler's own sequence runs
+// unscaled; anything else (zero, tiny, infinite, NaN) takes sqrtf itself.
+__device__ __forceinline__ float sqrt_rn(float x) {
+    const uint64_t plain = ballot(x >= 0x1p-96f) & ballot(x < __builtin_inff());
+    if (plain != ballot(true)) return sqrtf(x);
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const float ym = __uint_as_float(__float_as_uint(y) - 1u), yp = __uint_as_float(__float_as_uint(y) + 1u);
+    const float rm = __builtin_fmaf(-ym, y, x), rp = __builtin_fmaf(-yp, y, x);
+    float r = rm <= 0.0f ? ym : y;
+    r = rp > 0.0f ? yp : r;
+    return r;
 }
 
 // NR rows of a tile in flight: 2 x 16 B per lane per row (+ previous-frame words).
@@ -162,17 +205,13 @@ template <bool CLS>
 __device__ __forceinline__ uint32_t lane_alpha_bits(const MeshletCullParams &p, const WaveTileLds &L, const AlphaLds *A,
                                                     uint32_t rid, uint32_t ml, uint32_t word7) {
     if constexpr (CLS) {
-        const uint2 am = L.amask[rid];
+        const uint2 am = L.r[rid].amask;
         return ((am.x >> ml) & 1u) | (((am.y >> ml) & 1u) << 1);
     } else {
         const uint32_t mi = word7 & 0xFFFFu; // inactive lanes carry material 0 from the zero page (in bounds; unused)
         return A ? (uint32_t)A->bits[mi & (kAlphaTable - 1u)] : alpha_bits(p.ci, p.materials[mi].alpha_mode);
     }
 }
-
-struct MeshletVerdict {
-    bool visible, should_draw;
-};
 
 // wave-uniform, and a scalar for the compiler: row r's two records are affine with finite translations (setup_write)
 __device__ __forceinline__ bool row_is_affine(const WaveTileLds &L, int r) {
@@ -196,21 +235,23 @@ __device__ __forceinline__ Payload make_payload(uint32_t ml, uint32_t rid, const
 // w = 0 term of the cone-axis transform is +-0, which no comparison sees; and a finite view-space centre is what the
 // shortened plane tests of the symmetric frustum need (planes_std).  One non-finite lane (its products with 0 are NaN
 // in the reference's arithmetic) sends the whole row down the literal path.
-template <int PASS, int PROJ>
-__device__ __forceinline__ bool eval_geometry(const MeshletCullParams &p, const WaveTileLds &L, const PlaneLds &P,
-                                              uint32_t rid, const uint4 &a, const uint4 &b, bool visible_in_buffer,
-                                              Sphere &s, bool affine_row = false) {
+template <int PROJ>
+__device__ __forceinline__ uint64_t eval_geometry_mask(const MeshletCullParams &p, const WaveTileLds &L,
+                                                       const PlaneLds &P, uint32_t rid, const uint4 &a, const uint4 &b,
+                                                       Sphere &s, bool affine_row = false) {
     const OrbitGpuCullInfo &ci = p.ci;
-    const float4 m0 = L.mcol[rid][0], m1 = L.mcol[rid][1], m2 = L.mcol[rid][2], m3 = L.mcol[rid][3];
+    const RecordLds &R = L.r[rid];
+    const float4 m0 = R.mcol[0], m1 = R.mcol[1], m2 = R.mcol[2], m3 = R.mcol[3];
     const float cx = __uint_as_float(a.x), cy = __uint_as_float(a.y), cz = __uint_as_float(a.z);
     // transform_sphere (:37-43): matrix * vec4(c, 1), divide by w.
     float px = ((m0.x * cx + m1.x * cy) + m2.x * cz) + m3.x * 1.0f;
     float py = ((m0.y * cx + m1.y * cy) + m2.y * cz) + m3.y * 1.0f;
     float pz = ((m0.z * cx + m1.z * cy) + m2.z * cz) + m3.z * 1.0f;
     // (a non-finite centre makes all three non-finite: each holds a product with it)
-    const bool nonfinite = !(__builtin_isfinite(px) && __builtin_isfinite(py) && __builtin_isfinite(pz));
-    const bool literal = !affine_row || __ballot(nonfinite) != 0ull; // wave-uniform
-    if (literal) {
+    const uint64_t nonfinite = ballot(!__builtin_isfinite(px)) | ballot(!__builtin_isfinite(py)) | ballot(!__builtin_isfinite(pz));
+    // wave-uniform and held as a scalar integer (not a lane boolean)
+    const uint32_t literal = (affine_row ? 0u : 1u) | (uint32_t)nonfinite | (uint32_t)(nonfinite >> 32);
+    if (literal != 0u) {
         const float pw = ((m0.w * cx + m1.w * cy) + m2.w * cz) + m3.w * 1.0f;
         if (pw != 1.0f) { // x / 1.0f == x bit-for-bit, so the affine case skips three IEEE divisions
             px = px / pw;
@@ -221,16 +262,14 @@ __device__ __forceinline__ bool eval_geometry(const MeshletCullParams &p, const 
     s.x = px;
     s.y = py;
     s.z = pz;
-    s.r = __uint_as_float(a.w) * L.scale[rid];
+    s.r = __uint_as_float(a.w) * R.scale;
 
-    bool visible = true;
     // keeps the scheduler from hoisting the cone test's and the plane loop's LDS reads above the sphere transform:
     // without it the class variant of the evaluation holds 128 registers and spills (profiles/r03_notes.md)
     __builtin_amdgcn_sched_barrier(0);
-    if (PASS == 1) visible = visible_in_buffer;   // :137
     // The cone test (:148-158) does not depend on the plane loop: both are evaluated
     // and combined, which gives the scheduler two independent chains per meshlet.
-    bool cull;
+    uint64_t cull;
     {
         // cone axis / cutoff (:121-122): int(i8) / 127.0, axis = (M * vec4(a, 0)).xyz
         const int ax_i = (int)(int8_t)(b.x & 0xFF), ay_i = (int)(int8_t)((b.x >> 8) & 0xFF);
@@ -240,8 +279,8 @@ __device__ __forceinline__ bool eval_geometry(const MeshletCullParams &p, const 
         float axx = (m0.x * ax + m1.x * ay) + m2.x * az;
         float axy = (m0.y * ax + m1.y * ay) + m2.y * az;
         float axz = (m0.z * ax + m1.z * ay) + m2.z * az;
-        if (literal) {
-            const float4 tz = L.tzero[rid]; // m3 * 0.0f
+        if (literal != 0u) {
+            const float4 tz = R.tzero; // m3 * 0.0f
             axx += tz.x;
             axy += tz.y;
             axz += tz.z;
@@ -259,13 +298,20 @@ __device__ __forceinline__ bool eval_geometry(const MeshletCullParams &p, const 
             dz = s.z - 0.0f;
         }
         // as compiled: dot(d, axis) >= fma(cutoff, length(d), radius)  (oracle/orbit_oracle.c cone_cull)
-        cull = dot3(dx, dy, dz, axx, axy, axz) >= __builtin_fmaf(cutoff, sqrtf(dot3(dx, dy, dz, dx, dy, dz)), s.r);
+        cull = ballot(dot3(dx, dy, dz, axx, axy, axz) >= __builtin_fmaf(cutoff, sqrt_rn(dot3(dx, dy, dz, dx, dy, dz)), s.r));
     }
-    if (visible) { // :139-146
-        if (p.std_planes != 0u && !literal) visible = planes_std(P, s);
-        else visible = plane_test_lds(P, ci.cull_plane_count, s);
-    }
-    return visible && !cull;
+    // :139-146
+    const uint64_t inside = (p.std_planes != 0u && literal == 0u) ? planes_std(P, s) : plane_test_lds(P, ci.cull_plane_count, s);
+    return inside & ~cull;
+}
+
+// The lane's own verdict (pass 1 gates on last frame's bit first, :137).
+template <int PASS, int PROJ>
+__device__ __forceinline__ bool eval_geometry(const MeshletCullParams &p, const WaveTileLds &L, const PlaneLds &P,
+                                              uint32_t rid, const uint4 &a, const uint4 &b, bool visible_in_buffer,
+                                              Sphere &s, bool affine_row = false) {
+    const bool visible = lane_of(eval_geometry_mask<PROJ>(p, L, P, rid, a, b, s, affine_row));
+    return PASS == 1 ? (visible & visible_in_buffer) : visible;
 }
 
 // :207-213 from the final `visible`, the material's predicate bits and last frame's bit.
@@ -275,40 +321,31 @@ __device__ __forceinline__ bool should_draw_of(bool visible, uint32_t abits, boo
     return should_draw;
 }
 
-template <int PASS, int PROJ>
-__device__ __forceinline__ MeshletVerdict eval_meshlet(const MeshletCullParams &p, const WaveTileLds &L,
-                                                       const PlaneLds &P, uint32_t rid, const uint4 &a, const uint4 &b,
-                                                       uint32_t abits, bool visible_in_buffer, bool meshlet_occ,
-                                                       bool affine_row) {
-    Sphere s;
-    bool visible = eval_geometry<PASS, PROJ>(p, L, P, rid, a, b, visible_in_buffer, s, affine_row);
-    if (PASS == 2 && meshlet_occ && visible)
-        visible = occlusion_test(p.ci, s, __uint_as_float(a.w), L.scale[rid], p.pyr); // :161-205
-    return {visible, should_draw_of(visible, abits, visible_in_buffer, PASS == 2 && meshlet_occ)};
-}
-
 // Issues the meshlet loads of rows R0 .. R0+NR-1 of a tile (2 x 16 B per lane per row; STREAM: 16 + 4 + 2 B from the
 // derived streams — words y/z of `b` and the counts in w, which only a command needs, stay zero).
 template <int PASS, int R0, int NR, bool STREAM = false, bool CLS = false>
 __device__ __forceinline__ void rows_load(const MeshletCullParams &p, const WaveTileLds &L, int lane,
-                                          RowRegs<NR> &t) {
+                                          RowRegs<NR> &t, const StreamRsrc *SR = nullptr) {
     const bool meshlet_occ = p.ci.meshlet_visibility_buffer != ORBIT_NONE;
     const bool rw_vis = PASS != 0 && meshlet_occ;
     const uint32_t half = lane >> 5, ml = lane & 31;
 #pragma unroll
     for (int k = 0; k < NR; k++) {
-        const uint4 rec = L.rec[2 * (R0 + k) + half];
+        const uint4 rec = L.r[2 * (R0 + k) + half].rec;
         // straight-line loads (exact vmcnt accounting): lanes past meshlet_count (:111) read the zero page
         const bool active = ml < rec.z;
         if constexpr (STREAM) {
             // a meshlet the stream does not cover is not read from it: zeros, and the call's status says so
-            const bool in = active && p.ms.covers(rec.y + ml);
-            if (active && !in) latch_status(p.status, ORBIT_E_RANGE);
-            t.a[k] = *(in ? p.ms.sphere + (rec.y + ml) : reinterpret_cast<const uint4 *>(p.zero_page));
-            const uint32_t c = *(in ? p.ms.cone + (rec.y + ml) : reinterpret_cast<const uint32_t *>(p.zero_page));
-            uint16_t m = 0; // CLS: the predicate bits come from the alpha classes in the slab (setup_write_cls)
-            if constexpr (!CLS) m = *(in ? p.ms.mat + (rec.y + ml) : reinterpret_cast<const uint16_t *>(p.zero_page));
-            t.b[k] = make_uint4(c, 0u, 0u, (uint32_t)m);
+            const uint32_t rel = rec.y + ml - SR->first;
+            const bool in = active & (rel < SR->count);
+            if (active & !in) latch_status(p.status, ORBIT_E_RANGE);
+            const uint32_t i = in ? rel : kNoOffset >> 4; // x 16, x 4, x 2: outside each of the three resources
+            const auto sp = __builtin_amdgcn_raw_buffer_load_b128(SR->sphere, i << 4, 0, 0);
+            const uint32_t c = __builtin_amdgcn_raw_buffer_load_b32(SR->cone, i << 2, 0, 0);
+            t.a[k] = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+            uint32_t m = 0; // CLS: the predicate bits come from the alpha classes in the slab (setup_write_cls)
+            if constexpr (!CLS) m = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(SR->mat, i << 1, 0, 0);
+            t.b[k] = make_uint4(c, 0u, 0u, m);
         } else {
             const uint4 *src = active ? reinterpret_cast<const uint4 *>(p.meshlets + (rec.y + ml))
                                       : reinterpret_cast<const uint4 *>(p.zero_page);
@@ -324,50 +361,47 @@ __device__ __forceinline__ void rows_load(const MeshletCullParams &p, const Wave
     }
 }
 
-// Evaluates rows R0 .. R0+NR-1 of a tile: should-draw ballots into the slab,
-// survivor payload (optional), pass-2 visibility words (WRITE_VIS).  `total` is
-// the tile's running survivor count; the new count is returned.
-template <int PASS, int PROJ, bool WRITE_VIS, int R0, int NR, bool CLS = false>
+// Evaluates rows R0 .. R0+NR-1 of a tile: should-draw ballots into the slab, survivor payload (optional).  `total`
+// is the tile's running survivor count; the new count is returned.  This is pass 0, or pass 2 WITHOUT meshlet
+// occlusion (row_eval_occ has the other case): no visibility word is read or written, and a meshlet is drawn iff it
+// exists (:111), passes the geometry tests and its material the :207 test.  Every lane evaluates — lanes past
+// meshlet_count hold zeros, which are finite and harmless — and the verdict is masked: no divergent region around a
+// row.
+template <int PASS, int PROJ, int R0, int NR, bool CLS = false>
 __device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
                                               const AlphaLds *A, int lane, const RowRegs<NR> &t, uint32_t total,
                                               Payload *payload) {
-    const bool meshlet_occ = p.ci.meshlet_visibility_buffer != ORBIT_NONE;
-    const bool rw_vis = PASS != 0 && meshlet_occ;
+    static_assert(PASS == 0 || PASS == 2, "pass 1 is list-driven (meshlet_pass1_body)");
     const uint32_t half = lane >> 5, ml = lane & 31;
-    uint32_t abits[NR];
-#pragma unroll
-    for (int k = 0; k < NR; k++) abits[k] = lane_alpha_bits<CLS>(p, L, A, 2 * (R0 + k) + half, ml, t.b[k].w);
 #pragma unroll
     for (int k = 0; k < NR; k++) {
         const int r = R0 + k;
         const uint32_t rid = 2 * r + half;
-        const uint4 rec = L.rec[rid];
-        const bool active = ml < rec.z;
-        MeshletVerdict v = {false, false};
-#ifdef ORBIT_TRIAGE_NO_EVAL // scratch builds only (tools/mkvariant_any.sh): a free predicate with the same survival ratio
-        if (active) v.visible = v.should_draw = ((t.a[k].x + (t.b[k].x >> 31)) % 1000u) < 95u;
-#else
-        if (active) {
-            const bool visible_in_buffer = rw_vis ? ((t.prev[k] >> ml) & 1u) != 0 : true;
-            v = eval_meshlet<PASS, PROJ>(p, L, P, rid, t.a[k], t.b[k], abits[k], visible_in_buffer, meshlet_occ,
-                                         row_is_affine(L, r));
+        uint64_t allow; // lanes that hold a meshlet whose material passes (:207)
+        if constexpr (CLS) {
+            // from the alpha classes, already cut to meshlet_count (setup_write_cls): two uniform words
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.r[2 * r].amask.x);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.r[2 * r + 1].amask.x);
+            allow = (uint64_t)hi << 32 | lo;
+        } else {
+            const uint32_t abits = lane_alpha_bits<false>(p, L, A, rid, ml, t.b[k].w);
+            allow = ballot(ml < L.r[rid].rec.z) & ballot((abits & 1u) != 0u);
         }
+#ifdef ORBIT_TRIAGE_NO_EVAL // scratch builds only (tools/mkvariant_any.sh): a free predicate with the same survival ratio
+        const uint64_t geo = ballot(((t.a[k].x + (t.b[k].x >> 31)) % 1000u) < 95u);
+#else
+        Sphere s;
+        const uint64_t geo = eval_geometry_mask<PROJ>(p, L, P, rid, t.a[k], t.b[k], s, row_is_affine(L, r));
 #endif
-        const uint64_t mask = __ballot(v.should_draw);
+        const uint64_t mask = geo & allow;
         if (lane == 0) L.draw_mask[r] = mask;
-        if (payload && v.should_draw) {
+        if (payload && lane_of(mask)) {
             // survivor payload at the tile-local rank: everything the command needs except its
             // slot, so the emit launch reads one contiguous run per tile and rebuilds nothing
             const uint32_t rank = total + lane_prefix(mask);
             if (rank < kPayloadCap) payload[rank] = make_payload(ml, rid, t.b[k]);
         }
         total += (uint32_t)__popcll(mask);
-        if (PASS == 2 && WRITE_VIS) {
-            // pass-2 visibility words (:233-254); records with no lane write nothing
-            const uint64_t vis_mask = __ballot(v.visible);
-            if (meshlet_occ && ml == 0 && rec.z > 0)
-                p.meshlet_visibility[rec.w] = half ? (uint32_t)(vis_mask >> 32) : (uint32_t)vis_mask;
-        }
     }
     return total;
 }
@@ -413,7 +447,7 @@ __device__ __forceinline__ void cand_flush(const MeshletCullParams &p, WaveTileL
     bool visible = false;
     if (valid) {
         // the ring holds the MODEL-space radius: the test fuses radius * scale into three of its sums
-        const float scale = L.scale[(info.x >> 5) & 15u];
+        const float scale = L.r[(info.x >> 5) & 15u].scale;
         Sphere s;
         s.x = sp.x, s.y = sp.y, s.z = sp.z, s.r = sp.w * scale;
         visible = occlusion_test(p.ci, s, sp.w, scale, p.pyr); // :161-205
@@ -442,7 +476,7 @@ __device__ __forceinline__ void row_eval_occ(const MeshletCullParams &p, WaveTil
                                              CandState &cs, Payload *payload) {
     const uint32_t half = lane >> 5, ml = lane & 31;
     const uint32_t rid = 2 * R + half;
-    const uint4 rec = L.rec[rid];
+    const uint4 rec = L.r[rid].rec;
     const uint32_t abits = lane_alpha_bits<CLS>(p, L, A, rid, ml, t.b[0].w);
     const bool active = ml < rec.z;
     const bool visible_in_buffer = ((t.prev[0] >> ml) & 1u) != 0;
@@ -470,7 +504,7 @@ __device__ __forceinline__ void tile_finish_occ(const MeshletCullParams &p, Wave
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (lane < (int)kTileRecords) {
-        const uint4 rec = L.rec[lane];
+        const uint4 rec = L.r[lane].rec;
         uint32_t word = reinterpret_cast<const uint32_t *>(L.vis_mask)[lane];
         // task shaders keep `visible = true` in lanes past the count and write it (forward_depth_prepass.task:124,232)
         if (p.task_records && rec.z < 32u) word |= ~0u << rec.z;
@@ -526,8 +560,10 @@ __device__ __forceinline__ void setup_write_cls(WaveTileLds &L, const uint32_t *
     const uint32_t c0 = ~(hi | lo), c1 = lo & ~hi, c2 = hi & ~lo;
     // sel[2 c + k]: all ones if class c has predicate bit k (block-wide table: keeps the cull info's words out of the
     // scalar registers the rows need)
+    const uint32_t exist = rec.z >= 32u ? ~0u : ~(~0u << (rec.z & 31u)); // lanes below meshlet_count (:111)
     if ((lane & 3) == 0)
-        L.amask[lane >> 2] = make_uint2((c0 & sel[0]) | (c1 & sel[2]) | (c2 & sel[4]), (c0 & sel[1]) | (c1 & sel[3]) | (c2 & sel[5]));
+        L.r[lane >> 2].amask = make_uint2(((c0 & sel[0]) | (c1 & sel[2]) | (c2 & sel[4])) & exist,
+                                          ((c0 & sel[1]) | (c1 & sel[3]) | (c2 & sel[5])) & exist);
 }
 
 __device__ __forceinline__ void setup_write(const MeshletCullParams &p, WaveTileLds &L, const uint4 &rec,
@@ -535,16 +571,16 @@ __device__ __forceinline__ void setup_write(const MeshletCullParams &p, WaveTile
     const uint32_t rid = lane >> 2, col = lane & 3;
     float o[4];
     mat4_mul_col(p.ci.view_matrix, mc.x, mc.y, mc.z, mc.w, o);
-    L.mcol[rid][col] = make_float4(o[0], o[1], o[2], o[3]);
-    if (col == 3) L.tzero[rid] = make_float4(o[0] * 0.0f, o[1] * 0.0f, o[2] * 0.0f, 0.0f);
+    L.r[rid].mcol[col] = make_float4(o[0], o[1], o[2], o[3]);
+    if (col == 3) L.r[rid].tzero = make_float4(o[0] * 0.0f, o[1] * 0.0f, o[2] * 0.0f, 0.0f);
     const float d = dot3(o[0], o[1], o[2], o[0], o[1], o[2]);
     const float d0 = __shfl(d, (int)(rid * 4 + 0), 64);
     const float d1 = __shfl(d, (int)(rid * 4 + 1), 64);
     const float d2 = __shfl(d, (int)(rid * 4 + 2), 64);
     if (col == 0) {
-        L.scale[rid] = sqrtf(gmax(d0, gmax(d1, d2)));
-        L.rec[rid] = rec;
-        L.prev[rid] = prev_word;
+        L.r[rid].scale = sqrtf(gmax(d0, gmax(d1, d2)));
+        L.r[rid].rec = rec;
+        L.r[rid].prev = prev_word;
     }
     {   // affine_rows (WaveTileLds): a column's w is 0 (1 for the translation, whose xyz must be finite: x * 0 == 0)
         const bool okc = col == 3 ? (o[3] == 1.0f && o[0] * 0.0f == 0.0f && o[1] * 0.0f == 0.0f && o[2] * 0.0f == 0.0f)
@@ -657,6 +693,15 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         if (k < n_static) return t * stride + wave_g;
         return t >= 0x08000000u ? 0xFFFFFFFFu : n_static * stride + t * npools + pool;
     };
+    StreamRsrc SR = {};
+    if constexpr (STREAM) {
+        SR.first = p.ms.first;
+        SR.count = p.ms.count;
+        SR.sphere = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(p.ms.sphere + p.ms.first), 0, p.ms.count * 16u, kBufFlags);
+        SR.cone = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.ms.cone + p.ms.first), 0, p.ms.count * 4u, kBufFlags);
+        if constexpr (!CLS)
+            SR.mat = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.ms.mat + p.ms.first), 0, p.ms.count * 2u, kBufFlags);
+    }
     uint32_t w0, w1, w2, tk_raw;
     {
         const uint32_t t0 = claim(), t1 = claim(), t2 = claim();
@@ -666,7 +711,8 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         w2 = ticket_tile(t2, 2u);
     }
     // two single-row register sets: while one row is evaluated the next row's loads are in flight
-    // (STREAM: a row is 1.4 KiB instead of 2 KiB; sets of two rows each were measured — neutral, profiles/r02_notes.md)
+    // (STREAM: a row is 1.25 KiB instead of 2 KiB; sets of two rows each were measured in rounds 2 and 3 — neutral or
+    // slower, as are 5 and 6 resident waves per SIMD: profiles/r02_notes.md, r03_notes.md)
     RowRegs<1> qa, qb;
     uint4 rec2;
     {
@@ -682,8 +728,8 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         }
         setup_write(p, lds[wave][0], r0, m0, lane);
         setup_write(p, lds[wave][1], r1, m1, lane);
-        rows_load<PASS, 0, 1, STREAM, CLS>(p, lds[wave][0], lane, qa);
-        rows_load<PASS, 1, 1, STREAM, CLS>(p, lds[wave][0], lane, qb);
+        rows_load<PASS, 0, 1, STREAM, CLS>(p, lds[wave][0], lane, qa, &SR);
+        rows_load<PASS, 1, 1, STREAM, CLS>(p, lds[wave][0], lane, qb, &SR);
     }
     uint32_t it = 0;
 #ifdef ORBIT_TRIAGE
@@ -730,33 +776,33 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
 #define EV_ROW(R, Q)                                                                                                  \
     if constexpr (PASS == 2) {                                                                                        \
         if (occ2) row_eval_occ<PROJ, R, kCandRing, CLS>(p, L, planes, alpha, cand_ring[wave], lane, Q, cs, payload);  \
-        else cs.total = rows_eval<PASS, PROJ, true, R, 1, CLS>(p, L, planes, alpha, lane, Q, cs.total, payload);      \
+        else cs.total = rows_eval<PASS, PROJ, R, 1, CLS>(p, L, planes, alpha, lane, Q, cs.total, payload);      \
     } else {                                                                                                          \
-        cs.total = rows_eval<PASS, PROJ, true, R, 1, CLS>(p, L, planes, alpha, lane, Q, cs.total, payload);           \
+        cs.total = rows_eval<PASS, PROJ, R, 1, CLS>(p, L, planes, alpha, lane, Q, cs.total, payload);           \
     }
         EV_ROW(0, qa)
-        rows_load<PASS, 2, 1, STREAM, CLS>(p, L, lane, qa);
+        rows_load<PASS, 2, 1, STREAM, CLS>(p, L, lane, qa, &SR);
         EV_ROW(1, qb)
-        rows_load<PASS, 3, 1, STREAM, CLS>(p, L, lane, qb);
+        rows_load<PASS, 3, 1, STREAM, CLS>(p, L, lane, qb, &SR);
         EV_STAMP(0)
         EV_ROW(2, qa)
-        rows_load<PASS, 4, 1, STREAM, CLS>(p, L, lane, qa);
+        rows_load<PASS, 4, 1, STREAM, CLS>(p, L, lane, qa, &SR);
         EV_ROW(3, qb)
-        rows_load<PASS, 5, 1, STREAM, CLS>(p, L, lane, qb);
+        rows_load<PASS, 5, 1, STREAM, CLS>(p, L, lane, qb, &SR);
         const float4 mat2 = setup_load_mat(p, rec2, lane);
         uint32_t cls2 = 0u;
         if constexpr (CLS) cls2 = setup_load_cls(p, rec2, lane);
         const uint4 rec3 = setup_load_rec(p, w3, w3 < ntiles, nrec, lane);
         EV_STAMP(1)
         EV_ROW(4, qa)
-        rows_load<PASS, 6, 1, STREAM, CLS>(p, L, lane, qa);
+        rows_load<PASS, 6, 1, STREAM, CLS>(p, L, lane, qa, &SR);
         EV_ROW(5, qb)
-        rows_load<PASS, 7, 1, STREAM, CLS>(p, L, lane, qb);
+        rows_load<PASS, 7, 1, STREAM, CLS>(p, L, lane, qb, &SR);
         EV_STAMP(2)
         EV_ROW(6, qa)
-        rows_load<PASS, 0, 1, STREAM, CLS>(p, Ln, lane, qa);
+        rows_load<PASS, 0, 1, STREAM, CLS>(p, Ln, lane, qa, &SR);
         EV_ROW(7, qb)
-        rows_load<PASS, 1, 1, STREAM, CLS>(p, Ln, lane, qb);
+        rows_load<PASS, 1, 1, STREAM, CLS>(p, Ln, lane, qb, &SR);
         EV_STAMP(3)
         if constexpr (PASS == 2) {
             if (occ2) tile_finish_occ(p, L, cand_ring[wave], lane, cs, payload);
@@ -840,7 +886,7 @@ __device__ __forceinline__ uint32_t pass1_build_list(const WaveTileLds &L, uint1
 #pragma unroll
     for (int r = 0; r < (int)kTileRows; r++) {
         const uint32_t rid = 2 * r + half;
-        const bool c = ml < L.rec[rid].z && ((L.prev[rid] >> ml) & 1u) != 0;
+        const bool c = ml < L.r[rid].rec.z && ((L.r[rid].prev >> ml) & 1u) != 0;
         const uint64_t mask = __ballot(c);
         if (c) list[n + lane_prefix(mask)] = (uint16_t)(r * 64 + lane);
         n += (uint32_t)__popcll(mask);
@@ -859,7 +905,7 @@ __device__ __forceinline__ Pass1Item pass1_load(const MeshletCullParams &p, cons
     it.code = valid ? (uint32_t)list[j] : ~0u;
     const uint32_t rid = (it.code >> 5) & 15u, ml = it.code & 31u;
     // unconditional loads (exact vmcnt accounting): lanes without a candidate read the zero page
-    const uint4 *src = valid ? reinterpret_cast<const uint4 *>(p.meshlets + (L.rec[rid].y + ml))
+    const uint4 *src = valid ? reinterpret_cast<const uint4 *>(p.meshlets + (L.r[rid].rec.y + ml))
                              : reinterpret_cast<const uint4 *>(p.zero_page);
     it.a = src[0];
     it.b = src[1];
@@ -1177,9 +1223,6 @@ struct __attribute__((aligned(16))) ChainLds {
     uint16_t list[kGroupRecords * 32];
 };
 
-constexpr uint32_t kBufFlags = 0x00020000u; // raw buffer, 32-bit data format
-constexpr uint32_t kNoOffset = 0xFFFFFF00u; // beyond every resource of this launch, also after a lane's +60 bytes
-                                            // (orbit_meshlet_stream_create bounds the stream's arrays)
 
 struct ChainRsrc {
     __amdgpu_buffer_rsrc_t recs, counts, bases, masks; // the dispatch records, the scan scratch

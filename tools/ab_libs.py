@@ -30,7 +30,13 @@ smode = os.environ.get("STREAM", "0")
 with_stream = [smode == "1" or (smode == "odd" and k % 2 == 1) or (smode == "even" and k % 2 == 0) for k in range(len(engs))]
 for eng, w in zip(engs, with_stream):
     if w:
-        eng.bind_meshlet_stream(eng.meshlet_stream(meshlets, 0, E * M))
+        ms = eng.meshlet_stream(meshlets, 0, E * M)
+        if os.environ.get("CLASSES", "0") == "1":  # the stream's alpha classes (evaluation without material indices)
+            ms.set_materials(materials, spec.materials)
+        eng.bind_meshlet_stream(ms)
+# placement probes: TAIL_MB allocates (and keeps) a block behind the last engine's arrays; ORDER=reverse times the
+# engines in reverse order of creation
+tail = torch.empty(int(os.environ.get("TAIL_MB", 0)) << 20, dtype=torch.uint8, device=dev)
 ref = None
 for eng in engs:
     for _ in range(3):
@@ -46,7 +52,7 @@ tf, tm, te = [[] for _ in engs], [[] for _ in engs], [[] for _ in engs]
 for eng in engs:
     eng.profile(True)
 for r in range(R):
-    for k, eng in enumerate(engs):
+    for k, eng in (list(enumerate(engs))[::-1] if os.environ.get("ORDER") == "reverse" else enumerate(engs)):
         a, m, z = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         a.record()
         eng.entity_cull(ci, draws, mesh, disp, ent, E, disp_cap)
