@@ -446,6 +446,19 @@ int32_t orbit_debug_read_cycles(OrbitCtx *ctx, unsigned long long out[8]) {
     return ORBIT_OK;
 }
 
+// perf triage only (not part of the public ABI; all zeros unless the library was built with -DORBIT_TRIAGE): reads and
+// clears the executed sphere-box test counts of the cluster assignment — coarse tests, coarse passes, count launch
+// {filter, cluster} tests, write launch {filter, cluster} tests, write-launch blocks served from the hit cache, the
+// largest candidate list of a group
+// (the count launch's per-block {begin, end} wall-clock stamps land where orbit_debug_read_wave_stamps reads)
+int32_t orbit_debug_read_cluster_tests(OrbitCtx *ctx, unsigned long long out[8]) {
+    if (!ctx || !out) return ORBIT_E_INVALID;
+    if (hipDeviceSynchronize() != hipSuccess) return ORBIT_E_HIP;
+    if (hipMemcpy(out, ctx->debug_cycles + 16, 64, hipMemcpyDeviceToHost) != hipSuccess) return ORBIT_E_HIP;
+    if (hipMemset(ctx->debug_cycles + 16, 0, 64) != hipSuccess) return ORBIT_E_HIP;
+    return ORBIT_OK;
+}
+
 // ------------------------------------------------------------------ entity_cull
 // Validates one entity cull and fills its parameter block; `scratch` owns the scan scratch the launch will use
 // (`ctx` itself, or one of its view children), errors are reported on `ctx`.  Caller holds ctx->mu.
@@ -1023,6 +1036,7 @@ int32_t orbit_cluster_assign(OrbitCtx *ctx, const OrbitClusterCullInfo *info, co
     p.block_base = ctx->a_block_base;
     p.total = ctx->a_total;
     p.status = ctx->status;
+    p.debug_tests = ctx->debug_cycles + 16;
     hipError_t e = launch_cluster_assign(p, ctx->num_cus, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch cluster_assign");
     return ORBIT_OK;

@@ -169,6 +169,7 @@ struct ClusterAssignParams {
     uint32_t *block_base;
     uint32_t *total;
     int32_t *status;
+    unsigned long long *debug_tests; // -DORBIT_TRIAGE builds: executed sphere-box tests per level (tools/cluster_tests.py)
 };
 
 hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_count, hipStream_t s);

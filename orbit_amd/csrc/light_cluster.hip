@@ -252,9 +252,25 @@ __device__ __forceinline__ bool sphere_hits(const Aabb3 &a, const float4 l) {
     return sq <= l.w;
 }
 
+// Executed-test accounting (SURVEY §8d prices the assignment in sphere-box tests, not bytes): -DORBIT_TRIAGE builds
+// only, one atomic per wave at the end of its work; the product library compiles none of it.
+#ifdef ORBIT_TRIAGE
+#define ORBIT_COUNT_TESTS(slot, n)                                                                  \
+    do {                                                                                            \
+        if (p.debug_tests && (threadIdx.x & 63) == 0 && (n) != 0) atomicAdd(p.debug_tests + (slot), (unsigned long long)(n)); \
+    } while (0)
+#define ORBIT_MAX_TESTS(slot, n)                                                                    \
+    do {                                                                                            \
+        if (p.debug_tests && threadIdx.x == 0) atomicMax(p.debug_tests + (slot), (unsigned long long)(n)); \
+    } while (0)
+#else
+#define ORBIT_COUNT_TESTS(slot, n) ((void)0)
+#define ORBIT_MAX_TESTS(slot, n) ((void)0)
+#endif
+
 constexpr uint32_t kLightTile = 1024;  // coarse candidates a block filters per step; survivors live in LDS (20 KB)
 // 4 waves x 4 clusters: 8 x 2 and 16 x 1 (same 16 clusters per block) measured 14 % and 40 % slower (r01_notes.md)
-constexpr int kClustersPerWave = 4;    // cluster AABBs held in scalar registers per wave
+constexpr int kClustersPerWave = 2;    // cluster AABBs held in scalar registers per wave
 constexpr int kAssignWaves = 4;
 constexpr int kClustersPerBlock = kClustersPerWave * kAssignWaves;
 constexpr uint32_t kGroupClusters = 256; // coarse level: one candidate list per 256 consecutive active clusters
@@ -371,6 +387,7 @@ __global__ __launch_bounds__(256) void cluster_coarse_kernel(const ClusterAssign
     const uint32_t sidx = (vb % kCoarseSplit) * 4 + wave;
     uint32_t *out = p.coarse + ((size_t)group * kCoarseSegs + sidx) * seg;
     uint32_t cnt = 0;
+    [[maybe_unused]] uint32_t tested = 0;
     const uint32_t begin = sidx * seg, end = min(begin + seg, nl);
     for (uint32_t b0 = begin; b0 < end; b0 += 256) { // 4 loads per lane issued together
         float4 l[4];
@@ -390,8 +407,13 @@ __global__ __launch_bounds__(256) void cluster_coarse_kernel(const ClusterAssign
             const uint64_t m = __ballot(pass);
             if (pass) out[cnt + lane_prefix(m)] = li | (point ? 0u : kNotPoint);
             cnt += (uint32_t)__popcll(m);
+#ifdef ORBIT_TRIAGE
+            tested += (uint32_t)__popcll(__ballot(li < end && point && !un.any_nan));
+#endif
         }
     }
+    ORBIT_COUNT_TESTS(0, tested);
+    ORBIT_COUNT_TESTS(1, cnt);
     if (lane == 0) p.coarse_counts[group * kCoarseSegs + sidx] = cnt;
     }
 }
@@ -400,66 +422,109 @@ template <bool WRITE>
 __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const ClusterAssignParams p) {
     __shared__ float4 s_cand[kLightTile];       // a segment per wave: view-space light ...
     __shared__ uint32_t s_cand_idx[kLightTile]; // ... and its index | kNotPoint
-    __shared__ float s_box[kClustersPerBlock][6];
+    __shared__ float s_wbox[kAssignWaves][8];   // per wave: union of its clusters' boxes (6) and its any-NaN flag
     __shared__ uint32_t s_wave_cnt[kAssignWaves];
     __shared__ uint32_t s_cpre[kCoarseSegs + 1]; // prefix of the group's segment counts
+    __shared__ uint32_t s_ccnt[kCoarseSegs];     // the counts themselves
+    __shared__ uint32_t s_fast;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef ORBIT_TRIAGE_STAMPS // (a build of its own, tools/cluster_tests.py: the counters' atomics would dominate the stamps)
+    // block life stamps of the COUNT launch (wall clock, 100 MHz): debug_tests[16 + 2 b] = begin, [.. + 1] = end of
+    // block b; the end stamp is taken behind a wait for the block's own stores (tools/cluster_tests.py)
+    const unsigned long long t_begin = wall_clock64();
+    unsigned long long dbg_filtered = 0, dbg_ctotal = 0;
+#endif
     const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.unique);
-    const uint32_t n = min(hdr[3], p.max_clusters);
-    // grid-stride over the blocks of 16 active clusters that exist (see cluster_aabb_kernel)
-    for (uint32_t block_first = blockIdx.x * kClustersPerBlock; block_first < n;
-         block_first += gridDim.x * kClustersPerBlock) {
-    const uint32_t u0 = block_first + wave * kClustersPerWave;
-    if (wave == 0) { // exclusive prefix of the 16 segment counts (one load per lane, wave scan)
-        const uint32_t *cc = p.coarse_counts + (size_t)(block_first / kGroupClusters) * kCoarseSegs;
-        const uint32_t v = lane < (int)kCoarseSegs ? cc[lane] : 0u;
-        const uint32_t inc = wave_inclusive_scan(v);
-        if (lane < (int)kCoarseSegs) s_cpre[lane] = inc - v;
-        if (lane == (int)kCoarseSegs - 1) s_cpre[kCoarseSegs] = inc;
-    }
     const uint32_t *unique_idx = reinterpret_cast<const uint32_t *>(p.unique + ORBIT_COMPACT_HEADER);
-
-    // lanes 0..3 fetch the cached AABBs of the wave's clusters; broadcast through readlane into SGPRs
-    Aabb3 box = {};
-    uint32_t my_ci = 0, my_limit = 0, my_offset = 0;
-    const bool owns = lane < kClustersPerWave && u0 + lane < n;
-    if (owns) {
-        my_ci = unique_idx[u0 + lane];
+    uint32_t *out = reinterpret_cast<uint32_t *>(p.light_index_buffer + ORBIT_LIGHT_INDEX_HEADER);
+    // The kernel is a chain of dependent loads, not arithmetic (config 4 executes 0.4 M tests in it): what it costs is
+    // the number of memory round trips on a block's critical path and whether all blocks are resident at once.  So
+    // (1) the header word n is loaded first but consumed only after every load of the block's first item that needs no
+    // other load's result is in flight (indices are clamped to the buffers instead of compared with n), and (2) the
+    // coarse candidates are fetched speculatively — lane i takes entry i of the wave's four segments before the
+    // segment counts are known — which serves every group whose segments hold at most 64 candidates in two round
+    // trips (setup + candidates | lights); longer lists take the stepped path below.
+    const uint32_t n_raw = hdr[3];
+    uint32_t n = 0;
+    bool first_item = true;
+    constexpr uint32_t kSeg = kLightTile / kAssignWaves; // LDS candidates per wave and step
+    constexpr uint32_t kLoads = kSeg / 64u;              // coarse candidates per lane and step
+    static_assert(kLoads * kAssignWaves == kCoarseSegs, "wave w owns coarse segments kLoads * w ..");
+    // grid-stride over the blocks of 32 active clusters that exist (see cluster_aabb_kernel)
+    for (uint32_t block_first = blockIdx.x * kClustersPerBlock;; block_first += gridDim.x * kClustersPerBlock) {
+    if (!first_item && block_first >= n) break;
+    const uint32_t u0 = block_first + wave * kClustersPerWave;
+    const uint32_t group = block_first / kGroupClusters;
+    const uint32_t *cbase = p.coarse + (size_t)group * kCoarseSegs * p.coarse_seg;
+    // ---- round trip 1: everything addressed by the block's position alone
+    const uint32_t ul = min(u0 + ((uint32_t)lane & (kClustersPerWave - 1)), p.max_clusters - 1u); // lanes 0..7 count
+    uint32_t my_ci = unique_idx[ul];
+    Aabb3 box;
 #pragma unroll
-        for (int i = 0; i < 3; i++) box.mn[i] = p.aabb[6 * (size_t)(u0 + lane) + i], box.mx[i] = p.aabb[6 * (size_t)(u0 + lane) + 3 + i];
-        if (WRITE) {
-            my_limit = p.counts[u0 + lane];
-            // exclusive prefix of the capped counts: chunk-local prefix + chunk base of the two-level scan
-            my_offset = p.block_base[u0 + lane] +
-                        (p.block_sums + (p.max_clusters / kScanChunk + 2))[(u0 + lane) / kScanChunk];
-        }
+    for (int i = 0; i < 3; i++) box.mn[i] = p.aabb[6 * (size_t)ul + i], box.mx[i] = p.aabb[6 * (size_t)ul + 3 + i];
+    const uint32_t cc = p.coarse_counts[(size_t)group * kCoarseSegs + ((uint32_t)lane & (kCoarseSegs - 1))];
+    uint32_t my_limit = 0, my_offset = 0;
+    constexpr uint32_t kHcRounds = (kClustersPerWave * kHitCache + 63u) / 64u, kHcPerRound = 64u / kHitCache;
+    uint32_t hc[kHcRounds] = {};
+    if (WRITE) {
+        my_limit = p.counts[ul];
+        // exclusive prefix of the capped counts: chunk-local prefix + chunk base of the two-level scan
+        my_offset = p.block_base[ul] + (p.block_sums + (p.max_clusters / kScanChunk + 2))[ul / kScanChunk];
+        // (cluster, slot) per lane, two rounds: the indices the counting launch kept
+#pragma unroll
+        for (uint32_t j = 0; j < kHcRounds; j++)
+            hc[j] = p.hit_cache[(size_t)(u0 + j * kHcPerRound + (uint32_t)lane / kHitCache) * kHitCache + (uint32_t)lane % kHitCache];
+    }
+    uint32_t tag[kLoads];
+    if (!WRITE) {
+#pragma unroll
+        for (uint32_t r = 0; r < kLoads; r++) tag[r] = cbase[(size_t)(wave * kLoads + r) * p.coarse_seg + (uint32_t)lane];
+    }
+    if (first_item) {
+        n = min(n_raw, p.max_clusters);
+        first_item = false;
+        if (block_first >= n) break;
+    }
+    const bool owns = lane < kClustersPerWave && u0 + lane < n;
+    if (wave == 0) { // exclusive prefix of the 16 segment counts (wave scan); fast = no segment longer than a wave
+        const uint32_t v = lane < (int)kCoarseSegs ? cc : 0u;
+        const uint32_t inc = wave_inclusive_scan(v);
+        if (lane < (int)kCoarseSegs) s_cpre[lane] = inc - v, s_ccnt[lane] = v;
+        if (lane == (int)kCoarseSegs - 1) s_cpre[kCoarseSegs] = inc;
+        const bool lng = __ballot(v > 64u) != 0ull;
+        if (lane == 0) s_fast = lng ? 0u : 1u;
     }
     if (WRITE) {
         // A block whose clusters all found at most kHitCache lights copies the indices the counting launch kept
         // (the common case by far: a cluster holds a handful of lights) instead of testing everything again.
         if (__syncthreads_or(owns && my_limit > kHitCache) == 0) {
-            const uint32_t c = (uint32_t)lane / kHitCache, k = (uint32_t)lane % kHitCache; // (cluster, slot) per lane
-            static_assert(kClustersPerWave * kHitCache <= 64, "one lane per (cluster, slot)");
-            const uint32_t lim = (uint32_t)__shfl((int)my_limit, (int)c, 64);
-            const uint32_t off = (uint32_t)__shfl((int)my_offset, (int)c, 64);
-            const uint32_t ci = (uint32_t)__shfl((int)my_ci, (int)c, 64);
-            uint32_t *out = reinterpret_cast<uint32_t *>(p.light_index_buffer + ORBIT_LIGHT_INDEX_HEADER);
-            if (c < (uint32_t)kClustersPerWave && u0 + c < n) {
-                if (k < lim && off + k < p.light_index_capacity) out[off + k] = p.hit_cache[(size_t)(u0 + c) * kHitCache + k];
-                if (k == 0) { // imageStore(cluster_offset_image, cluster_id, (offset, count)), :149-150
-                    p.offset_image[2 * (size_t)ci + 0] = off;
-                    p.offset_image[2 * (size_t)ci + 1] = lim;
+#pragma unroll
+            for (uint32_t j = 0; j < kHcRounds; j++) { // one lane per (cluster, slot)
+                const uint32_t c = j * kHcPerRound + (uint32_t)lane / kHitCache, k = (uint32_t)lane % kHitCache;
+                const uint32_t lim = (uint32_t)__shfl((int)my_limit, (int)c, 64);
+                const uint32_t off = (uint32_t)__shfl((int)my_offset, (int)c, 64);
+                const uint32_t ci = (uint32_t)__shfl((int)my_ci, (int)c, 64);
+                if (c < (uint32_t)kClustersPerWave && u0 + c < n) {
+                    if (k < lim && off + k < p.light_index_capacity) out[off + k] = hc[j];
+                    if (k == 0) { // imageStore(cluster_offset_image, cluster_id, (offset, count)), :149-150
+                        p.offset_image[2 * (size_t)ci + 0] = off;
+                        p.offset_image[2 * (size_t)ci + 1] = lim;
+                    }
                 }
             }
-            continue; // block-uniform; nothing below the barrier above reads LDS on this path
+            ORBIT_COUNT_TESTS(6, wave == 0 ? 1u : 0u);
+            __syncthreads(); // s_cpre / s_ccnt are rewritten by the next item
+            continue;        // block-uniform
         }
     }
-    if (lane < kClustersPerWave) {
-        float *bx = s_box[wave * kClustersPerWave + lane];
+    // absent cluster: the empty box, neutral in the union
+    {
         const float inf = __uint_as_float(0x7f800000u);
 #pragma unroll
-        for (int i = 0; i < 3; i++) bx[i] = owns ? box.mn[i] : inf, bx[3 + i] = owns ? box.mx[i] : -inf;
+        for (int i = 0; i < 3; i++) box.mn[i] = owns ? box.mn[i] : inf, box.mx[i] = owns ? box.mx[i] : -inf;
     }
+    // the wave's boxes into scalar registers; their union over the wave (lanes 0..7 hold them), then over the block.
+    // With a NaN anywhere the filter is bypassed (flag), so what the selects make of a NaN operand does not matter.
     float mn[kClustersPerWave][3], mx[kClustersPerWave][3];
     uint32_t offset[kClustersPerWave], limit[kClustersPerWave], count[kClustersPerWave];
     bool valid[kClustersPerWave];
@@ -475,6 +540,30 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
         count[c] = 0;
         valid[c] = u0 + c < n;
     }
+    {
+        bool nan = false;
+        float lo[3], hi[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            lo[i] = box.mn[i], hi[i] = box.mx[i];
+            nan = nan || lo[i] != lo[i] || hi[i] != hi[i];
+        }
+        const bool wave_nan = (__ballot(nan) & ((1ull << kClustersPerWave) - 1ull)) != 0ull;
+#pragma unroll
+        for (int d = kClustersPerWave / 2; d >= 1; d >>= 1) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const float ol = __shfl_xor(lo[i], d, 64), oh = __shfl_xor(hi[i], d, 64);
+                lo[i] = ol < lo[i] ? ol : lo[i];
+                hi[i] = oh > hi[i] ? oh : hi[i];
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) s_wbox[wave][i] = lo[i], s_wbox[wave][3 + i] = hi[i];
+            s_wbox[wave][6] = wave_nan ? 1.0f : 0.0f;
+        }
+    }
     __syncthreads();
     BoxUnion un;
     un.any_nan = false;
@@ -483,47 +572,31 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
 #pragma unroll
         for (int i = 0; i < 3; i++) un.box.mn[i] = inf, un.box.mx[i] = -inf;
     }
-    for (int c = 0; c < kClustersPerBlock; c++) union_add(un, &s_box[c][0], &s_box[c][3]);
-
-    uint32_t *out = reinterpret_cast<uint32_t *>(p.light_index_buffer + ORBIT_LIGHT_INDEX_HEADER);
-    // The group's candidates in light order = its coarse segments back to back.  A step takes the next
-    // kLightTile entries of that sequence; wave w filters the w-th quarter of the step into LDS segment w.
-    constexpr uint32_t kSeg = kLightTile / kAssignWaves;
-    const uint32_t group = block_first / kGroupClusters;
-    const uint32_t *cbase = p.coarse + (size_t)group * kCoarseSegs * p.coarse_seg;
+#pragma unroll
+    for (int w = 0; w < kAssignWaves; w++) {
+        union_add(un, &s_wbox[w][0], &s_wbox[w][3]);
+        un.any_nan = un.any_nan || s_wbox[w][6] != 0.0f;
+    }
     const uint32_t ctotal = s_cpre[kCoarseSegs];
-    auto coarse_at = [&](uint32_t k) -> uint32_t { // k-th candidate of the group, k < ctotal
-        uint32_t sg = 0; // last segment whose prefix is <= k (bisection over the 16 prefixes)
-#pragma unroll
-        for (uint32_t half = kCoarseSegs / 2; half >= 1; half /= 2) sg += s_cpre[sg + half] <= k ? half : 0u;
-        return cbase[(size_t)sg * p.coarse_seg + (k - s_cpre[sg])];
-    };
-    // one step = 1024 coarse candidates = one group of 4 (index, light) load pairs per lane; the next step's
-    // loads are issued before this step's test phase
-    constexpr uint32_t kLoads = kSeg / 64u; // candidates per lane per step
-    uint32_t tag[kLoads];
+    const bool fast = !WRITE && s_fast != 0u; // block-uniform
+    [[maybe_unused]] uint32_t n_filter = 0, n_test = 0;
+    ORBIT_MAX_TESTS(7, ctotal);
+
     float4 l[kLoads];
-    auto load_step = [&](uint32_t step0) {
-        const uint32_t s_begin = step0 + wave * kSeg, s_end = min(s_begin + kSeg, ctotal);
-#pragma unroll
-        for (uint32_t r = 0; r < kLoads; r++) {
-            const uint32_t k = s_begin + r * 64u + (uint32_t)lane;
-            tag[r] = k < s_end ? coarse_at(k) : 0u;
-        }
-#pragma unroll
-        for (uint32_t r = 0; r < kLoads; r++) l[r] = p.view_lights[tag[r] & ~kNotPoint];
-    };
-    if (ctotal > 0) load_step(0);
-    for (uint32_t step0 = 0; step0 < ctotal; step0 += kLightTile) { // block-uniform trip count
-        // ---- filter: this wave's quarter of the step
+    bool have[kLoads];
+    // One step: the wave filters its (up to) kSeg candidates {tag, l, have} into LDS segment `wave`, in light order
+    // (filter_step); then, behind a barrier, every wave tests its clusters against the four segments in order
+    // (test_step).
+    auto filter_step = [&]() {
         uint32_t seg_n = 0; // wave-uniform
-        const uint32_t s_begin = step0 + wave * kSeg, s_end = min(s_begin + kSeg, ctotal);
 #pragma unroll
         for (uint32_t r = 0; r < kLoads; r++) {
-            const uint32_t k = s_begin + r * 64u + (uint32_t)lane;
             const bool point = (tag[r] & kNotPoint) == 0u;
-            const bool pass = k < s_end && (!point || un.any_nan || sphere_hits(un.box, l[r]));
+            const bool pass = have[r] && (!point || un.any_nan || sphere_hits(un.box, l[r]));
             const uint64_t m = __ballot(pass);
+#ifdef ORBIT_TRIAGE
+            n_filter += (uint32_t)__popcll(__ballot(have[r] && point && !un.any_nan));
+#endif
             if (pass) {
                 const uint32_t pos = wave * kSeg + seg_n + lane_prefix(m);
                 s_cand[pos] = l[r];
@@ -532,9 +605,15 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
             seg_n += (uint32_t)__popcll(m);
         }
         if (lane == 0) s_wave_cnt[wave] = seg_n;
-        if (step0 + kLightTile < ctotal) load_step(step0 + kLightTile); // in flight during the test phase
-        __syncthreads(); // all segments complete
-        // ---- test: the wave's clusters against the candidates, segment by segment (ascending light order)
+    };
+    // A wave with many candidates (a hot spot: a thousand lights over one block's clusters) is a serial loop of
+    // sphere-box tests at one wave per SIMD, and the launch lasts as long as its slowest block: the eight tests of a
+    // batch are straight-line code (eight independent chains, no branch between them), the ordered writes follow.
+    auto test_step = [&]() {
+#ifdef ORBIT_TRIAGE_STAMPS
+        dbg_filtered += s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+        dbg_ctotal = ctotal;
+#endif
         for (uint32_t seg = 0; seg < (uint32_t)kAssignWaves; seg++) {
             const uint32_t cnt = s_wave_cnt[seg];
             for (uint32_t b0 = 0; b0 < cnt; b0 += 64) {
@@ -543,43 +622,107 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
                 const float4 cl = s_cand[seg * kSeg + (in_list ? ci : 0)];
                 const uint32_t ctag = s_cand_idx[seg * kSeg + (in_list ? ci : 0)];
                 const bool point = (ctag & kNotPoint) == 0u;
+                uint64_t hits[kClustersPerWave];
 #pragma unroll
                 for (int c = 0; c < kClustersPerWave; c++) {
-                    if (!valid[c]) continue; // wave-uniform
                     Aabb3 a;
 #pragma unroll
                     for (int i = 0; i < 3; i++) a.mn[i] = mn[c][i], a.mx[i] = mx[c][i];
-                    const bool hit = in_list && (!point || sphere_hits(a, cl)); // :108-119
-                    const uint64_t m = __ballot(hit);
-                    if (hit) {
-                        const uint32_t k = count[c] + lane_prefix(m);
-                        if (WRITE) {
-                            if (k < limit[c] && offset[c] + k < p.light_index_capacity) // while (counter < light_count), :140
-                                out[offset[c] + k] = ctag & ~kNotPoint;
-                        } else if (k < kHitCache) {
-                            p.hit_cache[(size_t)(u0 + c) * kHitCache + k] = ctag & ~kNotPoint;
+                    hits[c] = __ballot(in_list && (!point || sphere_hits(a, cl))); // :108-119
+                }
+#ifdef ORBIT_TRIAGE
+                n_test += (uint32_t)__popcll(__ballot(in_list && point)) * (uint32_t)kClustersPerWave;
+#endif
+#pragma unroll
+                for (int c = 0; c < kClustersPerWave; c++) {
+                    const uint64_t m = hits[c];
+                    if (!valid[c] || m == 0ull) continue; // wave-uniform
+                    if (WRITE || count[c] < kHitCache) {  // wave-uniform: the counting launch keeps the first few only
+                        if ((m >> lane) & 1ull) {
+                            const uint32_t k = count[c] + lane_prefix(m);
+                            if (WRITE) {
+                                if (k < limit[c] && offset[c] + k < p.light_index_capacity) // while (counter < light_count), :140
+                                    out[offset[c] + k] = ctag & ~kNotPoint;
+                            } else if (k < kHitCache) {
+                                p.hit_cache[(size_t)(u0 + c) * kHitCache + k] = ctag & ~kNotPoint;
+                            }
                         }
                     }
                     count[c] += (uint32_t)__popcll(m);
                 }
             }
         }
-        __syncthreads(); // candidates consumed before the next step's filter overwrites them
-    }
+    };
+    if (fast) {
+        // ---- round trip 2: the lights of the speculatively fetched candidates (an entry past its segment's count
+        // is a stale index of an earlier call: never used)
 #pragma unroll
-    for (int c = 0; c < kClustersPerWave; c++) {
-        if (!valid[c] || lane != 0) continue;
-        if (!WRITE) {
-            p.counts[u0 + c] = min(count[c], ORBIT_MAX_LIGHTS_PER_CLUSTER); // :135
-        } else {
-            // imageStore(cluster_offset_image, cluster_id, (offset, count)), :149-150
-            const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)my_ci, c);
-            p.offset_image[2 * (size_t)ci + 0] = offset[c];
-            p.offset_image[2 * (size_t)ci + 1] = limit[c];
+        for (uint32_t r = 0; r < kLoads; r++) {
+            have[r] = (uint32_t)lane < s_ccnt[wave * kLoads + r];
+            tag[r] = have[r] ? tag[r] : 0u; // one address for the lanes without a candidate
+            l[r] = p.view_lights[tag[r] & ~kNotPoint];
+        }
+        filter_step();
+        __syncthreads(); // all segments complete
+        test_step();
+    } else {
+        // The group's candidates in light order = its coarse segments back to back.  A step takes the next kLightTile
+        // entries of that sequence; wave w filters the w-th quarter of the step into LDS segment w.  The next step's
+        // loads are issued before this step's test phase.
+        auto coarse_at = [&](uint32_t k) -> uint32_t { // k-th candidate of the group, k < ctotal
+            uint32_t sg = 0; // last segment whose prefix is <= k (bisection over the 16 prefixes)
+#pragma unroll
+            for (uint32_t half = kCoarseSegs / 2; half >= 1; half /= 2) sg += s_cpre[sg + half] <= k ? half : 0u;
+            return cbase[(size_t)sg * p.coarse_seg + (k - s_cpre[sg])];
+        };
+        auto load_step = [&](uint32_t step0) {
+            const uint32_t s_begin = step0 + wave * kSeg, s_end = min(s_begin + kSeg, ctotal);
+#pragma unroll
+            for (uint32_t r = 0; r < kLoads; r++) {
+                const uint32_t k = s_begin + r * 64u + (uint32_t)lane;
+                have[r] = k < s_end;
+                tag[r] = have[r] ? coarse_at(k) : 0u;
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < kLoads; r++) l[r] = p.view_lights[tag[r] & ~kNotPoint];
+        };
+        if (ctotal > 0) load_step(0);
+        for (uint32_t step0 = 0; step0 < ctotal; step0 += kLightTile) { // block-uniform trip count
+            filter_step();
+            if (step0 + kLightTile < ctotal) load_step(step0 + kLightTile); // in flight during the test phase
+            __syncthreads(); // all segments complete
+            test_step();
+            __syncthreads(); // candidates consumed before the next step's filter overwrites them
         }
     }
-    __syncthreads(); // s_cpre / s_box are rewritten by the next block of clusters
+    ORBIT_COUNT_TESTS(WRITE ? 4 : 2, n_filter);
+    ORBIT_COUNT_TESTS(WRITE ? 5 : 3, n_test);
+    {   // lane c publishes cluster c's result
+        uint32_t mine = 0, lim = 0, off = 0;
+#pragma unroll
+        for (int c = 0; c < kClustersPerWave; c++)
+            if (lane == c) mine = count[c], lim = limit[c], off = offset[c];
+        if (owns) {
+            if (!WRITE) {
+                p.counts[u0 + lane] = min(mine, ORBIT_MAX_LIGHTS_PER_CLUSTER); // :135
+            } else {
+                // imageStore(cluster_offset_image, cluster_id, (offset, count)), :149-150
+                p.offset_image[2 * (size_t)my_ci + 0] = off;
+                p.offset_image[2 * (size_t)my_ci + 1] = lim;
+            }
+        }
     }
+    __syncthreads(); // s_cpre / s_wbox are rewritten by the next block of clusters
+    }
+#ifdef ORBIT_TRIAGE_STAMPS
+    if (!WRITE && p.debug_tests && threadIdx.x == 0 && blockIdx.x < 4096u) {
+        __builtin_amdgcn_s_waitcnt(0);
+        p.debug_tests[16 + 2 * blockIdx.x] = t_begin;
+        p.debug_tests[16 + 2 * blockIdx.x + 1] = wall_clock64();
+        p.debug_tests[16 + 2 * (4096u + blockIdx.x)] = dbg_filtered;   // candidates behind the block's filter (wave 0's view: all segments)
+        p.debug_tests[16 + 2 * (4096u + blockIdx.x) + 1] = dbg_ctotal; // the group's coarse candidates
+    }
+#endif
     if (WRITE && blockIdx.x == 0 && threadIdx.x == 0) {
         const uint32_t total = *p.total;
         *reinterpret_cast<uint32_t *>(p.light_index_buffer) = total; // atomicAdd total, :136
@@ -629,7 +772,7 @@ hipError_t launch_cluster_assign(const ClusterAssignParams &p, uint32_t num_cus,
     // the number of active clusters is only known on the device: grids are bounded by the chip, not by the capacity,
     // and the kernels stride over the work that exists
     const uint32_t groups = (p.max_clusters + kGroupClusters - 1) / kGroupClusters;
-    const uint32_t blocks = min((p.max_clusters + kClustersPerBlock - 1) / kClustersPerBlock, num_cus * 16u);
+    const uint32_t blocks = min((p.max_clusters + kClustersPerBlock - 1) / kClustersPerBlock, num_cus * 32u);
     hipLaunchKernelGGL(cluster_aabb_kernel, dim3(min(groups, num_cus * 4u)), dim3(256), 0, s, p);
     hipLaunchKernelGGL(cluster_coarse_kernel, dim3(min(groups * kCoarseSplit, num_cus * 8u)), dim3(256), 0, s, p);
     hipLaunchKernelGGL(cluster_assign_kernel<false>, dim3(blocks), dim3(kAssignWaves * 64), 0, s, p);
