@@ -85,3 +85,26 @@ def test_bench_rccl_transport_with_a_world_of_one():
     c = d["config"]
     assert c["gather"] is True and c["transport"] == "rccl" and c["world_size"] == 1 and c["backend"] == "nccl"
     assert d["per_rank"]["exchange_ms"][0] > 0
+
+
+def test_bench_under_torch_distributed_run_as_the_driver_starts_it():
+    """The driver's own launch line for N > 1 — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` — with both ranks on the box's one GPU: bench.py
+    must take RANK / LOCAL_RANK / WORLD_SIZE from the launcher (not start ranks of its own), and rank 0 alone prints
+    the ONE JSON line."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "4", "--warmup", "2", "--entities", "6000", "--settle-ms", "5"],
+                       capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, ORBIT_BENCH_ONE_DEVICE="1", ORBIT_BENCH_BACKEND="gloo", ORBIT_BENCH_TIMEOUT_S="600"))
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["steps"] == 4 and d["warmup"] == 2
+    assert sum(d["per_rank"]["meshlets_in"]) == 6000 * 256 and d["value"] > 0

@@ -82,13 +82,15 @@ def main():
             c4["assign_ms"] = timeit(lambda: eng.cluster_assign(info, gu, gb, glights, gl, lcap, gimg), n=10, warm=2)
             torch.cuda.synchronize()
             c4["active_clusters"] = int(gu[12:16].view(torch.int32).item()); c4["light_indices"] = int(gl[:4].view(torch.int32).item())
-            c4["sphere_tests_per_s"] = 2.0 * c4["active_clusters"] * nl / (c4["assign_ms"] * 1e-3)
-            # distribution of lights per active cluster (compacted order) and per block of 16: what the hit cache sees
+            # what the reference's shader would have run in that time (2 x active x lights); the tests the three-level cull
+            # really executes are counted by tools/cluster_tests.py (0.26 % of these at this configuration)
+            c4["reference_equivalent_sphere_tests_per_s"] = 2.0 * c4["active_clusters"] * nl / (c4["assign_ms"] * 1e-3)
+            # distribution of lights per active cluster (compacted order) and per block of 8: what the hit cache sees
             na = c4["active_clusters"]
             uidx = gu[16:16 + 4 * na].view(torch.int32).long()
             cnt = gimg.view(torch.int32).view(-1, 2)[uidx, 1].cpu().numpy()
-            pad = np.zeros((-len(cnt)) % 16, dtype=cnt.dtype)
-            bmax = np.concatenate([cnt, pad]).reshape(-1, 16).max(axis=1)
+            pad = np.zeros((-len(cnt)) % 8, dtype=cnt.dtype)
+            bmax = np.concatenate([cnt, pad]).reshape(-1, 8).max(axis=1)
             c4["lights_per_cluster"] = {"mean": float(cnt.mean()), "p99": int(np.percentile(cnt, 99)), "max": int(cnt.max()),
                                         "blocks_over_16": int((bmax > 16).sum()), "blocks": int(len(bmax))}
             out["config4"] = c4
