@@ -3,7 +3,8 @@
 
 One "step" = one pass of the hot path over the scene: entity_cull + meshlet_cull
 (frustum + normal cone, occlusion_pass 0) on this rank's entity shard and, for
-N > 1, the rank-ordered all-gather of the compacted visible list (8-B items; orbit_amd/dist.py) —
+N > 1, the rank-ordered all-gather of the compacted visible list (12 B per dispatch record with a survivor;
+orbit_amd/dist.py) —
 what BASELINE.json's north_star names.  Turning the gathered list into 28-B commands on every GPU is a
 separate, optional stage (--expand all), reported on its own.
 Inputs are generated on the device and stay resident in HBM; the timed region is
@@ -44,11 +45,13 @@ def parse():
                     help="N>1: how the lists travel — p2p: direct stores into the peers' IPC-mapped buffers at "
                          "device-computed offsets, no host round trip (default; falls back to rccl when IPC is not "
                          "available); rccl: counts to the host, grouped RCCL send/recv")
-    ap.add_argument("--exchange", choices=("visible", "commands"), default="visible",
-                    help="N>1 exchange format: 8-B visible items expanded on every GPU against the replicated "
-                         "meshlet buffer (default), or the 28-B commands themselves")
+    ap.add_argument("--exchange", choices=("records", "visible", "commands"), default="records",
+                    help="N>1 exchange format of the visible list: records (default) — 12 B {entity, meshlet offset, "
+                         "should-draw ballot} per dispatch record with a survivor, half the items' bytes at "
+                         "config 5; visible — 8 B {meshlet, entity} per survivor; commands — the 28-B commands "
+                         "themselves")
     ap.add_argument("--expand", choices=("none", "all"), default="none",
-                    help="N>1, exchange visible: what happens to the gathered 8-B list inside the step — none "
+                    help="N>1, exchange records / visible: what happens to the gathered list inside the step — none "
                          "(default: the step is cull + all-gather, every rank then holds the whole visible list and "
                          "issues its draws from it or from its own shard, SURVEY.md §8e), or all (every rank also "
                          "expands the whole list into 28-B commands: N-independent work on every GPU)")
@@ -186,13 +189,18 @@ def main():
     # tensor, every rank stores its list straight into every peer's buffer (IPC-mapped, xGMI) at device-computed
     # offsets, one more fixed-size collective as completion (orbit_amd/dist.py P2PExchange, orbit_scatter_list).
     # Transport "rccl": counts read on the host, grouped RCCL send/recv of the lists (needs the nccl backend).
-    # Format "visible" (default): 8-B {meshlet_index, entity_index} items travel and every GPU expands the gathered
+    # Format "visible": 8-B {meshlet_index, entity_index} items travel and a GPU that wants commands expands the gathered
     # list into the 28-B commands itself — which needs the meshlet buffer (static geometry, 1.6 GB of 288 GB) on every
     # GPU; a rank still STREAMS only its own shard through meshlet_cull.  Format "commands": the 28-B lists travel as
     # they are and a rank holds only its meshlet shard.
     do_gather = use_dist and not args.no_gather and (backend == "nccl" or args.transport == "p2p")
+    # Format "records": the same ordered list at record granularity — 12 B {entity_index, meshlet_offset, ballot} per
+    # dispatch record with a survivor (orbit_meshlet_cull_visible_records), built straight from the evaluation's
+    # ballots (no survivor scan, no emit launch); half the 8-B items' bytes at config 5 (3.2 survivors per surviving record).
     visible_exchange = do_gather and args.exchange == "visible"
-    do_expand = visible_exchange and args.expand == "all"  # needs the whole meshlet buffer (+ stream) on every GPU
+    records_exchange = do_gather and args.exchange == "records"
+    compact_exchange = visible_exchange or records_exchange
+    do_expand = compact_exchange and args.expand == "all"  # needs the whole meshlet buffer (+ stream) on every GPU
     t0 = time.time()
     draws, mesh, ent, half = synth.gen_entity_tables(spec, dev)
     mb, me = (0, E) if do_expand else (b, e)
@@ -220,7 +228,8 @@ def main():
     # ONE slot: strictly serial frames, step time = frame latency, clean per-kernel durations.
     # N > 1: the exchange of step i runs on its own stream while step i+1 culls into the slot's other list buffer.
     F = max(1, args.frames_in_flight)
-    hdr, item = (L.VISIBLE_HEADER, 8) if visible_exchange else (L.DRAW_HEADER, 28)
+    hdr, item = (L.VISIBLE_HEADER, 12) if records_exchange else (L.VISIBLE_HEADER, 8) if visible_exchange else (L.DRAW_HEADER, 28)
+    list_cap = disp_cap if records_exchange else draw_cap  # entries a rank's list can hold (records / survivors)
 
     class Slot:
         def __init__(self):
@@ -228,7 +237,7 @@ def main():
                               max_draws=draw_cap)
             self.stream = torch.cuda.Stream(device=dev)
             self.disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device=dev)
-            self.lists = [torch.zeros(hdr + item * draw_cap, dtype=torch.uint8, device=dev)
+            self.lists = [torch.zeros(hdr + item * list_cap, dtype=torch.uint8, device=dev)
                           for _ in range(2 if do_gather else 1)]
             self.cull_done = [torch.cuda.Event() for _ in self.lists]
             self.xdone = [torch.cuda.Event() for _ in self.lists]
@@ -247,7 +256,7 @@ def main():
         mstream_build_ms = (time.perf_counter() - t0) * 1e3
         for s in slots:
             s.eng.bind_meshlet_stream(mstream)
-    # The exchange stage: two exchange buffers (alternating) and, for the 8-B format, a third stream for the expansion,
+    # The exchange stage: two exchange buffers (alternating) and, with --expand all, a third stream for the expansion,
     # so that three things overlap in steady state — the cull of step i+1 (slot stream), the wire of step i (exchange
     # stream) and the expansion of step i-1 (expansion stream): step time = max(cull, wire, expansion), not their sum.
     xstream = estream = gathered = None
@@ -256,13 +265,14 @@ def main():
     if do_gather:
         xstream = torch.cuda.Stream(device=dev)
         estream = torch.cuda.Stream(device=dev)
-        out_cap = draw_cap * world
+        out_cap = draw_cap * world  # commands of the whole scene (--expand all)
+        x_cap = list_cap * world    # entries of the gathered list
         transport = args.transport
         n_x = 2
         if transport == "p2p":
             ok = 1
             try:
-                exchanges = [odist.P2PExchange(slots[0].eng, out_cap, hdr, item, dev) for _ in range(n_x)]
+                exchanges = [odist.P2PExchange(slots[0].eng, x_cap, hdr, item, dev) for _ in range(n_x)]
             except Exception as ex:  # IPC not available between these processes: every rank falls back together
                 print(f"bench.py: p2p exchange unavailable on rank {rank} ({ex}); falling back to RCCL send/recv",
                       file=sys.stderr)
@@ -276,7 +286,7 @@ def main():
         if transport == "p2p":
             recv_bufs = [x.out for x in exchanges]
         else:
-            recv_bufs = [torch.zeros(hdr + item * out_cap, dtype=torch.uint8, device=dev) for _ in range(n_x)]
+            recv_bufs = [torch.zeros(hdr + item * x_cap, dtype=torch.uint8, device=dev) for _ in range(n_x)]
         x_events = [torch.cuda.Event() for _ in range(n_x)]  # exchange into recv_bufs[j] finished
         e_events = [torch.cuda.Event() for _ in range(n_x)]  # expansion out of recv_bufs[j] finished
         if do_expand:
@@ -286,7 +296,7 @@ def main():
 
     def gather(s, k):
         # the exchange of one list on the exchange stream, behind the cull that wrote the list — not behind the cull
-        # enqueued after it; the expansion (8-B format) follows on its own stream
+        # enqueued after it; the expansion (--expand all) follows on its own stream
         j = x_count[0] % len(recv_bufs)
         x_count[0] += 1
         with torch.cuda.stream(xstream):
@@ -301,7 +311,10 @@ def main():
         if do_expand:
             with torch.cuda.stream(estream):
                 estream.wait_event(x_events[j])
-                s.eng.expand_visible(recv_bufs[j], meshlets_base, gathered, out_cap, stream=estream)
+                if records_exchange:
+                    s.eng.expand_visible_records(recv_bufs[j], meshlets_base, gathered, out_cap, stream=estream)
+                else:
+                    s.eng.expand_visible(recv_bufs[j], meshlets_base, gathered, out_cap, stream=estream)
                 e_events[j].record(estream)
         return j
 
@@ -309,7 +322,10 @@ def main():
 
     def cull(s, k):
         s.eng.entity_cull(ci, draws, mesh, s.disp, ent, n_local_entities, disp_cap, draw_first=b, stream=s.stream)
-        if visible_exchange:
+        if records_exchange:
+            s.eng.meshlet_cull_visible_records(ci, s.disp, meshlets_base, s.lists[k], ent, materials, disp_cap, list_cap,
+                                               material_count=spec.materials, stream=s.stream)
+        elif visible_exchange:
             s.eng.meshlet_cull_visible(ci, s.disp, meshlets_base, s.lists[k], ent, materials, disp_cap, draw_cap,
                                        material_count=spec.materials, stream=s.stream)
         else:
@@ -454,7 +470,10 @@ def main():
         a.record(s0.stream)
         s0.eng.entity_cull(ci, draws, mesh, s0.disp, ent, n_local_entities, disp_cap, draw_first=b, stream=s0.stream)
         m.record(s0.stream)
-        if visible_exchange:
+        if records_exchange:
+            s0.eng.meshlet_cull_visible_records(ci, s0.disp, meshlets_base, s0.lists[0], ent, materials, disp_cap,
+                                                list_cap, material_count=spec.materials, stream=s0.stream)
+        elif visible_exchange:
             s0.eng.meshlet_cull_visible(ci, s0.disp, meshlets_base, s0.lists[0], ent, materials, disp_cap, draw_cap,
                                         material_count=spec.materials, stream=s0.stream)
         else:
@@ -511,21 +530,29 @@ def main():
 
     disp, draw = s0.disp, s0.lists[0]  # the latency frames above ran on slot 0: its buffers hold the last result
     n_rec = int(disp[:4].view(torch.int32).item())
-    n_draw = int(draw[:4].view(torch.int32).item())
-    if do_gather:  # the gathered list holds this rank's survivors at its rank-order position
-        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(counts, torch.tensor([n_draw], dtype=torch.int64, device=dev))
-        first = int(sum(int(c.item()) for c in counts[:rank]))
-        wire = recv_bufs[last_recv]  # what travelled: 8-B visible items or 28-B commands, rank order
-        assert torch.equal(wire[hdr + item * first:hdr + item * (first + n_draw)], draw[hdr:hdr + item * n_draw]), \
+    n_list = int(draw[:4].view(torch.int32).item())  # entries of this rank's list: records, items or commands
+    n_draw = int(draw[4:8].view(torch.int32).item()) if records_exchange else n_list  # its survivors
+    if do_gather:  # the gathered list holds this rank's entries at its rank-order position
+        counts = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([n_list, n_draw], dtype=torch.int64, device=dev))
+        first = int(sum(int(c[0].item()) for c in counts[:rank]))
+        first_draw = int(sum(int(c[1].item()) for c in counts[:rank]))
+        wire = recv_bufs[last_recv]  # what travelled: 12-B records, 8-B visible items or 28-B commands, rank order
+        assert torch.equal(wire[hdr + item * first:hdr + item * (first + n_list)], draw[hdr:hdr + item * n_list]), \
             "gathered list != local list"
-        assert int(wire[:4].view(torch.int32).item()) == int(sum(int(c.item()) for c in counts))
+        assert int(wire[:4].view(torch.int32).item()) == int(sum(int(c[0].item()) for c in counts))
         g_hdr, g_item = hdr, item
-        if do_expand:  # commands expanded from the gathered items: their (meshlet, entity) are this rank's items
-            mine = gathered[L.DRAW_HEADER + 28 * first:L.DRAW_HEADER + 28 * (first + n_draw)]
+        if do_expand:  # commands expanded from the gathered list: their (meshlet, entity) are this rank's survivors
+            mine = gathered[L.DRAW_HEADER + 28 * first_draw:L.DRAW_HEADER + 28 * (first_draw + n_draw)]
             cmds = mine.view(torch.int32).view(-1, 7)
-            items = draw[L.VISIBLE_HEADER:L.VISIBLE_HEADER + 8 * n_draw].view(torch.int32).view(-1, 2)
-            assert torch.equal(cmds[:, 6], items[:, 0]) and torch.equal(cmds[:, 4], items[:, 1]), \
+            if records_exchange:  # bit b of a record = {meshlet_offset + b, entity_index}, ascending
+                recs = draw[hdr:hdr + 12 * n_list].view(torch.int32).view(-1, 3)
+                bits = (recs[:, 2:3] >> torch.arange(32, device=dev, dtype=torch.int32)) & 1
+                r_idx, b_idx = torch.nonzero(bits, as_tuple=True)  # row-major: record order, then ascending bit
+                items = torch.stack([recs[r_idx, 1] + b_idx.to(torch.int32), recs[r_idx, 0]], dim=1)
+            else:
+                items = draw[L.VISIBLE_HEADER:L.VISIBLE_HEADER + 8 * n_draw].view(torch.int32).view(-1, 2)
+            assert len(items) == n_draw and torch.equal(cmds[:, 6], items[:, 0]) and torch.equal(cmds[:, 4], items[:, 1]), \
                 "expanded list != local visible list"
             g_hdr, g_item = L.DRAW_HEADER, 28
         else:
@@ -540,7 +567,7 @@ def main():
         assert torch.equal(lo, hi), "ranks hold different gathered lists"
     for s in slots:  # every slot and list buffer computed the same frame
         for l in s.lists:
-            assert torch.equal(l[:hdr + item * n_draw], draw[:hdr + item * n_draw]), "frame slots disagree"
+            assert torch.equal(l[:hdr + item * n_list], draw[:hdr + item * n_list]), "frame slots disagree"
 
     n_in = int(disp[L.DISPATCH_HEADER:L.DISPATCH_HEADER + 16 * n_rec].view(torch.int32).view(-1, 4)[:, 2].sum().item())
     # cull-only rate of this rank (for the N>1 breakdown)
@@ -584,8 +611,8 @@ def main():
     achieved = alg_bytes / (eval_ms * 1e-3) / 1e9
     # the chain emit: records again, 2-B counts of every meshlet (records without survivors are skipped: a few %), 64-B
     # ballots per tile, one link bit per meshlet
-    emit_read = (16 * n_rec + 2 * n_in + n_rec * 4 + n_in // 8) if (mstream is not None and not visible_exchange) else 0
-    op_bytes = alg_bytes + emit_read + item * n_draw + 4
+    emit_read = (16 * n_rec + 2 * n_in + n_rec * 4 + n_in // 8) if (mstream is not None and not compact_exchange) else 0
+    op_bytes = alg_bytes + emit_read + item * n_list + 4
     # the PMC passes were taken on the whole scene at N=1
     traffic, traffic_stamp = load_traffic(E, M, args.meshlet_source) if world == 1 else (None, None)
     lib_sha = lib_sha256()
@@ -629,8 +656,10 @@ def main():
                 "workload": f"config5: {E} entities x {M} = {E * M} synthetic meshlets, entity_cull + meshlet_cull, "
                             f"frustum + normal cone (occlusion_pass 0), all entities in view, "
                             f"{100.0 * tot_draw / max(tot_in, 1):.1f}% survivors ({args.scene_shape})"
-                            + ((", + rank-ordered all-gather of the visible list (8-B items, expanded to commands on "
-                                "every GPU)" if visible_exchange else ", + rank-ordered all-gather of the 28-B command lists")
+                            + ((", + rank-ordered all-gather of the visible list (12 B per dispatch record with a "
+                                "survivor: entity, meshlet offset, should-draw ballot)" if records_exchange else
+                                ", + rank-ordered all-gather of the visible list (8-B items)" if visible_exchange
+                                else ", + rank-ordered all-gather of the 28-B command lists")
                                + (" by direct xGMI stores at device-computed offsets, counts / completion over the "
                                   "process group" if transport == "p2p" else " by RCCL send/recv")
                                if do_gather else ""),
@@ -642,7 +671,8 @@ def main():
                 "warmup_effective": frames_before_timed,  # every frame this process ran before the timed region
                 "ms_per_step_without_settle": cold_ms_per_step,
                 "world_size": world_reported, "backend": (backend if use_dist else None),
-                "expand": (args.expand if visible_exchange else None),
+                "expand": (args.expand if compact_exchange else None),
+                "list_bytes_per_rank_max": (int(max(c[0].item() for c in counts)) * item if do_gather else None),
                 "exchange": (args.exchange if do_gather else None), "transport": transport,
                 "meshlet_source": (f"derived meshlet streams ({per_meshlet:g} B per meshlet evaluated"
                                    f"{' (alpha classes instead of material indices)' if not args.no_alpha_classes else ''}, "

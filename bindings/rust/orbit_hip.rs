@@ -124,6 +124,14 @@ extern "C" {
                                          out_capacity: u32, stream: *mut c_void) -> i32;
     pub fn orbit_expand_visible(ctx: *mut OrbitCtx, visible_buffer: *const c_void, meshlet_buffer: *const c_void,
                                 draw_commands_buffer: *mut c_void, draw_capacity: u32, stream: *mut c_void) -> i32;
+    /// The visible list at record granularity: 12 B {entity_index, meshlet_offset, mask} per dispatch record with a
+    /// survivor (half the 8-B items' bytes at BASELINE config 5); expanded on the receiving side.
+    pub fn orbit_meshlet_cull_visible_records(ctx: *mut OrbitCtx, cull_info: *const c_void, bufs: *const c_void,
+                                              record_buffer: *mut c_void, record_capacity: u32,
+                                              stream: *mut c_void) -> i32;
+    pub fn orbit_expand_visible_records(ctx: *mut OrbitCtx, record_buffer: *const c_void, meshlet_buffer: *const c_void,
+                                        draw_commands_buffer: *mut c_void, draw_capacity: u32,
+                                        stream: *mut c_void) -> i32;
     // derived meshlet streams: GpuAssets::add_mesh calls `update` for the range it wrote (assets/mod.rs:441-445),
     // every cull context binds the stream once
     pub fn orbit_meshlet_stream_create(ctx: *mut OrbitCtx, first_meshlet: u64, capacity: u64,

@@ -219,6 +219,18 @@ typedef struct OrbitVisibleMeshlet {
 ORBIT_STATIC_ASSERT(sizeof(OrbitVisibleMeshlet) == 8, "visible item is 8 B");
 #define ORBIT_VISIBLE_HEADER 8u
 
+/* The same ordered list compacted at record granularity (orbit_meshlet_cull_visible_records): one entry per dispatch
+ * record that has a survivor, in record order; bit b of `mask` set = meshlet `meshlet_offset + b` of entity
+ * `entity_index` is drawn, i.e. the item {meshlet_offset + b, entity_index} of the list above.  12 B per record
+ * instead of 8 B per survivor: half the bytes at 3.2 survivors per surviving record (BASELINE config 5), less the
+ * more coherent the survivors are. */
+typedef struct OrbitVisibleRecord {
+    uint32_t entity_index;
+    uint32_t meshlet_offset;
+    uint32_t mask; /* should-draw ballot of the record's (up to) 32 meshlets (meshlet_cull.comp:207-213) */
+} OrbitVisibleRecord;
+ORBIT_STATIC_ASSERT(sizeof(OrbitVisibleRecord) == 12, "visible record is 12 B");
+
 /* GpuCullInfo, draw_gen.rs:208-237 == CullInfo, types.glsl:202-228 */
 typedef struct OrbitGpuCullInfo {
     float view_matrix[16];         /* @0   */
@@ -730,6 +742,30 @@ int32_t orbit_gather_visible_meshlets(OrbitCtx *ctx, void *nccl_comm, uint32_t r
                                       uint32_t out_capacity, void *stream);
 int32_t orbit_expand_visible(OrbitCtx *ctx, const void *visible_buffer, const void *meshlet_buffer,
                              void *draw_commands_buffer, uint32_t draw_capacity, void *stream);
+
+/* The visible list at record granularity: 12 B per dispatch record with a
+ * survivor instead of 8 B per survivor (OrbitVisibleRecord) — half the
+ * bytes on the links at BASELINE config 5, which makes the sharded step
+ * cull-bound at every world size.
+ *   orbit_meshlet_cull_visible_records  orbit_meshlet_cull, but
+ *       `record_buffer` ({records, survivors} @0, OrbitVisibleRecord[] @8,
+ *       record_capacity entries) replaces bufs->draw_commands_buffer /
+ *       draw_capacity (not used).  Built from the evaluation's per-record
+ *       ballots: no survivor scan, no emit launch.  ORBIT_E_CAPACITY is
+ *       latched if the records do not fit (the header holds the clamped
+ *       count);
+ *   the lists of all ranks are concatenated in rank order like the other
+ *       two formats (orbit_scatter_list with header 8, stride 12; the
+ *       gathered header's second word is not maintained);
+ *   orbit_expand_visible_records  record list -> MeshletDrawCommandBuffer
+ *       in list order (= the canonical order), the command words read from
+ *       `meshlet_buffer` under global indices (or from a bound stream that
+ *       mirrors it); at most 64 M records per list. */
+int32_t orbit_meshlet_cull_visible_records(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info,
+                                           const OrbitMeshletCullBufs *bufs, void *record_buffer,
+                                           uint32_t record_capacity, void *stream);
+int32_t orbit_expand_visible_records(OrbitCtx *ctx, const void *record_buffer, const void *meshlet_buffer,
+                                     void *draw_commands_buffer, uint32_t draw_capacity, void *stream);
 
 /* ------------------------------------------------------------------------ */
 /* The same exchange without a host round trip (one node, one process per   */

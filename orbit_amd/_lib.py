@@ -107,6 +107,10 @@ SYMBOLS = {
     "orbit_meshlet_cull_visible": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(MeshletCullBufs), C.c_void_p,
                                                C.c_uint32, C.c_void_p]),
     "orbit_expand_visible": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "orbit_meshlet_cull_visible_records": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(MeshletCullBufs), C.c_void_p,
+                                                       C.c_uint32, C.c_void_p]),
+    "orbit_expand_visible_records": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                 C.c_void_p]),
     "orbit_p2p_alloc": (C.c_int32, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_void_p]),
     "orbit_p2p_free": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "orbit_p2p_open": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),

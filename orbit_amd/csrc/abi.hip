@@ -62,6 +62,7 @@ struct OrbitCtx {
     Payload *m_tile_payload = nullptr;
     uint32_t *m_tile_masks = nullptr, *m_chunk_sums = nullptr;
     uint32_t *m_tile_counts = nullptr, *m_tile_base = nullptr, *m_total = nullptr;
+    uint32_t *x_block_pop = nullptr; // orbit_expand_visible_records: survivors per 1024 records of the list
     uint32_t *c_chunk = nullptr; // compact: counts | bases | total
     float4 *a_view_lights = nullptr;
     uint32_t *a_light_flags = nullptr, *a_counts = nullptr, *a_block_sums = nullptr, *a_block_base = nullptr,
@@ -86,6 +87,9 @@ struct OrbitCtx {
     uint64_t class_culls = 0;                           // ... of which with its alpha classes
     char err[512] = {0};
 };
+
+// orbit_expand_visible_records: a list of up to kExpandBlocks * 1024 records (64 M) can be expanded
+constexpr uint32_t kExpandBlocks = 65536;
 
 namespace {
 
@@ -273,6 +277,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t o_eproto = carve(ent * sizeof(OrbitMeshletDispatch));
     const size_t o_ebs = carve(eblocks * 4), o_et = carve(256);
     const size_t o_mtc = carve(mtiles * 4), o_mtb = carve(mtiles * 4), o_mt = carve(256);
+    const size_t o_xbp = carve((size_t)kExpandBlocks * 4);
     const size_t o_mtm = carve(mtiles * 64);
     const size_t o_mtp = carve(mtiles * 128 * sizeof(Payload));
     const size_t mchunks = mtiles / kScanChunk + 2;
@@ -311,6 +316,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->e_total = (uint32_t *)(a + o_et);
     ctx->m_tile_counts = (uint32_t *)(a + o_mtc);
     ctx->m_tile_base = (uint32_t *)(a + o_mtb);
+    ctx->x_block_pop = (uint32_t *)(a + o_xbp);
     ctx->m_total = (uint32_t *)(a + o_mt);
     ctx->m_tile_masks = (uint32_t *)(a + o_mtm);
     ctx->m_tile_payload = (Payload *)(a + o_mtp);
@@ -532,7 +538,7 @@ namespace {
 // Validation + parameter block of one meshlet cull (see entity_cull_params).  Caller holds ctx->mu.
 int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
                             OrbitMeshTaskRecord *task_records, bool task_path, void *visible_buffer,
-                            uint32_t visible_capacity, bool visible_path, MeshletCullParams &p) {
+                            uint32_t visible_capacity, uint32_t visible_path /* 0, 1: items, 2: records */, MeshletCullParams &p) {
     int32_t rc = check_cull_info(ctx, ci);
     if (rc) return rc;
     if (!b) return fail(ctx, ORBIT_E_INVALID, "bufs is NULL");
@@ -559,7 +565,7 @@ int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCull
     p.pyr = make_pyramid_view(b->depth_pyramid, b->depth_pyramid_size, b->depth_pyramid_levels);
     p.dispatch_capacity = b->dispatch_capacity;
     p.draw_capacity = visible_path ? visible_capacity : b->draw_capacity;
-    p.visible_list = visible_path ? 1u : 0u;
+    p.visible_list = visible_path;
     p.material_count = b->material_count;
     {   // the symmetric five-plane frustum, recognised bit for bit (kernels.h MeshletCullParams::std_planes)
         auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
@@ -594,7 +600,7 @@ int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCull
 
 int32_t meshlet_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
                           OrbitMeshTaskRecord *task_records, bool task_path, void *stream,
-                          void *visible_buffer = nullptr, uint32_t visible_capacity = 0, bool visible_path = false) {
+                          void *visible_buffer = nullptr, uint32_t visible_capacity = 0, uint32_t visible_path = 0u) {
     if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
     MeshletCullParams p;
@@ -859,7 +865,12 @@ int32_t orbit_meshlet_task_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const
 
 int32_t orbit_meshlet_cull_visible(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
                                    void *visible_buffer, uint32_t visible_capacity, void *stream) {
-    return meshlet_cull_impl(ctx, ci, b, nullptr, false, stream, visible_buffer, visible_capacity, true);
+    return meshlet_cull_impl(ctx, ci, b, nullptr, false, stream, visible_buffer, visible_capacity, 1u);
+}
+
+int32_t orbit_meshlet_cull_visible_records(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
+                                           void *record_buffer, uint32_t record_capacity, void *stream) {
+    return meshlet_cull_impl(ctx, ci, b, nullptr, false, stream, record_buffer, record_capacity, 2u);
 }
 
 int32_t orbit_expand_visible(OrbitCtx *ctx, const void *visible_buffer, const void *meshlet_buffer,
@@ -878,6 +889,25 @@ int32_t orbit_expand_visible(OrbitCtx *ctx, const void *visible_buffer, const vo
                                                ctx->zero_page, ctx->status, (hipStream_t)stream);
     if (view.cmd) ctx->stream_culls++;
     if (e != hipSuccess) return hip_fail(ctx, e, "launch visible_expand");
+    return ORBIT_OK;
+}
+
+int32_t orbit_expand_visible_records(OrbitCtx *ctx, const void *record_buffer, const void *meshlet_buffer,
+                                     void *draw_commands_buffer, uint32_t draw_capacity, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!record_buffer || !meshlet_buffer || !draw_commands_buffer)
+        return fail(ctx, ORBIT_E_MISSING, "expand_visible_records: NULL argument");
+    const MeshletStreamView view = stream_view_for(ctx->meshlet_stream, meshlet_buffer, nullptr);
+    if (view.sphere && ctx->caps.validate_streams)
+        (void)launch_meshlet_stream_validate((const OrbitMeshlet *)meshlet_buffer, view, nullptr, 0, ctx->status,
+                                             (hipStream_t)stream);
+    const hipError_t e = launch_visible_records_expand((const uint8_t *)record_buffer, ctx->x_block_pop, kExpandBlocks,
+                                                       (const OrbitMeshlet *)meshlet_buffer, view,
+                                                       (uint8_t *)draw_commands_buffer, draw_capacity, ctx->zero_page,
+                                                       ctx->status, (hipStream_t)stream);
+    if (view.cmd) ctx->stream_culls++;
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch visible_records_expand");
     return ORBIT_OK;
 }
 

@@ -97,7 +97,7 @@ struct MeshletCullParams {
     OrbitMeshTaskRecord *task_records;
     // sharded engine (orbit_meshlet_cull_visible): draw_buffer is an OrbitVisibleMeshlet buffer (8-B header, 8 B per
     // survivor) and draw_capacity its capacity
-    uint32_t visible_list;
+    uint32_t visible_list; // 1: 8-B items, 2: 12-B records with their ballots (orbit_meshlet_cull_visible_records)
     // context scratch
     uint32_t *tile_counts;
     Payload *tile_payload; // 128 x 12 B per wave tile: survivors in tile-local order (make_payload, meshlet_cull.hip)
@@ -211,6 +211,11 @@ hipError_t launch_meshlet_stream_classes(const MeshletStreamView &ms, const Orbi
 hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, const MeshletStreamView &ms,
                                  uint8_t *draw_buffer, uint32_t draw_capacity, uint32_t num_cus, const void *zero_page,
                                  int32_t *status, hipStream_t s);
+// orbit_expand_visible_records: `records` = {records, survivors} header + 12-B {entity, meshlet_offset, mask} entries;
+// block_pop: scratch, one word per 1024 records (max_blocks words)
+hipError_t launch_visible_records_expand(const uint8_t *records, uint32_t *block_pop, uint32_t max_blocks,
+                                         const OrbitMeshlet *meshlets, const MeshletStreamView &ms, uint8_t *draw_buffer,
+                                         uint32_t draw_capacity, const void *zero_page, int32_t *status, hipStream_t s);
 struct ScatterListParams {
     const uint8_t *local_list;
     const uint32_t *counts;

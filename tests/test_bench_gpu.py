@@ -60,19 +60,21 @@ def _run_ranks(extra, env):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("expand", ["none", "all"])
-def test_bench_two_ranks_on_one_device_whole_device_path(expand):
+@pytest.mark.parametrize("expand,exchange", [("none", "records"), ("all", "records"), ("all", "visible"), ("none", "commands")])
+def test_bench_two_ranks_on_one_device_whole_device_path(expand, exchange):
     """`bench.py --gpus 2` as the driver starts it (bench.py spawns its ranks), both ranks on the box's one GPU: the
     real exchange — HIP IPC mappings of the peers' buffers, the scatter kernel, the count / completion collectives
     (over gloo: RCCL cannot put two ranks on one device) — then every rank's segment check and the cross-rank
     checksum of the gathered list inside bench.py (it exits non-zero if they fail)."""
-    d = _run_ranks(["--gpus", "2", "--expand", expand], dict(ORBIT_BENCH_ONE_DEVICE="1", ORBIT_BENCH_BACKEND="gloo"))
+    args = ["--gpus", "2", "--expand", expand] + ([] if exchange == "records" else ["--exchange", exchange])  # records: the default
+    d = _run_ranks(args, dict(ORBIT_BENCH_ONE_DEVICE="1", ORBIT_BENCH_BACKEND="gloo"))
     c = d["config"]
     assert d["n_gpus"] == 2 and c["world_size"] == 2 and c["gather"] is True and c["transport"] == "p2p"
-    assert c["exchange"] == "visible" and c["expand"] == expand and c["backend"] == "gloo"
+    assert c["exchange"] == exchange and c["backend"] == "gloo"
+    assert c["expand"] == (expand if exchange != "commands" else None)
     pr = d["per_rank"]
     assert len(pr["cull_ms"]) == 2 and len(pr["exchange_ms"]) == 2 and all(v > 0 for v in pr["cull_ms"] + pr["exchange_ms"])
-    assert (pr["expand_ms"] is None) == (expand == "none")
+    assert (pr["expand_ms"] is None) == (expand == "none" or exchange == "commands")
     assert sum(pr["meshlets_in"]) == c["meshlets_into_meshlet_cull"] == 6000 * 256
     assert sum(pr["survivors"]) == c["survivors"] > 0
     assert abs(d["value"] - c["meshlets_into_meshlet_cull"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

@@ -892,6 +892,107 @@ def test_compact_visible_lists_expand_to_the_canonical_list(torch_mod, engine, o
     assert ei.value.code == E_CAPACITY
 
 
+def _expected_visible_records(orecs, ocmds):
+    """The record-granular visible list the oracle's outputs imply: the commands come in (record, lane) order, so every
+    dispatch record takes the run of commands of its entity that fall into its meshlet range."""
+    out, j = [], 0
+    for r in orecs:
+        ent, off, cnt = int(r["entity_index"]), int(r["meshlet_offset"]), int(r["meshlet_count"])
+        mask = 0
+        while j < len(ocmds) and int(ocmds["cmd_first_instance"][j]) == ent and off <= int(ocmds["meshlet_index"][j]) < off + cnt:
+            bit = int(ocmds["meshlet_index"][j]) - off
+            assert not (mask >> bit) & 1 and (mask >> bit) == 0, "commands of a record must come in ascending lane order"
+            mask |= 1 << bit
+            j += 1
+        if mask:
+            out.append((ent, off, mask))
+    assert j == len(ocmds)
+    return np.array(out, dtype=L.VISIBLE_RECORD)
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_visible_record_lists_expand_to_the_canonical_list(torch_mod, engine, oracle, world):
+    """The 12-B-per-record exchange format: every rank's orbit_meshlet_cull_visible_records list is {entity_index,
+    meshlet_offset, should-draw ballot} of its dispatch records that have a survivor, in record order, with {records,
+    survivors} in the header; the rank-order concatenation, expanded by orbit_expand_visible_records, is the single-GPU
+    MeshletDrawCommandBuffer — also when the capacities cut it."""
+    from orbit_amd._lib import E_CAPACITY, OrbitError
+    from orbit_amd.dist import shard_ranges
+
+    torch = torch_mod
+    scene = sc.make_scene(31, 2600, meshlets_per_mesh=(1, 70), lods=2)  # > 1024 records per rank: several blocks
+    cam = sc.default_camera(rot=(0.2, 0.4))
+    ci = sc.make_cull_info(cam.view, cam.planes, alpha_mode_flag=L.ALPHA_ALL)
+    gs = GpuScene(torch, scene)
+    ref = run_oracle(oracle, scene, ci)
+    _, orecs = L.dispatch_buffer_records(ref[0])
+    on, ocmds = L.draw_buffer_commands(ref[1])
+    want = _expected_visible_records(orecs, ocmds)
+    assert on > 2000 and len(want) > 1100 and len(want) < len(orecs)  # some records have no survivor
+    cap_d, cap_c = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
+    parts = []
+    for b, e in shard_ranges(scene.entity_draw_count, world):
+        disp = torch.zeros(L.DISPATCH_HEADER + 16 * cap_d, dtype=torch.uint8, device="cuda")
+        vis = torch.full((L.VISIBLE_HEADER + 12 * cap_d + 64,), 0xCD, dtype=torch.uint8, device="cuda")
+        engine.entity_cull(ci, gs.draws, gs.mesh_infos, disp, gs.entities, e - b, cap_d, draw_first=b)
+        engine.meshlet_cull_visible_records(ci, disp, gs.meshlets, vis, gs.entities, gs.materials, cap_d, cap_d)
+        torch.cuda.synchronize()
+        engine.status()
+        hv = host(vis)
+        n, surv = (int(v) for v in hv[:8].view(np.uint32))
+        recs = hv[8:8 + 12 * n].view(L.VISIBLE_RECORD)
+        assert surv == sum(bin(int(m)).count("1") for m in recs["mask"]) and bool((hv[8 + 12 * n:] == 0xCD).all())
+        parts.append(recs)
+    got = np.concatenate(parts)
+    assert len(got) == len(want) and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # the gathered list, expanded on "the receiving GPU"
+    allrec = np.zeros(L.VISIBLE_HEADER + 12 * len(got), dtype=np.uint8)
+    allrec[:4].view(np.uint32)[0] = len(got)
+    allrec[8:] = got.view(np.uint8)
+    grec = dev(torch, allrec)
+    draw = torch.full((L.DRAW_HEADER + 28 * cap_c + 64,), 0xCD, dtype=torch.uint8, device="cuda")
+    engine.expand_visible_records(grec, gs.meshlets, draw, cap_c)
+    torch.cuda.synchronize()
+    engine.status()
+    n, cmds = L.draw_buffer_commands(host(draw))
+    assert n == on and np.array_equal(cmds.view(np.uint32), ocmds.view(np.uint32))
+    assert bool((host(draw)[4 + 28 * on:] == 0xCD).all())
+    # capacity cuts: the expansion writes a prefix, the cull keeps the first records; both latch the overflow
+    cut = on - 33
+    draw2 = torch.full((L.DRAW_HEADER + 28 * cut + 64,), 0xCD, dtype=torch.uint8, device="cuda")
+    engine.expand_visible_records(grec, gs.meshlets, draw2, cut)
+    torch.cuda.synchronize()
+    n2, cmds2 = L.draw_buffer_commands(host(draw2))
+    assert n2 == cut and np.array_equal(cmds2.view(np.uint32), ocmds[:cut].view(np.uint32))
+    assert bool((host(draw2)[4 + 28 * cut:] == 0xCD).all())
+    with pytest.raises(OrbitError) as ei:
+        engine.status()
+    assert ei.value.code == E_CAPACITY
+    if world == 1:
+        rcut = len(want) - 7
+        disp = torch.zeros(L.DISPATCH_HEADER + 16 * cap_d, dtype=torch.uint8, device="cuda")
+        vis = torch.full((L.VISIBLE_HEADER + 12 * rcut + 64,), 0xCD, dtype=torch.uint8, device="cuda")
+        engine.entity_cull(ci, gs.draws, gs.mesh_infos, disp, gs.entities, scene.entity_draw_count, cap_d)
+        engine.meshlet_cull_visible_records(ci, disp, gs.meshlets, vis, gs.entities, gs.materials, cap_d, rcut)
+        torch.cuda.synchronize()
+        hv = host(vis)
+        assert int(hv[:4].view(np.uint32)[0]) == rcut and int(hv[4:8].view(np.uint32)[0]) == on
+        assert np.array_equal(hv[8:8 + 12 * rcut].view(np.uint32), want[:rcut].view(np.uint32))
+        assert bool((hv[8 + 12 * rcut:] == 0xCD).all())
+        with pytest.raises(OrbitError) as ei:
+            engine.status()
+        assert ei.value.code == E_CAPACITY
+        # an empty frame: nothing in view
+        away = sc.default_camera(position=(0.0, 0.0, -5000.0))
+        ci0 = sc.make_cull_info(away.view, away.planes, alpha_mode_flag=L.ALPHA_ALL)
+        engine.entity_cull(ci0, gs.draws, gs.mesh_infos, disp, gs.entities, scene.entity_draw_count, cap_d)
+        engine.meshlet_cull_visible_records(ci0, disp, gs.meshlets, vis, gs.entities, gs.materials, cap_d, rcut)
+        engine.expand_visible_records(vis, gs.meshlets, draw2, cut)
+        torch.cuda.synchronize()
+        engine.status()
+        assert list(host(vis)[:8].view(np.uint32)) == [0, 0] and int(host(draw2)[:4].view(np.uint32)[0]) == 0
+
+
 def test_null_arguments_are_status_codes_not_crashes(torch_mod):
     """Every entry point of include/orbit_abi.h called with NULL handles / buffers: a status code comes back (the
     reference's unwrap / assert panics, as values across the C boundary), nothing is launched, nothing crashes."""
@@ -923,6 +1024,9 @@ def test_null_arguments_are_status_codes_not_crashes(torch_mod):
             lambda: lib.orbit_meshlet_cull_visible(ctx, cip, C.byref(mb), None, 16, None),
             lambda: lib.orbit_expand_visible(ctx, None, None, None, 16, None),
             lambda: lib.orbit_expand_visible(None, some, some, some, 16, None),
+            lambda: lib.orbit_meshlet_cull_visible_records(ctx, cip, C.byref(mb), None, 16, None),
+            lambda: lib.orbit_expand_visible_records(ctx, None, None, None, 16, None),
+            lambda: lib.orbit_expand_visible_records(None, some, some, some, 16, None),
             lambda: lib.orbit_depth_reduce(ctx, None, 64, 64, None, None),
             lambda: lib.orbit_depth_reduce(ctx, some, 0, 64, some, None),
             lambda: lib.orbit_depth_pyramid_desc(0, 0, None),
