@@ -993,6 +993,48 @@ def test_visible_record_lists_expand_to_the_canonical_list(torch_mod, engine, or
         assert list(host(vis)[:8].view(np.uint32)) == [0, 0] and int(host(draw2)[:4].view(np.uint32)[0]) == 0
 
 
+@pytest.mark.parametrize("occlusion_pass", [1, 2])
+def test_visible_records_in_the_occlusion_passes(torch_mod, engine, oracle, occlusion_pass):
+    """The record list of passes 1 (list-driven evaluation) and 2 (HiZ candidates): the oracle's dispatch records and
+    draw commands of the same pass, regrouped by record; the meshlet visibility words are those of the plain cull."""
+    torch = torch_mod
+    scene = sc.make_scene(71 + occlusion_pass, 900, n_meshes=140, lods=2, meshlets_per_mesh=(1, 70), extent=(20.0, 6.0, 20.0))
+    rng = np.random.default_rng(71)
+    cam = sc.default_camera(rot=(0.4, 0.9))
+    kw = dict(p00=cam.p00, p11=cam.p11, z_near=cam.z_near) if occlusion_pass == 2 else {}
+    ci = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=occlusion_pass, noskip_alphamode=L.ALPHA_MASKED, **kw)
+    evis = rng.integers(0, 2 ** 32, (scene.entity_draw_count + 31) // 32, dtype=np.uint32)
+    mvis = rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32)
+    pyr, ps = None, (0, 0)
+    if occlusion_pass == 2:
+        pyr, d = oracle.depth_reduce(sc.make_depth(5, 320, 180, cam), 320, 180)
+        ps = (d.width, d.height)
+    gs = GpuScene(torch, scene)
+    cap_d = scene.max_dispatches() + 8
+    disp = torch.zeros(L.DISPATCH_HEADER + 16 * cap_d, dtype=torch.uint8, device="cuda")
+    evis_d, mvis_d = dev(torch, evis), dev(torch, mvis)
+    pyr_d = None if pyr is None else dev(torch, pyr)
+    engine.entity_cull(ci, gs.draws, gs.mesh_infos, disp, gs.entities, scene.entity_draw_count, cap_d,
+                       visibility_buffer=evis_d, depth_pyramid=pyr_d, depth_pyramid_size=ps)
+    vis = torch.full((L.VISIBLE_HEADER + 12 * cap_d + 64,), 0xCD, dtype=torch.uint8, device="cuda")
+    engine.meshlet_cull_visible_records(ci, disp, gs.meshlets, vis, gs.entities, gs.materials, cap_d, cap_d,
+                                        meshlet_visibility_buffer=mvis_d, depth_pyramid=pyr_d, depth_pyramid_size=ps)
+    torch.cuda.synchronize()
+    engine.status()
+    ref = run_oracle(oracle, scene, ci, evis=evis, mvis=mvis, pyr=pyr, psize=ps)
+    _, orecs = L.dispatch_buffer_records(ref[0])
+    on, ocmds = L.draw_buffer_commands(ref[1])
+    want = _expected_visible_records(orecs, ocmds)
+    assert on > 0 and len(want) > 0
+    hv = host(vis)
+    n, surv = (int(v) for v in hv[:8].view(np.uint32))
+    assert n == len(want) and surv == on
+    assert np.array_equal(hv[8:8 + 12 * n].view(np.uint32), want.view(np.uint32))
+    assert bool((hv[8 + 12 * n:] == 0xCD).all())
+    if ref[3] is not None:
+        assert np.array_equal(host(mvis_d, np.uint32), ref[3]), "meshlet visibility words differ"
+
+
 def test_null_arguments_are_status_codes_not_crashes(torch_mod):
     """Every entry point of include/orbit_abi.h called with NULL handles / buffers: a status code comes back (the
     reference's unwrap / assert panics, as values across the C boundary), nothing is launched, nothing crashes."""
