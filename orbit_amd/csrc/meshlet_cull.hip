@@ -54,6 +54,21 @@ constexpr uint32_t kNoOffset = 0xFFFFFF00u; // beyond every resource of this lau
 
 // The streams a row reads, as buffer resources based at the stream's first meshlet: a row's address arithmetic is
 // one subtraction, one select and a shift per array instead of a 64-bit pointer select per load.
+// Cache policy of the derived streams' one-pass reads: nt (non-temporal, aux bit 1).  The evaluation's rows are read
+// once per frame and are four times the L2 + MALL: loaded with the default policy they evict each other and everything
+// else on their way through; as nt loads the same kernel streams 9 % faster (in-process A/B of both builds, both
+// orders: 0.2054 / 0.2146 -> 0.1901 / 0.1929 ms; profiles/r03_notes.md).  The chain emit's count stream likewise (-1 us);
+// its command STORES not (nt stores: +4 ... +17 us), nor the 32-B rows of the Meshlet-buffer evaluation (nothing for
+// the evaluation, +9 us for the payload emit behind it).
+#ifndef ORBIT_EVAL_LOAD_AUX
+#define ORBIT_EVAL_LOAD_AUX 2
+#endif
+#ifndef ORBIT_EMIT_CNT_AUX
+#define ORBIT_EMIT_CNT_AUX 2
+#endif
+#ifndef ORBIT_EMIT_STORE_AUX
+#define ORBIT_EMIT_STORE_AUX 0
+#endif
 struct StreamRsrc {
     __amdgpu_buffer_rsrc_t sphere, cone, mat;
     uint32_t first, count;
@@ -340,8 +355,8 @@ __device__ __forceinline__ void rows_load(const MeshletCullParams &p, const Wave
             const bool in = active & (rel < SR->count);
             if (active & !in) latch_status(p.status, ORBIT_E_RANGE);
             const uint32_t i = in ? rel : kNoOffset >> 4; // x 16, x 4, x 2: outside each of the three resources
-            const auto sp = __builtin_amdgcn_raw_buffer_load_b128(SR->sphere, i << 4, 0, 0);
-            const uint32_t c = __builtin_amdgcn_raw_buffer_load_b32(SR->cone, i << 2, 0, 0);
+            const auto sp = __builtin_amdgcn_raw_buffer_load_b128(SR->sphere, i << 4, 0, ORBIT_EVAL_LOAD_AUX);
+            const uint32_t c = __builtin_amdgcn_raw_buffer_load_b32(SR->cone, i << 2, 0, ORBIT_EVAL_LOAD_AUX);
             t.a[k] = make_uint4(sp[0], sp[1], sp[2], sp[3]);
             uint32_t m = 0; // CLS: the predicate bits come from the alpha classes in the slab (setup_write_cls)
             if constexpr (!CLS) m = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(SR->mat, i << 1, 0, 0);
@@ -349,7 +364,7 @@ __device__ __forceinline__ void rows_load(const MeshletCullParams &p, const Wave
         } else {
             const uint4 *src = active ? reinterpret_cast<const uint4 *>(p.meshlets + (rec.y + ml))
                                       : reinterpret_cast<const uint4 *>(p.zero_page);
-            t.a[k] = src[0];
+            t.a[k] = src[0]; // (default cache policy: nt does nothing for this evaluation and costs the payload emit 9 us)
             t.b[k] = src[1];
         }
         t.prev[k] = 0u;
@@ -1303,7 +1318,7 @@ __device__ __forceinline__ ChainStage chain_stage(const ChainRsrc &B, ChainLds &
     for (int q = 0; q < (int)kGroupRecords / 4; q++) off[q] = S.rs[4 * q + sub];
 #pragma unroll
     for (int q = 0; q < (int)kGroupRecords / 4; q++)
-        s.c2[q] = __builtin_amdgcn_raw_buffer_load_b32(B.cnt, off[q] + i4, 0, 0);
+        s.c2[q] = __builtin_amdgcn_raw_buffer_load_b32(B.cnt, off[q] + i4, 0, ORBIT_EMIT_CNT_AUX);
     // lane = record.  A record continues its predecessor's chain when that one was read too, ends where this one
     // begins, and every link from the predecessor's second meshlet to this record's first one holds; otherwise it
     // starts a chain from the gathered offsets of its first meshlet.
@@ -1527,7 +1542,7 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
 #pragma unroll
             for (uint32_t k = 0; k < 7; k++) {
                 const uint32_t w = k * 64u + (uint32_t)lane;
-                __builtin_amdgcn_raw_buffer_store_b32(S.cmd[w], win, w * 4u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(S.cmd[w], win, w * 4u, 0, ORBIT_EMIT_STORE_AUX);
             }
             __builtin_amdgcn_wave_barrier(); // cmd is rewritten by the next trip
         };

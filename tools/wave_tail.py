@@ -9,7 +9,7 @@ import _triage; _triage.use_triage_library()  # -DORBIT_TRIAGE build (bash tools
 import torch, numpy as np
 from orbit_amd import camera, synth, _lib
 from orbit_amd.engine import Engine
-spec = synth.C5Spec()
+spec = synth.C5Spec(entities=int(os.environ.get("E", 195_313)))  # E=24414: a rank's shard at N = 8
 dev = torch.device("cuda", 0)
 draws, mesh, ent, half = synth.gen_entity_tables(spec, dev)
 ml = synth.gen_meshlets(spec, 0, spec.entities, dev, half)
@@ -18,6 +18,8 @@ ci = camera.frame_cull_info((0.0, 0.0, 1300.0))
 E = spec.entities; dc = E * 8 + 8; cc = E * 128
 eng = Engine(0, max_entities=E + 256, max_dispatches=dc, max_draws=cc)
 disp = torch.zeros(12 + 16 * dc, dtype=torch.uint8, device=dev); draw = torch.zeros(4 + 28 * cc, dtype=torch.uint8, device=dev)
+if os.environ.get("STREAM", "0") == "1":  # from the derived streams with alpha classes, as bench.py culls
+    ms = eng.meshlet_stream(ml, 0, E * spec.meshlets_per_entity); ms.set_materials(mat, spec.materials); eng.bind_meshlet_stream(ms)
 eng.entity_cull(ci, draws, mesh, disp, ent, E, dc)
 lib = _lib.load()
 out = np.zeros(2 * 8192, dtype=np.uint64)
@@ -37,8 +39,6 @@ for rep in range(3):
     # per XCD (block index round-robins over the 8 XCDs)
     xcd = (np.arange(4096) // 4) % 8
     print("   median end per XCD:", " ".join(f"{np.median(e[xcd == x]):7.1f}" for x in range(8)))
-    tiles = np.array([len(range(w, 97657, 4096)) for w in range(4096)])
-    print("   median end of waves with 24 tiles %.1f, with 23 tiles %.1f" % (np.median(e[tiles == 24]), np.median(e[tiles == 23])))
     blk = np.arange(4096) // 4
     print("   median end by block-index octile:", " ".join(f"{np.median(e[(blk >= k * 128) & (blk < (k + 1) * 128)]):7.1f}" for k in range(8)))
     for x in range(8):
