@@ -359,7 +359,7 @@ __device__ __forceinline__ void rows_load(const MeshletCullParams &p, const Wave
             const uint32_t c = __builtin_amdgcn_raw_buffer_load_b32(SR->cone, i << 2, 0, ORBIT_EVAL_LOAD_AUX);
             t.a[k] = make_uint4(sp[0], sp[1], sp[2], sp[3]);
             uint32_t m = 0; // CLS: the predicate bits come from the alpha classes in the slab (setup_write_cls)
-            if constexpr (!CLS) m = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(SR->mat, i << 1, 0, 0);
+            if constexpr (!CLS) m = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(SR->mat, i << 1, 0, ORBIT_EVAL_LOAD_AUX);
             t.b[k] = make_uint4(c, 0u, 0u, m);
         } else {
             const uint4 *src = active ? reinterpret_cast<const uint4 *>(p.meshlets + (rec.y + ml))
@@ -640,6 +640,14 @@ __device__ __forceinline__ void setup_write(const MeshletCullParams &p, WaveTile
 // that the compiler's vmcnt accounting stays exact.
 constexpr int kEvWaves = 4;
 constexpr int kEvWavesPerSimd = 4; // resident waves per SIMD: compiled for (128 VGPRs) and launched at
+// Pass 0 from the derived streams needs fewer registers than the passes with the HiZ test (84 against 107-119) and is
+// compiled for / launched at five waves per SIMD: with the rows as nt loads the fifth wave is worth 3.5 % (0.1948 /
+// 0.1964 -> 0.1879 / 0.1897 ms; six: 0.1897 / 0.1909, three: 0.2175 / 0.2184) — with the default cache policy it was
+// worth nothing, and from the Meshlet buffer it costs 1.5 % (0.3470 -> 0.3525; r03_notes.md).
+#ifndef ORBIT_EV_WPS0
+#define ORBIT_EV_WPS0 5
+#endif
+constexpr int ev_waves_per_simd(int pass, bool stream) { return (pass == 0 && stream) ? ORBIT_EV_WPS0 : kEvWavesPerSimd; }
 
 // Views of one launch of the *_views kernels (orbit_cull_views): blockIdx.y = slot, idx[slot] = entry of the table.
 struct ViewGroup {
@@ -771,7 +779,7 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
     // duration and the rest of the kernel runs at 3, 2, 1 waves per SIMD (tools/wave_tail.py).  Every wave
     // therefore rotates its priority once per tile, offset by its block's dispatch rank, so that over any four
     // tiles each wave of a SIMD has held each priority once.
-    const uint32_t prio_rank = blockIdx.x / max(gridDim.x / (uint32_t)kEvWavesPerSimd, 1u);
+    const uint32_t prio_rank = blockIdx.x / max(gridDim.x / (uint32_t)ev_waves_per_simd(PASS, STREAM), 1u);
     while (w0 < ntiles) {
         if (!ORBIT_DBG(p, 32u)) {
             switch ((it + prio_rank) & 3u) {
@@ -854,12 +862,12 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
 }
 
 template <int PASS, int PROJ, bool PROF, bool STREAM = false, bool CLS = false>
-__global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_kernel(const MeshletCullParams p) {
+__global__ __launch_bounds__(kEvWaves * 64, ev_waves_per_simd(PASS, STREAM)) void meshlet_eval_kernel(const MeshletCullParams p) {
     meshlet_eval_body<PASS, PROJ, PROF, STREAM, CLS>(p);
 }
 // several views in one launch (orbit_cull_views): the views' parameter blocks by value, blockIdx.y picks one
 template <int PASS, int PROJ, bool STREAM, bool CLS = false>
-__global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_eval_views_kernel(const MeshletCullViews all,
+__global__ __launch_bounds__(kEvWaves * 64, ev_waves_per_simd(PASS, STREAM)) void meshlet_eval_views_kernel(const MeshletCullViews all,
                                                                                            const ViewGroup g) {
     meshlet_eval_body<PASS, PROJ, false, STREAM, CLS>(all.v[g.idx[blockIdx.y]]);
 }
@@ -2105,7 +2113,7 @@ hipError_t launch_pass(const MeshletCullParams &p, uint32_t num_cus, hipStream_t
     // nothing is enqueued for a capacity the emit launch cannot address (orbit_ctx_create rejects such caps already)
     if ((max_tiles + kScanChunk - 1) / kScanChunk > kEmitChunkTable) return hipErrorInvalidValue;
     // eval -> scan -> emit
-    uint32_t blocks = num_cus * (uint32_t)kEvWavesPerSimd; // 4-wave blocks: one wave per SIMD each
+    uint32_t blocks = num_cus * (uint32_t)ev_waves_per_simd(PASS, p.ms.sphere != nullptr); // 4-wave blocks: one wave per SIMD each
     const uint32_t need = (max_tiles + kEvWaves - 1) / kEvWaves;
     if (blocks > need) blocks = need;
     if (blocks == 0) blocks = 1;
@@ -2225,7 +2233,7 @@ hipError_t launch_meshlet_cull_views(const MeshletCullViews &all, uint32_t n, ui
                 need = max(need, (t + kEvWaves - 1) / kEvWaves);
             }
         // the views of a group share the device: each gets an equal part of the resident-wave budget
-        uint32_t blocks = max(num_cus * (uint32_t)kEvWavesPerSimd / m, 1u);
+        uint32_t blocks = max(num_cus * (uint32_t)ev_waves_per_simd((int)pass, src != 0) / m, 1u);
         if (blocks > need) blocks = need;
         const dim3 grid(blocks, m), block(kEvWaves * 64);
         const bool ortho = proj == 1;
