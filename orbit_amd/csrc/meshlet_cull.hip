@@ -697,7 +697,10 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
     // ticketed rounds: three on a long launch, fewer on a short one (a shard of the sharded engine has 2-3 rounds in all)
     const uint32_t dyn_rounds = ORBIT_DBG(p, 256u) ? 2u : ORBIT_DBG(p, 512u) ? 4u : ORBIT_DBG(p, 1024u) ? 1u : min(max(full_rounds / 4u, 1u), 3u);
     // a scene of at most one tile per wave has nothing to balance: static, no atomic in front of the first loads
-    const uint32_t n_static = (static_share || ntiles <= stride) ? 0xFFFFFFFFu : (ORBIT_DBG(p, 128u) ? 0u : (full_rounds >= dyn_rounds ? full_rounds - dyn_rounds : 0u));
+    // ... and the three tiles a wave claims before its first row never go through a ticket either: their records,
+    // matrices and rows are the launch's ramp, and an atomic in front of them is one more round trip before anything
+    // streams (a 1/8 shard of config 5 is three tiles per wave)
+    const uint32_t n_static = (static_share || ntiles <= stride) ? 0xFFFFFFFFu : (ORBIT_DBG(p, 128u) ? 0u : max(full_rounds >= dyn_rounds ? full_rounds - dyn_rounds : 0u, 3u));
     const uint32_t npools = min((uint32_t)kTicketPools, stride);
     const uint32_t pool = wave_g % npools;
     uint32_t *ticket_ctr = p.tickets + pool * kTicketStride;
