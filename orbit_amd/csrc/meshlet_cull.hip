@@ -1849,8 +1849,11 @@ __global__ __launch_bounds__(256) void visible_records_expand_kernel(const uint8
     __shared__ uint32_t s_chunk[kVrBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = *reinterpret_cast<const uint32_t *>(records);
-    const uint32_t nblocks = min((n + kVrBlock - 1u) / kVrBlock, max_blocks);
-    if (n > (size_t)max_blocks * kVrBlock && blockIdx.x == 0 && threadIdx.x == 0) latch_status(status, ORBIT_E_CAPACITY);
+    // the grid covers draw_capacity / 1024 blocks of records (every record holds a survivor: more records than that
+    // cannot fit) and the scratch max_blocks: a longer list is cut there, and says so
+    const uint32_t all_blocks = (n + kVrBlock - 1u) / kVrBlock;
+    const uint32_t nblocks = min(min(all_blocks, max_blocks), gridDim.x);
+    if (all_blocks > nblocks && blockIdx.x == 0 && threadIdx.x == 0) latch_status(status, ORBIT_E_CAPACITY);
     if (blockIdx.x >= nblocks && blockIdx.x != 0) return;
     const uint32_t upto = blockIdx.x == 0 ? nblocks : blockIdx.x;
     uint32_t part = 0;

@@ -968,6 +968,17 @@ def test_visible_record_lists_expand_to_the_canonical_list(torch_mod, engine, or
     with pytest.raises(OrbitError) as ei:
         engine.status()
     assert ei.value.code == E_CAPACITY
+    # a command capacity far below the list (fewer blocks of the expansion than the list has blocks of records)
+    tiny = 700
+    draw3 = torch.full((L.DRAW_HEADER + 28 * tiny + 64,), 0xCD, dtype=torch.uint8, device="cuda")
+    engine.expand_visible_records(grec, gs.meshlets, draw3, tiny)
+    torch.cuda.synchronize()
+    n3, cmds3 = L.draw_buffer_commands(host(draw3))
+    assert n3 == tiny and np.array_equal(cmds3.view(np.uint32), ocmds[:tiny].view(np.uint32))
+    assert bool((host(draw3)[4 + 28 * tiny:] == 0xCD).all())
+    with pytest.raises(OrbitError) as ei:
+        engine.status()
+    assert ei.value.code == E_CAPACITY
     if world == 1:
         rcut = len(want) - 7
         disp = torch.zeros(L.DISPATCH_HEADER + 16 * cap_d, dtype=torch.uint8, device="cuda")
