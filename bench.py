@@ -431,6 +431,17 @@ def main():
     # HIP events around the dominant kernel (meshlet_eval), recorded by the library on the launch stream.  An event
     # pair costs ~7 us of stream time (it keeps the next launch from being prefetched: tools/t_host.py), so every
     # `--time-every`-th launch per slot is timed, not all of them, and no other event is recorded inside the region.
+    # The library creates a launch's event pair on first use (hipEventCreate + the event's first record: not free).  So
+    # every pair the timed region will record is used once before it, on the same streams: ceil(K / time_every) + 1
+    # untimed steps with every launch timed (part of the warm-up: counted in warmup_effective).
+    prewarm = -(-args.steps // max(args.time_every, 1)) + 1
+    for s in slots:
+        s.eng.profile(True, every=1)
+    for _ in range(prewarm * F):
+        step()
+    drain()
+    torch.cuda.synchronize()
+    frames_before_timed += prewarm * F
     for s in slots:
         s.eng.profile(True, every=args.time_every)
     if use_dist:

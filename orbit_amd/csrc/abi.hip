@@ -411,26 +411,6 @@ int32_t orbit_ctx_profile(OrbitCtx *ctx, int32_t enable) {
     ctx->profiling = enable > 0 ? (uint32_t)enable : 0u;
     ctx->prof_used = 0;
     ctx->prof_calls = 0;
-    // the event pairs of the next 64 timed launches are made HERE, not inside an enqueue call: hipEventCreate costs
-    // 1-2 ms apiece beside running streams and collectives (a sharded bench run lost 35 ms of its timed region to
-    // twenty of them: tools/stall_probe.sh)
-    if (enable > 0) {
-        const hipError_t se = hipSetDevice(ctx->device);
-        if (se != hipSuccess) return hip_fail(ctx, se, "hipSetDevice");
-        const size_t had = ctx->prof_events.size();
-        while (ctx->prof_events.size() < 128) {
-            hipEvent_t ev;
-            if (hipEventCreate(&ev) != hipSuccess) return fail(ctx, ORBIT_E_HIP, "hipEventCreate");
-            ctx->prof_events.push_back(ev);
-        }
-        if (had < ctx->prof_events.size()) { // ... and recorded once (an event's first record allocates as well)
-            hipStream_t warm;
-            if (hipStreamCreateWithFlags(&warm, hipStreamNonBlocking) != hipSuccess) return fail(ctx, ORBIT_E_HIP, "hipStreamCreate");
-            for (size_t i = had; i < ctx->prof_events.size(); i++) (void)hipEventRecord(ctx->prof_events[i], warm);
-            (void)hipStreamSynchronize(warm);
-            (void)hipStreamDestroy(warm);
-        }
-    }
     return ORBIT_OK;
 }
 
