@@ -144,6 +144,27 @@ class _ShmTransport:
                 os.remove(p)
 
 
+def _visible_records(disp, cmds):
+    """{records, survivors} + 12-B {entity_index, meshlet_offset, mask} of the dispatch records that have a survivor:
+    what orbit_meshlet_cull_visible_records makes of the same cull (the commands come in (record, lane) order)."""
+    _, recs = L.dispatch_buffer_records(disp)
+    out, j = [], 0
+    for r in recs:
+        ent, off, cnt = int(r["entity_index"]), int(r["meshlet_offset"]), int(r["meshlet_count"])
+        mask = 0
+        while j < len(cmds) and int(cmds["cmd_first_instance"][j]) == ent and off <= int(cmds["meshlet_index"][j]) < off + cnt:
+            mask |= 1 << (int(cmds["meshlet_index"][j]) - off)
+            j += 1
+        if mask:
+            out.append((ent, off, mask))
+    assert j == len(cmds)
+    arr = np.array(out, dtype=L.VISIBLE_RECORD) if out else np.zeros(0, dtype=L.VISIBLE_RECORD)
+    buf = np.zeros(L.VISIBLE_HEADER + 12 * max(len(arr), 1), dtype=np.uint8)
+    buf[:8].view(np.uint32)[:] = (len(arr), len(cmds))
+    buf[8:8 + 12 * len(arr)] = arr.view(np.uint8)
+    return buf
+
+
 def _p2p_worker(rank, world, port, seed, n_entities, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -164,8 +185,10 @@ def _p2p_worker(rank, world, port, seed, n_entities, out_dir):
     vis[:4].view(np.uint32)[0] = n
     v = vis[8:8 + 8 * n].view(L.VISIBLE_MESHLET)
     v["meshlet_index"], v["entity_index"] = cmds["meshlet_index"], cmds["cmd_first_instance"]
+    rec = _visible_records(disp, cmds)  # the same list at record granularity (12 B per record with a survivor)
     capacity = scene.lod0_meshlets + 8
-    for name, local, header, stride in (("cmd", draw, L.DRAW_HEADER, 28), ("vis", vis, L.VISIBLE_HEADER, 8)):
+    for name, local, header, stride in (("cmd", draw, L.DRAW_HEADER, 28), ("vis", vis, L.VISIBLE_HEADER, 8),
+                                        ("rec", rec, L.VISIBLE_HEADER, 12)):
         t = _ShmTransport(f"{name}{rank}")
         ex = P2PExchange(None, capacity, header, stride, torch.device("cpu"), transport=t)
         for step in range(2):  # the buffers are reused step after step
@@ -204,3 +227,8 @@ def test_p2p_exchange_protocol_gloo(tmp_path, oracle, world, n_entities):
         items = gv[8:8 + 8 * n].view(L.VISIBLE_MESHLET)
         assert np.array_equal(items["meshlet_index"], cmds["meshlet_index"])
         assert np.array_equal(items["entity_index"], cmds["cmd_first_instance"])
+        gr = np.load(tmp_path / f"p2p_rec_{r}.npy")  # the record-granular list: the single-process one, in rank order
+        want = _visible_records(disp, cmds)
+        nr = int(want[:4].view(np.uint32)[0])
+        assert int(gr[:4].view(np.uint32)[0]) == nr and np.array_equal(gr[8:8 + 12 * nr], want[8:8 + 12 * nr])
+        assert np.all(gr[8 + 12 * nr:] == 0x55)
