@@ -154,8 +154,8 @@ __global__ __launch_bounds__(1024) void cluster_compact_kernel(const ClusterComp
 }
 
 // -------------------------------------------------------------- light_culling
-__global__ __launch_bounds__(256) void light_prepare_kernel(const ClusterAssignParams p) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void light_prepare_body(const ClusterAssignParams &p, uint32_t block) {
+    const uint32_t i = block * 256 + threadIdx.x;
     const uint32_t n = p.info.global_light_count;
     bool point = false;
     if (i < n) {
@@ -309,13 +309,18 @@ constexpr uint32_t kCoarseSplit = 4;                    // blocks that share the
 constexpr uint32_t kCoarseSegs = kCoarseSplit * 4;      // = waves per group = segments of its candidate list
 
 // coarse, part 1: AABBs of 256 consecutive active clusters (cached for every later launch) and their union.
-__global__ __launch_bounds__(256) void cluster_aabb_kernel(const ClusterAssignParams p) {
+// (The launch's first `prepare_blocks` blocks transform the lights instead: two independent pieces of work, one launch.)
+__global__ __launch_bounds__(256) void cluster_aabb_kernel(const ClusterAssignParams p, uint32_t prepare_blocks) {
     __shared__ float s_box[4][8];
+    if (blockIdx.x < prepare_blocks) { // block-uniform
+        light_prepare_body(p, blockIdx.x);
+        return;
+    }
     const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.unique);
     const uint32_t n = min(hdr[3], p.max_clusters);
     // grid-stride over the groups that exist (n is only known on the device; a grid sized by the capacity would
     // spend its time launching empty blocks)
-    for (uint32_t grp = blockIdx.x; grp * kGroupClusters < n; grp += gridDim.x) {
+    for (uint32_t grp = blockIdx.x - prepare_blocks; grp * kGroupClusters < n; grp += gridDim.x - prepare_blocks) {
     const uint32_t first = grp * kGroupClusters;
     const uint32_t *unique_idx = reinterpret_cast<const uint32_t *>(p.unique + ORBIT_COMPACT_HEADER);
     const uint32_t u = first + threadIdx.x;
@@ -468,8 +473,12 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
     uint32_t hc[kHcRounds] = {};
     if (WRITE) {
         my_limit = p.counts[ul];
-        // exclusive prefix of the capped counts: chunk-local prefix + chunk base of the two-level scan
-        my_offset = p.block_base[ul] + (p.block_sums + (p.max_clusters / kScanChunk + 2))[ul / kScanChunk];
+        // exclusive prefix of the capped counts: chunk-local prefix (scan launch) + the sums of the chunks before the
+        // block's (its 8 clusters share a chunk), added up here
+        static_assert(kScanChunk % kClustersPerBlock == 0, "a block's clusters share a scan chunk");
+        uint32_t part = 0;
+        for (uint32_t k = (uint32_t)lane; k < block_first / kScanChunk; k += 64u) part += p.block_sums[k];
+        my_offset = p.block_base[ul] + wave_reduce_add(part);
         // (cluster, slot) per lane, two rounds: the indices the counting launch kept
 #pragma unroll
         for (uint32_t j = 0; j < kHcRounds; j++)
@@ -723,10 +732,14 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
         p.debug_tests[16 + 2 * (4096u + blockIdx.x) + 1] = dbg_ctotal; // the group's coarse candidates
     }
 #endif
-    if (WRITE && blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint32_t total = *p.total;
-        *reinterpret_cast<uint32_t *>(p.light_index_buffer) = total; // atomicAdd total, :136
-        if (total > p.light_index_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+    if (WRITE && blockIdx.x == 0 && wave == 0) { // light_count = the sum over all chunks (atomicAdd total, :136)
+        uint32_t part = 0;
+        for (uint32_t k = (uint32_t)lane; k * kScanChunk < n; k += 64u) part += p.block_sums[k];
+        const uint32_t total = wave_reduce_add(part);
+        if (lane == 0) {
+            *reinterpret_cast<uint32_t *>(p.light_index_buffer) = total;
+            if (total > p.light_index_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+        }
     }
 }
 
@@ -760,11 +773,7 @@ hipError_t launch_cluster_compact(const ClusterCompactParams &p, hipStream_t s) 
 
 hipError_t launch_cluster_assign(const ClusterAssignParams &p, uint32_t num_cus, hipStream_t s) {
     const uint32_t nl = p.info.global_light_count;
-    if (nl > 0) {
-        hipLaunchKernelGGL(light_prepare_kernel, dim3((nl + 255) / 256), dim3(256), 0, s, p);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
+    const uint32_t prepare_blocks = (nl + 255u) / 256u;
     if (p.max_clusters == 0) {
         hipLaunchKernelGGL(write_word, dim3(1), dim3(1), 0, s, reinterpret_cast<uint32_t *>(p.light_index_buffer), 0u);
         return hipGetLastError();
@@ -773,15 +782,17 @@ hipError_t launch_cluster_assign(const ClusterAssignParams &p, uint32_t num_cus,
     // and the kernels stride over the work that exists
     const uint32_t groups = (p.max_clusters + kGroupClusters - 1) / kGroupClusters;
     const uint32_t blocks = min((p.max_clusters + kClustersPerBlock - 1) / kClustersPerBlock, num_cus * 32u);
-    hipLaunchKernelGGL(cluster_aabb_kernel, dim3(min(groups, num_cus * 4u)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(cluster_aabb_kernel, dim3(prepare_blocks + min(groups, num_cus * 4u)), dim3(256), 0, s, p, prepare_blocks);
     hipLaunchKernelGGL(cluster_coarse_kernel, dim3(min(groups * kCoarseSplit, num_cus * 8u)), dim3(256), 0, s, p);
     hipLaunchKernelGGL(cluster_assign_kernel<false>, dim3(blocks), dim3(kAssignWaves * 64), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // exclusive scan of the counts of the n active clusters (n read on the device from the compacted header):
     // chunk-local prefixes in block_base, chunk bases behind the chunk sums; the write launch adds the two
-    e = launch_scan_two_level(p.counts, p.block_base, reinterpret_cast<const uint32_t *>(p.unique) + 3, 1u,
-                              p.max_clusters, p.block_sums, p.block_sums + (p.max_clusters / kScanChunk + 2), p.total, s);
+    // (first level only: chunk-local prefixes + chunk sums; a write block adds up the sums of the chunks before its
+    // own — at most a thousand words in L2 — instead of a second scan launch)
+    e = launch_scan_chunks(p.counts, p.block_base, reinterpret_cast<const uint32_t *>(p.unique) + 3, 1u, p.max_clusters,
+                           p.block_sums, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(cluster_assign_kernel<true>, dim3(blocks), dim3(kAssignWaves * 64), 0, s, p);
     return hipGetLastError();
