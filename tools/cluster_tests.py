@@ -9,8 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")]
 import numpy as np, torch
 import scenes as sc
-from oracle import oracle
-from orbit_amd import layouts as L, _lib
+from orbit_amd import layouts as L, _lib, passes
 from orbit_amd.engine import Engine
 
 FLOP_PER_TEST, PEAK_TFLOPS = 20.0, 157.3  # SURVEY.md §8d; MI355X vector FP32 (MI355X_MICROARCH.md)
@@ -26,7 +25,8 @@ cam = sc.default_camera()
 W, H, nl = 1920, 1080, 10_000
 cx, cy, cz = 240, 135, 32
 gdepth, glights = dev(sc.make_depth(9, W, H, cam)), dev(sc.make_lights(4, nl))
-zs, zb = oracle.cluster_grid_info(cam.z_near, 200.0, cz)
+der = passes.cluster_settings_derive(passes.ClusterSettings(screen_resolution=(W, H), z_slice_count=cz, far_plane=200.0), cam.z_near)
+zs, zb = float(der.z_scale), float(der.z_bias)  # ClusterSettings (cluster.rs:35-72), the product's host mirror
 push = np.zeros((), dtype=L.MARK_ACTIVE_PUSH)
 push["cluster_count"], push["tile_size_px"], push["screen_size"] = (cx, cy, cz), 8, (W, H)
 push["z_near"], push["z_far"], push["z_scale"], push["z_bias"], push["depth_buffer_sample_count"] = cam.z_near, 200.0, zs, zb, 1
