@@ -189,6 +189,20 @@ struct MeshletCullViews {
     MeshletCullParams v[ORBIT_MAX_CULL_VIEWS];
 };
 hipError_t launch_meshlet_cull_views(const MeshletCullViews &all, uint32_t n, uint32_t num_cus, hipStream_t s);
+// Views of one launch of the *_views kernels (orbit_cull_views): blockIdx.y = slot, idx[slot] = entry of the table.
+struct ViewGroup {
+    uint8_t idx[ORBIT_MAX_CULL_VIEWS];
+};
+// The launches launch_meshlet_cull / launch_meshlet_cull_views are made of (meshlet_eval.hip, meshlet_emit.hip,
+// meshlet_lists.hip); grids are sized inside.
+hipError_t launch_meshlet_eval(const MeshletCullParams &p, uint32_t num_cus, hipStream_t s);
+hipError_t launch_meshlet_eval_views(const MeshletCullViews &all, const ViewGroup &g, uint32_t m, uint32_t pass,
+                                     bool ortho, int src, uint32_t max_tiles, uint32_t num_cus, hipStream_t s);
+hipError_t launch_meshlet_emit(const MeshletCullParams &p, bool stream, uint32_t num_cus, hipStream_t s);
+hipError_t launch_meshlet_emit_views(const MeshletCullViews &all, const ViewGroup &g, uint32_t m, uint32_t n, bool stream,
+                                     uint32_t max_tiles_all, uint32_t num_cus, hipStream_t s);
+hipError_t launch_task_records(const MeshletCullParams &p, hipStream_t s);
+hipError_t launch_visible_records(const MeshletCullParams &p, hipStream_t s);
 // Largest dispatch capacity launch_meshlet_cull accepts (the emit launch keeps one base per scan chunk in LDS);
 // checked by orbit_ctx_create against caps.max_dispatches, so no launch is ever enqueued for a larger one.
 uint32_t max_dispatch_capacity();
@@ -228,6 +242,9 @@ hipError_t launch_depth_reduce(const DepthReduceBatch &b, hipStream_t s);
 hipError_t launch_cluster_mark(const ClusterMarkParams &p, hipStream_t s);
 hipError_t launch_cluster_compact(const ClusterCompactParams &p, hipStream_t s);
 hipError_t launch_cluster_assign(const ClusterAssignParams &p, uint32_t num_cus, hipStream_t s);
+
+// chunk bases the emit launches keep in LDS (1 Mi tiles = 16 Mi dispatch records)
+constexpr uint32_t kEmitChunkTable = 1024;
 
 // Exclusive scan of `n` words by one 1024-thread block; *total = sum.
 hipError_t launch_scan_exclusive(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, hipStream_t s);

@@ -1,0 +1,535 @@
+// meshlet_eval.hip — the evaluation launches of meshlet_cull (shaders/meshlet_cull.comp:108-213,233-254 of the
+// reference repo): which meshlets of the dispatched records are drawn.
+//
+//   pass 0 / 2 : meshlet_eval_kernel streams every meshlet of every record; in
+//                pass 2 the HiZ test runs on candidates compacted in LDS.
+//   pass 1     : meshlet_pass1_kernel is list-driven — only meshlets whose
+//                last-frame bit is set are read at all.
+//   streams    : with derived meshlet streams bound (orbit_meshlet_stream_*; kernels.h
+//                MeshletStreamView) passes 0 / 2 read 20.25 - 22 B per meshlet instead of
+//                the 32-B Meshlet and keep no survivor payload (template flags STREAM, CLS).
+// Outputs per wave tile: the survivor count, the should-draw ballots and (Meshlet buffer) the survivors' payload —
+// what scan + emit (meshlet_emit.hip) or the list launches (meshlet_lists.hip) turn into the caller's buffers.
+#include "meshlet_common.h"
+
+namespace orbit {
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// eval launch -> scan -> emit launch.
+//
+//   meshlet_eval : streams records, matrices and meshlets through the software
+//                  pipeline below and writes, per wave tile, the 8 should-draw
+//                  ballots (64 B) and their popcount.  No inter-wave dependency
+//                  of any kind: tiles are assigned statically (grid stride), so
+//                  waves drift out of phase and one wave's evaluation overlaps
+//                  another's loads.  Pass-2 visibility words are written here.
+//   scan         : exclusive prefix over the tile counts (scan.h / entity_cull.hip).
+//   meshlet_emit : per tile, re-reads only the survivors' command words and
+//                  writes the 28-B commands at the scanned offsets.
+//
+// Software pipeline of one wave in meshlet_eval.  A tile's 8 rows go through two
+// single-row register sets A/B, so that one row's meshlet loads are in flight
+// during every evaluation (16 waves per CU x 2 KiB is more than the bytes in
+// flight that HBM latency x bandwidth asks of a CU):
+//     eval row 0 (A) ; load A <- row 2      eval row 1 (B) ; load B <- row 3
+//     eval row 2 (A) ; load A <- row 4      eval row 3 (B) ; load B <- row 5
+//     issue matrix loads (i+2), record load (i+3)      | small, one iteration ahead
+//     eval row 4 (A) ; load A <- row 6      eval row 5 (B) ; load B <- row 7
+//     eval row 6 (A) ; load A <- row 0 of i+1   eval row 7 (B) ; load B <- row 1 of i+1
+//     write slab(i+2) ; store masks(i), count(i)
+// The dependent chain record -> matrix -> meshlets of a tile is spread over three
+// iterations; all loads are unconditional (inactive lanes read a zero page) so
+// that the compiler's vmcnt accounting stays exact.
+constexpr int kEvWaves = 4;
+constexpr int kEvWavesPerSimd = 4; // resident waves per SIMD: compiled for (128 VGPRs) and launched at
+// Pass 0 from the derived streams needs fewer registers than the passes with the HiZ test (84 against 107-119) and is
+// compiled for / launched at five waves per SIMD: with the rows as nt loads the fifth wave is worth 3.5 % (0.1948 /
+// 0.1964 -> 0.1879 / 0.1897 ms; six: 0.1897 / 0.1909, three: 0.2175 / 0.2184) — with the default cache policy it was
+// worth nothing, and from the Meshlet buffer it costs 1.5 % (0.3470 -> 0.3525; r03_notes.md).
+#ifndef ORBIT_EV_WPS0
+#define ORBIT_EV_WPS0 5
+#endif
+constexpr int ev_waves_per_simd(int pass, bool stream) { return (pass == 0 && stream) ? ORBIT_EV_WPS0 : kEvWavesPerSimd; }
+
+
+// STREAM: meshlets from the derived streams; CLS (with STREAM): predicate bits from the streams' alpha classes
+template <int PASS, int PROJ, bool PROF, bool STREAM = false, bool CLS = false>
+__device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
+    __shared__ WaveTileLds lds[kEvWaves][3];
+    __shared__ PlaneLds planes;
+    __shared__ AlphaLds alpha_tab;
+    __shared__ CandLds<(PASS == 2 ? kCandRing : 1u)> cand_ring[kEvWaves]; // pass 2 only
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // pass 2 with meshlet occlusion: HiZ tests run on compacted candidates (cand_flush), not per row
+    const bool occ2 = PASS == 2 && p.ci.meshlet_visibility_buffer != ORBIT_NONE;
+    __shared__ uint32_t cls_sel[CLS ? 8 : 1]; // [2 c + k] = all ones if alpha class c has predicate bit k (alpha_bits)
+    planes_to_lds(p, planes);
+    if (CLS && threadIdx.x < 6) cls_sel[threadIdx.x] = ((alpha_bits(p.ci, threadIdx.x >> 1) >> (threadIdx.x & 1u)) & 1u) ? ~0u : 0u;
+    const AlphaLds *alpha = alpha_table_fill(p, alpha_tab) ? &alpha_tab : nullptr;
+    __syncthreads();
+    const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
+    const uint32_t ntiles = (nrec + kTileRecords - 1) / kTileRecords;
+    // Tile assignment: a static grid-stride share first, tickets for the rest.  With 23 or 24 tiles per wave handed out
+    // statically the waves finish over a span of ~45 us (the SIMD arbiter favours older waves, CUs differ) and the last
+    // 6 % of the kernel run at falling occupancy (tools/wave_tail.py); handing every tile out through an atomic ticket
+    // removes the tail but costs more than it saves (+5 %: the returning atomic sits in the in-order vector-memory
+    // queue in front of the row loads, once per tile).  So every wave takes its first S tiles statically (tile
+    // k * stride + g, as before) and only the last ~3 tiles' worth per wave go through tickets — 3-4 atomics per wave:
+    // fast waves draw more of them.  One counter cannot serve the ~290 claims/us at the very end (a returning atomic
+    // on one address saturates near 88/us on MI355X), so there are kTicketPools: wave g draws from pool g % npools,
+    // ticket n of pool q is tile S * stride + n * npools + q; every pool is drained by 1/npools of the waves of all
+    // XCDs, so the pools run dry within a tile's time of each other and nobody steals.  A claim is made three tiles
+    // before its rows are read (records -> matrices -> slab -> rows); a wave whose ticket is past the end drains its
+    // pipeline and leaves.
+    const uint32_t stride = gridDim.x * kEvWaves, wave_g = blockIdx.x * kEvWaves + wave;
+    const bool static_share = ORBIT_DBG(p, 64u); // triage: everything static, for A/B runs
+    const uint32_t full_rounds = ntiles / stride;
+    // ticketed rounds: three on a long launch, fewer on a short one (a shard of the sharded engine has 2-3 rounds in all)
+    const uint32_t dyn_rounds = ORBIT_DBG(p, 256u) ? 2u : ORBIT_DBG(p, 512u) ? 4u : ORBIT_DBG(p, 1024u) ? 1u : min(max(full_rounds / 4u, 1u), 3u);
+    // a scene of at most one tile per wave has nothing to balance: static, no atomic in front of the first loads
+    // ... and the three tiles a wave claims before its first row never go through a ticket either: their records,
+    // matrices and rows are the launch's ramp, and an atomic in front of them is one more round trip before anything
+    // streams (a 1/8 shard of config 5 is three tiles per wave)
+    const uint32_t n_static = (static_share || ntiles <= stride) ? 0xFFFFFFFFu : (ORBIT_DBG(p, 128u) ? 0u : max(full_rounds >= dyn_rounds ? full_rounds - dyn_rounds : 0u, 3u));
+    const uint32_t npools = min((uint32_t)kTicketPools, stride);
+    const uint32_t pool = wave_g % npools;
+    uint32_t *ticket_ctr = p.tickets + pool * kTicketStride;
+    uint32_t claims = 0; // claims made so far by this wave
+    auto claim = [&]() -> uint32_t { // lane 0's VGPR carries the claim; not read before ticket_tile()
+        uint32_t raw = claims;
+        if (claims >= n_static) {
+            raw = 0;
+            if (lane == 0) raw = atomicAdd(ticket_ctr, 1u);
+        }
+        claims++;
+        return raw;
+    };
+    auto ticket_tile = [&](uint32_t raw, uint32_t k) -> uint32_t { // k = index of the claim that returned `raw`
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw);
+        if (k < n_static) return t * stride + wave_g;
+        return t >= 0x08000000u ? 0xFFFFFFFFu : n_static * stride + t * npools + pool;
+    };
+    StreamRsrc SR = {};
+    if constexpr (STREAM) {
+        SR.first = p.ms.first;
+        SR.count = p.ms.count;
+        SR.sphere = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(p.ms.sphere + p.ms.first), 0, p.ms.count * 16u, kBufFlags);
+        SR.cone = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.ms.cone + p.ms.first), 0, p.ms.count * 4u, kBufFlags);
+        if constexpr (!CLS)
+            SR.mat = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.ms.mat + p.ms.first), 0, p.ms.count * 2u, kBufFlags);
+    }
+    uint32_t w0, w1, w2, tk_raw;
+    {
+        const uint32_t t0 = claim(), t1 = claim(), t2 = claim();
+        tk_raw = claim();
+        w0 = ticket_tile(t0, 0u);
+        w1 = ticket_tile(t1, 1u);
+        w2 = ticket_tile(t2, 2u);
+    }
+    // two single-row register sets: while one row is evaluated the next row's loads are in flight
+    // (STREAM: a row is 1.25 KiB instead of 2 KiB; sets of two rows each were measured in rounds 2 and 3 — neutral or
+    // slower, as are 5 and 6 resident waves per SIMD: profiles/r02_notes.md, r03_notes.md)
+    RowRegs<1> qa, qb;
+    uint4 rec2;
+    {
+        const uint4 r0 = setup_load_rec(p, w0, w0 < ntiles, nrec, lane);
+        const uint4 r1 = setup_load_rec(p, w1, w1 < ntiles, nrec, lane);
+        rec2 = setup_load_rec(p, w2, w2 < ntiles, nrec, lane);
+        const float4 m0 = setup_load_mat(p, r0, lane);
+        const float4 m1 = setup_load_mat(p, r1, lane);
+        if constexpr (CLS) {
+            const uint32_t c0 = setup_load_cls(p, r0, lane), c1 = setup_load_cls(p, r1, lane);
+            setup_write_cls(lds[wave][0], cls_sel, r0, c0, lane);
+            setup_write_cls(lds[wave][1], cls_sel, r1, c1, lane);
+        }
+        setup_write(p, lds[wave][0], r0, m0, lane);
+        setup_write(p, lds[wave][1], r1, m1, lane);
+        rows_load<PASS, 0, 1, STREAM, CLS>(p, lds[wave][0], lane, qa, &SR);
+        rows_load<PASS, 1, 1, STREAM, CLS>(p, lds[wave][0], lane, qb, &SR);
+    }
+    uint32_t it = 0;
+#ifdef ORBIT_TRIAGE
+    unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1;
+#define EV_STAMP(k)                            \
+    if (PROF && !(p.debug_flags & 16u)) {      \
+        t1 = __builtin_amdgcn_s_memtime();     \
+        __builtin_amdgcn_s_waitcnt(0xC07F);    \
+        tc[k] += t1 - t0;                      \
+        t0 = t1;                               \
+    }
+    unsigned long long wall_begin = 0;
+    if (p.debug_flags & 16u) wall_begin = wall_clock64(); // per-wave life stamps (tools/wave_tail.py)
+    if (PROF) {
+        t0 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
+#else
+#define EV_STAMP(k)
+    static_assert(!PROF, "phase stamps: -DORBIT_TRIAGE builds only");
+#endif
+    // The SIMD's arbiter serves the oldest wave first, and the four waves of a SIMD belong to the four blocks a CU
+    // holds, dispatched one after the other: left alone, the first block's waves finish at half the kernel's
+    // duration and the rest of the kernel runs at 3, 2, 1 waves per SIMD (tools/wave_tail.py).  Every wave
+    // therefore rotates its priority once per tile, offset by its block's dispatch rank, so that over any four
+    // tiles each wave of a SIMD has held each priority once.
+    const uint32_t prio_rank = blockIdx.x / max(gridDim.x / (uint32_t)ev_waves_per_simd(PASS, STREAM), 1u);
+    while (w0 < ntiles) {
+        if (!ORBIT_DBG(p, 32u)) {
+            switch ((it + prio_rank) & 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        }
+        const uint32_t w3 = ticket_tile(tk_raw, claims - 1u); // claimed one tile ago
+        tk_raw = claim();                                     // the tile after it
+        WaveTileLds &L = lds[wave][it % 3];
+        WaveTileLds &Ln = lds[wave][(it + 1) % 3]; // slab of an absent tile holds zero records
+        // no payload with the derived streams: the emit launch derives the survivors' command words itself
+        Payload *payload = (STREAM || p.task_records || p.visible_list == 2u) ? nullptr : p.tile_payload + (size_t)w0 * kPayloadCap;
+        CandState cs; // cs.total = the tile's running survivor count
+#define EV_ROW(R, Q)                                                                                                  \
+    if constexpr (PASS == 2) {                                                                                        \
+        if (occ2) row_eval_occ<PROJ, R, kCandRing, CLS>(p, L, planes, alpha, cand_ring[wave], lane, Q, cs, payload);  \
+        else cs.total = rows_eval<PASS, PROJ, R, 1, CLS>(p, L, planes, alpha, lane, Q, cs.total, payload);      \
+    } else {                                                                                                          \
+        cs.total = rows_eval<PASS, PROJ, R, 1, CLS>(p, L, planes, alpha, lane, Q, cs.total, payload);           \
+    }
+        EV_ROW(0, qa)
+        rows_load<PASS, 2, 1, STREAM, CLS>(p, L, lane, qa, &SR);
+        EV_ROW(1, qb)
+        rows_load<PASS, 3, 1, STREAM, CLS>(p, L, lane, qb, &SR);
+        EV_STAMP(0)
+        EV_ROW(2, qa)
+        rows_load<PASS, 4, 1, STREAM, CLS>(p, L, lane, qa, &SR);
+        EV_ROW(3, qb)
+        rows_load<PASS, 5, 1, STREAM, CLS>(p, L, lane, qb, &SR);
+        const float4 mat2 = setup_load_mat(p, rec2, lane);
+        uint32_t cls2 = 0u;
+        if constexpr (CLS) cls2 = setup_load_cls(p, rec2, lane);
+        const uint4 rec3 = setup_load_rec(p, w3, w3 < ntiles, nrec, lane);
+        EV_STAMP(1)
+        EV_ROW(4, qa)
+        rows_load<PASS, 6, 1, STREAM, CLS>(p, L, lane, qa, &SR);
+        EV_ROW(5, qb)
+        rows_load<PASS, 7, 1, STREAM, CLS>(p, L, lane, qb, &SR);
+        EV_STAMP(2)
+        EV_ROW(6, qa)
+        rows_load<PASS, 0, 1, STREAM, CLS>(p, Ln, lane, qa, &SR);
+        EV_ROW(7, qb)
+        rows_load<PASS, 1, 1, STREAM, CLS>(p, Ln, lane, qb, &SR);
+        EV_STAMP(3)
+        if constexpr (PASS == 2) {
+            if (occ2) tile_finish_occ(p, L, cand_ring[wave], lane, cs, payload);
+        }
+#undef EV_ROW
+        if constexpr (CLS) setup_write_cls(lds[wave][(it + 2) % 3], cls_sel, rec2, cls2, lane);
+        setup_write(p, lds[wave][(it + 2) % 3], rec2, mat2, lane); // also fences the mask writes of this tile
+        // the ballots are read back only by the task-record launch and, in the emit launch, for tiles with more
+        // survivors than the payload holds: the common tile writes its count and nothing else
+        if ((STREAM || p.task_records != nullptr || p.visible_list == 2u || cs.total > kPayloadCap) && lane < 2 * (int)kTileRows)
+            p.tile_masks[(size_t)w0 * (2 * kTileRows) + lane] = reinterpret_cast<const uint32_t *>(L.draw_mask)[lane];
+        if (lane == 0) p.tile_counts[w0] = cs.total;
+        EV_STAMP(4)
+        w0 = w1;
+        w1 = w2;
+        w2 = w3;
+        rec2 = rec3;
+        it++;
+    }
+#undef EV_STAMP
+#ifdef ORBIT_TRIAGE
+    if (PROF && lane == 0) {
+        for (int k = 0; k < 5; k++) atomicAdd(p.debug_cycles + k, tc[k]);
+        atomicAdd(p.debug_cycles + 7, 1ull);
+    }
+    if ((p.debug_flags & 16u) && lane == 0) {
+        const uint32_t wg = blockIdx.x * kEvWaves + wave;
+        if (wg < 8192u) {
+            p.debug_cycles[32 + 2 * wg] = wall_begin;
+            p.debug_cycles[32 + 2 * wg + 1] = wall_clock64();
+        }
+    }
+#endif
+}
+
+template <int PASS, int PROJ, bool PROF, bool STREAM = false, bool CLS = false>
+__global__ __launch_bounds__(kEvWaves * 64, ev_waves_per_simd(PASS, STREAM)) void meshlet_eval_kernel(const MeshletCullParams p) {
+    meshlet_eval_body<PASS, PROJ, PROF, STREAM, CLS>(p);
+}
+// several views in one launch (orbit_cull_views): the views' parameter blocks by value, blockIdx.y picks one
+template <int PASS, int PROJ, bool STREAM, bool CLS = false>
+__global__ __launch_bounds__(kEvWaves * 64, ev_waves_per_simd(PASS, STREAM)) void meshlet_eval_views_kernel(const MeshletCullViews all,
+                                                                                           const ViewGroup g) {
+    meshlet_eval_body<PASS, PROJ, false, STREAM, CLS>(all.v[g.idx[blockIdx.y]]);
+}
+
+// ---------------------------------------------------------------------------
+// Pass 1 (occlusion_pass == 1, :137): only meshlets that were visible last frame
+// are processed at all, and which those are is known from 4 bytes per record
+// before any meshlet is read.  So pass 1 is list-driven instead of streaming:
+// per wave tile the set bits of the 16 visibility words become a candidate list
+// in canonical (row, lane) order (LDS), and the tile is evaluated in chunks of
+// 64 candidates — gathered 32-B meshlet reads for the candidates only (dense
+// runs coalesce exactly like the streamed rows), full lanes in the evaluation.
+// At 10 % visibility that is ~40 % of the streamed bytes and one evaluation per
+// tile instead of eight.  Outputs (ballots, count, payload) and the scan + emit
+// that follow are those of the other passes.
+//
+// Pipeline of one wave: records 3 tiles ahead, matrices + visibility words 2
+// ahead, slab 1 ahead (as in meshlet_eval); the work items are (tile, chunk)
+// pairs through two register sets — while item k is evaluated the gathers of
+// item k+1 (next chunk, or chunk 0 of the next tile, whose list is built first)
+// are in flight.
+struct Pass1Item {
+    uint4 a, b;    // the candidate's Meshlet
+    uint32_t code; // row*64 + lane of the candidate, ~0u = none
+};
+
+__device__ __forceinline__ uint32_t pass1_load_prev(const MeshletCullParams &p, const uint4 &rec, int lane) {
+    const bool rw_vis = p.ci.meshlet_visibility_buffer != ORBIT_NONE;
+    const uint32_t *src = (rw_vis && rec.z != 0u && (lane & 3) == 0) ? p.meshlet_visibility + rec.w
+                                                                    : reinterpret_cast<const uint32_t *>(p.zero_page);
+    const uint32_t w = *src;
+    return rw_vis ? w : 0xFFFFFFFFu; // no meshlet visibility buffer: visible_in_buffer stays true (:128)
+}
+
+// Candidate list of a tile: lanes whose last-frame bit is set (:129-137), canonical order.
+__device__ __forceinline__ uint32_t pass1_build_list(const WaveTileLds &L, uint16_t *list, int lane) {
+    const uint32_t half = lane >> 5, ml = lane & 31;
+    uint32_t n = 0;
+#pragma unroll
+    for (int r = 0; r < (int)kTileRows; r++) {
+        const uint32_t rid = 2 * r + half;
+        const bool c = ml < L.r[rid].rec.z && ((L.r[rid].prev >> ml) & 1u) != 0;
+        const uint64_t mask = __ballot(c);
+        if (c) list[n + lane_prefix(mask)] = (uint16_t)(r * 64 + lane);
+        n += (uint32_t)__popcll(mask);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return n;
+}
+
+__device__ __forceinline__ Pass1Item pass1_load(const MeshletCullParams &p, const WaveTileLds &L,
+                                                const uint16_t *list, uint32_t n, uint32_t chunk, int lane) {
+    Pass1Item it;
+    const uint32_t j = chunk * 64u + (uint32_t)lane;
+    const bool valid = j < n;
+    it.code = valid ? (uint32_t)list[j] : ~0u;
+    const uint32_t rid = (it.code >> 5) & 15u, ml = it.code & 31u;
+    // unconditional loads (exact vmcnt accounting): lanes without a candidate read the zero page
+    const uint4 *src = valid ? reinterpret_cast<const uint4 *>(p.meshlets + (L.r[rid].rec.y + ml))
+                             : reinterpret_cast<const uint4 *>(p.zero_page);
+    it.a = src[0];
+    it.b = src[1];
+    return it;
+}
+
+template <int PROJ>
+__device__ __forceinline__ uint32_t pass1_eval(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
+                                               const AlphaLds *A, int lane, const Pass1Item &it, uint32_t total,
+                                               Payload *payload) {
+    const bool valid = it.code != ~0u;
+    const uint32_t rid = (it.code >> 5) & 15u, ml = it.code & 31u;
+    const uint32_t mi = it.b.w & 0xFFFFu; // zero page for lanes without a candidate: material 0, unused
+    const uint32_t abits = A ? (uint32_t)A->bits[mi & (kAlphaTable - 1u)] : alpha_bits(p.ci, p.materials[mi].alpha_mode);
+    bool should_draw = false;
+    if (valid) {
+        Sphere s;
+        const bool visible = eval_geometry<1, PROJ>(p, L, P, rid, it.a, it.b, true, s); // candidates have the bit set
+        should_draw = should_draw_of(visible, abits, true, false);
+    }
+    if (should_draw) atomicOr(reinterpret_cast<uint32_t *>(L.draw_mask) + rid, 1u << ml);
+    const uint64_t dm = __ballot(should_draw);
+    if (payload && should_draw) {
+        const uint32_t rank = total + lane_prefix(dm);
+        if (rank < kPayloadCap) payload[rank] = make_payload(ml, rid, it.b);
+    }
+    return total + (uint32_t)__popcll(dm);
+}
+
+template <int PROJ>
+__device__ __forceinline__ void meshlet_pass1_body(const MeshletCullParams &p) {
+    __shared__ WaveTileLds lds[kEvWaves][3];
+    __shared__ PlaneLds planes;
+    __shared__ AlphaLds alpha_tab;
+    __shared__ uint16_t s_list[kEvWaves][2][kTileRows * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    planes_to_lds(p, planes);
+    const AlphaLds *alpha = alpha_table_fill(p, alpha_tab) ? &alpha_tab : nullptr;
+    __syncthreads();
+    const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
+    const uint32_t ntiles = (nrec + kTileRecords - 1) / kTileRecords;
+    const uint32_t stride = gridDim.x * kEvWaves;
+    uint32_t w0 = blockIdx.x * kEvWaves + wave, w1 = w0 + stride, w2 = w1 + stride;
+    uint16_t *list_cur = s_list[wave][0], *list_next = s_list[wave][1];
+    uint4 rec2;
+    uint32_t n_cur;
+    Pass1Item cur;
+    {
+        const uint4 r0 = setup_load_rec(p, w0, w0 < ntiles, nrec, lane);
+        const uint4 r1 = setup_load_rec(p, w1, w1 < ntiles, nrec, lane);
+        rec2 = setup_load_rec(p, w2, w2 < ntiles, nrec, lane);
+        const float4 m0 = setup_load_mat(p, r0, lane);
+        const uint32_t p0 = pass1_load_prev(p, r0, lane);
+        const float4 m1 = setup_load_mat(p, r1, lane);
+        const uint32_t p1 = pass1_load_prev(p, r1, lane);
+        setup_write(p, lds[wave][0], r0, m0, lane, p0);
+        setup_write(p, lds[wave][1], r1, m1, lane, p1);
+        n_cur = pass1_build_list(lds[wave][0], list_cur, lane); // absent tile: zero records, empty list
+        cur = pass1_load(p, lds[wave][0], list_cur, n_cur, 0u, lane);
+    }
+    uint32_t it = 0;
+    while (w0 < ntiles) {
+        const uint32_t w3 = w2 + stride;
+        WaveTileLds &L = lds[wave][it % 3];
+        WaveTileLds &Ln = lds[wave][(it + 1) % 3]; // slab of an absent tile holds zero records
+        Payload *payload = p.task_records ? nullptr : p.tile_payload + (size_t)w0 * kPayloadCap;
+        const float4 mat2 = setup_load_mat(p, rec2, lane);
+        const uint32_t prev2 = pass1_load_prev(p, rec2, lane);
+        const uint4 rec3 = setup_load_rec(p, w3, w3 < ntiles, nrec, lane);
+        uint32_t total = 0, n_next = 0;
+        for (uint32_t chunk = 0;; chunk++) { // at least one trip: an empty tile still hands over to the next one
+            const bool last = (chunk + 1u) * 64u >= n_cur;
+            Pass1Item next;
+            if (!last) {
+                next = pass1_load(p, L, list_cur, n_cur, chunk + 1u, lane);
+            } else {
+                n_next = pass1_build_list(Ln, list_next, lane);
+                next = pass1_load(p, Ln, list_next, n_next, 0u, lane);
+            }
+            total = pass1_eval<PROJ>(p, L, planes, alpha, lane, cur, total, payload);
+            cur = next;
+            if (last) break;
+        }
+        setup_write(p, lds[wave][(it + 2) % 3], rec2, mat2, lane, prev2); // also fences the mask atomics of this tile
+        if ((p.task_records != nullptr || p.visible_list == 2u || total > kPayloadCap) && lane < 2 * (int)kTileRows) // see meshlet_eval
+            p.tile_masks[(size_t)w0 * (2 * kTileRows) + lane] = reinterpret_cast<const uint32_t *>(L.draw_mask)[lane];
+        if (lane == 0) p.tile_counts[w0] = total;
+        uint16_t *t = list_cur;
+        list_cur = list_next;
+        list_next = t;
+        n_cur = n_next;
+        w0 = w1;
+        w1 = w2;
+        w2 = w3;
+        rec2 = rec3;
+        it++;
+    }
+}
+
+template <int PROJ>
+__global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_pass1_kernel(const MeshletCullParams p) {
+    meshlet_pass1_body<PROJ>(p);
+}
+template <int PROJ>
+__global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_pass1_views_kernel(const MeshletCullViews all,
+                                                                                            const ViewGroup g) {
+    meshlet_pass1_body<PROJ>(all.v[g.idx[blockIdx.y]]);
+}
+
+// 4-wave blocks, one wave per SIMD each.  The fifth wave per SIMD pays once a wave has enough tiles to stream (8 and
+// more); a small launch is mostly its pipeline's ramp, which more, shorter waves only lengthen (a 1/4 and a 1/8
+// shard of config 5: 0.095 / 0.085 ms at four waves, 0.1025 / 0.090 at five)
+uint32_t eval_grid(uint32_t pass, bool stream, uint32_t max_tiles, uint32_t num_cus) {
+    uint32_t wps = (uint32_t)ev_waves_per_simd((int)pass, stream);
+    if (wps > (uint32_t)kEvWavesPerSimd && max_tiles < 8u * num_cus * wps * (uint32_t)kEvWaves) wps = (uint32_t)kEvWavesPerSimd;
+    uint32_t blocks = num_cus * wps;
+    const uint32_t need = (max_tiles + kEvWaves - 1) / kEvWaves;
+    if (blocks > need) blocks = need;
+    return blocks == 0 ? 1u : blocks;
+}
+
+template <int PASS>
+void launch_eval_pass(const MeshletCullParams &p, dim3 grid, hipStream_t s) {
+    const dim3 block(kEvWaves * 64);
+    const bool ortho = p.ci.projection_type == 1;
+    if constexpr (PASS == 1) { // list-driven: only last frame's visible meshlets are read
+        if (ortho)
+            hipLaunchKernelGGL((meshlet_pass1_kernel<1>), grid, block, 0, s, p);
+        else
+            hipLaunchKernelGGL((meshlet_pass1_kernel<0>), grid, block, 0, s, p);
+    } else if (p.ms.sphere != nullptr && p.ms.cls0 != nullptr) { // derived streams + alpha classes: 20.25 B per meshlet
+        if (ortho)
+            hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 1, false, true, true>), grid, block, 0, s, p);
+        else
+            hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 0, false, true, true>), grid, block, 0, s, p);
+    } else if (p.ms.sphere != nullptr) { // derived streams: 22 B per meshlet, no payload
+        if (ortho)
+            hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 1, false, true>), grid, block, 0, s, p);
+        else
+            hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 0, false, true>), grid, block, 0, s, p);
+    } else if constexpr (PASS == 0) {
+#ifdef ORBIT_TRIAGE
+        if (p.debug_flags & 8u) { // phase-stamped kernel (tools/phase.py); | 16: only the per-wave wall-clock stamps
+            if (ortho)
+                hipLaunchKernelGGL((meshlet_eval_kernel<0, 1, true>), grid, block, 0, s, p);
+            else
+                hipLaunchKernelGGL((meshlet_eval_kernel<0, 0, true>), grid, block, 0, s, p);
+        } else
+#endif
+        if (ortho) {
+            hipLaunchKernelGGL((meshlet_eval_kernel<0, 1, false>), grid, block, 0, s, p);
+        } else {
+            hipLaunchKernelGGL((meshlet_eval_kernel<0, 0, false>), grid, block, 0, s, p);
+        }
+    } else {
+        if (ortho)
+            hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 1, false>), grid, block, 0, s, p);
+        else
+            hipLaunchKernelGGL((meshlet_eval_kernel<PASS, 0, false>), grid, block, 0, s, p);
+    }
+}
+
+} // namespace
+
+hipError_t launch_meshlet_eval(const MeshletCullParams &p, uint32_t num_cus, hipStream_t s) {
+    const uint32_t max_tiles = (p.dispatch_capacity + kTileRecords - 1) / kTileRecords;
+    const uint32_t pass = p.ci.occlusion_pass;
+    const dim3 grid(eval_grid(pass, p.ms.sphere != nullptr, max_tiles, num_cus));
+    switch (pass) {
+    case 0: launch_eval_pass<0>(p, grid, s); break;
+    case 1: launch_eval_pass<1>(p, grid, s); break;
+    default: launch_eval_pass<2>(p, grid, s); break;
+    }
+    return hipGetLastError();
+}
+
+// One evaluation launch for the m views g.idx[0..m) of `all`, which share the occlusion pass, the projection and the
+// meshlet source `src` (0 = Meshlet buffer, 1 = derived streams, 2 = streams with alpha classes).
+hipError_t launch_meshlet_eval_views(const MeshletCullViews &all, const ViewGroup &g, uint32_t m, uint32_t pass,
+                                     bool ortho, int src, uint32_t max_tiles, uint32_t num_cus, hipStream_t s) {
+    // the views of a group share the device: each gets an equal part of the resident-wave budget
+    uint32_t blocks = max(num_cus * (uint32_t)ev_waves_per_simd((int)pass, src != 0) / m, 1u);
+    const uint32_t need = max((max_tiles + kEvWaves - 1) / kEvWaves, 1u);
+    if (blocks > need) blocks = need;
+    const dim3 grid(blocks, m), block(kEvWaves * 64);
+#define ORBIT_EVAL_VIEWS(PASS)                                                                                        \
+    if (src == 2) {                                                                                                   \
+        if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<PASS, 1, true, true>), grid, block, 0, s, all, g);   \
+        else hipLaunchKernelGGL((meshlet_eval_views_kernel<PASS, 0, true, true>), grid, block, 0, s, all, g);         \
+    } else if (src == 1) {                                                                                            \
+        if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<PASS, 1, true>), grid, block, 0, s, all, g);         \
+        else hipLaunchKernelGGL((meshlet_eval_views_kernel<PASS, 0, true>), grid, block, 0, s, all, g);               \
+    } else {                                                                                                          \
+        if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<PASS, 1, false>), grid, block, 0, s, all, g);        \
+        else hipLaunchKernelGGL((meshlet_eval_views_kernel<PASS, 0, false>), grid, block, 0, s, all, g);              \
+    }
+    if (pass == 1) {
+        if (ortho) hipLaunchKernelGGL((meshlet_pass1_views_kernel<1>), grid, block, 0, s, all, g);
+        else hipLaunchKernelGGL((meshlet_pass1_views_kernel<0>), grid, block, 0, s, all, g);
+    } else if (pass == 0) {
+        ORBIT_EVAL_VIEWS(0)
+    } else {
+        ORBIT_EVAL_VIEWS(2)
+    }
+#undef ORBIT_EVAL_VIEWS
+    return hipGetLastError();
+}
+
+} // namespace orbit

@@ -1,0 +1,430 @@
+// meshlet_lists.hip — the outputs of meshlet_cull that are not a MeshletDrawCommandBuffer, and the way back:
+//   task_records_kernel            per-record task payloads of the mesh-shading path (orbit_meshlet_task_cull)
+//   visible_records_*_kernel       the visible list compacted at record granularity (sharded engine)
+//   visible_expand_kernel,
+//   visible_records_expand_kernel  gathered lists -> commands on the receiving GPU (shaders/meshlet_cull.comp:216-230)
+//   scatter_list_kernel            a rank's list into every peer's buffer over xGMI (orbit_scatter_list)
+#include "meshlet_common.h"
+
+namespace orbit {
+
+namespace {
+
+// Visible list -> MeshletDrawCommandBuffer (meshlet_cull.comp:216-230 for survivors that were culled on another GPU):
+// lane = survivor, Meshlet bytes 16..31 gathered from the (replicated) meshlet buffer, commands staged through LDS
+// so that every store covers 256 contiguous bytes.  Grid-stride over chunks of 64 survivors per wave, software
+// pipelined: the items of chunk i+2 and the gathers of chunk i+1 are in flight while chunk i is written.  All loads
+// are unconditional (lanes past the list read the zero page) and the stores are buffer stores whose offset is out
+// of range for the words past the list, so the code is straight-line and every vmcnt wait is exact.
+struct ExpandChunk {
+    uint2 item;  // {meshlet_index, entity_index}
+    bool valid;
+};
+
+__device__ __forceinline__ ExpandChunk expand_load_items(const uint2 *items, uint32_t first, uint32_t n, int lane,
+                                                         const void *zero_page) {
+    ExpandChunk c;
+    const uint32_t i = first + (uint32_t)lane;
+    c.valid = first < n && i < n; // first can wrap past 2^32 only with n near 2^32: excluded by draw_capacity
+    c.item = *(c.valid ? items + i : reinterpret_cast<const uint2 *>(zero_page));
+    return c;
+}
+
+// STREAM: the three command words come from the derived 12-B stream (`cmd`, orbit_meshlet_stream_*) instead of bytes
+// 16..31 of the Meshlet: a third of the lines per survivor.
+template <bool STREAM>
+__device__ __forceinline__ uint4 expand_gather(const OrbitMeshlet *meshlets, const MeshletStreamView &ms,
+                                               const ExpandChunk &c, const void *zero_page, int32_t *status) {
+    if constexpr (STREAM) {
+        const bool in = c.valid && ms.covers(c.item.x);
+        if (c.valid && !in) latch_status(status, ORBIT_E_RANGE);
+        const uint32_t *c3 = in ? ms.cmd + (size_t)c.item.x * 3u : reinterpret_cast<const uint32_t *>(zero_page);
+        return make_uint4(0u, c3[0], c3[1], c3[2]);
+    } else {
+        return *(c.valid ? reinterpret_cast<const uint4 *>(meshlets + c.item.x) + 1
+                         : reinterpret_cast<const uint4 *>(zero_page));
+    }
+}
+
+template <bool STREAM>
+__global__ __launch_bounds__(256) void visible_expand_kernel(const uint8_t *visible, const OrbitMeshlet *meshlets,
+                                                             const MeshletStreamView ms, uint8_t *draw_buffer,
+                                                             uint32_t draw_capacity, const void *zero_page,
+                                                             int32_t *status) {
+    __shared__ uint32_t s_cmd[4][64 * 7];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *cmd = s_cmd[wave];
+    const uint32_t total = *reinterpret_cast<const uint32_t *>(visible);
+    const uint32_t n = min(total, draw_capacity);
+    const uint2 *items = reinterpret_cast<const uint2 *>(visible + ORBIT_VISIBLE_HEADER);
+    uint8_t *out = draw_buffer + ORBIT_DRAW_HEADER;
+    const uint32_t stride = gridDim.x * 4u * 64u;
+    // wave-uniform, and provably so for the compiler (buffer descriptors live in SGPRs)
+    uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 4u + wave) * 64u));
+    ExpandChunk c0 = expand_load_items(items, first, n, lane, zero_page);
+    ExpandChunk c1 = expand_load_items(items, first + stride, n, lane, zero_page);
+    uint4 b0 = expand_gather<STREAM>(meshlets, ms, c0, zero_page, status);
+    for (; first < n; first += stride) {
+        const ExpandChunk c2 = expand_load_items(items, first + 2u * stride, n, lane, zero_page);
+        const uint4 b1 = expand_gather<STREAM>(meshlets, ms, c1, zero_page, status);
+        uint32_t *c = cmd + lane * 7;
+        c[0] = (b0.w >> 24) * 3u;                     // cmd_index_count = triangle_count * 3
+        c[1] = 1u;                                    // cmd_instance_count
+        c[2] = (b0.z + ((b0.w >> 16) & 0xFFu)) * 4u;  // cmd_first_index = (data_offset + vertex_count) * 4
+        c[3] = b0.z;                                  // cmd_vertex_offset = int(data_offset)
+        c[4] = c0.item.y;                             // cmd_first_instance = entity_index
+        c[5] = b0.y;                                  // meshlet_vertex_offset
+        c[6] = c0.item.x;                             // meshlet_index
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the chunk's commands as one range-checked window: words past the list fall outside and are dropped
+        const uint32_t bytes = min(n - first, 64u) * 28u;
+        const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)first * 28u, 0, bytes, 0x00020000);
+#pragma unroll
+        for (uint32_t k = 0; k < 7; k++) {
+            const uint32_t w = k * 64u + (uint32_t)lane;
+            __builtin_amdgcn_raw_buffer_store_b32(cmd[w], win, w * 4u, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier(); // cmd is rewritten by the next chunk
+        c0 = c1;
+        c1 = c2;
+        b0 = b1;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *reinterpret_cast<uint32_t *>(draw_buffer) = n;
+        if (total > draw_capacity) latch_status(status, ORBIT_E_CAPACITY);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The visible list compacted at record granularity (sharded engine, orbit_meshlet_cull_visible_records): 12 B per
+// dispatch record that has a survivor — {entity_index, meshlet_offset, should-draw ballot of its (up to) 32 meshlets}
+// — in record order, behind an 8-B {records, survivors} header.  The same ordered list of (meshlet, entity) pairs as
+// the 8-B items (bit b of record r = item {meshlet_offset + b, entity_index}), in half the bytes at config 5 (3.2
+// survivors per surviving record): what travels over xGMI.  Built straight from the evaluation's per-record
+// ballots — no survivor scan, no emit: a count launch (block sums) and a write launch that adds up the sums of the
+// blocks before it.
+constexpr uint32_t kVrBlock = 1024; // records per block: 256 threads x 4
+
+__global__ __launch_bounds__(256) void visible_records_count_kernel(const MeshletCullParams p, uint32_t max_blocks) {
+    __shared__ uint32_t smem[8];
+    const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
+    if (blockIdx.x == 0 && threadIdx.x < kTicketPools) p.tickets[threadIdx.x * kTicketStride] = 0u; // next evaluation
+    const uint32_t r0 = blockIdx.x * kVrBlock + threadIdx.x * 4u;
+    uint32_t nz = 0, pop = 0;
+    if (blockIdx.x * kVrBlock < nrec) { // tile_masks is padded to whole tiles: the uint4 of a thread is always readable
+        const uint4 m = r0 < nrec ? *reinterpret_cast<const uint4 *>(p.tile_masks + r0) : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t w[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t v = r0 + k < nrec ? w[k] : 0u;
+            nz += v != 0u ? 1u : 0u;
+            pop += (uint32_t)__popc(v);
+        }
+    }
+    // (pop < 2^15 and nz < 2^11 per block: one reduction for both)
+    const uint32_t both = wave_reduce_add(nz << 16 | pop);
+    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = both;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t s = smem[0] + smem[1] + smem[2] + smem[3];
+        p.tile_base[blockIdx.x] = s >> 16;
+        p.tile_base[max_blocks + blockIdx.x] = s & 0xFFFFu;
+    }
+}
+
+__global__ __launch_bounds__(256) void visible_records_write_kernel(const MeshletCullParams p, uint32_t max_blocks) {
+    __shared__ uint32_t smem[8];
+    const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
+    const uint32_t nblocks = (nrec + kVrBlock - 1u) / kVrBlock;
+    if (blockIdx.x >= nblocks && blockIdx.x != 0) return;
+    // records of the blocks before this one; block 0 adds up everything for the header
+    const uint32_t upto = blockIdx.x == 0 ? nblocks : blockIdx.x;
+    uint32_t part_nz = 0, part_pop = 0;
+    for (uint32_t i = threadIdx.x; i < upto; i += 256u) {
+        part_nz += p.tile_base[i];
+        if (blockIdx.x == 0) part_pop += p.tile_base[max_blocks + i];
+    }
+    part_nz = wave_reduce_add(part_nz);
+    part_pop = wave_reduce_add(part_pop);
+    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = part_nz, smem[4 + (threadIdx.x >> 6)] = part_pop;
+    __syncthreads();
+    const uint32_t sum_nz = smem[0] + smem[1] + smem[2] + smem[3], sum_pop = smem[4] + smem[5] + smem[6] + smem[7];
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint32_t *hdr = reinterpret_cast<uint32_t *>(p.draw_buffer);
+        hdr[0] = min(sum_nz, p.draw_capacity);
+        hdr[1] = sum_pop;
+        *p.total = sum_nz;
+        if (sum_nz > p.draw_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+    }
+    if (blockIdx.x >= nblocks) return;
+    const uint32_t base = blockIdx.x == 0 ? 0u : sum_nz;
+    const uint32_t r0 = blockIdx.x * kVrBlock + threadIdx.x * 4u;
+    const uint4 m = r0 < nrec ? *reinterpret_cast<const uint4 *>(p.tile_masks + r0) : make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t w[4] = {m.x, m.y, m.z, m.w};
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) mine += (r0 + k < nrec && w[k] != 0u) ? 1u : 0u;
+    uint32_t total;
+    uint32_t slot = base + block_exclusive_scan<4>(mine, smem, &total);
+    const uint4 *recs = reinterpret_cast<const uint4 *>(p.dispatch_buffer + ORBIT_DISPATCH_HEADER);
+    uint32_t *out = reinterpret_cast<uint32_t *>(p.draw_buffer + ORBIT_VISIBLE_HEADER);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        if (r0 + k < nrec && w[k] != 0u) {
+            if (slot < p.draw_capacity) {
+                const uint4 rec = recs[r0 + k];
+                out[3 * (size_t)slot + 0] = rec.x; // entity_index
+                out[3 * (size_t)slot + 1] = rec.y; // meshlet_offset
+                out[3 * (size_t)slot + 2] = w[k];
+            }
+            slot++;
+        }
+    }
+}
+
+// Commands from a (gathered) record list, in list order = the canonical order: orbit_expand_visible_records.  A count
+// launch sums the survivors of every block of 1024 records; here a block adds up the blocks before it, a wave takes 64
+// records at a time, lays their survivors out in LDS as (record lane, bit) codes at the records' prefix offsets and
+// then writes them 64 commands at a time exactly like visible_expand_kernel.
+__global__ __launch_bounds__(256) void visible_records_pop_kernel(const uint8_t *records, uint32_t *block_pop,
+                                                                  uint32_t max_blocks) {
+    __shared__ uint32_t smem[4];
+    const uint32_t n = *reinterpret_cast<const uint32_t *>(records);
+    if (blockIdx.x * kVrBlock >= n || blockIdx.x >= max_blocks) return;
+    const uint32_t *recs = reinterpret_cast<const uint32_t *>(records + ORBIT_VISIBLE_HEADER);
+    uint32_t pop = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t r = blockIdx.x * kVrBlock + k * 256u + threadIdx.x;
+        pop += r < n ? (uint32_t)__popc(recs[3 * (size_t)r + 2]) : 0u;
+    }
+    pop = wave_reduce_add(pop);
+    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = pop;
+    __syncthreads();
+    if (threadIdx.x == 0) block_pop[blockIdx.x] = smem[0] + smem[1] + smem[2] + smem[3];
+}
+
+template <bool STREAM>
+__global__ __launch_bounds__(256) void visible_records_expand_kernel(const uint8_t *records, const uint32_t *block_pop,
+                                                                     uint32_t max_blocks, const OrbitMeshlet *meshlets,
+                                                                     const MeshletStreamView ms, uint8_t *draw_buffer,
+                                                                     uint32_t draw_capacity, const void *zero_page,
+                                                                     int32_t *status) {
+    __shared__ uint32_t s_cmd[4][64 * 7];
+    __shared__ uint16_t s_code[4][64 * 32];
+    __shared__ uint32_t smem[8];
+    __shared__ uint32_t s_chunk[kVrBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = *reinterpret_cast<const uint32_t *>(records);
+    // the grid covers draw_capacity / 1024 blocks of records (every record holds a survivor: more records than that
+    // cannot fit) and the scratch max_blocks: a longer list is cut there, and says so
+    const uint32_t all_blocks = (n + kVrBlock - 1u) / kVrBlock;
+    const uint32_t nblocks = min(min(all_blocks, max_blocks), gridDim.x);
+    if (all_blocks > nblocks && blockIdx.x == 0 && threadIdx.x == 0) latch_status(status, ORBIT_E_CAPACITY);
+    if (blockIdx.x >= nblocks && blockIdx.x != 0) return;
+    const uint32_t upto = blockIdx.x == 0 ? nblocks : blockIdx.x;
+    uint32_t part = 0;
+    for (uint32_t i = threadIdx.x; i < upto; i += 256u) part += block_pop[i];
+    part = wave_reduce_add(part);
+    if (lane == 0) smem[wave] = part;
+    __syncthreads();
+    const uint32_t before = smem[0] + smem[1] + smem[2] + smem[3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { // `count` header of the command list
+        *reinterpret_cast<uint32_t *>(draw_buffer) = min(before, draw_capacity);
+        if (before > draw_capacity) latch_status(status, ORBIT_E_CAPACITY);
+    }
+    if (blockIdx.x >= nblocks) return;
+    const uint32_t *recs = reinterpret_cast<const uint32_t *>(records + ORBIT_VISIBLE_HEADER);
+    // the block's 16 chunks of 64 records: wave w takes chunks 4w .. 4w+3; their survivor counts first
+    uint32_t ent[4], off[4], mask[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t r = blockIdx.x * kVrBlock + (wave * 4u + k) * 64u + (uint32_t)lane;
+        const bool in = r < n;
+        ent[k] = in ? recs[3 * (size_t)r + 0] : 0u;
+        off[k] = in ? recs[3 * (size_t)r + 1] : 0u;
+        mask[k] = in ? recs[3 * (size_t)r + 2] : 0u;
+        const uint32_t cs = wave_reduce_add((uint32_t)__popc(mask[k]));
+        if (lane == 0) s_chunk[wave * 4u + k] = cs;
+    }
+    __syncthreads();
+    uint32_t chunk_base = blockIdx.x == 0 ? 0u : before;
+    for (uint32_t c = 0; c < wave * 4u; c++) chunk_base += s_chunk[c];
+    uint32_t *cmd = s_cmd[wave];
+    uint16_t *code = s_code[wave];
+    uint8_t *out = draw_buffer + ORBIT_DRAW_HEADER;
+#pragma unroll 1
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t pc = (uint32_t)__popc(mask[k]);
+        const uint32_t inc = wave_inclusive_scan(pc);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        {   // lane = record: its survivors' codes at its prefix offset, ascending bits
+            uint32_t m = mask[k], at = inc - pc;
+            while (m != 0u) {
+                code[at++] = (uint16_t)((uint32_t)lane << 5 | (uint32_t)__builtin_ctz(m));
+                m &= m - 1u;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t j0 = 0; j0 < total; j0 += 64u) {
+            const uint32_t j = j0 + (uint32_t)lane;
+            const bool valid = j < total;
+            const uint32_t cd = valid ? code[j] : 0u;
+            const uint32_t mi = (uint32_t)__shfl((int)off[k], (int)(cd >> 5), 64) + (cd & 31u);
+            const uint32_t en = (uint32_t)__shfl((int)ent[k], (int)(cd >> 5), 64);
+            ExpandChunk ch;
+            ch.item = make_uint2(mi, en);
+            ch.valid = valid;
+            const uint4 b = expand_gather<STREAM>(meshlets, ms, ch, zero_page, status);
+            uint32_t *c = cmd + lane * 7;
+            c[0] = (b.w >> 24) * 3u;                    // cmd_index_count = triangle_count * 3
+            c[1] = 1u;                                  // cmd_instance_count
+            c[2] = (b.z + ((b.w >> 16) & 0xFFu)) * 4u;  // cmd_first_index = (data_offset + vertex_count) * 4
+            c[3] = b.z;                                 // cmd_vertex_offset = int(data_offset)
+            c[4] = en;                                  // cmd_first_instance = entity_index
+            c[5] = b.y;                                 // meshlet_vertex_offset
+            c[6] = mi;                                  // meshlet_index
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // the chunk's commands as one range-checked window: words past the list or the capacity are dropped
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(chunk_base + j0));
+            const uint32_t room = first < draw_capacity ? draw_capacity - first : 0u;
+            const uint32_t bytes = min(min(total - j0, 64u), room) * 28u;
+            const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)first * 28u, 0, bytes, 0x00020000);
+#pragma unroll
+            for (uint32_t q = 0; q < 7; q++) {
+                const uint32_t w = q * 64u + (uint32_t)lane;
+                __builtin_amdgcn_raw_buffer_store_b32(cmd[w], win, w * 4u, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier(); // cmd is rewritten by the next trip
+        }
+        chunk_base += total;
+        __builtin_amdgcn_wave_barrier(); // code is rewritten by the next chunk
+    }
+}
+
+// Sharded engine, exchange without a host round trip (orbit_scatter_list): this rank's items go to every rank's
+// output buffer — peers' buffers are mapped over xGMI — at the position the all-gathered counts give them.  A plain
+// dword copy: list items start 4 (commands) or 8 (visible items) bytes into their buffers and land at 28- or 8-byte
+// multiples, so 4 B is the common alignment; a wave moves 4 x 256 contiguous bytes per trip, loads first.
+// blockIdx.y = destination rank: the copies to all peers run side by side, each on its own link.
+__global__ __launch_bounds__(256) void scatter_list_kernel(const ScatterListParams p) {
+    const uint32_t dst_rank = blockIdx.y;
+    uint32_t first = 0, total = 0;
+    for (uint32_t r = 0; r < p.world; r++) {
+        const uint32_t c = p.counts[r];
+        if (r < p.rank) first += c;
+        total += c;
+    }
+    const uint32_t mine = p.counts[p.rank];
+    const uint32_t room = first < p.out_capacity ? p.out_capacity - first : 0u;
+    const uint32_t n_items = min(mine, room);
+    const uint64_t words = (uint64_t)n_items * p.stride / 4u;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(p.local_list + p.header_bytes);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(p.out[dst_rank] + p.header_bytes + (uint64_t)first * p.stride);
+    const uint64_t step = (uint64_t)gridDim.x * 256u * 4u;
+    for (uint64_t w = ((uint64_t)blockIdx.x * 256u + (threadIdx.x & ~63u)) * 4u + (threadIdx.x & 63u); w < words;
+         w += step) {
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = w + 64u * k < words ? src[w + 64u * k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (w + 64u * k < words) dst[w + 64u * k] = v[k];
+    }
+    if (dst_rank == p.rank && blockIdx.x == 0 && threadIdx.x == 0) {
+        uint32_t *hdr = reinterpret_cast<uint32_t *>(p.out[p.rank]);
+        hdr[0] = min(total, p.out_capacity);
+        for (uint32_t k = 1; k < p.header_bytes / 4u; k++) hdr[k] = 0u;
+        if (total > p.out_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+    }
+}
+
+// Mesh-shading path: one OrbitMeshTaskRecord per dispatch record from the record's should-draw ballot
+// (forward_depth_prepass.task:225-228,255-257).  Thread = record; the drawn lanes in ascending order.
+__global__ __launch_bounds__(256) void task_records_kernel(const MeshletCullParams p) {
+    const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
+    if (blockIdx.x == 0 && threadIdx.x < kTicketPools) p.tickets[threadIdx.x * kTicketStride] = 0u; // next evaluation
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= nrec) return;
+    const uint4 rec = reinterpret_cast<const uint4 *>(p.dispatch_buffer + ORBIT_DISPATCH_HEADER)[r];
+    uint32_t m = p.tile_masks[r]; // word r = tile r/16, record r%16
+    const uint32_t count = (uint32_t)__popc(m);
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        if (m != 0u) {
+            w[k / 4] |= (uint32_t)__builtin_ctz(m) << (8 * (k % 4));
+            m &= m - 1u;
+        }
+    }
+    uint32_t *out = reinterpret_cast<uint32_t *>(p.task_records + r);
+    out[0] = count;
+    out[1] = rec.x; // entity_index
+    out[2] = rec.y; // meshlet_offset
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[3 + k] = w[k];
+}
+
+} // namespace
+
+// mesh-shading path: expand the per-record ballots, no draw list
+hipError_t launch_task_records(const MeshletCullParams &p, hipStream_t s) {
+    const uint32_t tblocks = (p.dispatch_capacity + 255u) / 256u;
+    if (tblocks) hipLaunchKernelGGL(task_records_kernel, dim3(tblocks), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// the visible list at record granularity: straight from the per-record ballots
+hipError_t launch_visible_records(const MeshletCullParams &p, hipStream_t s) {
+    const uint32_t vblocks = max((p.dispatch_capacity + kVrBlock - 1u) / kVrBlock, 1u);
+    hipLaunchKernelGGL(visible_records_count_kernel, dim3(vblocks), dim3(256), 0, s, p, vblocks);
+    hipLaunchKernelGGL(visible_records_write_kernel, dim3(vblocks), dim3(256), 0, s, p, vblocks);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_list(const ScatterListParams &p, uint32_t num_cus, hipStream_t s) {
+    // enough blocks per destination to keep a link busy, few enough that `world` copies share the device
+    const uint32_t per_dst = max(num_cus * 2u / max(p.world, 1u), 8u);
+    hipLaunchKernelGGL(scatter_list_kernel, dim3(per_dst, p.world), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, const MeshletStreamView &ms,
+                                 uint8_t *draw_buffer, uint32_t draw_capacity, uint32_t num_cus, const void *zero_page,
+                                 int32_t *status, hipStream_t s) {
+    uint32_t blocks = num_cus * 8u;
+    const uint32_t need = (draw_capacity + 255u) / 256u;
+    if (blocks > need) blocks = need;
+    if (blocks == 0) blocks = 1;
+    if (ms.cmd)
+        hipLaunchKernelGGL(visible_expand_kernel<true>, dim3(blocks), dim3(256), 0, s, visible, meshlets, ms,
+                           draw_buffer, draw_capacity, zero_page, status);
+    else
+        hipLaunchKernelGGL(visible_expand_kernel<false>, dim3(blocks), dim3(256), 0, s, visible, meshlets, ms,
+                           draw_buffer, draw_capacity, zero_page, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_visible_records_expand(const uint8_t *records, uint32_t *block_pop, uint32_t max_blocks,
+                                         const OrbitMeshlet *meshlets, const MeshletStreamView &ms, uint8_t *draw_buffer,
+                                         uint32_t draw_capacity, const void *zero_page, int32_t *status, hipStream_t s) {
+    // a command list of draw_capacity entries has at most that many records behind it
+    const uint32_t blocks = max(min((draw_capacity + kVrBlock - 1u) / kVrBlock, max_blocks), 1u);
+    hipLaunchKernelGGL(visible_records_pop_kernel, dim3(blocks), dim3(256), 0, s, records, block_pop, max_blocks);
+    if (ms.cmd)
+        hipLaunchKernelGGL(visible_records_expand_kernel<true>, dim3(blocks), dim3(256), 0, s, records, block_pop,
+                           max_blocks, meshlets, ms, draw_buffer, draw_capacity, zero_page, status);
+    else
+        hipLaunchKernelGGL(visible_records_expand_kernel<false>, dim3(blocks), dim3(256), 0, s, records, block_pop,
+                           max_blocks, meshlets, ms, draw_buffer, draw_capacity, zero_page, status);
+    return hipGetLastError();
+}
+
+} // namespace orbit

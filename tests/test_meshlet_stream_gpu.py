@@ -273,7 +273,7 @@ def test_stream_argument_errors(torch_mod, engine):
 
 # ----------------------------------------------------------------------------- the derived command chain
 # The emit launch derives a survivor's vertex_offset / data_offset from one gathered base per chain and a prefix
-# sum over 2-B counts (orbit_amd/csrc/meshlet_cull.hip, meshlet_emit_chain_body), valid where the stream's link bits
+# sum over 2-B counts (orbit_amd/csrc/meshlet_emit.hip, meshlet_emit_chain_body), valid where the stream's link bits
 # hold; everywhere else it gathers.  The scenes of tests/scenes.py mix all of that ("uploaded" layout); these tests
 # put the breaks where the launch's cases meet.
 def _relayout(scene, seed, mode):
