@@ -22,6 +22,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The host driver of this pool only supports dmabuf IPC: without this, HIP-IPC mappings of the peers' list buffers
+# (the p2p transport) and RCCL's own device-memory sharing fail with "hipIpcGetMemHandle: invalid argument".  Set
+# before torch (and with it the HIP runtime) is loaded, in EVERY rank — also when the ranks are started by
+# torch.distributed.run and not by spawn_ranks() below.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -90,8 +96,10 @@ def spawn_ranks(args):
     import socket
     import subprocess
 
-    # The listening socket stays open (SO_REUSEADDR) until the children exist, so the port cannot be handed to another
-    # process in between; torch's TCPStore binds with SO_REUSEADDR too.
+    # A free port, found by binding to port 0.  The socket is bound, never listening, and closed once the children
+    # exist: between that and rank 0's TCPStore binding the port (after it has imported torch) the port is NOT
+    # reserved — another process could take it, and the rendezvous would then fail with EADDRINUSE within the job's
+    # deadline below (a loud failure, not a hang).  SO_REUSEADDR lets the TCPStore bind right behind this socket.
     sk = socket.socket()
     sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
     sk.bind(("127.0.0.1", 0))
@@ -261,7 +269,7 @@ def main():
     # stream) and the expansion of step i-1 (expansion stream): step time = max(cull, wire, expansion), not their sum.
     xstream = estream = gathered = None
     exchanges, recv_bufs, x_events, e_events = [], [], [], []
-    transport = None
+    transport = transport_fallback = None
     if do_gather:
         xstream = torch.cuda.Stream(device=dev)
         estream = torch.cuda.Stream(device=dev)
@@ -283,6 +291,7 @@ def main():
                 if backend != "nccl":
                     raise SystemExit("bench.py: p2p exchange unavailable and the backend cannot move device lists")
                 transport, exchanges = "rccl", []
+                transport_fallback = "p2p -> rccl: HIP IPC mapping of a peer's list buffer failed on at least one rank"
         if transport == "p2p":
             recv_bufs = [x.out for x in exchanges]
         else:
@@ -685,6 +694,7 @@ def main():
                 "expand": (args.expand if compact_exchange else None),
                 "list_bytes_per_rank_max": (int(max(c[0].item() for c in counts)) * item if do_gather else None),
                 "exchange": (args.exchange if do_gather else None), "transport": transport,
+                "transport_requested": (args.transport if do_gather else None), "transport_fallback": transport_fallback,
                 "meshlet_source": (f"derived meshlet streams ({per_meshlet:g} B per meshlet evaluated"
                                    f"{' (alpha classes instead of material indices)' if not args.no_alpha_classes else ''}, "
                                    f"commands derived from the 2-B count chain; built once from the meshlet buffer "

@@ -560,6 +560,13 @@ int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t cou
 /*            needs the look-up; a stream that holds one keeps evaluating    */
 /*            through the indices.  Call it wherever the renderer writes     */
 /*            materials (add_material, assets/mod.rs:520); NULL forgets.     */
+/*            An upload-time call: unless `stream` is being captured into a  */
+/*            graph it returns once the derivation has run (it waits for its */
+/*            own launch on `stream`), so that which evaluation kernel the   */
+/*            next cull takes never depends on timing.  The pointer is       */
+/*            dereferenced on the device by every later update: call         */
+/*            set_materials(NULL) (or with the new buffer) BEFORE the         */
+/*            material buffer is freed or re-created.                        */
 /*   validate compares the stream with `meshlet_buffer` (and the classes     */
 /*            with `material_buffer`, may be NULL) over the readable range   */
 /*            and latches ORBIT_E_STALE in the context's status on any       */
@@ -587,8 +594,9 @@ int32_t orbit_ctx_bind_meshlet_stream(OrbitCtx *ctx, OrbitMeshletStream *ms);
  * silently takes the plain path). */
 uint64_t orbit_ctx_meshlet_stream_culls(const OrbitCtx *ctx);
 /* ... of which evaluated from the alpha classes (no material index read): culls whose material buffer the classes
- * mirror, of a stream known to hold no meshlet of class 3 — "known" once the launch that derived the classes has
- * finished (the library polls, never waits: culls enqueued before that read the material indices). */
+ * mirror, of a stream known to hold no meshlet of class 3 — known when set_materials returns (it waits for its
+ * derivation unless it is being captured); after an update that derives classes, once that launch has finished
+ * (polled, never waited for: culls enqueued before that read the material indices). */
 uint64_t orbit_ctx_meshlet_class_culls(const OrbitCtx *ctx);
 
 /* ------------------------------------------------------------------------ */

@@ -36,7 +36,8 @@ struct OrbitMeshletStream {
     std::mutex mu;
     const void *source = nullptr;          // Meshlet buffer of the updates so far (nullptr: never updated)
     uint64_t valid_lo = 0, valid_hi = 0;   // hull of the ranges derived from `source`: what a cull may read
-    const void *materials = nullptr;       // orbit_meshlet_stream_set_materials: what the alpha classes mirror
+    const void *materials = nullptr;       // orbit_meshlet_stream_set_materials: what the alpha classes mirror; read on
+                                           // the DEVICE by every later update (the caller forgets it before freeing it)
     uint32_t material_count = 0;
     // "Some meshlet has class 3" (a material beyond the table, an alpha_mode > 2): written on the device by the launches
     // that derive classes, copied to pinned host memory behind them.  A cull reads the classes only once that copy has
@@ -285,16 +286,16 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t o_cc = carve((2 * cchunks + 64) * 4);
     const size_t o_avl = carve((size_t)caps.max_lights * 16 + 1024);
     const size_t o_alf = carve(((size_t)caps.max_lights / 32 + 64) * 4);
-    const size_t o_acn = carve(((size_t)caps.max_clusters + 256) * 4);
+    const size_t o_acn = carve(((size_t)caps.max_clusters + kAssignPad) * 4);
     // assign: block_sums holds chunk sums | chunk bases of the two-level scan; block_base one word per cluster
     const size_t o_abs = carve((2 * ((size_t)caps.max_clusters / kScanChunk + 2) + 64) * 4);
-    const size_t o_abb = carve(((size_t)caps.max_clusters + 256) * 4), o_at = carve(256);
+    const size_t o_abb = carve(((size_t)caps.max_clusters + kAssignPad) * 4), o_at = carve(256);
     // light assignment: cached cluster AABBs, and per group of 256 active clusters the coarse candidate lists
     const size_t agroups = (size_t)caps.max_clusters / 256 + 1;
     const size_t aseg = (((size_t)caps.max_lights + 15) / 16 + 63) / 64 * 64;
-    const size_t o_aab = carve(((size_t)caps.max_clusters + 256) * 6 * 4);
+    const size_t o_aab = carve(((size_t)caps.max_clusters + kAssignPad) * 6 * 4);
     const size_t o_aco = carve(agroups * 16 * aseg * 4), o_acc = carve(agroups * 16 * 4), o_agb = carve(agroups * 32);
-    const size_t o_ahc = carve(((size_t)caps.max_clusters + 256) * kHitCache * 4);
+    const size_t o_ahc = carve(((size_t)caps.max_clusters + kAssignPad) * kHitCache * 4);
     ctx->arena_bytes = off;
     e = hipMalloc((void **)&ctx->arena, ctx->arena_bytes);
     if (e != hipSuccess) {
@@ -796,6 +797,13 @@ int32_t orbit_meshlet_stream_set_materials(OrbitCtx *ctx, OrbitMeshletStream *ms
                                           (const OrbitMaterialData *)material_buffer, material_buffer ? material_count : 0u,
                                           ms->d_other, (hipStream_t)stream);
     if (e == hipSuccess) e = read_back_class_flag(ms, (hipStream_t)stream);
+    // Resolved before the call returns (an upload-time call; nothing to wait for while `stream` is only being
+    // captured): the first cull after set_materials takes the class kernel or the index kernel because of what the
+    // stream holds, never because of when the flag's copy happened to land.
+    if (e == hipSuccess && ms->other_recorded) {
+        e = hipEventSynchronize(ms->other_event);
+        if (e == hipSuccess) ms->other_pending = false;
+    }
     if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_stream_classes");
     ms->materials = material_buffer;
     ms->material_count = material_buffer ? material_count : 0u;

@@ -146,6 +146,9 @@ struct ClusterCompactParams {
 };
 
 constexpr uint32_t kHitCache = 16;
+// clusters of padding behind the per-cluster scratch arrays of the assignment (counts, bases, AABBs, hit cache): its
+// kernels read whole blocks / rounds of clusters speculatively (light_cluster.hip asserts its reach against this)
+constexpr uint32_t kAssignPad = 256;
 struct ClusterAssignParams {
     OrbitClusterCullInfo info;
     const uint8_t *unique;

@@ -269,7 +269,8 @@ __device__ __forceinline__ bool sphere_hits(const Aabb3 &a, const float4 l) {
 #endif
 
 constexpr uint32_t kLightTile = 1024;  // coarse candidates a block filters per step; survivors live in LDS (20 KB)
-// 4 waves x 4 clusters: 8 x 2 and 16 x 1 (same 16 clusters per block) measured 14 % and 40 % slower (r01_notes.md)
+// 4 waves x 2 clusters = 8 clusters per block (round 3; rounds 1-2 ran 4 x 4: the block's size is the size of the
+// launch's tail, DESIGN.md 4.4 — 16 -> 8 clusters per block took the count launch from 29.8 to 23.4 us)
 constexpr int kClustersPerWave = 2;    // cluster AABBs held in scalar registers per wave
 constexpr int kAssignWaves = 4;
 constexpr int kClustersPerBlock = kClustersPerWave * kAssignWaves;
@@ -455,14 +456,14 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
     constexpr uint32_t kSeg = kLightTile / kAssignWaves; // LDS candidates per wave and step
     constexpr uint32_t kLoads = kSeg / 64u;              // coarse candidates per lane and step
     static_assert(kLoads * kAssignWaves == kCoarseSegs, "wave w owns coarse segments kLoads * w ..");
-    // grid-stride over the blocks of 32 active clusters that exist (see cluster_aabb_kernel)
+    // grid-stride over the blocks of kClustersPerBlock (8) active clusters that exist (see cluster_aabb_kernel)
     for (uint32_t block_first = blockIdx.x * kClustersPerBlock;; block_first += gridDim.x * kClustersPerBlock) {
     if (!first_item && block_first >= n) break;
     const uint32_t u0 = block_first + wave * kClustersPerWave;
     const uint32_t group = block_first / kGroupClusters;
     const uint32_t *cbase = p.coarse + (size_t)group * kCoarseSegs * p.coarse_seg;
     // ---- round trip 1: everything addressed by the block's position alone
-    const uint32_t ul = min(u0 + ((uint32_t)lane & (kClustersPerWave - 1)), p.max_clusters - 1u); // lanes 0..7 count
+    const uint32_t ul = min(u0 + ((uint32_t)lane & (kClustersPerWave - 1)), p.max_clusters - 1u); // lanes 0 .. kClustersPerWave - 1 count
     uint32_t my_ci = unique_idx[ul];
     Aabb3 box;
 #pragma unroll
@@ -470,6 +471,11 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
     const uint32_t cc = p.coarse_counts[(size_t)group * kCoarseSegs + ((uint32_t)lane & (kCoarseSegs - 1))];
     uint32_t my_limit = 0, my_offset = 0;
     constexpr uint32_t kHcRounds = (kClustersPerWave * kHitCache + 63u) / 64u, kHcPerRound = 64u / kHitCache;
+    // The speculative hit-cache read below takes whole rounds of kHcPerRound clusters from u0 on, whether or not the
+    // wave owns them (or they exist): it reaches cluster block_first + kClustersPerBlock - kClustersPerWave +
+    // kHcRounds * kHcPerRound - 1 at most, and block_first < max_clusters + kClustersPerBlock (launch_cluster_assign's
+    // grid).  The scratch arrays are padded by kAssignPad clusters for exactly that (orbit_ctx_create).
+    static_assert(2u * kClustersPerBlock + kHcRounds * kHcPerRound <= kAssignPad, "hit-cache over-read exceeds the scratch padding");
     uint32_t hc[kHcRounds] = {};
     if (WRITE) {
         my_limit = p.counts[ul];
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
         uint32_t part = 0;
         for (uint32_t k = (uint32_t)lane; k < block_first / kScanChunk; k += 64u) part += p.block_sums[k];
         my_offset = p.block_base[ul] + wave_reduce_add(part);
-        // (cluster, slot) per lane, two rounds: the indices the counting launch kept
+        // (cluster, slot) per lane, kHcRounds round(s) of kHcPerRound clusters: the indices the counting launch kept
 #pragma unroll
         for (uint32_t j = 0; j < kHcRounds; j++)
             hc[j] = p.hit_cache[(size_t)(u0 + j * kHcPerRound + (uint32_t)lane / kHitCache) * kHitCache + (uint32_t)lane % kHitCache];
@@ -532,7 +538,7 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
 #pragma unroll
         for (int i = 0; i < 3; i++) box.mn[i] = owns ? box.mn[i] : inf, box.mx[i] = owns ? box.mx[i] : -inf;
     }
-    // the wave's boxes into scalar registers; their union over the wave (lanes 0..7 hold them), then over the block.
+    // the wave's boxes into scalar registers; their union over the wave (lanes 0 .. kClustersPerWave - 1 hold them), then over the block.
     // With a NaN anywhere the filter is bypassed (flag), so what the selects make of a NaN operand does not matter.
     float mn[kClustersPerWave][3], mx[kClustersPerWave][3];
     uint32_t offset[kClustersPerWave], limit[kClustersPerWave], count[kClustersPerWave];

@@ -249,6 +249,10 @@ void Context::sync_meshlet_stream(const GraphBufferHandle &meshlet_buffer, uint6
         check(orbit_meshlet_stream_create(ctx_, 0, capacity, &meshlet_stream_));
         meshlet_stream_capacity_ = capacity;
     }
+    // a re-created stream remembers no materials: hand it the ones the old one mirrored BEFORE its meshlets are derived,
+    // so that the update derives their alpha classes too (otherwise every later cull would read material indices)
+    if (fresh && stream_materials_ != nullptr)
+        check(orbit_meshlet_stream_set_materials(ctx_, meshlet_stream_, stream_materials_, stream_material_count_, stream_));
     if ((fresh || moved) && meshlet_stream_populated_ > 0)
         check(orbit_meshlet_stream_update(ctx_, meshlet_stream_, meshlet_buffer.ptr, 0, meshlet_stream_populated_, stream_));
     check(orbit_meshlet_stream_update(ctx_, meshlet_stream_, meshlet_buffer.ptr, first, count, stream_));
@@ -259,6 +263,8 @@ void Context::sync_meshlet_stream(const GraphBufferHandle &meshlet_buffer, uint6
 void Context::sync_meshlet_stream_materials(const GraphBufferHandle &materials_buffer, uint32_t material_count) {
     if (!meshlet_stream_) throw Panic("sync_meshlet_stream_materials: no meshlet stream yet");
     check(orbit_meshlet_stream_set_materials(ctx_, meshlet_stream_, materials_buffer.ptr, material_count, stream_));
+    stream_materials_ = materials_buffer.ptr;
+    stream_material_count_ = materials_buffer.ptr ? material_count : 0u;
 }
 GraphBufferHandle Context::create_transient(const std::string &name, size_t size) {
     auto it = transients_.find(name);

@@ -119,6 +119,10 @@ class Context {
     uint64_t meshlet_stream_capacity_ = 0;
     uint64_t meshlet_stream_populated_ = 0;       // high-water mark of the meshlets uploaded so far
     const void *meshlet_stream_source_ = nullptr; // the buffer they were derived from
+    // the material buffer the stream's alpha classes mirror (sync_meshlet_stream_materials): re-issued when the stream
+    // is re-created, forgotten (nullptr) before that buffer is freed or re-created
+    const void *stream_materials_ = nullptr;
+    uint32_t stream_material_count_ = 0;
     void *stream_ = nullptr;
     std::map<std::string, GraphBufferHandle> transients_;
 };
