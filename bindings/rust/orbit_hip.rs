@@ -16,7 +16,7 @@ pub struct OrbitMeshletStream { _private: [u8; 0] }
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct OrbitCaps {
     pub max_entities: u32, pub max_dispatches: u32, pub max_draws: u32, pub max_lights: u32,
-    pub max_clusters: u32, pub dispatch_size: u32, pub max_views: u32, pub validate_streams: u32,
+    pub max_clusters: u32, pub dispatch_size: u32, pub max_views: u32, pub validate_streams: u32, pub cull_path: u32,
 }
 
 /// push-constant order of shaders/entity_cull.comp:17-23 (== draw_gen.rs:372-376)
@@ -145,6 +145,7 @@ extern "C" {
                                          material_buffer: *const c_void, stream: *mut c_void) -> i32;
     pub fn orbit_meshlet_stream_destroy(ms: *mut OrbitMeshletStream) -> i32;
     pub fn orbit_ctx_bind_meshlet_stream(ctx: *mut OrbitCtx, ms: *mut OrbitMeshletStream) -> i32;
+    pub fn orbit_ctx_fused_culls(ctx: *const OrbitCtx) -> u64;
     pub fn orbit_ctx_meshlet_stream_culls(ctx: *const OrbitCtx) -> u64;
     pub fn orbit_ctx_meshlet_class_culls(ctx: *const OrbitCtx) -> u64;
     // exchange without a host round trip: IPC-mapped peer buffers + a device-side rank-ordered scatter

@@ -34,8 +34,9 @@ extern "C" {
 #define ORBIT_STATIC_ASSERT(c, m) _Static_assert(c, m)
 #endif
 
-#define ORBIT_ABI_VERSION 3u /* 2: *_CullBufs gained depth_pyramid_levels (per-mip images); 3: meshlet streams carry the
-                                command chain and alpha classes, OrbitCaps.validate_streams, ORBIT_E_STALE */
+#define ORBIT_ABI_VERSION 4u /* 2: *_CullBufs gained depth_pyramid_levels (per-mip images); 3: meshlet streams carry the
+                                command chain and alpha classes, OrbitCaps.validate_streams, ORBIT_E_STALE;
+                                4: OrbitCaps.cull_path, orbit_ctx_fused_culls (the one-launch cull of orbit_cull_views) */
 
 /* u32::MAX = "resource absent" (src/passes/draw_gen.rs:142-144,
  * shaders/meshlet_cull.comp:127). */
@@ -352,7 +353,12 @@ typedef struct OrbitCaps {
     uint32_t validate_streams; /* debug: != 0 makes every cull / expansion served from a bound meshlet stream first
                                   compare the stream with the meshlet buffer (one extra pass over both, ORBIT_E_STALE
                                   latched on a difference): finds a missing orbit_meshlet_stream_update */
+    uint32_t cull_path;        /* orbit_cull_views: 0 = the library chooses per call (views of at most 16 384
+                                  entity-draws each go through the one-launch cull, larger ones through the launch
+                                  chain), 1 = always the launch chain, 2 = always the one-launch cull.  Same outputs
+                                  either way; tests and A/B timings set it. */
 } OrbitCaps;
+ORBIT_STATIC_ASSERT(sizeof(OrbitCaps) == 36, "OrbitCaps layout");
 
 typedef struct OrbitCtx OrbitCtx;
 
@@ -500,6 +506,16 @@ typedef struct OrbitCullView {
 #define ORBIT_MAX_CULL_VIEWS 8
 /* The views must not share output buffers; visibility buffers written by two views (occlusion_pass 2) must differ. */
 int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t count, void *stream);
+/* One launch instead of the chain.  A call whose views all have both stages and between 1 and 16 384 entity-draws
+ * each — every scene the reference itself can hold: MAX_INSTANCE_COUNT = 100 000 instances, MAX_MESHLET_COUNT = 256 k
+ * (src/scene.rs:303, src/assets/mod.rs:202), a cull being one clear and two dispatches there (draw_gen.rs:283-322) —
+ * runs as ONE persistent launch per (occlusion pass, projection type) among its views: entity test, record append,
+ * meshlet test and ordered command append hand over inside the launch (orbit_amd/csrc/cull_fused.hip), which is what
+ * such a cull costs: its dependent memory round trips once, not once per launch.  count = 1 is the single cull
+ * (create_draw_commands, draw_gen.rs:239-322).  The outputs are those of the chain bit for bit; the path reads the 32-B
+ * Meshlet buffer (a bound stream is not consulted) and can be captured into a graph like every other call.
+ * OrbitCaps.cull_path overrides the choice.  Returns how many views this context has culled that way. */
+uint64_t orbit_ctx_fused_culls(const OrbitCtx *ctx);
 
 /* ------------------------------------------------------------------------ */
 /* Derived meshlet streams — an MI355X-side copy of the static meshlet       */

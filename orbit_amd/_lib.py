@@ -30,7 +30,7 @@ class OrbitError(RuntimeError):
 class Caps(C.Structure):
     _fields_ = [("max_entities", C.c_uint32), ("max_dispatches", C.c_uint32), ("max_draws", C.c_uint32),
                 ("max_lights", C.c_uint32), ("max_clusters", C.c_uint32), ("dispatch_size", C.c_uint32),
-                ("max_views", C.c_uint32), ("validate_streams", C.c_uint32)]
+                ("max_views", C.c_uint32), ("validate_streams", C.c_uint32), ("cull_path", C.c_uint32)]
 
 
 class EntityCullBufs(C.Structure):
@@ -74,6 +74,7 @@ class DepthPyramidDesc(C.Structure):
 # every symbol include/orbit_abi.h declares: (restype, argtypes)
 SYMBOLS = {
     "orbit_abi_version": (C.c_uint32, []),
+    "orbit_ctx_fused_culls": (C.c_uint64, [C.c_void_p]),
     "orbit_default_caps": (None, [C.POINTER(Caps)]),
     "orbit_ctx_create": (C.c_int32, [C.c_int32, C.POINTER(Caps), C.POINTER(C.c_void_p)]),
     "orbit_ctx_destroy": (C.c_int32, [C.c_void_p]),

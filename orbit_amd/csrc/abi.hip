@@ -71,6 +71,8 @@ struct OrbitCtx {
     float *a_aabb = nullptr, *a_group_box = nullptr;
     uint32_t a_coarse_seg = 0;
     uint32_t *m_tickets = nullptr;
+    uint32_t *f_sync = nullptr, *f_ent_flags = nullptr, *f_tile_flags = nullptr; // one-launch cull (cull_fused.hip)
+    uint64_t fused_culls = 0;                                                    // views culled by it so far
     uint32_t *g_counts = nullptr; // gather_visible: per-rank command counts
     int32_t *status = nullptr;
     uint32_t debug_flags = 0;
@@ -275,9 +277,11 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t o_zero = carve(256);
     const size_t o_gc = carve(256);
     const size_t o_tk = carve(kTicketPools * kTicketStride * 4);
+    const size_t o_fsy = carve(kFusedSyncWords * 4), o_fef = carve((ent / 256 + 2) * 4);
     const size_t o_eproto = carve(ent * sizeof(OrbitMeshletDispatch));
     const size_t o_ebs = carve(eblocks * 4), o_et = carve(256);
     const size_t o_mtc = carve(mtiles * 4), o_mtb = carve(mtiles * 4), o_mt = carve(256);
+    const size_t o_ftf = carve(mtiles * 4);
     const size_t o_xbp = carve((size_t)kExpandBlocks * 4);
     const size_t o_mtm = carve(mtiles * 64);
     const size_t o_mtp = carve(mtiles * 128 * sizeof(Payload));
@@ -337,12 +341,19 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->a_coarse_seg = (uint32_t)aseg;
     ctx->g_counts = (uint32_t *)(a + o_gc);
     ctx->m_tickets = (uint32_t *)(a + o_tk);
+    ctx->f_sync = (uint32_t *)(a + o_fsy);
+    ctx->f_ent_flags = (uint32_t *)(a + o_fef);
+    ctx->f_tile_flags = (uint32_t *)(a + o_ftf);
 #ifdef ORBIT_TRIAGE // perf-triage builds (tools/mkvariant_any.sh); the product library reads no environment variable
     const char *dbg = getenv("ORBIT_SP_DEBUG");
     ctx->debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u;
 #endif
     snprintf(ctx->err, sizeof(ctx->err), "no error");
     // scan scratch of views 1.. of orbit_cull_views, when the caller announced them
+    if (caps.cull_path > 2u) {
+        (void)orbit_ctx_destroy(ctx);
+        return fail(nullptr, ORBIT_E_INVALID, "caps.cull_path %u (0 auto, 1 launch chain, 2 one-launch cull)", caps.cull_path);
+    }
     if (caps.max_views > ORBIT_MAX_CULL_VIEWS) {
         (void)orbit_ctx_destroy(ctx);
         return fail(nullptr, ORBIT_E_CAPACITY, "caps.max_views %u > %u", caps.max_views, (unsigned)ORBIT_MAX_CULL_VIEWS);
@@ -680,6 +691,40 @@ int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t cou
         if (rc != ORBIT_OK) return rc;
         max_draws = v.entity_draw_count > max_draws ? v.entity_draw_count : max_draws;
     }
+    // Views of the reference's own size (src/scene.rs:303, assets/mod.rs:202) are bound by launch latency, not by
+    // bytes: all of them together as ONE launch per (pass, projection) (cull_fused.hip) — same outputs.  It evaluates
+    // the 32-B Meshlet buffer whatever stream is bound (the survivors' command words are then in the row registers).
+    bool fused = ctx->caps.cull_path != 1u && n_mesh == count;
+    for (uint32_t i = 0; i < count && fused; i++)
+        fused = views[i].entity_draw_count != 0u &&
+                (ctx->caps.cull_path == 2u || views[i].entity_draw_count <= kFusedMaxEntityDraws);
+    if (fused) {
+        FusedCullViews fv{};
+        uint32_t draws[ORBIT_MAX_CULL_VIEWS] = {};
+        for (uint32_t i = 0; i < count; i++) {
+            OrbitCtx *scratch = i == 0 ? ctx : ctx->view_ctx[i - 1];
+            FusedCullParams &f = fv.v[i];
+            f.m = mv.v[i];
+            f.m.ms = MeshletStreamView{};
+            f.entity_draw_buffer = ev.v[i].entity_draw_buffer;
+            f.mesh_infos = ev.v[i].mesh_infos;
+            f.visibility = ev.v[i].visibility;
+            f.e_pyr = ev.v[i].pyr;
+            f.draw_first = ev.v[i].draw_first;
+            f.draw_limit = ev.v[i].draw_limit;
+            f.e_dispatch_capacity = ev.v[i].dispatch_capacity;
+            f.ne_chunks = (views[i].entity_draw_count + 255u) / 256u;
+            f.e_total = ev.v[i].total;
+            f.sync = scratch->f_sync;
+            f.ent_flags = scratch->f_ent_flags;
+            f.tile_flags = scratch->f_tile_flags;
+            draws[i] = views[i].entity_draw_count;
+        }
+        e = launch_cull_fused_views(fv, draws, count, ctx->num_cus, s);
+        if (e != hipSuccess) return hip_fail(ctx, e, "launch cull_fused");
+        ctx->fused_culls += count;
+        return ORBIT_OK;
+    }
     e = launch_entity_cull_views(ev, count, max_draws, s);
     if (e == hipSuccess) e = launch_meshlet_cull_views(mv, n_mesh, ctx->num_cus, s);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch cull_views");
@@ -863,6 +908,7 @@ int32_t orbit_ctx_bind_meshlet_stream(OrbitCtx *ctx, OrbitMeshletStream *ms) {
     return ORBIT_OK;
 }
 
+uint64_t orbit_ctx_fused_culls(const OrbitCtx *ctx) { return ctx ? ctx->fused_culls : 0; }
 uint64_t orbit_ctx_meshlet_stream_culls(const OrbitCtx *ctx) { return ctx ? ctx->stream_culls : 0; }
 uint64_t orbit_ctx_meshlet_class_culls(const OrbitCtx *ctx) { return ctx ? ctx->class_culls : 0; }
 

@@ -9,14 +9,13 @@
 //   - visibility words are written from wave64 ballots split into two 32-bit
 //     words (the reference's `gl_SubgroupSize == 32` addressing made explicit);
 //   - the {0,1,1} header clear (draw_gen.rs:356-363) is fused into the emit.
-#include "kernels.h"
-#include "scan.h"
+#include "entity_common.h"
 
 namespace orbit {
 
 namespace {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = kEntityBlock;
 
 // One thread per entity-draw: evaluates the shader body up to the record
 // emission, stores a proto-record (meshlet_count == 0 when nothing is drawn).
@@ -25,82 +24,14 @@ constexpr int kBlock = 256;
 
 __device__ __forceinline__ void entity_cull_eval_body(const EntityCullParams &p) {
     __shared__ uint32_t smem[kBlock / 64 + 1];
-    const OrbitGpuCullInfo &ci = p.ci;
     const uint32_t local = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t g = p.draw_first + local;
     const uint32_t count = *reinterpret_cast<const uint32_t *>(p.entity_draw_buffer);
     const uint32_t end = min(count, p.draw_limit);
     const bool active = g < end; // entity_cull.comp:106
-    const bool meshlet_occ = ci.meshlet_visibility_buffer != ORBIT_NONE;
-
-    bool visible = false;
-    OrbitMeshletDispatch pr = {0u, 0u, 0u, 0u};
-    if (active) {
-        const OrbitEntityDraw *draws =
-            reinterpret_cast<const OrbitEntityDraw *>(p.entity_draw_buffer + ORBIT_ENTITY_DRAW_HEADER);
-        const OrbitEntityDraw ed = draws[g];
-        const OrbitMeshInfo *mi = p.mesh_infos + ed.mesh_index;
-        const float4 bs = *reinterpret_cast<const float4 *>(mi->bounding_sphere);
-        const float4 *mm = reinterpret_cast<const float4 *>(p.entities[ed.entity_index].model_matrix);
-        const float4 c0 = mm[0], c1 = mm[1], c2 = mm[2], c3 = mm[3];
-
-        visible = true;
-        bool visible_in_buffer = true;
-        if (ci.occlusion_pass == 1 || ci.occlusion_pass == 2)
-            visible_in_buffer = (p.visibility[g / 32] & (1u << (g % 32))) != 0; // :117-120
-        if (ci.occlusion_pass == 1) visible = visible_in_buffer;                // :123
-
-        // view * model, transform_sphere (:37-43,:131-134)
-        float m0[4], m1[4], m2[4], m3[4];
-        mat4_mul_col(ci.view_matrix, c0.x, c0.y, c0.z, c0.w, m0);
-        mat4_mul_col(ci.view_matrix, c1.x, c1.y, c1.z, c1.w, m1);
-        mat4_mul_col(ci.view_matrix, c2.x, c2.y, c2.z, c2.w, m2);
-        mat4_mul_col(ci.view_matrix, c3.x, c3.y, c3.z, c3.w, m3);
-        float pv[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) pv[r] = ((m0[r] * bs.x + m1[r] * bs.y) + m2[r] * bs.z) + m3[r] * 1.0f;
-        Sphere s;
-        s.x = pv[0] / pv[3];
-        s.y = pv[1] / pv[3];
-        s.z = pv[2] / pv[3];
-        const float dx = dot3(m0[0], m0[1], m0[2], m0[0], m0[1], m0[2]);
-        const float dy = dot3(m1[0], m1[1], m1[2], m1[0], m1[1], m1[2]);
-        const float dz = dot3(m2[0], m2[1], m2[2], m2[0], m2[1], m2[2]);
-        const float scale = sqrtf(gmax(dx, gmax(dy, dz)));
-        s.r = bs.w * scale;
-
-        if (visible) visible = plane_test(ci, s);                                        // :137-144
-        if (ci.occlusion_pass == 2 && visible) visible = occlusion_test(ci, s, bs.w, scale, p.pyr);  // :147-191
-
-        bool should_draw = visible;
-        if (ci.occlusion_pass == 2) should_draw = visible && (!visible_in_buffer || meshlet_occ); // :198-200
-
-        if (should_draw) { // :203-209
-            const float ex = ci.lod_target_pos_view_space[0] - s.x;
-            const float ey = ci.lod_target_pos_view_space[1] - s.y;
-            const float ez = ci.lod_target_pos_view_space[2] - s.z;
-            const float lod_distance = sqrtf(dot3(ex, ey, ez, ex, ey, ez)) - s.r;
-            const float lod_f = log2c(gmax(lod_distance, 0.0f) / ci.lod_base) / log2c(ci.lod_step);
-            uint32_t lod = f2u_sat(gmax(lod_f + 1.0f, 0.0f));
-            lod = min(max(lod, ci.min_mesh_lod), ci.max_mesh_lod);
-            lod = min(lod, mi->lod_count - 1u);
-            lod = min(lod, (uint32_t)ORBIT_MAX_MESH_LODS - 1u);
-            const OrbitMeshLod ml = mi->mesh_lods[lod];
-            pr.entity_index = ed.entity_index;
-            pr.meshlet_offset = ml.meshlet_offset;
-            pr.meshlet_count = ml.meshlet_count;
-            pr.visibility_offset = ed.visibility_offset;
-        }
-    }
-
-    // entity visibility bitset, pass 2 only (:226-243): word = g/32, bit = g%32.
-    if (ci.occlusion_pass == 2) {
-        const uint64_t b = __ballot(active && visible);
-        const uint32_t lane = threadIdx.x & 63;
-        const uint32_t wave_g = g - lane;
-        if (lane == 0 && wave_g < end) p.visibility[wave_g / 32] = (uint32_t)b;
-        if (lane == 32 && wave_g + 32 < end) p.visibility[wave_g / 32 + 1] = (uint32_t)(b >> 32);
-    }
+    bool visible;
+    const OrbitMeshletDispatch pr = entity_eval_one(p, g, active, visible);
+    entity_write_visibility(p, g, end, active && visible);
 
     p.proto[local] = pr;
     const uint32_t n = (pr.meshlet_count + ORBIT_MESHLET_DISPATCH_SIZE - 1u) / ORBIT_MESHLET_DISPATCH_SIZE; // :210
@@ -141,8 +72,7 @@ __device__ __forceinline__ void entity_cull_emit_body(const EntityCullParams &p)
     __shared__ OrbitMeshletDispatch s_proto[kBlock];
     const uint32_t local = blockIdx.x * kBlock + threadIdx.x;
     const OrbitMeshletDispatch pr = p.proto[local];
-    const uint32_t S = ORBIT_MESHLET_DISPATCH_SIZE;
-    const uint32_t n = (pr.meshlet_count + S - 1u) / S;
+    const uint32_t n = (pr.meshlet_count + ORBIT_MESHLET_DISPATCH_SIZE - 1u) / ORBIT_MESHLET_DISPATCH_SIZE;
     const uint32_t preceding = blockIdx.x == 0 ? gridDim.x : blockIdx.x; // block 0: grand total
     uint32_t part = 0;
     for (uint32_t i = threadIdx.x; i < preceding; i += kBlock) part += p.block_sums[i];
@@ -154,19 +84,8 @@ __device__ __forceinline__ void entity_cull_emit_body(const EntityCullParams &p)
     __syncthreads();
     OrbitMeshletDispatch *out = reinterpret_cast<OrbitMeshletDispatch *>(p.dispatch_buffer + ORBIT_DISPATCH_HEADER);
     for (uint32_t r = threadIdx.x; r < block_total; r += kBlock) {
-        // owner = last entity whose offset is <= r (entities without records share the next one's offset)
-        uint32_t lo = 0, hi = kBlock;
-        while (hi - lo > 1u) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (s_off[mid] <= r) lo = mid; else hi = mid;
-        }
-        const OrbitMeshletDispatch o = s_proto[lo];
-        const uint32_t j = r - s_off[lo];
-        OrbitMeshletDispatch rec;
-        rec.entity_index = o.entity_index;
-        rec.meshlet_offset = o.meshlet_offset + S * j;
-        rec.meshlet_count = min(o.meshlet_count - S * j, S);
-        rec.visibility_offset = o.visibility_offset + j; // :222: every record before j is full (count / S == 1)
+        const uint32_t owner = entity_record_owner(s_off, r);
+        const OrbitMeshletDispatch rec = entity_record(s_proto[owner], r - s_off[owner]);
         if (block_base + r < p.dispatch_capacity) out[block_base + r] = rec;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {

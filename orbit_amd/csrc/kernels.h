@@ -175,6 +175,33 @@ struct ClusterAssignParams {
     unsigned long long *debug_tests; // -DORBIT_TRIAGE builds: executed sphere-box tests per level (tools/cluster_tests.py)
 };
 
+// One-launch cull (cull_fused.hip): entity stage and meshlet stage of one view in one persistent kernel.  The meshlet
+// side is the launches' parameter block (Meshlet buffer only: m.ms empty, no task records, no visible list); the entity
+// side adds what entity_cull reads besides (ci, entities and the dispatch buffer are m's).
+constexpr uint32_t kSyEntTicket = 0, kSyEntDone = 32, kSyTotal = 64, kSyTileTicket = 96, kSyBlocksDone = 128;
+constexpr uint32_t kFusedSyncWords = 160; // the five counters above, each on a 128-B line of its own
+constexpr uint32_t kFusedMaxEntityDraws = 16384; // culls of more entity-draws take the launches (abi.hip)
+struct FusedCullParams {
+    MeshletCullParams m;
+    const uint8_t *entity_draw_buffer;
+    const OrbitMeshInfo *mesh_infos;
+    uint32_t *visibility; // entity bitset (occlusion passes)
+    PyramidView e_pyr;    // the entity stage's pyramid (pass 2)
+    uint32_t draw_first, draw_limit; // as EntityCullParams
+    uint32_t e_dispatch_capacity;    // OrbitEntityCullBufs::dispatch_capacity (what the record stores are bounded by)
+    uint32_t ne_chunks;              // ceil(entity_draw_count / 256) >= 1
+    uint32_t *e_total;
+    // context scratch, zero between launches (the last workgroup of a launch leaves it so)
+    uint32_t *sync;       // kFusedSyncWords
+    uint32_t *ent_flags;  // per entity chunk: records << 2 | state
+    uint32_t *tile_flags; // per wave tile: survivors (or their inclusive prefix) << 2 | state
+};
+struct FusedCullViews {
+    FusedCullParams v[ORBIT_MAX_CULL_VIEWS];
+};
+hipError_t launch_cull_fused_views(const FusedCullViews &all, const uint32_t *entity_draw_counts, uint32_t n,
+                                   uint32_t num_cus, hipStream_t s);
+
 hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_count, hipStream_t s);
 // orbit_cull_views: the parameter blocks of all views travel BY VALUE in the kernel-argument segment (a few KB: HIP on
 // gfx950 takes it — tools/ubench/kernarg_size.hip), so a view's block is read with scalar loads at a uniform offset

@@ -360,11 +360,13 @@ __device__ __forceinline__ void rows_load(const MeshletCullParams &p, const Wave
 // exists (:111), passes the geometry tests and its material the :207 test.  Every lane evaluates — lanes past
 // meshlet_count hold zeros, which are finite and harmless — and the verdict is masked: no divergent region around a
 // row.
-template <int PASS, int PROJ, int R0, int NR, bool CLS = false>
+template <int PASS, int PROJ, int R0, int NR, bool CLS = false, uint32_t CAP = kPayloadCap>
 __device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
                                               const AlphaLds *A, int lane, const RowRegs<NR> &t, uint32_t total,
                                               Payload *payload) {
-    static_assert(PASS == 0 || PASS == 2, "pass 1 is list-driven (meshlet_pass1_body)");
+    // (PASS == 1: the streamed form of pass 1, taken by the one-launch cull of cull_fused.hip — a lane is gated on last
+    // frame's bit first, :137; the large-scene launch is list-driven instead: meshlet_pass1_body)
+    static_assert(PASS != 1 || !CLS, "pass 1 reads the Meshlet buffer");
     const uint32_t half = lane >> 5, ml = lane & 31;
 #pragma unroll
     for (int k = 0; k < NR; k++) {
@@ -380,6 +382,9 @@ __device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTi
             const uint32_t abits = lane_alpha_bits<false>(p, L, A, rid, ml, t.b[k].w);
             allow = ballot(ml < L.r[rid].rec.z) & ballot((abits & 1u) != 0u);
         }
+        if constexpr (PASS == 1) { // visible = visible_in_buffer (:123,:137); without the buffer the bit stays true (:128)
+            if (p.ci.meshlet_visibility_buffer != ORBIT_NONE) allow &= ballot(((t.prev[k] >> ml) & 1u) != 0u);
+        }
 #ifdef ORBIT_TRIAGE_NO_EVAL // scratch builds only (tools/mkvariant_any.sh): a free predicate with the same survival ratio
         const uint64_t geo = ballot(((t.a[k].x + (t.b[k].x >> 31)) % 1000u) < 95u);
 #else
@@ -392,7 +397,7 @@ __device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTi
             // survivor payload at the tile-local rank: everything the command needs except its
             // slot, so the emit launch reads one contiguous run per tile and rebuilds nothing
             const uint32_t rank = total + lane_prefix(mask);
-            if (rank < kPayloadCap) payload[rank] = make_payload(ml, rid, t.b[k]);
+            if (rank < CAP) payload[rank] = make_payload(ml, rid, t.b[k]);
         }
         total += (uint32_t)__popcll(mask);
     }
@@ -427,7 +432,7 @@ struct CandState {
 __device__ __forceinline__ uint32_t ring_wrap(uint32_t i) { return i >= kCandRing ? i - kCandRing : i; }
 
 // Tests the first n (<= 64) candidates of the ring; lane j takes candidate j.
-template <uint32_t N>
+template <uint32_t N, uint32_t CAP = kPayloadCap>
 __device__ __forceinline__ void cand_flush(const MeshletCullParams &p, WaveTileLds &L, const CandLds<N> &C, int lane,
                                            CandState &cs, uint32_t n, Payload *payload) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -454,7 +459,7 @@ __device__ __forceinline__ void cand_flush(const MeshletCullParams &p, WaveTileL
     const uint64_t dm = __ballot(should_draw);
     if (payload && should_draw) {
         const uint32_t rank = cs.total + lane_prefix(dm);
-        if (rank < kPayloadCap)
+        if (rank < CAP)
             payload[rank] = make_payload(code & 31u, word, info);
     }
     cs.total += (uint32_t)__popcll(dm);
@@ -463,7 +468,7 @@ __device__ __forceinline__ void cand_flush(const MeshletCullParams &p, WaveTileL
 }
 
 // One row of a tile in pass 2 with meshlet occlusion: geometry tests, candidates into the ring.
-template <int PROJ, int R, uint32_t N, bool CLS = false>
+template <int PROJ, int R, uint32_t N, bool CLS = false, uint32_t CAP = kPayloadCap>
 __device__ __forceinline__ void row_eval_occ(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
                                              const AlphaLds *A, CandLds<N> &C, int lane, const RowRegs<1> &t,
                                              CandState &cs, Payload *payload) {
@@ -485,14 +490,14 @@ __device__ __forceinline__ void row_eval_occ(const MeshletCullParams &p, WaveTil
                                   t.b[0].y, t.b[0].z, t.b[0].w);
     }
     cs.count += (uint32_t)__popcll(mask);
-    if (cs.count >= kCandFlush) cand_flush(p, L, C, lane, cs, min(cs.count, 64u), payload);
+    if (cs.count >= kCandFlush) cand_flush<N, CAP>(p, L, C, lane, cs, min(cs.count, 64u), payload);
 }
 
 // End of a tile: remaining candidates, then the pass-2 visibility words (:233-254) of its 16 records.
-template <uint32_t N>
+template <uint32_t N, uint32_t CAP = kPayloadCap>
 __device__ __forceinline__ void tile_finish_occ(const MeshletCullParams &p, WaveTileLds &L, const CandLds<N> &C,
                                                 int lane, CandState &cs, Payload *payload) {
-    if (cs.count > 0) cand_flush(p, L, C, lane, cs, cs.count, payload);
+    if (cs.count > 0) cand_flush<N, CAP>(p, L, C, lane, cs, cs.count, payload);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

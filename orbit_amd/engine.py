@@ -322,6 +322,10 @@ class Engine:
         _lib.check(self._lib.orbit_ctx_bind_meshlet_stream(self._ctx, ms._h if ms is not None else None), self._ctx)
         self._meshlet_stream = ms
 
+    def fused_culls(self):
+        """Views this context has culled through the one-launch path of orbit_cull_views (include/orbit_abi.h)."""
+        return int(self._lib.orbit_ctx_fused_culls(self._ctx))
+
     def meshlet_stream_culls(self):
         """orbit_ctx_meshlet_stream_culls: meshlet culls launched from a bound stream so far."""
         return int(self._lib.orbit_ctx_meshlet_stream_culls(self._ctx))

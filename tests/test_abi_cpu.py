@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} is declared in include/orbit_abi.h but not exported"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes signature in orbit_amd/_lib.py"
-    assert lib.orbit_abi_version() == 3
+    assert lib.orbit_abi_version() == 4
 
 
 def test_header_compiles_as_c_and_cxx(tmp_path):
@@ -43,7 +43,7 @@ def test_header_compiles_as_c_and_cxx(tmp_path):
 
 def test_ctypes_mirrors_match_header_sizes():
     # the sizes below are the ORBIT_STATIC_ASSERTs of the header
-    assert C.sizeof(_lib.Caps) == 32
+    assert C.sizeof(_lib.Caps) == 36
     assert C.sizeof(_lib.EntityCullBufs) == 6 * 8 + 16 + 8   # + depth_pyramid_levels (ABI version 2)
     assert C.sizeof(_lib.MeshletCullBufs) == 7 * 8 + 24 + 8
     assert C.sizeof(_lib.DepthPyramidLevel) == 16 and C.sizeof(_lib.DepthReduceItem) == 40

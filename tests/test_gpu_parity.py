@@ -19,17 +19,23 @@ def torch_mod():
     return torch
 
 
-# every test that takes `engine` runs three times: from the 32-B Meshlet buffer, from the derived meshlet streams, and
-# from the streams with their alpha classes (no material index read; a third of the materials looked up at cull time)
-@pytest.fixture(scope="module", params=["meshlet_buffer", "meshlet_stream", "meshlet_stream_classes"])
+# every test that takes `engine` runs four times: from the 32-B Meshlet buffer, from the derived meshlet streams, from
+# the streams with their alpha classes (no material index read; a third of the materials looked up at cull time), and
+# with both cull stages as ONE launch (orbit_cull_views' one-launch path, tests/fused_engine.py)
+@pytest.fixture(scope="module", params=["meshlet_buffer", "meshlet_stream", "meshlet_stream_classes", "one_launch"])
 def engine(torch_mod, request):
     from orbit_amd.engine import Engine
     from stream_engine import StreamEngine
 
     kw = dict(max_entities=300_000, max_dispatches=2_000_000, max_draws=4_000_000, max_lights=12_000,
               max_clusters=240 * 135 * 32)
-    e = Engine(0, **kw) if request.param == "meshlet_buffer" else StreamEngine(
-        0, classes=request.param == "meshlet_stream_classes", **kw)
+    if request.param == "one_launch":  # entity + meshlet stage as ONE launch (cull_fused.hip)
+        from fused_engine import FusedEngine
+
+        e = FusedEngine(0, **kw)
+    else:
+        e = Engine(0, **kw) if request.param == "meshlet_buffer" else StreamEngine(
+            0, classes=request.param == "meshlet_stream_classes", **kw)
     yield e
     e.close()
 

@@ -18,14 +18,19 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gol
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["meshlet_buffer", "meshlet_stream", "meshlet_stream_classes"])
+@pytest.fixture(scope="module", params=["meshlet_buffer", "meshlet_stream", "meshlet_stream_classes", "one_launch"])
 def engine(torch_mod, request):
     from orbit_amd.engine import Engine
     from stream_engine import StreamEngine
 
     kw = dict(max_entities=8192, max_dispatches=60_000, max_draws=400_000)
-    e = Engine(0, **kw) if request.param == "meshlet_buffer" else StreamEngine(
-        0, classes=request.param == "meshlet_stream_classes", **kw)
+    if request.param == "one_launch":  # entity + meshlet stage as ONE launch (cull_fused.hip)
+        from fused_engine import FusedEngine
+
+        e = FusedEngine(0, **kw)
+    else:
+        e = Engine(0, **kw) if request.param == "meshlet_buffer" else StreamEngine(
+            0, classes=request.param == "meshlet_stream_classes", **kw)
     yield e
     e.close()
 
