@@ -455,6 +455,18 @@ int32_t orbit_debug_read_wave_stamps(OrbitCtx *ctx, unsigned long long *out) {
     return ORBIT_OK;
 }
 
+// triage only (not part of the public ABI): the progress marks of a -DORBIT_FUSED_DEBUG build of cull_fused.hip, copied
+// on a stream of their own so that they can be read while a launch is still running; out holds 8192 values
+int32_t orbit_debug_read_fused_marks(OrbitCtx *ctx, unsigned long long *out) {
+    if (!ctx || !out) return ORBIT_E_INVALID;
+    hipStream_t s;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return ORBIT_E_HIP;
+    hipError_t e = hipMemcpyAsync(out, ctx->debug_cycles + 64, 8192 * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipStreamDestroy(s);
+    return e == hipSuccess ? ORBIT_OK : ORBIT_E_HIP;
+}
+
 // perf triage only (not part of the public ABI): reads and clears the per-phase cycle sums
 int32_t orbit_debug_read_cycles(OrbitCtx *ctx, unsigned long long out[8]) {
     if (!ctx || !out) return ORBIT_E_INVALID;

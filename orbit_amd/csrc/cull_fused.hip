@@ -38,7 +38,10 @@ namespace {
 
 constexpr uint32_t kFusedWaves = 4;                // = kEntityBlock / 64
 constexpr uint32_t kFusedCap = kTileRecords * 32u; // survivors a tile can have: its payload slab holds them all
-constexpr uint32_t kSpinLimit = 1u << 21;          // polls before a wait gives up (seconds; a hop takes microseconds)
+#ifndef ORBIT_FUSED_SPIN_LOG2
+#define ORBIT_FUSED_SPIN_LOG2 18
+#endif
+constexpr uint32_t kSpinLimit = 1u << ORBIT_FUSED_SPIN_LOG2; // polls before a wait gives up (a good fraction of a second; a hop takes microseconds)
 static_assert(kFusedWaves * 64 == kEntityBlock, "one block shape for both phases");
 
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
@@ -73,6 +76,10 @@ __device__ __forceinline__ void poll_pause() { asm volatile("s_sleep 1" ::: "mem
 __device__ __forceinline__ uint32_t ticket(uint32_t *counter) {
     return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// a value every lane of the wave holds, as a scalar: loop conditions and branches on it are scalar branches (the
+// compiler cannot see that a word read from LDS behind a barrier is uniform, and wraps what follows — barriers
+// included — in divergent-loop bookkeeping)
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -105,7 +112,7 @@ __device__ __forceinline__ uint32_t chunks_before(const FusedCullParams &p, __am
 #pragma unroll
     for (uint32_t i = 0; i < kFusedWaves; i++) sum += smem[i];
     __syncthreads();
-    return sum;
+    return uniform(sum);
 }
 
 // Exclusive prefix of the survivor counts of the tiles before `t` (wave-uniform), by decoupled look-back: lane i reads
@@ -133,6 +140,17 @@ __device__ __forceinline__ uint32_t tiles_before(const FusedCullParams &p, __amd
         pos -= 64u; // 64 aggregates and no prefix among them: the next 64 (pos >= 64 here: tiles below 0 are prefixes)
     }
 }
+
+// -DORBIT_FUSED_DEBUG builds only (tools/fused_probe.py): progress marks, written through so that a copy engine can
+// read them while the launch is still running
+#ifdef ORBIT_FUSED_DEBUG
+#define FUSED_MARK(stage, value)                                                                                        \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 256u)                                                                    \
+    __hip_atomic_store(p.m.debug_cycles + 64 + (blockIdx.x * 4u + (threadIdx.x >> 6)) * 8u + (stage),                   \
+                       (unsigned long long)(value) | 1ull << 63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define FUSED_MARK(stage, value)
+#endif
 
 template <int PASS, int PROJ>
 __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
@@ -162,12 +180,17 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
     const uint32_t draw_end = min(draw_count, p.draw_limit);
 
     // ---------------------------------------------------------------- entity chunks (entity_cull.comp:104-245)
-    for (;;) {
-        if (threadIdx.x == 0) s_word[0] = ticket(p.sync + kSyEntTicket);
-        __syncthreads();
-        const uint32_t eb = s_word[0];
-        __syncthreads();
-        if (eb >= p.ne_chunks) break;
+    // ONE thread-0 region per iteration (signal the chunk just finished, draw the next ticket), its result broadcast
+    // behind a barrier and made a scalar: with a thread-0 region at the end of the body and another at the head of the
+    // next iteration the compiler threaded the two together and let the other lanes of wave 0 run ahead through the
+    // loop head's barrier — wave 0 then passed that barrier twice per iteration and the workgroup fell out of step
+    // (found on hardware with the progress marks below; look for s_barrier inside a depth-2 loop in the ISA).
+    if (threadIdx.x == 0) s_word[0] = ticket(p.sync + kSyEntTicket);
+    __syncthreads();
+    uint32_t eb = uniform(s_word[0]);
+    __syncthreads();
+    while (eb < p.ne_chunks) {
+        FUSED_MARK(0, eb);
         const uint32_t g = p.draw_first + eb * kEntityBlock + threadIdx.x;
         const bool active = g < draw_end; // :106
         bool visible;
@@ -176,11 +199,14 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
         const uint32_t n = (pr.meshlet_count + ORBIT_MESHLET_DISPATCH_SIZE - 1u) / ORBIT_MESHLET_DISPATCH_SIZE; // :210
         uint32_t chunk_total;
         s_off[threadIdx.x] = block_exclusive_scan<kFusedWaves>(n, smem, &chunk_total);
+        chunk_total = uniform(chunk_total);
         s_proto[threadIdx.x] = pr;
         // the chunk's count first (whoever waits for it must never wait for this chunk's own look-back) ...
-        if (threadIdx.x == 0) st_sc1(EF, eb * 4u, chunk_total << 2 | kAggregate);
+        st_sc1(EF, threadIdx.x == 0 ? eb * 4u : kNoOffset, chunk_total << 2 | kAggregate);
+        FUSED_MARK(1, chunk_total);
         // ... then the records of the chunks before it
         const uint32_t base = chunks_before(p, EF, eb, smem);
+        FUSED_MARK(2, base);
         for (uint32_t r = threadIdx.x; r < chunk_total; r += kEntityBlock) {
             const uint32_t owner = entity_record_owner(s_off, r);
             const OrbitMeshletDispatch rec = entity_record(s_proto[owner], r - s_off[owner]);
@@ -190,6 +216,7 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
         }
         drain_stores();
         __syncthreads(); // every wave's records are in memory; s_off / s_proto may be rewritten
+        FUSED_MARK(3, eb);
         if (threadIdx.x == 0) {
             if (eb == p.ne_chunks - 1u) { // the last chunk knows the total: the {x,1,1} header (draw_gen.rs:356-363)
                 const uint32_t total = base + chunk_total;
@@ -199,7 +226,8 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
                 hdr[2] = 1u;
                 *p.e_total = total;
                 if (total > p.e_dispatch_capacity) latch_status(p.m.status, ORBIT_E_CAPACITY);
-                if (min(total, min(p.e_dispatch_capacity, p.m.dispatch_capacity)) == 0u) { // no tile will run: the empty draw list is written here
+                if (min(total, min(p.e_dispatch_capacity, p.m.dispatch_capacity)) == 0u) {
+                    // no tile will run: the empty draw list is written here
                     *reinterpret_cast<uint32_t *>(p.m.draw_buffer) = 0u;
                     *p.m.total = 0u;
                 }
@@ -207,7 +235,11 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
                 drain_stores();
             }
             (void)ticket(p.sync + kSyEntDone); // behind the drains above: "this chunk's records are in memory"
+            s_word[0] = ticket(p.sync + kSyEntTicket);
         }
+        __syncthreads();
+        eb = uniform(s_word[0]);
+        __syncthreads();
     }
 
     // ---------------------------------------------------------------- every record is in memory
@@ -226,7 +258,8 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
         s_word[1] = total1 != 0u ? total1 - 1u : 0u;
     }
     __syncthreads();
-    const uint32_t nrec = min(s_word[1], min(p.e_dispatch_capacity, p.m.dispatch_capacity));
+    const uint32_t nrec = min(uniform(s_word[1]), min(p.e_dispatch_capacity, p.m.dispatch_capacity));
+    FUSED_MARK(4, nrec);
     const uint32_t ntiles = (nrec + kTileRecords - 1u) / kTileRecords;
     const __amdgpu_buffer_rsrc_t REC_R = rsrc_of(p.m.dispatch_buffer + ORBIT_DISPATCH_HEADER, nrec * 16u);
 
@@ -240,6 +273,7 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
         uint32_t t = 0;
         if (lane == 0) t = ticket(p.sync + kSyTileTicket);
         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        FUSED_MARK(5, t);
         if (t >= ntiles) break;
         // the tile's 16 records (lane = record * 4 + matrix column; past the last record: zeros), matrices, slab
         const uint32_t rec_index = t * kTileRecords + ((uint32_t)lane >> 2);
@@ -268,6 +302,7 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
             cs.total = rows_eval<PASS, PROJ, 0, (int)kTileRows, false, kFusedCap>(p.m, L, planes, alpha, lane, q, 0u, pay);
         }
         const uint32_t n = cs.total;
+        FUSED_MARK(6, n);
         // count out, base in
         uint32_t base = 0;
         if (t == 0u) {
@@ -315,10 +350,11 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
     }
 
     // ---------------------------------------------------------------- the last workgroup out resets the flags
+    FUSED_MARK(7, 1);
     __syncthreads();
     if (threadIdx.x == 0) s_word[0] = ticket(p.sync + kSyBlocksDone) == gridDim.x - 1u ? 1u : 0u;
     __syncthreads();
-    if (s_word[0] != 0u) { // every other workgroup has made its last access to them
+    if (uniform(s_word[0]) != 0u) { // every other workgroup has made its last access to them
         for (uint32_t i = threadIdx.x; i < p.ne_chunks; i += kEntityBlock) p.ent_flags[i] = 0u;
         for (uint32_t i = threadIdx.x; i < ntiles; i += kEntityBlock) p.tile_flags[i] = 0u;
         if (threadIdx.x < kFusedSyncWords / 32u) p.sync[threadIdx.x * 32u] = 0u;
