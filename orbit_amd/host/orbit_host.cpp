@@ -339,13 +339,10 @@ static void assert_planes(const CullInfo &ci) {
         throw Panic("assertion failed: cull_info.view_space_cull_planes.len() <= MAX_CULL_PLANES");
 }
 
-std::pair<OrbitGpuCullInfo, GraphBufferHandle> create_meshlet_dispatch_command(
-    graphics::Context &context, const std::string &name, const AssetGraphData &assets, const SceneGraphData &scene,
-    const CullInfo &cull_info) {
-    assert_planes(cull_info);
-    const GraphBufferHandle dispatch =
-        context.create_transient(name + "_meshlet_dispatch_buffer", MAX_MESHLET_DISPATCH_COUNT * 16);
-    const OrbitGpuCullInfo gpu = cull_info.to_gpu();
+// The two stages' buffer blocks (push-constant order of entity_cull.comp:17-23 / meshlet_cull.comp:16-23, as raw
+// device pointers), shared by the single-stage entry points and by create_draw_commands.
+static OrbitEntityCullBufs entity_bufs(const AssetGraphData &assets, const SceneGraphData &scene,
+                                       const CullInfo &cull_info, const GraphBufferHandle &dispatch) {
     OrbitEntityCullBufs b;
     std::memset(&b, 0, sizeof(b));
     b.entity_draw_buffer = scene.entity_draw_buffer.ptr;
@@ -358,16 +355,12 @@ std::pair<OrbitGpuCullInfo, GraphBufferHandle> create_meshlet_dispatch_command(
     b.depth_pyramid_size[1] = cull_info.occlusion_culling.depth_pyramid.height;
     // the buffer is MAX*16 bytes but records start at byte 12: one record less fits
     b.dispatch_capacity = (uint32_t)((dispatch.size - ORBIT_DISPATCH_HEADER) / 16);
-    context.check(orbit_entity_cull(context.abi(), &gpu, &b, (uint32_t)scene.entity_draw_count, context.stream()));
-    return {gpu, dispatch};
+    return b;
 }
 
-GraphBufferHandle create_meshlet_draw_commands(graphics::Context &context, const std::string &name,
-                                               const AssetGraphData &assets, const SceneGraphData &scene,
-                                               const CullInfo &cull_info, GraphBufferHandle dispatch) {
-    assert_planes(cull_info);
-    const GraphBufferHandle draws = context.create_transient(name, MAX_DRAW_COUNT * sizeof(OrbitMeshletDrawCommand));
-    const OrbitGpuCullInfo gpu = cull_info.to_gpu();
+static OrbitMeshletCullBufs meshlet_bufs(const AssetGraphData &assets, const SceneGraphData &scene,
+                                         const CullInfo &cull_info, const GraphBufferHandle &dispatch,
+                                         const GraphBufferHandle &draws) {
     OrbitMeshletCullBufs b;
     std::memset(&b, 0, sizeof(b));
     b.meshlet_dispatch_buffer = dispatch.ptr;
@@ -382,17 +375,52 @@ GraphBufferHandle create_meshlet_draw_commands(graphics::Context &context, const
     b.dispatch_capacity = (uint32_t)((dispatch.size - ORBIT_DISPATCH_HEADER) / 16);
     b.draw_capacity = (uint32_t)((draws.size - ORBIT_DRAW_HEADER) / sizeof(OrbitMeshletDrawCommand));
     b.material_count = assets.material_count;
+    return b;
+}
+
+std::pair<OrbitGpuCullInfo, GraphBufferHandle> create_meshlet_dispatch_command(
+    graphics::Context &context, const std::string &name, const AssetGraphData &assets, const SceneGraphData &scene,
+    const CullInfo &cull_info) {
+    assert_planes(cull_info);
+    const GraphBufferHandle dispatch =
+        context.create_transient(name + "_meshlet_dispatch_buffer", MAX_MESHLET_DISPATCH_COUNT * 16);
+    const OrbitGpuCullInfo gpu = cull_info.to_gpu();
+    const OrbitEntityCullBufs b = entity_bufs(assets, scene, cull_info, dispatch);
+    context.check(orbit_entity_cull(context.abi(), &gpu, &b, (uint32_t)scene.entity_draw_count, context.stream()));
+    return {gpu, dispatch};
+}
+
+GraphBufferHandle create_meshlet_draw_commands(graphics::Context &context, const std::string &name,
+                                               const AssetGraphData &assets, const SceneGraphData &scene,
+                                               const CullInfo &cull_info, GraphBufferHandle dispatch) {
+    assert_planes(cull_info);
+    const GraphBufferHandle draws = context.create_transient(name, MAX_DRAW_COUNT * sizeof(OrbitMeshletDrawCommand));
+    const OrbitGpuCullInfo gpu = cull_info.to_gpu();
+    const OrbitMeshletCullBufs b = meshlet_bufs(assets, scene, cull_info, dispatch, draws);
     context.check(orbit_meshlet_cull(context.abi(), &gpu, &b, context.stream()));
     return draws;
 }
 
+// Both stages (draw_gen.rs:239-322: one clear + entity_cull.comp + meshlet_cull.comp) as ONE call of the library, which
+// then runs a scene of the reference's size as one launch (orbit_cull_views, include/orbit_abi.h) and a larger one as
+// the launch chain — the same buffers either way.
 GraphBufferHandle create_draw_commands(graphics::Context &context, const std::string &name,
                                        const AssetGraphData &assets, const SceneGraphData &scene,
                                        const CullInfo &cull_info, const GraphBufferHandle *reuse_buffer) {
     assert_planes(cull_info);
-    auto r = create_meshlet_dispatch_command(context, name, assets, scene, cull_info);
     (void)reuse_buffer; // the transient cache returns the same buffer for the same name + size
-    return create_meshlet_draw_commands(context, name, assets, scene, cull_info, r.second);
+    const GraphBufferHandle dispatch =
+        context.create_transient(name + "_meshlet_dispatch_buffer", MAX_MESHLET_DISPATCH_COUNT * 16);
+    const GraphBufferHandle draws = context.create_transient(name, MAX_DRAW_COUNT * sizeof(OrbitMeshletDrawCommand));
+    const OrbitGpuCullInfo gpu = cull_info.to_gpu();
+    OrbitCullView view;
+    std::memset(&view, 0, sizeof(view));
+    view.cull_info = &gpu;
+    view.entity = entity_bufs(assets, scene, cull_info, dispatch);
+    view.meshlet = meshlet_bufs(assets, scene, cull_info, dispatch, draws);
+    view.entity_draw_count = (uint32_t)scene.entity_draw_count;
+    context.check(orbit_cull_views(context.abi(), &view, 1, context.stream()));
+    return draws;
 }
 
 static uint32_t next_power_of_two(uint32_t v) {

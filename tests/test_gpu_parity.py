@@ -1355,10 +1355,14 @@ def test_cull_views_late_pass_views_with_their_own_pyramids(torch_mod, oracle):
            sc.make_cull_info(sc.translation(3.0, -1.0, -20.0), cam.planes[:2], occlusion_pass=2, **ortho)]
     evis = [rng.integers(0, 2 ** 32, (scene.entity_draw_count + 31) // 32, dtype=np.uint32) for _ in cis]
     mvis = [rng.integers(0, 2 ** 32, scene.vis_words, dtype=np.uint32) for _ in cis]
-    eng = Engine(0, max_entities=8192, max_dispatches=40_000, max_draws=200_000, max_views=3)
     disp_cap, draw_cap = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
-    for source in ("meshlet_buffer", "meshlet_stream"):
-        if source == "meshlet_stream":
+    # the launch chain from the Meshlet buffer and from the derived streams (cull_path = 1), then the library's own
+    # choice for views of this size: the one-launch cull (one launch per projection type among the three views)
+    for source in ("meshlet_buffer", "meshlet_stream", "one_launch"):
+        if source != "meshlet_stream":
+            eng = Engine(0, max_entities=8192, max_dispatches=40_000, max_draws=200_000, max_views=3,
+                         cull_path=0 if source == "one_launch" else 1)
+        else:
             eng.bind_meshlet_stream(eng.meshlet_stream(gs.meshlets, 0, len(scene.meshlets)))
         pyrs = [torch.zeros(d.total_texels, dtype=torch.float32, device="cuda") for d in descs]
         gdepths = [dev(torch, d).view(torch.float32) for d in depths]
@@ -1389,7 +1393,9 @@ def test_cull_views_late_pass_views_with_their_own_pyramids(torch_mod, oracle):
             drawn.append(len(cmds))
         assert all(n > 0 for n in drawn), drawn
         assert eng.meshlet_stream_culls() == (3 if source == "meshlet_stream" else 0)
-    eng.close()
+        assert eng.fused_culls() == (3 if source == "one_launch" else 0)
+        if source != "meshlet_buffer":
+            eng.close()
 
 
 def test_non_affine_matrices_and_non_finite_centres_take_the_literal_path(torch_mod, engine, oracle):

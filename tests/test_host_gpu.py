@@ -73,6 +73,13 @@ def test_frame_sequence_through_host_api(torch_mod, oracle, meshlet_stream):
     n1 = int(odr[:4].view(np.uint32)[0])
     assert n1 > 0 and np.array_equal(fetch(draws, 4 + 28 * n1), odr[:4 + 28 * n1])
 
+    # the same cull through create_draw_commands (draw_gen.rs:239-322: both stages, as the shadow passes call it) — ONE
+    # library call, which runs a scene of this size as one launch: same transient buffers, same bytes
+    draws_b = passes.create_draw_commands(ctx, "early_forward_depth_prepass", assets, hscene, ci1)
+    torch.cuda.synchronize()
+    assert draws_b.ptr == draws.ptr and np.array_equal(fetch(draws_b, 4 + 28 * n1), odr[:4 + 28 * n1])
+    assert np.array_equal(fetch(disp, 12 + 16 * nrec), od[:12 + 16 * nrec])
+
     # -- DepthPyramid::update (forward.rs:362-367)
     depth = sc.make_depth(9, W, H, cam)
     gdepth = dev(torch, depth)

@@ -176,7 +176,9 @@ def test_cull_views_from_the_stream(torch_mod, oracle):
     cis = [sc.make_cull_info(cam.view, cam.planes, occlusion_pass=2, p00=cam.p00, p11=cam.p11, z_near=cam.z_near),
            sc.make_cull_info(cam.view, cam.planes),
            sc.make_cull_info(cam.view, cam.planes, occlusion_pass=1)]
-    eng = Engine(0, max_entities=8192, max_dispatches=40_000, max_draws=200_000, max_views=3)
+    # (cull_path = 1: the launch chain — views of this size would otherwise take the one-launch cull, which reads the
+    # Meshlet buffer whatever stream is bound)
+    eng = Engine(0, max_entities=8192, max_dispatches=40_000, max_draws=200_000, max_views=3, cull_path=1)
     eng.bind_meshlet_stream(eng.meshlet_stream(gs.meshlets, 0, len(scene.meshlets)))
     disp_cap, draw_cap = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
     pyr = dev(torch, opyr)

@@ -1,101 +1,294 @@
-"""Secondary timings (not the bench.py headline): BASELINE configs 2-4 stand-ins on one MI355X.
-HIP-event medians over 20 runs after 5 warm-ups; parity of each stage is covered by tests/."""
-import os, sys, json
+"""BASELINE.json configs 2-4 on one MI355X (secondary to bench.py's config-5 headline; GPU box): per config the GPU time
+of every path the library has for it, the CPU oracle's time on the same inputs with its thread count (BASELINE.md §3:
+the CPU baseline is reported next to every GPU figure), whether the GPU output equals the oracle's bit for bit, and
+algorithmic bytes / time (SURVEY.md §8d's formulas).  Workloads: tests/config_scenes.py — the very scenes
+tests/test_configs_gpu.py checks.  Protocol: 5 warm-ups, then >= 20 runs each inside its own HIP event
+pair, the median.  Usage: python tools/bench_configs.py > profiles/r04_configs.json"""
+import json
+import os
+import sys
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
-import numpy as np, torch
-import scenes as sc
+import numpy as np
+import torch
+
+import config_scenes as cs
 from oracle import oracle
 from orbit_amd import layouts as L
 from orbit_amd.engine import Engine, depth_pyramid_desc
 
-dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).cuda()
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).cuda()
+
+
+def host(t, dtype=np.uint8):
+    return t.cpu().numpy().view(dtype)
+
 
 def timeit(fn, n=20, warm=5):
-    for _ in range(warm): fn()
+    for _ in range(warm):
+        fn()
     ts = []
     for _ in range(n):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
     return float(np.median(ts))
 
+
+def graph_of(fn):
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    return g
+
+
+def cpu_time(fn, min_s=1.0, min_reps=3, max_reps=200):
+    t, reps, out = 0.0, 0, None
+    while (t < min_s or reps < min_reps) and reps < max_reps:
+        t0 = time.perf_counter()
+        out = fn()
+        t += time.perf_counter() - t0
+        reps += 1
+    return t / reps, reps, out
+
+
+class GScene:
+    def __init__(self, s):
+        self.s = s
+        self.draws, self.mesh, self.ent, self.mlt, self.mat = (dev(a) for a in (
+            s.entity_draw_buffer(), s.mesh_infos, s.entities, s.meshlets, s.materials))
+        self.cap_d, self.cap_c = s.max_dispatches() + 8, s.lod0_meshlets + 8
+
+    def view(self, ci, evis=None, mvis=None, pyr=None, psize=(0, 0)):
+        s = self.s
+        disp = torch.zeros(12 + 16 * self.cap_d, dtype=torch.uint8, device="cuda")
+        draw = torch.zeros(4 + 28 * self.cap_c, dtype=torch.uint8, device="cuda")
+        v = dict(cull_info=ci, entity_draw_buffer=self.draws, mesh_info_buffer=self.mesh, meshlet_dispatch_buffer=disp,
+                 entity_buffer=self.ent, entity_draw_count=s.entity_draw_count, dispatch_capacity=self.cap_d,
+                 meshlet_buffer=self.mlt, draw_commands_buffer=draw, material_buffer=self.mat, draw_capacity=self.cap_c,
+                 visibility_buffer=evis, meshlet_visibility_buffer=mvis, material_count=len(s.materials))
+        if pyr is not None:
+            v.update(depth_pyramid=pyr, depth_pyramid_size=psize)
+        return v, disp, draw
+
+
+PATHS = ("launch_chain", "launch_chain_from_streams", "one_launch")
+
+
+def engine_for(path, g):
+    eng = Engine(0, max_entities=8192, max_dispatches=40_000, max_draws=200_000, cull_path=2 if path == "one_launch" else 1)
+    if path == "launch_chain_from_streams":
+        ms = eng.meshlet_stream(g.mlt, 0, len(g.s.meshlets))
+        ms.set_materials(g.mat, len(g.s.materials))
+        eng.bind_meshlet_stream(ms)
+    return eng
+
+
+def cull_bytes(n_e, n_m, n_d, n_draw, tested=0, occlusion=False):
+    """entity_cull N_e (12 + 64 + 28) + 16 N_d + 4 ceil(N_e / 32); meshlet_cull 32 N_m + 16 N_d + 64 N_e +
+    28 N_draw + 4 (+ 8 N_m / 32 visibility words and 4 N_tested pyramid texels in the occlusion passes)."""
+    b = n_e * 104 + 16 * n_d + 4 * ((n_e + 31) // 32) + 32 * n_m + 16 * n_d + 64 * n_e + 28 * n_draw + 4
+    if occlusion:
+        b += 8 * n_m // 32 + 4 * tested
+    return b
+
+
+def counts(disp, draw):
+    n_d = int(disp[:4].view(np.uint32)[0])
+    n_m = int(disp[12:12 + 16 * n_d].view(np.uint32).reshape(-1, 4)[:, 2].sum())
+    return n_d, n_m, int(draw[:4].view(np.uint32)[0])
+
+
+def same(gdisp, gdraw, odisp, odraw):
+    n_d, n = int(odisp[:4].view(np.uint32)[0]), int(odraw[:4].view(np.uint32)[0])
+    return bool(np.array_equal(gdisp[:12 + 16 * n_d], odisp[:12 + 16 * n_d]) and np.array_equal(gdraw[:4 + 28 * n], odraw[:4 + 28 * n]))
+
+
 def main():
-    eng = Engine(0, max_entities=100_000, max_dispatches=1_000_000, max_draws=1_000_000, max_lights=12_000)
-    out = {}
-    cam = sc.default_camera()
-    # config 2: Sponza-class, frustum + cone, pass 0
-    s2 = sc.make_scene(2, 400, n_meshes=400, meshlets_per_mesh=(4, 26), extent=(15.0, 6.0, 9.0))
-    # config 3/4: Bistro-class, two-pass HiZ at 1080p
-    s3 = sc.make_scene(3, 2900, n_meshes=2900, meshlets_per_mesh=(4, 38), extent=(75.0, 20.0, 75.0))
-    W, H = 1920, 1080
-    for name, s in (("config2", s2), ("config3", s3)):
-        g = [dev(a) for a in (s.entity_draw_buffer(), s.mesh_infos, s.entities, s.meshlets, s.materials)]
-        cap_d, cap_c = s.max_dispatches() + 8, s.lod0_meshlets + 8
-        disp = torch.zeros(12 + 16 * cap_d, dtype=torch.uint8, device="cuda"); draw = torch.zeros(4 + 28 * cap_c, dtype=torch.uint8, device="cuda")
-        ci0 = sc.make_cull_info(cam.view, cam.planes)
-        def cull0():
-            eng.entity_cull(ci0, g[0], g[1], disp, g[2], s.entity_draw_count, cap_d)
-            eng.meshlet_cull(ci0, disp, g[3], draw, g[2], g[4], cap_d, cap_c, material_count=len(s.materials))
-        out[name] = {"entities": s.entity_draw_count, "meshlets_lod0": s.lod0_meshlets, "pass0_cull_ms": timeit(cull0)}
-        if name == "config3":
-            depth = sc.make_depth(9, W, H, cam); gdepth = dev(depth)
-            d = depth_pyramid_desc(W, H); pyr = torch.zeros(d.total_texels, dtype=torch.float32, device="cuda")
-            out[name]["depth_reduce_ms"] = timeit(lambda: eng.depth_reduce(gdepth, W, H, pyr))
-            evis = torch.zeros((s.entity_draw_count + 31) // 32, dtype=torch.int32, device="cuda"); mvis = torch.zeros(s.vis_words, dtype=torch.int32, device="cuda")
-            ci1 = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=1)
-            ci2 = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=2, p00=cam.p00, p11=cam.p11, z_near=cam.z_near)
-            ps = (d.width, d.height)
-            def frame():
-                eng.entity_cull(ci1, g[0], g[1], disp, g[2], s.entity_draw_count, cap_d, visibility_buffer=evis)
-                eng.meshlet_cull(ci1, disp, g[3], draw, g[2], g[4], cap_d, cap_c, meshlet_visibility_buffer=mvis, material_count=len(s.materials))
-                eng.depth_reduce(gdepth, W, H, pyr)
-                eng.entity_cull(ci2, g[0], g[1], disp, g[2], s.entity_draw_count, cap_d, visibility_buffer=evis, depth_pyramid=pyr, depth_pyramid_size=ps)
-                eng.meshlet_cull(ci2, disp, g[3], draw, g[2], g[4], cap_d, cap_c, meshlet_visibility_buffer=mvis, depth_pyramid=pyr, depth_pyramid_size=ps, material_count=len(s.materials))
-            out[name]["two_pass_frame_ms"] = timeit(frame)
-            # the same frame captured once into a HIP graph and replayed (12 launches, no per-call host work)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                frame()
-            out[name]["two_pass_frame_graph_ms"] = timeit(graph.replay)
-            # config 4: + 10k point lights, 240x135x32 clusters
-            nl = 10_000
-            lights = sc.make_lights(4, nl); glights = dev(lights)
-            cx, cy, cz = 240, 135, 32
-            zs, zb = oracle.cluster_grid_info(cam.z_near, 200.0, cz)
-            push = np.zeros((), dtype=L.MARK_ACTIVE_PUSH)
-            push["cluster_count"], push["tile_size_px"], push["screen_size"] = (cx, cy, cz), 8, (W, H)
-            push["z_near"], push["z_far"], push["z_scale"], push["z_bias"], push["depth_buffer_sample_count"] = cam.z_near, 200.0, zs, zb, 1
-            info = np.zeros((), dtype=L.CLUSTER_CULL_INFO)
-            info["world_to_view_matrix"] = sc.mat4_cols(cam.view)
-            info["screen_to_view_matrix"] = sc.mat4_cols(np.linalg.inv(cam.proj.astype(np.float64)).astype(np.float32))
-            info["cluster_count"], info["tile_size_px"], info["screen_size"] = (cx, cy, cz), 8, (W, H)
-            info["z_near"], info["z_far"], info["global_light_count"] = cam.z_near, 200.0, nl
-            total = cx * cy * cz
-            gm = torch.zeros(cx * cy, dtype=torch.int32, device="cuda"); gb = torch.zeros((total, 2), dtype=torch.int32, device="cuda")
-            gu = torch.zeros(16 + 4 * total, dtype=torch.uint8, device="cuda")
-            lcap = total * 32
-            gl = torch.zeros(4 + 4 * lcap, dtype=torch.uint8, device="cuda"); gimg = torch.zeros((total, 2), dtype=torch.int32, device="cuda")
-            c4 = {"lights": nl, "clusters": total}
-            c4["mark_ms"] = timeit(lambda: eng.cluster_mark(push, gdepth, gm, gb))
-            c4["compact_ms"] = timeit(lambda: eng.cluster_compact((cx, cy, cz), gm, gu, total))
-            c4["assign_ms"] = timeit(lambda: eng.cluster_assign(info, gu, gb, glights, gl, lcap, gimg), n=10, warm=2)
-            torch.cuda.synchronize()
-            c4["active_clusters"] = int(gu[12:16].view(torch.int32).item()); c4["light_indices"] = int(gl[:4].view(torch.int32).item())
-            # what the reference's shader would have run in that time (2 x active x lights); the tests the three-level cull
-            # really executes are counted by tools/cluster_tests.py (0.26 % of these at this configuration)
-            c4["reference_equivalent_sphere_tests_per_s"] = 2.0 * c4["active_clusters"] * nl / (c4["assign_ms"] * 1e-3)
-            # distribution of lights per active cluster (compacted order) and per block of 8: what the hit cache sees
-            na = c4["active_clusters"]
-            uidx = gu[16:16 + 4 * na].view(torch.int32).long()
-            cnt = gimg.view(torch.int32).view(-1, 2)[uidx, 1].cpu().numpy()
-            pad = np.zeros((-len(cnt)) % 8, dtype=cnt.dtype)
-            bmax = np.concatenate([cnt, pad]).reshape(-1, 8).max(axis=1)
-            c4["lights_per_cluster"] = {"mean": float(cnt.mean()), "p99": int(np.percentile(cnt, 99)), "max": int(cnt.max()),
-                                        "blocks_over_16": int((bmax > 16).sum()), "blocks": int(len(bmax))}
-            out["config4"] = c4
-    try: eng.status()
-    except Exception as e: out["status"] = str(e)
+    threads = oracle.max_threads()
+    cam = cs.camera()
+    out = {"protocol": "HIP-event median of 20 after 5 warm-ups (SURVEY.md §8d); CPU: oracle/orbit_oracle.c through "
+                       "oracle/orbit_oracle_mt.c (native build) on all host threads, mean of >= 3 runs over >= 1 s",
+           "cpu_threads": threads, "host_cores": os.cpu_count(), "cpu_flags": oracle.NATIVE_CFLAGS}
+    oracle.build()
+
+    # ---------------------------------------------------------------- config 2: frustum + cone, pass 0
+    s2 = cs.config2_scene()
+    g2 = GScene(s2)
+    ci0 = cs.pass0_cull_info(cam)
+    h2 = [a for a in (s2.entity_draw_buffer(), s2.mesh_infos, s2.entities, s2.meshlets, s2.materials)]
+    cpu_s, reps, (odisp, odraw, _, _, _) = cpu_time(lambda: oracle.cull_frame_mt(
+        ci0, h2[0], s2.entity_draw_count, h2[1], h2[2], h2[3], h2[4], g2.cap_d, g2.cap_c, threads, native=True))
+    n_d, n_m, n_draw = counts(odisp, odraw)
+    c2 = {"workload": f"config 2 (Sponza-class stand-in): {s2.entity_draw_count} entities, {s2.lod0_meshlets} meshlets LOD 0, "
+                      f"entity_cull + meshlet_cull, frustum + cone, occlusion_pass 0",
+          "dispatch_records": n_d, "meshlets_into_meshlet_cull": n_m, "draw_commands": n_draw,
+          "algorithmic_bytes": cull_bytes(s2.entity_draw_count, n_m, n_d, n_draw), "gpu": {}}
+    ok = True
+    for path in PATHS:
+        eng = engine_for(path, g2)
+        v, disp, draw = g2.view(ci0)
+        arr, keep = eng.prepare_views([v])
+        ms = timeit(lambda: eng.cull_views_prepared(arr))
+        gr = graph_of(lambda: eng.cull_views_prepared(arr))
+        c2["gpu"][path] = {"cull_ms": ms, "cull_graph_replay_ms": timeit(gr.replay)}
+        torch.cuda.synchronize()
+        eng.status()
+        ok = ok and same(host(disp), host(draw), odisp, odraw)
+        del gr
+        eng.close()
+    best = min(v["cull_ms"] for v in c2["gpu"].values())
+    c2["gpu_output_bit_identical"] = ok
+    c2["meshlets_per_sec"] = n_m / (best * 1e-3)
+    c2["achieved_GBps"] = c2["algorithmic_bytes"] / (best * 1e-3) / 1e9
+    c2["cpu_baseline"] = {"ms": cpu_s * 1e3, "value": n_m / cpu_s, "unit": "meshlets/s", "cores": threads, "kind": "port",
+                          "sample": f"the whole workload, {reps} runs"}
+    out["config2"] = c2
+
+    # ---------------------------------------------------------------- config 3: the two-pass frame at 1080p
+    s3 = cs.config3_scene()
+    g3 = GScene(s3)
+    W, H = cs.SCREEN
+    depth = cs.config3_depth(cam)
+    ev0, mv0 = cs.frame0_bits(oracle, s3, cam, depth)
+    ci1, ci2 = cs.two_pass_cull_infos(cam)
+    d = depth_pyramid_desc(W, H)
+    ps = (d.width, d.height)
+    h3 = [a for a in (s3.entity_draw_buffer(), s3.mesh_infos, s3.entities, s3.meshlets, s3.materials)]
+
+    def cpu_frame():
+        d1, w1, _, _, _ = oracle.cull_frame_mt(ci1, h3[0], s3.entity_draw_count, h3[1], h3[2], h3[3], h3[4], g3.cap_d,
+                                               g3.cap_c, threads, visibility=ev0, meshlet_visibility=mv0, native=True)
+        opyr, _ = oracle.depth_reduce(depth, W, H)
+        d2, w2, e2, m2, _ = oracle.cull_frame_mt(ci2, h3[0], s3.entity_draw_count, h3[1], h3[2], h3[3], h3[4], g3.cap_d,
+                                                 g3.cap_c, threads, visibility=ev0, meshlet_visibility=mv0, pyramid=opyr,
+                                                 pyramid_size=ps, native=True)
+        return d1, w1, d2, w2, e2, m2, opyr
+
+    cpu_s, reps, (od1, ow1, od2, ow2, oe2, om2, opyr) = cpu_time(cpu_frame)
+    nd1, nm1, ndraw1 = counts(od1, ow1)
+    nd2, nm2, ndraw2 = counts(od2, ow2)
+    mips = sum(d.mip_width[k] * d.mip_height[k] for k in range(d.mip_levels))
+    reduce_bytes = 4 * (W * H + 2 * mips - 1)
+    c3 = {"workload": f"config 3 (Bistro-class stand-in): {s3.entity_draw_count} entities, {s3.lod0_meshlets} meshlets LOD 0, "
+                      f"{W}x{H}, K = 64 occluders + ground; frame = pass-1 cull (bits of the oracle's frame 0) -> "
+                      f"depth_reduce -> pass-2 cull",
+          "pass1": {"dispatch_records": nd1, "meshlets_into_meshlet_cull": nm1, "draw_commands": ndraw1},
+          "pass2": {"dispatch_records": nd2, "meshlets_into_meshlet_cull": nm2, "draw_commands": ndraw2},
+          "algorithmic_bytes": cull_bytes(s3.entity_draw_count, nm1, nd1, ndraw1, occlusion=True) + reduce_bytes
+                               + cull_bytes(s3.entity_draw_count, nm2, nd2, ndraw2, tested=nm2, occlusion=True),
+          "depth_reduce_algorithmic_bytes": reduce_bytes, "gpu": {}}
+    ok = True
+    gdepth = dev(depth).view(torch.float32)
+    for path in PATHS:
+        eng = engine_for(path, g3)
+        evis, mvis = dev(ev0), dev(mv0)
+        ev_keep, mv_keep = evis.clone(), mvis.clone()
+        pyr = torch.zeros(d.total_texels, dtype=torch.float32, device="cuda")
+        v1, disp1, draw1 = g3.view(ci1, evis, mvis)
+        v2, disp2, draw2 = g3.view(ci2, evis, mvis, pyr, ps)
+        a1, k1 = eng.prepare_views([v1])
+        a2, k2 = eng.prepare_views([v2])
+
+        def frame():
+            # (the bits go back to the previous frame's before every frame: pass 2 rewrites them)
+            evis.copy_(ev_keep)
+            mvis.copy_(mv_keep)
+            eng.cull_views_prepared(a1)
+            eng.depth_reduce(gdepth, W, H, pyr)
+            eng.cull_views_prepared(a2)
+
+        def reset_only():
+            evis.copy_(ev_keep)
+            mvis.copy_(mv_keep)
+
+        r = {"pass1_cull_ms": timeit(lambda: eng.cull_views_prepared(a1)),
+             "depth_reduce_ms": timeit(lambda: eng.depth_reduce(gdepth, W, H, pyr))}
+        reset_ms = timeit(reset_only)
+        r["two_pass_frame_ms"] = timeit(frame) - reset_ms
+        gr = graph_of(frame)
+        r["two_pass_frame_graph_replay_ms"] = timeit(gr.replay) - reset_ms
+        r["bits_reset_ms_subtracted"] = reset_ms
+        frame()
+        torch.cuda.synchronize()
+        eng.status()
+        ok = ok and same(host(disp1), host(draw1), od1, ow1) and same(host(disp2), host(draw2), od2, ow2)
+        ok = ok and np.array_equal(host(evis, np.uint32), oe2) and np.array_equal(host(mvis, np.uint32), om2)
+        ok = ok and np.array_equal(host(pyr, np.uint32), opyr.view(np.uint32).reshape(-1))
+        c3["gpu"][path] = r
+        del gr
+        eng.close()
+    best = min(v["two_pass_frame_ms"] for v in c3["gpu"].values())
+    c3["gpu_output_bit_identical"] = bool(ok)
+    c3["meshlets_per_sec"] = (nm1 + nm2) / (best * 1e-3)
+    c3["achieved_GBps"] = c3["algorithmic_bytes"] / (best * 1e-3) / 1e9
+    c3["cpu_baseline"] = {"ms": cpu_s * 1e3, "value": (nm1 + nm2) / cpu_s, "unit": "meshlets/s", "cores": threads,
+                          "kind": "port", "sample": f"the whole frame (both culls on {threads} threads, depth_reduce on one), {reps} runs"}
+    out["config3"] = c3
+
+    # ---------------------------------------------------------------- config 4: + 10 000 lights, clustered binning
+    push, info, lights = cs.config4_inputs(oracle, cam)
+    cx, cy, cz = cs.CLUSTERS
+    total = cx * cy * cz
+    cap = cx * cy * max(4, cz)
+    lcap = total * 32
+    t0 = time.perf_counter()
+    om, ob = oracle.cluster_mark(push, depth)
+    t_mark = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ou, _ = oracle.cluster_compact((cx, cy, cz), om, cap)
+    t_compact = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ol, oimg, _ = oracle.cluster_assign(info, ou, ob, lights, lcap, total)
+    t_assign = time.perf_counter() - t0
+    n_active, n_idx = int(ou[12:16].view(np.uint32)[0]), int(ol[:4].view(np.uint32)[0])
+    eng = Engine(0, max_lights=12_000, max_clusters=total)
+    gm = torch.zeros(cx * cy, dtype=torch.int32, device="cuda")
+    gb = torch.zeros((total, 2), dtype=torch.int32, device="cuda")
+    gu = torch.zeros(16 + 4 * cap, dtype=torch.uint8, device="cuda")
+    gl = torch.zeros(4 + 4 * lcap, dtype=torch.uint8, device="cuda")
+    gimg = torch.zeros((total, 2), dtype=torch.int32, device="cuda")
+    glights = dev(lights)
+    c4 = {"workload": f"config 4: config 3's {W}x{H} depth, {cs.N_LIGHTS} point lights, {cx}x{cy}x{cz} = {total} clusters "
+                      f"(8-px tiles, far {cs.CLUSTER_FAR:g}); mark_active -> compaction -> light assignment",
+          "active_clusters": n_active, "light_indices": n_idx, "gpu": {}}
+    c4["gpu"]["mark_ms"] = timeit(lambda: eng.cluster_mark(push, gdepth, gm, gb))
+    c4["gpu"]["compact_ms"] = timeit(lambda: eng.cluster_compact((cx, cy, cz), gm, gu, cap))
+    c4["gpu"]["assign_ms"] = timeit(lambda: eng.cluster_assign(info, gu, gb, glights, gl, lcap, gimg), n=20, warm=3)
+    whole = lambda: eng.compute_clusters(push, info, gdepth, glights, gm, gb, gu, cap, gl, lcap, gimg)  # noqa: E731
+    c4["gpu"]["compute_clusters_ms"] = timeit(whole)
+    gr = graph_of(whole)
+    c4["gpu"]["compute_clusters_graph_replay_ms"] = timeit(gr.replay)
+    torch.cuda.synchronize()
+    eng.status()
+    act = ou[16:16 + 4 * n_active].view(np.uint32)
+    c4["gpu_output_bit_identical"] = bool(
+        np.array_equal(host(gm, np.uint32), om) and np.array_equal(host(gb, np.uint32).reshape(-1, 2), ob)
+        and np.array_equal(host(gu)[:16 + 4 * n_active], ou[:16 + 4 * n_active])
+        and np.array_equal(host(gl)[:4 + 4 * n_idx], ol[:4 + 4 * n_idx])
+        and np.array_equal(host(gimg, np.uint32).reshape(-1, 2)[act], oimg[act]))
+    # mark_active 4 W H samples + 4 tiles + 8 clusters touched; the assignment is priced in tests
+    touched = int((ob.reshape(-1, 2) != 0).any(axis=1).sum())
+    c4["mark_algorithmic_bytes"] = 4 * W * H + 4 * cx * cy + 8 * touched
+    c4["mark_achieved_GBps"] = c4["mark_algorithmic_bytes"] / (c4["gpu"]["mark_ms"] * 1e-3) / 1e9
+    ref_tests = 2.0 * n_active * cs.N_LIGHTS  # what light_culling.comp runs (count loop + write loop, :121-147)
+    c4["reference_sphere_box_tests"] = ref_tests
+    c4["reference_equivalent_tests_per_sec"] = ref_tests / (c4["gpu"]["assign_ms"] * 1e-3)
+    c4["cpu_baseline"] = {"ms": (t_mark + t_compact + t_assign) * 1e3, "mark_ms": t_mark * 1e3, "compact_ms": t_compact * 1e3,
+                          "assign_ms": t_assign * 1e3, "value": ref_tests / t_assign, "unit": "sphere-box tests/s (assign)",
+                          "cores": 1, "kind": "port", "sample": "the whole workload, one run of oracle/orbit_oracle.c (scalar, one thread)"}
+    out["config4"] = c4
+    eng.close()
     print(json.dumps(out, indent=1))
+
 
 main()
