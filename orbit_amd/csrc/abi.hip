@@ -281,7 +281,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t o_eproto = carve(ent * sizeof(OrbitMeshletDispatch));
     const size_t o_ebs = carve(eblocks * 4), o_et = carve(256);
     const size_t o_mtc = carve(mtiles * 4), o_mtb = carve(mtiles * 4), o_mt = carve(256);
-    const size_t o_ftf = carve(mtiles * 4);
+    const size_t o_ftf = carve(((size_t)caps.max_dispatches / 4 + 2) * 4); // one flag per tile of 4 records (cull_fused.hip)
     const size_t o_xbp = carve((size_t)kExpandBlocks * 4);
     const size_t o_mtm = carve(mtiles * 64);
     const size_t o_mtp = carve(mtiles * 128 * sizeof(Payload));

@@ -37,7 +37,12 @@ namespace orbit {
 namespace {
 
 constexpr uint32_t kFusedWaves = 4;                // = kEntityBlock / 64
-constexpr uint32_t kFusedCap = kTileRecords * 32u; // survivors a tile can have: its payload slab holds them all
+// A wave's unit of meshlet work here is the first ROWS rows of a wave tile (2 ROWS records): 8 rows (the launches' tile)
+// for larger scenes, 2 rows for the small ones — a lone wave evaluates a row in ~0.75 us (nothing else on its SIMD hides
+// its LDS reads and dependent arithmetic: 6.1 us for 8 rows, measured with the stamps below), so a scene of a few
+// hundred records is better cut into four times as many tiles on four times as many waves.
+constexpr uint32_t fused_tile_records(int rows) { return 2u * (uint32_t)rows; }
+constexpr uint32_t kFusedSmallEntityDraws = 4096; // views of up to this many entity-draws take the 2-row tiles
 #ifndef ORBIT_FUSED_SPIN_LOG2
 #define ORBIT_FUSED_SPIN_LOG2 18
 #endif
@@ -80,6 +85,12 @@ __device__ __forceinline__ uint32_t ticket(uint32_t *counter) {
 // compiler cannot see that a word read from LDS behind a barrier is uniform, and wraps what follows — barriers
 // included — in divergent-loop bookkeeping)
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// the entity phase's arrival word: chunks that have their records in memory << 32 | records so far — one atomic per
+// chunk, one 8-B poll tells a waiting workgroup both "all chunks are in" and the total
+__device__ __forceinline__ unsigned long long arrive(uint32_t *word, uint32_t records) {
+    return __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(word), 1ull << 32 | records, __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -144,16 +155,21 @@ __device__ __forceinline__ uint32_t tiles_before(const FusedCullParams &p, __amd
 // -DORBIT_FUSED_DEBUG builds only (tools/fused_probe.py): progress marks, written through so that a copy engine can
 // read them while the launch is still running
 #ifdef ORBIT_FUSED_DEBUG
+// (-DORBIT_FUSED_DEBUG=2: the time of the mark, 100 MHz ticks, instead of its value)
 #define FUSED_MARK(stage, value)                                                                                        \
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 256u)                                                                    \
     __hip_atomic_store(p.m.debug_cycles + 64 + (blockIdx.x * 4u + (threadIdx.x >> 6)) * 8u + (stage),                   \
-                       (unsigned long long)(value) | 1ull << 63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                       (ORBIT_FUSED_DEBUG >= 2 ? (unsigned long long)wall_clock64() : (unsigned long long)(value)) |     \
+                           1ull << 63,                                                                                   \
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #else
 #define FUSED_MARK(stage, value)
 #endif
 
-template <int PASS, int PROJ>
+template <int PASS, int PROJ, int ROWS>
 __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
+    constexpr uint32_t kRecs = fused_tile_records(ROWS); // records per tile
+    constexpr uint32_t kFusedCap = kRecs * 32u;          // survivors a tile can have: its payload slab holds them all
     __shared__ PlaneLds planes;
     __shared__ AlphaLds alpha_tab;
     __shared__ uint32_t smem[kFusedWaves + 1];
@@ -165,7 +181,7 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
     __shared__ uint32_t s_cmd[kFusedWaves][64 * 7];
     __shared__ uint32_t s_word[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t max_tiles = (p.m.dispatch_capacity + kTileRecords - 1u) / kTileRecords;
+    const uint32_t max_tiles = (p.m.dispatch_capacity + kRecs - 1u) / kRecs;
     const __amdgpu_buffer_rsrc_t SY = rsrc_of(p.sync, kFusedSyncWords * 4u);
     const __amdgpu_buffer_rsrc_t EF = rsrc_of(p.ent_flags, p.ne_chunks * 4u);
     const __amdgpu_buffer_rsrc_t TF = rsrc_of(p.tile_flags, max_tiles * 4u);
@@ -174,6 +190,16 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
     const __amdgpu_buffer_rsrc_t REC_W = rsrc_of(dispatch_buffer + ORBIT_DISPATCH_HEADER, p.e_dispatch_capacity * 16u);
     const FusedEntity E{p.m.ci, p.entity_draw_buffer, p.mesh_infos, p.m.entities, p.visibility, p.e_pyr};
 
+    // The parameter block lives in the kernel-argument segment and is read with scalar loads where it is used; a line
+    // of it that no wave of the CU has touched yet is a full memory round trip, paid in the middle of whichever phase
+    // touches it first.  One word of every 64-B line now, all in flight together under the first ticket's round trip.
+    {
+        const uint32_t *words = reinterpret_cast<const uint32_t *>(&p);
+        uint32_t touch = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < sizeof(FusedCullParams) / 4u; i += 16u) touch |= words[i];
+        asm volatile("" ::"s"(touch));
+    }
     planes_to_lds(p.m, planes);
     const AlphaLds *alpha = alpha_table_fill(p.m, alpha_tab) ? &alpha_tab : nullptr;
     const uint32_t draw_count = *reinterpret_cast<const uint32_t *>(p.entity_draw_buffer);
@@ -218,8 +244,10 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
         __syncthreads(); // every wave's records are in memory; s_off / s_proto may be rewritten
         FUSED_MARK(3, eb);
         if (threadIdx.x == 0) {
-            if (eb == p.ne_chunks - 1u) { // the last chunk knows the total: the {x,1,1} header (draw_gen.rs:356-363)
-                const uint32_t total = base + chunk_total;
+            // behind the drain above: "this chunk's records are in memory"
+            const unsigned long long before = arrive(p.sync + kSyEntDone, chunk_total);
+            if ((uint32_t)(before >> 32) == p.ne_chunks - 1u) { // the last chunk in: the {x,1,1} header (draw_gen.rs:356-363)
+                const uint32_t total = (uint32_t)before + chunk_total;
                 uint32_t *hdr = reinterpret_cast<uint32_t *>(dispatch_buffer);
                 hdr[0] = min(total, p.e_dispatch_capacity);
                 hdr[1] = 1u;
@@ -231,10 +259,7 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
                     *reinterpret_cast<uint32_t *>(p.m.draw_buffer) = 0u;
                     *p.m.total = 0u;
                 }
-                st_sc1(SY, kSyTotal * 4u, total + 1u);
-                drain_stores();
             }
-            (void)ticket(p.sync + kSyEntDone); // behind the drains above: "this chunk's records are in memory"
             s_word[0] = ticket(p.sync + kSyEntTicket);
         }
         __syncthreads();
@@ -243,24 +268,28 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
     }
 
     // ---------------------------------------------------------------- every record is in memory
+    // (the first tile tickets are drawn before the wait: their round trip runs under the poll; workgroups that had
+    // entity chunks arrive last and draw the highest tickets, so no low tile waits behind a busy workgroup)
+    // ONE atomic per workgroup for its waves' first tickets (a returning atomic on one word serves ~88 per us on this
+    // chip: a ticket per wave of a few hundred workgroups was microseconds of queueing in front of every tile)
     if (threadIdx.x == 0) {
-        uint32_t done = ld_sc1(SY, kSyEntDone * 4u);
-        for (uint32_t spins = 0; done < p.ne_chunks; spins++) {
+        s_word[0] = __hip_atomic_fetch_add(p.sync + kSyTileTicket, kFusedWaves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        auto w = __builtin_amdgcn_raw_buffer_load_b64(SY, kSyEntDone * 4u, 0, kSc1);
+        for (uint32_t spins = 0; w[1] < p.ne_chunks; spins++) {
             if (spins == kSpinLimit) {
                 latch_status(p.m.status, ORBIT_E_TIMEOUT);
                 break;
             }
             poll_pause();
-            done = ld_sc1(SY, kSyEntDone * 4u);
+            w = __builtin_amdgcn_raw_buffer_load_b64(SY, kSyEntDone * 4u, 0, kSc1);
         }
-        // stored and drained before the last chunk signalled
-        const uint32_t total1 = ld_sc1(SY, kSyTotal * 4u);
-        s_word[1] = total1 != 0u ? total1 - 1u : 0u;
+        s_word[1] = w[0];
     }
     __syncthreads();
+    uint32_t t_next = uniform(s_word[0]) + (uint32_t)wave;
     const uint32_t nrec = min(uniform(s_word[1]), min(p.e_dispatch_capacity, p.m.dispatch_capacity));
     FUSED_MARK(4, nrec);
-    const uint32_t ntiles = (nrec + kTileRecords - 1u) / kTileRecords;
+    const uint32_t ntiles = (nrec + kRecs - 1u) / kRecs;
     const __amdgpu_buffer_rsrc_t REC_R = rsrc_of(p.m.dispatch_buffer + ORBIT_DISPATCH_HEADER, nrec * 16u);
 
     // ---------------------------------------------------------------- tiles (meshlet_cull.comp:108-255)
@@ -270,25 +299,40 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
     uint32_t *cmd = s_cmd[wave];
     uint32_t *out = reinterpret_cast<uint32_t *>(p.m.draw_buffer + ORBIT_DRAW_HEADER);
     for (;;) {
-        uint32_t t = 0;
-        if (lane == 0) t = ticket(p.sync + kSyTileTicket);
-        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        const uint32_t t = uniform(t_next);
         FUSED_MARK(5, t);
         if (t >= ntiles) break;
         // the tile's 16 records (lane = record * 4 + matrix column; past the last record: zeros), matrices, slab
-        const uint32_t rec_index = t * kTileRecords + ((uint32_t)lane >> 2);
-        const auto rw = __builtin_amdgcn_raw_buffer_load_b128(REC_R, rec_index < nrec ? rec_index * 16u : kNoOffset, 0, kSc1);
+        const uint32_t rec_index = t * kRecs + ((uint32_t)lane >> 2);
+        const bool has_rec = ((uint32_t)lane >> 2) < kRecs && rec_index < nrec;
+        const auto rw = __builtin_amdgcn_raw_buffer_load_b128(REC_R, has_rec ? rec_index * 16u : kNoOffset, 0, kSc1);
         const uint4 rec = make_uint4(rw[0], rw[1], rw[2], rw[3]);
+#if defined(ORBIT_FUSED_DEBUG) && ORBIT_FUSED_DEBUG == 3
+        FUSED_MARK(0, t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FUSED_MARK(1, t);
+#endif
+        // The rows need the records only (meshlet offset and count), not the matrices: records into the slab first, then
+        // the rows' loads and the matrix loads go out TOGETHER — one memory round trip instead of two (in the streaming
+        // evaluation a software pipeline hides this dependence; a one-tile wave has nothing to hide it behind).
+        if ((lane & 3) == 0) L.r[lane >> 2].rec = rec;
+        wave_lds_fence();
+        // all eight rows at once
+        RowRegs<ROWS> q;
+        rows_load<PASS, 0, ROWS>(p.m, L, lane, q);
         const float4 mat = setup_load_mat(p.m, rec, lane);
         setup_write(p.m, L, rec, mat, lane);
-        // all eight rows at once: one memory round trip per tile
-        RowRegs<(int)kTileRows> q;
-        rows_load<PASS, 0, (int)kTileRows>(p.m, L, lane, q);
+#if defined(ORBIT_FUSED_DEBUG) && ORBIT_FUSED_DEBUG == 3
+        FUSED_MARK(2, t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FUSED_MARK(3, t);
+#endif
+        if (lane == 0) t_next = ticket(p.sync + kSyTileTicket); // the next one, under this tile's evaluation
         CandState cs; // cs.total = the tile's survivor count
         if (occ2) {
             if constexpr (PASS == 2) {
 #define ORBIT_FUSED_ROW(R)                                                                                             \
-    {                                                                                                                  \
+    if constexpr (R < ROWS) {                                                                                          \
         RowRegs<1> q1;                                                                                                 \
         q1.a[0] = q.a[R], q1.b[0] = q.b[R], q1.prev[0] = q.prev[R];                                                    \
         row_eval_occ<PROJ, R, kCandRing, false, kFusedCap>(p.m, L, planes, alpha, ring[wave], lane, q1, cs, pay);      \
@@ -299,7 +343,7 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
                 tile_finish_occ<kCandRing, kFusedCap>(p.m, L, ring[wave], lane, cs, pay);
             }
         } else {
-            cs.total = rows_eval<PASS, PROJ, 0, (int)kTileRows, false, kFusedCap>(p.m, L, planes, alpha, lane, q, 0u, pay);
+            cs.total = rows_eval<PASS, PROJ, 0, ROWS, false, kFusedCap, false>(p.m, L, planes, alpha, lane, q, 0u, pay);
         }
         const uint32_t n = cs.total;
         FUSED_MARK(6, n);
@@ -357,24 +401,24 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
     if (uniform(s_word[0]) != 0u) { // every other workgroup has made its last access to them
         for (uint32_t i = threadIdx.x; i < p.ne_chunks; i += kEntityBlock) p.ent_flags[i] = 0u;
         for (uint32_t i = threadIdx.x; i < ntiles; i += kEntityBlock) p.tile_flags[i] = 0u;
-        if (threadIdx.x < kFusedSyncWords / 32u) p.sync[threadIdx.x * 32u] = 0u;
+        if (threadIdx.x < kFusedSyncWords) p.sync[threadIdx.x] = 0u;
     }
 }
 
 // blockIdx.y = view (orbit_cull_views: one or several), every view on flags of its own.  The parameter blocks travel by
 // value in the kernel-argument segment and are read at a uniform offset (scalar loads, as needed): the single-view
 // form with the whole block in scalar registers spilled 67-86 of them.
-template <int PASS, int PROJ>
+template <int PASS, int PROJ, int ROWS>
 __global__ __launch_bounds__(kEntityBlock, 2) void cull_fused_views_kernel(const FusedCullViews all, const ViewGroup g) {
-    cull_fused_body<PASS, PROJ>(all.v[g.idx[blockIdx.y]]);
+    cull_fused_body<PASS, PROJ, ROWS>(all.v[g.idx[blockIdx.y]]);
 }
 
-// Workgroups of one view: a wave per expected tile (a record per entity-draw or so: a wave per 8 entity-draws is
-// plenty), a workgroup per entity chunk at least, never more than two per CU: the tickets make any number right, this
-// one makes the tiles one round.
-uint32_t fused_grid(uint32_t entity_draw_count, uint32_t num_cus) {
+// Workgroups of one view: a wave per expected tile (a record per entity-draw or so), a workgroup per entity chunk at
+// least, never more than two per CU: the tickets make any number right, this one makes the tiles one round.
+uint32_t fused_grid(uint32_t entity_draw_count, uint32_t rows, uint32_t num_cus) {
     const uint32_t chunks = (entity_draw_count + kEntityBlock - 1u) / kEntityBlock;
-    const uint32_t waves = (entity_draw_count + 7u) / 8u;
+    // a tile is 2 x rows records, and scenes have about a record per entity-draw, fewer after the entity test
+    const uint32_t waves = (entity_draw_count + 2u * rows - 1u) / (2u * rows);
     return max(min(max(chunks, (waves + kFusedWaves - 1u) / kFusedWaves), num_cus * 2u), 1u);
 }
 
@@ -396,17 +440,26 @@ hipError_t launch_cull_fused_views(const FusedCullViews &all, const uint32_t *en
                 most = max(most, entity_draw_counts[j]);
             }
         // the views share the device: each gets its part of the two-workgroups-per-CU budget
-        const dim3 grid(fused_grid(most, max(num_cus / m, 1u)), m), block(kEntityBlock);
+#ifdef ORBIT_FUSED_FORCE_ROWS
+        const uint32_t rows = ORBIT_FUSED_FORCE_ROWS;
+#else
+        const uint32_t rows = most <= kFusedSmallEntityDraws ? 2u : 8u;
+#endif
+        const dim3 grid(fused_grid(most, rows, max(num_cus / m, 1u)), m), block(kEntityBlock);
         const bool ortho = proj == 1;
-#define ORBIT_FUSED(PASS)                                                                              \
-    if (ortho) hipLaunchKernelGGL((cull_fused_views_kernel<PASS, 1>), grid, block, 0, s, all, g);      \
-    else hipLaunchKernelGGL((cull_fused_views_kernel<PASS, 0>), grid, block, 0, s, all, g);
+#define ORBIT_FUSED_R(PASS, ROWS)                                                                            \
+    if (ortho) hipLaunchKernelGGL((cull_fused_views_kernel<PASS, 1, ROWS>), grid, block, 0, s, all, g);      \
+    else hipLaunchKernelGGL((cull_fused_views_kernel<PASS, 0, ROWS>), grid, block, 0, s, all, g);
+#define ORBIT_FUSED(PASS)                      \
+    if (rows == 2u) { ORBIT_FUSED_R(PASS, 2) } \
+    else { ORBIT_FUSED_R(PASS, 8) }
         switch (pass) {
         case 0: ORBIT_FUSED(0) break;
         case 1: ORBIT_FUSED(1) break;
         default: ORBIT_FUSED(2) break;
         }
 #undef ORBIT_FUSED
+#undef ORBIT_FUSED_R
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

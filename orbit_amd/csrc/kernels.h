@@ -178,8 +178,9 @@ struct ClusterAssignParams {
 // One-launch cull (cull_fused.hip): entity stage and meshlet stage of one view in one persistent kernel.  The meshlet
 // side is the launches' parameter block (Meshlet buffer only: m.ms empty, no task records, no visible list); the entity
 // side adds what entity_cull reads besides (ci, entities and the dispatch buffer are m's).
-constexpr uint32_t kSyEntTicket = 0, kSyEntDone = 32, kSyTotal = 64, kSyTileTicket = 96, kSyBlocksDone = 128;
-constexpr uint32_t kFusedSyncWords = 160; // the five counters above, each on a 128-B line of its own
+// kSyEntDone is 8 bytes: chunks whose records are in memory << 32 | records so far (word 32: the records, word 33: the chunks)
+constexpr uint32_t kSyEntTicket = 0, kSyEntDone = 32, kSyTileTicket = 96, kSyBlocksDone = 128;
+constexpr uint32_t kFusedSyncWords = 160; // the counters above, each on a 128-B line of its own
 constexpr uint32_t kFusedMaxEntityDraws = 16384; // culls of more entity-draws take the launches (abi.hip)
 struct FusedCullParams {
     MeshletCullParams m;

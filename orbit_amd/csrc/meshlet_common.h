@@ -228,7 +228,7 @@ __device__ __forceinline__ Payload make_payload(uint32_t ml, uint32_t rid, const
 // w = 0 term of the cone-axis transform is +-0, which no comparison sees; and a finite view-space centre is what the
 // shortened plane tests of the symmetric frustum need (planes_std).  One non-finite lane (its products with 0 are NaN
 // in the reference's arithmetic) sends the whole row down the literal path.
-template <int PROJ>
+template <int PROJ, bool FENCE = true>
 __device__ __forceinline__ uint64_t eval_geometry_mask(const MeshletCullParams &p, const WaveTileLds &L,
                                                        const PlaneLds &P, uint32_t rid, const uint4 &a, const uint4 &b,
                                                        Sphere &s, bool affine_row = false) {
@@ -258,8 +258,9 @@ __device__ __forceinline__ uint64_t eval_geometry_mask(const MeshletCullParams &
     s.r = __uint_as_float(a.w) * R.scale;
 
     // keeps the scheduler from hoisting the cone test's and the plane loop's LDS reads above the sphere transform:
-    // without it the class variant of the evaluation holds 128 registers and spills (profiles/r03_notes.md)
-    __builtin_amdgcn_sched_barrier(0);
+    // without it the class variant of the evaluation holds 128 registers and spills (profiles/r03_notes.md).
+    // (FENCE = false: the one-launch cull — a lone wave per SIMD with registers to spare wants exactly that hoisting)
+    if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
     // The cone test (:148-158) does not depend on the plane loop: both are evaluated
     // and combined, which gives the scheduler two independent chains per meshlet.
     uint64_t cull;
@@ -360,7 +361,7 @@ __device__ __forceinline__ void rows_load(const MeshletCullParams &p, const Wave
 // exists (:111), passes the geometry tests and its material the :207 test.  Every lane evaluates — lanes past
 // meshlet_count hold zeros, which are finite and harmless — and the verdict is masked: no divergent region around a
 // row.
-template <int PASS, int PROJ, int R0, int NR, bool CLS = false, uint32_t CAP = kPayloadCap>
+template <int PASS, int PROJ, int R0, int NR, bool CLS = false, uint32_t CAP = kPayloadCap, bool FENCE = true>
 __device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTileLds &L, const PlaneLds &P,
                                               const AlphaLds *A, int lane, const RowRegs<NR> &t, uint32_t total,
                                               Payload *payload) {
@@ -389,7 +390,7 @@ __device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTi
         const uint64_t geo = ballot(((t.a[k].x + (t.b[k].x >> 31)) % 1000u) < 95u);
 #else
         Sphere s;
-        const uint64_t geo = eval_geometry_mask<PROJ>(p, L, P, rid, t.a[k], t.b[k], s, row_is_affine(L, r));
+        const uint64_t geo = eval_geometry_mask<PROJ, FENCE>(p, L, P, rid, t.a[k], t.b[k], s, row_is_affine(L, r));
 #endif
         const uint64_t mask = geo & allow;
         if (lane == 0) L.draw_mask[r] = mask;

@@ -90,7 +90,9 @@ def test_config3_two_pass_frame_1080p_64_occluders(torch_mod, oracle, path):
     _, c1 = assert_same((host(disp1), host(draw1), None, None), r1[:2] + (None, None))
     r2 = run_oracle(oracle, scene, ci2, ev0, mv0, opyr, ps)
     _, c2 = assert_same((host(disp2), host(draw2), host(evis, np.uint32), host(mvis, np.uint32)), r2)
-    assert len(c1) > 0 and len(c2) > 0, (len(c1), len(c2))
+    # (a static camera: pass 2 finds nothing NEWLY visible behind frame 0's own bits — it still tests every record of
+    # every entity against the pyramid and rewrites both bitsets, which is what the comparison above covers)
+    assert len(c1) > 0 and int(host(disp2)[:4].view(np.uint32)[0]) > 0, (len(c1), len(c2))
     eng.close()
 
 

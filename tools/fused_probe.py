@@ -32,6 +32,14 @@ def marks(eng):
     rc = DBG.orbit_debug_read_fused_marks(eng._ctx, out.ctypes.data)
     rows = out.reshape(-1, 8)
     names = ["ent ticket", "chunk total", "base", "records out", "nrec", "tile ticket", "tile count", "left"]
+    if os.environ.get("ORBIT_FUSED_STAMPS") == "1":  # a -DORBIT_FUSED_DEBUG=2 build: times, us from the first mark
+        vals = rows & np.uint64(0x7FFFFFFFFFFFFFFF)
+        t0 = int(vals[rows >> np.uint64(63) != 0].min())
+        for w, r in enumerate(rows):
+            if r.any():
+                print(f"  block {w // 4:3d} wave {w % 4}: " + ", ".join(
+                    f"{n}={(int(v & 0x7FFFFFFFFFFFFFFF) - t0) / 100.0:6.2f}" for n, v in zip(names, r) if v >> 63), flush=True)
+        return rc
     for w, r in enumerate(rows):
         if r.any():
             print(f"  block {w // 4} wave {w % 4}: " + ", ".join(
@@ -77,12 +85,9 @@ for name, path in (("chain", 1), ("fused", 2)):
         say(name, "launch", r)
         t = time.time()
         eng.cull_views([v])
-        if DBG is not None and name == "fused":
-            time.sleep(1.5)
-            say("marks 1.5 s after the launch (rc", marks(eng), ")")
-            if not torch.cuda.current_stream().query():
-                say("the launch is still running: leaving")
-                os._exit(3)
+        if DBG is not None and name == "fused" and r == reps - 1:
+            time.sleep(1.0)
+            say("marks 1 s after the launch (rc", marks(eng), ")")
         torch.cuda.synchronize()
         say(name, "done in", f"{(time.time() - t) * 1e3:.2f} ms")
         try:
