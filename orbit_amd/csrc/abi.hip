@@ -58,8 +58,7 @@ struct OrbitCtx {
     // scratch (device)
     uint8_t *arena = nullptr;
     size_t arena_bytes = 0;
-    OrbitMeshletDispatch *e_proto = nullptr;
-    uint32_t *e_block_sums = nullptr, *e_total = nullptr;
+    uint32_t *e_total = nullptr;
     Payload *m_tile_payload = nullptr;
     uint32_t *m_tile_masks = nullptr, *m_chunk_sums = nullptr;
     uint32_t *m_tile_counts = nullptr, *m_tile_base = nullptr, *m_total = nullptr;
@@ -263,7 +262,6 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
 
     // one arena for all scan scratch, carved at 256-B alignment
     const size_t ent = align_up((size_t)caps.max_entities, 256);
-    const size_t eblocks = ent / 256 + 1;
     const size_t mtiles = ((size_t)caps.max_dispatches + kTileRecords - 1) / kTileRecords + 1;
     const size_t cchunks = ((size_t)caps.max_clusters / 1024 + 64) * 32;
     size_t off = 0;
@@ -278,8 +276,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t o_gc = carve(256);
     const size_t o_tk = carve(kTicketPools * kTicketStride * 4);
     const size_t o_fsy = carve(kFusedSyncWords * 4), o_fef = carve((ent / 256 + 2) * 4);
-    const size_t o_eproto = carve(ent * sizeof(OrbitMeshletDispatch));
-    const size_t o_ebs = carve(eblocks * 4), o_et = carve(256);
+    const size_t o_et = carve(256);
     const size_t o_mtc = carve(mtiles * 4), o_mtb = carve(mtiles * 4), o_mt = carve(256);
     const size_t o_ftf = carve(((size_t)caps.max_dispatches / 4 + 2) * 4); // one flag per tile of 4 records (cull_fused.hip)
     const size_t o_xbp = carve((size_t)kExpandBlocks * 4);
@@ -316,8 +313,6 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->status = (int32_t *)(a + o_status);
     ctx->debug_cycles = (unsigned long long *)(a + o_dbg);
     ctx->zero_page = (void *)(a + o_zero);
-    ctx->e_proto = (OrbitMeshletDispatch *)(a + o_eproto);
-    ctx->e_block_sums = (uint32_t *)(a + o_ebs);
     ctx->e_total = (uint32_t *)(a + o_et);
     ctx->m_tile_counts = (uint32_t *)(a + o_mtc);
     ctx->m_tile_base = (uint32_t *)(a + o_mtb);
@@ -523,8 +518,9 @@ static int32_t entity_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitG
                                        : ((uint64_t)entity_draw_count + 255u) / 256u * 256u;
     p.draw_limit = limit > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)limit;
     p.dispatch_capacity = b->dispatch_capacity;
-    p.proto = scratch->e_proto;
-    p.block_sums = scratch->e_block_sums;
+    p.ne_chunks = (entity_draw_count + 255u) / 256u;
+    p.sync = scratch->f_sync;
+    p.ent_flags = scratch->f_ent_flags;
     p.total = scratch->e_total;
     p.status = scratch->status;
     return ORBIT_OK;
@@ -537,7 +533,7 @@ static int32_t entity_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const
     EntityCullParams p;
     const int32_t rc = entity_cull_params(ctx, ctx, ci, b, draw_first, entity_draw_count, exact_range, p);
     if (rc) return rc;
-    const hipError_t e = launch_entity_cull(p, entity_draw_count, (hipStream_t)stream);
+    const hipError_t e = launch_entity_cull(p, entity_draw_count, ctx->num_cus, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch entity_cull");
     return ORBIT_OK;
 }
@@ -737,7 +733,7 @@ int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t cou
         ctx->fused_culls += count;
         return ORBIT_OK;
     }
-    e = launch_entity_cull_views(ev, count, max_draws, s);
+    e = launch_entity_cull_views(ev, count, max_draws, ctx->num_cus, s);
     if (e == hipSuccess) e = launch_meshlet_cull_views(mv, n_mesh, ctx->num_cus, s);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch cull_views");
     for (uint32_t i = 0; i < n_mesh; i++)

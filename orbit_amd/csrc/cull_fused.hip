@@ -30,6 +30,7 @@
 // small is bound by latency, not by bytes, and the survivors' command words are then already in the row registers.
 // Outputs are bit-identical to the launches' (tests/test_fused_gpu.py).
 #include "entity_common.h"
+#include "handoff.h"
 #include "meshlet_common.h"
 
 namespace orbit {
@@ -43,17 +44,7 @@ constexpr uint32_t kFusedWaves = 4;                // = kEntityBlock / 64
 // hundred records is better cut into four times as many tiles on four times as many waves.
 constexpr uint32_t fused_tile_records(int rows) { return 2u * (uint32_t)rows; }
 constexpr uint32_t kFusedSmallEntityDraws = 4096; // views of up to this many entity-draws take the 2-row tiles
-#ifndef ORBIT_FUSED_SPIN_LOG2
-#define ORBIT_FUSED_SPIN_LOG2 18
-#endif
-constexpr uint32_t kSpinLimit = 1u << ORBIT_FUSED_SPIN_LOG2; // polls before a wait gives up (a good fraction of a second; a hop takes microseconds)
 static_assert(kFusedWaves * 64 == kEntityBlock, "one block shape for both phases");
-
-typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-constexpr int kSc1 = 16; // aux bit 4 of the buffer intrinsics on gfx950: sc1 — loads bypass the L1s, stores write through
-
-// flag words (entity chunks and tiles): value << 2 | state
-constexpr uint32_t kAggregate = 1u, kPrefix = 2u;
 
 // what entity_eval_one reads, over the fused parameter block (ci and entities are the meshlet side's)
 struct FusedEntity {
@@ -64,67 +55,6 @@ struct FusedEntity {
     uint32_t *visibility;
     PyramidView pyr;
 };
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void *base, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, kBufFlags);
-}
-__device__ __forceinline__ uint32_t ld_sc1(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
-    return __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, kSc1);
-}
-__device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, uint32_t v) {
-    __builtin_amdgcn_raw_buffer_store_b32(v, r, byte_off, 0, kSc1);
-}
-// every store this wave has issued has been performed (write-through stores: has reached memory)
-__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// between two polls (the clobber also keeps the poll's load inside the loop)
-__device__ __forceinline__ void poll_pause() { asm volatile("s_sleep 1" ::: "memory"); }
-__device__ __forceinline__ uint32_t ticket(uint32_t *counter) {
-    return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// a value every lane of the wave holds, as a scalar: loop conditions and branches on it are scalar branches (the
-// compiler cannot see that a word read from LDS behind a barrier is uniform, and wraps what follows — barriers
-// included — in divergent-loop bookkeeping)
-__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-// the entity phase's arrival word: chunks that have their records in memory << 32 | records so far — one atomic per
-// chunk, one 8-B poll tells a waiting workgroup both "all chunks are in" and the total
-__device__ __forceinline__ unsigned long long arrive(uint32_t *word, uint32_t records) {
-    return __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(word), 1ull << 32 | records, __ATOMIC_RELAXED,
-                                  __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Σ of the counts published for entity chunks [0, eb): every thread polls its share (bounded) — the whole look-back is
-// one step, because a cull has at most a few hundred chunks.
-__device__ __forceinline__ uint32_t chunks_before(const FusedCullParams &p, __amdgpu_buffer_rsrc_t EF, uint32_t eb,
-                                                  uint32_t *smem) {
-    uint32_t part = 0;
-    for (uint32_t j = threadIdx.x; j < eb; j += kEntityBlock) {
-        uint32_t v = ld_sc1(EF, j * 4u);
-        for (uint32_t spins = 0; v == 0u; spins++) {
-            if (spins == kSpinLimit) {
-                latch_status(p.m.status, ORBIT_E_TIMEOUT);
-                break;
-            }
-            poll_pause();
-            v = ld_sc1(EF, j * 4u);
-        }
-        part += v >> 2;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t w = wave_reduce_add(part);
-    __syncthreads(); // smem is the block scan's
-    if (lane == 0) smem[wave] = w;
-    __syncthreads();
-    uint32_t sum = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < kFusedWaves; i++) sum += smem[i];
-    __syncthreads();
-    return uniform(sum);
-}
 
 // Exclusive prefix of the survivor counts of the tiles before `t` (wave-uniform), by decoupled look-back: lane i reads
 // the flag of tile pos - 1 - i; the nearest inclusive prefix ends the walk, aggregates in front of it add up.  Tiles
@@ -172,9 +102,7 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
     constexpr uint32_t kFusedCap = kRecs * 32u;          // survivors a tile can have: its payload slab holds them all
     __shared__ PlaneLds planes;
     __shared__ AlphaLds alpha_tab;
-    __shared__ uint32_t smem[kFusedWaves + 1];
-    __shared__ uint32_t s_off[kEntityBlock];
-    __shared__ OrbitMeshletDispatch s_proto[kEntityBlock];
+    __shared__ EntityChunksLds ent_lds;
     __shared__ WaveTileLds slab[kFusedWaves];
     __shared__ CandLds<(PASS == 2 ? kCandRing : 1u)> ring[kFusedWaves]; // pass 2 only
     __shared__ Payload s_pay[kFusedWaves][kFusedCap];
@@ -183,11 +111,8 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t max_tiles = (p.m.dispatch_capacity + kRecs - 1u) / kRecs;
     const __amdgpu_buffer_rsrc_t SY = rsrc_of(p.sync, kFusedSyncWords * 4u);
-    const __amdgpu_buffer_rsrc_t EF = rsrc_of(p.ent_flags, p.ne_chunks * 4u);
     const __amdgpu_buffer_rsrc_t TF = rsrc_of(p.tile_flags, max_tiles * 4u);
-    // the dispatch records as the entity phase stores them: a slot past the capacity falls outside and is dropped
     uint8_t *dispatch_buffer = const_cast<uint8_t *>(p.m.dispatch_buffer);
-    const __amdgpu_buffer_rsrc_t REC_W = rsrc_of(dispatch_buffer + ORBIT_DISPATCH_HEADER, p.e_dispatch_capacity * 16u);
     const FusedEntity E{p.m.ci, p.entity_draw_buffer, p.mesh_infos, p.m.entities, p.visibility, p.e_pyr};
 
     // The parameter block lives in the kernel-argument segment and is read with scalar loads where it is used; a line
@@ -202,69 +127,22 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
     }
     planes_to_lds(p.m, planes);
     const AlphaLds *alpha = alpha_table_fill(p.m, alpha_tab) ? &alpha_tab : nullptr;
-    const uint32_t draw_count = *reinterpret_cast<const uint32_t *>(p.entity_draw_buffer);
-    const uint32_t draw_end = min(draw_count, p.draw_limit);
 
     // ---------------------------------------------------------------- entity chunks (entity_cull.comp:104-245)
-    // ONE thread-0 region per iteration (signal the chunk just finished, draw the next ticket), its result broadcast
-    // behind a barrier and made a scalar: with a thread-0 region at the end of the body and another at the head of the
-    // next iteration the compiler threaded the two together and let the other lanes of wave 0 run ahead through the
-    // loop head's barrier — wave 0 then passed that barrier twice per iteration and the workgroup fell out of step
-    // (found on hardware with the progress marks below; look for s_barrier inside a depth-2 loop in the ISA).
-    if (threadIdx.x == 0) s_word[0] = ticket(p.sync + kSyEntTicket);
-    __syncthreads();
-    uint32_t eb = uniform(s_word[0]);
-    __syncthreads();
-    while (eb < p.ne_chunks) {
-        FUSED_MARK(0, eb);
-        const uint32_t g = p.draw_first + eb * kEntityBlock + threadIdx.x;
-        const bool active = g < draw_end; // :106
-        bool visible;
-        const OrbitMeshletDispatch pr = entity_eval_one(E, g, active, visible);
-        entity_write_visibility(E, g, draw_end, active && visible);
-        const uint32_t n = (pr.meshlet_count + ORBIT_MESHLET_DISPATCH_SIZE - 1u) / ORBIT_MESHLET_DISPATCH_SIZE; // :210
-        uint32_t chunk_total;
-        s_off[threadIdx.x] = block_exclusive_scan<kFusedWaves>(n, smem, &chunk_total);
-        chunk_total = uniform(chunk_total);
-        s_proto[threadIdx.x] = pr;
-        // the chunk's count first (whoever waits for it must never wait for this chunk's own look-back) ...
-        st_sc1(EF, threadIdx.x == 0 ? eb * 4u : kNoOffset, chunk_total << 2 | kAggregate);
-        FUSED_MARK(1, chunk_total);
-        // ... then the records of the chunks before it
-        const uint32_t base = chunks_before(p, EF, eb, smem);
-        FUSED_MARK(2, base);
-        for (uint32_t r = threadIdx.x; r < chunk_total; r += kEntityBlock) {
-            const uint32_t owner = entity_record_owner(s_off, r);
-            const OrbitMeshletDispatch rec = entity_record(s_proto[owner], r - s_off[owner]);
-            const v4u w = {rec.entity_index, rec.meshlet_offset, rec.meshlet_count, rec.visibility_offset};
-            const uint64_t slot = (uint64_t)base + r; // (the sum can pass 2^32 / 16 only far beyond any capacity)
-            __builtin_amdgcn_raw_buffer_store_b128(w, REC_W, slot < p.e_dispatch_capacity ? (uint32_t)slot * 16u : kNoOffset, 0, kSc1);
-        }
-        drain_stores();
-        __syncthreads(); // every wave's records are in memory; s_off / s_proto may be rewritten
-        FUSED_MARK(3, eb);
-        if (threadIdx.x == 0) {
-            // behind the drain above: "this chunk's records are in memory"
-            const unsigned long long before = arrive(p.sync + kSyEntDone, chunk_total);
-            if ((uint32_t)(before >> 32) == p.ne_chunks - 1u) { // the last chunk in: the {x,1,1} header (draw_gen.rs:356-363)
-                const uint32_t total = (uint32_t)before + chunk_total;
-                uint32_t *hdr = reinterpret_cast<uint32_t *>(dispatch_buffer);
-                hdr[0] = min(total, p.e_dispatch_capacity);
-                hdr[1] = 1u;
-                hdr[2] = 1u;
-                *p.e_total = total;
-                if (total > p.e_dispatch_capacity) latch_status(p.m.status, ORBIT_E_CAPACITY);
-                if (min(total, min(p.e_dispatch_capacity, p.m.dispatch_capacity)) == 0u) {
-                    // no tile will run: the empty draw list is written here
-                    *reinterpret_cast<uint32_t *>(p.m.draw_buffer) = 0u;
-                    *p.m.total = 0u;
-                }
+    {
+        EntityChunksArgs a;
+        a.dispatch_buffer = dispatch_buffer;
+        a.dispatch_capacity = p.e_dispatch_capacity;
+        a.draw_first = p.draw_first, a.draw_limit = p.draw_limit;
+        a.ne_chunks = p.ne_chunks;
+        a.sync = p.sync, a.ent_flags = p.ent_flags, a.total = p.e_total, a.status = p.m.status;
+        entity_chunks(E, a, ent_lds, [&](uint32_t total) {
+            if (min(total, min(p.e_dispatch_capacity, p.m.dispatch_capacity)) == 0u) {
+                // no tile will run: the empty draw list is written here
+                *reinterpret_cast<uint32_t *>(p.m.draw_buffer) = 0u;
+                *p.m.total = 0u;
             }
-            s_word[0] = ticket(p.sync + kSyEntTicket);
-        }
-        __syncthreads();
-        eb = uniform(s_word[0]);
-        __syncthreads();
+        });
     }
 
     // ---------------------------------------------------------------- every record is in memory

@@ -2,8 +2,7 @@
 // the expansion of its proto-record into MeshletDispatch records, shared by the launches of entity_cull.hip and the
 // one-launch cull of cull_fused.hip.  Header-only.
 #pragma once
-#include "kernels.h"
-#include "scan.h"
+#include "handoff.h"
 
 namespace orbit {
 
@@ -113,6 +112,121 @@ __device__ __forceinline__ uint32_t entity_record_owner(const uint32_t *s_off, u
         if (s_off[mid] <= r) lo = mid; else hi = mid;
     }
     return lo;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The whole entity stage as ONE launch (entity_cull.hip's single launch, and the first phase of cull_fused.hip).
+// A workgroup draws a chunk of kEntityBlock entity-draws (ticket), evaluates them, publishes the chunk's record
+// count, adds up the counts published for the chunks before it (one poll: a cull has a few hundred chunks at most),
+// stores its MeshletDispatch records write-through at their canonical positions and adds itself to the arrival word
+// (chunks in << 32 | records so far); the last chunk in writes the {x,1,1} header (draw_gen.rs:356-363).
+struct EntityChunksArgs {
+    uint8_t *dispatch_buffer;
+    uint32_t dispatch_capacity;
+    uint32_t draw_first, draw_limit; // as EntityCullParams
+    uint32_t ne_chunks;              // ceil(entity_draw_count / kEntityBlock) >= 1
+    uint32_t *sync;                  // kFusedSyncWords counters (kernels.h), zero between launches
+    uint32_t *ent_flags;             // per chunk: records << 2 | state
+    uint32_t *total;
+    int32_t *status;
+};
+struct EntityChunksLds {
+    uint32_t smem[kEntityBlock / 64 + 1];
+    uint32_t off[kEntityBlock];
+    OrbitMeshletDispatch proto[kEntityBlock];
+    uint32_t word;
+};
+
+// Σ of the counts published for entity chunks [0, eb): every thread polls its share (bounded) — the whole look-back is
+// one step, because a cull has at most a few hundred chunks.
+__device__ __forceinline__ uint32_t chunks_before(int32_t *status, __amdgpu_buffer_rsrc_t EF, uint32_t eb, uint32_t *smem) {
+    uint32_t part = 0;
+    for (uint32_t j = threadIdx.x; j < eb; j += kEntityBlock) {
+        uint32_t v = ld_sc1(EF, j * 4u);
+        for (uint32_t spins = 0; v == 0u; spins++) {
+            if (spins == kSpinLimit) {
+                latch_status(status, ORBIT_E_TIMEOUT);
+                break;
+            }
+            poll_pause();
+            v = ld_sc1(EF, j * 4u);
+        }
+        part += v >> 2;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t w = wave_reduce_add(part);
+    __syncthreads(); // smem is the block scan's
+    if (lane == 0) smem[wave] = w;
+    __syncthreads();
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kEntityBlock / 64; i++) sum += smem[i];
+    __syncthreads();
+    return uniform(sum);
+}
+
+
+
+// E: what entity_eval_one reads (+ entity_draw_buffer for the count); on_total(total): thread 0 of the last chunk in.
+template <class E, class OnTotal>
+__device__ __forceinline__ void entity_chunks(const E &ent, const EntityChunksArgs &a, EntityChunksLds &S, OnTotal on_total) {
+    const __amdgpu_buffer_rsrc_t EF = rsrc_of(a.ent_flags, a.ne_chunks * 4u);
+    // the dispatch records as this phase stores them: a slot past the capacity falls outside and is dropped
+    const __amdgpu_buffer_rsrc_t REC_W = rsrc_of(a.dispatch_buffer + ORBIT_DISPATCH_HEADER, a.dispatch_capacity * 16u);
+    const uint32_t draw_count = *reinterpret_cast<const uint32_t *>(ent.entity_draw_buffer);
+    const uint32_t draw_end = min(draw_count, a.draw_limit);
+    // ONE thread-0 region per iteration (signal the chunk just finished, draw the next ticket), its result broadcast
+    // behind a barrier and made a scalar: with a thread-0 region at the end of the body and another at the head of the
+    // next iteration the compiler threaded the two together and let the other lanes of wave 0 run ahead through the
+    // loop head's barrier — wave 0 then passed that barrier twice per iteration and the workgroup fell out of step
+    // (found on hardware, tools/fused_probe.py; look for s_barrier inside a depth-2 loop in the ISA).
+    if (threadIdx.x == 0) S.word = ticket(a.sync + kSyEntTicket);
+    __syncthreads();
+    uint32_t eb = uniform(S.word);
+    __syncthreads();
+    while (eb < a.ne_chunks) {
+        const uint32_t g = a.draw_first + eb * kEntityBlock + threadIdx.x;
+        const bool active = g < draw_end; // :106
+        bool visible;
+        const OrbitMeshletDispatch pr = entity_eval_one(ent, g, active, visible);
+        entity_write_visibility(ent, g, draw_end, active && visible);
+        const uint32_t n = (pr.meshlet_count + ORBIT_MESHLET_DISPATCH_SIZE - 1u) / ORBIT_MESHLET_DISPATCH_SIZE; // :210
+        uint32_t chunk_total;
+        S.off[threadIdx.x] = block_exclusive_scan<kEntityBlock / 64>(n, S.smem, &chunk_total);
+        chunk_total = uniform(chunk_total);
+        S.proto[threadIdx.x] = pr;
+        // the chunk's count first (whoever waits for it must never wait for this chunk's own look-back) ...
+        st_sc1(EF, threadIdx.x == 0 ? eb * 4u : kHandoffNoOffset, chunk_total << 2 | kAggregate);
+        // ... then the records of the chunks before it
+        const uint32_t base = chunks_before(a.status, EF, eb, S.smem);
+        for (uint32_t r = threadIdx.x; r < chunk_total; r += kEntityBlock) {
+            const uint32_t owner = entity_record_owner(S.off, r);
+            const OrbitMeshletDispatch rec = entity_record(S.proto[owner], r - S.off[owner]);
+            const v4u w = {rec.entity_index, rec.meshlet_offset, rec.meshlet_count, rec.visibility_offset};
+            const uint64_t slot = (uint64_t)base + r; // (the sum can pass 2^32 / 16 only far beyond any capacity)
+            __builtin_amdgcn_raw_buffer_store_b128(w, REC_W, slot < a.dispatch_capacity ? (uint32_t)slot * 16u : kHandoffNoOffset, 0, kSc1);
+        }
+        drain_stores();
+        __syncthreads(); // every wave's records are in memory; off / proto may be rewritten
+        if (threadIdx.x == 0) {
+            // behind the drain above: "this chunk's records are in memory"
+            const unsigned long long before = arrive(a.sync + kSyEntDone, chunk_total);
+            if ((uint32_t)(before >> 32) == a.ne_chunks - 1u) { // the last chunk in: the {x,1,1} header (draw_gen.rs:356-363)
+                const uint32_t total = (uint32_t)before + chunk_total;
+                uint32_t *hdr = reinterpret_cast<uint32_t *>(a.dispatch_buffer);
+                hdr[0] = min(total, a.dispatch_capacity);
+                hdr[1] = 1u;
+                hdr[2] = 1u;
+                *a.total = total;
+                if (total > a.dispatch_capacity) latch_status(a.status, ORBIT_E_CAPACITY);
+                on_total(total);
+            }
+            S.word = ticket(a.sync + kSyEntTicket);
+        }
+        __syncthreads();
+        eb = uniform(S.word);
+        __syncthreads();
+    }
 }
 
 } // namespace

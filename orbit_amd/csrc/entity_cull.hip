@@ -1,107 +1,56 @@
 // entity_cull.hip — per-entity frustum / HiZ cull, LOD pick and deterministic
-// emission of MeshletDispatch records for gfx950.
+// emission of MeshletDispatch records for gfx950, as ONE launch.
 //
 // Restates shaders/entity_cull.comp:104-245 (reference repo) under the launch
 // protocol of src/passes/draw_gen.rs:327-380.  Differences in *how*, not *what*:
-//   - the record append is a prefix sum (eval -> emit, the emit launch sums the
-//     preceding blocks' counts itself), so the record sequence is the canonical
-//     ascending-gID order instead of atomics order;
+//   - the record append is a prefix sum, so the record sequence is the canonical
+//     ascending-gID order instead of atomics order: a workgroup evaluates a chunk of
+//     256 entity-draws, publishes the chunk's record count and adds up the counts
+//     of the chunks before it inside the launch (entity_common.h entity_chunks;
+//     rounds 1-3 made two launches of it: eval, then an emit that summed the block
+//     counts — 13 + 11 us at BASELINE config 5, each mostly its own ramp);
 //   - visibility words are written from wave64 ballots split into two 32-bit
 //     words (the reference's `gl_SubgroupSize == 32` addressing made explicit);
-//   - the {0,1,1} header clear (draw_gen.rs:356-363) is fused into the emit.
+//   - the {0,1,1} header clear (draw_gen.rs:356-363) is fused into the launch.
 #include "entity_common.h"
 
 namespace orbit {
 
 namespace {
 
-constexpr int kBlock = kEntityBlock;
+__device__ __forceinline__ void entity_cull_body(const EntityCullParams &p) {
+    __shared__ EntityChunksLds lds;
+    EntityChunksArgs a;
+    a.dispatch_buffer = p.dispatch_buffer;
+    a.dispatch_capacity = p.dispatch_capacity;
+    a.draw_first = p.draw_first, a.draw_limit = p.draw_limit;
+    a.ne_chunks = p.ne_chunks;
+    a.sync = p.sync, a.ent_flags = p.ent_flags, a.total = p.total, a.status = p.status;
+    entity_chunks(p, a, lds, [](uint32_t) {});
+    // the last workgroup out zeroes the flags: the next launch (or a graph replay) finds them as this one did
+    __syncthreads();
+    if (threadIdx.x == 0) lds.word = ticket(p.sync + kSyBlocksDone) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (uniform(lds.word) != 0u) { // every other workgroup has made its last access to them
+        for (uint32_t i = threadIdx.x; i < p.ne_chunks; i += kEntityBlock) p.ent_flags[i] = 0u;
+        if (threadIdx.x < kFusedSyncWords) p.sync[threadIdx.x] = 0u;
+    }
+}
 
-// One thread per entity-draw: evaluates the shader body up to the record
-// emission, stores a proto-record (meshlet_count == 0 when nothing is drawn).
 // The parameter block is the kernel's own argument (one view) or entry blockIdx.y of an array of them passed by value
 // (several views in one launch: orbit_cull_views).
-
-__device__ __forceinline__ void entity_cull_eval_body(const EntityCullParams &p) {
-    __shared__ uint32_t smem[kBlock / 64 + 1];
-    const uint32_t local = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t g = p.draw_first + local;
-    const uint32_t count = *reinterpret_cast<const uint32_t *>(p.entity_draw_buffer);
-    const uint32_t end = min(count, p.draw_limit);
-    const bool active = g < end; // entity_cull.comp:106
-    bool visible;
-    const OrbitMeshletDispatch pr = entity_eval_one(p, g, active, visible);
-    entity_write_visibility(p, g, end, active && visible);
-
-    p.proto[local] = pr;
-    const uint32_t n = (pr.meshlet_count + ORBIT_MESHLET_DISPATCH_SIZE - 1u) / ORBIT_MESHLET_DISPATCH_SIZE; // :210
-    uint32_t total;
-    (void)block_exclusive_scan<kBlock / 64>(n, smem, &total);
-    if (threadIdx.x == 0) p.block_sums[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(kBlock) void entity_cull_eval(const EntityCullParams p) { entity_cull_eval_body(p); }
-__global__ __launch_bounds__(kBlock) void entity_cull_eval_views(const EntityCullViews all) {
-    entity_cull_eval_body(all.v[blockIdx.y]);
-}
-
-// Sum of v over the block (every thread gets it).  `smem` holds NW words.
-template <int NW>
-__device__ __forceinline__ uint32_t block_reduce_add(uint32_t v, uint32_t *smem) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t w = wave_reduce_add(v);
-    if (lane == 0) smem[wave] = w;
-    __syncthreads();
-    uint32_t sum = 0;
-#pragma unroll
-    for (int i = 0; i < NW; i++) sum += smem[i];
-    __syncthreads();
-    return sum;
-}
-
-// Expands proto-records into ceil(m/S) MeshletDispatch records each, at the
-// scanned offsets (:211-223).  The block's base is the sum of the preceding
-// blocks' record counts, reduced here (a few KB from L2) instead of by a scan
-// launch in between; block 0 reduces all of them for the {x,1,1} header.
-// Thread = output record (owner found by bisection over the block's offsets in
-// LDS): consecutive lanes store consecutive 16-B records, where a thread-per-
-// entity loop stores 16 B every n x 16 B.
-__device__ __forceinline__ void entity_cull_emit_body(const EntityCullParams &p) {
-    __shared__ uint32_t smem[kBlock / 64 + 1];
-    __shared__ uint32_t s_off[kBlock];
-    __shared__ OrbitMeshletDispatch s_proto[kBlock];
-    const uint32_t local = blockIdx.x * kBlock + threadIdx.x;
-    const OrbitMeshletDispatch pr = p.proto[local];
-    const uint32_t n = (pr.meshlet_count + ORBIT_MESHLET_DISPATCH_SIZE - 1u) / ORBIT_MESHLET_DISPATCH_SIZE;
-    const uint32_t preceding = blockIdx.x == 0 ? gridDim.x : blockIdx.x; // block 0: grand total
-    uint32_t part = 0;
-    for (uint32_t i = threadIdx.x; i < preceding; i += kBlock) part += p.block_sums[i];
-    const uint32_t reduced = block_reduce_add<kBlock / 64>(part, smem);
-    const uint32_t block_base = blockIdx.x == 0 ? 0u : reduced;
-    uint32_t block_total;
-    s_off[threadIdx.x] = block_exclusive_scan<kBlock / 64>(n, smem, &block_total);
-    s_proto[threadIdx.x] = pr;
-    __syncthreads();
-    OrbitMeshletDispatch *out = reinterpret_cast<OrbitMeshletDispatch *>(p.dispatch_buffer + ORBIT_DISPATCH_HEADER);
-    for (uint32_t r = threadIdx.x; r < block_total; r += kBlock) {
-        const uint32_t owner = entity_record_owner(s_off, r);
-        const OrbitMeshletDispatch rec = entity_record(s_proto[owner], r - s_off[owner]);
-        if (block_base + r < p.dispatch_capacity) out[block_base + r] = rec;
+__global__ __launch_bounds__(kEntityBlock) void entity_cull_kernel(const EntityCullParams p) { entity_cull_body(p); }
+__global__ __launch_bounds__(kEntityBlock) void entity_cull_views_kernel(const EntityCullViews all) {
+    const EntityCullParams &p = all.v[blockIdx.y];
+    if (p.ne_chunks == 0u) { // a view without entity-draws: the pre-clear {0,1,1} is the whole effect
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            uint32_t *hdr = reinterpret_cast<uint32_t *>(p.dispatch_buffer);
+            hdr[0] = 0u, hdr[1] = 1u, hdr[2] = 1u;
+            *p.total = 0u;
+        }
+        return;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint32_t total = reduced;
-        *p.total = total;
-        uint32_t *hdr = reinterpret_cast<uint32_t *>(p.dispatch_buffer);
-        hdr[0] = min(total, p.dispatch_capacity);
-        hdr[1] = 1u;
-        hdr[2] = 1u;
-        if (total > p.dispatch_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void entity_cull_emit(const EntityCullParams p) { entity_cull_emit_body(p); }
-__global__ __launch_bounds__(kBlock) void entity_cull_emit_views(const EntityCullViews all) {
-    entity_cull_emit_body(all.v[blockIdx.y]);
+    entity_cull_body(p);
 }
 
 __global__ void write_dispatch_header(uint32_t *hdr, uint32_t x) {
@@ -110,33 +59,28 @@ __global__ void write_dispatch_header(uint32_t *hdr, uint32_t x) {
     hdr[2] = 1u;
 }
 
+// chunks are drawn by ticket: any grid is right; one workgroup per chunk up to four per CU keeps every chunk in flight
+uint32_t entity_grid(uint32_t chunks, uint32_t num_cus) { return max(min(chunks, num_cus * 4u), 1u); }
+
 } // namespace
 
-hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_count, hipStream_t s) {
-    const uint32_t blocks = (entity_draw_count + kBlock - 1) / kBlock;
-    if (blocks == 0) {
+hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_count, uint32_t num_cus, hipStream_t s) {
+    if (entity_draw_count == 0) {
         // nothing to test: the pre-clear {0,1,1} is the whole effect (draw_gen.rs:361-362)
         hipLaunchKernelGGL(write_dispatch_header, dim3(1), dim3(1), 0, s,
                            reinterpret_cast<uint32_t *>(p.dispatch_buffer), 0u);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(entity_cull_eval, dim3(blocks), dim3(kBlock), 0, s, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(entity_cull_emit, dim3(blocks), dim3(kBlock), 0, s, p);
+    hipLaunchKernelGGL(entity_cull_kernel, dim3(entity_grid(p.ne_chunks, num_cus)), dim3(kEntityBlock), 0, s, p);
     return hipGetLastError();
 }
 
-// Several views in one launch pair (orbit_cull_views): the grid covers the view with the most entity-draws, the other
-// views' surplus blocks find nothing active and write zero sums.
+// Several views in one launch (orbit_cull_views): the grid covers the view with the most entity-draws.
 hipError_t launch_entity_cull_views(const EntityCullViews &all, uint32_t n, uint32_t max_entity_draw_count,
-                                    hipStream_t s) {
-    uint32_t blocks = (max_entity_draw_count + kBlock - 1) / kBlock;
-    if (blocks == 0) blocks = 1; // emit block 0 still writes every view's {0,1,1} header
-    hipLaunchKernelGGL(entity_cull_eval_views, dim3(blocks, n), dim3(kBlock), 0, s, all);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(entity_cull_emit_views, dim3(blocks, n), dim3(kBlock), 0, s, all);
+                                    uint32_t num_cus, hipStream_t s) {
+    const uint32_t chunks = (max_entity_draw_count + kEntityBlock - 1) / kEntityBlock;
+    hipLaunchKernelGGL(entity_cull_views_kernel, dim3(entity_grid(chunks, max(num_cus / max(n, 1u), 1u)), n),
+                       dim3(kEntityBlock), 0, s, all);
     return hipGetLastError();
 }
 

@@ -33,9 +33,10 @@ struct EntityCullParams {
     uint32_t draw_first;      // first entity-draw of this launch (multiple of 32)
     uint32_t draw_limit;      // draw_first + 256 * ceil(entity_draw_count / 256)
     uint32_t dispatch_capacity;
-    // context scratch
-    OrbitMeshletDispatch *proto; // one proto-record per entity-draw of the launch
-    uint32_t *block_sums; // records per block of 256 entity-draws; the emit launch prefix-sums them itself
+    uint32_t ne_chunks;       // ceil(entity_draw_count / 256): chunks of the launch (entity_common.h entity_chunks)
+    // context scratch, zero between launches (the last workgroup of a launch leaves it so)
+    uint32_t *sync;       // kFusedSyncWords counters (below)
+    uint32_t *ent_flags;  // per chunk: records << 2 | state
     uint32_t *total;
     int32_t *status;
 };
@@ -203,7 +204,7 @@ struct FusedCullViews {
 hipError_t launch_cull_fused_views(const FusedCullViews &all, const uint32_t *entity_draw_counts, uint32_t n,
                                    uint32_t num_cus, hipStream_t s);
 
-hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_count, hipStream_t s);
+hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_count, uint32_t num_cus, hipStream_t s);
 // orbit_cull_views: the parameter blocks of all views travel BY VALUE in the kernel-argument segment (a few KB: HIP on
 // gfx950 takes it — tools/ubench/kernarg_size.hip), so a view's block is read with scalar loads at a uniform offset
 // (blockIdx.y), exactly like the single-view kernels read theirs.
@@ -211,7 +212,7 @@ struct EntityCullViews {
     EntityCullParams v[ORBIT_MAX_CULL_VIEWS];
 };
 hipError_t launch_entity_cull_views(const EntityCullViews &all, uint32_t n, uint32_t max_entity_draw_count,
-                                    hipStream_t s);
+                                    uint32_t num_cus, hipStream_t s);
 // ev0/ev1 (optional): recorded on `s` immediately before / after the dominant kernel of the op
 hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, hipStream_t s,
                                hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
