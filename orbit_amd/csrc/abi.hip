@@ -58,7 +58,8 @@ struct OrbitCtx {
     // scratch (device)
     uint8_t *arena = nullptr;
     size_t arena_bytes = 0;
-    uint32_t *e_total = nullptr;
+    OrbitMeshletDispatch *e_proto = nullptr;
+    uint32_t *e_block_sums = nullptr, *e_total = nullptr;
     Payload *m_tile_payload = nullptr;
     uint32_t *m_tile_masks = nullptr, *m_chunk_sums = nullptr;
     uint32_t *m_tile_counts = nullptr, *m_tile_base = nullptr, *m_total = nullptr;
@@ -276,7 +277,8 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t o_gc = carve(256);
     const size_t o_tk = carve(kTicketPools * kTicketStride * 4);
     const size_t o_fsy = carve(kFusedSyncWords * 4), o_fef = carve((ent / 256 + 2) * 4);
-    const size_t o_et = carve(256);
+    const size_t o_eproto = carve(ent * sizeof(OrbitMeshletDispatch));
+    const size_t o_ebs = carve((ent / 256 + 1) * 4), o_et = carve(256);
     const size_t o_mtc = carve(mtiles * 4), o_mtb = carve(mtiles * 4), o_mt = carve(256);
     const size_t o_ftf = carve(((size_t)caps.max_dispatches / 4 + 2) * 4); // one flag per tile of 4 records (cull_fused.hip)
     const size_t o_xbp = carve((size_t)kExpandBlocks * 4);
@@ -313,6 +315,8 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->status = (int32_t *)(a + o_status);
     ctx->debug_cycles = (unsigned long long *)(a + o_dbg);
     ctx->zero_page = (void *)(a + o_zero);
+    ctx->e_proto = (OrbitMeshletDispatch *)(a + o_eproto);
+    ctx->e_block_sums = (uint32_t *)(a + o_ebs);
     ctx->e_total = (uint32_t *)(a + o_et);
     ctx->m_tile_counts = (uint32_t *)(a + o_mtc);
     ctx->m_tile_base = (uint32_t *)(a + o_mtb);
@@ -519,6 +523,8 @@ static int32_t entity_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitG
     p.draw_limit = limit > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)limit;
     p.dispatch_capacity = b->dispatch_capacity;
     p.ne_chunks = (entity_draw_count + 255u) / 256u;
+    p.proto = scratch->e_proto;
+    p.block_sums = scratch->e_block_sums;
     p.sync = scratch->f_sync;
     p.ent_flags = scratch->f_ent_flags;
     p.total = scratch->e_total;

@@ -1,5 +1,5 @@
 // entity_cull.hip — per-entity frustum / HiZ cull, LOD pick and deterministic
-// emission of MeshletDispatch records for gfx950, as ONE launch.
+// emission of MeshletDispatch records for gfx950: ONE launch up to 32 768 entity-draws, two above.
 //
 // Restates shaders/entity_cull.comp:104-245 (reference repo) under the launch
 // protocol of src/passes/draw_gen.rs:327-380.  Differences in *how*, not *what*:
@@ -53,6 +53,101 @@ __global__ __launch_bounds__(kEntityBlock) void entity_cull_views_kernel(const E
     entity_cull_body(p);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The two-launch form, for culls of more than kEntityOneLaunchChunks chunks.  Every workgroup of the one-launch form
+// makes three returning atomics on shared words (its ticket, its arrival, its leaving), and one word serves ~88 of
+// them per microsecond on this chip: at BASELINE config 5 (763 chunks) the tickets alone queue for 9 us and the launch
+// takes 44 us where eval + emit take 13 + 11 (profiles/r04_notes.md).  Below a hundred chunks that queue is a microsecond
+// and one launch wins.
+constexpr uint32_t kEntityOneLaunchChunks = 128;
+
+// One thread per entity-draw: evaluates the shader body up to the record
+// emission, stores a proto-record (meshlet_count == 0 when nothing is drawn).
+// The parameter block is the kernel's own argument (one view) or entry blockIdx.y of an array of them passed by value
+// (several views in one launch: orbit_cull_views).
+
+__device__ __forceinline__ void entity_cull_eval_body(const EntityCullParams &p) {
+    __shared__ uint32_t smem[kEntityBlock / 64 + 1];
+    const uint32_t local = blockIdx.x * kEntityBlock + threadIdx.x;
+    const uint32_t g = p.draw_first + local;
+    const uint32_t count = *reinterpret_cast<const uint32_t *>(p.entity_draw_buffer);
+    const uint32_t end = min(count, p.draw_limit);
+    const bool active = g < end; // entity_cull.comp:106
+    bool visible;
+    const OrbitMeshletDispatch pr = entity_eval_one(p, g, active, visible);
+    entity_write_visibility(p, g, end, active && visible);
+
+    p.proto[local] = pr;
+    const uint32_t n = (pr.meshlet_count + ORBIT_MESHLET_DISPATCH_SIZE - 1u) / ORBIT_MESHLET_DISPATCH_SIZE; // :210
+    uint32_t total;
+    (void)block_exclusive_scan<kEntityBlock / 64>(n, smem, &total);
+    if (threadIdx.x == 0) p.block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kEntityBlock) void entity_cull_eval(const EntityCullParams p) { entity_cull_eval_body(p); }
+__global__ __launch_bounds__(kEntityBlock) void entity_cull_eval_views(const EntityCullViews all) {
+    entity_cull_eval_body(all.v[blockIdx.y]);
+}
+
+// Sum of v over the block (every thread gets it).  `smem` holds NW words.
+template <int NW>
+__device__ __forceinline__ uint32_t block_reduce_add(uint32_t v, uint32_t *smem) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t w = wave_reduce_add(v);
+    if (lane == 0) smem[wave] = w;
+    __syncthreads();
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) sum += smem[i];
+    __syncthreads();
+    return sum;
+}
+
+// Expands proto-records into ceil(m/S) MeshletDispatch records each, at the
+// scanned offsets (:211-223).  The block's base is the sum of the preceding
+// blocks' record counts, reduced here (a few KB from L2) instead of by a scan
+// launch in between; block 0 reduces all of them for the {x,1,1} header.
+// Thread = output record (owner found by bisection over the block's offsets in
+// LDS): consecutive lanes store consecutive 16-B records, where a thread-per-
+// entity loop stores 16 B every n x 16 B.
+__device__ __forceinline__ void entity_cull_emit_body(const EntityCullParams &p) {
+    __shared__ uint32_t smem[kEntityBlock / 64 + 1];
+    __shared__ uint32_t s_off[kEntityBlock];
+    __shared__ OrbitMeshletDispatch s_proto[kEntityBlock];
+    const uint32_t local = blockIdx.x * kEntityBlock + threadIdx.x;
+    const OrbitMeshletDispatch pr = p.proto[local];
+    const uint32_t n = (pr.meshlet_count + ORBIT_MESHLET_DISPATCH_SIZE - 1u) / ORBIT_MESHLET_DISPATCH_SIZE;
+    const uint32_t preceding = blockIdx.x == 0 ? gridDim.x : blockIdx.x; // block 0: grand total
+    uint32_t part = 0;
+    for (uint32_t i = threadIdx.x; i < preceding; i += kEntityBlock) part += p.block_sums[i];
+    const uint32_t reduced = block_reduce_add<kEntityBlock / 64>(part, smem);
+    const uint32_t block_base = blockIdx.x == 0 ? 0u : reduced;
+    uint32_t block_total;
+    s_off[threadIdx.x] = block_exclusive_scan<kEntityBlock / 64>(n, smem, &block_total);
+    s_proto[threadIdx.x] = pr;
+    __syncthreads();
+    OrbitMeshletDispatch *out = reinterpret_cast<OrbitMeshletDispatch *>(p.dispatch_buffer + ORBIT_DISPATCH_HEADER);
+    for (uint32_t r = threadIdx.x; r < block_total; r += kEntityBlock) {
+        const uint32_t owner = entity_record_owner(s_off, r);
+        const OrbitMeshletDispatch rec = entity_record(s_proto[owner], r - s_off[owner]);
+        if (block_base + r < p.dispatch_capacity) out[block_base + r] = rec;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t total = reduced;
+        *p.total = total;
+        uint32_t *hdr = reinterpret_cast<uint32_t *>(p.dispatch_buffer);
+        hdr[0] = min(total, p.dispatch_capacity);
+        hdr[1] = 1u;
+        hdr[2] = 1u;
+        if (total > p.dispatch_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+    }
+}
+
+__global__ __launch_bounds__(kEntityBlock) void entity_cull_emit(const EntityCullParams p) { entity_cull_emit_body(p); }
+__global__ __launch_bounds__(kEntityBlock) void entity_cull_emit_views(const EntityCullViews all) {
+    entity_cull_emit_body(all.v[blockIdx.y]);
+}
+
 __global__ void write_dispatch_header(uint32_t *hdr, uint32_t x) {
     hdr[0] = x;
     hdr[1] = 1u;
@@ -71,7 +166,14 @@ hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_co
                            reinterpret_cast<uint32_t *>(p.dispatch_buffer), 0u);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(entity_cull_kernel, dim3(entity_grid(p.ne_chunks, num_cus)), dim3(kEntityBlock), 0, s, p);
+    if (p.ne_chunks <= kEntityOneLaunchChunks) {
+        hipLaunchKernelGGL(entity_cull_kernel, dim3(entity_grid(p.ne_chunks, num_cus)), dim3(kEntityBlock), 0, s, p);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(entity_cull_eval, dim3(p.ne_chunks), dim3(kEntityBlock), 0, s, p);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(entity_cull_emit, dim3(p.ne_chunks), dim3(kEntityBlock), 0, s, p);
     return hipGetLastError();
 }
 
@@ -79,6 +181,13 @@ hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_co
 hipError_t launch_entity_cull_views(const EntityCullViews &all, uint32_t n, uint32_t max_entity_draw_count,
                                     uint32_t num_cus, hipStream_t s) {
     const uint32_t chunks = (max_entity_draw_count + kEntityBlock - 1) / kEntityBlock;
+    if (chunks > kEntityOneLaunchChunks) { // (surplus blocks of the smaller views find nothing active and write zero sums)
+        hipLaunchKernelGGL(entity_cull_eval_views, dim3(chunks, n), dim3(kEntityBlock), 0, s, all);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(entity_cull_emit_views, dim3(chunks, n), dim3(kEntityBlock), 0, s, all);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(entity_cull_views_kernel, dim3(entity_grid(chunks, max(num_cus / max(n, 1u), 1u)), n),
                        dim3(kEntityBlock), 0, s, all);
     return hipGetLastError();

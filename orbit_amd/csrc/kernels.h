@@ -34,7 +34,10 @@ struct EntityCullParams {
     uint32_t draw_limit;      // draw_first + 256 * ceil(entity_draw_count / 256)
     uint32_t dispatch_capacity;
     uint32_t ne_chunks;       // ceil(entity_draw_count / 256): chunks of the launch (entity_common.h entity_chunks)
-    // context scratch, zero between launches (the last workgroup of a launch leaves it so)
+    // context scratch of the two-launch form (entity_cull.hip: more than 128 chunks)
+    OrbitMeshletDispatch *proto; // one proto-record per entity-draw of the launch
+    uint32_t *block_sums; // records per block of 256 entity-draws; the emit launch prefix-sums them itself
+    // context scratch of the one-launch form, zero between launches (the last workgroup of a launch leaves it so)
     uint32_t *sync;       // kFusedSyncWords counters (below)
     uint32_t *ent_flags;  // per chunk: records << 2 | state
     uint32_t *total;
