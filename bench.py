@@ -56,11 +56,16 @@ def parse():
                          "should-draw ballot} per dispatch record with a survivor, half the items' bytes at "
                          "config 5; visible — 8 B {meshlet, entity} per survivor; commands — the 28-B commands "
                          "themselves")
-    ap.add_argument("--expand", choices=("none", "all"), default="none",
-                    help="N>1, exchange records / visible: what happens to the gathered list inside the step — none "
-                         "(default: the step is cull + all-gather, every rank then holds the whole visible list and "
-                         "issues its draws from it or from its own shard, SURVEY.md §8e), or all (every rank also "
-                         "expands the whole list into 28-B commands: N-independent work on every GPU)")
+    ap.add_argument("--expand", choices=("own", "none", "all"), default="own",
+                    help="N>1, exchange records / visible: which 28-B MeshletDrawCommandBuffer the step ends in — own "
+                         "(default: every rank turns ITS shard's list into the commands of its shard, the indirect-draw "
+                         "buffer it issues its own draws from, SURVEY.md §8e, beside the all-gathered visible list), "
+                         "none (the step is cull + all-gather only: the visible list is the product), or all (every "
+                         "rank expands the WHOLE gathered list: N-independent work on every GPU)")
+    ap.add_argument("--signalling", choices=("device", "collectives"), default="device",
+                    help="N>1, transport p2p: how counts and completion of an exchange travel — device (default: stores "
+                         "into the peers' control blocks awaited on the device, orbit_exchange_list: no collective and "
+                         "no host call in a step) or collectives (two fixed-size torch.distributed collectives per step)")
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="frame slots (OrbitCtx + stream + buffers each) the steps go round-robin over; 1 = strictly serial")
     ap.add_argument("--time-every", type=int, default=3,
@@ -209,6 +214,7 @@ def main():
     records_exchange = do_gather and args.exchange == "records"
     compact_exchange = visible_exchange or records_exchange
     do_expand = compact_exchange and args.expand == "all"  # needs the whole meshlet buffer (+ stream) on every GPU
+    own_expand = records_exchange and args.expand == "own"  # this rank's commands from this rank's record list
     t0 = time.time()
     draws, mesh, ent, half = synth.gen_entity_tables(spec, dev)
     mb, me = (0, E) if do_expand else (b, e)
@@ -247,6 +253,8 @@ def main():
             self.disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device=dev)
             self.lists = [torch.zeros(hdr + item * list_cap, dtype=torch.uint8, device=dev)
                           for _ in range(2 if do_gather else 1)]
+            # --expand own: the shard's indirect-draw buffer, rebuilt every step from the shard's record list
+            self.own_cmds = torch.zeros(L.DRAW_HEADER + 28 * draw_cap, dtype=torch.uint8, device=dev) if own_expand else None
             self.cull_done = [torch.cuda.Event() for _ in self.lists]
             self.xdone = [torch.cuda.Event() for _ in self.lists]
             self.uses = 0
@@ -280,7 +288,8 @@ def main():
         if transport == "p2p":
             ok = 1
             try:
-                exchanges = [odist.P2PExchange(slots[0].eng, x_cap, hdr, item, dev) for _ in range(n_x)]
+                exchanges = [odist.P2PExchange(slots[0].eng, x_cap, hdr, item, dev, signalling=args.signalling)
+                             for _ in range(n_x)]
             except Exception as ex:  # IPC not available between these processes: every rank falls back together
                 print(f"bench.py: p2p exchange unavailable on rank {rank} ({ex}); falling back to RCCL send/recv",
                       file=sys.stderr)
@@ -341,6 +350,13 @@ def main():
             s.eng.meshlet_cull(ci, s.disp, meshlets_base, s.lists[k], ent, materials, disp_cap, draw_cap,
                                material_count=spec.materials, stream=s.stream)
 
+    def expand_own(s, k):
+        # the rank's own indirect-draw buffer: its shard's survivors as 28-B commands, in canonical order, from the
+        # record list it has just produced (behind the cull on the slot's stream; the exchange of that list runs beside)
+        s.eng.expand_visible_records(s.lists[k], meshlets_base, s.own_cmds, draw_cap, stream=s.stream)
+
+    step_marks = []  # N > 1: one timing event per step of the timed region, behind that step's exchange
+
     def step(i=None):
         s = slots[step_no[0] % F]
         step_no[0] += 1
@@ -351,8 +367,14 @@ def main():
         cull(s, k)
         if do_gather:
             s.cull_done[k].record(s.stream)
+            if own_expand:
+                expand_own(s, k)
             if pending:
                 gather(*pending.pop())  # previous step's list travels while this step's cull runs
+                if i is not None:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record(xstream)
+                    step_marks.append(ev)
             pending.append((s, k))
 
     def drain():
@@ -469,6 +491,14 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # N > 1: the intervals between the completions of consecutive steps' exchanges inside the timed region (HIP events on
+    # the exchange stream) — the steady-state step time without whatever a single slow step adds to wall / K
+    step_intervals = None
+    if len(step_marks) >= 3:
+        iv = [step_marks[i].elapsed_time(step_marks[i + 1]) for i in range(len(step_marks) - 1)]
+        step_intervals = {"median_ms": float(np.median(iv)), "min_ms": float(min(iv)), "max_ms": float(max(iv)),
+                          "intervals": len(iv),
+                          "what": "time between the completions of consecutive steps' exchanges inside the timed region"}
     if mstream is not None and not args.no_alpha_classes:
         assert all(s.eng.meshlet_class_culls() >= args.steps // F for s in slots), "the alpha classes were not used"
     eval_sum, eval_launches = 0.0, 0
@@ -483,7 +513,7 @@ def main():
 
     # one frame alone on an idle device (nothing else in flight): the latency a single cull costs, and its parts
     s0 = slots[0]
-    serial, op_ms, x_ms, ex_ms = [], [], [], []
+    serial, op_ms, x_ms, ex_ms, own_ms = [], [], [], [], []
     last_recv = 0
     for _ in range(5):
         a, m, z = (torch.cuda.Event(enable_timing=True) for _ in range(3))
@@ -500,9 +530,15 @@ def main():
             s0.eng.meshlet_cull(ci, s0.disp, meshlets_base, s0.lists[0], ent, materials, disp_cap, draw_cap,
                                 material_count=spec.materials, stream=s0.stream)
         z.record(s0.stream)
+        if own_expand:  # the shard's own command buffer from the list just produced, alone on the device
+            oz = torch.cuda.Event(enable_timing=True)
+            expand_own(s0, 0)
+            oz.record(s0.stream)
         torch.cuda.synchronize()
         serial.append(a.elapsed_time(z))
         op_ms.append(m.elapsed_time(z))
+        if own_expand:
+            own_ms.append(z.elapsed_time(oz))
         if do_gather:  # the exchange (+ expansion) of that list alone
             if use_dist:
                 dist.barrier()
@@ -585,6 +621,15 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert torch.equal(lo, hi), "ranks hold different gathered lists"
+    if own_expand:  # the shard's indirect-draw buffer holds exactly the survivors the shard's record list names, in order
+        cmds = s0.own_cmds
+        assert int(cmds[:4].view(torch.int32).item()) == n_draw, "own command buffer: wrong count"
+        cw = cmds[L.DRAW_HEADER:L.DRAW_HEADER + 28 * n_draw].view(torch.int32).view(-1, 7)
+        recs = draw[hdr:hdr + 12 * n_list].view(torch.int32).view(-1, 3)
+        bits = (recs[:, 2:3] >> torch.arange(32, device=dev, dtype=torch.int32)) & 1
+        r_idx, b_idx = torch.nonzero(bits, as_tuple=True)
+        assert torch.equal(cw[:, 6], recs[r_idx, 1] + b_idx.to(torch.int32)) and torch.equal(cw[:, 4], recs[r_idx, 0]), \
+            "own command buffer != the shard's visible list"
     for s in slots:  # every slot and list buffer computed the same frame
         for l in s.lists:
             assert torch.equal(l[:hdr + item * n_list], draw[:hdr + item * n_list]), "frame slots disagree"
@@ -692,6 +737,15 @@ def main():
                 "ms_per_step_without_settle": cold_ms_per_step,
                 "world_size": world_reported, "backend": (backend if use_dist else None),
                 "expand": (args.expand if compact_exchange else None),
+                "step_product": (None if not do_gather else
+                                 "the all-gathered visible list on every GPU + every rank's own shard as a 28-B "
+                                 "MeshletDrawCommandBuffer (its indirect draws)" if own_expand else
+                                 "the all-gathered visible list on every GPU + the whole list expanded into 28-B commands "
+                                 "on every GPU" if do_expand else
+                                 "the all-gathered visible list only (no command buffer is built inside the step)"
+                                 if compact_exchange else "the all-gathered 28-B command list on every GPU"),
+                "signalling": (exchanges[0].signalling if exchanges else None),
+                "step_intervals": step_intervals,
                 "list_bytes_per_rank_max": (int(max(c[0].item() for c in counts)) * item if do_gather else None),
                 "exchange": (args.exchange if do_gather else None), "transport": transport,
                 "transport_requested": (args.transport if do_gather else None), "transport_fallback": transport_fallback,
@@ -723,6 +777,7 @@ def main():
             "ms_per_step_from_meshlet_buffer": buffer_path_ms_per_step,
             "per_rank": dict(per_rank_rows, cull_ms_max=kernel_ms_max_frame, exchange_ms_max=exchange_ms_max,
                              expand_ms_max=expand_ms_max,
+                             own_commands_ms_rank0=(float(np.median(own_ms)) if own_ms else None),
                              what="one frame alone on each rank's device, per rank: entity_cull + meshlet_cull of its "
                                   "shard, the exchange of its list, the expansion of the gathered list (--expand all "
                                   "only).  In the timed region they overlap (cull of step i+1, wire of step i, "

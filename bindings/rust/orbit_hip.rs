@@ -157,6 +157,9 @@ extern "C" {
     pub fn orbit_scatter_list(ctx: *mut OrbitCtx, local_list: *const c_void, counts: *const u32, rank: u32, world: u32,
                               out_buffers: *const *mut c_void, out_capacity: u32, header_bytes: u32, stride: u32,
                               stream: *mut c_void) -> i32;
+    pub fn orbit_exchange_list(ctx: *mut OrbitCtx, local_list: *const c_void, rank: u32, world: u32,
+                               out_buffers: *const *mut c_void, ctrl_buffers: *const *mut c_void, out_capacity: u32,
+                               header_bytes: u32, stride: u32, stream: *mut c_void) -> i32;
 }
 
 /// Turns a non-zero status into the panic the Vulkan path produced (assert!/unwrap, draw_gen.rs:247).

@@ -808,6 +808,7 @@ int32_t orbit_expand_visible_records(OrbitCtx *ctx, const void *record_buffer, c
 
 #define ORBIT_P2P_HANDLE_BYTES 64 /* hipIpcMemHandle_t */
 #define ORBIT_P2P_MAX_WORLD 16
+#define ORBIT_P2P_CTRL_BYTES 1024 /* a rank's control block of orbit_exchange_list (orbit_p2p_alloc'ed, zero-filled) */
 
 /* Exchange buffers: device memory of this context's GPU that peers may map.
  * orbit_p2p_alloc returns the pointer and an opaque handle to send to the other
@@ -834,6 +835,24 @@ int32_t orbit_p2p_close(OrbitCtx *ctx, void *peer_ptr);
 int32_t orbit_scatter_list(OrbitCtx *ctx, const void *local_list, const uint32_t *counts, uint32_t rank,
                            uint32_t world, void *const *out_buffers, uint32_t out_capacity,
                            uint32_t header_bytes, uint32_t stride, void *stream);
+
+/* The whole exchange on the device — no collective, no host in the step, capturable into a graph.
+ * orbit_scatter_list needs the all-gathered counts as an argument and a collective behind it as the completion
+ * barrier: two host-issued collectives per step.  Here both travel like the lists themselves, as stores into the
+ * peers' IPC-mapped memory: every rank owns a CONTROL BLOCK (ORBIT_P2P_CTRL_BYTES from orbit_p2p_alloc, which
+ * zero-fills it; mapped by every peer with orbit_p2p_open).  One call enqueues two launches on `stream`: a scatter that
+ * first stores this rank's count into every peer's block, waits (on the device, bounded: ORBIT_E_TIMEOUT) for the counts
+ * of the ranks before it, copies the list to its rank-ordered position in every rank's `out_buffers[r]` and then raises
+ * "done" in that rank's block; and a one-workgroup launch that waits until every rank's count and "done" for this
+ * exchange have arrived and writes the header {total, 0 ..} of this rank's own buffer.  Work enqueued behind the call
+ * reads the complete list.  Exchanges are numbered by a counter in the control block (all ranks count in step), so a
+ * captured graph replays correctly.  Every rank must call it the same number of times, with the same `world`; a
+ * rank's out buffer must not be rewritten (by the next exchange into the same buffer) while its consumers still read
+ * it: alternate two (buffer, control block) pairs, as bench.py does.
+ *   ctrl_buffers  HOST array of `world` device pointers: rank r's control block as mapped in THIS process */
+int32_t orbit_exchange_list(OrbitCtx *ctx, const void *local_list, uint32_t rank, uint32_t world,
+                            void *const *out_buffers, void *const *ctrl_buffers, uint32_t out_capacity,
+                            uint32_t header_bytes, uint32_t stride, void *stream);
 
 #ifdef __cplusplus
 }

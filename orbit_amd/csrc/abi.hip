@@ -1392,6 +1392,36 @@ int32_t orbit_scatter_list(OrbitCtx *ctx, const void *local_list, const uint32_t
     return ORBIT_OK;
 }
 
+int32_t orbit_exchange_list(OrbitCtx *ctx, const void *local_list, uint32_t rank, uint32_t world,
+                            void *const *out_buffers, void *const *ctrl_buffers, uint32_t out_capacity,
+                            uint32_t header_bytes, uint32_t stride, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!local_list || !out_buffers || !ctrl_buffers) return fail(ctx, ORBIT_E_MISSING, "exchange_list: NULL argument");
+    if (world == 0 || world > ORBIT_P2P_MAX_WORLD || rank >= world)
+        return fail(ctx, ORBIT_E_INVALID, "exchange_list: rank %u of world %u (max %u)", rank, world,
+                    (unsigned)ORBIT_P2P_MAX_WORLD);
+    if (header_bytes < 4 || header_bytes % 4u || stride == 0 || stride % 4u)
+        return fail(ctx, ORBIT_E_INVALID, "exchange_list: header %u / stride %u must be multiples of 4", header_bytes,
+                    stride);
+    ExchangeListParams p{};
+    p.local_list = (const uint8_t *)local_list;
+    for (uint32_t r = 0; r < world; r++) {
+        if (!out_buffers[r] || !ctrl_buffers[r]) return fail(ctx, ORBIT_E_MISSING, "exchange_list: buffer %u is NULL", r);
+        p.out[r] = (uint8_t *)out_buffers[r];
+        p.ctrl[r] = (uint8_t *)ctrl_buffers[r];
+    }
+    p.rank = rank;
+    p.world = world;
+    p.out_capacity = out_capacity;
+    p.header_bytes = header_bytes;
+    p.stride = stride;
+    p.status = ctx->status;
+    const hipError_t e = launch_exchange_list(p, ctx->num_cus, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch exchange_list");
+    return ORBIT_OK;
+}
+
 int32_t orbit_gather_visible(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint32_t world,
                              const void *local_draw_buffer, void *out_draw_buffer, uint32_t out_capacity,
                              void *stream) {

@@ -273,6 +273,15 @@ struct ScatterListParams {
     int32_t *status;
 };
 hipError_t launch_scatter_list(const ScatterListParams &p, uint32_t num_cus, hipStream_t s);
+// orbit_exchange_list: scatter + device-side counts and completion (meshlet_lists.hip)
+struct ExchangeListParams {
+    const uint8_t *local_list;
+    uint8_t *out[16];  // ORBIT_P2P_MAX_WORLD: rank r's output buffer as mapped here
+    uint8_t *ctrl[16]; // rank r's control block as mapped here (ORBIT_P2P_CTRL_BYTES each, zero at first use)
+    uint32_t rank, world, out_capacity, header_bytes, stride;
+    int32_t *status;
+};
+hipError_t launch_exchange_list(const ExchangeListParams &p, uint32_t num_cus, hipStream_t s);
 hipError_t launch_depth_reduce(const DepthReduceBatch &b, hipStream_t s);
 hipError_t launch_cluster_mark(const ClusterMarkParams &p, hipStream_t s);
 hipError_t launch_cluster_compact(const ClusterCompactParams &p, hipStream_t s);

@@ -372,7 +372,135 @@ __global__ __launch_bounds__(256) void task_records_kernel(const MeshletCullPara
     for (int k = 0; k < 8; k++) out[3 + k] = w[k];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// orbit_exchange_list: the rank-ordered all-gather of the ranks' lists with NO host in the step — the counts and the
+// completion travel the way the lists do, as stores into the peers' IPC-mapped memory.  Every rank owns a control
+// block (ExchangeCtrl, mapped by all peers):
+//   count[e & 1][r]  {items of rank r, epoch e}: stored by rank r into EVERY rank's block at the start of its scatter;
+//   done[r]          epoch e: stored by rank r into a rank's block once its items for epoch e have reached that rank's
+//                    output buffer (behind a system-scope fence of every storing workgroup);
+//   epoch            this rank's last finished exchange: all ranks count exchanges in step, so epochs agree without
+//                    ever being communicated — and a replayed graph finds the epoch where the last replay left it.
+// Scatter launch: count out to every peer; wait (bounded) for every rank's count — those of the ranks before this one
+// fix the offset; copy the list into every peer's buffer (blockIdx.y = destination: all links side by side); the last workgroup
+// of a destination to finish raises done there.  Wait launch (one workgroup): until every rank's count and done for
+// this epoch have arrived here, then the header {total, 0 ..} and the epoch.  What runs behind it in stream order
+// reads the complete list.  The count slots alternate by epoch parity: a peer may start exchange e + 1 (it has seen
+// this rank's done for e) while this rank's wait launch still reads the counts of e; it cannot start e + 2 before this
+// rank's count for e + 1, i.e. before that wait launch has finished.
+struct ExchangeCtrl {
+    unsigned long long count[2][ORBIT_P2P_MAX_WORLD]; // items | epoch << 32
+    unsigned long long done[ORBIT_P2P_MAX_WORLD];     // epoch
+    uint32_t epoch;
+    uint32_t left[ORBIT_P2P_MAX_WORLD];               // scatter workgroups of this rank done with destination d
+};
+static_assert(sizeof(ExchangeCtrl) <= ORBIT_P2P_CTRL_BYTES, "control block size");
+
+constexpr uint32_t kExchangeSpinLimit = 1u << 22; // polls (with a pause each) before a wait gives up: seconds
+
+__device__ __forceinline__ unsigned long long sys_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void sys_store(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(256) void exchange_scatter_kernel(const ExchangeListParams p) {
+    __shared__ uint32_t s_first, s_mine;
+    ExchangeCtrl *mine_ctrl = reinterpret_cast<ExchangeCtrl *>(p.ctrl[p.rank]);
+    const uint32_t dst_rank = blockIdx.y;
+    const uint32_t e = __hip_atomic_load(&mine_ctrl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const uint32_t mine = *reinterpret_cast<const uint32_t *>(p.local_list);
+    if (blockIdx.x == 0 && threadIdx.x == 0) // this rank's count, to the destination this workgroup row serves
+        sys_store(&reinterpret_cast<ExchangeCtrl *>(p.ctrl[dst_rank])->count[e & 1u][p.rank], (unsigned long long)e << 32 | mine);
+    if (threadIdx.x == 0) s_first = 0u, s_mine = mine;
+    __syncthreads();
+    // The counts of ALL ranks (their stores into THIS rank's block); those of the ranks before this one fix the offset.
+    // Waiting for every rank's count is also what orders this exchange behind the peers' use of the previous one: a
+    // rank stores its count at the start of ITS scatter, i.e. (stream order) after whatever it enqueued to read the
+    // list of the previous exchange out of the buffer this scatter is about to write into — the guarantee the
+    // count all-gather gives the collective form.
+    if (threadIdx.x < p.world) {
+        unsigned long long v = sys_load(&mine_ctrl->count[e & 1u][threadIdx.x]);
+        for (uint32_t spins = 0; (uint32_t)(v >> 32) != e; spins++) {
+            if (spins == kExchangeSpinLimit) {
+                latch_status(p.status, ORBIT_E_TIMEOUT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+            v = sys_load(&mine_ctrl->count[e & 1u][threadIdx.x]);
+        }
+        if (threadIdx.x < p.rank) atomicAdd(&s_first, (uint32_t)v);
+    }
+    __syncthreads();
+    const uint32_t first = s_first;
+    const uint32_t room = first < p.out_capacity ? p.out_capacity - first : 0u;
+    const uint32_t n_items = min(mine, room);
+    const uint64_t words = (uint64_t)n_items * p.stride / 4u;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(p.local_list + p.header_bytes);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(p.out[dst_rank] + p.header_bytes + (uint64_t)first * p.stride);
+    const uint64_t step = (uint64_t)gridDim.x * 256u * 4u;
+    for (uint64_t w = ((uint64_t)blockIdx.x * 256u + (threadIdx.x & ~63u)) * 4u + (threadIdx.x & 63u); w < words;
+         w += step) {
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = w + 64u * k < words ? src[w + 64u * k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (w + 64u * k < words) dst[w + 64u * k] = v[k];
+    }
+    // every store of this workgroup has left for the destination before it counts itself out; the last one out raises
+    // done there
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t before = __hip_atomic_fetch_add(&mine_ctrl->left[dst_rank], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == gridDim.x - 1u) {
+            __hip_atomic_store(&mine_ctrl->left[dst_rank], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            sys_store(&reinterpret_cast<ExchangeCtrl *>(p.ctrl[dst_rank])->done[p.rank], (unsigned long long)e);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void exchange_wait_kernel(const ExchangeListParams p) {
+    ExchangeCtrl *c = reinterpret_cast<ExchangeCtrl *>(p.ctrl[p.rank]);
+    const uint32_t e = __hip_atomic_load(&c->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    uint32_t count = 0;
+    if (threadIdx.x < p.world) {
+        unsigned long long v = sys_load(&c->count[e & 1u][threadIdx.x]), d = sys_load(&c->done[threadIdx.x]);
+        for (uint32_t spins = 0; (uint32_t)(v >> 32) != e || (uint32_t)d != e; spins++) {
+            if (spins == kExchangeSpinLimit) {
+                latch_status(p.status, ORBIT_E_TIMEOUT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+            v = sys_load(&c->count[e & 1u][threadIdx.x]);
+            d = sys_load(&c->done[threadIdx.x]);
+        }
+        count = (uint32_t)v;
+    }
+    const uint32_t total = wave_reduce_add(count);
+    if (threadIdx.x == 0) {
+        uint32_t *hdr = reinterpret_cast<uint32_t *>(p.out[p.rank]);
+        hdr[0] = min(total, p.out_capacity);
+        for (uint32_t k = 1; k < p.header_bytes / 4u; k++) hdr[k] = 0u;
+        if (total > p.out_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+        __hip_atomic_store(&c->epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 } // namespace
+
+hipError_t launch_exchange_list(const ExchangeListParams &p, uint32_t num_cus, hipStream_t s) {
+    // enough workgroups per destination to keep a link busy, few enough that `world` copies share the device
+    const uint32_t per_dst = max(num_cus * 2u / max(p.world, 1u), 8u);
+    hipLaunchKernelGGL(exchange_scatter_kernel, dim3(per_dst, p.world), dim3(256), 0, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(exchange_wait_kernel, dim3(1), dim3(64), 0, s, p);
+    return hipGetLastError();
+}
 
 // mesh-shading path: expand the per-record ballots, no draw list
 hipError_t launch_task_records(const MeshletCullParams &p, hipStream_t s) {

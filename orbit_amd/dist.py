@@ -116,10 +116,17 @@ class P2PExchange:
     collective is the completion barrier.  RCCL carries 2 x 4 B per rank and step; the lists travel as plain stores
     on all links at once.
 
+    `signalling` = "device" (default): not even those two collectives — counts and completion are stores into the
+    peers' control blocks, awaited on the device (orbit_exchange_list): a step is kernels only, nothing in it is issued
+    through torch.distributed, and it can be captured into a graph.  "collectives": the form above.
+
     `transport` (tests): an object with the same `alloc / open / scatter` surface; the default drives the HIP library.
     """
 
-    def __init__(self, engine, item_capacity, header, stride, device, group=None, transport=None):
+    CTRL_BYTES = 1024  # ORBIT_P2P_CTRL_BYTES
+
+    def __init__(self, engine, item_capacity, header, stride, device, group=None, transport=None, signalling="device"):
+        self.signalling = signalling if (transport is None or hasattr(transport, "exchange")) else "collectives"
         self.group, self.header, self.stride, self.capacity = group, header, stride, int(item_capacity)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.device = device
@@ -140,6 +147,22 @@ class P2PExchange:
         except Exception as ex:  # noqa: BLE001
             err = ex
         self._agree(err, "mapping a peer's exchange buffer")
+        self.ctrls = None
+        if self.signalling == "device":  # every rank's control block, mapped like the output buffers
+            err = None
+            try:
+                self.ctrl, chandle = self.t.alloc(self.CTRL_BYTES)
+            except Exception as ex:  # noqa: BLE001
+                err, chandle = ex, None
+            self._agree(err, "allocating / exporting the control block")
+            chandles = [None] * self.world
+            dist.all_gather_object(chandles, chandle, group=group)
+            try:
+                self.ctrls = [self.ctrl if r == self.rank else self.t.open(chandles[r], self.CTRL_BYTES)
+                              for r in range(self.world)]
+            except Exception as ex:  # noqa: BLE001
+                err = ex
+            self._agree(err, "mapping a peer's control block")
         self.counts = torch.zeros(self.world, dtype=torch.int32, device=device)
         self.token = torch.zeros(1, dtype=torch.int32, device=device)
         dist.barrier(group=group)  # every peer has mapped every buffer before the first scatter
@@ -153,6 +176,10 @@ class P2PExchange:
     def exchange(self, local_list, stream=None):
         """Enqueues one exchange of `local_list` ({count | header | items}); afterwards (in stream order) `self.out`
         holds {total | header | all ranks' items in rank order}.  No host synchronisation."""
+        if self.signalling == "device":  # two launches, no collective: counts and completion travel like the lists
+            self.t.exchange(local_list, self.rank, self.world, self.peers, self.ctrls, self.capacity, self.header,
+                            self.stride, stream)
+            return self.out
         mine = local_list[:4].view(torch.int32)
         dist.all_gather_into_tensor(self.counts, mine, group=self.group)       # 4 B per rank, stays on the device
         self.t.scatter(local_list, self.counts, self.rank, self.world, self.peers, self.capacity, self.header,
@@ -182,6 +209,9 @@ class _HipTransport:
 
     def scatter(self, local_list, counts, rank, world, peers, capacity, header, stride, stream):
         self.eng.scatter_list(local_list, counts, rank, world, peers, capacity, header, stride, stream=stream)
+
+    def exchange(self, local_list, rank, world, peers, ctrls, capacity, header, stride, stream):
+        self.eng.exchange_list(local_list, rank, world, peers, ctrls, capacity, header, stride, stream=stream)
 
     def close(self):
         for ptr in self.opened:

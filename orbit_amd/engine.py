@@ -342,6 +342,16 @@ class Engine:
         _lib.check(self._lib.orbit_scatter_list(self._ctx, _ptr(local_list), _ptr(counts), rank, world, arr,
                                                 out_capacity, header_bytes, stride, _stream(stream)), self._ctx)
 
+    def exchange_list(self, local_list, rank, world, out_buffers, ctrl_buffers, out_capacity, header_bytes, stride,
+                      stream=None):
+        """orbit_exchange_list: the rank-ordered all-gather of the ranks' lists with counts and completion signalled on
+        the device (no collective, no host round trip; capturable).  `out_buffers` / `ctrl_buffers`: lists of device
+        pointers (ints or tensors), rank r's output buffer / control block as mapped in this process."""
+        outs = (C.c_void_p * world)(*[_ptr(b) for b in out_buffers])
+        ctrls = (C.c_void_p * world)(*[_ptr(b) for b in ctrl_buffers])
+        _lib.check(self._lib.orbit_exchange_list(self._ctx, _ptr(local_list), rank, world, outs, ctrls, out_capacity,
+                                                 header_bytes, stride, _stream(stream)), self._ctx)
+
     def gather_visible_meshlets(self, nccl_comm, rank, world, local_visible_buffer, out_visible_buffer, out_capacity,
                                 stream=None):
         comm = nccl_comm if isinstance(nccl_comm, C.c_void_p) else C.c_void_p(int(nccl_comm))

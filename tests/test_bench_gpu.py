@@ -60,21 +60,28 @@ def _run_ranks(extra, env):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("expand,exchange", [("none", "records"), ("all", "records"), ("all", "visible"), ("none", "commands")])
-def test_bench_two_ranks_on_one_device_whole_device_path(expand, exchange):
+@pytest.mark.parametrize("expand,exchange,signalling", [
+    ("own", "records", "device"),  # the default step: kernels only, the shard's command buffer built inside it
+    ("none", "records", "device"), ("all", "records", "device"), ("all", "visible", "collectives"),
+    ("none", "commands", "device"), ("own", "records", "collectives")])
+def test_bench_two_ranks_on_one_device_whole_device_path(expand, exchange, signalling):
     """`bench.py --gpus 2` as the driver starts it (bench.py spawns its ranks), both ranks on the box's one GPU: the
-    real exchange — HIP IPC mappings of the peers' buffers, the scatter kernel, the count / completion collectives
-    (over gloo: RCCL cannot put two ranks on one device) — then every rank's segment check and the cross-rank
-    checksum of the gathered list inside bench.py (it exits non-zero if they fail)."""
-    args = ["--gpus", "2", "--expand", expand] + ([] if exchange == "records" else ["--exchange", exchange])  # records: the default
+    real exchange — HIP IPC mappings of the peers' buffers and control blocks, the scatter kernel, counts and completion
+    signalled on the device (or by two collectives over gloo: RCCL cannot put two ranks on one device) — then every
+    rank's segment check, the check of its own command buffer and the cross-rank checksum of the gathered list inside
+    bench.py (it exits non-zero if they fail)."""
+    args = ["--gpus", "2", "--expand", expand, "--signalling", signalling] + (
+        [] if exchange == "records" else ["--exchange", exchange])  # records: the default
     d = _run_ranks(args, dict(ORBIT_BENCH_ONE_DEVICE="1", ORBIT_BENCH_BACKEND="gloo"))
     c = d["config"]
     assert d["n_gpus"] == 2 and c["world_size"] == 2 and c["gather"] is True and c["transport"] == "p2p"
-    assert c["exchange"] == exchange and c["backend"] == "gloo"
+    assert c["exchange"] == exchange and c["backend"] == "gloo" and c["signalling"] == signalling
+    assert c["transport_fallback"] is None and c["step_intervals"]["intervals"] >= 2
     assert c["expand"] == (expand if exchange != "commands" else None)
+    assert ("own shard" in c["step_product"]) == (expand == "own" and exchange == "records")
     pr = d["per_rank"]
     assert len(pr["cull_ms"]) == 2 and len(pr["exchange_ms"]) == 2 and all(v > 0 for v in pr["cull_ms"] + pr["exchange_ms"])
-    assert (pr["expand_ms"] is None) == (expand == "none" or exchange == "commands")
+    assert (pr["expand_ms"] is None) == (expand != "all" or exchange == "commands")
     assert sum(pr["meshlets_in"]) == c["meshlets_into_meshlet_cull"] == 6000 * 256
     assert sum(pr["survivors"]) == c["survivors"] > 0
     assert abs(d["value"] - c["meshlets_into_meshlet_cull"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

@@ -22,7 +22,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, seed, n_entities, out_dir):
+def _worker(rank, world, port, seed, n_entities, out_dir, signalling="collectives"):
     import torch
     import torch.distributed as dist
 
@@ -48,14 +48,34 @@ def _worker(rank, world, port, seed, n_entities, out_dir):
     eng.entity_cull(ci, edb, mi, disp, ents, e - b, disp_cap, draw_first=b)
     eng.meshlet_cull(ci, disp, mlt, draw, ents, mats, disp_cap, cap)
     eng.meshlet_cull_visible(ci, disp, mlt, vis, ents, mats, disp_cap, cap)
-    ex_c = P2PExchange(eng, cap, L.DRAW_HEADER, 28, dev)
-    ex_v = P2PExchange(eng, cap, L.VISIBLE_HEADER, 8, dev)
+    ex_c = P2PExchange(eng, cap, L.DRAW_HEADER, 28, dev, signalling=signalling)
+    ex_v = P2PExchange(eng, cap, L.VISIBLE_HEADER, 8, dev, signalling=signalling)
+    assert ex_c.signalling == signalling
     expanded = torch.zeros(L.DRAW_HEADER + 28 * cap, dtype=torch.uint8, device=dev)
-    for step in range(3):  # buffers are reused step after step
+    steps = 3 if signalling == "collectives" else 12
+    for step in range(steps):  # buffers are reused step after step
         out_c = ex_c.exchange(draw)
         out_v = ex_v.exchange(vis)
         eng.expand_visible(out_v, mlt, expanded, cap)
     torch.cuda.synchronize()
+    if signalling == "device":
+        # the same step — cull of the shard, both exchanges, the expansion — captured into ONE graph and replayed: no
+        # collective and no host call inside (the epochs live in the control blocks)
+        expanded.zero_()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                eng.entity_cull(ci, edb, mi, disp, ents, e - b, disp_cap, draw_first=b, stream=s)
+                eng.meshlet_cull(ci, disp, mlt, draw, ents, mats, disp_cap, cap, stream=s)
+                eng.meshlet_cull_visible(ci, disp, mlt, vis, ents, mats, disp_cap, cap, stream=s)
+                ex_c.exchange(draw, stream=s)
+                ex_v.exchange(vis, stream=s)
+                eng.expand_visible(ex_v.out, mlt, expanded, cap, stream=s)
+        dist.barrier()  # every rank has captured (capture itself enqueues nothing)
+        for _ in range(5):
+            g.replay()
+        torch.cuda.synchronize()
     eng.status()
     dist.barrier()
     np.save(os.path.join(out_dir, f"cmd_{rank}.npy"), out_c.cpu().numpy())
@@ -67,12 +87,15 @@ def _worker(rank, world, port, seed, n_entities, out_dir):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("signalling", ["collectives", "device"])
 @pytest.mark.parametrize("world,n_entities", [(2, 700), (3, 333)])
-def test_p2p_exchange_processes_sharing_one_gpu(tmp_path, oracle, world, n_entities):
+def test_p2p_exchange_processes_sharing_one_gpu(tmp_path, oracle, world, n_entities, signalling):
+    """signalling = "device": orbit_exchange_list — counts and completion are stores into the peers' control blocks
+    awaited on the device; the step has no collective in it and is also replayed from a captured graph."""
     import torch.multiprocessing as mp
 
     seed = 35
-    mp.spawn(_worker, args=(world, _free_port(), seed, n_entities, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), seed, n_entities, str(tmp_path), signalling), nprocs=world, join=True)
     scene = sc.make_scene(seed, n_entities, n_meshes=60)
     cam = sc.default_camera()
     ci = sc.make_cull_info(cam.view, cam.planes)
