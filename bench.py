@@ -699,6 +699,11 @@ def main():
                       "what": f"torch.sum over the {words.numel() * 4 / 1e9:.2f} GB meshlet buffer viewed as f32, median of 5",
                       "meshlet_eval_vs_stream": achieved / (words.numel() * 4 / (sms * 1e-3) / 1e9)}
 
+    # "frustum + cone (pass 0) as headline, two-pass as secondary" — the same scene through the whole
+    # two-pass HiZ frame, after the timed region, N = 1 only.
+    two_pass = run_two_pass(args, spec, slots[0], draws, mesh, ent, meshlets_base, materials, disp_cap, draw_cap, dev, L) \
+        if (world == 1 and not use_dist) else None
+
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_sample_entities > 0:
         cpu_baseline = run_cpu_baseline(args, spec, ci, draws, mesh, ent, meshlets, materials, disp, draw, L)
@@ -772,6 +777,7 @@ def main():
             },
             "cpu_baseline": cpu_baseline,
             "protocol_8d": protocol_8d,
+            "two_pass": two_pass,
             "frame_latency_ms": frame_latency_ms,
             "frame_latency_ms_from_meshlet_buffer": buffer_path_latency_ms,
             "ms_per_step_from_meshlet_buffer": buffer_path_ms_per_step,
@@ -792,6 +798,69 @@ def main():
         s.eng.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def run_two_pass(args, spec, slot, draws, mesh, ent, meshlets_base, materials, disp_cap, draw_cap, dev, L):
+    """The bench scene through the full two-pass frame of the renderer (forward.rs:286-298,391-403): pass-1 cull (last
+    frame's bits) -> depth_reduce (1920x1080) -> pass-2 cull, steady state (frames >= 3), one HIP event pair per frame,
+    the median.  Depth: a wall 950 m in front of the camera over 60 % of the screen (tools/bench_c5_two_pass.py, which
+    also checks the frame against the oracle; tests/test_gpu_full_size.py does so in the GPU suite)."""
+    from orbit_amd import camera
+    from orbit_amd.engine import depth_pyramid_desc
+
+    eng = slot.eng
+    E, M = spec.entities, spec.meshlets_per_entity
+    W, H = 1920, 1080
+    from orbit_amd import passes
+
+    z_near = 0.01  # the renderer's camera (src/app.rs:744-752), as camera.frame_cull_info builds it
+    depth = torch.zeros(H, W, dtype=torch.float32, device=dev)
+    depth[:, : int(0.6 * W)] = z_near / 950.0
+    d = depth_pyramid_desc(W, H)
+    pyr = torch.zeros(d.total_texels, dtype=torch.float32, device=dev)
+    ps = (d.width, d.height)
+    draw1 = torch.zeros(L.DRAW_HEADER + 28 * draw_cap, dtype=torch.uint8, device=dev)
+    draw2 = torch.zeros_like(draw1)
+    evis = torch.zeros((E + 31) // 32, dtype=torch.int32, device=dev)
+    mvis = torch.zeros(E * spec.vis_words_per_entity, dtype=torch.int32, device=dev)
+    st = slot.stream
+    # OcclusionCullInfo::VisibilityRead / VisibilityWrite through the host mirror (forward.rs:266-298, 371-403)
+    ci1 = camera.frame_cull_info((0.0, 0.0, 1300.0), n_planes=args.planes, occlusion_kind=passes.VISIBILITY_READ,
+                                 visibility_buffer=evis, meshlet_visibility_buffer=mvis)
+    ci2 = camera.frame_cull_info((0.0, 0.0, 1300.0), n_planes=args.planes, occlusion_kind=passes.VISIBILITY_WRITE,
+                                 visibility_buffer=evis, meshlet_visibility_buffer=mvis, depth_pyramid=pyr,
+                                 depth_pyramid_size=ps)
+
+    def frame():
+        eng.entity_cull(ci1, draws, mesh, slot.disp, ent, E, disp_cap, visibility_buffer=evis, stream=st)
+        eng.meshlet_cull(ci1, slot.disp, meshlets_base, draw1, ent, materials, disp_cap, draw_cap,
+                         meshlet_visibility_buffer=mvis, material_count=spec.materials, stream=st)
+        eng.depth_reduce(depth, W, H, pyr, stream=st)
+        eng.entity_cull(ci2, draws, mesh, slot.disp, ent, E, disp_cap, visibility_buffer=evis, depth_pyramid=pyr,
+                        depth_pyramid_size=ps, stream=st)
+        eng.meshlet_cull(ci2, slot.disp, meshlets_base, draw2, ent, materials, disp_cap, draw_cap,
+                         meshlet_visibility_buffer=mvis, depth_pyramid=pyr, depth_pyramid_size=ps,
+                         material_count=spec.materials, stream=st)
+
+    ts = []
+    for f in range(11):
+        a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st)
+        frame()
+        z.record(st)
+        torch.cuda.synchronize()
+        if f >= 3:
+            ts.append(a.elapsed_time(z))
+    eng.status()
+    ms = float(np.median(ts))
+    return {"what": "pass-1 cull -> depth_reduce 1920x1080 -> pass-2 cull of the same scene (entity_cull + meshlet_cull "
+                    "each), steady state, median of 8 frames each inside one HIP event pair; wall at 950 m over 60 % of the "
+                    "screen",
+            "frame_ms": ms, "frame_ms_min": float(min(ts)), "frame_ms_max": float(max(ts)),
+            "meshlets_per_sec": E * M / (ms * 1e-3),
+            "pass1_draws": int(draw1[:4].view(torch.int32).item()), "pass2_draws": int(draw2[:4].view(torch.int32).item()),
+            "visible_meshlets": int(torch.count_nonzero((mvis.view(torch.uint8).unsqueeze(1) >> torch.arange(
+                8, device=dev, dtype=torch.uint8)) & 1).item())}
 
 
 def dry_ranks(args, rank, world, json_fd):

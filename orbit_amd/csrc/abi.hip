@@ -72,6 +72,7 @@ struct OrbitCtx {
     uint32_t a_coarse_seg = 0;
     uint32_t *m_tickets = nullptr;
     uint32_t *f_sync = nullptr, *f_ent_flags = nullptr, *f_tile_flags = nullptr; // one-launch cull (cull_fused.hip)
+    uint32_t *d_tickets = nullptr; // depth_reduce: one arrival counter per pyramid of a batch
     uint64_t fused_culls = 0;                                                    // views culled by it so far
     uint32_t *g_counts = nullptr; // gather_visible: per-rank command counts
     int32_t *status = nullptr;
@@ -277,6 +278,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t o_gc = carve(256);
     const size_t o_tk = carve(kTicketPools * kTicketStride * 4);
     const size_t o_fsy = carve(kFusedSyncWords * 4), o_fef = carve((ent / 256 + 2) * 4);
+    const size_t o_dtk = carve((size_t)kMaxPyramidBatch * kDepthTicketWords * 4);
     const size_t o_eproto = carve(ent * sizeof(OrbitMeshletDispatch));
     const size_t o_ebs = carve((ent / 256 + 1) * 4), o_et = carve(256);
     const size_t o_mtc = carve(mtiles * 4), o_mtb = carve(mtiles * 4), o_mt = carve(256);
@@ -341,6 +343,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->g_counts = (uint32_t *)(a + o_gc);
     ctx->m_tickets = (uint32_t *)(a + o_tk);
     ctx->f_sync = (uint32_t *)(a + o_fsy);
+    ctx->d_tickets = (uint32_t *)(a + o_dtk);
     ctx->f_ent_flags = (uint32_t *)(a + o_fef);
     ctx->f_tile_flags = (uint32_t *)(a + o_ftf);
 #ifdef ORBIT_TRIAGE // perf-triage builds (tools/mkvariant_any.sh); the product library reads no environment variable
@@ -1005,6 +1008,7 @@ int32_t orbit_depth_reduce_multi(OrbitCtx *ctx, const OrbitDepthReduceItem *item
     static_assert(ORBIT_MAX_PYRAMID_BATCH == kMaxPyramidBatch, "batch size");
     DepthReduceBatch b{};
     b.count = count;
+    b.tickets = ctx->d_tickets;
     for (uint32_t i = 0; i < count; i++) {
         const OrbitDepthReduceItem &it = items[i];
         if (!it.depth || (!it.pyramid) == (!it.levels))

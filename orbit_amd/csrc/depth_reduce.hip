@@ -16,7 +16,7 @@
 // exactly texels {2X, 2X+1} of the source (clamped when the source dimension
 // is already 1); only level 0 (screen -> next_pow2/2, a non-integer ratio) uses
 // the fractional footprint arithmetic.
-#include "kernels.h"
+#include "handoff.h"
 
 namespace orbit {
 
@@ -24,6 +24,11 @@ namespace {
 
 constexpr int kTile = 32;
 constexpr int kInBlockLevels = 6; // levels 0..5 from one 32x32 tile
+
+// does the tile launch finish this pyramid itself (its last workgroup reduces levels 6.. in LDS)?
+__host__ __device__ inline bool tail_in_launch(const DepthReduceParams &p) {
+    return p.mips > (uint32_t)kInBlockLevels && (p.w0 >> (kInBlockLevels - 1)) <= 64u && (p.h0 >> (kInBlockLevels - 1)) <= 64u;
+}
 
 __device__ __forceinline__ float reduce4(const float *src, uint32_t pitch, int ox, int oy, uint32_t sw, uint32_t sh,
                                          uint32_t X, uint32_t Y) {
@@ -36,7 +41,43 @@ __device__ __forceinline__ float reduce4(const float *src, uint32_t pitch, int o
     return gmin(gmin(a, b), gmin(c, d));
 }
 
+// Levels kInBlockLevels.. : the workgroup that finishes LAST among a pyramid's tile workgroups does them, inside the
+// same launch (rounds 1-3: a second, one-workgroup launch that went to memory and back for every level: 4.2 us + a
+// launch boundary at 1080p).  Every workgroup stores its one texel of level kInBlockLevels - 1 write-through, drains it
+// and takes a ticket; the last ticket's holder loads that level (at most kTailSide^2 texels) with sc1 loads into LDS and
+// reduces the remaining levels there.  Larger pyramids (level 5 beyond 64 x 64: a level 0 beyond 2048^2) keep the second
+// launch.  handoff.h has the rules this follows.
+constexpr uint32_t kTailSide = 64;
+
+__device__ __forceinline__ void depth_reduce_tail_in_lds(const DepthReduceParams &p, float *a, float *b) {
+    const uint32_t k0 = kInBlockLevels - 1;
+    const uint32_t w5 = max(p.w0 >> k0, 1u), h5 = max(p.h0 >> k0, 1u);
+    const __amdgpu_buffer_rsrc_t L5 = rsrc_of(p.level[k0], (uint32_t)(((size_t)(h5 - 1u) * p.pitch[k0] + w5) * 4u));
+    for (uint32_t i = threadIdx.x; i < w5 * h5; i += blockDim.x)
+        a[i] = __uint_as_float(ld_sc1(L5, ((i / w5) * p.pitch[k0] + i % w5) * 4u));
+    __syncthreads();
+    float *src = a, *dst = b;
+    uint32_t spitch = w5;
+    for (uint32_t k = kInBlockLevels; k < p.mips; k++) {
+        const uint32_t sw = max(p.w0 >> (k - 1), 1u), sh = max(p.h0 >> (k - 1), 1u);
+        const uint32_t dw = max(p.w0 >> k, 1u), dh = max(p.h0 >> k, 1u);
+        for (uint32_t i = threadIdx.x; i < dw * dh; i += blockDim.x) {
+            const uint32_t X = i % dw, Y = i / dw;
+            const float v = reduce4(src, spitch, 0, 0, sw, sh, X, Y);
+            dst[Y * dw + X] = v;
+            p.level[k][(size_t)Y * p.pitch[k] + X] = v;
+        }
+        __syncthreads();
+        float *t = src;
+        src = dst, dst = t;
+        spitch = dw;
+    }
+}
+
+// (Staging a tile's source region — at most 66 x 66 texels of the depth buffer — in LDS first, rows loaded coalesced, was
+// measured in round 4 and lost: 14.0 against 12.1 us for the launch at 1080p; the footprints' own loads hit the L1.)
 __global__ __launch_bounds__(256) void depth_reduce_tiles(const DepthReduceBatch batch) {
+    __shared__ float tail_lds[kTailSide * kTailSide]; // the in-launch tail's (one workgroup of the launch uses it)
     __shared__ float buf0[kTile * kTile];
     __shared__ float buf1[(kTile / 2) * (kTile / 2)];
     const DepthReduceParams &p = batch.p[blockIdx.z];
@@ -84,17 +125,46 @@ __global__ __launch_bounds__(256) void depth_reduce_tiles(const DepthReduceBatch
             float v = 0.0f;
             if (X < dw && Y < dh) {
                 v = reduce4(src, spitch, (int)oxs, (int)oys, sw, sh, X, Y);
-                p.level[k][(size_t)Y * p.pitch[k] + X] = v;
+                float *out = p.level[k] + ((size_t)Y * p.pitch[k] + X);
+                // the level the in-launch tail reads from other workgroups' hands: write-through
+                if (k == kInBlockLevels - 1) __hip_atomic_store(reinterpret_cast<uint32_t *>(out), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *out = v;
             }
             dstl[ly * tw + lx] = v;
         }
         __syncthreads();
     }
+    if (!tail_in_launch(p)) return; // (block-uniform)
+    // the pyramid's last workgroup out does levels 6.. (the buffers above are free again: reused as its LDS)
+    __shared__ uint32_t s_last;
+    drain_stores();
+    __syncthreads();
+    if (t == 0) {
+        // two levels of arrival counters — a row of tile workgroups, then the rows: a thousand returning atomics on ONE
+        // word queue for 12 us on this chip (~88 per us and word); 32 + 32 on 33 words do not
+        const uint32_t tx = (p.w0 + kTile - 1) / kTile, ty = (p.h0 + kTile - 1) / kTile;
+        uint32_t *base = batch.tickets + blockIdx.z * kDepthTicketWords;
+        uint32_t *row = base + (1u + blockIdx.y) * 16u;
+        uint32_t last = 0u;
+        if (ticket(row) == tx - 1u) {
+            __hip_atomic_store(row, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // next launch
+            if (ticket(base) == ty - 1u) {
+                __hip_atomic_store(base, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1u;
+            }
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (uniform(s_last) == 0u) return;
+    static_assert((kTailSide / 2) * (kTailSide / 2) <= kTile * kTile, "tail buffers");
+    depth_reduce_tail_in_lds(p, tail_lds, buf0);
 }
 
-// Levels kInBlockLevels.. from global memory, one block.
+// Levels kInBlockLevels.. from global memory, one block (pyramids too large for the in-launch tail).
 __global__ __launch_bounds__(1024) void depth_reduce_tail(const DepthReduceBatch batch) {
     const DepthReduceParams &p = batch.p[blockIdx.x];
+    if (tail_in_launch(p)) return;
     for (uint32_t k = kInBlockLevels; k < p.mips; k++) {
         const float *src = p.level[k - 1];
         float *dst = p.level[k];
@@ -112,16 +182,17 @@ __global__ __launch_bounds__(1024) void depth_reduce_tail(const DepthReduceBatch
 
 hipError_t launch_depth_reduce(const DepthReduceBatch &b, hipStream_t s) {
     if (b.count == 0 || b.count > kMaxPyramidBatch) return hipErrorInvalidValue;
-    uint32_t gx = 0, gy = 0, max_mips = 0;
+    uint32_t gx = 0, gy = 0;
+    bool second = false;
     for (uint32_t i = 0; i < b.count; i++) {
         gx = max(gx, (b.p[i].w0 + kTile - 1) / kTile);
         gy = max(gy, (b.p[i].h0 + kTile - 1) / kTile);
-        max_mips = max(max_mips, b.p[i].mips);
+        second = second || (b.p[i].mips > (uint32_t)kInBlockLevels && !tail_in_launch(b.p[i]));
     }
     hipLaunchKernelGGL(depth_reduce_tiles, dim3(gx, gy, b.count), dim3(256), 0, s, b);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (max_mips > (uint32_t)kInBlockLevels) { // pyramids without a tail fall through their (empty) level loop
+    if (second) {
         hipLaunchKernelGGL(depth_reduce_tail, dim3(b.count), dim3(1024), 0, s, b);
         e = hipGetLastError();
     }

@@ -131,7 +131,11 @@ constexpr uint32_t kMaxPyramidBatch = 8;
 struct DepthReduceBatch {
     DepthReduceParams p[kMaxPyramidBatch];
     uint32_t count;
+    uint32_t *tickets; // context scratch: kMaxPyramidBatch x kDepthTicketWords, zero between launches (depth_reduce.hip)
 };
+// per pyramid: one arrival counter for the rows and one per row of tile workgroups (at most 64 rows take the in-launch
+// tail), 64 B apart
+constexpr uint32_t kDepthTicketWords = (1u + 64u) * 16u;
 
 struct ClusterMarkParams {
     OrbitMarkActivePush pc;

@@ -48,6 +48,9 @@ def test_bench_line_has_the_contract_fields(source):
     assert p8["warmup"] == 5 and p8["steps"] >= 20 and p8["ms_per_step_min"] <= p8["ms_per_step_median"] <= p8["ms_per_step_max"]
     assert d["config"]["warmup_effective"] >= d["config"]["settle_frames"] + d["warmup"] + 25
     assert len(d["roofline"]["library_sha256"]) == 64 and d["roofline"]["traffic_current"] is None
+    tp = d["two_pass"]  # config 5's two-pass frame as the secondary figure
+    assert tp["frame_ms_min"] <= tp["frame_ms"] <= tp["frame_ms_max"] and tp["meshlets_per_sec"] > 0
+    assert tp["pass1_draws"] + tp["pass2_draws"] > 0 and tp["visible_meshlets"] > 0
 
 
 def _run_ranks(extra, env):
