@@ -492,6 +492,31 @@ hipError_t launch_meshlet_eval(const MeshletCullParams &p, uint32_t num_cus, hip
     const uint32_t max_tiles = (p.dispatch_capacity + kTileRecords - 1) / kTileRecords;
     const uint32_t pass = p.ci.occlusion_pass;
     const dim3 grid(eval_grid(pass, p.ms.sphere != nullptr, max_tiles, num_cus));
+#ifndef ORBIT_PASS2_BY_VALUE
+    // Pass 2 goes through the several-views kernel with one view.  With the block as the kernel's own argument the
+    // compiler keeps all of it in scalar registers and, next to the HiZ test's own, runs out of them: 25-34 spilled
+    // (v_writelane / v_readlane in a kernel that is bound by its vector pipe); read from the argument segment at a
+    // uniform offset as it is needed, none (-Rpass-analysis=kernel-resource-usage; profiles/r04_notes.md).
+    if (pass == 2u) {
+        MeshletCullViews one{};
+        one.v[0] = p;
+        ViewGroup g{};
+        const int src = p.ms.sphere == nullptr ? 0 : (p.ms.cls0 != nullptr ? 2 : 1);
+        const dim3 block(kEvWaves * 64);
+        const bool ortho = p.ci.projection_type == 1;
+        if (src == 2) {
+            if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<2, 1, true, true>), grid, block, 0, s, one, g);
+            else hipLaunchKernelGGL((meshlet_eval_views_kernel<2, 0, true, true>), grid, block, 0, s, one, g);
+        } else if (src == 1) {
+            if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<2, 1, true>), grid, block, 0, s, one, g);
+            else hipLaunchKernelGGL((meshlet_eval_views_kernel<2, 0, true>), grid, block, 0, s, one, g);
+        } else {
+            if (ortho) hipLaunchKernelGGL((meshlet_eval_views_kernel<2, 1, false>), grid, block, 0, s, one, g);
+            else hipLaunchKernelGGL((meshlet_eval_views_kernel<2, 0, false>), grid, block, 0, s, one, g);
+        }
+        return hipGetLastError();
+    }
+#endif
     switch (pass) {
     case 0: launch_eval_pass<0>(p, grid, s); break;
     case 1: launch_eval_pass<1>(p, grid, s); break;
