@@ -96,18 +96,36 @@ __device__ __forceinline__ uint32_t tiles_before(const FusedCullParams &p, __amd
 #define FUSED_MARK(stage, value)
 #endif
 
-template <int PASS, int PROJ, int ROWS>
-__device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
+// The workgroup's LDS: one set for the kernel, whichever pass its view runs (the three passes are three instantiations of
+// the body inside ONE kernel — a view's pass is uniform per workgroup — so that a frame's views of different passes and
+// projections are one launch).
+template <int ROWS>
+struct FusedLds {
+    PlaneLds planes;
+    AlphaLds alpha_tab;
+    EntityChunksLds ent;
+    WaveTileLds slab[kFusedWaves];
+    CandLds<kCandRing> ring[kFusedWaves]; // pass 2 only
+    Payload pay[kFusedWaves][fused_tile_records(ROWS) * 32u];
+    uint32_t cmd[kFusedWaves][64 * 7];
+    uint32_t word[2];
+};
+
+// PASS is a template parameter (it shapes the evaluation); the projection type is read at run time (PROJ = -1 in the
+// evaluation's templates: one uniform branch in the cone test).
+template <int PASS, int ROWS>
+__device__ __forceinline__ void cull_fused_body(const FusedCullParams &p, FusedLds<ROWS> &S) {
+    constexpr int PROJ = -1;
     constexpr uint32_t kRecs = fused_tile_records(ROWS); // records per tile
     constexpr uint32_t kFusedCap = kRecs * 32u;          // survivors a tile can have: its payload slab holds them all
-    __shared__ PlaneLds planes;
-    __shared__ AlphaLds alpha_tab;
-    __shared__ EntityChunksLds ent_lds;
-    __shared__ WaveTileLds slab[kFusedWaves];
-    __shared__ CandLds<(PASS == 2 ? kCandRing : 1u)> ring[kFusedWaves]; // pass 2 only
-    __shared__ Payload s_pay[kFusedWaves][kFusedCap];
-    __shared__ uint32_t s_cmd[kFusedWaves][64 * 7];
-    __shared__ uint32_t s_word[2];
+    PlaneLds &planes = S.planes;
+    AlphaLds &alpha_tab = S.alpha_tab;
+    EntityChunksLds &ent_lds = S.ent;
+    WaveTileLds(&slab)[kFusedWaves] = S.slab;
+    CandLds<kCandRing>(&ring)[kFusedWaves] = S.ring;
+    Payload(&s_pay)[kFusedWaves][kFusedCap] = S.pay;
+    uint32_t(&s_cmd)[kFusedWaves][64 * 7] = S.cmd;
+    uint32_t(&s_word)[2] = S.word;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t max_tiles = (p.m.dispatch_capacity + kRecs - 1u) / kRecs;
     const __amdgpu_buffer_rsrc_t SY = rsrc_of(p.sync, kFusedSyncWords * 4u);
@@ -286,58 +304,52 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p) {
 // blockIdx.y = view (orbit_cull_views: one or several), every view on flags of its own.  The parameter blocks travel by
 // value in the kernel-argument segment and are read at a uniform offset (scalar loads, as needed): the single-view
 // form with the whole block in scalar registers spilled 67-86 of them.
-template <int PASS, int PROJ, int ROWS>
+template <int ROWS>
 __global__ __launch_bounds__(kEntityBlock, 2) void cull_fused_views_kernel(const FusedCullViews all, const ViewGroup g) {
-    cull_fused_body<PASS, PROJ, ROWS>(all.v[g.idx[blockIdx.y]]);
+    __shared__ FusedLds<ROWS> lds;
+    const FusedCullParams &p = all.v[g.idx[blockIdx.y]];
+    switch (p.m.ci.occlusion_pass) { // uniform per workgroup
+    case 0: cull_fused_body<0, ROWS>(p, lds); break;
+    case 1: cull_fused_body<1, ROWS>(p, lds); break;
+    default: cull_fused_body<2, ROWS>(p, lds); break;
+    }
 }
 
 // Workgroups of one view: a wave per expected tile (a record per entity-draw or so), a workgroup per entity chunk at
-// least, never more than two per CU: the tickets make any number right, this one makes the tiles one round.
-uint32_t fused_grid(uint32_t entity_draw_count, uint32_t rows, uint32_t num_cus) {
+// least, never more than a CU holds at once (3 per CU with the 2-row tiles' 43 KB of LDS, 2 with the 8-row tiles' 61 KB),
+// shared among the `views` of the launch: the tickets make any number right, this one makes the tiles one round.
+uint32_t fused_grid(uint32_t entity_draw_count, uint32_t rows, uint32_t num_cus, uint32_t views) {
     const uint32_t chunks = (entity_draw_count + kEntityBlock - 1u) / kEntityBlock;
     // a tile is 2 x rows records, and scenes have about a record per entity-draw, fewer after the entity test
     const uint32_t waves = (entity_draw_count + 2u * rows - 1u) / (2u * rows);
-    return max(min(max(chunks, (waves + kFusedWaves - 1u) / kFusedWaves), num_cus * 2u), 1u);
+    const uint32_t cap = max(num_cus * (rows == 2u ? 3u : 2u) / max(views, 1u), 1u);
+    return max(min(max(chunks, (waves + kFusedWaves - 1u) / kFusedWaves), cap), 1u);
 }
 
 } // namespace
 
-// orbit_cull_views: the n views of `all`, one launch per (occlusion pass, projection) they use
+// orbit_cull_views: the n views of `all` — ONE launch for all of them (two when views of up to and of more than
+// kFusedSmallEntityDraws entity-draws meet in one call: they take different tile sizes)
 hipError_t launch_cull_fused_views(const FusedCullViews &all, const uint32_t *entity_draw_counts, uint32_t n,
                                    uint32_t num_cus, hipStream_t s) {
-    bool done[ORBIT_MAX_CULL_VIEWS] = {};
-    for (uint32_t i = 0; i < n; i++) {
-        if (done[i]) continue;
-        const uint32_t pass = all.v[i].m.ci.occlusion_pass, proj = all.v[i].m.ci.projection_type;
+    for (uint32_t rows = 2u; rows <= 8u; rows += 6u) {
         ViewGroup g{};
         uint32_t m = 0, most = 0;
-        for (uint32_t j = i; j < n; j++)
-            if (!done[j] && all.v[j].m.ci.occlusion_pass == pass && all.v[j].m.ci.projection_type == proj) {
-                done[j] = true;
+        for (uint32_t j = 0; j < n; j++) {
+#ifdef ORBIT_FUSED_FORCE_ROWS
+            const uint32_t want = ORBIT_FUSED_FORCE_ROWS;
+#else
+            const uint32_t want = entity_draw_counts[j] <= kFusedSmallEntityDraws ? 2u : 8u;
+#endif
+            if (want == rows) {
                 g.idx[m++] = (uint8_t)j;
                 most = max(most, entity_draw_counts[j]);
             }
-        // the views share the device: each gets its part of the two-workgroups-per-CU budget
-#ifdef ORBIT_FUSED_FORCE_ROWS
-        const uint32_t rows = ORBIT_FUSED_FORCE_ROWS;
-#else
-        const uint32_t rows = most <= kFusedSmallEntityDraws ? 2u : 8u;
-#endif
-        const dim3 grid(fused_grid(most, rows, max(num_cus / m, 1u)), m), block(kEntityBlock);
-        const bool ortho = proj == 1;
-#define ORBIT_FUSED_R(PASS, ROWS)                                                                            \
-    if (ortho) hipLaunchKernelGGL((cull_fused_views_kernel<PASS, 1, ROWS>), grid, block, 0, s, all, g);      \
-    else hipLaunchKernelGGL((cull_fused_views_kernel<PASS, 0, ROWS>), grid, block, 0, s, all, g);
-#define ORBIT_FUSED(PASS)                      \
-    if (rows == 2u) { ORBIT_FUSED_R(PASS, 2) } \
-    else { ORBIT_FUSED_R(PASS, 8) }
-        switch (pass) {
-        case 0: ORBIT_FUSED(0) break;
-        case 1: ORBIT_FUSED(1) break;
-        default: ORBIT_FUSED(2) break;
         }
-#undef ORBIT_FUSED
-#undef ORBIT_FUSED_R
+        if (m == 0) continue;
+        const dim3 grid(fused_grid(most, rows, num_cus, m), m), block(kEntityBlock);
+        if (rows == 2u) hipLaunchKernelGGL((cull_fused_views_kernel<2>), grid, block, 0, s, all, g);
+        else hipLaunchKernelGGL((cull_fused_views_kernel<8>), grid, block, 0, s, all, g);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

@@ -56,7 +56,12 @@ out = {"scene": f"{scene.entity_draw_count} entity draws, {len(scene.meshlets)} 
 out["culls_one_after_the_other_ms"] = timeit(sequential)
 ref = [v["draw_commands_buffer"].clone() for v in views]
 arr, keep = eng.prepare_views(views)
+# the library's choice for views of this size: the one-launch cull (one launch per projection type: 2 for the 5 views)
 out["orbit_cull_views_ms"] = timeit(lambda: eng.cull_views_prepared(arr))
+out["orbit_cull_views_fused_views"] = eng.fused_culls()
+# ... and the launch chain (cull_path = 1: one entity launch, 2 evaluations, scan, emit for the 5 views)
+eng_chain = Engine(0, cull_path=1)
+out["orbit_cull_views_launch_chain_ms"] = timeit(lambda: eng_chain.cull_views_prepared(arr))
 # the same two ways as replayed HIP graphs (no host in the loop)
 def graph_of(fn):
     st = torch.cuda.Stream()
