@@ -699,14 +699,14 @@ def main():
                       "what": f"torch.sum over the {words.numel() * 4 / 1e9:.2f} GB meshlet buffer viewed as f32, median of 5",
                       "meshlet_eval_vs_stream": achieved / (words.numel() * 4 / (sms * 1e-3) / 1e9)}
 
-    # SURVEY.md §8d C5: "frustum + cone (pass 0) as headline, two-pass as secondary" — the same scene through the whole
-    # two-pass HiZ frame, after the timed region, N = 1 only.
-    two_pass = run_two_pass(args, spec, slots[0], draws, mesh, ent, meshlets_base, materials, disp_cap, draw_cap, dev, L) \
-        if (world == 1 and not use_dist) else None
-
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_sample_entities > 0:
         cpu_baseline = run_cpu_baseline(args, spec, ci, draws, mesh, ent, meshlets, materials, disp, draw, L)
+
+    # SURVEY.md §8d C5: "frustum + cone (pass 0) as headline, two-pass as secondary" — the same scene through the whole
+    # two-pass HiZ frame, after everything that looks at the headline frame's buffers (it reuses slot 0's), N = 1 only.
+    two_pass = run_two_pass(args, spec, slots[0], draws, mesh, ent, meshlets_base, materials, disp_cap, draw_cap, dev, L) \
+        if (world == 1 and not use_dist) else None
 
     if rank == 0:
         out = {
