@@ -1,10 +1,13 @@
 # The sharded engine's stages alone on one device, for the whole scene and for 1/2, 1/4, 1/8 of it (a rank's shard at
-# N = 2, 4, 8), from both meshlet sources and for both compact list formats (12-B records, 8-B items): cull, exchange
-# of the list (a world of one: the device-side cost without a wire), list bytes, and — with --expand all — the
-# expansion of the list.   usage (GPU box, repo root): bash tools/shard_pieces.sh
-for src in stream buffer; do for fmt in records visible; do for e in 195313 97656 48828 24414; do for x in none all; do
-ORBIT_BENCH_FORCE_DIST=1 timeout 300 python bench.py --meshlet-source $src --exchange $fmt --entities $e --expand $x --cpu-sample-entities 0 2>/dev/null | python3 -c "
+# N = 2, 4, 8): a world of one with the real exchange code (device-signalled orbit_exchange_list through IPC-mapped
+# buffers — the device-side cost without a wire), for the three things a step can end in (--expand own / none / all).
+# Per row: wall / K, the median and the maximum interval between consecutive steps' exchange completions inside the timed
+# region (config.step_intervals), the stages alone (cull, exchange, expansion of the whole list, the shard's own
+# commands), the evaluation launch, the list's bytes.    usage (GPU box, repo root): bash tools/shard_pieces.sh [sources]
+for src in ${1:-stream buffer}; do for e in 195313 97656 48828 24414; do for x in own none all; do
+ORBIT_BENCH_FORCE_DIST=1 timeout 300 python bench.py --meshlet-source $src --entities $e --expand $x --steps 30 --cpu-sample-entities 0 2>/dev/null | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.read()); p=d['per_rank']
-print('$src', '$fmt', $e, 'expand=$x', 'step', round(d['ms_per_step'],4), 'cull', round(p['cull_ms_max'],4), 'xchg', p['exchange_ms_max'] and round(p['exchange_ms_max'],4), 'expand', p['expand_ms_max'] and round(p['expand_ms_max'],4), 'eval', round(d['roofline']['avg_launch_ms'],4), 'list_MB', round(d['config'].get('list_bytes_per_rank_max', 0) / 1e6, 2))"
-done; done; done; done
+d=json.loads(sys.stdin.read()); p=d['per_rank']; c=d['config']; si=c['step_intervals'] or {}
+r=lambda v: v if v is None else round(v,4)
+print('$src', 'records', $e, 'expand=$x', c['signalling'], 'step', r(d['ms_per_step']), 'interval median', r(si.get('median_ms')), 'max', r(si.get('max_ms')), 'cull', r(p['cull_ms_max']), 'xchg', r(p['exchange_ms_max']), 'expand_all', r(p['expand_ms_max']), 'own_cmds', r(p.get('own_commands_ms_rank0')), 'eval', r(d['roofline']['avg_launch_ms']), 'list_MB', round((c.get('list_bytes_per_rank_max') or 0) / 1e6, 2))"
+done; done; done
