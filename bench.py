@@ -58,8 +58,9 @@ def parse():
                          "themselves")
     ap.add_argument("--expand", choices=("own", "none", "all"), default="own",
                     help="N>1, exchange records / visible: which 28-B MeshletDrawCommandBuffer the step ends in — own "
-                         "(default: every rank turns ITS shard's list into the commands of its shard, the indirect-draw "
-                         "buffer it issues its own draws from, SURVEY.md §8e, beside the all-gathered visible list), "
+                         "(default: every rank's cull ends in BOTH the record list it sends and the 28-B commands of its "
+                         "own shard, the indirect-draw buffer it issues its own draws from, SURVEY.md §8e — one "
+                         "evaluation, orbit_meshlet_cull_records_and_commands), "
                          "none (the step is cull + all-gather only: the visible list is the product), or all (every "
                          "rank expands the WHOLE gathered list: N-independent work on every GPU)")
     ap.add_argument("--signalling", choices=("device", "collectives"), default="device",
@@ -340,7 +341,13 @@ def main():
 
     def cull(s, k):
         s.eng.entity_cull(ci, draws, mesh, s.disp, ent, n_local_entities, disp_cap, draw_first=b, stream=s.stream)
-        if records_exchange:
+        if own_expand:
+            # one evaluation, two products: the record list this rank sends and the 28-B commands of its own shard (its
+            # indirect-draw buffer, "each rank issues its own draws": SURVEY.md §8e) — list launches, then scan + emit
+            s.eng.meshlet_cull_records_and_commands(ci, s.disp, meshlets_base, s.lists[k], s.own_cmds, ent, materials,
+                                                    disp_cap, list_cap, draw_cap, material_count=spec.materials,
+                                                    stream=s.stream)
+        elif records_exchange:
             s.eng.meshlet_cull_visible_records(ci, s.disp, meshlets_base, s.lists[k], ent, materials, disp_cap, list_cap,
                                                material_count=spec.materials, stream=s.stream)
         elif visible_exchange:
@@ -349,11 +356,6 @@ def main():
         else:
             s.eng.meshlet_cull(ci, s.disp, meshlets_base, s.lists[k], ent, materials, disp_cap, draw_cap,
                                material_count=spec.materials, stream=s.stream)
-
-    def expand_own(s, k):
-        # the rank's own indirect-draw buffer: its shard's survivors as 28-B commands, in canonical order, from the
-        # record list it has just produced (behind the cull on the slot's stream; the exchange of that list runs beside)
-        s.eng.expand_visible_records(s.lists[k], meshlets_base, s.own_cmds, draw_cap, stream=s.stream)
 
     step_marks = []  # N > 1: one timing event per step of the timed region, behind that step's exchange
 
@@ -367,8 +369,6 @@ def main():
         cull(s, k)
         if do_gather:
             s.cull_done[k].record(s.stream)
-            if own_expand:
-                expand_own(s, k)
             if pending:
                 gather(*pending.pop())  # previous step's list travels while this step's cull runs
                 if i is not None:
@@ -513,14 +513,18 @@ def main():
 
     # one frame alone on an idle device (nothing else in flight): the latency a single cull costs, and its parts
     s0 = slots[0]
-    serial, op_ms, x_ms, ex_ms, own_ms = [], [], [], [], []
+    serial, op_ms, x_ms, ex_ms = [], [], [], []
     last_recv = 0
     for _ in range(5):
         a, m, z = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         a.record(s0.stream)
         s0.eng.entity_cull(ci, draws, mesh, s0.disp, ent, n_local_entities, disp_cap, draw_first=b, stream=s0.stream)
         m.record(s0.stream)
-        if records_exchange:
+        if own_expand:
+            s0.eng.meshlet_cull_records_and_commands(ci, s0.disp, meshlets_base, s0.lists[0], s0.own_cmds, ent, materials,
+                                                     disp_cap, list_cap, draw_cap, material_count=spec.materials,
+                                                     stream=s0.stream)
+        elif records_exchange:
             s0.eng.meshlet_cull_visible_records(ci, s0.disp, meshlets_base, s0.lists[0], ent, materials, disp_cap,
                                                 list_cap, material_count=spec.materials, stream=s0.stream)
         elif visible_exchange:
@@ -530,15 +534,9 @@ def main():
             s0.eng.meshlet_cull(ci, s0.disp, meshlets_base, s0.lists[0], ent, materials, disp_cap, draw_cap,
                                 material_count=spec.materials, stream=s0.stream)
         z.record(s0.stream)
-        if own_expand:  # the shard's own command buffer from the list just produced, alone on the device
-            oz = torch.cuda.Event(enable_timing=True)
-            expand_own(s0, 0)
-            oz.record(s0.stream)
         torch.cuda.synchronize()
         serial.append(a.elapsed_time(z))
         op_ms.append(m.elapsed_time(z))
-        if own_expand:
-            own_ms.append(z.elapsed_time(oz))
         if do_gather:  # the exchange (+ expansion) of that list alone
             if use_dist:
                 dist.barrier()
@@ -783,7 +781,6 @@ def main():
             "ms_per_step_from_meshlet_buffer": buffer_path_ms_per_step,
             "per_rank": dict(per_rank_rows, cull_ms_max=kernel_ms_max_frame, exchange_ms_max=exchange_ms_max,
                              expand_ms_max=expand_ms_max,
-                             own_commands_ms_rank0=(float(np.median(own_ms)) if own_ms else None),
                              what="one frame alone on each rank's device, per rank: entity_cull + meshlet_cull of its "
                                   "shard, the exchange of its list, the expansion of the gathered list (--expand all "
                                   "only).  In the timed region they overlap (cull of step i+1, wire of step i, "

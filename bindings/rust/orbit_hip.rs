@@ -92,7 +92,7 @@ extern "C" {
     pub fn orbit_cull_views(ctx: *mut OrbitCtx, views: *const OrbitCullView, count: u32, stream: *mut c_void) -> i32;
     pub fn orbit_depth_reduce(ctx: *mut OrbitCtx, depth: *const f32, screen_w: u32, screen_h: u32,
                               pyramid: *mut f32, stream: *mut c_void) -> i32;
-    /// update_multiple_depth_pyramids::<C> (draw_gen.rs:569-628): up to 8 pyramids in one launch pair
+    /// update_multiple_depth_pyramids::<C> (draw_gen.rs:569-628): up to 8 pyramids in one launch
     pub fn orbit_depth_reduce_multi(ctx: *mut OrbitCtx, items: *const OrbitDepthReduceItem, count: u32,
                                     stream: *mut c_void) -> i32;
     pub fn orbit_cluster_mark(ctx: *mut OrbitCtx, push: *const c_void, depth: *const f32, masks: *mut u32,
@@ -157,6 +157,9 @@ extern "C" {
     pub fn orbit_scatter_list(ctx: *mut OrbitCtx, local_list: *const c_void, counts: *const u32, rank: u32, world: u32,
                               out_buffers: *const *mut c_void, out_capacity: u32, header_bytes: u32, stride: u32,
                               stream: *mut c_void) -> i32;
+    pub fn orbit_meshlet_cull_records_and_commands(ctx: *mut OrbitCtx, cull_info: *const c_void,
+                                                   bufs: *const OrbitMeshletCullBufs, record_buffer: *mut c_void,
+                                                   record_capacity: u32, stream: *mut c_void) -> i32;
     pub fn orbit_exchange_list(ctx: *mut OrbitCtx, local_list: *const c_void, rank: u32, world: u32,
                                out_buffers: *const *mut c_void, ctrl_buffers: *const *mut c_void, out_capacity: u32,
                                header_bytes: u32, stride: u32, stream: *mut c_void) -> i32;
@@ -188,6 +191,24 @@ pub fn check(ctx: *const OrbitCtx, rc: i32) {
 //                                                   scene.entity_draw_count as u32, hip_stream) });
 //         });
 //     // the fill_buffer clears (draw_gen.rs:356-363) disappear: the library writes the {n,1,1} header itself.
+
+// --- body swap in src/passes/draw_gen.rs::create_draw_commands (lines 239-325: both stages) -----------------------
+//
+// ONE pass, ONE library call; the library runs a scene of the renderer's size (<= 16 384 entity-draws per view) as ONE
+// launch and a larger one as the launch chain, with the same buffers either way:
+//
+//     context.add_pass(format!("{draw_commands_name}_culling_hip"))
+//         .with_dependency(meshlet_dispatch_buffer, AccessKind::ComputeShaderWrite)
+//         .with_dependency(draw_commands_buffer, AccessKind::ComputeShaderWrite)
+//         .record_custom(move |_cmd, graph| {
+//             let view = OrbitCullView { cull_info: bytes_of(&gpu_cull_info_data).as_ptr() as _,
+//                                        entity: entity_bufs(graph), meshlet: meshlet_bufs(graph),  // as above / below
+//                                        entity_draw_count: scene.entity_draw_count as u32, skip_meshlet_stage: 0 };
+//             check(ctx, unsafe { orbit_cull_views(ctx, &view, 1, hip_stream) });
+//         });
+//
+// The frame's five independent culls (forward.rs:286-298 + shadow_renderer.rs:391-403) become one pass the same way:
+// an array of five OrbitCullView and count = 5 — one launch for all of them.
 
 // --- optional: derived meshlet streams, in src/assets/mod.rs ---------------------------------------------------
 //

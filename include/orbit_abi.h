@@ -790,6 +790,13 @@ int32_t orbit_meshlet_cull_visible_records(OrbitCtx *ctx, const OrbitGpuCullInfo
                                            uint32_t record_capacity, void *stream);
 int32_t orbit_expand_visible_records(OrbitCtx *ctx, const void *record_buffer, const void *meshlet_buffer,
                                      void *draw_commands_buffer, uint32_t draw_capacity, void *stream);
+/* Both products of ONE evaluation: the record list (as orbit_meshlet_cull_visible_records: what the rank sends) and the
+ * rank's own MeshletDrawCommandBuffer in bufs->draw_commands_buffer / draw_capacity (as orbit_meshlet_cull: what it
+ * draws from, "each rank keeps its shard and issues its own indirect draws") — the list launches, then
+ * scan + emit of the same ballots; cheaper than the list followed by orbit_expand_visible_records of it. */
+int32_t orbit_meshlet_cull_records_and_commands(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info,
+                                                const OrbitMeshletCullBufs *bufs, void *record_buffer,
+                                                uint32_t record_capacity, void *stream);
 
 /* ------------------------------------------------------------------------ */
 /* The same exchange without a host round trip (one node, one process per   */

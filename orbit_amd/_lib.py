@@ -74,6 +74,8 @@ class DepthPyramidDesc(C.Structure):
 # every symbol include/orbit_abi.h declares: (restype, argtypes)
 SYMBOLS = {
     "orbit_abi_version": (C.c_uint32, []),
+    "orbit_meshlet_cull_records_and_commands": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(MeshletCullBufs),
+                                                            C.c_void_p, C.c_uint32, C.c_void_p]),
     "orbit_exchange_list": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "orbit_ctx_fused_culls": (C.c_uint64, [C.c_void_p]),

@@ -613,6 +613,8 @@ int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCull
         for (int k = 0; k < 6; k++) p.stdp[k] = ok ? v[k] : 0.0f;
     }
     p.task_records = task_records;
+    p.also_commands = nullptr;
+    p.also_commands_capacity = 0u;
     p.tile_counts = scratch->m_tile_counts;
     p.tile_masks = scratch->m_tile_masks;
     p.tile_payload = scratch->m_tile_payload;
@@ -629,13 +631,19 @@ int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCull
 
 int32_t meshlet_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
                           OrbitMeshTaskRecord *task_records, bool task_path, void *stream,
-                          void *visible_buffer = nullptr, uint32_t visible_capacity = 0, uint32_t visible_path = 0u) {
+                          void *visible_buffer = nullptr, uint32_t visible_capacity = 0, uint32_t visible_path = 0u,
+                          bool also_commands = false) {
     if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
     MeshletCullParams p;
     const int32_t rc = meshlet_cull_params(ctx, ctx, ci, b, task_records, task_path, visible_buffer, visible_capacity,
                                            visible_path, p);
     if (rc) return rc;
+    if (also_commands) { // the record list AND the commands of the same evaluation (sharded engine)
+        if (!b->draw_commands_buffer) return fail(ctx, ORBIT_E_MISSING, "records_and_commands: draw_commands_buffer is NULL");
+        p.also_commands = (uint8_t *)b->draw_commands_buffer;
+        p.also_commands_capacity = b->draw_capacity;
+    }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ctx->profiling && (ctx->prof_calls++ % ctx->profiling) == 0) {
         if (ctx->prof_used + 2 > ctx->prof_events.size()) {
@@ -942,6 +950,11 @@ int32_t orbit_meshlet_cull_visible(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, co
 int32_t orbit_meshlet_cull_visible_records(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
                                            void *record_buffer, uint32_t record_capacity, void *stream) {
     return meshlet_cull_impl(ctx, ci, b, nullptr, false, stream, record_buffer, record_capacity, 2u);
+}
+
+int32_t orbit_meshlet_cull_records_and_commands(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
+                                                void *record_buffer, uint32_t record_capacity, void *stream) {
+    return meshlet_cull_impl(ctx, ci, b, nullptr, false, stream, record_buffer, record_capacity, 2u, true);
 }
 
 int32_t orbit_expand_visible(OrbitCtx *ctx, const void *visible_buffer, const void *meshlet_buffer,

@@ -102,6 +102,11 @@ struct MeshletCullParams {
     // sharded engine (orbit_meshlet_cull_visible): draw_buffer is an OrbitVisibleMeshlet buffer (8-B header, 8 B per
     // survivor) and draw_capacity its capacity
     uint32_t visible_list; // 1: 8-B items, 2: 12-B records with their ballots (orbit_meshlet_cull_visible_records)
+    // visible_list == 2 only (orbit_meshlet_cull_records_and_commands): non-null = the same evaluation ALSO ends in the
+    // MeshletDrawCommandBuffer (scan + emit behind the record launches) — a shard's own indirect draws next to the list
+    // it sends
+    uint8_t *also_commands;
+    uint32_t also_commands_capacity;
     // context scratch
     uint32_t *tile_counts;
     Payload *tile_payload; // 128 x 12 B per wave tile: survivors in tile-local order (make_payload, meshlet_cull.hip)

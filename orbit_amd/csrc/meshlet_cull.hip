@@ -26,7 +26,19 @@ hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, hip
     if ((e = launch_meshlet_eval(p, num_cus, s)) != hipSuccess) return e;
     if (ev1 && (e = hipEventRecord(ev1, s)) != hipSuccess) return e;
     if (p.task_records) return launch_task_records(p, s);
-    if (p.visible_list == 2u) return launch_visible_records(p, s);
+    if (p.visible_list == 2u) {
+        e = launch_visible_records(p, s);
+        if (e != hipSuccess || p.also_commands == nullptr) return e;
+        // the same evaluation's commands as well: scan + emit as in a plain cull, into the second buffer
+        MeshletCullParams c = p;
+        c.visible_list = 0u;
+        c.draw_buffer = p.also_commands;
+        c.draw_capacity = p.also_commands_capacity;
+        e = launch_scan_chunks(c.tile_counts, c.tile_base, reinterpret_cast<const uint32_t *>(c.dispatch_buffer),
+                               kTileRecords, max_tiles, c.chunk_sums, s, c.tickets, kTicketPools * kTicketStride);
+        if (e != hipSuccess) return e;
+        return launch_meshlet_emit(c, c.ci.occlusion_pass != 1 && c.ms.sphere != nullptr, num_cus, s);
+    }
     // first scan level only (chunk-local prefixes + chunk sums); the emit launch redoes the second in LDS
     e = launch_scan_chunks(p.tile_counts, p.tile_base, reinterpret_cast<const uint32_t *>(p.dispatch_buffer),
                            kTileRecords, max_tiles, p.chunk_sums, s, p.tickets, kTicketPools * kTicketStride);

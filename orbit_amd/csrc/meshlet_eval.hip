@@ -189,7 +189,8 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         WaveTileLds &L = lds[wave][it % 3];
         WaveTileLds &Ln = lds[wave][(it + 1) % 3]; // slab of an absent tile holds zero records
         // no payload with the derived streams: the emit launch derives the survivors' command words itself
-        Payload *payload = (STREAM || p.task_records || p.visible_list == 2u) ? nullptr : p.tile_payload + (size_t)w0 * kPayloadCap;
+        Payload *payload = (STREAM || p.task_records || (p.visible_list == 2u && p.also_commands == nullptr))
+                               ? nullptr : p.tile_payload + (size_t)w0 * kPayloadCap;
         CandState cs; // cs.total = the tile's running survivor count
 #define EV_ROW(R, Q)                                                                                                  \
     if constexpr (PASS == 2) {                                                                                        \

@@ -449,15 +449,18 @@ __global__ __launch_bounds__(256) void exchange_scatter_kernel(const ExchangeLis
         for (int k = 0; k < 4; k++)
             if (w + 64u * k < words) dst[w + 64u * k] = v[k];
     }
-    // every store of this workgroup has left for the destination before it counts itself out; the last one out raises
-    // done there
-    __threadfence_system();
+    // Every store of this workgroup has left for the destination before it counts itself out; the last one out raises
+    // done there.  Every wave drains its own stores, the workgroup meets, ONE lane makes the system-scope release (a
+    // fence by all 256 threads of 512 workgroups is 512 cache write-backs queued behind each other: the first version
+    // of this kernel spent 70 us of a 90-us exchange there).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t before = __hip_atomic_fetch_add(&mine_ctrl->left[dst_rank], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (before == gridDim.x - 1u) {
             __hip_atomic_store(&mine_ctrl->left[dst_rank], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence_system();
             sys_store(&reinterpret_cast<ExchangeCtrl *>(p.ctrl[dst_rank])->done[p.rank], (unsigned long long)e);
         }
     }
@@ -493,8 +496,13 @@ __global__ __launch_bounds__(64) void exchange_wait_kernel(const ExchangeListPar
 } // namespace
 
 hipError_t launch_exchange_list(const ExchangeListParams &p, uint32_t num_cus, hipStream_t s) {
-    // enough workgroups per destination to keep a link busy, few enough that `world` copies share the device
-    const uint32_t per_dst = max(num_cus * 2u / max(p.world, 1u), 8u);
+    // enough workgroups per destination to keep a link busy, few enough that `world` copies share the device — and no
+    // more than the list can feed: a workgroup per 32 KB of a rank's share of the gathered capacity (the list's own
+    // length is on the device), every workgroup being a fence and two atomics of fixed cost
+    const uint64_t share = (uint64_t)p.out_capacity * p.stride / max(p.world, 1u);
+    const uint64_t want = (share + 32767u) / 32768u;
+    const uint32_t by_bytes = want > (1u << 20) ? (1u << 20) : (uint32_t)want;
+    const uint32_t per_dst = max(min(num_cus * 2u / max(p.world, 1u), by_bytes), 8u);
     hipLaunchKernelGGL(exchange_scatter_kernel, dim3(per_dst, p.world), dim3(256), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -206,7 +206,7 @@ class Engine:
     def meshlet_cull(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, draw_commands_buffer, entity_buffer,
                      material_buffer, dispatch_capacity, draw_capacity, meshlet_visibility_buffer=None,
                      depth_pyramid=None, depth_pyramid_size=(0, 0), material_count=0, stream=None, task_records=None,
-                     visible_buffer=None, depth_pyramid_levels=None, record_buffer=None):
+                     visible_buffer=None, depth_pyramid_levels=None, record_buffer=None, record_capacity=None):
         ci = _host_bytes(cull_info, 400)
         b = _lib.MeshletCullBufs()
         b.meshlet_dispatch_buffer = _ptr(meshlet_dispatch_buffer)
@@ -221,6 +221,12 @@ class Engine:
         b.draw_capacity = draw_capacity
         b.material_count = material_count
         b.depth_pyramid_levels = _ptr(depth_pyramid_levels)
+        if record_buffer is not None and record_capacity is not None:
+            # sharded engine: the record list AND this rank's own commands (draw_commands_buffer / draw_capacity)
+            _lib.check(self._lib.orbit_meshlet_cull_records_and_commands(
+                self._ctx, ci.ctypes.data_as(C.c_void_p), C.byref(b), _ptr(record_buffer), record_capacity,
+                _stream(stream)), self._ctx)
+            return
         if record_buffer is not None:  # sharded engine: the visible list at record granularity (12 B per record)
             _lib.check(self._lib.orbit_meshlet_cull_visible_records(self._ctx, ci.ctypes.data_as(C.c_void_p), C.byref(b),
                                                                     _ptr(record_buffer), draw_capacity, _stream(stream)),
@@ -280,6 +286,14 @@ class Engine:
         dispatch record with a survivor, in record order."""
         self.meshlet_cull(cull_info, meshlet_dispatch_buffer, meshlet_buffer, None, entity_buffer, material_buffer,
                           dispatch_capacity, record_capacity, record_buffer=record_buffer, **kw)
+
+    def meshlet_cull_records_and_commands(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, record_buffer,
+                                          draw_commands_buffer, entity_buffer, material_buffer, dispatch_capacity,
+                                          record_capacity, draw_capacity, **kw):
+        """orbit_meshlet_cull_records_and_commands: one evaluation, the 12-B record list and the 28-B commands."""
+        self.meshlet_cull(cull_info, meshlet_dispatch_buffer, meshlet_buffer, draw_commands_buffer, entity_buffer,
+                          material_buffer, dispatch_capacity, draw_capacity, record_buffer=record_buffer,
+                          record_capacity=record_capacity, **kw)
 
     def expand_visible_records(self, record_buffer, meshlet_buffer, draw_commands_buffer, draw_capacity, stream=None):
         """orbit_expand_visible_records: record list -> MeshletDrawCommandBuffer, in list order."""

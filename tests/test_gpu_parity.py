@@ -1050,6 +1050,22 @@ def test_visible_records_in_the_occlusion_passes(torch_mod, engine, oracle, occl
     assert bool((hv[8 + 12 * n:] == 0xCD).all())
     if ref[3] is not None:
         assert np.array_equal(host(mvis_d, np.uint32), ref[3]), "meshlet visibility words differ"
+    # ... and both products of ONE evaluation (orbit_meshlet_cull_records_and_commands: the list a shard sends and the
+    # commands it draws from): the same record list, and the oracle's MeshletDrawCommandBuffer
+    mvis_d.copy_(dev(torch, mvis))
+    cap_c = scene.lod0_meshlets + 8
+    vis2 = torch.full((L.VISIBLE_HEADER + 12 * cap_d + 64,), 0xCD, dtype=torch.uint8, device="cuda")
+    draw = torch.full((L.DRAW_HEADER + 28 * cap_c + 64,), 0xEF, dtype=torch.uint8, device="cuda")
+    engine.meshlet_cull_records_and_commands(ci, disp, gs.meshlets, vis2, draw, gs.entities, gs.materials, cap_d, cap_d,
+                                             cap_c, meshlet_visibility_buffer=mvis_d, depth_pyramid=pyr_d,
+                                             depth_pyramid_size=ps)
+    torch.cuda.synchronize()
+    engine.status()
+    assert torch.equal(vis2, vis), "record list differs from orbit_meshlet_cull_visible_records'"
+    hd = host(draw)
+    assert np.array_equal(hd[:4 + 28 * on], ref[1][:4 + 28 * on]) and bool((hd[4 + 28 * cap_c:] == 0xEF).all())
+    if ref[3] is not None:
+        assert np.array_equal(host(mvis_d, np.uint32), ref[3]), "meshlet visibility words differ"
 
 
 def test_null_arguments_are_status_codes_not_crashes(torch_mod):

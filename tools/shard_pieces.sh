@@ -9,5 +9,5 @@ ORBIT_BENCH_FORCE_DIST=1 timeout 300 python bench.py --meshlet-source $src --ent
 import json,sys
 d=json.loads(sys.stdin.read()); p=d['per_rank']; c=d['config']; si=c['step_intervals'] or {}
 r=lambda v: v if v is None else round(v,4)
-print('$src', 'records', $e, 'expand=$x', c['signalling'], 'step', r(d['ms_per_step']), 'interval median', r(si.get('median_ms')), 'max', r(si.get('max_ms')), 'cull', r(p['cull_ms_max']), 'xchg', r(p['exchange_ms_max']), 'expand_all', r(p['expand_ms_max']), 'own_cmds', r(p.get('own_commands_ms_rank0')), 'eval', r(d['roofline']['avg_launch_ms']), 'list_MB', round((c.get('list_bytes_per_rank_max') or 0) / 1e6, 2))"
+print('$src', 'records', $e, 'expand=$x', c['signalling'], 'step', r(d['ms_per_step']), 'interval median', r(si.get('median_ms')), 'max', r(si.get('max_ms')), 'cull', r(p['cull_ms_max']), 'xchg', r(p['exchange_ms_max']), 'expand_all', r(p['expand_ms_max']), 'eval', r(d['roofline']['avg_launch_ms']), 'list_MB', round((c.get('list_bytes_per_rank_max') or 0) / 1e6, 2))"
 done; done; done
