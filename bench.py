@@ -755,7 +755,7 @@ def main():
                 "meshlet_source": (f"derived meshlet streams ({per_meshlet:g} B per meshlet evaluated"
                                    f"{' (alpha classes instead of material indices)' if not args.no_alpha_classes else ''}, "
                                    f"commands derived from the 2-B count chain; built once from the meshlet buffer "
-                                   f"before the timed region in {mstream_build_ms:.2f} ms, +36.4 B of HBM per meshlet)"
+                                   f"before the timed region in {mstream_build_ms:.2f} ms, +36.65 B of HBM per meshlet)"
                                    if mstream is not None
                                    else "the 32-B Meshlet buffer"),
             },

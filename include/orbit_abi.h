@@ -527,7 +527,7 @@ uint64_t orbit_ctx_fused_culls(const OrbitCtx *ctx);
 /* them (bounding sphere, cone, material index) — 20 and a quarter once the  */
 /* material's alpha_mode is known — and only the ~10 % that survive need the */
 /* rest (vertex_offset, data_offset, counts) for their command.  A stream    */
-/* object keeps derived arrays for a range of the buffer (36.4 B of HBM per  */
+/* object keeps derived arrays for a range of the buffer (36.65 B of HBM per */
 /* meshlet on top of the buffer itself):                                     */
 /*   spheres 16 B, cones 4 B, material indices 2 B — what every meshlet's    */
 /*     test reads;                                                           */
@@ -556,7 +556,7 @@ uint64_t orbit_ctx_fused_culls(const OrbitCtx *ctx);
 /*                                                                           */
 /*   create   arrays for global meshlet indices [first_meshlet,              */
 /*            first_meshlet + capacity), capacity <= 2^27 (device memory:    */
-/*            36.4 B x capacity, zero-filled)                                */
+/*            36.65 B x capacity, zero-filled)                               */
 /*   update   re-derives [first, first + count) from `meshlet_buffer` (same  */
 /*            global indexing as bufs->meshlet_buffer), enqueued on `stream`;*/
 /*            call it wherever the renderer writes meshlets (add_mesh) —     */

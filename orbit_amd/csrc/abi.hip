@@ -31,6 +31,7 @@ struct OrbitMeshletStream {
     uint32_t *cmd = nullptr;
     uint16_t *cnt = nullptr;
     uint32_t *link = nullptr, *cls0 = nullptr, *cls1 = nullptr; // word 0 = meshlets (first & ~31) .. +31
+    uint2 *base32 = nullptr;                                     // entry 0 = meshlet (first & ~31)
     // A stream may be bound to several contexts, each with its own lock: its own state has its own.  The device-side
     // order of an update against the culls that read it is the caller's, like the order of the meshlet upload itself.
     std::mutex mu;
@@ -161,6 +162,7 @@ MeshletStreamView stream_arrays(const OrbitMeshletStream *ms, uint64_t lo, uint6
     v.cmd = ms->cmd - 3u * ms->first;
     v.cnt = ms->cnt - ms->first;
     v.link = ms->link - (ms->first >> 5);
+    v.base32 = ms->base32 - (ms->first >> 5);
     v.cls0 = ms->cls0 - (ms->first >> 5);
     v.cls1 = ms->cls1 - (ms->first >> 5);
     v.first = (uint32_t)lo;
@@ -791,6 +793,7 @@ int32_t orbit_meshlet_stream_create(OrbitCtx *ctx, uint64_t first_meshlet, uint6
                   {(void **)&ms->cmd, capacity * 12u, 0},
                   {(void **)&ms->cnt, capacity * sizeof(uint16_t) + 256u, 0},
                   {(void **)&ms->link, bit_words * sizeof(uint32_t), 0},
+                  {(void **)&ms->base32, bit_words * sizeof(uint2), 0},
                   {(void **)&ms->cls0, bit_words * sizeof(uint32_t), 0xFF},  // class 3: look the material up
                   {(void **)&ms->cls1, bit_words * sizeof(uint32_t), 0xFF}};
     // Zero-filled: a meshlet inside the derived range that no update has reached (a gap between two uploads) is a
@@ -806,7 +809,7 @@ int32_t orbit_meshlet_stream_create(OrbitCtx *ctx, uint64_t first_meshlet, uint6
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ms->other_event, hipEventDisableTiming);
     if (e != hipSuccess) {
         orbit_meshlet_stream_destroy(ms);
-        return hip_fail(ctx, e, "meshlet_stream_create: hipMalloc (36.4 B per meshlet)");
+        return hip_fail(ctx, e, "meshlet_stream_create: hipMalloc (36.65 B per meshlet)");
     }
     *out_stream = ms;
     return ORBIT_OK;
@@ -913,6 +916,7 @@ int32_t orbit_meshlet_stream_destroy(OrbitMeshletStream *ms) {
     (void)hipFree(ms->cmd);
     (void)hipFree(ms->cnt);
     (void)hipFree(ms->link);
+    (void)hipFree(ms->base32);
     (void)hipFree(ms->cls0);
     (void)hipFree(ms->cls1);
     (void)hipFree(ms->d_other);

@@ -61,6 +61,10 @@ struct MeshletStreamView {
     const uint32_t *cmd;  // 3 words per meshlet: vertex_offset, data_offset, word 7 again
     const uint16_t *cnt;  // vertex_count | triangle_count << 8
     const uint32_t *link; // bit (i & 31) of word (i >> 5): meshlet i continues meshlet i - 1's chain
+    // {vertex_offset, data_offset} of every meshlet whose global index is a multiple of 32, addressed like `link`
+    // (entry i >> 5): where a dispatch record starts on such an index — every record of a mesh whose meshlets start on
+    // one — the chain's base is a dense 8-B read instead of a 128-B line gathered for 8 B out of `cmd`
+    const uint2 *base32;
     // Alpha classes (orbit_meshlet_stream_set_materials): the alpha_mode of the meshlet's material as two bit planes
     // (class = bit of cls0 | bit of cls1 << 1, addressed like `link`); 0..2 = that alpha_mode, 3 = look the material
     // up.  Non-null only for a cull whose material buffer is the one the classes were derived from AND whose stream

@@ -223,7 +223,7 @@ struct __attribute__((aligned(16))) ChainLds {
 
 struct ChainRsrc {
     __amdgpu_buffer_rsrc_t recs, counts, bases, masks; // the dispatch records, the scan scratch
-    __amdgpu_buffer_rsrc_t cnt, link, cmd;             // the stream (based at its first meshlet)
+    __amdgpu_buffer_rsrc_t cnt, link, cmd, base32;     // the stream (based at its first meshlet)
     uint32_t first, count, first_word;
 };
 
@@ -311,9 +311,19 @@ __device__ __forceinline__ ChainStage chain_stage(const ChainRsrc &B, ChainLds &
     const bool cont = has && !first && prev_full != 0u && e.y == prev_y + 32u && (s.link32 & 1u) != 0u;
     const bool start = has && !cont;
     s.flags = (has ? 1u : 0u) | (start ? 2u : 0u);
-    const uint32_t co = start ? (e.y - B.first) * 12u : kNoOffset;
-    s.bv = __builtin_amdgcn_raw_buffer_load_b32(B.cmd, co, 0, 0);
-    s.bd = __builtin_amdgcn_raw_buffer_load_b32(B.cmd, co, 0 + 4, 0);
+    // a chain's base: {vertex_offset, data_offset} of the record's first meshlet — from the dense base32 array where the
+    // record starts on a multiple of 32 (8 B per record, neighbours in one line), gathered out of `cmd` (a 128-B line for
+    // 8 B) where it does not.  Two loads from each array, the unused pair at an offset outside the resource: the
+    // vector-memory code of the loop stays straight-line.
+    const bool aligned = (e.y & 31u) == 0u;
+    const uint32_t co = (start && !aligned) ? (e.y - B.first) * 12u : kNoOffset;
+    const uint32_t bo = (start && aligned) ? ((e.y >> 5) - B.first_word) * 8u : kNoOffset;
+    const uint32_t gv = __builtin_amdgcn_raw_buffer_load_b32(B.cmd, co, 0, 0);
+    const uint32_t gd = __builtin_amdgcn_raw_buffer_load_b32(B.cmd, co, 0 + 4, 0);
+    const uint32_t dv = __builtin_amdgcn_raw_buffer_load_b32(B.base32, bo, 0, 0);
+    const uint32_t dd = __builtin_amdgcn_raw_buffer_load_b32(B.base32, bo, 0 + 4, 0);
+    s.bv = gv | dv; // (the pair that was not asked for reads zeros)
+    s.bd = gd | dd;
     // A submesh or allocation boundary INSIDE the record restarts the chain there: the offsets of the meshlet behind the
     // first broken link are gathered as well (none: nothing is read).  Survivors behind a second one gather their own.
     const uint32_t brk = chain_first_break(s.link32);
@@ -376,6 +386,8 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
                                                (((p.ms.first + p.ms.count + 31u) >> 5) - B.first_word + 2u) * 4u, kBufFlags);
     B.cmd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.ms.cmd + (size_t)p.ms.first * 3u), 0,
                                               p.ms.count * 12u, kBufFlags);
+    B.base32 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint2 *>(p.ms.base32 + B.first_word), 0,
+                                                 (((p.ms.first + p.ms.count + 31u) >> 5) - B.first_word) * 8u, kBufFlags);
     uint32_t *out = reinterpret_cast<uint32_t *>(p.draw_buffer + ORBIT_DRAW_HEADER);
     const uint32_t stride = gridDim.x * 4;
     const uint32_t sub = (uint32_t)lane >> 4, i16 = (uint32_t)lane & 15u;

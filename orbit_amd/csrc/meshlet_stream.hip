@@ -20,6 +20,7 @@ struct StreamBuildArrays {
     uint32_t *cmd;
     uint16_t *cnt;
     uint32_t *link, *cls0, *cls1;
+    uint2 *base32;
     uint64_t s_first, s_end; // the stream's range
     const OrbitMaterialData *materials; // alpha classes come from here (nullptr: class 3 everywhere)
     uint32_t material_count;
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(256) void meshlet_stream_build_kernel(const OrbitMe
             A.cmd[m * 3u + 1u] = b.z;
             A.cmd[m * 3u + 2u] = b.w;
             A.cnt[m] = (uint16_t)(b.w >> 16);
+            if ((m & 31u) == 0u) A.base32[m >> 5] = make_uint2(b.y, b.z); // {vertex_offset, data_offset}
             vtx = b.y, data = b.z;
             cls = alpha_class(A, b.w & 0xFFFFu);
             if (cls == 3u && A.materials != nullptr) *A.other = 1u;
@@ -126,6 +128,7 @@ static StreamBuildArrays stream_build_arrays(const MeshletStreamView &ms, const 
                              const_cast<uint16_t *>(ms.mat),   const_cast<uint32_t *>(ms.cmd),
                              const_cast<uint16_t *>(ms.cnt),   const_cast<uint32_t *>(ms.link),
                              const_cast<uint32_t *>(ms.cls0),  const_cast<uint32_t *>(ms.cls1),
+                             const_cast<uint2 *>(ms.base32),
                              (uint64_t)ms.first,               (uint64_t)ms.first + ms.count,
                              materials,                        material_count,
                              other};
@@ -155,6 +158,10 @@ __global__ __launch_bounds__(256) void meshlet_stream_validate_kernel(const Orbi
         if (A.materials) {
             const uint32_t cls = ((A.cls0[m >> 5] >> (m & 31u)) & 1u) | (((A.cls1[m >> 5] >> (m & 31u)) & 1u) << 1);
             same = same && cls == alpha_class(A, b.w & 0xFFFFu);
+        }
+        if ((m & 31u) == 0u) {
+            const uint2 b32 = A.base32[m >> 5];
+            same = same && b32.x == b.y && b32.y == b.z;
         }
         if (m > A.s_first) { // the link bit against the two meshlets it relates
             const uint4 pb = reinterpret_cast<const uint4 *>(meshlets + (m - 1u))[1];
