@@ -249,7 +249,7 @@ def main():
     class Slot:
         def __init__(self):
             self.eng = Engine(device_index, max_entities=n_local_entities + 256, max_dispatches=disp_cap,
-                              max_draws=draw_cap)
+                              max_draws=draw_cap, cull_path=int(os.environ.get("ORBIT_BENCH_CULL_PATH", "0")))  # triage
             self.stream = torch.cuda.Stream(device=dev)
             self.disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device=dev)
             self.lists = [torch.zeros(hdr + item * list_cap, dtype=torch.uint8, device=dev)
