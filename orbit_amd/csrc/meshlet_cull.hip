@@ -1,7 +1,8 @@
 // meshlet_cull.hip — the launch protocol of one meshlet cull (src/passes/draw_gen.rs:382-435 of the reference repo:
 // clear, one dispatch of shaders/meshlet_cull.comp over the entity stage's records) as this library runs it:
 //
-//   evaluation (meshlet_eval.hip) -> scan of the tiles' survivor counts (scan.hip) -> emit (meshlet_emit.hip)
+//   evaluation (meshlet_eval.hip) -> scan of the tiles' survivor counts (scan.hip; inside the emit launch where the
+//   commands come from the derived streams) -> emit (meshlet_emit.hip)
 //
 // or, for the outputs that are not a draw-command list, evaluation -> list launches (meshlet_lists.hip).  Tile bases
 // come from a prefix sum, so the command sequence is the canonical (record, lane) order with no atomics.  (A
@@ -15,6 +16,24 @@ uint32_t max_dispatch_capacity() {
     const uint64_t cap = (uint64_t)kEmitChunkTable * kScanChunk * kTileRecords;
     return cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
 }
+
+namespace {
+
+// Prefix sum over the tiles' survivor counts + emit.  The chain emit (commands from the derived streams) scans inside
+// its own launch (meshlet_emit.hip emit_scan_duty); the others get the first scan level (chunk-local prefixes + chunk
+// sums) as a launch and redo the second in LDS.
+hipError_t scan_and_emit(const MeshletCullParams &p, uint32_t max_tiles, uint32_t num_cus, hipStream_t s) {
+    // the list-driven pass 1 keeps its payload whatever the meshlet source
+    const bool stream = p.ci.occlusion_pass != 1 && p.ms.sphere != nullptr;
+    if (!(stream && !p.visible_list)) {
+        const hipError_t e = launch_scan_chunks(p.tile_counts, p.tile_base, reinterpret_cast<const uint32_t *>(p.dispatch_buffer),
+                                                kTileRecords, max_tiles, p.chunk_sums, s, p.tickets, kTicketPools * kTicketStride);
+        if (e != hipSuccess) return e;
+    }
+    return launch_meshlet_emit(p, stream, num_cus, s);
+}
+
+} // namespace
 
 hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, hipStream_t s, hipEvent_t ev0,
                                hipEvent_t ev1) {
@@ -34,17 +53,9 @@ hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, hip
         c.visible_list = 0u;
         c.draw_buffer = p.also_commands;
         c.draw_capacity = p.also_commands_capacity;
-        e = launch_scan_chunks(c.tile_counts, c.tile_base, reinterpret_cast<const uint32_t *>(c.dispatch_buffer),
-                               kTileRecords, max_tiles, c.chunk_sums, s, c.tickets, kTicketPools * kTicketStride);
-        if (e != hipSuccess) return e;
-        return launch_meshlet_emit(c, c.ci.occlusion_pass != 1 && c.ms.sphere != nullptr, num_cus, s);
+        return scan_and_emit(c, max_tiles, num_cus, s);
     }
-    // first scan level only (chunk-local prefixes + chunk sums); the emit launch redoes the second in LDS
-    e = launch_scan_chunks(p.tile_counts, p.tile_base, reinterpret_cast<const uint32_t *>(p.dispatch_buffer),
-                           kTileRecords, max_tiles, p.chunk_sums, s, p.tickets, kTicketPools * kTicketStride);
-    if (e != hipSuccess) return e;
-    // the list-driven pass 1 keeps its payload whatever the meshlet source
-    return launch_meshlet_emit(p, p.ci.occlusion_pass != 1 && p.ms.sphere != nullptr, num_cus, s);
+    return scan_and_emit(p, max_tiles, num_cus, s);
 }
 
 // orbit_cull_views, meshlet stage.  The evaluation launches are grouped by (occlusion pass, projection, source) — a
@@ -80,19 +91,25 @@ hipError_t launch_meshlet_cull_views(const MeshletCullViews &all, uint32_t n, ui
         const hipError_t e = launch_meshlet_eval_views(all, g, m, pass, proj == 1, src, group_tiles, num_cus, s);
         if (e != hipSuccess) return e;
     }
-    ScanViews sv{};
-    for (uint32_t i = 0; i < n; i++)
-        sv.v[i] = {host[i].tile_counts, host[i].tile_base, reinterpret_cast<const uint32_t *>(host[i].dispatch_buffer),
-                   host[i].chunk_sums, host[i].tickets, tiles_of(i)};
-    hipError_t e = launch_scan_chunks_views(sv, n, kTileRecords, max_tiles_all, kTicketPools * kTicketStride, s);
-    if (e != hipSuccess) return e;
-    // the emit launch of the views whose evaluation kept a payload, and of those that kept only ballots
+    hipError_t e = hipSuccess;
+    // the emit launch of the views whose evaluation kept a payload (behind the scan launch of those views), and of
+    // those that kept only ballots (the chain emit: it scans itself)
     for (int stream = 0; stream < 2; stream++) {
         ViewGroup g{};
         uint32_t m = 0;
         for (uint32_t i = 0; i < n; i++)
             if ((source(i) != 0) == (stream != 0)) g.idx[m++] = (uint8_t)i;
         if (m == 0) continue;
+        if (stream == 0) {
+            ScanViews sv{};
+            for (uint32_t k = 0; k < m; k++) {
+                const uint32_t i = g.idx[k];
+                sv.v[k] = {host[i].tile_counts, host[i].tile_base, reinterpret_cast<const uint32_t *>(host[i].dispatch_buffer),
+                           host[i].chunk_sums, host[i].tickets, tiles_of(i)};
+            }
+            e = launch_scan_chunks_views(sv, m, kTileRecords, max_tiles_all, kTicketPools * kTicketStride, s);
+            if (e != hipSuccess) return e;
+        }
         e = launch_meshlet_emit_views(all, g, m, n, stream != 0, max_tiles_all, num_cus, s);
         if (e != hipSuccess) return e;
     }

@@ -8,10 +8,69 @@
 //                                upload chain (kernels.h MeshletStreamView)
 //   meshlet_emit_kernel<true, *> the 8-B visible list {meshlet_index, entity_index}
 #include "meshlet_common.h"
+#include "handoff.h"
 
 namespace orbit {
 
 namespace {
+
+// ---------------------------------------------------------------------------
+// The prefix sum over the tiles' survivor counts, inside the CHAIN emit launch (the other emit launches keep the scan
+// launch in front of them: scan.hip).  Rounds 1-3 ran its first level as a launch of its own between evaluation and
+// emit: 4.8 us + a launch boundary at BASELINE config 5 for 196 KB of counts.  Now the first workgroups of the chain
+// emit scan one chunk of kScanChunk tiles each (chunk-local exclusive prefixes to
+// tile_base, stored write-through), publish the chunk's sum as sum << 1 | 1 in chunk_sums (zero since the
+// evaluation launch of this cull cleared it), and every workgroup waits for the sums of all chunks — ONE hop, under
+// which the launch's own ramp (records, ballots, links: nothing of which depends on the bases) can run — and builds the
+// chunk bases in LDS as before.  A workgroup waits only for workgroups of lower index (handoff.h: bounded polls).
+// tile_base is then read with sc1 loads (another workgroup of this launch stored it).
+// Returns the grand total; s_chunk_base[c] = exclusive prefix of chunk c for c < kEmitChunkTable.
+__device__ __forceinline__ void emit_scan_duty(const MeshletCullParams &p, uint32_t ntiles, uint32_t nchunks, uint32_t *s_scan) {
+    if (blockIdx.x == 0 && threadIdx.x < kTicketPools) p.tickets[threadIdx.x * kTicketStride] = 0u; // next evaluation
+    static_assert(kScanChunk == 4 * 256, "a thread of the emit block scans four tiles of a chunk");
+    const __amdgpu_buffer_rsrc_t CS = rsrc_of(p.chunk_sums, nchunks * 4u);
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) { // block-uniform
+        const uint32_t i = c * kScanChunk + threadIdx.x * 4u;
+        uint4 v = *reinterpret_cast<const uint4 *>(p.tile_counts + i); // (the scratch is padded past the last tile)
+        v.x = i < ntiles ? v.x : 0u;
+        v.y = i + 1u < ntiles ? v.y : 0u;
+        v.z = i + 2u < ntiles ? v.z : 0u;
+        v.w = i + 3u < ntiles ? v.w : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan<4>(v.x + v.y + v.z + v.w, s_scan, &total);
+        const v4u o = {ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z};
+        // whole quads up to the one that holds the last tile (the scratch is padded to 256 B: that quad lies inside)
+        const __amdgpu_buffer_rsrc_t TB = rsrc_of(p.tile_base + c * kScanChunk, min(kScanChunk, (ntiles - c * kScanChunk + 3u) & ~3u) * 4u);
+        __builtin_amdgcn_raw_buffer_store_b128(o, TB, threadIdx.x * 16u, 0, kSc1);
+        drain_stores();
+        __syncthreads(); // every wave's prefixes are in memory
+        st_sc1(CS, threadIdx.x == 0 ? c * 4u : kHandoffNoOffset, total << 1 | 1u);
+    }
+}
+
+__device__ __forceinline__ uint32_t emit_scan_wait(const MeshletCullParams &p, uint32_t nchunks, uint32_t *s_chunk_base,
+                                                   uint32_t *s_scan) {
+    const __amdgpu_buffer_rsrc_t CS = rsrc_of(p.chunk_sums, nchunks * 4u);
+    uint32_t grand_total = 0;
+    for (uint32_t c0 = 0; c0 < nchunks; c0 += 256) { // block-uniform trip count
+        const uint32_t c = c0 + threadIdx.x;
+        uint32_t v = ld_sc1(CS, c < nchunks ? c * 4u : kHandoffNoOffset);
+        for (uint32_t spins = 0; c < nchunks && v == 0u; spins++) {
+            if (spins == kSpinLimit) {
+                latch_status(p.status, ORBIT_E_TIMEOUT);
+                break;
+            }
+            poll_pause();
+            v = ld_sc1(CS, c * 4u);
+        }
+        uint32_t sub;
+        const uint32_t ex = block_exclusive_scan<4>(v >> 1, s_scan, &sub);
+        if (c < nchunks && c < kEmitChunkTable) s_chunk_base[c] = grand_total + ex;
+        grand_total += sub;
+    }
+    __syncthreads();
+    return grand_total;
+}
 
 // One wave per tile (grid stride): commands of the tile's survivors at the
 // scanned offset (:216-230).  Everything a tile needs is loaded ahead of its
@@ -234,7 +293,7 @@ struct ChainGroup {
     uint32_t base;      // chunk-local output slot of the group's first survivor
 };
 
-__device__ __forceinline__ ChainGroup chain_prefetch(const ChainRsrc &B, uint32_t group, int lane) {
+__device__ __forceinline__ ChainGroup chain_prefetch(const ChainRsrc &B, uint32_t group, int lane, bool with_base = true) {
     ChainGroup e;
     const uint32_t g = group < 0x007FFFFFu ? group : 0x007FFFFFu; // keeps g * 512 out of range instead of wrapping
     const uint32_t k = (uint32_t)lane & 31u;
@@ -242,7 +301,9 @@ __device__ __forceinline__ ChainGroup chain_prefetch(const ChainRsrc &B, uint32_
     e.ent = r[0], e.y = r[1], e.z = r[2];
     e.mword = __builtin_amdgcn_raw_buffer_load_b32(B.masks, (g * kGroupRecords + k) * 4u, 0, 0);
     e.count = __builtin_amdgcn_raw_buffer_load_b32(B.counts, (g * kGroupTiles + ((uint32_t)lane & 1u)) * 4u, 0, 0);
-    e.base = __builtin_amdgcn_raw_buffer_load_b32(B.bases, g * kGroupTiles * 4u, 0, 0);
+    // (stored by this launch: sc1; the launch's first prefetches run before the scan is known to be complete and fetch
+    // their bases behind the wait)
+    e.base = __builtin_amdgcn_raw_buffer_load_b32(B.bases, with_base ? g * kGroupTiles * 4u : kNoOffset, 0, kSc1);
     return e;
 }
 
@@ -361,16 +422,7 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
     const uint32_t ngroups = (ntiles + kGroupTiles - 1) / kGroupTiles;
     const uint32_t nchunks = (ntiles + kScanChunk - 1) / kScanChunk;
     static_assert(kScanChunk % kGroupTiles == 0, "a group's tiles share a scan chunk: its survivors are contiguous");
-    uint32_t grand_total = 0;
-    for (uint32_t c0 = 0; c0 < nchunks; c0 += 256) { // block-uniform trip count
-        const uint32_t c = c0 + threadIdx.x;
-        const uint32_t v = c < nchunks ? p.chunk_sums[c] : 0u;
-        uint32_t sub;
-        const uint32_t ex = block_exclusive_scan<4>(v, s_scan, &sub);
-        if (c < nchunks && c < kEmitChunkTable) s_chunk_base[c] = grand_total + ex;
-        grand_total += sub;
-    }
-    __syncthreads();
+    emit_scan_duty(p, ntiles, nchunks, s_scan);
     ChainRsrc B;
     B.recs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.dispatch_buffer) + ORBIT_DISPATCH_HEADER, 0,
                                                nrec * 16u, kBufFlags);
@@ -552,14 +604,26 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
 
     // The pipelined loop over the wave's groups: records and ballots three groups ahead, link words two, counts and
     // bases one.  A group past the end reads zero records: nothing else is loaded for it.
-    const uint32_t group0 = blockIdx.x * 4 + wave;
+    // (the waves of the first workgroups — the ones with scan duty — are the ones with a group less where the groups do
+    // not divide evenly)
+    const uint32_t group0 = stride - 1u - (blockIdx.x * 4 + wave);
     uint32_t group = group0, it = 0;
-    ChainGroup cur = chain_prefetch(B, group, lane);
-    ChainGroup nxt = chain_prefetch(B, group + stride, lane);
-    ChainGroup nn = chain_prefetch(B, group + 2 * stride, lane);
+    ChainGroup cur = chain_prefetch(B, group, lane, false);
+    ChainGroup nxt = chain_prefetch(B, group + stride, lane, false);
+    ChainGroup nn = chain_prefetch(B, group + 2 * stride, lane, false);
     ChainStage cs = chain_stage(B, S, cur, link_stage(B, cur), lane);
     LinkStage nk = link_stage(B, nxt);
     if (lane < (int)kSlowWords) S.slow[lane] = 0u;
+    // the launch's ramp above ran under the scan of the first workgroups; now its result
+    const uint32_t grand_total = emit_scan_wait(p, nchunks, s_chunk_base, s_scan);
+    {
+        auto base_of = [&](uint32_t g) {
+            return __builtin_amdgcn_raw_buffer_load_b32(B.bases, (g < 0x007FFFFFu ? g : 0x007FFFFFu) * kGroupTiles * 4u, 0, kSc1);
+        };
+        cur.base = base_of(group);
+        nxt.base = base_of(group + stride);
+        nn.base = base_of(group + 2 * stride);
+    }
     auto step = [&]() __attribute__((always_inline)) {
         const ChainGroup n3 = chain_prefetch(B, group + 3 * stride, lane);
         const LinkStage nnk = link_stage(B, nn);

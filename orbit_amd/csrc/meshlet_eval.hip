@@ -54,6 +54,15 @@ constexpr int kEvWavesPerSimd = 4; // resident waves per SIMD: compiled for (128
 constexpr int ev_waves_per_simd(int pass, bool stream) { return (pass == 0 && stream) ? ORBIT_EV_WPS0 : kEvWavesPerSimd; }
 
 
+// The emit launch behind this evaluation scans the tiles' counts itself and publishes each chunk's sum as a non-zero
+// word of chunk_sums (meshlet_emit.hip emit_scan_duty): the first workgroup of every evaluation zeroes them.
+__device__ __forceinline__ void clear_chunk_sums(const MeshletCullParams &p) {
+    if (blockIdx.x != 0) return;
+    const uint32_t max_tiles = (p.dispatch_capacity + kTileRecords - 1) / kTileRecords;
+    const uint32_t max_chunks = (max_tiles + kScanChunk - 1) / kScanChunk;
+    for (uint32_t c = threadIdx.x; c < max_chunks; c += kEvWaves * 64) p.chunk_sums[c] = 0u;
+}
+
 // STREAM: meshlets from the derived streams; CLS (with STREAM): predicate bits from the streams' alpha classes
 template <int PASS, int PROJ, bool PROF, bool STREAM = false, bool CLS = false>
 __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
@@ -66,6 +75,7 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
     const bool occ2 = PASS == 2 && p.ci.meshlet_visibility_buffer != ORBIT_NONE;
     __shared__ uint32_t cls_sel[CLS ? 8 : 1]; // [2 c + k] = all ones if alpha class c has predicate bit k (alpha_bits)
     planes_to_lds(p, planes);
+    clear_chunk_sums(p);
     if (CLS && threadIdx.x < 6) cls_sel[threadIdx.x] = ((alpha_bits(p.ci, threadIdx.x >> 1) >> (threadIdx.x & 1u)) & 1u) ? ~0u : 0u;
     const AlphaLds *alpha = alpha_table_fill(p, alpha_tab) ? &alpha_tab : nullptr;
     __syncthreads();
@@ -362,6 +372,7 @@ __device__ __forceinline__ void meshlet_pass1_body(const MeshletCullParams &p) {
     __shared__ uint16_t s_list[kEvWaves][2][kTileRows * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     planes_to_lds(p, planes);
+    clear_chunk_sums(p);
     const AlphaLds *alpha = alpha_table_fill(p, alpha_tab) ? &alpha_tab : nullptr;
     __syncthreads();
     const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
