@@ -278,7 +278,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t o_dbg = carve(256 + 16 * 8192); // phase sums + per-wave {begin, end} wall-clock stamps (triage builds)
     const size_t o_zero = carve(256);
     const size_t o_gc = carve(256);
-    const size_t o_tk = carve(kTicketPools * kTicketStride * 4);
+    const size_t o_tk = carve((kTicketPools + kEmitTicketPools) * kTicketStride * 4);
     const size_t o_fsy = carve(kFusedSyncWords * 4), o_fef = carve((ent / 256 + 2) * 4);
     const size_t o_dtk = carve((size_t)kMaxPyramidBatch * kDepthTicketWords * 4);
     const size_t o_eproto = carve(ent * sizeof(OrbitMeshletDispatch));

@@ -16,6 +16,8 @@ constexpr uint32_t kTileRows = 8;
 // meshlet_eval hands tiles out through kTicketPools counters (one 256-B line each); zero between evaluations
 constexpr uint32_t kTicketPools = 8;
 constexpr uint32_t kTicketStride = 64; // words
+// ... followed by kEmitTicketPools counters of the chain emit's group tickets (meshlet_emit.hip), zeroed by the evaluation
+constexpr uint32_t kEmitTicketPools = 16;
 
 // what meshlet_eval keeps per survivor for the emit launch (meshlet_cull.hip make_payload)
 struct Payload {
@@ -118,7 +120,7 @@ struct MeshletCullParams {
     uint32_t *tile_base;   // chunk-local exclusive prefix of tile_counts
     uint32_t *chunk_sums;  // per kScanChunk tiles; the emit launch prefix-sums them itself (LDS)
     uint32_t *total;
-    uint32_t *tickets;     // kTicketPools x kTicketStride words (meshlet_eval tile tickets)
+    uint32_t *tickets;     // (kTicketPools + kEmitTicketPools) x kTicketStride words (tile tickets, emit group tickets)
     const void *zero_page; // 256 zero bytes of context scratch: target of inactive lanes' loads
     unsigned long long *debug_cycles; // ORBIT_SP_DEBUG & 8: per-phase s_memtime sums (8 slots)
     uint32_t debug_flags; // ORBIT_SP_DEBUG (perf triage only): 8 = per-phase cycle stamps (pass 0 only)

@@ -265,7 +265,8 @@ __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
 // All loads are range-checked buffer loads (an offset outside the resource reads zero): no pointer selects, no
 // branches around loads, 32-bit address arithmetic, and the stream's coverage check comes for free.
 constexpr uint32_t kGroupTiles = 2, kGroupRecords = kGroupTiles * kTileRecords; // 32 records = 1024 meshlets
-constexpr uint32_t kSlowWords = 32; // 1024 iterations per wave: more than any grid the library launches leaves a wave
+constexpr uint32_t kSlowWords = 16; // 512 iterations per wave: more than any grid the library launches leaves a wave
+constexpr uint32_t kDynGroups = 16; // ticketed groups a wave takes inside its pipelined loop (power of two)
 
 struct __attribute__((aligned(16))) ChainLds {
     uint4 rec[kGroupRecords];            // phase B -> C: {data_offset base, vertex_offset, entity_index, meshlet_offset}
@@ -275,6 +276,7 @@ struct __attribute__((aligned(16))) ChainLds {
     uint32_t link[kGroupRecords];        // link bits of the record's 32 lanes
     uint32_t tot[kGroupRecords / 2];     // [quad-row pair * 4 + sub]: data words of records 4 q + sub / 4 (q + 4) + sub (16:16)
     uint32_t slow[kSlowWords];           // bit i: the wave's i-th group needs the general form (process<!FAST>)
+    uint32_t dyn[kDynGroups];            // the wave's ticketed groups (its iterations n_static ..)
     uint32_t cmd[64 * 7];
     uint16_t list[kGroupRecords * 32];
 };
@@ -604,13 +606,40 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
 
     // The pipelined loop over the wave's groups: records and ballots three groups ahead, link words two, counts and
     // bases one.  A group past the end reads zero records: nothing else is loaded for it.
-    // (the waves of the first workgroups — the ones with scan duty — are the ones with a group less where the groups do
-    // not divide evenly)
-    const uint32_t group0 = stride - 1u - (blockIdx.x * 4 + wave);
-    uint32_t group = group0, it = 0;
-    ChainGroup cur = chain_prefetch(B, group, lane, false);
-    ChainGroup nxt = chain_prefetch(B, group + stride, lane, false);
-    ChainGroup nn = chain_prefetch(B, group + 2 * stride, lane, false);
+    // Which groups: a static grid-stride share first, tickets for the rest — as in the evaluation (meshlet_eval.hip).
+    // With six groups per wave handed out statically the workgroups of a CU finished between 35 and 58 us of a 58-us
+    // launch (per-workgroup stamps: the later a workgroup was dispatched, the later), i.e. the last third of the launch
+    // ran at falling occupancy.  A claim is made four groups before the group is processed, so its round trip is never
+    // waited for; pool = wave mod pools (a returning atomic on one word serves ~88 per us).
+    // (the waves of the first workgroups — the ones with scan duty — are the ones with a group less where the static
+    // groups do not divide evenly)
+    const uint32_t wave_g = blockIdx.x * 4 + wave;
+    const uint32_t group0 = stride - 1u - wave_g;
+    const uint32_t full_rounds = ngroups / stride;
+    const uint32_t n_static = full_rounds < 4u ? 0xFFFFFFFFu : max(full_rounds - min(max(full_rounds / 4u, 1u), 3u), 4u);
+    const uint32_t npools = min(kEmitTicketPools, stride), pool = wave_g % npools;
+    uint32_t *ticket_ctr = p.tickets + (kTicketPools + pool) * kTicketStride;
+    constexpr uint32_t kNoGroup = 0x007FFFFFu, kNoTicket = 0x00400000u;
+    bool dry = false, capped = false; // wave-uniform: the pool has no group left / this wave has had kDynGroups of them
+    auto dyn_group = [&](uint32_t t) { return t >= kNoTicket ? kNoGroup : n_static * stride + t * npools + pool; };
+    auto claim = [&](uint32_t iter) -> uint32_t { // for iteration `iter` of this wave; lane 0's VGPR carries the answer
+        uint32_t raw = kNoTicket;
+        if (iter >= n_static && !dry) {
+            if (iter - n_static < kDynGroups) {
+                raw = 0u;
+                if (lane == 0) raw = atomicAdd(ticket_ctr, 1u);
+            } else {
+                capped = true;
+            }
+        }
+        return raw;
+    };
+    uint32_t it = 0;
+    uint32_t g_cur = group0, g_nxt = group0 + stride, g_nn = group0 + 2u * stride; // (n_static >= 4)
+    uint32_t tk_raw = kNoTicket;                                                   // iteration 3 is static
+    ChainGroup cur = chain_prefetch(B, g_cur, lane, false);
+    ChainGroup nxt = chain_prefetch(B, g_nxt, lane, false);
+    ChainGroup nn = chain_prefetch(B, g_nn, lane, false);
     ChainStage cs = chain_stage(B, S, cur, link_stage(B, cur), lane);
     LinkStage nk = link_stage(B, nxt);
     if (lane < (int)kSlowWords) S.slow[lane] = 0u;
@@ -618,17 +647,25 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
     const uint32_t grand_total = emit_scan_wait(p, nchunks, s_chunk_base, s_scan);
     {
         auto base_of = [&](uint32_t g) {
-            return __builtin_amdgcn_raw_buffer_load_b32(B.bases, (g < 0x007FFFFFu ? g : 0x007FFFFFu) * kGroupTiles * 4u, 0, kSc1);
+            return __builtin_amdgcn_raw_buffer_load_b32(B.bases, (g < kNoGroup ? g : kNoGroup) * kGroupTiles * 4u, 0, kSc1);
         };
-        cur.base = base_of(group);
-        nxt.base = base_of(group + stride);
-        nn.base = base_of(group + 2 * stride);
+        cur.base = base_of(g_cur);
+        nxt.base = base_of(g_nxt);
+        nn.base = base_of(g_nn);
     }
     auto step = [&]() __attribute__((always_inline)) {
-        const ChainGroup n3 = chain_prefetch(B, group + 3 * stride, lane);
+        // the group three iterations ahead: static, or the ticket claimed one iteration ago
+        uint32_t g3 = group0 + (it + 3u) * stride;
+        if (it + 3u >= n_static) {
+            g3 = dyn_group((uint32_t)__builtin_amdgcn_readfirstlane((int)tk_raw));
+            if (g3 >= ngroups) dry = true;
+            else if (lane == 0) S.dyn[(it + 3u - n_static) & (kDynGroups - 1u)] = g3; // (for the slow pass below)
+        }
+        tk_raw = claim(it + 4u);
+        const ChainGroup n3 = chain_prefetch(B, g3, lane);
         const LinkStage nnk = link_stage(B, nn);
         const ChainStage ns = chain_stage(B, S, nxt, nk, lane);
-        const bool slow = process(std::true_type{}, cur, cs, group);
+        const bool slow = process(std::true_type{}, cur, cs, g_cur);
         // (the launchers size the grid so that a wave never has more than 32 * kSlowWords iterations)
         if (slow && lane == 0) S.slow[(it >> 5) & (kSlowWords - 1u)] |= 1u << (it & 31u);
         cur = nxt;
@@ -636,29 +673,44 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
         nxt = nn;
         nk = nnk;
         nn = n3;
-        group += stride;
+        g_cur = g_nxt;
+        g_nxt = g_nn;
+        g_nn = g3;
         it++;
     };
     // The first group outside the loop: the loop is then entered with its steady-state queue of loads and stores in
     // flight, and the compiler's wait counts inside it are the steady state's (from the prologue alone the link
     // words would look six operations old, and every iteration would drain its predecessor's stores to be safe).
-    if (group < ngroups) {
+    if (g_cur < ngroups) {
         step();
-        while (group < ngroups) step();
+        while (g_cur < ngroups) step();
     }
     // The groups the loop left: one at a time, loads awaited as they come.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    auto one_group = [&](uint32_t g) {
+        const ChainGroup e = chain_prefetch(B, g, lane);
+        const ChainStage st = chain_stage(B, S, e, link_stage(B, e), lane);
+        process(std::false_type{}, e, st, g);
+    };
     for (uint32_t w = 0; w < kSlowWords; w++) {
         uint32_t bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.slow[w]);
         while (bits != 0u) {
-            const uint32_t g = group0 + (w * 32u + (uint32_t)__builtin_ctz(bits)) * stride;
+            const uint32_t i = w * 32u + (uint32_t)__builtin_ctz(bits); // the wave's i-th iteration
             bits &= bits - 1u;
-            const ChainGroup e = chain_prefetch(B, g, lane);
-            const ChainStage st = chain_stage(B, S, e, link_stage(B, e), lane);
-            process(std::false_type{}, e, st, g);
+            one_group(i < n_static ? group0 + i * stride
+                                   : (uint32_t)__builtin_amdgcn_readfirstlane((int)S.dyn[(i - n_static) & (kDynGroups - 1u)]));
         }
+    }
+    // a wave that has had its kDynGroups ticketed groups while its pool still had some (a launch with few waves running):
+    // the rest of the pool, one group at a time
+    while (capped) {
+        uint32_t raw = 0u;
+        if (lane == 0) raw = atomicAdd(ticket_ctr, 1u);
+        const uint32_t g = dyn_group((uint32_t)__builtin_amdgcn_readfirstlane((int)raw));
+        if (g >= ngroups) break;
+        one_group(g);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // `count` header: subsumes the fill_buffer(count = 0) of draw_gen.rs:411-417
@@ -702,7 +754,7 @@ hipError_t launch_meshlet_emit(const MeshletCullParams &p, bool stream, uint32_t
     } else if (stream) {
         // a wave per group of two tiles; never more than 32 * kSlowWords groups per wave
         const uint32_t gneed = (eneed + kGroupTiles - 1) / kGroupTiles;
-        const uint32_t cblocks = max(max(min(num_cus * (uint32_t)kChainWavesPerSimd, gneed), (gneed + 32u * kSlowWords - 1u) / (32u * kSlowWords)), 1u);
+        const uint32_t cblocks = max(max(min(num_cus * (uint32_t)kChainWavesPerSimd, gneed), (gneed + 32u * kSlowWords - kDynGroups - 1u) / (32u * kSlowWords - kDynGroups)), 1u);
         hipLaunchKernelGGL(meshlet_emit_chain_kernel, dim3(cblocks), dim3(256), 0, s, p);
     } else {
         hipLaunchKernelGGL((meshlet_emit_kernel<false, false>), dim3(eblocks), dim3(256), 0, s, p);
@@ -721,7 +773,7 @@ hipError_t launch_meshlet_emit_views(const MeshletCullViews &all, const ViewGrou
     if (stream)
         hipLaunchKernelGGL(meshlet_emit_chain_views_kernel,
                            dim3(max(max(min(num_cus * (uint32_t)kChainWavesPerSimd / m, (eneed + kGroupTiles - 1) / kGroupTiles),
-                                        ((eneed + kGroupTiles - 1) / kGroupTiles + 32u * kSlowWords - 1u) / (32u * kSlowWords)), 1u), m),
+                                        ((eneed + kGroupTiles - 1) / kGroupTiles + 32u * kSlowWords - kDynGroups - 1u) / (32u * kSlowWords - kDynGroups)), 1u), m),
                            dim3(256), 0, s, all, g);
     else hipLaunchKernelGGL(meshlet_emit_views_kernel<false>, dim3(eblocks, m), dim3(256), 0, s, all, g);
     return hipGetLastError();

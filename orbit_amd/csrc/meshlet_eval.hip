@@ -61,6 +61,7 @@ __device__ __forceinline__ void clear_chunk_sums(const MeshletCullParams &p) {
     const uint32_t max_tiles = (p.dispatch_capacity + kTileRecords - 1) / kTileRecords;
     const uint32_t max_chunks = (max_tiles + kScanChunk - 1) / kScanChunk;
     for (uint32_t c = threadIdx.x; c < max_chunks; c += kEvWaves * 64) p.chunk_sums[c] = 0u;
+    if (threadIdx.x < kEmitTicketPools) p.tickets[(kTicketPools + threadIdx.x) * kTicketStride] = 0u; // its group tickets
 }
 
 // STREAM: meshlets from the derived streams; CLS (with STREAM): predicate bits from the streams' alpha classes
