@@ -297,6 +297,24 @@ def main():
                 ok = 0
             flag = torch.tensor([ok], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1 and args.signalling == "device":
+                # device signalling has to work between the devices of THIS node before the timed steps rely on it: one
+                # known exchange per buffer, compared; if it fails the step keeps the mapped buffers and signals through
+                # two 4-B collectives instead — and the line says so
+                if not all([x.probe(check_status=slots[0].eng.status) for x in exchanges]):
+                    print(f"bench.py: the device-signalled exchange failed its probe on rank {rank}; "
+                          "falling back to --signalling collectives", file=sys.stderr)
+                    for x in exchanges:
+                        x.close()
+                    transport_fallback = "device signalling -> collectives: the probe exchange failed on at least one rank"
+                    try:
+                        exchanges = [odist.P2PExchange(slots[0].eng, x_cap, hdr, item, dev, signalling="collectives")
+                                     for _ in range(n_x)]
+                    except Exception as ex:
+                        print(f"bench.py: p2p exchange unavailable on rank {rank} ({ex})", file=sys.stderr)
+                        ok = 0
+                    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
                 if backend != "nccl":
                     raise SystemExit("bench.py: p2p exchange unavailable and the backend cannot move device lists")

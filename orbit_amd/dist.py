@@ -187,6 +187,37 @@ class P2PExchange:
         dist.all_reduce(self.token, group=self.group)                          # completion: peers' scatters are done
         return self.out
 
+    def probe(self, check_status=None):
+        """One exchange of a known list per rank (rank r sends r + 1 items whose bytes are r + 1), read back and
+        compared: True on every rank only if every rank received all ranks' items in rank order.  A launcher calls it
+        before it relies on this exchange (bench.py: device signalling has to work between the devices of THIS node;
+        if it does not, the step falls back to the collectives form and says so).  `check_status`: called after the
+        synchronisation, raises if the device latched an error (a bounded poll that ran out)."""
+        n = self.rank + 1
+        if self.capacity < self.world * (self.world + 1) // 2:
+            return True  # nothing this small can be sent through it
+        local = torch.zeros(self.header + self.stride * self.world, dtype=torch.uint8, device=self.device)
+        local[:4].view(torch.int32)[0] = n
+        local[self.header:self.header + self.stride * n] = n
+        ok = 1
+        try:
+            self.exchange(local, stream=None)
+            if torch.device(self.device).type == "cuda":
+                torch.cuda.synchronize(self.device)
+            if check_status is not None:
+                check_status()
+            total = self.world * (self.world + 1) // 2
+            got = self.out[:self.header + self.stride * total].clone()
+            want = torch.cat([torch.full((self.stride * (r + 1),), r + 1, dtype=torch.uint8, device=self.device)
+                              for r in range(self.world)])
+            if int(got[:4].view(torch.int32)[0]) != total or not torch.equal(got[self.header:], want):
+                ok = 0
+        except Exception:  # noqa: BLE001 - the verdict is agreed on below
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return int(flag.item()) == 1
+
     def close(self):
         self.t.close()
 

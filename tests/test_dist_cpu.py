@@ -187,6 +187,10 @@ def _p2p_worker(rank, world, port, seed, n_entities, out_dir):
     v["meshlet_index"], v["entity_index"] = cmds["meshlet_index"], cmds["cmd_first_instance"]
     rec = _visible_records(disp, cmds)  # the same list at record granularity (12 B per record with a survivor)
     capacity = scene.lod0_meshlets + 8
+    # the self-check a launcher runs before it relies on an exchange (bench.py): a known list per rank, compared
+    pr = P2PExchange(None, 64, L.VISIBLE_HEADER, 12, torch.device("cpu"), transport=_ShmTransport(f"probe{rank}"))
+    assert pr.probe()
+    pr.close()
     for name, local, header, stride in (("cmd", draw, L.DRAW_HEADER, 28), ("vis", vis, L.VISIBLE_HEADER, 8),
                                         ("rec", rec, L.VISIBLE_HEADER, 12)):
         t = _ShmTransport(f"{name}{rank}")
