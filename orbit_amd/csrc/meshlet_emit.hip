@@ -22,47 +22,72 @@ namespace {
 // tile_base, stored write-through), publish the chunk's sum as sum << 1 | 1 in chunk_sums (zero since the
 // evaluation launch of this cull cleared it), and every workgroup waits for the sums of all chunks — ONE hop, under
 // which the launch's own ramp (records, ballots, links: nothing of which depends on the bases) can run — and builds the
-// chunk bases in LDS as before.  A workgroup waits only for workgroups of lower index (handoff.h: bounded polls).
+// chunk bases in LDS as before.  A workgroup whose wait outlasts its patience does the missing scan itself (below).
 // tile_base is then read with sc1 loads (another workgroup of this launch stored it).
 // Returns the grand total; s_chunk_base[c] = exclusive prefix of chunk c for c < kEmitChunkTable.
-__device__ __forceinline__ void emit_scan_duty(const MeshletCullParams &p, uint32_t ntiles, uint32_t nchunks, uint32_t *s_scan) {
-    if (blockIdx.x == 0 && threadIdx.x < kTicketPools) p.tickets[threadIdx.x * kTicketStride] = 0u; // next evaluation
+__device__ __forceinline__ void emit_scan_chunk(const MeshletCullParams &p, uint32_t c, uint32_t ntiles,
+                                                __amdgpu_buffer_rsrc_t CS, uint32_t *s_scan) {
     static_assert(kScanChunk == 4 * 256, "a thread of the emit block scans four tiles of a chunk");
-    const __amdgpu_buffer_rsrc_t CS = rsrc_of(p.chunk_sums, nchunks * 4u);
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) { // block-uniform
-        const uint32_t i = c * kScanChunk + threadIdx.x * 4u;
-        uint4 v = *reinterpret_cast<const uint4 *>(p.tile_counts + i); // (the scratch is padded past the last tile)
-        v.x = i < ntiles ? v.x : 0u;
-        v.y = i + 1u < ntiles ? v.y : 0u;
-        v.z = i + 2u < ntiles ? v.z : 0u;
-        v.w = i + 3u < ntiles ? v.w : 0u;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan<4>(v.x + v.y + v.z + v.w, s_scan, &total);
-        const v4u o = {ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z};
-        // whole quads up to the one that holds the last tile (the scratch is padded to 256 B: that quad lies inside)
-        const __amdgpu_buffer_rsrc_t TB = rsrc_of(p.tile_base + c * kScanChunk, min(kScanChunk, (ntiles - c * kScanChunk + 3u) & ~3u) * 4u);
-        __builtin_amdgcn_raw_buffer_store_b128(o, TB, threadIdx.x * 16u, 0, kSc1);
-        drain_stores();
-        __syncthreads(); // every wave's prefixes are in memory
-        st_sc1(CS, threadIdx.x == 0 ? c * 4u : kHandoffNoOffset, total << 1 | 1u);
-    }
+    const uint32_t i = c * kScanChunk + threadIdx.x * 4u;
+    uint4 v = *reinterpret_cast<const uint4 *>(p.tile_counts + i); // (the scratch is padded past the last tile)
+    v.x = i < ntiles ? v.x : 0u;
+    v.y = i + 1u < ntiles ? v.y : 0u;
+    v.z = i + 2u < ntiles ? v.z : 0u;
+    v.w = i + 3u < ntiles ? v.w : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan<4>(v.x + v.y + v.z + v.w, s_scan, &total);
+    const v4u o = {ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z};
+    // whole quads up to the one that holds the last tile (the scratch is padded to 256 B: that quad lies inside)
+    const __amdgpu_buffer_rsrc_t TB = rsrc_of(p.tile_base + c * kScanChunk, min(kScanChunk, (ntiles - c * kScanChunk + 3u) & ~3u) * 4u);
+    __builtin_amdgcn_raw_buffer_store_b128(o, TB, threadIdx.x * 16u, 0, kSc1);
+    drain_stores();
+    __syncthreads(); // every wave's prefixes are in memory
+    st_sc1(CS, threadIdx.x == 0 ? c * 4u : kHandoffNoOffset, total << 1 | 1u);
 }
 
-__device__ __forceinline__ uint32_t emit_scan_wait(const MeshletCullParams &p, uint32_t nchunks, uint32_t *s_chunk_base,
-                                                   uint32_t *s_scan) {
+__device__ __forceinline__ void emit_scan_duty(const MeshletCullParams &p, uint32_t ntiles, uint32_t nchunks, uint32_t *s_scan) {
+    if (blockIdx.x == 0 && threadIdx.x < kTicketPools) p.tickets[threadIdx.x * kTicketStride] = 0u; // next evaluation
     const __amdgpu_buffer_rsrc_t CS = rsrc_of(p.chunk_sums, nchunks * 4u);
-    uint32_t grand_total = 0;
-    for (uint32_t c0 = 0; c0 < nchunks; c0 += 256) { // block-uniform trip count
-        const uint32_t c = c0 + threadIdx.x;
-        uint32_t v = ld_sc1(CS, c < nchunks ? c * 4u : kHandoffNoOffset);
-        for (uint32_t spins = 0; c < nchunks && v == 0u; spins++) {
-            if (spins == kSpinLimit) {
-                latch_status(p.status, ORBIT_E_TIMEOUT);
-                break;
-            }
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) emit_scan_chunk(p, c, ntiles, CS, s_scan); // block-uniform
+}
+
+// Nothing here waits for another workgroup for good: a workgroup whose patience with a chunk's sum runs out scans that
+// chunk itself (the same words, the same values: harmless twice).  The first workgroups of a launch are dispatched
+// first and the wait is normally a few polls; but two launches of this kind sharing the device — two processes on one
+// GPU — can each hold the slots the other's first workgroups are waiting for (found with bench.py --gpus 2 on one
+// device: both ran into the poll bound), and no assumption about dispatch order or residency is worth a hang.
+constexpr uint32_t kScanPatience = 256; // polls (each a memory round trip: some hundred microseconds in all)
+
+__device__ __forceinline__ uint32_t emit_scan_wait(const MeshletCullParams &p, uint32_t ntiles, uint32_t nchunks,
+                                                   uint32_t *s_chunk_base, uint32_t *s_scan) {
+    const __amdgpu_buffer_rsrc_t CS = rsrc_of(p.chunk_sums, nchunks * 4u);
+    bool missing = false;
+    for (uint32_t c = threadIdx.x; c < nchunks; c += 256) {
+        uint32_t v = ld_sc1(CS, c * 4u);
+        for (uint32_t spins = 0; v == 0u && spins < kScanPatience; spins++) {
             poll_pause();
             v = ld_sc1(CS, c * 4u);
         }
+        missing = missing || v == 0u;
+    }
+    const uint64_t wave_missing = __ballot(missing);
+    if ((threadIdx.x & 63) == 0) s_scan[threadIdx.x >> 6] = wave_missing != 0ull ? 1u : 0u;
+    __syncthreads();
+    const uint32_t any_missing = uniform(s_scan[0] | s_scan[1] | s_scan[2] | s_scan[3]);
+    __syncthreads();
+    if (any_missing != 0u) {
+        for (uint32_t c = 0; c < nchunks; c++) {
+            if (threadIdx.x == 0) s_chunk_base[0] = ld_sc1(CS, c * 4u);
+            __syncthreads();
+            const uint32_t have = uniform(s_chunk_base[0]);
+            __syncthreads();
+            if (have == 0u) emit_scan_chunk(p, c, ntiles, CS, s_scan);
+        }
+    }
+    uint32_t grand_total = 0;
+    for (uint32_t c0 = 0; c0 < nchunks; c0 += 256) { // block-uniform trip count
+        const uint32_t c = c0 + threadIdx.x;
+        const uint32_t v = ld_sc1(CS, c < nchunks ? c * 4u : kHandoffNoOffset); // (every sum is in: seen above, or stored here)
         uint32_t sub;
         const uint32_t ex = block_exclusive_scan<4>(v >> 1, s_scan, &sub);
         if (c < nchunks && c < kEmitChunkTable) s_chunk_base[c] = grand_total + ex;
@@ -644,7 +669,7 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
     LinkStage nk = link_stage(B, nxt);
     if (lane < (int)kSlowWords) S.slow[lane] = 0u;
     // the launch's ramp above ran under the scan of the first workgroups; now its result
-    const uint32_t grand_total = emit_scan_wait(p, nchunks, s_chunk_base, s_scan);
+    const uint32_t grand_total = emit_scan_wait(p, ntiles, nchunks, s_chunk_base, s_scan);
     {
         auto base_of = [&](uint32_t g) {
             return __builtin_amdgcn_raw_buffer_load_b32(B.bases, (g < kNoGroup ? g : kNoGroup) * kGroupTiles * 4u, 0, kSc1);
