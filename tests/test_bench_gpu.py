@@ -90,6 +90,19 @@ def test_bench_two_ranks_on_one_device_whole_device_path(expand, exchange, signa
     assert abs(d["value"] - c["meshlets_into_meshlet_cull"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
+def test_bench_two_ranks_on_one_device_at_full_size():
+    """The same with the whole 50 M-meshlet scene: two processes whose device-filling launches share the GPU.  A launch
+    that hands work over inside itself must not depend on a workgroup that has not been dispatched — with two such
+    launches resident each can hold the slots the other's first workgroups need (round 4: the chain emit's scan duty
+    did, both ranks ran into the poll bound, ORBIT_E_TIMEOUT, until a waiting workgroup learned to do a missing chunk
+    itself: meshlet_emit.hip emit_scan_wait).  bench.py checks every rank's outputs and the device status."""
+    d = _run_ranks(["--gpus", "2", "--entities", "195313", "--steps", "6", "--cpu-sample-entities", "0"],
+                   dict(ORBIT_BENCH_ONE_DEVICE="1", ORBIT_BENCH_BACKEND="gloo"))
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["transport"] == "p2p" and c["signalling"] == "device" and c["transport_fallback"] is None
+    assert sum(d["per_rank"]["meshlets_in"]) == 195313 * 256 and sum(d["per_rank"]["survivors"]) == c["survivors"] > 0
+
+
 def test_bench_rccl_transport_with_a_world_of_one():
     """The RCCL send/recv transport (counts to the host, grouped send/recv) through a real communicator — of one rank,
     all this box can hold."""

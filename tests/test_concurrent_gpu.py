@@ -1,0 +1,64 @@
+"""Two contexts culling at the same time on one device, each on its own stream (a renderer with two frames in flight):
+frame after frame both produce the list either produces alone, and no in-launch wait runs out.  Launches that hand work
+over INSIDE a launch must never depend on a workgroup that is not running; the case that showed what happens when one
+does — two PROCESSES sharing the device — is tests/test_bench_gpu.py::test_bench_two_ranks_on_one_device_at_full_size
+(two streams of one process did not reproduce it).  2 x 10 M meshlets: every launch takes its device-filling form."""
+import pytest
+
+import scenes as sc
+from orbit_amd import layouts as L
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("source", ["stream", "buffer"])
+def test_two_contexts_cull_concurrently(source):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from orbit_amd import synth
+    from orbit_amd.engine import Engine
+
+    dev = torch.device("cuda", 0)
+    spec = synth.C5Spec(entities=40_000)
+    E, M = spec.entities, spec.meshlets_per_entity
+    draws, mesh, ent, half = synth.gen_entity_tables(spec, dev)
+    meshlets = synth.gen_meshlets(spec, 0, E, dev, half)
+    materials = synth.gen_materials(spec, dev)
+    cam = sc.default_camera(position=(0.0, 0.0, 1300.0))
+    ci = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=0)
+    disp_cap, draw_cap = E * spec.records_per_entity + 8, E * M // 2 + 1024
+
+    class Side:
+        def __init__(self):
+            self.eng = Engine(0, max_entities=E + 256, max_dispatches=disp_cap, max_draws=draw_cap)
+            if source == "stream":
+                ms = self.eng.meshlet_stream(meshlets, 0, E * M)
+                ms.set_materials(materials, spec.materials)
+                self.eng.bind_meshlet_stream(ms)
+            self.stream = torch.cuda.Stream(device=dev)
+            self.disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device=dev)
+            self.draw = torch.zeros(L.DRAW_HEADER + 28 * draw_cap, dtype=torch.uint8, device=dev)
+
+        def frame(self):
+            self.eng.entity_cull(ci, draws, mesh, self.disp, ent, E, disp_cap, stream=self.stream)
+            self.eng.meshlet_cull(ci, self.disp, meshlets, self.draw, ent, materials, disp_cap, draw_cap,
+                                  material_count=spec.materials, stream=self.stream)
+
+    a, b = Side(), Side()
+    a.frame()  # alone: the reference
+    torch.cuda.synchronize()
+    a.eng.status()
+    want = a.draw.clone()
+    n = int(want[:4].view(torch.int32).item())
+    assert n > 0
+    for _ in range(12):  # both at once, frame after frame
+        a.draw.zero_(), b.draw.zero_()
+        torch.cuda.synchronize()
+        a.frame(), b.frame()
+        a.frame(), b.frame()
+        torch.cuda.synchronize()
+        a.eng.status(), b.eng.status()  # no poll ran out
+        used = L.DRAW_HEADER + 28 * n
+        assert torch.equal(a.draw[:used], want[:used]) and torch.equal(b.draw[:used], want[:used])
