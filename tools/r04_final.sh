@@ -17,4 +17,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_configs -- pytho
 f=$(find $O/prof_configs -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats_configs.csv; rm -rf $O/prof_configs
 python3 tools/bench_views.py > $O/views.json 2>> $O/bench.err
 bash tools/shard_pieces.sh stream > $O/shard_pieces.txt 2>> $O/bench.err
+bash tools/traffic.sh stream > $O/traffic_stream.log 2>&1; bash tools/traffic.sh buffer > $O/traffic_buffer.log 2>&1
+cp $R/gpurun_out/traffic_stream.json $R/gpurun_out/traffic.json $O/ 2>/dev/null
+# the default line again, now that the PMC passes of THIS library exist (roofline.traffic_current)
+cp $O/traffic_stream.json $O/traffic.json $R/profiles/ && python3 $R/bench.py > $O/bench_line.json 2>> $O/bench.err
 ls -la $O
