@@ -78,6 +78,7 @@ struct OrbitCtx {
     uint32_t *g_counts = nullptr; // gather_visible: per-rank command counts
     int32_t *status = nullptr;
     uint32_t debug_flags = 0;
+    uint32_t scan_patience = 256; // meshlet_emit.hip emit_scan_wait (orbit_debug_set_scan_patience)
     unsigned long long *debug_cycles = nullptr;
     void *zero_page = nullptr;
     // measurement hook: HIP event pairs around the dominant kernel (meshlet_eval)
@@ -471,6 +472,16 @@ int32_t orbit_debug_read_fused_marks(OrbitCtx *ctx, unsigned long long *out) {
     return e == hipSuccess ? ORBIT_OK : ORBIT_E_HIP;
 }
 
+// tests only (not part of the public ABI): how many polls a workgroup of the chain emit waits for a chunk's sum before
+// it scans the chunk itself (meshlet_emit.hip emit_scan_wait; default 256).  0 makes every waiting workgroup do so at
+// once — the path that otherwise only runs when the launch's first workgroups are not being dispatched.
+int32_t orbit_debug_set_scan_patience(OrbitCtx *ctx, uint32_t polls) {
+    if (!ctx) return ORBIT_E_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->scan_patience = polls;
+    return ORBIT_OK;
+}
+
 // perf triage only (not part of the public ABI): reads and clears the per-phase cycle sums
 int32_t orbit_debug_read_cycles(OrbitCtx *ctx, unsigned long long out[8]) {
     if (!ctx || !out) return ORBIT_E_INVALID;
@@ -626,6 +637,7 @@ int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCull
     p.tickets = scratch->m_tickets;
     p.debug_flags = scratch->debug_flags;
     p.debug_cycles = scratch->debug_cycles;
+    p.scan_patience = ctx->scan_patience;
     p.zero_page = scratch->zero_page;
     p.status = scratch->status;
     return ORBIT_OK;

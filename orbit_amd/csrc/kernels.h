@@ -124,6 +124,7 @@ struct MeshletCullParams {
     const void *zero_page; // 256 zero bytes of context scratch: target of inactive lanes' loads
     unsigned long long *debug_cycles; // ORBIT_SP_DEBUG & 8: per-phase s_memtime sums (8 slots)
     uint32_t debug_flags; // ORBIT_SP_DEBUG (perf triage only): 8 = per-phase cycle stamps (pass 0 only)
+    uint32_t scan_patience; // chain emit: polls before a waiting workgroup scans a missing chunk itself
     int32_t *status;
 };
 

@@ -56,7 +56,7 @@ __device__ __forceinline__ void emit_scan_duty(const MeshletCullParams &p, uint3
 // first and the wait is normally a few polls; but two launches of this kind sharing the device — two processes on one
 // GPU — can each hold the slots the other's first workgroups are waiting for (found with bench.py --gpus 2 on one
 // device: both ran into the poll bound), and no assumption about dispatch order or residency is worth a hang.
-constexpr uint32_t kScanPatience = 256; // polls (each a memory round trip: some hundred microseconds in all)
+// (patience: p.scan_patience polls, 256 by default — each a memory round trip, some hundred microseconds in all)
 
 __device__ __forceinline__ uint32_t emit_scan_wait(const MeshletCullParams &p, uint32_t ntiles, uint32_t nchunks,
                                                    uint32_t *s_chunk_base, uint32_t *s_scan) {
@@ -64,7 +64,7 @@ __device__ __forceinline__ uint32_t emit_scan_wait(const MeshletCullParams &p, u
     bool missing = false;
     for (uint32_t c = threadIdx.x; c < nchunks; c += 256) {
         uint32_t v = ld_sc1(CS, c * 4u);
-        for (uint32_t spins = 0; v == 0u && spins < kScanPatience; spins++) {
+        for (uint32_t spins = 0; v == 0u && spins < p.scan_patience; spins++) {
             poll_pause();
             v = ld_sc1(CS, c * 4u);
         }

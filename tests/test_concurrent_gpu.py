@@ -62,3 +62,56 @@ def test_two_contexts_cull_concurrently(source):
         a.eng.status(), b.eng.status()  # no poll ran out
         used = L.DRAW_HEADER + 28 * n
         assert torch.equal(a.draw[:used], want[:used]) and torch.equal(b.draw[:used], want[:used])
+
+
+def test_chain_emit_when_every_waiting_workgroup_scans_for_itself():
+    """The chain emit's first workgroups scan the tiles' counts for the rest of the launch; a workgroup whose patience
+    with a chunk's sum runs out scans the chunk itself (meshlet_emit.hip emit_scan_wait) — the path that otherwise only
+    runs when those first workgroups are not being dispatched.  With the patience set to zero every workgroup takes it
+    at once (ten chunks here, a thousand workgroups writing the same prefixes): the list must not change."""
+    import ctypes as C
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from orbit_amd import _lib, synth
+    from orbit_amd.engine import Engine
+
+    dev = torch.device("cuda", 0)
+    spec = synth.C5Spec(entities=40_000)
+    E, M = spec.entities, spec.meshlets_per_entity
+    draws, mesh, ent, half = synth.gen_entity_tables(spec, dev)
+    meshlets = synth.gen_meshlets(spec, 0, E, dev, half)
+    materials = synth.gen_materials(spec, dev)
+    cam = sc.default_camera(position=(0.0, 0.0, 1300.0))
+    ci = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=0)
+    disp_cap, draw_cap = E * spec.records_per_entity + 8, E * M // 2 + 1024
+    eng = Engine(0, max_entities=E + 256, max_dispatches=disp_cap, max_draws=draw_cap)
+    ms = eng.meshlet_stream(meshlets, 0, E * M)
+    ms.set_materials(materials, spec.materials)
+    eng.bind_meshlet_stream(ms)
+    disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device=dev)
+    draw = torch.zeros(L.DRAW_HEADER + 28 * draw_cap, dtype=torch.uint8, device=dev)
+
+    def frame():
+        draw.zero_()
+        eng.entity_cull(ci, draws, mesh, disp, ent, E, disp_cap)
+        eng.meshlet_cull(ci, disp, meshlets, draw, ent, materials, disp_cap, draw_cap, material_count=spec.materials)
+        torch.cuda.synchronize()
+        eng.status()
+        return draw.clone()
+
+    want = frame()
+    n = int(want[:4].view(torch.int32).item())
+    assert n > 100_000 and int(disp[:4].view(torch.int32).item()) > 10 * 1024 * 16  # more than ten scan chunks of tiles
+    lib = _lib.load()
+    lib.orbit_debug_set_scan_patience.restype = C.c_int32
+    lib.orbit_debug_set_scan_patience.argtypes = [C.c_void_p, C.c_uint32]
+    assert lib.orbit_debug_set_scan_patience(eng._ctx, 0) == 0
+    try:
+        for _ in range(6):
+            assert torch.equal(frame(), want)
+    finally:
+        assert lib.orbit_debug_set_scan_patience(eng._ctx, 256) == 0
+    assert torch.equal(frame(), want)
