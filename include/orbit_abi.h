@@ -817,7 +817,10 @@ int32_t orbit_meshlet_cull_records_and_commands(OrbitCtx *ctx, const OrbitGpuCul
 #define ORBIT_P2P_MAX_WORLD 16
 #define ORBIT_P2P_CTRL_BYTES 1024 /* a rank's control block of orbit_exchange_list (orbit_p2p_alloc'ed, zero-filled) */
 
-/* Exchange buffers: device memory of this context's GPU that peers may map.
+/* Exchange buffers: FINE-GRAINED device memory of this context's GPU that peers may map (hipExtMallocWithFlags,
+ * hipDeviceMallocFinegrained: what a peer stores into it over xGMI — list segments, and the control words a waiting
+ * kernel of this device polls while it runs — is visible here without a kernel boundary in between; ordinary device
+ * memory is coherent between devices only at kernel boundaries).
  * orbit_p2p_alloc returns the pointer and an opaque handle to send to the other
  * processes (any host channel: a file, torch.distributed.all_gather_object);
  * orbit_p2p_open maps a peer's buffer into this process (hipIpcOpenMemHandle;

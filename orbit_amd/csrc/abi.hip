@@ -1351,9 +1351,13 @@ int32_t orbit_p2p_alloc(OrbitCtx *ctx, uint64_t bytes, void **out_ptr, uint8_t o
     *out_ptr = nullptr;
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return hip_fail(ctx, e, "hipSetDevice");
+    // Fine-grained device memory: what a peer GPU stores into it over xGMI — the list segments, and the counts and
+    // completion words this device's waiting kernel polls while it runs — must be visible to this device without a
+    // kernel boundary in between.  Ordinary (coarse-grained) device memory is only coherent between devices at kernel
+    // boundaries: the device's L2 may keep serving a polled control word it cached before the peer's store arrived.
     void *ptr = nullptr;
-    e = hipMalloc(&ptr, bytes);
-    if (e != hipSuccess) return hip_fail(ctx, e, "hipMalloc(p2p buffer)");
+    e = hipExtMallocWithFlags(&ptr, bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipExtMallocWithFlags(p2p buffer, fine-grained)");
     e = hipMemset(ptr, 0, bytes);
     if (e == hipSuccess) e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t *>(out_handle), ptr);
     if (e != hipSuccess) {
