@@ -272,7 +272,8 @@ __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
 // instead and derives the rest, because the uploader lays a mesh's meshlets out as a chain (kernels.h
 // MeshletStreamView): data_offset[i + 1] = data_offset[i] + vertex_count[i] + ceil(3 * triangle_count[i] / 4), one
 // vertex_offset per submesh.
-// The launch is bound by vector-instruction issue (profiles/r03_notes.md), so a wave works on a GROUP of two
+// Round 3 found the launch bound by vector-instruction issue (profiles/r03_notes.md: since round 4 it moves its bytes at
+// the rate the chip streams at, profiles/r04_notes.md §6), so a wave works on a GROUP of two
 // consecutive wave tiles — 32 dispatch records — at a time: everything that is per record runs on 32 lanes instead of
 // 16, and everything that is per tile is paid once per two.
 //   phase A  lane = two neighbouring meshlets of a record (a 16-lane DPP row = one record, four records per
@@ -753,7 +754,8 @@ template <bool STREAM>
 __global__ __launch_bounds__(256) void meshlet_emit_views_kernel(const MeshletCullViews all, const ViewGroup g) {
     meshlet_emit_body<false, STREAM>(all.v[g.idx[blockIdx.y]]);
 }
-// the chain emit is bound by instruction issue: kChainWavesPerSimd resident waves per SIMD (the register budget the
+// kChainWavesPerSimd resident waves per SIMD (three are 2 % slower, a fifth has neither the registers nor the LDS; the
+// launch is bound by its bytes: profiles/r04_notes.md §6) — the register budget the
 // compiler gets) and exactly that many blocks per CU in the grid — a block more per CU would run as a second round
 constexpr int kChainWavesPerSimd = 4;
 __global__ __launch_bounds__(256, kChainWavesPerSimd) void meshlet_emit_chain_kernel(const MeshletCullParams p) {
