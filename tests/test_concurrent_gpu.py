@@ -115,3 +115,51 @@ def test_chain_emit_when_every_waiting_workgroup_scans_for_itself():
     finally:
         assert lib.orbit_debug_set_scan_patience(eng._ctx, 256) == 0
     assert torch.equal(frame(), want)
+
+
+@pytest.mark.parametrize("layout,survive", [("uploaded", 0.6), ("scattered", 0.6), ("uploaded", 0.02)])
+def test_chain_emit_ticketed_groups_in_their_general_form(layout, survive):
+    """The chain emit hands its groups out statically first and by ticket for the tail (a launch of four and more rounds:
+    here 140 000 entities = 35.8 M meshlets = 17 500 groups over 4 096 waves), and a group the pipelined loop cannot
+    serve — more than 128 survivors, or survivors behind a second chain break inside a record — is done again in the
+    general form behind the loop, from the group index the wave kept for that iteration.  60 % survivors make EVERY
+    group such a group (ticketed ones included), offsets that follow no rule break every chain; 2 % survivors leave the
+    pipelined form on its own.  The Meshlet-buffer path (payload emit, its own scan launch) is the independent answer."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from orbit_amd import synth
+    from orbit_amd.engine import Engine
+
+    dev = torch.device("cuda", 0)
+    spec = synth.C5Spec(entities=140_000)
+    E, M = spec.entities, spec.meshlets_per_entity
+    draws, mesh, ent, half = synth.gen_entity_tables(spec, dev)
+    meshlets = synth.gen_meshlets(spec, 0, E, dev, half, survive_target=survive, layout=layout)
+    materials = synth.gen_materials(spec, dev)
+    cam = sc.default_camera(position=(0.0, 0.0, 1300.0))
+    ci = sc.make_cull_info(cam.view, cam.planes, occlusion_pass=0)
+    disp_cap, draw_cap = E * spec.records_per_entity + 8, E * M + 1024
+    eng = Engine(0, max_entities=E + 256, max_dispatches=disp_cap, max_draws=draw_cap)
+    disp = torch.zeros(L.DISPATCH_HEADER + 16 * disp_cap, dtype=torch.uint8, device=dev)
+    draw = torch.zeros(L.DRAW_HEADER + 28 * draw_cap, dtype=torch.uint8, device=dev)
+
+    def frame():
+        draw[:L.DRAW_HEADER].zero_()
+        eng.entity_cull(ci, draws, mesh, disp, ent, E, disp_cap)
+        eng.meshlet_cull(ci, disp, meshlets, draw, ent, materials, disp_cap, draw_cap, material_count=spec.materials)
+        torch.cuda.synchronize()
+        eng.status()
+        n = int(draw[:4].view(torch.int32).item())
+        return n, draw[:L.DRAW_HEADER + 28 * n].clone()
+
+    n_ref, ref = frame()  # from the Meshlet buffer
+    assert int(disp[:4].view(torch.int32).item()) >= 4 * 4096 * 32  # four rounds of groups and more: tickets are on
+    assert abs(n_ref / (E * M) - survive) < 0.25 * survive
+    ms = eng.meshlet_stream(meshlets, 0, E * M)
+    ms.set_materials(materials, spec.materials)
+    eng.bind_meshlet_stream(ms)
+    for _ in range(3):
+        n, got = frame()
+        assert n == n_ref and torch.equal(got, ref)
