@@ -29,7 +29,9 @@ __device__ __forceinline__ void emit_scan_chunk(const MeshletCullParams &p, uint
                                                 __amdgpu_buffer_rsrc_t CS, uint32_t *s_scan) {
     static_assert(kScanChunk == 4 * 256, "a thread of the emit block scans four tiles of a chunk");
     const uint32_t i = c * kScanChunk + threadIdx.x * 4u;
-    uint4 v = *reinterpret_cast<const uint4 *>(p.tile_counts + i); // (the scratch is padded past the last tile)
+    // range-checked: quads past the one that holds the last tile read zeros (that quad lies inside the 256-B padding)
+    const auto q = __builtin_amdgcn_raw_buffer_load_b128(rsrc_of(p.tile_counts, ((ntiles + 3u) & ~3u) * 4u), i * 4u, 0, 0);
+    uint4 v = make_uint4(q[0], q[1], q[2], q[3]);
     v.x = i < ntiles ? v.x : 0u;
     v.y = i + 1u < ntiles ? v.y : 0u;
     v.z = i + 2u < ntiles ? v.z : 0u;
