@@ -85,11 +85,14 @@ __device__ __forceinline__ uint32_t emit_scan_wait(const MeshletCullParams &p, u
             __syncthreads();
             if (have == 0u) emit_scan_chunk(p, c, ntiles, CS, s_scan);
         }
+        drain_stores(); // the sums stored here are in memory before anyone of this workgroup reads them back below
+        __syncthreads();
     }
     uint32_t grand_total = 0;
     for (uint32_t c0 = 0; c0 < nchunks; c0 += 256) { // block-uniform trip count
         const uint32_t c = c0 + threadIdx.x;
         const uint32_t v = ld_sc1(CS, c < nchunks ? c * 4u : kHandoffNoOffset); // (every sum is in: seen above, or stored here)
+        if (c < nchunks && v == 0u) latch_status(p.status, ORBIT_E_TIMEOUT); // (cannot happen: reported rather than summed as zero)
         uint32_t sub;
         const uint32_t ex = block_exclusive_scan<4>(v >> 1, s_scan, &sub);
         if (c < nchunks && c < kEmitChunkTable) s_chunk_base[c] = grand_total + ex;
