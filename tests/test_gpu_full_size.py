@@ -274,3 +274,42 @@ def test_config5_two_pass_frame_against_the_oracle(torch_mod, oracle, meshlet_st
         assert f.eng.meshlet_stream_culls() == (3 if meshlet_stream else 0)  # the three pass-2 culls
     finally:
         f.close()
+
+
+def test_the_largest_stream_both_sources_agree(torch_mod):
+    """The largest scene a derived meshlet stream holds — 524 288 entities x 256 = 2^27 meshlets (4.3 GB of Meshlets,
+    2.1 M dispatch records, 131 k wave tiles = 128 scan chunks, 65 k emit groups = 16 rounds of the chain emit's grid) —
+    through the two meshlet sources: the Meshlet-buffer path (payload emit behind its scan launch) and the stream path
+    (chain emit: scan inside the launch, static share + ticketed groups) are independent implementations of the same
+    ordered list; it must be the same list, in canonical order.  One meshlet more is refused."""
+    torch = torch_mod
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * (1 << 30):
+        pytest.skip("needs ~25 GB of device memory")
+    f = Frame(torch, 524_288, meshlet_stream=False)
+    try:
+        E, M = f.spec.entities, f.spec.meshlets_per_entity
+        assert E * M == 1 << 27
+        _, draw_a, cmds = f.cull(0)
+        n0 = len(cmds)
+        assert 0.05 * E * M < n0 < 0.2 * E * M
+        key = cmds[:, 4].to(torch.int64) * (1 << 32) + (cmds[:, 6].to(torch.int64) & 0xFFFFFFFF)
+        assert bool((key[1:] > key[:-1]).all())
+        del key
+        want = draw_a[:L.DRAW_HEADER + 28 * n0].clone()
+        del draw_a, cmds
+        from orbit_amd._lib import OrbitError
+
+        with pytest.raises(OrbitError):
+            f.eng.meshlet_stream(f.meshlets, 0, E * M + 1)
+        ms = f.eng.meshlet_stream(f.meshlets, 0, E * M)
+        ms.set_materials(f.materials, f.spec.materials)
+        torch.cuda.synchronize()
+        f.eng.bind_meshlet_stream(ms)
+        for _ in range(2):
+            _, draw_b, cmds_b = f.cull(0)
+            assert len(cmds_b) == n0 and torch.equal(draw_b[:L.DRAW_HEADER + 28 * n0], want)
+            del draw_b, cmds_b
+        assert f.eng.meshlet_stream_culls() > 0
+    finally:
+        f.close()
