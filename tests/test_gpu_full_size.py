@@ -313,3 +313,40 @@ def test_the_largest_stream_both_sources_agree(torch_mod):
         assert f.eng.meshlet_stream_culls() > 0
     finally:
         f.close()
+
+
+def test_the_largest_dispatch_capacity(torch_mod):
+    """The largest cull the library addresses — 2 097 150 entities x 256 = 537 M meshlets (17 GB of Meshlets), 16.7 M
+    dispatch records (`orbit_max_dispatch_capacity`), 1 M wave tiles = 1 024 scan chunks: the emit launch's chunk table
+    is full — from the Meshlet buffer: deterministic, in canonical order, and equal to the concatenation of eight
+    entity ranges culled on their own (other grids, other tile boundaries)."""
+    torch = torch_mod
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * (1 << 30):
+        pytest.skip("needs ~45 GB of device memory")
+    f = Frame(torch, 2_097_150, meshlet_stream=False)
+    try:
+        E, M = f.spec.entities, f.spec.meshlets_per_entity
+        assert f.disp_cap > 16_777_216 - 64
+        _, draw_a, cmds = f.cull(0)
+        n0 = len(cmds)
+        assert 0.05 * E * M < n0 < 0.2 * E * M
+        key = cmds[:, 4].to(torch.int64) * (1 << 32) + (cmds[:, 6].to(torch.int64) & 0xFFFFFFFF)
+        assert bool((key[1:] > key[:-1]).all())
+        del key
+        want = cmds.clone()
+        del draw_a, cmds
+        _, _, again = f.cull(0)
+        assert torch.equal(again, want)
+        del again
+        from orbit_amd import dist as odist
+
+        at = 0
+        for b, e in odist.shard_ranges(E, 8):
+            _, _, c = f.cull(0, first=b, count=e - b)
+            assert torch.equal(c, want[at:at + len(c)])
+            at += len(c)
+            del c
+        assert at == n0
+    finally:
+        f.close()
