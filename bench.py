@@ -152,6 +152,9 @@ def spawn_ranks(args):
         raise SystemExit(f"bench.py: rank(s) failed (rank, exit code): {bad}; exit codes of all ranks: {rcs}")
 
 
+RUNTIME_WARM_FRAMES = 1024  # frames a process has enqueued before anything is timed (see the settle phase)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -466,6 +469,12 @@ def main():
         if use_dist:
             dist.all_reduce(per_frame, op=dist.ReduceOp.MAX)
         more = int(np.ceil(args.settle_ms * 1e-3 / max(float(per_frame.item()), 1e-6))) - 16
+        # ... and until the process has enqueued RUNTIME_WARM_FRAMES frames in all: the HIP runtime blocks the enqueuing
+        # thread ONCE for 10-50 ms somewhere in a process's first ~500 frames of this step (tools/stall_find.py: after
+        # frame 416 / 468 / 548 depending on what else was submitted; a device whose host is less than that ahead runs
+        # dry).  With the default K = 30 that moment came 60-130 frames AFTER the timed region; with K = 100 it sat
+        # inside it (0.27 -> 0.6-0.7 ms per step).  A renderer is past it after its first second; so is the timed region.
+        more = max(more, RUNTIME_WARM_FRAMES - frames_before_timed - 16)
         more = min(max(more, 0), 8192)
         for _ in range(more):
             step()
