@@ -21,7 +21,7 @@
 #include <string>
 #include <vector>
 
-#include "../include/orbit_abi.h"
+#include "../include/orbit_abi_ext.h"
 
 namespace {
 

@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/orbit_abi.h"
+#include "../../include/orbit_abi_ext.h"
 #include "orbit_device.h"
 
 namespace orbit {

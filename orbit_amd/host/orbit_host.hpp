@@ -15,7 +15,7 @@
 #include <utility>
 #include <vector>
 
-#include "../../include/orbit_abi.h"
+#include "../../include/orbit_abi_ext.h"
 
 namespace orbit {
 

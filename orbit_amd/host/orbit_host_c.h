@@ -3,7 +3,7 @@
  * (src/passes/draw_gen.rs, src/passes/cluster.rs, src/math.rs, src/camera.rs). */
 #ifndef ORBIT_HOST_C_H
 #define ORBIT_HOST_C_H
-#include "../../include/orbit_abi.h"
+#include "../../include/orbit_abi_ext.h"
 #ifdef __cplusplus
 extern "C" {
 #endif

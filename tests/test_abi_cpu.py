@@ -12,21 +12,29 @@ import pytest
 from orbit_amd import _lib, layouts as L
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "orbit_abi.h")
+HEADER = os.path.join(ROOT, "include", "orbit_abi.h")          # the drop-in core
+HEADER_EXT = os.path.join(ROOT, "include", "orbit_abi_ext.h")  # everything beyond it
+HEADERS = (HEADER, HEADER_EXT)
 
 
-def declared_symbols():
-    text = open(HEADER).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(orbit_[a-z0-9_]+)\s*\(", text)))
+def declared_symbols(headers=HEADERS):
+    names = set()
+    for h in headers:
+        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(orbit_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     names = declared_symbols()
-    assert len(names) >= 18
+    assert len(names) >= 44
+    # the core header alone is the drop-in of SURVEY.md §8b: the context, the four passes, the shard range, the gather
+    core = declared_symbols((HEADER,))
+    assert len(core) <= 20 and {"orbit_entity_cull", "orbit_meshlet_cull", "orbit_depth_reduce", "orbit_compute_clusters",
+                                "orbit_gather_visible", "orbit_ctx_create", "orbit_last_error"} <= set(core)
     for n in names:
-        assert hasattr(lib, n), f"{n} is declared in include/orbit_abi.h but not exported"
+        assert hasattr(lib, n), f"{n} is declared in include/orbit_abi*.h but not exported"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes signature in orbit_amd/_lib.py"
     assert lib.orbit_abi_version() == 4
 
@@ -34,11 +42,14 @@ def test_library_exports_every_declared_symbol():
 def test_header_compiles_as_c_and_cxx(tmp_path):
     src = tmp_path / "t.c"
     src.write_text('#include "orbit_abi.h"\nint main(void){return sizeof(OrbitGpuCullInfo)==400?0:1;}\n')
+    ext = tmp_path / "e.c"
+    ext.write_text('#include "orbit_abi_ext.h"\nint main(void){return sizeof(OrbitCullView)>0&&sizeof(OrbitVisibleRecord)==12?0:1;}\n')
     for cc, std in (("gcc", "-std=c11"), ("g++", "-std=c++17")):
         exe = tmp_path / f"t_{cc}"
-        subprocess.run([cc, std, "-x", "c" if cc == "gcc" else "c++", "-I", os.path.join(ROOT, "include"),
-                        str(src), "-o", str(exe)], check=True)
-        assert subprocess.run([str(exe)]).returncode == 0
+        for unit in (src, ext):
+            subprocess.run([cc, std, "-x", "c" if cc == "gcc" else "c++", "-I", os.path.join(ROOT, "include"),
+                            str(unit), "-o", str(exe)], check=True)
+            assert subprocess.run([str(exe)]).returncode == 0
 
 
 def test_ctypes_mirrors_match_header_sizes():
@@ -146,14 +157,86 @@ def test_orbitscene_round_trip(tmp_path):
         orbitscene.read(tmp_path / "bad")
 
 
-def test_rust_binding_declares_every_entry_point():
-    """bindings/rust/orbit_hip.rs is the text a maintainer adds on the reference side (no Rust toolchain here, so it
-    is not compiled): at least its `extern "C"` block must name every function of include/orbit_abi.h."""
-    import re
+def c_prototypes():
+    """{name: (return, [param, ...])} of every function both headers declare; a scalar is its fixed-width type
+    ("i32", "u32", "u64", "f32"), a pointer is ("ptr", depth, pointee is const) — `T name[N]` parameters are pointers."""
+    scalars = {"int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "float": "f32", "void": "void"}
 
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    header = open(os.path.join(root, "include", "orbit_abi.h")).read()
-    rust = open(os.path.join(root, "bindings", "rust", "orbit_hip.rs")).read()
-    declared = set(re.findall(r"\b(orbit_[a-z0-9_]+)\s*\(", header))
-    bound = set(re.findall(r"\bfn (orbit_[a-z0-9_]+)", rust))
-    assert declared and declared <= bound, sorted(declared - bound)
+    def classify(decl, is_param):
+        decl = decl.strip()
+        depth = decl.count("*") + (1 if "[" in decl else 0)
+        # is what the (outermost) pointer points to const?  `void *const *p`: the text in front of the last `*` ends in
+        # const; `const T *p` / `const T p[N]`: the base type is const and there is one level
+        before_last = decl.rsplit("*", 1)[0].rstrip() if "*" in decl else ""
+        decl = re.sub(r"\[[^\]]*\]", "", decl).replace("*", " ")
+        words = decl.split()
+        if is_param and len(words) > 1 and words[-1] not in scalars and not words[-1].startswith("Orbit"):
+            words = words[:-1]  # the parameter's name
+        const = before_last.endswith("const") or (depth == 1 and words[0] == "const")
+        base = [w for w in words if w != "const"][0]
+        if depth:
+            return ("ptr", depth, const)
+        assert base in scalars, decl
+        return scalars[base]
+
+    out = {}
+    for h in HEADERS:
+        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        for ret, name, params in re.findall(r"([A-Za-z_][\w \t\*]*?)\b(orbit_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+            ps = [] if params.strip() in ("", "void") else [classify(q, True) for q in params.split(",")]
+            out[name] = (classify(ret, False), ps)
+    return out
+
+
+def rust_prototypes():
+    """The same out of the `extern "C"` block of bindings/rust/orbit_hip.rs."""
+    rust = open(os.path.join(ROOT, "bindings", "rust", "orbit_hip.rs")).read()
+    rust = re.sub(r"//[^\n]*", "", rust)
+
+    def classify(ty):
+        ty = ty.strip()
+        depth, const = 0, False
+        while ty.startswith("*"):
+            kind, ty = ty.split(None, 1)
+            if depth == 0:
+                const = kind == "*const"
+            depth += 1
+        return ("ptr", depth, const) if depth else ty
+
+    out = {}
+    for name, params, ret in re.findall(r"\bfn (orbit_[a-z0-9_]+)\s*\(([^)]*)\)\s*(?:->\s*([^;{]+))?;", rust):
+        ps = [classify(q.split(":", 1)[1]) for q in params.split(",") if q.strip()]
+        out[name] = (classify(ret) if ret.strip() else "void", ps)
+    return out
+
+
+def test_rust_binding_matches_the_headers_signature_by_signature():
+    """bindings/rust/orbit_hip.rs is the text a maintainer pastes on the reference side; no Rust toolchain compiles it
+    here, so this is what keeps it from drifting: every function of include/orbit_abi.h and orbit_abi_ext.h is declared
+    with the same number of parameters, the same fixed-width scalars in the same places, pointers of the same depth
+    (and the same constness of what they point to), and the same return type."""
+    c, r = c_prototypes(), rust_prototypes()
+    assert len(c) >= 44 and set(c) == set(declared_symbols())
+    assert set(c) <= set(r), sorted(set(c) - set(r))
+    assert set(r) <= set(c), f"bound but not declared in the headers: {sorted(set(r) - set(c))}"
+    for name, (ret, params) in sorted(c.items()):
+        rret, rparams = r[name]
+        assert len(params) == len(rparams), f"{name}: {len(params)} parameters in C, {len(rparams)} in Rust"
+        for k, (a, b) in enumerate(zip(params, rparams)):
+            assert a == b, f"{name}, parameter {k}: C {a} vs Rust {b}"
+        assert ret == rret or (ret[0] == "ptr" and rret[0] == "ptr" and ret[1] == rret[1]), f"{name}: returns {ret} vs {rret}"
+
+
+def test_ctypes_table_matches_the_headers_signature_by_signature():
+    """orbit_amd/_lib.py SYMBOLS against the same prototypes: parameter count, scalar width, pointer-ness."""
+    widths = {C.c_int32: "i32", C.c_uint32: "u32", C.c_uint64: "u64", C.c_float: "f32", None: "void"}
+    for name, (ret, params) in sorted(c_prototypes().items()):
+        restype, argtypes = _lib.SYMBOLS[name]
+        assert len(argtypes) == len(params), f"{name}: {len(params)} parameters in C, {len(argtypes)} in ctypes"
+        for k, (a, ty) in enumerate(zip(params, argtypes)):
+            is_ptr = ty in (C.c_void_p, C.c_char_p) or hasattr(ty, "contents")
+            assert (a[0] == "ptr") == is_ptr if isinstance(a, tuple) else (not is_ptr and widths[ty] == a), (name, k, a, ty)
+        if isinstance(ret, tuple):
+            assert restype in (C.c_void_p, C.c_char_p), name
+        else:
+            assert widths[restype] == ret, (name, ret, restype)
