@@ -3,10 +3,11 @@
 
 One "step" = one pass of the hot path over the scene: entity_cull + meshlet_cull
 (frustum + normal cone, occlusion_pass 0) on this rank's entity shard and, for
-N > 1, the rank-ordered all-gather of the compacted visible list (12 B per dispatch record with a survivor;
-orbit_amd/dist.py) —
-what BASELINE.json's north_star names.  Turning the gathered list into 28-B commands on every GPU is a
-separate, optional stage (--expand all), reported on its own.
+N > 1, the rank-ordered all-gather of the visible list at record granularity (12 B per dispatch record: entity,
+meshlet offset, should-draw ballot — written by the evaluation launch itself; orbit_amd/dist.py) —
+what BASELINE.json's north_star names.  By default (--expand own) a rank's cull also ends in the 28-B
+MeshletDrawCommandBuffer of its own shard, the indirect-draw buffer it draws from; --expand none leaves that
+out, --expand all makes every GPU expand the whole gathered list (a separate stage on its own stream).
 Inputs are generated on the device and stay resident in HBM; the timed region is
 K steps between barrier + synchronize on both sides, max over ranks.
 
@@ -50,10 +51,12 @@ def parse():
     ap.add_argument("--transport", choices=("p2p", "rccl"), default="p2p",
                     help="N>1: how the lists travel — p2p: direct stores into the peers' IPC-mapped buffers at "
                          "device-computed offsets, no host round trip (default; falls back to rccl when IPC is not "
-                         "available); rccl: counts to the host, grouped RCCL send/recv")
+                         "available); rccl: the record list as ONE RCCL all-gather of fixed-capacity segments + a "
+                         "device-side compaction (no count on the host, no stream wait: north_star's transport); the "
+                         "8-B item / 28-B command lists as grouped RCCL send/recv with the counts read on the host")
     ap.add_argument("--exchange", choices=("records", "visible", "commands"), default="records",
                     help="N>1 exchange format of the visible list: records (default) — 12 B {entity, meshlet offset, "
-                         "should-draw ballot} per dispatch record with a survivor, half the items' bytes at "
+                         "should-draw ballot} per dispatch record (the evaluation launch writes it), half the items' bytes at "
                          "config 5; visible — 8 B {meshlet, entity} per survivor; commands — the 28-B commands "
                          "themselves")
     ap.add_argument("--expand", choices=("own", "none", "all"), default="own",
@@ -67,6 +70,9 @@ def parse():
                     help="N>1, transport p2p: how counts and completion of an exchange travel — device (default: stores "
                          "into the peers' control blocks awaited on the device, orbit_exchange_list: no collective and "
                          "no host call in a step) or collectives (two fixed-size torch.distributed collectives per step)")
+    ap.add_argument("--two-calls", action="store_true",
+                    help="N>1, exchange records: the rank's cull as orbit_entity_cull_range + orbit_meshlet_cull_visible_records "
+                         "(_records_and_commands) instead of ONE orbit_cull_shard call (for A/B: the same outputs)")
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="frame slots (OrbitCtx + stream + buffers each) the steps go round-robin over; 1 = strictly serial")
     ap.add_argument("--time-every", type=int, default=3,
@@ -212,8 +218,8 @@ def main():
     # they are and a rank holds only its meshlet shard.
     do_gather = use_dist and not args.no_gather and (backend == "nccl" or args.transport == "p2p")
     # Format "records": the same ordered list at record granularity — 12 B {entity_index, meshlet_offset, ballot} per
-    # dispatch record with a survivor (orbit_meshlet_cull_visible_records), built straight from the evaluation's
-    # ballots (no survivor scan, no emit launch); half the 8-B items' bytes at config 5 (3.2 survivors per surviving record).
+    # dispatch record (orbit_meshlet_cull_visible_records), written by the evaluation launch itself (no survivor scan, no
+    # launch behind it); half the 8-B items' bytes at config 5 (3 survivors per record).
     visible_exchange = do_gather and args.exchange == "visible"
     records_exchange = do_gather and args.exchange == "records"
     compact_exchange = visible_exchange or records_exchange
@@ -248,6 +254,10 @@ def main():
     F = max(1, args.frames_in_flight)
     hdr, item = (L.VISIBLE_HEADER, 12) if records_exchange else (L.VISIBLE_HEADER, 8) if visible_exchange else (L.DRAW_HEADER, 28)
     list_cap = disp_cap if records_exchange else draw_cap  # entries a rank's list can hold (records / survivors)
+    # the record list as a fixed-capacity segment of an RCCL all-gather (--transport rccl): the same capacity on every rank
+    seg_cap = max(e_ - b_ for b_, e_ in odist.shard_ranges(E, world)) * rec_per_ent + 8
+    if records_exchange:
+        list_cap = seg_cap
 
     class Slot:
         def __init__(self):
@@ -301,31 +311,29 @@ def main():
             flag = torch.tensor([ok], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1 and args.signalling == "device":
-                # device signalling has to work between the devices of THIS node before the timed steps rely on it: one
-                # known exchange per buffer, compared; if it fails the step keeps the mapped buffers and signals through
-                # two 4-B collectives instead — and the line says so
-                if not all([x.probe(check_status=slots[0].eng.status) for x in exchanges]):
-                    print(f"bench.py: the device-signalled exchange failed its probe on rank {rank}; "
-                          "falling back to --signalling collectives", file=sys.stderr)
-                    for x in exchanges:
-                        x.close()
-                    transport_fallback = "device signalling -> collectives: the probe exchange failed on at least one rank"
-                    try:
-                        exchanges = [odist.P2PExchange(slots[0].eng, x_cap, hdr, item, dev, signalling="collectives")
-                                     for _ in range(n_x)]
-                    except Exception as ex:
-                        print(f"bench.py: p2p exchange unavailable on rank {rank} ({ex})", file=sys.stderr)
-                        ok = 0
-                    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                # device signalling has to work between the devices of THIS node before the timed steps rely on it: the
+                # constructor ran one known exchange per buffer and compared it (P2PExchange probe_on_init); where that
+                # failed the object signals through two 4-B collectives instead — on all ranks alike, and the line says so
+                fell = [x.fallback for x in exchanges if x.fallback]
+                if fell:
+                    print(f"bench.py: the device-signalled exchange failed its probe (rank {rank}); "
+                          "the step signals through collectives", file=sys.stderr)
+                    transport_fallback = fell[0]
             if int(flag.item()) == 0:
                 if backend != "nccl":
                     raise SystemExit("bench.py: p2p exchange unavailable and the backend cannot move device lists")
                 transport, exchanges = "rccl", []
                 transport_fallback = "p2p -> rccl: HIP IPC mapping of a peer's list buffer failed on at least one rank"
-        if transport == "p2p":
+        if transport == "rccl" and records_exchange:
+            # north_star's transport, device-only: ONE ncclAllGather of the ranks' record lists as fixed-capacity
+            # segments + one compaction launch (orbit_amd/dist.py AllGatherExchange, orbit_compact_segments) — no count
+            # on the host, no stream wait; also where the p2p transport lands when IPC mapping fails
+            exchanges = [odist.AllGatherExchange(slots[0].eng, seg_cap, x_cap, hdr, item, dev) for _ in range(n_x)]
+            if not all([x.probe(check_status=slots[0].eng.status) for x in exchanges]):
+                raise SystemExit("bench.py: the RCCL all-gather exchange failed its probe")
+        if exchanges:
             recv_bufs = [x.out for x in exchanges]
-        else:
+        else:  # 8-B items / 28-B commands over RCCL: variable-size send/recv, counts on the host
             recv_bufs = [torch.zeros(hdr + item * x_cap, dtype=torch.uint8, device=dev) for _ in range(n_x)]
         x_events = [torch.cuda.Event() for _ in range(n_x)]  # exchange into recv_bufs[j] finished
         e_events = [torch.cuda.Event() for _ in range(n_x)]  # expansion out of recv_bufs[j] finished
@@ -342,7 +350,7 @@ def main():
         with torch.cuda.stream(xstream):
             xstream.wait_event(s.cull_done[k])
             xstream.wait_event(e_events[j])  # the expansion that read this receive buffer two exchanges ago
-            if transport == "p2p":
+            if exchanges:  # p2p (device-signalled or with two collectives) or the RCCL all-gather: nothing waits for the host
                 exchanges[j].exchange(s.lists[k], stream=xstream)
             else:
                 odist.gather_visible(s.lists[k], recv_bufs[j], header=hdr, stride=item)
@@ -361,6 +369,14 @@ def main():
     step_no = [0]
 
     def cull(s, k):
+        if records_exchange and not args.two_calls:
+            # a rank's whole cull as ONE call (orbit_cull_shard) and, up to 65 536 entity-draws, ONE launch: entity test,
+            # record append, meshlet test and the record list the rank sends — plus, with --expand own, the emit launch for
+            # the 28-B commands of its own shard (its indirect-draw buffer, "each rank issues its own draws": SURVEY §8e)
+            s.eng.cull_shard(ci, draws, mesh, s.disp, ent, b, n_local_entities, disp_cap, meshlets_base, materials,
+                             s.lists[k], list_cap, draw_commands_buffer=s.own_cmds if own_expand else None,
+                             draw_capacity=draw_cap if own_expand else 0, material_count=spec.materials, stream=s.stream)
+            return
         s.eng.entity_cull(ci, draws, mesh, s.disp, ent, n_local_entities, disp_cap, draw_first=b, stream=s.stream)
         if own_expand:
             # one evaluation, two products: the record list this rank sends and the 28-B commands of its own shard (its
@@ -407,7 +423,7 @@ def main():
             torch.cuda.current_stream().wait_stream(xstream)
             torch.cuda.current_stream().wait_stream(estream)
 
-    if do_gather and transport == "rccl":  # RCCL channel set-up is not part of any step, warm or timed
+    if do_gather and transport == "rccl" and not exchanges:  # RCCL channel set-up is not part of any step, warm or timed
         assert odist.warm_up(dev)
     # Power-state settle (see --settle-ms): the same frames, back to back, until the device has been busy that long.
     # The frame count must be the same on every rank (a step of the sharded engine contains collectives), so it is
@@ -545,9 +561,15 @@ def main():
     for _ in range(5):
         a, m, z = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         a.record(s0.stream)
-        s0.eng.entity_cull(ci, draws, mesh, s0.disp, ent, n_local_entities, disp_cap, draw_first=b, stream=s0.stream)
-        m.record(s0.stream)
-        if own_expand:
+        if records_exchange and not args.two_calls:  # one call, one launch: there is no "meshlet stage alone"
+            m = a
+            cull(s0, 0)
+        else:
+            s0.eng.entity_cull(ci, draws, mesh, s0.disp, ent, n_local_entities, disp_cap, draw_first=b, stream=s0.stream)
+            m.record(s0.stream)
+        if records_exchange and not args.two_calls:
+            pass
+        elif own_expand:
             s0.eng.meshlet_cull_records_and_commands(ci, s0.disp, meshlets_base, s0.lists[0], s0.own_cmds, ent, materials,
                                                      disp_cap, list_cap, draw_cap, material_count=spec.materials,
                                                      stream=s0.stream)
@@ -751,12 +773,13 @@ def main():
                 "workload": f"config5: {E} entities x {M} = {E * M} synthetic meshlets, entity_cull + meshlet_cull, "
                             f"frustum + normal cone (occlusion_pass 0), all entities in view, "
                             f"{100.0 * tot_draw / max(tot_in, 1):.1f}% survivors ({args.scene_shape})"
-                            + ((", + rank-ordered all-gather of the visible list (12 B per dispatch record with a "
-                                "survivor: entity, meshlet offset, should-draw ballot)" if records_exchange else
+                            + ((", + rank-ordered all-gather of the visible list (12 B per dispatch record: entity, "
+                                "meshlet offset, should-draw ballot)" if records_exchange else
                                 ", + rank-ordered all-gather of the visible list (8-B items)" if visible_exchange
                                 else ", + rank-ordered all-gather of the 28-B command lists")
-                               + (" by direct xGMI stores at device-computed offsets, counts / completion over the "
-                                  "process group" if transport == "p2p" else " by RCCL send/recv")
+                               + (" by direct xGMI stores at device-computed offsets" if transport == "p2p" else
+                                  " by ONE RCCL all-gather of fixed-capacity list segments + a device-side compaction"
+                                  if exchanges else " by RCCL send/recv (counts read on the host)")
                                if do_gather else ""),
                 "entities": E, "meshlets": E * M, "meshlets_into_meshlet_cull": tot_in, "survivors": tot_draw,
                 "scene_shape": args.scene_shape,

@@ -163,6 +163,22 @@ extern "C" {
     pub fn orbit_exchange_list(ctx: *mut OrbitCtx, local_list: *const c_void, rank: u32, world: u32,
                                out_buffers: *const *mut c_void, ctrl_buffers: *const *mut c_void, out_capacity: u32,
                                header_bytes: u32, stride: u32, stream: *mut c_void) -> i32;
+    /// A rank's whole cull (entity range + meshlet stage into the record list [+ its own commands]) as one call — one
+    /// launch for pass 0 and up to 65 536 entity-draws.
+    pub fn orbit_cull_shard(ctx: *mut OrbitCtx, cull_info: *const c_void, entity_bufs: *const OrbitEntityCullBufs,
+                            draw_first: u32, draw_count: u32, meshlet_bufs: *const OrbitMeshletCullBufs,
+                            record_buffer: *mut c_void, record_capacity: u32, with_commands: u32,
+                            stream: *mut c_void) -> i32;
+    pub fn orbit_ctx_shard_culls(ctx: *const OrbitCtx) -> u64;
+    /// north_star's transport, device-only: ONE ncclAllGather of the ranks' fixed-capacity list segments, then one
+    /// launch that compacts them into the contiguous rank-ordered list (no count on the host, no stream wait).
+    pub fn orbit_allgather_list(ctx: *mut OrbitCtx, nccl_comm: *mut c_void, rank: u32, world: u32,
+                                local_list: *const c_void, segment_capacity: u32, segments: *mut c_void,
+                                out_list: *mut c_void, out_capacity: u32, header_bytes: u32, stride: u32,
+                                stream: *mut c_void) -> i32;
+    pub fn orbit_compact_segments(ctx: *mut OrbitCtx, segments: *const c_void, world: u32, segment_capacity: u32,
+                                  out_list: *mut c_void, out_capacity: u32, header_bytes: u32, stride: u32,
+                                  stream: *mut c_void) -> i32;
 }
 
 /// Turns a non-zero status into the panic the Vulkan path produced (assert!/unwrap, draw_gen.rs:247).

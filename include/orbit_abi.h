@@ -41,9 +41,12 @@ extern "C" {
 #define ORBIT_STATIC_ASSERT(c, m) _Static_assert(c, m)
 #endif
 
-#define ORBIT_ABI_VERSION 4u /* 2: *_CullBufs gained depth_pyramid_levels (per-mip images); 3: meshlet streams carry the
+#define ORBIT_ABI_VERSION 5u /* 2: *_CullBufs gained depth_pyramid_levels (per-mip images); 3: meshlet streams carry the
                                 command chain and alpha classes, OrbitCaps.validate_streams, ORBIT_E_STALE;
-                                4: OrbitCaps.cull_path, orbit_ctx_fused_culls (the one-launch cull of orbit_cull_views) */
+                                4: OrbitCaps.cull_path, orbit_ctx_fused_culls (the one-launch cull of orbit_cull_views);
+                                5: this header is the drop-in core, the rest moved to orbit_abi_ext.h; the record list holds an
+                                entry per dispatch record (written by the evaluation launch); orbit_allgather_list,
+                                orbit_compact_segments */
 
 /* u32::MAX = "resource absent" (src/passes/draw_gen.rs:142-144,
  * shaders/meshlet_cull.comp:127). */
@@ -338,9 +341,12 @@ typedef struct OrbitCaps {
     uint32_t validate_streams; /* debug: != 0 makes every cull / expansion served from a bound meshlet stream first
                                   compare the stream with the meshlet buffer (one extra pass over both, ORBIT_E_STALE
                                   latched on a difference): finds a missing orbit_meshlet_stream_update */
-    uint32_t cull_path;        /* orbit_cull_views: 0 = the library chooses per call (views of at most 16 384
-                                  entity-draws each go through the one-launch cull, larger ones through the launch
-                                  chain), 1 = always the launch chain, 2 = always the one-launch cull.  Same outputs
+    uint32_t cull_path;        /* orbit_cull_views / orbit_cull_shard: 0 = the library chooses per call (views of at
+                                  most 16 384 entity-draws each go through the one-launch cull, larger ones through the
+                                  launch chain), 1 = always the launch chain, 2 = the one-launch cull whatever the size —
+                                  for calls it can serve: every view with both stages and at least one entity-draw; a
+                                  call with a view of 0 entity-draws or skip_meshlet_stage runs the chain under every
+                                  setting, as does a context with validate_streams and a bound stream.  Same outputs
                                   either way; tests and A/B timings set it. */
 } OrbitCaps;
 ORBIT_STATIC_ASSERT(sizeof(OrbitCaps) == 36, "OrbitCaps layout");
@@ -434,7 +440,9 @@ typedef struct OrbitMeshletCullBufs {
     uint32_t *meshlet_visibility_buffer; /* required iff cull_info says present */
     const float *depth_pyramid;
     uint32_t depth_pyramid_size[2];
-    uint32_t dispatch_capacity; /* upper bound of records in the dispatch buffer */
+    uint32_t dispatch_capacity; /* upper bound of records in the dispatch buffer, which holds at least
+                                   12 + 16 * dispatch_capacity bytes (the library may read any of them, also
+                                   records past the count in the header) */
     uint32_t draw_capacity;     /* commands the draw buffer can hold */
     uint32_t material_count;    /* entries in material_buffer (assets/mod.rs: materials arena);
                                    0 = unknown.  Only an optimisation hint: when given (<= 4096)

@@ -33,11 +33,12 @@ typedef struct OrbitVisibleMeshlet {
 ORBIT_STATIC_ASSERT(sizeof(OrbitVisibleMeshlet) == 8, "visible item is 8 B");
 #define ORBIT_VISIBLE_HEADER 8u
 
-/* The same ordered list compacted at record granularity (orbit_meshlet_cull_visible_records): one entry per dispatch
- * record that has a survivor, in record order; bit b of `mask` set = meshlet `meshlet_offset + b` of entity
- * `entity_index` is drawn, i.e. the item {meshlet_offset + b, entity_index} of the list above.  12 B per record
- * instead of 8 B per survivor: half the bytes at 3.2 survivors per surviving record (BASELINE config 5), less the
- * more coherent the survivors are. */
+/* The same ordered list at record granularity (orbit_meshlet_cull_visible_records): one entry per dispatch record, in
+ * record order; bit b of `mask` set = meshlet `meshlet_offset + b` of entity `entity_index` is drawn, i.e. the item
+ * {meshlet_offset + b, entity_index} of the list above (mask 0: a record without a survivor — it contributes no item).
+ * 12 B per record instead of 8 B per survivor: half the bytes at 3 survivors per record (BASELINE config 5), never
+ * more than 3/8 of a byte per dispatched meshlet — and an entry's position is its record's index, so the evaluation
+ * launch writes the list itself: no count, no scan, no launch behind it. */
 typedef struct OrbitVisibleRecord {
     uint32_t entity_index;
     uint32_t meshlet_offset;
@@ -185,8 +186,11 @@ int32_t orbit_meshlet_stream_validate(OrbitCtx *ctx, OrbitMeshletStream *ms, con
 int32_t orbit_meshlet_stream_destroy(OrbitMeshletStream *ms);
 int32_t orbit_ctx_bind_meshlet_stream(OrbitCtx *ctx, OrbitMeshletStream *ms);
 /* Calls this context has served from a bound stream so far — meshlet culls of passes 0 and 2 (each such view of
- * orbit_cull_views counts) and orbit_expand_visible (tests and integration checks: a call whose meshlet_buffer is not the stream's source
- * silently takes the plain path). */
+ * orbit_cull_views' launch chain counts) and orbit_expand_visible (tests and integration checks: a call whose
+ * meshlet_buffer is not the stream's source silently takes the plain path).  Views that orbit_cull_views runs as its
+ * ONE launch (up to 16 384 entity-draws, OrbitCaps.cull_path) read the 32-B Meshlet buffer and do not count —
+ * orbit_ctx_fused_culls counts those — and neither ORBIT_E_RANGE nor the validate_streams check applies to them
+ * (a context created with validate_streams keeps the chain for that reason). */
 uint64_t orbit_ctx_meshlet_stream_culls(const OrbitCtx *ctx);
 /* ... of which evaluated from the alpha classes (no material index read): culls whose material buffer the classes
  * mirror, of a stream known to hold no meshlet of class 3 — known when set_materials returns (it waits for its
@@ -245,17 +249,20 @@ int32_t orbit_gather_visible_meshlets(OrbitCtx *ctx, void *nccl_comm, uint32_t r
 int32_t orbit_expand_visible(OrbitCtx *ctx, const void *visible_buffer, const void *meshlet_buffer,
                              void *draw_commands_buffer, uint32_t draw_capacity, void *stream);
 
-/* The visible list at record granularity: 12 B per dispatch record with a
- * survivor instead of 8 B per survivor (OrbitVisibleRecord) — half the
+/* The visible list at record granularity: 12 B per dispatch record
+ * instead of 8 B per survivor (OrbitVisibleRecord) — half the
  * bytes on the links at BASELINE config 5, which makes the sharded step
  * cull-bound at every world size.
  *   orbit_meshlet_cull_visible_records  orbit_meshlet_cull, but
  *       `record_buffer` ({records, survivors} @0, OrbitVisibleRecord[] @8,
  *       record_capacity entries) replaces bufs->draw_commands_buffer /
- *       draw_capacity (not used).  Built from the evaluation's per-record
- *       ballots: no survivor scan, no emit launch.  ORBIT_E_CAPACITY is
- *       latched if the records do not fit (the header holds the clamped
- *       count);
+ *       draw_capacity (not used).  Entry i is dispatch record i with its
+ *       should-draw ballot, written by the evaluation launch itself (ONE
+ *       launch for the whole cull; the header by its last workgroup):
+ *       records = the dispatched records, survivors = the set bits of all of
+ *       them.  ORBIT_E_CAPACITY is latched if the records do not fit (the
+ *       header holds the clamped count, the first record_capacity entries
+ *       are written);
  *   the lists of all ranks are concatenated in rank order like the other
  *       two formats (orbit_scatter_list with header 8, stride 12; the
  *       gathered header's second word is not maintained);
@@ -270,11 +277,23 @@ int32_t orbit_expand_visible_records(OrbitCtx *ctx, const void *record_buffer, c
                                      void *draw_commands_buffer, uint32_t draw_capacity, void *stream);
 /* Both products of ONE evaluation: the record list (as orbit_meshlet_cull_visible_records: what the rank sends) and the
  * rank's own MeshletDrawCommandBuffer in bufs->draw_commands_buffer / draw_capacity (as orbit_meshlet_cull: what it
- * draws from, "each rank keeps its shard and issues its own indirect draws") — the list launches, then
- * scan + emit of the same ballots; cheaper than the list followed by orbit_expand_visible_records of it. */
+ * draws from, "each rank keeps its shard and issues its own indirect draws") — the evaluation writes the
+ * list, scan + emit of the same ballots follow; cheaper than the list followed by orbit_expand_visible_records of it. */
 int32_t orbit_meshlet_cull_records_and_commands(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info,
                                                 const OrbitMeshletCullBufs *bufs, void *record_buffer,
                                                 uint32_t record_capacity, void *stream);
+/* A rank's whole cull as ONE call — orbit_entity_cull_range over [draw_first, draw_first + draw_count) followed by
+ * orbit_meshlet_cull_visible_records (with_commands == 0) or orbit_meshlet_cull_records_and_commands (!= 0) on the
+ * records it appended (meshlet_bufs->meshlet_dispatch_buffer must be entity_bufs->meshlet_dispatch_buffer) — and, for
+ * occlusion pass 0 and at most 65 536 entity-draws, ONE launch for the entity test, the record append, the meshlet
+ * test and the record list (+ the emit launch when the commands are wanted): a shard's step is mostly its launches'
+ * fixed costs, and this is what a 1/8 shard of BASELINE config 5 pays them once for instead of four times.  Other
+ * passes and larger ranges run the two calls' launch chain; the outputs are the same bit for bit either way
+ * (OrbitCaps.cull_path = 1 forces the chain).  orbit_ctx_shard_culls: calls that took the one launch. */
+int32_t orbit_cull_shard(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info, const OrbitEntityCullBufs *entity_bufs,
+                         uint32_t draw_first, uint32_t draw_count, const OrbitMeshletCullBufs *meshlet_bufs,
+                         void *record_buffer, uint32_t record_capacity, uint32_t with_commands, void *stream);
+uint64_t orbit_ctx_shard_culls(const OrbitCtx *ctx);
 
 /* ------------------------------------------------------------------------ */
 /* The same exchange without a host round trip (one node, one process per   */
@@ -341,6 +360,41 @@ int32_t orbit_scatter_list(OrbitCtx *ctx, const void *local_list, const uint32_t
 int32_t orbit_exchange_list(OrbitCtx *ctx, const void *local_list, uint32_t rank, uint32_t world,
                             void *const *out_buffers, void *const *ctrl_buffers, uint32_t out_capacity,
                             uint32_t header_bytes, uint32_t stride, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* north_star's transport — "an RCCL all-gather of the compacted visible    */
+/* list" — with no host in it either.  orbit_gather_visible* (orbit_abi.h)   */
+/* moves variable-size messages and must read their sizes on the host; a    */
+/* collective of a FIXED size needs no size: every rank contributes its     */
+/* whole list buffer as a segment {count | header | segment_capacity items},*/
+/* ONE ncclAllGather moves all segments to all ranks, and one launch         */
+/* compacts them — the counts are read on the device — into the contiguous  */
+/* rank-ordered list {total | header | items}: byte for byte what            */
+/* orbit_exchange_list delivers.  Nothing is read back, no stream is         */
+/* synchronised, both steps can be captured into a graph.  The price is the */
+/* segments' slack on the links (capacity - count items per rank): nothing  */
+/* for the record list, which holds an entry per dispatch record and is as  */
+/* long as the shard's entity stage made it — the list this is meant for    */
+/* (28-B commands or 8-B items sized for the worst case would move mostly    */
+/* slack: those keep orbit_gather_visible*).                                 */
+/*   local_list        this rank's list; the buffer holds at least           */
+/*                     header_bytes + stride * segment_capacity bytes        */
+/*   segment_capacity  items per segment, the same on every rank             */
+/*   segments          world x (header_bytes + stride * segment_capacity)    */
+/*                     bytes of device memory: the collective's receive      */
+/*                     buffer (caller-owned like every buffer)               */
+/*   out_list          {total | header | out_capacity items}; a total beyond */
+/*                     out_capacity latches ORBIT_E_CAPACITY                 */
+/* orbit_compact_segments is the second half alone, for callers that issue   */
+/* the collective themselves (bench.py: torch.distributed's                  */
+/* all_gather_into_tensor, which is ncclAllGather on ROCm).                  */
+/* ------------------------------------------------------------------------ */
+int32_t orbit_allgather_list(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint32_t world, const void *local_list,
+                             uint32_t segment_capacity, void *segments, void *out_list, uint32_t out_capacity,
+                             uint32_t header_bytes, uint32_t stride, void *stream);
+int32_t orbit_compact_segments(OrbitCtx *ctx, const void *segments, uint32_t world, uint32_t segment_capacity,
+                               void *out_list, uint32_t out_capacity, uint32_t header_bytes, uint32_t stride,
+                               void *stream);
 
 #ifdef __cplusplus
 }

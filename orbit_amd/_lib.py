@@ -71,7 +71,7 @@ class DepthPyramidDesc(C.Structure):
                 ("mip_width", C.c_uint32 * MAX_PYRAMID_MIPS), ("mip_height", C.c_uint32 * MAX_PYRAMID_MIPS)]
 
 
-# every symbol include/orbit_abi.h declares: (restype, argtypes)
+# every symbol include/orbit_abi.h and orbit_abi_ext.h declare: (restype, argtypes)
 SYMBOLS = {
     "orbit_abi_version": (C.c_uint32, []),
     "orbit_meshlet_cull_records_and_commands": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(MeshletCullBufs),
@@ -129,6 +129,13 @@ SYMBOLS = {
     "orbit_ctx_bind_meshlet_stream": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "orbit_ctx_meshlet_stream_culls": (C.c_uint64, [C.c_void_p]),
     "orbit_ctx_meshlet_class_culls": (C.c_uint64, [C.c_void_p]),
+    "orbit_cull_shard": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(EntityCullBufs), C.c_uint32, C.c_uint32,
+                                     C.POINTER(MeshletCullBufs), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "orbit_ctx_shard_culls": (C.c_uint64, [C.c_void_p]),
+    "orbit_allgather_list": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
+                                         C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "orbit_compact_segments": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
+                                           C.c_uint32, C.c_uint32, C.c_void_p]),
     "orbit_scatter_list": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                        C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
 }

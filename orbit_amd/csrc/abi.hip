@@ -71,10 +71,11 @@ struct OrbitCtx {
              *a_total = nullptr, *a_coarse = nullptr, *a_coarse_counts = nullptr, *a_hit_cache = nullptr;
     float *a_aabb = nullptr, *a_group_box = nullptr;
     uint32_t a_coarse_seg = 0;
-    uint32_t *m_tickets = nullptr;
+    uint32_t *m_tickets = nullptr, *m_list_sync = nullptr, *f_done = nullptr;
     uint32_t *f_sync = nullptr, *f_ent_flags = nullptr, *f_tile_flags = nullptr; // one-launch cull (cull_fused.hip)
     uint32_t *d_tickets = nullptr; // depth_reduce: one arrival counter per pyramid of a batch
     uint64_t fused_culls = 0;                                                    // views culled by it so far
+    uint64_t shard_culls = 0;                                                    // orbit_cull_shard calls that took ONE launch
     uint32_t *g_counts = nullptr; // gather_visible: per-rank command counts
     int32_t *status = nullptr;
     uint32_t debug_flags = 0;
@@ -280,6 +281,8 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t o_zero = carve(256);
     const size_t o_gc = carve(256);
     const size_t o_tk = carve((kTicketPools + kEmitTicketPools) * kTicketStride * 4);
+    const size_t o_ls = carve(kListSyncWords * 4);
+    const size_t o_sd = carve((size_t)kShardDoneWords * kShardDoneStride * 4);
     const size_t o_fsy = carve(kFusedSyncWords * 4), o_fef = carve((ent / 256 + 2) * 4);
     const size_t o_dtk = carve((size_t)kMaxPyramidBatch * kDepthTicketWords * 4);
     const size_t o_eproto = carve(ent * sizeof(OrbitMeshletDispatch));
@@ -345,6 +348,8 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->a_coarse_seg = (uint32_t)aseg;
     ctx->g_counts = (uint32_t *)(a + o_gc);
     ctx->m_tickets = (uint32_t *)(a + o_tk);
+    ctx->m_list_sync = (uint32_t *)(a + o_ls);
+    ctx->f_done = (uint32_t *)(a + o_sd);
     ctx->f_sync = (uint32_t *)(a + o_fsy);
     ctx->d_tickets = (uint32_t *)(a + o_dtk);
     ctx->f_ent_flags = (uint32_t *)(a + o_fef);
@@ -635,6 +640,7 @@ int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCull
     p.chunk_sums = scratch->m_chunk_sums;
     p.total = scratch->m_total;
     p.tickets = scratch->m_tickets;
+    p.list_sync = scratch->m_list_sync;
     p.debug_flags = scratch->debug_flags;
     p.debug_cycles = scratch->debug_cycles;
     p.scan_patience = ctx->scan_patience;
@@ -733,7 +739,9 @@ int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t cou
     // Views of the reference's own size (src/scene.rs:303, assets/mod.rs:202) are bound by launch latency, not by
     // bytes: all of them together as ONE launch per (pass, projection) (cull_fused.hip) — same outputs.  It evaluates
     // the 32-B Meshlet buffer whatever stream is bound (the survivors' command words are then in the row registers).
-    bool fused = ctx->caps.cull_path != 1u && n_mesh == count;
+    // (a context that validates its stream on every cull keeps the chain: the one launch never reads the stream, and
+    // the validation and ORBIT_E_RANGE are what such a context exists for)
+    bool fused = ctx->caps.cull_path != 1u && n_mesh == count && !(ctx->caps.validate_streams != 0u && ctx->meshlet_stream != nullptr);
     for (uint32_t i = 0; i < count && fused; i++)
         fused = views[i].entity_draw_count != 0u &&
                 (ctx->caps.cull_path == 2u || views[i].entity_draw_count <= kFusedMaxEntityDraws);
@@ -866,13 +874,13 @@ int32_t orbit_meshlet_stream_update(OrbitCtx *ctx, OrbitMeshletStream *ms, const
 int32_t orbit_meshlet_stream_set_materials(OrbitCtx *ctx, OrbitMeshletStream *ms, const void *material_buffer,
                                            uint32_t material_count, void *stream) {
     if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::unique_lock<std::mutex> lock(ctx->mu);
     if (!ms) return fail(ctx, ORBIT_E_MISSING, "meshlet_stream_set_materials: stream is NULL");
     if (ms->device != ctx->device)
         return fail(ctx, ORBIT_E_INVALID, "meshlet_stream_set_materials: stream lives on device %d", ms->device);
     if (material_buffer && material_count == 0)
         return fail(ctx, ORBIT_E_INVALID, "meshlet_stream_set_materials: material_count is 0");
-    std::lock_guard<std::mutex> slock(ms->mu);
+    std::unique_lock<std::mutex> slock(ms->mu);
     // every meshlet the arrays hold, derived or not (the indices of never-derived ones are zero)
     ms->other_pending = true; // no cull trusts the classes until the flag of THIS derivation has come back
     ms->other_recorded = false;
@@ -882,16 +890,26 @@ int32_t orbit_meshlet_stream_set_materials(OrbitCtx *ctx, OrbitMeshletStream *ms
                                           (const OrbitMaterialData *)material_buffer, material_buffer ? material_count : 0u,
                                           ms->d_other, (hipStream_t)stream);
     if (e == hipSuccess) e = read_back_class_flag(ms, (hipStream_t)stream);
-    // Resolved before the call returns (an upload-time call; nothing to wait for while `stream` is only being
-    // captured): the first cull after set_materials takes the class kernel or the index kernel because of what the
-    // stream holds, never because of when the flag's copy happened to land.
-    if (e == hipSuccess && ms->other_recorded) {
-        e = hipEventSynchronize(ms->other_event);
-        if (e == hipSuccess) ms->other_pending = false;
-    }
     if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_stream_classes");
     ms->materials = material_buffer;
     ms->material_count = material_buffer ? material_count : 0u;
+    // Resolved before the call returns (an upload-time call; nothing to wait for while `stream` is only being
+    // captured): the first cull after set_materials takes the class kernel or the index kernel because of what the
+    // stream holds, never because of when the flag's copy happened to land.  The wait itself is made WITHOUT the two
+    // locks — it lasts as long as everything already queued on `stream`, and other threads' enqueues on this context
+    // (or on any context the stream is bound to) have nothing to do with it; nothing is written behind it: the next
+    // cull's event query finds the event complete and clears `other_pending` itself (stream_view_for).
+    const bool wait = ms->other_recorded;
+    hipEvent_t ev = ms->other_event;
+    slock.unlock();
+    lock.unlock();
+    if (wait) {
+        e = hipEventSynchronize(ev);
+        if (e != hipSuccess) {
+            lock.lock();
+            return hip_fail(ctx, e, "hipEventSynchronize(alpha-class flag)");
+        }
+    }
     return ORBIT_OK;
 }
 
@@ -972,6 +990,92 @@ int32_t orbit_meshlet_cull_records_and_commands(OrbitCtx *ctx, const OrbitGpuCul
                                                 void *record_buffer, uint32_t record_capacity, void *stream) {
     return meshlet_cull_impl(ctx, ci, b, nullptr, false, stream, record_buffer, record_capacity, 2u, true);
 }
+
+// One shard's cull of the sharded engine as one call: orbit_entity_cull_range + orbit_meshlet_cull_visible_records (or
+// _records_and_commands) — and, for pass 0 and at most kShardMaxChunks x 256 entity-draws, ONE launch for both stages
+// and the list (+ the emit launch for the commands).
+int32_t orbit_cull_shard(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitEntityCullBufs *eb, uint32_t draw_first,
+                         uint32_t draw_count, const OrbitMeshletCullBufs *mb, void *record_buffer,
+                         uint32_t record_capacity, uint32_t with_commands, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    EntityCullParams ep;
+    MeshletCullParams p;
+    int32_t rc = entity_cull_params(ctx, ctx, ci, eb, draw_first, draw_count, true, ep);
+    if (rc == ORBIT_OK) rc = meshlet_cull_params(ctx, ctx, ci, mb, nullptr, false, record_buffer, record_capacity, 2u, p);
+    if (rc != ORBIT_OK) return rc;
+    if (mb->meshlet_dispatch_buffer != eb->meshlet_dispatch_buffer)
+        return fail(ctx, ORBIT_E_INVALID, "cull_shard: the meshlet stage must read the entity stage's dispatch buffer");
+    if (with_commands) {
+        if (!mb->draw_commands_buffer) return fail(ctx, ORBIT_E_MISSING, "cull_shard: draw_commands_buffer is NULL");
+        p.also_commands = (uint8_t *)mb->draw_commands_buffer;
+        p.also_commands_capacity = mb->draw_capacity;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (ctx->profiling && (ctx->prof_calls++ % ctx->profiling) == 0) {
+        if (ctx->prof_used + 2 > ctx->prof_events.size()) {
+            for (int i = 0; i < 2; i++) {
+                hipEvent_t ev;
+                if (hipEventCreate(&ev) != hipSuccess) return fail(ctx, ORBIT_E_HIP, "hipEventCreate");
+                ctx->prof_events.push_back(ev);
+            }
+        }
+        ev0 = ctx->prof_events[ctx->prof_used];
+        ev1 = ctx->prof_events[ctx->prof_used + 1];
+        ctx->prof_used += 2;
+    }
+    if (p.ms.sphere && ctx->caps.validate_streams) { // debug: is the stream still a mirror?
+        const hipError_t ve = launch_meshlet_stream_validate(p.meshlets, p.ms, p.ms.cls0 ? p.materials : nullptr,
+                                                             ctx->meshlet_stream->material_count, ctx->status, s);
+        if (ve != hipSuccess) return hip_fail(ctx, ve, "launch meshlet_stream_validate");
+    }
+    const uint32_t chunks = (draw_count + 255u) / 256u;
+    const bool one_launch = ci->occlusion_pass == 0u && chunks >= 1u && chunks <= kShardMaxChunks && ctx->caps.cull_path != 1u;
+    hipError_t e;
+    if (one_launch) {
+        FusedCullParams f{};
+        f.m = p;
+        f.entity_draw_buffer = ep.entity_draw_buffer;
+        f.mesh_infos = ep.mesh_infos;
+        f.visibility = ep.visibility;
+        f.e_pyr = ep.pyr;
+        f.draw_first = ep.draw_first;
+        f.draw_limit = ep.draw_limit;
+        f.e_dispatch_capacity = ep.dispatch_capacity;
+        f.ne_chunks = chunks;
+        f.e_total = ep.total;
+        f.sync = ctx->f_sync;
+        f.ent_flags = ctx->f_ent_flags;
+        f.tile_flags = ctx->f_tile_flags;
+        f.done_flags = ctx->f_done;
+        if (ev0 && (e = hipEventRecord(ev0, s)) != hipSuccess) return hip_fail(ctx, e, "hipEventRecord");
+        e = launch_shard_cull(f, ctx->num_cus, s);
+        if (e != hipSuccess) return hip_fail(ctx, e, "launch shard_cull");
+        if (ev1 && (e = hipEventRecord(ev1, s)) != hipSuccess) return hip_fail(ctx, e, "hipEventRecord");
+        if (with_commands) { // scan + emit of the same evaluation's ballots, into the command buffer
+            MeshletCullParams c = p;
+            c.visible_list = 0u;
+            c.draw_buffer = p.also_commands;
+            c.draw_capacity = p.also_commands_capacity;
+            e = launch_meshlet_scan_emit(c, ctx->num_cus, s);
+            if (e != hipSuccess) return hip_fail(ctx, e, "launch scan + emit");
+        }
+        ctx->shard_culls++;
+    } else {
+        e = launch_entity_cull(ep, draw_count, ctx->num_cus, s);
+        if (e != hipSuccess) return hip_fail(ctx, e, "launch entity_cull");
+        e = launch_meshlet_cull(p, ctx->num_cus, s, ev0, ev1);
+        if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_cull");
+    }
+    if (p.ms.sphere && ci->occlusion_pass != 1) {
+        ctx->stream_culls++;
+        if (p.ms.cls0) ctx->class_culls++;
+    }
+    return ORBIT_OK;
+}
+
+uint64_t orbit_ctx_shard_culls(const OrbitCtx *ctx) { return ctx ? ctx->shard_culls : 0; }
 
 int32_t orbit_expand_visible(OrbitCtx *ctx, const void *visible_buffer, const void *meshlet_buffer,
                              void *draw_commands_buffer, uint32_t draw_capacity, void *stream) {
@@ -1457,6 +1561,56 @@ int32_t orbit_exchange_list(OrbitCtx *ctx, const void *local_list, uint32_t rank
     const hipError_t e = launch_exchange_list(p, ctx->num_cus, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch exchange_list");
     return ORBIT_OK;
+}
+
+static int32_t compact_segments_locked(OrbitCtx *ctx, const void *segments, uint32_t world, uint32_t segment_capacity,
+                                       void *out_list, uint32_t out_capacity, uint32_t header_bytes, uint32_t stride,
+                                       void *stream) {
+    if (!segments || !out_list) return fail(ctx, ORBIT_E_MISSING, "compact_segments: NULL argument");
+    if (world == 0 || world > kMaxGatherWorld)
+        return fail(ctx, ORBIT_E_INVALID, "compact_segments: world %u (max %u)", world, kMaxGatherWorld);
+    if (header_bytes < 4 || header_bytes % 4u || stride == 0 || stride % 4u)
+        return fail(ctx, ORBIT_E_INVALID, "compact_segments: header %u / stride %u must be multiples of 4", header_bytes,
+                    stride);
+    const hipError_t e = launch_compact_segments((const uint8_t *)segments, world, segment_capacity, (uint8_t *)out_list,
+                                                 out_capacity, header_bytes, stride, ctx->num_cus, ctx->status,
+                                                 (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch compact_segments");
+    return ORBIT_OK;
+}
+
+int32_t orbit_compact_segments(OrbitCtx *ctx, const void *segments, uint32_t world, uint32_t segment_capacity,
+                               void *out_list, uint32_t out_capacity, uint32_t header_bytes, uint32_t stride,
+                               void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    return compact_segments_locked(ctx, segments, world, segment_capacity, out_list, out_capacity, header_bytes, stride,
+                                   stream);
+}
+
+int32_t orbit_allgather_list(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint32_t world, const void *local_list,
+                             uint32_t segment_capacity, void *segments, void *out_list, uint32_t out_capacity,
+                             uint32_t header_bytes, uint32_t stride, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!nccl_comm || !local_list || !segments || !out_list)
+        return fail(ctx, ORBIT_E_MISSING, "allgather_list: NULL argument");
+    if (world == 0 || world > kMaxGatherWorld || rank >= world)
+        return fail(ctx, ORBIT_E_INVALID, "allgather_list: rank %u of world %u (max %u)", rank, world, kMaxGatherWorld);
+    if (header_bytes < 4 || header_bytes % 4u || stride == 0 || stride % 4u)
+        return fail(ctx, ORBIT_E_INVALID, "allgather_list: header %u / stride %u must be multiples of 4", header_bytes,
+                    stride);
+    const Rccl &nc = rccl();
+    if (!nc.ok) return fail(ctx, ORBIT_E_COMM, "allgather_list: librccl is not loadable in this process");
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipSetDevice");
+    // ONE collective of a fixed size: every rank's whole segment {count | header | segment_capacity items}.  Nothing is
+    // read back, nothing waits: the counts stay on the device, where the compaction reads them.
+    const size_t seg_bytes = (size_t)header_bytes + (size_t)stride * segment_capacity;
+    const ncclResult_t r = nc.all_gather(local_list, segments, seg_bytes, ncclUint8, (ncclComm_t)nccl_comm, (hipStream_t)stream);
+    if (r != ncclSuccess) return fail(ctx, ORBIT_E_COMM, "ncclAllGather(list segments): %s", nc.error_string(r));
+    return compact_segments_locked(ctx, segments, world, segment_capacity, out_list, out_capacity, header_bytes, stride,
+                                   stream);
 }
 
 int32_t orbit_gather_visible(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint32_t world,

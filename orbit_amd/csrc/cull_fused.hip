@@ -46,16 +46,6 @@ constexpr uint32_t fused_tile_records(int rows) { return 2u * (uint32_t)rows; }
 constexpr uint32_t kFusedSmallEntityDraws = 4096; // views of up to this many entity-draws take the 2-row tiles
 static_assert(kFusedWaves * 64 == kEntityBlock, "one block shape for both phases");
 
-// what entity_eval_one reads, over the fused parameter block (ci and entities are the meshlet side's)
-struct FusedEntity {
-    const OrbitGpuCullInfo &ci;
-    const uint8_t *entity_draw_buffer;
-    const OrbitMeshInfo *mesh_infos;
-    const OrbitEntityData *entities;
-    uint32_t *visibility;
-    PyramidView pyr;
-};
-
 // Exclusive prefix of the survivor counts of the tiles before `t` (wave-uniform), by decoupled look-back: lane i reads
 // the flag of tile pos - 1 - i; the nearest inclusive prefix ends the walk, aggregates in front of it add up.  Tiles
 // below 0 read as "prefix 0".
@@ -171,7 +161,7 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p, FusedL
     if (threadIdx.x == 0) {
         s_word[0] = __hip_atomic_fetch_add(p.sync + kSyTileTicket, kFusedWaves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         auto w = __builtin_amdgcn_raw_buffer_load_b64(SY, kSyEntDone * 4u, 0, kSc1);
-        for (uint32_t spins = 0; w[1] < p.ne_chunks; spins++) {
+        for (uint32_t spins = 0; arrived_chunks(w) < p.ne_chunks; spins++) {
             if (spins == kSpinLimit) {
                 latch_status(p.m.status, ORBIT_E_TIMEOUT);
                 break;
@@ -179,7 +169,7 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p, FusedL
             poll_pause();
             w = __builtin_amdgcn_raw_buffer_load_b64(SY, kSyEntDone * 4u, 0, kSc1);
         }
-        s_word[1] = w[0];
+        s_word[1] = arrived_records(w);
     }
     __syncthreads();
     uint32_t t_next = uniform(s_word[0]) + (uint32_t)wave;

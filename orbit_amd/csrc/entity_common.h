@@ -114,6 +114,16 @@ __device__ __forceinline__ uint32_t entity_record_owner(const uint32_t *s_off, u
     return lo;
 }
 
+// what entity_eval_one reads, over a fused parameter block (FusedCullParams: ci and entities are the meshlet side's)
+struct FusedEntity {
+    const OrbitGpuCullInfo &ci;
+    const uint8_t *entity_draw_buffer;
+    const OrbitMeshInfo *mesh_infos;
+    const OrbitEntityData *entities;
+    uint32_t *visibility;
+    PyramidView pyr;
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // The whole entity stage as ONE launch (entity_cull.hip's single launch, and the first phase of cull_fused.hip).
 // A workgroup draws a chunk of kEntityBlock entity-draws (ticket), evaluates them, publishes the chunk's record
@@ -193,7 +203,11 @@ __device__ __forceinline__ void entity_chunks(const E &ent, const EntityChunksAr
         const uint32_t n = (pr.meshlet_count + ORBIT_MESHLET_DISPATCH_SIZE - 1u) / ORBIT_MESHLET_DISPATCH_SIZE; // :210
         uint32_t chunk_total;
         S.off[threadIdx.x] = block_exclusive_scan<kEntityBlock / 64>(n, S.smem, &chunk_total);
-        chunk_total = uniform(chunk_total);
+        // What this chunk PUBLISHES is cut to capacity + 1: the flag holds the count << 2 and the arrival word adds
+        // chunks << 32 | records, so a count of 2^30 (a corrupt mesh_infos meshlet_count) would wrap the one and carry
+        // into the chunk counter of the other — the header would never be written, or tiles would start early.  Every
+        // record past the capacity is dropped anyway, and capacity + 1 is what latches ORBIT_E_CAPACITY.
+        chunk_total = min(uniform(chunk_total), a.dispatch_capacity + 1u);
         S.proto[threadIdx.x] = pr;
         // the chunk's count first (whoever waits for it must never wait for this chunk's own look-back) ...
         st_sc1(EF, threadIdx.x == 0 ? eb * 4u : kHandoffNoOffset, chunk_total << 2 | kAggregate);
@@ -211,8 +225,9 @@ __device__ __forceinline__ void entity_chunks(const E &ent, const EntityChunksAr
         if (threadIdx.x == 0) {
             // behind the drain above: "this chunk's records are in memory"
             const unsigned long long before = arrive(a.sync + kSyEntDone, chunk_total);
-            if ((uint32_t)(before >> 32) == a.ne_chunks - 1u) { // the last chunk in: the {x,1,1} header (draw_gen.rs:356-363)
-                const uint32_t total = (uint32_t)before + chunk_total;
+            if ((uint32_t)(before >> 40) == a.ne_chunks - 1u) { // the last chunk in: the {x,1,1} header (draw_gen.rs:356-363)
+                const unsigned long long total64 = (before & kArriveRecords) + chunk_total;
+                const uint32_t total = total64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)total64;
                 uint32_t *hdr = reinterpret_cast<uint32_t *>(a.dispatch_buffer);
                 hdr[0] = min(total, a.dispatch_capacity);
                 hdr[1] = 1u;

@@ -46,12 +46,20 @@ __device__ __forceinline__ uint32_t ticket(uint32_t *counter) {
 // compiler cannot see that a word read from LDS behind a barrier is uniform, and wraps what follows — barriers
 // included — in divergent-loop bookkeeping)
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-// the entity phase's arrival word: chunks that have their records in memory << 32 | records so far — one atomic per
-// chunk, one 8-B poll tells a waiting workgroup both "all chunks are in" and the total
+// the entity phase's arrival word: chunks that have their records in memory << 40 | records so far — one atomic per
+// chunk, one 8-B poll tells a waiting workgroup both "all chunks are in" and the total.  A chunk publishes at most
+// capacity + 1 records (entity_chunks), so 40 bits hold the sum of any number of chunks a launch can have: the record
+// field never carries into the chunk count, whatever mesh_infos holds.
+constexpr unsigned long long kArriveOne = 1ull << 40, kArriveRecords = kArriveOne - 1ull;
 __device__ __forceinline__ unsigned long long arrive(uint32_t *word, uint32_t records) {
-    return __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(word), 1ull << 32 | records, __ATOMIC_RELAXED,
+    return __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(word), kArriveOne | records, __ATOMIC_RELAXED,
                                   __HIP_MEMORY_SCOPE_AGENT);
 }
+// the arrival word as loaded with one 8-byte load: {chunks in, records so far (saturated to 32 bits)}
+template <class V2>
+__device__ __forceinline__ uint32_t arrived_chunks(const V2 &w) { return w[1] >> 8; }
+template <class V2>
+__device__ __forceinline__ uint32_t arrived_records(const V2 &w) { return (w[1] & 0xFFu) != 0u ? 0xFFFFFFFFu : w[0]; }
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -18,6 +18,14 @@ constexpr uint32_t kTicketPools = 8;
 constexpr uint32_t kTicketStride = 64; // words
 // ... followed by kEmitTicketPools counters of the chain emit's group tickets (meshlet_emit.hip), zeroed by the evaluation
 constexpr uint32_t kEmitTicketPools = 16;
+// The record list (visible_list == 2) is written by the evaluation itself — no launch follows it that could write the
+// list's header or zero the tile tickets, so the evaluation's LAST workgroup does (meshlet_common.h records_finish):
+// kListGroups 8-byte arrival words {arrivals << 40 | survivors} (workgroup b arrives at word b % kListGroups; the last one
+// of a group carries the group's sum to the top word: nobody queues behind a thousand returning atomics on one word),
+// every word on a 128-B line of its own; zero between launches (the last workgroup leaves them so).
+constexpr uint32_t kListGroups = 32;
+constexpr uint32_t kListSyncStride = 32; // words
+constexpr uint32_t kListSyncWords = (kListGroups + 1) * kListSyncStride;
 
 // what meshlet_eval keeps per survivor for the emit launch (meshlet_cull.hip make_payload)
 struct Payload {
@@ -107,7 +115,8 @@ struct MeshletCullParams {
     OrbitMeshTaskRecord *task_records;
     // sharded engine (orbit_meshlet_cull_visible): draw_buffer is an OrbitVisibleMeshlet buffer (8-B header, 8 B per
     // survivor) and draw_capacity its capacity
-    uint32_t visible_list; // 1: 8-B items, 2: 12-B records with their ballots (orbit_meshlet_cull_visible_records)
+    uint32_t visible_list; // 1: 8-B items, 2: 12-B records with their ballots (orbit_meshlet_cull_visible_records: one
+                           // entry per dispatch record, written by the evaluation launch itself)
     // visible_list == 2 only (orbit_meshlet_cull_records_and_commands): non-null = the same evaluation ALSO ends in the
     // MeshletDrawCommandBuffer (scan + emit behind the record launches) — a shard's own indirect draws next to the list
     // it sends
@@ -121,6 +130,7 @@ struct MeshletCullParams {
     uint32_t *chunk_sums;  // per kScanChunk tiles; the emit launch prefix-sums them itself (LDS)
     uint32_t *total;
     uint32_t *tickets;     // (kTicketPools + kEmitTicketPools) x kTicketStride words (tile tickets, emit group tickets)
+    uint32_t *list_sync;   // kListSyncWords: arrival counters and survivor sums of an evaluation that writes the record list
     const void *zero_page; // 256 zero bytes of context scratch: target of inactive lanes' loads
     unsigned long long *debug_cycles; // ORBIT_SP_DEBUG & 8: per-phase s_memtime sums (8 slots)
     uint32_t debug_flags; // ORBIT_SP_DEBUG (perf triage only): 8 = per-phase cycle stamps (pass 0 only)
@@ -198,7 +208,7 @@ struct ClusterAssignParams {
 // One-launch cull (cull_fused.hip): entity stage and meshlet stage of one view in one persistent kernel.  The meshlet
 // side is the launches' parameter block (Meshlet buffer only: m.ms empty, no task records, no visible list); the entity
 // side adds what entity_cull reads besides (ci, entities and the dispatch buffer are m's).
-// kSyEntDone is 8 bytes: chunks whose records are in memory << 32 | records so far (word 32: the records, word 33: the chunks)
+// kSyEntDone is 8 bytes: chunks whose records are in memory << 40 | records so far (handoff.h arrive / arrived_*)
 constexpr uint32_t kSyEntTicket = 0, kSyEntDone = 32, kSyTileTicket = 96, kSyBlocksDone = 128;
 constexpr uint32_t kFusedSyncWords = 160; // the counters above, each on a 128-B line of its own
 constexpr uint32_t kFusedMaxEntityDraws = 16384; // culls of more entity-draws take the launches (abi.hip)
@@ -216,12 +226,26 @@ struct FusedCullParams {
     uint32_t *sync;       // kFusedSyncWords
     uint32_t *ent_flags;  // per entity chunk: records << 2 | state
     uint32_t *tile_flags; // per wave tile: survivors (or their inclusive prefix) << 2 | state
+    uint32_t *done_flags; // shard launch only: kShardDoneWords x kShardDoneStride words, zero between launches
 };
 struct FusedCullViews {
     FusedCullParams v[ORBIT_MAX_CULL_VIEWS];
 };
 hipError_t launch_cull_fused_views(const FusedCullViews &all, const uint32_t *entity_draw_counts, uint32_t n,
                                    uint32_t num_cus, hipStream_t s);
+// The shard launch of the sharded engine (orbit_cull_shard; meshlet_eval.hip): entity stage + evaluation + record list of
+// one pass-0 view in ONE launch — f.m as for a cull with visible_list == 2 (a bound stream is used), the entity side as
+// for the one-launch cull (f.tile_flags unused).  At most kShardMaxChunks chunks of 256 entity-draws: every chunk adds
+// up the counts of the chunks before it, and beyond a few hundred the pair of entity launches is faster (r04 notes).
+constexpr uint32_t kShardMaxChunks = 256;
+// "every chunk is in" as the waiting workgroups of a shard launch read it: kShardDoneWords copies of {1 << 40 | records},
+// each on a 128-B line of its own, stored by whoever completes the last chunk; workgroup b polls copy b % kShardDoneWords.
+// (A thousand workgroups polling the arrival word itself put a thousand loads per microsecond on one line — the line the
+// chunks' arrival atomics need: the entity phase took 20 us instead of 6.)
+constexpr uint32_t kShardDoneWords = 64, kShardDoneStride = 32; // words
+hipError_t launch_shard_cull(const FusedCullParams &f, uint32_t num_cus, hipStream_t s);
+// scan + emit of an evaluation that has already run (the commands behind a shard launch's record list)
+hipError_t launch_meshlet_scan_emit(const MeshletCullParams &p, uint32_t num_cus, hipStream_t s);
 
 hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_count, uint32_t num_cus, hipStream_t s);
 // orbit_cull_views: the parameter blocks of all views travel BY VALUE in the kernel-argument segment (a few KB: HIP on
@@ -253,7 +277,6 @@ hipError_t launch_meshlet_emit(const MeshletCullParams &p, bool stream, uint32_t
 hipError_t launch_meshlet_emit_views(const MeshletCullViews &all, const ViewGroup &g, uint32_t m, uint32_t n, bool stream,
                                      uint32_t max_tiles_all, uint32_t num_cus, hipStream_t s);
 hipError_t launch_task_records(const MeshletCullParams &p, hipStream_t s);
-hipError_t launch_visible_records(const MeshletCullParams &p, hipStream_t s);
 // Largest dispatch capacity launch_meshlet_cull accepts (the emit launch keeps one base per scan chunk in LDS);
 // checked by orbit_ctx_create against caps.max_dispatches, so no launch is ever enqueued for a larger one.
 uint32_t max_dispatch_capacity();
@@ -289,6 +312,10 @@ struct ScatterListParams {
     int32_t *status;
 };
 hipError_t launch_scatter_list(const ScatterListParams &p, uint32_t num_cus, hipStream_t s);
+// orbit_compact_segments: `world` segments {count | header | segment_capacity items} -> {total | header | items}
+hipError_t launch_compact_segments(const uint8_t *segments, uint32_t world, uint32_t segment_capacity, uint8_t *out,
+                                   uint32_t out_capacity, uint32_t header_bytes, uint32_t stride, uint32_t num_cus,
+                                   int32_t *status, hipStream_t s);
 // orbit_exchange_list: scatter + device-side counts and completion (meshlet_lists.hip)
 struct ExchangeListParams {
     const uint8_t *local_list;

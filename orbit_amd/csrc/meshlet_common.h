@@ -596,6 +596,77 @@ __device__ __forceinline__ void setup_write(const MeshletCullParams &p, WaveTile
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---------------------------------------------------------------------------
+// The record list of the sharded engine (orbit_meshlet_cull_visible_records, visible_list == 2): one 12-B
+// {entity_index, meshlet_offset, should-draw ballot} entry per DISPATCH RECORD, in record order, behind an 8-B
+// {records, survivors} header — the same ordered list of (meshlet, entity) pairs as the 8-B items (bit b of record r =
+// item {meshlet_offset + b, entity_index}; a record without a survivor is an entry with mask 0), at most 3/8 of a
+// byte per dispatched meshlet: what travels over xGMI.  An entry's position is its record's index, so the evaluation
+// writes the list itself, tile by tile — no count, no scan, no launch behind it (rounds 3-4 compacted the entries of
+// records with survivors into a dense list: two more launches per cull, 12 us of an 80-us shard step, to save the 4 % of
+// entries that are empty on BASELINE config 5).
+// The 16 entries of wave tile `tile` from its slab (records and final ballots): lane = 3 x record + word, one
+// contiguous 192-B store; the tile's survivors are added to the wave's sum in LDS (`wave_sum`).
+__device__ __forceinline__ void tile_records_out(const MeshletCullParams &p, const WaveTileLds &L, uint32_t nrec, uint32_t tile,
+                                                 uint32_t survivors, uint32_t *wave_sum, int lane) {
+    // entries past the dispatched records or the list's capacity fall outside the resource and are dropped
+    const __amdgpu_buffer_rsrc_t list =
+        __builtin_amdgcn_make_buffer_rsrc(p.draw_buffer + ORBIT_VISIBLE_HEADER, 0, min(nrec, p.draw_capacity) * 12u, kBufFlags);
+    if (lane == 0) *wave_sum += survivors;
+    const uint32_t r = (uint32_t)lane / 3u, k = (uint32_t)lane - 3u * r;
+    const uint32_t rr = r < kTileRecords ? r : 0u;
+    const uint4 rec = L.r[rr].rec;
+    const uint32_t m = reinterpret_cast<const uint32_t *>(L.draw_mask)[rr];
+    const uint32_t v = k == 0u ? rec.x : (k == 1u ? rec.y : m);
+    const uint32_t off = lane < (int)(3u * kTileRecords) ? tile * (kTileRecords * 12u) + (uint32_t)lane * 4u : kNoOffset;
+    __builtin_amdgcn_raw_buffer_store_b32(v, list, off, 0, 0);
+}
+
+// End of an evaluation that wrote the record list; every thread of the workgroup calls it (a barrier inside).
+// s_red[w] = survivors of the tiles wave w evaluated (tile_records_out).  A workgroup arrives with ONE returning
+// 64-bit atomic — arrivals << 40 | survivors — on the word of its group (workgroup b: group b % kListGroups), the last
+// one of a group carries the group's sum on to the top word the same way, and the last one there holds the total: it
+// writes the header {min(records, capacity), survivors}, latches an overflow, and leaves the words and the tile tickets
+// zero for the next launch (a replayed graph finds them as the first launch did).  One atomic on a workgroup's way
+// out (two for kListGroups of them), each word reached by 1 / kListGroups of the workgroups.
+// (ent_flags / ne_chunks / sync: the shard launch's entity-stage hand-over words, zeroed by the same last workgroup)
+template <int WAVES>
+__device__ __forceinline__ void records_finish(const MeshletCullParams &p, uint32_t nrec, const uint32_t *s_red,
+                                               uint32_t *ent_flags = nullptr, uint32_t ne_chunks = 0u, uint32_t *sync = nullptr,
+                                               uint32_t *done_flags = nullptr) {
+    // this wave's ticket claims have returned and its list stores have left: nothing of it is in flight behind the arrival
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    unsigned long long sum = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; w++) sum += s_red[w];
+    constexpr unsigned long long kOne = 1ull << 40, kSum = kOne - 1ull;
+    unsigned long long *sy = reinterpret_cast<unsigned long long *>(p.list_sync);
+    const uint32_t g = blockIdx.x % kListGroups;
+    const uint32_t in_group = (gridDim.x - g + kListGroups - 1u) / kListGroups;
+    const unsigned long long a = __hip_atomic_fetch_add(sy + g * (kListSyncStride / 2u), kOne | sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(a >> 40) != in_group - 1u) return;
+    const unsigned long long group_sum = (a & kSum) + sum;
+    const uint32_t groups = min(gridDim.x, kListGroups);
+    const unsigned long long t = __hip_atomic_fetch_add(sy + kListGroups * (kListSyncStride / 2u), kOne | group_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(t >> 40) != groups - 1u) return;
+    // every workgroup has arrived
+    const unsigned long long total = (t & kSum) + group_sum;
+    for (uint32_t k = 0; k <= kListGroups; k++) sy[k * (kListSyncStride / 2u)] = 0ull;
+    uint32_t *hdr = reinterpret_cast<uint32_t *>(p.draw_buffer);
+    hdr[0] = min(nrec, p.draw_capacity);
+    hdr[1] = (uint32_t)total;
+    *p.total = nrec;
+    if (nrec > p.draw_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+    for (uint32_t q = 0; q < kTicketPools; q++) p.tickets[q * kTicketStride] = 0u; // the next evaluation's tile tickets
+    if (ent_flags != nullptr) {
+        for (uint32_t i = 0; i < ne_chunks; i++) ent_flags[i] = 0u;
+        for (uint32_t i = 0; i < kFusedSyncWords; i++) sync[i] = 0u;
+        for (uint32_t k = 0; k < kShardDoneWords; k++) done_flags[k * kShardDoneStride] = 0u, done_flags[k * kShardDoneStride + 1u] = 0u;
+    }
+}
+
 // Triage switches (tools/: wave_tail.py, ab_inproc.py, phase.py) exist only in -DORBIT_TRIAGE builds
 // (tools/mkvariant_any.sh); the product library's kernels take no debug input of any kind.
 #ifdef ORBIT_TRIAGE

@@ -4,7 +4,8 @@
 //   evaluation (meshlet_eval.hip) -> scan of the tiles' survivor counts (scan.hip; inside the emit launch where the
 //   commands come from the derived streams) -> emit (meshlet_emit.hip)
 //
-// or, for the outputs that are not a draw-command list, evaluation -> list launches (meshlet_lists.hip).  Tile bases
+// or, for the outputs that are not a draw-command list, evaluation -> list launches (meshlet_lists.hip); the record list
+// of the sharded engine is written by the evaluation itself (meshlet_common.h tile_records_out).  Tile bases
 // come from a prefix sum, so the command sequence is the canonical (record, lane) order with no atomics.  (A
 // single-launch variant with a per-tile decoupled look-back was measured slower on the 50 M-meshlet scene and removed:
 // profiles/r01_notes.md; scenes of the reference's own size take the one-launch path of cull_fused.hip.)
@@ -35,6 +36,12 @@ hipError_t scan_and_emit(const MeshletCullParams &p, uint32_t max_tiles, uint32_
 
 } // namespace
 
+hipError_t launch_meshlet_scan_emit(const MeshletCullParams &p, uint32_t num_cus, hipStream_t s) {
+    const uint32_t max_tiles = (p.dispatch_capacity + kTileRecords - 1) / kTileRecords;
+    if ((max_tiles + kScanChunk - 1) / kScanChunk > kEmitChunkTable) return hipErrorInvalidValue;
+    return scan_and_emit(p, max_tiles, num_cus, s);
+}
+
 hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, hipStream_t s, hipEvent_t ev0,
                                hipEvent_t ev1) {
     const uint32_t max_tiles = (p.dispatch_capacity + kTileRecords - 1) / kTileRecords;
@@ -46,8 +53,8 @@ hipError_t launch_meshlet_cull(const MeshletCullParams &p, uint32_t num_cus, hip
     if (ev1 && (e = hipEventRecord(ev1, s)) != hipSuccess) return e;
     if (p.task_records) return launch_task_records(p, s);
     if (p.visible_list == 2u) {
-        e = launch_visible_records(p, s);
-        if (e != hipSuccess || p.also_commands == nullptr) return e;
+        // the record list is complete: the evaluation wrote its entries and its last workgroup the header
+        if (p.also_commands == nullptr) return hipSuccess;
         // the same evaluation's commands as well: scan + emit as in a plain cull, into the second buffer
         MeshletCullParams c = p;
         c.visible_list = 0u;

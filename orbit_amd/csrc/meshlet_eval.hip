@@ -10,6 +10,7 @@
 //                the 32-B Meshlet and keep no survivor payload (template flags STREAM, CLS).
 // Outputs per wave tile: the survivor count, the should-draw ballots and (Meshlet buffer) the survivors' payload —
 // what scan + emit (meshlet_emit.hip) or the list launches (meshlet_lists.hip) turn into the caller's buffers.
+#include "entity_common.h"
 #include "meshlet_common.h"
 
 namespace orbit {
@@ -65,8 +66,39 @@ __device__ __forceinline__ void clear_chunk_sums(const MeshletCullParams &p) {
 }
 
 // STREAM: meshlets from the derived streams; CLS (with STREAM): predicate bits from the streams' alpha classes
-template <int PASS, int PROJ, bool PROF, bool STREAM = false, bool CLS = false>
-__device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
+// LIST: the instantiation can write the record list (visible_list == 2).  Only the several-views kernel has it: it
+// reads its parameter block from the argument segment where it needs it, while the single-view kernels hold theirs
+// in scalar registers, and the list's handful of extra words there cost the pass-0 kernels 13 v_readlane per tile
+// (18 spilled SGPRs instead of 2) whether a cull writes a list or not.  A cull with a list is launched as one view.
+//
+// FUSED (with LIST; the shard launch of the sharded engine, shard_cull_kernel below): the ENTITY STAGE runs inside this
+// launch, in front of the tiles — the one-launch form of entity_cull (entity_common.h entity_chunks: chunks drawn by
+// ticket, counts published, look-back, records stored write-through, arrival) by the first workgroups, while every
+// workgroup sets up and then waits for "all chunks in" (one 8-byte word: chunks << 32 | records).  A shard's step is
+// then ONE launch where it was entity launch + evaluation + two list launches: at a 1/8 shard of config 5 the launches'
+// fixed costs (each ~4 us of dispatch and drain around its waves' life, a boundary between them) were a third of the
+// step.  What a workgroup waits for here is drawn by whoever runs (tickets), and a workgroup whose patience runs out
+// draws entity tickets itself: nothing depends on dispatch order or residency (handoff.h).  Records are read with sc1
+// loads (another workgroup of this launch stored them), never before the arrival word says they are there.
+constexpr uint32_t kShardPatience = 256; // polls of the arrival word before a waiting workgroup helps with the chunks
+
+template <bool FUSED>
+__device__ __forceinline__ uint4 eval_load_rec(const MeshletCullParams &p, uint32_t tile, bool tile_valid, uint32_t nrec, int lane) {
+    if constexpr (FUSED) {
+        const __amdgpu_buffer_rsrc_t R = rsrc_of(p.dispatch_buffer + ORBIT_DISPATCH_HEADER, nrec * 16u);
+        const uint32_t rec_index = tile * kTileRecords + (uint32_t)(lane >> 2);
+        const auto w = __builtin_amdgcn_raw_buffer_load_b128(R, (tile_valid && rec_index < nrec) ? rec_index * 16u : kNoOffset, 0, kSc1);
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        return setup_load_rec(p, tile, tile_valid, nrec, lane);
+    }
+}
+
+template <int PASS, int PROJ, bool PROF, bool STREAM = false, bool CLS = false, bool LIST = false, bool FUSED = false>
+__device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p, const FusedCullParams *fp = nullptr) {
+    static_assert(!FUSED || LIST, "the shard launch writes the record list");
+    __shared__ std::conditional_t<FUSED, EntityChunksLds, uint32_t> ent_lds;
+    __shared__ uint32_t s_word[2];
     __shared__ WaveTileLds lds[kEvWaves][3];
     __shared__ PlaneLds planes;
     __shared__ AlphaLds alpha_tab;
@@ -75,12 +107,78 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
     // pass 2 with meshlet occlusion: HiZ tests run on compacted candidates (cand_flush), not per row
     const bool occ2 = PASS == 2 && p.ci.meshlet_visibility_buffer != ORBIT_NONE;
     __shared__ uint32_t cls_sel[CLS ? 8 : 1]; // [2 c + k] = all ones if alpha class c has predicate bit k (alpha_bits)
+    __shared__ uint32_t s_red[kEvWaves];      // records_finish
+    // The launch's ramp is a chain of dependent round trips — record count -> records -> matrices -> rows — and on a
+    // shard of the sharded engine (three tiles per wave) it is a fifth of a wave's life.  Two of the hops go: the
+    // records of a wave's first three tiles (always static, below) are requested TOGETHER with the count, bounded by
+    // the buffer's capacity instead of the count and cut to the count when it is there; and the first rows go out with
+    // the first matrices (the rows need a record's meshlet offset and count, not its matrix).
+    uint32_t nrec_raw = 0;
+    if constexpr (!FUSED) nrec_raw = *reinterpret_cast<const uint32_t *>(p.dispatch_buffer);
+    const uint32_t stride = gridDim.x * kEvWaves, wave_g = blockIdx.x * kEvWaves + wave;
+    uint4 r0, r1, rec2;
+    if constexpr (!FUSED) {
+        const uint32_t cap_tiles = (p.dispatch_capacity + kTileRecords - 1) / kTileRecords;
+        r0 = setup_load_rec(p, wave_g, wave_g < cap_tiles, p.dispatch_capacity, lane);
+        r1 = setup_load_rec(p, wave_g + stride, wave_g + stride < cap_tiles, p.dispatch_capacity, lane);
+        rec2 = setup_load_rec(p, wave_g + 2u * stride, wave_g + 2u * stride < cap_tiles, p.dispatch_capacity, lane);
+    }
     planes_to_lds(p, planes);
     clear_chunk_sums(p);
+    if (threadIdx.x < kEvWaves) s_red[threadIdx.x] = 0u;
     if (CLS && threadIdx.x < 6) cls_sel[threadIdx.x] = ((alpha_bits(p.ci, threadIdx.x >> 1) >> (threadIdx.x & 1u)) & 1u) ? ~0u : 0u;
     const AlphaLds *alpha = alpha_table_fill(p, alpha_tab) ? &alpha_tab : nullptr;
     __syncthreads();
-    const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
+    if constexpr (FUSED) {
+        // ------------------------------------------------------------ the entity stage (entity_cull.comp:104-245)
+        const FusedCullParams &f = *fp;
+        const FusedEntity E{p.ci, f.entity_draw_buffer, f.mesh_infos, p.entities, f.visibility, f.e_pyr};
+        EntityChunksArgs a;
+        a.dispatch_buffer = const_cast<uint8_t *>(p.dispatch_buffer);
+        a.dispatch_capacity = f.e_dispatch_capacity;
+        a.draw_first = f.draw_first, a.draw_limit = f.draw_limit;
+        a.ne_chunks = f.ne_chunks;
+        a.sync = f.sync, a.ent_flags = f.ent_flags, a.total = f.e_total, a.status = p.status;
+        // whoever completes the LAST chunk tells everybody: a copy of {1 << 40 | records} on each of kShardDoneWords
+        // lines (thread 0 of that workgroup; write-through).  The waiting workgroups poll a copy each, not the arrival
+        // word the chunks' atomics need.
+        const __amdgpu_buffer_rsrc_t DN = rsrc_of(f.done_flags, kShardDoneWords * kShardDoneStride * 4u);
+        auto tell_all = [&](uint32_t total) {
+            typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+            const v2u v = {total, 1u << 8};
+            for (uint32_t k = 0; k < kShardDoneWords; k++)
+                __builtin_amdgcn_raw_buffer_store_b64(v, DN, k * kShardDoneStride * 4u, 0, kSc1);
+        };
+        // the first workgroups take the chunks (tickets: whichever of them run); everybody else goes to wait
+        if (blockIdx.x < f.ne_chunks) entity_chunks(E, a, ent_lds, tell_all);
+        const uint32_t my_copy = (blockIdx.x % kShardDoneWords) * kShardDoneStride * 4u;
+        for (uint32_t round = 0;; round++) {
+            if (threadIdx.x == 0) {
+                if (round == 0u && blockIdx.x >= f.ne_chunks) asm volatile("s_sleep 64" ::: "memory"); // a chunk takes microseconds
+                auto w = __builtin_amdgcn_raw_buffer_load_b64(DN, my_copy, 0, kSc1);
+                for (uint32_t spins = 0; arrived_chunks(w) == 0u && spins < kShardPatience; spins++) {
+                    asm volatile("s_sleep 8" ::: "memory");
+                    w = __builtin_amdgcn_raw_buffer_load_b64(DN, my_copy, 0, kSc1);
+                }
+                s_word[0] = arrived_chunks(w) != 0u ? 1u : 0u;
+                s_word[1] = arrived_records(w);
+            }
+            __syncthreads();
+            const uint32_t done = uniform(s_word[0]);
+            nrec_raw = uniform(s_word[1]);
+            __syncthreads();
+            if (done != 0u) break;
+            if (round == kSpinLimit / kShardPatience) {
+                if (threadIdx.x == 0) latch_status(p.status, ORBIT_E_TIMEOUT);
+                nrec_raw = 0u; // nothing is evaluated from records that may not be there
+                break;
+            }
+            // patience ran out: whoever holds the missing chunks may not be running — draw them here
+            entity_chunks(E, a, ent_lds, tell_all);
+        }
+        nrec_raw = min(nrec_raw, f.e_dispatch_capacity);
+    }
+    const uint32_t nrec = min(nrec_raw, p.dispatch_capacity);
     const uint32_t ntiles = (nrec + kTileRecords - 1) / kTileRecords;
     // Tile assignment: a static grid-stride share first, tickets for the rest.  With 23 or 24 tiles per wave handed out
     // statically the waves finish over a span of ~45 us (the SIMD arbiter favours older waves, CUs differ) and the last
@@ -94,7 +192,6 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
     // XCDs, so the pools run dry within a tile's time of each other and nobody steals.  A claim is made three tiles
     // before its rows are read (records -> matrices -> slab -> rows); a wave whose ticket is past the end drains its
     // pipeline and leaves.
-    const uint32_t stride = gridDim.x * kEvWaves, wave_g = blockIdx.x * kEvWaves + wave;
     const bool static_share = ORBIT_DBG(p, 64u); // triage: everything static, for A/B runs
     const uint32_t full_rounds = ntiles / stride;
     // ticketed rounds: three on a long launch, fewer on a short one (a shard of the sharded engine has 2-3 rounds in all)
@@ -103,7 +200,7 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
     // ... and the three tiles a wave claims before its first row never go through a ticket either: their records,
     // matrices and rows are the launch's ramp, and an atomic in front of them is one more round trip before anything
     // streams (a 1/8 shard of config 5 is three tiles per wave)
-    const uint32_t n_static = (static_share || ntiles <= stride) ? 0xFFFFFFFFu : (ORBIT_DBG(p, 128u) ? 0u : max(full_rounds >= dyn_rounds ? full_rounds - dyn_rounds : 0u, 3u));
+    const uint32_t n_static = (static_share || ntiles <= stride) ? 0xFFFFFFFFu : (ORBIT_DBG(p, 128u) ? 3u : max(full_rounds >= dyn_rounds ? full_rounds - dyn_rounds : 0u, 3u));
     const uint32_t npools = min((uint32_t)kTicketPools, stride);
     const uint32_t pool = wave_g % npools;
     uint32_t *ticket_ctr = p.tickets + pool * kTicketStride;
@@ -143,22 +240,39 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
     // (STREAM: a row is 1.25 KiB instead of 2 KiB; sets of two rows each were measured in rounds 2 and 3 — neutral or
     // slower, as are 5 and 6 resident waves per SIMD: profiles/r02_notes.md, r03_notes.md)
     RowRegs<1> qa, qb;
-    uint4 rec2;
     {
-        const uint4 r0 = setup_load_rec(p, w0, w0 < ntiles, nrec, lane);
-        const uint4 r1 = setup_load_rec(p, w1, w1 < ntiles, nrec, lane);
-        rec2 = setup_load_rec(p, w2, w2 < ntiles, nrec, lane);
+        // the records requested before the count was known: a lane past the count holds "no record" (zeros), as if it
+        // had read the zero page (w0 .. w2 are the static tiles wave_g + k * stride: n_static >= 3)
+        if constexpr (FUSED) { // the records exist now: loaded here, past the caches
+            r0 = eval_load_rec<true>(p, w0, w0 < ntiles, nrec, lane);
+            r1 = eval_load_rec<true>(p, w1, w1 < ntiles, nrec, lane);
+            rec2 = eval_load_rec<true>(p, w2, w2 < ntiles, nrec, lane);
+        } else {
+            const uint4 none = make_uint4(0u, 0u, 0u, 0u);
+            const uint32_t rl = (uint32_t)lane >> 2;
+            if (!(w0 < ntiles && w0 * kTileRecords + rl < nrec)) r0 = none;
+            if (!(w1 < ntiles && w1 * kTileRecords + rl < nrec)) r1 = none;
+            if (!(w2 < ntiles && w2 * kTileRecords + rl < nrec)) rec2 = none;
+        }
+        // tile 0's records into its slab, so that its first rows can go out with the matrices (setup_write stores
+        // them again, with everything else)
+        if ((lane & 3) == 0) lds[wave][0].r[lane >> 2].rec = r0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // (the matrices first: the slab writes below wait for them, with the rows still in flight behind)
         const float4 m0 = setup_load_mat(p, r0, lane);
         const float4 m1 = setup_load_mat(p, r1, lane);
+        uint32_t c0 = 0u, c1 = 0u;
+        if constexpr (CLS) c0 = setup_load_cls(p, r0, lane), c1 = setup_load_cls(p, r1, lane);
+        rows_load<PASS, 0, 1, STREAM, CLS>(p, lds[wave][0], lane, qa, &SR);
+        rows_load<PASS, 1, 1, STREAM, CLS>(p, lds[wave][0], lane, qb, &SR);
         if constexpr (CLS) {
-            const uint32_t c0 = setup_load_cls(p, r0, lane), c1 = setup_load_cls(p, r1, lane);
             setup_write_cls(lds[wave][0], cls_sel, r0, c0, lane);
             setup_write_cls(lds[wave][1], cls_sel, r1, c1, lane);
         }
         setup_write(p, lds[wave][0], r0, m0, lane);
         setup_write(p, lds[wave][1], r1, m1, lane);
-        rows_load<PASS, 0, 1, STREAM, CLS>(p, lds[wave][0], lane, qa, &SR);
-        rows_load<PASS, 1, 1, STREAM, CLS>(p, lds[wave][0], lane, qb, &SR);
     }
     uint32_t it = 0;
 #ifdef ORBIT_TRIAGE
@@ -222,7 +336,7 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         const float4 mat2 = setup_load_mat(p, rec2, lane);
         uint32_t cls2 = 0u;
         if constexpr (CLS) cls2 = setup_load_cls(p, rec2, lane);
-        const uint4 rec3 = setup_load_rec(p, w3, w3 < ntiles, nrec, lane);
+        const uint4 rec3 = eval_load_rec<FUSED>(p, w3, w3 < ntiles, nrec, lane);
         EV_STAMP(1)
         EV_ROW(4, qa)
         rows_load<PASS, 6, 1, STREAM, CLS>(p, L, lane, qa, &SR);
@@ -242,9 +356,14 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         setup_write(p, lds[wave][(it + 2) % 3], rec2, mat2, lane); // also fences the mask writes of this tile
         // the ballots are read back only by the task-record launch and, in the emit launch, for tiles with more
         // survivors than the payload holds: the common tile writes its count and nothing else
-        if ((STREAM || p.task_records != nullptr || p.visible_list == 2u || cs.total > kPayloadCap) && lane < 2 * (int)kTileRows)
+        // (nor does anything read them behind a record list without commands)
+        const bool rec_list = LIST && p.visible_list == 2u;
+        if (((STREAM && !(rec_list && p.also_commands == nullptr)) || p.task_records != nullptr || cs.total > kPayloadCap) && lane < 2 * (int)kTileRows)
             p.tile_masks[(size_t)w0 * (2 * kTileRows) + lane] = reinterpret_cast<const uint32_t *>(L.draw_mask)[lane];
         if (lane == 0) p.tile_counts[w0] = cs.total;
+        // the record list (visible_list == 2) is written here, an entry per dispatch record at the record's index; the
+        // wave's survivors add up in LDS (nothing of the list lives in a register across tiles)
+        if (rec_list) tile_records_out(p, L, nrec, w0, cs.total, s_red + wave, lane);
         EV_STAMP(4)
         w0 = w1;
         w1 = w2;
@@ -253,6 +372,8 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p) {
         it++;
     }
 #undef EV_STAMP
+    if constexpr (FUSED) records_finish<kEvWaves>(p, nrec, s_red, fp->ent_flags, fp->ne_chunks, fp->sync, fp->done_flags);
+    else if (LIST && p.visible_list == 2u) records_finish<kEvWaves>(p, nrec, s_red);
 #ifdef ORBIT_TRIAGE
     if (PROF && lane == 0) {
         for (int k = 0; k < 5; k++) atomicAdd(p.debug_cycles + k, tc[k]);
@@ -276,7 +397,18 @@ __global__ __launch_bounds__(kEvWaves * 64, ev_waves_per_simd(PASS, STREAM)) voi
 template <int PASS, int PROJ, bool STREAM, bool CLS = false>
 __global__ __launch_bounds__(kEvWaves * 64, ev_waves_per_simd(PASS, STREAM)) void meshlet_eval_views_kernel(const MeshletCullViews all,
                                                                                            const ViewGroup g) {
-    meshlet_eval_body<PASS, PROJ, false, STREAM, CLS>(all.v[g.idx[blockIdx.y]]);
+    meshlet_eval_body<PASS, PROJ, false, STREAM, CLS, true>(all.v[g.idx[blockIdx.y]]);
+}
+
+// The shard launch: entity stage + evaluation + record list of ONE view (pass 0).  The parameter block is read from the
+// argument segment at a uniform offset like the several-views kernels' (a block held in scalar registers spills).
+struct ShardCullArgs {
+    FusedCullParams v[2]; // [1] unused: the index is what keeps the block out of the scalar registers
+};
+template <int PROJ, bool STREAM, bool CLS>
+__global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void shard_cull_kernel(const ShardCullArgs all, const ViewGroup g) {
+    const FusedCullParams &f = all.v[g.idx[blockIdx.y] & 1u];
+    meshlet_eval_body<0, PROJ, false, STREAM, CLS, true, true>(f.m, &f);
 }
 
 // ---------------------------------------------------------------------------
@@ -365,15 +497,17 @@ __device__ __forceinline__ uint32_t pass1_eval(const MeshletCullParams &p, WaveT
     return total + (uint32_t)__popcll(dm);
 }
 
-template <int PROJ>
+template <int PROJ, bool LIST = false> // LIST: as in meshlet_eval_body
 __device__ __forceinline__ void meshlet_pass1_body(const MeshletCullParams &p) {
     __shared__ WaveTileLds lds[kEvWaves][3];
     __shared__ PlaneLds planes;
     __shared__ AlphaLds alpha_tab;
     __shared__ uint16_t s_list[kEvWaves][2][kTileRows * 64];
+    __shared__ uint32_t s_red[kEvWaves]; // records_finish
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     planes_to_lds(p, planes);
     clear_chunk_sums(p);
+    if (threadIdx.x < kEvWaves) s_red[threadIdx.x] = 0u;
     const AlphaLds *alpha = alpha_table_fill(p, alpha_tab) ? &alpha_tab : nullptr;
     __syncthreads();
     const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
@@ -421,9 +555,10 @@ __device__ __forceinline__ void meshlet_pass1_body(const MeshletCullParams &p) {
             if (last) break;
         }
         setup_write(p, lds[wave][(it + 2) % 3], rec2, mat2, lane, prev2); // also fences the mask atomics of this tile
-        if ((p.task_records != nullptr || p.visible_list == 2u || total > kPayloadCap) && lane < 2 * (int)kTileRows) // see meshlet_eval
+        if ((p.task_records != nullptr || total > kPayloadCap) && lane < 2 * (int)kTileRows) // see meshlet_eval
             p.tile_masks[(size_t)w0 * (2 * kTileRows) + lane] = reinterpret_cast<const uint32_t *>(L.draw_mask)[lane];
         if (lane == 0) p.tile_counts[w0] = total;
+        if (LIST && p.visible_list == 2u) tile_records_out(p, L, nrec, w0, total, s_red + wave, lane);
         uint16_t *t = list_cur;
         list_cur = list_next;
         list_next = t;
@@ -434,6 +569,7 @@ __device__ __forceinline__ void meshlet_pass1_body(const MeshletCullParams &p) {
         rec2 = rec3;
         it++;
     }
+    if (LIST && p.visible_list == 2u) records_finish<kEvWaves>(p, nrec, s_red);
 }
 
 template <int PROJ>
@@ -443,7 +579,7 @@ __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_pass1_
 template <int PROJ>
 __global__ __launch_bounds__(kEvWaves * 64, kEvWavesPerSimd) void meshlet_pass1_views_kernel(const MeshletCullViews all,
                                                                                             const ViewGroup g) {
-    meshlet_pass1_body<PROJ>(all.v[g.idx[blockIdx.y]]);
+    meshlet_pass1_body<PROJ, true>(all.v[g.idx[blockIdx.y]]);
 }
 
 // 4-wave blocks, one wave per SIMD each.  The fifth wave per SIMD pays once a wave has enough tiles to stream (8 and
@@ -506,6 +642,14 @@ hipError_t launch_meshlet_eval(const MeshletCullParams &p, uint32_t num_cus, hip
     const uint32_t pass = p.ci.occlusion_pass;
     const dim3 grid(eval_grid(pass, p.ms.sphere != nullptr, max_tiles, num_cus));
 #ifndef ORBIT_PASS2_BY_VALUE
+    // (a cull that writes the record list, whatever its pass: only the several-views kernel can — meshlet_eval_body LIST)
+    if (p.visible_list == 2u) {
+        MeshletCullViews one{};
+        one.v[0] = p;
+        const ViewGroup g{};
+        const int src = p.ms.sphere == nullptr ? 0 : (p.ms.cls0 != nullptr ? 2 : 1);
+        return launch_meshlet_eval_views(one, g, 1u, pass, p.ci.projection_type == 1, src, max_tiles, num_cus, s);
+    }
     // Pass 2 goes through the several-views kernel with one view.  With the block as the kernel's own argument the
     // compiler keeps all of it in scalar registers and, next to the HiZ test's own, runs out of them: 25-34 spilled
     // (v_writelane / v_readlane in a kernel that is bound by its vector pipe); read from the argument segment at a
@@ -538,6 +682,31 @@ hipError_t launch_meshlet_eval(const MeshletCullParams &p, uint32_t num_cus, hip
     return hipGetLastError();
 }
 
+// orbit_cull_shard: the entity stage, the evaluation and the record list of a shard in one launch (pass 0, at most
+// kShardMaxChunks chunks of 256 entity-draws; the caller checks both)
+hipError_t launch_shard_cull(const FusedCullParams &f, uint32_t num_cus, hipStream_t s) {
+    const MeshletCullParams &p = f.m;
+    const uint32_t max_tiles = (p.dispatch_capacity + kTileRecords - 1) / kTileRecords;
+    // every chunk needs a workgroup that may take it: at least as many workgroups as chunks
+    const dim3 grid(max(eval_grid(0u, p.ms.sphere != nullptr, max_tiles, num_cus), min(f.ne_chunks, num_cus * (uint32_t)kEvWavesPerSimd))), block(kEvWaves * 64);
+    ShardCullArgs a{};
+    a.v[0] = f;
+    const ViewGroup g{};
+    const bool ortho = p.ci.projection_type == 1;
+    const int src = p.ms.sphere == nullptr ? 0 : (p.ms.cls0 != nullptr ? 2 : 1);
+    if (src == 2) {
+        if (ortho) hipLaunchKernelGGL((shard_cull_kernel<1, true, true>), grid, block, 0, s, a, g);
+        else hipLaunchKernelGGL((shard_cull_kernel<0, true, true>), grid, block, 0, s, a, g);
+    } else if (src == 1) {
+        if (ortho) hipLaunchKernelGGL((shard_cull_kernel<1, true, false>), grid, block, 0, s, a, g);
+        else hipLaunchKernelGGL((shard_cull_kernel<0, true, false>), grid, block, 0, s, a, g);
+    } else {
+        if (ortho) hipLaunchKernelGGL((shard_cull_kernel<1, false, false>), grid, block, 0, s, a, g);
+        else hipLaunchKernelGGL((shard_cull_kernel<0, false, false>), grid, block, 0, s, a, g);
+    }
+    return hipGetLastError();
+}
+
 // One evaluation launch for the m views g.idx[0..m) of `all`, which share the occlusion pass, the projection and the
 // meshlet source `src` (0 = Meshlet buffer, 1 = derived streams, 2 = streams with alpha classes).
 hipError_t launch_meshlet_eval_views(const MeshletCullViews &all, const ViewGroup &g, uint32_t m, uint32_t pass,
@@ -546,6 +715,7 @@ hipError_t launch_meshlet_eval_views(const MeshletCullViews &all, const ViewGrou
     uint32_t blocks = max(num_cus * (uint32_t)ev_waves_per_simd((int)pass, src != 0) / m, 1u);
     const uint32_t need = max((max_tiles + kEvWaves - 1) / kEvWaves, 1u);
     if (blocks > need) blocks = need;
+    if (m == 1u) blocks = eval_grid(pass, src != 0, max_tiles, num_cus); // one view: the single-view launch's grid
     const dim3 grid(blocks, m), block(kEvWaves * 64);
 #define ORBIT_EVAL_VIEWS(PASS)                                                                                        \
     if (src == 2) {                                                                                                   \

@@ -1,9 +1,9 @@
 // meshlet_lists.hip — the outputs of meshlet_cull that are not a MeshletDrawCommandBuffer, and the way back:
 //   task_records_kernel            per-record task payloads of the mesh-shading path (orbit_meshlet_task_cull)
-//   visible_records_*_kernel       the visible list compacted at record granularity (sharded engine)
 //   visible_expand_kernel,
 //   visible_records_expand_kernel  gathered lists -> commands on the receiving GPU (shaders/meshlet_cull.comp:216-230)
 //   scatter_list_kernel            a rank's list into every peer's buffer over xGMI (orbit_scatter_list)
+//   compact_segments_kernel        the segments of an ncclAllGather -> one contiguous list (orbit_allgather_list)
 #include "meshlet_common.h"
 
 namespace orbit {
@@ -97,93 +97,7 @@ __global__ __launch_bounds__(256) void visible_expand_kernel(const uint8_t *visi
     }
 }
 
-// ---------------------------------------------------------------------------
-// The visible list compacted at record granularity (sharded engine, orbit_meshlet_cull_visible_records): 12 B per
-// dispatch record that has a survivor — {entity_index, meshlet_offset, should-draw ballot of its (up to) 32 meshlets}
-// — in record order, behind an 8-B {records, survivors} header.  The same ordered list of (meshlet, entity) pairs as
-// the 8-B items (bit b of record r = item {meshlet_offset + b, entity_index}), in half the bytes at config 5 (3.2
-// survivors per surviving record): what travels over xGMI.  Built straight from the evaluation's per-record
-// ballots — no survivor scan, no emit: a count launch (block sums) and a write launch that adds up the sums of the
-// blocks before it.
-constexpr uint32_t kVrBlock = 1024; // records per block: 256 threads x 4
-
-__global__ __launch_bounds__(256) void visible_records_count_kernel(const MeshletCullParams p, uint32_t max_blocks) {
-    __shared__ uint32_t smem[8];
-    const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
-    if (blockIdx.x == 0 && threadIdx.x < kTicketPools) p.tickets[threadIdx.x * kTicketStride] = 0u; // next evaluation
-    const uint32_t r0 = blockIdx.x * kVrBlock + threadIdx.x * 4u;
-    uint32_t nz = 0, pop = 0;
-    if (blockIdx.x * kVrBlock < nrec) { // tile_masks is padded to whole tiles: the uint4 of a thread is always readable
-        const uint4 m = r0 < nrec ? *reinterpret_cast<const uint4 *>(p.tile_masks + r0) : make_uint4(0u, 0u, 0u, 0u);
-        const uint32_t w[4] = {m.x, m.y, m.z, m.w};
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-            const uint32_t v = r0 + k < nrec ? w[k] : 0u;
-            nz += v != 0u ? 1u : 0u;
-            pop += (uint32_t)__popc(v);
-        }
-    }
-    // (pop < 2^15 and nz < 2^11 per block: one reduction for both)
-    const uint32_t both = wave_reduce_add(nz << 16 | pop);
-    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = both;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t s = smem[0] + smem[1] + smem[2] + smem[3];
-        p.tile_base[blockIdx.x] = s >> 16;
-        p.tile_base[max_blocks + blockIdx.x] = s & 0xFFFFu;
-    }
-}
-
-__global__ __launch_bounds__(256) void visible_records_write_kernel(const MeshletCullParams p, uint32_t max_blocks) {
-    __shared__ uint32_t smem[8];
-    const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.dispatch_buffer), p.dispatch_capacity);
-    const uint32_t nblocks = (nrec + kVrBlock - 1u) / kVrBlock;
-    if (blockIdx.x >= nblocks && blockIdx.x != 0) return;
-    // records of the blocks before this one; block 0 adds up everything for the header
-    const uint32_t upto = blockIdx.x == 0 ? nblocks : blockIdx.x;
-    uint32_t part_nz = 0, part_pop = 0;
-    for (uint32_t i = threadIdx.x; i < upto; i += 256u) {
-        part_nz += p.tile_base[i];
-        if (blockIdx.x == 0) part_pop += p.tile_base[max_blocks + i];
-    }
-    part_nz = wave_reduce_add(part_nz);
-    part_pop = wave_reduce_add(part_pop);
-    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = part_nz, smem[4 + (threadIdx.x >> 6)] = part_pop;
-    __syncthreads();
-    const uint32_t sum_nz = smem[0] + smem[1] + smem[2] + smem[3], sum_pop = smem[4] + smem[5] + smem[6] + smem[7];
-    __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        uint32_t *hdr = reinterpret_cast<uint32_t *>(p.draw_buffer);
-        hdr[0] = min(sum_nz, p.draw_capacity);
-        hdr[1] = sum_pop;
-        *p.total = sum_nz;
-        if (sum_nz > p.draw_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
-    }
-    if (blockIdx.x >= nblocks) return;
-    const uint32_t base = blockIdx.x == 0 ? 0u : sum_nz;
-    const uint32_t r0 = blockIdx.x * kVrBlock + threadIdx.x * 4u;
-    const uint4 m = r0 < nrec ? *reinterpret_cast<const uint4 *>(p.tile_masks + r0) : make_uint4(0u, 0u, 0u, 0u);
-    const uint32_t w[4] = {m.x, m.y, m.z, m.w};
-    uint32_t mine = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 4; k++) mine += (r0 + k < nrec && w[k] != 0u) ? 1u : 0u;
-    uint32_t total;
-    uint32_t slot = base + block_exclusive_scan<4>(mine, smem, &total);
-    const uint4 *recs = reinterpret_cast<const uint4 *>(p.dispatch_buffer + ORBIT_DISPATCH_HEADER);
-    uint32_t *out = reinterpret_cast<uint32_t *>(p.draw_buffer + ORBIT_VISIBLE_HEADER);
-#pragma unroll
-    for (uint32_t k = 0; k < 4; k++) {
-        if (r0 + k < nrec && w[k] != 0u) {
-            if (slot < p.draw_capacity) {
-                const uint4 rec = recs[r0 + k];
-                out[3 * (size_t)slot + 0] = rec.x; // entity_index
-                out[3 * (size_t)slot + 1] = rec.y; // meshlet_offset
-                out[3 * (size_t)slot + 2] = w[k];
-            }
-            slot++;
-        }
-    }
-}
+constexpr uint32_t kVrBlock = 1024; // records per block of the record list's expansion: 256 threads x 4
 
 // Commands from a (gathered) record list, in list order = the canonical order: orbit_expand_visible_records.  A count
 // launch sums the survivors of every block of 1024 records; here a block adds up the blocks before it, a wave takes 64
@@ -346,6 +260,51 @@ __global__ __launch_bounds__(256) void scatter_list_kernel(const ScatterListPara
     }
 }
 
+// orbit_compact_segments — behind the all-gather of north_star, ncclAllGather of the ranks' lists as FIXED-CAPACITY
+// segments {count | header | segment_capacity items} (a collective of a fixed size needs no count on the host: no
+// read-back, no stream synchronisation, capturable): the segments' items, in rank order, become the one contiguous list
+// {total | header | items} that the p2p exchange delivers — byte for byte.  blockIdx.y = segment; every workgroup adds up
+// the counts of the segments before its own (a handful of words), then the plain dword copy of scatter_list_kernel.
+struct CompactSegmentsParams {
+    const uint8_t *segments;
+    uint8_t *out;
+    uint32_t world, segment_capacity, out_capacity, header_bytes, stride;
+    int32_t *status;
+};
+
+__global__ __launch_bounds__(256) void compact_segments_kernel(const CompactSegmentsParams p) {
+    const uint32_t seg = blockIdx.y;
+    const uint64_t seg_bytes = (uint64_t)p.header_bytes + (uint64_t)p.stride * p.segment_capacity;
+    uint32_t first = 0, total = 0, mine = 0;
+    for (uint32_t r = 0; r < p.world; r++) {
+        // a count beyond the segment's capacity is a sender's overflow (it latched its own error): cut here
+        const uint32_t c = min(*reinterpret_cast<const uint32_t *>(p.segments + seg_bytes * r), p.segment_capacity);
+        if (r < seg) first += c;
+        if (r == seg) mine = c;
+        total += c;
+    }
+    const uint32_t room = first < p.out_capacity ? p.out_capacity - first : 0u;
+    const uint64_t words = (uint64_t)min(mine, room) * p.stride / 4u;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(p.segments + seg_bytes * seg + p.header_bytes);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(p.out + p.header_bytes + (uint64_t)first * p.stride);
+    const uint64_t step = (uint64_t)gridDim.x * 256u * 4u;
+    for (uint64_t w = ((uint64_t)blockIdx.x * 256u + (threadIdx.x & ~63u)) * 4u + (threadIdx.x & 63u); w < words;
+         w += step) {
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = w + 64u * k < words ? src[w + 64u * k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (w + 64u * k < words) dst[w + 64u * k] = v[k];
+    }
+    if (seg == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        uint32_t *hdr = reinterpret_cast<uint32_t *>(p.out);
+        hdr[0] = min(total, p.out_capacity);
+        for (uint32_t k = 1; k < p.header_bytes / 4u; k++) hdr[k] = 0u;
+        if (total > p.out_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+    }
+}
+
 // Mesh-shading path: one OrbitMeshTaskRecord per dispatch record from the record's should-draw ballot
 // (forward_depth_prepass.task:225-228,255-257).  Thread = record; the drawn lanes in ascending order.
 __global__ __launch_bounds__(256) void task_records_kernel(const MeshletCullParams p) {
@@ -406,14 +365,14 @@ __device__ __forceinline__ void sys_store(unsigned long long *p, unsigned long l
 }
 
 __global__ __launch_bounds__(256) void exchange_scatter_kernel(const ExchangeListParams p) {
-    __shared__ uint32_t s_first, s_mine;
+    __shared__ uint32_t s_first, s_mine, s_timeout;
     ExchangeCtrl *mine_ctrl = reinterpret_cast<ExchangeCtrl *>(p.ctrl[p.rank]);
     const uint32_t dst_rank = blockIdx.y;
     const uint32_t e = __hip_atomic_load(&mine_ctrl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     const uint32_t mine = *reinterpret_cast<const uint32_t *>(p.local_list);
     if (blockIdx.x == 0 && threadIdx.x == 0) // this rank's count, to the destination this workgroup row serves
         sys_store(&reinterpret_cast<ExchangeCtrl *>(p.ctrl[dst_rank])->count[e & 1u][p.rank], (unsigned long long)e << 32 | mine);
-    if (threadIdx.x == 0) s_first = 0u, s_mine = mine;
+    if (threadIdx.x == 0) s_first = 0u, s_mine = mine, s_timeout = 0u;
     __syncthreads();
     // The counts of ALL ranks (their stores into THIS rank's block); those of the ranks before this one fix the offset.
     // Waiting for every rank's count is also what orders this exchange behind the peers' use of the previous one: a
@@ -425,6 +384,7 @@ __global__ __launch_bounds__(256) void exchange_scatter_kernel(const ExchangeLis
         for (uint32_t spins = 0; (uint32_t)(v >> 32) != e; spins++) {
             if (spins == kExchangeSpinLimit) {
                 latch_status(p.status, ORBIT_E_TIMEOUT);
+                s_timeout = 1u;
                 break;
             }
             __builtin_amdgcn_s_sleep(8);
@@ -435,7 +395,9 @@ __global__ __launch_bounds__(256) void exchange_scatter_kernel(const ExchangeLis
     __syncthreads();
     const uint32_t first = s_first;
     const uint32_t room = first < p.out_capacity ? p.out_capacity - first : 0u;
-    const uint32_t n_items = min(mine, room);
+    // a count that never came: the offset is made of a stale slot — nothing of this rank is copied anywhere (a list in
+    // the wrong place would corrupt the peers' otherwise valid lists); the epoch still advances, ranks stay in step
+    const uint32_t n_items = s_timeout != 0u ? 0u : min(mine, room);
     const uint64_t words = (uint64_t)n_items * p.stride / 4u;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(p.local_list + p.header_bytes);
     uint32_t *dst = reinterpret_cast<uint32_t *>(p.out[dst_rank] + p.header_bytes + (uint64_t)first * p.stride);
@@ -470,11 +432,13 @@ __global__ __launch_bounds__(64) void exchange_wait_kernel(const ExchangeListPar
     ExchangeCtrl *c = reinterpret_cast<ExchangeCtrl *>(p.ctrl[p.rank]);
     const uint32_t e = __hip_atomic_load(&c->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     uint32_t count = 0;
+    bool timed_out = false;
     if (threadIdx.x < p.world) {
         unsigned long long v = sys_load(&c->count[e & 1u][threadIdx.x]), d = sys_load(&c->done[threadIdx.x]);
         for (uint32_t spins = 0; (uint32_t)(v >> 32) != e || (uint32_t)d != e; spins++) {
             if (spins == kExchangeSpinLimit) {
                 latch_status(p.status, ORBIT_E_TIMEOUT);
+                timed_out = true;
                 break;
             }
             __builtin_amdgcn_s_sleep(8);
@@ -483,7 +447,9 @@ __global__ __launch_bounds__(64) void exchange_wait_kernel(const ExchangeListPar
         }
         count = (uint32_t)v;
     }
-    const uint32_t total = wave_reduce_add(count);
+    // a rank that never arrived: the list is incomplete or misplaced — consumers get an EMPTY list (and the latched
+    // ORBIT_E_TIMEOUT), never one with a hole in it
+    const uint32_t total = __ballot(timed_out) != 0ull ? 0u : wave_reduce_add(count);
     if (threadIdx.x == 0) {
         uint32_t *hdr = reinterpret_cast<uint32_t *>(p.out[p.rank]);
         hdr[0] = min(total, p.out_capacity);
@@ -517,11 +483,14 @@ hipError_t launch_task_records(const MeshletCullParams &p, hipStream_t s) {
     return hipGetLastError();
 }
 
-// the visible list at record granularity: straight from the per-record ballots
-hipError_t launch_visible_records(const MeshletCullParams &p, hipStream_t s) {
-    const uint32_t vblocks = max((p.dispatch_capacity + kVrBlock - 1u) / kVrBlock, 1u);
-    hipLaunchKernelGGL(visible_records_count_kernel, dim3(vblocks), dim3(256), 0, s, p, vblocks);
-    hipLaunchKernelGGL(visible_records_write_kernel, dim3(vblocks), dim3(256), 0, s, p, vblocks);
+hipError_t launch_compact_segments(const uint8_t *segments, uint32_t world, uint32_t segment_capacity, uint8_t *out,
+                                   uint32_t out_capacity, uint32_t header_bytes, uint32_t stride, uint32_t num_cus,
+                                   int32_t *status, hipStream_t s) {
+    CompactSegmentsParams p{segments, out, world, segment_capacity, out_capacity, header_bytes, stride, status};
+    // a workgroup per 32 KB of a segment, the device's worth at most
+    const uint64_t want = ((uint64_t)segment_capacity * stride + 32767u) / 32768u;
+    const uint32_t per_seg = (uint32_t)max((uint64_t)1, min(want, (uint64_t)max(num_cus * 4u / max(world, 1u), 8u)));
+    hipLaunchKernelGGL(compact_segments_kernel, dim3(per_seg, world), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

@@ -120,12 +120,20 @@ class P2PExchange:
     peers' control blocks, awaited on the device (orbit_exchange_list): a step is kernels only, nothing in it is issued
     through torch.distributed, and it can be captured into a graph.  "collectives": the form above.
 
+    The device-signalled form polls words that a PEER DEVICE stores while the polling kernel runs.  Whether that works
+    between the devices of a node is a property of the node, so the constructor proves it before anyone relies on it:
+    with `probe_on_init` (the default) a known exchange is run and compared on every rank (`probe`), and if it fails on
+    any rank ALL ranks move to the collectives form together — `signalling` says which form the object ended up with and
+    `fallback` why.  A library user who constructs the object directly therefore never gets an unproven path.
+
     `transport` (tests): an object with the same `alloc / open / scatter` surface; the default drives the HIP library.
     """
 
     CTRL_BYTES = 1024  # ORBIT_P2P_CTRL_BYTES
 
-    def __init__(self, engine, item_capacity, header, stride, device, group=None, transport=None, signalling="device"):
+    def __init__(self, engine, item_capacity, header, stride, device, group=None, transport=None, signalling="device",
+                 probe_on_init=True):
+        self.fallback = None
         self.signalling = signalling if (transport is None or hasattr(transport, "exchange")) else "collectives"
         self.group, self.header, self.stride, self.capacity = group, header, stride, int(item_capacity)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
@@ -166,6 +174,17 @@ class P2PExchange:
         self.counts = torch.zeros(self.world, dtype=torch.int32, device=device)
         self.token = torch.zeros(1, dtype=torch.int32, device=device)
         dist.barrier(group=group)  # every peer has mapped every buffer before the first scatter
+        if self.signalling == "device" and probe_on_init:
+            status = engine.status if engine is not None else None
+            if not self.probe(check_status=status):  # agreed on by all ranks inside probe()
+                self.signalling = "collectives"
+                self.fallback = "device signalling -> collectives: the probe exchange failed on at least one rank"
+                if status is not None:
+                    try:
+                        status()  # clear what the failed probe latched (a poll that ran out)
+                    except Exception:  # noqa: BLE001
+                        pass
+                dist.barrier(group=group)
 
     def _agree(self, err, what):
         ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=self.device)
@@ -220,6 +239,76 @@ class P2PExchange:
 
     def close(self):
         self.t.close()
+
+
+class AllGatherExchange:
+    """north_star's transport: the rank-ordered all-gather of the ranks' lists as ONE RCCL all-gather — of a FIXED size,
+    so that nothing about it needs the host: every rank contributes its whole list buffer as a segment
+    {count | header | segment_capacity items} (torch.distributed.all_gather_into_tensor = ncclAllGather on ROCm), and one
+    launch (orbit_compact_segments) reads the counts on the device and compacts the segments into the contiguous list
+    {total | header | items} that P2PExchange delivers, byte for byte.  No count read-back, no stream synchronisation,
+    capturable.  What the fixed size costs is the segments' slack on the links; the record list (one entry per dispatch
+    record of the shard) has next to none.  Same surface as P2PExchange (`exchange`, `out`, `probe`, `close`); it is
+    what bench.py's `--transport rccl` runs and what the p2p transport falls back to.
+
+    `compact` (tests): a callable with orbit_compact_segments' arguments; the default drives the HIP library."""
+
+    signalling = "rccl-allgather"
+
+    def __init__(self, engine, segment_capacity, item_capacity, header, stride, device, group=None, compact=None):
+        self.group, self.header, self.stride = group, header, stride
+        self.segment_capacity, self.capacity = int(segment_capacity), int(item_capacity)
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device = device
+        self.seg_bytes = header + stride * self.segment_capacity
+        self.segments = torch.zeros(self.world * self.seg_bytes, dtype=torch.uint8, device=device)
+        self.out = torch.zeros(header + stride * self.capacity, dtype=torch.uint8, device=device)
+        self.compact = compact if compact is not None else (
+            lambda seg, world, cap, out, out_cap, hdr, st, stream: engine.compact_segments(seg, world, cap, out, out_cap,
+                                                                                           hdr, st, stream=stream))
+
+    def exchange(self, local_list, stream=None):
+        """Enqueues one exchange of `local_list` ({count | header | items}, a buffer of at least one segment's bytes);
+        afterwards (in stream order) `self.out` holds {total | header | all ranks' items in rank order}."""
+        if local_list.numel() < self.seg_bytes:
+            raise ValueError(f"AllGatherExchange: the list buffer holds {local_list.numel()} B, a segment is {self.seg_bytes} B")
+        # issued in the caller's stream context: ProcessGroupNCCL orders the collective behind the current stream and the
+        # current stream behind the collective, all on the device
+        dist.all_gather_into_tensor(self.segments, local_list[:self.seg_bytes], group=self.group)
+        self.compact(self.segments, self.world, self.segment_capacity, self.out, self.capacity, self.header, self.stride,
+                     stream)
+        return self.out
+
+    def probe(self, check_status=None):
+        """As P2PExchange.probe: rank r sends r + 1 known items; True on every rank only if every rank received all
+        ranks' items in rank order."""
+        n = self.rank + 1
+        if self.segment_capacity < self.world or self.capacity < self.world * (self.world + 1) // 2:
+            return True
+        local = torch.zeros(self.seg_bytes, dtype=torch.uint8, device=self.device)
+        local[:4].view(torch.int32)[0] = n
+        local[self.header:self.header + self.stride * n] = n
+        ok = 1
+        try:
+            self.exchange(local, stream=None)
+            if torch.device(self.device).type == "cuda":
+                torch.cuda.synchronize(self.device)
+            if check_status is not None:
+                check_status()
+            total = self.world * (self.world + 1) // 2
+            got = self.out[:self.header + self.stride * total].clone()
+            want = torch.cat([torch.full((self.stride * (r + 1),), r + 1, dtype=torch.uint8, device=self.device)
+                              for r in range(self.world)])
+            if int(got[:4].view(torch.int32)[0]) != total or not torch.equal(got[self.header:], want):
+                ok = 0
+        except Exception:  # noqa: BLE001 - the verdict is agreed on below
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return int(flag.item()) == 1
+
+    def close(self):
+        pass
 
 
 class _HipTransport:

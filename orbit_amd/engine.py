@@ -283,7 +283,7 @@ class Engine:
     def meshlet_cull_visible_records(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, record_buffer,
                                      entity_buffer, material_buffer, dispatch_capacity, record_capacity, **kw):
         """orbit_meshlet_cull_visible_records: {records, survivors} + 12-B {entity_index, meshlet_offset, mask} per
-        dispatch record with a survivor, in record order."""
+        dispatch record, in record order (mask 0: no survivor), written by the evaluation launch itself."""
         self.meshlet_cull(cull_info, meshlet_dispatch_buffer, meshlet_buffer, None, entity_buffer, material_buffer,
                           dispatch_capacity, record_capacity, record_buffer=record_buffer, **kw)
 
@@ -294,6 +294,39 @@ class Engine:
         self.meshlet_cull(cull_info, meshlet_dispatch_buffer, meshlet_buffer, draw_commands_buffer, entity_buffer,
                           material_buffer, dispatch_capacity, draw_capacity, record_buffer=record_buffer,
                           record_capacity=record_capacity, **kw)
+
+    def cull_shard(self, cull_info, entity_draw_buffer, mesh_info_buffer, meshlet_dispatch_buffer, entity_buffer,
+                   draw_first, draw_count, dispatch_capacity, meshlet_buffer, material_buffer, record_buffer,
+                   record_capacity, draw_commands_buffer=None, draw_capacity=0, material_count=0,
+                   visibility_buffer=None, meshlet_visibility_buffer=None, depth_pyramid=None,
+                   depth_pyramid_size=(0, 0), stream=None):
+        """orbit_cull_shard: a rank's whole cull — entity range, meshlet stage, record list (and, with
+        draw_commands_buffer, the rank's own 28-B commands) — as one call; one launch (+ the emit) for pass 0 and up to
+        65 536 entity-draws."""
+        ci = _host_bytes(cull_info, 400)
+        e, m = _lib.EntityCullBufs(), _lib.MeshletCullBufs()
+        e.entity_draw_buffer = _ptr(entity_draw_buffer)
+        e.mesh_info_buffer = _ptr(mesh_info_buffer)
+        e.meshlet_dispatch_buffer = m.meshlet_dispatch_buffer = _ptr(meshlet_dispatch_buffer)
+        e.entity_buffer = m.entity_buffer = _ptr(entity_buffer)
+        e.visibility_buffer = _ptr(visibility_buffer)
+        e.depth_pyramid = m.depth_pyramid = _ptr(depth_pyramid)
+        e.depth_pyramid_size[0], e.depth_pyramid_size[1] = depth_pyramid_size
+        m.depth_pyramid_size[0], m.depth_pyramid_size[1] = depth_pyramid_size
+        e.dispatch_capacity = m.dispatch_capacity = dispatch_capacity
+        m.meshlet_buffer = _ptr(meshlet_buffer)
+        m.draw_commands_buffer = _ptr(draw_commands_buffer)
+        m.material_buffer = _ptr(material_buffer)
+        m.meshlet_visibility_buffer = _ptr(meshlet_visibility_buffer)
+        m.draw_capacity = draw_capacity
+        m.material_count = material_count
+        _lib.check(self._lib.orbit_cull_shard(self._ctx, ci.ctypes.data_as(C.c_void_p), C.byref(e), draw_first, draw_count,
+                                              C.byref(m), _ptr(record_buffer), record_capacity,
+                                              1 if draw_commands_buffer is not None else 0, _stream(stream)), self._ctx)
+
+    def shard_culls(self):
+        """orbit_ctx_shard_culls: orbit_cull_shard calls of this context that took the one launch."""
+        return int(self._lib.orbit_ctx_shard_culls(self._ctx))
 
     def expand_visible_records(self, record_buffer, meshlet_buffer, draw_commands_buffer, draw_capacity, stream=None):
         """orbit_expand_visible_records: record list -> MeshletDrawCommandBuffer, in list order."""
@@ -365,6 +398,22 @@ class Engine:
         ctrls = (C.c_void_p * world)(*[_ptr(b) for b in ctrl_buffers])
         _lib.check(self._lib.orbit_exchange_list(self._ctx, _ptr(local_list), rank, world, outs, ctrls, out_capacity,
                                                  header_bytes, stride, _stream(stream)), self._ctx)
+
+    def allgather_list(self, nccl_comm, rank, world, local_list, segment_capacity, segments, out_list, out_capacity,
+                       header_bytes, stride, stream=None):
+        """orbit_allgather_list: ONE ncclAllGather of the ranks' fixed-capacity list segments + the compaction launch; no
+        count is read back, no stream is synchronised (`nccl_comm`: the ncclComm_t as an integer / c_void_p)."""
+        comm = nccl_comm if isinstance(nccl_comm, C.c_void_p) else C.c_void_p(int(nccl_comm))
+        _lib.check(self._lib.orbit_allgather_list(self._ctx, comm, rank, world, _ptr(local_list), segment_capacity,
+                                                  _ptr(segments), _ptr(out_list), out_capacity, header_bytes, stride,
+                                                  _stream(stream)), self._ctx)
+
+    def compact_segments(self, segments, world, segment_capacity, out_list, out_capacity, header_bytes, stride,
+                         stream=None):
+        """orbit_compact_segments: `world` gathered segments {count | header | segment_capacity items} -> the contiguous
+        rank-ordered list {total | header | items}."""
+        _lib.check(self._lib.orbit_compact_segments(self._ctx, _ptr(segments), world, segment_capacity, _ptr(out_list),
+                                                    out_capacity, header_bytes, stride, _stream(stream)), self._ctx)
 
     def gather_visible_meshlets(self, nccl_comm, rank, world, local_visible_buffer, out_visible_buffer, out_capacity,
                                 stream=None):

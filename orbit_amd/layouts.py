@@ -56,7 +56,7 @@ MESHLET_DISPATCH = np.dtype([("entity_index", "<u4"), ("meshlet_offset", "<u4"),
 # types.glsl:180-189, src/assets/mod.rs:98-109
 VISIBLE_HEADER = 8  # {u32 count; u32 0}
 VISIBLE_MESHLET = np.dtype([("meshlet_index", "<u4"), ("entity_index", "<u4")])  # include/orbit_abi.h (sharded engine)
-# the same list at record granularity: {u32 records; u32 survivors} header, 12 B per dispatch record with a survivor
+# the same list at record granularity: {u32 records; u32 survivors} header, 12 B per dispatch record
 VISIBLE_RECORD = np.dtype([("entity_index", "<u4"), ("meshlet_offset", "<u4"), ("mask", "<u4")])
 MESH_TASK_RECORD = np.dtype([("task_mesh_count", "<u4"), ("entity_index", "<u4"), ("meshlet_offset", "<u4"),
                              ("meshlet_indices", "u1", (32,))])  # EmitMeshTasksEXT count + types.glsl:196-200

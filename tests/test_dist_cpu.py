@@ -145,7 +145,7 @@ class _ShmTransport:
 
 
 def _visible_records(disp, cmds):
-    """{records, survivors} + 12-B {entity_index, meshlet_offset, mask} of the dispatch records that have a survivor:
+    """{records, survivors} + 12-B {entity_index, meshlet_offset, mask} of every dispatch record (mask 0: no survivor):
     what orbit_meshlet_cull_visible_records makes of the same cull (the commands come in (record, lane) order)."""
     _, recs = L.dispatch_buffer_records(disp)
     out, j = [], 0
@@ -155,8 +155,7 @@ def _visible_records(disp, cmds):
         while j < len(cmds) and int(cmds["cmd_first_instance"][j]) == ent and off <= int(cmds["meshlet_index"][j]) < off + cnt:
             mask |= 1 << (int(cmds["meshlet_index"][j]) - off)
             j += 1
-        if mask:
-            out.append((ent, off, mask))
+        out.append((ent, off, mask))
     assert j == len(cmds)
     arr = np.array(out, dtype=L.VISIBLE_RECORD) if out else np.zeros(0, dtype=L.VISIBLE_RECORD)
     buf = np.zeros(L.VISIBLE_HEADER + 12 * max(len(arr), 1), dtype=np.uint8)
@@ -165,11 +164,26 @@ def _visible_records(disp, cmds):
     return buf
 
 
+def _compact_segments_numpy(segments, world, segment_capacity, out, out_capacity, header, stride, stream=None):
+    """orbit_compact_segments restated with numpy (meshlet_lists.hip compact_segments_kernel): the segments' items in
+    rank order behind {total, 0 ..}; a count beyond the segment's capacity is cut, nothing is written past out_capacity."""
+    seg_bytes = header + stride * segment_capacity
+    counts = [min(int(segments[seg_bytes * r:seg_bytes * r + 4].view(torch.int32)[0]), segment_capacity) for r in range(world)]
+    first = 0
+    for r in range(world):
+        n = min(counts[r], max(out_capacity - first, 0))
+        out[header + stride * first:header + stride * (first + n)] = \
+            segments[seg_bytes * r + header:seg_bytes * r + header + stride * n]
+        first += counts[r]
+    out[:header] = 0
+    out[:4].view(torch.int32)[0] = min(sum(counts), out_capacity)
+
+
 def _p2p_worker(rank, world, port, seed, n_entities, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle
-    from orbit_amd.dist import P2PExchange
+    from orbit_amd.dist import AllGatherExchange, P2PExchange
 
     scene = sc.make_scene(seed, n_entities, n_meshes=40)
     cam = sc.default_camera()
@@ -185,7 +199,7 @@ def _p2p_worker(rank, world, port, seed, n_entities, out_dir):
     vis[:4].view(np.uint32)[0] = n
     v = vis[8:8 + 8 * n].view(L.VISIBLE_MESHLET)
     v["meshlet_index"], v["entity_index"] = cmds["meshlet_index"], cmds["cmd_first_instance"]
-    rec = _visible_records(disp, cmds)  # the same list at record granularity (12 B per record with a survivor)
+    rec = _visible_records(disp, cmds)  # the same list at record granularity (12 B per dispatch record)
     capacity = scene.lod0_meshlets + 8
     # the self-check a launcher runs before it relies on an exchange (bench.py): a known list per rank, compared
     pr = P2PExchange(None, 64, L.VISIBLE_HEADER, 12, torch.device("cpu"), transport=_ShmTransport(f"probe{rank}"))
@@ -201,6 +215,20 @@ def _p2p_worker(rank, world, port, seed, n_entities, out_dir):
         np.save(os.path.join(out_dir, f"p2p_{name}_{rank}.npy"), out.numpy().copy())
         dist.barrier()
         ex.close()
+    # north_star's transport: the record list as ONE all-gather of fixed-capacity segments + the compaction — the same
+    # capacity on every rank (the largest shard's records), this rank's list in a buffer of a whole segment
+    seg_cap = max(e_ - b_ for b_, e_ in shard_ranges(scene.entity_draw_count, world)) * 3 + 8
+    n_rec = int(rec[:4].view(np.uint32)[0])
+    assert n_rec <= seg_cap
+    local = np.full(L.VISIBLE_HEADER + 12 * seg_cap, 0x33, dtype=np.uint8)  # the slack behind the list travels too
+    local[:8 + 12 * n_rec] = rec[:8 + 12 * n_rec]
+    ag = AllGatherExchange(None, seg_cap, capacity, L.VISIBLE_HEADER, 12, torch.device("cpu"), compact=_compact_segments_numpy)
+    assert ag.probe()
+    ag.out[:] = 0x55
+    for step in range(2):
+        out = ag.exchange(torch.from_numpy(local.copy()))
+        dist.barrier()
+    np.save(os.path.join(out_dir, f"allgather_rec_{rank}.npy"), out.numpy().copy())
     dist.destroy_process_group()
 
 
@@ -236,3 +264,7 @@ def test_p2p_exchange_protocol_gloo(tmp_path, oracle, world, n_entities):
         nr = int(want[:4].view(np.uint32)[0])
         assert int(gr[:4].view(np.uint32)[0]) == nr and np.array_equal(gr[8:8 + 12 * nr], want[8:8 + 12 * nr])
         assert np.all(gr[8 + 12 * nr:] == 0x55)
+        # ... and the same list through the all-gather of fixed-capacity segments: what the p2p exchange delivered, byte
+        # for byte (header included), and nothing written behind it
+        ga = np.load(tmp_path / f"allgather_rec_{r}.npy")
+        assert np.array_equal(ga[:8 + 12 * nr], gr[:8 + 12 * nr]) and np.all(ga[8 + 12 * nr:] == 0x55)
