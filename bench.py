@@ -70,11 +70,24 @@ def parse():
                     help="N>1, transport p2p: how counts and completion of an exchange travel — device (default: stores "
                          "into the peers' control blocks awaited on the device, orbit_exchange_list: no collective and "
                          "no host call in a step) or collectives (two fixed-size torch.distributed collectives per step)")
+    ap.add_argument("--graph", action="store_true",
+                    help="N>1 (transport p2p with device signalling, --expand own / none, one frame slot): replay every "
+                         "timed step as a captured HIP graph — cull on the slot's stream, the exchange of the previous "
+                         "step's list beside it on the exchange stream, fork and join inside the capture — instead of "
+                         "enqueueing its launches from Python.  The host then spends 0.03 ms per step instead of 0.045 and "
+                         "wall / K stays within 4 %% of the median step interval (eager: 12 %%), but consecutive graph "
+                         "launches leave a gap of their own on this runtime: a 1/8 shard's step 0.084 ms against 0.079 "
+                         "eager (profiles/r05_notes.md) — so it is an option, not the default")
     ap.add_argument("--two-calls", action="store_true",
                     help="N>1, exchange records: the rank's cull as orbit_entity_cull_range + orbit_meshlet_cull_visible_records "
                          "(_records_and_commands) instead of ONE orbit_cull_shard call (for A/B: the same outputs)")
-    ap.add_argument("--frames-in-flight", type=int, default=1,
-                    help="frame slots (OrbitCtx + stream + buffers each) the steps go round-robin over; 1 = strictly serial")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frame slots (OrbitCtx + stream + buffers each) the steps go round-robin over; 1 = strictly serial "
+                         "frames.  0 (default) = 1 at N = 1 (step time = frame latency, a launch's HIP-event duration is "
+                         "the kernel's own) and 2 at N > 1, the renderer's FRAME_COUNT (context.rs:1275-1316): a shard's "
+                         "cull is a chain of dependent round trips — its entity stage alone is 15-19 us of a 60-us launch "
+                         "at a 1/8 shard — which only another frame's work can fill: 0.076 -> 0.049 ms per step there "
+                         "(--expand all: 1)")
     ap.add_argument("--time-every", type=int, default=3,
                     help="the dominant kernel of every n-th launch per frame slot is timed with HIP events")
     ap.add_argument("--meshlet-source", choices=("stream", "buffer"), default="stream",
@@ -251,7 +264,9 @@ def main():
     # part of their run and the HIP-event duration of a launch is no longer that kernel's own time.  The default is
     # ONE slot: strictly serial frames, step time = frame latency, clean per-kernel durations.
     # N > 1: the exchange of step i runs on its own stream while step i+1 culls into the slot's other list buffer.
-    F = max(1, args.frames_in_flight)
+    # (--expand all keeps one slot: its expansion stream is the fifth stream of the process, one more than the runtime has
+    # hardware queues for, and the host then blocks in the enqueue calls: 0.13 ms per step at a 1/8 shard)
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (2 if (use_dist and args.expand != "all") else 1)
     hdr, item = (L.VISIBLE_HEADER, 12) if records_exchange else (L.VISIBLE_HEADER, 8) if visible_exchange else (L.DRAW_HEADER, 28)
     list_cap = disp_cap if records_exchange else draw_cap  # entries a rank's list can hold (records / survivors)
     # the record list as a fixed-capacity segment of an RCCL all-gather (--transport rccl): the same capacity on every rank
@@ -349,13 +364,15 @@ def main():
         x_count[0] += 1
         with torch.cuda.stream(xstream):
             xstream.wait_event(s.cull_done[k])
-            xstream.wait_event(e_events[j])  # the expansion that read this receive buffer two exchanges ago
+            if do_expand:
+                xstream.wait_event(e_events[j])  # the expansion that read this receive buffer two exchanges ago
             if exchanges:  # p2p (device-signalled or with two collectives) or the RCCL all-gather: nothing waits for the host
                 exchanges[j].exchange(s.lists[k], stream=xstream)
             else:
                 odist.gather_visible(s.lists[k], recv_bufs[j], header=hdr, stride=item)
             s.xdone[k].record(xstream)  # the list buffer may be overwritten
-            x_events[j].record(xstream)
+            if do_expand:
+                x_events[j].record(xstream)
         if do_expand:
             with torch.cuda.stream(estream):
                 estream.wait_event(x_events[j])
@@ -368,14 +385,20 @@ def main():
 
     step_no = [0]
 
+    shard_calls = {}  # (slot, list index) -> the prepared orbit_cull_shard call (argument blocks built once)
+
     def cull(s, k):
         if records_exchange and not args.two_calls:
             # a rank's whole cull as ONE call (orbit_cull_shard) and, up to 65 536 entity-draws, ONE launch: entity test,
             # record append, meshlet test and the record list the rank sends — plus, with --expand own, the emit launch for
             # the 28-B commands of its own shard (its indirect-draw buffer, "each rank issues its own draws": SURVEY §8e)
-            s.eng.cull_shard(ci, draws, mesh, s.disp, ent, b, n_local_entities, disp_cap, meshlets_base, materials,
-                             s.lists[k], list_cap, draw_commands_buffer=s.own_cmds if own_expand else None,
-                             draw_capacity=draw_cap if own_expand else 0, material_count=spec.materials, stream=s.stream)
+            call = shard_calls.get((id(s), k))
+            if call is None:
+                call = shard_calls[(id(s), k)] = s.eng.prepare_cull_shard(
+                    ci, draws, mesh, s.disp, ent, b, n_local_entities, disp_cap, meshlets_base, materials, s.lists[k], list_cap,
+                    draw_commands_buffer=s.own_cmds if own_expand else None, draw_capacity=draw_cap if own_expand else 0,
+                    material_count=spec.materials, stream=s.stream)
+            call()
             return
         s.eng.entity_cull(ci, draws, mesh, s.disp, ent, n_local_entities, disp_cap, draw_first=b, stream=s.stream)
         if own_expand:
@@ -395,6 +418,10 @@ def main():
                                material_count=spec.materials, stream=s.stream)
 
     step_marks = []  # N > 1: one timing event per step of the timed region, behind that step's exchange
+    mark_ring = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 2)] if do_gather else []  # created (and
+    # recorded once, below) before the region: creating an event per step inside it is host work in the step
+    for ev in mark_ring:
+        ev.record()
 
     def step(i=None):
         s = slots[step_no[0] % F]
@@ -409,7 +436,7 @@ def main():
             if pending:
                 gather(*pending.pop())  # previous step's list travels while this step's cull runs
                 if i is not None:
-                    ev = torch.cuda.Event(enable_timing=True)
+                    ev = mark_ring[len(step_marks)]
                     ev.record(xstream)
                     step_marks.append(ev)
             pending.append((s, k))
@@ -509,22 +536,59 @@ def main():
     # every pair the timed region will record is used once before it, on the same streams: ceil(K / time_every) + 1
     # untimed steps with every launch timed (part of the warm-up: counted in warmup_effective).
     prewarm = -(-args.steps // max(args.time_every, 1)) + 1
-    for s in slots:
-        s.eng.profile(True, every=1)
-    for _ in range(prewarm * F):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    frames_before_timed += prewarm * F
-    for s in slots:
-        s.eng.profile(True, every=args.time_every)
+    # N > 1: the step as a captured graph (--graph).  Two graphs, because consecutive steps alternate between the
+    # slot's two list buffers and the two exchange buffers: graph k = { cull into list k  ||  exchange of list 1 - k, the
+    # previous step's } — fork and join inside the capture, so that a replay is the steady-state step: K replays are K
+    # culls and K exchanges, each exchange beside the cull of the step after it.
+    use_graph = bool(do_gather and args.graph and F == 1 and not do_expand and exchanges
+                     and all(getattr(x, "signalling", None) == "device" for x in exchanges))
+    graphs = []
+    if use_graph:
+        s0g = slots[0]
+        torch.cuda.synchronize()
+        for k in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(s0g.stream):
+                with torch.cuda.graph(g, stream=s0g.stream):
+                    xstream.wait_stream(s0g.stream)
+                    cull(s0g, k)
+                    with torch.cuda.stream(xstream):
+                        exchanges[1 - k].exchange(s0g.lists[1 - k], stream=xstream)
+                    s0g.stream.wait_stream(xstream)
+            graphs.append(g)
+        if use_dist:
+            dist.barrier()  # every rank has captured (capture enqueues nothing)
+        for i in range(2 * prewarm):  # the replays' own warm-up
+            with torch.cuda.stream(s0g.stream):
+                graphs[i % 2].replay()
+        torch.cuda.synchronize()
+        frames_before_timed += 2 * prewarm
+    else:
+        for s in slots:
+            s.eng.profile(True, every=1)
+        for _ in range(prewarm * F):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        frames_before_timed += prewarm * F
+        for s in slots:
+            s.eng.profile(True, every=args.time_every)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    drain()  # every one of the K lists has been produced (and, N > 1, exchanged) inside the timed region
+    if use_graph:
+        with torch.cuda.stream(s0g.stream):
+            for i in range(args.steps):
+                graphs[i % 2].replay()
+                mark_ring[i].record(s0g.stream)
+                step_marks.append(mark_ring[i])
+        t_enqueued = time.perf_counter()
+    else:
+        for i in range(args.steps):
+            step(i)
+        t_enqueued = time.perf_counter()
+        drain()  # every one of the K lists has been produced (and, N > 1, exchanged) inside the timed region
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -544,6 +608,23 @@ def main():
                           "what": "time between the completions of consecutive steps' exchanges inside the timed region"}
     if mstream is not None and not args.no_alpha_classes:
         assert all(s.eng.meshlet_class_culls() >= args.steps // F for s in slots), "the alpha classes were not used"
+    host_enqueue_ms_per_step = (t_enqueued - t0) / args.steps * 1e3  # what the host spent handing the K steps over
+    if use_graph:  # the dominant kernel's launches, timed by the library in eager steps behind the region (an event pair
+        # recorded inside a captured graph cannot be read)
+        for s in slots:
+            s.eng.status()
+            s.eng.profile(True, every=1)
+        for _ in range(3):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        for s in slots:
+            s.eng.profile_read()
+            s.eng.profile(True, every=1)
+        for _ in range(max(8, args.steps // 2)):
+            step()
+        drain()
+        torch.cuda.synchronize()
     eval_sum, eval_launches = 0.0, 0
     for s in slots:
         s.eng.status()
@@ -799,6 +880,8 @@ def main():
                                  if compact_exchange else "the all-gathered 28-B command list on every GPU"),
                 "signalling": (exchanges[0].signalling if exchanges else None),
                 "step_intervals": step_intervals,
+                "steps_as_graph": (use_graph if do_gather else None),
+                "host_enqueue_ms_per_step": host_enqueue_ms_per_step,
                 "list_bytes_per_rank_max": (int(max(c[0].item() for c in counts)) * item if do_gather else None),
                 "exchange": (args.exchange if do_gather else None), "transport": transport,
                 "transport_requested": (args.transport if do_gather else None), "transport_fallback": transport_fallback,

@@ -219,6 +219,20 @@ __device__ __forceinline__ bool row_is_affine(const WaveTileLds &L, int r) {
 __device__ __forceinline__ Payload make_payload(uint32_t ml, uint32_t rid, const uint4 &b) {
     return Payload{b.y, b.z, (b.w & 0xFFFF0000u) | (ml << 4) | rid};
 }
+// Cache policy of the payload stores (A/B builds: tools/ab_strict.py; 0 = plain stores, the product; 2 = nt, 16 = sc1)
+#ifndef ORBIT_PAYLOAD_STORE_AUX
+#define ORBIT_PAYLOAD_STORE_AUX 0
+#endif
+__device__ __forceinline__ void store_payload(Payload *tile_payload, uint32_t rank, const Payload &v) {
+#if ORBIT_PAYLOAD_STORE_AUX == 0
+    tile_payload[rank] = v;
+#else
+    typedef unsigned int v3u __attribute__((ext_vector_type(3)));
+    const __amdgpu_buffer_rsrc_t R = __builtin_amdgcn_make_buffer_rsrc(tile_payload, 0, kPayloadCap * 12u, kBufFlags);
+    const v3u w = {v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b96(w, R, rank * 12u, 0, ORBIT_PAYLOAD_STORE_AUX);
+#endif
+}
 
 // One meshlet (one lane): meshlet_cull.comp:113-213.  PASS = cull_info.occlusion_pass
 // and PROJ = cull_info.projection_type are compile-time (PROJ < 0: read at run time).
@@ -398,7 +412,10 @@ __device__ __forceinline__ uint32_t rows_eval(const MeshletCullParams &p, WaveTi
             // survivor payload at the tile-local rank: everything the command needs except its
             // slot, so the emit launch reads one contiguous run per tile and rebuilds nothing
             const uint32_t rank = total + lane_prefix(mask);
-            if (rank < CAP) payload[rank] = make_payload(ml, rid, t.b[k]);
+            if (rank < CAP) {
+                if constexpr (CAP == kPayloadCap) store_payload(payload, rank, make_payload(ml, rid, t.b[k]));
+                else payload[rank] = make_payload(ml, rid, t.b[k]); // (the one-launch cull's LDS payload)
+            }
         }
         total += (uint32_t)__popcll(mask);
     }

@@ -104,6 +104,10 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p, co
     __shared__ AlphaLds alpha_tab;
     __shared__ CandLds<(PASS == 2 ? kCandRing : 1u)> cand_ring[kEvWaves]; // pass 2 only
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef ORBIT_TRIAGE
+    const unsigned long long wall_enter = wall_clock64(); // (ORBIT_SP_DEBUG & 2048: the wave's begin stamp is this one)
+    unsigned long long wall_chunks = 0;
+#endif
     // pass 2 with meshlet occlusion: HiZ tests run on compacted candidates (cand_flush), not per row
     const bool occ2 = PASS == 2 && p.ci.meshlet_visibility_buffer != ORBIT_NONE;
     __shared__ uint32_t cls_sel[CLS ? 8 : 1]; // [2 c + k] = all ones if alpha class c has predicate bit k (alpha_bits)
@@ -151,6 +155,9 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p, co
         };
         // the first workgroups take the chunks (tickets: whichever of them run); everybody else goes to wait
         if (blockIdx.x < f.ne_chunks) entity_chunks(E, a, ent_lds, tell_all);
+#ifdef ORBIT_TRIAGE
+        wall_chunks = wall_clock64(); // (ORBIT_SP_DEBUG & 4096: the wave's begin stamp is "its workgroup's chunks are done")
+#endif
         const uint32_t my_copy = (blockIdx.x % kShardDoneWords) * kShardDoneStride * 4u;
         for (uint32_t round = 0;; round++) {
             if (threadIdx.x == 0) {
@@ -285,7 +292,7 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p, co
         t0 = t1;                               \
     }
     unsigned long long wall_begin = 0;
-    if (p.debug_flags & 16u) wall_begin = wall_clock64(); // per-wave life stamps (tools/wave_tail.py)
+    if (p.debug_flags & 16u) wall_begin = (p.debug_flags & 2048u) ? wall_enter : (p.debug_flags & 4096u) ? wall_chunks : wall_clock64(); // per-wave life stamps (tools/wave_tail.py)
     if (PROF) {
         t0 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_waitcnt(0xC07F);

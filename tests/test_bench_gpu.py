@@ -104,12 +104,32 @@ def test_bench_two_ranks_on_one_device_at_full_size():
 
 
 def test_bench_rccl_transport_with_a_world_of_one():
-    """The RCCL send/recv transport (counts to the host, grouped send/recv) through a real communicator — of one rank,
-    all this box can hold."""
+    """The RCCL transport through a real communicator — of one rank, all this box can hold: the record list as ONE
+    all-gather of fixed-capacity segments + the device-side compaction (north_star's transport, nothing waits for the
+    host), and the 8-B item list as grouped send/recv with the counts read on the host."""
     d = _run_ranks(["--gpus", "1", "--transport", "rccl", "--cpu-sample-entities", "0"], dict(ORBIT_BENCH_FORCE_DIST="1"))
     c = d["config"]
     assert c["gather"] is True and c["transport"] == "rccl" and c["world_size"] == 1 and c["backend"] == "nccl"
+    assert c["signalling"] == "rccl-allgather" and "all-gather of fixed-capacity" in c["workload"]
     assert d["per_rank"]["exchange_ms"][0] > 0
+    d = _run_ranks(["--gpus", "1", "--transport", "rccl", "--exchange", "visible", "--expand", "all", "--cpu-sample-entities", "0"],
+                   dict(ORBIT_BENCH_FORCE_DIST="1"))
+    assert d["config"]["transport"] == "rccl" and d["config"]["signalling"] is None and d["per_rank"]["exchange_ms"][0] > 0
+
+
+@pytest.mark.parametrize("extra", [["--graph", "--frames-in-flight", "1"], ["--frames-in-flight", "1"], ["--two-calls"],
+                                   ["--frames-in-flight", "2", "--expand", "none"]])
+def test_bench_two_ranks_step_variants(extra):
+    """The N > 1 step's other shapes, two ranks on the box's one GPU: every timed step replayed as a captured graph (cull
+    beside the previous list's exchange, fork and join inside the capture), strictly serial frames, the two calls
+    orbit_cull_shard replaces, two frames in flight without the command buffer.  bench.py checks every rank's lists."""
+    d = _run_ranks(["--gpus", "2"] + extra, dict(ORBIT_BENCH_ONE_DEVICE="1", ORBIT_BENCH_BACKEND="gloo"))
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["transport"] == "p2p" and c["signalling"] == "device" and c["transport_fallback"] is None
+    assert c["steps_as_graph"] == ("--graph" in extra)
+    assert c["frames_in_flight"] == (1 if "1" in extra else 2)
+    assert c["host_enqueue_ms_per_step"] > 0 and c["step_intervals"]["intervals"] >= 2
+    assert sum(d["per_rank"]["meshlets_in"]) == 6000 * 256 and sum(d["per_rank"]["survivors"]) == c["survivors"] > 0
 
 
 def test_bench_under_torch_distributed_run_as_the_driver_starts_it():

@@ -19,7 +19,11 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from orbit_amd import camera, layouts as L, synth
+from orbit_amd import _lib, camera, layouts as L, synth
+
+if os.environ.get("LIB"):  # another build of the library (tools/mkvariant_any.sh), e.g. LIB=tools/variants/paystore2.so
+    _lib.LIB_PATH = os.path.join(ROOT, os.environ["LIB"])
+    print("library", _lib.LIB_PATH)
 from orbit_amd.engine import Engine
 
 N = int(os.environ.get("ENGINES", 4))

@@ -1,0 +1,34 @@
+# Round-5 measurement set (GPU box, repo root): bash tools/r05_final.sh  -> gpurun_out/r05_final/*
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05_final; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $O/bench_line.json 2> $O/bench.err
+python3 $R/bench.py --meshlet-source buffer > $O/bench_line_meshlet_buffer.json 2>> $O/bench.err
+for src in stream buffer; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$src -- python3 $R/bench.py --steps 20 --warmup 3 --cpu-sample-entities 0 --meshlet-source $src > $O/prof_$src.log 2>&1
+  grep '^{' $O/prof_$src.log | tail -1 > $O/bench_line_under_rocprof_$src.json
+  f=$(find $O/prof_$src -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats_$src.csv; rm -rf $O/prof_$src $O/prof_$src.log
+done
+# the default command itself under rocprofv3 (CPU baseline and all)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- python3 $R/bench.py > $O/prof_default.log 2>&1
+grep '^{' $O/prof_default.log | tail -1 > $O/bench_line_under_rocprof_default_command.json
+f=$(find $O/prof_default -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats_default_command.csv; rm -rf $O/prof_default $O/prof_default.log
+# a rank's shard at N = 8 and N = 4 through the whole sharded step (world of one), strictly serial frames: kernel stats
+for e in 24414 48828; do
+  ORBIT_BENCH_FORCE_DIST=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_shard_$e -- python3 $R/bench.py --entities $e --frames-in-flight 1 --cpu-sample-entities 0 --steps 30 > $O/prof_shard_$e.log 2>&1
+  f=$(find $O/prof_shard_$e -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats_shard_$e.csv; rm -rf $O/prof_shard_$e $O/prof_shard_$e.log
+done
+ORBIT_BENCH_ONE_DEVICE=1 ORBIT_BENCH_BACKEND=gloo python3 $R/bench.py --gpus 2 --cpu-sample-entities 0 > $O/bench_line_two_ranks_one_device.json 2>> $O/bench.err
+ORBIT_BENCH_FORCE_DIST=1 python3 $R/bench.py --transport rccl --cpu-sample-entities 0 > $O/bench_line_world_of_one_rccl_allgather.json 2>> $O/bench.err
+cd $R
+python3 tools/bench_c5_two_pass.py --check > $O/c5_two_pass.json 2>> $O/bench.err
+python3 tools/bench_configs.py > $O/configs.json 2>> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_configs -- python3 tools/bench_configs.py > /dev/null 2>> $O/bench.err
+f=$(find $O/prof_configs -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats_configs.csv; rm -rf $O/prof_configs
+python3 tools/bench_views.py > $O/views.json 2>> $O/bench.err
+bash tools/shard_pieces.sh "stream buffer" > $O/shard_pieces.txt 2>> $O/bench.err
+tools/ubench/hop.bin > $O/hops.json 2>> $O/bench.err
+bash tools/traffic.sh stream > $O/traffic_stream.log 2>&1; bash tools/traffic.sh buffer > $O/traffic_buffer.log 2>&1
+cp $R/gpurun_out/traffic_stream.json $R/gpurun_out/traffic.json $O/ 2>/dev/null
+# the default line again, now that the PMC passes of THIS library exist (roofline.traffic_current)
+cp $O/traffic_stream.json $O/traffic.json $R/profiles/ && python3 $R/bench.py > $O/bench_line.json 2>> $O/bench.err
+ls -la $O
