@@ -99,6 +99,9 @@ def parse():
                          "worst case for everything that touches survivors), or coherent — every entity a ball whose "
                          "camera-facing cap survives: runs of neighbouring meshlets, records without any "
                          "(orbit_amd/synth.py)")
+    ap.add_argument("--no-mesh-table", action="store_true",
+                    help="stream source without orbit_meshlet_stream_update_meshes: the entity stage reads every mesh's "
+                         "128-B MeshInfo line instead of its 32-B side entry")
     ap.add_argument("--no-alpha-classes", action="store_true",
                     help="stream source without orbit_meshlet_stream_set_materials: the evaluation reads the 2-B "
                          "material index of every meshlet (22 B per meshlet)")
@@ -297,6 +300,8 @@ def main():
         mstream = slots[0].eng.meshlet_stream(meshlets_base, mb * M, (me - mb) * M)
         if not args.no_alpha_classes:  # as the renderer would after add_material: the evaluation reads no material index
             mstream.set_materials(materials, spec.materials)
+        if not args.no_mesh_table:  # as the renderer would after add_mesh: the entity stage reads 32 B per mesh, not 128
+            mstream.update_meshes(mesh, 0, E)
         torch.cuda.synchronize()
         mstream_build_ms = (time.perf_counter() - t0) * 1e3
         for s in slots:
@@ -354,6 +359,7 @@ def main():
         e_events = [torch.cuda.Event() for _ in range(n_x)]  # expansion out of recv_bufs[j] finished
         if do_expand:
             gathered = torch.zeros(L.DRAW_HEADER + 28 * out_cap, dtype=torch.uint8, device=dev)
+    explicit_stream_exchange = bool(exchanges) and all(getattr(x, "signalling", None) == "device" for x in exchanges)
     pending = []  # (slot, list index) culled but not yet exchanged (at most one)
     x_count = [0]
 
@@ -362,17 +368,20 @@ def main():
         # enqueued after it; the expansion (--expand all) follows on its own stream
         j = x_count[0] % len(recv_bufs)
         x_count[0] += 1
-        with torch.cuda.stream(xstream):
-            xstream.wait_event(s.cull_done[k])
-            if do_expand:
-                xstream.wait_event(e_events[j])  # the expansion that read this receive buffer two exchanges ago
-            if exchanges:  # p2p (device-signalled or with two collectives) or the RCCL all-gather: nothing waits for the host
-                exchanges[j].exchange(s.lists[k], stream=xstream)
-            else:
-                odist.gather_visible(s.lists[k], recv_bufs[j], header=hdr, stride=item)
-            s.xdone[k].record(xstream)  # the list buffer may be overwritten
-            if do_expand:
-                x_events[j].record(xstream)
+        xstream.wait_event(s.cull_done[k])
+        if do_expand:
+            xstream.wait_event(e_events[j])  # the expansion that read this receive buffer two exchanges ago
+        if explicit_stream_exchange:  # device-signalled p2p: the library enqueues on the stream it is given — no stream
+            exchanges[j].exchange(s.lists[k], stream=xstream)  # context (torch's costs ~10 us of host time per step)
+        else:
+            with torch.cuda.stream(xstream):  # torch.distributed calls go to the current stream
+                if exchanges:  # p2p with two collectives, or the RCCL all-gather: nothing waits for the host
+                    exchanges[j].exchange(s.lists[k], stream=xstream)
+                else:
+                    odist.gather_visible(s.lists[k], recv_bufs[j], header=hdr, stride=item)
+        s.xdone[k].record(xstream)  # the list buffer may be overwritten
+        if do_expand:
+            x_events[j].record(xstream)
         if do_expand:
             with torch.cuda.stream(estream):
                 estream.wait_event(x_events[j])
@@ -887,7 +896,8 @@ def main():
                 "transport_requested": (args.transport if do_gather else None), "transport_fallback": transport_fallback,
                 "meshlet_source": (f"derived meshlet streams ({per_meshlet:g} B per meshlet evaluated"
                                    f"{' (alpha classes instead of material indices)' if not args.no_alpha_classes else ''}, "
-                                   f"commands derived from the 2-B count chain; built once from the meshlet buffer "
+                                   f"commands derived from the 2-B count chain"
+                                   f"{'; the entity stage reads a 32-B side entry per mesh instead of its 128-B MeshInfo' if not args.no_mesh_table else ''}; built once from the meshlet buffer "
                                    f"before the timed region in {mstream_build_ms:.2f} ms, +36.65 B of HBM per meshlet)"
                                    if mstream is not None
                                    else "the 32-B Meshlet buffer"),

@@ -144,6 +144,11 @@ extern "C" {
     pub fn orbit_meshlet_stream_validate(ctx: *mut OrbitCtx, ms: *mut OrbitMeshletStream, meshlet_buffer: *const c_void,
                                          material_buffer: *const c_void, stream: *mut c_void) -> i32;
     pub fn orbit_meshlet_stream_destroy(ms: *mut OrbitMeshletStream) -> i32;
+    // GpuAssets::add_mesh calls `update_meshes` for the MeshInfo it wrote (assets/mod.rs:18-28): the entity stage then
+    // reads a 32-B side entry per mesh instead of the 128-B MeshInfo line
+    pub fn orbit_meshlet_stream_update_meshes(ctx: *mut OrbitCtx, ms: *mut OrbitMeshletStream, mesh_info_buffer: *const c_void,
+                                              first_mesh: u32, count: u32, stream: *mut c_void) -> i32;
+    pub fn orbit_ctx_mesh_side_culls(ctx: *const OrbitCtx) -> u64;
     pub fn orbit_ctx_bind_meshlet_stream(ctx: *mut OrbitCtx, ms: *mut OrbitMeshletStream) -> i32;
     pub fn orbit_ctx_fused_culls(ctx: *const OrbitCtx) -> u64;
     pub fn orbit_ctx_meshlet_stream_culls(ctx: *const OrbitCtx) -> u64;

@@ -183,6 +183,20 @@ int32_t orbit_meshlet_stream_set_materials(OrbitCtx *ctx, OrbitMeshletStream *ms
                                            uint32_t material_count, void *stream);
 int32_t orbit_meshlet_stream_validate(OrbitCtx *ctx, OrbitMeshletStream *ms, const void *meshlet_buffer,
                                       const void *material_buffer, void *stream);
+/* The entity stage's share of the same idea.  GpuAssets::add_mesh also writes the mesh's 128-B MeshInfo
+ * (src/assets/mod.rs:18-28, types.glsl:123-141) once, and every frame's entity cull then fetches that whole line per
+ * entity-draw for 28 bytes of it: the bounding sphere, lod_count and the chosen MeshLod.  update_meshes derives a 32-B
+ * side entry {sphere, lod_count, mesh_lods[0]} for meshes [first_mesh, first_mesh + count) of `mesh_info_buffer`
+ * (32 B of device memory per mesh; the table — at least 2^20 entries, zero-filled — is allocated by the first call);
+ * entity culls (orbit_entity_cull[_range], orbit_cull_views, orbit_cull_shard) of contexts the stream is bound to whose
+ * bufs->mesh_info_buffer is that pointer read the entry instead of the MeshInfo, and the MeshInfo itself only where a
+ * LOD other than 0 is picked or where no update reached the mesh.  Same results bit for bit.  Call it wherever the
+ * renderer writes mesh infos; an update from another buffer pointer starts the table over, NULL forgets it;
+ * orbit_meshlet_stream_validate (and every entity cull of a context with validate_streams) compares the table with the
+ * buffer it was derived from (ORBIT_E_STALE).  orbit_ctx_mesh_side_culls: entity culls that were handed the table. */
+int32_t orbit_meshlet_stream_update_meshes(OrbitCtx *ctx, OrbitMeshletStream *ms, const void *mesh_info_buffer,
+                                           uint32_t first_mesh, uint32_t count, void *stream);
+uint64_t orbit_ctx_mesh_side_culls(const OrbitCtx *ctx);
 int32_t orbit_meshlet_stream_destroy(OrbitMeshletStream *ms);
 int32_t orbit_ctx_bind_meshlet_stream(OrbitCtx *ctx, OrbitMeshletStream *ms);
 /* Calls this context has served from a bound stream so far — meshlet culls of passes 0 and 2 (each such view of

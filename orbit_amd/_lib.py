@@ -126,6 +126,8 @@ SYMBOLS = {
     "orbit_meshlet_stream_set_materials": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "orbit_meshlet_stream_validate": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orbit_meshlet_stream_destroy": (C.c_int32, [C.c_void_p]),
+    "orbit_meshlet_stream_update_meshes": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "orbit_ctx_mesh_side_culls": (C.c_uint64, [C.c_void_p]),
     "orbit_ctx_bind_meshlet_stream": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "orbit_ctx_meshlet_stream_culls": (C.c_uint64, [C.c_void_p]),
     "orbit_ctx_meshlet_class_culls": (C.c_uint64, [C.c_void_p]),

@@ -49,7 +49,16 @@ struct OrbitMeshletStream {
     bool other_pending = false;  // a derivation is under way (or its outcome unknowable): do not trust the classes
     bool other_recorded = false; // other_event was recorded for the pending derivation (on a stream that really runs)
     std::atomic<int> bindings{0};          // contexts it is bound to (orbit_meshlet_stream_destroy refuses while > 0)
+    // orbit_meshlet_stream_update_meshes: 32-B side entries of the meshes of `mesh_source` (kernels.h MeshSide);
+    // allocated (zero-filled) by the first update, meshes [0, mesh_hi) may be read
+    MeshSide *mesh_side = nullptr;
+    uint32_t mesh_capacity = 0, mesh_hi = 0;
+    const void *mesh_source = nullptr;
+    uint64_t mesh_side_culls = 0;          // entity culls that were handed the table
 };
+
+// meshes the side table holds when none was asked for more: 32 MB (the reference's MAX_MESH_COUNT is 10 000)
+constexpr uint32_t kMeshSideMinCapacity = 1u << 20;
 
 struct OrbitCtx {
     int device = 0;
@@ -186,6 +195,15 @@ MeshletStreamView stream_view_for(OrbitMeshletStream *ms, const void *meshlet_bu
     if (classes && (ms->other_pending || *ms->h_other != 0u)) classes = false;
     if (!classes) v.cls0 = v.cls1 = nullptr;
     return v;
+}
+
+// The mesh side table an entity cull of `mesh_info_buffer` may read: only the one derived from that very buffer.
+MeshSideView mesh_side_for(OrbitMeshletStream *ms, const void *mesh_info_buffer) {
+    if (!ms) return MeshSideView{nullptr, 0u};
+    std::lock_guard<std::mutex> lock(ms->mu);
+    if (ms->mesh_side == nullptr || ms->mesh_source != mesh_info_buffer || ms->mesh_hi == 0u) return MeshSideView{nullptr, 0u};
+    ms->mesh_side_culls++;
+    return MeshSideView{ms->mesh_side, ms->mesh_hi};
 }
 
 // Enqueues the read-back of the stream's class flag behind the launch that may have set it.  On a stream that is being
@@ -532,6 +550,7 @@ static int32_t entity_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitG
     p.ci = *ci;
     p.entity_draw_buffer = (const uint8_t *)b->entity_draw_buffer;
     p.mesh_infos = (const OrbitMeshInfo *)b->mesh_info_buffer;
+    p.mesh_side = mesh_side_for(ctx->meshlet_stream, b->mesh_info_buffer);
     p.dispatch_buffer = (uint8_t *)b->meshlet_dispatch_buffer;
     p.entities = (const OrbitEntityData *)b->entity_buffer;
     p.visibility = b->visibility_buffer;
@@ -560,6 +579,11 @@ static int32_t entity_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const
     EntityCullParams p;
     const int32_t rc = entity_cull_params(ctx, ctx, ci, b, draw_first, entity_draw_count, exact_range, p);
     if (rc) return rc;
+    if (p.mesh_side.table && ctx->caps.validate_streams) { // debug: is the mesh side table still a mirror?
+        const hipError_t ve = launch_mesh_side_validate(p.mesh_infos, 0u, p.mesh_side.count, p.mesh_side.table, ctx->status,
+                                                        (hipStream_t)stream);
+        if (ve != hipSuccess) return hip_fail(ctx, ve, "launch mesh_side_validate");
+    }
     const hipError_t e = launch_entity_cull(p, entity_draw_count, ctx->num_cus, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch entity_cull");
     return ORBIT_OK;
@@ -755,6 +779,7 @@ int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t cou
             f.m.ms = MeshletStreamView{};
             f.entity_draw_buffer = ev.v[i].entity_draw_buffer;
             f.mesh_infos = ev.v[i].mesh_infos;
+            f.mesh_side = ev.v[i].mesh_side;
             f.visibility = ev.v[i].visibility;
             f.e_pyr = ev.v[i].pyr;
             f.draw_first = ev.v[i].draw_first;
@@ -913,6 +938,56 @@ int32_t orbit_meshlet_stream_set_materials(OrbitCtx *ctx, OrbitMeshletStream *ms
     return ORBIT_OK;
 }
 
+int32_t orbit_meshlet_stream_update_meshes(OrbitCtx *ctx, OrbitMeshletStream *ms, const void *mesh_info_buffer,
+                                           uint32_t first_mesh, uint32_t count, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ms) return fail(ctx, ORBIT_E_MISSING, "meshlet_stream_update_meshes: stream is NULL");
+    if (ms->device != ctx->device)
+        return fail(ctx, ORBIT_E_INVALID, "meshlet_stream_update_meshes: stream lives on device %d", ms->device);
+    std::lock_guard<std::mutex> slock(ms->mu);
+    if (!mesh_info_buffer) { // forget: entity culls read the MeshInfos again
+        ms->mesh_source = nullptr;
+        ms->mesh_hi = 0u;
+        return ORBIT_OK;
+    }
+    if ((uint64_t)first_mesh + count > 0xFFFFFFFFull) return fail(ctx, ORBIT_E_INVALID, "meshlet_stream_update_meshes: range");
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipSetDevice");
+    if (ms->mesh_side == nullptr) { // the first update allocates (an upload-time call, like orbit_meshlet_stream_create)
+        const uint32_t cap = first_mesh + count > kMeshSideMinCapacity ? first_mesh + count : kMeshSideMinCapacity;
+        e = hipMalloc((void **)&ms->mesh_side, (size_t)cap * sizeof(MeshSide));
+        if (e == hipSuccess) e = hipMemset(ms->mesh_side, 0, (size_t)cap * sizeof(MeshSide));
+        if (e != hipSuccess) {
+            (void)hipFree(ms->mesh_side);
+            ms->mesh_side = nullptr;
+            return hip_fail(ctx, e, "meshlet_stream_update_meshes: hipMalloc (32 B per mesh)");
+        }
+        ms->mesh_capacity = cap;
+    }
+    if (first_mesh + count > ms->mesh_capacity)
+        return fail(ctx, ORBIT_E_CAPACITY, "meshlet_stream_update_meshes: meshes [%u, +%u) beyond the table's %u", first_mesh,
+                    count, ms->mesh_capacity);
+    if (ms->mesh_source != mesh_info_buffer && ms->mesh_hi != 0u) { // another buffer: what was derived says nothing about it
+        e = hipMemsetAsync(ms->mesh_side, 0, (size_t)ms->mesh_hi * sizeof(MeshSide), (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(ctx, e, "meshlet_stream_update_meshes: hipMemsetAsync");
+        ms->mesh_hi = 0u;
+    }
+    e = launch_mesh_side_build((const OrbitMeshInfo *)mesh_info_buffer, first_mesh, count, ms->mesh_side, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch mesh_side_build");
+    if (count != 0u) {
+        ms->mesh_source = mesh_info_buffer;
+        if (first_mesh + count > ms->mesh_hi) ms->mesh_hi = first_mesh + count;
+    }
+    return ORBIT_OK;
+}
+
+uint64_t orbit_ctx_mesh_side_culls(const OrbitCtx *ctx) {
+    if (!ctx || !ctx->meshlet_stream) return 0;
+    std::lock_guard<std::mutex> lock(ctx->meshlet_stream->mu);
+    return ctx->meshlet_stream->mesh_side_culls;
+}
+
 int32_t orbit_meshlet_stream_validate(OrbitCtx *ctx, OrbitMeshletStream *ms, const void *meshlet_buffer,
                                       const void *material_buffer, void *stream) {
     if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
@@ -920,6 +995,14 @@ int32_t orbit_meshlet_stream_validate(OrbitCtx *ctx, OrbitMeshletStream *ms, con
     if (!ms || !meshlet_buffer) return fail(ctx, ORBIT_E_MISSING, "meshlet_stream_validate: NULL argument");
     if (ms->device != ctx->device)
         return fail(ctx, ORBIT_E_INVALID, "meshlet_stream_validate: stream lives on device %d", ms->device);
+    {   // the mesh side table against the mesh_info buffer it was derived from (if any)
+        std::lock_guard<std::mutex> slock(ms->mu);
+        if (ms->mesh_side != nullptr && ms->mesh_source != nullptr && ms->mesh_hi != 0u) {
+            const hipError_t me = launch_mesh_side_validate((const OrbitMeshInfo *)ms->mesh_source, 0u, ms->mesh_hi, ms->mesh_side,
+                                                            ctx->status, (hipStream_t)stream);
+            if (me != hipSuccess) return hip_fail(ctx, me, "launch mesh_side_validate");
+        }
+    }
     MeshletStreamView v = stream_view_for(ms, meshlet_buffer, nullptr);
     if (!v.sphere) return ORBIT_OK; // mirrors another buffer (or nothing): no cull of this one reads it
     // the classes are checked against the buffer they were derived from, whether or not a cull would read them yet
@@ -950,6 +1033,7 @@ int32_t orbit_meshlet_stream_destroy(OrbitMeshletStream *ms) {
     (void)hipFree(ms->cls0);
     (void)hipFree(ms->cls1);
     (void)hipFree(ms->d_other);
+    (void)hipFree(ms->mesh_side);
     if (ms->h_other) (void)hipHostFree(ms->h_other);
     if (ms->other_event) (void)hipEventDestroy(ms->other_event);
     delete ms;
@@ -1038,6 +1122,7 @@ int32_t orbit_cull_shard(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitE
         f.m = p;
         f.entity_draw_buffer = ep.entity_draw_buffer;
         f.mesh_infos = ep.mesh_infos;
+        f.mesh_side = ep.mesh_side;
         f.visibility = ep.visibility;
         f.e_pyr = ep.pyr;
         f.draw_first = ep.draw_first;

@@ -121,7 +121,7 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p, FusedL
     const __amdgpu_buffer_rsrc_t SY = rsrc_of(p.sync, kFusedSyncWords * 4u);
     const __amdgpu_buffer_rsrc_t TF = rsrc_of(p.tile_flags, max_tiles * 4u);
     uint8_t *dispatch_buffer = const_cast<uint8_t *>(p.m.dispatch_buffer);
-    const FusedEntity E{p.m.ci, p.entity_draw_buffer, p.mesh_infos, p.m.entities, p.visibility, p.e_pyr};
+    const FusedEntity E{p.m.ci, p.entity_draw_buffer, p.mesh_infos, p.mesh_side, p.m.entities, p.visibility, p.e_pyr};
 
     // The parameter block lives in the kernel-argument segment and is read with scalar loads where it is used; a line
     // of it that no wave of the CU has touched yet is a full memory round trip, paid in the middle of whichever phase

@@ -24,7 +24,15 @@ __device__ __forceinline__ OrbitMeshletDispatch entity_eval_one(const P &p, uint
             reinterpret_cast<const OrbitEntityDraw *>(p.entity_draw_buffer + ORBIT_ENTITY_DRAW_HEADER);
         const OrbitEntityDraw ed = draws[g];
         const OrbitMeshInfo *mi = p.mesh_infos + ed.mesh_index;
-        const float4 bs = *reinterpret_cast<const float4 *>(mi->bounding_sphere);
+        // the mesh's 32-B side entry where the caller keeps one (kernels.h MeshSide): the same bits as the MeshInfo's
+        uint4 side_a = make_uint4(0u, 0u, 0u, 0u), side_b = make_uint4(0u, 0u, 0u, 0u);
+        if (p.mesh_side.table != nullptr && ed.mesh_index < p.mesh_side.count) {
+            const uint4 *se = reinterpret_cast<const uint4 *>(p.mesh_side.table + ed.mesh_index);
+            side_a = se[0], side_b = se[1];
+        }
+        const bool side = side_b.w != 0u;
+        float4 bs = make_float4(__uint_as_float(side_a.x), __uint_as_float(side_a.y), __uint_as_float(side_a.z), __uint_as_float(side_a.w));
+        if (!side) bs = *reinterpret_cast<const float4 *>(mi->bounding_sphere);
         const float4 *mm = reinterpret_cast<const float4 *>(p.entities[ed.entity_index].model_matrix);
         const float4 c0 = mm[0], c1 = mm[1], c2 = mm[2], c3 = mm[3];
 
@@ -67,9 +75,10 @@ __device__ __forceinline__ OrbitMeshletDispatch entity_eval_one(const P &p, uint
             const float lod_f = log2c(gmax(lod_distance, 0.0f) / ci.lod_base) / log2c(ci.lod_step);
             uint32_t lod = f2u_sat(gmax(lod_f + 1.0f, 0.0f));
             lod = min(max(lod, ci.min_mesh_lod), ci.max_mesh_lod);
-            lod = min(lod, mi->lod_count - 1u);
+            lod = min(lod, (side ? side_b.x : mi->lod_count) - 1u);
             lod = min(lod, (uint32_t)ORBIT_MAX_MESH_LODS - 1u);
-            const OrbitMeshLod ml = mi->mesh_lods[lod];
+            OrbitMeshLod ml = {side_b.y, side_b.z};
+            if (!side || lod != 0u) ml = mi->mesh_lods[lod];
             pr.entity_index = ed.entity_index;
             pr.meshlet_offset = ml.meshlet_offset;
             pr.meshlet_count = ml.meshlet_count;
@@ -103,22 +112,44 @@ __device__ __forceinline__ OrbitMeshletDispatch entity_record(const OrbitMeshlet
     return rec;
 }
 
-// owner of output record r of a block = last entity whose exclusive record offset is <= r (entities without records
-// share the next one's offset): bisection over the block's offsets in LDS
-__device__ __forceinline__ uint32_t entity_record_owner(const uint32_t *s_off, uint32_t r) {
-    uint32_t lo = 0, hi = kEntityBlock;
-    while (hi - lo > 1u) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (s_off[mid] <= r) lo = mid; else hi = mid;
+// The block's `total` records, thread = output record, handed to store(r, record).  The owner of output record r of a
+// block = the last entity whose exclusive record offset is <= r (entities without records share the next one's offset):
+// bisection over the block's offsets in LDS.  FOUR records per thread and trip:
+// a bisection is eight dependent LDS reads and a workgroup of this stage runs one wave per SIMD with little else
+// resident, so nothing hides that latency but the thread's own other records (the four chains are independent; the loop
+// with one record per trip was 2/3 of a chunk's time at 8 records per entity).  kEntityBlock = 2^8: the bisection's trip
+// count is fixed, the compiler interleaves the chains.
+template <class Store>
+__device__ __forceinline__ void entity_expand_records(const uint32_t *s_off, const OrbitMeshletDispatch *s_proto, uint32_t total,
+                                                      Store store) {
+    constexpr uint32_t U = 4;
+    for (uint32_t r0 = threadIdx.x; r0 < total; r0 += U * kEntityBlock) {
+        uint32_t lo[U], hi[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) lo[u] = 0u, hi[u] = kEntityBlock;
+#pragma unroll
+        for (int step = 0; step < 8; step++) {
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t mid = (lo[u] + hi[u]) >> 1;
+                if (s_off[mid] <= r0 + u * kEntityBlock) lo[u] = mid; else hi[u] = mid;
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t r = r0 + u * kEntityBlock;
+            if (r < total) store(r, entity_record(s_proto[lo[u]], r - s_off[lo[u]]));
+        }
     }
-    return lo;
 }
+static_assert(kEntityBlock == 256, "entity_expand_records: eight bisection steps");
 
 // what entity_eval_one reads, over a fused parameter block (FusedCullParams: ci and entities are the meshlet side's)
 struct FusedEntity {
     const OrbitGpuCullInfo &ci;
     const uint8_t *entity_draw_buffer;
     const OrbitMeshInfo *mesh_infos;
+    MeshSideView mesh_side;
     const OrbitEntityData *entities;
     uint32_t *visibility;
     PyramidView pyr;
@@ -213,13 +244,11 @@ __device__ __forceinline__ void entity_chunks(const E &ent, const EntityChunksAr
         st_sc1(EF, threadIdx.x == 0 ? eb * 4u : kHandoffNoOffset, chunk_total << 2 | kAggregate);
         // ... then the records of the chunks before it
         const uint32_t base = chunks_before(a.status, EF, eb, S.smem);
-        for (uint32_t r = threadIdx.x; r < chunk_total; r += kEntityBlock) {
-            const uint32_t owner = entity_record_owner(S.off, r);
-            const OrbitMeshletDispatch rec = entity_record(S.proto[owner], r - S.off[owner]);
+        entity_expand_records(S.off, S.proto, chunk_total, [&](uint32_t r, const OrbitMeshletDispatch &rec) {
             const v4u w = {rec.entity_index, rec.meshlet_offset, rec.meshlet_count, rec.visibility_offset};
             const uint64_t slot = (uint64_t)base + r; // (the sum can pass 2^32 / 16 only far beyond any capacity)
             __builtin_amdgcn_raw_buffer_store_b128(w, REC_W, slot < a.dispatch_capacity ? (uint32_t)slot * 16u : kHandoffNoOffset, 0, kSc1);
-        }
+        });
         drain_stores();
         __syncthreads(); // every wave's records are in memory; off / proto may be rewritten
         if (threadIdx.x == 0) {

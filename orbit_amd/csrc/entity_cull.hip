@@ -127,11 +127,9 @@ __device__ __forceinline__ void entity_cull_emit_body(const EntityCullParams &p)
     s_proto[threadIdx.x] = pr;
     __syncthreads();
     OrbitMeshletDispatch *out = reinterpret_cast<OrbitMeshletDispatch *>(p.dispatch_buffer + ORBIT_DISPATCH_HEADER);
-    for (uint32_t r = threadIdx.x; r < block_total; r += kEntityBlock) {
-        const uint32_t owner = entity_record_owner(s_off, r);
-        const OrbitMeshletDispatch rec = entity_record(s_proto[owner], r - s_off[owner]);
+    entity_expand_records(s_off, s_proto, block_total, [&](uint32_t r, const OrbitMeshletDispatch &rec) {
         if (block_base + r < p.dispatch_capacity) out[block_base + r] = rec;
-    }
+    });
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const uint32_t total = reduced;
         *p.total = total;

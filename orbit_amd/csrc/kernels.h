@@ -32,10 +32,27 @@ struct Payload {
     uint32_t y, z, w; // Meshlet::vertex_offset, Meshlet::data_offset, {triangles:8 | vertices:8 | lane:5 << 4 | record:4}
 };
 
+// What the entity stage reads of a mesh, as a derived 32-B copy of the static 128-B MeshInfo
+// (orbit_meshlet_stream_update_meshes): the entity test needs the bounding sphere (16 B at offset 0), lod_count (4 B at
+// 56) and the chosen MeshLod (8 B at 64 + 8 lod) — 28 bytes of a 128-B line per entity-draw, the line being what HBM
+// delivers (the launch moved 3.4 x its algorithmic bytes: profiles/r03_rdreq_sizes.txt).  With the table a mesh costs a
+// quarter of a line; the MeshInfo itself is read only where a LOD other than 0 is picked, or where no update reached the
+// mesh (valid == 0: the tables are zero-filled).
+struct MeshSide {
+    float sphere[4];
+    uint32_t lod_count, lod0_offset, lod0_count, valid;
+};
+static_assert(sizeof(MeshSide) == 32, "MeshSide layout");
+struct MeshSideView {
+    const MeshSide *table; // nullptr: none (or it mirrors another mesh_info buffer)
+    uint32_t count;        // meshes [0, count) have an entry
+};
+
 struct EntityCullParams {
     OrbitGpuCullInfo ci;
     const uint8_t *entity_draw_buffer;
     const OrbitMeshInfo *mesh_infos;
+    MeshSideView mesh_side;
     uint8_t *dispatch_buffer;
     const OrbitEntityData *entities;
     uint32_t *visibility;
@@ -216,6 +233,7 @@ struct FusedCullParams {
     MeshletCullParams m;
     const uint8_t *entity_draw_buffer;
     const OrbitMeshInfo *mesh_infos;
+    MeshSideView mesh_side;
     uint32_t *visibility; // entity bitset (occlusion passes)
     PyramidView e_pyr;    // the entity stage's pyramid (pass 2)
     uint32_t draw_first, draw_limit; // as EntityCullParams
@@ -293,6 +311,10 @@ hipError_t launch_meshlet_stream_validate(const OrbitMeshlet *meshlets, const Me
                                           const OrbitMaterialData *materials, uint32_t material_count, int32_t *status,
                                           hipStream_t s);
 // the alpha classes of the whole stream, from its material indices (orbit_meshlet_stream_set_materials)
+// meshes [first, first + count) of `mesh_infos` -> their 32-B side entries; and the comparison (ORBIT_E_STALE)
+hipError_t launch_mesh_side_build(const OrbitMeshInfo *mesh_infos, uint32_t first, uint32_t count, MeshSide *table, hipStream_t s);
+hipError_t launch_mesh_side_validate(const OrbitMeshInfo *mesh_infos, uint32_t first, uint32_t count, const MeshSide *table,
+                                     int32_t *status, hipStream_t s);
 hipError_t launch_meshlet_stream_classes(const MeshletStreamView &ms, const OrbitMaterialData *materials,
                                          uint32_t material_count, uint32_t *other, hipStream_t s);
 // ms.cmd (optional): the derived command-word stream of `meshlets`, based at global meshlet index 0

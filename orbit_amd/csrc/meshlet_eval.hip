@@ -136,7 +136,7 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p, co
     if constexpr (FUSED) {
         // ------------------------------------------------------------ the entity stage (entity_cull.comp:104-245)
         const FusedCullParams &f = *fp;
-        const FusedEntity E{p.ci, f.entity_draw_buffer, f.mesh_infos, p.entities, f.visibility, f.e_pyr};
+        const FusedEntity E{p.ci, f.entity_draw_buffer, f.mesh_infos, f.mesh_side, p.entities, f.visibility, f.e_pyr};
         EntityChunksArgs a;
         a.dispatch_buffer = const_cast<uint8_t *>(p.dispatch_buffer);
         a.dispatch_capacity = f.e_dispatch_capacity;

@@ -192,4 +192,48 @@ hipError_t launch_meshlet_stream_classes(const MeshletStreamView &ms, const Orbi
     return hipGetLastError();
 }
 
+namespace {
+
+// orbit_meshlet_stream_update_meshes: thread = mesh
+__global__ __launch_bounds__(256) void mesh_side_build_kernel(const OrbitMeshInfo *mesh_infos, uint32_t first, uint32_t count,
+                                                             MeshSide *table) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const OrbitMeshInfo &m = mesh_infos[first + i];
+    MeshSide s;
+    s.sphere[0] = m.bounding_sphere[0], s.sphere[1] = m.bounding_sphere[1], s.sphere[2] = m.bounding_sphere[2], s.sphere[3] = m.bounding_sphere[3];
+    s.lod_count = m.lod_count;
+    s.lod0_offset = m.mesh_lods[0].meshlet_offset;
+    s.lod0_count = m.mesh_lods[0].meshlet_count;
+    s.valid = 1u;
+    table[first + i] = s;
+}
+
+__global__ __launch_bounds__(256) void mesh_side_validate_kernel(const OrbitMeshInfo *mesh_infos, uint32_t first, uint32_t count,
+                                                                const MeshSide *table, int32_t *status) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const OrbitMeshInfo &m = mesh_infos[first + i];
+    const MeshSide s = table[first + i];
+    if (s.valid == 0u) return; // never derived: the entity stage reads the MeshInfo itself
+    bool same = s.lod_count == m.lod_count && s.lod0_offset == m.mesh_lods[0].meshlet_offset && s.lod0_count == m.mesh_lods[0].meshlet_count;
+    for (int k = 0; k < 4; k++) same = same && __float_as_uint(s.sphere[k]) == __float_as_uint(m.bounding_sphere[k]);
+    if (!same) latch_status(status, ORBIT_E_STALE);
+}
+
+} // namespace
+
+hipError_t launch_mesh_side_build(const OrbitMeshInfo *mesh_infos, uint32_t first, uint32_t count, MeshSide *table, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(mesh_side_build_kernel, dim3((count + 255u) / 256u), dim3(256), 0, s, mesh_infos, first, count, table);
+    return hipGetLastError();
+}
+
+hipError_t launch_mesh_side_validate(const OrbitMeshInfo *mesh_infos, uint32_t first, uint32_t count, const MeshSide *table,
+                                     int32_t *status, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(mesh_side_validate_kernel, dim3((count + 255u) / 256u), dim3(256), 0, s, mesh_infos, first, count, table, status);
+    return hipGetLastError();
+}
+
 } // namespace orbit

@@ -314,6 +314,7 @@ class AllGatherExchange:
 class _HipTransport:
     def __init__(self, engine, device):
         self.eng, self.device, self.own, self.opened = engine, device, [], []
+        self._calls = {}
 
     def alloc(self, nbytes):
         ptr, handle = self.eng.p2p_alloc(nbytes)
@@ -331,7 +332,14 @@ class _HipTransport:
         self.eng.scatter_list(local_list, counts, rank, world, peers, capacity, header, stride, stream=stream)
 
     def exchange(self, local_list, rank, world, peers, ctrls, capacity, header, stride, stream):
-        self.eng.exchange_list(local_list, rank, world, peers, ctrls, capacity, header, stride, stream=stream)
+        # the argument blocks of a (list buffer, stream) pair are built once: a step loop calls this every step with the
+        # same buffers, and filling two pointer arrays per call is ~15 us of host time in a 50-us step
+        key = (local_list.data_ptr() if hasattr(local_list, "data_ptr") else int(local_list), id(stream))
+        call = self._calls.get(key)
+        if call is None:
+            call = self._calls[key] = self.eng.prepare_exchange_list(local_list, rank, world, peers, ctrls, capacity, header,
+                                                                    stride, stream=stream)
+        call()
 
     def close(self):
         for ptr in self.opened:

@@ -72,6 +72,13 @@ class MeshletStream:
         _lib.check(self._lib.orbit_meshlet_stream_set_materials(self._engine._ctx, self._h, _ptr(material_buffer),
                                                                 int(material_count), _stream(stream)), self._engine._ctx)
 
+    def update_meshes(self, mesh_info_buffer, first_mesh, count, stream=None):
+        """orbit_meshlet_stream_update_meshes: 32-B side entries of meshes [first_mesh, first_mesh + count) of
+        `mesh_info_buffer` (None forgets the table); entity culls of that buffer then read them instead of the MeshInfos."""
+        _lib.check(self._lib.orbit_meshlet_stream_update_meshes(self._engine._ctx, self._h, _ptr(mesh_info_buffer),
+                                                                int(first_mesh), int(count), _stream(stream)),
+                   self._engine._ctx)
+
     def validate(self, meshlet_buffer, material_buffer=None, stream=None):
         """orbit_meshlet_stream_validate: ORBIT_E_STALE is latched (Engine.status raises) if the stream differs."""
         _lib.check(self._lib.orbit_meshlet_stream_validate(self._engine._ctx, self._h, _ptr(meshlet_buffer),
@@ -355,6 +362,10 @@ class Engine:
 
         return call
 
+    def mesh_side_culls(self):
+        """orbit_ctx_mesh_side_culls: entity culls of the bound stream that were handed its mesh side table."""
+        return int(self._lib.orbit_ctx_mesh_side_culls(self._ctx))
+
     def shard_culls(self):
         """orbit_ctx_shard_culls: orbit_cull_shard calls of this context that took the one launch."""
         return int(self._lib.orbit_ctx_shard_culls(self._ctx))
@@ -429,6 +440,22 @@ class Engine:
         ctrls = (C.c_void_p * world)(*[_ptr(b) for b in ctrl_buffers])
         _lib.check(self._lib.orbit_exchange_list(self._ctx, _ptr(local_list), rank, world, outs, ctrls, out_capacity,
                                                  header_bytes, stride, _stream(stream)), self._ctx)
+
+    def prepare_exchange_list(self, local_list, rank, world, out_buffers, ctrl_buffers, out_capacity, header_bytes, stride,
+                              stream=None):
+        """exchange_list with its pointer arrays built once: returns a function of no arguments (see prepare_cull_shard)."""
+        outs = (C.c_void_p * world)(*[_ptr(b) for b in out_buffers])
+        ctrls = (C.c_void_p * world)(*[_ptr(b) for b in ctrl_buffers])
+        fn, ctx, lst, st = self._lib.orbit_exchange_list, self._ctx, _ptr(local_list), _stream(stream)
+        keep = (outs, ctrls, local_list, stream)
+
+        def call():
+            rc = fn(ctx, lst, rank, world, outs, ctrls, out_capacity, header_bytes, stride, st)
+            if rc != _lib.OK:
+                _lib.check(rc, ctx)
+            return keep
+
+        return call
 
     def allgather_list(self, nccl_comm, rank, world, local_list, segment_capacity, segments, out_list, out_capacity,
                        header_bytes, stride, stream=None):
