@@ -316,8 +316,8 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t o_avl = carve((size_t)caps.max_lights * 16 + 1024);
     const size_t o_alf = carve(((size_t)caps.max_lights / 32 + 64) * 4);
     const size_t o_acn = carve(((size_t)caps.max_clusters + kAssignPad) * 4);
-    // assign: block_sums holds chunk sums | chunk bases of the two-level scan; block_base one word per cluster
-    const size_t o_abs = carve((2 * ((size_t)caps.max_clusters / kScanChunk + 2) + 64) * 4);
+    // assign: block_sums holds the sums of the chunks' counts (a line each); block_base the list of heavy blocks
+    const size_t o_abs = carve((((size_t)caps.max_clusters / kScanChunk + 2) * kChunkSumStride + 64) * 4);
     const size_t o_abb = carve(((size_t)caps.max_clusters + kAssignPad) * 4), o_at = carve(256);
     // light assignment: cached cluster AABBs, and per group of 256 active clusters the coarse candidate lists
     const size_t agroups = (size_t)caps.max_clusters / 256 + 1;

@@ -192,10 +192,14 @@ struct ClusterCompactParams {
     int32_t *status;
 };
 
-constexpr uint32_t kHitCache = 16;
+// light indices the count launch keeps per cluster (256 B of scratch per cluster of caps.max_clusters): the write launch
+// copies the lists of clusters that found at most this many (thread = cluster, kPlaceDirect words a round) and tests only
+// the others again
+constexpr uint32_t kHitCache = 64, kPlaceDirect = 16;
 // clusters of padding behind the per-cluster scratch arrays of the assignment (counts, bases, AABBs, hit cache): its
 // kernels read whole blocks / rounds of clusters speculatively (light_cluster.hip asserts its reach against this)
 constexpr uint32_t kAssignPad = 256;
+constexpr uint32_t kChunkSumStride = 32; // words between the sums of two chunks of kScanChunk clusters: a 128-B line each
 struct ClusterAssignParams {
     OrbitClusterCullInfo info;
     const uint8_t *unique;

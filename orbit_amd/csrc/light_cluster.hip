@@ -319,10 +319,14 @@ __global__ __launch_bounds__(256) void cluster_aabb_kernel(const ClusterAssignPa
     }
     const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.unique);
     const uint32_t n = min(hdr[3], p.max_clusters);
+    // what the count launch accumulates into: the number of its heavy blocks, and (below) the sums of the chunks
+    if (blockIdx.x == prepare_blocks && threadIdx.x == 0) p.total[0] = 0u;
     // grid-stride over the groups that exist (n is only known on the device; a grid sized by the capacity would
     // spend its time launching empty blocks)
     for (uint32_t grp = blockIdx.x - prepare_blocks; grp * kGroupClusters < n; grp += gridDim.x - prepare_blocks) {
     const uint32_t first = grp * kGroupClusters;
+    static_assert(kScanChunk % kGroupClusters == 0, "a chunk of the offsets' sums is whole groups");
+    if (threadIdx.x == 0 && first % kScanChunk == 0u) p.block_sums[(size_t)(first / kScanChunk) * kChunkSumStride] = 0u;
     const uint32_t *unique_idx = reinterpret_cast<const uint32_t *>(p.unique + ORBIT_COMPACT_HEADER);
     const uint32_t u = first + threadIdx.x;
     const float inf = __uint_as_float(0x7f800000u);
@@ -424,8 +428,89 @@ __global__ __launch_bounds__(256) void cluster_coarse_kernel(const ClusterAssign
     }
 }
 
+// Offsets without a scan launch: the count launch adds every wave's (capped) counts to the sum of its chunk of
+// kScanChunk clusters and lists the blocks that hold a cluster with more than kHitCache lights ("heavy").  A cluster's
+// offset is then the sum of the chunks before its own plus the counts of its chunk's clusters before it — at most a
+// thousand words each, read by whoever needs the offset.  The write launch is two kinds of blocks: the first
+// `place_blocks` take 256 clusters each (thread = cluster), compute the offsets and copy the lists of the clusters
+// whose hits the count launch kept (all but a few); the others stride over the heavy blocks and test those clusters
+// again (WRITE = true below).
+__device__ __forceinline__ void cluster_place_body(const ClusterAssignParams &p, uint32_t place_blocks) {
+    __shared__ uint32_t s_scan[4 + 1];
+    __shared__ uint32_t s_part[4];
+    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.unique);
+    const uint32_t *unique_idx = reinterpret_cast<const uint32_t *>(p.unique + ORBIT_COMPACT_HEADER);
+    uint32_t *out = reinterpret_cast<uint32_t *>(p.light_index_buffer + ORBIT_LIGHT_INDEX_HEADER);
+    const uint32_t n = min(hdr[3], p.max_clusters);
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    static_assert(kScanChunk % 256u == 0, "a piece of 256 clusters lies in one chunk");
+    for (uint32_t piece = blockIdx.x; piece * 256u < max(n, 1u); piece += place_blocks) { // (n = 0: block 0 writes the header)
+        const uint32_t u = piece * 256u + t;
+        const bool in = u < n;
+        const uint32_t cnt = in ? p.counts[u] : 0u;
+        const uint32_t ci = in ? unique_idx[u] : 0u;
+        uint4 h[kPlaceDirect / 4];
+#pragma unroll
+        for (uint32_t j = 0; j < kPlaceDirect / 4; j++) // the first 64 B whatever the count says: no load waits for another
+            h[j] = reinterpret_cast<const uint4 *>(p.hit_cache + (size_t)min(u, p.max_clusters) * kHitCache)[j];
+        const uint32_t chunk = piece * 256u / kScanChunk;
+        uint32_t part = 0;
+        for (uint32_t k = t; k < chunk; k += 256u) part += p.block_sums[(size_t)k * kChunkSumStride];
+        uint32_t cv[kScanChunk / 256u - 1u]; // the counts of the chunk's clusters in front of the piece, loaded together
+#pragma unroll
+        for (uint32_t j = 0; j < kScanChunk / 256u - 1u; j++) {
+            const uint32_t v = chunk * kScanChunk + j * 256u + t;
+            cv[j] = v < piece * 256u ? p.counts[v] : 0u;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kScanChunk / 256u - 1u; j++) part += cv[j];
+        part = wave_reduce_add(part);
+        if (lane == 0) s_part[wave] = part;
+        uint32_t piece_total;
+        const uint32_t ex = block_exclusive_scan<4>(cnt, s_scan, &piece_total); // (its barriers order s_part as well)
+        const uint32_t before = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+        const uint32_t off = before + ex;
+        // the kept hits, kPlaceDirect at a time (thread = cluster).  The first round's loads were issued above; a further
+        // round is taken only by waves that hold a cluster that long (a round trip of their own: a few waves per launch)
+        const bool kept = in && cnt <= kHitCache;
+#pragma unroll
+        for (uint32_t r = 0; r < kHitCache / kPlaceDirect; r++) {
+            if (r != 0u) {
+                if (__ballot(kept && cnt > r * kPlaceDirect) == 0ull) break; // wave-uniform
+#pragma unroll
+                for (uint32_t j = 0; j < kPlaceDirect / 4; j++)
+                    h[j] = reinterpret_cast<const uint4 *>(p.hit_cache + (size_t)min(u, p.max_clusters) * kHitCache + r * kPlaceDirect)[j];
+            }
+            const uint32_t w[kPlaceDirect] = {h[0].x, h[0].y, h[0].z, h[0].w, h[1].x, h[1].y, h[1].z, h[1].w,
+                                              h[2].x, h[2].y, h[2].z, h[2].w, h[3].x, h[3].y, h[3].z, h[3].w};
+#pragma unroll
+            for (uint32_t k = 0; k < kPlaceDirect; k++)
+                if (kept && r * kPlaceDirect + k < cnt && (uint64_t)off + r * kPlaceDirect + k < p.light_index_capacity)
+                    out[off + r * kPlaceDirect + k] = w[k]; // :138-147
+        }
+        if (kept) { // imageStore(cluster_offset_image, cluster_id, (offset, count)), :149-150
+            p.offset_image[2 * (size_t)ci + 0] = off;
+            p.offset_image[2 * (size_t)ci + 1] = cnt;
+        }
+        if (t == 0 && piece * 256u + 256u >= n) { // the last piece: light_count = the sum of all counts (atomicAdd total, :136)
+            const uint32_t total = before + piece_total;
+            *reinterpret_cast<uint32_t *>(p.light_index_buffer) = total;
+            if (total > p.light_index_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
+        }
+        __syncthreads(); // s_part is rewritten by the next piece
+    }
+}
+
+#ifndef ORBIT_ASSIGN_WAVES // five waves per SIMD: five blocks per CU resident (96 registers; the count launch is its blocks' latencies)
+#define ORBIT_ASSIGN_WAVES __attribute__((amdgpu_waves_per_eu(5)))
+#endif
 template <bool WRITE>
-__global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const ClusterAssignParams p) {
+__global__ __launch_bounds__(kAssignWaves * 64) ORBIT_ASSIGN_WAVES
+void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
+    if (WRITE && blockIdx.x < place_blocks) { // block-uniform
+        cluster_place_body(p, place_blocks);
+        return;
+    }
     __shared__ float4 s_cand[kLightTile];       // a segment per wave: view-space light ...
     __shared__ uint32_t s_cand_idx[kLightTile]; // ... and its index | kNotPoint
     __shared__ float s_wbox[kAssignWaves][8];   // per wave: union of its clusters' boxes (6) and its any-NaN flag
@@ -433,6 +518,7 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
     __shared__ uint32_t s_cpre[kCoarseSegs + 1]; // prefix of the group's segment counts
     __shared__ uint32_t s_ccnt[kCoarseSegs];     // the counts themselves
     __shared__ uint32_t s_fast;
+    __shared__ uint32_t s_wtot[kClustersPerBlock]; // count launch: the clusters' capped counts
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #ifdef ORBIT_TRIAGE_STAMPS // (a build of its own, tools/cluster_tests.py: the counters' atomics would dominate the stamps)
     // block life stamps of the COUNT launch (wall clock, 100 MHz): debug_tests[16 + 2 b] = begin, [.. + 1] = end of
@@ -456,8 +542,14 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
     constexpr uint32_t kSeg = kLightTile / kAssignWaves; // LDS candidates per wave and step
     constexpr uint32_t kLoads = kSeg / 64u;              // coarse candidates per lane and step
     static_assert(kLoads * kAssignWaves == kCoarseSegs, "wave w owns coarse segments kLoads * w ..");
-    // grid-stride over the blocks of kClustersPerBlock (8) active clusters that exist (see cluster_aabb_kernel)
-    for (uint32_t block_first = blockIdx.x * kClustersPerBlock;; block_first += gridDim.x * kClustersPerBlock) {
+    // grid-stride over the blocks of kClustersPerBlock (8) active clusters that exist (see cluster_aabb_kernel); WRITE: over
+    // the heavy blocks the count launch listed (p.block_base, p.total[0] of them; past the list: a block beyond every n)
+    const uint32_t heavy_n = WRITE ? min(p.total[0], p.max_clusters / kClustersPerBlock + 1u) : 0u;
+    uint32_t heavy_i = WRITE ? blockIdx.x - place_blocks : 0u;
+    const uint32_t beyond = (p.max_clusters / kClustersPerBlock + 1u) * kClustersPerBlock; // >= n, inside the scratch padding
+    auto heavy_at = [&](uint32_t i) { return i < heavy_n ? min(p.block_base[i] * kClustersPerBlock, beyond) : beyond; };
+    for (uint32_t block_first = WRITE ? heavy_at(heavy_i) : blockIdx.x * kClustersPerBlock;;
+         block_first = WRITE ? heavy_at(heavy_i += gridDim.x - place_blocks) : block_first + gridDim.x * kClustersPerBlock) {
     if (!first_item && block_first >= n) break;
     const uint32_t u0 = block_first + wave * kClustersPerWave;
     const uint32_t group = block_first / kGroupClusters;
@@ -470,25 +562,24 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
     for (int i = 0; i < 3; i++) box.mn[i] = p.aabb[6 * (size_t)ul + i], box.mx[i] = p.aabb[6 * (size_t)ul + 3 + i];
     const uint32_t cc = p.coarse_counts[(size_t)group * kCoarseSegs + ((uint32_t)lane & (kCoarseSegs - 1))];
     uint32_t my_limit = 0, my_offset = 0;
-    constexpr uint32_t kHcRounds = (kClustersPerWave * kHitCache + 63u) / 64u, kHcPerRound = 64u / kHitCache;
-    // The speculative hit-cache read below takes whole rounds of kHcPerRound clusters from u0 on, whether or not the
-    // wave owns them (or they exist): it reaches cluster block_first + kClustersPerBlock - kClustersPerWave +
-    // kHcRounds * kHcPerRound - 1 at most, and block_first < max_clusters + kClustersPerBlock (launch_cluster_assign's
-    // grid).  The scratch arrays are padded by kAssignPad clusters for exactly that (orbit_ctx_create).
-    static_assert(2u * kClustersPerBlock + kHcRounds * kHcPerRound <= kAssignPad, "hit-cache over-read exceeds the scratch padding");
-    uint32_t hc[kHcRounds] = {};
     if (WRITE) {
         my_limit = p.counts[ul];
-        // exclusive prefix of the capped counts: chunk-local prefix (scan launch) + the sums of the chunks before the
-        // block's (its 8 clusters share a chunk), added up here
+        // exclusive prefix of the capped counts: the sums of the chunks before the block's (its 8 clusters share a
+        // chunk), the counts of the chunk's clusters before the wave's first one, the wave's own clusters before the lane's
         static_assert(kScanChunk % kClustersPerBlock == 0, "a block's clusters share a scan chunk");
+        const uint32_t chunk = min(block_first, p.max_clusters) / kScanChunk;
         uint32_t part = 0;
-        for (uint32_t k = (uint32_t)lane; k < block_first / kScanChunk; k += 64u) part += p.block_sums[k];
-        my_offset = p.block_base[ul] + wave_reduce_add(part);
-        // (cluster, slot) per lane, kHcRounds round(s) of kHcPerRound clusters: the indices the counting launch kept
+        for (uint32_t k = (uint32_t)lane; k < chunk; k += 64u) part += p.block_sums[(size_t)k * kChunkSumStride];
+        uint32_t cv[kScanChunk / 64u]; // (loaded together: a loop of load-and-add is sixteen round trips in a row)
 #pragma unroll
-        for (uint32_t j = 0; j < kHcRounds; j++)
-            hc[j] = p.hit_cache[(size_t)(u0 + j * kHcPerRound + (uint32_t)lane / kHitCache) * kHitCache + (uint32_t)lane % kHitCache];
+        for (uint32_t j = 0; j < kScanChunk / 64u; j++) {
+            const uint32_t v = chunk * kScanChunk + j * 64u + (uint32_t)lane;
+            cv[j] = v < min(u0, p.max_clusters) ? p.counts[v] : 0u;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kScanChunk / 64u; j++) part += cv[j];
+        const uint32_t mine = lane < kClustersPerWave ? my_limit : 0u;
+        my_offset = wave_reduce_add(part) + (wave_inclusive_scan(mine) - mine);
     }
     uint32_t tag[kLoads];
     if (!WRITE) {
@@ -508,29 +599,6 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
         if (lane == (int)kCoarseSegs - 1) s_cpre[kCoarseSegs] = inc;
         const bool lng = __ballot(v > 64u) != 0ull;
         if (lane == 0) s_fast = lng ? 0u : 1u;
-    }
-    if (WRITE) {
-        // A block whose clusters all found at most kHitCache lights copies the indices the counting launch kept
-        // (the common case by far: a cluster holds a handful of lights) instead of testing everything again.
-        if (__syncthreads_or(owns && my_limit > kHitCache) == 0) {
-#pragma unroll
-            for (uint32_t j = 0; j < kHcRounds; j++) { // one lane per (cluster, slot)
-                const uint32_t c = j * kHcPerRound + (uint32_t)lane / kHitCache, k = (uint32_t)lane % kHitCache;
-                const uint32_t lim = (uint32_t)__shfl((int)my_limit, (int)c, 64);
-                const uint32_t off = (uint32_t)__shfl((int)my_offset, (int)c, 64);
-                const uint32_t ci = (uint32_t)__shfl((int)my_ci, (int)c, 64);
-                if (c < (uint32_t)kClustersPerWave && u0 + c < n) {
-                    if (k < lim && off + k < p.light_index_capacity) out[off + k] = hc[j];
-                    if (k == 0) { // imageStore(cluster_offset_image, cluster_id, (offset, count)), :149-150
-                        p.offset_image[2 * (size_t)ci + 0] = off;
-                        p.offset_image[2 * (size_t)ci + 1] = lim;
-                    }
-                }
-            }
-            ORBIT_COUNT_TESTS(6, wave == 0 ? 1u : 0u);
-            __syncthreads(); // s_cpre / s_ccnt are rewritten by the next item
-            continue;        // block-uniform
-        }
     }
     // absent cluster: the empty box, neutral in the union
     {
@@ -652,6 +720,7 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
                 for (int c = 0; c < kClustersPerWave; c++) {
                     const uint64_t m = hits[c];
                     if (!valid[c] || m == 0ull) continue; // wave-uniform
+                    if (WRITE && limit[c] <= kHitCache) continue; // (its list was copied by a placement block)
                     if (WRITE || count[c] < kHitCache) {  // wave-uniform: the counting launch keeps the first few only
                         if ((m >> lane) & 1ull) {
                             const uint32_t k = count[c] + lane_prefix(m);
@@ -717,17 +786,36 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
 #pragma unroll
         for (int c = 0; c < kClustersPerWave; c++)
             if (lane == c) mine = count[c], lim = limit[c], off = offset[c];
+        const uint32_t capped = owns ? min(mine, ORBIT_MAX_LIGHTS_PER_CLUSTER) : 0u; // :135
         if (owns) {
             if (!WRITE) {
-                p.counts[u0 + lane] = min(mine, ORBIT_MAX_LIGHTS_PER_CLUSTER); // :135
-            } else {
+                p.counts[u0 + lane] = capped;
+            } else if (lim > kHitCache) {
                 // imageStore(cluster_offset_image, cluster_id, (offset, count)), :149-150
                 p.offset_image[2 * (size_t)my_ci + 0] = off;
                 p.offset_image[2 * (size_t)my_ci + 1] = lim;
             }
         }
+        if (!WRITE) { // the chunk's sum (what every offset behind it is made of) and the list of heavy blocks
+            if (lane < kClustersPerWave) s_wtot[wave * kClustersPerWave + lane] = capped;
+        }
     }
-    __syncthreads(); // s_cpre / s_wbox are rewritten by the next block of clusters
+    if (!WRITE) {
+        __syncthreads(); // (also: s_cpre / s_wbox are rewritten by the next block of clusters)
+        if (threadIdx.x == 0) {
+            // ONE atomic per block, and every chunk's word on a line of its own: atomics on one 128-B line queue in one
+            // L2 channel whatever their words (17 000 of them on the 34 adjacent words of config 4: 85 us)
+            uint32_t block_total = 0, most = 0;
+#pragma unroll
+            for (int c = 0; c < kClustersPerBlock; c++) block_total += s_wtot[c], most = max(most, s_wtot[c]);
+            if (block_total != 0u)
+                (void)__hip_atomic_fetch_add(p.block_sums + (size_t)(block_first / kScanChunk) * kChunkSumStride, block_total,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (most > kHitCache)
+                p.block_base[__hip_atomic_fetch_add(p.total, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = block_first / kClustersPerBlock;
+        }
+    }
+    if (WRITE) __syncthreads(); // s_cpre / s_wbox are rewritten by the next block of clusters
     }
 #ifdef ORBIT_TRIAGE_STAMPS
     if (!WRITE && p.debug_tests && threadIdx.x == 0 && blockIdx.x < 4096u) {
@@ -738,15 +826,6 @@ __global__ __launch_bounds__(kAssignWaves * 64) void cluster_assign_kernel(const
         p.debug_tests[16 + 2 * (4096u + blockIdx.x) + 1] = dbg_ctotal; // the group's coarse candidates
     }
 #endif
-    if (WRITE && blockIdx.x == 0 && wave == 0) { // light_count = the sum over all chunks (atomicAdd total, :136)
-        uint32_t part = 0;
-        for (uint32_t k = (uint32_t)lane; k * kScanChunk < n; k += 64u) part += p.block_sums[k];
-        const uint32_t total = wave_reduce_add(part);
-        if (lane == 0) {
-            *reinterpret_cast<uint32_t *>(p.light_index_buffer) = total;
-            if (total > p.light_index_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
-        }
-    }
 }
 
 // header for an empty active list: light_count = 0 (cluster.rs:575-581)
@@ -790,17 +869,15 @@ hipError_t launch_cluster_assign(const ClusterAssignParams &p, uint32_t num_cus,
     const uint32_t blocks = min((p.max_clusters + kClustersPerBlock - 1) / kClustersPerBlock, num_cus * 32u);
     hipLaunchKernelGGL(cluster_aabb_kernel, dim3(prepare_blocks + min(groups, num_cus * 4u)), dim3(256), 0, s, p, prepare_blocks);
     hipLaunchKernelGGL(cluster_coarse_kernel, dim3(min(groups * kCoarseSplit, num_cus * 8u)), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(cluster_assign_kernel<false>, dim3(blocks), dim3(kAssignWaves * 64), 0, s, p);
+    hipLaunchKernelGGL(cluster_assign_kernel<false>, dim3(blocks), dim3(kAssignWaves * 64), 0, s, p, 0u);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // exclusive scan of the counts of the n active clusters (n read on the device from the compacted header):
-    // chunk-local prefixes in block_base, chunk bases behind the chunk sums; the write launch adds the two
-    // (first level only: chunk-local prefixes + chunk sums; a write block adds up the sums of the chunks before its
-    // own — at most a thousand words in L2 — instead of a second scan launch)
-    e = launch_scan_chunks(p.counts, p.block_base, reinterpret_cast<const uint32_t *>(p.unique) + 3, 1u, p.max_clusters,
-                           p.block_sums, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cluster_assign_kernel<true>, dim3(blocks), dim3(kAssignWaves * 64), 0, s, p);
+    // placement blocks (256 clusters each) + workers for the heavy blocks (they leave at once when there are none)
+    const uint32_t place_blocks = min((p.max_clusters + 255u) / 256u, num_cus * 2u);
+#ifndef ORBIT_HEAVY_WORKERS
+#define ORBIT_HEAVY_WORKERS num_cus
+#endif
+    hipLaunchKernelGGL(cluster_assign_kernel<true>, dim3(place_blocks + ORBIT_HEAVY_WORKERS), dim3(kAssignWaves * 64), 0, s, p, place_blocks);
     return hipGetLastError();
 }
 
