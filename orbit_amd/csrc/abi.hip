@@ -74,11 +74,13 @@ struct OrbitCtx {
     uint32_t *m_tile_masks = nullptr, *m_chunk_sums = nullptr;
     uint32_t *m_tile_counts = nullptr, *m_tile_base = nullptr, *m_total = nullptr;
     uint32_t *x_block_pop = nullptr; // orbit_expand_visible_records: survivors per 1024 records of the list
-    uint32_t *c_chunk = nullptr; // compact: counts | bases | total
+    uint32_t *c_chunk = nullptr; // compact: its own chunk counts | the ones a counting mark launch left (c_chunk_words each)
+    size_t c_chunk_words = 0;
     float4 *a_view_lights = nullptr;
     uint32_t *a_light_flags = nullptr, *a_counts = nullptr, *a_block_sums = nullptr, *a_block_base = nullptr,
              *a_total = nullptr, *a_coarse = nullptr, *a_coarse_counts = nullptr, *a_hit_cache = nullptr;
     float *a_aabb = nullptr, *a_group_box = nullptr;
+    uint32_t *a_group_order = nullptr;
     uint32_t a_coarse_seg = 0;
     uint32_t *m_tickets = nullptr, *m_list_sync = nullptr, *f_done = nullptr;
     uint32_t *f_sync = nullptr, *f_ent_flags = nullptr, *f_tile_flags = nullptr; // one-launch cull (cull_fused.hip)
@@ -323,7 +325,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t agroups = (size_t)caps.max_clusters / 256 + 1;
     const size_t aseg = (((size_t)caps.max_lights + 15) / 16 + 63) / 64 * 64;
     const size_t o_aab = carve(((size_t)caps.max_clusters + kAssignPad) * 6 * 4);
-    const size_t o_aco = carve(agroups * 16 * aseg * 4), o_acc = carve(agroups * 16 * 4), o_agb = carve(agroups * 32);
+    const size_t o_aco = carve(agroups * 16 * aseg * 4), o_acc = carve(agroups * 16 * 4), o_agb = carve(agroups * 32), o_ago = carve((agroups + 1) * 4);
     const size_t o_ahc = carve(((size_t)caps.max_clusters + kAssignPad) * kHitCache * 4);
     ctx->arena_bytes = off;
     e = hipMalloc((void **)&ctx->arena, ctx->arena_bytes);
@@ -352,6 +354,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->m_tile_payload = (Payload *)(a + o_mtp);
     ctx->m_chunk_sums = (uint32_t *)(a + o_mcs);
     ctx->c_chunk = (uint32_t *)(a + o_cc);
+    ctx->c_chunk_words = cchunks;
     ctx->a_view_lights = (float4 *)(a + o_avl);
     ctx->a_light_flags = (uint32_t *)(a + o_alf);
     ctx->a_counts = (uint32_t *)(a + o_acn);
@@ -363,6 +366,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->a_hit_cache = (uint32_t *)(a + o_ahc);
     ctx->a_coarse_counts = (uint32_t *)(a + o_acc);
     ctx->a_group_box = (float *)(a + o_agb);
+    ctx->a_group_order = (uint32_t *)(a + o_ago);
     ctx->a_coarse_seg = (uint32_t)aseg;
     ctx->g_counts = (uint32_t *)(a + o_gc);
     ctx->m_tickets = (uint32_t *)(a + o_tk);
@@ -1278,10 +1282,13 @@ int32_t orbit_depth_reduce(OrbitCtx *ctx, const float *depth, uint32_t sw, uint3
 }
 
 // ---------------------------------------------------------------- light_cluster
-int32_t orbit_cluster_mark(OrbitCtx *ctx, const OrbitMarkActivePush *push, const float *depth,
-                           uint32_t *tile_depth_slice_mask, OrbitClusterDepthBounds *depth_bounds, void *stream) {
-    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+// The three stages behind their entry points (ctx->mu held).  `count_chunks`: the mark launch also takes the
+// compaction's chunk counts (orbit_compute_clusters; the words are zero: cleared at creation and by every assignment
+// that follows a counting mark); `counted`: the compaction finds them there; `clear_counts`: the assignment's first
+// launch clears them again.
+static int32_t cluster_mark_locked(OrbitCtx *ctx, const OrbitMarkActivePush *push, const float *depth,
+                                   uint32_t *tile_depth_slice_mask, OrbitClusterDepthBounds *depth_bounds, bool count_chunks,
+                                   void *stream) {
     if (!push || !depth || !tile_depth_slice_mask || !depth_bounds)
         return fail(ctx, ORBIT_E_MISSING, "cluster_mark: NULL argument");
     if (push->cluster_count[2] > 32 || push->tile_size_px == 0 || push->depth_buffer_sample_count == 0)
@@ -1292,39 +1299,43 @@ int32_t orbit_cluster_mark(OrbitCtx *ctx, const OrbitMarkActivePush *push, const
     p.depth = depth;
     p.masks = tile_depth_slice_mask;
     p.bounds = depth_bounds;
+    p.chunk_counts = count_chunks ? ctx->c_chunk + ctx->c_chunk_words : nullptr;
     hipError_t e = launch_cluster_mark(p, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch cluster_mark");
     return ORBIT_OK;
 }
 
-int32_t orbit_cluster_compact(OrbitCtx *ctx, const uint32_t cluster_count[3], const uint32_t *masks,
-                              void *unique_cluster_buffer, uint32_t index_capacity, void *stream) {
-    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+static int32_t cluster_compact_check(OrbitCtx *ctx, const uint32_t cluster_count[3], const uint32_t *masks,
+                                     void *unique_cluster_buffer) {
     if (!cluster_count || !masks || !unique_cluster_buffer)
         return fail(ctx, ORBIT_E_MISSING, "cluster_compact: NULL argument");
     const uint64_t total = (uint64_t)cluster_count[0] * cluster_count[1] * cluster_count[2];
     if (cluster_count[2] > 32 || total > ctx->caps.max_clusters)
         return fail(ctx, ORBIT_E_CAPACITY, "cluster grid %ux%ux%u exceeds caps.max_clusters %u or 32 slices",
                     cluster_count[0], cluster_count[1], cluster_count[2], ctx->caps.max_clusters);
+    return ORBIT_OK;
+}
+
+static int32_t cluster_compact_locked(OrbitCtx *ctx, const uint32_t cluster_count[3], const uint32_t *masks,
+                                      void *unique_cluster_buffer, uint32_t index_capacity, bool counted, void *stream) {
+    const int32_t rc = cluster_compact_check(ctx, cluster_count, masks, unique_cluster_buffer);
+    if (rc != ORBIT_OK) return rc;
     ClusterCompactParams p;
     memcpy(p.cc, cluster_count, 12);
     p.masks = masks;
     p.unique = (uint8_t *)unique_cluster_buffer;
     p.index_capacity = index_capacity;
-    p.chunk_counts = ctx->c_chunk;
+    p.chunk_counts = counted ? ctx->c_chunk + ctx->c_chunk_words : ctx->c_chunk;
     p.status = ctx->status;
+    p.counted = counted;
     hipError_t e = launch_cluster_compact(p, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch cluster_compact");
     return ORBIT_OK;
 }
 
-int32_t orbit_cluster_assign(OrbitCtx *ctx, const OrbitClusterCullInfo *info, const void *unique_cluster_buffer,
-                             const OrbitClusterDepthBounds *depth_bounds, const OrbitLightData *lights,
-                             void *light_index_buffer, uint32_t light_index_capacity, uint32_t *cluster_offset_image,
-                             void *stream) {
-    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+static int32_t cluster_assign_check(OrbitCtx *ctx, const OrbitClusterCullInfo *info, const void *unique_cluster_buffer,
+                                    const OrbitClusterDepthBounds *depth_bounds, const OrbitLightData *lights,
+                                    void *light_index_buffer, uint32_t *cluster_offset_image) {
     if (!info || !unique_cluster_buffer || !depth_bounds || !light_index_buffer || !cluster_offset_image)
         return fail(ctx, ORBIT_E_MISSING, "cluster_assign: NULL argument");
     if (info->global_light_count > 0 && !lights) return fail(ctx, ORBIT_E_MISSING, "cluster_assign: lights is NULL");
@@ -1334,6 +1345,17 @@ int32_t orbit_cluster_assign(OrbitCtx *ctx, const OrbitClusterCullInfo *info, co
     const uint64_t total = (uint64_t)info->cluster_count[0] * info->cluster_count[1] * info->cluster_count[2];
     if (total > ctx->caps.max_clusters)
         return fail(ctx, ORBIT_E_CAPACITY, "cluster grid exceeds caps.max_clusters %u", ctx->caps.max_clusters);
+    return ORBIT_OK;
+}
+
+static int32_t cluster_assign_locked(OrbitCtx *ctx, const OrbitClusterCullInfo *info, const void *unique_cluster_buffer,
+                                     const OrbitClusterDepthBounds *depth_bounds, const OrbitLightData *lights,
+                                     void *light_index_buffer, uint32_t light_index_capacity, uint32_t *cluster_offset_image,
+                                     uint32_t clear_counts, void *stream) {
+    const int32_t rc = cluster_assign_check(ctx, info, unique_cluster_buffer, depth_bounds, lights, light_index_buffer,
+                                            cluster_offset_image);
+    if (rc != ORBIT_OK) return rc;
+    const uint64_t total = (uint64_t)info->cluster_count[0] * info->cluster_count[1] * info->cluster_count[2];
     ClusterAssignParams p;
     p.info = *info;
     p.unique = (const uint8_t *)unique_cluster_buffer;
@@ -1351,15 +1373,42 @@ int32_t orbit_cluster_assign(OrbitCtx *ctx, const OrbitClusterCullInfo *info, co
     p.hit_cache = ctx->a_hit_cache;
     p.coarse_counts = ctx->a_coarse_counts;
     p.group_box = ctx->a_group_box;
+    p.group_order = ctx->a_group_order;
     p.coarse_seg = ctx->a_coarse_seg;
     p.block_sums = ctx->a_block_sums;
     p.block_base = ctx->a_block_base;
     p.total = ctx->a_total;
+    p.zero_words = clear_counts ? ctx->c_chunk + ctx->c_chunk_words : nullptr;
+    p.zero_count = clear_counts;
     p.status = ctx->status;
     p.debug_tests = ctx->debug_cycles + 16;
     hipError_t e = launch_cluster_assign(p, ctx->num_cus, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch cluster_assign");
     return ORBIT_OK;
+}
+
+int32_t orbit_cluster_mark(OrbitCtx *ctx, const OrbitMarkActivePush *push, const float *depth,
+                           uint32_t *tile_depth_slice_mask, OrbitClusterDepthBounds *depth_bounds, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    return cluster_mark_locked(ctx, push, depth, tile_depth_slice_mask, depth_bounds, false, stream);
+}
+
+int32_t orbit_cluster_compact(OrbitCtx *ctx, const uint32_t cluster_count[3], const uint32_t *masks,
+                              void *unique_cluster_buffer, uint32_t index_capacity, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    return cluster_compact_locked(ctx, cluster_count, masks, unique_cluster_buffer, index_capacity, false, stream);
+}
+
+int32_t orbit_cluster_assign(OrbitCtx *ctx, const OrbitClusterCullInfo *info, const void *unique_cluster_buffer,
+                             const OrbitClusterDepthBounds *depth_bounds, const OrbitLightData *lights,
+                             void *light_index_buffer, uint32_t light_index_capacity, uint32_t *cluster_offset_image,
+                             void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    return cluster_assign_locked(ctx, info, unique_cluster_buffer, depth_bounds, lights, light_index_buffer,
+                                 light_index_capacity, cluster_offset_image, 0u, stream);
 }
 
 int32_t orbit_compute_clusters(OrbitCtx *ctx, const OrbitMarkActivePush *push, const OrbitClusterCullInfo *info,
@@ -1368,24 +1417,31 @@ int32_t orbit_compute_clusters(OrbitCtx *ctx, const OrbitMarkActivePush *push, c
                                uint32_t index_capacity, void *light_index_buffer, uint32_t light_index_capacity,
                                uint32_t *cluster_offset_image, void *stream) {
     if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
-    if (!push || !info) {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        return fail(ctx, ORBIT_E_MISSING, "compute_clusters: NULL parameter block");
-    }
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!push || !info) return fail(ctx, ORBIT_E_MISSING, "compute_clusters: NULL parameter block");
     for (int i = 0; i < 3; i++)
-        if (push->cluster_count[i] != info->cluster_count[i]) {
-            std::lock_guard<std::mutex> lock(ctx->mu);
+        if (push->cluster_count[i] != info->cluster_count[i])
             return fail(ctx, ORBIT_E_INVALID, "compute_clusters: cluster_count[%d] differs between push (%u) and info (%u)",
                         i, push->cluster_count[i], info->cluster_count[i]);
-        }
+    // Everything the later stages would refuse is refused before the first launch: the mark launch leaves the
+    // compaction's chunk counts behind, and only the assignment's first launch clears them again.
+    int32_t rc = cluster_compact_check(ctx, push->cluster_count, tile_depth_slice_mask, unique_cluster_buffer);
+    if (rc == ORBIT_OK)
+        rc = cluster_assign_check(ctx, info, unique_cluster_buffer, depth_bounds, lights, light_index_buffer, cluster_offset_image);
+    if (rc != ORBIT_OK) return rc;
     // stream order is the only dependency between the stages (cluster.rs:380-395)
-    int32_t rc = orbit_cluster_mark(ctx, push, depth, tile_depth_slice_mask, depth_bounds, stream);
-    if (rc != ORBIT_OK) return rc;
-    rc = orbit_cluster_compact(ctx, push->cluster_count, tile_depth_slice_mask, unique_cluster_buffer, index_capacity,
-                               stream);
-    if (rc != ORBIT_OK) return rc;
-    return orbit_cluster_assign(ctx, info, unique_cluster_buffer, depth_bounds, lights, light_index_buffer,
-                                light_index_capacity, cluster_offset_image, stream);
+    rc = cluster_mark_locked(ctx, push, depth, tile_depth_slice_mask, depth_bounds, true, stream);
+    if (rc != ORBIT_OK) return rc; // (refused before its launch: nothing was counted)
+    const uint32_t tiles = push->cluster_count[0] * push->cluster_count[1];
+    const uint32_t count_words = push->cluster_count[2] * ((tiles + 1023u) / 1024u);
+    rc = cluster_compact_locked(ctx, push->cluster_count, tile_depth_slice_mask, unique_cluster_buffer, index_capacity, true,
+                                stream);
+    if (rc == ORBIT_OK)
+        rc = cluster_assign_locked(ctx, info, unique_cluster_buffer, depth_bounds, lights, light_index_buffer,
+                                   light_index_capacity, cluster_offset_image, count_words, stream);
+    if (rc != ORBIT_OK) // a launch failed behind the counting mark: the words must not stay
+        (void)hipMemsetAsync(ctx->c_chunk + ctx->c_chunk_words, 0, (size_t)count_words * 4u, (hipStream_t)stream);
+    return rc;
 }
 
 // ------------------------------------------------------------------- multi-GPU

@@ -181,6 +181,9 @@ struct ClusterMarkParams {
     const float *depth;
     uint32_t *masks;
     OrbitClusterDepthBounds *bounds;
+    // orbit_compute_clusters: the launch also counts the active clusters per (z slice, chunk of 1024 tiles) — what the
+    // compaction's first launch computes from the masks — into these words (zero before the launch; nullptr: no counting)
+    uint32_t *chunk_counts;
 };
 
 struct ClusterCompactParams {
@@ -190,6 +193,7 @@ struct ClusterCompactParams {
     uint32_t index_capacity;
     uint32_t *chunk_counts; // cz * nchunks
     int32_t *status;
+    bool counted;           // chunk_counts already holds the counts (the mark launch took them): one launch
 };
 
 // light indices the count launch keeps per cluster (256 B of scratch per cluster of caps.max_clusters): the write launch
@@ -217,11 +221,14 @@ struct ClusterAssignParams {
     float *aabb;             // 6 floats per active cluster (compacted order), written by the coarse launch
     uint32_t *coarse;        // per group of 256 active clusters: 16 segments x coarse_seg candidate light indices
     uint32_t *coarse_counts; // 16 per group
-    float *group_box;        // 8 floats per group: union AABB (6), any-NaN flag, unused
+    float *group_box;        // 8 words per group: union AABB (6), any-NaN flag, unused
+    uint32_t *group_order;   // the groups in the order the count launch takes them (longest candidate lists first)
     uint32_t coarse_seg;     // capacity of one segment (= lights per wave of the coarse filter, a multiple of 64)
     uint32_t *block_sums;
     uint32_t *block_base;
     uint32_t *total;
+    uint32_t *zero_words;    // orbit_compute_clusters: the mark launch's chunk counts, cleared again by the first
+    uint32_t zero_count;     // launch here (consumed by then; nullptr / 0: nothing)
     int32_t *status;
     unsigned long long *debug_tests; // -DORBIT_TRIAGE builds: executed sphere-box tests per level (tools/cluster_tests.py)
 };

@@ -21,8 +21,7 @@
 //             hit ballots become popcounts in the count pass and
 //             ballot-ranked ordered writes in the write pass; ranges are
 //             allocated by prefix sum in compacted order.
-#include "kernels.h"
-#include "scan.h"
+#include "handoff.h"
 
 namespace orbit {
 
@@ -33,13 +32,16 @@ namespace {
 // and issues the first 64 depth loads of all of them before it evaluates any: the kernel is a short chain of
 // load -> log2 -> ballots -> stores per tile, so memory-level parallelism per wave is what shortens it.
 constexpr uint32_t kMarkTiles = 4;
+constexpr uint32_t kMarkWaves = 16; // 64 tiles per block: a quarter of the counting atomics of four-wave blocks
 
-__global__ __launch_bounds__(256) void cluster_mark_kernel(const ClusterMarkParams p) {
+__global__ __launch_bounds__(kMarkWaves * 64) void cluster_mark_kernel(const ClusterMarkParams p) {
+    __shared__ uint32_t s_zc[kMarkWaves][32]; // counting: per wave and z slice, how many of the wave's tiles are active in it
     const OrbitMarkActivePush &pc = p.pc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t cx = pc.cluster_count[0], cy = pc.cluster_count[1], cz = pc.cluster_count[2];
-    const uint32_t tile0 = (blockIdx.x * 4 + wave) * kMarkTiles;
-    if (tile0 >= cx * cy) return; // wave-uniform
+    const uint32_t tile0 = (blockIdx.x * kMarkWaves + wave) * kMarkTiles;
+    uint32_t zc = 0; // lane = z slice
+    if (tile0 < cx * cy) { // wave-uniform
     const uint32_t ts = pc.tile_size_px, sc = pc.depth_buffer_sample_count;
     const uint32_t W = pc.screen_size[0], H = pc.screen_size[1];
     const uint32_t items = ts * ts * sc;
@@ -106,6 +108,23 @@ __global__ __launch_bounds__(256) void cluster_mark_kernel(const ClusterMarkPara
             p.bounds[tile + (size_t)lane * cx * cy] = b;
         }
         if (lane == 0) p.masks[tile] = tile_mask;
+        zc += (uint32_t)lane < cz ? (tile_mask >> (lane & 31)) & 1u : 0u; // cluster_common.glsl:31-34
+    }
+    }
+    if (p.chunk_counts == nullptr) return; // (uniform)
+    // the block's 64 consecutive tiles lie in one chunk of 1024: one atomic per z slice the block is active in — a
+    // handful, the tiles of a block see neighbouring depths — on the word of (slice, chunk).  (Atomics on one 128-B line
+    // queue in its L2 channel at ~4 ns each: four-wave blocks, 16 tiles, cost the launch 2 us at config 4.)
+    static_assert(1024 % (kMarkWaves * kMarkTiles) == 0, "a block's tiles share a compaction chunk");
+    if (lane < 32) s_zc[wave][lane] = zc;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kMarkWaves; w++) sum += s_zc[w][threadIdx.x];
+        const uint32_t nchunks = (cx * cy + 1023u) / 1024u, chunk = blockIdx.x * (kMarkWaves * kMarkTiles) / 1024u;
+        if (sum != 0u)
+            (void)__hip_atomic_fetch_add(p.chunk_counts + threadIdx.x * nchunks + chunk, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -319,11 +338,53 @@ __global__ __launch_bounds__(256) void cluster_aabb_kernel(const ClusterAssignPa
     }
     const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.unique);
     const uint32_t n = min(hdr[3], p.max_clusters);
-    // what the count launch accumulates into: the number of its heavy blocks, and (below) the sums of the chunks
-    if (blockIdx.x == prepare_blocks && threadIdx.x == 0) p.total[0] = 0u;
+    if (blockIdx.x == prepare_blocks) { // the launch's housekeeping block
+        // what the count launch accumulates into: the number of its heavy blocks (and, per group below, the chunks' sums);
+        // the chunk counts a counting mark launch left (the compaction has read them)
+        if (threadIdx.x == 0) p.total[0] = 0u;
+        for (uint32_t k = threadIdx.x; k < p.zero_count; k += 256u) p.zero_words[k] = 0u;
+        // The order the count launch takes the groups in: longest candidate lists first.  That launch lasts as long as
+        // its last block, a block's time grows with its group's list, and in compacted order the long ones come
+        // wherever the lights are (config 4: the one group with 1 099 candidates started 9 us into the launch and ended
+        // it at 22).  A scheduling hint only — any permutation gives the same lists — so it is taken from what is at
+        // hand now: the segment counts the PREVIOUS assignment's coarse launch left (this one's rewrites them two
+        // launches on).  Three classes by the group's total, stable within a class; one packed scan places all three.
+        __shared__ uint32_t s_scan[4 + 1];
+        const uint32_t groups = (n + kGroupClusters - 1u) / kGroupClusters;
+        auto cls = [&](uint32_t g) -> uint32_t { // 0: > 512 candidates, 1: > 128, 2: the rest
+            const uint4 *c = reinterpret_cast<const uint4 *>(p.coarse_counts + (size_t)g * kCoarseSegs);
+            uint32_t t = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kCoarseSegs / 4; j++) t += (c[j].x + c[j].y) + (c[j].z + c[j].w);
+            return t > 512u ? 0u : t > 128u ? 1u : 2u;
+        };
+        uint32_t base[3] = {0u, 0u, 0u}; // where each class begins, then how far it has been filled
+        const uint32_t c_first = threadIdx.x < groups ? cls(threadIdx.x) : 3u; // (kept for the first round below)
+        {
+            uint32_t c0 = c_first == 0u ? 1u : 0u, c1 = c_first == 1u ? 1u : 0u;
+            for (uint32_t g = 256u + threadIdx.x; g < groups; g += 256u) {
+                const uint32_t c = cls(g);
+                c0 += c == 0u ? 1u : 0u, c1 += c == 1u ? 1u : 0u;
+            }
+            uint32_t t0, t1;
+            (void)block_exclusive_scan<4>(c0, s_scan, &t0);
+            (void)block_exclusive_scan<4>(c1, s_scan, &t1);
+            base[1] = t0, base[2] = t0 + t1;
+        }
+        for (uint32_t g0 = 0; g0 < groups; g0 += 256u) { // block-uniform trip count
+            const uint32_t g = g0 + threadIdx.x;
+            const uint32_t c = g0 == 0u ? c_first : (g < groups ? cls(g) : 3u);
+            uint32_t tot; // 10 bits per class: at most 256 flags each
+            const uint32_t ex = block_exclusive_scan<4>(c < 3u ? 1u << (10u * c) : 0u, s_scan, &tot);
+            if (c < 3u) p.group_order[base[c] + ((ex >> (10u * c)) & 1023u)] = g;
+#pragma unroll
+            for (uint32_t k = 0; k < 3u; k++) base[k] += (tot >> (10u * k)) & 1023u;
+        }
+        return;
+    }
     // grid-stride over the groups that exist (n is only known on the device; a grid sized by the capacity would
     // spend its time launching empty blocks)
-    for (uint32_t grp = blockIdx.x - prepare_blocks; grp * kGroupClusters < n; grp += gridDim.x - prepare_blocks) {
+    for (uint32_t grp = blockIdx.x - prepare_blocks - 1u; grp * kGroupClusters < n; grp += gridDim.x - prepare_blocks - 1u) {
     const uint32_t first = grp * kGroupClusters;
     static_assert(kScanChunk % kGroupClusters == 0, "a chunk of the offsets' sums is whole groups");
     if (threadIdx.x == 0 && first % kScanChunk == 0u) p.block_sums[(size_t)(first / kScanChunk) * kChunkSumStride] = 0u;
@@ -548,9 +609,25 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
     uint32_t heavy_i = WRITE ? blockIdx.x - place_blocks : 0u;
     const uint32_t beyond = (p.max_clusters / kClustersPerBlock + 1u) * kClustersPerBlock; // >= n, inside the scratch padding
     auto heavy_at = [&](uint32_t i) { return i < heavy_n ? min(p.block_base[i] * kClustersPerBlock, beyond) : beyond; };
-    for (uint32_t block_first = WRITE ? heavy_at(heavy_i) : blockIdx.x * kClustersPerBlock;;
-         block_first = WRITE ? heavy_at(heavy_i += gridDim.x - place_blocks) : block_first + gridDim.x * kClustersPerBlock) {
-    if (!first_item && block_first >= n) break;
+    // count launch: the blocks of the groups with the longest candidate lists first (p.group_order, cluster_coarse_kernel):
+    // linear item L = rank of the group * 32 + block of the group.  An entry past the groups that exist is an old one:
+    // a valid group index, used for nothing once n is known.
+    constexpr uint32_t kGroupBlocks = kGroupClusters / kClustersPerBlock;
+    uint32_t item = blockIdx.x;
+    auto count_at = [&](uint32_t L) {
+        return p.group_order[min(L / kGroupBlocks, p.max_clusters / kGroupClusters)] * kGroupClusters + (L % kGroupBlocks) * kClustersPerBlock;
+    };
+    uint32_t next_first = WRITE ? 0u : count_at(item);
+    for (uint32_t block_first = WRITE ? heavy_at(heavy_i) : next_first;;
+         block_first = WRITE ? heavy_at(heavy_i += gridDim.x - place_blocks) : next_first) {
+    if (!WRITE) {
+        if (!first_item && item >= (n + kGroupClusters - 1u) / kGroupClusters * kGroupBlocks) break;
+        item += gridDim.x;
+        next_first = count_at(item); // (in flight while this item is worked on)
+        if (!first_item && block_first >= n) continue; // the last group's blocks beyond n
+    } else if (!first_item && block_first >= n) {
+        break;
+    }
     const uint32_t u0 = block_first + wave * kClustersPerWave;
     const uint32_t group = block_first / kGroupClusters;
     const uint32_t *cbase = p.coarse + (size_t)group * kCoarseSegs * p.coarse_seg;
@@ -589,7 +666,12 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
     if (first_item) {
         n = min(n_raw, p.max_clusters);
         first_item = false;
-        if (block_first >= n) break;
+        if (WRITE) {
+            if (block_first >= n) break;
+        } else {
+            if (item - gridDim.x >= (n + kGroupClusters - 1u) / kGroupClusters * kGroupBlocks) break;
+            if (block_first >= n) continue;
+        }
     }
     const bool owns = lane < kClustersPerWave && u0 + lane < n;
     if (wave == 0) { // exclusive prefix of the 16 segment counts (wave scan); fast = no segment longer than a wave
@@ -836,8 +918,8 @@ __global__ void write_word(uint32_t *p, uint32_t v) { *p = v; }
 hipError_t launch_cluster_mark(const ClusterMarkParams &p, hipStream_t s) {
     const uint32_t tiles = p.pc.cluster_count[0] * p.pc.cluster_count[1];
     if (tiles == 0) return hipSuccess;
-    const uint32_t per_block = 4 * kMarkTiles;
-    hipLaunchKernelGGL(cluster_mark_kernel, dim3((tiles + per_block - 1) / per_block), dim3(256), 0, s, p);
+    const uint32_t per_block = kMarkWaves * kMarkTiles;
+    hipLaunchKernelGGL(cluster_mark_kernel, dim3((tiles + per_block - 1) / per_block), dim3(kMarkWaves * 64), 0, s, p);
     return hipGetLastError();
 }
 
@@ -849,9 +931,11 @@ hipError_t launch_cluster_compact(const ClusterCompactParams &p, hipStream_t s) 
         hipLaunchKernelGGL(write_word, dim3(1), dim3(1), 0, s, reinterpret_cast<uint32_t *>(p.unique) + 3, 0u);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(cluster_compact_kernel<false>, dim3(nchunks, cz), dim3(1024), 0, s, p);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (!p.counted) {
+        hipLaunchKernelGGL(cluster_compact_kernel<false>, dim3(nchunks, cz), dim3(1024), 0, s, p);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(cluster_compact_kernel<true>, dim3(nchunks, cz), dim3(1024), 0, s, p);
     return hipGetLastError();
 }
@@ -867,7 +951,7 @@ hipError_t launch_cluster_assign(const ClusterAssignParams &p, uint32_t num_cus,
     // and the kernels stride over the work that exists
     const uint32_t groups = (p.max_clusters + kGroupClusters - 1) / kGroupClusters;
     const uint32_t blocks = min((p.max_clusters + kClustersPerBlock - 1) / kClustersPerBlock, num_cus * 32u);
-    hipLaunchKernelGGL(cluster_aabb_kernel, dim3(prepare_blocks + min(groups, num_cus * 4u)), dim3(256), 0, s, p, prepare_blocks);
+    hipLaunchKernelGGL(cluster_aabb_kernel, dim3(prepare_blocks + 1u + min(groups, num_cus * 4u)), dim3(256), 0, s, p, prepare_blocks);
     hipLaunchKernelGGL(cluster_coarse_kernel, dim3(min(groups * kCoarseSplit, num_cus * 8u)), dim3(256), 0, s, p);
     hipLaunchKernelGGL(cluster_assign_kernel<false>, dim3(blocks), dim3(kAssignWaves * 64), 0, s, p, 0u);
     hipError_t e = hipGetLastError();
