@@ -76,7 +76,7 @@ struct OrbitCtx {
     uint32_t *x_block_pop = nullptr; // orbit_expand_visible_records: survivors per 1024 records of the list
     uint32_t *c_chunk = nullptr; // compact: its own chunk counts | the ones a counting mark launch left (c_chunk_words each)
     size_t c_chunk_words = 0;
-    float4 *a_view_lights = nullptr;
+    float4 *a_view_lights = nullptr, *a_coarse_lights = nullptr;
     uint32_t *a_light_flags = nullptr, *a_counts = nullptr, *a_block_sums = nullptr, *a_block_base = nullptr,
              *a_total = nullptr, *a_coarse = nullptr, *a_coarse_counts = nullptr, *a_hit_cache = nullptr;
     float *a_aabb = nullptr, *a_group_box = nullptr;
@@ -325,7 +325,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t agroups = (size_t)caps.max_clusters / 256 + 1;
     const size_t aseg = (((size_t)caps.max_lights + 15) / 16 + 63) / 64 * 64;
     const size_t o_aab = carve(((size_t)caps.max_clusters + kAssignPad) * 6 * 4);
-    const size_t o_aco = carve(agroups * 16 * aseg * 4), o_acc = carve(agroups * 16 * 4), o_agb = carve(agroups * 32), o_ago = carve((agroups + 1) * 4);
+    const size_t o_aco = carve(agroups * 16 * aseg * 4), o_acl = carve(agroups * 16 * aseg * 16), o_acc = carve(agroups * 16 * 4), o_agb = carve(agroups * 32), o_ago = carve((agroups + 1) * 4);
     const size_t o_ahc = carve(((size_t)caps.max_clusters + kAssignPad) * kHitCache * 4);
     ctx->arena_bytes = off;
     e = hipMalloc((void **)&ctx->arena, ctx->arena_bytes);
@@ -363,6 +363,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->a_total = (uint32_t *)(a + o_at);
     ctx->a_aabb = (float *)(a + o_aab);
     ctx->a_coarse = (uint32_t *)(a + o_aco);
+    ctx->a_coarse_lights = (float4 *)(a + o_acl);
     ctx->a_hit_cache = (uint32_t *)(a + o_ahc);
     ctx->a_coarse_counts = (uint32_t *)(a + o_acc);
     ctx->a_group_box = (float *)(a + o_agb);
@@ -1370,6 +1371,7 @@ static int32_t cluster_assign_locked(OrbitCtx *ctx, const OrbitClusterCullInfo *
     p.counts = ctx->a_counts;
     p.aabb = ctx->a_aabb;
     p.coarse = ctx->a_coarse;
+    p.coarse_lights = ctx->a_coarse_lights;
     p.hit_cache = ctx->a_hit_cache;
     p.coarse_counts = ctx->a_coarse_counts;
     p.group_box = ctx->a_group_box;

@@ -220,6 +220,7 @@ struct ClusterAssignParams {
     uint32_t *hit_cache;     // per active cluster: its first kHitCache light indices, kept by the counting launch
     float *aabb;             // 6 floats per active cluster (compacted order), written by the coarse launch
     uint32_t *coarse;        // per group of 256 active clusters: 16 segments x coarse_seg candidate light indices
+    float4 *coarse_lights;   // ... and, slot for slot, the candidates' view-space lights (no gather in the count launch)
     uint32_t *coarse_counts; // 16 per group
     float *group_box;        // 8 words per group: union AABB (6), any-NaN flag, unused
     uint32_t *group_order;   // the groups in the order the count launch takes them (longest candidate lists first)

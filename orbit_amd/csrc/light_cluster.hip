@@ -457,6 +457,7 @@ __global__ __launch_bounds__(256) void cluster_coarse_kernel(const ClusterAssign
     const uint32_t nl = p.info.global_light_count, seg = p.coarse_seg;
     const uint32_t sidx = (vb % kCoarseSplit) * 4 + wave;
     uint32_t *out = p.coarse + ((size_t)group * kCoarseSegs + sidx) * seg;
+    float4 *out_l = p.coarse_lights + ((size_t)group * kCoarseSegs + sidx) * seg; // the candidate itself beside its index
     uint32_t cnt = 0;
     [[maybe_unused]] uint32_t tested = 0;
     const uint32_t begin = sidx * seg, end = min(begin + seg, nl);
@@ -476,7 +477,11 @@ __global__ __launch_bounds__(256) void cluster_coarse_kernel(const ClusterAssign
             const bool point = (pt >> r) & 1u;
             const bool pass = li < end && (!point || un.any_nan || sphere_hits(un.box, l[r]));
             const uint64_t m = __ballot(pass);
-            if (pass) out[cnt + lane_prefix(m)] = li | (point ? 0u : kNotPoint);
+            if (pass) {
+                const uint32_t pos = cnt + lane_prefix(m);
+                out[pos] = li | (point ? 0u : kNotPoint);
+                out_l[pos] = l[r];
+            }
             cnt += (uint32_t)__popcll(m);
 #ifdef ORBIT_TRIAGE
             tested += (uint32_t)__popcll(__ballot(li < end && point && !un.any_nan));
@@ -562,6 +567,130 @@ __device__ __forceinline__ void cluster_place_body(const ClusterAssignParams &p,
     }
 }
 
+// ---- the count launch's item for ONE wave (see cluster_assign_kernel): eight clusters, lane c < 8 holds cluster c
+constexpr uint32_t kWaveSpec = 8;              // candidates per coarse segment this path handles (fetched speculatively)
+constexpr uint32_t kWaveClusters = kClustersPerBlock;
+struct WaveItem {
+    uint32_t ci;       // lanes 0..7: the cluster's index in the grid
+    float lo[3], hi[3]; // ... its AABB
+    uint32_t tag[2];   // round r: entry (lane & 7) of segment 8 r + (lane >> 3) — segments ascending = light order
+    float4 l[2];
+};
+
+__device__ __forceinline__ void wave_item_loads(const ClusterAssignParams &p, WaveItem &w, uint32_t block_first,
+                                                const uint32_t *unique_idx, const uint32_t *cbase, const float4 *clbase, int lane) {
+    static_assert(kWaveClusters == 8 && kCoarseSegs == 16 && kWaveSpec == 8, "lane = (segment of the round, entry) = (lane >> 3, lane & 7)");
+    const uint32_t ul = min(block_first + ((uint32_t)lane & (kWaveClusters - 1)), p.max_clusters - 1u);
+    w.ci = unique_idx[ul];
+#pragma unroll
+    for (int i = 0; i < 3; i++) w.lo[i] = p.aabb[6 * (size_t)ul + i], w.hi[i] = p.aabb[6 * (size_t)ul + 3 + i];
+#pragma unroll
+    for (uint32_t r = 0; r < 2; r++) {
+        const uint32_t slot = (r * 8u + ((uint32_t)lane >> 3)) * p.coarse_seg + ((uint32_t)lane & 7u);
+        w.tag[r] = cbase[slot];
+        w.l[r] = clbase[slot];
+    }
+}
+
+__device__ __forceinline__ void wave_item(const ClusterAssignParams &p, const WaveItem &w, uint32_t block_first, uint32_t n,
+                                          uint32_t seg_counts, float4 *s_cand, uint32_t *s_cand_idx, float *s_box, int lane) {
+    const bool owns = lane < (int)kWaveClusters && block_first + (uint32_t)lane < n;
+    const float inf = __uint_as_float(0x7f800000u);
+    // the eight boxes: absent cluster = the empty box, neutral in the union; union by a butterfly over lanes 0..7
+    float lo[3], hi[3];
+    bool nan = false;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        lo[i] = owns ? w.lo[i] : inf, hi[i] = owns ? w.hi[i] : -inf;
+        nan = nan || lo[i] != lo[i] || hi[i] != hi[i];
+    }
+    BoxUnion un;
+    un.any_nan = (__ballot(nan) & 0xFFull) != 0ull; // (then the filter is bypassed: what the selects make of a NaN does not matter)
+    // every cluster's box where the test loop reads it with uniform addresses (LDS broadcasts; 48 scalar registers
+    // held across the loop spilled), and the union by a butterfly over lanes 0..7
+    if (lane < (int)kWaveClusters) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) s_box[lane * 8 + i] = lo[i], s_box[lane * 8 + 4 + i] = hi[i];
+    }
+#pragma unroll
+    for (int d = (int)kWaveClusters / 2; d >= 1; d >>= 1) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float ol = __shfl_xor(lo[i], d, 64), oh = __shfl_xor(hi[i], d, 64);
+            lo[i] = ol < lo[i] ? ol : lo[i];
+            hi[i] = oh > hi[i] ? oh : hi[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        un.box.mn[i] = __uint_as_float(__builtin_amdgcn_readfirstlane((int)__float_as_uint(lo[i])));
+        un.box.mx[i] = __uint_as_float(__builtin_amdgcn_readfirstlane((int)__float_as_uint(hi[i])));
+    }
+    // filter: two rounds of 8 segments x 8 entries, survivors appended to the wave's LDS list in lane order = light order
+    uint32_t total = 0;
+    [[maybe_unused]] uint32_t n_filter = 0, n_test = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < 2; r++) {
+        const uint32_t cnt = (uint32_t)__shfl((int)seg_counts, (int)(r * 8u + ((uint32_t)lane >> 3)), 64);
+        const bool have = ((uint32_t)lane & 7u) < cnt;
+        const bool point = (w.tag[r] & kNotPoint) == 0u;
+        const bool pass = have && (!point || un.any_nan || sphere_hits(un.box, w.l[r]));
+        const uint64_t m = __ballot(pass);
+#ifdef ORBIT_TRIAGE
+        n_filter += (uint32_t)__popcll(__ballot(have && point && !un.any_nan));
+#endif
+        if (pass) {
+            const uint32_t pos = total + lane_prefix(m);
+            s_cand[pos] = w.l[r];
+            s_cand_idx[pos] = w.tag[r];
+        }
+        total += (uint32_t)__popcll(m);
+    }
+    wave_lds_fence();
+    // test: lane = candidate, against the eight boxes in turn (a rolled loop: unrolled, the compiler hoists all 48 box
+    // words out of the candidate loop and spills); lane c keeps cluster c's count; the first kHitCache hits of a
+    // cluster are kept for the write launch
+    uint32_t mine = 0;
+    for (uint32_t b0 = 0; b0 < total; b0 += 64u) { // (at most two trips)
+        const uint32_t k = b0 + (uint32_t)lane;
+        const bool in_list = k < total;
+        const float4 cl = s_cand[in_list ? k : 0u];
+        const uint32_t ctag = s_cand_idx[in_list ? k : 0u];
+        const bool point = (ctag & kNotPoint) == 0u;
+#ifdef ORBIT_TRIAGE
+        n_test += (uint32_t)__popcll(__ballot(in_list && point)) * kWaveClusters;
+#endif
+#pragma unroll 1
+        for (uint32_t c = 0; c < kWaveClusters; c++) {
+            if (block_first + c >= n) break; // wave-uniform
+            Aabb3 a;
+#pragma unroll
+            for (int i = 0; i < 3; i++) a.mn[i] = s_box[c * 8u + i], a.mx[i] = s_box[c * 8u + 4u + i];
+            const uint64_t m = __ballot(in_list && (!point || sphere_hits(a, cl))); // :108-119
+            if (m == 0ull) continue; // wave-uniform
+            const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)c);
+            if (before < kHitCache && ((m >> lane) & 1ull)) {
+                const uint32_t slot = before + lane_prefix(m);
+                if (slot < kHitCache) p.hit_cache[(size_t)(block_first + c) * kHitCache + slot] = ctag & ~kNotPoint;
+            }
+            mine += (uint32_t)lane == c ? (uint32_t)__popcll(m) : 0u;
+        }
+    }
+    ORBIT_COUNT_TESTS(2, n_filter);
+    ORBIT_COUNT_TESTS(3, n_test);
+    const uint32_t capped = owns ? min(mine, ORBIT_MAX_LIGHTS_PER_CLUSTER) : 0u; // :135
+    if (owns) p.counts[block_first + (uint32_t)lane] = capped;
+    const uint32_t block_total = wave_reduce_add(capped);
+    const bool heavy = __ballot(capped > kHitCache) != 0ull;
+    if (lane == 0) { // as the four-wave path does at its end
+        if (block_total != 0u)
+            (void)__hip_atomic_fetch_add(p.block_sums + (size_t)(block_first / kScanChunk) * kChunkSumStride, block_total,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (heavy)
+            p.block_base[__hip_atomic_fetch_add(p.total, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = block_first / kClustersPerBlock;
+    }
+}
+
 #ifndef ORBIT_ASSIGN_WAVES // five waves per SIMD: five blocks per CU resident (96 registers; the count launch is its blocks' latencies)
 #define ORBIT_ASSIGN_WAVES __attribute__((amdgpu_waves_per_eu(5)))
 #endif
@@ -574,7 +703,8 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
     }
     __shared__ float4 s_cand[kLightTile];       // a segment per wave: view-space light ...
     __shared__ uint32_t s_cand_idx[kLightTile]; // ... and its index | kNotPoint
-    __shared__ float s_wbox[kAssignWaves][8];   // per wave: union of its clusters' boxes (6) and its any-NaN flag
+    __shared__ float s_wbox[kWaveClusters][8];  // per wave: union of its clusters' boxes (6) and its any-NaN flag (one-wave
+                                                // items: the eight clusters' boxes)
     __shared__ uint32_t s_wave_cnt[kAssignWaves];
     __shared__ uint32_t s_cpre[kCoarseSegs + 1]; // prefix of the group's segment counts
     __shared__ uint32_t s_ccnt[kCoarseSegs];     // the counts themselves
@@ -586,6 +716,14 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
     // block b; the end stamp is taken behind a wait for the block's own stores (tools/cluster_tests.py)
     const unsigned long long t_begin = wall_clock64();
     unsigned long long dbg_filtered = 0, dbg_ctotal = 0;
+    unsigned long long dbg_phase = 0; // the first item's phases, 16 bits each, in 10-ns ticks from t_begin (thread 0's view):
+    uint32_t dbg_phases = 0;          // setup loads consumed | boxes united (barrier) | candidates filtered (barrier) | tested
+#define ORBIT_PHASE_STAMP()                                                                                          \
+    do {                                                                                                             \
+        if (dbg_phases < 4u) dbg_phase |= ((wall_clock64() - t_begin) & 0xFFFFull) << (16u * dbg_phases), dbg_phases++; \
+    } while (0)
+#else
+#define ORBIT_PHASE_STAMP() ((void)0)
 #endif
     const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.unique);
     const uint32_t *unique_idx = reinterpret_cast<const uint32_t *>(p.unique + ORBIT_COMPACT_HEADER);
@@ -631,6 +769,35 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
     const uint32_t u0 = block_first + wave * kClustersPerWave;
     const uint32_t group = block_first / kGroupClusters;
     const uint32_t *cbase = p.coarse + (size_t)group * kCoarseSegs * p.coarse_seg;
+    const float4 *clbase = p.coarse_lights + (size_t)group * kCoarseSegs * p.coarse_seg; // (the lights, slot for slot)
+    if (!WRITE) {
+        // Most blocks are light work — ten coarse candidates in their group at the median, a hundred at the 90th
+        // percentile, three behind the block's own filter (config 4) — and the launch is bound by the instructions its
+        // waves issue, not by their loads: four waves that each set up, unite boxes, filter a quarter of ten candidates
+        // and walk four LDS segments to test two clusters spend four times the instructions of one wave doing all of
+        // it.  So when no segment of the group holds more than kWaveSpec candidates, wave 0 takes the block's eight
+        // clusters alone and the other waves leave the item (no barrier anywhere on this path).  Longer lists take the
+        // four waves together, below.
+        if (first_item) {
+            n = min(n_raw, p.max_clusters);
+            first_item = false;
+            if (item - gridDim.x >= (n + kGroupClusters - 1u) / kGroupClusters * kGroupBlocks) break;
+            if (block_first >= n) continue;
+        }
+        const uint32_t seg_counts = p.coarse_counts[(size_t)group * kCoarseSegs + ((uint32_t)lane & (kCoarseSegs - 1))];
+        if (__ballot(seg_counts > kWaveSpec) == 0ull) { // wave-uniform, and the same in all four waves
+            if (wave == 0) {
+                ORBIT_PHASE_STAMP();
+                // (fetched only now: issued beside the counts these loads were measured no faster — 62.8 against 62.0 us
+                // for the chain — and their registers, live across the branch, spill under this kernel's budget)
+                WaveItem wi;
+                wave_item_loads(p, wi, block_first, unique_idx, cbase, clbase, lane);
+                wave_item(p, wi, block_first, n, seg_counts, s_cand, s_cand_idx, &s_wbox[0][0], lane);
+                ORBIT_PHASE_STAMP();
+            }
+            continue;
+        }
+    }
     // ---- round trip 1: everything addressed by the block's position alone
     const uint32_t ul = min(u0 + ((uint32_t)lane & (kClustersPerWave - 1)), p.max_clusters - 1u); // lanes 0 .. kClustersPerWave - 1 count
     uint32_t my_ci = unique_idx[ul];
@@ -659,9 +826,15 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
         my_offset = wave_reduce_add(part) + (wave_inclusive_scan(mine) - mine);
     }
     uint32_t tag[kLoads];
-    if (!WRITE) {
-#pragma unroll
-        for (uint32_t r = 0; r < kLoads; r++) tag[r] = cbase[(size_t)(wave * kLoads + r) * p.coarse_seg + (uint32_t)lane];
+    float4 l[kLoads];
+    // speculative: the first kSpec (16) entries of the wave's four segments, one per lane (lane = segment * 16 + entry)
+    // — a block's group has ten candidates at the median and a hundred at the 90th percentile (config 4), a few per
+    // segment; groups with a longer segment fetch theirs once the counts are known
+    constexpr uint32_t kSpec = 64u / kLoads;
+    const uint32_t spec_seg = wave * kLoads + (uint32_t)lane / kSpec, spec_entry = (uint32_t)lane % kSpec;
+    if (!WRITE) { // (in the first of the four register sets the other paths fill)
+        tag[0] = cbase[spec_seg * p.coarse_seg + spec_entry];
+        l[0] = clbase[spec_seg * p.coarse_seg + spec_entry];
     }
     if (first_item) {
         n = min(n_raw, p.max_clusters);
@@ -679,9 +852,10 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
         const uint32_t inc = wave_inclusive_scan(v);
         if (lane < (int)kCoarseSegs) s_cpre[lane] = inc - v, s_ccnt[lane] = v;
         if (lane == (int)kCoarseSegs - 1) s_cpre[kCoarseSegs] = inc;
-        const bool lng = __ballot(v > 64u) != 0ull;
-        if (lane == 0) s_fast = lng ? 0u : 1u;
+        const bool lng = __ballot(v > 64u) != 0ull, mid = __ballot(v > kSpec) != 0ull;
+        if (lane == 0) s_fast = lng ? 0u : mid ? 1u : 2u; // 2: every segment within the speculative fetch
     }
+    ORBIT_PHASE_STAMP();
     // absent cluster: the empty box, neutral in the union
     {
         const float inf = __uint_as_float(0x7f800000u);
@@ -730,6 +904,7 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
         }
     }
     __syncthreads();
+    ORBIT_PHASE_STAMP();
     BoxUnion un;
     un.any_nan = false;
     {
@@ -743,19 +918,20 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
         un.any_nan = un.any_nan || s_wbox[w][6] != 0.0f;
     }
     const uint32_t ctotal = s_cpre[kCoarseSegs];
-    const bool fast = !WRITE && s_fast != 0u; // block-uniform
+    const bool fast = !WRITE && s_fast != 0u, spec = !WRITE && s_fast == 2u; // block-uniform
     [[maybe_unused]] uint32_t n_filter = 0, n_test = 0;
     ORBIT_MAX_TESTS(7, ctotal);
 
-    float4 l[kLoads];
     bool have[kLoads];
     // One step: the wave filters its (up to) kSeg candidates {tag, l, have} into LDS segment `wave`, in light order
     // (filter_step); then, behind a barrier, every wave tests its clusters against the four segments in order
     // (test_step).
+    uint32_t filter_rounds = kLoads; // (block-uniform; 1: the speculative fetch, whose one round holds all four segments)
     auto filter_step = [&]() {
         uint32_t seg_n = 0; // wave-uniform
 #pragma unroll
         for (uint32_t r = 0; r < kLoads; r++) {
+            if (r >= filter_rounds) break;
             const bool point = (tag[r] & kNotPoint) == 0u;
             const bool pass = have[r] && (!point || un.any_nan || sphere_hits(un.box, l[r]));
             const uint64_t m = __ballot(pass);
@@ -820,26 +996,35 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
         }
     };
     if (fast) {
-        // ---- round trip 2: the lights of the speculatively fetched candidates (an entry past its segment's count
-        // is a stale index of an earlier call: never used)
+        if (spec) {
+            // no second round trip: the candidates came with their lights (an entry past its segment's count is a stale
+            // one of an earlier call: never used).  One filter round: lanes in segment order = light order.
+            have[0] = spec_entry < s_ccnt[spec_seg];
+            filter_rounds = 1u;
+        } else {
+            // segments of up to 64: one step, fetched now that the counts are known (index and light, slot for slot)
 #pragma unroll
-        for (uint32_t r = 0; r < kLoads; r++) {
-            have[r] = (uint32_t)lane < s_ccnt[wave * kLoads + r];
-            tag[r] = have[r] ? tag[r] : 0u; // one address for the lanes without a candidate
-            l[r] = p.view_lights[tag[r] & ~kNotPoint];
+            for (uint32_t r = 0; r < kLoads; r++) {
+                have[r] = (uint32_t)lane < s_ccnt[wave * kLoads + r];
+                const uint32_t slot = (wave * kLoads + r) * p.coarse_seg + (have[r] ? (uint32_t)lane : 0u); // (< 16 segments of caps.max_lights / 16)
+                tag[r] = cbase[slot];
+                l[r] = clbase[slot];
+            }
         }
         filter_step();
         __syncthreads(); // all segments complete
+        ORBIT_PHASE_STAMP();
         test_step();
+        ORBIT_PHASE_STAMP();
     } else {
         // The group's candidates in light order = its coarse segments back to back.  A step takes the next kLightTile
         // entries of that sequence; wave w filters the w-th quarter of the step into LDS segment w.  The next step's
         // loads are issued before this step's test phase.
-        auto coarse_at = [&](uint32_t k) -> uint32_t { // k-th candidate of the group, k < ctotal
+        auto coarse_at = [&](uint32_t k) -> uint32_t { // slot of the k-th candidate of the group, k < ctotal
             uint32_t sg = 0; // last segment whose prefix is <= k (bisection over the 16 prefixes)
 #pragma unroll
             for (uint32_t half = kCoarseSegs / 2; half >= 1; half /= 2) sg += s_cpre[sg + half] <= k ? half : 0u;
-            return cbase[(size_t)sg * p.coarse_seg + (k - s_cpre[sg])];
+            return sg * p.coarse_seg + (k - s_cpre[sg]);
         };
         auto load_step = [&](uint32_t step0) {
             const uint32_t s_begin = step0 + wave * kSeg, s_end = min(s_begin + kSeg, ctotal);
@@ -847,10 +1032,10 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
             for (uint32_t r = 0; r < kLoads; r++) {
                 const uint32_t k = s_begin + r * 64u + (uint32_t)lane;
                 have[r] = k < s_end;
-                tag[r] = have[r] ? coarse_at(k) : 0u;
+                const uint32_t slot = have[r] ? coarse_at(k) : 0u; // one address for the lanes without a candidate
+                tag[r] = cbase[slot];
+                l[r] = clbase[slot];
             }
-#pragma unroll
-            for (uint32_t r = 0; r < kLoads; r++) l[r] = p.view_lights[tag[r] & ~kNotPoint];
         };
         if (ctotal > 0) load_step(0);
         for (uint32_t step0 = 0; step0 < ctotal; step0 += kLightTile) { // block-uniform trip count
@@ -904,8 +1089,9 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
         __builtin_amdgcn_s_waitcnt(0);
         p.debug_tests[16 + 2 * blockIdx.x] = t_begin;
         p.debug_tests[16 + 2 * blockIdx.x + 1] = wall_clock64();
-        p.debug_tests[16 + 2 * (4096u + blockIdx.x)] = dbg_filtered;   // candidates behind the block's filter (wave 0's view: all segments)
-        p.debug_tests[16 + 2 * (4096u + blockIdx.x) + 1] = dbg_ctotal; // the group's coarse candidates
+        p.debug_tests[16 + 2 * (4096u + blockIdx.x)] = dbg_phase; // (fast path only: four phases; else what was passed)
+        // candidates behind the block's filter (wave 0's view: all segments) << 32 | the group's coarse candidates
+        p.debug_tests[16 + 2 * (4096u + blockIdx.x) + 1] = dbg_filtered << 32 | dbg_ctotal;
     }
 #endif
 }

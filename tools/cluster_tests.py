@@ -100,8 +100,17 @@ if os.path.exists(sp):
     out["count_launch_block_life_us"] = {"blocks_stamped": int(len(a)), "working_blocks": int(nb),
         "working_begin_p0_50_90_99_100": q(w[:, 0]), "working_end_p0_50_90_99_100": q(w[:, 1]),
         "working_duration_p0_50_90_99_100": q(w[:, 1] - w[:, 0]),
-        "slowest_working_blocks_index_duration_filtered_coarse": [[int(i), round(float(w[i, 1] - w[i, 0]), 2), int(st[2 * (4096 + i)]), int(st[2 * (4096 + i) + 1])] for i in np.argsort(w[:, 1] - w[:, 0])[::-1][:16]],
+        "slowest_working_blocks_index_duration_filtered_coarse": [[int(i), round(float(w[i, 1] - w[i, 0]), 2), int(st[2 * (4096 + i) + 1]) >> 32, int(st[2 * (4096 + i) + 1]) & 0xFFFFFFFF] for i in np.argsort(w[:, 1] - w[:, 0])[::-1][:16]],
         "blocks_over_12_us": int(((w[:, 1] - w[:, 0]) > 12.0).sum()),
+        "coarse_candidates_of_the_blocks_group_p10_50_90_99_100": [int(v) for v in np.percentile([int(st[2 * (4096 + i) + 1]) & 0xFFFFFFFF for i in range(nb)], [10, 50, 90, 99, 100])],
+        "candidates_behind_the_blocks_filter_p10_50_90_99_100": [int(v) for v in np.percentile([int(st[2 * (4096 + i) + 1]) >> 32 for i in range(nb)], [10, 50, 90, 99, 100])],
+        # thread 0's first item, us from the block's begin: setup loads consumed | boxes united | candidates filtered | tested | end
+        "phases_p10_50_90": (lambda ph, dur: {name: [round(float(v), 2) for v in np.percentile(col, [10, 50, 90])] for name, col in
+                             (("setup_loads_consumed", ph[:, 0]), ("boxes_united", ph[:, 1]), ("candidates_filtered", ph[:, 2]),
+                              ("tested", ph[:, 3]), ("end", dur))})(
+            np.array([[((int(st[2 * (4096 + i)]) >> (16 * k)) & 0xFFFF) / 100.0 for k in range(4)] for i in range(nb)
+                      if (int(st[2 * (4096 + i)]) >> 48) != 0]),
+            np.array([w[i, 1] - w[i, 0] for i in range(nb) if (int(st[2 * (4096 + i)]) >> 48) != 0])),
         "idle_begin_p0_50_90_99_100": q(idle[:, 0]) if len(idle) else None, "idle_end_p0_50_90_99_100": q(idle[:, 1]) if len(idle) else None}
 print(json.dumps(out, indent=1))
 if len(sys.argv) > 1:
