@@ -137,6 +137,8 @@ __global__ __launch_bounds__(1024) void cluster_compact_kernel(const ClusterComp
     __shared__ uint32_t smem[1024 / 64 + 1];
     const uint32_t tiles = p.cc[0] * p.cc[1];
     const uint32_t z = blockIdx.y, chunk = blockIdx.x;
+    // (most (slice, chunk) pairs hold no active cluster: their emit blocks leave on the one word that says so)
+    if (EMIT && (blockIdx.x | blockIdx.y) != 0u && p.chunk_counts[z * gridDim.x + chunk] == 0u) return;
     const uint32_t i = chunk * 1024 + threadIdx.x;
     const uint32_t active = (i < tiles && (p.masks[i] & shl1(z))) ? 1u : 0u; // cluster_common.glsl:31-34
     uint32_t block_total;
