@@ -519,6 +519,15 @@ int32_t orbit_debug_read_cycles(OrbitCtx *ctx, unsigned long long out[8]) {
     return ORBIT_OK;
 }
 
+// perf triage only (not part of the public ABI): the seven wall-clock stamps a -DORBIT_TRIAGE_STAMPS build of
+// depth_reduce.hip leaves in the unused words of pyramid 0's arrival counters (tools/depth_stamps.py)
+int32_t orbit_debug_read_depth_stamps(OrbitCtx *ctx, unsigned long long out[7]) {
+    if (!ctx || !out) return ORBIT_E_INVALID;
+    if (hipDeviceSynchronize() != hipSuccess) return ORBIT_E_HIP;
+    if (hipMemcpy(out, ctx->d_tickets + 2, 56, hipMemcpyDeviceToHost) != hipSuccess) return ORBIT_E_HIP;
+    return ORBIT_OK;
+}
+
 // perf triage only (not part of the public ABI; all zeros unless the library was built with -DORBIT_TRIAGE): reads and
 // clears the executed sphere-box test counts of the cluster assignment — coarse tests, coarse passes, count launch
 // {filter, cluster} tests, write launch {filter, cluster} tests, write-launch blocks served from the hit cache, the

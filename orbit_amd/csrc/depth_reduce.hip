@@ -84,29 +84,49 @@ __global__ __launch_bounds__(256) void depth_reduce_tiles(const DepthReduceBatch
     const int t = threadIdx.x;
     const uint32_t ox0 = blockIdx.x * kTile, oy0 = blockIdx.y * kTile;
     if (ox0 >= p.w0 || oy0 >= p.h0) return; // the grid covers the largest pyramid of the batch (block-uniform)
+#ifdef ORBIT_TRIAGE_STAMPS // tools/depth_stamps.py: the critical path of the launch in wall-clock stamps (100 MHz), written
+    // into the unused words of the pyramid's arrival counters: [0] workgroup (0, 0)'s start; of the workgroup that
+    // finishes last: [1] its start, [2] level 0 in LDS, [3] levels 1..5 done, [4] its stores drained, [5] tickets
+    // taken, [6] tail done
+    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(batch.tickets + blockIdx.z * kDepthTicketWords + 2);
+    const unsigned long long st_start = wall_clock64();
+    unsigned long long st_l0 = 0, st_levels = 0, st_drained = 0;
+    if (t == 0 && blockIdx.x == 0 && blockIdx.y == 0) stamps[0] = st_start;
+#endif
 
-    // level 0: each thread produces a 2x2 quad of the tile
+    // level 0: each thread produces a 2x2 quad of the tile.  All four footprints are fetched before the first texel is
+    // stored: a store into the pyramid may alias the depth buffer for all the compiler knows, so with the store between
+    // them every footprint's loads waited for the one before (four round trips in a row: 4.6 of the launch's 11 us).
     {
         float *dst = p.level[0];
         const int qx = t & 15, qy = t >> 4;
+        float q[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const uint32_t x = ox0 + 2 * qx + i, y = oy0 + 2 * qy + j;
+                // (vec2(pos) + 0.5) / vec2(dimensions), depth_reduce.comp:18; a texel outside the level: its clamped
+                // neighbour's footprint, fetched and dropped
+                const float u = ((float)min(x, p.w0 - 1u) + 0.5f) / (float)p.w0;
+                const float vv = ((float)min(y, p.h0 - 1u) + 0.5f) / (float)p.h0;
+                q[j][i] = footprint_min(p.depth, p.depth_pitch, p.screen_w, p.screen_h, u, vv);
+            }
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int i = 0; i < 2; i++) {
                 const int lx = 2 * qx + i, ly = 2 * qy + j;
                 const uint32_t x = ox0 + lx, y = oy0 + ly;
-                float v = 0.0f;
-                if (x < p.w0 && y < p.h0) {
-                    // (vec2(pos) + 0.5) / vec2(dimensions), depth_reduce.comp:18
-                    const float u = ((float)x + 0.5f) / (float)p.w0;
-                    const float vv = ((float)y + 0.5f) / (float)p.h0;
-                    v = footprint_min(p.depth, p.depth_pitch, p.screen_w, p.screen_h, u, vv);
-                    dst[(size_t)y * p.pitch[0] + x] = v;
-                }
-                buf0[ly * kTile + lx] = v;
+                const bool in = x < p.w0 && y < p.h0;
+                if (in) dst[(size_t)y * p.pitch[0] + x] = q[j][i];
+                buf0[ly * kTile + lx] = in ? q[j][i] : 0.0f;
             }
     }
     __syncthreads();
+#ifdef ORBIT_TRIAGE_STAMPS
+    st_l0 = wall_clock64();
+#endif
 
     // levels 1..5 inside the block, ping-ponging between the two LDS buffers
     const int last = min((int)p.mips, kInBlockLevels);
@@ -137,8 +157,14 @@ __global__ __launch_bounds__(256) void depth_reduce_tiles(const DepthReduceBatch
     if (!tail_in_launch(p)) return; // (block-uniform)
     // the pyramid's last workgroup out does levels 6.. (the buffers above are free again: reused as its LDS)
     __shared__ uint32_t s_last;
+#ifdef ORBIT_TRIAGE_STAMPS
+    st_levels = wall_clock64();
+#endif
     drain_stores();
     __syncthreads();
+#ifdef ORBIT_TRIAGE_STAMPS
+    st_drained = wall_clock64();
+#endif
     if (t == 0) {
         // two levels of arrival counters — a row of tile workgroups, then the rows: a thousand returning atomics on ONE
         // word queue for 12 us on this chip (~88 per us and word); 32 + 32 on 33 words do not
@@ -157,8 +183,18 @@ __global__ __launch_bounds__(256) void depth_reduce_tiles(const DepthReduceBatch
     }
     __syncthreads();
     if (uniform(s_last) == 0u) return;
+#ifdef ORBIT_TRIAGE_STAMPS
+    const unsigned long long st_tickets = wall_clock64();
+#endif
     static_assert((kTailSide / 2) * (kTailSide / 2) <= kTile * kTile, "tail buffers");
     depth_reduce_tail_in_lds(p, tail_lds, buf0);
+#ifdef ORBIT_TRIAGE_STAMPS
+    if (t == 0) {
+        drain_stores();
+        stamps[1] = st_start, stamps[2] = st_l0, stamps[3] = st_levels, stamps[4] = st_drained, stamps[5] = st_tickets;
+        stamps[6] = wall_clock64();
+    }
+#endif
 }
 
 // Levels kInBlockLevels.. from global memory, one block (pyramids too large for the in-launch tail).

@@ -140,8 +140,10 @@ CHAINS = {
     "launch_chain_from_streams": dict(L=3, a=1, l=11, h=2),  # the chain emit scans inside its launch
     # depth_reduce: depth -> tile levels (LDS) -> level 5 written through -> last tile workgroup (2 arrival atomics) -> tail
     "depth_reduce": dict(L=1, a=2, l=2, h=1),
-    # mark (depth -> masks/bounds) | compact count, scan, write | AABBs + lights | coarse | count | scan | write
-    "compute_clusters": dict(L=8, a=0, l=18, h=0),
+    # mark + the compaction's counts (depth -> masks / bounds) | compaction emit (own count -> masks + preceding counts)
+    # | AABBs + lights + group order (header -> list -> bounds) | coarse filter (union box -> lights) | count (header,
+    # order, segment counts -> the item's boxes and candidates) | write (header -> counts, kept hits, sums)
+    "compute_clusters": dict(L=6, a=0, l=12, h=0),
 }
 
 
