@@ -25,6 +25,13 @@ python3 tools/bench_configs.py > $O/configs.json 2>> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_configs -- python3 tools/bench_configs.py > /dev/null 2>> $O/bench.err
 f=$(find $O/prof_configs -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats_configs.csv; rm -rf $O/prof_configs
 python3 tools/bench_views.py > $O/views.json 2>> $O/bench.err
+# the cluster chain and the pyramid on their own: per entry point, the chain's kernels, the count launch's blocks, the
+# pyramid launch's critical path (stamps builds: tools/variants/{triage,stamps,dstamps}.so, built before the call)
+python3 tools/cluster_time.py > $O/cluster_time.json 2>> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cluster -- python3 tools/cluster_time.py > /dev/null 2>> $O/bench.err
+f=$(find $O/prof_cluster -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats_cluster_chain.csv; rm -rf $O/prof_cluster
+python3 tools/cluster_tests.py $O/cluster_tests.json > /dev/null 2>> $O/bench.err
+python3 tools/depth_stamps.py $O/depth_stamps.json > /dev/null 2>> $O/bench.err
 bash tools/shard_pieces.sh "stream buffer" > $O/shard_pieces.txt 2>> $O/bench.err
 tools/ubench/hop.bin > $O/hops.json 2>> $O/bench.err
 bash tools/traffic.sh stream > $O/traffic_stream.log 2>&1; bash tools/traffic.sh buffer > $O/traffic_buffer.log 2>&1
