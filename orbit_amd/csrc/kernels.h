@@ -216,7 +216,7 @@ struct ClusterAssignParams {
     // context scratch
     float4 *view_lights;     // (x, y, z, r*r) per light in view space
     uint32_t *light_flags;   // bit i set = light i is a point light
-    uint32_t *counts;        // per active cluster
+    uint32_t *counts;        // per active cluster: min(lights found, ORBIT_MAX_LIGHTS_PER_CLUSTER)
     uint32_t *hit_cache;     // per active cluster: its first kHitCache light indices, kept by the counting launch
     float *aabb;             // 6 floats per active cluster (compacted order), written by the coarse launch
     uint32_t *coarse;        // per group of 256 active clusters: 16 segments x coarse_seg candidate light indices
@@ -225,9 +225,10 @@ struct ClusterAssignParams {
     float *group_box;        // 8 words per group: union AABB (6), any-NaN flag, unused
     uint32_t *group_order;   // the groups in the order the count launch takes them (longest candidate lists first)
     uint32_t coarse_seg;     // capacity of one segment (= lights per wave of the coarse filter, a multiple of 64)
-    uint32_t *block_sums;
-    uint32_t *block_base;
-    uint32_t *total;
+    uint32_t *block_sums;    // the sum of the (capped) counts of every chunk of kScanChunk active clusters, kChunkSumStride
+                             // words apart (count launch: one atomic per block; cleared by the AABB launch)
+    uint32_t *block_base;    // the count launch's heavy blocks (block indices; a cluster with more than kHitCache lights)
+    uint32_t *total;         // word 0: how many of those
     uint32_t *zero_words;    // orbit_compute_clusters: the mark launch's chunk counts, cleared again by the first
     uint32_t zero_count;     // launch here (consumed by then; nullptr / 0: nothing)
     int32_t *status;

@@ -16,11 +16,14 @@
 //             light_culling.comp:111) and cluster AABBs are computed once;
 //             then three conservative levels — all lights against the union
 //             box of 256 consecutive active clusters, those candidates
-//             against the union box of a block's 16 clusters, the survivors
-//             (lane = candidate) against the 4 AABBs a wave keeps in SGPRs:
-//             hit ballots become popcounts in the count pass and
-//             ballot-ranked ordered writes in the write pass; ranges are
-//             allocated by prefix sum in compacted order.
+//             against the union box of a block's 8 clusters, the survivors
+//             (lane = candidate) against the single boxes: hit ballots become
+//             popcounts and kept hits in the count launch; the write launch
+//             allocates ranges in compacted order (chunk sums + the counts in
+//             front within the chunk) and copies the kept lists, testing
+//             again only the few clusters that found more than were kept.
+//   Four launches for the assignment, six for orbit_compute_clusters (whose
+//   mark launch also takes the compaction's counts): DESIGN.md 4.4.
 #include "handoff.h"
 
 namespace orbit {

@@ -1,0 +1,150 @@
+"""orbit_compute_clusters as ONE call (src/passes/cluster.rs:368-591) beyond what tests/test_gpu_parity.py's _light_clusters
+checks per scene: its mark launch leaves the compaction's chunk counts behind and the assignment clears them, its count
+launch takes the groups in the order the PREVIOUS call left — state that lives in the context between calls.  So: calls
+of different grids, light sets and active-cluster counts one after the other on one context, in both directions; a
+refused call in between (nothing may be left behind by it); the separate entry points interleaved with the one call;
+the call replayed as a graph.  Always against the oracle's five buffers."""
+import numpy as np
+import pytest
+
+from orbit_amd import layouts as L
+from test_gpu_parity import cluster_inputs, dev, host, torch_mod  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+# (W, H, lights, tile, z slices, radius scale): small grid / few lights, the 1080p grid with a hot spot, a grid whose
+# clusters saturate at 256 lights (heavy blocks: the write launch tests them again), no lights at all
+SCENES = [(320, 180, 200, 8, 32, None), (1920, 1080, 3000, 8, 32, 4.0), (128, 72, 5000, 16, 16, 12.0), (200, 120, 0, 8, 8, None),
+          (640, 360, 1500, 8, 32, 2.0)]
+
+
+def _scene(oracle, i):
+    W, H, n_lights, tile, zs, rs = SCENES[i]
+    push, depth, info, lights = cluster_inputs(oracle, 11 + i, W, H, n_lights, tile, zs)
+    if rs is not None:
+        lights["outer_radius"] *= np.float32(rs)
+    cc = [int(v) for v in push["cluster_count"]]
+    total = cc[0] * cc[1] * cc[2]
+    cap = cc[0] * cc[1] * max(4, cc[2])
+    om, ob = oracle.cluster_mark(push, depth)
+    ou, _ = oracle.cluster_compact(cc, om, cap)
+    n_active = int(ou[12:16].view(np.uint32)[0])
+    lcap = n_active * 256 + 16
+    ol, oimg, dropped = oracle.cluster_assign(info, ou, ob, lights, lcap, total)
+    assert dropped == 0
+    return dict(push=push, depth=depth, info=info, lights=lights, cc=cc, total=total, cap=cap, lcap=lcap, n_active=n_active,
+                n_lights=n_lights, ref=(om, ob, ou, ol, oimg))
+
+
+def _buffers(torch, s):
+    return dict(gm=torch.full((s["cc"][0] * s["cc"][1],), 0x5A5A5A5A, dtype=torch.int32, device="cuda"),
+                gb=torch.full((s["total"], 2), 0x5A5A5A5A, dtype=torch.int32, device="cuda"),
+                gu=torch.full((L.COMPACT_HEADER + 4 * s["cap"],), 0xEE, dtype=torch.uint8, device="cuda"),
+                gl=torch.full((L.LIGHT_INDEX_HEADER + 4 * s["lcap"],), 0xEE, dtype=torch.uint8, device="cuda"),
+                gimg=torch.zeros((s["total"], 2), dtype=torch.int32, device="cuda"),
+                depth=dev(torch, s["depth"]), lights=dev(torch, s["lights"]) if s["n_lights"] else None)
+
+
+def _poison(b):
+    """What a call must overwrite (the image is written for active clusters only: zero, as the renderer clears it)."""
+    b["gm"].fill_(0x5A5A5A5A)
+    b["gb"].fill_(0x5A5A5A5A)
+    b["gu"].fill_(0xEE)
+    b["gl"].fill_(0xEE)
+    b["gimg"].zero_()
+
+
+def _call(engine, s, b):
+    engine.compute_clusters(s["push"], s["info"], b["depth"], b["lights"], b["gm"], b["gb"], b["gu"], s["cap"], b["gl"], s["lcap"],
+                            b["gimg"])
+
+
+def _check(torch, engine, s, b, what):
+    torch.cuda.synchronize()
+    engine.status()
+    om, ob, ou, ol, oimg = s["ref"]
+    n, n_idx = s["n_active"], int(ol[:4].view(np.uint32)[0])
+    assert np.array_equal(host(b["gm"], np.uint32), om), f"{what}: tile masks"
+    assert np.array_equal(host(b["gb"], np.uint32).reshape(-1, 2), ob), f"{what}: depth bounds"
+    assert np.array_equal(host(b["gu"])[:16 + 4 * n], ou[:16 + 4 * n]), f"{what}: compacted list"
+    assert np.array_equal(host(b["gl"])[:4 + 4 * n_idx], ol[:4 + 4 * n_idx]), f"{what}: light index lists"
+    assert np.array_equal(host(b["gimg"], np.uint32).reshape(-1, 2), oimg), f"{what}: (offset, count) image"
+
+
+@pytest.fixture()
+def engine(torch_mod):
+    from orbit_amd.engine import Engine
+
+    e = Engine(0, max_lights=6000, max_clusters=240 * 135 * 32)
+    yield e
+    e.close()
+
+
+def test_calls_of_different_scenes_on_one_context(torch_mod, engine, oracle):
+    """Every scene after every other one: more groups than the call before, fewer, none (no lights: every cluster gets
+    (offset, 0)), heavy blocks after none and none after some — the group order and the heavy list of a call are what
+    the one before left."""
+    torch = torch_mod
+    scenes = [_scene(oracle, i) for i in range(len(SCENES))]
+    bufs = [_buffers(torch, s) for s in scenes]
+    assert max(int(s["ref"][4][:, 1].max()) for s in scenes) == 256 and scenes[3]["n_lights"] == 0
+    order = [0, 1, 2, 3, 4, 3, 2, 1, 0, 2, 0, 4, 1, 1]
+    for k, i in enumerate(order):
+        _poison(bufs[i])
+        _call(engine, scenes[i], bufs[i])
+        _check(torch, engine, scenes[i], bufs[i], f"call {k} (scene {i})")
+
+
+def test_a_refused_call_leaves_nothing_behind(torch_mod, engine, oracle):
+    """Arguments the later stages would refuse are refused before the mark launch (whose chunk counts only the
+    assignment's first launch clears): a good call, refused ones of every kind, the good call again."""
+    from orbit_amd._lib import OrbitError
+
+    torch = torch_mod
+    s = _scene(oracle, 0)
+    b = _buffers(torch, s)
+    _call(engine, s, b)
+    _check(torch, engine, s, b, "first")
+    bad_info = s["info"].copy()
+    bad_info["global_light_count"] = 6001  # > caps.max_lights
+    bad_grid = s["info"].copy()
+    bad_grid["cluster_count"] = (s["cc"][0] + 1, s["cc"][1], s["cc"][2])  # differs from the push block's
+    for info, lights, gu in ((bad_info, b["lights"], b["gu"]), (bad_grid, b["lights"], b["gu"]), (s["info"], None, b["gu"]),
+                             (s["info"], b["lights"], None)):
+        with pytest.raises(OrbitError):
+            engine.compute_clusters(s["push"], info, b["depth"], lights, b["gm"], b["gb"], gu, s["cap"], b["gl"], s["lcap"], b["gimg"])
+    _poison(b)
+    _call(engine, s, b)
+    _check(torch, engine, s, b, "after the refused calls")
+
+
+def test_the_three_entry_points_between_calls(torch_mod, engine, oracle):
+    """orbit_cluster_mark / _compact / _assign on their own (a mark launch that counts nothing, a compaction that counts
+    for itself, an assignment that transforms its lights itself) between orbit_compute_clusters calls of another scene."""
+    torch = torch_mod
+    s0, s1 = _scene(oracle, 4), _scene(oracle, 0)
+    b0, b1 = _buffers(torch, s0), _buffers(torch, s1)
+    _call(engine, s0, b0)
+    _check(torch, engine, s0, b0, "one call")
+    engine.cluster_mark(s1["push"], b1["depth"], b1["gm"], b1["gb"])
+    engine.cluster_compact(s1["cc"], b1["gm"], b1["gu"], s1["cap"])
+    _call(engine, s0, b0)  # in between: the one call of the other scene
+    engine.cluster_assign(s1["info"], b1["gu"], b1["gb"], b1["lights"], b1["gl"], s1["lcap"], b1["gimg"])
+    _check(torch, engine, s1, b1, "three calls")
+    _check(torch, engine, s0, b0, "one call again")
+
+
+def test_compute_clusters_replayed_as_a_graph(torch_mod, engine, oracle):
+    """Captured once, replayed: every counter the launches leave behind is back where the next replay expects it."""
+    torch = torch_mod
+    s = _scene(oracle, 1)
+    b = _buffers(torch, s)
+    _call(engine, s, b)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        _call(engine, s, b)
+    for k in range(4):
+        _poison(b)
+        g.replay()
+        _check(torch, engine, s, b, f"replay {k}")
