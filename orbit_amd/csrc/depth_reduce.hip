@@ -74,6 +74,44 @@ __device__ __forceinline__ void depth_reduce_tail_in_lds(const DepthReduceParams
     }
 }
 
+// min of a value and its partner's (lane ^ mask) in reduce4's operand order: `first` = this lane holds the first operand
+// (the lower coordinate); both lanes of the pair end up with the same value
+__device__ __forceinline__ float pair_min(float v, int mask, bool first) {
+    const float o = __shfl_xor(v, mask, 64);
+    return first ? gmin(v, o) : gmin(o, v);
+}
+
+// The tail of a pyramid whose level kInBlockLevels - 1 is 32 x 32 and whose top is 1 x 1 five levels on (a 1024^2 level 0:
+// the 1080p screen's) by ONE wave without LDS: lane (lx, ly) of an 8 x 8 grid loads its 4 x 4 block of that level (sc1:
+// written through by the tile workgroups), reduces two levels in its own registers and three by lane exchanges.  The
+// general form above takes five LDS round trips and barriers for the same levels (2.8 of the launch's 10.3 us).
+__device__ __forceinline__ void depth_reduce_tail_one_wave(const DepthReduceParams &p, int lane) {
+    const uint32_t k0 = kInBlockLevels - 1;
+    const uint32_t lx = (uint32_t)lane & 7u, ly = (uint32_t)lane >> 3;
+    const __amdgpu_buffer_rsrc_t L5 = rsrc_of(p.level[k0], (uint32_t)((31u * p.pitch[k0] + 32u) * 4u));
+    float a[4][4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++)
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) a[j][i] = __uint_as_float(ld_sc1(L5, ((4u * ly + j) * p.pitch[k0] + 4u * lx + i) * 4u));
+    float b[2][2]; // level k0 + 1: 16 x 16
+#pragma unroll
+    for (uint32_t j = 0; j < 2; j++)
+#pragma unroll
+        for (uint32_t i = 0; i < 2; i++) {
+            b[j][i] = gmin(gmin(a[2 * j][2 * i], a[2 * j][2 * i + 1]), gmin(a[2 * j + 1][2 * i], a[2 * j + 1][2 * i + 1]));
+            p.level[k0 + 1][(size_t)(2u * ly + j) * p.pitch[k0 + 1] + 2u * lx + i] = b[j][i];
+        }
+    const float c = gmin(gmin(b[0][0], b[0][1]), gmin(b[1][0], b[1][1])); // 8 x 8: one per lane
+    p.level[k0 + 2][(size_t)ly * p.pitch[k0 + 2] + lx] = c;
+    const float d = pair_min(pair_min(c, 1, (lx & 1u) == 0u), 8, (ly & 1u) == 0u); // 4 x 4
+    if (((lx | ly) & 1u) == 0u) p.level[k0 + 3][(size_t)(ly >> 1) * p.pitch[k0 + 3] + (lx >> 1)] = d;
+    const float e = pair_min(pair_min(d, 2, (lx & 2u) == 0u), 16, (ly & 2u) == 0u); // 2 x 2
+    if (((lx | ly) & 3u) == 0u) p.level[k0 + 4][(size_t)(ly >> 2) * p.pitch[k0 + 4] + (lx >> 2)] = e;
+    const float f = pair_min(pair_min(e, 4, (lx & 4u) == 0u), 32, (ly & 4u) == 0u); // 1 x 1
+    if (lane == 0) p.level[k0 + 5][0] = f;
+}
+
 // (Staging a tile's source region — at most 66 x 66 texels of the depth buffer — in LDS first, rows loaded coalesced, was
 // measured in round 4 and lost: 14.0 against 12.1 us for the launch at 1080p; the footprints' own loads hit the L1.)
 __global__ __launch_bounds__(256) void depth_reduce_tiles(const DepthReduceBatch batch) {
@@ -86,14 +124,19 @@ __global__ __launch_bounds__(256) void depth_reduce_tiles(const DepthReduceBatch
     if (ox0 >= p.w0 || oy0 >= p.h0) return; // the grid covers the largest pyramid of the batch (block-uniform)
 #ifdef ORBIT_TRIAGE_STAMPS // tools/depth_stamps.py: the critical path of the launch in wall-clock stamps (100 MHz), written
     // into the unused words of the pyramid's arrival counters: [0] workgroup (0, 0)'s start; of the workgroup that
-    // finishes last: [1] its start, [2] level 0 in LDS, [3] levels 1..5 done, [4] its stores drained, [5] tickets
-    // taken, [6] tail done
+    // finishes last: [1] its start, [2] level 0 done (a whole tile: levels 0..5), [3] levels 1..5 done, [4] its stores
+    // drained, [5] tickets taken, [6] tail done
     unsigned long long *stamps = reinterpret_cast<unsigned long long *>(batch.tickets + blockIdx.z * kDepthTicketWords + 2);
     const unsigned long long st_start = wall_clock64();
     unsigned long long st_l0 = 0, st_levels = 0, st_drained = 0;
     if (t == 0 && blockIdx.x == 0 && blockIdx.y == 0) stamps[0] = st_start;
 #endif
 
+    // a tile that lies whole inside every level it produces (level-0 sides multiples of 32, six levels or more — every
+    // pyramid of a screen of 64 pixels a side or more): levels 1..3 by lane exchanges, 4 and 5 by one wave behind ONE
+    // barrier; others go through LDS level by level with the clamps of the general form
+    const bool whole = p.w0 % kTile == 0u && p.h0 % kTile == 0u && p.mips >= (uint32_t)kInBlockLevels; // (block-uniform)
+    __shared__ float s_l3[16];
     // level 0: each thread produces a 2x2 quad of the tile.  All four footprints are fetched before the first texel is
     // stored: a store into the pyramid may alias the depth buffer for all the compiler knows, so with the store between
     // them every footprint's loads waited for the one before (four round trips in a row: 4.6 of the launch's 11 us).
@@ -120,16 +163,42 @@ __global__ __launch_bounds__(256) void depth_reduce_tiles(const DepthReduceBatch
                 const uint32_t x = ox0 + lx, y = oy0 + ly;
                 const bool in = x < p.w0 && y < p.h0;
                 if (in) dst[(size_t)y * p.pitch[0] + x] = q[j][i];
-                buf0[ly * kTile + lx] = in ? q[j][i] : 0.0f;
+                if (!whole) buf0[ly * kTile + lx] = in ? q[j][i] : 0.0f;
             }
+        if (whole) {
+            static_assert(kTile == 32 && kInBlockLevels == 6, "lane = (qy & 3) * 16 + qx; levels 1..5 of a 32 x 32 tile");
+            const uint32_t uqx = (uint32_t)qx, uqy = (uint32_t)qy;
+            // reduce4's order: (x0, y0), (x1, y0) | (x0, y1), (x1, y1)
+            const float v1 = gmin(gmin(q[0][0], q[0][1]), gmin(q[1][0], q[1][1]));
+            p.level[1][(size_t)((oy0 >> 1) + uqy) * p.pitch[1] + (ox0 >> 1) + uqx] = v1;
+            const float v2 = pair_min(pair_min(v1, 1, (uqx & 1u) == 0u), 16, (uqy & 1u) == 0u);
+            if (((uqx | uqy) & 1u) == 0u) p.level[2][(size_t)((oy0 >> 2) + (uqy >> 1)) * p.pitch[2] + (ox0 >> 2) + (uqx >> 1)] = v2;
+            const float v3 = pair_min(pair_min(v2, 2, (uqx & 2u) == 0u), 32, (uqy & 2u) == 0u);
+            if (((uqx | uqy) & 3u) == 0u) {
+                p.level[3][(size_t)((oy0 >> 3) + (uqy >> 2)) * p.pitch[3] + (ox0 >> 3) + (uqx >> 2)] = v3;
+                s_l3[(uqy >> 2) * 4u + (uqx >> 2)] = v3; // (rows 4 w .. 4 w + 3 of quads are wave w's: the next level crosses waves)
+            }
+            __syncthreads();
+            if (t < 64) { // (wave 0; lanes 16.. repeat lanes 0..15)
+                const uint32_t x = (uint32_t)t & 3u, y = ((uint32_t)t >> 2) & 3u;
+                const float w3 = s_l3[y * 4u + x];
+                const float v4 = pair_min(pair_min(w3, 1, (x & 1u) == 0u), 4, (y & 1u) == 0u);
+                if (t < 16 && ((x | y) & 1u) == 0u) p.level[4][(size_t)((oy0 >> 4) + (y >> 1)) * p.pitch[4] + (ox0 >> 4) + (x >> 1)] = v4;
+                const float v5 = pair_min(pair_min(v4, 2, (x & 2u) == 0u), 8, (y & 2u) == 0u);
+                // the level the in-launch tail reads from other workgroups' hands: write-through
+                if (t == 0 && p.mips > 5u)
+                    __hip_atomic_store(reinterpret_cast<uint32_t *>(p.level[5] + ((size_t)(oy0 >> 5) * p.pitch[5] + (ox0 >> 5))),
+                                       __float_as_uint(v5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
-    __syncthreads();
+    if (!whole) __syncthreads();
 #ifdef ORBIT_TRIAGE_STAMPS
     st_l0 = wall_clock64();
 #endif
 
     // levels 1..5 inside the block, ping-ponging between the two LDS buffers
-    const int last = min((int)p.mips, kInBlockLevels);
+    const int last = whole ? 0 : min((int)p.mips, kInBlockLevels);
     for (int k = 1; k < last; k++) {
         const float *src = (k & 1) ? buf0 : buf1;
         float *dstl = (k & 1) ? buf1 : buf0;
@@ -187,7 +256,11 @@ __global__ __launch_bounds__(256) void depth_reduce_tiles(const DepthReduceBatch
     const unsigned long long st_tickets = wall_clock64();
 #endif
     static_assert((kTailSide / 2) * (kTailSide / 2) <= kTile * kTile, "tail buffers");
-    depth_reduce_tail_in_lds(p, tail_lds, buf0);
+    if ((p.w0 >> (kInBlockLevels - 1)) == 32u && (p.h0 >> (kInBlockLevels - 1)) == 32u && p.mips == (uint32_t)kInBlockLevels + 5u) {
+        if (t < 64) depth_reduce_tail_one_wave(p, t);
+    } else {
+        depth_reduce_tail_in_lds(p, tail_lds, buf0);
+    }
 #ifdef ORBIT_TRIAGE_STAMPS
     if (t == 0) {
         drain_stores();

@@ -45,11 +45,11 @@ hop = lambda a, b: round(float(np.median(r[:, b] - r[:, a])), 2)
 out = {"workload": f"depth_reduce {W}x{H} -> {d.width}x{d.height}, {d.mip_levels} levels", "launch_by_events_us": {"product": round(product_us, 2), "stamps_build": round(stamps_build_us, 2)},
        "last_workgroup_hops_us": {
            "first workgroup's start -> the last one's start (dispatch of the grid)": hop(0, 1),
-           "start -> level 0 in LDS (footprint loads of the depth buffer, 4 per thread and texel)": hop(1, 2),
-           "levels 1..5 in LDS (five barriers)": hop(2, 3),
+           "start -> levels 0..5 (level 0: four footprints of four loads per thread; 1..3 by lane exchanges, 4 and 5 by one wave behind one barrier)": hop(1, 2),
+           "(a tile that is not whole inside its levels: levels 1..5 through LDS)": hop(2, 3),
            "its stores drained (level 5 written through)": hop(3, 4),
            "two arrival tickets (row, then rows)": hop(4, 5),
-           "tail: level 5 loaded (sc1), levels 6.. reduced in LDS, stored, drained": hop(5, 6),
+           "tail: level 5 loaded (sc1), levels 6..10 by one wave (registers, lane exchanges), stored, drained": hop(5, 6),
            "first workgroup's start -> tail done": hop(0, 6)},
        "note": "what the events see beyond the last line is the launch itself (tools/ubench/hop.hip: an empty launch between two events takes ~6 us)"}
 print(json.dumps(out, indent=1))
