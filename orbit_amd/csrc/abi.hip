@@ -130,6 +130,17 @@ int32_t hip_fail(OrbitCtx *ctx, hipError_t e, const char *what) {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// hipMemset of device memory returns before the fill has run (it is ordered on the null stream), and the streams the
+// library is called on later need not wait for the null stream (hipStreamNonBlocking: torch's side streams are): a
+// context's first cull could run while its scratch was still being cleared under it (found by
+// tests/test_concurrent_gpu.py once the arena had grown by a gigabyte).  Every fill of memory that launches on OTHER
+// streams will use is therefore waited for before the call that made it returns.
+hipError_t memset_now(void *ptr, int value, size_t bytes) {
+    hipError_t e = hipMemset(ptr, value, bytes);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    return e;
+}
+
 uint32_t mip_levels_from_size(uint32_t max_size) { // src/math.rs:18-20
     uint32_t l = 0;
     while ((max_size >> (l + 1)) != 0) l++;
@@ -333,7 +344,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
         delete ctx;
         return hip_fail(nullptr, e, "hipMalloc(scratch arena)");
     }
-    e = hipMemset(ctx->arena, 0, ctx->arena_bytes);
+    e = memset_now(ctx->arena, 0, ctx->arena_bytes);
     if (e != hipSuccess) {
         (void)hipFree(ctx->arena);
         delete ctx;
@@ -434,12 +445,12 @@ int32_t orbit_ctx_status(OrbitCtx *ctx, void *stream, int32_t sync) {
         e = hipMemcpy(&cv, child->status, 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) return hip_fail(ctx, e, "hipMemcpy(status)");
         if (cv != 0) {
-            (void)hipMemset(child->status, 0, 4);
+            (void)memset_now(child->status, 0, 4);
             if (v == 0) v = cv;
         }
     }
     if (v != 0) {
-        e = hipMemset(ctx->status, 0, 4);
+        e = memset_now(ctx->status, 0, 4);
         if (e != hipSuccess) return hip_fail(ctx, e, "hipMemset(status)");
         return fail(ctx, v, v == ORBIT_E_CAPACITY ? "an append overflowed a caller buffer (entries dropped)"
                             : v == ORBIT_E_RANGE  ? "a meshlet outside the bound meshlet stream was culled or expanded"
@@ -859,10 +870,10 @@ int32_t orbit_meshlet_stream_create(OrbitCtx *ctx, uint64_t first_meshlet, uint6
     // defined, empty meshlet — never uninitialised memory.
     for (auto &a : arrays) {
         if (e == hipSuccess) e = hipMalloc(a.p, a.bytes);
-        if (e == hipSuccess) e = hipMemset(*a.p, a.fill, a.bytes);
+        if (e == hipSuccess) e = hipMemset(*a.p, a.fill, a.bytes); // (waited for below)
     }
     if (e == hipSuccess) e = hipMalloc((void **)&ms->d_other, 256);
-    if (e == hipSuccess) e = hipMemset(ms->d_other, 0, 256);
+    if (e == hipSuccess) e = memset_now(ms->d_other, 0, 256); // ... and every fill above: updates launch on the caller's streams
     if (e == hipSuccess) e = hipHostMalloc((void **)&ms->h_other, sizeof(uint32_t), hipHostMallocDefault);
     if (e == hipSuccess) *ms->h_other = 0u;
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ms->other_event, hipEventDisableTiming);
@@ -971,7 +982,7 @@ int32_t orbit_meshlet_stream_update_meshes(OrbitCtx *ctx, OrbitMeshletStream *ms
     if (ms->mesh_side == nullptr) { // the first update allocates (an upload-time call, like orbit_meshlet_stream_create)
         const uint32_t cap = first_mesh + count > kMeshSideMinCapacity ? first_mesh + count : kMeshSideMinCapacity;
         e = hipMalloc((void **)&ms->mesh_side, (size_t)cap * sizeof(MeshSide));
-        if (e == hipSuccess) e = hipMemset(ms->mesh_side, 0, (size_t)cap * sizeof(MeshSide));
+        if (e == hipSuccess) e = memset_now(ms->mesh_side, 0, (size_t)cap * sizeof(MeshSide));
         if (e != hipSuccess) {
             (void)hipFree(ms->mesh_side);
             ms->mesh_side = nullptr;
@@ -1614,7 +1625,7 @@ int32_t orbit_p2p_alloc(OrbitCtx *ctx, uint64_t bytes, void **out_ptr, uint8_t o
     void *ptr = nullptr;
     e = hipExtMallocWithFlags(&ptr, bytes, hipDeviceMallocFinegrained);
     if (e != hipSuccess) return hip_fail(ctx, e, "hipExtMallocWithFlags(p2p buffer, fine-grained)");
-    e = hipMemset(ptr, 0, bytes);
+    e = memset_now(ptr, 0, bytes);
     if (e == hipSuccess) e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t *>(out_handle), ptr);
     if (e != hipSuccess) {
         (void)hipFree(ptr);
