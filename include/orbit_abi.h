@@ -327,7 +327,13 @@ ORBIT_STATIC_ASSERT(sizeof(OrbitGpuClusterInfoBuffer) == 52, "GpuClusterInfoBuff
 
 /* Runtime capacities replace the reference's compile-time constants
  * (draw_gen.rs:15-16, scene.rs:303-304, assets/mod.rs:197-205).  They size the
- * context's private scan scratch only; caller buffers stay caller-owned. */
+ * context's private scratch only; caller buffers stay caller-owned.  What the
+ * scratch costs in device memory, by its largest terms: 96 B per dispatch record
+ * of max_dispatches (survivor payload of the Meshlet-buffer path) + 8 B (ballots,
+ * counts); per cluster of max_clusters 256 B (the light indices the count launch
+ * keeps) + 36 B; per group of 256 clusters 20 B x max_lights (the coarse candidate
+ * lists: index + view-space light) — 0.57 GB at orbit_default_caps, zero-filled
+ * once by orbit_ctx_create, which returns when the fill has run. */
 typedef struct OrbitCaps {
     uint32_t max_entities;   /* scene.rs:303   MAX_INSTANCE_COUNT   = 100_000   */
     uint32_t max_dispatches; /* draw_gen.rs:16 MAX_MESHLET_DISPATCH = 1_000_000 */
