@@ -733,13 +733,13 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
     const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.unique);
     const uint32_t *unique_idx = reinterpret_cast<const uint32_t *>(p.unique + ORBIT_COMPACT_HEADER);
     uint32_t *out = reinterpret_cast<uint32_t *>(p.light_index_buffer + ORBIT_LIGHT_INDEX_HEADER);
-    // The kernel is a chain of dependent loads, not arithmetic (config 4 executes 0.4 M tests in it): what it costs is
-    // the number of memory round trips on a block's critical path and whether all blocks are resident at once.  So
-    // (1) the header word n is loaded first but consumed only after every load of the block's first item that needs no
-    // other load's result is in flight (indices are clamped to the buffers instead of compared with n), and (2) the
-    // coarse candidates are fetched speculatively — lane i takes entry i of the wave's four segments before the
-    // segment counts are known — which serves every group whose segments hold at most 64 candidates in two round
-    // trips (setup + candidates | lights); longer lists take the stepped path below.
+    // Little arithmetic (config 4 executes 0.4 M tests here) in a great many short waves: what the launch costs is the
+    // instructions its waves issue and the dependent round trips of a block.  The header word n is loaded
+    // first but consumed only after the first item's loads that need no other load's result are in flight (indices are
+    // clamped to the buffers instead of compared with n).  A group whose coarse segments are all short is one wave's work
+    // (wave_item); in the four-wave form the first 16 entries of every segment are fetched before the segment counts are
+    // known, which serves groups whose segments hold no more; up to 64 per segment take one fetched step, longer lists
+    // the stepped path.
     const uint32_t n_raw = hdr[3];
     uint32_t n = 0;
     bool first_item = true;
@@ -841,15 +841,10 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
         tag[0] = cbase[spec_seg * p.coarse_seg + spec_entry];
         l[0] = clbase[spec_seg * p.coarse_seg + spec_entry];
     }
-    if (first_item) {
+    if (first_item) { // (WRITE: the count launch's first item found n above)
         n = min(n_raw, p.max_clusters);
         first_item = false;
-        if (WRITE) {
-            if (block_first >= n) break;
-        } else {
-            if (item - gridDim.x >= (n + kGroupClusters - 1u) / kGroupClusters * kGroupBlocks) break;
-            if (block_first >= n) continue;
-        }
+        if (block_first >= n) break;
     }
     const bool owns = lane < kClustersPerWave && u0 + lane < n;
     if (wave == 0) { // exclusive prefix of the 16 segment counts (wave scan); fast = no segment longer than a wave
