@@ -402,8 +402,8 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
         (void)orbit_ctx_destroy(ctx);
         return fail(nullptr, ORBIT_E_CAPACITY, "caps.max_views %u > %u", caps.max_views, (unsigned)ORBIT_MAX_CULL_VIEWS);
     }
-    OrbitCaps child_caps = caps;
-    child_caps.max_views = 0;
+    OrbitCaps child_caps = caps; // (a view's scratch: the culls' only — no cluster or light scratch, the bulk of a context's)
+    child_caps.max_views = 0, child_caps.max_clusters = 0, child_caps.max_lights = 0;
     for (uint32_t v = 1; v < caps.max_views; v++) {
         OrbitCtx *child = nullptr;
         const int32_t rc = orbit_ctx_create(device_id, &child_caps, &child);
@@ -762,7 +762,7 @@ int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t cou
     while (ctx->view_ctx.size() + 1 < count) {
         OrbitCtx *child = nullptr;
         OrbitCaps child_caps = ctx->caps;
-        child_caps.max_views = 0;
+        child_caps.max_views = 0, child_caps.max_clusters = 0, child_caps.max_lights = 0;
         const int32_t rc = orbit_ctx_create(ctx->device, &child_caps, &child);
         if (rc != ORBIT_OK) return fail(ctx, rc, "cull_views: scratch for view %zu: %s", ctx->view_ctx.size() + 1, g_err);
         ctx->view_ctx.push_back(child);
