@@ -249,7 +249,10 @@ def test_two_pass_sequence(torch_mod, engine, oracle, size):
         assert_same(run_gpu(torch, engine, gs, ci1, ones_e, m), run_oracle(oracle, scene, ci1, ones_e, m))
 
 
-@pytest.mark.parametrize("size", [(96, 54), (130, 40), (64, 64), (17, 9), (200, 3), (2560, 1080), (1, 1)])
+# ... (1280, 720): whole tiles and a 32 x 16 tail; (3840, 2160): the largest in-launch tail (level 5 of 64 x 64);
+# (4100, 40): level 5 of 128 x 1 — the second launch
+@pytest.mark.parametrize("size", [(96, 54), (130, 40), (64, 64), (17, 9), (200, 3), (2560, 1080), (1, 1), (1280, 720),
+                                  (3840, 2160), (4100, 40)])
 def test_depth_reduce(torch_mod, engine, oracle, size):
     torch = torch_mod
     W, H = size
@@ -355,6 +358,24 @@ def test_randomized_depth_reduce(torch_mod, engine, oracle, seed):
     engine.depth_reduce(dev(torch, depth), W, H, gpyr)
     torch.cuda.synchronize()
     assert np.array_equal(host(gpyr, np.uint32), opyr.view(np.uint32)), (W, H)
+
+
+@pytest.mark.parametrize("size", [(1920, 1080), (1500, 900), (1280, 720)])
+def test_depth_reduce_of_arbitrary_bits_at_screen_sizes(torch_mod, engine, oracle, size):
+    """NaN, inf, negative and denormal texels through the paths only whole tiles and a 1024^2 pyramid take: levels 1-5 by
+    lane exchanges and the one-wave tail place their operands as reduce4 does — which of two NaNs (or a NaN and a number)
+    a ReduceMin keeps depends on the order."""
+    torch = torch_mod
+    W, H = size
+    rng = np.random.default_rng(W)
+    depth = rng.random((H, W), dtype=np.float32)
+    bits = rng.integers(0, 2 ** 32, (H, W), dtype=np.uint32)
+    depth = np.where(rng.random((H, W)) < 0.3, bits.view(np.float32), depth).astype(np.float32)
+    opyr, d = oracle.depth_reduce(depth, W, H)
+    gpyr = torch.full((d.total_texels,), -1.0, dtype=torch.float32, device="cuda")
+    engine.depth_reduce(dev(torch, depth), W, H, gpyr)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(gpyr, np.uint32), opyr.view(np.uint32))
 
 
 def test_orthographic(torch_mod, engine, oracle):
