@@ -775,6 +775,13 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
     const uint32_t group = block_first / kGroupClusters;
     const uint32_t *cbase = p.coarse + (size_t)group * kCoarseSegs * p.coarse_seg;
     const float4 *clbase = p.coarse_lights + (size_t)group * kCoarseSegs * p.coarse_seg; // (the lights, slot for slot)
+    // ---- round trip 1: everything addressed by the block's position alone (count launch: before it is known whether
+    // the four waves will need it — a group with long lists is the launch's critical path, one round trip shorter so)
+    const uint32_t ul = min(u0 + ((uint32_t)lane & (kClustersPerWave - 1)), p.max_clusters - 1u); // lanes 0 .. kClustersPerWave - 1 count
+    uint32_t my_ci = unique_idx[ul];
+    Aabb3 box;
+#pragma unroll
+    for (int i = 0; i < 3; i++) box.mn[i] = p.aabb[6 * (size_t)ul + i], box.mx[i] = p.aabb[6 * (size_t)ul + 3 + i];
     if (!WRITE) {
         // Most blocks are light work — ten coarse candidates in their group at the median, a hundred at the 90th
         // percentile, three behind the block's own filter (config 4) — and the launch is bound by the instructions its
@@ -803,12 +810,6 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
             continue;
         }
     }
-    // ---- round trip 1: everything addressed by the block's position alone
-    const uint32_t ul = min(u0 + ((uint32_t)lane & (kClustersPerWave - 1)), p.max_clusters - 1u); // lanes 0 .. kClustersPerWave - 1 count
-    uint32_t my_ci = unique_idx[ul];
-    Aabb3 box;
-#pragma unroll
-    for (int i = 0; i < 3; i++) box.mn[i] = p.aabb[6 * (size_t)ul + i], box.mx[i] = p.aabb[6 * (size_t)ul + 3 + i];
     const uint32_t cc = p.coarse_counts[(size_t)group * kCoarseSegs + ((uint32_t)lane & (kCoarseSegs - 1))];
     uint32_t my_limit = 0, my_offset = 0;
     if (WRITE) {
@@ -919,6 +920,7 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
     }
     const uint32_t ctotal = s_cpre[kCoarseSegs];
     const bool fast = !WRITE && s_fast != 0u, spec = !WRITE && s_fast == 2u; // block-uniform
+
     [[maybe_unused]] uint32_t n_filter = 0, n_test = 0;
     ORBIT_MAX_TESTS(7, ctotal);
 
@@ -955,13 +957,18 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
         dbg_filtered += s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
         dbg_ctotal = ctotal;
 #endif
-        for (uint32_t seg = 0; seg < (uint32_t)kAssignWaves; seg++) {
-            const uint32_t cnt = s_wave_cnt[seg];
+        // the four waves' segments back to back (= light order) as ONE list: a block with twenty survivors spread over
+        // four segments tests one batch of 64 lanes, not four
+        static_assert(kAssignWaves == 4, "three prefixes place a candidate in its segment");
+        const uint32_t end0 = s_wave_cnt[0], end1 = end0 + s_wave_cnt[1], end2 = end1 + s_wave_cnt[2], cnt = end2 + s_wave_cnt[3];
+        {
             for (uint32_t b0 = 0; b0 < cnt; b0 += 64) {
                 const uint32_t ci = b0 + lane;
                 const bool in_list = ci < cnt;
-                const float4 cl = s_cand[seg * kSeg + (in_list ? ci : 0)];
-                const uint32_t ctag = s_cand_idx[seg * kSeg + (in_list ? ci : 0)];
+                const uint32_t seg = (ci >= end0 ? 1u : 0u) + (ci >= end1 ? 1u : 0u) + (ci >= end2 ? 1u : 0u);
+                const uint32_t at = in_list ? seg * kSeg + (ci - (seg == 0u ? 0u : seg == 1u ? end0 : seg == 2u ? end1 : end2)) : 0u;
+                const float4 cl = s_cand[at];
+                const uint32_t ctag = s_cand_idx[at];
                 const bool point = (ctag & kNotPoint) == 0u;
                 uint64_t hits[kClustersPerWave];
 #pragma unroll
@@ -1042,8 +1049,10 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
             filter_step();
             if (step0 + kLightTile < ctotal) load_step(step0 + kLightTile); // in flight during the test phase
             __syncthreads(); // all segments complete
+            ORBIT_PHASE_STAMP();
             test_step();
             __syncthreads(); // candidates consumed before the next step's filter overwrites them
+            ORBIT_PHASE_STAMP();
         }
     }
     ORBIT_COUNT_TESTS(WRITE ? 4 : 2, n_filter);

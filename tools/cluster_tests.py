@@ -102,6 +102,8 @@ if os.path.exists(sp):
         "working_duration_p0_50_90_99_100": q(w[:, 1] - w[:, 0]),
         "slowest_working_blocks_index_duration_filtered_coarse": [[int(i), round(float(w[i, 1] - w[i, 0]), 2), int(st[2 * (4096 + i) + 1]) >> 32, int(st[2 * (4096 + i) + 1]) & 0xFFFFFFFF] for i in np.argsort(w[:, 1] - w[:, 0])[::-1][:16]],
         "blocks_over_12_us": int(((w[:, 1] - w[:, 0]) > 12.0).sum()),
+        # the slowest blocks' phase stamps (us from the block's begin; stepped path: filtered / tested of step 0, then of step 1)
+        "slowest_blocks_phases": [[int(i), round(float(w[i, 1] - w[i, 0]), 2)] + [((int(st[2 * (4096 + i)]) >> (16 * k)) & 0xFFFF) / 100.0 for k in range(4)] for i in np.argsort(w[:, 1] - w[:, 0])[::-1][:8]],
         "coarse_candidates_of_the_blocks_group_p10_50_90_99_100": [int(v) for v in np.percentile([int(st[2 * (4096 + i) + 1]) & 0xFFFFFFFF for i in range(nb)], [10, 50, 90, 99, 100])],
         "candidates_behind_the_blocks_filter_p10_50_90_99_100": [int(v) for v in np.percentile([int(st[2 * (4096 + i) + 1]) >> 32 for i in range(nb)], [10, 50, 90, 99, 100])],
         # thread 0's first item, us from the block's begin: setup loads consumed | boxes united | candidates filtered | tested | end
