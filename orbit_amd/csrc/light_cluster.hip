@@ -708,8 +708,10 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
     }
     __shared__ float4 s_cand[kLightTile];       // a segment per wave: view-space light ...
     __shared__ uint32_t s_cand_idx[kLightTile]; // ... and its index | kNotPoint
-    __shared__ float s_wbox[kWaveClusters][8];  // per wave: union of its clusters' boxes (6) and its any-NaN flag (one-wave
-                                                // items: the eight clusters' boxes)
+    __shared__ float s_wbox[kAssignWaves][8];   // per wave: union of its clusters' boxes (6) and its any-NaN flag
+    __shared__ float s_ibox[kWaveClusters][8];  // one-wave items: the eight clusters' boxes.  Wave 0's own words: waves 1-3
+                                                // leave a one-wave item without a barrier and may be writing s_wbox for the
+                                                // NEXT (four-wave) item while wave 0 still tests this one
     __shared__ uint32_t s_wave_cnt[kAssignWaves];
     __shared__ uint32_t s_cpre[kCoarseSegs + 1]; // prefix of the group's segment counts
     __shared__ uint32_t s_ccnt[kCoarseSegs];     // the counts themselves
@@ -804,7 +806,7 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
                 // for the chain — and their registers, live across the branch, spill under this kernel's budget)
                 WaveItem wi;
                 wave_item_loads(p, wi, block_first, unique_idx, cbase, clbase, lane);
-                wave_item(p, wi, block_first, n, seg_counts, s_cand, s_cand_idx, &s_wbox[0][0], lane);
+                wave_item(p, wi, block_first, n, seg_counts, s_cand, s_cand_idx, &s_ibox[0][0], lane);
                 ORBIT_PHASE_STAMP();
             }
             continue;

@@ -7,6 +7,7 @@ the call replayed as a graph.  Always against the oracle's five buffers."""
 import numpy as np
 import pytest
 
+import scenes as sc
 from orbit_amd import layouts as L
 from test_gpu_parity import cluster_inputs, dev, host, torch_mod  # noqa: F401
 
@@ -148,3 +149,41 @@ def test_compute_clusters_replayed_as_a_graph(torch_mod, engine, oracle):
         _poison(b)
         g.replay()
         _check(torch, engine, s, b, f"replay {k}")
+
+
+@pytest.mark.parametrize("radius_scale", [0.25, 0.5, 0.9, 2.5])
+def test_one_wave_and_four_wave_items_alternate_in_one_workgroup(torch_mod, engine, oracle, radius_scale):
+    """ADVICE r05 (light_cluster.hip, count launch): a group whose coarse segments all hold <= 8 candidates is ONE wave's
+    item — waves 1-3 leave it without a barrier — and the next item of the same workgroup may be a four-wave one whose
+    waves 1-3 write their union boxes at once.  The one-wave item's eight boxes therefore live in LDS of their own.
+    1080p grid (> 65 536 active clusters: the count launch's workgroups take several items), lights in clumps so that
+    neighbouring groups fall on both sides of the 8-per-segment line, many repetitions (a race is a matter of timing),
+    every repetition against the oracle's five buffers."""
+    torch = torch_mod
+    W, H, n_lights = 1920, 1080, 2400
+    push, depth, info, lights = cluster_inputs(oracle, 22, W, H, n_lights, 8, 32)
+    # a tile's 64 samples spread over several z slices: > 100 000 active clusters
+    depth = (depth * sc.rnd_range(22, 91, np.arange(W * H), 0.6, 1.6).reshape(H, W)).astype(np.float32)
+    # clumps: every light is pulled towards one of 40 centres, half of the clumps tight, half loose
+    k = np.arange(n_lights)
+    centre = (k * 7) % 40
+    cpos = np.stack([np.cos(centre * 0.9) * (10.0 + centre), np.full(n_lights, 2.0), -8.0 - 1.7 * centre], axis=1).astype(np.float32)
+    pull = np.where(centre % 2 == 0, np.float32(0.96), np.float32(0.7))[:, None]
+    lights["position"][:, :3] = (lights["position"][:, :3] * (np.float32(1.0) - pull) + cpos * pull).astype(np.float32)
+    lights["outer_radius"] *= np.float32(radius_scale)
+    cc = [int(v) for v in push["cluster_count"]]
+    total, cap = cc[0] * cc[1] * cc[2], cc[0] * cc[1] * cc[2]
+    om, ob = oracle.cluster_mark(push, depth)
+    ou, _ = oracle.cluster_compact(cc, om, cap)
+    n_active = int(ou[12:16].view(np.uint32)[0])
+    assert n_active > 65536 + 8192, n_active  # several items per workgroup of the count launch
+    lcap = n_active * 256 + 16
+    ol, oimg, dropped = oracle.cluster_assign(info, ou, ob, lights, lcap, total)
+    assert dropped == 0
+    s = dict(push=push, depth=depth, info=info, lights=lights, cc=cc, total=total, cap=cap, lcap=lcap, n_active=n_active,
+             n_lights=n_lights, ref=(om, ob, ou, ol, oimg))
+    b = _buffers(torch, s)
+    for rep in range(24):
+        _poison(b)
+        _call(engine, s, b)
+        _check(torch, engine, s, b, f"repetition {rep}")
