@@ -7,7 +7,7 @@ N > 1, the rank-ordered all-gather of the visible list at record granularity (12
 meshlet offset, should-draw ballot — written by the evaluation launch itself; orbit_amd/dist.py) —
 what BASELINE.json's north_star names.  By default (--expand own) a rank's cull also ends in the 28-B
 MeshletDrawCommandBuffer of its own shard, the indirect-draw buffer it draws from; --expand none leaves that
-out, --expand all makes every GPU expand the whole gathered list (a separate stage on its own stream).
+out.  At N > 1 the transport not chosen is timed in a short leg behind the timed region (`transport_alt`).
 Inputs are generated on the device and stay resident in HBM; the timed region is
 K steps between barrier + synchronize on both sides, max over ranks.
 
@@ -49,27 +49,21 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="minimum CPU time spent in the oracle baseline")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather (cull only)")
     ap.add_argument("--transport", choices=("p2p", "rccl"), default="p2p",
-                    help="N>1: how the lists travel — p2p: direct stores into the peers' IPC-mapped buffers at "
-                         "device-computed offsets, no host round trip (default; falls back to rccl when IPC is not "
-                         "available); rccl: the record list as ONE RCCL all-gather of fixed-capacity segments + a "
-                         "device-side compaction (no count on the host, no stream wait: north_star's transport); the "
-                         "8-B item / 28-B command lists as grouped RCCL send/recv with the counts read on the host")
-    ap.add_argument("--exchange", choices=("records", "visible", "commands"), default="records",
-                    help="N>1 exchange format of the visible list: records (default) — 12 B {entity, meshlet offset, "
-                         "should-draw ballot} per dispatch record (the evaluation launch writes it), half the items' bytes at "
-                         "config 5; visible — 8 B {meshlet, entity} per survivor; commands — the 28-B commands "
-                         "themselves")
-    ap.add_argument("--expand", choices=("own", "none", "all"), default="own",
-                    help="N>1, exchange records / visible: which 28-B MeshletDrawCommandBuffer the step ends in — own "
-                         "(default: every rank's cull ends in BOTH the record list it sends and the 28-B commands of its "
-                         "own shard, the indirect-draw buffer it issues its own draws from, SURVEY.md §8e — one "
-                         "evaluation, orbit_meshlet_cull_records_and_commands), "
-                         "none (the step is cull + all-gather only: the visible list is the product), or all (every "
-                         "rank expands the WHOLE gathered list: N-independent work on every GPU)")
-    ap.add_argument("--signalling", choices=("device", "collectives"), default="device",
-                    help="N>1, transport p2p: how counts and completion of an exchange travel — device (default: stores "
-                         "into the peers' control blocks awaited on the device, orbit_exchange_list: no collective and "
-                         "no host call in a step) or collectives (two fixed-size torch.distributed collectives per step)")
+                    help="N>1: how the record lists travel — p2p: direct stores into the peers' IPC-mapped buffers at "
+                         "device-computed offsets, counts and completion signalled on the device (orbit_exchange_list; "
+                         "default; falls back to rccl when IPC mapping or the device-signalled probe fails); rccl: ONE "
+                         "RCCL all-gather of fixed-capacity list segments + a device-side compaction "
+                         "(orbit_compact_segments: north_star's transport).  Neither reads a count on the host.  The "
+                         "transport NOT chosen is timed in a short leg behind the timed region (transport_alt)")
+    ap.add_argument("--no-transport-alt", action="store_true", help="N>1: skip the other transport's leg")
+    ap.add_argument("--expand", choices=("own", "none"), default="own",
+                    help="N>1: own (default) — every rank's cull ends in BOTH the record list it sends and the 28-B "
+                         "MeshletDrawCommandBuffer of its own shard, the indirect-draw buffer it issues its own draws "
+                         "from (SURVEY.md §8e; one evaluation, orbit_cull_shard); none — the step is cull + all-gather "
+                         "only: the visible list is the product")
+    ap.add_argument("--verify-single-rank", action="store_true",
+                    help="N>1: behind the timed region rank 0 culls the WHOLE scene alone (one orbit_cull_shard over all "
+                         "entity-draws) and compares its record list byte for byte with the gathered one")
     ap.add_argument("--graph", action="store_true",
                     help="N>1 (transport p2p with device signalling, --expand own / none, one frame slot): replay every "
                          "timed step as a captured HIP graph — cull on the slot's stream, the exchange of the previous "
@@ -78,16 +72,12 @@ def parse():
                          "wall / K stays within 4 %% of the median step interval (eager: 12 %%), but consecutive graph "
                          "launches leave a gap of their own on this runtime: a 1/8 shard's step 0.084 ms against 0.079 "
                          "eager (profiles/r05_notes.md) — so it is an option, not the default")
-    ap.add_argument("--two-calls", action="store_true",
-                    help="N>1, exchange records: the rank's cull as orbit_entity_cull_range + orbit_meshlet_cull_visible_records "
-                         "(_records_and_commands) instead of ONE orbit_cull_shard call (for A/B: the same outputs)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frame slots (OrbitCtx + stream + buffers each) the steps go round-robin over; 1 = strictly serial "
                          "frames.  0 (default) = 1 at N = 1 (step time = frame latency, a launch's HIP-event duration is "
                          "the kernel's own) and 2 at N > 1, the renderer's FRAME_COUNT (context.rs:1275-1316): a shard's "
                          "cull is a chain of dependent round trips — its entity stage alone is 15-19 us of a 60-us launch "
-                         "at a 1/8 shard — which only another frame's work can fill: 0.076 -> 0.049 ms per step there "
-                         "(--expand all: 1)")
+                         "at a 1/8 shard — which only another frame's work can fill: 0.076 -> 0.049 ms per step there")
     ap.add_argument("--time-every", type=int, default=3,
                     help="the dominant kernel of every n-th launch per frame slot is timed with HIP events")
     ap.add_argument("--meshlet-source", choices=("stream", "buffer"), default="stream",
@@ -224,26 +214,18 @@ def main():
     n_local_meshlets = n_local_entities * M
     rec_per_ent = spec.records_per_entity
 
-    # N > 1: the exchange step.  Transport "p2p" (default): no host round trip — counts all-gathered into a device
-    # tensor, every rank stores its list straight into every peer's buffer (IPC-mapped, xGMI) at device-computed
-    # offsets, one more fixed-size collective as completion (orbit_amd/dist.py P2PExchange, orbit_scatter_list).
-    # Transport "rccl": counts read on the host, grouped RCCL send/recv of the lists (needs the nccl backend).
-    # Format "visible": 8-B {meshlet_index, entity_index} items travel and a GPU that wants commands expands the gathered
-    # list into the 28-B commands itself — which needs the meshlet buffer (static geometry, 1.6 GB of 288 GB) on every
-    # GPU; a rank still STREAMS only its own shard through meshlet_cull.  Format "commands": the 28-B lists travel as
-    # they are and a rank holds only its meshlet shard.
-    do_gather = use_dist and not args.no_gather and (backend == "nccl" or args.transport == "p2p")
-    # Format "records": the same ordered list at record granularity — 12 B {entity_index, meshlet_offset, ballot} per
-    # dispatch record (orbit_meshlet_cull_visible_records), written by the evaluation launch itself (no survivor scan, no
-    # launch behind it); half the 8-B items' bytes at config 5 (3 survivors per record).
-    visible_exchange = do_gather and args.exchange == "visible"
-    records_exchange = do_gather and args.exchange == "records"
-    compact_exchange = visible_exchange or records_exchange
-    do_expand = compact_exchange and args.expand == "all"  # needs the whole meshlet buffer (+ stream) on every GPU
-    own_expand = records_exchange and args.expand == "own"  # this rank's commands from this rank's record list
+    # N > 1: the exchange step — the rank-ordered all-gather of the ranks' visible lists at record granularity: 12 B
+    # {entity_index, meshlet_offset, should-draw ballot} per dispatch record, written by the evaluation launch itself
+    # (orbit_cull_shard).  Transport "p2p" (default): every rank stores its list straight into every peer's buffer
+    # (IPC-mapped, xGMI) at device-computed offsets, counts and completion signalled on the device (orbit_exchange_list,
+    # orbit_amd/dist.py P2PExchange).  Transport "rccl": ONE ncclAllGather of fixed-capacity segments + a device-side
+    # compaction (AllGatherExchange).  No count is read on the host by either; a rank holds only its meshlet shard.
+    do_gather = use_dist and not args.no_gather
+    records_exchange = do_gather
+    own_expand = records_exchange and args.expand == "own"  # this rank's commands from this rank's evaluation
     t0 = time.time()
     draws, mesh, ent, half = synth.gen_entity_tables(spec, dev)
-    mb, me = (0, E) if do_expand else (b, e)
+    mb, me = b, e
     meshlets = synth.gen_meshlets(spec, mb, me, dev, half, survive_target=args.survive, shape=args.scene_shape)
     materials = synth.gen_materials(spec, dev)
     torch.cuda.synchronize()
@@ -267,15 +249,11 @@ def main():
     # part of their run and the HIP-event duration of a launch is no longer that kernel's own time.  The default is
     # ONE slot: strictly serial frames, step time = frame latency, clean per-kernel durations.
     # N > 1: the exchange of step i runs on its own stream while step i+1 culls into the slot's other list buffer.
-    # (--expand all keeps one slot: its expansion stream is the fifth stream of the process, one more than the runtime has
-    # hardware queues for, and the host then blocks in the enqueue calls: 0.13 ms per step at a 1/8 shard)
-    F = args.frames_in_flight if args.frames_in_flight > 0 else (2 if (use_dist and args.expand != "all") else 1)
-    hdr, item = (L.VISIBLE_HEADER, 12) if records_exchange else (L.VISIBLE_HEADER, 8) if visible_exchange else (L.DRAW_HEADER, 28)
-    list_cap = disp_cap if records_exchange else draw_cap  # entries a rank's list can hold (records / survivors)
-    # the record list as a fixed-capacity segment of an RCCL all-gather (--transport rccl): the same capacity on every rank
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (2 if use_dist else 1)
+    hdr, item = (L.VISIBLE_HEADER, 12) if records_exchange else (L.DRAW_HEADER, 28)
+    # the record list is also a fixed-capacity segment of an RCCL all-gather: the same capacity on every rank
     seg_cap = max(e_ - b_ for b_, e_ in odist.shard_ranges(E, world)) * rec_per_ent + 8
-    if records_exchange:
-        list_cap = seg_cap
+    list_cap = seg_cap if records_exchange else draw_cap  # entries a rank's list can hold (records / commands)
 
     class Slot:
         def __init__(self):
@@ -306,90 +284,66 @@ def main():
         mstream_build_ms = (time.perf_counter() - t0) * 1e3
         for s in slots:
             s.eng.bind_meshlet_stream(mstream)
-    # The exchange stage: two exchange buffers (alternating) and, with --expand all, a third stream for the expansion,
-    # so that three things overlap in steady state — the cull of step i+1 (slot stream), the wire of step i (exchange
-    # stream) and the expansion of step i-1 (expansion stream): step time = max(cull, wire, expansion), not their sum.
-    xstream = estream = gathered = None
-    exchanges, recv_bufs, x_events, e_events = [], [], [], []
+    # The exchange stage: two exchange buffers (alternating) on a stream of its own, so that the cull of step i+1 (slot
+    # stream) and the wire of step i (exchange stream) overlap in steady state: step time = max(cull, wire), not their sum.
+    xstream = None
+    exchanges, recv_bufs = [], []
     transport = transport_fallback = None
+    x_cap = list_cap * world  # entries of the gathered list
+    n_x = 2
+
+    def make_exchanges(name):
+        """The exchange objects of transport `name`, agreed on by all ranks: (list, None) or (None, why not)."""
+        ok, made, why = 1, [], None
+        try:
+            if name == "p2p":
+                made = [odist.P2PExchange(slots[0].eng, x_cap, hdr, item, dev) for _ in range(n_x)]
+                fell = [x.fallback for x in made if x.fallback]
+                if fell:  # the device-signalled exchange failed its probe between the devices of THIS node (all ranks alike)
+                    ok, why = 0, fell[0]
+            else:
+                made = [odist.AllGatherExchange(slots[0].eng, seg_cap, x_cap, hdr, item, dev) for _ in range(n_x)]
+                if not all([x.probe(check_status=slots[0].eng.status) for x in made]):
+                    ok, why = 0, "the all-gather exchange failed its probe"
+        except Exception as ex:  # noqa: BLE001 - e.g. IPC not available between these processes: agreed on below
+            print(f"bench.py: transport {name} unavailable on rank {rank} ({ex})", file=sys.stderr)
+            ok, why = 0, f"{name}: {ex}"
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return made, None
+        for x in made:
+            try:
+                x.close()
+            except Exception:  # noqa: BLE001
+                pass
+        return None, why or f"{name} failed on another rank"
+
     if do_gather:
         xstream = torch.cuda.Stream(device=dev)
-        estream = torch.cuda.Stream(device=dev)
-        out_cap = draw_cap * world  # commands of the whole scene (--expand all)
-        x_cap = list_cap * world    # entries of the gathered list
         transport = args.transport
-        n_x = 2
-        if transport == "p2p":
-            ok = 1
-            try:
-                exchanges = [odist.P2PExchange(slots[0].eng, x_cap, hdr, item, dev, signalling=args.signalling)
-                             for _ in range(n_x)]
-            except Exception as ex:  # IPC not available between these processes: every rank falls back together
-                print(f"bench.py: p2p exchange unavailable on rank {rank} ({ex}); falling back to RCCL send/recv",
-                      file=sys.stderr)
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1 and args.signalling == "device":
-                # device signalling has to work between the devices of THIS node before the timed steps rely on it: the
-                # constructor ran one known exchange per buffer and compared it (P2PExchange probe_on_init); where that
-                # failed the object signals through two 4-B collectives instead — on all ranks alike, and the line says so
-                fell = [x.fallback for x in exchanges if x.fallback]
-                if fell:
-                    print(f"bench.py: the device-signalled exchange failed its probe (rank {rank}); "
-                          "the step signals through collectives", file=sys.stderr)
-                    transport_fallback = fell[0]
-            if int(flag.item()) == 0:
-                if backend != "nccl":
-                    raise SystemExit("bench.py: p2p exchange unavailable and the backend cannot move device lists")
-                transport, exchanges = "rccl", []
-                transport_fallback = "p2p -> rccl: HIP IPC mapping of a peer's list buffer failed on at least one rank"
-        if transport == "rccl" and records_exchange:
-            # north_star's transport, device-only: ONE ncclAllGather of the ranks' record lists as fixed-capacity
-            # segments + one compaction launch (orbit_amd/dist.py AllGatherExchange, orbit_compact_segments) — no count
-            # on the host, no stream wait; also where the p2p transport lands when IPC mapping fails
-            exchanges = [odist.AllGatherExchange(slots[0].eng, seg_cap, x_cap, hdr, item, dev) for _ in range(n_x)]
-            if not all([x.probe(check_status=slots[0].eng.status) for x in exchanges]):
-                raise SystemExit("bench.py: the RCCL all-gather exchange failed its probe")
-        if exchanges:
-            recv_bufs = [x.out for x in exchanges]
-        else:  # 8-B items / 28-B commands over RCCL: variable-size send/recv, counts on the host
-            recv_bufs = [torch.zeros(hdr + item * x_cap, dtype=torch.uint8, device=dev) for _ in range(n_x)]
-        x_events = [torch.cuda.Event() for _ in range(n_x)]  # exchange into recv_bufs[j] finished
-        e_events = [torch.cuda.Event() for _ in range(n_x)]  # expansion out of recv_bufs[j] finished
-        if do_expand:
-            gathered = torch.zeros(L.DRAW_HEADER + 28 * out_cap, dtype=torch.uint8, device=dev)
-    explicit_stream_exchange = bool(exchanges) and all(getattr(x, "signalling", None) == "device" for x in exchanges)
+        exchanges, why = make_exchanges(transport)
+        if exchanges is None and transport == "p2p":  # every rank lands on north_star's transport together
+            transport_fallback = f"p2p -> rccl: {why}"
+            print(f"bench.py: {transport_fallback}", file=sys.stderr)
+            transport = "rccl"
+            exchanges, why = make_exchanges(transport)
+        if exchanges is None:
+            raise SystemExit(f"bench.py: no transport for the visible list: {why}")
+        recv_bufs = [x.out for x in exchanges]
     pending = []  # (slot, list index) culled but not yet exchanged (at most one)
     x_count = [0]
 
     def gather(s, k):
         # the exchange of one list on the exchange stream, behind the cull that wrote the list — not behind the cull
-        # enqueued after it; the expansion (--expand all) follows on its own stream
+        # enqueued after it.  The device-signalled p2p exchange is enqueued by the library on the stream it is given (no
+        # stream context: torch's costs ~10 us of host time per step); the all-gather is a torch.distributed call and goes
+        # to the stream AllGatherExchange makes current
         j = x_count[0] % len(recv_bufs)
         x_count[0] += 1
         xstream.wait_event(s.cull_done[k])
-        if do_expand:
-            xstream.wait_event(e_events[j])  # the expansion that read this receive buffer two exchanges ago
-        if explicit_stream_exchange:  # device-signalled p2p: the library enqueues on the stream it is given — no stream
-            exchanges[j].exchange(s.lists[k], stream=xstream)  # context (torch's costs ~10 us of host time per step)
-        else:
-            with torch.cuda.stream(xstream):  # torch.distributed calls go to the current stream
-                if exchanges:  # p2p with two collectives, or the RCCL all-gather: nothing waits for the host
-                    exchanges[j].exchange(s.lists[k], stream=xstream)
-                else:
-                    odist.gather_visible(s.lists[k], recv_bufs[j], header=hdr, stride=item)
+        exchanges[j].exchange(s.lists[k], stream=xstream)
         s.xdone[k].record(xstream)  # the list buffer may be overwritten
-        if do_expand:
-            x_events[j].record(xstream)
-        if do_expand:
-            with torch.cuda.stream(estream):
-                estream.wait_event(x_events[j])
-                if records_exchange:
-                    s.eng.expand_visible_records(recv_bufs[j], meshlets_base, gathered, out_cap, stream=estream)
-                else:
-                    s.eng.expand_visible(recv_bufs[j], meshlets_base, gathered, out_cap, stream=estream)
-                e_events[j].record(estream)
         return j
 
     step_no = [0]
@@ -397,7 +351,7 @@ def main():
     shard_calls = {}  # (slot, list index) -> the prepared orbit_cull_shard call (argument blocks built once)
 
     def cull(s, k):
-        if records_exchange and not args.two_calls:
+        if records_exchange:
             # a rank's whole cull as ONE call (orbit_cull_shard) and, up to 65 536 entity-draws, ONE launch: entity test,
             # record append, meshlet test and the record list the rank sends — plus, with --expand own, the emit launch for
             # the 28-B commands of its own shard (its indirect-draw buffer, "each rank issues its own draws": SURVEY §8e)
@@ -410,21 +364,8 @@ def main():
             call()
             return
         s.eng.entity_cull(ci, draws, mesh, s.disp, ent, n_local_entities, disp_cap, draw_first=b, stream=s.stream)
-        if own_expand:
-            # one evaluation, two products: the record list this rank sends and the 28-B commands of its own shard (its
-            # indirect-draw buffer, "each rank issues its own draws": SURVEY.md §8e) — list launches, then scan + emit
-            s.eng.meshlet_cull_records_and_commands(ci, s.disp, meshlets_base, s.lists[k], s.own_cmds, ent, materials,
-                                                    disp_cap, list_cap, draw_cap, material_count=spec.materials,
-                                                    stream=s.stream)
-        elif records_exchange:
-            s.eng.meshlet_cull_visible_records(ci, s.disp, meshlets_base, s.lists[k], ent, materials, disp_cap, list_cap,
-                                               material_count=spec.materials, stream=s.stream)
-        elif visible_exchange:
-            s.eng.meshlet_cull_visible(ci, s.disp, meshlets_base, s.lists[k], ent, materials, disp_cap, draw_cap,
-                                       material_count=spec.materials, stream=s.stream)
-        else:
-            s.eng.meshlet_cull(ci, s.disp, meshlets_base, s.lists[k], ent, materials, disp_cap, draw_cap,
-                               material_count=spec.materials, stream=s.stream)
+        s.eng.meshlet_cull(ci, s.disp, meshlets_base, s.lists[k], ent, materials, disp_cap, draw_cap,
+                           material_count=spec.materials, stream=s.stream)
 
     step_marks = []  # N > 1: one timing event per step of the timed region, behind that step's exchange
     mark_ring = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 2)] if do_gather else []  # created (and
@@ -457,10 +398,7 @@ def main():
             torch.cuda.current_stream().wait_stream(s.stream)
         if xstream is not None:
             torch.cuda.current_stream().wait_stream(xstream)
-            torch.cuda.current_stream().wait_stream(estream)
 
-    if do_gather and transport == "rccl" and not exchanges:  # RCCL channel set-up is not part of any step, warm or timed
-        assert odist.warm_up(dev)
     # Power-state settle (see --settle-ms): the same frames, back to back, until the device has been busy that long.
     # The frame count must be the same on every rank (a step of the sharded engine contains collectives), so it is
     # derived from the slowest rank's time for the first eight frames, not from each rank's own clock.
@@ -549,8 +487,7 @@ def main():
     # slot's two list buffers and the two exchange buffers: graph k = { cull into list k  ||  exchange of list 1 - k, the
     # previous step's } — fork and join inside the capture, so that a replay is the steady-state step: K replays are K
     # culls and K exchanges, each exchange beside the cull of the step after it.
-    use_graph = bool(do_gather and args.graph and F == 1 and not do_expand and exchanges
-                     and all(getattr(x, "signalling", None) == "device" for x in exchanges))
+    use_graph = bool(do_gather and args.graph and F == 1 and transport == "p2p")
     graphs = []
     if use_graph:
         s0g = slots[0]
@@ -646,50 +583,32 @@ def main():
 
     # one frame alone on an idle device (nothing else in flight): the latency a single cull costs, and its parts
     s0 = slots[0]
-    serial, op_ms, x_ms, ex_ms = [], [], [], []
+    serial, op_ms, x_ms = [], [], []
     last_recv = 0
     for _ in range(5):
         a, m, z = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         a.record(s0.stream)
-        if records_exchange and not args.two_calls:  # one call, one launch: there is no "meshlet stage alone"
+        if records_exchange:  # one call, one launch: there is no "meshlet stage alone"
             m = a
             cull(s0, 0)
         else:
             s0.eng.entity_cull(ci, draws, mesh, s0.disp, ent, n_local_entities, disp_cap, draw_first=b, stream=s0.stream)
             m.record(s0.stream)
-        if records_exchange and not args.two_calls:
-            pass
-        elif own_expand:
-            s0.eng.meshlet_cull_records_and_commands(ci, s0.disp, meshlets_base, s0.lists[0], s0.own_cmds, ent, materials,
-                                                     disp_cap, list_cap, draw_cap, material_count=spec.materials,
-                                                     stream=s0.stream)
-        elif records_exchange:
-            s0.eng.meshlet_cull_visible_records(ci, s0.disp, meshlets_base, s0.lists[0], ent, materials, disp_cap,
-                                                list_cap, material_count=spec.materials, stream=s0.stream)
-        elif visible_exchange:
-            s0.eng.meshlet_cull_visible(ci, s0.disp, meshlets_base, s0.lists[0], ent, materials, disp_cap, draw_cap,
-                                        material_count=spec.materials, stream=s0.stream)
-        else:
             s0.eng.meshlet_cull(ci, s0.disp, meshlets_base, s0.lists[0], ent, materials, disp_cap, draw_cap,
                                 material_count=spec.materials, stream=s0.stream)
         z.record(s0.stream)
         torch.cuda.synchronize()
         serial.append(a.elapsed_time(z))
         op_ms.append(m.elapsed_time(z))
-        if do_gather:  # the exchange (+ expansion) of that list alone
-            if use_dist:
-                dist.barrier()
-            xa, xm, xz = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        if do_gather:  # the exchange of that list alone
+            dist.barrier()
+            xa, xm = (torch.cuda.Event(enable_timing=True) for _ in range(2))
             s0.cull_done[0].record(s0.stream)
             xa.record(xstream)
             last_recv = gather(s0, 0)
             xm.record(xstream)
-            if do_expand:
-                xz.record(estream)
             torch.cuda.synchronize()
             x_ms.append(xa.elapsed_time(xm))
-            if do_expand:
-                ex_ms.append(xm.elapsed_time(xz))
     # the same frames from the 32-B Meshlet buffer (stream unbound), for the record, outside any metric
     buffer_path_latency_ms = buffer_path_ms_per_step = None
     if mstream is not None and not do_gather:
@@ -719,45 +638,98 @@ def main():
     frame_latency_ms = float(np.median(serial))
     kernel_ms = float(np.median(op_ms))  # whole meshlet_cull op (eval + scan + emit) of a frame alone on the device
     exchange_ms = float(np.median(x_ms)) if x_ms else None
-    expand_ms = float(np.median(ex_ms)) if ex_ms else None
 
     disp, draw = s0.disp, s0.lists[0]  # the latency frames above ran on slot 0: its buffers hold the last result
     n_rec = int(disp[:4].view(torch.int32).item())
     n_list = int(draw[:4].view(torch.int32).item())  # entries of this rank's list: records, items or commands
     n_draw = int(draw[4:8].view(torch.int32).item()) if records_exchange else n_list  # its survivors
+    transport_alt = single_rank_check = None
     if do_gather:  # the gathered list holds this rank's entries at its rank-order position
         counts = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
         dist.all_gather(counts, torch.tensor([n_list, n_draw], dtype=torch.int64, device=dev))
         first = int(sum(int(c[0].item()) for c in counts[:rank]))
-        first_draw = int(sum(int(c[1].item()) for c in counts[:rank]))
-        wire = recv_bufs[last_recv]  # what travelled: 12-B records, 8-B visible items or 28-B commands, rank order
+        wire = recv_bufs[last_recv]  # what travelled: 12-B records, rank order
         assert torch.equal(wire[hdr + item * first:hdr + item * (first + n_list)], draw[hdr:hdr + item * n_list]), \
             "gathered list != local list"
-        assert int(wire[:4].view(torch.int32).item()) == int(sum(int(c[0].item()) for c in counts))
-        g_hdr, g_item = hdr, item
-        if do_expand:  # commands expanded from the gathered list: their (meshlet, entity) are this rank's survivors
-            mine = gathered[L.DRAW_HEADER + 28 * first_draw:L.DRAW_HEADER + 28 * (first_draw + n_draw)]
-            cmds = mine.view(torch.int32).view(-1, 7)
-            if records_exchange:  # bit b of a record = {meshlet_offset + b, entity_index}, ascending
-                recs = draw[hdr:hdr + 12 * n_list].view(torch.int32).view(-1, 3)
-                bits = (recs[:, 2:3] >> torch.arange(32, device=dev, dtype=torch.int32)) & 1
-                r_idx, b_idx = torch.nonzero(bits, as_tuple=True)  # row-major: record order, then ascending bit
-                items = torch.stack([recs[r_idx, 1] + b_idx.to(torch.int32), recs[r_idx, 0]], dim=1)
-            else:
-                items = draw[L.VISIBLE_HEADER:L.VISIBLE_HEADER + 8 * n_draw].view(torch.int32).view(-1, 2)
-            assert len(items) == n_draw and torch.equal(cmds[:, 6], items[:, 0]) and torch.equal(cmds[:, 4], items[:, 1]), \
-                "expanded list != local visible list"
-            g_hdr, g_item = L.DRAW_HEADER, 28
-        else:
-            gathered = wire
+        total = int(wire[:4].view(torch.int32).item())
+        assert total == int(sum(int(c[0].item()) for c in counts))
+
+        def list_checksum(buf):
+            words = buf[hdr:hdr + item * total].view(torch.int32).to(torch.int64)
+            return torch.stack([words.sum(), (words * (torch.arange(words.numel(), device=dev) % 8191 + 1)).sum()])
+
         # the whole gathered list is the same on every rank: a checksum of it must agree
-        total = int(gathered[:4].view(torch.int32).item())
-        words = gathered[g_hdr:g_hdr + g_item * total].view(torch.int32).to(torch.int64)
-        chk = torch.stack([words.sum(), (words * (torch.arange(words.numel(), device=dev) % 8191 + 1)).sum()])
+        chk = list_checksum(wire)
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert torch.equal(lo, hi), "ranks hold different gathered lists"
+        gathered_main = wire[:hdr + item * total].clone()
+
+        # The OTHER transport, behind the timed region (as protocol_8d at N = 1: in the line, never the metric): the same
+        # steps with the exchange objects swapped — so that ONE scaling run compares north_star's RCCL all-gather with the
+        # direct xGMI stores on the same node, scene and step.  Its gathered list must be the main transport's, byte for byte.
+        if not args.no_transport_alt:
+            alt_name = "rccl" if transport == "p2p" else "p2p"
+            alt, why = make_exchanges(alt_name)
+            if alt is None:
+                transport_alt = {"name": alt_name, "ms_per_step": None, "unavailable": why}
+            else:
+                main_ex, main_recv = exchanges[:], recv_bufs[:]
+                exchanges[:], recv_bufs[:] = alt, [x.out for x in alt]
+                for _ in range(max(args.warmup, 2) + 2 * F):
+                    step()
+                drain()
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                ta = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                drain()
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                alt_t = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device=dev)
+                dist.all_reduce(alt_t, op=dist.ReduceOp.MAX)
+                slots[0].eng.status()
+                j = (x_count[0] - 1) % len(recv_bufs)
+                same = torch.tensor([1 if torch.equal(recv_bufs[j][:hdr + item * total], gathered_main) else 0],
+                                    dtype=torch.int32, device=dev)
+                dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                if int(same.item()) != 1:
+                    raise SystemExit(f"bench.py: transport {alt_name} delivered a different list than {transport}")
+                transport_alt = {"name": alt_name, "ms_per_step": float(alt_t.item()) / args.steps * 1e3, "steps": args.steps,
+                                 "signalling": alt[0].signalling, "list_identical_to_main_transport": True,
+                                 "what": "the same steps with the other transport's exchange objects, behind the timed "
+                                         "region; wall / K between barrier + synchronize, max over ranks"}
+                exchanges[:], recv_bufs[:] = main_ex, main_recv
+                for x in alt:
+                    x.close()
+        # --verify-single-rank: the gathered list against ONE rank culling the whole scene (rank 0, the Meshlet buffer —
+        # no derived stream: another evaluation path — through one orbit_cull_shard over all entity-draws)
+        if args.verify_single_rank:
+            ok = 1
+            if rank == 0:
+                full = synth.gen_meshlets(spec, 0, E, dev, half, survive_target=args.survive, shape=args.scene_shape)
+                cap_f = E * rec_per_ent + 8
+                eng_f = Engine(device_index, max_entities=E + 256, max_dispatches=cap_f, max_draws=draw_cap)
+                disp_f = torch.zeros(L.DISPATCH_HEADER + 16 * cap_f, dtype=torch.uint8, device=dev)
+                rec_f = torch.zeros(hdr + item * cap_f, dtype=torch.uint8, device=dev)
+                eng_f.cull_shard(ci, draws, mesh, disp_f, ent, 0, E, cap_f, full, materials, rec_f, cap_f,
+                                 material_count=spec.materials)
+                torch.cuda.synchronize()
+                eng_f.status()
+                n_f = int(rec_f[:4].view(torch.int32).item())
+                if n_f != total or not torch.equal(rec_f[hdr:hdr + item * n_f], gathered_main[hdr:]):
+                    ok = 0
+                eng_f.close()
+                del full, disp_f, rec_f
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) != 1:
+                raise SystemExit("bench.py: the gathered list differs from a single rank's list of the whole scene")
+            single_rank_check = {"gathered_list_equals_single_rank_list": True, "records": total}
     if own_expand:  # the shard's indirect-draw buffer holds exactly the survivors the shard's record list names, in order
         cmds = s0.own_cmds
         assert int(cmds[:4].view(torch.int32).item()) == n_draw, "own command buffer: wrong count"
@@ -777,23 +749,21 @@ def main():
         agg = torch.tensor([n_in, n_draw], dtype=torch.int64, device=dev)
         dist.all_reduce(agg)
         tot_in, tot_draw = int(agg[0].item()), int(agg[1].item())
-        km = torch.tensor([kernel_ms, frame_latency_ms, exchange_ms or 0.0, expand_ms or 0.0, float(n_in), float(n_draw)],
+        km = torch.tensor([kernel_ms, frame_latency_ms, exchange_ms or 0.0, 0.0, float(n_in), float(n_draw)],
                           dtype=torch.float64, device=dev)
         per = [torch.zeros_like(km) for _ in range(world)]
         dist.all_gather(per, km)
-        per = torch.stack(per).cpu().numpy()  # [rank, (meshlet_cull op, frame, exchange, expand, meshlets in, survivors)]
+        per = torch.stack(per).cpu().numpy()  # [rank, (meshlet_cull op, frame, exchange, -, meshlets in, survivors)]
         kernel_ms_max, kernel_ms_max_frame = float(per[:, 0].max()), float(per[:, 1].max())
         exchange_ms_max = float(per[:, 2].max()) if exchange_ms is not None else None
-        expand_ms_max = float(per[:, 3].max()) if expand_ms is not None else None
         per_rank_rows = {"cull_ms": [float(v) for v in per[:, 1]],
                          "exchange_ms": [float(v) for v in per[:, 2]] if exchange_ms is not None else None,
-                         "expand_ms": [float(v) for v in per[:, 3]] if expand_ms is not None else None,
                          "meshlets_in": [int(v) for v in per[:, 4]], "survivors": [int(v) for v in per[:, 5]]}
         world_reported = dist.get_world_size()
     else:
         tot_in, tot_draw, kernel_ms_max, kernel_ms_max_frame = n_in, n_draw, kernel_ms, frame_latency_ms
-        exchange_ms_max = expand_ms_max = None
-        per_rank_rows = {"cull_ms": [frame_latency_ms], "exchange_ms": None, "expand_ms": None,
+        exchange_ms_max = None
+        per_rank_rows = {"cull_ms": [frame_latency_ms], "exchange_ms": None,
                          "meshlets_in": [n_in], "survivors": [n_draw]}
         world_reported = 1
 
@@ -813,7 +783,7 @@ def main():
     achieved = alg_bytes / (eval_ms * 1e-3) / 1e9
     # the chain emit: records again, 2-B counts of every meshlet (records without survivors are skipped: a few %), 64-B
     # ballots per tile, one link bit per meshlet
-    emit_read = (16 * n_rec + 2 * n_in + n_rec * 4 + n_in // 8) if (mstream is not None and not compact_exchange) else 0
+    emit_read = (16 * n_rec + 2 * n_in + n_rec * 4 + n_in // 8) if (mstream is not None and not records_exchange) else 0
     op_bytes = alg_bytes + emit_read + item * n_list + 4
     # the PMC passes were taken on the whole scene at N=1
     traffic, traffic_stamp = load_traffic(E, M, args.meshlet_source) if world == 1 else (None, None)
@@ -864,12 +834,9 @@ def main():
                             f"frustum + normal cone (occlusion_pass 0), all entities in view, "
                             f"{100.0 * tot_draw / max(tot_in, 1):.1f}% survivors ({args.scene_shape})"
                             + ((", + rank-ordered all-gather of the visible list (12 B per dispatch record: entity, "
-                                "meshlet offset, should-draw ballot)" if records_exchange else
-                                ", + rank-ordered all-gather of the visible list (8-B items)" if visible_exchange
-                                else ", + rank-ordered all-gather of the 28-B command lists")
+                                "meshlet offset, should-draw ballot)")
                                + (" by direct xGMI stores at device-computed offsets" if transport == "p2p" else
-                                  " by ONE RCCL all-gather of fixed-capacity list segments + a device-side compaction"
-                                  if exchanges else " by RCCL send/recv (counts read on the host)")
+                                  " by ONE RCCL all-gather of fixed-capacity list segments + a device-side compaction")
                                if do_gather else ""),
                 "entities": E, "meshlets": E * M, "meshlets_into_meshlet_cull": tot_in, "survivors": tot_draw,
                 "scene_shape": args.scene_shape,
@@ -879,20 +846,17 @@ def main():
                 "warmup_effective": frames_before_timed,  # every frame this process ran before the timed region
                 "ms_per_step_without_settle": cold_ms_per_step,
                 "world_size": world_reported, "backend": (backend if use_dist else None),
-                "expand": (args.expand if compact_exchange else None),
+                "expand": (args.expand if do_gather else None),
                 "step_product": (None if not do_gather else
                                  "the all-gathered visible list on every GPU + every rank's own shard as a 28-B "
                                  "MeshletDrawCommandBuffer (its indirect draws)" if own_expand else
-                                 "the all-gathered visible list on every GPU + the whole list expanded into 28-B commands "
-                                 "on every GPU" if do_expand else
-                                 "the all-gathered visible list only (no command buffer is built inside the step)"
-                                 if compact_exchange else "the all-gathered 28-B command list on every GPU"),
+                                 "the all-gathered visible list only (no command buffer is built inside the step)"),
                 "signalling": (exchanges[0].signalling if exchanges else None),
                 "step_intervals": step_intervals,
                 "steps_as_graph": (use_graph if do_gather else None),
                 "host_enqueue_ms_per_step": host_enqueue_ms_per_step,
                 "list_bytes_per_rank_max": (int(max(c[0].item() for c in counts)) * item if do_gather else None),
-                "exchange": (args.exchange if do_gather else None), "transport": transport,
+                "exchange": ("records" if do_gather else None), "transport": transport,
                 "transport_requested": (args.transport if do_gather else None), "transport_fallback": transport_fallback,
                 "meshlet_source": (f"derived meshlet streams ({per_meshlet:g} B per meshlet evaluated"
                                    f"{' (alpha classes instead of material indices)' if not args.no_alpha_classes else ''}, "
@@ -919,15 +883,15 @@ def main():
             "cpu_baseline": cpu_baseline,
             "protocol_8d": protocol_8d,
             "two_pass": two_pass,
+            "transport_alt": transport_alt,
+            "single_rank_check": single_rank_check,
             "frame_latency_ms": frame_latency_ms,
             "frame_latency_ms_from_meshlet_buffer": buffer_path_latency_ms,
             "ms_per_step_from_meshlet_buffer": buffer_path_ms_per_step,
             "per_rank": dict(per_rank_rows, cull_ms_max=kernel_ms_max_frame, exchange_ms_max=exchange_ms_max,
-                             expand_ms_max=expand_ms_max,
-                             what="one frame alone on each rank's device, per rank: entity_cull + meshlet_cull of its "
-                                  "shard, the exchange of its list, the expansion of the gathered list (--expand all "
-                                  "only).  In the timed region they overlap (cull of step i+1, wire of step i, "
-                                  "expansion of i-1): step time = the slowest stage, not the sum"),
+                             what="one frame alone on each rank's device, per rank: the cull of its shard (entity + "
+                                  "meshlet stage), the exchange of its list.  In the timed region they overlap (cull of "
+                                  "step i+1, wire of step i): step time = the slower stage, not the sum"),
             "cull_only_meshlets_per_sec": tot_in / (kernel_ms_max * 1e-3) if kernel_ms_max > 0 else None,
             "scene_gen_s": gen_s,
         }

@@ -111,21 +111,13 @@ extern "C" {
                                   lights: *const c_void, masks: *mut u32, bounds: *mut c_void, unique: *mut c_void,
                                   index_capacity: u32, light_index_buffer: *mut c_void, light_index_capacity: u32,
                                   cluster_offset_image: *mut u32, stream: *mut c_void) -> i32;
-    /// Sharded engine only: rank-ordered all-gather of the visible lists over the caller's ncclComm_t.
+    /// Sharded engine: the shard range; SURVEY §8b's gather of 28-B command lists over the caller's ncclComm_t (one host sync).
     pub fn orbit_shard_range(entity_draw_count: u32, rank: u32, world: u32, begin: *mut u32, end: *mut u32);
     pub fn orbit_gather_visible(ctx: *mut OrbitCtx, nccl_comm: *mut c_void, rank: u32, world: u32,
                                 local_draw_buffer: *const c_void, out_draw_buffer: *mut c_void, out_capacity: u32,
                                 stream: *mut c_void) -> i32;
-    /// Compact exchange (8 B per survivor): cull into a visible list, all-gather, expand on every GPU.
-    pub fn orbit_meshlet_cull_visible(ctx: *mut OrbitCtx, cull_info: *const c_void, bufs: *const c_void,
-                                      visible_buffer: *mut c_void, visible_capacity: u32, stream: *mut c_void) -> i32;
-    pub fn orbit_gather_visible_meshlets(ctx: *mut OrbitCtx, nccl_comm: *mut c_void, rank: u32, world: u32,
-                                         local_visible_buffer: *const c_void, out_visible_buffer: *mut c_void,
-                                         out_capacity: u32, stream: *mut c_void) -> i32;
-    pub fn orbit_expand_visible(ctx: *mut OrbitCtx, visible_buffer: *const c_void, meshlet_buffer: *const c_void,
-                                draw_commands_buffer: *mut c_void, draw_capacity: u32, stream: *mut c_void) -> i32;
-    /// The visible list at record granularity: 12 B {entity_index, meshlet_offset, mask} per dispatch record with a
-    /// survivor (half the 8-B items' bytes at BASELINE config 5); expanded on the receiving side.
+    /// The sharded engine's visible list: 12 B {entity_index, meshlet_offset, mask} per dispatch record, written by the
+    /// evaluation launch itself; expanded on the receiving side.
     pub fn orbit_meshlet_cull_visible_records(ctx: *mut OrbitCtx, cull_info: *const c_void, bufs: *const c_void,
                                               record_buffer: *mut c_void, record_capacity: u32,
                                               stream: *mut c_void) -> i32;
@@ -153,15 +145,11 @@ extern "C" {
     pub fn orbit_ctx_fused_culls(ctx: *const OrbitCtx) -> u64;
     pub fn orbit_ctx_meshlet_stream_culls(ctx: *const OrbitCtx) -> u64;
     pub fn orbit_ctx_meshlet_class_culls(ctx: *const OrbitCtx) -> u64;
-    // exchange without a host round trip: IPC-mapped peer buffers + a device-side rank-ordered scatter
+    // exchange without a host in the step: IPC-mapped peer buffers + a device-signalled rank-ordered scatter (orbit_exchange_list)
     pub fn orbit_p2p_alloc(ctx: *mut OrbitCtx, bytes: u64, out_ptr: *mut *mut c_void, out_handle: *mut [u8; 64]) -> i32;
     pub fn orbit_p2p_free(ctx: *mut OrbitCtx, ptr: *mut c_void) -> i32;
     pub fn orbit_p2p_open(ctx: *mut OrbitCtx, handle: *const [u8; 64], out_peer_ptr: *mut *mut c_void) -> i32;
     pub fn orbit_p2p_close(ctx: *mut OrbitCtx, peer_ptr: *mut c_void) -> i32;
-    /// `counts`: DEVICE u32[world] (the all-gathered list lengths); `out_buffers`: HOST array of `world` device pointers
-    pub fn orbit_scatter_list(ctx: *mut OrbitCtx, local_list: *const c_void, counts: *const u32, rank: u32, world: u32,
-                              out_buffers: *const *mut c_void, out_capacity: u32, header_bytes: u32, stride: u32,
-                              stream: *mut c_void) -> i32;
     pub fn orbit_meshlet_cull_records_and_commands(ctx: *mut OrbitCtx, cull_info: *const c_void,
                                                    bufs: *const OrbitMeshletCullBufs, record_buffer: *mut c_void,
                                                    record_capacity: u32, stream: *mut c_void) -> i32;

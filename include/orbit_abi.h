@@ -41,12 +41,16 @@ extern "C" {
 #define ORBIT_STATIC_ASSERT(c, m) _Static_assert(c, m)
 #endif
 
-#define ORBIT_ABI_VERSION 5u /* 2: *_CullBufs gained depth_pyramid_levels (per-mip images); 3: meshlet streams carry the
+#define ORBIT_ABI_VERSION 6u /* 2: *_CullBufs gained depth_pyramid_levels (per-mip images); 3: meshlet streams carry the
                                 command chain and alpha classes, OrbitCaps.validate_streams, ORBIT_E_STALE;
                                 4: OrbitCaps.cull_path, orbit_ctx_fused_culls (the one-launch cull of orbit_cull_views);
                                 5: this header is the drop-in core, the rest moved to orbit_abi_ext.h; the record list holds an
                                 entry per dispatch record (written by the evaluation launch); orbit_allgather_list,
-                                orbit_compact_segments */
+                                orbit_compact_segments;
+                                6: retired — the 8-B item list (orbit_meshlet_cull_visible, orbit_expand_visible,
+                                orbit_gather_visible_meshlets) and orbit_scatter_list (the exchange signalled by two
+                                collectives): the sharded engine is ONE product (orbit_abi_ext.h); OrbitCaps.dispatch_size
+                                takes 32, 64 or 128 (pass 0 and the task path); orbit_frame_late */
 
 /* u32::MAX = "resource absent" (src/passes/draw_gen.rs:142-144,
  * shaders/meshlet_cull.comp:127). */
@@ -364,7 +368,7 @@ typedef struct OrbitCtx OrbitCtx;
  * points of ONE context must all be ordered on the device — use one stream per context, or order the streams with
  * events — exactly as the reference's passes are ordered by its render graph.  Work that may overlap (a second view
  * culled on another stream, the per-rank contexts of the sharded engine) takes one context per stream; contexts are
- * independent.  orbit_expand_visible and the orbit_gather_visible* calls touch none of the cull scratch and
+ * independent.  orbit_exchange_list, orbit_allgather_list and orbit_gather_visible touch none of the cull scratch and
  * may run on a side stream of the same context (bench.py does: the exchange of step i overlaps the cull of step i+1). */
 
 uint32_t orbit_abi_version(void);
@@ -558,7 +562,11 @@ void orbit_shard_range(uint32_t entity_draw_count, uint32_t rank, uint32_t world
  * RCCL is resolved from the library already loaded in the process (the one
  * that made `nccl_comm`); there is no link-time dependency.  The counts are
  * all-gathered first and read on the host (message sizes): ONE stream
- * synchronisation per call, the only entry point that has one.  The lists
+ * synchronisation per call, the only entry point that has one — SURVEY.md
+ * §8b's export for a caller that wants the 28-B commands themselves gathered
+ * through its own communicator.  It is NOT the sharded engine's step: that
+ * sends 12-B records with no host in it (orbit_abi_ext.h: orbit_cull_shard,
+ * orbit_exchange_list / orbit_allgather_list).  The lists
  * travel as grouped send/recv straight into out + prefix[rank] (direct
  * fan-out over the point-to-point xGMI links).  ORBIT_E_CAPACITY if the
  * concatenation does not fit (nothing is written past out_capacity). */

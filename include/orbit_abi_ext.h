@@ -9,7 +9,8 @@
  *   - several views in one call / one launch (orbit_cull_views),
  *   - derived meshlet streams (an MI355X-side re-layout of the static meshlet buffer),
  *   - several pyramids in one launch,
- *   - the sharded engine's list formats, its device-side exchanges (HIP-IPC stores; RCCL all-gather) and expansions,
+ *   - the sharded engine: the shard cull, the record list, its device-side exchanges (HIP-IPC stores; RCCL all-gather)
+ *     and the expansion of a gathered list,
  *   - the measurement hook of bench.py.
  * A build that only needs the drop-in includes orbit_abi.h alone; liborbit_cull.so exports both sets.
  */
@@ -22,23 +23,15 @@
 extern "C" {
 #endif
 
-/* Compact visible list of the sharded engine (no reference counterpart: the
- * reference is single-GPU): what identifies a MeshletDrawCommand given the
- * meshlet buffer — 8 B instead of 28 B on the xGMI links.  Buffer layout:
- * {u32 count; u32 0} @0, items[] @8, in canonical command order. */
-typedef struct OrbitVisibleMeshlet {
-    uint32_t meshlet_index; /* MeshletDrawCommand::meshlet_index */
-    uint32_t entity_index;  /* MeshletDrawCommand::cmd_first_instance */
-} OrbitVisibleMeshlet;
-ORBIT_STATIC_ASSERT(sizeof(OrbitVisibleMeshlet) == 8, "visible item is 8 B");
+/* The visible list of the sharded engine (no reference counterpart: the reference is single-GPU) — the ONE format a rank
+ * sends: the ordered survivor list at RECORD granularity.  Buffer layout: {u32 records; u32 survivors} @0, entries[] @8,
+ * one entry per dispatch record, in record order; bit b of `mask` set = meshlet `meshlet_offset + b` of entity
+ * `entity_index` is drawn (mask 0: a record without a survivor).  12 B per record: never more than 3/8 of a byte per
+ * dispatched meshlet on the xGMI links (28-B commands: 66 MB over one link at N = 2 of BASELINE config 5, slower than
+ * not sharding) — and an entry's position is its record's index, so the evaluation launch writes the list itself: no
+ * count, no scan, no launch behind it.  (Rounds 2-5 also carried an 8-B {meshlet, entity} item per survivor; retired
+ * in round 6 — twice the bytes at config 5 and an emit launch to make it.) */
 #define ORBIT_VISIBLE_HEADER 8u
-
-/* The same ordered list at record granularity (orbit_meshlet_cull_visible_records): one entry per dispatch record, in
- * record order; bit b of `mask` set = meshlet `meshlet_offset + b` of entity `entity_index` is drawn, i.e. the item
- * {meshlet_offset + b, entity_index} of the list above (mask 0: a record without a survivor — it contributes no item).
- * 12 B per record instead of 8 B per survivor: half the bytes at 3 survivors per record (BASELINE config 5), never
- * more than 3/8 of a byte per dispatched meshlet — and an entry's position is its record's index, so the evaluation
- * launch writes the list itself: no count, no scan, no launch behind it. */
 typedef struct OrbitVisibleRecord {
     uint32_t entity_index;
     uint32_t meshlet_offset;
@@ -113,7 +106,8 @@ uint64_t orbit_ctx_fused_culls(const OrbitCtx *ctx);
 /*     test reads;                                                           */
 /*   alpha classes, 2 bits — the material's alpha_mode, so that the test     */
 /*     reads no material index (set_materials below);                        */
-/*   command words 12 B — gathered per survivor by orbit_expand_visible;     */
+/*   command words 12 B — gathered per survivor by                           */
+/*     orbit_expand_visible_records;                                         */
 /*   counts 2 B + 1 link bit — the command chain: compute_meshlets /         */
 /*     add_mesh lay a mesh's meshlets out so that a meshlet's data_offset is */
 /*     its predecessor's plus the predecessor's vertex_count +               */
@@ -125,10 +119,11 @@ uint64_t orbit_ctx_fused_culls(const OrbitCtx *ctx);
 /*     Meshlets laid out any other way are served by gathers: the chain is   */
 /*     an acceleration, never an assumption.                                 */
 /* With a stream bound to a context, orbit_meshlet_cull / _task_cull /       */
-/* _cull_visible calls whose bufs->meshlet_buffer is the pointer the stream  */
-/* was last updated from evaluate occlusion passes 0 and 2 from the arrays   */
-/* and write no survivor payload, and orbit_expand_visible gathers 12 B      */
-/* instead of touching the survivors' Meshlets.  Results are bit-identical   */
+/* _cull_visible_records / orbit_cull_shard calls whose bufs->meshlet_buffer */
+/* is the pointer the stream was last updated from evaluate occlusion passes */
+/* 0 and 2 from the arrays and write no survivor payload, and                */
+/* orbit_expand_visible_records gathers 12 B instead of touching the         */
+/* survivors' Meshlets.  Results are bit-identical                           */
 /* to the plain path (every test of tests/test_gpu_parity.py runs all ways). */
 /* orbit_cull_views applies the same rule per view.  Pass 1 (list-driven     */
 /* gathers) and any call with another meshlet_buffer pointer read the        */
@@ -200,7 +195,7 @@ uint64_t orbit_ctx_mesh_side_culls(const OrbitCtx *ctx);
 int32_t orbit_meshlet_stream_destroy(OrbitMeshletStream *ms);
 int32_t orbit_ctx_bind_meshlet_stream(OrbitCtx *ctx, OrbitMeshletStream *ms);
 /* Calls this context has served from a bound stream so far — meshlet culls of passes 0 and 2 (each such view of
- * orbit_cull_views' launch chain counts) and orbit_expand_visible (tests and integration checks: a call whose
+ * orbit_cull_views' launch chain counts) and orbit_expand_visible_records (tests and integration checks: a call whose
  * meshlet_buffer is not the stream's source silently takes the plain path).  Views that orbit_cull_views runs as its
  * ONE launch (up to 16 384 entity-draws, OrbitCaps.cull_path) read the 32-B Meshlet buffer and do not count —
  * orbit_ctx_fused_culls counts those — and neither ORBIT_E_RANGE nor the validate_streams check applies to them
@@ -242,48 +237,37 @@ int32_t orbit_depth_reduce_multi(OrbitCtx *ctx, const OrbitDepthReduceItem *item
 int32_t orbit_ctx_profile(OrbitCtx *ctx, int32_t enable);
 int32_t orbit_ctx_profile_read(OrbitCtx *ctx, float *avg_ms, uint32_t *launches);
 
-/* The same exchange with 8 B instead of 28 B per survivor on the links, for
- * nodes whose GPUs all hold the meshlet buffer (static geometry, 32 B per
- * meshlet): every rank culls its entity range into a compact visible list,
- * the lists are all-gathered in rank order, and each GPU expands the result
- * into the canonical MeshletDrawCommandBuffer itself.
- *   orbit_meshlet_cull_visible  orbit_meshlet_cull, but `visible_buffer`
- *       ({count, 0} @0, OrbitVisibleMeshlet[] @8, visible_capacity items)
- *       replaces bufs->draw_commands_buffer / draw_capacity (not used);
- *   orbit_gather_visible_meshlets  orbit_gather_visible on such buffers;
- *   orbit_expand_visible  visible list -> MeshletDrawCommandBuffer, the
- *       command words read from `meshlet_buffer` under global indices;
- *       ORBIT_E_CAPACITY is latched if the list does not fit. */
-int32_t orbit_meshlet_cull_visible(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info,
-                                   const OrbitMeshletCullBufs *bufs, void *visible_buffer,
-                                   uint32_t visible_capacity, void *stream);
-int32_t orbit_gather_visible_meshlets(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint32_t world,
-                                      const void *local_visible_buffer, void *out_visible_buffer,
-                                      uint32_t out_capacity, void *stream);
-int32_t orbit_expand_visible(OrbitCtx *ctx, const void *visible_buffer, const void *meshlet_buffer,
-                             void *draw_commands_buffer, uint32_t draw_capacity, void *stream);
-
-/* The visible list at record granularity: 12 B per dispatch record
- * instead of 8 B per survivor (OrbitVisibleRecord) — half the
- * bytes on the links at BASELINE config 5, which makes the sharded step
- * cull-bound at every world size.
- *   orbit_meshlet_cull_visible_records  orbit_meshlet_cull, but
- *       `record_buffer` ({records, survivors} @0, OrbitVisibleRecord[] @8,
- *       record_capacity entries) replaces bufs->draw_commands_buffer /
- *       draw_capacity (not used).  Entry i is dispatch record i with its
- *       should-draw ballot, written by the evaluation launch itself (ONE
- *       launch for the whole cull; the header by its last workgroup):
- *       records = the dispatched records, survivors = the set bits of all of
- *       them.  ORBIT_E_CAPACITY is latched if the records do not fit (the
- *       header holds the clamped count, the first record_capacity entries
- *       are written);
- *   the lists of all ranks are concatenated in rank order like the other
- *       two formats (orbit_scatter_list with header 8, stride 12; the
- *       gathered header's second word is not maintained);
- *   orbit_expand_visible_records  record list -> MeshletDrawCommandBuffer
- *       in list order (= the canonical order), the command words read from
- *       `meshlet_buffer` under global indices (or from a bound stream that
- *       mirrors it); at most 64 M records per list. */
+/* ------------------------------------------------------------------------ */
+/* The sharded engine — ONE product.  Per rank and frame:    */
+/*   1. orbit_cull_shard: the rank's entity range through both stages; ends  */
+/*      in the record list of its shard (what it sends) and, optionally, the */
+/*      28-B MeshletDrawCommandBuffer of its shard (what it draws from);     */
+/*   2. the rank-ordered all-gather of the record lists — every rank's list  */
+/*      is in canonical order and the shards are contiguous in entity order, */
+/*      so the concatenation in rank order IS the single-GPU sequence:       */
+/*      orbit_exchange_list (direct xGMI stores into the peers' IPC-mapped   */
+/*      buffers, counts and completion signalled on the device; default) or  */
+/*      orbit_allgather_list (north_star's RCCL all-gather; the fallback);   */
+/*      neither reads a count on the host, both are capturable;              */
+/*   3. where a GPU wants the WHOLE scene's commands: orbit_expand_visible_   */
+/*      records of the gathered list (needs the meshlet buffer there).       */
+/*                                                                           */
+/*   orbit_meshlet_cull_visible_records  orbit_meshlet_cull, but              */
+/*       `record_buffer` ({records, survivors} @0, OrbitVisibleRecord[] @8,  */
+/*       record_capacity entries) replaces bufs->draw_commands_buffer /      */
+/*       draw_capacity (not used).  Entry i is dispatch record i with its    */
+/*       should-draw ballot, written by the evaluation launch itself (ONE    */
+/*       launch for the whole cull; the header by its last workgroup):       */
+/*       records = the dispatched records, survivors = the set bits of all   */
+/*       of them.  ORBIT_E_CAPACITY is latched if the records do not fit     */
+/*       (the header holds the clamped count, the first record_capacity      */
+/*       entries are written);                                               */
+/*   orbit_expand_visible_records  record list -> MeshletDrawCommandBuffer   */
+/*       in list order (= the canonical order), the command words read from  */
+/*       `meshlet_buffer` under global indices (or from a bound stream that  */
+/*       mirrors it); at most 64 M records per list (the gathered header's   */
+/*       second word is not maintained by the exchanges and not read here).  */
+/* ------------------------------------------------------------------------ */
 int32_t orbit_meshlet_cull_visible_records(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info,
                                            const OrbitMeshletCullBufs *bufs, void *record_buffer,
                                            uint32_t record_capacity, void *stream);
@@ -310,18 +294,11 @@ int32_t orbit_cull_shard(OrbitCtx *ctx, const OrbitGpuCullInfo *cull_info, const
 uint64_t orbit_ctx_shard_culls(const OrbitCtx *ctx);
 
 /* ------------------------------------------------------------------------ */
-/* The same exchange without a host round trip (one node, one process per   */
-/* GPU, peers reachable over xGMI).  orbit_gather_visible* must read the    */
-/* message sizes on the host because RCCL send/recv take them as arguments; */
-/* here the bulk data does not go through RCCL at all: every rank copies    */
-/* its list straight into every peer's output buffer at the rank-ordered    */
-/* position, with the offsets computed on the device from the all-gathered  */
-/* counts.  Per step and rank: one fixed-size collective for the counts     */
-/* (4 B per rank, e.g. ncclAllGather / torch all_gather_into_tensor — its    */
-/* result stays on the device), orbit_scatter_list, and one fixed-size      */
-/* collective as the completion barrier (peers have finished writing into   */
-/* this rank's buffer once it returns, because every rank enqueues it       */
-/* behind its own scatter).  Nothing waits for the host.                    */
+/* The exchange by direct stores (one node, one process per GPU, peers       */
+/* reachable over xGMI): the bulk data does not go through RCCL at all —     */
+/* every rank copies its list straight into every peer's output buffer at    */
+/* the rank-ordered position, the offsets computed on the device from counts */
+/* that travelled the same way.  Nothing waits for the host.                 */
 /* ------------------------------------------------------------------------ */
 
 #define ORBIT_P2P_HANDLE_BYTES 64 /* hipIpcMemHandle_t */
@@ -343,24 +320,13 @@ int32_t orbit_p2p_free(OrbitCtx *ctx, void *ptr);
 int32_t orbit_p2p_open(OrbitCtx *ctx, const uint8_t handle[ORBIT_P2P_HANDLE_BYTES], void **out_peer_ptr);
 int32_t orbit_p2p_close(OrbitCtx *ctx, void *peer_ptr);
 
-/* Rank-ordered scatter of this rank's list into all `world` output buffers.
- *   local_list   {u32 count @0 | header_bytes | items of `stride` bytes}: a MeshletDrawCommandBuffer
- *                (header 4, stride 28) or a visible list (header 8, stride 8)
- *   counts       DEVICE array of `world` u32: every rank's item count, in rank order (counts[rank] must equal
- *                the local count; it is the all-gathered copy that fixes the offsets on every rank alike)
+/* The whole exchange on the device — no collective, no host in the step, capturable into a graph.
+ *   local_list   {u32 count @0 | header_bytes | items of `stride` bytes}: a record list (header 8, stride 12); any
+ *                header / stride that are multiples of 4 work (a MeshletDrawCommandBuffer: 4 / 28)
  *   out_buffers  HOST array of `world` device pointers: rank r's output buffer as mapped in THIS process
  *                (out_buffers[rank] = this rank's own buffer); same layout as local_list, `out_capacity` items
- * Every rank writes its items at out_r + header_bytes + stride * (counts[0] + .. + counts[rank-1]) for all r, and the
- * header {total, 0..} of its own buffer.  A concatenation that does not fit latches ORBIT_E_CAPACITY (nothing is
- * written past out_capacity). */
-int32_t orbit_scatter_list(OrbitCtx *ctx, const void *local_list, const uint32_t *counts, uint32_t rank,
-                           uint32_t world, void *const *out_buffers, uint32_t out_capacity,
-                           uint32_t header_bytes, uint32_t stride, void *stream);
-
-/* The whole exchange on the device — no collective, no host in the step, capturable into a graph.
- * orbit_scatter_list needs the all-gathered counts as an argument and a collective behind it as the completion
- * barrier: two host-issued collectives per step.  Here both travel like the lists themselves, as stores into the
- * peers' IPC-mapped memory: every rank owns a CONTROL BLOCK (ORBIT_P2P_CTRL_BYTES from orbit_p2p_alloc, which
+ * Counts and completion travel like the lists themselves, as stores into the peers' IPC-mapped memory: every rank
+ * owns a CONTROL BLOCK (ORBIT_P2P_CTRL_BYTES from orbit_p2p_alloc, which
  * zero-fills it; mapped by every peer with orbit_p2p_open).  One call enqueues two launches on `stream`: a scatter that
  * first stores this rank's count into every peer's block, waits (on the device, bounded: ORBIT_E_TIMEOUT) for the counts
  * of the ranks before it, copies the list to its rank-ordered position in every rank's `out_buffers[r]` and then raises
@@ -377,8 +343,8 @@ int32_t orbit_exchange_list(OrbitCtx *ctx, const void *local_list, uint32_t rank
 
 /* ------------------------------------------------------------------------ */
 /* north_star's transport — "an RCCL all-gather of the compacted visible    */
-/* list" — with no host in it either.  orbit_gather_visible* (orbit_abi.h)   */
-/* moves variable-size messages and must read their sizes on the host; a    */
+/* list" — with no host in it either.  RCCL send/recv take message sizes as  */
+/* host arguments (orbit_gather_visible of orbit_abi.h reads them back); a   */
 /* collective of a FIXED size needs no size: every rank contributes its     */
 /* whole list buffer as a segment {count | header | segment_capacity items},*/
 /* ONE ncclAllGather moves all segments to all ranks, and one launch         */

@@ -107,11 +107,6 @@ SYMBOLS = {
     "orbit_shard_range": (None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "orbit_gather_visible": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                          C.c_uint32, C.c_void_p]),
-    "orbit_gather_visible_meshlets": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
-                                                  C.c_void_p, C.c_uint32, C.c_void_p]),
-    "orbit_meshlet_cull_visible": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(MeshletCullBufs), C.c_void_p,
-                                               C.c_uint32, C.c_void_p]),
-    "orbit_expand_visible": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "orbit_meshlet_cull_visible_records": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(MeshletCullBufs), C.c_void_p,
                                                        C.c_uint32, C.c_void_p]),
     "orbit_expand_visible_records": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
@@ -138,8 +133,6 @@ SYMBOLS = {
                                          C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "orbit_compact_segments": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
                                            C.c_uint32, C.c_uint32, C.c_void_p]),
-    "orbit_scatter_list": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
-                                       C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
 }
 
 _lib = None

@@ -634,7 +634,7 @@ namespace {
 // Validation + parameter block of one meshlet cull (see entity_cull_params).  Caller holds ctx->mu.
 int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
                             OrbitMeshTaskRecord *task_records, bool task_path, void *visible_buffer,
-                            uint32_t visible_capacity, uint32_t visible_path /* 0, 1: items, 2: records */, MeshletCullParams &p) {
+                            uint32_t visible_capacity, uint32_t visible_path /* 0: commands, 2: records */, MeshletCullParams &p) {
     int32_t rc = check_cull_info(ctx, ci);
     if (rc) return rc;
     if (!b) return fail(ctx, ORBIT_E_INVALID, "bufs is NULL");
@@ -1085,11 +1085,6 @@ int32_t orbit_meshlet_task_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const
     return meshlet_cull_impl(ctx, ci, b, task_records, true, stream);
 }
 
-int32_t orbit_meshlet_cull_visible(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
-                                   void *visible_buffer, uint32_t visible_capacity, void *stream) {
-    return meshlet_cull_impl(ctx, ci, b, nullptr, false, stream, visible_buffer, visible_capacity, 1u);
-}
-
 int32_t orbit_meshlet_cull_visible_records(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
                                            void *record_buffer, uint32_t record_capacity, void *stream) {
     return meshlet_cull_impl(ctx, ci, b, nullptr, false, stream, record_buffer, record_capacity, 2u);
@@ -1139,6 +1134,10 @@ int32_t orbit_cull_shard(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitE
                                                              ctx->meshlet_stream->material_count, ctx->status, s);
         if (ve != hipSuccess) return hip_fail(ctx, ve, "launch meshlet_stream_validate");
     }
+    if (ep.mesh_side.table && ctx->caps.validate_streams) { // ... and the mesh side table (as orbit_entity_cull does)
+        const hipError_t ve = launch_mesh_side_validate(ep.mesh_infos, 0u, ep.mesh_side.count, ep.mesh_side.table, ctx->status, s);
+        if (ve != hipSuccess) return hip_fail(ctx, ve, "launch mesh_side_validate");
+    }
     const uint32_t chunks = (draw_count + 255u) / 256u;
     const bool one_launch = ci->occlusion_pass == 0u && chunks >= 1u && chunks <= kShardMaxChunks && ctx->caps.cull_path != 1u;
     hipError_t e;
@@ -1186,25 +1185,6 @@ int32_t orbit_cull_shard(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitE
 }
 
 uint64_t orbit_ctx_shard_culls(const OrbitCtx *ctx) { return ctx ? ctx->shard_culls : 0; }
-
-int32_t orbit_expand_visible(OrbitCtx *ctx, const void *visible_buffer, const void *meshlet_buffer,
-                             void *draw_commands_buffer, uint32_t draw_capacity, void *stream) {
-    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    if (!visible_buffer || !meshlet_buffer || !draw_commands_buffer)
-        return fail(ctx, ORBIT_E_MISSING, "expand_visible: NULL argument");
-    // a bound stream that mirrors this meshlet buffer serves the survivors' command words (12-B gathers)
-    const MeshletStreamView view = stream_view_for(ctx->meshlet_stream, meshlet_buffer, nullptr);
-    if (view.sphere && ctx->caps.validate_streams)
-        (void)launch_meshlet_stream_validate((const OrbitMeshlet *)meshlet_buffer, view, nullptr, 0, ctx->status,
-                                             (hipStream_t)stream);
-    const hipError_t e = launch_visible_expand((const uint8_t *)visible_buffer, (const OrbitMeshlet *)meshlet_buffer, view,
-                                               (uint8_t *)draw_commands_buffer, draw_capacity, ctx->num_cus,
-                                               ctx->zero_page, ctx->status, (hipStream_t)stream);
-    if (view.cmd) ctx->stream_culls++;
-    if (e != hipSuccess) return hip_fail(ctx, e, "launch visible_expand");
-    return ORBIT_OK;
-}
 
 int32_t orbit_expand_visible_records(OrbitCtx *ctx, const void *record_buffer, const void *meshlet_buffer,
                                      void *draw_commands_buffer, uint32_t draw_capacity, void *stream) {
@@ -1526,10 +1506,6 @@ __global__ void write_u32_kernel(uint32_t *dst, uint32_t v) { *dst = v; }
 
 } // namespace
 
-extern "C" {
-
-} // extern "C"
-
 namespace {
 
 // Rank-ordered all-gather of {u32 count @0 | header_bytes | items of `stride` bytes} buffers.
@@ -1571,11 +1547,6 @@ int32_t gather_lists(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint32_t wor
     hipLaunchKernelGGL(write_u32_kernel, dim3(1), dim3(1), 0, s, (uint32_t *)out, (uint32_t)prefix[world]);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(ctx, e, "launch write_u32");
-    if (header_bytes > 4) { // second header word of the visible list
-        hipLaunchKernelGGL(write_u32_kernel, dim3(1), dim3(1), 0, s, (uint32_t *)out + 1, 0u);
-        e = hipGetLastError();
-        if (e != hipSuccess) return hip_fail(ctx, e, "launch write_u32");
-    }
     if (counts[rank] > 0) {
         e = hipMemcpyAsync(out + header_bytes + stride * prefix[rank], mine, stride * counts[rank],
                            hipMemcpyDeviceToDevice, s);
@@ -1666,36 +1637,6 @@ int32_t orbit_p2p_close(OrbitCtx *ctx, void *peer_ptr) {
     return e == hipSuccess ? ORBIT_OK : hip_fail(ctx, e, "hipIpcCloseMemHandle");
 }
 
-int32_t orbit_scatter_list(OrbitCtx *ctx, const void *local_list, const uint32_t *counts, uint32_t rank, uint32_t world,
-                           void *const *out_buffers, uint32_t out_capacity, uint32_t header_bytes, uint32_t stride,
-                           void *stream) {
-    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    if (!local_list || !counts || !out_buffers) return fail(ctx, ORBIT_E_MISSING, "scatter_list: NULL argument");
-    if (world == 0 || world > ORBIT_P2P_MAX_WORLD || rank >= world)
-        return fail(ctx, ORBIT_E_INVALID, "scatter_list: rank %u of world %u (max %u)", rank, world,
-                    (unsigned)ORBIT_P2P_MAX_WORLD);
-    if (header_bytes < 4 || header_bytes % 4u || stride == 0 || stride % 4u)
-        return fail(ctx, ORBIT_E_INVALID, "scatter_list: header %u / stride %u must be multiples of 4", header_bytes,
-                    stride);
-    ScatterListParams p{};
-    p.local_list = (const uint8_t *)local_list;
-    p.counts = counts;
-    for (uint32_t r = 0; r < world; r++) {
-        if (!out_buffers[r]) return fail(ctx, ORBIT_E_MISSING, "scatter_list: out_buffers[%u] is NULL", r);
-        p.out[r] = (uint8_t *)out_buffers[r];
-    }
-    p.rank = rank;
-    p.world = world;
-    p.out_capacity = out_capacity;
-    p.header_bytes = header_bytes;
-    p.stride = stride;
-    p.status = ctx->status;
-    const hipError_t e = launch_scatter_list(p, ctx->num_cus, (hipStream_t)stream);
-    if (e != hipSuccess) return hip_fail(ctx, e, "launch scatter_list");
-    return ORBIT_OK;
-}
-
 int32_t orbit_exchange_list(OrbitCtx *ctx, const void *local_list, uint32_t rank, uint32_t world,
                             void *const *out_buffers, void *const *ctrl_buffers, uint32_t out_capacity,
                             uint32_t header_bytes, uint32_t stride, void *stream) {
@@ -1781,13 +1722,6 @@ int32_t orbit_gather_visible(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint
                              void *stream) {
     return gather_lists(ctx, nccl_comm, rank, world, local_draw_buffer, out_draw_buffer, out_capacity, stream,
                         ORBIT_DRAW_HEADER, sizeof(OrbitMeshletDrawCommand));
-}
-
-int32_t orbit_gather_visible_meshlets(OrbitCtx *ctx, void *nccl_comm, uint32_t rank, uint32_t world,
-                                      const void *local_visible_buffer, void *out_visible_buffer,
-                                      uint32_t out_capacity, void *stream) {
-    return gather_lists(ctx, nccl_comm, rank, world, local_visible_buffer, out_visible_buffer, out_capacity, stream,
-                        ORBIT_VISIBLE_HEADER, sizeof(OrbitVisibleMeshlet));
 }
 
 } // extern "C"

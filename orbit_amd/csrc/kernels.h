@@ -130,10 +130,10 @@ struct MeshletCullParams {
     // mesh-shading path (orbit_meshlet_task_cull): non-null = survivors stay with their record, one
     // OrbitMeshTaskRecord per dispatch record, and no draw list is produced
     OrbitMeshTaskRecord *task_records;
-    // sharded engine (orbit_meshlet_cull_visible): draw_buffer is an OrbitVisibleMeshlet buffer (8-B header, 8 B per
-    // survivor) and draw_capacity its capacity
-    uint32_t visible_list; // 1: 8-B items, 2: 12-B records with their ballots (orbit_meshlet_cull_visible_records: one
-                           // entry per dispatch record, written by the evaluation launch itself)
+    // sharded engine (orbit_meshlet_cull_visible_records / orbit_cull_shard): draw_buffer is the record list (8-B header,
+    // 12 B {entity, meshlet offset, should-draw ballot} per dispatch record) and draw_capacity its capacity
+    uint32_t visible_list; // 0: commands; 2: the record list, written by the evaluation launch itself (1 was the 8-B item
+                           // list, retired in round 6)
     // visible_list == 2 only (orbit_meshlet_cull_records_and_commands): non-null = the same evaluation ALSO ends in the
     // MeshletDrawCommandBuffer (scan + emit behind the record launches) — a shard's own indirect draws next to the list
     // it sends
@@ -331,22 +331,11 @@ hipError_t launch_mesh_side_validate(const OrbitMeshInfo *mesh_infos, uint32_t f
 hipError_t launch_meshlet_stream_classes(const MeshletStreamView &ms, const OrbitMaterialData *materials,
                                          uint32_t material_count, uint32_t *other, hipStream_t s);
 // ms.cmd (optional): the derived command-word stream of `meshlets`, based at global meshlet index 0
-hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, const MeshletStreamView &ms,
-                                 uint8_t *draw_buffer, uint32_t draw_capacity, uint32_t num_cus, const void *zero_page,
-                                 int32_t *status, hipStream_t s);
 // orbit_expand_visible_records: `records` = {records, survivors} header + 12-B {entity, meshlet_offset, mask} entries;
 // block_pop: scratch, one word per 1024 records (max_blocks words)
 hipError_t launch_visible_records_expand(const uint8_t *records, uint32_t *block_pop, uint32_t max_blocks,
                                          const OrbitMeshlet *meshlets, const MeshletStreamView &ms, uint8_t *draw_buffer,
                                          uint32_t draw_capacity, const void *zero_page, int32_t *status, hipStream_t s);
-struct ScatterListParams {
-    const uint8_t *local_list;
-    const uint32_t *counts;
-    uint8_t *out[16]; // ORBIT_P2P_MAX_WORLD
-    uint32_t rank, world, out_capacity, header_bytes, stride;
-    int32_t *status;
-};
-hipError_t launch_scatter_list(const ScatterListParams &p, uint32_t num_cus, hipStream_t s);
 // orbit_compact_segments: `world` segments {count | header | segment_capacity items} -> {total | header | items}
 hipError_t launch_compact_segments(const uint8_t *segments, uint32_t world, uint32_t segment_capacity, uint8_t *out,
                                    uint32_t out_capacity, uint32_t header_bytes, uint32_t stride, uint32_t num_cus,

@@ -26,7 +26,7 @@ namespace {
 hipError_t scan_and_emit(const MeshletCullParams &p, uint32_t max_tiles, uint32_t num_cus, hipStream_t s) {
     // the list-driven pass 1 keeps its payload whatever the meshlet source
     const bool stream = p.ci.occlusion_pass != 1 && p.ms.sphere != nullptr;
-    if (!(stream && !p.visible_list)) {
+    if (!stream) {
         const hipError_t e = launch_scan_chunks(p.tile_counts, p.tile_base, reinterpret_cast<const uint32_t *>(p.dispatch_buffer),
                                                 kTileRecords, max_tiles, p.chunk_sums, s, p.tickets, kTicketPools * kTicketStride);
         if (e != hipSuccess) return e;

@@ -149,14 +149,9 @@ __device__ __forceinline__ Payload emit_load_payload(const MeshletCullParams &p,
 // codes (ballot rank = list position, i.e. canonical order), Meshlet bytes
 // 16..31 gathered.  The second scan level (chunk sums -> chunk bases, at most a
 // few dozen values) is redone by every block in LDS instead of being a launch.
-// VISIBLE: instead of the 28-B commands the launch writes the compact visible list — 8 B per survivor
-// {meshlet_index, entity_index} after an 8-B {count, 0} header — which is what the sharded engine sends over
-// xGMI (visible_expand_kernel turns the gathered lists into commands on the receiving GPU).
-// STREAM (derived meshlet streams): meshlet_eval kept no payload; every tile is rebuilt from its ballots.  The visible
-// list needs nothing else (this body); draw commands come from meshlet_emit_chain_body below.
-template <bool VISIBLE, bool STREAM = false>
+// (Draw commands of an evaluation that read the derived streams — no payload — come from meshlet_emit_chain_body below.)
 __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
-    static_assert(VISIBLE || !STREAM, "draw commands from the streams: meshlet_emit_chain_body");
+    constexpr bool STREAM = false; // this body serves the evaluations that kept a payload
     __shared__ uint16_t s_list[4][kTileRows * 64];
     __shared__ uint32_t s_cmd[4][64 * 7];
     __shared__ uint32_t s_chunk_base[kEmitChunkTable];
@@ -214,10 +209,8 @@ __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
                     const uint32_t code = j < n ? list[j] : 0u;
                     const uint32_t rid = (code >> 6) * 2u + ((code >> 5) & 1u); // record 2r + half
                     const uint32_t mi = (uint32_t)__shfl((int)cur.rec.y, (int)rid, 64) + (code & 31u);
-                    uint4 b = make_uint4(0u, 0u, 0u, 0u); // STREAM: the visible list carries indices only
-                    if constexpr (!STREAM)
-                        b = *(j < n ? reinterpret_cast<const uint4 *>(p.meshlets + mi) + 1
-                                    : reinterpret_cast<const uint4 *>(p.zero_page));
+                    const uint4 b = *(j < n ? reinterpret_cast<const uint4 *>(p.meshlets + mi) + 1
+                                            : reinterpret_cast<const uint4 *>(p.zero_page));
                     pay = make_payload(code & 31u, rid, b);
                 } else {
                     pay = j0 == 0u ? cur_pay : emit_load_payload(p, tile, n, j0, lane);
@@ -225,12 +218,6 @@ __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
                 const uint32_t pay_rid = pay.w & 15u;
                 const uint32_t ent = (uint32_t)__shfl((int)cur.rec.x, (int)pay_rid, 64);
                 const uint32_t pay_meshlet = (uint32_t)__shfl((int)cur.rec.y, (int)pay_rid, 64) + ((pay.w >> 4) & 31u);
-                if (VISIBLE) {
-                    const uint32_t slot = base + j;
-                    if (j < n && slot < p.draw_capacity)
-                        reinterpret_cast<uint2 *>(p.draw_buffer + ORBIT_VISIBLE_HEADER)[slot] = make_uint2(pay_meshlet, ent);
-                    continue;
-                }
                 const uint32_t vertex_count = (pay.w >> 16) & 0xFFu;
                 const uint32_t triangle_count = pay.w >> 24;
                 uint32_t *c = cmd + lane * 7;
@@ -265,7 +252,6 @@ __device__ __forceinline__ void meshlet_emit_body(const MeshletCullParams &p) {
         // `count` header: subsumes the fill_buffer(count = 0) of draw_gen.rs:411-417
         *p.total = grand_total;
         *reinterpret_cast<uint32_t *>(p.draw_buffer) = min(grand_total, p.draw_capacity);
-        if (VISIBLE) reinterpret_cast<uint32_t *>(p.draw_buffer)[1] = 0u;
         if (grand_total > p.draw_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
     }
 }
@@ -751,13 +737,11 @@ __device__ __forceinline__ void meshlet_emit_chain_body(const MeshletCullParams 
     }
 }
 
-template <bool VISIBLE, bool STREAM = false>
 __global__ __launch_bounds__(256) void meshlet_emit_kernel(const MeshletCullParams p) {
-    meshlet_emit_body<VISIBLE, STREAM>(p);
+    meshlet_emit_body(p);
 }
-template <bool STREAM>
 __global__ __launch_bounds__(256) void meshlet_emit_views_kernel(const MeshletCullViews all, const ViewGroup g) {
-    meshlet_emit_body<false, STREAM>(all.v[g.idx[blockIdx.y]]);
+    meshlet_emit_body(all.v[g.idx[blockIdx.y]]);
 }
 // kChainWavesPerSimd resident waves per SIMD (three are 2 % slower, a fifth has neither the registers nor the LDS; the
 // launch is bound by its bytes: profiles/r04_notes.md §6) — the register budget the
@@ -780,16 +764,13 @@ hipError_t launch_meshlet_emit(const MeshletCullParams &p, bool stream, uint32_t
     const uint32_t eneed = (max_tiles + 3) / 4;
     if (eblocks > eneed) eblocks = eneed;
     if (eblocks == 0) eblocks = 1;
-    if (p.visible_list) {
-        if (stream) hipLaunchKernelGGL((meshlet_emit_kernel<true, true>), dim3(eblocks), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((meshlet_emit_kernel<true, false>), dim3(eblocks), dim3(256), 0, s, p);
-    } else if (stream) {
+    if (stream) {
         // a wave per group of two tiles; never more than 32 * kSlowWords groups per wave
         const uint32_t gneed = (eneed + kGroupTiles - 1) / kGroupTiles;
         const uint32_t cblocks = max(max(min(num_cus * (uint32_t)kChainWavesPerSimd, gneed), (gneed + 32u * kSlowWords - kDynGroups - 1u) / (32u * kSlowWords - kDynGroups)), 1u);
         hipLaunchKernelGGL(meshlet_emit_chain_kernel, dim3(cblocks), dim3(256), 0, s, p);
     } else {
-        hipLaunchKernelGGL((meshlet_emit_kernel<false, false>), dim3(eblocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(meshlet_emit_kernel, dim3(eblocks), dim3(256), 0, s, p);
     }
     return hipGetLastError();
 }
@@ -807,7 +788,7 @@ hipError_t launch_meshlet_emit_views(const MeshletCullViews &all, const ViewGrou
                            dim3(max(max(min(num_cus * (uint32_t)kChainWavesPerSimd / m, (eneed + kGroupTiles - 1) / kGroupTiles),
                                         ((eneed + kGroupTiles - 1) / kGroupTiles + 32u * kSlowWords - kDynGroups - 1u) / (32u * kSlowWords - kDynGroups)), 1u), m),
                            dim3(256), 0, s, all, g);
-    else hipLaunchKernelGGL(meshlet_emit_views_kernel<false>, dim3(eblocks, m), dim3(256), 0, s, all, g);
+    else hipLaunchKernelGGL(meshlet_emit_views_kernel, dim3(eblocks, m), dim3(256), 0, s, all, g);
     return hipGetLastError();
 }
 

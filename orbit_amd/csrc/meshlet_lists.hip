@@ -1,8 +1,7 @@
 // meshlet_lists.hip — the outputs of meshlet_cull that are not a MeshletDrawCommandBuffer, and the way back:
 //   task_records_kernel            per-record task payloads of the mesh-shading path (orbit_meshlet_task_cull)
-//   visible_expand_kernel,
-//   visible_records_expand_kernel  gathered lists -> commands on the receiving GPU (shaders/meshlet_cull.comp:216-230)
-//   scatter_list_kernel            a rank's list into every peer's buffer over xGMI (orbit_scatter_list)
+//   visible_records_expand_kernel  a gathered record list -> commands on the receiving GPU (shaders/meshlet_cull.comp:216-230)
+//   exchange_scatter/wait_kernel   a rank's list into every peer's buffer over xGMI, signalled on the device (orbit_exchange_list)
 //   compact_segments_kernel        the segments of an ncclAllGather -> one contiguous list (orbit_allgather_list)
 #include "meshlet_common.h"
 
@@ -10,25 +9,12 @@ namespace orbit {
 
 namespace {
 
-// Visible list -> MeshletDrawCommandBuffer (meshlet_cull.comp:216-230 for survivors that were culled on another GPU):
-// lane = survivor, Meshlet bytes 16..31 gathered from the (replicated) meshlet buffer, commands staged through LDS
-// so that every store covers 256 contiguous bytes.  Grid-stride over chunks of 64 survivors per wave, software
-// pipelined: the items of chunk i+2 and the gathers of chunk i+1 are in flight while chunk i is written.  All loads
-// are unconditional (lanes past the list read the zero page) and the stores are buffer stores whose offset is out
-// of range for the words past the list, so the code is straight-line and every vmcnt wait is exact.
+// A survivor of a gathered list: {meshlet_index, entity_index}; lanes past the list read the zero page, so the code is
+// straight-line and every vmcnt wait is exact.
 struct ExpandChunk {
-    uint2 item;  // {meshlet_index, entity_index}
+    uint2 item;
     bool valid;
 };
-
-__device__ __forceinline__ ExpandChunk expand_load_items(const uint2 *items, uint32_t first, uint32_t n, int lane,
-                                                         const void *zero_page) {
-    ExpandChunk c;
-    const uint32_t i = first + (uint32_t)lane;
-    c.valid = first < n && i < n; // first can wrap past 2^32 only with n near 2^32: excluded by draw_capacity
-    c.item = *(c.valid ? items + i : reinterpret_cast<const uint2 *>(zero_page));
-    return c;
-}
 
 // STREAM: the three command words come from the derived 12-B stream (`cmd`, orbit_meshlet_stream_*) instead of bytes
 // 16..31 of the Meshlet: a third of the lines per survivor.
@@ -46,63 +32,12 @@ __device__ __forceinline__ uint4 expand_gather(const OrbitMeshlet *meshlets, con
     }
 }
 
-template <bool STREAM>
-__global__ __launch_bounds__(256) void visible_expand_kernel(const uint8_t *visible, const OrbitMeshlet *meshlets,
-                                                             const MeshletStreamView ms, uint8_t *draw_buffer,
-                                                             uint32_t draw_capacity, const void *zero_page,
-                                                             int32_t *status) {
-    __shared__ uint32_t s_cmd[4][64 * 7];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t *cmd = s_cmd[wave];
-    const uint32_t total = *reinterpret_cast<const uint32_t *>(visible);
-    const uint32_t n = min(total, draw_capacity);
-    const uint2 *items = reinterpret_cast<const uint2 *>(visible + ORBIT_VISIBLE_HEADER);
-    uint8_t *out = draw_buffer + ORBIT_DRAW_HEADER;
-    const uint32_t stride = gridDim.x * 4u * 64u;
-    // wave-uniform, and provably so for the compiler (buffer descriptors live in SGPRs)
-    uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 4u + wave) * 64u));
-    ExpandChunk c0 = expand_load_items(items, first, n, lane, zero_page);
-    ExpandChunk c1 = expand_load_items(items, first + stride, n, lane, zero_page);
-    uint4 b0 = expand_gather<STREAM>(meshlets, ms, c0, zero_page, status);
-    for (; first < n; first += stride) {
-        const ExpandChunk c2 = expand_load_items(items, first + 2u * stride, n, lane, zero_page);
-        const uint4 b1 = expand_gather<STREAM>(meshlets, ms, c1, zero_page, status);
-        uint32_t *c = cmd + lane * 7;
-        c[0] = (b0.w >> 24) * 3u;                     // cmd_index_count = triangle_count * 3
-        c[1] = 1u;                                    // cmd_instance_count
-        c[2] = (b0.z + ((b0.w >> 16) & 0xFFu)) * 4u;  // cmd_first_index = (data_offset + vertex_count) * 4
-        c[3] = b0.z;                                  // cmd_vertex_offset = int(data_offset)
-        c[4] = c0.item.y;                             // cmd_first_instance = entity_index
-        c[5] = b0.y;                                  // meshlet_vertex_offset
-        c[6] = c0.item.x;                             // meshlet_index
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // the chunk's commands as one range-checked window: words past the list fall outside and are dropped
-        const uint32_t bytes = min(n - first, 64u) * 28u;
-        const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)first * 28u, 0, bytes, 0x00020000);
-#pragma unroll
-        for (uint32_t k = 0; k < 7; k++) {
-            const uint32_t w = k * 64u + (uint32_t)lane;
-            __builtin_amdgcn_raw_buffer_store_b32(cmd[w], win, w * 4u, 0, 0);
-        }
-        __builtin_amdgcn_wave_barrier(); // cmd is rewritten by the next chunk
-        c0 = c1;
-        c1 = c2;
-        b0 = b1;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *reinterpret_cast<uint32_t *>(draw_buffer) = n;
-        if (total > draw_capacity) latch_status(status, ORBIT_E_CAPACITY);
-    }
-}
-
 constexpr uint32_t kVrBlock = 1024; // records per block of the record list's expansion: 256 threads x 4
 
 // Commands from a (gathered) record list, in list order = the canonical order: orbit_expand_visible_records.  A count
 // launch sums the survivors of every block of 1024 records; here a block adds up the blocks before it, a wave takes 64
 // records at a time, lays their survivors out in LDS as (record lane, bit) codes at the records' prefix offsets and
-// then writes them 64 commands at a time exactly like visible_expand_kernel.
+// then writes them 64 commands at a time through LDS (every store covers 256 contiguous bytes).
 __global__ __launch_bounds__(256) void visible_records_pop_kernel(const uint8_t *records, uint32_t *block_pop,
                                                                   uint32_t max_blocks) {
     __shared__ uint32_t smem[4];
@@ -223,48 +158,13 @@ __global__ __launch_bounds__(256) void visible_records_expand_kernel(const uint8
     }
 }
 
-// Sharded engine, exchange without a host round trip (orbit_scatter_list): this rank's items go to every rank's
-// output buffer — peers' buffers are mapped over xGMI — at the position the all-gathered counts give them.  A plain
-// dword copy: list items start 4 (commands) or 8 (visible items) bytes into their buffers and land at 28- or 8-byte
-// multiples, so 4 B is the common alignment; a wave moves 4 x 256 contiguous bytes per trip, loads first.
-// blockIdx.y = destination rank: the copies to all peers run side by side, each on its own link.
-__global__ __launch_bounds__(256) void scatter_list_kernel(const ScatterListParams p) {
-    const uint32_t dst_rank = blockIdx.y;
-    uint32_t first = 0, total = 0;
-    for (uint32_t r = 0; r < p.world; r++) {
-        const uint32_t c = p.counts[r];
-        if (r < p.rank) first += c;
-        total += c;
-    }
-    const uint32_t mine = p.counts[p.rank];
-    const uint32_t room = first < p.out_capacity ? p.out_capacity - first : 0u;
-    const uint32_t n_items = min(mine, room);
-    const uint64_t words = (uint64_t)n_items * p.stride / 4u;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(p.local_list + p.header_bytes);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(p.out[dst_rank] + p.header_bytes + (uint64_t)first * p.stride);
-    const uint64_t step = (uint64_t)gridDim.x * 256u * 4u;
-    for (uint64_t w = ((uint64_t)blockIdx.x * 256u + (threadIdx.x & ~63u)) * 4u + (threadIdx.x & 63u); w < words;
-         w += step) {
-        uint32_t v[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = w + 64u * k < words ? src[w + 64u * k] : 0u;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (w + 64u * k < words) dst[w + 64u * k] = v[k];
-    }
-    if (dst_rank == p.rank && blockIdx.x == 0 && threadIdx.x == 0) {
-        uint32_t *hdr = reinterpret_cast<uint32_t *>(p.out[p.rank]);
-        hdr[0] = min(total, p.out_capacity);
-        for (uint32_t k = 1; k < p.header_bytes / 4u; k++) hdr[k] = 0u;
-        if (total > p.out_capacity) latch_status(p.status, ORBIT_E_CAPACITY);
-    }
-}
-
 // orbit_compact_segments — behind the all-gather of north_star, ncclAllGather of the ranks' lists as FIXED-CAPACITY
 // segments {count | header | segment_capacity items} (a collective of a fixed size needs no count on the host: no
 // read-back, no stream synchronisation, capturable): the segments' items, in rank order, become the one contiguous list
 // {total | header | items} that the p2p exchange delivers — byte for byte.  blockIdx.y = segment; every workgroup adds up
-// the counts of the segments before its own (a handful of words), then the plain dword copy of scatter_list_kernel.
+// the counts of the segments before its own (a handful of words), then a plain dword copy: list items start 8 bytes into
+// their buffers and land at 12-byte multiples, so 4 B is the common alignment; a wave moves 4 x 256 contiguous bytes per
+// trip, loads first.
 struct CompactSegmentsParams {
     const uint8_t *segments;
     uint8_t *out;
@@ -491,29 +391,6 @@ hipError_t launch_compact_segments(const uint8_t *segments, uint32_t world, uint
     const uint64_t want = ((uint64_t)segment_capacity * stride + 32767u) / 32768u;
     const uint32_t per_seg = (uint32_t)max((uint64_t)1, min(want, (uint64_t)max(num_cus * 4u / max(world, 1u), 8u)));
     hipLaunchKernelGGL(compact_segments_kernel, dim3(per_seg, world), dim3(256), 0, s, p);
-    return hipGetLastError();
-}
-
-hipError_t launch_scatter_list(const ScatterListParams &p, uint32_t num_cus, hipStream_t s) {
-    // enough blocks per destination to keep a link busy, few enough that `world` copies share the device
-    const uint32_t per_dst = max(num_cus * 2u / max(p.world, 1u), 8u);
-    hipLaunchKernelGGL(scatter_list_kernel, dim3(per_dst, p.world), dim3(256), 0, s, p);
-    return hipGetLastError();
-}
-
-hipError_t launch_visible_expand(const uint8_t *visible, const OrbitMeshlet *meshlets, const MeshletStreamView &ms,
-                                 uint8_t *draw_buffer, uint32_t draw_capacity, uint32_t num_cus, const void *zero_page,
-                                 int32_t *status, hipStream_t s) {
-    uint32_t blocks = num_cus * 8u;
-    const uint32_t need = (draw_capacity + 255u) / 256u;
-    if (blocks > need) blocks = need;
-    if (blocks == 0) blocks = 1;
-    if (ms.cmd)
-        hipLaunchKernelGGL(visible_expand_kernel<true>, dim3(blocks), dim3(256), 0, s, visible, meshlets, ms,
-                           draw_buffer, draw_capacity, zero_page, status);
-    else
-        hipLaunchKernelGGL(visible_expand_kernel<false>, dim3(blocks), dim3(256), 0, s, visible, meshlets, ms,
-                           draw_buffer, draw_capacity, zero_page, status);
     return hipGetLastError();
 }
 

@@ -100,6 +100,46 @@ class MeshletStream:
             pass
 
 
+class PreparedShardCull:
+    """Engine.prepare_cull_shard: orbit_cull_shard's argument blocks, kept alive and reusable frame after frame."""
+
+    def __init__(self, engine, cull_info, entity_draw_buffer, mesh_info_buffer, meshlet_dispatch_buffer, entity_buffer,
+                 draw_first, draw_count, dispatch_capacity, meshlet_buffer, material_buffer, record_buffer, record_capacity,
+                 draw_commands_buffer, draw_capacity, material_count, visibility_buffer, meshlet_visibility_buffer,
+                 depth_pyramid, depth_pyramid_size, stream):
+        self.cull_info = _host_bytes(cull_info, 400).copy()  # the call reads THIS buffer: update it in place per frame
+        e, m = _lib.EntityCullBufs(), _lib.MeshletCullBufs()
+        e.entity_draw_buffer = _ptr(entity_draw_buffer)
+        e.mesh_info_buffer = _ptr(mesh_info_buffer)
+        e.meshlet_dispatch_buffer = m.meshlet_dispatch_buffer = _ptr(meshlet_dispatch_buffer)
+        e.entity_buffer = m.entity_buffer = _ptr(entity_buffer)
+        e.visibility_buffer = _ptr(visibility_buffer)
+        e.depth_pyramid = m.depth_pyramid = _ptr(depth_pyramid)
+        e.depth_pyramid_size[0], e.depth_pyramid_size[1] = depth_pyramid_size
+        m.depth_pyramid_size[0], m.depth_pyramid_size[1] = depth_pyramid_size
+        e.dispatch_capacity = m.dispatch_capacity = dispatch_capacity
+        m.meshlet_buffer = _ptr(meshlet_buffer)
+        m.draw_commands_buffer = _ptr(draw_commands_buffer)
+        m.material_buffer = _ptr(material_buffer)
+        m.meshlet_visibility_buffer = _ptr(meshlet_visibility_buffer)
+        m.draw_capacity = draw_capacity
+        m.material_count = material_count
+        self._fn, self._ctx = engine._lib.orbit_cull_shard, engine._ctx
+        self._cip, self._ep, self._mp = self.cull_info.ctypes.data_as(C.c_void_p), C.byref(e), C.byref(m)
+        self._rec, self._st = _ptr(record_buffer), _stream(stream)
+        self._args = (int(draw_first), int(draw_count), int(record_capacity), 1 if draw_commands_buffer is not None else 0)
+        self._keep = (e, m, stream, engine)  # the blocks (and the stream object) live as long as the call does
+
+    def set_cull_info(self, cull_info):
+        self.cull_info[:] = _host_bytes(cull_info, 400)
+
+    def __call__(self):
+        first, count, cap, with_cmds = self._args
+        rc = self._fn(self._ctx, self._cip, self._ep, first, count, self._mp, self._rec, cap, with_cmds, self._st)
+        if rc != _lib.OK:
+            _lib.check(rc, self._ctx)
+
+
 class Engine:
     """One ``OrbitCtx``: scan scratch sized from ``caps`` on one gfx950 device."""
 
@@ -213,7 +253,7 @@ class Engine:
     def meshlet_cull(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, draw_commands_buffer, entity_buffer,
                      material_buffer, dispatch_capacity, draw_capacity, meshlet_visibility_buffer=None,
                      depth_pyramid=None, depth_pyramid_size=(0, 0), material_count=0, stream=None, task_records=None,
-                     visible_buffer=None, depth_pyramid_levels=None, record_buffer=None, record_capacity=None):
+                     depth_pyramid_levels=None, record_buffer=None, record_capacity=None):
         ci = _host_bytes(cull_info, 400)
         b = _lib.MeshletCullBufs()
         b.meshlet_dispatch_buffer = _ptr(meshlet_dispatch_buffer)
@@ -237,11 +277,6 @@ class Engine:
         if record_buffer is not None:  # sharded engine: the visible list at record granularity (12 B per record)
             _lib.check(self._lib.orbit_meshlet_cull_visible_records(self._ctx, ci.ctypes.data_as(C.c_void_p), C.byref(b),
                                                                     _ptr(record_buffer), draw_capacity, _stream(stream)),
-                       self._ctx)
-            return
-        if visible_buffer is not None:  # sharded engine: compact visible list, draw_capacity = its capacity
-            _lib.check(self._lib.orbit_meshlet_cull_visible(self._ctx, ci.ctypes.data_as(C.c_void_p), C.byref(b),
-                                                            _ptr(visible_buffer), draw_capacity, _stream(stream)),
                        self._ctx)
             return
         if task_records is not None:
@@ -280,12 +315,6 @@ class Engine:
                 keep.append(lv)
                 a.levels = lv
         _lib.check(self._lib.orbit_depth_reduce_multi(self._ctx, arr, len(items), _stream(stream)), self._ctx)
-
-    def meshlet_cull_visible(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, visible_buffer, entity_buffer,
-                             material_buffer, dispatch_capacity, visible_capacity, **kw):
-        """orbit_meshlet_cull_visible: survivors as {count, 0} + 8-B {meshlet_index, entity_index} items."""
-        self.meshlet_cull(cull_info, meshlet_dispatch_buffer, meshlet_buffer, None, entity_buffer, material_buffer,
-                          dispatch_capacity, visible_capacity, visible_buffer=visible_buffer, **kw)
 
     def meshlet_cull_visible_records(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, record_buffer,
                                      entity_buffer, material_buffer, dispatch_capacity, record_capacity, **kw):
@@ -333,34 +362,21 @@ class Engine:
 
     def prepare_cull_shard(self, cull_info, entity_draw_buffer, mesh_info_buffer, meshlet_dispatch_buffer, entity_buffer,
                            draw_first, draw_count, dispatch_capacity, meshlet_buffer, material_buffer, record_buffer,
-                           record_capacity, draw_commands_buffer=None, draw_capacity=0, material_count=0, stream=None):
-        """The same call with its argument blocks built ONCE: returns a function of no arguments that enqueues the shard
+                           record_capacity, draw_commands_buffer=None, draw_capacity=0, material_count=0,
+                           visibility_buffer=None, meshlet_visibility_buffer=None, depth_pyramid=None,
+                           depth_pyramid_size=(0, 0), stream=None):
+        """cull_shard with its argument blocks built ONCE: returns a PreparedShardCull — calling it enqueues the shard
         cull on `stream` (a per-frame caller whose buffers do not change — bench.py's step loop — spends its host time in
-        the library, not in filling ctypes structs: ~10 us per call)."""
-        ci = _host_bytes(cull_info, 400).copy()
-        e, m = _lib.EntityCullBufs(), _lib.MeshletCullBufs()
-        e.entity_draw_buffer = _ptr(entity_draw_buffer)
-        e.mesh_info_buffer = _ptr(mesh_info_buffer)
-        e.meshlet_dispatch_buffer = m.meshlet_dispatch_buffer = _ptr(meshlet_dispatch_buffer)
-        e.entity_buffer = m.entity_buffer = _ptr(entity_buffer)
-        e.dispatch_capacity = m.dispatch_capacity = dispatch_capacity
-        m.meshlet_buffer = _ptr(meshlet_buffer)
-        m.draw_commands_buffer = _ptr(draw_commands_buffer)
-        m.material_buffer = _ptr(material_buffer)
-        m.draw_capacity = draw_capacity
-        m.material_count = material_count
-        fn, ctx, cip, ep, mp = self._lib.orbit_cull_shard, self._ctx, ci.ctypes.data_as(C.c_void_p), C.byref(e), C.byref(m)
-        rec, st = _ptr(record_buffer), _stream(stream)
-        with_cmds = 1 if draw_commands_buffer is not None else 0
-        keep = (ci, e, m, stream)
-
-        def call():
-            rc = fn(ctx, cip, ep, draw_first, draw_count, mp, rec, record_capacity, with_cmds, st)
-            if rc != _lib.OK:
-                _lib.check(rc, ctx)
-            return keep  # (keeps the blocks alive as long as the function is)
-
-        return call
+        the library, not in filling ctypes structs: ~10 us per call).  The 400-B CullInfo is the object's own copy:
+        write the next frame's into `prepared.cull_info` (a uint8[400] numpy view, `prepared.set_cull_info(ci)`) before
+        the call.  `stream` is part of what is prepared and must be given (the stream current at prepare time is not
+        the stream current at call time)."""
+        if stream is None:
+            raise ValueError("prepare_cull_shard: pass the stream the prepared call enqueues on")
+        return PreparedShardCull(self, cull_info, entity_draw_buffer, mesh_info_buffer, meshlet_dispatch_buffer, entity_buffer,
+                                 draw_first, draw_count, dispatch_capacity, meshlet_buffer, material_buffer, record_buffer,
+                                 record_capacity, draw_commands_buffer, draw_capacity, material_count, visibility_buffer,
+                                 meshlet_visibility_buffer, depth_pyramid, depth_pyramid_size, stream)
 
     def mesh_side_culls(self):
         """orbit_ctx_mesh_side_culls: entity culls of the bound stream that were handed its mesh side table."""
@@ -376,13 +392,7 @@ class Engine:
                                                           _ptr(draw_commands_buffer), draw_capacity, _stream(stream)),
                    self._ctx)
 
-    def expand_visible(self, visible_buffer, meshlet_buffer, draw_commands_buffer, draw_capacity, stream=None):
-        """orbit_expand_visible: visible list -> MeshletDrawCommandBuffer (command words from the meshlet buffer)."""
-        _lib.check(self._lib.orbit_expand_visible(self._ctx, _ptr(visible_buffer), _ptr(meshlet_buffer),
-                                                  _ptr(draw_commands_buffer), draw_capacity, _stream(stream)),
-                   self._ctx)
-
-    # -- exchange without a host round trip (orbit_p2p_* / orbit_scatter_list)
+    # -- exchange without a host in the step (orbit_p2p_* / orbit_exchange_list)
     def p2p_alloc(self, nbytes):
         """(device pointer, 64-byte IPC handle) of an exchange buffer peers can map."""
         ptr, handle = C.c_void_p(), (C.c_uint8 * 64)()
@@ -422,14 +432,6 @@ class Engine:
     def meshlet_class_culls(self):
         """orbit_ctx_meshlet_class_culls: ... of which evaluated from the stream's alpha classes."""
         return int(self._lib.orbit_ctx_meshlet_class_culls(self._ctx))
-
-    def scatter_list(self, local_list, counts, rank, world, out_buffers, out_capacity, header_bytes, stride,
-                     stream=None):
-        """orbit_scatter_list: this rank's items into every rank's output buffer at the rank-ordered position;
-        `counts` is a DEVICE int32[world] tensor, `out_buffers` a list of device pointers (ints or tensors)."""
-        arr = (C.c_void_p * world)(*[_ptr(b) for b in out_buffers])
-        _lib.check(self._lib.orbit_scatter_list(self._ctx, _ptr(local_list), _ptr(counts), rank, world, arr,
-                                                out_capacity, header_bytes, stride, _stream(stream)), self._ctx)
 
     def exchange_list(self, local_list, rank, world, out_buffers, ctrl_buffers, out_capacity, header_bytes, stride,
                       stream=None):
@@ -472,13 +474,6 @@ class Engine:
         rank-ordered list {total | header | items}."""
         _lib.check(self._lib.orbit_compact_segments(self._ctx, _ptr(segments), world, segment_capacity, _ptr(out_list),
                                                     out_capacity, header_bytes, stride, _stream(stream)), self._ctx)
-
-    def gather_visible_meshlets(self, nccl_comm, rank, world, local_visible_buffer, out_visible_buffer, out_capacity,
-                                stream=None):
-        comm = nccl_comm if isinstance(nccl_comm, C.c_void_p) else C.c_void_p(int(nccl_comm))
-        _lib.check(self._lib.orbit_gather_visible_meshlets(self._ctx, comm, rank, world, _ptr(local_visible_buffer),
-                                                           _ptr(out_visible_buffer), out_capacity, _stream(stream)),
-                   self._ctx)
 
     def gather_visible(self, nccl_comm, rank, world, local_draw_buffer, out_draw_buffer, out_capacity, stream=None):
         """Rank-ordered all-gather of the visible lists over the caller's RCCL communicator

@@ -55,7 +55,6 @@ MESHLET_DISPATCH = np.dtype([("entity_index", "<u4"), ("meshlet_offset", "<u4"),
                              ("visibility_offset", "<u4")])
 # types.glsl:180-189, src/assets/mod.rs:98-109
 VISIBLE_HEADER = 8  # {u32 count; u32 0}
-VISIBLE_MESHLET = np.dtype([("meshlet_index", "<u4"), ("entity_index", "<u4")])  # include/orbit_abi.h (sharded engine)
 # the same list at record granularity: {u32 records; u32 survivors} header, 12 B per dispatch record
 VISIBLE_RECORD = np.dtype([("entity_index", "<u4"), ("meshlet_offset", "<u4"), ("mask", "<u4")])
 MESH_TASK_RECORD = np.dtype([("task_mesh_count", "<u4"), ("entity_index", "<u4"), ("meshlet_offset", "<u4"),
@@ -103,7 +102,7 @@ _SIZES = {
     "ENTITY_DRAW": (ENTITY_DRAW, 12), "ENTITY_DATA": (ENTITY_DATA, 128), "MESH_INFO": (MESH_INFO, 128),
     "MESHLET": (MESHLET, 32), "MATERIAL": (MATERIAL, 80), "LIGHT": (LIGHT, 64),
     "MESHLET_DISPATCH": (MESHLET_DISPATCH, 16), "MESHLET_DRAW_COMMAND": (MESHLET_DRAW_COMMAND, 28),
-    "MESH_TASK_RECORD": (MESH_TASK_RECORD, 44), "VISIBLE_MESHLET": (VISIBLE_MESHLET, 8), "VISIBLE_RECORD": (VISIBLE_RECORD, 12),
+    "MESH_TASK_RECORD": (MESH_TASK_RECORD, 44), "VISIBLE_RECORD": (VISIBLE_RECORD, 12),
     "GPU_CULL_INFO": (GPU_CULL_INFO, 400), "CLUSTER_DEPTH_BOUNDS": (CLUSTER_DEPTH_BOUNDS, 8),
     "MARK_ACTIVE_PUSH": (MARK_ACTIVE_PUSH, 56), "CLUSTER_CULL_INFO": (CLUSTER_CULL_INFO, 192),
     "GPU_CLUSTER_INFO_BUFFER": (GPU_CLUSTER_INFO_BUFFER, 52),

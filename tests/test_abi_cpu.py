@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} is declared in include/orbit_abi*.h but not exported"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes signature in orbit_amd/_lib.py"
-    assert lib.orbit_abi_version() == 5
+    assert lib.orbit_abi_version() == 6
 
 
 def test_header_compiles_as_c_and_cxx(tmp_path):

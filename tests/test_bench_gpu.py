@@ -63,31 +63,49 @@ def _run_ranks(extra, env):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("expand,exchange,signalling", [
-    ("own", "records", "device"),  # the default step: kernels only, the shard's command buffer built inside it
-    ("none", "records", "device"), ("all", "records", "device"), ("all", "visible", "collectives"),
-    ("none", "commands", "device"), ("own", "records", "collectives")])
-def test_bench_two_ranks_on_one_device_whole_device_path(expand, exchange, signalling):
+@pytest.mark.parametrize("expand", ["own", "none"])
+def test_bench_two_ranks_on_one_device_whole_device_path(expand):
     """`bench.py --gpus 2` as the driver starts it (bench.py spawns its ranks), both ranks on the box's one GPU: the
     real exchange — HIP IPC mappings of the peers' buffers and control blocks, the scatter kernel, counts and completion
-    signalled on the device (or by two collectives over gloo: RCCL cannot put two ranks on one device) — then every
-    rank's segment check, the check of its own command buffer and the cross-rank checksum of the gathered list inside
-    bench.py (it exits non-zero if they fail)."""
-    args = ["--gpus", "2", "--expand", expand, "--signalling", signalling] + (
-        [] if exchange == "records" else ["--exchange", exchange])  # records: the default
-    d = _run_ranks(args, dict(ORBIT_BENCH_ONE_DEVICE="1", ORBIT_BENCH_BACKEND="gloo"))
+    signalled on the device (the process group over gloo: RCCL cannot put two ranks on one device) — then every rank's
+    segment check, the check of its own command buffer and the cross-rank checksum of the gathered list inside bench.py
+    (it exits non-zero if they fail); behind the timed region the OTHER transport's leg (the all-gather of fixed-capacity
+    segments + compaction), whose list must be the main transport's byte for byte."""
+    d = _run_ranks(["--gpus", "2", "--expand", expand], dict(ORBIT_BENCH_ONE_DEVICE="1", ORBIT_BENCH_BACKEND="gloo"))
     c = d["config"]
     assert d["n_gpus"] == 2 and c["world_size"] == 2 and c["gather"] is True and c["transport"] == "p2p"
-    assert c["exchange"] == exchange and c["backend"] == "gloo" and c["signalling"] == signalling
+    assert c["exchange"] == "records" and c["backend"] == "gloo" and c["signalling"] == "device"
     assert c["transport_fallback"] is None and c["step_intervals"]["intervals"] >= 2
-    assert c["expand"] == (expand if exchange != "commands" else None)
-    assert ("own shard" in c["step_product"]) == (expand == "own" and exchange == "records")
+    assert c["expand"] == expand and ("own shard" in c["step_product"]) == (expand == "own")
     pr = d["per_rank"]
     assert len(pr["cull_ms"]) == 2 and len(pr["exchange_ms"]) == 2 and all(v > 0 for v in pr["cull_ms"] + pr["exchange_ms"])
-    assert (pr["expand_ms"] is None) == (expand != "all" or exchange == "commands")
     assert sum(pr["meshlets_in"]) == c["meshlets_into_meshlet_cull"] == 6000 * 256
     assert sum(pr["survivors"]) == c["survivors"] > 0
     assert abs(d["value"] - c["meshlets_into_meshlet_cull"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    ta = d["transport_alt"]
+    assert ta["name"] == "rccl" and ta["signalling"] == "rccl-allgather" and ta["ms_per_step"] > 0
+    assert ta["list_identical_to_main_transport"] is True and ta["steps"] == 4
+
+
+@pytest.mark.parametrize("world,transport", [(8, "p2p"), (5, "p2p"), (8, "rccl")])
+def test_bench_at_the_world_size_north_star_names_on_one_device(world, transport):
+    """`ORBIT_BENCH_ONE_DEVICE=1 bench.py --gpus 8` (and 5: not a power of two): the whole N > 1 bench path — spawn, shard
+    ranges, eight contexts' culls and eight device-signalled exchanges sharing the box's one GPU, two frames in flight —
+    at the world size the driver's scaling run ends with.  bench.py checks every rank's segment of the gathered list, its
+    own command buffer and the cross-rank checksum; --verify-single-rank additionally holds the gathered list against ONE
+    rank culling the whole scene (from the Meshlet buffer: another evaluation path), and the other transport's leg must
+    deliver the same bytes."""
+    d = _run_ranks(["--gpus", str(world), "--entities", "24000", "--transport", transport, "--verify-single-rank",
+                    "--cpu-sample-entities", "0"], dict(ORBIT_BENCH_ONE_DEVICE="1", ORBIT_BENCH_BACKEND="gloo"))
+    c = d["config"]
+    assert d["n_gpus"] == world and c["world_size"] == world and c["transport"] == transport and c["transport_fallback"] is None
+    assert c["signalling"] == ("device" if transport == "p2p" else "rccl-allgather")
+    pr = d["per_rank"]
+    assert len(pr["cull_ms"]) == world and sum(pr["meshlets_in"]) == 24000 * 256 and sum(pr["survivors"]) == c["survivors"] > 0
+    assert d["single_rank_check"]["gathered_list_equals_single_rank_list"] is True
+    assert d["single_rank_check"]["records"] == 24000 * 8
+    ta = d["transport_alt"]
+    assert ta["name"] == ("rccl" if transport == "p2p" else "p2p") and ta["list_identical_to_main_transport"] is True
 
 
 def test_bench_two_ranks_on_one_device_at_full_size():
@@ -106,23 +124,22 @@ def test_bench_two_ranks_on_one_device_at_full_size():
 def test_bench_rccl_transport_with_a_world_of_one():
     """The RCCL transport through a real communicator — of one rank, all this box can hold: the record list as ONE
     all-gather of fixed-capacity segments + the device-side compaction (north_star's transport, nothing waits for the
-    host), and the 8-B item list as grouped send/recv with the counts read on the host."""
+    host)."""
     d = _run_ranks(["--gpus", "1", "--transport", "rccl", "--cpu-sample-entities", "0"], dict(ORBIT_BENCH_FORCE_DIST="1"))
     c = d["config"]
     assert c["gather"] is True and c["transport"] == "rccl" and c["world_size"] == 1 and c["backend"] == "nccl"
     assert c["signalling"] == "rccl-allgather" and "all-gather of fixed-capacity" in c["workload"]
     assert d["per_rank"]["exchange_ms"][0] > 0
-    d = _run_ranks(["--gpus", "1", "--transport", "rccl", "--exchange", "visible", "--expand", "all", "--cpu-sample-entities", "0"],
-                   dict(ORBIT_BENCH_FORCE_DIST="1"))
-    assert d["config"]["transport"] == "rccl" and d["config"]["signalling"] is None and d["per_rank"]["exchange_ms"][0] > 0
+    ta = d["transport_alt"]  # ... and the p2p exchange as the other transport's leg, with a world of one
+    assert ta["name"] == "p2p" and ta["signalling"] == "device" and ta["list_identical_to_main_transport"] is True
 
 
-@pytest.mark.parametrize("extra", [["--graph", "--frames-in-flight", "1"], ["--frames-in-flight", "1"], ["--two-calls"],
+@pytest.mark.parametrize("extra", [["--graph", "--frames-in-flight", "1"], ["--frames-in-flight", "1"],
                                    ["--frames-in-flight", "2", "--expand", "none"]])
 def test_bench_two_ranks_step_variants(extra):
     """The N > 1 step's other shapes, two ranks on the box's one GPU: every timed step replayed as a captured graph (cull
-    beside the previous list's exchange, fork and join inside the capture), strictly serial frames, the two calls
-    orbit_cull_shard replaces, two frames in flight without the command buffer.  bench.py checks every rank's lists."""
+    beside the previous list's exchange, fork and join inside the capture), strictly serial frames, two frames in flight
+    without the command buffer.  bench.py checks every rank's lists."""
     d = _run_ranks(["--gpus", "2"] + extra, dict(ORBIT_BENCH_ONE_DEVICE="1", ORBIT_BENCH_BACKEND="gloo"))
     c = d["config"]
     assert d["n_gpus"] == 2 and c["transport"] == "p2p" and c["signalling"] == "device" and c["transport_fallback"] is None

@@ -1,8 +1,10 @@
-"""world_size-2 gloo test of the rank-ordered visible-list gather (orbit_amd/dist.py): the
-concatenation of per-shard oracle outputs over contiguous 32-aligned entity ranges must be
-the single-process canonical sequence, and the gather must reproduce it on every rank."""
+"""Multi-process gloo tests of the sharded engine's exchange (orbit_amd/dist.py), worlds of 2, 3, 5 and 8: the
+concatenation of per-shard oracle outputs over contiguous 32-aligned entity ranges must be the single-process canonical
+sequence, and both transports — the device-signalled p2p exchange (its control-block protocol restated over shared
+memory) and the all-gather of fixed-capacity segments — must reproduce it on every rank."""
 import os
 import socket
+import time
 
 import numpy as np
 import pytest
@@ -12,7 +14,7 @@ import torch.multiprocessing as mp
 
 import scenes as sc
 from orbit_amd import layouts as L
-from orbit_amd.dist import gather_visible, shard_ranges, warm_up
+from orbit_amd.dist import shard_ranges
 
 
 def _free_port():
@@ -23,68 +25,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, seed, n_entities, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from oracle import oracle
-
-    scene = sc.make_scene(seed, n_entities, n_meshes=40)
-    cam = sc.default_camera()
-    ci = sc.make_cull_info(cam.view, cam.planes)
-    b, e = shard_ranges(scene.entity_draw_count, world)[rank]
-    cap = scene.max_dispatches() + 8
-    disp, _, _ = oracle.entity_cull(ci, scene.entity_draw_buffer(), e - b, scene.mesh_infos, scene.entities, cap,
-                                    draw_first=b)
-    draw, _, _ = oracle.meshlet_cull(ci, disp, scene.meshlets, scene.lod0_meshlets + 8, scene.entities,
-                                     scene.materials)
-    local = torch.from_numpy(draw.copy())
-    out = torch.zeros(L.DRAW_HEADER + 28 * (scene.lod0_meshlets + 8), dtype=torch.uint8)
-    assert warm_up(torch.device("cpu"))
-    counts = gather_visible(local, out)
-    assert counts[rank] == int(draw[:4].view(np.uint32)[0])
-    np.save(os.path.join(out_dir, f"gathered_{rank}.npy"), out.numpy())
-    # the compact exchange format (8 B per survivor after an 8-B header) through the same collective pattern
-    n, cmds = L.draw_buffer_commands(draw)
-    vis = np.zeros(L.VISIBLE_HEADER + 8 * n, dtype=np.uint8)
-    vis[:4].view(np.uint32)[0] = n
-    v = vis[8:].view(L.VISIBLE_MESHLET)
-    v["meshlet_index"], v["entity_index"] = cmds["meshlet_index"], cmds["cmd_first_instance"]
-    out_v = torch.full((L.VISIBLE_HEADER + 8 * (scene.lod0_meshlets + 8),), 0x77, dtype=torch.uint8)
-    counts_v = gather_visible(torch.from_numpy(vis), out_v, header=L.VISIBLE_HEADER, stride=8)
-    assert counts_v == counts
-    np.save(os.path.join(out_dir, f"gathered_vis_{rank}.npy"), out_v.numpy())
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("n_entities", [257, 64])
-def test_gather_visible_gloo_world2(tmp_path, oracle, n_entities):
-    world, seed = 2, 31
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, seed, n_entities, str(tmp_path)), nprocs=world, join=True)
-    scene = sc.make_scene(seed, n_entities, n_meshes=40)
-    cam = sc.default_camera()
-    ci = sc.make_cull_info(cam.view, cam.planes)
-    disp, _, _ = oracle.entity_cull(ci, scene.entity_draw_buffer(), scene.entity_draw_count, scene.mesh_infos,
-                                    scene.entities, scene.max_dispatches() + 8)
-    ref, _, _ = oracle.meshlet_cull(ci, disp, scene.meshlets, scene.lod0_meshlets + 8, scene.entities,
-                                    scene.materials)
-    n = int(ref[:4].view(np.uint32)[0])
-    assert n > 0
-    for r in range(world):
-        got = np.load(tmp_path / f"gathered_{r}.npy")
-        assert int(got[:4].view(np.uint32)[0]) == n
-        assert np.array_equal(got[:4 + 28 * n], ref[:4 + 28 * n]), f"rank {r}: gathered list != single-process list"
-        gv = np.load(tmp_path / f"gathered_vis_{r}.npy")
-        _, cmds = L.draw_buffer_commands(ref)
-        assert [int(v) for v in gv[:8].view(np.uint32)] == [n, 0]
-        items = gv[8:8 + 8 * n].view(L.VISIBLE_MESHLET)
-        assert np.array_equal(items["meshlet_index"], cmds["meshlet_index"])
-        assert np.array_equal(items["entity_index"], cmds["cmd_first_instance"])
-        assert np.all(gv[8 + 8 * n:] == 0x77)
-
-
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_bench_launches_its_own_ranks(world):
     """`python bench.py --gpus N` outside torch.distributed.run starts N fresh rank processes itself (before anything
     touches a GPU), forwards rank 0's ONE JSON line and fails if a rank fails.  ORBIT_BENCH_DRY_RANKS=1 stops the ranks
@@ -111,32 +52,70 @@ def test_bench_launches_its_own_ranks(world):
     assert r2.returncode != 0 and b"WORLD_SIZE" in r2.stderr
 
 
-# ----------------------------------------------------------------------------- exchange without a host round trip
+# ----------------------------------------------------------------------------- the exchange, no host in the step
 class _ShmTransport:
-    """CPU stand-in for the HIP transport of dist.P2PExchange: exchange buffers are files in /dev/shm mapped by every
-    rank (the IPC mapping), the scatter is orbit_scatter_list restated with numpy (same offsets, same header rule)."""
+    """CPU stand-in for the HIP transport of dist.P2PExchange: exchange buffers and control blocks are files in /dev/shm
+    mapped by every rank (the IPC mapping), and `exchange` restates orbit_exchange_list's two launches
+    (orbit_amd/csrc/meshlet_lists.hip: exchange_scatter_kernel, exchange_wait_kernel) with numpy — the same control-block
+    layout, the same epochs and count-slot parity, the same bounded waits — run by real processes polling real shared
+    memory.  ExchangeCtrl: u64 count[2][16] @0 (items | epoch << 32), u64 done[16] @256, u32 epoch @384."""
+
+    MAX_WORLD, TIMEOUT_S = 16, 60.0
 
     def __init__(self, tag):
-        self.tag, self.paths = tag, []
+        self.tag, self.paths, self.timeouts = tag, [], 0
 
     def alloc(self, nbytes):
-        path = f"/dev/shm/orbit_test_{self.tag}_{os.getpid()}"
+        path = f"/dev/shm/orbit_test_{self.tag}_{os.getpid()}_{len(self.paths)}"
         m = np.lib.format.open_memmap(path, mode="w+", dtype=np.uint8, shape=(nbytes,))
-        m[:] = 0x55
+        m[:] = 0  # orbit_p2p_alloc zero-fills
         self.paths.append(path)
         return torch.from_numpy(m), path
 
     def open(self, handle, nbytes):
         return torch.from_numpy(np.load(handle, mmap_mode="r+"))
 
-    def scatter(self, local_list, counts, rank, world, peers, capacity, header, stride, stream):
-        c = [int(v) for v in counts.tolist()]
-        first, total = sum(c[:rank]), sum(c)
-        n = min(c[rank], max(capacity - first, 0))
+    @staticmethod
+    def _count(ctrl):
+        return ctrl.numpy()[:256].view(np.uint64).reshape(2, 16)
+
+    @staticmethod
+    def _done(ctrl):
+        return ctrl.numpy()[256:384].view(np.uint64)
+
+    def _wait(self, cond):
+        t0 = time.time()
+        while not cond():
+            if time.time() - t0 > self.TIMEOUT_S:
+                self.timeouts += 1  # ORBIT_E_TIMEOUT
+                return False
+            time.sleep(0.0005)
+        return True
+
+    def exchange(self, local_list, rank, world, peers, ctrls, capacity, header, stride, stream):
+        mine = ctrls[rank]
+        epoch = mine.numpy()[384:388].view(np.uint32)
+        e = int(epoch[0]) + 1
+        n_mine = int(local_list[:4].view(torch.int32)[0])
+        # scatter launch: this rank's count into every rank's block ...
+        for r in range(world):
+            self._count(ctrls[r])[e & 1, rank] = np.uint64((e << 32) | n_mine)
+        # ... bounded wait for EVERY rank's count of this epoch (those of the lower ranks fix the offset)
+        slot = self._count(mine)[e & 1]
+        ok = self._wait(lambda: all(int(slot[r]) >> 32 == e for r in range(world)))
+        first = sum(int(slot[r]) & 0xFFFFFFFF for r in range(rank))
+        n = min(n_mine, max(capacity - first, 0)) if ok else 0  # a count that never came: nothing is copied anywhere
         for r in range(world):
             peers[r][header + stride * first:header + stride * (first + n)] = local_list[header:header + stride * n]
+        for r in range(world):  # ... and done, at every destination
+            self._done(ctrls[r])[rank] = np.uint64(e)
+        # wait launch: every rank's count and done for this epoch, then the header and the epoch
+        done = self._done(mine)
+        ok = self._wait(lambda: all(int(slot[r]) >> 32 == e and int(done[r]) == e for r in range(world)))
+        total = sum(int(slot[r]) & 0xFFFFFFFF for r in range(world)) if ok else 0
         peers[rank][:header] = 0
         peers[rank][:4].view(torch.int32)[0] = min(total, capacity)
+        epoch[0] = e
 
     def close(self):
         for p in self.paths:
@@ -195,23 +174,19 @@ def _p2p_worker(rank, world, port, seed, n_entities, out_dir):
     draw, _, _ = oracle.meshlet_cull(ci, disp, scene.meshlets, scene.lod0_meshlets + 8, scene.entities,
                                      scene.materials)
     n, cmds = L.draw_buffer_commands(draw)
-    vis = np.zeros(L.VISIBLE_HEADER + 8 * max(n, 1), dtype=np.uint8)
-    vis[:4].view(np.uint32)[0] = n
-    v = vis[8:8 + 8 * n].view(L.VISIBLE_MESHLET)
-    v["meshlet_index"], v["entity_index"] = cmds["meshlet_index"], cmds["cmd_first_instance"]
-    rec = _visible_records(disp, cmds)  # the same list at record granularity (12 B per dispatch record)
+    rec = _visible_records(disp, cmds)  # the shard's list at record granularity (12 B per dispatch record)
     capacity = scene.lod0_meshlets + 8
-    # the self-check a launcher runs before it relies on an exchange (bench.py): a known list per rank, compared
-    pr = P2PExchange(None, 64, L.VISIBLE_HEADER, 12, torch.device("cpu"), transport=_ShmTransport(f"probe{rank}"))
-    assert pr.probe()
-    pr.close()
-    for name, local, header, stride in (("cmd", draw, L.DRAW_HEADER, 28), ("vis", vis, L.VISIBLE_HEADER, 8),
-                                        ("rec", rec, L.VISIBLE_HEADER, 12)):
+    # the probe the constructor runs (a known list per rank, compared on every rank) is part of every object below
+    for name, local, header, stride in (("cmd", draw, L.DRAW_HEADER, 28), ("rec", rec, L.VISIBLE_HEADER, 12)):
         t = _ShmTransport(f"{name}{rank}")
         ex = P2PExchange(None, capacity, header, stride, torch.device("cpu"), transport=t)
-        for step in range(2):  # the buffers are reused step after step
+        assert ex.fallback is None and ex.signalling == "device"
+        ex.out[:] = 0x55
+        dist.barrier()
+        for step in range(4):  # the buffers are reused step after step: epochs 2 .. 5 behind the probe's, both count slots
             out = ex.exchange(torch.from_numpy(local.copy()))
-            dist.barrier()
+        assert t.timeouts == 0
+        dist.barrier()
         np.save(os.path.join(out_dir, f"p2p_{name}_{rank}.npy"), out.numpy().copy())
         dist.barrier()
         ex.close()
@@ -232,11 +207,12 @@ def _p2p_worker(rank, world, port, seed, n_entities, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_entities", [(2, 257), (3, 300), (3, 40)])
+@pytest.mark.parametrize("world,n_entities", [(2, 257), (3, 300), (3, 40), (5, 333), (8, 200), (8, 1000)])
 def test_p2p_exchange_protocol_gloo(tmp_path, oracle, world, n_entities):
-    """dist.P2PExchange (counts all-gather -> device-side offsets -> every rank writes its list into every peer's
-    buffer -> completion collective), both list formats, worlds of 2 and 3 (one shard may be empty): every rank ends
-    with the single-process canonical list."""
+    """dist.P2PExchange — orbit_exchange_list's protocol (count out to every control block; wait for all counts; copy
+    to the rank-ordered position in every peer's buffer; done; wait for all counts and dones; header; epoch) restated
+    over shared memory — with 28-B commands and 12-B records, and dist.AllGatherExchange, worlds of 2, 3, 5 and 8
+    (shards may be empty: 200 entity-draws over 8 ranks, 40 over 3): every rank ends with the single-process list."""
     seed = 33
     port = _free_port()
     mp.spawn(_p2p_worker, args=(world, port, seed, n_entities, str(tmp_path)), nprocs=world, join=True)
@@ -254,11 +230,6 @@ def test_p2p_exchange_protocol_gloo(tmp_path, oracle, world, n_entities):
         assert int(got[:4].view(np.uint32)[0]) == n
         assert np.array_equal(got[:4 + 28 * n], ref[:4 + 28 * n]), f"rank {r}: exchanged list != single-process list"
         assert np.all(got[4 + 28 * n:] == 0x55)  # nothing written past the list
-        gv = np.load(tmp_path / f"p2p_vis_{r}.npy")
-        assert [int(v) for v in gv[:8].view(np.uint32)] == [n, 0]
-        items = gv[8:8 + 8 * n].view(L.VISIBLE_MESHLET)
-        assert np.array_equal(items["meshlet_index"], cmds["meshlet_index"])
-        assert np.array_equal(items["entity_index"], cmds["cmd_first_instance"])
         gr = np.load(tmp_path / f"p2p_rec_{r}.npy")  # the record-granular list: the single-process one, in rank order
         want = _visible_records(disp, cmds)
         nr = int(want[:4].view(np.uint32)[0])

@@ -861,64 +861,6 @@ def test_sharded_ranges_concatenate_to_the_canonical_list(torch_mod, engine, ora
     assert len(got) == on and np.array_equal(got.view(np.uint32), ocmds.view(np.uint32))
 
 
-@pytest.mark.parametrize("world", [1, 3])
-def test_compact_visible_lists_expand_to_the_canonical_list(torch_mod, engine, oracle, world):
-    """The 8-B-per-survivor exchange format of the sharded engine: every rank's orbit_meshlet_cull_visible list is
-    {meshlet_index, entity_index} of its commands in canonical order; the rank-order concatenation, expanded against
-    the full meshlet buffer by orbit_expand_visible, is the single-GPU MeshletDrawCommandBuffer — also when the
-    capacities cut it."""
-    from orbit_amd._lib import E_CAPACITY, OrbitError
-    from orbit_amd.dist import shard_ranges
-
-    torch = torch_mod
-    scene = sc.make_scene(29, 800, meshlets_per_mesh=(1, 70), lods=2)
-    cam = sc.default_camera(rot=(0.2, 0.4))
-    ci = sc.make_cull_info(cam.view, cam.planes, alpha_mode_flag=L.ALPHA_ALL)
-    gs = GpuScene(torch, scene)
-    ref = run_oracle(oracle, scene, ci)
-    on, ocmds = L.draw_buffer_commands(ref[1])
-    assert on > 500
-    cap_d, cap_c = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
-    items = []
-    for b, e in shard_ranges(scene.entity_draw_count, world):
-        disp = torch.zeros(L.DISPATCH_HEADER + 16 * cap_d, dtype=torch.uint8, device="cuda")
-        vis = torch.full((L.VISIBLE_HEADER + 8 * cap_c + 64,), 0xCD, dtype=torch.uint8, device="cuda")
-        engine.entity_cull(ci, gs.draws, gs.mesh_infos, disp, gs.entities, e - b, cap_d, draw_first=b)
-        engine.meshlet_cull_visible(ci, disp, gs.meshlets, vis, gs.entities, gs.materials, cap_d, cap_c)
-        torch.cuda.synchronize()
-        hv = host(vis)
-        n, pad = (int(v) for v in hv[:8].view(np.uint32))
-        assert pad == 0 and bool((hv[8 + 8 * n:] == 0xCD).all())
-        items.append(hv[8:8 + 8 * n].view(L.VISIBLE_MESHLET))
-    got = np.concatenate(items)
-    assert len(got) == on
-    assert np.array_equal(got["meshlet_index"], ocmds["meshlet_index"])
-    assert np.array_equal(got["entity_index"], ocmds["cmd_first_instance"])
-    # the gathered list, expanded on "the receiving GPU"
-    allvis = np.zeros(L.VISIBLE_HEADER + 8 * on, dtype=np.uint8)
-    allvis[:4].view(np.uint32)[0] = on
-    allvis[8:] = got.view(np.uint8)
-    gvis = dev(torch, allvis)
-    draw = torch.full((L.DRAW_HEADER + 28 * cap_c + 64,), 0xCD, dtype=torch.uint8, device="cuda")
-    engine.expand_visible(gvis, gs.meshlets, draw, cap_c)
-    torch.cuda.synchronize()
-    engine.status()
-    n, cmds = L.draw_buffer_commands(host(draw))
-    assert n == on and np.array_equal(cmds.view(np.uint32), ocmds.view(np.uint32))
-    assert bool((host(draw)[4 + 28 * on:] == 0xCD).all())
-    # capacity cut in the expansion: prefix written, overflow latched
-    cut = on - 33
-    draw2 = torch.full((L.DRAW_HEADER + 28 * cut + 64,), 0xCD, dtype=torch.uint8, device="cuda")
-    engine.expand_visible(gvis, gs.meshlets, draw2, cut)
-    torch.cuda.synchronize()
-    n2, cmds2 = L.draw_buffer_commands(host(draw2))
-    assert n2 == cut and np.array_equal(cmds2.view(np.uint32), ocmds[:cut].view(np.uint32))
-    assert bool((host(draw2)[4 + 28 * cut:] == 0xCD).all())
-    with pytest.raises(OrbitError) as ei:
-        engine.status()
-    assert ei.value.code == E_CAPACITY
-
-
 def _expected_visible_records(orecs, ocmds):
     """The record-granular visible list the oracle's outputs imply — one entry per dispatch record, in record order: the
     commands come in (record, lane) order, so every dispatch record takes the run of commands of its entity that fall
@@ -1107,6 +1049,7 @@ def test_null_arguments_are_status_codes_not_crashes(torch_mod):
         eb, mb = _lib.EntityCullBufs(), _lib.MeshletCullBufs()  # all-NULL buffer sets
         bad = (_lib.E_INVALID, _lib.E_MISSING)
         some = C.c_void_p(ctx.value)  # any non-NULL pointer for arguments that are checked for NULL only
+        one_ptr = (C.c_void_p * 1)(ctx.value)  # ... and a pointer array of one
         calls = [
             lambda: lib.orbit_entity_cull(None, cip, C.byref(eb), 1, None),
             lambda: lib.orbit_entity_cull(ctx, None, C.byref(eb), 1, None),
@@ -1117,9 +1060,6 @@ def test_null_arguments_are_status_codes_not_crashes(torch_mod):
             lambda: lib.orbit_meshlet_cull(ctx, cip, C.byref(mb), None),
             lambda: lib.orbit_meshlet_cull(None, cip, C.byref(mb), None),
             lambda: lib.orbit_meshlet_task_cull(ctx, cip, C.byref(mb), None, None),
-            lambda: lib.orbit_meshlet_cull_visible(ctx, cip, C.byref(mb), None, 16, None),
-            lambda: lib.orbit_expand_visible(ctx, None, None, None, 16, None),
-            lambda: lib.orbit_expand_visible(None, some, some, some, 16, None),
             lambda: lib.orbit_meshlet_cull_visible_records(ctx, cip, C.byref(mb), None, 16, None),
             lambda: lib.orbit_expand_visible_records(ctx, None, None, None, 16, None),
             lambda: lib.orbit_expand_visible_records(None, some, some, some, 16, None),
@@ -1131,7 +1071,6 @@ def test_null_arguments_are_status_codes_not_crashes(torch_mod):
             lambda: lib.orbit_cluster_assign(ctx, None, None, None, None, None, 0, None, None),
             lambda: lib.orbit_compute_clusters(ctx, None, None, None, None, None, None, None, 0, None, 0, None, None),
             lambda: lib.orbit_gather_visible(ctx, None, 0, 1, None, None, 0, None),
-            lambda: lib.orbit_gather_visible_meshlets(ctx, None, 0, 1, None, None, 0, None),
             lambda: lib.orbit_ctx_profile_read(ctx, None, None),
             lambda: lib.orbit_ctx_status(None, None, 0),
             lambda: lib.orbit_cull_views(ctx, None, 1, None),
@@ -1139,9 +1078,13 @@ def test_null_arguments_are_status_codes_not_crashes(torch_mod):
             lambda: lib.orbit_cull_views(ctx, C.cast(C.pointer(_lib.CullView()), C.POINTER(_lib.CullView)), 1, None),
             lambda: lib.orbit_depth_reduce_multi(ctx, None, 1, None),
             lambda: lib.orbit_depth_reduce_multi(ctx, C.cast(C.pointer(_lib.DepthReduceItem()), C.POINTER(_lib.DepthReduceItem)), 1, None),
-            lambda: lib.orbit_scatter_list(ctx, None, None, 0, 1, None, 0, 4, 28, None),
-            lambda: lib.orbit_scatter_list(ctx, some, some, 3, 2, some, 0, 4, 28, None),
-            lambda: lib.orbit_scatter_list(ctx, some, some, 0, 1, some, 0, 6, 28, None),
+            lambda: lib.orbit_exchange_list(ctx, None, 0, 1, None, None, 0, 8, 12, None),
+            lambda: lib.orbit_exchange_list(ctx, some, 3, 2, one_ptr, one_ptr, 0, 8, 12, None),
+            lambda: lib.orbit_exchange_list(ctx, some, 0, 1, one_ptr, one_ptr, 0, 6, 12, None),
+            lambda: lib.orbit_exchange_list(ctx, some, 0, 17, one_ptr, one_ptr, 0, 8, 12, None),
+            lambda: lib.orbit_compact_segments(ctx, None, 1, 16, None, 16, 8, 12, None),
+            lambda: lib.orbit_compact_segments(ctx, some, 65, 16, some, 16, 8, 12, None),
+            lambda: lib.orbit_allgather_list(ctx, None, 0, 1, some, 16, some, some, 16, 8, 12, None),
             lambda: lib.orbit_p2p_alloc(ctx, 0, None, None),
             lambda: lib.orbit_p2p_open(ctx, None, None),
         ]
@@ -1267,35 +1210,37 @@ def test_cull_views_early_pass_and_cascades(torch_mod, oracle):
     eng.close()
 
 
-def test_scatter_list_capacity_and_header(torch_mod):
-    """orbit_scatter_list with a world of one: the list lands at offset 0 behind a {total, 0} header; an output that
-    cannot hold the concatenation latches ORBIT_E_CAPACITY, the header is clamped and nothing is written past it."""
+def test_exchange_list_capacity_and_header(torch_mod):
+    """orbit_exchange_list with a world of one (its own control block, epochs counted across calls): the list lands at
+    offset 0 behind a {total, 0} header; an output that cannot hold the concatenation latches ORBIT_E_CAPACITY, the header
+    is clamped and nothing is written past it."""
     torch = torch_mod
     from orbit_amd._lib import E_CAPACITY, OrbitError
+    from orbit_amd.dist import device_view
     from orbit_amd.engine import Engine
 
     eng = Engine(0)
     n = 1000
-    items = torch.arange(2 * n, dtype=torch.int32, device="cuda")
-    local = torch.zeros(L.VISIBLE_HEADER + 8 * n, dtype=torch.uint8, device="cuda")
-    local[:4].view(torch.int32)[0] = n
-    local[8:].view(torch.int32)[:] = items
-    counts = torch.tensor([n], dtype=torch.int32, device="cuda")
-    out = torch.full((L.VISIBLE_HEADER + 8 * n + 64,), 0x5A, dtype=torch.uint8, device="cuda")
-    eng.scatter_list(local, counts, 0, 1, [out], n, L.VISIBLE_HEADER, 8)
-    torch.cuda.synchronize()
-    eng.status()
-    assert [int(v) for v in out[:8].view(torch.int32)] == [n, 0]
-    assert torch.equal(out[8:8 + 8 * n], local[8:]) and bool((out[8 + 8 * n:] == 0x5A).all())
-    out.fill_(0x5A)
-    eng.scatter_list(local, counts, 0, 1, [out], n - 100, L.VISIBLE_HEADER, 8)
-    torch.cuda.synchronize()
-    assert int(out[:4].view(torch.int32)[0]) == n - 100
-    assert torch.equal(out[8:8 + 8 * (n - 100)], local[8:8 + 8 * (n - 100)])
-    assert bool((out[8 + 8 * (n - 100):] == 0x5A).all())
+    local = torch.zeros(L.VISIBLE_HEADER + 12 * n, dtype=torch.uint8, device="cuda")
+    local[:8].view(torch.int32)[:] = torch.tensor([n, 77], dtype=torch.int32)
+    local[8:].view(torch.int32)[:] = torch.arange(3 * n, dtype=torch.int32, device="cuda")
+    out_bytes = L.VISIBLE_HEADER + 12 * n + 64
+    out_ptr, _ = eng.p2p_alloc(out_bytes)
+    ctrl_ptr, _ = eng.p2p_alloc(1024)
+    out = device_view(out_ptr, out_bytes, torch.device("cuda", 0))
+    for cap in (n, n, n - 100):  # three epochs on one control block; the last one cut by the capacity
+        out.fill_(0x5A)
+        eng.exchange_list(local, 0, 1, [out_ptr], [ctrl_ptr], cap, L.VISIBLE_HEADER, 12)
+        torch.cuda.synchronize()
+        assert [int(v) for v in out[:8].view(torch.int32)] == [cap, 0]
+        assert torch.equal(out[8:8 + 12 * cap], local[8:8 + 12 * cap]) and bool((out[8 + 12 * cap:] == 0x5A).all())
+        if cap == n:
+            eng.status()
     with pytest.raises(OrbitError) as ei:
         eng.status()
     assert ei.value.code == E_CAPACITY
+    eng.p2p_free(ctrl_ptr)
+    eng.p2p_free(out_ptr)
     eng.close()
 
 

@@ -126,11 +126,11 @@ def test_visible_list_and_expansion_from_the_stream(torch_mod, engine, oracle):
     engine.bind_meshlet_stream(ms)
     cap_d, cap_c = scene.max_dispatches() + 8, scene.lod0_meshlets + 8
     disp = torch.zeros(L.DISPATCH_HEADER + 16 * cap_d, dtype=torch.uint8, device="cuda")
-    vis = torch.full((L.VISIBLE_HEADER + 8 * cap_c + 64,), 0xCD, dtype=torch.uint8, device="cuda")
+    vis = torch.full((L.VISIBLE_HEADER + 12 * cap_d + 64,), 0xCD, dtype=torch.uint8, device="cuda")
     draw = torch.full((L.DRAW_HEADER + 28 * cap_c + 64,), 0xCD, dtype=torch.uint8, device="cuda")
     engine.entity_cull(ci, gs.draws, gs.mesh_infos, disp, gs.entities, scene.entity_draw_count, cap_d)
-    engine.meshlet_cull_visible(ci, disp, gs.meshlets, vis, gs.entities, gs.materials, cap_d, cap_c)
-    engine.expand_visible(vis, gs.meshlets, draw, cap_c)
+    engine.meshlet_cull_visible_records(ci, disp, gs.meshlets, vis, gs.entities, gs.materials, cap_d, cap_d)
+    engine.expand_visible_records(vis, gs.meshlets, draw, cap_c)
     torch.cuda.synchronize()
     engine.status()
     assert engine.meshlet_stream_culls() == 2  # the cull and the expansion
@@ -229,12 +229,13 @@ def test_meshlet_outside_the_stream_latches_range_error(torch_mod, engine, oracl
         engine.status()
     assert ei.value.code == E_RANGE
     engine.status()  # the latch is cleared by the read
-    # expansion of a list that names a meshlet past the stream
-    vis = np.zeros(L.VISIBLE_HEADER + 8 * 2, dtype=np.uint8)
-    vis[:4].view(np.uint32)[0] = 2
-    vis[8:].view(np.uint32)[:] = [1, 0, half + 3, 0]
+    # expansion of a record list that names a meshlet past the stream: {entity 0, offset 1, bit 0}, {entity 0, offset
+    # half + 3, bit 0}
+    vis = np.zeros(L.VISIBLE_HEADER + 12 * 2, dtype=np.uint8)
+    vis[:8].view(np.uint32)[:] = [2, 2]
+    vis[8:].view(np.uint32)[:] = [0, 1, 1, 0, half + 3, 1]
     draw = torch.zeros(L.DRAW_HEADER + 28 * 4, dtype=torch.uint8, device="cuda")
-    engine.expand_visible(dev(torch, vis), gs.meshlets, draw, 4)
+    engine.expand_visible_records(dev(torch, vis), gs.meshlets, draw, 4)
     with pytest.raises(OrbitError) as ei:
         engine.status()
     assert ei.value.code == E_RANGE
