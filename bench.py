@@ -36,6 +36,9 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+RUNTIME_WARM_FRAMES = 0  # rounds 4-5: 1024 frames enqueued before anything was timed (see the settle phase); no longer
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,12 +98,19 @@ def parse():
     ap.add_argument("--no-alpha-classes", action="store_true",
                     help="stream source without orbit_meshlet_stream_set_materials: the evaluation reads the 2-B "
                          "material index of every meshlet (22 B per meshlet)")
+    ap.add_argument("--settle-with", choices=("stream", "frames"), default="frames",
+                    help="what keeps the device busy during the settle: frames of the engine (default: the power management "
+                         "follows the workload — see the settle phase) or streaming reads of the meshlet buffer (no frame "
+                         "of the engine runs, warmup_effective stays 8 + W; the region then runs ~3 %% slower)")
     ap.add_argument("--settle-ms", type=float, default=60.0,
                     help="device time spent on back-to-back frames BEFORE the warmup steps, so that the device is in "
                          "its sustained power state when they start: from idle, the firmware's power controller "
                          "overshoots for ~15 ms (frames 5-45 run up to 25 %% slower than both the first frames and "
                          "the steady state, tools/sustained.sh) — exactly where 5 warmup + 20 timed steps would sit. "
                          "Not steps: reported as config.settle_ms; 0 disables")
+    ap.add_argument("--runtime-warm-frames", type=int, default=RUNTIME_WARM_FRAMES,
+                    help="frames a process has enqueued before anything is timed (the settle phase runs at least until "
+                         "then; see RUNTIME_WARM_FRAMES)")
     ap.add_argument("--planes", type=int, default=5, help="cull planes used (5 = forward.rs:268; fewer only for triage)")
     return ap.parse_args()
 
@@ -162,9 +172,6 @@ def spawn_ranks(args):
     bad = failed or [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
         raise SystemExit(f"bench.py: rank(s) failed (rank, exit code): {bad}; exit codes of all ranks: {rcs}")
-
-
-RUNTIME_WARM_FRAMES = 1024  # frames a process has enqueued before anything is timed (see the settle phase)
 
 
 def main():
@@ -399,89 +406,66 @@ def main():
         if xstream is not None:
             torch.cuda.current_stream().wait_stream(xstream)
 
-    # Power-state settle (see --settle-ms): the same frames, back to back, until the device has been busy that long.
-    # The frame count must be the same on every rank (a step of the sharded engine contains collectives), so it is
-    # derived from the slowest rank's time for the first eight frames, not from each rank's own clock.
-    # SURVEY.md §8d, literally: the 32-B Meshlet buffer (no derived stream), 5 warm-up steps from an idle device, then
-    # >= 20 steps each bracketed by its own HIP event pair on the launch stream; the median.  Never the headline
-    # (that is the settled stream path below), always in the line — N = 1 only (a step of N > 1 contains collectives).
-    protocol_8d = None
+    # ---- before the timed region (config.warmup_effective counts every frame of it):
+    #   1. eight cold frames: code objects, first touches of every buffer;
+    #   2. the power-state settle (--settle-ms, default 60): from idle, the device's power management needs ~50 ms OF THIS
+    #      WORKLOAD to reach the clocks it then holds — W + K = 25 steps straight from idle run at 0.30 ms per step, after
+    #      ~200 back-to-back frames at 0.259-0.260 (profiles/r06_notes.md §settle).  Keeping the device busy with something
+    #      else does not do it: 60, 300 or 1 000 ms of streaming reads of the same meshlet buffer (--settle-with stream)
+    #      leave the region at 0.268-0.272 — the governor follows the workload, not the clock on the wall.  So the settle
+    #      is frames of the engine, as many as fill --settle-ms: ~230 at config 5.
+    #      Rounds 4-5 ran at least 1 024 frames here (--runtime-warm-frames) to keep the HIP runtime's one long host-side
+    #      stall of a process out of the region.  That stall comes when the enqueuing thread is ~1 200 commands AHEAD of the
+    #      device (tools/stall_find.py, profiles/r06_notes.md §stall: after frame 393 with three launches per frame, 336 with
+    #      a fresh timing event per frame as well, 200 with two; never when the host is slowed down) — a state a region of
+    #      K <= 300 steps entered through a synchronisation does not reach, and neither do the ~230 settle frames;
+    #   3. the measurement hook's event pairs, created before the region (orbit_ctx_profile_reserve) instead of by
+    #      ceil(K / 3) + 1 extra frames;
+    #   4. the W warm-up steps the command line asks for.
+    #   The SURVEY §8d protocol run and the from-idle W + K steps — reported, never the metric — now run BEHIND the region.
     frames_before_timed = 0
-    if world == 1 and not use_dist:
-        s0 = slots[0]
-        if mstream is not None:
-            s0.eng.bind_meshlet_stream(None)
-        for _ in range(5):
-            cull(s0, 0)
-        n8 = max(20, args.steps)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n8)]
-        for a, z in evs:
-            a.record(s0.stream)
-            cull(s0, 0)
-            z.record(s0.stream)
-        torch.cuda.synchronize()
-        ms8 = sorted(a.elapsed_time(z) for a, z in evs)
-        protocol_8d = {"what": "SURVEY.md §8d as written: Meshlet buffer (32 B per meshlet, no derived stream, no "
-                               "update contract), 5 warm-up steps from idle, no settle phase, then one HIP event pair "
-                               "per step; median",
-                       "steps": n8, "warmup": 5, "ms_per_step_median": ms8[len(ms8) // 2], "ms_per_step_min": ms8[0],
-                       "ms_per_step_max": ms8[-1], "meshlets_per_sec": n_local_meshlets / (ms8[len(ms8) // 2] * 1e-3)}
-        frames_before_timed += 5 + n8
-        if mstream is not None:
-            s0.eng.bind_meshlet_stream(mstream)
     settle_frames = 0
-    cold_ms_per_step = None
-    if args.settle_ms > 0:
-        # for the record: the same W + K steps straight from idle, i.e. inside the transient (never the metric)
-        for _ in range(args.warmup):
-            step()
-        drain()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        tc = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        drain()
-        torch.cuda.synchronize()
-        cold = torch.tensor([(time.perf_counter() - tc) / args.steps * 1e3], dtype=torch.float64, device=dev)
-        if use_dist:
-            dist.all_reduce(cold, op=dist.ReduceOp.MAX)
-        cold_ms_per_step = float(cold.item())
-        frames_before_timed += args.warmup + args.steps
-        for batch in range(2):  # eight cold frames (code objects, first touches), then eight that are timed
-            t_settle = time.perf_counter()
+    for _ in range(8):
+        step()
+    drain()
+    torch.cuda.synchronize()
+    frames_before_timed += 8
+    if args.settle_ms > 0 and args.settle_with == "stream":
+        words = meshlets.view(torch.float32)
+        t_end = time.perf_counter() + args.settle_ms * 1e-3
+        while time.perf_counter() < t_end:
             for _ in range(8):
-                step()
-            drain()
+                words.sum()
             torch.cuda.synchronize()
+    elif args.settle_ms > 0:
+        # (the frame count must be the same on every rank — a step of the sharded engine may contain collectives — so it is
+        # derived from the slowest rank's time for eight frames, not from each rank's own clock)
+        t_settle = time.perf_counter()
+        for _ in range(8):
+            step()
+        drain()
+        torch.cuda.synchronize()
         per_frame = torch.tensor([(time.perf_counter() - t_settle) / 8], dtype=torch.float64, device=dev)
         if use_dist:
             dist.all_reduce(per_frame, op=dist.ReduceOp.MAX)
-        more = int(np.ceil(args.settle_ms * 1e-3 / max(float(per_frame.item()), 1e-6))) - 16
-        # ... and until the process has enqueued RUNTIME_WARM_FRAMES frames in all: the HIP runtime blocks the enqueuing
-        # thread ONCE for 10-50 ms somewhere in a process's first ~500 frames of this step (tools/stall_find.py: after
-        # frame 416 / 468 / 548 depending on what else was submitted; a device whose host is less than that ahead runs
-        # dry).  With the default K = 30 that moment came 60-130 frames AFTER the timed region; with K = 100 it sat
-        # inside it (0.27 -> 0.6-0.7 ms per step).  A renderer is past it after its first second; so is the timed region.
-        more = max(more, RUNTIME_WARM_FRAMES - frames_before_timed - 16)
-        more = min(max(more, 0), 8192)
+        more = int(np.ceil(args.settle_ms * 1e-3 / max(float(per_frame.item()), 1e-6))) - 8
+        more = min(max(max(more, args.runtime_warm_frames - 16), 0), 8192)
         for _ in range(more):
             step()
         drain()
         torch.cuda.synchronize()
-        settle_frames = 16 + more
-    frames_before_timed += settle_frames + args.warmup
+        settle_frames = 8 + more
+        frames_before_timed += settle_frames
     for _ in range(args.warmup):
         step()
     drain()
     torch.cuda.synchronize()
+    frames_before_timed += args.warmup
     # HIP events around the dominant kernel (meshlet_eval), recorded by the library on the launch stream.  An event
     # pair costs ~7 us of stream time (it keeps the next launch from being prefetched: tools/t_host.py), so every
     # `--time-every`-th launch per slot is timed, not all of them, and no other event is recorded inside the region.
-    # The library creates a launch's event pair on first use (hipEventCreate + the event's first record: not free).  So
-    # every pair the timed region will record is used once before it, on the same streams: ceil(K / time_every) + 1
-    # untimed steps with every launch timed (part of the warm-up: counted in warmup_effective).
+    # The library creates a launch's event pair on first use (hipEventCreate + the event's first record: not free): every
+    # pair the timed region will record is created before it (orbit_ctx_profile_reserve), on the slot's stream.
     prewarm = -(-args.steps // max(args.time_every, 1)) + 1
     # N > 1: the step as a captured graph (--graph).  Two graphs, because consecutive steps alternate between the
     # slot's two list buffers and the two exchange buffers: graph k = { cull into list k  ||  exchange of list 1 - k, the
@@ -504,21 +488,16 @@ def main():
             graphs.append(g)
         if use_dist:
             dist.barrier()  # every rank has captured (capture enqueues nothing)
-        for i in range(2 * prewarm):  # the replays' own warm-up
+        for i in range(4):  # the replays' own warm-up
             with torch.cuda.stream(s0g.stream):
                 graphs[i % 2].replay()
         torch.cuda.synchronize()
-        frames_before_timed += 2 * prewarm
+        frames_before_timed += 4
     else:
         for s in slots:
-            s.eng.profile(True, every=1)
-        for _ in range(prewarm * F):
-            step()
-        drain()
-        torch.cuda.synchronize()
-        frames_before_timed += prewarm * F
-        for s in slots:
+            s.eng.profile_reserve(prewarm + 1, stream=s.stream)
             s.eng.profile(True, every=args.time_every)
+        torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -580,6 +559,51 @@ def main():
         s.eng.profile(False)
     assert eval_launches >= 1, "no launch of the dominant kernel was timed"
     eval_ms = eval_sum / eval_launches
+
+    # For the record, behind the timed region (never the metric): the same W + K steps straight from an idle device, i.e.
+    # inside the power controller's transient — what the settle phase is there to keep out of the number.
+    time.sleep(0.25)
+    for _ in range(args.warmup):
+        step()
+    drain()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    tc = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    drain()
+    torch.cuda.synchronize()
+    cold = torch.tensor([(time.perf_counter() - tc) / args.steps * 1e3], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(cold, op=dist.ReduceOp.MAX)
+    cold_ms_per_step = float(cold.item())
+    # SURVEY.md §8d, literally: the 32-B Meshlet buffer (no derived stream), 5 warm-up steps from an idle device, then
+    # >= 20 steps each bracketed by its own HIP event pair on the launch stream; the median.  Never the headline (that is
+    # the settled stream path above), always in the line — N = 1 only (a step of N > 1 contains an exchange).
+    protocol_8d = None
+    if world == 1 and not use_dist:
+        s0 = slots[0]
+        if mstream is not None:
+            s0.eng.bind_meshlet_stream(None)
+        time.sleep(0.25)
+        for _ in range(5):
+            cull(s0, 0)
+        n8 = max(20, args.steps)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n8)]
+        for a, z in evs:
+            a.record(s0.stream)
+            cull(s0, 0)
+            z.record(s0.stream)
+        torch.cuda.synchronize()
+        ms8 = sorted(a.elapsed_time(z) for a, z in evs)
+        protocol_8d = {"what": "SURVEY.md §8d as written: Meshlet buffer (32 B per meshlet, no derived stream, no "
+                               "update contract), 5 warm-up steps from idle (a 0.25-s pause behind the timed region), no "
+                               "settle phase, then one HIP event pair per step; median",
+                       "steps": n8, "warmup": 5, "ms_per_step_median": ms8[len(ms8) // 2], "ms_per_step_min": ms8[0],
+                       "ms_per_step_max": ms8[-1], "meshlets_per_sec": n_local_meshlets / (ms8[len(ms8) // 2] * 1e-3)}
+        if mstream is not None:
+            s0.eng.bind_meshlet_stream(mstream)
 
     # one frame alone on an idle device (nothing else in flight): the latency a single cull costs, and its parts
     s0 = slots[0]
@@ -844,7 +868,8 @@ def main():
                 "frames_in_flight": F,
                 "settle_ms": args.settle_ms, "settle_frames": settle_frames,
                 "warmup_effective": frames_before_timed,  # every frame this process ran before the timed region
-                "ms_per_step_without_settle": cold_ms_per_step,
+                "settle_with": args.settle_with,
+                "ms_per_step_without_settle": cold_ms_per_step,  # W + K steps from idle, behind the timed region
                 "world_size": world_reported, "backend": (backend if use_dist else None),
                 "expand": (args.expand if do_gather else None),
                 "step_product": (None if not do_gather else

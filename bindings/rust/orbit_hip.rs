@@ -17,6 +17,22 @@ pub struct OrbitMeshletStream { _private: [u8; 0] }
 pub struct OrbitCaps {
     pub max_entities: u32, pub max_dispatches: u32, pub max_draws: u32, pub max_lights: u32,
     pub max_clusters: u32, pub dispatch_size: u32, pub max_views: u32, pub validate_streams: u32, pub cull_path: u32,
+    pub arena_candidates: u32, pub arith_profile: u32,
+}
+
+/// orbit_compute_clusters' arguments as a block (orbit_frame_late)
+#[repr(C)]
+pub struct OrbitClusterFrame {
+    pub push: *const c_void, pub info: *const c_void, pub depth: *const f32, pub lights: *const c_void,
+    pub tile_depth_slice_mask: *mut u32, pub depth_bounds: *mut c_void, pub unique_cluster_buffer: *mut c_void,
+    pub light_index_buffer: *mut c_void, pub cluster_offset_image: *mut u32,
+    pub index_capacity: u32, pub light_index_capacity: u32,
+}
+#[repr(C)]
+pub struct OrbitFrameLate {
+    pub pyramids: *const c_void, pub late_views: *const c_void, pub cascade_views: *const c_void,
+    pub clusters: *const OrbitClusterFrame,
+    pub pyramid_count: u32, pub late_view_count: u32, pub cascade_view_count: u32, pub _pad: u32,
 }
 
 /// push-constant order of shaders/entity_cull.comp:17-23 (== draw_gen.rs:372-376)
@@ -88,6 +104,7 @@ extern "C" {
     pub fn orbit_depth_pyramid_desc_from_mip0(mip0_w: u32, mip0_h: u32, desc: *mut OrbitDepthPyramidDesc) -> i32;
     /// Measurement hooks: HIP events around the dominant kernel on the launch stream.
     pub fn orbit_ctx_profile(ctx: *mut OrbitCtx, enable: i32) -> i32;
+    pub fn orbit_ctx_profile_reserve(ctx: *mut OrbitCtx, pairs: u32, stream: *mut c_void) -> i32;
     pub fn orbit_ctx_profile_read(ctx: *mut OrbitCtx, avg_ms: *mut f32, launches: *mut u32) -> i32;
     pub fn orbit_cull_views(ctx: *mut OrbitCtx, views: *const OrbitCullView, count: u32, stream: *mut c_void) -> i32;
     pub fn orbit_depth_reduce(ctx: *mut OrbitCtx, depth: *const f32, screen_w: u32, screen_h: u32,
@@ -143,6 +160,9 @@ extern "C" {
     pub fn orbit_ctx_mesh_side_culls(ctx: *const OrbitCtx) -> u64;
     pub fn orbit_ctx_bind_meshlet_stream(ctx: *mut OrbitCtx, ms: *mut OrbitMeshletStream) -> i32;
     pub fn orbit_ctx_fused_culls(ctx: *const OrbitCtx) -> u64;
+    /// The late half of a frame (app.rs:1151-1212) with its independent chains side by side: {pyramids -> late culls} on
+    /// `stream`, {cascade culls} and {compute_clusters} on two streams of the context, forked and joined by events.
+    pub fn orbit_frame_late(ctx: *mut OrbitCtx, frame: *const OrbitFrameLate, stream: *mut c_void) -> i32;
     pub fn orbit_ctx_meshlet_stream_culls(ctx: *const OrbitCtx) -> u64;
     pub fn orbit_ctx_meshlet_class_culls(ctx: *const OrbitCtx) -> u64;
     // exchange without a host in the step: IPC-mapped peer buffers + a device-signalled rank-ordered scatter (orbit_exchange_list)

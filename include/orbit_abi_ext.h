@@ -9,6 +9,7 @@
  *   - several views in one call / one launch (orbit_cull_views),
  *   - derived meshlet streams (an MI355X-side re-layout of the static meshlet buffer),
  *   - several pyramids in one launch,
+ *   - the late half of a frame with its independent chains side by side (orbit_frame_late),
  *   - the sharded engine: the shard cull, the record list, its device-side exchanges (HIP-IPC stores; RCCL all-gather)
  *     and the expansion of a gathered list,
  *   - the measurement hook of bench.py.
@@ -226,6 +227,59 @@ ORBIT_STATIC_ASSERT(sizeof(OrbitDepthReduceItem) == 40, "depth-reduce item is 40
 int32_t orbit_depth_reduce_multi(OrbitCtx *ctx, const OrbitDepthReduceItem *items, uint32_t count, void *stream);
 
 /* ------------------------------------------------------------------------ */
+/* The late half of a frame as ONE call with its independent chains side by  */
+/* side.  Between "the depth buffer exists" and the forward pass the renderer */
+/* records (src/app.rs:1151-1212): the depth pyramid(s) and the late          */
+/* (VisibilityWrite) culls of render_depth_prepass (forward.rs:371-403,      */
+/* draw_gen.rs:510-566), render_shadows' cascade culls (shadow_renderer.rs:  */
+/* 391-403: occlusion_pass 0, no pyramid) and compute_clusters (cluster.rs:  */
+/* 368-397).  Three chains that share no output: on scenes of the            */
+/* reference's own size each is a handful of dependent, latency-bound        */
+/* launches on a device that is 95 % idle during any one of them — issued    */
+/* one after the other on one stream they cost their sum.                    */
+/* orbit_frame_late runs                                                     */
+/*   A  pyramids (orbit_depth_reduce_multi) -> late_views (orbit_cull_views), */
+/*   B  cascade_views (orbit_cull_views) and                                  */
+/*   C  clusters (orbit_compute_clusters)                                     */
+/* side by side: the chain with the most dependent launches stays on         */
+/* `stream`, the other two run on two streams of the context, forked behind  */
+/* whatever `stream` holds when                                              */
+/* the call is made and joined into `stream` before it returns — events only, */
+/* no host wait: the call can be captured into a graph, and work enqueued    */
+/* on `stream` behind it sees all three chains' outputs.  Outputs are byte   */
+/* for byte those of the serial calls.  Every group is optional (count 0 /   */
+/* NULL); late + cascade views together at most ORBIT_MAX_CULL_VIEWS (each   */
+/* view on its own scan scratch, OrbitCaps.max_views); everything is         */
+/* validated before anything is enqueued.  The chains' inputs must be        */
+/* complete in `stream` order when the call is made (the depth buffer, last  */
+/* frame's visibility words); their output buffers must differ.  The two     */
+/* side streams are created by the first call that needs them.               */
+/* ------------------------------------------------------------------------ */
+typedef struct OrbitClusterFrame { /* orbit_compute_clusters' arguments */
+    const OrbitMarkActivePush *push;
+    const OrbitClusterCullInfo *info;
+    const float *depth;
+    const OrbitLightData *lights;
+    uint32_t *tile_depth_slice_mask;
+    OrbitClusterDepthBounds *depth_bounds;
+    void *unique_cluster_buffer;
+    void *light_index_buffer;
+    uint32_t *cluster_offset_image;
+    uint32_t index_capacity;
+    uint32_t light_index_capacity;
+} OrbitClusterFrame;
+ORBIT_STATIC_ASSERT(sizeof(OrbitClusterFrame) == 80, "cluster frame block is 80 B");
+typedef struct OrbitFrameLate {
+    const OrbitDepthReduceItem *pyramids; /* chain A, first: the late views' pyramids (NULL / 0: none) */
+    const OrbitCullView *late_views;      /* chain A, then: the VisibilityWrite culls that read them */
+    const OrbitCullView *cascade_views;   /* chain B */
+    const OrbitClusterFrame *clusters;    /* chain C (NULL: none) */
+    uint32_t pyramid_count, late_view_count, cascade_view_count, _pad;
+} OrbitFrameLate;
+ORBIT_STATIC_ASSERT(sizeof(OrbitFrameLate) == 48, "frame-late descriptor is 48 B");
+int32_t orbit_frame_late(OrbitCtx *ctx, const OrbitFrameLate *frame, void *stream);
+
+/* ------------------------------------------------------------------------ */
 /* Measurement hook (bench.py).  While enabled, every orbit_meshlet_cull     */
 /* records a HIP event pair on the caller's stream around the op's dominant  */
 /* kernel (the streaming meshlet evaluation); profile_read waits for the     */
@@ -235,6 +289,9 @@ int32_t orbit_depth_reduce_multi(OrbitCtx *ctx, const OrbitDepthReduceItem *item
 /* prefetched), 0 switches the hook off.                                     */
 /* ------------------------------------------------------------------------ */
 int32_t orbit_ctx_profile(OrbitCtx *ctx, int32_t enable);
+/* The pairs are created on first use (a hipEventCreate and a first record each: host time inside the region that is
+ * being timed); _reserve creates `pairs` of them up front, each recorded once on `stream`. */
+int32_t orbit_ctx_profile_reserve(OrbitCtx *ctx, uint32_t pairs, void *stream);
 int32_t orbit_ctx_profile_read(OrbitCtx *ctx, float *avg_ms, uint32_t *launches);
 
 /* ------------------------------------------------------------------------ */

@@ -30,7 +30,8 @@ class OrbitError(RuntimeError):
 class Caps(C.Structure):
     _fields_ = [("max_entities", C.c_uint32), ("max_dispatches", C.c_uint32), ("max_draws", C.c_uint32),
                 ("max_lights", C.c_uint32), ("max_clusters", C.c_uint32), ("dispatch_size", C.c_uint32),
-                ("max_views", C.c_uint32), ("validate_streams", C.c_uint32), ("cull_path", C.c_uint32)]
+                ("max_views", C.c_uint32), ("validate_streams", C.c_uint32), ("cull_path", C.c_uint32),
+                ("arena_candidates", C.c_uint32), ("arith_profile", C.c_uint32)]
 
 
 class EntityCullBufs(C.Structure):
@@ -71,6 +72,20 @@ class DepthPyramidDesc(C.Structure):
                 ("mip_width", C.c_uint32 * MAX_PYRAMID_MIPS), ("mip_height", C.c_uint32 * MAX_PYRAMID_MIPS)]
 
 
+class ClusterFrame(C.Structure):  # OrbitClusterFrame
+    _fields_ = [("push", C.c_void_p), ("info", C.c_void_p), ("depth", C.c_void_p), ("lights", C.c_void_p),
+                ("tile_depth_slice_mask", C.c_void_p), ("depth_bounds", C.c_void_p), ("unique_cluster_buffer", C.c_void_p),
+                ("light_index_buffer", C.c_void_p), ("cluster_offset_image", C.c_void_p), ("index_capacity", C.c_uint32),
+                ("light_index_capacity", C.c_uint32)]
+
+
+class FrameLate(C.Structure):  # OrbitFrameLate
+    _fields_ = [("pyramids", C.POINTER(DepthReduceItem)), ("late_views", C.POINTER(CullView)),
+                ("cascade_views", C.POINTER(CullView)), ("clusters", C.POINTER(ClusterFrame)),
+                ("pyramid_count", C.c_uint32), ("late_view_count", C.c_uint32), ("cascade_view_count", C.c_uint32),
+                ("_pad", C.c_uint32)]
+
+
 # every symbol include/orbit_abi.h and orbit_abi_ext.h declare: (restype, argtypes)
 SYMBOLS = {
     "orbit_abi_version": (C.c_uint32, []),
@@ -79,6 +94,7 @@ SYMBOLS = {
     "orbit_exchange_list": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "orbit_ctx_fused_culls": (C.c_uint64, [C.c_void_p]),
+    "orbit_frame_late": (C.c_int32, [C.c_void_p, C.POINTER(FrameLate), C.c_void_p]),
     "orbit_default_caps": (None, [C.POINTER(Caps)]),
     "orbit_ctx_create": (C.c_int32, [C.c_int32, C.POINTER(Caps), C.POINTER(C.c_void_p)]),
     "orbit_ctx_destroy": (C.c_int32, [C.c_void_p]),
@@ -103,6 +119,7 @@ SYMBOLS = {
                                            C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
                                            C.c_void_p]),
     "orbit_ctx_profile": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "orbit_ctx_profile_reserve": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "orbit_ctx_profile_read": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "orbit_shard_range": (None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "orbit_gather_visible": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,

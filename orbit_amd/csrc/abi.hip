@@ -68,6 +68,8 @@ struct OrbitCtx {
     // scratch (device)
     uint8_t *arena = nullptr;
     size_t arena_bytes = 0;
+    float arena_probe_ms[8] = {}; // orbit_ctx_create's placement probe: time per candidate arena, which one was kept
+    uint32_t arena_probe_n = 0, arena_chosen = 0;
     OrbitMeshletDispatch *e_proto = nullptr;
     uint32_t *e_block_sums = nullptr, *e_total = nullptr;
     Payload *m_tile_payload = nullptr;
@@ -100,6 +102,8 @@ struct OrbitCtx {
     size_t prof_used = 0;
     // orbit_cull_views: child contexts (own scan scratch) for views 1.., created on first use
     std::vector<OrbitCtx *> view_ctx;
+    hipStream_t side_stream[2] = {nullptr, nullptr}; // orbit_frame_late: the chains beside the caller's stream
+    hipEvent_t side_event[3] = {nullptr, nullptr, nullptr}; // fork, join of chain B, join of chain C
     OrbitMeshletStream *meshlet_stream = nullptr; // orbit_ctx_bind_meshlet_stream
     uint64_t stream_culls = 0;                          // meshlet culls launched from it
     uint64_t class_culls = 0;                           // ... of which with its alpha classes
@@ -110,6 +114,19 @@ struct OrbitCtx {
 constexpr uint32_t kExpandBlocks = 65536;
 
 namespace {
+
+constexpr uint32_t kMaxArenaCandidates = 8;
+
+// orbit_ctx_create's placement probe: what the Meshlet-buffer evaluation stores per wave tile of 512 meshlets at 10 %
+// survivors — a run of ~51 payload entries at the head of the tile's 1536-B slot, 64 B of ballots, the count.
+__global__ __launch_bounds__(256) void arena_probe_kernel(Payload *payload, uint32_t *masks, uint32_t *counts, uint32_t tiles) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t t = blockIdx.x * 4u + wave; t < tiles; t += gridDim.x * 4u) {
+        if (lane < 51u) payload[(size_t)t * 128u + lane] = Payload{t, lane, 0u};
+        if (lane < 16u) masks[(size_t)t * 16u + lane] = lane;
+        if (lane == 0u) counts[t] = 51u;
+    }
+}
 
 thread_local char g_err[512] = "no error";
 
@@ -274,6 +291,8 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
                     "dispatch_size %u: only 32 keeps the reference's visibility-word addressing consistent "
                     "(src/graphics/device.rs:369-372)",
                     caps.dispatch_size);
+    if (caps.arith_profile > ORBIT_ARITH_CONTRACTED)
+        return fail(nullptr, ORBIT_E_INVALID, "arith_profile %u (0 canonical, 1 contracted)", caps.arith_profile);
     if (caps.max_dispatches > max_dispatch_capacity())
         return fail(nullptr, ORBIT_E_CAPACITY, "caps.max_dispatches %u > %u (chunk-base table of the emit launch)",
                     caps.max_dispatches, max_dispatch_capacity());
@@ -339,11 +358,56 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t o_aco = carve(agroups * 16 * aseg * 4), o_acl = carve(agroups * 16 * aseg * 16), o_acc = carve(agroups * 16 * 4), o_agb = carve(agroups * 32), o_ago = carve((agroups + 1) * 4);
     const size_t o_ahc = carve(((size_t)caps.max_clusters + kAssignPad) * kHitCache * 4);
     ctx->arena_bytes = off;
-    e = hipMalloc((void **)&ctx->arena, ctx->arena_bytes);
-    if (e != hipSuccess) {
-        delete ctx;
-        return hip_fail(nullptr, e, "hipMalloc(scratch arena)");
+    // Where the arena lands physically is worth 7 % of the Meshlet-buffer evaluation at BASELINE config 5 (its sparse
+    // payload runs: 311 us against 333-343 by process, profiles/r05_strict_path_placement.txt) — and the arena is THIS
+    // library's allocation: several candidates, a probe of that evaluation's write pattern against each (payload runs of
+    // ~50 x 12 B per 1536-B tile slot, 64 B of ballots, a count), the fastest kept, the rest freed (OrbitCaps.arena_candidates).
+    const size_t payload_bytes = mtiles * 128 * sizeof(Payload);
+    uint32_t ncand = caps.arena_candidates ? caps.arena_candidates : (payload_bytes > (32u << 20) ? 4u : 1u);
+    if (ncand > kMaxArenaCandidates) ncand = kMaxArenaCandidates;
+    uint8_t *cand[kMaxArenaCandidates] = {};
+    ctx->arena_probe_n = 0;
+    for (uint32_t c = 0; c < ncand; c++) {
+        e = hipMalloc((void **)&cand[c], ctx->arena_bytes);
+        if (e != hipSuccess) {
+            if (c == 0) {
+                delete ctx;
+                return hip_fail(nullptr, e, "hipMalloc(scratch arena)");
+            }
+            (void)hipGetLastError(); // fewer candidates than asked for is not an error
+            ncand = c;
+            break;
+        }
     }
+    uint32_t best = 0;
+    if (ncand > 1) {
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        bool timed = hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess;
+        const uint32_t tiles = (uint32_t)(mtiles - 1);
+        for (uint32_t c = 0; c < ncand && timed; c++) {
+            float best_ms = 1e30f;
+            for (int rep = 0; rep < 4 && timed; rep++) { // the first launch warms (page tables, code object): not counted
+                timed = hipEventRecord(ev[0], nullptr) == hipSuccess;
+                hipLaunchKernelGGL(arena_probe_kernel, dim3(ctx->num_cus * 8u), dim3(256), 0, nullptr,
+                                   (Payload *)(cand[c] + o_mtp), (uint32_t *)(cand[c] + o_mtm), (uint32_t *)(cand[c] + o_mtc), tiles);
+                timed = timed && hipGetLastError() == hipSuccess && hipEventRecord(ev[1], nullptr) == hipSuccess &&
+                        hipEventSynchronize(ev[1]) == hipSuccess;
+                float ms = 0.f;
+                timed = timed && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess;
+                if (rep > 0 && ms < best_ms) best_ms = ms;
+            }
+            ctx->arena_probe_ms[c] = best_ms;
+            ctx->arena_probe_n = c + 1;
+            if (best_ms < ctx->arena_probe_ms[best]) best = c;
+        }
+        if (!timed) best = 0; // (a probe that could not be timed decides nothing)
+        if (ev[0]) (void)hipEventDestroy(ev[0]);
+        if (ev[1]) (void)hipEventDestroy(ev[1]);
+    }
+    ctx->arena_chosen = best;
+    for (uint32_t c = 0; c < ncand; c++)
+        if (c != best) (void)hipFree(cand[c]);
+    ctx->arena = cand[best];
     e = memset_now(ctx->arena, 0, ctx->arena_bytes);
     if (e != hipSuccess) {
         (void)hipFree(ctx->arena);
@@ -403,7 +467,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
         return fail(nullptr, ORBIT_E_CAPACITY, "caps.max_views %u > %u", caps.max_views, (unsigned)ORBIT_MAX_CULL_VIEWS);
     }
     OrbitCaps child_caps = caps; // (a view's scratch: the culls' only — no cluster or light scratch, the bulk of a context's)
-    child_caps.max_views = 0, child_caps.max_clusters = 0, child_caps.max_lights = 0;
+    child_caps.max_views = 0, child_caps.max_clusters = 0, child_caps.max_lights = 0, child_caps.arena_candidates = 1;
     for (uint32_t v = 1; v < caps.max_views; v++) {
         OrbitCtx *child = nullptr;
         const int32_t rc = orbit_ctx_create(device_id, &child_caps, &child);
@@ -422,6 +486,10 @@ int32_t orbit_ctx_destroy(OrbitCtx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (hipEvent_t ev : ctx->prof_events) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->side_event)
+        if (ev) (void)hipEventDestroy(ev);
+    for (hipStream_t st : ctx->side_stream)
+        if (st) (void)hipStreamDestroy(st);
     for (OrbitCtx *child : ctx->view_ctx) (void)orbit_ctx_destroy(child);
     if (ctx->meshlet_stream) ctx->meshlet_stream->bindings.fetch_sub(1);
     if (ctx->arena) (void)hipFree(ctx->arena);
@@ -467,6 +535,24 @@ int32_t orbit_ctx_profile(OrbitCtx *ctx, int32_t enable) {
     ctx->profiling = enable > 0 ? (uint32_t)enable : 0u;
     ctx->prof_used = 0;
     ctx->prof_calls = 0;
+    return ORBIT_OK;
+}
+
+// The hook's event pairs are created on first use (hipEventCreate + an event's first record: tens of microseconds of
+// host time each) — a caller that times a region creates them BEFORE it: `pairs` pairs exist afterwards, each recorded
+// once on `stream`.
+int32_t orbit_ctx_profile_reserve(OrbitCtx *ctx, uint32_t pairs, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (pairs > 65536u) return fail(ctx, ORBIT_E_CAPACITY, "profile_reserve: %u pairs", pairs);
+    while (ctx->prof_events.size() < 2u * (size_t)pairs) {
+        hipEvent_t ev;
+        hipError_t e = hipEventCreate(&ev);
+        if (e != hipSuccess) return hip_fail(ctx, e, "hipEventCreate");
+        ctx->prof_events.push_back(ev);
+        e = hipEventRecord(ev, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(ctx, e, "hipEventRecord");
+    }
     return ORBIT_OK;
 }
 
@@ -518,6 +604,32 @@ int32_t orbit_debug_set_scan_patience(OrbitCtx *ctx, uint32_t polls) {
     if (!ctx) return ORBIT_E_INVALID;
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->scan_patience = polls;
+    return ORBIT_OK;
+}
+
+// measurement only (not part of the public ABI): orbit_ctx_create's placement probe — milliseconds per candidate arena
+// (out holds 8), how many were tried, which one was kept
+int32_t orbit_debug_arena_probe(const OrbitCtx *ctx, float *out_ms, uint32_t *out_n, uint32_t *out_chosen) {
+    if (!ctx || !out_ms || !out_n || !out_chosen) return ORBIT_E_INVALID;
+    for (uint32_t i = 0; i < 8; i++) out_ms[i] = ctx->arena_probe_ms[i];
+    *out_n = ctx->arena_probe_n;
+    *out_chosen = ctx->arena_chosen;
+    return ORBIT_OK;
+}
+
+// tests only (not part of the public ABI): cluster_mark's z slice through the hardware log2 with its guard band
+// (orbit_device.h depth_slice) against the canonical software form, for every float bit pattern in [lo_bits, hi_bits]:
+// out = {mismatches, samples decided by the canonical path, bits of the largest |v_log_f32 - log2c| seen}
+int32_t orbit_debug_log2_guard(OrbitCtx *ctx, uint32_t lo_bits, uint32_t hi_bits, float z_scale, float z_bias,
+                               unsigned long long out[3]) {
+    if (!ctx || !out || hi_bits < lo_bits) return ORBIT_E_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    unsigned long long *d = ctx->debug_cycles + 8;
+    if (hipMemset(d, 0, 24) != hipSuccess) return ORBIT_E_HIP;
+    if (launch_log2_guard_check(lo_bits, hi_bits, z_scale, z_bias, d, nullptr) != hipSuccess) return ORBIT_E_HIP;
+    if (hipDeviceSynchronize() != hipSuccess) return ORBIT_E_HIP;
+    if (hipMemcpy(out, d, 24, hipMemcpyDeviceToHost) != hipSuccess) return ORBIT_E_HIP;
+    if (hipMemset(d, 0, 24) != hipSuccess) return ORBIT_E_HIP;
     return ORBIT_OK;
 }
 
@@ -749,88 +861,121 @@ int32_t orbit_meshlet_cull(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbi
     return meshlet_cull_impl(ctx, ci, b, nullptr, false, stream);
 }
 
-int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t count, void *stream) {
-    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+} // extern "C"
+
+namespace {
+
+// One orbit_cull_views call, validated and laid out, not yet enqueued (orbit_frame_late validates all its groups before
+// it forks anything).  Scratch: view i runs on scratch set `scratch_base + i` (0 = the context itself, k = child k - 1).
+struct PreparedCullViews {
+    EntityCullViews ev{};
+    MeshletCullViews mv{};
+    FusedCullViews fv{};
+    uint32_t draws[ORBIT_MAX_CULL_VIEWS] = {};
+    uint32_t count = 0, n_mesh = 0, max_draws = 0;
+    bool fused = false;
+};
+
+OrbitCtx *scratch_of(OrbitCtx *ctx, uint32_t k) { return k == 0 ? ctx : ctx->view_ctx[k - 1]; }
+
+// Caller holds ctx->mu.  Allocates missing scratch sets (the only allocation an enqueue call can ever make).
+int32_t prepare_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t count, uint32_t scratch_base,
+                           PreparedCullViews &pc) {
     if (!views || count == 0) return fail(ctx, ORBIT_E_MISSING, "cull_views: no views");
-    if (count > ORBIT_MAX_CULL_VIEWS)
-        return fail(ctx, ORBIT_E_CAPACITY, "cull_views: %u views (max %u)", count, (unsigned)ORBIT_MAX_CULL_VIEWS);
-    hipStream_t s = (hipStream_t)stream;
+    if (count > ORBIT_MAX_CULL_VIEWS || scratch_base + count > ORBIT_MAX_CULL_VIEWS)
+        return fail(ctx, ORBIT_E_CAPACITY, "cull_views: %u views (max %u)", scratch_base + count, (unsigned)ORBIT_MAX_CULL_VIEWS);
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return hip_fail(ctx, e, "hipSetDevice");
     // scan scratch per view (views 1.. on child contexts), created once
-    while (ctx->view_ctx.size() + 1 < count) {
+    while (ctx->view_ctx.size() + 1 < scratch_base + count) {
         OrbitCtx *child = nullptr;
         OrbitCaps child_caps = ctx->caps;
-        child_caps.max_views = 0, child_caps.max_clusters = 0, child_caps.max_lights = 0;
+        child_caps.max_views = 0, child_caps.max_clusters = 0, child_caps.max_lights = 0, child_caps.arena_candidates = 1;
         const int32_t rc = orbit_ctx_create(ctx->device, &child_caps, &child);
         if (rc != ORBIT_OK) return fail(ctx, rc, "cull_views: scratch for view %zu: %s", ctx->view_ctx.size() + 1, g_err);
         ctx->view_ctx.push_back(child);
     }
     // every view's parameter block, validated before anything is enqueued; the blocks travel by value in the
     // kernels' argument segments (a few KB)
-    EntityCullViews ev{};
-    MeshletCullViews mv{};
-    uint32_t max_draws = 0, n_mesh = 0;
+    pc.count = count;
     for (uint32_t i = 0; i < count; i++) {
         const OrbitCullView &v = views[i];
-        OrbitCtx *scratch = i == 0 ? ctx : ctx->view_ctx[i - 1];
-        int32_t rc = entity_cull_params(ctx, scratch, v.cull_info, &v.entity, 0u, v.entity_draw_count, false, ev.v[i]);
+        OrbitCtx *scratch = scratch_of(ctx, scratch_base + i);
+        int32_t rc = entity_cull_params(ctx, scratch, v.cull_info, &v.entity, 0u, v.entity_draw_count, false, pc.ev.v[i]);
         if (rc == ORBIT_OK && !v.skip_meshlet_stage) {
-            rc = meshlet_cull_params(ctx, scratch, v.cull_info, &v.meshlet, nullptr, false, nullptr, 0, false, mv.v[n_mesh]);
+            rc = meshlet_cull_params(ctx, scratch, v.cull_info, &v.meshlet, nullptr, false, nullptr, 0, false, pc.mv.v[pc.n_mesh]);
             if (rc == ORBIT_OK && v.meshlet.meshlet_dispatch_buffer != v.entity.meshlet_dispatch_buffer)
                 rc = fail(ctx, ORBIT_E_INVALID, "view %u: the meshlet stage must read the entity stage's dispatch buffer", i);
-            n_mesh++;
+            pc.n_mesh++;
         }
         if (rc != ORBIT_OK) return rc;
-        max_draws = v.entity_draw_count > max_draws ? v.entity_draw_count : max_draws;
+        pc.max_draws = v.entity_draw_count > pc.max_draws ? v.entity_draw_count : pc.max_draws;
     }
     // Views of the reference's own size (src/scene.rs:303, assets/mod.rs:202) are bound by launch latency, not by
     // bytes: all of them together as ONE launch per (pass, projection) (cull_fused.hip) — same outputs.  It evaluates
     // the 32-B Meshlet buffer whatever stream is bound (the survivors' command words are then in the row registers).
     // (a context that validates its stream on every cull keeps the chain: the one launch never reads the stream, and
     // the validation and ORBIT_E_RANGE are what such a context exists for)
-    bool fused = ctx->caps.cull_path != 1u && n_mesh == count && !(ctx->caps.validate_streams != 0u && ctx->meshlet_stream != nullptr);
+    bool fused = ctx->caps.cull_path != 1u && pc.n_mesh == count && !(ctx->caps.validate_streams != 0u && ctx->meshlet_stream != nullptr);
     for (uint32_t i = 0; i < count && fused; i++)
         fused = views[i].entity_draw_count != 0u &&
                 (ctx->caps.cull_path == 2u || views[i].entity_draw_count <= kFusedMaxEntityDraws);
+    pc.fused = fused;
     if (fused) {
-        FusedCullViews fv{};
-        uint32_t draws[ORBIT_MAX_CULL_VIEWS] = {};
         for (uint32_t i = 0; i < count; i++) {
-            OrbitCtx *scratch = i == 0 ? ctx : ctx->view_ctx[i - 1];
-            FusedCullParams &f = fv.v[i];
-            f.m = mv.v[i];
+            OrbitCtx *scratch = scratch_of(ctx, scratch_base + i);
+            FusedCullParams &f = pc.fv.v[i];
+            f.m = pc.mv.v[i];
             f.m.ms = MeshletStreamView{};
-            f.entity_draw_buffer = ev.v[i].entity_draw_buffer;
-            f.mesh_infos = ev.v[i].mesh_infos;
-            f.mesh_side = ev.v[i].mesh_side;
-            f.visibility = ev.v[i].visibility;
-            f.e_pyr = ev.v[i].pyr;
-            f.draw_first = ev.v[i].draw_first;
-            f.draw_limit = ev.v[i].draw_limit;
-            f.e_dispatch_capacity = ev.v[i].dispatch_capacity;
+            f.entity_draw_buffer = pc.ev.v[i].entity_draw_buffer;
+            f.mesh_infos = pc.ev.v[i].mesh_infos;
+            f.mesh_side = pc.ev.v[i].mesh_side;
+            f.visibility = pc.ev.v[i].visibility;
+            f.e_pyr = pc.ev.v[i].pyr;
+            f.draw_first = pc.ev.v[i].draw_first;
+            f.draw_limit = pc.ev.v[i].draw_limit;
+            f.e_dispatch_capacity = pc.ev.v[i].dispatch_capacity;
             f.ne_chunks = (views[i].entity_draw_count + 255u) / 256u;
-            f.e_total = ev.v[i].total;
+            f.e_total = pc.ev.v[i].total;
             f.sync = scratch->f_sync;
             f.ent_flags = scratch->f_ent_flags;
             f.tile_flags = scratch->f_tile_flags;
-            draws[i] = views[i].entity_draw_count;
+            pc.draws[i] = views[i].entity_draw_count;
         }
-        e = launch_cull_fused_views(fv, draws, count, ctx->num_cus, s);
+    }
+    return ORBIT_OK;
+}
+
+int32_t launch_prepared_cull_views(OrbitCtx *ctx, const PreparedCullViews &pc, hipStream_t s) {
+    hipError_t e;
+    if (pc.fused) {
+        e = launch_cull_fused_views(pc.fv, pc.draws, pc.count, ctx->num_cus, s);
         if (e != hipSuccess) return hip_fail(ctx, e, "launch cull_fused");
-        ctx->fused_culls += count;
+        ctx->fused_culls += pc.count;
         return ORBIT_OK;
     }
-    e = launch_entity_cull_views(ev, count, max_draws, ctx->num_cus, s);
-    if (e == hipSuccess) e = launch_meshlet_cull_views(mv, n_mesh, ctx->num_cus, s);
+    e = launch_entity_cull_views(pc.ev, pc.count, pc.max_draws, ctx->num_cus, s);
+    if (e == hipSuccess) e = launch_meshlet_cull_views(pc.mv, pc.n_mesh, ctx->num_cus, s);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch cull_views");
-    for (uint32_t i = 0; i < n_mesh; i++)
-        if (mv.v[i].ms.sphere && mv.v[i].ci.occlusion_pass != 1) {
+    for (uint32_t i = 0; i < pc.n_mesh; i++)
+        if (pc.mv.v[i].ms.sphere && pc.mv.v[i].ci.occlusion_pass != 1) {
             ctx->stream_culls++;
-            if (mv.v[i].ms.cls0) ctx->class_culls++;
+            if (pc.mv.v[i].ms.cls0) ctx->class_culls++;
         }
     return ORBIT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t orbit_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t count, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    PreparedCullViews pc;
+    const int32_t rc = prepare_cull_views(ctx, views, count, 0u, pc);
+    if (rc != ORBIT_OK) return rc;
+    return launch_prepared_cull_views(ctx, pc, (hipStream_t)stream);
 }
 
 int32_t orbit_meshlet_stream_create(OrbitCtx *ctx, uint64_t first_meshlet, uint64_t capacity,
@@ -1221,15 +1366,14 @@ int32_t orbit_depth_pyramid_desc_from_mip0(uint32_t w0, uint32_t h0, OrbitDepthP
     return ORBIT_OK;
 }
 
-int32_t orbit_depth_reduce_multi(OrbitCtx *ctx, const OrbitDepthReduceItem *items, uint32_t count, void *stream) {
-    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+// Validates a batch of pyramids and fills the launch's parameter block (ctx->mu held; nothing is enqueued).
+static int32_t prepare_depth_reduce(OrbitCtx *ctx, const OrbitDepthReduceItem *items, uint32_t count, DepthReduceBatch &b) {
     if (!items || count == 0) return fail(ctx, ORBIT_E_MISSING, "depth_reduce: no items");
     if (count > ORBIT_MAX_PYRAMID_BATCH)
         return fail(ctx, ORBIT_E_CAPACITY, "depth_reduce: %u pyramids in one batch (max %u)", count,
                     (unsigned)ORBIT_MAX_PYRAMID_BATCH);
     static_assert(ORBIT_MAX_PYRAMID_BATCH == kMaxPyramidBatch, "batch size");
-    DepthReduceBatch b{};
+    b = DepthReduceBatch{};
     b.count = count;
     b.tickets = ctx->d_tickets;
     for (uint32_t i = 0; i < count; i++) {
@@ -1263,6 +1407,15 @@ int32_t orbit_depth_reduce_multi(OrbitCtx *ctx, const OrbitDepthReduceItem *item
             }
         }
     }
+    return ORBIT_OK;
+}
+
+int32_t orbit_depth_reduce_multi(OrbitCtx *ctx, const OrbitDepthReduceItem *items, uint32_t count, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DepthReduceBatch b;
+    const int32_t rc = prepare_depth_reduce(ctx, items, count, b);
+    if (rc != ORBIT_OK) return rc;
     const hipError_t e = launch_depth_reduce(b, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch depth_reduce");
     return ORBIT_OK;
@@ -1413,26 +1566,34 @@ int32_t orbit_cluster_assign(OrbitCtx *ctx, const OrbitClusterCullInfo *info, co
                                  light_index_capacity, cluster_offset_image, 0u, stream);
 }
 
-int32_t orbit_compute_clusters(OrbitCtx *ctx, const OrbitMarkActivePush *push, const OrbitClusterCullInfo *info,
-                               const float *depth, const OrbitLightData *lights, uint32_t *tile_depth_slice_mask,
-                               OrbitClusterDepthBounds *depth_bounds, void *unique_cluster_buffer,
-                               uint32_t index_capacity, void *light_index_buffer, uint32_t light_index_capacity,
-                               uint32_t *cluster_offset_image, void *stream) {
-    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+// Everything orbit_compute_clusters would refuse, refused before its first launch (ctx->mu held): the mark launch leaves
+// the compaction's chunk counts behind, and only the assignment's first launch clears them again.
+static int32_t compute_clusters_check(OrbitCtx *ctx, const OrbitMarkActivePush *push, const OrbitClusterCullInfo *info,
+                                      const float *depth, const OrbitLightData *lights, uint32_t *tile_depth_slice_mask,
+                                      OrbitClusterDepthBounds *depth_bounds, void *unique_cluster_buffer,
+                                      void *light_index_buffer, uint32_t *cluster_offset_image) {
     if (!push || !info) return fail(ctx, ORBIT_E_MISSING, "compute_clusters: NULL parameter block");
     for (int i = 0; i < 3; i++)
         if (push->cluster_count[i] != info->cluster_count[i])
             return fail(ctx, ORBIT_E_INVALID, "compute_clusters: cluster_count[%d] differs between push (%u) and info (%u)",
                         i, push->cluster_count[i], info->cluster_count[i]);
-    // Everything the later stages would refuse is refused before the first launch: the mark launch leaves the
-    // compaction's chunk counts behind, and only the assignment's first launch clears them again.
+    if (!depth || !tile_depth_slice_mask || !depth_bounds) return fail(ctx, ORBIT_E_MISSING, "cluster_mark: NULL argument");
+    if (push->cluster_count[2] > 32 || push->tile_size_px == 0 || push->depth_buffer_sample_count == 0)
+        return fail(ctx, ORBIT_E_INVALID, "cluster_mark: z slices %u (> 32), tile %u or samples %u invalid",
+                    push->cluster_count[2], push->tile_size_px, push->depth_buffer_sample_count);
     int32_t rc = cluster_compact_check(ctx, push->cluster_count, tile_depth_slice_mask, unique_cluster_buffer);
     if (rc == ORBIT_OK)
         rc = cluster_assign_check(ctx, info, unique_cluster_buffer, depth_bounds, lights, light_index_buffer, cluster_offset_image);
-    if (rc != ORBIT_OK) return rc;
+    return rc;
+}
+
+static int32_t compute_clusters_launch(OrbitCtx *ctx, const OrbitMarkActivePush *push, const OrbitClusterCullInfo *info,
+                                       const float *depth, const OrbitLightData *lights, uint32_t *tile_depth_slice_mask,
+                                       OrbitClusterDepthBounds *depth_bounds, void *unique_cluster_buffer,
+                                       uint32_t index_capacity, void *light_index_buffer, uint32_t light_index_capacity,
+                                       uint32_t *cluster_offset_image, void *stream) {
     // stream order is the only dependency between the stages (cluster.rs:380-395)
-    rc = cluster_mark_locked(ctx, push, depth, tile_depth_slice_mask, depth_bounds, true, stream);
+    int32_t rc = cluster_mark_locked(ctx, push, depth, tile_depth_slice_mask, depth_bounds, true, stream);
     if (rc != ORBIT_OK) return rc; // (refused before its launch: nothing was counted)
     const uint32_t tiles = push->cluster_count[0] * push->cluster_count[1];
     const uint32_t count_words = push->cluster_count[2] * ((tiles + 1023u) / 1024u);
@@ -1443,6 +1604,117 @@ int32_t orbit_compute_clusters(OrbitCtx *ctx, const OrbitMarkActivePush *push, c
                                    light_index_capacity, cluster_offset_image, count_words, stream);
     if (rc != ORBIT_OK) // a launch failed behind the counting mark: the words must not stay
         (void)hipMemsetAsync(ctx->c_chunk + ctx->c_chunk_words, 0, (size_t)count_words * 4u, (hipStream_t)stream);
+    return rc;
+}
+
+int32_t orbit_compute_clusters(OrbitCtx *ctx, const OrbitMarkActivePush *push, const OrbitClusterCullInfo *info,
+                               const float *depth, const OrbitLightData *lights, uint32_t *tile_depth_slice_mask,
+                               OrbitClusterDepthBounds *depth_bounds, void *unique_cluster_buffer,
+                               uint32_t index_capacity, void *light_index_buffer, uint32_t light_index_capacity,
+                               uint32_t *cluster_offset_image, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    const int32_t rc = compute_clusters_check(ctx, push, info, depth, lights, tile_depth_slice_mask, depth_bounds,
+                                              unique_cluster_buffer, light_index_buffer, cluster_offset_image);
+    if (rc != ORBIT_OK) return rc;
+    return compute_clusters_launch(ctx, push, info, depth, lights, tile_depth_slice_mask, depth_bounds, unique_cluster_buffer,
+                                   index_capacity, light_index_buffer, light_index_capacity, cluster_offset_image, stream);
+}
+
+// The late half of a frame — everything the renderer records between "the depth buffer exists" and the forward pass
+// (src/app.rs:1151-1212: the late cull of render_depth_prepass, render_shadows' cascade culls, compute_clusters) — as ONE
+// call whose independent chains run side by side: {pyramids -> pass-2 culls} on the caller's stream, {cascade culls} and
+// {compute_clusters} on two streams of the context, forked behind what the caller had enqueued and joined before the call
+// returns control of the stream (events only: capturable).  Each chain is a handful of dependent latency-bound launches on
+// a device that is 95 % idle during any one of them; serially they cost their sum, side by side the longest.
+int32_t orbit_frame_late(OrbitCtx *ctx, const OrbitFrameLate *f, void *stream) {
+    if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!f) return fail(ctx, ORBIT_E_MISSING, "frame_late: NULL descriptor");
+    if (f->late_view_count + f->cascade_view_count > ORBIT_MAX_CULL_VIEWS)
+        return fail(ctx, ORBIT_E_CAPACITY, "frame_late: %u views (max %u)", f->late_view_count + f->cascade_view_count,
+                    (unsigned)ORBIT_MAX_CULL_VIEWS);
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipSetDevice");
+    // everything is validated (and every scratch set exists) before anything is enqueued or forked
+    DepthReduceBatch pyr;
+    PreparedCullViews late, casc;
+    int32_t rc = ORBIT_OK;
+    if (f->pyramid_count) rc = prepare_depth_reduce(ctx, f->pyramids, f->pyramid_count, pyr);
+    if (rc == ORBIT_OK && f->late_view_count) rc = prepare_cull_views(ctx, f->late_views, f->late_view_count, 0u, late);
+    if (rc == ORBIT_OK && f->cascade_view_count)
+        rc = prepare_cull_views(ctx, f->cascade_views, f->cascade_view_count, f->late_view_count, casc);
+    const OrbitClusterFrame *c = f->clusters;
+    if (rc == ORBIT_OK && c)
+        rc = compute_clusters_check(ctx, c->push, c->info, c->depth, c->lights, c->tile_depth_slice_mask, c->depth_bounds,
+                                    c->unique_cluster_buffer, c->light_index_buffer, c->cluster_offset_image);
+    if (rc != ORBIT_OK) return rc;
+    const bool chain_a = f->pyramid_count || f->late_view_count, chain_b = f->cascade_view_count != 0, chain_c = c != nullptr;
+    // the side streams and the four events: created by the first call that forks (never while anything is enqueued)
+    if ((chain_b || chain_c) && !ctx->side_stream[0]) {
+        for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipStreamCreateWithFlags(&ctx->side_stream[i], hipStreamNonBlocking);
+        for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->side_event[i], hipEventDisableTiming);
+        if (e != hipSuccess) return hip_fail(ctx, e, "frame_late: side streams");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    // The LONGEST chain stays on the caller's stream: a forked chain starts a fork's latency late (the side stream waits
+    // for an event of `s`: a cross-queue dependency, ~5 us) and its join is a wait in `s` — both are hidden only behind
+    // work `s` itself still has.  Measured on configs 3 + 4 as a replayed graph: the cluster chain (59 us alone) forked
+    // beside {pyramid, late cull} on `s` took 76 us; on `s` with the others forked, what the chain itself takes.  Weight =
+    // dependent launches of the chain.
+    const uint32_t w_a = (f->pyramid_count ? 1u : 0u) + (f->late_view_count ? (late.fused ? 1u : 5u) : 0u);
+    const uint32_t w_b = chain_b ? (casc.fused ? 1u : 5u) : 0u, w_c = chain_c ? 6u : 0u;
+    hipStream_t sa = s, sb = s, sc = s;
+    {
+        const uint32_t heaviest = (w_c >= w_a && w_c >= w_b) ? 2u : (w_a >= w_b ? 0u : 1u);
+        int side = 0;
+        if (chain_a && heaviest != 0u) sa = ctx->side_stream[side++];
+        if (chain_b && heaviest != 1u) sb = ctx->side_stream[side++];
+        if (chain_c && heaviest != 2u) sc = ctx->side_stream[side++];
+    }
+    const bool fork_a = chain_a && sa != s, fork_b = chain_b && sb != s, fork_c = chain_c && sc != s;
+    if (fork_a || fork_b || fork_c) {
+        e = hipEventRecord(ctx->side_event[0], s);
+        if (e == hipSuccess && fork_a) e = hipStreamWaitEvent(sa, ctx->side_event[0], 0);
+        if (e == hipSuccess && fork_b) e = hipStreamWaitEvent(sb, ctx->side_event[0], 0);
+        if (e == hipSuccess && fork_c) e = hipStreamWaitEvent(sc, ctx->side_event[0], 0);
+        if (e != hipSuccess) return hip_fail(ctx, e, "frame_late: fork");
+    }
+    // Enqueue order.  Eagerly the call is bound by the HOST (fourteen launches and seven event operations are ~45 us of
+    // enqueueing for chains of 36 and 60 us): the forked chains go first — they run while the host still enqueues the
+    // long one — 80.8 us for configs 3 + 4 against 89.0 the other way round and 89.6 serially.  While the stream is being
+    // CAPTURED the order only decides which branch the graph runs on the launch stream, and that should be the long one:
+    // replayed, 81.6 us against 93.3 (profiles/r06_notes.md, all four arrangements).
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &capture) == hipSuccess && capture != hipStreamCaptureStatusNone;
+    auto run_a = [&]() -> int32_t {
+        if (f->pyramid_count) {
+            const hipError_t le = launch_depth_reduce(pyr, sa);
+            if (le != hipSuccess) return hip_fail(ctx, le, "launch depth_reduce");
+        }
+        return f->late_view_count ? launch_prepared_cull_views(ctx, late, sa) : ORBIT_OK;
+    };
+    auto run_b = [&]() -> int32_t { return launch_prepared_cull_views(ctx, casc, sb); };
+    auto run_c = [&]() -> int32_t {
+        return compute_clusters_launch(ctx, c->push, c->info, c->depth, c->lights, c->tile_depth_slice_mask, c->depth_bounds,
+                                       c->unique_cluster_buffer, c->index_capacity, c->light_index_buffer,
+                                       c->light_index_capacity, c->cluster_offset_image, sc);
+    };
+    for (int pass = 0; pass < 2 && rc == ORBIT_OK; pass++) {
+        const bool forked_now = capturing ? pass == 1 : pass == 0; // eager: forked chains first; captured: the one on `s` first
+        if (rc == ORBIT_OK && chain_a && fork_a == forked_now) rc = run_a();
+        if (rc == ORBIT_OK && chain_b && fork_b == forked_now) rc = run_b();
+        if (rc == ORBIT_OK && chain_c && fork_c == forked_now) rc = run_c();
+    }
+    // join — also behind a launch error: a forked stream must come back (a capture would otherwise be left unjoined)
+    int ev = 1;
+    for (hipStream_t side : {fork_a ? sa : nullptr, fork_b ? sb : nullptr, fork_c ? sc : nullptr}) {
+        if (!side) continue;
+        e = hipEventRecord(ctx->side_event[ev], side);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, ctx->side_event[ev], 0);
+        if (e != hipSuccess && rc == ORBIT_OK) rc = hip_fail(ctx, e, "frame_late: join");
+        ev++;
+    }
     return rc;
 }
 

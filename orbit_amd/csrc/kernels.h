@@ -351,6 +351,8 @@ struct ExchangeListParams {
 hipError_t launch_exchange_list(const ExchangeListParams &p, uint32_t num_cus, hipStream_t s);
 hipError_t launch_depth_reduce(const DepthReduceBatch &b, hipStream_t s);
 hipError_t launch_cluster_mark(const ClusterMarkParams &p, hipStream_t s);
+// tests: the hardware-log2 slice against the canonical one for every float in [lo, hi] (bit patterns); out: 3 x u64
+hipError_t launch_log2_guard_check(uint32_t lo, uint32_t hi, float z_scale, float z_bias, unsigned long long *out, hipStream_t s);
 hipError_t launch_cluster_compact(const ClusterCompactParams &p, hipStream_t s);
 hipError_t launch_cluster_assign(const ClusterAssignParams &p, uint32_t num_cus, hipStream_t s);
 

@@ -80,8 +80,9 @@ __global__ __launch_bounds__(kMarkWaves * 64) void cluster_mark_kernel(const Clu
             uint32_t slice = 0xFFFFFFFFu, bmin = 0, bmax = 0, bit = 0;
             if (valid) {
                 const float linear_z = pc.z_near / d;                       // :28
-                // cluster_common.glsl:18-20 as compiled (mark_active.comp.spv): one fused operation
-                slice = f2u_sat(__builtin_fmaf(log2c(linear_z), pc.z_scale, pc.z_bias));
+                // cluster_common.glsl:18-20 as compiled (mark_active.comp.spv): one fused operation — through the
+                // hardware log2 where that provably gives the canonical slice (orbit_device.h depth_slice)
+                slice = depth_slice(linear_z, pc.z_scale, pc.z_bias);
                 bit = shl1(slice);                                          // :30
                 const float inv = 1.0f - d;                                 // :33
                 // the sign / payload of a NaN produced by arithmetic is implementation-defined: canonical quiet NaN
@@ -1110,7 +1111,36 @@ void cluster_assign_kernel(const ClusterAssignParams p, uint32_t place_blocks) {
 // header for an empty active list: light_count = 0 (cluster.rs:575-581)
 __global__ void write_word(uint32_t *p, uint32_t v) { *p = v; }
 
+// orbit_debug_log2_guard (tests): depth_slice against depth_slice_canonical for EVERY float bit pattern in [lo, hi] —
+// out[0] = mismatches, out[1] = samples the canonical path decided, out[2] = bits of the largest
+// |v_log_f32 - log2c| / (1 + |log2c|) over the positive normal inputs (the guard band's premise: < 2^-22)
+__global__ __launch_bounds__(256) void log2_guard_kernel(uint32_t lo, uint32_t hi, float z_scale, float z_bias,
+                                                         unsigned long long *out) {
+    unsigned long long bad = 0, slow = 0;
+    float worst = 0.0f;
+    const uint64_t n = (uint64_t)hi - lo + 1u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
+        const float x = __uint_as_float(lo + (uint32_t)i);
+        const uint32_t a = depth_slice(x, z_scale, z_bias), b = depth_slice_canonical(x, z_scale, z_bias);
+        bad += a != b ? 1u : 0u;
+        const float L = __builtin_amdgcn_logf(x);
+        slow += depth_slice_safe(x, L, __builtin_fmaf(L, z_scale, z_bias), z_scale) ? 0u : 1u;
+        if (x >= 0x1p-126f && x < __builtin_inff()) {
+            const float c = log2c(x);
+            worst = fmaxf(worst, __builtin_fabsf(L - c) / (1.0f + __builtin_fabsf(c)));
+        }
+    }
+    atomicAdd(out + 0, bad);
+    atomicAdd(out + 1, slow);
+    atomicMax(reinterpret_cast<unsigned int *>(out + 2), __float_as_uint(worst));
+}
+
 } // namespace
+
+hipError_t launch_log2_guard_check(uint32_t lo, uint32_t hi, float z_scale, float z_bias, unsigned long long *out, hipStream_t s) {
+    hipLaunchKernelGGL(log2_guard_kernel, dim3(256 * 16), dim3(256), 0, s, lo, hi, z_scale, z_bias, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_cluster_mark(const ClusterMarkParams &p, hipStream_t s) {
     const uint32_t tiles = p.pc.cluster_count[0] * p.pc.cluster_count[1];

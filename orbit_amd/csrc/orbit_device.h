@@ -79,6 +79,37 @@ __device__ __forceinline__ float log2c(float x) {
     return r + (float)e;
 }
 
+// cluster_common.glsl:18-20 as compiled (mark_active.comp.spv: one fused operation): the canonical z slice of a depth
+// sample, uint(fma(log2c(linear_z), z_scale, z_bias)).
+__device__ __forceinline__ uint32_t depth_slice_canonical(float linear_z, float z_scale, float z_bias) {
+    return f2u_sat(__builtin_fmaf(log2c(linear_z), z_scale, z_bias));
+}
+// The same integer from the HARDWARE log2 (v_log_f32, one instruction instead of log2c's thirty) wherever that cannot
+// differ.  v_log_f32 and log2c both approximate log2: over every positive normal float they lie within 2^-22 (1 + |log2 x|)
+// of each other (measured, not assumed: orbit_debug_log2_guard runs all of them; the test holds the library to it), so the
+// two fused results t = fma(L, z_scale, z_bias) differ by at most |z_scale| 2^-22 (1 + |L|) plus one rounding of t — and a
+// t further than `guard` (twice that) from every integer truncates to the same slice either way.  Inside the band (about one
+// sample in ten thousand at the renderer's grids), for denormal / non-finite / negative inputs and for huge t the canonical
+// form decides: the result is the canonical one BY CONSTRUCTION, the band only has to be wide enough.
+__device__ __forceinline__ bool depth_slice_safe(float linear_z, float L, float t, float z_scale) {
+    const float guard = __builtin_fmaf(__builtin_fabsf(z_scale) * (1.0f + __builtin_fabsf(L)), 0x1p-21f,
+                                       __builtin_fmaf(__builtin_fabsf(t), 0x1p-22f, 0x1p-21f));
+    const float off = __builtin_fabsf(t - __builtin_rintf(t));
+    // (every comparison is false for a NaN: NaN takes the canonical path)
+    return off > guard && __builtin_fabsf(t) < 0x1p20f && linear_z >= 0x1p-126f && linear_z < __builtin_inff();
+}
+__device__ __forceinline__ uint32_t depth_slice(float linear_z, float z_scale, float z_bias) {
+    const float L = __builtin_amdgcn_logf(linear_z);
+    const float t = __builtin_fmaf(L, z_scale, z_bias);
+    const bool safe = depth_slice_safe(linear_z, L, t, z_scale);
+    uint32_t slice = f2u_sat(t);
+    if (__ballot(!safe) != 0ull) { // wave-uniform: a wave without a lane in the band never runs the polynomial
+        const uint32_t canonical = depth_slice_canonical(linear_z, z_scale, z_bias);
+        slice = safe ? slice : canonical;
+    }
+    return slice;
+}
+
 // int(i8) / 127.0 (meshlet_cull.comp:121-122) AS COMPILED: the reference's shader binaries multiply by the rounded
 // reciprocal (meshlet_cull.comp.spv, OpFMul by 0x3C010204 — spirv-opt's reciprocal folding); 16 of the 256 inputs
 // differ from the IEEE quotient by one ulp, and the oracle follows the binary (oracle/orbit_oracle.c snorm8).

@@ -172,9 +172,21 @@ class Engine:
         """Raises OrbitError for a device-latched condition (capacity overflow, timeout)."""
         _lib.check(self._lib.orbit_ctx_status(self._ctx, _stream(stream), 1 if sync else 0), self._ctx)
 
+    def arena_probe(self):
+        """orbit_ctx_create's placement probe (measurement only): (ms per candidate arena, index of the one kept)."""
+        ms, n, chosen = (C.c_float * 8)(), C.c_uint32(), C.c_uint32()
+        self._lib.orbit_debug_arena_probe.restype = C.c_int32
+        self._lib.orbit_debug_arena_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.check(self._lib.orbit_debug_arena_probe(self._ctx, ms, C.byref(n), C.byref(chosen)), self._ctx)
+        return [float(v) for v in ms[:n.value]], int(chosen.value)
+
     def profile(self, enable=True, every=1):
         """HIP-event timing of the dominant kernel of meshlet_cull (measurement hook); every n-th call is timed."""
         _lib.check(self._lib.orbit_ctx_profile(self._ctx, int(every) if enable else 0), self._ctx)
+
+    def profile_reserve(self, pairs, stream=None):
+        """orbit_ctx_profile_reserve: the hook's event pairs created (and recorded once on `stream`) before a timed region."""
+        _lib.check(self._lib.orbit_ctx_profile_reserve(self._ctx, int(pairs), _stream(stream)), self._ctx)
 
     def profile_read(self):
         ms, n = C.c_float(), C.c_uint32()
@@ -301,6 +313,11 @@ class Engine:
         """orbit_depth_reduce_multi (update_multiple_depth_pyramids::<C>, draw_gen.rs:569-628): one launch pair for up
         to 8 pyramids.  items: dicts with depth, width, height and either pyramid (packed chain) or levels (list of
         (tensor-or-pointer, row_pitch) per mip: separate per-mip images); optional depth_row_pitch."""
+        arr, keep = self.prepare_depth_reduce_items(items)
+        _lib.check(self._lib.orbit_depth_reduce_multi(self._ctx, arr, len(items), _stream(stream)), self._ctx)
+
+    def prepare_depth_reduce_items(self, items):
+        """-> (ctypes OrbitDepthReduceItem array, objects that must outlive it); items as for depth_reduce_multi."""
         arr = (_lib.DepthReduceItem * len(items))()
         keep = []
         for it, a in zip(items, arr):
@@ -314,7 +331,41 @@ class Engine:
                     l.texels, l.row_pitch = _ptr(t), pitch
                 keep.append(lv)
                 a.levels = lv
-        _lib.check(self._lib.orbit_depth_reduce_multi(self._ctx, arr, len(items), _stream(stream)), self._ctx)
+        return arr, keep
+
+    def prepare_frame_late(self, pyramids=(), late_views=(), cascade_views=(), clusters=None):
+        """orbit_frame_late's descriptor, built once (a per-frame caller keeps it): `pyramids` as for depth_reduce_multi,
+        `late_views` / `cascade_views` as for cull_views, `clusters` a dict with compute_clusters' arguments (push, info,
+        depth, lights, tile_depth_slice_mask, depth_bounds, unique_cluster_buffer, index_capacity, light_index_buffer,
+        light_index_capacity, cluster_offset_image).  -> (descriptor, objects that must outlive it)."""
+        f, keep = _lib.FrameLate(), []
+        if pyramids:
+            arr, k = self.prepare_depth_reduce_items(list(pyramids))
+            f.pyramids, f.pyramid_count = arr, len(arr)
+            keep += [arr, k]
+        for name, views in (("late_views", late_views), ("cascade_views", cascade_views)):
+            if views:
+                arr, k = self.prepare_views(list(views))
+                setattr(f, name, arr)
+                setattr(f, name[:-1] + "_count", len(arr))
+                keep += [arr, k]
+        if clusters is not None:
+            c = _lib.ClusterFrame()
+            pc = _host_bytes(clusters["push"], layouts.MARK_ACTIVE_PUSH.itemsize).copy()
+            ib = _host_bytes(clusters["info"], layouts.CLUSTER_CULL_INFO.itemsize).copy()
+            c.push, c.info = pc.ctypes.data, ib.ctypes.data
+            for k in ("depth", "lights", "tile_depth_slice_mask", "depth_bounds", "unique_cluster_buffer",
+                      "light_index_buffer", "cluster_offset_image"):
+                setattr(c, k, _ptr(clusters.get(k)))
+            c.index_capacity, c.light_index_capacity = clusters["index_capacity"], clusters["light_index_capacity"]
+            f.clusters = C.pointer(c)
+            keep += [c, pc, ib]
+        return f, keep
+
+    def frame_late(self, frame, stream=None):
+        """orbit_frame_late on a descriptor of prepare_frame_late: {pyramids -> late culls} || {cascade culls} ||
+        {compute_clusters}, forked behind `stream` and joined into it."""
+        _lib.check(self._lib.orbit_frame_late(self._ctx, C.byref(frame), _stream(stream)), self._ctx)
 
     def meshlet_cull_visible_records(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, record_buffer,
                                      entity_buffer, material_buffer, dispatch_capacity, record_capacity, **kw):

@@ -46,7 +46,9 @@ def test_bench_line_has_the_contract_fields(source):
     assert ("derived meshlet streams" in d["config"]["meshlet_source"]) == (source == "stream")
     p8 = d["protocol_8d"]  # SURVEY.md §8d literally: Meshlet buffer, 5 warm-ups, >= 20 event-timed steps, median
     assert p8["warmup"] == 5 and p8["steps"] >= 20 and p8["ms_per_step_min"] <= p8["ms_per_step_median"] <= p8["ms_per_step_max"]
-    assert d["config"]["warmup_effective"] >= d["config"]["settle_frames"] + d["warmup"] + 25
+    # every frame the process ran before the timed region: eight cold ones, the settle's (5 ms here), the W asked for
+    assert d["config"]["warmup_effective"] == 8 + d["config"]["settle_frames"] + d["warmup"] and d["config"]["settle_frames"] >= 8
+    assert d["config"]["settle_with"] == "frames" and d["config"]["ms_per_step_without_settle"] > 0
     assert len(d["roofline"]["library_sha256"]) == 64 and d["roofline"]["traffic_current"] is None
     tp = d["two_pass"]  # config 5's two-pass frame as the secondary figure
     assert tp["frame_ms_min"] <= tp["frame_ms"] <= tp["frame_ms_max"] and tp["meshlets_per_sec"] > 0
@@ -95,8 +97,12 @@ def test_bench_at_the_world_size_north_star_names_on_one_device(world, transport
     own command buffer and the cross-rank checksum; --verify-single-rank additionally holds the gathered list against ONE
     rank culling the whole scene (from the Meshlet buffer: another evaluation path), and the other transport's leg must
     deliver the same bytes."""
+    # (--runtime-warm-frames 48: with the all-gather as the MAIN transport every step of this one-device configuration
+    # stages its segments through gloo and the host — a thousand settle frames of that are ten minutes, and no number of
+    # this run is a measurement)
     d = _run_ranks(["--gpus", str(world), "--entities", "24000", "--transport", transport, "--verify-single-rank",
-                    "--cpu-sample-entities", "0"], dict(ORBIT_BENCH_ONE_DEVICE="1", ORBIT_BENCH_BACKEND="gloo"))
+                    "--cpu-sample-entities", "0", "--runtime-warm-frames", "48"],
+                   dict(ORBIT_BENCH_ONE_DEVICE="1", ORBIT_BENCH_BACKEND="gloo"))
     c = d["config"]
     assert d["n_gpus"] == world and c["world_size"] == world and c["transport"] == transport and c["transport_fallback"] is None
     assert c["signalling"] == ("device" if transport == "p2p" else "rccl-allgather")

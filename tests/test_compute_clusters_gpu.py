@@ -187,3 +187,31 @@ def test_one_wave_and_four_wave_items_alternate_in_one_workgroup(torch_mod, engi
         _poison(b)
         _call(engine, s, b)
         _check(torch, engine, s, b, f"repetition {rep}")
+
+
+def test_hardware_log2_slice_equals_the_canonical_slice_for_every_float(torch_mod, engine, oracle):
+    """cluster_mark takes a sample's z slice from v_log_f32 wherever that cannot differ from the canonical software log2
+    (orbit_amd/csrc/orbit_device.h depth_slice: outside a guard band around the integers of the fused result, normal finite
+    positive inputs only) and from the canonical form otherwise.  "Cannot differ" is checked, not assumed: every float bit
+    pattern — all 2^32, sign, denormals, infinities and NaNs included — through both forms on the device, for the grids'
+    (z_scale, z_bias) of the tests and a few hostile ones: zero mismatches, and the hardware form really is the one used
+    (the canonical path decides < 1 % of the finite positive inputs)."""
+    import ctypes as C
+
+    lib = engine._lib
+    lib.orbit_debug_log2_guard.restype = C.c_int32
+    lib.orbit_debug_log2_guard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p]
+    grids = [oracle.cluster_grid_info(0.01, 200.0, 32), oracle.cluster_grid_info(0.01, 200.0, 16),
+             oracle.cluster_grid_info(0.1, 1000.0, 24), oracle.cluster_grid_info(0.01, 200.0, 8),
+             (31.75, -3.0), (-2.5, 40.0), (1e-3, 0.5), (0.0, 7.0)]
+    for zs, zb in grids:
+        out = (C.c_uint64 * 3)()
+        assert lib.orbit_debug_log2_guard(engine._ctx, 0, 0xFFFFFFFF, float(zs), float(zb), out) == 0
+        assert out[0] == 0, f"z_scale {zs}, z_bias {zb}: {out[0]} floats get another slice from the hardware log2"
+        worst = np.array([out[2] & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0]
+        assert worst < 2.0 ** -22, f"|v_log_f32 - log2c| / (1 + |log2c|) reaches {worst}: the guard band's premise"
+    # positive normal inputs only: how often the canonical path has to decide (the band + |t| >= 2^20)
+    zs, zb = grids[0]
+    out = (C.c_uint64 * 3)()
+    assert lib.orbit_debug_log2_guard(engine._ctx, 0x00800000, 0x7F7FFFFF, float(zs), float(zb), out) == 0
+    assert out[0] == 0 and out[1] < 0.01 * (0x7F7FFFFF - 0x00800000), out[1]

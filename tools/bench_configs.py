@@ -362,6 +362,83 @@ def main():
                           "cores": 1, "kind": "port", "sample": "the whole workload, one run of oracle/orbit_oracle.c (scalar, one thread)"}
     out["config4"] = c4
     eng.close()
+
+    # ---------------------------------------------------------------- the frame: configs 3 + 4 together
+    # What the renderer records per frame around these passes (src/app.rs:1151-1212): the early cull, then — once the depth
+    # buffer exists — the pyramid + the late cull, the four cascade culls, compute_clusters.  Serially on one stream, and
+    # through orbit_frame_late (the three late chains side by side on streams of the context).
+    from orbit_amd import passes
+
+    engf = Engine(0, max_entities=8192, max_dispatches=40_000, max_draws=200_000, max_lights=12_000, max_clusters=total,
+                  max_views=5)
+    evis, mvis = dev(ev0), dev(mv0)
+    ev_keep, mv_keep = evis.clone(), mvis.clone()
+    pyr = torch.zeros(d.total_texels, dtype=torch.float32, device="cuda")
+    v1, disp1, draw1 = g3.view(ci1, evis, mvis)
+    v2, disp2, draw2 = g3.view(ci2, evis, mvis, pyr, ps)
+    casc = []
+    for k in range(4):
+        hci, _, _ = passes.shadow_cascade(direction=(-0.45, 0.2, 0.1, 0.86), camera_position=(0.0, 2.0, 0.0),
+                                          camera_orientation=(0.0, 0.0, 0.0, 1.0), camera_fov=float(cam.fov),
+                                          camera_near_clip=cam.z_near, camera_aspect_ratio=cam.aspect, cascade_index=k,
+                                          max_shadow_distance=80.0)
+        casc.append(g3.view(passes.cull_info_to_gpu(hci)))
+    a1, k1 = engf.prepare_views([v1])
+    a2, k2 = engf.prepare_views([v2])
+    ac, kc = engf.prepare_views([v for v, _, _ in casc])
+    pyramids = [dict(depth=gdepth, width=W, height=H, pyramid=pyr)]
+    clusters = dict(push=push, info=info, depth=gdepth, lights=glights, tile_depth_slice_mask=gm, depth_bounds=gb,
+                    unique_cluster_buffer=gu, index_capacity=cap, light_index_buffer=gl, light_index_capacity=lcap,
+                    cluster_offset_image=gimg)
+    f_late, kf = engf.prepare_frame_late(pyramids=pyramids, late_views=[v2], clusters=clusters)
+    f_all, kfa = engf.prepare_frame_late(pyramids=pyramids, late_views=[v2], cascade_views=[v for v, _, _ in casc], clusters=clusters)
+
+    def reset():
+        evis.copy_(ev_keep)
+        mvis.copy_(mv_keep)
+
+    def late_serial(cascades):
+        engf.depth_reduce(gdepth, W, H, pyr)
+        engf.cull_views_prepared(a2)
+        if cascades:
+            engf.cull_views_prepared(ac)
+        engf.compute_clusters(push, info, gdepth, glights, gm, gb, gu, cap, gl, lcap, gimg)
+
+    variants = {
+        "late_serial": lambda: (reset(), late_serial(False)),
+        "late_overlapped": lambda: (reset(), engf.frame_late(f_late)),
+        "late_with_cascades_serial": lambda: (reset(), late_serial(True)),
+        "late_with_cascades_overlapped": lambda: (reset(), engf.frame_late(f_all)),
+        "frame_serial": lambda: (reset(), engf.cull_views_prepared(a1), late_serial(False)),
+        "frame_overlapped": lambda: (reset(), engf.cull_views_prepared(a1), engf.frame_late(f_late)),
+        "frame_with_cascades_serial": lambda: (reset(), engf.cull_views_prepared(a1), late_serial(True)),
+        "frame_with_cascades_overlapped": lambda: (reset(), engf.cull_views_prepared(a1), engf.frame_late(f_all)),
+    }
+    reset_ms = timeit(reset)
+    fr = {"what": "configs 3 + 4 as one frame (src/app.rs:1151-1212): early cull, then the late half — pyramid + late cull, "
+                  "[the four cascade culls,] compute_clusters — serially on one stream and through orbit_frame_late (the "
+                  "chains side by side on streams of the context, forked and joined by events); HIP-event median of 20, "
+                  "the bits' reset subtracted", "bits_reset_ms_subtracted": reset_ms, "ms": {}, "graph_replay_ms": {}}
+    for name, fn in variants.items():
+        fr["ms"][name] = timeit(fn) - reset_ms
+        gr = graph_of(fn)
+        fr["graph_replay_ms"][name] = timeit(gr.replay) - reset_ms
+        del gr
+    # the overlapped frame's outputs against the oracle (the serial ones were checked above, config by config)
+    variants["frame_with_cascades_overlapped"]()
+    torch.cuda.synchronize()
+    engf.status()
+    act = ou[16:16 + 4 * n_active].view(np.uint32)
+    fr["gpu_output_bit_identical"] = bool(
+        same(host(disp1), host(draw1), od1, ow1) and same(host(disp2), host(draw2), od2, ow2)
+        and np.array_equal(host(evis, np.uint32), oe2) and np.array_equal(host(mvis, np.uint32), om2)
+        and np.array_equal(host(pyr, np.uint32), opyr.view(np.uint32).reshape(-1))
+        and np.array_equal(host(gm, np.uint32), om) and np.array_equal(host(gb, np.uint32).reshape(-1, 2), ob)
+        and np.array_equal(host(gu)[:16 + 4 * n_active], ou[:16 + 4 * n_active])
+        and np.array_equal(host(gl)[:4 + 4 * n_idx], ol[:4 + 4 * n_idx])
+        and np.array_equal(host(gimg, np.uint32).reshape(-1, 2)[act], oimg[act]))
+    out["frame_configs_3_and_4"] = fr
+    engf.close()
     print(json.dumps(out, indent=1))
 
 

@@ -26,6 +26,36 @@ N = int(os.environ.get("N", 800))
 evs = [torch.cuda.Event(enable_timing=True) for _ in range(N + 1)]
 torch.cuda.synchronize()
 time.sleep(float(os.environ.get("PRE_SLEEP_MS", 0)) / 1e3)
+# PRE_LAUNCHES=n: n tiny launches (+ an event record every eighth) before the frames — does the one long stall of the
+# process depend on how many submissions it has made (then this pre-pays it), or on the frames' own work?
+pre = int(os.environ.get("PRE_LAUNCHES", 0))
+if pre:
+    tiny = torch.zeros(64, device=dev)
+    pe = torch.cuda.Event()
+    tp0 = time.perf_counter()
+    gaps = []
+    last = tp0
+    for i in range(pre):
+        tiny.add_(1.0)
+        if i % 8 == 0:
+            pe.record()
+        now = time.perf_counter()
+        if now - last > 2e-3:
+            gaps.append((i, (now - last) * 1e3))
+        last = now
+    torch.cuda.synchronize()
+    print(f"pre-launches {pre}: {(time.perf_counter() - tp0) * 1e3:.1f} ms; host gaps > 2 ms: {[(i, round(g, 1)) for i, g in gaps]}")
+# EVENTS_PER_FRAME (default 1; 0: host time stamps only, 2: two new timing events per frame), REUSE_EVENT=1: the SAME
+# timing event re-recorded every frame, PRE_EVENTS=n: n timing events created and recorded once before the frames —
+# which of these moves the stall?
+epf = int(os.environ.get("EVENTS_PER_FRAME", 1))
+reuse = os.environ.get("REUSE_EVENT") == "1"
+pre_events = [torch.cuda.Event(enable_timing=True) for _ in range(int(os.environ.get("PRE_EVENTS", 0)))]
+for ev in pre_events:
+    ev.record()
+torch.cuda.synchronize()
+extra = [torch.cuda.Event(enable_timing=True) for _ in range(N + 1)] if epf == 2 else None
+one = torch.cuda.Event(enable_timing=True)
 t_host = []
 evs[0].record()
 sync_at = {int(x) for x in os.environ.get("SYNC_AT", "").split(",") if x}
@@ -34,9 +64,23 @@ for i in range(N):
         torch.cuda.synchronize()
     eng.entity_cull(ci, draws, mesh, disp, ent, E, disp_cap)
     eng.meshlet_cull(ci, disp, meshlets, draw, ent, materials, disp_cap, draw_cap, material_count=spec.materials)
-    evs[i + 1].record()
+    if reuse:
+        one.record()
+    elif epf >= 1:
+        evs[i + 1].record()
+        if epf == 2:
+            extra[i].record()
     t_host.append(time.perf_counter())
+if reuse or epf == 0:
+    evs[N].record()
 torch.cuda.synchronize()
+if reuse or epf == 0:
+    th = (np.array(t_host) - t_host[0]) * 1e3
+    print(f"N {N}: device total {evs[0].elapsed_time(evs[N]):.1f} ms; host enqueue total {th[-1]:.1f} ms (no per-frame events)")
+    hgap = np.diff(th)
+    for j in np.nonzero(hgap > 2.0)[0][:20]:
+        print(f"  host gap between enqueues: {hgap[j]:.2f} ms after frame {j} (host time {th[j]:.1f} ms)")
+    sys.exit(0)
 dt = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(N)])
 cum = np.cumsum(dt)
 th = (np.array(t_host) - t_host[0]) * 1e3
