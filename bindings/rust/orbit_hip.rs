@@ -17,7 +17,7 @@ pub struct OrbitMeshletStream { _private: [u8; 0] }
 pub struct OrbitCaps {
     pub max_entities: u32, pub max_dispatches: u32, pub max_draws: u32, pub max_lights: u32,
     pub max_clusters: u32, pub dispatch_size: u32, pub max_views: u32, pub validate_streams: u32, pub cull_path: u32,
-    pub arena_candidates: u32, pub arith_profile: u32,
+    pub arith_profile: u32,
 }
 
 /// orbit_compute_clusters' arguments as a block (orbit_frame_late)

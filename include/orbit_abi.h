@@ -358,20 +358,13 @@ typedef struct OrbitCaps {
                                   call with a view of 0 entity-draws or skip_meshlet_stage runs the chain under every
                                   setting, as does a context with validate_streams and a bound stream.  Same outputs
                                   either way; tests and A/B timings set it. */
-    uint32_t arena_candidates; /* the context's scratch arena (the survivor payload the Meshlet-buffer evaluation writes,
-                                  ballots, counts) is ONE device allocation, and where it lands physically is worth 7 %
-                                  of that evaluation at BASELINE config 5 (311 against 333-343 us by process,
-                                  profiles/r05_strict_path_placement.txt).  orbit_ctx_create therefore allocates this
-                                  many candidate arenas (0 = the default: 4 when the payload region exceeds 32 MB, else
-                                  1; at most 8), times a probe of the evaluation's write pattern against each, keeps
-                                  the fastest and frees the rest — a few milliseconds, once.  1 = take the first. */
     uint32_t arith_profile;    /* ORBIT_ARITH_*: how the points SPIR-V leaves to a driver's compiler are decided
                                   (DESIGN.md section 2).  0 = canonical: no contraction, the shared software log2 —
                                   the oracle's and the committed vectors' choice.  1 = contracted: dot products, plane
                                   tests, the projected bounds and the cone test fused the way a driver's compiler
                                   contracts them, hardware log2; pinned by tests/golden/spirv_cull_contracted.npz. */
 } OrbitCaps;
-ORBIT_STATIC_ASSERT(sizeof(OrbitCaps) == 44, "OrbitCaps layout");
+ORBIT_STATIC_ASSERT(sizeof(OrbitCaps) == 40, "OrbitCaps layout");
 #define ORBIT_ARITH_CANONICAL 0u
 #define ORBIT_ARITH_CONTRACTED 1u
 

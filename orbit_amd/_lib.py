@@ -31,7 +31,7 @@ class Caps(C.Structure):
     _fields_ = [("max_entities", C.c_uint32), ("max_dispatches", C.c_uint32), ("max_draws", C.c_uint32),
                 ("max_lights", C.c_uint32), ("max_clusters", C.c_uint32), ("dispatch_size", C.c_uint32),
                 ("max_views", C.c_uint32), ("validate_streams", C.c_uint32), ("cull_path", C.c_uint32),
-                ("arena_candidates", C.c_uint32), ("arith_profile", C.c_uint32)]
+                ("arith_profile", C.c_uint32)]
 
 
 class EntityCullBufs(C.Structure):

@@ -68,8 +68,6 @@ struct OrbitCtx {
     // scratch (device)
     uint8_t *arena = nullptr;
     size_t arena_bytes = 0;
-    float arena_probe_ms[8] = {}; // orbit_ctx_create's placement probe: time per candidate arena, which one was kept
-    uint32_t arena_probe_n = 0, arena_chosen = 0;
     OrbitMeshletDispatch *e_proto = nullptr;
     uint32_t *e_block_sums = nullptr, *e_total = nullptr;
     Payload *m_tile_payload = nullptr;
@@ -114,19 +112,6 @@ struct OrbitCtx {
 constexpr uint32_t kExpandBlocks = 65536;
 
 namespace {
-
-constexpr uint32_t kMaxArenaCandidates = 8;
-
-// orbit_ctx_create's placement probe: what the Meshlet-buffer evaluation stores per wave tile of 512 meshlets at 10 %
-// survivors — a run of ~51 payload entries at the head of the tile's 1536-B slot, 64 B of ballots, the count.
-__global__ __launch_bounds__(256) void arena_probe_kernel(Payload *payload, uint32_t *masks, uint32_t *counts, uint32_t tiles) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t t = blockIdx.x * 4u + wave; t < tiles; t += gridDim.x * 4u) {
-        if (lane < 51u) payload[(size_t)t * 128u + lane] = Payload{t, lane, 0u};
-        if (lane < 16u) masks[(size_t)t * 16u + lane] = lane;
-        if (lane == 0u) counts[t] = 51u;
-    }
-}
 
 thread_local char g_err[512] = "no error";
 
@@ -358,56 +343,16 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t o_aco = carve(agroups * 16 * aseg * 4), o_acl = carve(agroups * 16 * aseg * 16), o_acc = carve(agroups * 16 * 4), o_agb = carve(agroups * 32), o_ago = carve((agroups + 1) * 4);
     const size_t o_ahc = carve(((size_t)caps.max_clusters + kAssignPad) * kHitCache * 4);
     ctx->arena_bytes = off;
-    // Where the arena lands physically is worth 7 % of the Meshlet-buffer evaluation at BASELINE config 5 (its sparse
-    // payload runs: 311 us against 333-343 by process, profiles/r05_strict_path_placement.txt) — and the arena is THIS
-    // library's allocation: several candidates, a probe of that evaluation's write pattern against each (payload runs of
-    // ~50 x 12 B per 1536-B tile slot, 64 B of ballots, a count), the fastest kept, the rest freed (OrbitCaps.arena_candidates).
-    const size_t payload_bytes = mtiles * 128 * sizeof(Payload);
-    uint32_t ncand = caps.arena_candidates ? caps.arena_candidates : (payload_bytes > (32u << 20) ? 4u : 1u);
-    if (ncand > kMaxArenaCandidates) ncand = kMaxArenaCandidates;
-    uint8_t *cand[kMaxArenaCandidates] = {};
-    ctx->arena_probe_n = 0;
-    for (uint32_t c = 0; c < ncand; c++) {
-        e = hipMalloc((void **)&cand[c], ctx->arena_bytes);
-        if (e != hipSuccess) {
-            if (c == 0) {
-                delete ctx;
-                return hip_fail(nullptr, e, "hipMalloc(scratch arena)");
-            }
-            (void)hipGetLastError(); // fewer candidates than asked for is not an error
-            ncand = c;
-            break;
-        }
+    // (Where the arena lands physically was suspected of the Meshlet-buffer evaluation's two speeds, 311 against 333-343 us
+    // by process at BASELINE config 5.  Round 6 allocated four candidate arenas here and timed a probe of that
+    // evaluation's write pattern against each: the probe does not tell them apart — 14.3-14.9 us on all — and engines on
+    // probed and unprobed arenas ran the same 328-353 us; five engines alive on one buffer 348-352: the spread is between
+    // boxes and processes, not between arenas of a process.  Removed; profiles/r06_notes.md.)
+    e = hipMalloc((void **)&ctx->arena, ctx->arena_bytes);
+    if (e != hipSuccess) {
+        delete ctx;
+        return hip_fail(nullptr, e, "hipMalloc(scratch arena)");
     }
-    uint32_t best = 0;
-    if (ncand > 1) {
-        hipEvent_t ev[2] = {nullptr, nullptr};
-        bool timed = hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess;
-        const uint32_t tiles = (uint32_t)(mtiles - 1);
-        for (uint32_t c = 0; c < ncand && timed; c++) {
-            float best_ms = 1e30f;
-            for (int rep = 0; rep < 4 && timed; rep++) { // the first launch warms (page tables, code object): not counted
-                timed = hipEventRecord(ev[0], nullptr) == hipSuccess;
-                hipLaunchKernelGGL(arena_probe_kernel, dim3(ctx->num_cus * 8u), dim3(256), 0, nullptr,
-                                   (Payload *)(cand[c] + o_mtp), (uint32_t *)(cand[c] + o_mtm), (uint32_t *)(cand[c] + o_mtc), tiles);
-                timed = timed && hipGetLastError() == hipSuccess && hipEventRecord(ev[1], nullptr) == hipSuccess &&
-                        hipEventSynchronize(ev[1]) == hipSuccess;
-                float ms = 0.f;
-                timed = timed && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess;
-                if (rep > 0 && ms < best_ms) best_ms = ms;
-            }
-            ctx->arena_probe_ms[c] = best_ms;
-            ctx->arena_probe_n = c + 1;
-            if (best_ms < ctx->arena_probe_ms[best]) best = c;
-        }
-        if (!timed) best = 0; // (a probe that could not be timed decides nothing)
-        if (ev[0]) (void)hipEventDestroy(ev[0]);
-        if (ev[1]) (void)hipEventDestroy(ev[1]);
-    }
-    ctx->arena_chosen = best;
-    for (uint32_t c = 0; c < ncand; c++)
-        if (c != best) (void)hipFree(cand[c]);
-    ctx->arena = cand[best];
     e = memset_now(ctx->arena, 0, ctx->arena_bytes);
     if (e != hipSuccess) {
         (void)hipFree(ctx->arena);
@@ -467,7 +412,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
         return fail(nullptr, ORBIT_E_CAPACITY, "caps.max_views %u > %u", caps.max_views, (unsigned)ORBIT_MAX_CULL_VIEWS);
     }
     OrbitCaps child_caps = caps; // (a view's scratch: the culls' only — no cluster or light scratch, the bulk of a context's)
-    child_caps.max_views = 0, child_caps.max_clusters = 0, child_caps.max_lights = 0, child_caps.arena_candidates = 1;
+    child_caps.max_views = 0, child_caps.max_clusters = 0, child_caps.max_lights = 0;
     for (uint32_t v = 1; v < caps.max_views; v++) {
         OrbitCtx *child = nullptr;
         const int32_t rc = orbit_ctx_create(device_id, &child_caps, &child);
@@ -604,16 +549,6 @@ int32_t orbit_debug_set_scan_patience(OrbitCtx *ctx, uint32_t polls) {
     if (!ctx) return ORBIT_E_INVALID;
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->scan_patience = polls;
-    return ORBIT_OK;
-}
-
-// measurement only (not part of the public ABI): orbit_ctx_create's placement probe — milliseconds per candidate arena
-// (out holds 8), how many were tried, which one was kept
-int32_t orbit_debug_arena_probe(const OrbitCtx *ctx, float *out_ms, uint32_t *out_n, uint32_t *out_chosen) {
-    if (!ctx || !out_ms || !out_n || !out_chosen) return ORBIT_E_INVALID;
-    for (uint32_t i = 0; i < 8; i++) out_ms[i] = ctx->arena_probe_ms[i];
-    *out_n = ctx->arena_probe_n;
-    *out_chosen = ctx->arena_chosen;
     return ORBIT_OK;
 }
 
@@ -890,7 +825,7 @@ int32_t prepare_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t c
     while (ctx->view_ctx.size() + 1 < scratch_base + count) {
         OrbitCtx *child = nullptr;
         OrbitCaps child_caps = ctx->caps;
-        child_caps.max_views = 0, child_caps.max_clusters = 0, child_caps.max_lights = 0, child_caps.arena_candidates = 1;
+        child_caps.max_views = 0, child_caps.max_clusters = 0, child_caps.max_lights = 0;
         const int32_t rc = orbit_ctx_create(ctx->device, &child_caps, &child);
         if (rc != ORBIT_OK) return fail(ctx, rc, "cull_views: scratch for view %zu: %s", ctx->view_ctx.size() + 1, g_err);
         ctx->view_ctx.push_back(child);

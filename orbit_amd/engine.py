@@ -172,14 +172,6 @@ class Engine:
         """Raises OrbitError for a device-latched condition (capacity overflow, timeout)."""
         _lib.check(self._lib.orbit_ctx_status(self._ctx, _stream(stream), 1 if sync else 0), self._ctx)
 
-    def arena_probe(self):
-        """orbit_ctx_create's placement probe (measurement only): (ms per candidate arena, index of the one kept)."""
-        ms, n, chosen = (C.c_float * 8)(), C.c_uint32(), C.c_uint32()
-        self._lib.orbit_debug_arena_probe.restype = C.c_int32
-        self._lib.orbit_debug_arena_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        _lib.check(self._lib.orbit_debug_arena_probe(self._ctx, ms, C.byref(n), C.byref(chosen)), self._ctx)
-        return [float(v) for v in ms[:n.value]], int(chosen.value)
-
     def profile(self, enable=True, every=1):
         """HIP-event timing of the dominant kernel of meshlet_cull (measurement hook); every n-th call is timed."""
         _lib.check(self._lib.orbit_ctx_profile(self._ctx, int(every) if enable else 0), self._ctx)

@@ -54,7 +54,7 @@ def test_header_compiles_as_c_and_cxx(tmp_path):
 
 def test_ctypes_mirrors_match_header_sizes():
     # the sizes below are the ORBIT_STATIC_ASSERTs of the header
-    assert C.sizeof(_lib.Caps) == 44
+    assert C.sizeof(_lib.Caps) == 40
     assert C.sizeof(_lib.EntityCullBufs) == 6 * 8 + 16 + 8   # + depth_pyramid_levels (ABI version 2)
     assert C.sizeof(_lib.MeshletCullBufs) == 7 * 8 + 24 + 8
     assert C.sizeof(_lib.DepthPyramidLevel) == 16 and C.sizeof(_lib.DepthReduceItem) == 40
