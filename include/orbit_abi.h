@@ -59,7 +59,7 @@ extern "C" {
 #define ORBIT_MAX_MESH_LODS 8    /* shaders/include/types.glsl:4 */
 /* The only dispatch size for which the reference's visibility-word addressing
  * is self-consistent (src/graphics/device.rs:369-372). */
-#define ORBIT_MESHLET_DISPATCH_SIZE 32u
+#define ORBIT_MESHLET_DISPATCH_SIZE 32u /* the default of OrbitCaps.dispatch_size */
 #define ORBIT_MAX_LIGHTS_PER_CLUSTER 256u /* light_culling.comp:135 */
 
 enum {
@@ -344,7 +344,21 @@ typedef struct OrbitCaps {
     uint32_t max_draws;      /* draw_gen.rs:15 MAX_DRAW_COUNT       = 1_000_000 */
     uint32_t max_lights;     /* scene.rs:304   MAX_LIGHT_COUNT      = 2_000     */
     uint32_t max_clusters;   /* tiles_x * tiles_y * max(4, z_slices): cluster.rs:53-56 */
-    uint32_t dispatch_size;  /* spec constant 0 of both cull shaders; must be 32 */
+    uint32_t dispatch_size;  /* MESHLET_DISPATCH_SIZE, spec constant 0 of both cull shaders, which the reference derives
+                                from the device (src/graphics/device.rs:369-372; the shaders' own default is 64,
+                                entity_cull.comp:26): 32 (default), 64 or 128.  32 is the one value for which the
+                                reference is consistent throughout and serves everything.  With 64 / 128,
+                                orbit_entity_cull writes records of up to that many meshlets (entity_cull.comp:210-223)
+                                and orbit_meshlet_cull / orbit_cull_views / orbit_frame_late consume them — the command
+                                list is the same as with 32, as the reference's binaries' is
+                                (tests/golden/spirv_cull_dispatch_sizes.npz) — for OCCLUSION PASS 0.  Refused there, with
+                                ORBIT_E_INVALID and the reason: passes 1 / 2 (an entity owns ceil(meshlets / 32)
+                                visibility words, src/scene.rs:427, but a record's word offset advances by
+                                meshlet_count / S, entity_cull.comp:222, and the ballots are S bits wide), the
+                                mesh-shading path (MeshTaskPayload.meshlet_indices has 32 entries whatever S is,
+                                types.glsl:196-200) and the sharded engine (one 32-bit ballot per list entry).
+                                caps.max_dispatches counts the caller's records; the scratch is sized for S / 32 times
+                                as many records of 32. */
     uint32_t max_views;      /* orbit_cull_views: scan scratch for this many views is allocated at context creation
                                 (0: for one view; more is then allocated on the first call that needs it — the only
                                 allocation an enqueue call can ever make) */

@@ -95,6 +95,22 @@ def hiz_sample(pyr, w0, h0, u, v, lod):
     return float(lib().oracle_hiz_sample(_p(pyr), w0, h0, C.c_float(u), C.c_float(v), C.c_float(lod)))
 
 
+class dispatch_size:
+    """`with oracle.dispatch_size(64): ...` — MESHLET_DISPATCH_SIZE of the cull shaders for the calls inside (pass 0 of
+    entity_cull / meshlet_cull only; 32 outside)."""
+
+    def __init__(self, s):
+        self.s = int(s)
+
+    def __enter__(self):
+        lib().oracle_set_dispatch_size(C.c_uint32(self.s))
+        return self
+
+    def __exit__(self, *exc):
+        lib().oracle_set_dispatch_size(C.c_uint32(32))
+        return False
+
+
 def entity_cull(cull_info, entity_draw_buffer, entity_draw_count, mesh_infos, entities, dispatch_capacity,
                 visibility=None, pyramid=None, pyramid_size=(0, 0), draw_first=None):
     """Returns (dispatch_buffer bytes, visibility words (copy, updated in pass 2), dropped).

@@ -85,6 +85,8 @@ struct OrbitCtx {
     uint32_t *m_tickets = nullptr, *m_list_sync = nullptr, *f_done = nullptr;
     uint32_t *f_sync = nullptr, *f_ent_flags = nullptr, *f_tile_flags = nullptr; // one-launch cull (cull_fused.hip)
     uint32_t *d_tickets = nullptr; // depth_reduce: one arrival counter per pyramid of a batch
+    uint8_t *m_split = nullptr;    // dispatch_size 64 / 128: the caller's records as records of 32 (entity_cull.hip split_records_body)
+    uint32_t rec_shift = 5;        // log2 of caps.dispatch_size
     uint64_t fused_culls = 0;                                                    // views culled by it so far
     uint64_t shard_culls = 0;                                                    // orbit_cull_shard calls that took ONE launch
     uint32_t *g_counts = nullptr; // gather_visible: per-rank command counts
@@ -271,11 +273,15 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     OrbitCaps caps;
     if (caps_in) caps = *caps_in;
     else orbit_default_caps(&caps);
-    if (caps.dispatch_size != ORBIT_MESHLET_DISPATCH_SIZE)
-        return fail(nullptr, ORBIT_E_INVALID,
-                    "dispatch_size %u: only 32 keeps the reference's visibility-word addressing consistent "
-                    "(src/graphics/device.rs:369-372)",
+    if (caps.dispatch_size != 32u && caps.dispatch_size != 64u && caps.dispatch_size != 128u)
+        return fail(nullptr, ORBIT_E_INVALID, "dispatch_size %u: 32, 64 or 128 (src/graphics/device.rs:369-372)",
                     caps.dispatch_size);
+    const uint32_t rec_shift = caps.dispatch_size == 32u ? 5u : caps.dispatch_size == 64u ? 6u : 7u;
+    // the meshlet stage works on records of 32 whatever the caller's records hold: its scratch is sized for those
+    const uint64_t md32 = (uint64_t)caps.max_dispatches << (rec_shift - 5u);
+    if (md32 > max_dispatch_capacity())
+        return fail(nullptr, ORBIT_E_CAPACITY, "caps.max_dispatches %u x dispatch_size %u / 32 > %u (chunk-base table of the emit launch)",
+                    caps.max_dispatches, caps.dispatch_size, max_dispatch_capacity());
     if (caps.arith_profile > ORBIT_ARITH_CONTRACTED)
         return fail(nullptr, ORBIT_E_INVALID, "arith_profile %u (0 canonical, 1 contracted)", caps.arith_profile);
     if (caps.max_dispatches > max_dispatch_capacity())
@@ -303,7 +309,7 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
 
     // one arena for all scan scratch, carved at 256-B alignment
     const size_t ent = align_up((size_t)caps.max_entities, 256);
-    const size_t mtiles = ((size_t)caps.max_dispatches + kTileRecords - 1) / kTileRecords + 1;
+    const size_t mtiles = ((size_t)md32 + kTileRecords - 1) / kTileRecords + 1;
     const size_t cchunks = ((size_t)caps.max_clusters / 1024 + 64) * 32;
     size_t off = 0;
     auto carve = [&](size_t bytes) {
@@ -323,7 +329,8 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     const size_t o_eproto = carve(ent * sizeof(OrbitMeshletDispatch));
     const size_t o_ebs = carve((ent / 256 + 1) * 4), o_et = carve(256);
     const size_t o_mtc = carve(mtiles * 4), o_mtb = carve(mtiles * 4), o_mt = carve(256);
-    const size_t o_ftf = carve(((size_t)caps.max_dispatches / 4 + 2) * 4); // one flag per tile of 4 records (cull_fused.hip)
+    const size_t o_ftf = carve(((size_t)md32 / 4 + 2) * 4); // one flag per tile of 4 records (cull_fused.hip)
+    const size_t o_split = carve(rec_shift > 5u ? ORBIT_DISPATCH_HEADER + 16 * (size_t)md32 : 0); // dispatch_size 64 / 128
     const size_t o_xbp = carve((size_t)kExpandBlocks * 4);
     const size_t o_mtm = carve(mtiles * 64);
     const size_t o_mtp = carve(mtiles * 128 * sizeof(Payload));
@@ -397,6 +404,8 @@ int32_t orbit_ctx_create(int32_t device_id, const OrbitCaps *caps_in, OrbitCtx *
     ctx->d_tickets = (uint32_t *)(a + o_dtk);
     ctx->f_ent_flags = (uint32_t *)(a + o_fef);
     ctx->f_tile_flags = (uint32_t *)(a + o_ftf);
+    ctx->m_split = rec_shift > 5u ? a + o_split : nullptr;
+    ctx->rec_shift = rec_shift;
 #ifdef ORBIT_TRIAGE // perf-triage builds (tools/mkvariant_any.sh); the product library reads no environment variable
     const char *dbg = getenv("ORBIT_SP_DEBUG");
     ctx->debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u;
@@ -615,6 +624,12 @@ static int32_t entity_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitG
     if (ci->occlusion_pass == 2 &&
         ((!b->depth_pyramid && !b->depth_pyramid_levels) || !b->depth_pyramid_size[0] || !b->depth_pyramid_size[1]))
         return fail(ctx, ORBIT_E_MISSING, "occlusion_pass 2 needs depth_pyramid");
+    if (ctx->rec_shift > 5u && ci->occlusion_pass != 0)
+        return fail(ctx, ORBIT_E_INVALID,
+                    "occlusion_pass %u with dispatch_size %u: the reference's visibility words are consistent for 32 only — an "
+                    "entity gets ceil(meshlets / 32) words (src/scene.rs:427) while entity_cull.comp:222 advances a record's "
+                    "word offset by meshlet_count / S; other dispatch sizes serve occlusion pass 0",
+                    ci->occlusion_pass, ctx->caps.dispatch_size);
     if (draw_first % 32u) return fail(ctx, ORBIT_E_INVALID, "draw_first %u is not a multiple of 32", draw_first);
     if (entity_draw_count > ctx->caps.max_entities)
         return fail(ctx, ORBIT_E_CAPACITY, "entity_draw_count %u > caps.max_entities %u", entity_draw_count,
@@ -635,6 +650,7 @@ static int32_t entity_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitG
     p.draw_limit = limit > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)limit;
     p.dispatch_capacity = b->dispatch_capacity;
     p.ne_chunks = (entity_draw_count + 255u) / 256u;
+    p.rec_shift = ctx->rec_shift;
     p.proto = scratch->e_proto;
     p.block_sums = scratch->e_block_sums;
     p.sync = scratch->f_sync;
@@ -688,6 +704,21 @@ int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCull
     if (!b->meshlet_dispatch_buffer || !b->meshlet_buffer || !b->entity_buffer || !b->material_buffer ||
         (task_path ? (void *)task_records : visible_path ? visible_buffer : b->draw_commands_buffer) == nullptr)
         return fail(ctx, ORBIT_E_MISSING, "meshlet_cull: a required buffer is NULL");
+    if (ctx->rec_shift > 5u) { // dispatch_size 64 / 128: pass 0 into a MeshletDrawCommandBuffer, nothing else
+        if (ci->occlusion_pass != 0)
+            return fail(ctx, ORBIT_E_INVALID,
+                        "occlusion_pass %u with dispatch_size %u: the reference's visibility words are consistent for 32 only "
+                        "(src/scene.rs:427 against meshlet_cull.comp:129-134, 233-254); other dispatch sizes serve pass 0",
+                        ci->occlusion_pass, ctx->caps.dispatch_size);
+        if (task_path)
+            return fail(ctx, ORBIT_E_INVALID,
+                        "the mesh-shading path with dispatch_size %u: MeshTaskPayload.meshlet_indices has 32 entries whatever "
+                        "the dispatch size (shaders/include/types.glsl:196-200) — a record with more survivors writes past it",
+                        ctx->caps.dispatch_size);
+        if (visible_path)
+            return fail(ctx, ORBIT_E_INVALID, "the sharded engine's record list is defined for dispatch_size 32 (one 32-bit "
+                                              "ballot per record); this context has %u", ctx->caps.dispatch_size);
+    }
     const bool meshlet_occ = ci->meshlet_visibility_buffer != ORBIT_NONE;
     if (meshlet_occ && ci->occlusion_pass != 0 && !b->meshlet_visibility_buffer)
         return fail(ctx, ORBIT_E_MISSING, "cull_info declares a meshlet visibility buffer but the pointer is NULL");
@@ -707,6 +738,10 @@ int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCull
     p.meshlet_visibility = b->meshlet_visibility_buffer;
     p.pyr = make_pyramid_view(b->depth_pyramid, b->depth_pyramid_size, b->depth_pyramid_levels);
     p.dispatch_capacity = b->dispatch_capacity;
+    if (ctx->rec_shift > 5u) { // the launches read the records of 32 that split_params_for's launch derives
+        p.dispatch_buffer = scratch->m_split;
+        p.dispatch_capacity = b->dispatch_capacity << (ctx->rec_shift - 5u);
+    }
     p.draw_capacity = visible_path ? visible_capacity : b->draw_capacity;
     p.visible_list = visible_path;
     p.material_count = b->material_count;
@@ -745,6 +780,17 @@ int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCull
     return ORBIT_OK;
 }
 
+// dispatch_size 64 / 128: the launch that turns the caller's S-sized records into the records of 32 the meshlet stage
+// reads (entity_cull.hip split_records_body), on `scratch`'s buffer.
+SplitRecordsParams split_params_for(const OrbitCtx *ctx, const OrbitCtx *scratch, const OrbitMeshletCullBufs *b) {
+    SplitRecordsParams sp;
+    sp.src = (const uint8_t *)b->meshlet_dispatch_buffer;
+    sp.dst = scratch->m_split;
+    sp.src_capacity = b->dispatch_capacity;
+    sp.rec_shift = ctx->rec_shift;
+    return sp;
+}
+
 int32_t meshlet_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitMeshletCullBufs *b,
                           OrbitMeshTaskRecord *task_records, bool task_path, void *stream,
                           void *visible_buffer = nullptr, uint32_t visible_capacity = 0, uint32_t visible_path = 0u,
@@ -779,7 +825,10 @@ int32_t meshlet_cull_impl(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const Orbit
                                                              (hipStream_t)stream);
         if (ve != hipSuccess) return hip_fail(ctx, ve, "launch meshlet_stream_validate");
     }
-    hipError_t e = launch_meshlet_cull(p, ctx->num_cus, (hipStream_t)stream, ev0, ev1);
+    hipError_t e = hipSuccess;
+    if (ctx->rec_shift > 5u) e = launch_split_records(split_params_for(ctx, ctx, b), (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch split_records");
+    e = launch_meshlet_cull(p, ctx->num_cus, (hipStream_t)stream, ev0, ev1);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch meshlet_cull");
     if (p.ms.sphere && ci->occlusion_pass != 1) {
         ctx->stream_culls++;
@@ -806,6 +855,7 @@ struct PreparedCullViews {
     EntityCullViews ev{};
     MeshletCullViews mv{};
     FusedCullViews fv{};
+    SplitRecordsViews sv{}; // dispatch_size 64 / 128: entry k serves mv.v[k]
     uint32_t draws[ORBIT_MAX_CULL_VIEWS] = {};
     uint32_t count = 0, n_mesh = 0, max_draws = 0;
     bool fused = false;
@@ -839,6 +889,7 @@ int32_t prepare_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t c
         int32_t rc = entity_cull_params(ctx, scratch, v.cull_info, &v.entity, 0u, v.entity_draw_count, false, pc.ev.v[i]);
         if (rc == ORBIT_OK && !v.skip_meshlet_stage) {
             rc = meshlet_cull_params(ctx, scratch, v.cull_info, &v.meshlet, nullptr, false, nullptr, 0, false, pc.mv.v[pc.n_mesh]);
+            if (rc == ORBIT_OK && ctx->rec_shift > 5u) pc.sv.v[pc.n_mesh] = split_params_for(ctx, scratch, &v.meshlet);
             if (rc == ORBIT_OK && v.meshlet.meshlet_dispatch_buffer != v.entity.meshlet_dispatch_buffer)
                 rc = fail(ctx, ORBIT_E_INVALID, "view %u: the meshlet stage must read the entity stage's dispatch buffer", i);
             pc.n_mesh++;
@@ -851,7 +902,9 @@ int32_t prepare_cull_views(OrbitCtx *ctx, const OrbitCullView *views, uint32_t c
     // the 32-B Meshlet buffer whatever stream is bound (the survivors' command words are then in the row registers).
     // (a context that validates its stream on every cull keeps the chain: the one launch never reads the stream, and
     // the validation and ORBIT_E_RANGE are what such a context exists for)
-    bool fused = ctx->caps.cull_path != 1u && pc.n_mesh == count && !(ctx->caps.validate_streams != 0u && ctx->meshlet_stream != nullptr);
+    // (and a context of another dispatch size: the one launch hands 32-meshlet records over inside itself)
+    bool fused = ctx->caps.cull_path != 1u && pc.n_mesh == count && ctx->rec_shift == 5u &&
+                 !(ctx->caps.validate_streams != 0u && ctx->meshlet_stream != nullptr);
     for (uint32_t i = 0; i < count && fused; i++)
         fused = views[i].entity_draw_count != 0u &&
                 (ctx->caps.cull_path == 2u || views[i].entity_draw_count <= kFusedMaxEntityDraws);
@@ -890,6 +943,7 @@ int32_t launch_prepared_cull_views(OrbitCtx *ctx, const PreparedCullViews &pc, h
         return ORBIT_OK;
     }
     e = launch_entity_cull_views(pc.ev, pc.count, pc.max_draws, ctx->num_cus, s);
+    if (e == hipSuccess && ctx->rec_shift > 5u && pc.n_mesh) e = launch_split_records_views(pc.sv, pc.n_mesh, s);
     if (e == hipSuccess) e = launch_meshlet_cull_views(pc.mv, pc.n_mesh, ctx->num_cus, s);
     if (e != hipSuccess) return hip_fail(ctx, e, "launch cull_views");
     for (uint32_t i = 0; i < pc.n_mesh; i++)
@@ -1183,6 +1237,9 @@ int32_t orbit_cull_shard(OrbitCtx *ctx, const OrbitGpuCullInfo *ci, const OrbitE
                          uint32_t record_capacity, uint32_t with_commands, void *stream) {
     if (!ctx) return fail(nullptr, ORBIT_E_INVALID, "ctx is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    if (ctx->rec_shift != 5u)
+        return fail(ctx, ORBIT_E_INVALID, "cull_shard: the sharded engine's record list is defined for dispatch_size 32; this "
+                                          "context has %u", ctx->caps.dispatch_size);
     EntityCullParams ep;
     MeshletCullParams p;
     int32_t rc = entity_cull_params(ctx, ctx, ci, eb, draw_first, draw_count, true, ep);

@@ -143,6 +143,7 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p, FusedL
         a.dispatch_capacity = p.e_dispatch_capacity;
         a.draw_first = p.draw_first, a.draw_limit = p.draw_limit;
         a.ne_chunks = p.ne_chunks;
+        a.rec_shift = 5u; // (contexts of another dispatch size take the launch chain: abi.hip)
         a.sync = p.sync, a.ent_flags = p.ent_flags, a.total = p.e_total, a.status = p.m.status;
         entity_chunks(E, a, ent_lds, [&](uint32_t total) {
             if (min(total, min(p.e_dispatch_capacity, p.m.dispatch_capacity)) == 0u) {

@@ -102,8 +102,9 @@ __device__ __forceinline__ void entity_write_visibility(const P &p, uint32_t g, 
 }
 
 // Record j of an entity whose proto-record is `o` (:211-223): every record before j is full (count / S == 1, :222).
-__device__ __forceinline__ OrbitMeshletDispatch entity_record(const OrbitMeshletDispatch &o, uint32_t j) {
-    const uint32_t S = ORBIT_MESHLET_DISPATCH_SIZE;
+// S = MESHLET_DISPATCH_SIZE = 1 << rec_shift (OrbitCaps.dispatch_size: 32, or 64 / 128 in pass 0).
+__device__ __forceinline__ OrbitMeshletDispatch entity_record(const OrbitMeshletDispatch &o, uint32_t j, uint32_t rec_shift) {
+    const uint32_t S = 1u << rec_shift;
     OrbitMeshletDispatch rec;
     rec.entity_index = o.entity_index;
     rec.meshlet_offset = o.meshlet_offset + S * j;
@@ -121,7 +122,7 @@ __device__ __forceinline__ OrbitMeshletDispatch entity_record(const OrbitMeshlet
 // count is fixed, the compiler interleaves the chains.
 template <class Store>
 __device__ __forceinline__ void entity_expand_records(const uint32_t *s_off, const OrbitMeshletDispatch *s_proto, uint32_t total,
-                                                      Store store) {
+                                                      uint32_t rec_shift, Store store) {
     constexpr uint32_t U = 4;
     for (uint32_t r0 = threadIdx.x; r0 < total; r0 += U * kEntityBlock) {
         uint32_t lo[U], hi[U];
@@ -138,7 +139,7 @@ __device__ __forceinline__ void entity_expand_records(const uint32_t *s_off, con
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
             const uint32_t r = r0 + u * kEntityBlock;
-            if (r < total) store(r, entity_record(s_proto[lo[u]], r - s_off[lo[u]]));
+            if (r < total) store(r, entity_record(s_proto[lo[u]], r - s_off[lo[u]], rec_shift));
         }
     }
 }
@@ -166,6 +167,7 @@ struct EntityChunksArgs {
     uint32_t dispatch_capacity;
     uint32_t draw_first, draw_limit; // as EntityCullParams
     uint32_t ne_chunks;              // ceil(entity_draw_count / kEntityBlock) >= 1
+    uint32_t rec_shift;              // log2 of MESHLET_DISPATCH_SIZE (5; 6 / 7: OrbitCaps.dispatch_size 64 / 128)
     uint32_t *sync;                  // kFusedSyncWords counters (kernels.h), zero between launches
     uint32_t *ent_flags;             // per chunk: records << 2 | state
     uint32_t *total;
@@ -231,7 +233,7 @@ __device__ __forceinline__ void entity_chunks(const E &ent, const EntityChunksAr
         bool visible;
         const OrbitMeshletDispatch pr = entity_eval_one(ent, g, active, visible);
         entity_write_visibility(ent, g, draw_end, active && visible);
-        const uint32_t n = (pr.meshlet_count + ORBIT_MESHLET_DISPATCH_SIZE - 1u) / ORBIT_MESHLET_DISPATCH_SIZE; // :210
+        const uint32_t n = (pr.meshlet_count + (1u << a.rec_shift) - 1u) >> a.rec_shift; // :210
         uint32_t chunk_total;
         S.off[threadIdx.x] = block_exclusive_scan<kEntityBlock / 64>(n, S.smem, &chunk_total);
         // What this chunk PUBLISHES is cut to capacity + 1: the flag holds the count << 2 and the arrival word adds
@@ -244,7 +246,7 @@ __device__ __forceinline__ void entity_chunks(const E &ent, const EntityChunksAr
         st_sc1(EF, threadIdx.x == 0 ? eb * 4u : kHandoffNoOffset, chunk_total << 2 | kAggregate);
         // ... then the records of the chunks before it
         const uint32_t base = chunks_before(a.status, EF, eb, S.smem);
-        entity_expand_records(S.off, S.proto, chunk_total, [&](uint32_t r, const OrbitMeshletDispatch &rec) {
+        entity_expand_records(S.off, S.proto, chunk_total, a.rec_shift, [&](uint32_t r, const OrbitMeshletDispatch &rec) {
             const v4u w = {rec.entity_index, rec.meshlet_offset, rec.meshlet_count, rec.visibility_offset};
             const uint64_t slot = (uint64_t)base + r; // (the sum can pass 2^32 / 16 only far beyond any capacity)
             __builtin_amdgcn_raw_buffer_store_b128(w, REC_W, slot < a.dispatch_capacity ? (uint32_t)slot * 16u : kHandoffNoOffset, 0, kSc1);

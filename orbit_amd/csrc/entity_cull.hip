@@ -25,6 +25,7 @@ __device__ __forceinline__ void entity_cull_body(const EntityCullParams &p) {
     a.dispatch_capacity = p.dispatch_capacity;
     a.draw_first = p.draw_first, a.draw_limit = p.draw_limit;
     a.ne_chunks = p.ne_chunks;
+    a.rec_shift = p.rec_shift;
     a.sync = p.sync, a.ent_flags = p.ent_flags, a.total = p.total, a.status = p.status;
     entity_chunks(p, a, lds, [](uint32_t) {});
     // the last workgroup out zeroes the flags: the next launch (or a graph replay) finds them as this one did
@@ -78,7 +79,7 @@ __device__ __forceinline__ void entity_cull_eval_body(const EntityCullParams &p)
     entity_write_visibility(p, g, end, active && visible);
 
     p.proto[local] = pr;
-    const uint32_t n = (pr.meshlet_count + ORBIT_MESHLET_DISPATCH_SIZE - 1u) / ORBIT_MESHLET_DISPATCH_SIZE; // :210
+    const uint32_t n = (pr.meshlet_count + (1u << p.rec_shift) - 1u) >> p.rec_shift; // :210
     uint32_t total;
     (void)block_exclusive_scan<kEntityBlock / 64>(n, smem, &total);
     if (threadIdx.x == 0) p.block_sums[blockIdx.x] = total;
@@ -116,7 +117,7 @@ __device__ __forceinline__ void entity_cull_emit_body(const EntityCullParams &p)
     __shared__ OrbitMeshletDispatch s_proto[kEntityBlock];
     const uint32_t local = blockIdx.x * kEntityBlock + threadIdx.x;
     const OrbitMeshletDispatch pr = p.proto[local];
-    const uint32_t n = (pr.meshlet_count + ORBIT_MESHLET_DISPATCH_SIZE - 1u) / ORBIT_MESHLET_DISPATCH_SIZE;
+    const uint32_t n = (pr.meshlet_count + (1u << p.rec_shift) - 1u) >> p.rec_shift;
     const uint32_t preceding = blockIdx.x == 0 ? gridDim.x : blockIdx.x; // block 0: grand total
     uint32_t part = 0;
     for (uint32_t i = threadIdx.x; i < preceding; i += kEntityBlock) part += p.block_sums[i];
@@ -127,7 +128,7 @@ __device__ __forceinline__ void entity_cull_emit_body(const EntityCullParams &p)
     s_proto[threadIdx.x] = pr;
     __syncthreads();
     OrbitMeshletDispatch *out = reinterpret_cast<OrbitMeshletDispatch *>(p.dispatch_buffer + ORBIT_DISPATCH_HEADER);
-    entity_expand_records(s_off, s_proto, block_total, [&](uint32_t r, const OrbitMeshletDispatch &rec) {
+    entity_expand_records(s_off, s_proto, block_total, p.rec_shift, [&](uint32_t r, const OrbitMeshletDispatch &rec) {
         if (block_base + r < p.dispatch_capacity) out[block_base + r] = rec;
     });
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -152,6 +153,30 @@ __global__ void write_dispatch_header(uint32_t *hdr, uint32_t x) {
     hdr[2] = 1u;
 }
 
+// OrbitCaps.dispatch_size 64 / 128: the caller's dispatch buffer holds S-sized records (what the reference's entity_cull
+// writes with that spec constant); the meshlet stage's kernels are built on 32-meshlet records — one wave row holds two.
+// Every S-record becomes S / 32 records of 32 in a buffer of the context (a record's tail parts may be empty: count 0), in
+// order: the canonical (record, lane) command order is the ascending meshlet order per entity however the records are cut
+// (tests/golden/spirv_cull_dispatch_sizes.npz: the reference's binaries produce the same command list at 32, 64 and 128).
+__device__ __forceinline__ void split_records_body(const SplitRecordsParams &p) {
+    const uint32_t nrec = min(*reinterpret_cast<const uint32_t *>(p.src), p.src_capacity);
+    const uint32_t parts = 1u << (p.rec_shift - 5u);
+    const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+    if (v == 0u) {
+        uint32_t *hdr = reinterpret_cast<uint32_t *>(p.dst);
+        hdr[0] = nrec * parts, hdr[1] = 1u, hdr[2] = 1u;
+    }
+    if (v >= nrec * parts) return;
+    const uint4 rec = reinterpret_cast<const uint4 *>(p.src + ORBIT_DISPATCH_HEADER)[v >> (p.rec_shift - 5u)];
+    const uint32_t first = (v & (parts - 1u)) * 32u;
+    const uint32_t count = rec.z > first ? min(rec.z - first, 32u) : 0u;
+    // (an empty part keeps the record's own offset: no lane of it is ever active, no address past the entity is formed)
+    reinterpret_cast<uint4 *>(p.dst + ORBIT_DISPATCH_HEADER)[v] =
+        make_uint4(rec.x, count ? rec.y + first : rec.y, count, rec.w + (v & (parts - 1u)));
+}
+__global__ __launch_bounds__(256) void split_records_kernel(const SplitRecordsParams p) { split_records_body(p); }
+__global__ __launch_bounds__(256) void split_records_views_kernel(const SplitRecordsViews all) { split_records_body(all.v[blockIdx.y]); }
+
 // chunks are drawn by ticket: any grid is right; one workgroup per chunk up to four per CU keeps every chunk in flight
 uint32_t entity_grid(uint32_t chunks, uint32_t num_cus) { return max(min(chunks, num_cus * 4u), 1u); }
 
@@ -172,6 +197,19 @@ hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_co
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(entity_cull_emit, dim3(p.ne_chunks), dim3(kEntityBlock), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_records(const SplitRecordsParams &p, hipStream_t s) {
+    const uint64_t threads = ((uint64_t)p.src_capacity << (p.rec_shift - 5u)) + 1u;
+    hipLaunchKernelGGL(split_records_kernel, dim3((uint32_t)((threads + 255u) / 256u)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_records_views(const SplitRecordsViews &all, uint32_t n, hipStream_t s) {
+    uint64_t most = 1;
+    for (uint32_t i = 0; i < n; i++) most = max(most, ((uint64_t)all.v[i].src_capacity << (all.v[i].rec_shift - 5u)) + 1u);
+    hipLaunchKernelGGL(split_records_views_kernel, dim3((uint32_t)((most + 255u) / 256u), n), dim3(256), 0, s, all);
     return hipGetLastError();
 }
 

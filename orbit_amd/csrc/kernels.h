@@ -61,6 +61,7 @@ struct EntityCullParams {
     uint32_t draw_limit;      // draw_first + 256 * ceil(entity_draw_count / 256)
     uint32_t dispatch_capacity;
     uint32_t ne_chunks;       // ceil(entity_draw_count / 256): chunks of the launch (entity_common.h entity_chunks)
+    uint32_t rec_shift;       // log2 of MESHLET_DISPATCH_SIZE: 5 (OrbitCaps.dispatch_size 32), 6 / 7 for 64 / 128 (pass 0)
     // context scratch of the two-launch form (entity_cull.hip: more than 128 chunks)
     OrbitMeshletDispatch *proto; // one proto-record per entity-draw of the launch
     uint32_t *block_sums; // records per block of 256 entity-draws; the emit launch prefix-sums them itself
@@ -282,6 +283,19 @@ hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_co
 // orbit_cull_views: the parameter blocks of all views travel BY VALUE in the kernel-argument segment (a few KB: HIP on
 // gfx950 takes it — tools/ubench/kernarg_size.hip), so a view's block is read with scalar loads at a uniform offset
 // (blockIdx.y), exactly like the single-view kernels read theirs.
+// OrbitCaps.dispatch_size 64 / 128 (entity_cull.hip split_records_body): the caller's S-sized records -> records of 32
+struct SplitRecordsParams {
+    const uint8_t *src;    // the caller's dispatch buffer: {count,1,1} + 16-B records of up to 1 << rec_shift meshlets
+    uint8_t *dst;          // context scratch: {count << (rec_shift - 5),1,1} + records of up to 32
+    uint32_t src_capacity; // records `src` can hold
+    uint32_t rec_shift;    // 6 / 7
+};
+struct SplitRecordsViews {
+    SplitRecordsParams v[ORBIT_MAX_CULL_VIEWS];
+};
+hipError_t launch_split_records(const SplitRecordsParams &p, hipStream_t s);
+hipError_t launch_split_records_views(const SplitRecordsViews &all, uint32_t n, hipStream_t s);
+
 struct EntityCullViews {
     EntityCullParams v[ORBIT_MAX_CULL_VIEWS];
 };

@@ -142,6 +142,7 @@ __device__ __forceinline__ void meshlet_eval_body(const MeshletCullParams &p, co
         a.dispatch_capacity = f.e_dispatch_capacity;
         a.draw_first = f.draw_first, a.draw_limit = f.draw_limit;
         a.ne_chunks = f.ne_chunks;
+        a.rec_shift = 5u; // (orbit_cull_shard refuses other dispatch sizes)
         a.sync = f.sync, a.ent_flags = f.ent_flags, a.total = f.e_total, a.status = p.status;
         // whoever completes the LAST chunk tells everybody: a copy of {1 << 40 | records} on each of kShardDoneWords
         // lines (thread 0 of that workgroup; write-through).  The waiting workgroups poll a copy each, not the arrival

@@ -1,5 +1,6 @@
 """Generates tests/golden/spirv_cull.npz and spirv_cluster.npz (no argument), spirv_pyramid.npz (`pyramid`: depth_reduce.comp.spv
-level by level) and spirv_compact.npz (`compact`: active_cluster_compaction.comp.spv): inputs and OUTPUTS OF THE
+level by level), spirv_compact.npz (`compact`: active_cluster_compaction.comp.spv) and spirv_cull_dispatch_sizes.npz
+(`dispatch`: the two cull shaders with MESHLET_DISPATCH_SIZE = 64 / 128, pass 0): inputs and OUTPUTS OF THE
 REFERENCE'S OWN COMPILED SHADERS.
 
 Run in the build container only (it reads /root/reference/shaders/{entity_cull,meshlet_cull}.comp.spv,
@@ -36,10 +37,10 @@ RCP127 = np.frombuffer(np.array([0x3C010204], np.uint32).tobytes(), np.float32)[
 _mods = {}
 
 
-def module(name):
-    if name not in _mods:
-        _mods[name] = vm.Module(REF + name, spec={0: 32})  # constant_id 0 = MESHLET_DISPATCH_SIZE / local_size_x
-    return _mods[name]
+def module(name, S=32):
+    if (name, S) not in _mods:
+        _mods[name, S] = vm.Module(REF + name, spec={0: S})  # constant_id 0 = MESHLET_DISPATCH_SIZE / local_size_x
+    return _mods[name, S]
 
 
 def log2(x):
@@ -136,7 +137,7 @@ def depth_knife_edge(scene, cam, ci, ortho, seed, rng):
     return np.full((H, W), np.frombuffer(np.array([lo + (seed & 1)], np.uint32).tobytes(), F)[0], F)
 
 
-def case(seed, occlusion_pass, ortho, knife, n=140):
+def case(seed, occlusion_pass, ortho, knife, n=140, S=32):
     rng = np.random.default_rng(seed)
     scene = sc.make_scene(seed, n, meshlets_per_mesh=(1, 70), lods=3,
                           meshlet_layout="scattered")  # the layout the committed vectors were made with
@@ -175,13 +176,23 @@ def case(seed, occlusion_pass, ortho, knife, n=140):
                samplers={k: {"id": k} for k in range(8)}, subgroup=32,
                sample=lambda img, smp, u, v, lod: np.array(
                    [oracle.hiz_sample(pyr, ps[0], ps[1], float(u), float(v), float(lod)), 0, 0, 0], F))
-    vm.Machine(module("entity_cull.comp.spv"), B, np.array([1, 2, 3, 4, 5], np.uint32).tobytes(), log2, **kwm).run(
+    vm.Machine(module("entity_cull.comp.spv", S), B, np.array([1, 2, 3, 4, 5], np.uint32).tobytes(), log2, **kwm).run(
         (scene.entity_draw_count + 255) // 256, batch=8)
     nrec = int(B[3][:4].view(np.uint32)[0])
-    vm.Machine(module("meshlet_cull.comp.spv"), B, np.array([3, 8, 9, 4, 5, 10], np.uint32).tobytes(), log2,
+    vm.Machine(module("meshlet_cull.comp.spv", S), B, np.array([3, 8, 9, 4, 5, 10], np.uint32).tobytes(), log2,
                **kwm).run(nrec, batch=256)
     ndraw = int(B[9][:4].view(np.uint32)[0])
     assert nrec <= cap_d and ndraw <= cap_c
+    if S != 32:
+        # other dispatch sizes (spec constant 0 = 64 / 128: what src/graphics/device.rs:369-372 derives on devices whose
+        # mesh-shader workgroup is that wide): pass 0 only — the visibility-word protocol is consistent for S = 32 alone
+        # (scene.rs:427, entity_cull.comp:222) — and no task-shader run: MeshTaskPayload.meshlet_indices has 32 entries
+        # whatever S is (types.glsl:196-200), a record with more survivors writes past it
+        assert occlusion_pass == 0
+        return dict(cull_info=np.array(ci).reshape(1), entity_draws=scene.entity_draw_buffer(), mesh_infos=scene.mesh_infos,
+                    entities=scene.entities, meshlets=scene.meshlets, materials=scene.materials,
+                    caps=np.array([cap_d, cap_c], np.uint32), dispatch_size=np.array([S], np.uint32),
+                    spv_dispatch=B[3][:L.DISPATCH_HEADER + 16 * nrec].copy(), spv_draw=B[9][:L.DRAW_HEADER + 28 * ndraw].copy())
     # the mesh-shading path: the task shader's binary on the same dispatch records (one workgroup per record), from
     # the same visibility words the meshlet stage started from
     T = dict(B)
@@ -386,7 +397,41 @@ def compact_main():
     print(path, os.path.getsize(path), "bytes")
 
 
+def dispatch_main():
+    """tests/golden/spirv_cull_dispatch_sizes.npz: entity_cull.comp.spv + meshlet_cull.comp.spv with spec constant 0 = 64
+    and 128, occlusion pass 0, perspective / orthographic x plain / knife-edge — and, per case, whether the binaries'
+    command list equals the S = 32 binaries' on the same scene (the canonical (record, lane) order is the ascending
+    meshlet order per entity whatever S cuts the records into).  Outputs only: the inputs are those of spirv_cull.npz's
+    pass-0 cases (asserted)."""
+    out = {}
+    committed = np.load(os.path.join(HERE, "spirv_cull.npz"))
+    for S in (64, 128):
+        for ortho in (False, True):
+            for knife in (False, True):
+                seed = 3 + (2 if ortho else 0) + (1 if knife else 0)  # the seeds of spirv_cull.npz's pass-0 cases
+                name = f"s{S}_p0_{'ortho' if ortho else 'persp'}_{'knife' if knife else 'plain'}"
+                c = case(seed, 0, ortho, knife, S=S)
+                c32 = case(seed, 0, ortho, knife, S=32)
+                same = np.array_equal(c["spv_draw"], c32["spv_draw"])
+                assert same, "the command list depends on the dispatch size?"
+                # the inputs ARE spirv_cull.npz's pass-0 case of the same projection and kind: stored there, checked here
+                base = f"p0_{'ortho' if ortho else 'persp'}_{'knife' if knife else 'plain'}"
+                for k in ("cull_info", "entity_draws", "mesh_infos", "entities", "meshlets", "materials", "caps"):
+                    assert np.array_equal(np.ascontiguousarray(c[k]).view(np.uint8).reshape(-1),
+                                          np.ascontiguousarray(committed[f"{base}/{k}"]).view(np.uint8).reshape(-1)), (base, k)
+                for k in ("dispatch_size", "spv_dispatch", "spv_draw"):
+                    out[f"{name}/{k}"] = c[k]
+                print("%-26s records %5d (S = 32: %5d)  draws %6d  commands equal to S = 32: %s" % (
+                    name, int(c["spv_dispatch"][:4].view(np.uint32)[0]), int(c32["spv_dispatch"][:4].view(np.uint32)[0]),
+                    int(c["spv_draw"][:4].view(np.uint32)[0]), same))
+    path = os.path.join(HERE, "spirv_cull_dispatch_sizes.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "dispatch":
+        return dispatch_main()
     if len(sys.argv) > 1 and sys.argv[1] == "pyramid":
         return pyramid_main()
     if len(sys.argv) > 1 and sys.argv[1] == "compact":

@@ -170,3 +170,42 @@ def test_oracle_compaction_equals_the_binary_as_a_multiset(oracle, name):
     assert dropped == 0 and n > 100 and np.array_equal(ou[:16], spv[:16])
     got, want = ou[16:16 + 4 * n].view(np.uint32), spv[16:16 + 4 * n].view(np.uint32)
     assert np.array_equal(np.sort(want), got) and len(np.unique(want)) == n
+
+
+# ----------------------------------------------------------------------------- MESHLET_DISPATCH_SIZE = 64 / 128 (pass 0)
+GOLD_S = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spirv_cull_dispatch_sizes.npz")
+S_CASES = [(S, proj, kind) for S in (64, 128) for proj in ("persp", "ortho") for kind in ("plain", "knife")]
+
+
+def load_s_case(vectors, vectors_s, S, proj, kind):
+    """Inputs of spirv_cull.npz's pass-0 case + the binaries' outputs with spec constant 0 = S."""
+    c = load_case(vectors, f"p0_{proj}_{kind}")
+    name = f"s{S}_p0_{proj}_{kind}"
+    assert int(vectors_s[f"{name}/dispatch_size"][0]) == S
+    c["spv_dispatch"], c["spv_draw"] = vectors_s[f"{name}/spv_dispatch"], vectors_s[f"{name}/spv_draw"]
+    return c
+
+
+@pytest.mark.parametrize("S,proj,kind", S_CASES)
+def test_oracle_equals_the_reference_binaries_at_other_dispatch_sizes(oracle, vectors, S, proj, kind):
+    """entity_cull.comp.spv / meshlet_cull.comp.spv with spec constant 0 = 64 and 128 (what device.rs:369-372 derives on
+    devices whose mesh-shader workgroup is that wide), occlusion pass 0: S-sized dispatch records, and the SAME command
+    list as S = 32 — the canonical (record, lane) order is the ascending meshlet order per entity however the records
+    are cut."""
+    vs = np.load(GOLD_S)
+    c = load_s_case(vectors, vs, S, proj, kind)
+    n_draws = int(np.frombuffer(c["draws"][:4].tobytes(), np.uint32)[0])
+    with oracle.dispatch_size(S):
+        od, _, dropped = oracle.entity_cull(c["ci"], c["draws"], n_draws, c["mesh_infos"], c["entities"], c["caps"][0])
+        nrec = int(c["spv_dispatch"][:4].view(np.uint32)[0])
+        assert dropped == 0 and int(od[:4].view(np.uint32)[0]) == nrec
+        assert np.array_equal(od[:L.DISPATCH_HEADER + 16 * nrec], c["spv_dispatch"]), "dispatch records differ from the binary's"
+        recs = od[L.DISPATCH_HEADER:L.DISPATCH_HEADER + 16 * nrec].view(np.uint32).reshape(-1, 4)
+        assert recs[:, 2].max() > 32 and recs[:, 2].max() <= S
+        oc, _, dropped = oracle.meshlet_cull(c["ci"], od, c["meshlets"], c["caps"][1], c["entities"], c["materials"])
+    ndraw = int(c["spv_draw"][:4].view(np.uint32)[0])
+    assert dropped == 0 and int(oc[:4].view(np.uint32)[0]) == ndraw
+    assert np.array_equal(oc[:L.DRAW_HEADER + 28 * ndraw], c["spv_draw"]), "draw commands differ from the binary's"
+    # ... which are the S = 32 binaries' commands
+    assert np.array_equal(c["spv_draw"], vectors[f"p0_{proj}_{kind}/spv_draw"])
+    assert oracle.lib().oracle_get_dispatch_size() == 32

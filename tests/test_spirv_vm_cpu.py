@@ -48,6 +48,21 @@ def test_rerunning_the_binaries_reproduces_the_committed_cull_vectors(occlusion_
 
 
 @pytest.mark.skipif(not os.path.exists(REF), reason="the reference's shader binaries are not on this machine")
+@pytest.mark.parametrize("S,ortho,knife", [(64, False, True), (128, True, False)])
+def test_rerunning_the_binaries_at_another_dispatch_size_reproduces_the_committed_vectors(S, ortho, knife):
+    """tests/golden/spirv_cull_dispatch_sizes.npz: the two cull binaries with spec constant 0 = 64 / 128, pass 0."""
+    import make_spirv_vectors as gen
+
+    seed = 3 + (2 if ortho else 0) + (1 if knife else 0)
+    name = f"s{S}_p0_{'ortho' if ortho else 'persp'}_{'knife' if knife else 'plain'}"
+    stored = np.load(os.path.join(HERE, "golden", "spirv_cull_dispatch_sizes.npz"))
+    fresh = gen.case(seed, 0, ortho, knife, S=S)
+    for k in ("dispatch_size", "spv_dispatch", "spv_draw"):
+        assert np.array_equal(np.ascontiguousarray(fresh[k]).view(np.uint8).reshape(-1),
+                              np.ascontiguousarray(stored[f"{name}/{k}"]).view(np.uint8).reshape(-1)), (name, k)
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference's shader binaries are not on this machine")
 def test_rerunning_the_binaries_reproduces_a_committed_cluster_vector():
     import make_spirv_vectors as gen
 
