@@ -616,6 +616,12 @@ static int32_t entity_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitG
                                   bool exact_range, EntityCullParams &p) {
     int32_t rc = check_cull_info(ctx, ci);
     if (rc) return rc;
+    if (ctx->rec_shift > 5u && ci->occlusion_pass != 0)
+        return fail(ctx, ORBIT_E_INVALID,
+                    "occlusion_pass %u with dispatch_size %u: the reference's visibility words are consistent for 32 only — an "
+                    "entity gets ceil(meshlets / 32) words (src/scene.rs:427) while entity_cull.comp:222 advances a record's "
+                    "word offset by meshlet_count / S; other dispatch sizes serve occlusion pass 0",
+                    ci->occlusion_pass, ctx->caps.dispatch_size);
     if (!b) return fail(ctx, ORBIT_E_INVALID, "bufs is NULL");
     if (!b->entity_draw_buffer || !b->mesh_info_buffer || !b->meshlet_dispatch_buffer || !b->entity_buffer)
         return fail(ctx, ORBIT_E_MISSING, "entity_cull: a required buffer is NULL");
@@ -624,12 +630,6 @@ static int32_t entity_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitG
     if (ci->occlusion_pass == 2 &&
         ((!b->depth_pyramid && !b->depth_pyramid_levels) || !b->depth_pyramid_size[0] || !b->depth_pyramid_size[1]))
         return fail(ctx, ORBIT_E_MISSING, "occlusion_pass 2 needs depth_pyramid");
-    if (ctx->rec_shift > 5u && ci->occlusion_pass != 0)
-        return fail(ctx, ORBIT_E_INVALID,
-                    "occlusion_pass %u with dispatch_size %u: the reference's visibility words are consistent for 32 only — an "
-                    "entity gets ceil(meshlets / 32) words (src/scene.rs:427) while entity_cull.comp:222 advances a record's "
-                    "word offset by meshlet_count / S; other dispatch sizes serve occlusion pass 0",
-                    ci->occlusion_pass, ctx->caps.dispatch_size);
     if (draw_first % 32u) return fail(ctx, ORBIT_E_INVALID, "draw_first %u is not a multiple of 32", draw_first);
     if (entity_draw_count > ctx->caps.max_entities)
         return fail(ctx, ORBIT_E_CAPACITY, "entity_draw_count %u > caps.max_entities %u", entity_draw_count,

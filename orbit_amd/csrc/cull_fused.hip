@@ -89,13 +89,34 @@ __device__ __forceinline__ uint32_t tiles_before(const FusedCullParams &p, __amd
 // The workgroup's LDS: one set for the kernel, whichever pass its view runs (the three passes are three instantiations of
 // the body inside ONE kernel — a view's pass is uniform per workgroup — so that a frame's views of different passes and
 // projections are one launch).
+// Scenes of up to kFusedLocalChunks chunks (768 entity-draws: BASELINE config 2 has 400) in passes 0 and 1: EVERY workgroup
+// evaluates every entity-draw itself and keeps the proto-records and their record offsets in LDS — the entity stage's
+// four hand-overs between workgroups (chunk ticket, count look-back, "all chunks in", the records' way through memory
+// and back) are then no part of the cull's chain of dependent round trips; a tile's records are rebuilt from the
+// offsets by bisection.  Workgroup 0 writes the caller's dispatch buffer.  Pass 2 is excluded: it rewrites the entity
+// bitset its own evaluation reads, which only the chunked form (each entity-draw evaluated once) orders.
+constexpr uint32_t kFusedLocalChunks = 3;
+constexpr uint32_t kFusedLocalEntries = kFusedLocalChunks * kEntityBlock;
+struct LocalEntityLds {
+    uint32_t smem[kEntityBlock / 64 + 1];
+    uint32_t off[1024]; // exclusive record offsets of the entity-draws; entries past the last one hold 0xFFFFFFFF
+    OrbitMeshletDispatch proto[kFusedLocalEntries];
+};
+static_assert(kFusedLocalEntries <= 1024, "ten bisection steps");
+struct ChunkedEntityLds {
+    EntityChunksLds ent;
+    CandLds<kCandRing> ring[kFusedWaves]; // pass 2 only
+};
+
 template <int ROWS>
 struct FusedLds {
     PlaneLds planes;
     AlphaLds alpha_tab;
-    EntityChunksLds ent;
+    union { // (local: passes 0 / 1 of small scenes; never together with the chunked phase or pass 2's ring)
+        ChunkedEntityLds chunked;
+        LocalEntityLds local;
+    } u;
     WaveTileLds slab[kFusedWaves];
-    CandLds<kCandRing> ring[kFusedWaves]; // pass 2 only
     Payload pay[kFusedWaves][fused_tile_records(ROWS) * 32u];
     uint32_t cmd[kFusedWaves][64 * 7];
     uint32_t word[2];
@@ -103,16 +124,21 @@ struct FusedLds {
 
 // PASS is a template parameter (it shapes the evaluation); the projection type is read at run time (PROJ = -1 in the
 // evaluation's templates: one uniform branch in the cone test).
-template <int PASS, int ROWS>
+// LOCAL: the entity stage in every workgroup (see LocalEntityLds) — a kernel of its own: with both forms of the entity
+// stage inlined into one kernel the compiler copies the whole parameter block to scratch (6.8 KB per lane, every scalar
+// of the evaluation a vector register).
+template <int PASS, int ROWS, bool LOCAL>
 __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p, FusedLds<ROWS> &S) {
+    static_assert(!LOCAL || (ROWS == 2 && PASS != 2), "the local entity stage: small scenes, passes 0 and 1");
     constexpr int PROJ = -1;
     constexpr uint32_t kRecs = fused_tile_records(ROWS); // records per tile
     constexpr uint32_t kFusedCap = kRecs * 32u;          // survivors a tile can have: its payload slab holds them all
     PlaneLds &planes = S.planes;
     AlphaLds &alpha_tab = S.alpha_tab;
-    EntityChunksLds &ent_lds = S.ent;
+    EntityChunksLds &ent_lds = S.u.chunked.ent;
+    LocalEntityLds &loc = S.u.local;
     WaveTileLds(&slab)[kFusedWaves] = S.slab;
-    CandLds<kCandRing>(&ring)[kFusedWaves] = S.ring;
+    CandLds<kCandRing>(&ring)[kFusedWaves] = S.u.chunked.ring;
     Payload(&s_pay)[kFusedWaves][kFusedCap] = S.pay;
     uint32_t(&s_cmd)[kFusedWaves][64 * 7] = S.cmd;
     uint32_t(&s_word)[2] = S.word;
@@ -136,8 +162,49 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p, FusedL
     planes_to_lds(p.m, planes);
     const AlphaLds *alpha = alpha_table_fill(p.m, alpha_tab) ? &alpha_tab : nullptr;
 
-    // ---------------------------------------------------------------- entity chunks (entity_cull.comp:104-245)
-    {
+    constexpr bool local = LOCAL; // (the launcher sends a view here only with ne_chunks <= kFusedLocalChunks)
+    uint32_t local_total = 0;
+    if constexpr (LOCAL) {
+        // ------------------------------------------------------------ every entity-draw, in every workgroup (:104-223)
+        const uint32_t draw_count = *reinterpret_cast<const uint32_t *>(E.entity_draw_buffer);
+        const uint32_t draw_end = min(draw_count, p.draw_limit);
+#pragma unroll 1
+        for (uint32_t c = 0; c < kFusedLocalChunks; c++) { // (fixed trip count: barriers inside)
+            const uint32_t g = p.draw_first + c * kEntityBlock + threadIdx.x;
+            const bool active = c < p.ne_chunks && g < draw_end; // :106
+            bool visible;
+            const OrbitMeshletDispatch pr = entity_eval_one(E, g, active, visible);
+            const uint32_t n = (pr.meshlet_count + 31u) >> 5; // :210
+            uint32_t chunk_total;
+            const uint32_t ex = block_exclusive_scan<kEntityBlock / 64>(n, loc.smem, &chunk_total);
+            loc.off[c * kEntityBlock + threadIdx.x] = local_total + ex;
+            loc.proto[c * kEntityBlock + threadIdx.x] = pr;
+            // (cut as the chunked form cuts what a chunk publishes: a corrupt meshlet_count must not wrap the sum)
+            local_total = min(local_total + uniform(chunk_total), p.e_dispatch_capacity + 1u);
+        }
+        for (uint32_t i = kFusedLocalEntries + threadIdx.x; i < 1024u; i += kEntityBlock) loc.off[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        if (blockIdx.x == 0) { // the caller's dispatch buffer: records, the {x,1,1} header (draw_gen.rs:356-363), the total
+            OrbitMeshletDispatch *out_rec = reinterpret_cast<OrbitMeshletDispatch *>(dispatch_buffer + ORBIT_DISPATCH_HEADER);
+            for (uint32_t r = threadIdx.x; r < min(local_total, p.e_dispatch_capacity); r += kEntityBlock) {
+                uint32_t lo = 0;
+#pragma unroll
+                for (uint32_t step = 512u; step >= 1u; step >>= 1) lo += loc.off[lo + step] <= r ? step : 0u;
+                out_rec[r] = entity_record(loc.proto[lo], r - loc.off[lo], 5u);
+            }
+            if (threadIdx.x == 0) {
+                uint32_t *hdr = reinterpret_cast<uint32_t *>(dispatch_buffer);
+                hdr[0] = min(local_total, p.e_dispatch_capacity), hdr[1] = 1u, hdr[2] = 1u;
+                *p.e_total = local_total;
+                if (local_total > p.e_dispatch_capacity) latch_status(p.m.status, ORBIT_E_CAPACITY);
+                if (min(local_total, min(p.e_dispatch_capacity, p.m.dispatch_capacity)) == 0u) {
+                    *reinterpret_cast<uint32_t *>(p.m.draw_buffer) = 0u; // no tile will run: the empty draw list
+                    *p.m.total = 0u;
+                }
+            }
+        }
+    } else {
+        // ------------------------------------------------------------ entity chunks (entity_cull.comp:104-245)
         EntityChunksArgs a;
         a.dispatch_buffer = dispatch_buffer;
         a.dispatch_capacity = p.e_dispatch_capacity;
@@ -159,7 +226,10 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p, FusedL
     // entity chunks arrive last and draw the highest tickets, so no low tile waits behind a busy workgroup)
     // ONE atomic per workgroup for its waves' first tickets (a returning atomic on one word serves ~88 per us on this
     // chip: a ticket per wave of a few hundred workgroups was microseconds of queueing in front of every tile)
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && local) { // nothing to wait for: the records are this workgroup's own
+        s_word[0] = __hip_atomic_fetch_add(p.sync + kSyTileTicket, kFusedWaves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_word[1] = local_total;
+    } else if (threadIdx.x == 0) {
         s_word[0] = __hip_atomic_fetch_add(p.sync + kSyTileTicket, kFusedWaves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         auto w = __builtin_amdgcn_raw_buffer_load_b64(SY, kSyEntDone * 4u, 0, kSc1);
         for (uint32_t spins = 0; arrived_chunks(w) < p.ne_chunks; spins++) {
@@ -192,8 +262,18 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p, FusedL
         // the tile's 16 records (lane = record * 4 + matrix column; past the last record: zeros), matrices, slab
         const uint32_t rec_index = t * kRecs + ((uint32_t)lane >> 2);
         const bool has_rec = ((uint32_t)lane >> 2) < kRecs && rec_index < nrec;
-        const auto rw = __builtin_amdgcn_raw_buffer_load_b128(REC_R, has_rec ? rec_index * 16u : kNoOffset, 0, kSc1);
-        const uint4 rec = make_uint4(rw[0], rw[1], rw[2], rw[3]);
+        uint4 rec;
+        if constexpr (LOCAL) { // from the offsets in LDS: the last entity-draw whose exclusive offset is <= the record's index
+            uint32_t lo = 0;
+#pragma unroll
+            for (uint32_t step = 512u; step >= 1u; step >>= 1) lo += loc.off[lo + step] <= rec_index ? step : 0u;
+            const OrbitMeshletDispatch r = entity_record(loc.proto[lo], rec_index - loc.off[lo], 5u);
+            rec = has_rec ? make_uint4(r.entity_index, r.meshlet_offset, r.meshlet_count, r.visibility_offset)
+                          : make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            const auto rw = __builtin_amdgcn_raw_buffer_load_b128(REC_R, has_rec ? rec_index * 16u : kNoOffset, 0, kSc1);
+            rec = make_uint4(rw[0], rw[1], rw[2], rw[3]);
+        }
 #if defined(ORBIT_FUSED_DEBUG) && ORBIT_FUSED_DEBUG == 3
         FUSED_MARK(0, t);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -300,10 +380,17 @@ __global__ __launch_bounds__(kEntityBlock, 2) void cull_fused_views_kernel(const
     __shared__ FusedLds<ROWS> lds;
     const FusedCullParams &p = all.v[g.idx[blockIdx.y]];
     switch (p.m.ci.occlusion_pass) { // uniform per workgroup
-    case 0: cull_fused_body<0, ROWS>(p, lds); break;
-    case 1: cull_fused_body<1, ROWS>(p, lds); break;
-    default: cull_fused_body<2, ROWS>(p, lds); break;
+    case 0: cull_fused_body<0, ROWS, false>(p, lds); break;
+    case 1: cull_fused_body<1, ROWS, false>(p, lds); break;
+    default: cull_fused_body<2, ROWS, false>(p, lds); break;
     }
+}
+// views of passes 0 / 1 with at most kFusedLocalChunks chunks of entity-draws (the launcher's grouping)
+__global__ __launch_bounds__(kEntityBlock, 2) void cull_fused_local_views_kernel(const FusedCullViews all, const ViewGroup g) {
+    __shared__ FusedLds<2> lds;
+    const FusedCullParams &p = all.v[g.idx[blockIdx.y]];
+    if (p.m.ci.occlusion_pass == 0) cull_fused_body<0, 2, true>(p, lds);
+    else cull_fused_body<1, 2, true>(p, lds);
 }
 
 // Workgroups of one view: a wave per expected tile (a record per entity-draw or so), a workgroup per entity chunk at
@@ -323,23 +410,30 @@ uint32_t fused_grid(uint32_t entity_draw_count, uint32_t rows, uint32_t num_cus,
 // kFusedSmallEntityDraws entity-draws meet in one call: they take different tile sizes)
 hipError_t launch_cull_fused_views(const FusedCullViews &all, const uint32_t *entity_draw_counts, uint32_t n,
                                    uint32_t num_cus, hipStream_t s) {
-    for (uint32_t rows = 2u; rows <= 8u; rows += 6u) {
+    // three shapes: 0 = the local entity stage (passes 0 / 1, at most kFusedLocalChunks chunks: 2-row tiles), 1 = 2-row
+    // tiles, 2 = 8-row tiles
+    for (uint32_t shape = 0; shape < 3u; shape++) {
         ViewGroup g{};
         uint32_t m = 0, most = 0;
         for (uint32_t j = 0; j < n; j++) {
 #ifdef ORBIT_FUSED_FORCE_ROWS
-            const uint32_t want = ORBIT_FUSED_FORCE_ROWS;
+            const uint32_t want = ORBIT_FUSED_FORCE_ROWS == 2 ? 1u : 2u;
 #else
-            const uint32_t want = entity_draw_counts[j] <= kFusedSmallEntityDraws ? 2u : 8u;
+            const uint32_t chunks = (entity_draw_counts[j] + kEntityBlock - 1u) / kEntityBlock;
+            const uint32_t want = (chunks <= kFusedLocalChunks && all.v[j].m.ci.occlusion_pass != 2u) ? 0u
+                                  : entity_draw_counts[j] <= kFusedSmallEntityDraws                    ? 1u
+                                                                                                       : 2u;
 #endif
-            if (want == rows) {
+            if (want == shape) {
                 g.idx[m++] = (uint8_t)j;
                 most = max(most, entity_draw_counts[j]);
             }
         }
         if (m == 0) continue;
+        const uint32_t rows = shape == 2u ? 8u : 2u;
         const dim3 grid(fused_grid(most, rows, num_cus, m), m), block(kEntityBlock);
-        if (rows == 2u) hipLaunchKernelGGL((cull_fused_views_kernel<2>), grid, block, 0, s, all, g);
+        if (shape == 0u) hipLaunchKernelGGL(cull_fused_local_views_kernel, grid, block, 0, s, all, g);
+        else if (shape == 1u) hipLaunchKernelGGL((cull_fused_views_kernel<2>), grid, block, 0, s, all, g);
         else hipLaunchKernelGGL((cull_fused_views_kernel<8>), grid, block, 0, s, all, g);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
