@@ -111,6 +111,22 @@ class dispatch_size:
         return False
 
 
+class arith_profile:
+    """`with oracle.arith_profile(1): ...` — the cull shaders' Dot / matrix products / Length as fma chains
+    (OrbitCaps.arith_profile = ORBIT_ARITH_CONTRACTED) for the calls inside; canonical (0) outside."""
+
+    def __init__(self, profile):
+        self.profile = int(profile)
+
+    def __enter__(self):
+        lib().oracle_set_arith_profile(C.c_uint32(self.profile))
+        return self
+
+    def __exit__(self, *exc):
+        lib().oracle_set_arith_profile(C.c_uint32(0))
+        return False
+
+
 def entity_cull(cull_info, entity_draw_buffer, entity_draw_count, mesh_infos, entities, dispatch_capacity,
                 visibility=None, pyramid=None, pyramid_size=(0, 0), draw_first=None):
     """Returns (dispatch_buffer bytes, visibility words (copy, updated in pass 2), dropped).

@@ -651,6 +651,7 @@ static int32_t entity_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitG
     p.dispatch_capacity = b->dispatch_capacity;
     p.ne_chunks = (entity_draw_count + 255u) / 256u;
     p.rec_shift = ctx->rec_shift;
+    p.arith = ctx->caps.arith_profile;
     p.proto = scratch->e_proto;
     p.block_sums = scratch->e_block_sums;
     p.sync = scratch->f_sync;
@@ -744,6 +745,7 @@ int32_t meshlet_cull_params(OrbitCtx *ctx, OrbitCtx *scratch, const OrbitGpuCull
     }
     p.draw_capacity = visible_path ? visible_capacity : b->draw_capacity;
     p.visible_list = visible_path;
+    p.arith = ctx->caps.arith_profile;
     p.material_count = b->material_count;
     {   // the symmetric five-plane frustum, recognised bit for bit (kernels.h MeshletCullParams::std_planes)
         auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };

@@ -410,6 +410,9 @@ uint32_t fused_grid(uint32_t entity_draw_count, uint32_t rows, uint32_t num_cus,
 // kFusedSmallEntityDraws entity-draws meet in one call: they take different tile sizes)
 hipError_t launch_cull_fused_views(const FusedCullViews &all, const uint32_t *entity_draw_counts, uint32_t n,
                                    uint32_t num_cus, hipStream_t s) {
+#if !ORBIT_CONTRACT
+    if (all.v[0].m.arith != 0u) return launch_cull_fused_views_contracted(all, entity_draw_counts, n, num_cus, s);
+#endif
     // three shapes: 0 = the local entity stage (passes 0 / 1, at most kFusedLocalChunks chunks: 2-row tiles), 1 = 2-row
     // tiles, 2 = 8-row tiles
     for (uint32_t shape = 0; shape < 3u; shape++) {

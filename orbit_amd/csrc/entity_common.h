@@ -50,7 +50,7 @@ __device__ __forceinline__ OrbitMeshletDispatch entity_eval_one(const P &p, uint
         mat4_mul_col(ci.view_matrix, c3.x, c3.y, c3.z, c3.w, m3);
         float pv[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) pv[r] = ((m0[r] * bs.x + m1[r] * bs.y) + m2[r] * bs.z) + m3[r] * 1.0f;
+        for (int r = 0; r < 4; r++) pv[r] = madd(m3[r], 1.0f, madd(m2[r], bs.z, madd(m1[r], bs.y, m0[r] * bs.x)));
         Sphere s;
         s.x = pv[0] / pv[3];
         s.y = pv[1] / pv[3];

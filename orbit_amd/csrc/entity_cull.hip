@@ -183,6 +183,9 @@ uint32_t entity_grid(uint32_t chunks, uint32_t num_cus) { return max(min(chunks,
 } // namespace
 
 hipError_t launch_entity_cull(const EntityCullParams &p, uint32_t entity_draw_count, uint32_t num_cus, hipStream_t s) {
+#if !ORBIT_CONTRACT
+    if (p.arith != 0u) return launch_entity_cull_contracted(p, entity_draw_count, num_cus, s); // OrbitCaps.arith_profile
+#endif
     if (entity_draw_count == 0) {
         // nothing to test: the pre-clear {0,1,1} is the whole effect (draw_gen.rs:361-362)
         hipLaunchKernelGGL(write_dispatch_header, dim3(1), dim3(1), 0, s,
@@ -216,6 +219,9 @@ hipError_t launch_split_records_views(const SplitRecordsViews &all, uint32_t n, 
 // Several views in one launch (orbit_cull_views): the grid covers the view with the most entity-draws.
 hipError_t launch_entity_cull_views(const EntityCullViews &all, uint32_t n, uint32_t max_entity_draw_count,
                                     uint32_t num_cus, hipStream_t s) {
+#if !ORBIT_CONTRACT
+    if (all.v[0].arith != 0u) return launch_entity_cull_views_contracted(all, n, max_entity_draw_count, num_cus, s);
+#endif
     const uint32_t chunks = (max_entity_draw_count + kEntityBlock - 1) / kEntityBlock;
     if (chunks > kEntityOneLaunchChunks) { // (surplus blocks of the smaller views find nothing active and write zero sums)
         hipLaunchKernelGGL(entity_cull_eval_views, dim3(chunks, n), dim3(kEntityBlock), 0, s, all);

@@ -62,6 +62,7 @@ struct EntityCullParams {
     uint32_t dispatch_capacity;
     uint32_t ne_chunks;       // ceil(entity_draw_count / 256): chunks of the launch (entity_common.h entity_chunks)
     uint32_t rec_shift;       // log2 of MESHLET_DISPATCH_SIZE: 5 (OrbitCaps.dispatch_size 32), 6 / 7 for 64 / 128 (pass 0)
+    uint32_t arith;           // OrbitCaps.arith_profile: != 0 sends the launch to the contracted build of the kernels
     // context scratch of the two-launch form (entity_cull.hip: more than 128 chunks)
     OrbitMeshletDispatch *proto; // one proto-record per entity-draw of the launch
     uint32_t *block_sums; // records per block of 256 entity-draws; the emit launch prefix-sums them itself
@@ -133,6 +134,7 @@ struct MeshletCullParams {
     OrbitMeshTaskRecord *task_records;
     // sharded engine (orbit_meshlet_cull_visible_records / orbit_cull_shard): draw_buffer is the record list (8-B header,
     // 12 B {entity, meshlet offset, should-draw ballot} per dispatch record) and draw_capacity its capacity
+    uint32_t arith;        // OrbitCaps.arith_profile: != 0 sends the evaluation to the contracted build of the kernels
     uint32_t visible_list; // 0: commands; 2: the record list, written by the evaluation launch itself (1 was the 8-B item
                            // list, retired in round 6)
     // visible_list == 2 only (orbit_meshlet_cull_records_and_commands): non-null = the same evaluation ALSO ends in the
@@ -299,6 +301,23 @@ hipError_t launch_split_records_views(const SplitRecordsViews &all, uint32_t n, 
 struct EntityCullViews {
     EntityCullParams v[ORBIT_MAX_CULL_VIEWS];
 };
+struct MeshletCullViews;
+struct FusedCullViews;
+struct ViewGroup;
+#if !ORBIT_CONTRACT
+// The translation units that evaluate geometry, compiled a second time with ORBIT_CONTRACT = 1 (*_contracted.hip: dots and
+// matrix products as fma chains, OrbitCaps.arith_profile): the canonical launchers below hand a launch whose parameter
+// block says `arith` to these.
+hipError_t launch_entity_cull_contracted(const EntityCullParams &p, uint32_t entity_draw_count, uint32_t num_cus, hipStream_t s);
+hipError_t launch_entity_cull_views_contracted(const EntityCullViews &all, uint32_t n, uint32_t max_entity_draw_count,
+                                               uint32_t num_cus, hipStream_t s);
+hipError_t launch_meshlet_eval_contracted(const MeshletCullParams &p, uint32_t num_cus, hipStream_t s);
+hipError_t launch_meshlet_eval_views_contracted(const MeshletCullViews &all, const ViewGroup &g, uint32_t m, uint32_t pass,
+                                                bool ortho, int src, uint32_t max_tiles, uint32_t num_cus, hipStream_t s);
+hipError_t launch_shard_cull_contracted(const FusedCullParams &f, uint32_t num_cus, hipStream_t s);
+hipError_t launch_cull_fused_views_contracted(const FusedCullViews &all, const uint32_t *entity_draw_counts, uint32_t n,
+                                              uint32_t num_cus, hipStream_t s);
+#endif
 hipError_t launch_entity_cull_views(const EntityCullViews &all, uint32_t n, uint32_t max_entity_draw_count,
                                     uint32_t num_cus, hipStream_t s);
 // ev0/ev1 (optional): recorded on `s` immediately before / after the dominant kernel of the op

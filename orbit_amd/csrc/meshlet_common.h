@@ -108,13 +108,24 @@ __device__ __forceinline__ bool lane_of(uint64_t wave_mask) { return __builtin_a
 __device__ __forceinline__ uint64_t planes_std(const PlaneLds &P, const Sphere &s) {
     const float4 k = P.std0;
     const float4 n = P.std1;
-    const float t1 = k.x * s.x, t2 = k.y * s.z, t3 = k.z * s.y, t4 = k.w * s.z, t5 = n.x * s.z;
     const float nr = -s.r;
+#if ORBIT_CONTRACT
+    // the same planes as fma chains: (a, 0, c, 0) . s = fma(c, z, fma(0, y, a x)) = fma(c, z, a x) for a finite y, its
+    // mirror fma(c, z, -(a x)); the near plane's fma(e, z, fma(0, y, 0 x)) is the rounded product e z
+    const float t1 = k.x * s.x, t3 = k.z * s.y, t5 = n.x * s.z;
+    uint64_t in = ballot(__builtin_fmaf(k.y, s.z, t1) > nr);
+    in &= ballot(__builtin_fmaf(k.y, s.z, -t1) > nr);
+    in &= ballot(__builtin_fmaf(k.w, s.z, t3) > nr);
+    in &= ballot(__builtin_fmaf(k.w, s.z, -t3) > nr);
+    in &= ballot((t5 + n.y) > nr);
+#else
+    const float t1 = k.x * s.x, t2 = k.y * s.z, t3 = k.z * s.y, t4 = k.w * s.z, t5 = n.x * s.z;
     uint64_t in = ballot((t1 + t2) > nr);
     in &= ballot((t2 - t1) > nr);
     in &= ballot((t3 + t4) > nr);
     in &= ballot((t4 - t3) > nr);
     in &= ballot((t5 + n.y) > nr);
+#endif
     return in;
 }
 
@@ -251,15 +262,15 @@ __device__ __forceinline__ uint64_t eval_geometry_mask(const MeshletCullParams &
     const float4 m0 = R.mcol[0], m1 = R.mcol[1], m2 = R.mcol[2], m3 = R.mcol[3];
     const float cx = __uint_as_float(a.x), cy = __uint_as_float(a.y), cz = __uint_as_float(a.z);
     // transform_sphere (:37-43): matrix * vec4(c, 1), divide by w.
-    float px = ((m0.x * cx + m1.x * cy) + m2.x * cz) + m3.x * 1.0f;
-    float py = ((m0.y * cx + m1.y * cy) + m2.y * cz) + m3.y * 1.0f;
-    float pz = ((m0.z * cx + m1.z * cy) + m2.z * cz) + m3.z * 1.0f;
+    float px = madd(m3.x, 1.0f, madd(m2.x, cz, madd(m1.x, cy, m0.x * cx)));
+    float py = madd(m3.y, 1.0f, madd(m2.y, cz, madd(m1.y, cy, m0.y * cx)));
+    float pz = madd(m3.z, 1.0f, madd(m2.z, cz, madd(m1.z, cy, m0.z * cx)));
     // (a non-finite centre makes all three non-finite: each holds a product with it)
     const uint64_t nonfinite = ballot(!__builtin_isfinite(px)) | ballot(!__builtin_isfinite(py)) | ballot(!__builtin_isfinite(pz));
     // wave-uniform and held as a scalar integer (not a lane boolean)
     const uint32_t literal = (affine_row ? 0u : 1u) | (uint32_t)nonfinite | (uint32_t)(nonfinite >> 32);
     if (literal != 0u) {
-        const float pw = ((m0.w * cx + m1.w * cy) + m2.w * cz) + m3.w * 1.0f;
+        const float pw = madd(m3.w, 1.0f, madd(m2.w, cz, madd(m1.w, cy, m0.w * cx)));
         if (pw != 1.0f) { // x / 1.0f == x bit-for-bit, so the affine case skips three IEEE divisions
             px = px / pw;
             py = py / pw;
@@ -284,9 +295,9 @@ __device__ __forceinline__ uint64_t eval_geometry_mask(const MeshletCullParams &
         const int az_i = (int)(int8_t)((b.x >> 16) & 0xFF), co_i = (int)(int8_t)(b.x >> 24);
         const float ax = snorm8(ax_i), ay = snorm8(ay_i), az = snorm8(az_i);
         const float cutoff = snorm8(co_i);
-        float axx = (m0.x * ax + m1.x * ay) + m2.x * az;
-        float axy = (m0.y * ax + m1.y * ay) + m2.y * az;
-        float axz = (m0.z * ax + m1.z * ay) + m2.z * az;
+        float axx = madd(m2.x, az, madd(m1.x, ay, m0.x * ax));
+        float axy = madd(m2.y, az, madd(m1.y, ay, m0.y * ax));
+        float axz = madd(m2.z, az, madd(m1.z, ay, m0.z * ax));
         if (literal != 0u) {
             const float4 tz = R.tzero; // m3 * 0.0f
             axx += tz.x;

@@ -646,6 +646,9 @@ void launch_eval_pass(const MeshletCullParams &p, dim3 grid, hipStream_t s) {
 } // namespace
 
 hipError_t launch_meshlet_eval(const MeshletCullParams &p, uint32_t num_cus, hipStream_t s) {
+#if !ORBIT_CONTRACT
+    if (p.arith != 0u) return launch_meshlet_eval_contracted(p, num_cus, s); // OrbitCaps.arith_profile
+#endif
     const uint32_t max_tiles = (p.dispatch_capacity + kTileRecords - 1) / kTileRecords;
     const uint32_t pass = p.ci.occlusion_pass;
     const dim3 grid(eval_grid(pass, p.ms.sphere != nullptr, max_tiles, num_cus));
@@ -693,6 +696,9 @@ hipError_t launch_meshlet_eval(const MeshletCullParams &p, uint32_t num_cus, hip
 // orbit_cull_shard: the entity stage, the evaluation and the record list of a shard in one launch (pass 0, at most
 // kShardMaxChunks chunks of 256 entity-draws; the caller checks both)
 hipError_t launch_shard_cull(const FusedCullParams &f, uint32_t num_cus, hipStream_t s) {
+#if !ORBIT_CONTRACT
+    if (f.m.arith != 0u) return launch_shard_cull_contracted(f, num_cus, s);
+#endif
     const MeshletCullParams &p = f.m;
     const uint32_t max_tiles = (p.dispatch_capacity + kTileRecords - 1) / kTileRecords;
     // every chunk needs a workgroup that may take it: at least as many workgroups as chunks
@@ -719,6 +725,9 @@ hipError_t launch_shard_cull(const FusedCullParams &f, uint32_t num_cus, hipStre
 // meshlet source `src` (0 = Meshlet buffer, 1 = derived streams, 2 = streams with alpha classes).
 hipError_t launch_meshlet_eval_views(const MeshletCullViews &all, const ViewGroup &g, uint32_t m, uint32_t pass,
                                      bool ortho, int src, uint32_t max_tiles, uint32_t num_cus, hipStream_t s) {
+#if !ORBIT_CONTRACT
+    if (all.v[g.idx[0]].arith != 0u) return launch_meshlet_eval_views_contracted(all, g, m, pass, ortho, src, max_tiles, num_cus, s);
+#endif
     // the views of a group share the device: each gets an equal part of the resident-wave budget
     uint32_t blocks = max(num_cus * (uint32_t)ev_waves_per_simd((int)pass, src != 0) / m, 1u);
     const uint32_t need = max((max_tiles + kEvWaves - 1) / kEvWaves, 1u);

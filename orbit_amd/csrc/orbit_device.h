@@ -39,9 +39,26 @@ __device__ __forceinline__ int f2i_clamp(float f, int hi) {
 // 1u << s, 0 for s >= 32 (gfx950 would wrap the shift count: mask explicitly).
 __device__ __forceinline__ uint32_t shl1(uint32_t s) { return s < 32u ? (1u << s) : 0u; }
 
-__device__ __forceinline__ float dot2(float ax, float ay, float bx, float by) { return ax * bx + ay * by; }
+// The one driver-defined point of the cull shaders that OrbitCaps.arith_profile selects: what becomes of
+// OpDot / OpMatrixTimesVector / OpMatrixTimesMatrix / Length / Distance.  madd(a, b, acc) is one term of such a sum:
+// canonical (ORBIT_CONTRACT 0, the product's default build) a rounded product added to the accumulator — the expression
+// trees below are then exactly the left-to-right sums of rounds 1-5 —, contracted (ORBIT_CONTRACT 1: the translation units
+// that evaluate geometry are compiled a second time, *_contracted.hip) one fma, which is how oracle/spirv_vm.py's
+// `fused_dot` runs the reference's binaries for tests/golden/spirv_cull_contracted.npz.  Everything the binaries spell out
+// themselves (FMul, FAdd, Fma, FDiv) is written out below and is the same in both builds.
+#ifndef ORBIT_CONTRACT
+#define ORBIT_CONTRACT 0
+#endif
+__device__ __forceinline__ float madd(float a, float b, float acc) {
+#if ORBIT_CONTRACT
+    return __builtin_fmaf(a, b, acc);
+#else
+    return acc + a * b;
+#endif
+}
+__device__ __forceinline__ float dot2(float ax, float ay, float bx, float by) { return madd(ay, by, ax * bx); }
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
-    return (ax * bx + ay * by) + az * bz;
+    return madd(az, bz, madd(ay, by, ax * bx));
 }
 
 // Canonical software log2: same specification as oracle/orbit_oracle.c
@@ -166,12 +183,13 @@ __device__ __forceinline__ void project_sphere(const Sphere &s, float p00, float
     const float r = s.r;
     const float cxx = -s.x, cxy = -s.z;
     const float vxx = sqrtf(__builtin_fmaf(-r, r, dot2(cxx, cxy, cxx, cxy))), vxy = r;
-    const float minx_x = vxx * cxx + (-vxy) * cxy, minx_y = vxy * cxx + vxx * cxy;
-    const float maxx_x = vxx * cxx + vxy * cxy, maxx_y = (-vxy) * cxx + vxx * cxy;
+    // (mat2(vx.x, vx.y, -vx.y, vx.x) * cx and its mirror: OpMatrixTimesVector in the binaries)
+    const float minx_x = madd(-vxy, cxy, vxx * cxx), minx_y = madd(vxx, cxy, vxy * cxx);
+    const float maxx_x = madd(vxy, cxy, vxx * cxx), maxx_y = madd(vxx, cxy, (-vxy) * cxx);
     const float cyx = -s.y, cyy = -s.z;
     const float vyx = sqrtf(__builtin_fmaf(-r, r, dot2(cyx, cyy, cyx, cyy))), vyy = r;
-    const float miny_x = vyx * cyx + (-vyy) * cyy, miny_y = vyy * cyx + vyx * cyy;
-    const float maxy_x = vyx * cyx + vyy * cyy, maxy_y = (-vyy) * cyx + vyx * cyy;
+    const float miny_x = madd(-vyy, cyy, vyx * cyx), miny_y = madd(vyx, cyy, vyy * cyx);
+    const float maxy_x = madd(vyy, cyy, vyx * cyx), maxy_y = madd(vyx, cyy, (-vyy) * cyx);
     const float a0 = minx_x / minx_y * p00, a1 = miny_x / miny_y * p11;
     const float a2 = maxx_x / maxx_y * p00, a3 = maxy_x / maxy_y * p11;
     aabb[0] = __builtin_fmaf(a0, 0.5f, 0.5f);
@@ -231,7 +249,7 @@ __device__ __forceinline__ bool plane_test(const OrbitGpuCullInfo &ci, const Sph
 // One column of (A * B): A column-major in registers/SGPRs, b = column of B.
 __device__ __forceinline__ void mat4_mul_col(const float *a, float b0, float b1, float b2, float b3, float out[4]) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) out[r] = ((a[0 + r] * b0 + a[4 + r] * b1) + a[8 + r] * b2) + a[12 + r] * b3;
+    for (int r = 0; r < 4; r++) out[r] = madd(a[12 + r], b3, madd(a[8 + r], b2, madd(a[4 + r], b1, a[0 + r] * b0)));
 }
 
 // Latched device status word (orbit_ctx_status): first error wins.

@@ -1,6 +1,7 @@
 """Generates tests/golden/spirv_cull.npz and spirv_cluster.npz (no argument), spirv_pyramid.npz (`pyramid`: depth_reduce.comp.spv
 level by level), spirv_compact.npz (`compact`: active_cluster_compaction.comp.spv) and spirv_cull_dispatch_sizes.npz
-(`dispatch`: the two cull shaders with MESHLET_DISPATCH_SIZE = 64 / 128, pass 0): inputs and OUTPUTS OF THE
+(`dispatch`: the two cull shaders with MESHLET_DISPATCH_SIZE = 64 / 128, pass 0) and spirv_cull_contracted.npz
+(`contracted`: the cull cases with Dot / matrix products / Length as fma chains): inputs and OUTPUTS OF THE
 REFERENCE'S OWN COMPILED SHADERS.
 
 Run in the build container only (it reads /root/reference/shaders/{entity_cull,meshlet_cull}.comp.spv,
@@ -137,7 +138,7 @@ def depth_knife_edge(scene, cam, ci, ortho, seed, rng):
     return np.full((H, W), np.frombuffer(np.array([lo + (seed & 1)], np.uint32).tobytes(), F)[0], F)
 
 
-def case(seed, occlusion_pass, ortho, knife, n=140, S=32):
+def case(seed, occlusion_pass, ortho, knife, n=140, S=32, fused_dot=False):
     rng = np.random.default_rng(seed)
     scene = sc.make_scene(seed, n, meshlets_per_mesh=(1, 70), lods=3,
                           meshlet_layout="scattered")  # the layout the committed vectors were made with
@@ -173,7 +174,7 @@ def case(seed, occlusion_pass, ortho, knife, n=140, S=32):
     buf(6, evis.copy()), buf(7, mvis.copy()), buf(8, scene.meshlets), buf(10, scene.materials)
     B[9] = np.zeros(L.DRAW_HEADER + 28 * cap_c, np.uint8)
     kwm = dict(images={11: {"size": lambda lod: (max(ps[0] >> lod, 1), max(ps[1] >> lod, 1))}},
-               samplers={k: {"id": k} for k in range(8)}, subgroup=32,
+               samplers={k: {"id": k} for k in range(8)}, subgroup=32, fused_dot=fused_dot,
                sample=lambda img, smp, u, v, lod: np.array(
                    [oracle.hiz_sample(pyr, ps[0], ps[1], float(u), float(v), float(lod)), 0, 0, 0], F))
     vm.Machine(module("entity_cull.comp.spv", S), B, np.array([1, 2, 3, 4, 5], np.uint32).tobytes(), log2, **kwm).run(
@@ -397,6 +398,37 @@ def compact_main():
     print(path, os.path.getsize(path), "bytes")
 
 
+def contracted_main():
+    """tests/golden/spirv_cull_contracted.npz: the twelve cull cases of spirv_cull.npz (same seeds, same inputs — asserted)
+    through the same binaries with the ONE driver-defined point a GPU compiler most likely decides the other way: every
+    OpDot / OpMatrixTimesVector / OpMatrixTimesMatrix / Length / Distance as an fma chain (acc = a0 b0; acc = fma(ak, bk,
+    acc) in component order) instead of rounded products and sums — OrbitCaps.arith_profile = ORBIT_ARITH_CONTRACTED.
+    Outputs only."""
+    out, summary = {}, []
+    committed = np.load(os.path.join(HERE, "spirv_cull.npz"))
+    for occlusion_pass in (0, 1, 2):
+        for ortho in (False, True):
+            for knife in (False, True):
+                seed = 3 + 7 * occlusion_pass + (2 if ortho else 0) + (1 if knife else 0)
+                name = f"p{occlusion_pass}_{'ortho' if ortho else 'persp'}_{'knife' if knife else 'plain'}"
+                c = case(seed, occlusion_pass, ortho, knife, fused_dot=True)
+                for k in ("cull_info", "entity_draws", "mesh_infos", "entities", "meshlets", "materials", "caps", "evis_in",
+                          "mvis_in", "pyramid"):
+                    assert np.array_equal(np.ascontiguousarray(c[k]).view(np.uint8).reshape(-1),
+                                          np.ascontiguousarray(committed[f"{name}/{k}"]).view(np.uint8).reshape(-1)), (name, k)
+                differ = 0
+                for k in ("spv_dispatch", "spv_draw", "spv_evis", "spv_mvis", "spv_task_records", "spv_task_mvis"):
+                    out[f"{name}/{k}"] = c[k]
+                    a, b = np.ascontiguousarray(c[k]).view(np.uint8).reshape(-1), np.ascontiguousarray(committed[f"{name}/{k}"]).view(np.uint8).reshape(-1)
+                    differ += int(len(a) != len(b) or not np.array_equal(a, b))
+                summary.append((name, int(c["spv_dispatch"][:4].view(np.uint32)[0]), int(c["spv_draw"][:4].view(np.uint32)[0]), differ))
+    path = os.path.join(HERE, "spirv_cull_contracted.npz")
+    np.savez_compressed(path, **out)
+    for sm in summary:
+        print("%-22s records %5d  draws %6d  outputs that differ from the canonical run: %d of 6" % sm)
+    print(path, os.path.getsize(path), "bytes")
+
+
 def dispatch_main():
     """tests/golden/spirv_cull_dispatch_sizes.npz: entity_cull.comp.spv + meshlet_cull.comp.spv with spec constant 0 = 64
     and 128, occlusion pass 0, perspective / orthographic x plain / knife-edge — and, per case, whether the binaries'
@@ -432,6 +464,8 @@ def dispatch_main():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "dispatch":
         return dispatch_main()
+    if len(sys.argv) > 1 and sys.argv[1] == "contracted":
+        return contracted_main()
     if len(sys.argv) > 1 and sys.argv[1] == "pyramid":
         return pyramid_main()
     if len(sys.argv) > 1 and sys.argv[1] == "compact":

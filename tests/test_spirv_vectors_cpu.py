@@ -209,3 +209,57 @@ def test_oracle_equals_the_reference_binaries_at_other_dispatch_sizes(oracle, ve
     # ... which are the S = 32 binaries' commands
     assert np.array_equal(c["spv_draw"], vectors[f"p0_{proj}_{kind}/spv_draw"])
     assert oracle.lib().oracle_get_dispatch_size() == 32
+
+
+# ----------------------------------------------------------------------------- the contracted arithmetic profile
+GOLD_C = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spirv_cull_contracted.npz")
+OUTPUTS = ("spv_dispatch", "spv_draw", "spv_evis", "spv_mvis", "spv_task_records", "spv_task_mvis")
+
+
+def load_contracted_case(vectors, name):
+    """Inputs of spirv_cull.npz's case + the binaries' outputs with Dot / matrix products / Length as fma chains."""
+    vc = np.load(GOLD_C)
+    c = load_case(vectors, name)
+    for k in OUTPUTS:
+        c[k] = vc[f"{name}/{k}"]
+    c["spv_task_records"] = c["spv_task_records"].view(L.MESH_TASK_RECORD)
+    return c
+
+
+def test_the_contracted_profile_decides_knife_edges_the_other_way(vectors):
+    """What the second profile is for: on the plain scenes both profiles give the same bytes, on the perspective
+    knife-edge scenes (a cone test within an ulp of equality, a depth bisected to a sphere's closest point) they do not."""
+    vc = np.load(GOLD_C)
+    differ = {n for n in CASES if any(not np.array_equal(vc[f"{n}/{k}"].view(np.uint8).reshape(-1),
+                                                         vectors[f"{n}/{k}"].view(np.uint8).reshape(-1)) for k in OUTPUTS)}
+    assert differ == {"p0_persp_knife", "p1_persp_knife", "p2_persp_knife"}, differ
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_contracted_profile_equals_the_binaries_run_contracted(oracle, vectors, name):
+    """OrbitCaps.arith_profile = ORBIT_ARITH_CONTRACTED as the oracle restates it (oracle_set_arith_profile) against the
+    reference's binaries executed with every OpDot / OpMatrixTimes* / Length / Distance as an fma chain
+    (tests/golden/spirv_cull_contracted.npz): records, commands, both bitsets, the task records."""
+    c = load_contracted_case(vectors, name)
+    p = int(c["ci"]["occlusion_pass"])
+    n_draws = int(np.frombuffer(c["draws"][:4].tobytes(), np.uint32)[0])
+    pk = (c["pyr"], c["ps"]) if p == 2 else ()
+    with oracle.arith_profile(1):
+        od, oev, dropped = oracle.entity_cull(c["ci"], c["draws"], n_draws, c["mesh_infos"], c["entities"], c["caps"][0],
+                                              c["evis"] if p else None, *pk)
+        nrec = int(c["spv_dispatch"][:4].view(np.uint32)[0])
+        assert dropped == 0 and int(od[:4].view(np.uint32)[0]) == nrec
+        assert np.array_equal(od[:L.DISPATCH_HEADER + 16 * nrec], c["spv_dispatch"]), "dispatch records differ from the binary's"
+        oc, omv, dropped = oracle.meshlet_cull(c["ci"], od, c["meshlets"], c["caps"][1], c["entities"], c["materials"],
+                                               c["mvis"] if p else None, *pk)
+        ndraw = int(c["spv_draw"][:4].view(np.uint32)[0])
+        assert dropped == 0 and int(oc[:4].view(np.uint32)[0]) == ndraw
+        assert np.array_equal(oc[:L.DRAW_HEADER + 28 * ndraw], c["spv_draw"]), "draw commands differ from the binary's"
+        if p:
+            assert np.array_equal(oev, c["spv_evis"]) and np.array_equal(omv, c["spv_mvis"]), "visibility words differ"
+        recs, tmv = oracle.meshlet_task_cull(c["ci"], c["spv_dispatch"], c["meshlets"], c["entities"], c["materials"],
+                                             c["mvis"] if p else None, *pk)
+        assert np.array_equal(recs.view(np.uint8), c["spv_task_records"].view(np.uint8)), "task records differ from the binary's"
+        if p == 2:
+            assert np.array_equal(tmv, c["spv_task_mvis"])
+    assert oracle.lib().oracle_get_arith_profile() == 0
