@@ -168,12 +168,19 @@ __device__ __forceinline__ void cull_fused_body(const FusedCullParams &p, FusedL
         // ------------------------------------------------------------ every entity-draw, in every workgroup (:104-223)
         const uint32_t draw_count = *reinterpret_cast<const uint32_t *>(E.entity_draw_buffer);
         const uint32_t draw_end = min(draw_count, p.draw_limit);
-#pragma unroll 1
-        for (uint32_t c = 0; c < kFusedLocalChunks; c++) { // (fixed trip count: barriers inside)
+        // (evaluated first, all chunks: the chunks' chains of dependent gathers — draw -> mesh entry + matrix — are
+        // independent of each other and unrolled side by side; the scans with their barriers follow)
+        OrbitMeshletDispatch prs[kFusedLocalChunks];
+#pragma unroll
+        for (uint32_t c = 0; c < kFusedLocalChunks; c++) {
             const uint32_t g = p.draw_first + c * kEntityBlock + threadIdx.x;
             const bool active = c < p.ne_chunks && g < draw_end; // :106
             bool visible;
-            const OrbitMeshletDispatch pr = entity_eval_one(E, g, active, visible);
+            prs[c] = entity_eval_one(E, g, active, visible);
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < kFusedLocalChunks; c++) { // (fixed trip count: barriers inside)
+            const OrbitMeshletDispatch pr = prs[c];
             const uint32_t n = (pr.meshlet_count + 31u) >> 5; // :210
             uint32_t chunk_total;
             const uint32_t ex = block_exclusive_scan<kEntityBlock / 64>(n, loc.smem, &chunk_total);
@@ -423,7 +430,12 @@ hipError_t launch_cull_fused_views(const FusedCullViews &all, const uint32_t *en
             const uint32_t want = ORBIT_FUSED_FORCE_ROWS == 2 ? 1u : 2u;
 #else
             const uint32_t chunks = (entity_draw_counts[j] + kEntityBlock - 1u) / kEntityBlock;
-            const uint32_t want = (chunks <= kFusedLocalChunks && all.v[j].m.ci.occlusion_pass != 2u) ? 0u
+#ifdef ORBIT_FUSED_NO_LOCAL // (A/B builds: the chunked entity stage for every view)
+            const uint32_t local_max = 0u;
+#else
+            const uint32_t local_max = kFusedLocalChunks;
+#endif
+            const uint32_t want = (chunks <= local_max && all.v[j].m.ci.occlusion_pass != 2u) ? 0u
                                   : entity_draw_counts[j] <= kFusedSmallEntityDraws                    ? 1u
                                                                                                        : 2u;
 #endif

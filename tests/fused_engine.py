@@ -39,9 +39,9 @@ class FusedEngine(Engine):
     def meshlet_cull(self, cull_info, meshlet_dispatch_buffer, meshlet_buffer, draw_commands_buffer, entity_buffer,
                      material_buffer, dispatch_capacity, draw_capacity, meshlet_visibility_buffer=None,
                      depth_pyramid=None, depth_pyramid_size=(0, 0), material_count=0, stream=None, task_records=None,
-                     visible_buffer=None, depth_pyramid_levels=None, record_buffer=None, record_capacity=None):
+                     depth_pyramid_levels=None, record_buffer=None, record_capacity=None):
         p, self._pending = self._pending, None
-        plain = task_records is None and visible_buffer is None and record_buffer is None and depth_pyramid_levels is None
+        plain = task_records is None and record_buffer is None and depth_pyramid_levels is None
         if p is None or not plain or p["meshlet_dispatch_buffer"] is not meshlet_dispatch_buffer \
                 or p["dispatch_capacity"] != dispatch_capacity or isinstance(meshlet_buffer, int):
             return super().meshlet_cull(cull_info, meshlet_dispatch_buffer, meshlet_buffer, draw_commands_buffer,

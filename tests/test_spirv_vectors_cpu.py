@@ -263,3 +263,25 @@ def test_oracle_contracted_profile_equals_the_binaries_run_contracted(oracle, ve
         if p == 2:
             assert np.array_equal(tmv, c["spv_task_mvis"])
     assert oracle.lib().oracle_get_arith_profile() == 0
+
+
+def test_knife_edge_scene_export_for_a_vulkan_box(tmp_path, vectors):
+    """tools/export_knife_edge_scenes.py (docs/vulkan_pin.md): the six knife-edge cases as `.orbitscene` dumps whose
+    sections are the vectors' inputs verbatim, with both profiles' expectations beside them."""
+    import subprocess
+    import sys
+
+    from orbit_amd import orbitscene
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "export_knife_edge_scenes.py"), str(tmp_path)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    vc = np.load(GOLD_C)
+    for name in ("p0_persp_knife", "p2_ortho_knife"):
+        d = orbitscene.read(str(tmp_path / f"{name}.orbitscene"))
+        assert d["meshlets"].tobytes() == vectors[f"{name}/meshlets"].tobytes()
+        assert d["cull_info"].tobytes() == vectors[f"{name}/cull_info"].tobytes()
+        e = np.load(tmp_path / f"{name}.expected.npz")
+        assert np.array_equal(e["canonical_draw"], vectors[f"{name}/spv_draw"]) and np.array_equal(e["contracted_draw"], vc[f"{name}/spv_draw"])
+    assert (tmp_path / "p2_persp_knife.orbitscene").exists() and "2 of 4 outputs differ" in r.stdout

@@ -63,6 +63,21 @@ def test_rerunning_the_binaries_at_another_dispatch_size_reproduces_the_committe
 
 
 @pytest.mark.skipif(not os.path.exists(REF), reason="the reference's shader binaries are not on this machine")
+@pytest.mark.parametrize("occlusion_pass,ortho,knife", [(0, False, True), (2, False, True), (1, True, False)])
+def test_rerunning_the_binaries_contracted_reproduces_the_committed_vectors(occlusion_pass, ortho, knife):
+    """tests/golden/spirv_cull_contracted.npz: the same binaries with Dot / matrix products / Length as fma chains."""
+    import make_spirv_vectors as gen
+
+    seed = 3 + 7 * occlusion_pass + (2 if ortho else 0) + (1 if knife else 0)
+    name = f"p{occlusion_pass}_{'ortho' if ortho else 'persp'}_{'knife' if knife else 'plain'}"
+    stored = np.load(os.path.join(HERE, "golden", "spirv_cull_contracted.npz"))
+    fresh = gen.case(seed, occlusion_pass, ortho, knife, fused_dot=True)
+    for k in ("spv_dispatch", "spv_draw", "spv_evis", "spv_mvis", "spv_task_records", "spv_task_mvis"):
+        assert np.array_equal(np.ascontiguousarray(fresh[k]).view(np.uint8).reshape(-1),
+                              np.ascontiguousarray(stored[f"{name}/{k}"]).view(np.uint8).reshape(-1)), (name, k)
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference's shader binaries are not on this machine")
 def test_rerunning_the_binaries_reproduces_a_committed_cluster_vector():
     import make_spirv_vectors as gen
 
