@@ -48,7 +48,7 @@ class FusedEngine(Engine):
                                         entity_buffer, material_buffer, dispatch_capacity, draw_capacity,
                                         meshlet_visibility_buffer=meshlet_visibility_buffer, depth_pyramid=depth_pyramid,
                                         depth_pyramid_size=depth_pyramid_size, material_count=material_count,
-                                        stream=stream, task_records=task_records, visible_buffer=visible_buffer,
+                                        stream=stream, task_records=task_records,
                                         depth_pyramid_levels=depth_pyramid_levels, record_buffer=record_buffer,
                                         record_capacity=record_capacity)
         import torch
