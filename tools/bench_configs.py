@@ -28,12 +28,16 @@ def host(t, dtype=np.uint8):
     return t.cpu().numpy().view(dtype)
 
 
-def timeit(fn, n=20, warm=5):
+def timeit(fn, n=20, warm=5, lead=0):
+    """lead = calls enqueued right in front of the timed one (0: the timed call starts on an idle queue and its launch
+    latency is inside the event pair — the floor model's launch_us; 2: the call as one of a flow of frames)"""
     for _ in range(warm):
         fn()
     ts = []
     for _ in range(n):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(lead):
+            fn()
         a.record()
         fn()
         b.record()
@@ -160,7 +164,7 @@ def main():
     threads = oracle.max_threads()
     cam = cs.camera()
     hops = measure_hops()
-    out = {"protocol": "HIP-event median of 20 after 5 warm-ups (SURVEY.md §8d); CPU: oracle/orbit_oracle.c through "
+    out = {"protocol": "HIP-event median of 20 after 5 warm-ups (SURVEY.md §8d), each timed call on an idle queue (*_behind_two_others_ms: two further calls enqueued in front of it — a call in a flow of frames, its launch latency hidden); CPU: oracle/orbit_oracle.c through "
                        "oracle/orbit_oracle_mt.c (native build) on all host threads, mean of >= 3 runs over >= 1 s",
            "cpu_threads": threads, "host_cores": os.cpu_count(), "cpu_flags": oracle.NATIVE_CFLAGS,
            "links": hops,
@@ -193,7 +197,8 @@ def main():
         gr = graph_of(lambda: eng.cull_views_prepared(arr))
         fl = floor_us(hops, path)
         c2["gpu"][path] = {"cull_ms": ms, "cull_graph_replay_ms": timeit(gr.replay), "floor_us": fl,
-                           "frac_of_floor": (fl / (ms * 1e3)) if fl else None}
+                           "frac_of_floor": (fl / (ms * 1e3)) if fl else None,
+                           "cull_behind_two_others_ms": timeit(lambda: eng.cull_views_prepared(arr), lead=2)}
         torch.cuda.synchronize()
         eng.status()
         ok = ok and same(host(disp), host(draw), odisp, odraw)
@@ -327,6 +332,7 @@ def main():
     c4["gpu"]["assign_ms"] = timeit(lambda: eng.cluster_assign(info, gu, gb, glights, gl, lcap, gimg), n=20, warm=3)
     whole = lambda: eng.compute_clusters(push, info, gdepth, glights, gm, gb, gu, cap, gl, lcap, gimg)  # noqa: E731
     c4["gpu"]["compute_clusters_ms"] = timeit(whole)
+    c4["gpu"]["compute_clusters_behind_two_others_ms"] = timeit(whole, lead=2)
     gr = graph_of(whole)
     c4["gpu"]["compute_clusters_graph_replay_ms"] = timeit(gr.replay)
     fl = floor_us(hops, "compute_clusters")
