@@ -42,7 +42,8 @@ __global__ __launch_bounds__(kMarkWaves * 64) void cluster_mark_kernel(const Clu
     const OrbitMarkActivePush &pc = p.pc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t cx = pc.cluster_count[0], cy = pc.cluster_count[1], cz = pc.cluster_count[2];
-    const uint32_t tile0 = (blockIdx.x * kMarkWaves + wave) * kMarkTiles;
+    // (wave-uniform: the tile walk below stays in scalar registers)
+    const uint32_t tile0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * kMarkWaves + wave) * kMarkTiles));
     uint32_t zc = 0; // lane = z slice
     if (tile0 < cx * cy) { // wave-uniform
     const uint32_t ts = pc.tile_size_px, sc = pc.depth_buffer_sample_count;
@@ -50,19 +51,37 @@ __global__ __launch_bounds__(kMarkWaves * 64) void cluster_mark_kernel(const Clu
     const uint32_t items = ts * ts * sc;
     // sample `it` of tile `tile`: its address, or none (mark_active.comp:40)
     auto sample = [&](uint32_t tile, uint32_t it, size_t &index) -> bool {
-        const uint32_t tx = tile % cx, ty = tile / cx;
-        const uint32_t pix = it / sc, smp = it % sc;
-        const uint32_t px = tx * ts + pix % ts, py = ty * ts + pix / ts;
+        // (divisors the compiler cannot see through: their reciprocals are not hoisted into every wave's prologue)
+        uint32_t dcx = cx, dsc = sc, dts = ts;
+        asm volatile("" : "+s"(dcx), "+s"(dsc), "+s"(dts));
+        const uint32_t tx = tile % dcx, ty = tile / dcx;
+        const uint32_t pix = it / dsc, smp = it % dsc;
+        const uint32_t px = tx * ts + pix % dts, py = ty * ts + pix / dts;
         index = ((size_t)py * W + px) * sc + smp;
         return tile < cx * cy && it < items && px < W && py < H;
     };
+    // The first 64 samples of every tile — all of them at the reference's 8-px tiles and one sample — by the same
+    // arithmetic with the divisions taken out: a lane's place inside a tile is the same in every tile (once per wave,
+    // shifts where tile size and sample count allow), a tile's corner is wave-uniform and walks along the row.
+    // (A u32 division is ~25 vector instructions, a third of them quarter-rate multiplies; `sample` above cost this
+    // launch, which is bound by its vector instructions, three of them per tile and lane.)
+    uint32_t lpix = (uint32_t)lane, lsmp = 0u;
+    if (sc != 1u) lpix = (uint32_t)lane / sc, lsmp = (uint32_t)lane % sc;
+    uint32_t lpx, lpy;
+    if ((ts & (ts - 1u)) == 0u && ts != 0u) lpx = lpix & (ts - 1u), lpy = lpix >> __builtin_ctz(ts);
+    else lpx = lpix % ts, lpy = lpix / ts;
+    const size_t lane_index = ((size_t)lpy * W + lpx) * sc + lsmp;
+    const bool lane_in = (uint32_t)lane < items;
+    uint32_t tx = tile0 % cx, ty = tile0 / cx; // (scalar)
     float first[kMarkTiles];
     bool first_valid[kMarkTiles];
 #pragma unroll
     for (uint32_t t = 0; t < kMarkTiles; t++) {
-        size_t index;
-        first_valid[t] = sample(tile0 + t, (uint32_t)lane, index);
+        // ((py W + px) sc + smp with py = ty ts + lpy, px = tx ts + lpx: the tile's corner + the lane's place)
+        const size_t index = ((size_t)(ty * ts) * W + tx * ts) * sc + lane_index;
+        first_valid[t] = tile0 + t < cx * cy && lane_in && tx * ts + lpx < W && ty * ts + lpy < H;
         first[t] = first_valid[t] ? p.depth[index] : 0.0f;
+        if (++tx == cx) tx = 0u, ty++;
     }
 #pragma unroll
     for (uint32_t t = 0; t < kMarkTiles; t++) {
@@ -72,7 +91,7 @@ __global__ __launch_bounds__(kMarkWaves * 64) void cluster_mark_kernel(const Clu
         for (uint32_t base = 0; base < items; base += 64) {
             bool valid = first_valid[t];
             float d = first[t];
-            if (base != 0) {
+            if (base != 0) { // (larger tiles or several samples: the general form, its divisions set up in here only)
                 size_t index;
                 valid = sample(tile, base + (uint32_t)lane, index);
                 d = valid ? p.depth[index] : 0.0f;

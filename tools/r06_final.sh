@@ -22,7 +22,8 @@ cd $R
 python3 tools/bench_c5_two_pass.py --check > $O/c5_two_pass.json 2>> $O/bench.err
 python3 tools/bench_configs.py > $O/configs.json 2>> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_configs -- python3 tools/bench_configs.py > /dev/null 2>> $O/bench.err
-f=$(find $O/prof_configs -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats_configs.csv; rm -rf $O/prof_configs
+# (the largest stats file: the tool itself, not its hop micro-benchmark child process)
+f=$(ls -S $(find $O/prof_configs -name "*kernel_stats.csv") | head -1); cp $f $O/kernel_stats_configs.csv; rm -rf $O/prof_configs
 python3 tools/bench_views.py > $O/views.json 2>> $O/bench.err
 python3 tools/cluster_time.py > $O/cluster_time.json 2>> $O/bench.err
 tools/ubench/hop.bin > $O/hops.json 2>> $O/bench.err
