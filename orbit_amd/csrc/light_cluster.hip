@@ -39,6 +39,13 @@ constexpr uint32_t kMarkWaves = 16; // 64 tiles per block: a quarter of the coun
 
 __global__ __launch_bounds__(kMarkWaves * 64) void cluster_mark_kernel(const ClusterMarkParams p) {
     __shared__ uint32_t s_zc[kMarkWaves][32]; // counting: per wave and z slice, how many of the wave's tiles are active in it
+    // A tile's 32 depth bounds belong to 32 planes of the bounds array (slice-major): stored by the tile's wave they are
+    // 32 eight-byte requests to 32 lines per tile, and the CU's one write port made 1.6 us of the launch out of them
+    // (profiles/r06_notes.md).  They go through LDS instead: a plane's 64 entries of the block's 64 consecutive tiles are
+    // 512 contiguous bytes, one wave's store.  (Row stride 65 entries: the waves' column writes touch every bank once.)
+    constexpr uint32_t kBlockTiles = kMarkWaves * kMarkTiles;
+    __shared__ uint2 s_bounds[32][kBlockTiles + 1];
+    __shared__ uint32_t s_masks[kBlockTiles];
     const OrbitMarkActivePush &pc = p.pc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t cx = pc.cluster_count[0], cy = pc.cluster_count[1], cz = pc.cluster_count[2];
@@ -124,23 +131,36 @@ __global__ __launch_bounds__(kMarkWaves * 64) void cluster_mark_kernel(const Clu
                 }
             }
         }
-        if ((uint32_t)lane < cz) {
-            OrbitClusterDepthBounds b;
-            b.min_depth = acc_min;
-            b.max_depth = acc_max;
-            p.bounds[tile + (size_t)lane * cx * cy] = b;
-        }
-        if (lane == 0) p.masks[tile] = tile_mask;
+        if ((uint32_t)lane < cz) s_bounds[lane][wave * kMarkTiles + t] = make_uint2(acc_min, acc_max);
+        if (lane == 0) s_masks[wave * kMarkTiles + t] = tile_mask;
         zc += (uint32_t)lane < cz ? (tile_mask >> (lane & 31)) & 1u : 0u; // cluster_common.glsl:31-34
     }
+    }
+    if (p.chunk_counts != nullptr && lane < 32) s_zc[wave][lane] = zc;
+    __syncthreads();
+    {   // the block's outputs, every word of them once (tiles past the end were never filled in and are not stored)
+        static_assert(sizeof(OrbitClusterDepthBounds) == sizeof(uint2), "bounds entry");
+        const uint32_t tiles = cx * cy, block_tile0 = blockIdx.x * kBlockTiles;
+        const uint32_t tb = (uint32_t)lane, tile = block_tile0 + tb; // kBlockTiles == 64: a wave per plane and round
+        static_assert(kBlockTiles == 64, "one wave stores one plane's entries of the block");
+        if (tile < tiles) {
+#pragma unroll
+            for (uint32_t slice = (uint32_t)wave; slice < 32u; slice += kMarkWaves) {
+                if (slice >= cz) break; // wave-uniform
+                const uint2 b = s_bounds[slice][tb];
+                OrbitClusterDepthBounds o;
+                o.min_depth = b.x;
+                o.max_depth = b.y;
+                p.bounds[tile + (size_t)slice * tiles] = o;
+            }
+            if (wave == 0) p.masks[tile] = s_masks[tb];
+        }
     }
     if (p.chunk_counts == nullptr) return; // (uniform)
     // the block's 64 consecutive tiles lie in one chunk of 1024: one atomic per z slice the block is active in — a
     // handful, the tiles of a block see neighbouring depths — on the word of (slice, chunk).  (Atomics on one 128-B line
     // queue in its L2 channel at ~4 ns each: four-wave blocks, 16 tiles, cost the launch 2 us at config 4.)
     static_assert(1024 % (kMarkWaves * kMarkTiles) == 0, "a block's tiles share a compaction chunk");
-    if (lane < 32) s_zc[wave][lane] = zc;
-    __syncthreads();
     if (threadIdx.x < 32) {
         uint32_t sum = 0;
 #pragma unroll
