@@ -13,3 +13,4 @@ cp $O/kernel_stats_default_command.csv $P/r06_kernel_stats_default_command.csv; 
 cp $O/kernel_stats_shard_e8.csv $P/r06_kernel_stats_shard_e8.csv
 cp $O/views.json $P/r06_views.json; cp $O/cluster_time.json $P/r06_cluster_time.json
 cp $O/traffic_stream.json $P/traffic_stream.json; cp $O/traffic.json $P/traffic.json
+cp $O/bench_line_two_frames_in_flight.json $P/r06_bench_line_two_frames_in_flight.json

@@ -3,6 +3,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06_final; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_line.json 2> $O/bench.err
 python3 $R/bench.py --meshlet-source buffer > $O/bench_line_meshlet_buffer.json 2>> $O/bench.err
+python3 $R/bench.py --frames-in-flight 2 --cpu-sample-entities 0 > $O/bench_line_two_frames_in_flight.json 2>> $O/bench.err
 for src in stream buffer; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$src -- python3 $R/bench.py --steps 20 --warmup 3 --cpu-sample-entities 0 --meshlet-source $src > $O/prof_$src.log 2>&1
   grep '^{' $O/prof_$src.log | tail -1 > $O/bench_line_under_rocprof_$src.json
