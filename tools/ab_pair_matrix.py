@@ -17,7 +17,7 @@ from orbit_amd.engine import Engine
 os.environ["ORBIT_DEBUG_ARENA"] = "1"
 lib = _lib.load_variant(os.path.join(ROOT, "tools/variants/abi_dbg.so"))
 dev = torch.device("cuda", 0)
-spec = synth.C5Spec()
+spec = synth.C5Spec(meshlets_per_entity=int(os.environ.get("M", 256)))
 E, M = spec.entities, spec.meshlets_per_entity
 draws, mesh, ent, half = synth.gen_entity_tables(spec, dev)
 meshlets = synth.gen_meshlets(spec, 0, E, dev, half)
@@ -44,18 +44,21 @@ def timed(eng, buf, reps=7):
     return round(float(np.median(out[2:]) * 1e3), 1)
 
 
+NE = int(os.environ.get("ENGINES", 5))
 engs, bufs, pads = [engine()], [meshlets], []
 engs[0].entity_cull(ci, draws, mesh, disp, ent, E, disp_cap)
 torch.cuda.synchronize()
 for k in range(3):
     pads.append(torch.empty((7 + 13 * k) << 20, dtype=torch.uint8, device=dev))
     bufs.append(meshlets.clone())
+    if len(engs) < NE:
+        engs.append(engine())
+if len(engs) < NE:
     engs.append(engine())
-engs.append(engine())
 for _ in range(300):
     engs[0].meshlet_cull(ci, disp, meshlets, draw, ent, materials, disp_cap, draw_cap, material_count=spec.materials)
 torch.cuda.synchronize()
-rows = {"buffers": [hex(b.data_ptr()) for b in bufs], "disp": hex(disp.data_ptr()),
+rows = {"meshlets_per_entity": M, "buffers": [hex(b.data_ptr()) for b in bufs], "disp": hex(disp.data_ptr()),
         "us[engine][buffer]": [[timed(e, b) for b in bufs] for e in engs]}
 rows["again"] = [[timed(e, b) for b in bufs] for e in engs]
 print(json.dumps(rows))
