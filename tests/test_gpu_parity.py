@@ -488,7 +488,10 @@ def cluster_inputs(oracle, seed, W, H, n_lights, tile_px=8, z_slices=32, far=200
 
 @pytest.mark.parametrize("W,H,n_lights,tile,zs,samples,pf", [
     (320, 180, 200, 8, 32, 1, 1.0), (333, 187, 64, 16, 24, 1, 0.9), (256, 128, 300, 8, 32, 4, 1.0),
-    (1920, 1080, 1000, 8, 32, 1, 1.0), (64, 64, 0, 8, 8, 1, 1.0), (200, 120, 40, 64, 32, 1, 1.0)])
+    (1920, 1080, 1000, 8, 32, 1, 1.0), (64, 64, 0, 8, 8, 1, 1.0), (200, 120, 40, 64, 32, 1, 1.0),
+    # tile sizes that are not powers of two (the mark launch's lane geometry has a shift form and a division form), with
+    # and without several samples; a tile of fewer than 64 samples and one of more than 64
+    (330, 190, 100, 12, 32, 1, 1.0), (200, 100, 50, 6, 16, 2, 1.0), (150, 90, 30, 5, 32, 1, 0.9), (97, 61, 20, 3, 7, 4, 1.0)])
 def test_light_clusters(torch_mod, engine, oracle, W, H, n_lights, tile, zs, samples, pf):
     _light_clusters(torch_mod, engine, oracle, W, H, n_lights, tile, zs, samples, pf, poison=False)
 
