@@ -420,6 +420,16 @@ def main():
         "frame_with_cascades_serial": lambda: (reset(), engf.cull_views_prepared(a1), late_serial(True)),
         "frame_with_cascades_overlapped": lambda: (reset(), engf.cull_views_prepared(a1), engf.frame_late(f_all)),
     }
+    if os.environ.get("ORBIT_FRAME_ANATOMY"):  # what the overlapped late half is made of: its chains alone and in pairs
+        f_c, kf1 = engf.prepare_frame_late(clusters=clusters)
+        f_cp, kf2 = engf.prepare_frame_late(pyramids=pyramids, clusters=clusters)
+        f_cv, kf3 = engf.prepare_frame_late(late_views=[v2], clusters=clusters)
+        f_pv, kf4 = engf.prepare_frame_late(pyramids=pyramids, late_views=[v2])
+        variants = {"clusters": lambda: (reset(), engf.frame_late(f_c)),
+                    "clusters+pyramid": lambda: (reset(), engf.frame_late(f_cp)),
+                    "clusters+late_cull": lambda: (reset(), engf.frame_late(f_cv)),
+                    "pyramid+late_cull": lambda: (reset(), engf.frame_late(f_pv)),
+                    "all three": lambda: (reset(), engf.frame_late(f_late))}
     reset_ms = timeit(reset)
     fr = {"what": "configs 3 + 4 as one frame (src/app.rs:1151-1212): early cull, then the late half — pyramid + late cull, "
                   "[the four cascade culls,] compute_clusters — serially on one stream and through orbit_frame_late (the "
@@ -430,6 +440,9 @@ def main():
         gr = graph_of(fn)
         fr["graph_replay_ms"][name] = timeit(gr.replay) - reset_ms
         del gr
+    if os.environ.get("ORBIT_FRAME_ANATOMY"):
+        print(json.dumps(fr, indent=1))
+        return
     # the overlapped frame's outputs against the oracle (the serial ones were checked above, config by config)
     variants["frame_with_cascades_overlapped"]()
     torch.cuda.synchronize()
